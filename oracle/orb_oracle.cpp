@@ -1,0 +1,732 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.
+//
+// CPU restatement of the reference ORB front-end (lturing/ORB_SLAM3_modified,
+// src/ORBextractor.cc) together with the OpenCV 4.x primitives that file calls
+// (cv::resize INTER_LINEAR 8u, copyMakeBorder, cv::FAST 9/16 + score + NMS,
+// cv::GaussianBlur 7x7 sigma 2 fixed point, cv::fastAtan2, cvRound).
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+// this library, and only as the checker.  The shipped product (liborbx.so) never
+// links, imports or calls it.
+//
+// PARITY STATUS: **parity unpinned**.  The reference holds no test, golden
+// vector or fixture for this path and cannot be compiled here
+// (OpenCV / Eigen absent).  The OpenCV semantics below are the
+// repo's normative definition of "reference CPU path"; every primitive is
+// isolated (orbo_resize_linear, orbo_fast, orbo_gaussian_blur7, orbo_fast_atan2)
+// so it can be re-validated against a real OpenCV build later.
+//
+// Float rules: compile with -ffp-contract=off (no FMA fusion),
+// cosf/sinf are the host glibc's, division is IEEE.
+//
+// Each function cites the reference file:line it follows.
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <list>
+#include <utility>
+#include <vector>
+
+namespace {
+
+constexpr int kPatchSize = 31;       // src/ORBextractor.cc:71
+constexpr int kHalfPatch = 15;       // :72
+constexpr int kEdgeThreshold = 19;   // :73
+
+struct KeyPt {            // layout-identical to cv::KeyPoint (7 x 4 B)
+  float x, y, size, angle, response;
+  int32_t octave, class_id;
+};
+
+// rBRIEF pattern, src/ORBextractor.cc:149-407 (data table).
+const int8_t kPattern[1024] = {
+#include "orb_pattern.inc"
+};
+
+// cvRound(float/double): round half to even (lrint / cvtss2si semantics).
+inline int cv_round(float v) { return (int)lrintf(v); }
+inline int cv_round(double v) { return (int)lrint(v); }
+
+// ---------------------------------------------------------------------------
+// cv::resize(src, dst, dsize, 0, 0, INTER_LINEAR), CV_8UC1 — SURVEY §8(c)-R.
+// Called by the reference at src/ORBextractor.cc:1183.
+// ---------------------------------------------------------------------------
+void resize_linear_u8(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh,
+                      int dstride) {
+  const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+  const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+  std::vector<int> xofs(dw), yofs(dh);
+  std::vector<short> ialpha(dw * 2), ibeta(dh * 2);
+  int xmax = dw;
+  for (int dx = 0; dx < dw; dx++) {
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = (int)std::floor(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx + 1 >= sw) {
+      xmax = std::min(xmax, dx);
+      if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+    }
+    xofs[dx] = sx;
+    float c0 = 1.f - fx, c1 = fx;
+    int a0 = cv_round(c0 * 2048.f), a1 = cv_round(c1 * 2048.f);
+    ialpha[dx * 2] = (short)std::min(std::max(a0, -32768), 32767);
+    ialpha[dx * 2 + 1] = (short)std::min(std::max(a1, -32768), 32767);
+  }
+  for (int dy = 0; dy < dh; dy++) {
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    int sy = (int)std::floor(fy);
+    fy -= sy;
+    yofs[dy] = sy;
+    float c0 = 1.f - fy, c1 = fy;
+    int b0 = cv_round(c0 * 2048.f), b1 = cv_round(c1 * 2048.f);
+    ibeta[dy * 2] = (short)std::min(std::max(b0, -32768), 32767);
+    ibeta[dy * 2 + 1] = (short)std::min(std::max(b1, -32768), 32767);
+  }
+  std::vector<int> row0(dw), row1(dw);
+  auto hresize = [&](const uint8_t* S, int* D) {
+    int dx = 0;
+    for (; dx < xmax; dx++) {
+      int sx = xofs[dx];
+      D[dx] = S[sx] * ialpha[dx * 2] + S[sx + 1] * ialpha[dx * 2 + 1];
+    }
+    for (; dx < dw; dx++) D[dx] = S[xofs[dx]] * 2048;
+  };
+  auto clip = [](int x, int a, int b) { return x >= a ? (x < b ? x : b - 1) : a; };
+  for (int dy = 0; dy < dh; dy++) {
+    int sy0 = clip(yofs[dy], 0, sh), sy1 = clip(yofs[dy] + 1, 0, sh);
+    hresize(src + (size_t)sy0 * sstride, row0.data());
+    hresize(src + (size_t)sy1 * sstride, row1.data());
+    int b0 = ibeta[dy * 2], b1 = ibeta[dy * 2 + 1];
+    uint8_t* D = dst + (size_t)dy * dstride;
+    for (int x = 0; x < dw; x++)
+      D[x] = (uint8_t)((((b0 * (row0[x] >> 4)) >> 16) + ((b1 * (row1[x] >> 4)) >> 16) + 2) >> 2);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// cv::FAST(img, kps, threshold, true) default TYPE_9_16 — SURVEY §8(c)-F.
+// Literal row-buffer formulation of OpenCV's FAST_t<16> + cornerScore<16>
+// (the HIP path uses the closed single-pass form; this one is the checker).
+// Called by the reference at src/ORBextractor.cc:826,845.
+// ---------------------------------------------------------------------------
+const int kCircle[16][2] = {{0, 3},  {1, 3},   {2, 2},   {3, 1},   {3, 0},  {3, -1}, {2, -2}, {1, -3},
+                            {0, -3}, {-1, -3}, {-2, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-2, 2}, {-1, 3}};
+
+int corner_score16(const uint8_t* ptr, const int pixel[25], int threshold) {
+  const int K = 8, N = K * 3 + 1;
+  int v = ptr[0];
+  short d[N];
+  for (int k = 0; k < N; k++) d[k] = (short)(v - ptr[pixel[k]]);
+  int a0 = threshold;
+  for (int k = 0; k < 16; k += 2) {
+    int a = std::min((int)d[k + 1], (int)d[k + 2]);
+    a = std::min(a, (int)d[k + 3]);
+    if (a <= a0) continue;
+    a = std::min(a, (int)d[k + 4]);
+    a = std::min(a, (int)d[k + 5]);
+    a = std::min(a, (int)d[k + 6]);
+    a = std::min(a, (int)d[k + 7]);
+    a = std::min(a, (int)d[k + 8]);
+    a0 = std::max(a0, std::min(a, (int)d[k]));
+    a0 = std::max(a0, std::min(a, (int)d[k + 9]));
+  }
+  int b0 = -a0;
+  for (int k = 0; k < 16; k += 2) {
+    int b = std::max((int)d[k + 1], (int)d[k + 2]);
+    b = std::max(b, (int)d[k + 3]);
+    b = std::max(b, (int)d[k + 4]);
+    b = std::max(b, (int)d[k + 5]);
+    if (b >= b0) continue;
+    b = std::max(b, (int)d[k + 6]);
+    b = std::max(b, (int)d[k + 7]);
+    b = std::max(b, (int)d[k + 8]);
+    b0 = std::min(b0, std::max(b, (int)d[k]));
+    b0 = std::min(b0, std::max(b, (int)d[k + 9]));
+  }
+  return -b0 - 1;
+}
+
+void fast9_16(const uint8_t* img, int cols, int rows, int stride, int threshold, bool nms,
+              std::vector<KeyPt>& out) {
+  out.clear();
+  const int K = 8, N = 25;
+  int pixel[25];
+  for (int k = 0; k < 16; k++) pixel[k] = kCircle[k][0] + kCircle[k][1] * stride;
+  for (int k = 16; k < 25; k++) pixel[k] = pixel[k - 16];
+  threshold = std::min(std::max(threshold, 0), 255);
+  uint8_t tab[512];
+  for (int i = -255; i <= 255; i++) tab[i + 255] = (uint8_t)(i < -threshold ? 1 : i > threshold ? 2 : 0);
+  if (cols <= 0 || rows <= 0) return;
+  std::vector<uint8_t> bufmem((size_t)cols * 3, 0);
+  std::vector<int> cpmem((size_t)(cols + 1) * 3, 0);
+  uint8_t* buf[3] = {bufmem.data(), bufmem.data() + cols, bufmem.data() + 2 * cols};
+  int* cpbuf[3] = {cpmem.data(), cpmem.data() + (cols + 1), cpmem.data() + 2 * (cols + 1)};
+  for (int i = 3; i < rows - 2; i++) {
+    const uint8_t* ptr = img + (size_t)i * stride + 3;
+    uint8_t* curr = buf[(i - 3) % 3];
+    int* cornerpos = cpbuf[(i - 3) % 3] + 1;
+    std::memset(curr, 0, cols);
+    int ncorners = 0;
+    if (i < rows - 3) {
+      for (int j = 3; j < cols - 3; j++, ptr++) {
+        int v = ptr[0];
+        const uint8_t* t = &tab[0] - v + 255;
+        int d = t[ptr[pixel[0]]] | t[ptr[pixel[8]]];
+        if (d == 0) continue;
+        d &= t[ptr[pixel[2]]] | t[ptr[pixel[10]]];
+        d &= t[ptr[pixel[4]]] | t[ptr[pixel[12]]];
+        d &= t[ptr[pixel[6]]] | t[ptr[pixel[14]]];
+        if (d == 0) continue;
+        d &= t[ptr[pixel[1]]] | t[ptr[pixel[9]]];
+        d &= t[ptr[pixel[3]]] | t[ptr[pixel[11]]];
+        d &= t[ptr[pixel[5]]] | t[ptr[pixel[13]]];
+        d &= t[ptr[pixel[7]]] | t[ptr[pixel[15]]];
+        if (d & 1) {
+          int vt = v - threshold, count = 0;
+          for (int k = 0; k < N; k++) {
+            int x = ptr[pixel[k]];
+            if (x < vt) {
+              if (++count > K) {
+                cornerpos[ncorners++] = j;
+                if (nms) curr[j] = (uint8_t)corner_score16(ptr, pixel, threshold);
+                break;
+              }
+            } else
+              count = 0;
+          }
+        }
+        if (d & 2) {
+          int vt = v + threshold, count = 0;
+          for (int k = 0; k < N; k++) {
+            int x = ptr[pixel[k]];
+            if (x > vt) {
+              if (++count > K) {
+                cornerpos[ncorners++] = j;
+                if (nms) curr[j] = (uint8_t)corner_score16(ptr, pixel, threshold);
+                break;
+              }
+            } else
+              count = 0;
+          }
+        }
+      }
+    }
+    cornerpos[-1] = ncorners;
+    if (i == 3) continue;
+    const uint8_t* prev = buf[(i - 4 + 3) % 3];
+    const uint8_t* pprev = buf[(i - 5 + 3) % 3];
+    cornerpos = cpbuf[(i - 4 + 3) % 3] + 1;
+    ncorners = cornerpos[-1];
+    for (int k = 0; k < ncorners; k++) {
+      int j = cornerpos[k];
+      int score = prev[j];
+      if (!nms || (score > prev[j + 1] && score > prev[j - 1] && score > pprev[j - 1] && score > pprev[j] &&
+                   score > pprev[j + 1] && score > curr[j - 1] && score > curr[j] && score > curr[j + 1])) {
+        KeyPt kp{(float)j, (float)(i - 1), 7.f, -1.f, (float)score, 0, -1};
+        out.push_back(kp);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// cv::GaussianBlur(Size(7,7), 2, 2, BORDER_REFLECT_101) on contiguous CV_8UC1 —
+// SURVEY §8(c)-G (8.8 fixed-point path).  Called at src/ORBextractor.cc:1133.
+// ---------------------------------------------------------------------------
+inline int reflect101(int p, int n) {
+  if (n == 1) return 0;
+  while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
+  return p;
+}
+
+void gaussian_kernel7_fixed(int k[7]) {
+  // bit-exact kernel exp(-x^2/(2 sigma^2)), normalised, x256, error-diffused from the outside in.
+  const double sigma = 2.0;
+  double v[7], sum = 0;
+  for (int i = 0; i < 7; i++) {
+    double x = i - 3;
+    v[i] = std::exp(-0.5 * x * x / (sigma * sigma));
+    sum += v[i];
+  }
+  double err = 0;
+  int s = 0;
+  for (int i = 0; i < 3; i++) {
+    double adj = v[i] / sum * 256.0 + err;
+    int q = cv_round(adj);
+    err = adj - q;
+    k[i] = k[6 - i] = q;
+    s += q;
+  }
+  k[3] = 256 - 2 * s;
+}
+
+void gaussian_blur7(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride) {
+  int k[7];
+  gaussian_kernel7_fixed(k);
+  std::vector<uint16_t> tmp((size_t)w * h);
+  for (int y = 0; y < h; y++) {
+    const uint8_t* S = src + (size_t)y * sstride;
+    for (int x = 0; x < w; x++) {
+      uint32_t acc = 0;
+      for (int t = 0; t < 7; t++) acc += (uint32_t)k[t] * S[reflect101(x + t - 3, w)];
+      tmp[(size_t)y * w + x] = (uint16_t)acc;  // <= 255*256, exact in 16 bit
+    }
+  }
+  for (int y = 0; y < h; y++) {
+    for (int x = 0; x < w; x++) {
+      uint32_t acc = 0;
+      for (int t = 0; t < 7; t++) acc += (uint32_t)k[t] * tmp[(size_t)reflect101(y + t - 3, h) * w + x];
+      dst[(size_t)y * dstride + x] = (uint8_t)((acc + 32768u) >> 16);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// cv::fastAtan2(y, x) in degrees — SURVEY §8(c)-A.  Called at src/ORBextractor.cc:102.
+// ---------------------------------------------------------------------------
+float fast_atan2(float y, float x) {
+  const float p1 = 0.9997878412794807f * (float)(180 / M_PI);
+  const float p3 = -0.3258083974640975f * (float)(180 / M_PI);
+  const float p5 = 0.1555786518463281f * (float)(180 / M_PI);
+  const float p7 = -0.04432655554792128f * (float)(180 / M_PI);
+  float ax = std::fabs(x), ay = std::fabs(y);
+  float a, c, c2;
+  if (ax >= ay) {
+    c = ay / (ax + (float)DBL_EPSILON);
+    c2 = c * c;
+    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  } else {
+    c = ax / (ay + (float)DBL_EPSILON);
+    c2 = c * c;
+    a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
+// glibc cosf/sinf through volatile pointers so the compiler can neither fold nor merge them.
+float (*volatile p_cosf)(float) = cosf;
+float (*volatile p_sinf)(float) = sinf;
+
+struct Image {
+  int w = 0, h = 0;
+  std::vector<uint8_t> px;  // contiguous, stride == w
+  const uint8_t* row(int y) const { return px.data() + (size_t)y * w; }
+};
+
+// src/ORBextractor.cc:76-103
+float ic_angle(const Image& im, float ptx, float pty, const std::vector<int>& umax) {
+  int m_01 = 0, m_10 = 0;
+  const int step = im.w;
+  const uint8_t* center = im.row(cv_round(pty)) + cv_round(ptx);
+  for (int u = -kHalfPatch; u <= kHalfPatch; ++u) m_10 += u * center[u];
+  for (int v = 1; v <= kHalfPatch; ++v) {
+    int v_sum = 0;
+    int d = umax[v];
+    for (int u = -d; u <= d; ++u) {
+      int val_plus = center[u + v * step], val_minus = center[u - v * step];
+      v_sum += (val_plus - val_minus);
+      m_10 += u * (val_plus + val_minus);
+    }
+    m_01 += v * v_sum;
+  }
+  return fast_atan2((float)m_01, (float)m_10);
+}
+
+// src/ORBextractor.cc:106-146
+void orb_descriptor(const KeyPt& kp, const Image& blurred, uint8_t* desc) {
+  const float factorPI = (float)(M_PI / 180.f);
+  float angle = (float)kp.angle * factorPI;
+  float a = (float)p_cosf(angle), b = (float)p_sinf(angle);
+  const int step = blurred.w;
+  const uint8_t* center = blurred.row(cv_round(kp.y)) + cv_round(kp.x);
+  const int8_t* pat = kPattern;
+  auto tap = [&](int idx) -> int {
+    float px = (float)pat[idx * 2], py = (float)pat[idx * 2 + 1];
+    int ry = cv_round(px * b + py * a);
+    int rx = cv_round(px * a - py * b);
+    return center[ry * step + rx];
+  };
+  for (int i = 0; i < 32; ++i, pat += 32) {
+    int val = 0;
+    for (int j = 0; j < 8; j++) {
+      int t0 = tap(2 * j), t1 = tap(2 * j + 1);
+      val |= (t0 < t1) << j;
+    }
+    desc[i] = (uint8_t)val;
+  }
+}
+
+// src/ORBextractor.cc:480-536 (ExtractorNode) — coordinates kept as ints like cv::Point2i.
+struct Node {
+  std::vector<KeyPt> keys;
+  int ULx, ULy, URx, URy, BLx, BLy, BRx, BRy;
+  std::list<Node>::iterator lit;
+  bool no_more = false;
+  void divide(Node& n1, Node& n2, Node& n3, Node& n4) const {
+    const int halfX = (int)std::ceil(static_cast<float>(URx - ULx) / 2);
+    const int halfY = (int)std::ceil(static_cast<float>(BRy - ULy) / 2);
+    n1.ULx = ULx; n1.ULy = ULy;
+    n1.URx = ULx + halfX; n1.URy = ULy;
+    n1.BLx = ULx; n1.BLy = ULy + halfY;
+    n1.BRx = ULx + halfX; n1.BRy = ULy + halfY;
+    n2.ULx = n1.URx; n2.ULy = n1.URy;
+    n2.URx = URx; n2.URy = URy;
+    n2.BLx = n1.BRx; n2.BLy = n1.BRy;
+    n2.BRx = URx; n2.BRy = ULy + halfY;
+    n3.ULx = n1.BLx; n3.ULy = n1.BLy;
+    n3.URx = n1.BRx; n3.URy = n1.BRy;
+    n3.BLx = BLx; n3.BLy = BLy;
+    n3.BRx = n1.BRx; n3.BRy = BLy;
+    n4.ULx = n3.URx; n4.ULy = n3.URy;
+    n4.URx = n2.BRx; n4.URy = n2.BRy;
+    n4.BLx = n3.BRx; n4.BLy = n3.BRy;
+    n4.BRx = BRx; n4.BRy = BRy;
+    for (const KeyPt& kp : keys) {
+      if (kp.x < n1.URx) {
+        if (kp.y < n1.BRy) n1.keys.push_back(kp);
+        else n3.keys.push_back(kp);
+      } else if (kp.y < n1.BRy)
+        n2.keys.push_back(kp);
+      else
+        n4.keys.push_back(kp);
+    }
+    if (n1.keys.size() == 1) n1.no_more = true;
+    if (n2.keys.size() == 1) n2.no_more = true;
+    if (n3.keys.size() == 1) n3.no_more = true;
+    if (n4.keys.size() == 1) n4.no_more = true;
+  }
+};
+
+// src/ORBextractor.cc:538-553
+bool compare_nodes(std::pair<int, Node*>& e1, std::pair<int, Node*>& e2) {
+  if (e1.first < e2.first) return true;
+  if (e1.first > e2.first) return false;
+  return e1.second->ULx < e2.second->ULx;
+}
+
+// src/ORBextractor.cc:555-779
+std::vector<KeyPt> distribute_octree(const std::vector<KeyPt>& cand, int minX, int maxX, int minY, int maxY, int N,
+                                     int* stat_sorted_phase) {
+  const int nIni = (int)std::round(static_cast<float>(maxX - minX) / (maxY - minY));
+  const float hX = static_cast<float>(maxX - minX) / nIni;
+  std::list<Node> nodes;
+  std::vector<Node*> ini(nIni);
+  for (int i = 0; i < nIni; i++) {
+    Node ni;
+    ni.ULx = (int)(hX * static_cast<float>(i)); ni.ULy = 0;
+    ni.URx = (int)(hX * static_cast<float>(i + 1)); ni.URy = 0;
+    ni.BLx = ni.ULx; ni.BLy = maxY - minY;
+    ni.BRx = ni.URx; ni.BRy = maxY - minY;
+    nodes.push_back(ni);
+    ini[i] = &nodes.back();
+  }
+  for (const KeyPt& kp : cand) ini[(size_t)(kp.x / hX)]->keys.push_back(kp);
+  for (auto lit = nodes.begin(); lit != nodes.end();) {
+    if (lit->keys.size() == 1) { lit->no_more = true; ++lit; }
+    else if (lit->keys.empty()) lit = nodes.erase(lit);
+    else ++lit;
+  }
+  bool finish = false;
+  std::vector<std::pair<int, Node*>> size_ptr;
+  auto push_children = [&](Node& c, int* nToExpand) {
+    if (c.keys.size() > 0) {
+      nodes.push_front(c);
+      if (c.keys.size() > 1) {
+        if (nToExpand) ++*nToExpand;
+        size_ptr.push_back(std::make_pair((int)c.keys.size(), &nodes.front()));
+        nodes.front().lit = nodes.begin();
+      }
+    }
+  };
+  while (!finish) {
+    int prevSize = (int)nodes.size();
+    auto lit = nodes.begin();
+    int nToExpand = 0;
+    size_ptr.clear();
+    while (lit != nodes.end()) {
+      if (lit->no_more) { ++lit; continue; }
+      Node n1, n2, n3, n4;
+      lit->divide(n1, n2, n3, n4);
+      push_children(n1, &nToExpand);
+      push_children(n2, &nToExpand);
+      push_children(n3, &nToExpand);
+      push_children(n4, &nToExpand);
+      lit = nodes.erase(lit);
+    }
+    if ((int)nodes.size() >= N || (int)nodes.size() == prevSize) {
+      finish = true;
+    } else if (((int)nodes.size() + nToExpand * 3) > N) {
+      if (stat_sorted_phase) ++*stat_sorted_phase;
+      while (!finish) {
+        prevSize = (int)nodes.size();
+        std::vector<std::pair<int, Node*>> prev = size_ptr;
+        size_ptr.clear();
+        std::sort(prev.begin(), prev.end(), compare_nodes);
+        for (int j = (int)prev.size() - 1; j >= 0; j--) {
+          Node n1, n2, n3, n4;
+          prev[j].second->divide(n1, n2, n3, n4);
+          push_children(n1, nullptr);
+          push_children(n2, nullptr);
+          push_children(n3, nullptr);
+          push_children(n4, nullptr);
+          nodes.erase(prev[j].second->lit);
+          if ((int)nodes.size() >= N) break;
+        }
+        if ((int)nodes.size() >= N || (int)nodes.size() == prevSize) finish = true;
+      }
+    }
+  }
+  std::vector<KeyPt> result;
+  for (auto& nd : nodes) {
+    const KeyPt* best = &nd.keys[0];
+    float maxResponse = best->response;
+    for (size_t k = 1; k < nd.keys.size(); k++) {
+      if (nd.keys[k].response > maxResponse) {
+        best = &nd.keys[k];
+        maxResponse = nd.keys[k].response;
+      }
+    }
+    result.push_back(*best);
+  }
+  return result;
+}
+
+struct Extractor {
+  int nfeatures, nlevels, iniTh, minTh;
+  double scaleFactor;  // include/ORBextractor.h:96 — double member initialised from a float
+  std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
+  std::vector<int> quota, umax;
+  // state of the last extract() (stage dumps)
+  std::vector<Image> pyr, blurred;
+  std::vector<std::vector<KeyPt>> cand, kps;
+  int sorted_phase_count = 0;
+
+  // src/ORBextractor.cc:409-469
+  Extractor(int nf, float sf, int nl, int ini, int mn) : nfeatures(nf), nlevels(nl), iniTh(ini), minTh(mn), scaleFactor(sf) {
+    scale.resize(nlevels); sigma2.resize(nlevels);
+    scale[0] = 1.0f; sigma2[0] = 1.0f;
+    for (int i = 1; i < nlevels; i++) {
+      scale[i] = (float)(scale[i - 1] * scaleFactor);
+      sigma2[i] = scale[i] * scale[i];
+    }
+    inv_scale.resize(nlevels); inv_sigma2.resize(nlevels);
+    for (int i = 0; i < nlevels; i++) {
+      inv_scale[i] = 1.0f / scale[i];
+      inv_sigma2[i] = 1.0f / sigma2[i];
+    }
+    quota.resize(nlevels);
+    float factor = (float)(1.0f / scaleFactor);
+    float desired = nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nlevels));
+    int sum = 0;
+    for (int level = 0; level < nlevels - 1; level++) {
+      quota[level] = cv_round(desired);
+      sum += quota[level];
+      desired *= factor;
+    }
+    quota[nlevels - 1] = std::max(nfeatures - sum, 0);
+    umax.resize(kHalfPatch + 1);
+    int v, v0, vmax = (int)std::floor(kHalfPatch * std::sqrt(2.f) / 2 + 1);
+    int vmin = (int)std::ceil(kHalfPatch * std::sqrt(2.f) / 2);
+    const double hp2 = kHalfPatch * kHalfPatch;
+    for (v = 0; v <= vmax; ++v) umax[v] = cv_round(std::sqrt(hp2 - v * v));
+    for (v = kHalfPatch, v0 = 0; v >= vmin; --v) {
+      while (umax[v0] == umax[v0 + 1]) ++v0;
+      umax[v] = v0;
+      ++v0;
+    }
+  }
+
+  // src/ORBextractor.cc:1170-1195 (padding bytes are never read by the extractor; levels stored unpadded)
+  void compute_pyramid(const uint8_t* img, int rows, int cols, int stride) {
+    pyr.assign(nlevels, Image());
+    for (int level = 0; level < nlevels; ++level) {
+      float s = inv_scale[level];
+      int w = cv_round((float)cols * s), h = cv_round((float)rows * s);
+      Image& L = pyr[level];
+      L.w = w; L.h = h; L.px.resize((size_t)w * h);
+      if (level != 0) {
+        const Image& P = pyr[level - 1];
+        resize_linear_u8(P.px.data(), P.w, P.h, P.w, L.px.data(), w, h, w);
+      } else {
+        for (int y = 0; y < rows; y++) std::memcpy(L.px.data() + (size_t)y * w, img + (size_t)y * stride, cols);
+      }
+    }
+  }
+
+  // src/ORBextractor.cc:781-896
+  void compute_keypoints() {
+    cand.assign(nlevels, {});
+    kps.assign(nlevels, {});
+    const float W = 35;
+    for (int level = 0; level < nlevels; ++level) {
+      const Image& im = pyr[level];
+      const int minBorderX = kEdgeThreshold - 3, minBorderY = minBorderX;
+      const int maxBorderX = im.w - kEdgeThreshold + 3, maxBorderY = im.h - kEdgeThreshold + 3;
+      std::vector<KeyPt>& toDistribute = cand[level];
+      const float width = (float)(maxBorderX - minBorderX), height = (float)(maxBorderY - minBorderY);
+      const int nCols = (int)(width / W), nRows = (int)(height / W);
+      const int wCell = (int)std::ceil(width / nCols), hCell = (int)std::ceil(height / nRows);
+      std::vector<KeyPt> cell;
+      for (int i = 0; i < nRows; i++) {
+        const float iniY = (float)(minBorderY + i * hCell);
+        float maxY = iniY + hCell + 6;
+        if (iniY >= maxBorderY - 3) continue;
+        if (maxY > maxBorderY) maxY = (float)maxBorderY;
+        for (int j = 0; j < nCols; j++) {
+          const float iniX = (float)(minBorderX + j * wCell);
+          float maxX = iniX + wCell + 6;
+          if (iniX >= maxBorderX - 6) continue;
+          if (maxX > maxBorderX) maxX = (float)maxBorderX;
+          const int x0 = (int)iniX, x1 = (int)maxX, y0 = (int)iniY, y1 = (int)maxY;
+          const uint8_t* sub = im.row(y0) + x0;
+          fast9_16(sub, x1 - x0, y1 - y0, im.w, iniTh, true, cell);
+          if (cell.empty()) fast9_16(sub, x1 - x0, y1 - y0, im.w, minTh, true, cell);
+          for (KeyPt kp : cell) {
+            kp.x += j * wCell;
+            kp.y += i * hCell;
+            toDistribute.push_back(kp);
+          }
+        }
+      }
+      std::vector<KeyPt>& keypoints = kps[level];
+      keypoints = distribute_octree(toDistribute, minBorderX, maxBorderX, minBorderY, maxBorderY, quota[level],
+                                    &sorted_phase_count);
+      const int scaledPatchSize = (int)(kPatchSize * scale[level]);
+      for (KeyPt& kp : keypoints) {
+        kp.x += minBorderX;
+        kp.y += minBorderY;
+        kp.octave = level;
+        kp.size = (float)scaledPatchSize;
+      }
+    }
+    for (int level = 0; level < nlevels; ++level)
+      for (KeyPt& kp : kps[level]) kp.angle = ic_angle(pyr[level], kp.x, kp.y, umax);
+  }
+
+  // src/ORBextractor.cc:1086-1168
+  int extract(const uint8_t* img, int rows, int cols, int stride, int lap0, int lap1, KeyPt* out_kps,
+              uint8_t* out_desc, int cap, int* n_out, int* mono_out) {
+    *n_out = 0; *mono_out = 0;
+    if (!img || rows <= 0 || cols <= 0) return -1;
+    sorted_phase_count = 0;
+    compute_pyramid(img, rows, cols, stride);
+    compute_keypoints();
+    int nkeypoints = 0;
+    for (int level = 0; level < nlevels; ++level) nkeypoints += (int)kps[level].size();
+    *n_out = nkeypoints;
+    if (nkeypoints > cap) return -2;
+    blurred.assign(nlevels, Image());
+    int monoIndex = 0, stereoIndex = nkeypoints - 1;
+    for (int level = 0; level < nlevels; ++level) {
+      std::vector<KeyPt>& keypoints = kps[level];
+      if (keypoints.empty()) continue;
+      Image& B = blurred[level];
+      B.w = pyr[level].w; B.h = pyr[level].h; B.px.resize(pyr[level].px.size());
+      gaussian_blur7(pyr[level].px.data(), B.w, B.h, B.w, B.px.data(), B.w);
+      std::vector<uint8_t> desc(keypoints.size() * 32);
+      for (size_t i = 0; i < keypoints.size(); i++) orb_descriptor(keypoints[i], B, &desc[i * 32]);
+      float s = scale[level];
+      int i = 0;
+      for (const KeyPt& kp0 : keypoints) {
+        KeyPt kp = kp0;  // keep level coordinates in the stage dump
+        if (level != 0) { kp.x *= s; kp.y *= s; }
+        int idx;
+        if (kp.x >= lap0 && kp.x <= lap1) idx = stereoIndex--;
+        else idx = monoIndex++;
+        out_kps[idx] = kp;
+        std::memcpy(out_desc + (size_t)idx * 32, &desc[(size_t)i * 32], 32);
+        i++;
+      }
+    }
+    *mono_out = monoIndex;
+    return 0;
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+void* orbo_create(int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh) {
+  return new Extractor(nfeatures, scaleFactor, nlevels, iniTh, minTh);
+}
+void orbo_destroy(void* h) { delete (Extractor*)h; }
+
+int orbo_extract(void* h, const uint8_t* img, int rows, int cols, int stride, int lap0, int lap1, void* kps,
+                 uint8_t* desc, int cap, int* n_out, int* mono_out) {
+  return ((Extractor*)h)->extract(img, rows, cols, stride, lap0, lap1, (KeyPt*)kps, desc, cap, n_out, mono_out);
+}
+
+void orbo_tables(void* h, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2, int* quota, int* umax16) {
+  Extractor* e = (Extractor*)h;
+  for (int i = 0; i < e->nlevels; i++) {
+    if (scale) scale[i] = e->scale[i];
+    if (inv_scale) inv_scale[i] = e->inv_scale[i];
+    if (sigma2) sigma2[i] = e->sigma2[i];
+    if (inv_sigma2) inv_sigma2[i] = e->inv_sigma2[i];
+    if (quota) quota[i] = e->quota[i];
+  }
+  if (umax16) for (int i = 0; i < 16; i++) umax16[i] = e->umax[i];
+}
+
+int orbo_level_size(void* h, int level, int* w, int* hgt) {
+  Extractor* e = (Extractor*)h;
+  if (level < 0 || level >= (int)e->pyr.size()) return -1;
+  *w = e->pyr[level].w; *hgt = e->pyr[level].h;
+  return 0;
+}
+int orbo_level_copy(void* h, int level, int blurred, uint8_t* dst, int dst_stride) {
+  Extractor* e = (Extractor*)h;
+  const std::vector<Image>& v = blurred ? e->blurred : e->pyr;
+  if (level < 0 || level >= (int)v.size() || v[level].px.empty()) return -1;
+  for (int y = 0; y < v[level].h; y++) std::memcpy(dst + (size_t)y * dst_stride, v[level].row(y), v[level].w);
+  return 0;
+}
+// stage 0 = FAST candidates handed to the quadtree (cell-shifted, border-relative coords);
+// stage 1 = distributed keypoints with orientation (level coords)
+int orbo_level_keypoints(void* h, int level, int stage, void* dst, int cap) {
+  Extractor* e = (Extractor*)h;
+  const auto& v = stage == 0 ? e->cand : e->kps;
+  if (level < 0 || level >= (int)v.size()) return -1;
+  int n = (int)v[level].size();
+  if (dst) std::memcpy(dst, v[level].data(), sizeof(KeyPt) * (size_t)std::min(n, cap));
+  return n;
+}
+int orbo_sorted_phase_count(void* h) { return ((Extractor*)h)->sorted_phase_count; }
+
+// isolated primitives
+void orbo_resize_linear(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh, int dstride) {
+  resize_linear_u8(src, sw, sh, sstride, dst, dw, dh, dstride);
+}
+int orbo_fast(const uint8_t* img, int cols, int rows, int stride, int threshold, int nms, void* dst, int cap) {
+  std::vector<KeyPt> v;
+  fast9_16(img, cols, rows, stride, threshold, nms != 0, v);
+  if (dst) std::memcpy(dst, v.data(), sizeof(KeyPt) * std::min((size_t)cap, v.size()));
+  return (int)v.size();
+}
+void orbo_gaussian_blur7(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride) {
+  gaussian_blur7(src, w, h, sstride, dst, dstride);
+}
+void orbo_gaussian_kernel7(int* k) { gaussian_kernel7_fixed(k); }
+float orbo_fast_atan2(float y, float x) { return fast_atan2(y, x); }
+void orbo_cos_sin_deg(float angle_deg, float* a, float* b) {
+  const float factorPI = (float)(M_PI / 180.f);
+  float r = angle_deg * factorPI;
+  *a = p_cosf(r);
+  *b = p_sinf(r);
+}
+int orbo_distribute(const void* cand, int n, int minX, int maxX, int minY, int maxY, int N, void* dst, int cap) {
+  std::vector<KeyPt> c((const KeyPt*)cand, (const KeyPt*)cand + n);
+  std::vector<KeyPt> r = distribute_octree(c, minX, maxX, minY, maxY, N, nullptr);
+  if (dst) std::memcpy(dst, r.data(), sizeof(KeyPt) * std::min((size_t)cap, r.size()));
+  return (int)r.size();
+}
+const int8_t* orbo_pattern() { return kPattern; }
+
+}  // extern "C"

@@ -1,0 +1,167 @@
+"""ctypes binding of the CPU oracle (oracle/liborb_oracle.so).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg — never by the
+product package `orb_slam3_modified_amd`."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liborb_oracle.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+
+def build(force: bool = False) -> str:
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".cpp", ".inc", "Makefile"))]
+    stale = (not os.path.exists(_LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        vp, ip, fp, u8p = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_void_p
+        L.orbo_create.restype = vp
+        L.orbo_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.orbo_destroy.argtypes = [vp]
+        L.orbo_extract.restype = C.c_int
+        L.orbo_extract.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, u8p, C.c_int, ip, ip]
+        L.orbo_tables.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+        L.orbo_level_size.argtypes = [vp, C.c_int, ip, ip]
+        L.orbo_level_copy.restype = C.c_int
+        L.orbo_level_copy.argtypes = [vp, C.c_int, C.c_int, u8p, C.c_int]
+        L.orbo_level_keypoints.restype = C.c_int
+        L.orbo_level_keypoints.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
+        L.orbo_sorted_phase_count.argtypes = [vp]
+        L.orbo_resize_linear.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p, C.c_int, C.c_int, C.c_int]
+        L.orbo_fast.restype = C.c_int
+        L.orbo_fast.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+        L.orbo_gaussian_blur7.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p, C.c_int]
+        L.orbo_gaussian_kernel7.argtypes = [vp]
+        L.orbo_fast_atan2.restype = C.c_float
+        L.orbo_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.orbo_cos_sin_deg.argtypes = [C.c_float, fp, fp]
+        L.orbo_distribute.restype = C.c_int
+        L.orbo_distribute.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+        L.orbo_pattern.restype = C.POINTER(C.c_int8)
+        _lib = L
+    return _lib
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OracleExtractor:
+    """Mirror of ORB_SLAM3::ORBextractor (include/ORBextractor.h:49-83) over the oracle."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        self.nfeatures, self.nlevels = nfeatures, nlevels
+        self._h = lib().orbo_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        self.cap = nfeatures + 3 * nlevels + 64
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orbo_destroy(self._h)
+            self._h = None
+
+    def tables(self):
+        n = self.nlevels
+        sc, isc, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        quota, umax = np.zeros(n, np.int32), np.zeros(16, np.int32)
+        lib().orbo_tables(self._h, _ptr(sc), _ptr(isc), _ptr(s2), _ptr(is2), _ptr(quota), _ptr(umax))
+        return dict(scale=sc, inv_scale=isc, sigma2=s2, inv_sigma2=is2, quota=quota, umax=umax)
+
+    def extract(self, img: np.ndarray, lapping=(0, 0)):
+        """Returns (keypoints[KP_DTYPE], descriptors[n,32] u8, monoIndex)."""
+        assert img.dtype == np.uint8 and img.ndim == 2
+        img = np.ascontiguousarray(img)
+        kps = np.zeros(self.cap, KP_DTYPE)
+        desc = np.zeros((self.cap, 32), np.uint8)
+        n, mono = C.c_int(0), C.c_int(0)
+        rc = lib().orbo_extract(self._h, _ptr(img), img.shape[0], img.shape[1], img.strides[0], int(lapping[0]),
+                                int(lapping[1]), _ptr(kps), _ptr(desc), self.cap, C.byref(n), C.byref(mono))
+        if rc != 0:
+            raise RuntimeError(f"oracle extract rc={rc} n={n.value}")
+        return kps[:n.value].copy(), desc[:n.value].copy(), mono.value
+
+    def level(self, level: int, blurred: bool = False) -> np.ndarray:
+        w, h = C.c_int(0), C.c_int(0)
+        assert lib().orbo_level_size(self._h, level, C.byref(w), C.byref(h)) == 0
+        out = np.zeros((h.value, w.value), np.uint8)
+        if lib().orbo_level_copy(self._h, level, int(blurred), _ptr(out), w.value) != 0:
+            raise RuntimeError("level not available")
+        return out
+
+    def level_keypoints(self, level: int, stage: int) -> np.ndarray:
+        n = lib().orbo_level_keypoints(self._h, level, stage, None, 0)
+        out = np.zeros(max(n, 1), KP_DTYPE)
+        lib().orbo_level_keypoints(self._h, level, stage, _ptr(out), n)
+        return out[:n]
+
+    def sorted_phase_count(self) -> int:
+        return lib().orbo_sorted_phase_count(self._h)
+
+
+def resize_linear(src: np.ndarray, dw: int, dh: int) -> np.ndarray:
+    src = np.ascontiguousarray(src)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().orbo_resize_linear(_ptr(src), src.shape[1], src.shape[0], src.strides[0], _ptr(dst), dw, dh, dw)
+    return dst
+
+
+def fast(img: np.ndarray, threshold: int, nms: bool = True) -> np.ndarray:
+    img = np.ascontiguousarray(img)
+    cap = img.size
+    out = np.zeros(max(cap, 1), KP_DTYPE)
+    n = lib().orbo_fast(_ptr(img), img.shape[1], img.shape[0], img.strides[0], threshold, int(nms), _ptr(out), cap)
+    return out[:n]
+
+
+def gaussian_blur7(img: np.ndarray) -> np.ndarray:
+    img = np.ascontiguousarray(img)
+    dst = np.zeros_like(img)
+    lib().orbo_gaussian_blur7(_ptr(img), img.shape[1], img.shape[0], img.strides[0], _ptr(dst), dst.strides[0])
+    return dst
+
+
+def gaussian_kernel7() -> np.ndarray:
+    k = np.zeros(7, np.int32)
+    lib().orbo_gaussian_kernel7(_ptr(k))
+    return k
+
+
+def fast_atan2(y: float, x: float) -> float:
+    return float(lib().orbo_fast_atan2(y, x))
+
+
+def cos_sin_deg(angle_deg: float):
+    a, b = C.c_float(0), C.c_float(0)
+    lib().orbo_cos_sin_deg(angle_deg, C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def distribute(cand: np.ndarray, minX, maxX, minY, maxY, N) -> np.ndarray:
+    cand = np.ascontiguousarray(cand)
+    out = np.zeros(len(cand) + 8, KP_DTYPE)
+    n = lib().orbo_distribute(_ptr(cand), len(cand), minX, maxX, minY, maxY, N, _ptr(out), len(out))
+    return out[:n]
+
+
+def pattern() -> np.ndarray:
+    p = lib().orbo_pattern()
+    return np.ctypeslib.as_array(p, shape=(1024,)).copy()
