@@ -1,0 +1,170 @@
+/* orbx — MI355X-native ORB front-end: the C-ABI drop-in boundary.
+ *
+ * The reference has no FFI layer: its boundary for this path is three C++ classes compiled into
+ * libORB_SLAM3.so.  Everything those classes compute is exported here as plain C
+ * (pointers + sizes, no C++/torch types); include/ORBextractor.h, include/ORBmatcher.h and
+ * include/ORBVocabulary.h are header-only adapters that re-create the reference signatures on top of
+ * these entry points, so Frame.cc / Tracking.cc / LocalMapping.cc compile unchanged.
+ *
+ * Conventions: functions return ORBX_OK (0) or a negative error code and never throw; a context is not
+ * thread-safe, distinct contexts are (the reference runs two extractor instances concurrently in stereo,
+ * src/Frame.cc:122-125).  "d_" pointers are device (HBM) pointers on the context's GPU, all others are
+ * host pointers.  `stream` is a hipStream_t passed as void* (NULL = the context's own stream).
+ * There is no CPU fallback: without a gfx950 device every compute entry point fails with ORBX_E_DEVICE.
+ */
+#ifndef ORBX_H
+#define ORBX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBX_OK 0
+#define ORBX_E_INVALID (-1)   /* bad argument */
+#define ORBX_E_EMPTY (-2)     /* empty image: the reference returns -1 (src/ORBextractor.cc:1090-1091) */
+#define ORBX_E_DEVICE (-3)    /* no usable GPU / HIP runtime error (see orbx_last_error) */
+#define ORBX_E_CAPACITY (-4)  /* an internal or caller buffer is too small */
+#define ORBX_E_FORMAT (-5)    /* vocabulary file malformed */
+
+typedef struct orbx_ctx orbx_ctx;
+typedef struct orbx_voc orbx_voc;
+
+/* Layout-identical to cv::KeyPoint (pt.x, pt.y, size, angle, response, octave, class_id): 28 bytes. */
+typedef struct orbx_keypoint {
+  float x, y, size, angle, response;
+  int32_t octave, class_id;
+} orbx_keypoint;
+
+/* ---- extractor: replaces ORB_SLAM3::ORBextractor (include/ORBextractor.h:49-83) ------------------- */
+
+/* ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)
+ * src/ORBextractor.cc:409-469.  device_id < 0 selects the current HIP device. */
+int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast,
+                int device_id);
+void orbx_destroy(orbx_ctx* ctx);
+const char* orbx_last_error(const orbx_ctx* ctx);
+
+/* Rows a caller must provide per frame for keypoints / descriptors: nfeatures + 3*nlevels. */
+int orbx_keypoint_capacity(const orbx_ctx* ctx);
+
+/* GetLevels / GetScaleFactor(s) / GetInverseScaleFactors / GetScaleSigmaSquares / GetInverseScaleSigmaSquares
+ * (include/ORBextractor.h:63-82) and the per-level feature quotas (src/ORBextractor.cc:434-445).
+ * Any output pointer may be NULL; arrays hold nlevels entries. */
+int orbx_levels(const orbx_ctx* ctx);
+int orbx_scale_tables(const orbx_ctx* ctx, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                      int32_t* features_per_level);
+
+/* ORBextractor::operator()(image, mask [ignored], keypoints, descriptors, vLappingArea)
+ * src/ORBextractor.cc:1086-1168, one frame, host buffers (H2D image, kernels, D2H results).
+ * img: CV_8UC1 rows x cols with `stride` bytes per row.  kps / desc hold orbx_keypoint_capacity() rows
+ * (desc: 32 bytes per row).  *n_out = number of keypoints, *mono_index_out = the value operator() returns.
+ * Returns ORBX_E_EMPTY for an empty image (reference: -1). */
+int orbx_extract(orbx_ctx* ctx, const uint8_t* img, int rows, int cols, size_t stride, int lap0, int lap1,
+                 orbx_keypoint* kps, uint8_t* desc, int* n_out, int* mono_index_out);
+
+/* The same computation over `nframes` frames of one shape that are already resident in HBM, results left in
+ * HBM (the batch-replay / benchmark path; frames are independent).
+ *   d_imgs   : frame f, row r at d_imgs + f*frame_stride + r*row_stride
+ *   d_kps    : [nframes][capacity] orbx_keypoint      d_desc : [nframes][capacity][32] bytes
+ *   d_counts : [nframes][2] int32 = {n keypoints, monoIndex}
+ * Asynchronous on `stream`. */
+int orbx_extract_batch_device(orbx_ctx* ctx, const uint8_t* d_imgs, int nframes, int rows, int cols, size_t row_stride,
+                              size_t frame_stride, int lap0, int lap1, orbx_keypoint* d_kps, uint8_t* d_desc,
+                              int32_t* d_counts, void* stream);
+
+/* Host-buffer convenience over the batch path (H2D all frames, extract, D2H). counts: [nframes][2]. */
+int orbx_extract_batch(orbx_ctx* ctx, const uint8_t* imgs, int nframes, int rows, int cols, size_t row_stride,
+                       size_t frame_stride, int lap0, int lap1, orbx_keypoint* kps, uint8_t* desc, int32_t* counts);
+
+/* mvImagePyramid[level] of frame `frame` of the last extraction (include/ORBextractor.h:83), copied to host
+ * (the reference's stereo matcher reads it, src/Frame.cc:818,908-925).  dst may be NULL to query w/h. */
+int orbx_pyramid_level(orbx_ctx* ctx, int frame, int level, uint8_t* dst, size_t dst_stride, int* w, int* h);
+
+/* Stage dumps of the last extraction, for parity tests.
+ *  stage 0: FAST candidates handed to the quadtree, in the reference's order (vToDistributeKeys,
+ *           src/ORBextractor.cc:863-868): packed x | y<<12 | score<<24, border-relative coordinates.
+ *  stage 1: keypoints kept by the quadtree, list order (src/ORBextractor.cc:758-776): same packing,
+ *           level coordinates.
+ * Returns the number of entries (or a negative error); dst may be NULL. */
+int orbx_debug_level_points(orbx_ctx* ctx, int frame, int level, int stage, uint32_t* dst, int cap);
+
+/* Per-kernel device time of the extractor, measured with HIP events on the launch stream.
+ * orbx_profile_enable(ctx,1) makes every following extraction record events around each kernel;
+ * orbx_profile_read returns, for kernel slot i < ORBX_NUM_KERNELS, accumulated milliseconds and launches. */
+#define ORBX_NUM_KERNELS 6
+int orbx_profile_enable(orbx_ctx* ctx, int on);
+int orbx_profile_read(orbx_ctx* ctx, double ms[ORBX_NUM_KERNELS], int64_t launches[ORBX_NUM_KERNELS]);
+const char* orbx_kernel_name(int slot);
+
+/* ---- matcher primitives: replace the inner loops of ORB_SLAM3::ORBmatcher --------------------------- */
+
+/* ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:2058-2074; dup FORB::distance, FORB.cpp:77-96):
+ * 256-bit Hamming distance of two 32-byte descriptors.  Pure host helper (one pair). */
+int orbx_hamming(const uint8_t a[32], const uint8_t b[32]);
+
+/* Guided nearest-neighbour search over CSR candidate lists — the shared inner loop of the 12 Search... / Fuse
+ * routines.  Query q (0..nq-1) is compared with train rows cand[row_ptr[q] .. row_ptr[q+1]).
+ *   best_idx[q]   : train index of the minimum distance; ties -> FIRST candidate in list order
+ *                   (strict `<` update, e.g. src/ORBmatcher.cc:103-111), or LAST when last_wins != 0
+ *                   (the `<=` update of SearchForTriangulation, src/ORBmatcher.cc:1017); -1 if no candidate
+ *   best_dist[q]  : that distance (256 if none)
+ *   second_idx/second_dist[q]: the runner-up under the same (distance, list position) order, i.e. exactly the
+ *                   bestDist2 / bestLevel2 bookkeeping of src/ORBmatcher.cc:103-118 (-1 / 256 if none)
+ *   dist_out      : optional [nnz] all candidate distances (for the host-side greedy replays), may be NULL
+ * Host pointers; q_desc [nq][32], t_desc [nt][32]. */
+int orbx_nn_csr(orbx_ctx* ctx, const uint8_t* q_desc, int nq, const uint8_t* t_desc, int nt, const int32_t* row_ptr,
+                const int32_t* cand, int last_wins, int32_t* best_idx, int32_t* best_dist, int32_t* second_idx,
+                int32_t* second_dist, int32_t* dist_out);
+
+/* cv::BFMatcher(NORM_HAMMING).knnMatch(k=2) as used at src/Frame.cc:43,1144: for each query the two nearest
+ * train descriptors (ties -> lower train index first).  idx/dist: [nq][2]; missing entries = -1 / 256. */
+int orbx_knn2_allpairs(orbx_ctx* ctx, const uint8_t* q_desc, int nq, const uint8_t* t_desc, int nt, int32_t* idx,
+                       int32_t* dist);
+
+/* Device-resident variants of the two searches above (all pointers in HBM, async on `stream`). */
+int orbx_nn_csr_device(orbx_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, const int32_t* d_row_ptr,
+                       const int32_t* d_cand, int last_wins, int32_t* d_best_idx, int32_t* d_best_dist,
+                       int32_t* d_second_idx, int32_t* d_second_dist, int32_t* d_dist_out, void* stream);
+int orbx_knn2_allpairs_device(orbx_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_idx,
+                              int32_t* d_dist, void* stream);
+
+/* ---- bag of words: replaces ORBVocabulary = DBoW2::TemplatedVocabulary<cv::Mat, FORB> ----------------- */
+
+/* TemplatedVocabulary::loadFromTextFile (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1424).
+ * Blank lines are skipped (the reference manufactures a phantom node from a trailing newline).
+ * The tree is uploaded to the GPU of `ctx`. */
+int orbx_voc_load_text(orbx_ctx* ctx, const char* path, orbx_voc** out);
+/* Build from memory: node i (1-based ids, node 0 = root) has parent[i], is_leaf[i], 32-byte descriptor, weight. */
+int orbx_voc_create(orbx_ctx* ctx, int k, int L, int scoring, int weighting, int nnodes_excl_root, const int32_t* parent,
+                    const uint8_t* is_leaf, const uint8_t* desc, const double* weight, orbx_voc** out);
+void orbx_voc_destroy(orbx_voc* voc);
+int orbx_voc_info(const orbx_voc* voc, int* k, int* L, int* nnodes, int* nwords);
+
+/* The per-feature part of TemplatedVocabulary::transform(features, BowVector&, FeatureVector&, levelsup)
+ * (TemplatedVocabulary.h:1127-1259): tree descent of every descriptor.
+ *   word[i]   : word id of the leaf reached      weight[i] : that word's weight (0 => feature is dropped)
+ *   node[i]   : node id at level L - levelsup (the FeatureVector key)
+ * The ordered-map accumulation + L1 normalisation (BowVector.cpp:34-85, FeatureVector.cpp:30-45) is
+ * orbx_bow_finalize below (host, ascending-id order, double). */
+int orbx_bow_transform(orbx_voc* voc, const uint8_t* desc, int n, int levelsup, uint32_t* word, double* weight,
+                       uint32_t* node);
+int orbx_bow_transform_device(orbx_voc* voc, const uint8_t* d_desc, int n, int levelsup, uint32_t* d_word,
+                              double* d_weight, uint32_t* d_node, void* stream);
+/* BowVector accumulate (addWeight) + normalize(L1): out ids ascending, values double; returns nnz in *n_out.
+ * ids/vals hold n entries. */
+int orbx_bow_finalize(const orbx_voc* voc, const uint32_t* word, const double* weight, int n, uint32_t* ids,
+                      double* vals, int* n_out);
+/* L1Scoring::score (Thirdparty/DBoW2/DBoW2/ScoringObject.cpp:23-68) of two sorted sparse vectors. */
+double orbx_bow_score_l1(const uint32_t* ida, const double* va, int na, const uint32_t* idb, const double* vb, int nb);
+/* One query vector against many database vectors (CSR), on the GPU: the KeyFrameDatabase scoring loop
+ * (src/KeyFrameDatabase.cc:162,303,391,531,662,783).  scores: [ndb]. */
+int orbx_bow_score_l1_batch(orbx_ctx* ctx, const uint32_t* q_ids, const double* q_vals, int nq, const int32_t* db_ptr,
+                            const uint32_t* db_ids, const double* db_vals, int ndb, double* scores);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBX_H */

@@ -165,3 +165,82 @@ def distribute(cand: np.ndarray, minX, maxX, minY, maxY, N) -> np.ndarray:
 def pattern() -> np.ndarray:
     p = lib().orbo_pattern()
     return np.ctypeslib.as_array(p, shape=(1024,)).copy()
+
+
+# ---- matcher / bag-of-words oracle (oracle/match_oracle.cpp) ------------------------------------------------
+def _mlib():
+    L = lib()
+    if not getattr(L, "_mo_bound", False):
+        vp = C.c_void_p
+        L.mo_hamming.restype = C.c_int
+        L.mo_hamming.argtypes = [vp, vp]
+        L.mo_nn_csr.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp]
+        L.mo_knn2.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
+        L.mo_voc_load.restype = vp
+        L.mo_voc_load.argtypes = [C.c_char_p]
+        L.mo_voc_free.argtypes = [vp]
+        L.mo_voc_descend.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp]
+        L.mo_voc_transform.restype = C.c_int
+        L.mo_voc_transform.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, C.POINTER(C.c_int)]
+        L.mo_score_l1.restype = C.c_double
+        L.mo_score_l1.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int]
+        L._mo_bound = True
+    return L
+
+
+def hamming(a, b) -> int:
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    return int(_mlib().mo_hamming(_ptr(a), _ptr(b)))
+
+
+def nn_csr(q, t, row_ptr, cand, last_wins=False):
+    q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+    rp = np.ascontiguousarray(row_ptr, np.int32); cd = np.ascontiguousarray(cand, np.int32)
+    nq = len(q)
+    bi, bd, si, sd = (np.zeros(max(nq, 1), np.int32) for _ in range(4))
+    do = np.zeros(max(len(cd), 1), np.int32)
+    _mlib().mo_nn_csr(_ptr(q), nq, _ptr(t), _ptr(rp), _ptr(cd), int(last_wins), _ptr(bi), _ptr(bd), _ptr(si), _ptr(sd), _ptr(do))
+    return bi[:nq], bd[:nq], si[:nq], sd[:nq], do[:len(cd)]
+
+
+def knn2(q, t):
+    q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+    idx = np.zeros((max(len(q), 1), 2), np.int32); dist = np.zeros((max(len(q), 1), 2), np.int32)
+    _mlib().mo_knn2(_ptr(q), len(q), _ptr(t), len(t), _ptr(idx), _ptr(dist))
+    return idx[:len(q)], dist[:len(q)]
+
+
+class OracleVocabulary:
+    def __init__(self, path: str):
+        self._h = _mlib().mo_voc_load(path.encode())
+        if not self._h:
+            raise RuntimeError("oracle vocabulary load failed")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _mlib().mo_voc_free(self._h)
+            self._h = None
+
+    def descend(self, desc, levelsup=4):
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        n = len(d)
+        word, node, w = np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.float64)
+        _mlib().mo_voc_descend(self._h, _ptr(d), n, levelsup, _ptr(word), _ptr(w), _ptr(node))
+        return word[:n], w[:n], node[:n]
+
+    def transform(self, desc, levelsup=4):
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        n = len(d)
+        ids, vals = np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.float64)
+        fvn, fvf, nfv = np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.uint32), C.c_int(0)
+        k = _mlib().mo_voc_transform(self._h, _ptr(d), n, levelsup, _ptr(ids), _ptr(vals), _ptr(fvn), _ptr(fvf), C.byref(nfv))
+        fv = {}
+        for a, b in zip(fvn[:nfv.value], fvf[:nfv.value]):
+            fv.setdefault(int(a), []).append(int(b))
+        return (ids[:k].copy(), vals[:k].copy()), fv
+
+
+def score_l1(a, b) -> float:
+    ia, va = np.ascontiguousarray(a[0], np.uint32), np.ascontiguousarray(a[1], np.float64)
+    ib, vb = np.ascontiguousarray(b[0], np.uint32), np.ascontiguousarray(b[1], np.float64)
+    return float(_mlib().mo_score_l1(_ptr(ia), _ptr(va), len(ia), _ptr(ib), _ptr(vb), len(ib)))

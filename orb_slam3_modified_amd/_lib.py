@@ -1,0 +1,98 @@
+"""ctypes loader for liborbx.so (the C-ABI drop-in boundary, include/orbx.h).
+
+The shared library is built in-tree by `python -m orb_slam3_modified_amd.build` (hipcc, gfx950).
+There is no Python/CPU fallback: if the library is missing the import of any compute class raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liborbx.so")
+
+ORBX_OK, ORBX_E_INVALID, ORBX_E_EMPTY, ORBX_E_DEVICE, ORBX_E_CAPACITY, ORBX_E_FORMAT = 0, -1, -2, -3, -4, -5
+NUM_KERNELS = 6
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+
+class OrbxError(RuntimeError):
+    def __init__(self, code: int, msg: str = ""):
+        super().__init__(f"orbx error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not built — run `python -m orb_slam3_modified_amd.build` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, sz, f32 = C.c_void_p, C.c_int, C.c_size_t, C.c_float
+    ip = C.POINTER(C.c_int)
+    sig = {
+        "orbx_create": (i32, [C.POINTER(vp), i32, f32, i32, i32, i32, i32]),
+        "orbx_destroy": (None, [vp]),
+        "orbx_last_error": (C.c_char_p, [vp]),
+        "orbx_keypoint_capacity": (i32, [vp]),
+        "orbx_levels": (i32, [vp]),
+        "orbx_scale_tables": (i32, [vp, vp, vp, vp, vp, vp]),
+        "orbx_extract": (i32, [vp, vp, i32, i32, sz, i32, i32, vp, vp, ip, ip]),
+        "orbx_extract_batch_device": (i32, [vp, vp, i32, i32, i32, sz, sz, i32, i32, vp, vp, vp, vp]),
+        "orbx_extract_batch": (i32, [vp, vp, i32, i32, i32, sz, sz, i32, i32, vp, vp, vp]),
+        "orbx_pyramid_level": (i32, [vp, i32, i32, vp, sz, ip, ip]),
+        "orbx_debug_level_points": (i32, [vp, i32, i32, i32, vp, i32]),
+        "orbx_profile_enable": (i32, [vp, i32]),
+        "orbx_profile_read": (i32, [vp, vp, vp]),
+        "orbx_kernel_name": (C.c_char_p, [i32]),
+        "orbx_hamming": (i32, [vp, vp]),
+        "orbx_nn_csr": (i32, [vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]),
+        "orbx_knn2_allpairs": (i32, [vp, vp, i32, vp, i32, vp, vp]),
+        "orbx_nn_csr_device": (i32, [vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
+        "orbx_knn2_allpairs_device": (i32, [vp, vp, i32, vp, i32, vp, vp, vp]),
+        "orbx_voc_load_text": (i32, [vp, C.c_char_p, C.POINTER(vp)]),
+        "orbx_voc_create": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, C.POINTER(vp)]),
+        "orbx_voc_destroy": (None, [vp]),
+        "orbx_voc_info": (i32, [vp, ip, ip, ip, ip]),
+        "orbx_bow_transform": (i32, [vp, vp, i32, i32, vp, vp, vp]),
+        "orbx_bow_transform_device": (i32, [vp, vp, i32, i32, vp, vp, vp, vp]),
+        "orbx_bow_finalize": (i32, [vp, vp, vp, i32, vp, vp, ip]),
+        "orbx_bow_score_l1": (C.c_double, [vp, vp, i32, vp, vp, i32]),
+        "orbx_bow_score_l1_batch": (i32, [vp, vp, vp, i32, vp, vp, vp, i32, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError here == header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    L._orbx_symbols = tuple(sig)
+    _lib = L
+    return L
+
+
+def ptr(a) -> C.c_void_p:
+    """void* of a numpy array, an int address, or None."""
+    if a is None:
+        return C.c_void_p(0)
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    return C.c_void_p(int(a))
+
+
+def check(rc: int, ctx=None) -> int:
+    if rc < 0:
+        msg = ""
+        if ctx:
+            m = lib().orbx_last_error(ctx)
+            msg = m.decode() if m else ""
+        raise OrbxError(rc, msg)
+    return rc

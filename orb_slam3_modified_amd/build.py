@@ -1,0 +1,38 @@
+"""In-tree build of liborbx.so (HIP, gfx950 only).  `python -m orb_slam3_modified_amd.build [--force]`."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "liborbx.so")
+SOURCES = ["orbx_extractor.hip", "orbx_matcher.hip"]
+# -ffp-contract=off: the float paths (fastAtan2 polynomial, BRIEF rotation) must not be fused into FMAs,
+# the CPU reference evaluates them as separate IEEE operations (DESIGN.md "bit-exactness").
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",
+         "-Wno-unused-function"]
+
+
+def _stale() -> bool:
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "orbx.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not (force or _stale()):
+        return OUT
+    hipcc = os.environ.get("HIPCC", "hipcc")
+    cmd = [hipcc] + FLAGS + ["-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd, cwd=CSRC)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

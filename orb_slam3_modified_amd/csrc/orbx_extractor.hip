@@ -1,0 +1,530 @@
+// orbx extractor: host side of the C ABI (include/orbx.h) — scale tables, level/cell geometry, device
+// buffers sized for batch replay, kernel launch sequence.  No CPU compute fallback: every entry point that
+// produces features needs a HIP device and reports ORBX_E_DEVICE otherwise.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "orbx_internal.h"
+#include "orbx_kernels.hip"
+
+namespace orbx {
+
+int set_err(orbx_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+static inline int cv_round(float v) { return (int)lrintf(v); }
+static inline int cv_round(double v) { return (int)lrint(v); }
+static inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
+
+// resize tables (cv::resize INTER_LINEAR 8u): per destination index the two source
+// indices and the two 11-bit weights.  The clamped tail (`S[sx]*2048`) is encoded as weights (2048, 0).
+static void build_axis_table(int ssize, int dsize, bool is_x, std::vector<XTab>& out) {
+  const double scale = 1.0 / ((double)dsize / ssize);
+  int dmax = dsize;
+  for (int d = 0; d < dsize; d++) {
+    float f = (float)((d + 0.5) * scale - 0.5);
+    int s = (int)std::floor(f);
+    f -= s;
+    XTab t;
+    if (is_x) {
+      if (s < 0) { f = 0; s = 0; }
+      if (s + 1 >= ssize) {
+        dmax = std::min(dmax, d);
+        if (s >= ssize - 1) { f = 0; s = ssize - 1; }
+      }
+      int a0 = std::min(std::max(cv_round((1.f - f) * 2048.f), -32768), 32767);
+      int a1 = std::min(std::max(cv_round(f * 2048.f), -32768), 32767);
+      if (d >= dmax) { t.s0 = (uint16_t)s; t.s1 = (uint16_t)s; t.a0 = 2048; t.a1 = 0; }
+      else { t.s0 = (uint16_t)s; t.s1 = (uint16_t)(s + 1); t.a0 = (int16_t)a0; t.a1 = (int16_t)a1; }
+    } else {
+      // rows: the index is clamped, the weights are not (OpenCV keeps fy)
+      int a0 = std::min(std::max(cv_round((1.f - f) * 2048.f), -32768), 32767);
+      int a1 = std::min(std::max(cv_round(f * 2048.f), -32768), 32767);
+      auto clip = [&](int v) { return v < 0 ? 0 : (v >= ssize ? ssize - 1 : v); };
+      t.s0 = (uint16_t)clip(s); t.s1 = (uint16_t)clip(s + 1); t.a0 = (int16_t)a0; t.a1 = (int16_t)a1;
+    }
+    out.push_back(t);
+  }
+}
+
+// Level / cell geometry: src/ORBextractor.cc:1174-1175 (level sizes), :789-822 (cells), :559-579 (roots).
+static int build_geometry(orbx_ctx* ctx, int rows, int cols, Geometry& geo) {
+  geo = Geometry();
+  geo.rows = rows; geo.cols = cols; geo.nlevels = ctx->nlevels;
+  if (rows > kMaxDim || cols > kMaxDim) return set_err(ctx, ORBX_E_INVALID, "image larger than 4095 px per side");
+  geo.lv.resize(ctx->nlevels);
+  int cand_off = 0, kp_off = 0;
+  int64_t plane_off = 0;
+  for (int l = 0; l < ctx->nlevels; l++) {
+    LevelGeom& L = geo.lv[l];
+    std::memset(&L, 0, sizeof(L));
+    const float s = ctx->inv_scale[l];
+    L.w = cv_round((float)cols * s);
+    L.h = cv_round((float)rows * s);
+    L.pitch = round_up(L.w, 64);
+    L.plane_off = plane_off;
+    if (l > 0) plane_off += (int64_t)L.pitch * L.h;
+    const int minB = kBorder, maxBX = L.w - kBorder, maxBY = L.h - kBorder;
+    const float width = (float)(maxBX - minB), height = (float)(maxBY - minB);
+    const float W = 35;
+    L.ncols = (int)(width / W);
+    L.nrows = (int)(height / W);
+    if (L.ncols < 1 || L.nrows < 1)
+      return set_err(ctx, ORBX_E_INVALID, "image too small for this number of pyramid levels (level < 67 px)");
+    L.wcell = (int)std::ceil(width / L.ncols);
+    L.hcell = (int)std::ceil(height / L.nrows);
+    L.cell_begin = (int)geo.cells.size();
+    L.cand_off = cand_off;
+    for (int i = 0; i < L.nrows; i++) {
+      const float iniY = (float)(minB + i * L.hcell);
+      float maxY = iniY + L.hcell + 6;
+      if (iniY >= maxBY - 3) continue;
+      if (maxY > maxBY) maxY = (float)maxBY;
+      for (int j = 0; j < L.ncols; j++) {
+        const float iniX = (float)(minB + j * L.wcell);
+        float maxX = iniX + L.wcell + 6;
+        if (iniX >= maxBX - 6) continue;
+        if (maxX > maxBX) maxX = (float)maxBX;
+        CellGeom c;
+        c.level = (int16_t)l;
+        c.x0 = (int16_t)iniX; c.y0 = (int16_t)iniY;
+        c.cw = (int16_t)((int)maxX - (int)iniX); c.ch = (int16_t)((int)maxY - (int)iniY);
+        c.relx = (int16_t)(j * L.wcell); c.rely = (int16_t)(i * L.hcell);
+        const int dw = c.cw - 6, dh = c.ch - 6;
+        if (dw <= 0 || dh <= 0) continue;  // FAST has no interior pixel: the reference gets no keypoint here
+        c.slot_off = cand_off;
+        c.slot_cap = ((dw + 1) / 2) * ((dh + 1) / 2);  // strict 3x3 NMS: survivors are never 8-adjacent
+        cand_off += c.slot_cap;
+        geo.cells.push_back(c);
+        geo.max_cell_w = std::max(geo.max_cell_w, (int)c.cw);
+        geo.max_cell_h = std::max(geo.max_cell_h, (int)c.ch);
+      }
+    }
+    L.ncells = (int)geo.cells.size() - L.cell_begin;
+    L.cand_cap = cand_off - L.cand_off;
+    geo.max_cells_per_level = std::max(geo.max_cells_per_level, L.ncells);
+    L.quota = ctx->quota[l];
+    geo.max_quota = std::max(geo.max_quota, L.quota);
+    L.nroots = (int)std::round((float)(maxBX - minB) / (maxBY - minB));
+    if (L.nroots < 1 || L.nroots > kMaxRoots)
+      return set_err(ctx, ORBX_E_INVALID, "aspect ratio outside the supported 0.5 .. 8.5 range");
+    L.hX = (float)(maxBX - minB) / L.nroots;
+    for (int i = 0; i < L.nroots; i++) {
+      L.root_x0[i] = (int)(L.hX * (float)i);
+      L.root_x1[i] = (int)(L.hX * (float)(i + 1));
+    }
+    L.kp_off = kp_off;
+    L.kp_cap = std::max(L.quota + 3, 4 * kMaxRoots);
+    kp_off += L.kp_cap;
+    L.scale = ctx->scale[l];
+    L.scaled_patch = (int)(kPatchSize * ctx->scale[l]);
+    if (l > 0) {
+      L.xtab_off = (int)geo.xtab.size();
+      build_axis_table(geo.lv[l - 1].w, L.w, true, geo.xtab);
+      L.ytab_off = (int)geo.ytab.size();
+      build_axis_table(geo.lv[l - 1].h, L.h, false, geo.ytab);
+    }
+  }
+  geo.pyr_bytes = plane_off;
+  geo.cand_total = cand_off;
+  geo.kp_total = kp_off;
+  return ORBX_OK;
+}
+
+static void free_buffers(orbx_ctx* ctx) {
+  auto fr = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
+  fr(ctx->d_geo); fr(ctx->d_cells); fr(ctx->d_xtab); fr(ctx->d_ytab);
+  fr(ctx->d_pyr); fr(ctx->d_cand); fr(ctx->d_cell_cnt); fr(ctx->d_pts); fr(ctx->d_lvl_kp); fr(ctx->d_lvl_n); fr(ctx->d_outidx);
+  ctx->batch_cap = 0;
+}
+
+static int ensure_buffers(orbx_ctx* ctx, int rows, int cols, int nframes) {
+  const bool same_shape = ctx->geo.rows == rows && ctx->geo.cols == cols && ctx->d_geo;
+  if (same_shape && nframes <= ctx->batch_cap) return ORBX_OK;
+  ORBX_HIP(ctx, hipDeviceSynchronize());
+  Geometry geo;
+  int rc = build_geometry(ctx, rows, cols, geo);
+  if (rc != ORBX_OK) return rc;
+  free_buffers(ctx);
+  ctx->geo = geo;
+  DeviceGeom dg;
+  std::memset(&dg, 0, sizeof(dg));
+  dg.nlevels = geo.nlevels; dg.rows = rows; dg.cols = cols;
+  dg.ncells_total = (int)geo.cells.size(); dg.cand_total = geo.cand_total; dg.kp_total = geo.kp_total;
+  dg.out_cap = ctx->out_cap;
+  for (int l = 0; l < geo.nlevels; l++) {
+    const LevelGeom& L = geo.lv[l];
+    DeviceLevel& D = dg.lv[l];
+    D.w = L.w; D.h = L.h; D.pitch = L.pitch; D.plane_off = L.plane_off;
+    D.cell_begin = L.cell_begin; D.ncells = L.ncells; D.cand_off = L.cand_off; D.cand_cap = L.cand_cap;
+    D.quota = L.quota; D.kp_off = L.kp_off; D.kp_cap = L.kp_cap; D.nroots = L.nroots;
+    for (int i = 0; i < kMaxRoots; i++) { D.root_x0[i] = L.root_x0[i]; D.root_x1[i] = L.root_x1[i]; }
+    D.hX = L.hX; D.scale = L.scale; D.scaled_patch = L.scaled_patch; D.xtab_off = L.xtab_off; D.ytab_off = L.ytab_off;
+  }
+  ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_geo, sizeof(DeviceGeom)));
+  ORBX_HIP(ctx, hipMemcpy(ctx->d_geo, &dg, sizeof(dg), hipMemcpyHostToDevice));
+  ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_cells, sizeof(CellGeom) * geo.cells.size()));
+  ORBX_HIP(ctx, hipMemcpy(ctx->d_cells, geo.cells.data(), sizeof(CellGeom) * geo.cells.size(), hipMemcpyHostToDevice));
+  ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_xtab, sizeof(XTab) * std::max<size_t>(geo.xtab.size(), 1)));
+  ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_ytab, sizeof(XTab) * std::max<size_t>(geo.ytab.size(), 1)));
+  if (!geo.xtab.empty()) {
+    ORBX_HIP(ctx, hipMemcpy(ctx->d_xtab, geo.xtab.data(), sizeof(XTab) * geo.xtab.size(), hipMemcpyHostToDevice));
+    ORBX_HIP(ctx, hipMemcpy(ctx->d_ytab, geo.ytab.data(), sizeof(XTab) * geo.ytab.size(), hipMemcpyHostToDevice));
+  }
+  const size_t B = (size_t)nframes;
+  ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_pyr, std::max<size_t>(B * (size_t)geo.pyr_bytes, 64)));
+  ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_cand, B * geo.cand_total * sizeof(uint32_t)));
+  ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_cell_cnt, B * geo.cells.size() * sizeof(int32_t)));
+  ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_pts, B * 2 * geo.cand_total * sizeof(uint32_t)));
+  ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_lvl_kp, B * geo.kp_total * sizeof(uint32_t)));
+  ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_lvl_n, B * geo.nlevels * sizeof(int32_t)));
+  ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_outidx, B * ctx->out_cap * sizeof(int32_t)));
+  ctx->batch_cap = nframes;
+  return ORBX_OK;
+}
+
+struct ProfScope {
+  orbx_ctx* ctx; int slot; hipStream_t st; hipEvent_t e0 = nullptr, e1 = nullptr;
+  ProfScope(orbx_ctx* c, int s, hipStream_t stream) : ctx(c), slot(s), st(stream) {
+    if (ctx->profiling) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st); }
+  }
+  ~ProfScope() {
+    if (ctx->profiling) {
+      (void)hipEventRecord(e1, st);
+      ctx->ev_pool.push_back(e0); ctx->ev_pool.push_back(e1);
+      ctx->prof_n[slot] += 1;
+      // slot is recovered from the pool position when the times are read
+      ctx->ev_pool.push_back((hipEvent_t)(intptr_t)(slot + 1));
+    }
+  }
+};
+
+static void gaussian_kernel7(int k[7]) {
+  // cv::getGaussianKernel(7, 2) in 8.8 fixed point, rounding error diffused from the outside in
+  double v[7], sum = 0;
+  for (int i = 0; i < 7; i++) { const double x = i - 3; v[i] = std::exp(-0.5 * x * x / 4.0); sum += v[i]; }
+  double err = 0; int s = 0;
+  for (int i = 0; i < 3; i++) {
+    const double adj = v[i] / sum * 256.0 + err;
+    const int q = cv_round(adj);
+    err = adj - q; k[i] = k[6 - i] = q; s += q;
+  }
+  k[3] = 256 - 2 * s;
+}
+
+static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int nframes, int rows, int cols, size_t row_stride,
+                           size_t frame_stride, int lap0, int lap1, orbx_keypoint* d_kps, uint8_t* d_desc,
+                           int32_t* d_counts, hipStream_t st) {
+  const Geometry& geo = ctx->geo;
+  // K1: pyramid chain (levels depend on each other: one launch per level over the whole batch)
+  {
+    ProfScope ps(ctx, 0, st);
+    for (int l = 1; l < geo.nlevels; l++) {
+      const LevelGeom& D = geo.lv[l];
+      const LevelGeom& S = geo.lv[l - 1];
+      const uint8_t* src; long long sfs; int sp;
+      if (l == 1) { src = d_imgs; sfs = (long long)frame_stride; sp = (int)row_stride; }
+      else { src = ctx->d_pyr + S.plane_off; sfs = geo.pyr_bytes; sp = S.pitch; }
+      dim3 grid((D.w + 255) / 256, (D.h + 3) / 4, nframes), block(64, 4, 1);
+      hipLaunchKernelGGL(k_resize, grid, block, 0, st, src, sfs, sp, ctx->d_pyr + D.plane_off, (long long)geo.pyr_bytes,
+                         D.pitch, D.w, D.h, ctx->d_xtab + D.xtab_off, ctx->d_ytab + D.ytab_off);
+    }
+  }
+  // K2: FAST cells
+  {
+    ProfScope ps(ctx, 1, st);
+    const int tile_pitch = round_up(geo.max_cell_w, 4);
+    const int tile_rows = geo.max_cell_h;
+    const size_t lds = (size_t)tile_pitch * tile_rows * 3;
+    dim3 grid((unsigned)geo.cells.size(), nframes, 1);
+    hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), lds, st, ctx->d_geo, ctx->d_cells, d_imgs, (long long)row_stride,
+                       (long long)frame_stride, ctx->d_pyr, (long long)geo.pyr_bytes, ctx->d_cand, ctx->d_cell_cnt,
+                       ctx->ini_th, ctx->min_th, tile_pitch, tile_rows);
+  }
+  // K3: quadtree
+  {
+    ProfScope ps(ctx, 2, st);
+    const int node_cap = round_up(geo.max_quota + 4 * kMaxRoots + 8, 4);
+    const int scan_cap = round_up(std::max(node_cap, geo.max_cells_per_level) + 8, 4);
+    const size_t lds = (size_t)node_cap * (2 * sizeof(QNode) + 2 * 8 + sizeof(int4) + 4) + (size_t)scan_cap * 8;
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return set_err(ctx, ORBX_E_CAPACITY, "nfeatures too large for the quadtree kernel's LDS");
+    }
+    dim3 grid(geo.nlevels, nframes, 1);
+    hipLaunchKernelGGL(k_quadtree, grid, dim3(256), lds, st, ctx->d_geo, ctx->d_cells, ctx->d_cand, ctx->d_cell_cnt,
+                       ctx->d_pts, ctx->d_lvl_kp, ctx->d_lvl_n, node_cap, scan_cap);
+  }
+  // K3b: output slots
+  {
+    ProfScope ps(ctx, 3, st);
+    hipLaunchKernelGGL(k_assemble, dim3(nframes), dim3(256), (size_t)ctx->out_cap * 8 + 64, st, ctx->d_geo, ctx->d_lvl_kp,
+                       ctx->d_lvl_n, ctx->d_outidx, d_counts, lap0, lap1);
+  }
+  // K4: orientation + descriptors
+  {
+    ProfScope ps(ctx, 4, st);
+    DescConsts dc;
+    for (int i = 0; i < 16; i++) dc.umax[i] = ctx->umax[i];
+    gaussian_kernel7(dc.gk);
+    dim3 grid((ctx->out_cap + 3) / 4, nframes, 1);
+    hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, st, ctx->d_geo, d_imgs, (long long)row_stride, (long long)frame_stride,
+                       ctx->d_pyr, (long long)geo.pyr_bytes, ctx->d_lvl_kp, ctx->d_lvl_n, ctx->d_outidx, d_kps, d_desc, dc);
+  }
+  ORBX_HIP(ctx, hipGetLastError());
+  return ORBX_OK;
+}
+
+}  // namespace orbx
+
+using namespace orbx;
+
+extern "C" {
+
+int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th, int device_id) {
+  if (!out) return ORBX_E_INVALID;
+  *out = nullptr;
+  if (nfeatures < 1 || nlevels < 1 || nlevels > kMaxLevels || !(scale_factor > 1.0f) || ini_th < 0 || min_th < 0)
+    return ORBX_E_INVALID;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ORBX_E_DEVICE;
+  if (device_id < 0) { if (hipGetDevice(&device_id) != hipSuccess) return ORBX_E_DEVICE; }
+  if (device_id >= ndev) return ORBX_E_INVALID;
+  orbx_ctx* ctx = new (std::nothrow) orbx_ctx();
+  if (!ctx) return ORBX_E_CAPACITY;
+  ctx->nfeatures = nfeatures; ctx->nlevels = nlevels; ctx->ini_th = std::min(std::max(ini_th, 0), 255);
+  ctx->min_th = std::min(std::max(min_th, 0), 255); ctx->device = device_id;
+  ctx->scale_factor = scale_factor;  // include/ORBextractor.h:96: double member initialised from the float argument
+  // src/ORBextractor.cc:414-430
+  ctx->scale.resize(nlevels); ctx->sigma2.resize(nlevels); ctx->inv_scale.resize(nlevels); ctx->inv_sigma2.resize(nlevels);
+  ctx->scale[0] = 1.0f; ctx->sigma2[0] = 1.0f;
+  for (int i = 1; i < nlevels; i++) {
+    ctx->scale[i] = (float)(ctx->scale[i - 1] * ctx->scale_factor);
+    ctx->sigma2[i] = ctx->scale[i] * ctx->scale[i];
+  }
+  for (int i = 0; i < nlevels; i++) { ctx->inv_scale[i] = 1.0f / ctx->scale[i]; ctx->inv_sigma2[i] = 1.0f / ctx->sigma2[i]; }
+  // src/ORBextractor.cc:434-445
+  ctx->quota.resize(nlevels);
+  const float factor = (float)(1.0f / ctx->scale_factor);
+  float desired = nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nlevels));
+  int sum = 0;
+  for (int l = 0; l < nlevels - 1; l++) {
+    ctx->quota[l] = cv_round(desired);
+    sum += ctx->quota[l];
+    desired *= factor;
+  }
+  ctx->quota[nlevels - 1] = std::max(nfeatures - sum, 0);
+  // src/ORBextractor.cc:453-468
+  {
+    int* umax = ctx->umax;
+    int v, v0, vmax = (int)std::floor(kHalfPatch * std::sqrt(2.f) / 2 + 1);
+    int vmin = (int)std::ceil(kHalfPatch * std::sqrt(2.f) / 2);
+    const double hp2 = kHalfPatch * kHalfPatch;
+    for (v = 0; v <= vmax; ++v) umax[v] = cv_round(std::sqrt(hp2 - v * v));
+    for (v = kHalfPatch, v0 = 0; v >= vmin; --v) {
+      while (umax[v0] == umax[v0 + 1]) ++v0;
+      umax[v] = v0;
+      ++v0;
+    }
+  }
+  ctx->out_cap = 0;
+  for (int l = 0; l < nlevels; l++) ctx->out_cap += std::max(ctx->quota[l] + 3, 4 * kMaxRoots);
+  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return ORBX_E_DEVICE;
+  }
+  *out = ctx;
+  return ORBX_OK;
+}
+
+void orbx_destroy(orbx_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  free_buffers(ctx);
+  auto fr = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
+  fr(ctx->d_stage_img); fr(ctx->d_stage_kps); fr(ctx->d_stage_desc); fr(ctx->d_stage_counts);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* orbx_last_error(const orbx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+int orbx_keypoint_capacity(const orbx_ctx* ctx) { return ctx ? ctx->out_cap : ORBX_E_INVALID; }
+int orbx_levels(const orbx_ctx* ctx) { return ctx ? ctx->nlevels : ORBX_E_INVALID; }
+
+int orbx_scale_tables(const orbx_ctx* ctx, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                      int32_t* features_per_level) {
+  if (!ctx) return ORBX_E_INVALID;
+  for (int i = 0; i < ctx->nlevels; i++) {
+    if (scale) scale[i] = ctx->scale[i];
+    if (inv_scale) inv_scale[i] = ctx->inv_scale[i];
+    if (sigma2) sigma2[i] = ctx->sigma2[i];
+    if (inv_sigma2) inv_sigma2[i] = ctx->inv_sigma2[i];
+    if (features_per_level) features_per_level[i] = ctx->quota[i];
+  }
+  return ORBX_OK;
+}
+
+int orbx_extract_batch_device(orbx_ctx* ctx, const uint8_t* d_imgs, int nframes, int rows, int cols, size_t row_stride,
+                              size_t frame_stride, int lap0, int lap1, orbx_keypoint* d_kps, uint8_t* d_desc,
+                              int32_t* d_counts, void* stream) {
+  if (!ctx) return ORBX_E_INVALID;
+  if (!d_imgs || rows <= 0 || cols <= 0 || nframes <= 0) return set_err(ctx, ORBX_E_EMPTY, "empty image");
+  if (!d_kps || !d_desc || !d_counts || row_stride < (size_t)cols || nframes > 65535)
+    return set_err(ctx, ORBX_E_INVALID, "bad batch arguments");
+  ORBX_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_buffers(ctx, rows, cols, nframes);
+  if (rc != ORBX_OK) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  ctx->last_imgs = d_imgs; ctx->last_row_stride = row_stride; ctx->last_frame_stride = frame_stride;
+  ctx->last_nframes = nframes;
+  return launch_pipeline(ctx, d_imgs, nframes, rows, cols, row_stride, frame_stride, lap0, lap1, d_kps, d_desc, d_counts, st);
+}
+
+static int ensure_stage(orbx_ctx* ctx, int nframes, size_t img_bytes) {
+  if (img_bytes > ctx->stage_img_bytes) {
+    if (ctx->d_stage_img) (void)hipFree(ctx->d_stage_img);
+    ctx->d_stage_img = nullptr; ctx->stage_img_bytes = 0;
+    ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_stage_img, img_bytes));
+    ctx->stage_img_bytes = img_bytes;
+  }
+  if (nframes > ctx->stage_frames) {
+    auto fr = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
+    fr(ctx->d_stage_kps); fr(ctx->d_stage_desc); fr(ctx->d_stage_counts);
+    ctx->stage_frames = 0;
+    ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_stage_kps, (size_t)nframes * ctx->out_cap * sizeof(orbx_keypoint)));
+    ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_stage_desc, (size_t)nframes * ctx->out_cap * 32));
+    ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_stage_counts, (size_t)nframes * 2 * sizeof(int32_t)));
+    ctx->stage_frames = nframes;
+  }
+  return ORBX_OK;
+}
+
+int orbx_extract_batch(orbx_ctx* ctx, const uint8_t* imgs, int nframes, int rows, int cols, size_t row_stride,
+                       size_t frame_stride, int lap0, int lap1, orbx_keypoint* kps, uint8_t* desc, int32_t* counts) {
+  if (!ctx) return ORBX_E_INVALID;
+  if (!imgs || rows <= 0 || cols <= 0 || nframes <= 0) return set_err(ctx, ORBX_E_EMPTY, "empty image");
+  if (!kps || !desc || !counts || row_stride < (size_t)cols) return set_err(ctx, ORBX_E_INVALID, "bad arguments");
+  ORBX_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t pitch = (size_t)round_up(cols, 64), fbytes = pitch * rows;
+  int rc = ensure_stage(ctx, nframes, fbytes * nframes);
+  if (rc != ORBX_OK) return rc;
+  for (int f = 0; f < nframes; f++)
+    ORBX_HIP(ctx, hipMemcpy2DAsync(ctx->d_stage_img + f * fbytes, pitch, imgs + f * frame_stride, row_stride, cols, rows,
+                                   hipMemcpyHostToDevice, ctx->stream));
+  rc = orbx_extract_batch_device(ctx, ctx->d_stage_img, nframes, rows, cols, pitch, fbytes, lap0, lap1, ctx->d_stage_kps,
+                                 ctx->d_stage_desc, ctx->d_stage_counts, ctx->stream);
+  if (rc != ORBX_OK) return rc;
+  ORBX_HIP(ctx, hipMemcpyAsync(counts, ctx->d_stage_counts, (size_t)nframes * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  ORBX_HIP(ctx, hipMemcpyAsync(kps, ctx->d_stage_kps, (size_t)nframes * ctx->out_cap * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, ctx->stream));
+  ORBX_HIP(ctx, hipMemcpyAsync(desc, ctx->d_stage_desc, (size_t)nframes * ctx->out_cap * 32, hipMemcpyDeviceToHost, ctx->stream));
+  ORBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // a negative level count marks a quadtree capacity overflow (never expected; fail loudly)
+  std::vector<int32_t> ln((size_t)nframes * ctx->nlevels);
+  ORBX_HIP(ctx, hipMemcpy(ln.data(), ctx->d_lvl_n, ln.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+  for (int32_t v : ln) if (v < 0) return set_err(ctx, ORBX_E_CAPACITY, "quadtree produced more nodes than the level capacity");
+  return ORBX_OK;
+}
+
+int orbx_extract(orbx_ctx* ctx, const uint8_t* img, int rows, int cols, size_t stride, int lap0, int lap1,
+                 orbx_keypoint* kps, uint8_t* desc, int* n_out, int* mono_index_out) {
+  if (n_out) *n_out = 0;
+  if (mono_index_out) *mono_index_out = 0;
+  if (!ctx) return ORBX_E_INVALID;
+  if (!img || rows <= 0 || cols <= 0) return set_err(ctx, ORBX_E_EMPTY, "empty image");
+  int32_t counts[2] = {0, 0};
+  int rc = orbx_extract_batch(ctx, img, 1, rows, cols, stride, stride * rows, lap0, lap1, kps, desc, counts);
+  if (rc != ORBX_OK) return rc;
+  if (n_out) *n_out = counts[0];
+  if (mono_index_out) *mono_index_out = counts[1];
+  return ORBX_OK;
+}
+
+int orbx_pyramid_level(orbx_ctx* ctx, int frame, int level, uint8_t* dst, size_t dst_stride, int* w, int* h) {
+  if (!ctx || !ctx->d_geo || level < 0 || level >= ctx->nlevels || frame < 0 || frame >= ctx->last_nframes)
+    return ctx ? set_err(ctx, ORBX_E_INVALID, "no such pyramid level") : ORBX_E_INVALID;
+  const LevelGeom& L = ctx->geo.lv[level];
+  if (w) *w = L.w;
+  if (h) *h = L.h;
+  if (!dst) return ORBX_OK;
+  ORBX_HIP(ctx, hipSetDevice(ctx->device));
+  ORBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const uint8_t* src; size_t sp;
+  if (level == 0) { src = ctx->last_imgs + (size_t)frame * ctx->last_frame_stride; sp = ctx->last_row_stride; }
+  else { src = ctx->d_pyr + (size_t)frame * ctx->geo.pyr_bytes + L.plane_off; sp = L.pitch; }
+  ORBX_HIP(ctx, hipMemcpy2D(dst, dst_stride, src, sp, L.w, L.h, hipMemcpyDeviceToHost));
+  return ORBX_OK;
+}
+
+int orbx_debug_level_points(orbx_ctx* ctx, int frame, int level, int stage, uint32_t* dst, int cap) {
+  if (!ctx || !ctx->d_geo || level < 0 || level >= ctx->nlevels || frame < 0 || frame >= ctx->last_nframes)
+    return ctx ? set_err(ctx, ORBX_E_INVALID, "no such level") : ORBX_E_INVALID;
+  ORBX_HIP(ctx, hipSetDevice(ctx->device));
+  ORBX_HIP(ctx, hipDeviceSynchronize());
+  const Geometry& geo = ctx->geo;
+  const LevelGeom& L = geo.lv[level];
+  if (stage == 0) {
+    std::vector<int32_t> cnt(L.ncells);
+    ORBX_HIP(ctx, hipMemcpy(cnt.data(), ctx->d_cell_cnt + (size_t)frame * geo.cells.size() + L.cell_begin,
+                            sizeof(int32_t) * L.ncells, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> slots(L.cand_cap);
+    ORBX_HIP(ctx, hipMemcpy(slots.data(), ctx->d_cand + (size_t)frame * geo.cand_total + L.cand_off,
+                            sizeof(uint32_t) * L.cand_cap, hipMemcpyDeviceToHost));
+    int n = 0;
+    for (int c = 0; c < L.ncells; c++) {
+      const CellGeom& cg = geo.cells[L.cell_begin + c];
+      for (int e = 0; e < cnt[c]; e++) {
+        if (dst && n < cap) dst[n] = slots[cg.slot_off - L.cand_off + e];
+        n++;
+      }
+    }
+    return n;
+  }
+  int32_t n = 0;
+  ORBX_HIP(ctx, hipMemcpy(&n, ctx->d_lvl_n + (size_t)frame * geo.nlevels + level, sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (n < 0) return set_err(ctx, ORBX_E_CAPACITY, "quadtree level overflow");
+  if (dst && n > 0)
+    ORBX_HIP(ctx, hipMemcpy(dst, ctx->d_lvl_kp + (size_t)frame * geo.kp_total + L.kp_off, sizeof(uint32_t) * std::min(n, cap),
+                            hipMemcpyDeviceToHost));
+  return n;
+}
+
+int orbx_profile_enable(orbx_ctx* ctx, int on) {
+  if (!ctx) return ORBX_E_INVALID;
+  ctx->profiling = on != 0;
+  return ORBX_OK;
+}
+
+int orbx_profile_read(orbx_ctx* ctx, double ms[ORBX_NUM_KERNELS], int64_t launches[ORBX_NUM_KERNELS]) {
+  if (!ctx) return ORBX_E_INVALID;
+  ORBX_HIP(ctx, hipSetDevice(ctx->device));
+  ORBX_HIP(ctx, hipDeviceSynchronize());
+  for (size_t i = 0; i + 3 <= ctx->ev_pool.size(); i += 3) {
+    hipEvent_t e0 = ctx->ev_pool[i], e1 = ctx->ev_pool[i + 1];
+    const int slot = (int)(intptr_t)ctx->ev_pool[i + 2] - 1;
+    float t = 0;
+    if (hipEventElapsedTime(&t, e0, e1) == hipSuccess && slot >= 0 && slot < ORBX_NUM_KERNELS) ctx->prof_ms[slot] += t;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  }
+  ctx->ev_pool.clear();
+  for (int i = 0; i < ORBX_NUM_KERNELS; i++) {
+    if (ms) ms[i] = ctx->prof_ms[i];
+    if (launches) launches[i] = ctx->prof_n[i];
+    ctx->prof_ms[i] = 0; ctx->prof_n[i] = 0;
+  }
+  return ORBX_OK;
+}
+
+const char* orbx_kernel_name(int slot) {
+  static const char* names[ORBX_NUM_KERNELS] = {"k_resize(pyramid chain)", "k_fast_cells", "k_quadtree", "k_assemble",
+                                                "k_describe", "reserved"};
+  return slot >= 0 && slot < ORBX_NUM_KERNELS ? names[slot] : "";
+}
+
+}  // extern "C"

@@ -1,0 +1,122 @@
+// Internal declarations shared by the orbx translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/orbx.h"
+
+namespace orbx {
+
+constexpr int kEdge = 19;        // EDGE_THRESHOLD, src/ORBextractor.cc:73
+constexpr int kBorder = 16;      // EDGE_THRESHOLD-3 = minBorderX/Y, src/ORBextractor.cc:789-790
+constexpr int kHalfPatch = 15;   // HALF_PATCH_SIZE, src/ORBextractor.cc:72
+constexpr int kPatchSize = 31;   // PATCH_SIZE, src/ORBextractor.cc:71
+constexpr int kMaxLevels = 16;
+constexpr int kMaxRoots = 8;
+constexpr int kMaxDim = 4095;    // packed point format: 12 bits per coordinate
+
+// packed point: x | y << 12 | score << 24
+__host__ __device__ inline uint32_t pack_pt(int x, int y, int s) { return (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)s << 24); }
+__host__ __device__ inline int pt_x(uint32_t p) { return (int)(p & 0xfffu); }
+__host__ __device__ inline int pt_y(uint32_t p) { return (int)((p >> 12) & 0xfffu); }
+__host__ __device__ inline int pt_s(uint32_t p) { return (int)(p >> 24); }
+
+struct XTab { uint16_t s0, s1; int16_t a0, a1; };  // resize tables: source index pair + 11-bit weights
+
+struct LevelGeom {
+  int w, h, pitch;          // pixels; pitch in bytes (levels >= 1; level 0 uses the caller's strides)
+  int64_t plane_off;        // byte offset of this level inside one frame's pyramid block (levels >= 1)
+  int ncols, nrows, wcell, hcell;
+  int cell_begin, ncells;   // range in the cell table
+  int cand_off, cand_cap;   // range in one frame's candidate-slot array (u32 entries)
+  int quota, kp_off, kp_cap;  // quadtree output range in one frame's level-keypoint array
+  int nroots;
+  int root_x0[kMaxRoots], root_x1[kMaxRoots];
+  float hX, scale;
+  int scaled_patch;         // (int)(PATCH_SIZE*scale): KeyPoint::size
+  int xtab_off, ytab_off;   // offsets into the device resize tables (entries)
+};
+
+struct CellGeom {
+  int16_t level, x0, y0, cw, ch;  // sub-image origin (level coords) and size incl. the +6 margin
+  int16_t relx, rely;             // j*wCell, i*hCell (added to FAST coordinates, src/ORBextractor.cc:865-866)
+  int32_t slot_off, slot_cap;     // range in one frame's candidate-slot array
+};
+
+struct Geometry {
+  int rows = 0, cols = 0, nlevels = 0;
+  std::vector<LevelGeom> lv;
+  std::vector<CellGeom> cells;
+  std::vector<XTab> xtab, ytab;
+  int64_t pyr_bytes = 0;      // per frame, levels >= 1
+  int cand_total = 0;         // per frame
+  int kp_total = 0;           // per frame (sum of kp_cap)
+  int max_cell_w = 0, max_cell_h = 0, max_cells_per_level = 0, max_quota = 0;
+};
+
+struct DeviceLevel {  // POD copy of LevelGeom fields the kernels need
+  int w, h, pitch;
+  long long plane_off;
+  int cell_begin, ncells, cand_off, cand_cap, quota, kp_off, kp_cap, nroots;
+  int root_x0[kMaxRoots], root_x1[kMaxRoots];
+  float hX, scale;
+  int scaled_patch, xtab_off, ytab_off;
+};
+
+struct DeviceGeom {
+  int nlevels, rows, cols, ncells_total, cand_total, kp_total, out_cap;
+  DeviceLevel lv[kMaxLevels];
+};
+
+}  // namespace orbx
+
+struct orbx_ctx {
+  int nfeatures, nlevels, ini_th, min_th, device;
+  double scale_factor;
+  std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
+  std::vector<int> quota;
+  int umax[16];
+  int out_cap;  // nfeatures + 3*nlevels
+
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // geometry + device buffers for the current (rows, cols, batch capacity)
+  orbx::Geometry geo;
+  orbx::DeviceGeom* d_geo = nullptr;
+  orbx::CellGeom* d_cells = nullptr;
+  orbx::XTab* d_xtab = nullptr;
+  orbx::XTab* d_ytab = nullptr;
+  int batch_cap = 0;
+  uint8_t* d_pyr = nullptr;        // [batch][pyr_bytes]
+  uint32_t* d_cand = nullptr;      // [batch][cand_total]
+  int32_t* d_cell_cnt = nullptr;   // [batch][ncells]
+  uint32_t* d_pts = nullptr;       // [batch][2][cand_total]  quadtree ping-pong
+  uint32_t* d_lvl_kp = nullptr;    // [batch][kp_total]
+  int32_t* d_lvl_n = nullptr;      // [batch][nlevels]
+  int32_t* d_outidx = nullptr;     // [batch][out_cap]
+  // single-frame staging (orbx_extract)
+  uint8_t* d_stage_img = nullptr; size_t stage_img_bytes = 0;
+  orbx_keypoint* d_stage_kps = nullptr; uint8_t* d_stage_desc = nullptr; int32_t* d_stage_counts = nullptr;
+  int stage_frames = 0;
+  // last extraction (for orbx_pyramid_level / debug dumps)
+  const uint8_t* last_imgs = nullptr; size_t last_row_stride = 0, last_frame_stride = 0; int last_nframes = 0;
+  // profiling
+  bool profiling = false;
+  double prof_ms[ORBX_NUM_KERNELS] = {0};
+  int64_t prof_n[ORBX_NUM_KERNELS] = {0};
+  std::vector<hipEvent_t> ev_pool;
+};
+
+namespace orbx {
+int set_err(orbx_ctx* ctx, int code, const std::string& msg);
+#define ORBX_HIP(ctx, expr)                                                                          \
+  do {                                                                                               \
+    hipError_t _e = (expr);                                                                          \
+    if (_e != hipSuccess)                                                                            \
+      return orbx::set_err((ctx), ORBX_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+}  // namespace orbx

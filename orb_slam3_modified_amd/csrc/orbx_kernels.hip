@@ -1,0 +1,695 @@
+// orbx extractor kernels for gfx950 (CDNA4, wave64).  Integer/bitwise work, no MFMA.
+//
+//   k_resize      : one pyramid level from the previous one (OpenCV INTER_LINEAR 8u fixed point).
+//   k_fast_cells  : per (frame, 35-px cell): LDS-staged tile -> FAST-9/16 score -> 3x3 NMS inside the cell
+//                   -> iniTh/minTh selection -> ordered compaction (wave ballot + popcount prefix).
+//   k_quadtree    : per (frame, level): DistributeOctTree as flat list + segment partition (ballot ranks),
+//                   libstdc++-exact sort for the tie order.
+//   k_assemble    : per frame: output slot of every keypoint (mono side ascending / lapping side descending).
+//   k_describe    : per keypoint (one wave): 43x43 patch in LDS -> IC angle -> 7x7 fixed-point blur of the
+//                   37x37 neighbourhood -> 256 steered tests, one wave ballot = 8 descriptor bytes.
+//
+// Float code relies on -ffp-contract=off (no FMA fusion) and IEEE division; see DESIGN.md "bit-exactness".
+#include <hip/hip_runtime.h>
+
+#include "glibc_sincosf.h"
+#include "gnu_sort.h"
+#include "orbx_internal.h"
+
+namespace orbx {
+
+__constant__ int8_t c_pattern[1024] = {
+#include "orb_pattern.inc"
+};
+
+// ------------------------------------------------------------------------------------------------
+// K1: cv::resize INTER_LINEAR, CV_8UC1 (src/ORBextractor.cc:1183).  4 output pixels per thread.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src, long long src_frame_stride,
+                                                int src_pitch, uint8_t* __restrict__ dst, long long dst_frame_stride,
+                                                int dst_pitch, int dw, int dh, const XTab* __restrict__ xt,
+                                                const XTab* __restrict__ yt) {
+  const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
+  const int dy = blockIdx.y * 4 + threadIdx.y;
+  if (dy >= dh || x4 >= dw) return;
+  const XTab ty = yt[dy];
+  const uint8_t* S0 = src + (long long)blockIdx.z * src_frame_stride + (long long)ty.s0 * src_pitch;
+  const uint8_t* S1 = src + (long long)blockIdx.z * src_frame_stride + (long long)ty.s1 * src_pitch;
+  const int b0 = ty.a0, b1 = ty.a1;
+  uint32_t packed = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int dx = min(x4 + i, dw - 1);
+    const XTab tx = xt[dx];
+    const int h0 = S0[tx.s0] * tx.a0 + S0[tx.s1] * tx.a1;
+    const int h1 = S1[tx.s0] * tx.a0 + S1[tx.s1] * tx.a1;
+    const int v = ((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xff;
+    packed |= (uint32_t)v << (8 * i);
+  }
+  *(uint32_t*)(dst + (long long)blockIdx.z * dst_frame_stride + (long long)dy * dst_pitch + x4) = packed;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: FAST score + per-cell NMS + threshold selection + ordered compaction.
+// ------------------------------------------------------------------------------------------------
+// S(p) = max over the 16 nine-pixel arcs of min(v - p_k), and the same for (p_k - v), minus 1:
+// the value OpenCV's cornerScore<16> returns for any threshold at which p is a corner.
+__device__ __forceinline__ int fast_score16(int v, const int (&p)[16]) {
+  int d[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) d[k] = v - p[k];
+  int mn2[16], mx2[16], mn4[16], mx4[16], mn8[16], mx8[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+  for (int k = 0; k < 16; k++) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
+#pragma unroll
+  for (int k = 0; k < 16; k++) { mn8[k] = min(mn4[k], mn4[(k + 4) & 15]); mx8[k] = max(mx4[k], mx4[(k + 4) & 15]); }
+  int A = -256, B = 256;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    A = max(A, min(mn8[k], d[(k + 8) & 15]));
+    B = min(B, max(mx8[k], d[(k + 8) & 15]));
+  }
+  return max(A, -B) - 1;
+}
+
+__global__ __launch_bounds__(256) void k_fast_cells(const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
+                                                    const uint8_t* __restrict__ imgs, long long img_row_stride,
+                                                    long long img_frame_stride, const uint8_t* __restrict__ pyr,
+                                                    long long pyr_frame_bytes, uint32_t* __restrict__ cand,
+                                                    int32_t* __restrict__ cell_cnt, int ini_th, int min_th, int tile_pitch,
+                                                    int tile_rows) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  uint8_t* tile = smem;                                  // [tile_rows][tile_pitch] raw pixels
+  uint8_t* sc = tile + tile_rows * tile_pitch;           // [tile_rows][tile_pitch] scores, 1-px zero frame
+  uint8_t* sv = sc + tile_rows * tile_pitch;             // survivors (score or 0), same layout
+  __shared__ int wave_tot[4];
+
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int frame = blockIdx.y;
+  const CellGeom cg = cells[blockIdx.x];
+  const DeviceLevel& lv = g->lv[cg.level];
+  const uint8_t* img;
+  long long pitch;
+  if (cg.level == 0) { img = imgs + (long long)frame * img_frame_stride; pitch = img_row_stride; }
+  else { img = pyr + (long long)frame * pyr_frame_bytes + lv.plane_off; pitch = lv.pitch; }
+  const int cw = cg.cw, ch = cg.ch, dw = cw - 6, dh = ch - 6;
+  const uint8_t* src = img + (long long)cg.y0 * pitch + cg.x0;
+  // stage the (cw x ch) sub-image; clear the score frame
+  for (int i = t; i < cw * ch; i += 256) {
+    const int r = i / cw, c = i - r * cw;
+    tile[r * tile_pitch + c] = src[(long long)r * pitch + c];
+  }
+  for (int i = t; i < (dh + 2) * tile_pitch; i += 256) sc[i] = 0;
+  __syncthreads();
+  const int npx = dw * dh;
+  const float inv_dw = 1.0f / (float)dw;
+  // score map over the detection domain (local x in [3,cw-4], y in [3,ch-4])
+  for (int i = t; i < npx; i += 256) {
+    int y = (int)((float)i * inv_dw);
+    if (y * dw > i) y--;
+    if ((y + 1) * dw <= i) y++;
+    const int x = i - y * dw;
+    const uint8_t* c0 = tile + (y + 3) * tile_pitch + (x + 3);
+    const int v = c0[0];
+    int p[16];
+    p[0] = c0[3 * tile_pitch];       p[1] = c0[3 * tile_pitch + 1];   p[2] = c0[2 * tile_pitch + 2];
+    p[3] = c0[tile_pitch + 3];       p[4] = c0[3];                    p[5] = c0[-tile_pitch + 3];
+    p[6] = c0[-2 * tile_pitch + 2];  p[7] = c0[-3 * tile_pitch + 1];  p[8] = c0[-3 * tile_pitch];
+    p[9] = c0[-3 * tile_pitch - 1];  p[10] = c0[-2 * tile_pitch - 2]; p[11] = c0[-tile_pitch - 3];
+    p[12] = c0[-3];                  p[13] = c0[tile_pitch - 3];      p[14] = c0[2 * tile_pitch - 2];
+    p[15] = c0[3 * tile_pitch - 1];
+    int s = fast_score16(v, p);
+    if (s < min_th) s = 0;
+    sc[(y + 1) * tile_pitch + (x + 1)] = (uint8_t)s;
+  }
+  __syncthreads();
+  // 3x3 strict NMS inside the cell (neighbours outside the detection domain are 0)
+  int any_ini = 0;
+  for (int i = t; i < npx; i += 256) {
+    int y = (int)((float)i * inv_dw);
+    if (y * dw > i) y--;
+    if ((y + 1) * dw <= i) y++;
+    const int x = i - y * dw;
+    const uint8_t* q = sc + (y + 1) * tile_pitch + (x + 1);
+    const int s = q[0];
+    int keep = 0;
+    if (s > 0) {
+      keep = s > q[-1] && s > q[1] && s > q[-tile_pitch - 1] && s > q[-tile_pitch] && s > q[-tile_pitch + 1] &&
+             s > q[tile_pitch - 1] && s > q[tile_pitch] && s > q[tile_pitch + 1];
+    }
+    sv[i] = keep ? (uint8_t)s : 0;
+    any_ini |= keep && s >= ini_th;
+  }
+  const int use_ini = __syncthreads_or(any_ini);
+  const int T = use_ini ? ini_th : min_th;
+  // ordered compaction: pixel order == thread order inside every 256-chunk
+  uint32_t* slot = cand + (long long)frame * g->cand_total + cg.slot_off;
+  int base = 0;
+  for (int c0 = 0; c0 < npx; c0 += 256) {
+    const int i = c0 + t;
+    const int s = i < npx ? sv[i] : 0;
+    const int keep = s >= T && s > 0;
+    const unsigned long long b = __ballot(keep);
+    const int rank = __popcll(b & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wv] = __popcll(b);
+    __syncthreads();
+    int pre = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int wt = wave_tot[k]; pre += k < wv ? wt : 0; tot += wt; }
+    if (keep) {
+      int y = (int)((float)i * inv_dw);
+      if (y * dw > i) y--;
+      if ((y + 1) * dw <= i) y++;
+      const int x = i - y * dw;
+      slot[base + pre + rank] = pack_pt(x + 3 + cg.relx, y + 3 + cg.rely, s);
+    }
+    base += tot;
+    __syncthreads();
+  }
+  if (t == 0) cell_cnt[(long long)frame * g->ncells_total + blockIdx.x] = base;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: quadtree distribution (src/ORBextractor.cc:555-779), see tests/support/quadtree_model.cpp for the
+// sequential statement of the same array formulation.
+// ------------------------------------------------------------------------------------------------
+struct QNode { int16_t x0, y0, x1, y1; int32_t start, count; };
+
+constexpr unsigned long long kM21 = (1ull << 21) - 1ull;
+
+__device__ __forceinline__ unsigned long long block_excl_scan(unsigned long long* a, int n, unsigned long long* wt) {
+  const int T = blockDim.x, t = threadIdx.x, lane = t & 63, w = t >> 6, NW = T >> 6;
+  const int ipt = (n + T - 1) / T;
+  const int b = min(t * ipt, n), e = min(b + ipt, n);
+  unsigned long long local = 0;
+  for (int i = b; i < e; i++) local += a[i];
+  unsigned long long inc = local;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned long long v = __shfl_up(inc, o);
+    if (lane >= o) inc += v;
+  }
+  if (lane == 63) wt[w] = inc;
+  __syncthreads();
+  unsigned long long off = 0, total = 0;
+  for (int k = 0; k < NW; k++) { const unsigned long long v = wt[k]; off += k < w ? v : 0; total += v; }
+  unsigned long long run = off + inc - local;
+  for (int i = b; i < e; i++) { const unsigned long long v = a[i]; a[i] = run; run += v; }
+  __syncthreads();
+  return total;
+}
+
+// One wave: child counts of `nd` (DivideNode, src/ORBextractor.cc:480-536) and optional stable scatter cur->nxt.
+__device__ __forceinline__ int4 wave_split(const QNode nd, const uint32_t* cur, uint32_t* nxt, bool scatter) {
+  const int lane = threadIdx.x & 63;
+  const int sx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1);  // ceil(float(w)/2)
+  const int sy = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
+  int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+  for (int o = 0; o < nd.count; o += 64) {
+    const int e = o + lane;
+    int chd = 4;
+    if (e < nd.count) {
+      const uint32_t p = cur[nd.start + e];
+      chd = (pt_x(p) < sx ? 0 : 1) + (pt_y(p) < sy ? 0 : 2);
+    }
+    c0 += __popcll(__ballot(chd == 0));
+    c1 += __popcll(__ballot(chd == 1));
+    c2 += __popcll(__ballot(chd == 2));
+    c3 += __popcll(__ballot(chd == 3));
+  }
+  if (scatter) {
+    int r0 = nd.start, r1 = r0 + c0, r2 = r1 + c1, r3 = r2 + c2;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int o = 0; o < nd.count; o += 64) {
+      const int e = o + lane;
+      int chd = 4;
+      uint32_t p = 0;
+      if (e < nd.count) {
+        p = cur[nd.start + e];
+        chd = (pt_x(p) < sx ? 0 : 1) + (pt_y(p) < sy ? 0 : 2);
+      }
+      const unsigned long long b0 = __ballot(chd == 0), b1 = __ballot(chd == 1), b2 = __ballot(chd == 2),
+                               b3 = __ballot(chd == 3);
+      if (chd < 4) {
+        const unsigned long long mine = chd == 0 ? b0 : chd == 1 ? b1 : chd == 2 ? b2 : b3;
+        const int basep = chd == 0 ? r0 : chd == 1 ? r1 : chd == 2 ? r2 : r3;
+        nxt[basep + __popcll(mine & lt)] = p;
+      }
+      r0 += __popcll(b0); r1 += __popcll(b1); r2 += __popcll(b2); r3 += __popcll(b3);
+    }
+  }
+  return make_int4(c0, c1, c2, c3);
+}
+
+__device__ __forceinline__ QNode child_node(const QNode nd, int c, int start, int count) {
+  const int sx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1);
+  const int sy = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
+  QNode r;
+  r.x0 = (c & 1) ? sx : nd.x0; r.x1 = (c & 1) ? nd.x1 : sx;
+  r.y0 = (c & 2) ? sy : nd.y0; r.y1 = (c & 2) ? nd.y1 : sy;
+  r.start = start; r.count = count;
+  return r;
+}
+
+__device__ __forceinline__ unsigned long long expand_elem(const QNode n, int pos) {
+  const uint32_t key = ((uint32_t)n.count << 13) | (uint32_t)(n.x0 & 0x1fff);
+  return ((unsigned long long)key << 32) | (uint32_t)pos;
+}
+
+__global__ __launch_bounds__(256) void k_quadtree(const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
+                                                  const uint32_t* __restrict__ cand, const int32_t* __restrict__ cell_cnt,
+                                                  uint32_t* __restrict__ pts, uint32_t* __restrict__ lvl_kp,
+                                                  int32_t* __restrict__ lvl_n, int node_cap, int scan_cap) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  QNode* LA = (QNode*)smem;
+  QNode* LB = LA + node_cap;
+  unsigned long long* EA = (unsigned long long*)(LB + node_cap);
+  unsigned long long* EB = EA + node_cap;
+  unsigned long long* scan = EB + node_cap;
+  int4* kids = (int4*)(scan + scan_cap);
+  int* flag = (int*)(kids + node_cap);
+  __shared__ unsigned long long wt[8];
+  __shared__ int sh_cnt[kMaxRoots];
+  __shared__ int sh_jstar;
+
+  const int T = blockDim.x, t = threadIdx.x, lane = t & 63, w = t >> 6, NW = T >> 6;
+  const int level = blockIdx.x, frame = blockIdx.y;
+  const DeviceLevel& lv = g->lv[level];
+  const int N = lv.quota;
+  uint32_t* cur = pts + ((long long)frame * 2 + 0) * g->cand_total + lv.cand_off;
+  uint32_t* nxt = pts + ((long long)frame * 2 + 1) * g->cand_total + lv.cand_off;
+  const int32_t* ccnt = cell_cnt + (long long)frame * g->ncells_total + lv.cell_begin;
+  const uint32_t* fcand = cand + (long long)frame * g->cand_total;
+
+  // ---- gather the per-cell lists in cell order (vToDistributeKeys, src/ORBextractor.cc:863-868)
+  for (int c = t; c < lv.ncells; c += T) scan[c] = (unsigned long long)ccnt[c];
+  __syncthreads();
+  const int n = (int)block_excl_scan(scan, lv.ncells, wt);
+  for (int c = w; c < lv.ncells; c += NW) {
+    const int cnt = ccnt[c], off = (int)scan[c];
+    const uint32_t* s = fcand + cells[lv.cell_begin + c].slot_off;
+    for (int e = lane; e < cnt; e += 64) cur[off + e] = s[e];
+  }
+  __syncthreads();
+  int nL = 0, nE = 0;
+  if (n == 0) {
+    if (t == 0) lvl_n[frame * g->nlevels + level] = 0;
+    return;
+  }
+  // ---- root nodes (src/ORBextractor.cc:559-601)
+  const int H = lv.h - 2 * kBorder;
+  if (lv.nroots == 1) {
+    if (t == 0) { QNode r; r.x0 = lv.root_x0[0]; r.y0 = 0; r.x1 = lv.root_x1[0]; r.y1 = H; r.start = 0; r.count = n; LA[0] = r; }
+    nL = 1;
+  } else {
+    if (t < kMaxRoots) sh_cnt[t] = 0;
+    __syncthreads();
+    for (int i = t; i < n; i += T) {
+      const int b = (int)__fdiv_rn((float)pt_x(cur[i]), lv.hX);
+      atomicAdd(&sh_cnt[b], 1);
+    }
+    __syncthreads();
+    if (w == 0) {  // stable bucket scatter by one wave
+      int run[kMaxRoots];
+      int acc = 0;
+      for (int b = 0; b < lv.nroots; b++) { run[b] = acc; acc += sh_cnt[b]; }
+      const unsigned long long lt = (1ull << lane) - 1ull;
+      for (int o = 0; o < n; o += 64) {
+        const int e = o + lane;
+        int bk = -1;
+        uint32_t p = 0;
+        if (e < n) { p = cur[e]; bk = (int)__fdiv_rn((float)pt_x(p), lv.hX); }
+        for (int b = 0; b < lv.nroots; b++) {
+          const unsigned long long m = __ballot(bk == b);
+          if (bk == b) nxt[run[b] + __popcll(m & lt)] = p;
+          run[b] += __popcll(m);
+        }
+      }
+      if (lane == 0) {
+        int k = 0, off = 0;
+        for (int b = 0; b < lv.nroots; b++) {
+          if (sh_cnt[b] > 0) {
+            QNode r; r.x0 = lv.root_x0[b]; r.y0 = 0; r.x1 = lv.root_x1[b]; r.y1 = H; r.start = off; r.count = sh_cnt[b];
+            LA[k++] = r;
+          }
+          off += sh_cnt[b];
+        }
+        sh_jstar = k;
+      }
+    }
+    __syncthreads();
+    nL = sh_jstar;
+    { uint32_t* tmp = cur; cur = nxt; nxt = tmp; }
+    __syncthreads();
+  }
+  __syncthreads();
+
+  bool finish = false, sorted_phase = false;
+  while (!finish) {
+    if (!sorted_phase) {
+      // ======== full pass: split every node holding more than one point (src/ORBextractor.cc:612-681)
+      const int prevSize = nL;
+      for (int i = w; i < nL; i += NW) {
+        const QNode nd = LA[i];
+        if (nd.count > 1) {
+          const int4 c = wave_split(nd, cur, nxt, true);
+          if (lane == 0) kids[i] = c;
+        } else if (lane == 0) {
+          nxt[nd.start] = cur[nd.start];
+        }
+      }
+      __syncthreads();
+      for (int i = t; i < nL; i += T) {
+        unsigned long long v;
+        if (LA[i].count > 1) {
+          const int4 c = kids[i];
+          const unsigned long long k = (c.x > 0) + (c.y > 0) + (c.z > 0) + (c.w > 0);
+          const unsigned long long q = (c.x > 1) + (c.y > 1) + (c.z > 1) + (c.w > 1);
+          v = k | (q << 21);
+        } else {
+          v = 1ull << 42;
+        }
+        scan[i] = v;
+      }
+      __syncthreads();
+      const unsigned long long tot = block_excl_scan(scan, nL, wt);
+      const int totalKids = (int)(tot & kM21), nToExpand = (int)((tot >> 21) & kM21), nNoMore = (int)(tot >> 42);
+      for (int i = t; i < nL; i += T) {
+        const unsigned long long pre = scan[i];
+        const int kpre = (int)(pre & kM21), qpre = (int)((pre >> 21) & kM21), spre = (int)(pre >> 42);
+        const QNode nd = LA[i];
+        if (nd.count > 1) {
+          const int4 c = kids[i];
+          const int cnt[4] = {c.x, c.y, c.z, c.w};
+          const int k = (c.x > 0) + (c.y > 0) + (c.z > 0) + (c.w > 0);
+          int ci = 0, qi = 0, st = nd.start;
+#pragma unroll
+          for (int ch = 0; ch < 4; ch++) {
+            if (cnt[ch] > 0) {
+              const int pos = totalKids - (kpre + k) + (k - 1 - ci);
+              const QNode cn = child_node(nd, ch, st, cnt[ch]);
+              LB[pos] = cn;
+              if (cnt[ch] > 1) { EB[qpre + qi] = expand_elem(cn, pos); qi++; }
+              ci++;
+            }
+            st += cnt[ch];
+          }
+        } else {
+          LB[totalKids + spre] = nd;
+        }
+      }
+      __syncthreads();
+      { QNode* tl = LA; LA = LB; LB = tl; }
+      { unsigned long long* te = EA; EA = EB; EB = te; }
+      { uint32_t* tp = cur; cur = nxt; nxt = tp; }
+      nL = totalKids + nNoMore;
+      nE = nToExpand;
+      if (nL >= N || nL == prevSize) finish = true;
+      else if (nL + 3 * nE > N) sorted_phase = true;
+    } else {
+      // ======== sorted expansion (src/ORBextractor.cc:692-753)
+      const int prevSize = nL;
+      const int m = nE;
+      if (t == 0) orbx_sort::gnu_sort(EA, m);
+      __syncthreads();
+      for (int j = w; j < m; j += NW) {
+        const int4 c = wave_split(LA[(uint32_t)EA[j]], cur, nxt, false);
+        if (lane == 0) kids[j] = c;
+      }
+      for (int i = t; i < nL; i += T) flag[i] = 0;
+      __syncthreads();
+      if (t == 0) {
+        int running = nL, js = 0;
+        for (int j = m - 1; j >= 0; j--) {
+          const int4 c = kids[j];
+          running += (c.x > 0) + (c.y > 0) + (c.z > 0) + (c.w > 0) - 1;
+          if (running >= N) { js = j; break; }
+        }
+        sh_jstar = js;
+      }
+      __syncthreads();
+      const int jstar = sh_jstar;
+      const int mp = m - jstar;  // processed nodes: sorted positions jstar..m-1 (largest first in time)
+      for (int j = jstar + t; j < m; j += T) flag[(uint32_t)EA[j]] = j + 1;
+      __syncthreads();
+      for (int i = w; i < nL; i += NW) {
+        const QNode nd = LA[i];
+        if (flag[i]) {
+          wave_split(nd, cur, nxt, true);
+        } else {
+          for (int e = lane; e < nd.count; e += 64) nxt[nd.start + e] = cur[nd.start + e];
+        }
+      }
+      for (int jj = t; jj < mp; jj += T) {
+        const int4 c = kids[jstar + jj];
+        const unsigned long long k = (c.x > 0) + (c.y > 0) + (c.z > 0) + (c.w > 0);
+        const unsigned long long q = (c.x > 1) + (c.y > 1) + (c.z > 1) + (c.w > 1);
+        scan[jj] = k | (q << 21);
+      }
+      __syncthreads();
+      const unsigned long long tot = block_excl_scan(scan, mp, wt);
+      const int front = (int)(tot & kM21), qtot = (int)((tot >> 21) & kM21);
+      for (int jj = t; jj < mp; jj += T) {
+        const int j = jstar + jj;
+        const unsigned long long pre = scan[jj];
+        const int basep = (int)(pre & kM21), qpre = (int)((pre >> 21) & kM21);
+        const QNode nd = LA[(uint32_t)EA[j]];
+        const int4 c = kids[j];
+        const int cnt[4] = {c.x, c.y, c.z, c.w};
+        const int k = (c.x > 0) + (c.y > 0) + (c.z > 0) + (c.w > 0);
+        const int q = (c.x > 1) + (c.y > 1) + (c.z > 1) + (c.w > 1);
+        const int eoff = qtot - (qpre + q);  // creation order runs j = m-1 down to jstar
+        int ci = 0, qi = 0, st = nd.start;
+#pragma unroll
+        for (int ch = 0; ch < 4; ch++) {
+          if (cnt[ch] > 0) {
+            const int pos = basep + (k - 1 - ci);
+            const QNode cn = child_node(nd, ch, st, cnt[ch]);
+            LB[pos] = cn;
+            if (cnt[ch] > 1) { EB[eoff + qi] = expand_elem(cn, pos); qi++; }
+            ci++;
+          }
+          st += cnt[ch];
+        }
+      }
+      __syncthreads();
+      for (int i = t; i < nL; i += T) scan[i] = flag[i] ? 0ull : 1ull;
+      __syncthreads();
+      const int keepTot = (int)block_excl_scan(scan, nL, wt);
+      for (int i = t; i < nL; i += T)
+        if (!flag[i]) LB[front + (int)scan[i]] = LA[i];
+      __syncthreads();
+      { QNode* tl = LA; LA = LB; LB = tl; }
+      { unsigned long long* te = EA; EA = EB; EB = te; }
+      { uint32_t* tp = cur; cur = nxt; nxt = tp; }
+      nL = front + keepTot;
+      nE = qtot;
+      if (nL >= N || nL == prevSize) finish = true;
+    }
+  }
+  // ---- best point of every node, first maximum wins (src/ORBextractor.cc:757-776)
+  uint32_t* out = lvl_kp + (long long)frame * g->kp_total + lv.kp_off;
+  const int nout = min(nL, lv.kp_cap);
+  for (int i = t; i < nout; i += T) {
+    const QNode nd = LA[i];
+    uint32_t best = cur[nd.start];
+    for (int e = 1; e < nd.count; e++) {
+      const uint32_t p = cur[nd.start + e];
+      if (pt_s(p) > pt_s(best)) best = p;
+    }
+    out[i] = pack_pt(pt_x(best) + kBorder, pt_y(best) + kBorder, pt_s(best));
+  }
+  if (t == 0) lvl_n[frame * g->nlevels + level] = nL <= lv.kp_cap ? nL : -nL;  // negative = capacity overflow
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3b: output slots (src/ORBextractor.cc:1122,1143-1164)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_assemble(const DeviceGeom* __restrict__ g, const uint32_t* __restrict__ lvl_kp,
+                                                  const int32_t* __restrict__ lvl_n, int32_t* __restrict__ outidx,
+                                                  int32_t* __restrict__ counts, int lap0, int lap1) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  unsigned long long* scan = (unsigned long long*)smem;
+  __shared__ unsigned long long wt[8];
+  __shared__ int loff[kMaxLevels + 1];
+  const int t = threadIdx.x, T = blockDim.x, frame = blockIdx.x;
+  if (t == 0) {
+    int acc = 0;
+    for (int l = 0; l < g->nlevels; l++) { loff[l] = acc; acc += max(lvl_n[frame * g->nlevels + l], 0); }
+    loff[g->nlevels] = acc;
+  }
+  __syncthreads();
+  const int total = min(loff[g->nlevels], g->out_cap);
+  const uint32_t* kp = lvl_kp + (long long)frame * g->kp_total;
+  for (int i = t; i < total; i += T) {
+    int l = 0;
+    while (i >= loff[l + 1]) l++;
+    const uint32_t p = kp[g->lv[l].kp_off + (i - loff[l])];
+    float x = (float)pt_x(p);
+    if (l != 0) x = __fmul_rn(x, g->lv[l].scale);
+    scan[i] = (x >= (float)lap0 && x <= (float)lap1) ? 1ull : 0ull;
+  }
+  __syncthreads();
+  const int nst = (int)block_excl_scan(scan, total, wt);
+  for (int i = t; i < total; i += T) {
+    int l = 0;
+    while (i >= loff[l + 1]) l++;
+    const uint32_t p = kp[g->lv[l].kp_off + (i - loff[l])];
+    float x = (float)pt_x(p);
+    if (l != 0) x = __fmul_rn(x, g->lv[l].scale);
+    const bool st = x >= (float)lap0 && x <= (float)lap1;
+    const int pre = (int)scan[i];
+    outidx[(long long)frame * g->out_cap + i] = st ? total - 1 - pre : i - pre;
+  }
+  if (t == 0) { counts[frame * 2] = total; counts[frame * 2 + 1] = total - nst; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: orientation + blurred patch + steered BRIEF, one wave per keypoint.
+// ------------------------------------------------------------------------------------------------
+struct DescConsts { int umax[16]; int gk[7]; };
+
+constexpr int kR = 21;            // 18 (max rotated tap reach) + 3 (blur radius)
+constexpr int kRaw = 2 * kR + 1;  // 43
+constexpr int kRawP = 44;
+constexpr int kBl = 37;           // blurred neighbourhood: taps reach +-18
+constexpr int kBlP = 40;
+constexpr int kTmpP = 38;
+
+__device__ __forceinline__ int reflect101(int p, int n) {
+  while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
+  return p;
+}
+
+// cv::fastAtan2, degrees; separate IEEE mul/add, correctly rounded division.
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+  const float scale = (float)(180.0 / 3.14159265358979323846);
+  const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale;
+  const float p5 = 0.1555786518463281f * scale, p7 = -0.04432655554792128f * scale;
+  const float ax = fabsf(x), ay = fabsf(y);
+  const float eps = (float)2.2204460492503131e-16;
+  float a, c, c2;
+  if (ax >= ay) {
+    c = __fdiv_rn(ay, __fadd_rn(ax, eps));
+    c2 = __fmul_rn(c, c);
+    a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+  } else {
+    c = __fdiv_rn(ax, __fadd_rn(ay, eps));
+    c2 = __fmul_rn(c, c);
+    a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+  }
+  if (x < 0) a = __fsub_rn(180.f, a);
+  if (y < 0) a = __fsub_rn(360.f, a);
+  return a;
+}
+
+__global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__ g, const uint8_t* __restrict__ imgs,
+                                                  long long img_row_stride, long long img_frame_stride,
+                                                  const uint8_t* __restrict__ pyr, long long pyr_frame_bytes,
+                                                  const uint32_t* __restrict__ lvl_kp, const int32_t* __restrict__ lvl_n,
+                                                  const int32_t* __restrict__ outidx, orbx_keypoint* __restrict__ out_kps,
+                                                  uint8_t* __restrict__ out_desc, DescConsts dc) {
+  __shared__ __align__(16) uint8_t s_raw[4][kRaw * kRawP];
+  __shared__ __align__(16) uint16_t s_tmp[4][kRaw * kTmpP];
+  __shared__ __align__(16) uint8_t s_blur[4][kBl * kBlP];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int frame = blockIdx.y;
+  const int gi = blockIdx.x * 4 + w;
+  int l = 0, acc = 0, total = 0;
+  for (int k = 0; k < g->nlevels; k++) {
+    const int nk = max(lvl_n[frame * g->nlevels + k], 0);
+    if (gi >= total + nk) { acc = total + nk; l = k + 1; }
+    total += nk;
+  }
+  total = min(total, g->out_cap);
+  if (gi >= total) return;  // wave-uniform; no block-level barrier below
+  const DeviceLevel& lv = g->lv[l];
+  const uint32_t p = lvl_kp[(long long)frame * g->kp_total + lv.kp_off + (gi - acc)];
+  const int kx = pt_x(p), ky = pt_y(p);
+  const uint8_t* img;
+  long long pitch;
+  if (l == 0) { img = imgs + (long long)frame * img_frame_stride; pitch = img_row_stride; }
+  else { img = pyr + (long long)frame * pyr_frame_bytes + lv.plane_off; pitch = lv.pitch; }
+  uint8_t* raw = s_raw[w];
+  uint16_t* tmp = s_tmp[w];
+  uint8_t* blur = s_blur[w];
+  // 43x43 neighbourhood, BORDER_REFLECT_101 at the level edges (only the blur margin can cross them)
+  if (lane < kRaw) {
+    const int sxc = reflect101(kx - kR + lane, lv.w);
+    for (int r = 0; r < kRaw; r++) {
+      const int syc = reflect101(ky - kR + r, lv.h);
+      raw[r * kRawP + lane] = img[(long long)syc * pitch + sxc];
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // intensity centroid on the un-blurred level (src/ORBextractor.cc:76-103)
+  int m10 = 0, m01 = 0;
+  if (lane < kPatchSize) {
+    const int v = lane - kHalfPatch;
+    const int um = dc.umax[v < 0 ? -v : v];
+    const uint8_t* row = raw + (kR + v) * kRawP + kR;
+    int rs = 0;
+    for (int u = -um; u <= um; u++) { const int I = row[u]; m10 += u * I; rs += I; }
+    m01 = v * rs;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+  const float angle = fast_atan2_deg((float)m01, (float)m10);
+  // separable 7x7 fixed-point Gaussian: rows 0..42 x cols 3..39 -> tmp, then 37x37 -> blur
+  for (int i = lane; i < kRaw * kBl; i += 64) {
+    const int r = i / kBl, c = i - r * kBl;
+    const uint8_t* s = raw + r * kRawP + c;
+    uint32_t a = 0;
+#pragma unroll
+    for (int k = 0; k < 7; k++) a += (uint32_t)dc.gk[k] * s[k];
+    tmp[r * kTmpP + c] = (uint16_t)a;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (int i = lane; i < kBl * kBl; i += 64) {
+    const int r = i / kBl, c = i - r * kBl;
+    const uint16_t* s = tmp + r * kTmpP + c;
+    uint32_t a = 0;
+#pragma unroll
+    for (int k = 0; k < 7; k++) a += (uint32_t)dc.gk[k] * s[k * kTmpP];
+    blur[r * kBlP + c] = (uint8_t)((a + 32768u) >> 16);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // steered BRIEF (src/ORBextractor.cc:107-146)
+  const float factorPI = (float)(3.14159265358979323846 / 180.f);
+  const float ang = __fmul_rn(angle, factorPI);
+  const float a = orbx_glibc::cosf_exact(ang), b = orbx_glibc::sinf_exact(ang);
+  const int slot = outidx[(long long)frame * g->out_cap + gi];
+  uint8_t* dsc = out_desc + ((long long)frame * g->out_cap + slot) * 32;
+  const uint8_t* ctr = blur + 18 * kBlP + 18;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int tst = q * 64 + lane;
+    const float x0 = (float)c_pattern[tst * 4 + 0], y0 = (float)c_pattern[tst * 4 + 1];
+    const float x1 = (float)c_pattern[tst * 4 + 2], y1 = (float)c_pattern[tst * 4 + 3];
+    const int ry0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
+    const int rx0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+    const int ry1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
+    const int rx1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+    const int t0 = ctr[ry0 * kBlP + rx0], t1 = ctr[ry1 * kBlP + rx1];
+    const unsigned long long bits = __ballot(t0 < t1);
+    if (lane == 0) *(unsigned long long*)(dsc + q * 8) = bits;
+  }
+  if (lane == 0) {
+    orbx_keypoint kp;
+    float fx = (float)kx, fy = (float)ky;
+    if (l != 0) { fx = __fmul_rn(fx, lv.scale); fy = __fmul_rn(fy, lv.scale); }
+    kp.x = fx; kp.y = fy; kp.size = (float)lv.scaled_patch; kp.angle = angle; kp.response = (float)pt_s(p);
+    kp.octave = l; kp.class_id = -1;
+    out_kps[(long long)frame * g->out_cap + slot] = kp;
+  }
+}
+
+}  // namespace orbx

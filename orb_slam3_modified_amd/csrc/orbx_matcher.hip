@@ -1,0 +1,526 @@
+// orbx matcher + bag-of-words: Hamming nearest-neighbour kernels (wave per query, 64-bit popcount) and the
+// DBoW2 vocabulary descent / L1 scoring, behind the C ABI of include/orbx.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <new>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "orbx_internal.h"
+
+namespace orbx {
+
+// ---------------------------------------------------------------------------------------------------
+// Hamming kernels.  A descriptor is 32 bytes = 4 x u64; distance = sum popcount(a ^ b)
+// (ORBmatcher::DescriptorDistance, src/ORBmatcher.cc:2058-2074 — the SWAR bit hack there IS popcount).
+// ---------------------------------------------------------------------------------------------------
+struct Desc { unsigned long long w[4]; };
+
+__device__ __forceinline__ Desc load_desc(const uint8_t* p) {
+  const uint4* q = (const uint4*)p;  // 32-byte rows of a contiguous [n][32] array are 16-byte aligned
+  const uint4 a = q[0], b = q[1];
+  Desc d;
+  d.w[0] = (unsigned long long)a.x | ((unsigned long long)a.y << 32);
+  d.w[1] = (unsigned long long)a.z | ((unsigned long long)a.w << 32);
+  d.w[2] = (unsigned long long)b.x | ((unsigned long long)b.y << 32);
+  d.w[3] = (unsigned long long)b.z | ((unsigned long long)b.w << 32);
+  return d;
+}
+__device__ __forceinline__ int hamming(const Desc& a, const Desc& b) {
+  return __popcll(a.w[0] ^ b.w[0]) + __popcll(a.w[1] ^ b.w[1]) + __popcll(a.w[2] ^ b.w[2]) + __popcll(a.w[3] ^ b.w[3]);
+}
+
+constexpr unsigned long long kNoKey = ~0ull;
+
+// keep the two smallest keys
+__device__ __forceinline__ void top2_push(unsigned long long& k1, unsigned long long& k2, unsigned long long k) {
+  if (k < k1) { k2 = k1; k1 = k; }
+  else if (k < k2) k2 = k;
+}
+__device__ __forceinline__ void top2_wave_reduce(unsigned long long& k1, unsigned long long& k2) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long p1 = __shfl_xor(k1, o), p2 = __shfl_xor(k2, o);
+    const unsigned long long lo = k1 < p1 ? k1 : p1, hi = k1 < p1 ? p1 : k1;
+    const unsigned long long s2 = k2 < p2 ? k2 : p2;
+    k1 = lo;
+    k2 = hi < s2 ? hi : s2;
+  }
+}
+
+// Guided NN over CSR candidate lists: one wave per query, lanes stride the candidates.
+// key = dist << 32 | position   (first minimum wins, strict `<`)  or
+//       dist << 32 | ~position  (last minimum wins, SearchForTriangulation's `<=`).
+__global__ __launch_bounds__(256) void k_nn_csr(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ tr,
+                                                const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ cand,
+                                                int last_wins, int32_t* __restrict__ best_idx, int32_t* __restrict__ best_dist,
+                                                int32_t* __restrict__ second_idx, int32_t* __restrict__ second_dist,
+                                                int32_t* __restrict__ dist_out) {
+  const int lane = threadIdx.x & 63;
+  const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (qi >= nq) return;
+  const Desc dq = load_desc(q + (size_t)qi * 32);
+  const int b = row_ptr[qi], e = row_ptr[qi + 1];
+  unsigned long long k1 = kNoKey, k2 = kNoKey;
+  for (int c = b + lane; c < e; c += 64) {
+    const int ti = cand[c];
+    const int d = hamming(dq, load_desc(tr + (size_t)ti * 32));
+    if (dist_out) dist_out[c] = d;
+    const uint32_t pos = (uint32_t)(c - b);
+    top2_push(k1, k2, ((unsigned long long)d << 32) | (last_wins ? (0xffffffffu - pos) : pos));
+  }
+  top2_wave_reduce(k1, k2);
+  if (lane == 0) {
+    auto decode = [&](unsigned long long k, int32_t* oi, int32_t* od) {
+      if (k == kNoKey) { if (oi) oi[qi] = -1; if (od) od[qi] = 256; return; }
+      uint32_t pos = (uint32_t)k;
+      if (last_wins) pos = 0xffffffffu - pos;
+      if (oi) oi[qi] = cand[b + (int)pos];
+      if (od) od[qi] = (int32_t)(k >> 32);
+    };
+    decode(k1, best_idx, best_dist);
+    decode(k2, second_idx, second_dist);
+  }
+}
+
+// All-pairs 2-NN (cv::BFMatcher(NORM_HAMMING).knnMatch(k=2), src/Frame.cc:1144): wave per query; the train
+// set is streamed through LDS in tiles shared by the block's 4 queries.
+__global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ tr, int nt,
+                                              int32_t* __restrict__ idx, int32_t* __restrict__ dist) {
+  __shared__ uint4 tile[256 * 2];  // 256 train descriptors
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int qi = blockIdx.x * 4 + w;
+  Desc dq;
+  if (qi < nq) dq = load_desc(q + (size_t)qi * 32);
+  else dq.w[0] = dq.w[1] = dq.w[2] = dq.w[3] = 0;
+  unsigned long long k1 = kNoKey, k2 = kNoKey;
+  for (int t0 = 0; t0 < nt; t0 += 256) {
+    const int nload = min(256, nt - t0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nload * 2; i += 256) tile[i] = ((const uint4*)(tr + (size_t)t0 * 32))[i];
+    __syncthreads();
+    for (int c = lane; c < nload; c += 64) {
+      const uint4 a = tile[c * 2], b = tile[c * 2 + 1];
+      Desc dt;
+      dt.w[0] = (unsigned long long)a.x | ((unsigned long long)a.y << 32);
+      dt.w[1] = (unsigned long long)a.z | ((unsigned long long)a.w << 32);
+      dt.w[2] = (unsigned long long)b.x | ((unsigned long long)b.y << 32);
+      dt.w[3] = (unsigned long long)b.z | ((unsigned long long)b.w << 32);
+      top2_push(k1, k2, ((unsigned long long)hamming(dq, dt) << 32) | (uint32_t)(t0 + c));
+    }
+  }
+  top2_wave_reduce(k1, k2);
+  if (lane == 0 && qi < nq) {
+    idx[qi * 2] = k1 == kNoKey ? -1 : (int32_t)(uint32_t)k1;
+    dist[qi * 2] = k1 == kNoKey ? 256 : (int32_t)(k1 >> 32);
+    idx[qi * 2 + 1] = k2 == kNoKey ? -1 : (int32_t)(uint32_t)k2;
+    dist[qi * 2 + 1] = k2 == kNoKey ? 256 : (int32_t)(k2 >> 32);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Vocabulary tree (DBoW2 TemplatedVocabulary<cv::Mat, FORB>)
+// ---------------------------------------------------------------------------------------------------
+struct DevNode { int32_t child_begin, nchild, word_id, pad; double weight; };
+
+// wave per feature: lanes < nchild evaluate one child each; first minimum wins (TemplatedVocabulary.h:1238-1249)
+__global__ __launch_bounds__(256) void k_bow_descend(const DevNode* __restrict__ nodes, const uint8_t* __restrict__ slot_desc,
+                                                     const int32_t* __restrict__ slot_node, const uint8_t* __restrict__ desc,
+                                                     int n, int L, int levelsup, uint32_t* __restrict__ word,
+                                                     double* __restrict__ weight, uint32_t* __restrict__ node_out) {
+  const int lane = threadIdx.x & 63;
+  const int fi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (fi >= n) return;
+  const Desc df = load_desc(desc + (size_t)fi * 32);
+  const int nid_level = L - levelsup;
+  uint32_t nid = 0;
+  int final_id = 0, level = 0;
+  DevNode nd = nodes[0];
+  while (nd.nchild > 0) {
+    ++level;
+    unsigned long long key = kNoKey;
+    for (int c = lane; c < nd.nchild; c += 64) {
+      const int d = hamming(df, load_desc(slot_desc + (size_t)(nd.child_begin + c) * 32));
+      const unsigned long long k = ((unsigned long long)d << 32) | (uint32_t)c;
+      key = k < key ? k : key;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long p = __shfl_xor(key, o); key = p < key ? p : key; }
+    final_id = slot_node[nd.child_begin + (int)(uint32_t)key];
+    if (level == nid_level) nid = (uint32_t)final_id;
+    nd = nodes[final_id];
+  }
+  if (lane == 0) {
+    word[fi] = (uint32_t)nd.word_id;
+    weight[fi] = nd.weight;
+    node_out[fi] = nid;
+  }
+}
+
+// L1Scoring::score (ScoringObject.cpp:23-68): thread per database vector, sequential merge in ascending id
+// order so the double accumulation order equals std::map iteration.
+__global__ __launch_bounds__(256) void k_bow_score_l1(const uint32_t* __restrict__ qid, const double* __restrict__ qv, int nq,
+                                                      const int32_t* __restrict__ db_ptr, const uint32_t* __restrict__ did,
+                                                      const double* __restrict__ dv, int ndb, double* __restrict__ scores) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ndb) return;
+  int a = 0, b = db_ptr[i];
+  const int be = db_ptr[i + 1];
+  double score = 0;
+  while (a < nq && b < be) {
+    const uint32_t ia = qid[a], ib = did[b];
+    if (ia == ib) {
+      const double vi = qv[a], wi = dv[b];
+      const double t = __dsub_rn(__dsub_rn(fabs(__dsub_rn(vi, wi)), fabs(vi)), fabs(wi));
+      score = __dadd_rn(score, t);
+      ++a; ++b;
+    } else if (ia < ib) ++a;
+    else ++b;
+  }
+  scores[i] = -score / 2.0;
+}
+
+}  // namespace orbx
+
+struct orbx_voc {
+  orbx_ctx* ctx = nullptr;
+  int k = 0, L = 0, scoring = 0, weighting = 0;
+  std::vector<int32_t> parent;            // per node (0 = root)
+  std::vector<std::vector<int32_t>> children;
+  std::vector<uint8_t> is_leaf;
+  std::vector<uint8_t> desc;              // [nnodes][32]
+  std::vector<double> weight;
+  std::vector<int32_t> word_id;           // per node, -1 for inner nodes
+  int nwords = 0;
+  // device copy
+  orbx::DevNode* d_nodes = nullptr;
+  uint8_t* d_slot_desc = nullptr;
+  int32_t* d_slot_node = nullptr;
+};
+
+using namespace orbx;
+
+namespace {
+
+int upload_voc(orbx_voc* v) {
+  orbx_ctx* ctx = v->ctx;
+  const int nn = (int)v->parent.size();
+  std::vector<DevNode> nodes(nn);
+  std::vector<uint8_t> sdesc;
+  std::vector<int32_t> snode;
+  for (int i = 0; i < nn; i++) {
+    DevNode& d = nodes[i];
+    d.child_begin = (int32_t)snode.size();
+    d.nchild = (int32_t)v->children[i].size();
+    d.word_id = v->word_id[i];
+    d.pad = 0;
+    d.weight = v->weight[i];
+    for (int32_t c : v->children[i]) {
+      snode.push_back(c);
+      sdesc.insert(sdesc.end(), v->desc.begin() + (size_t)c * 32, v->desc.begin() + (size_t)c * 32 + 32);
+    }
+  }
+  ORBX_HIP(ctx, hipSetDevice(ctx->device));
+  ORBX_HIP(ctx, hipMalloc((void**)&v->d_nodes, sizeof(DevNode) * nn));
+  ORBX_HIP(ctx, hipMemcpy(v->d_nodes, nodes.data(), sizeof(DevNode) * nn, hipMemcpyHostToDevice));
+  ORBX_HIP(ctx, hipMalloc((void**)&v->d_slot_desc, std::max<size_t>(sdesc.size(), 32)));
+  ORBX_HIP(ctx, hipMalloc((void**)&v->d_slot_node, std::max<size_t>(snode.size(), 1) * sizeof(int32_t)));
+  if (!snode.empty()) {
+    ORBX_HIP(ctx, hipMemcpy(v->d_slot_desc, sdesc.data(), sdesc.size(), hipMemcpyHostToDevice));
+    ORBX_HIP(ctx, hipMemcpy(v->d_slot_node, snode.data(), snode.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
+  return ORBX_OK;
+}
+
+int finish_voc(orbx_voc* v) {
+  const int nn = (int)v->parent.size();
+  v->children.assign(nn, {});
+  v->word_id.assign(nn, -1);
+  v->nwords = 0;
+  for (int i = 1; i < nn; i++) {
+    const int p = v->parent[i];
+    if (p < 0 || p >= nn) return set_err(v->ctx, ORBX_E_FORMAT, "vocabulary: parent id out of range");
+    v->children[p].push_back(i);
+    if (v->is_leaf[i]) v->word_id[i] = v->nwords++;
+  }
+  for (int i = 0; i < nn; i++)
+    if (!v->is_leaf[i] && v->children[i].empty() && nn > 1 && i != 0)
+      return set_err(v->ctx, ORBX_E_FORMAT, "vocabulary: inner node without children");
+  return upload_voc(v);
+}
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t n) { return hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T)); }
+};
+
+}  // namespace
+
+extern "C" {
+
+int orbx_hamming(const uint8_t a[32], const uint8_t b[32]) {
+  int d = 0;
+  for (int i = 0; i < 4; i++) {
+    uint64_t x, y;
+    std::memcpy(&x, a + 8 * i, 8);
+    std::memcpy(&y, b + 8 * i, 8);
+    d += __builtin_popcountll(x ^ y);
+  }
+  return d;
+}
+
+int orbx_nn_csr_device(orbx_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, const int32_t* d_row_ptr,
+                       const int32_t* d_cand, int last_wins, int32_t* d_best_idx, int32_t* d_best_dist,
+                       int32_t* d_second_idx, int32_t* d_second_dist, int32_t* d_dist_out, void* stream) {
+  if (!ctx || nq < 0 || nt < 0) return ORBX_E_INVALID;
+  if (nq == 0) return ORBX_OK;
+  ORBX_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  hipLaunchKernelGGL(k_nn_csr, dim3((nq + 3) / 4), dim3(256), 0, st, d_q, nq, d_t, d_row_ptr, d_cand, last_wins, d_best_idx,
+                     d_best_dist, d_second_idx, d_second_dist, d_dist_out);
+  ORBX_HIP(ctx, hipGetLastError());
+  return ORBX_OK;
+}
+
+int orbx_nn_csr(orbx_ctx* ctx, const uint8_t* q_desc, int nq, const uint8_t* t_desc, int nt, const int32_t* row_ptr,
+                const int32_t* cand, int last_wins, int32_t* best_idx, int32_t* best_dist, int32_t* second_idx,
+                int32_t* second_dist, int32_t* dist_out) {
+  if (!ctx || nq < 0 || nt < 0 || (nq > 0 && (!q_desc || !row_ptr))) return ORBX_E_INVALID;
+  if (nq == 0) return ORBX_OK;
+  const int nnz = row_ptr[nq];
+  for (int i = 0; i < nnz; i++)
+    if (cand[i] < 0 || cand[i] >= nt) return set_err(ctx, ORBX_E_INVALID, "candidate index out of range");
+  ORBX_HIP(ctx, hipSetDevice(ctx->device));
+  DevBuf<uint8_t> dq, dt;
+  DevBuf<int32_t> drp, dc, dbi, dbd, dsi, dsd, ddo;
+  ORBX_HIP(ctx, dq.alloc((size_t)nq * 32)); ORBX_HIP(ctx, dt.alloc((size_t)nt * 32));
+  ORBX_HIP(ctx, drp.alloc(nq + 1)); ORBX_HIP(ctx, dc.alloc(nnz));
+  ORBX_HIP(ctx, dbi.alloc(nq)); ORBX_HIP(ctx, dbd.alloc(nq)); ORBX_HIP(ctx, dsi.alloc(nq)); ORBX_HIP(ctx, dsd.alloc(nq));
+  ORBX_HIP(ctx, ddo.alloc(nnz));
+  ORBX_HIP(ctx, hipMemcpy(dq.p, q_desc, (size_t)nq * 32, hipMemcpyHostToDevice));
+  if (nt) ORBX_HIP(ctx, hipMemcpy(dt.p, t_desc, (size_t)nt * 32, hipMemcpyHostToDevice));
+  ORBX_HIP(ctx, hipMemcpy(drp.p, row_ptr, sizeof(int32_t) * (nq + 1), hipMemcpyHostToDevice));
+  if (nnz) ORBX_HIP(ctx, hipMemcpy(dc.p, cand, sizeof(int32_t) * nnz, hipMemcpyHostToDevice));
+  int rc = orbx_nn_csr_device(ctx, dq.p, nq, dt.p, nt, drp.p, dc.p, last_wins, dbi.p, dbd.p, dsi.p, dsd.p,
+                              dist_out ? ddo.p : nullptr, ctx->stream);
+  if (rc != ORBX_OK) return rc;
+  ORBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (best_idx) ORBX_HIP(ctx, hipMemcpy(best_idx, dbi.p, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
+  if (best_dist) ORBX_HIP(ctx, hipMemcpy(best_dist, dbd.p, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
+  if (second_idx) ORBX_HIP(ctx, hipMemcpy(second_idx, dsi.p, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
+  if (second_dist) ORBX_HIP(ctx, hipMemcpy(second_dist, dsd.p, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
+  if (dist_out && nnz) ORBX_HIP(ctx, hipMemcpy(dist_out, ddo.p, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost));
+  return ORBX_OK;
+}
+
+int orbx_knn2_allpairs_device(orbx_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_idx,
+                              int32_t* d_dist, void* stream) {
+  if (!ctx || nq < 0 || nt < 0) return ORBX_E_INVALID;
+  if (nq == 0) return ORBX_OK;
+  ORBX_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  hipLaunchKernelGGL(k_knn2, dim3((nq + 3) / 4), dim3(256), 0, st, d_q, nq, d_t, nt, d_idx, d_dist);
+  ORBX_HIP(ctx, hipGetLastError());
+  return ORBX_OK;
+}
+
+int orbx_knn2_allpairs(orbx_ctx* ctx, const uint8_t* q_desc, int nq, const uint8_t* t_desc, int nt, int32_t* idx,
+                       int32_t* dist) {
+  if (!ctx || nq < 0 || nt < 0 || (nq > 0 && (!q_desc || !idx || !dist))) return ORBX_E_INVALID;
+  if (nq == 0) return ORBX_OK;
+  ORBX_HIP(ctx, hipSetDevice(ctx->device));
+  DevBuf<uint8_t> dq, dt;
+  DevBuf<int32_t> di, dd;
+  ORBX_HIP(ctx, dq.alloc((size_t)nq * 32)); ORBX_HIP(ctx, dt.alloc((size_t)nt * 32));
+  ORBX_HIP(ctx, di.alloc((size_t)nq * 2)); ORBX_HIP(ctx, dd.alloc((size_t)nq * 2));
+  ORBX_HIP(ctx, hipMemcpy(dq.p, q_desc, (size_t)nq * 32, hipMemcpyHostToDevice));
+  if (nt) ORBX_HIP(ctx, hipMemcpy(dt.p, t_desc, (size_t)nt * 32, hipMemcpyHostToDevice));
+  int rc = orbx_knn2_allpairs_device(ctx, dq.p, nq, dt.p, nt, di.p, dd.p, ctx->stream);
+  if (rc != ORBX_OK) return rc;
+  ORBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ORBX_HIP(ctx, hipMemcpy(idx, di.p, sizeof(int32_t) * nq * 2, hipMemcpyDeviceToHost));
+  ORBX_HIP(ctx, hipMemcpy(dist, dd.p, sizeof(int32_t) * nq * 2, hipMemcpyDeviceToHost));
+  return ORBX_OK;
+}
+
+// ---- vocabulary ------------------------------------------------------------------------------------
+
+int orbx_voc_create(orbx_ctx* ctx, int k, int L, int scoring, int weighting, int n, const int32_t* parent,
+                    const uint8_t* is_leaf, const uint8_t* desc, const double* weight, orbx_voc** out) {
+  if (!ctx || !out || n < 0 || (n > 0 && (!parent || !is_leaf || !desc || !weight))) return ORBX_E_INVALID;
+  *out = nullptr;
+  if (k < 0 || k > 20 || L < 1 || L > 10 || scoring < 0 || scoring > 5 || weighting < 0 || weighting > 3)
+    return set_err(ctx, ORBX_E_FORMAT, "vocabulary header out of range (TemplatedVocabulary.h:1359)");
+  orbx_voc* v = new (std::nothrow) orbx_voc();
+  if (!v) return ORBX_E_CAPACITY;
+  v->ctx = ctx; v->k = k; v->L = L; v->scoring = scoring; v->weighting = weighting;
+  v->parent.assign(n + 1, 0); v->is_leaf.assign(n + 1, 0); v->desc.assign((size_t)(n + 1) * 32, 0); v->weight.assign(n + 1, 0.0);
+  for (int i = 0; i < n; i++) {
+    v->parent[i + 1] = parent[i];
+    v->is_leaf[i + 1] = is_leaf[i] ? 1 : 0;
+    std::memcpy(&v->desc[(size_t)(i + 1) * 32], desc + (size_t)i * 32, 32);
+    v->weight[i + 1] = weight[i];
+  }
+  int rc = finish_voc(v);
+  if (rc != ORBX_OK) { orbx_voc_destroy(v); return rc; }
+  *out = v;
+  return ORBX_OK;
+}
+
+// TemplatedVocabulary::loadFromTextFile (TemplatedVocabulary.h:1338-1424): "k L scoring weighting" then one
+// line per node "parent isLeaf b0..b31 weight"; node ids are the 1-based line order.
+int orbx_voc_load_text(orbx_ctx* ctx, const char* path, orbx_voc** out) {
+  if (!ctx || !path || !out) return ORBX_E_INVALID;
+  *out = nullptr;
+  std::ifstream f(path);
+  if (!f.is_open()) return set_err(ctx, ORBX_E_FORMAT, std::string("cannot open ") + path);
+  std::string line;
+  if (!std::getline(f, line)) return set_err(ctx, ORBX_E_FORMAT, "empty vocabulary file");
+  int k = -1, L = -1, n1 = -1, n2 = -1;
+  { std::stringstream ss(line); ss >> k >> L >> n1 >> n2; }
+  if (k < 0 || k > 20 || L < 1 || L > 10 || n1 < 0 || n1 > 5 || n2 < 0 || n2 > 3)
+    return set_err(ctx, ORBX_E_FORMAT, "Vocabulary loading failure: This is not a correct text file!");
+  std::vector<int32_t> parent;
+  std::vector<uint8_t> leaf, desc;
+  std::vector<double> weight;
+  while (std::getline(f, line)) {
+    if (line.find_first_not_of(" \t\r\n") == std::string::npos) continue;  // no phantom node
+    std::stringstream ss(line);
+    int pid = 0, isleaf = 0;
+    ss >> pid >> isleaf;
+    uint8_t d[32];
+    for (int i = 0; i < 32; i++) { int b = 0; ss >> b; d[i] = (uint8_t)b; }
+    double w = 0;
+    ss >> w;
+    if (ss.fail()) return set_err(ctx, ORBX_E_FORMAT, "vocabulary: malformed node line");
+    parent.push_back(pid); leaf.push_back(isleaf > 0); desc.insert(desc.end(), d, d + 32); weight.push_back(w);
+  }
+  return orbx_voc_create(ctx, k, L, n1, n2, (int)parent.size(), parent.data(), leaf.data(), desc.data(), weight.data(), out);
+}
+
+void orbx_voc_destroy(orbx_voc* v) {
+  if (!v) return;
+  if (v->d_nodes) (void)hipFree(v->d_nodes);
+  if (v->d_slot_desc) (void)hipFree(v->d_slot_desc);
+  if (v->d_slot_node) (void)hipFree(v->d_slot_node);
+  delete v;
+}
+
+int orbx_voc_info(const orbx_voc* v, int* k, int* L, int* nnodes, int* nwords) {
+  if (!v) return ORBX_E_INVALID;
+  if (k) *k = v->k;
+  if (L) *L = v->L;
+  if (nnodes) *nnodes = (int)v->parent.size();
+  if (nwords) *nwords = v->nwords;
+  return ORBX_OK;
+}
+
+int orbx_bow_transform_device(orbx_voc* v, const uint8_t* d_desc, int n, int levelsup, uint32_t* d_word, double* d_weight,
+                              uint32_t* d_node, void* stream) {
+  if (!v || n < 0) return ORBX_E_INVALID;
+  orbx_ctx* ctx = v->ctx;
+  if (v->parent.size() <= 1) return set_err(ctx, ORBX_E_INVALID, "empty vocabulary");
+  if (n == 0) return ORBX_OK;
+  ORBX_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  hipLaunchKernelGGL(k_bow_descend, dim3((n + 3) / 4), dim3(256), 0, st, v->d_nodes, v->d_slot_desc, v->d_slot_node, d_desc, n,
+                     v->L, levelsup, d_word, d_weight, d_node);
+  ORBX_HIP(ctx, hipGetLastError());
+  return ORBX_OK;
+}
+
+int orbx_bow_transform(orbx_voc* v, const uint8_t* desc, int n, int levelsup, uint32_t* word, double* weight, uint32_t* node) {
+  if (!v || n < 0 || (n > 0 && (!desc || !word || !weight || !node))) return ORBX_E_INVALID;
+  if (n == 0) return ORBX_OK;
+  orbx_ctx* ctx = v->ctx;
+  ORBX_HIP(ctx, hipSetDevice(ctx->device));
+  DevBuf<uint8_t> dd; DevBuf<uint32_t> dw, dn; DevBuf<double> dwt;
+  ORBX_HIP(ctx, dd.alloc((size_t)n * 32)); ORBX_HIP(ctx, dw.alloc(n)); ORBX_HIP(ctx, dn.alloc(n)); ORBX_HIP(ctx, dwt.alloc(n));
+  ORBX_HIP(ctx, hipMemcpy(dd.p, desc, (size_t)n * 32, hipMemcpyHostToDevice));
+  int rc = orbx_bow_transform_device(v, dd.p, n, levelsup, dw.p, dwt.p, dn.p, ctx->stream);
+  if (rc != ORBX_OK) return rc;
+  ORBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ORBX_HIP(ctx, hipMemcpy(word, dw.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+  ORBX_HIP(ctx, hipMemcpy(weight, dwt.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+  ORBX_HIP(ctx, hipMemcpy(node, dn.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+  return ORBX_OK;
+}
+
+// BowVector::addWeight / addIfNotExist + normalize (BowVector.cpp:34-85) and the weighting switch of
+// TemplatedVocabulary::transform (TemplatedVocabulary.h:1145-1192): host, ordered map, doubles.
+int orbx_bow_finalize(const orbx_voc* v, const uint32_t* word, const double* weight, int n, uint32_t* ids, double* vals,
+                      int* n_out) {
+  if (!v || n < 0 || !n_out || (n > 0 && (!word || !weight || !ids || !vals))) return ORBX_E_INVALID;
+  std::map<uint32_t, double> bow;
+  const bool tf = v->weighting == 0 /*TF_IDF*/ || v->weighting == 1 /*TF*/;
+  for (int i = 0; i < n; i++) {
+    if (!(weight[i] > 0)) continue;
+    auto it = bow.lower_bound(word[i]);
+    if (it != bow.end() && it->first == word[i]) { if (tf) it->second += weight[i]; }
+    else bow.insert(it, std::make_pair(word[i], weight[i]));
+  }
+  // mustNormalize: L1_NORM->L1, L2_NORM->L2, CHI_SQUARE/KL/BHATTACHARYYA->L1, DOT_PRODUCT->none (ScoringObject.h)
+  const bool must = v->scoring != 5;
+  const bool l2 = v->scoring == 1;
+  if (tf && !bow.empty() && !must) {
+    const double nd = (double)bow.size();
+    for (auto& kv : bow) kv.second /= nd;
+  }
+  if (must) {
+    double norm = 0.0;
+    if (!l2) { for (auto& kv : bow) norm += std::fabs(kv.second); }
+    else { for (auto& kv : bow) norm += kv.second * kv.second; norm = std::sqrt(norm); }
+    if (norm > 0.0) for (auto& kv : bow) kv.second /= norm;
+  }
+  int k = 0;
+  for (auto& kv : bow) { ids[k] = kv.first; vals[k] = kv.second; k++; }
+  *n_out = k;
+  return ORBX_OK;
+}
+
+double orbx_bow_score_l1(const uint32_t* ida, const double* va, int na, const uint32_t* idb, const double* vb, int nb) {
+  int a = 0, b = 0;
+  double score = 0;
+  while (a < na && b < nb) {
+    if (ida[a] == idb[b]) {
+      const double vi = va[a], wi = vb[b];
+      score += std::fabs(vi - wi) - std::fabs(vi) - std::fabs(wi);
+      ++a; ++b;
+    } else if (ida[a] < idb[b]) ++a;
+    else ++b;
+  }
+  return -score / 2.0;
+}
+
+int orbx_bow_score_l1_batch(orbx_ctx* ctx, const uint32_t* q_ids, const double* q_vals, int nq, const int32_t* db_ptr,
+                            const uint32_t* db_ids, const double* db_vals, int ndb, double* scores) {
+  if (!ctx || nq < 0 || ndb < 0 || (ndb > 0 && (!db_ptr || !scores))) return ORBX_E_INVALID;
+  if (ndb == 0) return ORBX_OK;
+  ORBX_HIP(ctx, hipSetDevice(ctx->device));
+  const int nnz = db_ptr[ndb];
+  DevBuf<uint32_t> dqi, ddi; DevBuf<double> dqv, ddv, dsc; DevBuf<int32_t> dp;
+  ORBX_HIP(ctx, dqi.alloc(nq)); ORBX_HIP(ctx, dqv.alloc(nq)); ORBX_HIP(ctx, ddi.alloc(nnz)); ORBX_HIP(ctx, ddv.alloc(nnz));
+  ORBX_HIP(ctx, dsc.alloc(ndb)); ORBX_HIP(ctx, dp.alloc(ndb + 1));
+  if (nq) { ORBX_HIP(ctx, hipMemcpy(dqi.p, q_ids, sizeof(uint32_t) * nq, hipMemcpyHostToDevice));
+            ORBX_HIP(ctx, hipMemcpy(dqv.p, q_vals, sizeof(double) * nq, hipMemcpyHostToDevice)); }
+  if (nnz) { ORBX_HIP(ctx, hipMemcpy(ddi.p, db_ids, sizeof(uint32_t) * nnz, hipMemcpyHostToDevice));
+             ORBX_HIP(ctx, hipMemcpy(ddv.p, db_vals, sizeof(double) * nnz, hipMemcpyHostToDevice)); }
+  ORBX_HIP(ctx, hipMemcpy(dp.p, db_ptr, sizeof(int32_t) * (ndb + 1), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_bow_score_l1, dim3((ndb + 255) / 256), dim3(256), 0, ctx->stream, dqi.p, dqv.p, nq, dp.p, ddi.p, ddv.p,
+                     ndb, dsc.p);
+  ORBX_HIP(ctx, hipGetLastError());
+  ORBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ORBX_HIP(ctx, hipMemcpy(scores, dsc.p, sizeof(double) * ndb, hipMemcpyDeviceToHost));
+  return ORBX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,126 @@
+"""Host-side mirror of ORB_SLAM3::ORBextractor (reference include/ORBextractor.h:49-83) over the C ABI.
+
+Same constructor arguments, same call semantics (`operator()` -> `__call__` returning monoIndex, keypoints in
+the reference's output order, 32-byte descriptors), same getters, `mvImagePyramid` available after a call.
+All arithmetic runs in the HIP kernels of liborbx.so; this file only marshals buffers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import KP_DTYPE, check, lib, ptr
+
+
+class ORBextractor:
+    HARRIS_SCORE, FAST_SCORE = 0, 1  # include/ORBextractor.h:47
+
+    def __init__(self, nfeatures: int, scaleFactor: float, nlevels: int, iniThFAST: int, minThFAST: int,
+                 device_id: int = -1):
+        self._L = lib()
+        self._ctx = C.c_void_p(0)
+        rc = self._L.orbx_create(C.byref(self._ctx), nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device_id)
+        if rc != 0:
+            raise _lib.OrbxError(rc, "orbx_create failed (no HIP device?)" if rc == _lib.ORBX_E_DEVICE else "bad arguments")
+        self.nfeatures, self.nlevels, self.scaleFactor = nfeatures, nlevels, float(np.float32(scaleFactor))
+        self.capacity = self._L.orbx_keypoint_capacity(self._ctx)
+        n = nlevels
+        self._scale, self._inv, self._s2, self._is2 = (np.zeros(n, np.float32) for _ in range(4))
+        self._quota = np.zeros(n, np.int32)
+        check(self._L.orbx_scale_tables(self._ctx, ptr(self._scale), ptr(self._inv), ptr(self._s2), ptr(self._is2),
+                                        ptr(self._quota)), self._ctx)
+        self._last_frames = 0
+
+    def close(self):
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self._L.orbx_destroy(self._ctx)
+            self._ctx = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- getters (include/ORBextractor.h:63-82) -------------------------------------------------------
+    def GetLevels(self) -> int: return self.nlevels
+    def GetScaleFactor(self) -> float: return self.scaleFactor
+    def GetScaleFactors(self) -> np.ndarray: return self._scale.copy()
+    def GetInverseScaleFactors(self) -> np.ndarray: return self._inv.copy()
+    def GetScaleSigmaSquares(self) -> np.ndarray: return self._s2.copy()
+    def GetInverseScaleSigmaSquares(self) -> np.ndarray: return self._is2.copy()
+    def features_per_level(self) -> np.ndarray: return self._quota.copy()
+
+    # ---- operator() (src/ORBextractor.cc:1086-1168) ----------------------------------------------------
+    def __call__(self, image: np.ndarray, mask=None, vLappingArea: Sequence[int] = (0, 0)
+                 ) -> Tuple[int, np.ndarray, np.ndarray]:
+        """Returns (monoIndex, keypoints[KP_DTYPE], descriptors[n,32] uint8); (-1, empty, empty) for an empty image."""
+        if image is None or image.size == 0:
+            return -1, np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8)
+        assert image.dtype == np.uint8 and image.ndim == 2, "CV_8UC1 expected (src/ORBextractor.cc:1094)"
+        if image.strides[1] != 1:
+            image = np.ascontiguousarray(image)
+        kps = np.zeros(self.capacity, KP_DTYPE)
+        desc = np.zeros((self.capacity, 32), np.uint8)
+        n, mono = C.c_int(0), C.c_int(0)
+        check(self._L.orbx_extract(self._ctx, ptr(image), image.shape[0], image.shape[1], image.strides[0],
+                                   int(vLappingArea[0]), int(vLappingArea[1]), ptr(kps), ptr(desc), C.byref(n),
+                                   C.byref(mono)), self._ctx)
+        self._last_frames = 1
+        return mono.value, kps[:n.value].copy(), desc[:n.value].copy()
+
+    def extract_batch(self, images: np.ndarray, vLappingArea: Sequence[int] = (0, 0)
+                      ) -> List[Tuple[int, np.ndarray, np.ndarray]]:
+        """Batch replay over host frames [B, H, W] (frames are independent: SURVEY.md §8(e))."""
+        assert images.dtype == np.uint8 and images.ndim == 3
+        images = np.ascontiguousarray(images)
+        B, H, W = images.shape
+        kps = np.zeros((B, self.capacity), KP_DTYPE)
+        desc = np.zeros((B, self.capacity, 32), np.uint8)
+        counts = np.zeros((B, 2), np.int32)
+        check(self._L.orbx_extract_batch(self._ctx, ptr(images), B, H, W, images.strides[1], images.strides[0],
+                                         int(vLappingArea[0]), int(vLappingArea[1]), ptr(kps), ptr(desc), ptr(counts)),
+              self._ctx)
+        self._last_frames = B
+        return [(int(counts[f, 1]), kps[f, :counts[f, 0]].copy(), desc[f, :counts[f, 0]].copy()) for f in range(B)]
+
+    def extract_batch_device(self, d_imgs: int, nframes: int, rows: int, cols: int, row_stride: int, frame_stride: int,
+                             d_kps: int, d_desc: int, d_counts: int, vLappingArea: Sequence[int] = (0, 0),
+                             stream: int = 0) -> None:
+        """Device-resident batch: raw HBM addresses (e.g. torch `tensor.data_ptr()`); asynchronous on `stream`."""
+        check(self._L.orbx_extract_batch_device(self._ctx, ptr(d_imgs), nframes, rows, cols, row_stride, frame_stride,
+                                                int(vLappingArea[0]), int(vLappingArea[1]), ptr(d_kps), ptr(d_desc),
+                                                ptr(d_counts), ptr(stream)), self._ctx)
+        self._last_frames = nframes
+
+    # ---- mvImagePyramid (include/ORBextractor.h:83) ---------------------------------------------------
+    def pyramid_level(self, level: int, frame: int = 0) -> np.ndarray:
+        w, h = C.c_int(0), C.c_int(0)
+        check(self._L.orbx_pyramid_level(self._ctx, frame, level, None, 0, C.byref(w), C.byref(h)), self._ctx)
+        out = np.zeros((h.value, w.value), np.uint8)
+        check(self._L.orbx_pyramid_level(self._ctx, frame, level, ptr(out), w.value, C.byref(w), C.byref(h)), self._ctx)
+        return out
+
+    @property
+    def mvImagePyramid(self) -> List[np.ndarray]:
+        return [self.pyramid_level(l) for l in range(self.nlevels)]
+
+    # ---- stage dumps / profiling ------------------------------------------------------------------------
+    def debug_level_points(self, level: int, stage: int, frame: int = 0):
+        n = check(self._L.orbx_debug_level_points(self._ctx, frame, level, stage, None, 0), self._ctx)
+        buf = np.zeros(max(n, 1), np.uint32)
+        check(self._L.orbx_debug_level_points(self._ctx, frame, level, stage, ptr(buf), n), self._ctx)
+        buf = buf[:n]
+        return (buf & 0xfff).astype(np.int32), ((buf >> 12) & 0xfff).astype(np.int32), (buf >> 24).astype(np.int32)
+
+    def profile_enable(self, on: bool = True):
+        check(self._L.orbx_profile_enable(self._ctx, int(on)), self._ctx)
+
+    def profile_read(self):
+        ms = np.zeros(_lib.NUM_KERNELS, np.float64)
+        n = np.zeros(_lib.NUM_KERNELS, np.int64)
+        check(self._L.orbx_profile_read(self._ctx, ptr(ms), ptr(n)), self._ctx)
+        return {self._L.orbx_kernel_name(i).decode(): (float(ms[i]), int(n[i])) for i in range(_lib.NUM_KERNELS)}
