@@ -91,6 +91,12 @@ int orbx_pyramid_level(orbx_ctx* ctx, int frame, int level, uint8_t* dst, size_t
  * Returns the number of entries (or a negative error); dst may be NULL. */
 int orbx_debug_level_points(orbx_ctx* ctx, int frame, int level, int stage, uint32_t* dst, int cap);
 
+/* Test hook for the two float paths of the descriptor kernel: angle[i] = cv::fastAtan2(y[i], x[i]) (or y[i] itself
+ * when angle_is_input), a[i] / b[i] = cosf / sinf(angle * pi/180) as the reference computes them
+ * (src/ORBextractor.cc:102,111-112).  Host pointers. */
+int orbx_debug_trig(orbx_ctx* ctx, const float* y, const float* x, int n, int angle_is_input, float* angle, float* a,
+                    float* b);
+
 /* Per-kernel device time of the extractor, measured with HIP events on the launch stream.
  * orbx_profile_enable(ctx,1) makes every following extraction record events around each kernel;
  * orbx_profile_read returns, for kernel slot i < ORBX_NUM_KERNELS, accumulated milliseconds and launches. */

@@ -244,3 +244,69 @@ def score_l1(a, b) -> float:
     ia, va = np.ascontiguousarray(a[0], np.uint32), np.ascontiguousarray(a[1], np.float64)
     ib, vb = np.ascontiguousarray(b[0], np.uint32), np.ascontiguousarray(b[1], np.float64)
     return float(_mlib().mo_score_l1(_ptr(ia), _ptr(va), len(ia), _ptr(ib), _ptr(vb), len(ib)))
+
+
+# ---- the REFERENCE's own DBoW2 code (oracle/_ref/libref_dbow2.so, built by oracle/ref_fragments.mk) ---------
+_REF_PATH = os.path.join(_HERE, "_ref", "libref_dbow2.so")
+_ref = None
+
+
+def ref_available() -> bool:
+    return os.path.exists(_REF_PATH)
+
+
+def ref_lib():
+    global _ref
+    if _ref is None:
+        R = C.CDLL(_REF_PATH)
+        vp = C.c_void_p
+        R.ref_forb_distance.restype = C.c_int
+        R.ref_forb_distance.argtypes = [vp, vp]
+        R.ref_voc_load.restype = vp
+        R.ref_voc_load.argtypes = [C.c_char_p]
+        R.ref_voc_free.argtypes = [vp]
+        R.ref_voc_size.argtypes = [vp]
+        R.ref_voc_transform.restype = C.c_int
+        R.ref_voc_transform.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, C.POINTER(C.c_int)]
+        R.ref_voc_score.restype = C.c_double
+        R.ref_voc_score.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int]
+        _ref = R
+    return _ref
+
+
+def ref_hamming(a, b) -> int:
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    return int(ref_lib().ref_forb_distance(_ptr(a), _ptr(b)))
+
+
+class RefVocabulary:
+    """DBoW2::TemplatedVocabulary<cv::Mat, FORB> of the reference itself."""
+
+    def __init__(self, path: str):
+        self._h = ref_lib().ref_voc_load(path.encode())
+        if not self._h:
+            raise RuntimeError("reference vocabulary load failed")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            ref_lib().ref_voc_free(self._h)
+            self._h = None
+
+    def size(self) -> int:
+        return ref_lib().ref_voc_size(self._h)
+
+    def transform(self, desc, levelsup=4):
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        n = len(d)
+        ids, vals = np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.float64)
+        fvn, fvf, nfv = np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.uint32), C.c_int(0)
+        k = ref_lib().ref_voc_transform(self._h, _ptr(d), n, levelsup, _ptr(ids), _ptr(vals), _ptr(fvn), _ptr(fvf), C.byref(nfv))
+        fv = {}
+        for a, b in zip(fvn[:nfv.value], fvf[:nfv.value]):
+            fv.setdefault(int(a), []).append(int(b))
+        return (ids[:k].copy(), vals[:k].copy()), fv
+
+    def score(self, a, b) -> float:
+        ia, va = np.ascontiguousarray(a[0], np.uint32), np.ascontiguousarray(a[1], np.float64)
+        ib, vb = np.ascontiguousarray(b[0], np.uint32), np.ascontiguousarray(b[1], np.float64)
+        return float(ref_lib().ref_voc_score(self._h, _ptr(ia), _ptr(va), len(ia), _ptr(ib), _ptr(vb), len(ib)))

@@ -521,6 +521,27 @@ int orbx_profile_read(orbx_ctx* ctx, double ms[ORBX_NUM_KERNELS], int64_t launch
   return ORBX_OK;
 }
 
+int orbx_debug_trig(orbx_ctx* ctx, const float* y, const float* x, int n, int angle_is_input, float* angle, float* a,
+                    float* b) {
+  if (!ctx || n < 0 || !y || !angle || !a || !b || (!angle_is_input && !x)) return ORBX_E_INVALID;
+  if (n == 0) return ORBX_OK;
+  ORBX_HIP(ctx, hipSetDevice(ctx->device));
+  float *dy = nullptr, *dx = nullptr, *dang = nullptr, *da = nullptr, *db = nullptr;
+  const size_t bytes = (size_t)n * sizeof(float);
+  ORBX_HIP(ctx, hipMalloc((void**)&dy, bytes)); ORBX_HIP(ctx, hipMalloc((void**)&dx, bytes));
+  ORBX_HIP(ctx, hipMalloc((void**)&dang, bytes)); ORBX_HIP(ctx, hipMalloc((void**)&da, bytes)); ORBX_HIP(ctx, hipMalloc((void**)&db, bytes));
+  ORBX_HIP(ctx, hipMemcpy(dy, y, bytes, hipMemcpyHostToDevice));
+  if (x) ORBX_HIP(ctx, hipMemcpy(dx, x, bytes, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_debug_trig, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, dy, dx, n, angle_is_input, dang, da, db);
+  ORBX_HIP(ctx, hipGetLastError());
+  ORBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ORBX_HIP(ctx, hipMemcpy(angle, dang, bytes, hipMemcpyDeviceToHost));
+  ORBX_HIP(ctx, hipMemcpy(a, da, bytes, hipMemcpyDeviceToHost));
+  ORBX_HIP(ctx, hipMemcpy(b, db, bytes, hipMemcpyDeviceToHost));
+  (void)hipFree(dy); (void)hipFree(dx); (void)hipFree(dang); (void)hipFree(da); (void)hipFree(db);
+  return ORBX_OK;
+}
+
 const char* orbx_kernel_name(int slot) {
   static const char* names[ORBX_NUM_KERNELS] = {"k_resize(pyramid chain)", "k_fast_cells", "k_quadtree", "k_assemble",
                                                 "k_describe", "reserved"};

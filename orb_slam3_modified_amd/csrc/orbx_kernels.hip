@@ -692,4 +692,19 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
   }
 }
 
+
+// Debug/test kernel: the two float paths of K4 in isolation (fastAtan2, then glibc-exact cosf/sinf of
+// angle*factorPI) so tests can sweep far more arguments than real frames produce.
+__global__ void k_debug_trig(const float* __restrict__ y, const float* __restrict__ x, int n, int angle_is_input,
+                             float* __restrict__ angle, float* __restrict__ a, float* __restrict__ b) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float ang = angle_is_input ? y[i] : fast_atan2_deg(y[i], x[i]);
+  const float factorPI = (float)(3.14159265358979323846 / 180.f);
+  const float r = __fmul_rn(ang, factorPI);
+  angle[i] = ang;
+  a[i] = orbx_glibc::cosf_exact(r);
+  b[i] = orbx_glibc::sinf_exact(r);
+}
+
 }  // namespace orbx

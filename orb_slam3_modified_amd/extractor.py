@@ -116,6 +116,15 @@ class ORBextractor:
         buf = buf[:n]
         return (buf & 0xfff).astype(np.int32), ((buf >> 12) & 0xfff).astype(np.int32), (buf >> 24).astype(np.int32)
 
+    def debug_trig(self, y, x=None):
+        """Device fastAtan2 + cos/sin (test hook): returns (angle_deg, cos, sin) float32 arrays."""
+        y = np.ascontiguousarray(y, np.float32)
+        xx = None if x is None else np.ascontiguousarray(x, np.float32)
+        n = len(y)
+        ang, a, b = (np.zeros(max(n, 1), np.float32) for _ in range(3))
+        check(self._L.orbx_debug_trig(self._ctx, ptr(y), ptr(xx), n, int(x is None), ptr(ang), ptr(a), ptr(b)), self._ctx)
+        return ang[:n], a[:n], b[:n]
+
     def profile_enable(self, on: bool = True):
         check(self._L.orbx_profile_enable(self._ctx, int(on)), self._ctx)
 

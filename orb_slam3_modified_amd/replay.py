@@ -1,0 +1,118 @@
+"""Batch-replay driver: camera streams sharded one per GPU, optional RCCL all-gather of the per-frame
+feature blocks (BASELINE.json config 5).
+
+One process per GPU (`torch.distributed`, backend "nccl" = RCCL on ROCm; "gloo" for the CPU unit tests of the
+sharding / packing logic).  Frames are independent units, so extraction itself needs no collective; the only
+exchange is the all-gather that gives every rank all cameras' descriptors, and it is issued asynchronously so it
+overlaps the next batch's kernels (double-buffered feature blocks).
+
+Feature block layout per rank and step (one contiguous uint8 buffer, fixed size so the gather is regular):
+    [B][cap] orbx_keypoint (28 B) | [B][cap][32] descriptor bytes | [B][2] int32 (n, monoIndex)
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+KP_BYTES = 28
+
+
+def _up256(n: int) -> int:
+    return (n + 255) // 256 * 256
+
+
+@dataclass
+class BlockLayout:
+    frames: int
+    cap: int
+
+    @property
+    def kps_bytes(self) -> int: return self.frames * self.cap * KP_BYTES
+    @property
+    def desc_bytes(self) -> int: return self.frames * self.cap * 32
+    @property
+    def counts_bytes(self) -> int: return self.frames * 2 * 4
+    @property
+    def desc_off(self) -> int: return _up256(self.kps_bytes)
+    @property
+    def counts_off(self) -> int: return self.desc_off + _up256(self.desc_bytes)
+    @property
+    def nbytes(self) -> int: return self.counts_off + _up256(self.counts_bytes)
+
+
+def shard_streams(n_streams: int, world_size: int, rank: int) -> List[int]:
+    """Camera stream c runs on GPU c mod G."""
+    return [c for c in range(n_streams) if c % world_size == rank]
+
+
+def unpack_block(block: np.ndarray, layout: BlockLayout):
+    """Host view of one rank's feature block -> list of (monoIndex, keypoints, descriptors) per frame."""
+    from ._lib import KP_DTYPE
+    b = np.ascontiguousarray(block).view(np.uint8).reshape(-1)
+    kps = b[:layout.kps_bytes].view(KP_DTYPE).reshape(layout.frames, layout.cap)
+    desc = b[layout.desc_off:layout.desc_off + layout.desc_bytes].reshape(layout.frames, layout.cap, 32)
+    counts = b[layout.counts_off:layout.counts_off + layout.counts_bytes].view(np.int32).reshape(layout.frames, 2)
+    return [(int(counts[f, 1]), kps[f, :counts[f, 0]].copy(), desc[f, :counts[f, 0]].copy()) for f in range(layout.frames)]
+
+
+class ReplayEngine:
+    """Per-rank replay loop over device-resident frames with an overlapped all-gather of feature blocks."""
+
+    def __init__(self, extractor, frames_dev, lapping=(0, 1000), gather: bool = True, process_group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.ex = extractor
+        self.frames = frames_dev  # torch uint8 [B, H, W] on this rank's GPU
+        self.B, self.H, self.W = frames_dev.shape
+        self.lap = lapping
+        self.layout = BlockLayout(self.B, extractor.capacity)
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.gather = gather and self.world > 1
+        self.pg = process_group
+        dev = frames_dev.device
+        self.blocks = [torch.zeros(self.layout.nbytes, dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.gathered = [torch.zeros(self.layout.nbytes * self.world, dtype=torch.uint8, device=dev) if self.gather else None
+                         for _ in range(2)]
+        self.pending = [None, None]
+        self.step_idx = 0
+
+    def step(self):
+        """One pass of the hot path over this rank's batch (+ async all-gather of the resulting block)."""
+        torch = self.torch
+        i = self.step_idx & 1
+        if self.pending[i] is not None:  # the gather that last read this buffer must be done before we overwrite it
+            self.pending[i].wait()
+            self.pending[i] = None
+        blk = self.blocks[i]
+        base = blk.data_ptr()
+        st = torch.cuda.current_stream().cuda_stream
+        self.ex.extract_batch_device(self.frames.data_ptr(), self.B, self.H, self.W, self.frames.stride(1), self.frames.stride(0),
+                                     base, base + self.layout.desc_off, base + self.layout.counts_off, self.lap, st)
+        if self.gather:
+            self.pending[i] = self.dist.all_gather_into_tensor(self.gathered[i], blk, group=self.pg, async_op=True)
+        self.step_idx += 1
+        return i
+
+    def drain(self):
+        for i in (0, 1):
+            if self.pending[i] is not None:
+                self.pending[i].wait()
+                self.pending[i] = None
+
+    def counts(self, i: int):
+        lo = self.layout
+        return self.blocks[i][lo.counts_off:lo.counts_off + lo.counts_bytes].view(self.torch.int32).reshape(self.B, 2)
+
+
+def gather_blocks_cpu(block: np.ndarray, layout: BlockLayout, process_group=None) -> Optional[List[np.ndarray]]:
+    """The same exchange on host tensors (gloo): used by the CPU multi-process tests of the packing / sharding."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(process_group)
+    t = torch.from_numpy(np.ascontiguousarray(block).view(np.uint8).reshape(-1).copy())
+    outs = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(outs, t, group=process_group)
+    return [o.numpy() for o in outs]

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz (run in the build container: needs oracle/_ref/libref_dbow2.so, i.e. the reference).
+
+  extractor_small.npz : oracle outputs for three small seeded frames (the reference extractor cannot run here:
+                        OpenCV is absent -> these pin the oracle, not the reference; "parity unpinned")
+  bow_reference.npz   : outputs of the REFERENCE'S OWN DBoW2 code (loadFromTextFile / transform / score) on a small
+                        vocabulary -> a true reference golden
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle import pyoracle as po  # noqa: E402
+from orb_slam3_modified_amd import synth  # noqa: E402
+from tests.vocab_util import make_vocabulary  # noqa: E402
+
+out = {}
+frames = {"g320": synth.make_stream(2, 240, 320, 777), "g376": synth.make_stream(1, 240, 376, 778)}
+alld = []
+for key, fr in frames.items():
+    for t, img in enumerate(fr):
+        kps, desc, mono = po.OracleExtractor(300, 1.2, 5, 20, 7).extract(img, (0, 1000))
+        out[f"{key}_{t}_imgsha"] = hashlib.sha256(img.tobytes()).hexdigest()
+        out[f"{key}_{t}_kps"], out[f"{key}_{t}_desc"], out[f"{key}_{t}_mono"] = kps, desc, mono
+        alld.append(desc)
+np.savez_compressed(os.path.join(HERE, "extractor_small.npz"), **out)
+
+alld = np.concatenate(alld)
+voc = os.path.join(HERE, "voc_k5_L3.txt")
+make_vocabulary(voc, alld, 5, 3, seed=42)
+rv = po.RefVocabulary(voc)
+d1, d2 = alld[:300], alld[300:600]
+(ids, vals), fv = rv.transform(d1, 2)
+(ids2, vals2), _ = rv.transform(d2, 2)
+np.savez_compressed(os.path.join(HERE, "bow_reference.npz"), desc=d1, ids=ids, vals=vals, ids2=ids2, vals2=vals2,
+                    fv_keys=np.array(list(fv.keys()), np.int64), fv_lens=np.array([len(v) for v in fv.values()], np.int64),
+                    fv_vals=np.concatenate([np.array(v, np.int64) for v in fv.values()]),
+                    score12=rv.score((ids, vals), (ids2, vals2)))
+with open(os.path.join(HERE, "MANIFEST.sha256"), "w") as f:
+    for name in ("extractor_small.npz", "bow_reference.npz", "voc_k5_L3.txt"):
+        f.write(f"{name} {hashlib.sha256(open(os.path.join(HERE, name), 'rb').read()).hexdigest()}\n")
+print("golden vectors written")

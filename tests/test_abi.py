@@ -1,0 +1,62 @@
+"""The C-ABI library loads and exports every symbol include/orbx.h declares (no compute calls: CPU-only)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    h = open(os.path.join(ROOT, "include", "orbx.h")).read()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    return sorted(set(re.findall(r"\b(orbx_[a-z0-9_]+)\s*\(", h)))
+
+
+def test_library_built_in_tree():
+    from orb_slam3_modified_amd import build
+    path = build.build()
+    assert os.path.dirname(path) == os.path.join(ROOT, "orb_slam3_modified_amd")
+
+
+def test_every_declared_symbol_is_exported():
+    from orb_slam3_modified_amd import _lib
+    L = C.CDLL(_lib.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 28
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    assert set(_lib.lib()._orbx_symbols) == set(names)  # the Python binding covers the whole header
+
+
+def test_no_device_fails_loudly():
+    from tests.conftest import HAS_GPU
+    if HAS_GPU:
+        pytest.skip("GPU present")
+    from orb_slam3_modified_amd import ORBextractor, OrbxError
+    with pytest.raises(OrbxError) as e:
+        ORBextractor(1000, 1.2, 8, 20, 7)
+    assert e.value.code == -3  # ORBX_E_DEVICE: there is no CPU fallback
+
+
+def test_host_only_entry_points():
+    import numpy as np
+    from orb_slam3_modified_amd import ORBmatcher
+    a, b = np.zeros(32, np.uint8), np.full(32, 255, np.uint8)
+    assert ORBmatcher.DescriptorDistance(a, b) == 256
+    assert ORBmatcher.ComputeThreeMaxima([0, 5, 9, 1, 9, 0]) == (2, 4, 1)
+    assert ORBmatcher.ComputeThreeMaxima([0, 50, 4, 1]) == (1, -1, -1)
+    from orb_slam3_modified_amd import _lib
+    ia = np.array([1, 5, 9], np.uint32); va = np.array([0.2, 0.3, 0.5])
+    s = _lib.lib().orbx_bow_score_l1(_lib.ptr(ia), _lib.ptr(va), 3, _lib.ptr(ia), _lib.ptr(va), 3)
+    assert abs(s - 1.0) < 1e-15
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "orb_slam3_modified_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".inc")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "pyoracle" not in txt and "liborb_oracle" not in txt and "oracle/" not in txt.replace("oracle/orb_pattern", ""), f

@@ -1,0 +1,184 @@
+"""Parity tests proper: the HIP extractor (through the C ABI) against the CPU oracle, bit for bit.
+
+Keypoint fields are compared as raw 32-bit patterns (x, y, size, angle, response, octave, class_id), descriptors
+byte for byte, the return value (monoIndex) and the output ORDER included.  `response` is the
+integer FAST score (the reference never computes a Harris score), so the north-star's 1e-4
+tolerance collapses to exact equality; the only float fields (angle, scaled x/y) are required bit-exact too.
+"""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from orb_slam3_modified_amd import ORBextractor, OrbxError, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_same(gpu_res, ora_res, tag=""):
+    mono_g, kps_g, desc_g = gpu_res
+    kps_o, desc_o, mono_o = ora_res
+    assert mono_g == mono_o, (tag, mono_g, mono_o)
+    assert len(kps_g) == len(kps_o), (tag, len(kps_g), len(kps_o))
+    for f in kps_g.dtype.names:
+        a, b = kps_g[f].view(np.int32), kps_o[f].view(np.int32)
+        assert np.array_equal(a, b), (tag, f, int((a != b).sum()))
+    assert np.array_equal(desc_g, desc_o), (tag, "descriptor bits", int(np.unpackbits(desc_g ^ desc_o).sum()))
+
+
+CONFIGS = [
+    # (rows, cols, nfeatures, lapping, nframes)
+    (480, 640, 1000, (0, 1000), 3),     # BASELINE configs[1]: single 640x480 frame, bit-exact check (mono call)
+    (480, 752, 1000, (0, 1000), 2),     # EuRoC native: two quadtree roots
+    (350, 600, 1000, (0, 1000), 2),     # EuRoC.yaml resized shape
+    (512, 512, 1500, (0, 1000), 1),     # TUM-VI.yaml shape
+    (480, 640, 5000, (0, 1000), 1),     # mpIniORBextractor (5 x nFeatures)
+    (480, 640, 1000, (0, 0), 1),        # stereo / RGB-D call: everything ascending, returns N
+    (480, 640, 1200, (200, 400), 1),    # fisheye lapping columns: both output branches
+]
+
+
+@pytest.mark.parametrize("rows,cols,nf,lap,nframes", CONFIGS)
+def test_extract_bit_exact(rows, cols, nf, lap, nframes):
+    frames = synth.make_stream(nframes, rows, cols)
+    gpu = ORBextractor(nf, 1.2, 8, 20, 7)
+    ora = po.OracleExtractor(nf, 1.2, 8, 20, 7)
+    for t, img in enumerate(frames):
+        assert_same(gpu(img, None, lap), ora.extract(img, lap), f"{cols}x{rows} nf{nf} f{t}")
+
+
+def test_config4_tumvi_1024_both_output_branches():
+    img = synth.make_stream(1, 1024, 1024)[0]
+    gpu = ORBextractor(2000, 1.2, 8, 20, 7)
+    res = gpu(img, None, (0, 1000))
+    assert_same(res, po.OracleExtractor(2000, 1.2, 8, 20, 7).extract(img, (0, 1000)), "1024^2")
+    mono, kps, _ = res
+    assert 0 < mono < len(kps) and (kps["x"][:mono] > 1000).all()
+
+
+def test_stage_parity_pyramid_candidates_quadtree():
+    img = synth.make_stream(1)[0]
+    gpu = ORBextractor(1000, 1.2, 8, 20, 7)
+    ora = po.OracleExtractor(1000, 1.2, 8, 20, 7)
+    gpu(img, None, (0, 1000)); ora.extract(img, (0, 1000))
+    pyr = gpu.mvImagePyramid
+    for l in range(8):
+        assert np.array_equal(pyr[l], ora.level(l)), f"pyramid level {l}"
+        gx, gy, gs = gpu.debug_level_points(l, 0)
+        c = ora.level_keypoints(l, 0)
+        assert np.array_equal(gx, c["x"].astype(np.int32)) and np.array_equal(gy, c["y"].astype(np.int32))
+        assert np.array_equal(gs, c["response"].astype(np.int32)), f"FAST candidates level {l}"
+        gx, gy, gs = gpu.debug_level_points(l, 1)
+        k = ora.level_keypoints(l, 1)
+        assert np.array_equal(gx, k["x"].astype(np.int32)) and np.array_equal(gy, k["y"].astype(np.int32)), f"quadtree level {l}"
+
+
+@pytest.mark.parametrize("name", ["constant", "noise", "checker", "gradient", "saturated"])
+def test_degenerate_images(name):
+    rng = np.random.default_rng(5)
+    img = {"constant": np.full((480, 640), 77, np.uint8),
+           "noise": rng.integers(0, 256, (480, 640)).astype(np.uint8),
+           "checker": ((np.indices((480, 640)).sum(0) // 8) % 2 * 200 + 20).astype(np.uint8),
+           "gradient": np.tile(np.linspace(0, 255, 640).astype(np.uint8), (480, 1)),
+           "saturated": np.where(rng.random((480, 640)) < 0.5, 0, 255).astype(np.uint8)}[name]
+    gpu = ORBextractor(1000, 1.2, 8, 20, 7)
+    assert_same(gpu(img, None, (0, 1000)), po.OracleExtractor(1000, 1.2, 8, 20, 7).extract(img, (0, 1000)), name)
+
+
+@pytest.mark.parametrize("nlevels,sf,ini,mn", [(1, 1.2, 20, 7), (4, 1.5, 30, 10), (8, 1.2, 7, 7), (6, 1.1, 20, 0)])
+def test_other_parameters(nlevels, sf, ini, mn):
+    img = synth.make_stream(1, 360, 480)[0]
+    gpu = ORBextractor(800, sf, nlevels, ini, mn)
+    assert_same(gpu(img, None, (0, 1000)), po.OracleExtractor(800, sf, nlevels, ini, mn).extract(img, (0, 1000)),
+                f"L{nlevels} sf{sf}")
+    t = po.OracleExtractor(800, sf, nlevels, ini, mn).tables()
+    assert np.array_equal(gpu.GetScaleFactors(), t["scale"]) and np.array_equal(gpu.features_per_level(), t["quota"])
+    assert np.array_equal(gpu.GetInverseScaleSigmaSquares(), t["inv_sigma2"])
+
+
+def test_strided_input_and_roi():
+    big = synth.make_stream(1, 600, 800)[0]
+    roi = big[60:540, 80:720]            # non-contiguous rows, like a cv::Mat ROI with step > cols
+    assert not roi.flags["C_CONTIGUOUS"]
+    gpu = ORBextractor(1000, 1.2, 8, 20, 7)
+    assert_same(gpu(roi, None, (0, 1000)), po.OracleExtractor(1000, 1.2, 8, 20, 7).extract(np.ascontiguousarray(roi), (0, 1000)))
+
+
+def test_empty_and_invalid_inputs():
+    gpu = ORBextractor(1000, 1.2, 8, 20, 7)
+    mono, kps, desc = gpu(np.zeros((0, 0), np.uint8))
+    assert mono == -1 and len(kps) == 0 and desc.shape == (0, 32)        # src/ORBextractor.cc:1090-1091
+    with pytest.raises(OrbxError):
+        gpu(np.zeros((60, 60), np.uint8))                                  # too small for 8 levels: rejected loudly
+    with pytest.raises(OrbxError):
+        ORBextractor(0, 1.2, 8, 20, 7)
+
+
+def test_batch_equals_single_and_is_order_independent():
+    frames = synth.make_stream(6)
+    gpu = ORBextractor(1000, 1.2, 8, 20, 7)
+    ora = po.OracleExtractor(1000, 1.2, 8, 20, 7)
+    res = gpu.extract_batch(frames, (0, 1000))
+    for t in range(6):
+        assert_same(res[t], ora.extract(frames[t], (0, 1000)), f"batch f{t}")
+    perm = np.array([4, 2, 5, 0, 3, 1])
+    res2 = gpu.extract_batch(frames[perm], (0, 1000))
+    for i, t in enumerate(perm):
+        assert res2[i][0] == res[t][0] and res2[i][1].tobytes() == res[t][1].tobytes() and np.array_equal(res2[i][2], res[t][2])
+    again = gpu.extract_batch(frames, (0, 1000))       # idempotent: persistent buffers carry no state across calls
+    for t in range(6):
+        assert again[t][1].tobytes() == res[t][1].tobytes() and np.array_equal(again[t][2], res[t][2])
+
+
+def test_shape_change_and_two_instances():
+    a, b = ORBextractor(1000, 1.2, 8, 20, 7), ORBextractor(1000, 1.2, 8, 20, 7)   # stereo: two instances live together
+    ora = po.OracleExtractor(1000, 1.2, 8, 20, 7)
+    f1, f2 = synth.make_stream(1, 480, 640)[0], synth.make_stream(1, 350, 600, synth.DEFAULT_SEED + 9)[0]
+    for img in (f1, f2, f1):
+        assert_same(a(img, None, (0, 0)), ora.extract(img, (0, 0)))
+        assert_same(b(img, None, (0, 0)), ora.extract(img, (0, 0)))
+
+
+def test_full_size_batch_properties():
+    """BASELINE full size (256 frames/step): size-independent properties + sampled bit-exact frames."""
+    B = 256
+    base = synth.make_stream(32)
+    frames = base[np.arange(B) % 32]
+    gpu = ORBextractor(1000, 1.2, 8, 20, 7)
+    res = gpu.extract_batch(frames, (0, 1000))
+    ora = po.OracleExtractor(1000, 1.2, 8, 20, 7)
+    q = gpu.features_per_level()
+    for t in range(B):
+        mono, kps, desc = res[t]
+        assert 990 <= len(kps) <= gpu.capacity and mono == 0
+        assert (kps["octave"][::-1][np.argsort(kps["octave"][::-1], kind="stable")] == np.sort(kps["octave"])).all()
+        cnt = np.bincount(kps["octave"], minlength=8)
+        assert (cnt <= q + 2).all()                                   # at most N+2 per level
+        assert (kps["angle"] >= 0).all() and (kps["angle"] < 360.001).all() and (kps["class_id"] == -1).all()
+        assert (kps["response"] >= 7).all() and (kps["response"] == np.floor(kps["response"])).all()
+        if t >= 32:                                                   # replayed frame -> identical result
+            assert kps.tobytes() == res[t - 32][1].tobytes() and np.array_equal(desc, res[t - 32][2])
+    for t in (0, 7, 19, 31):
+        assert_same(res[t], ora.extract(frames[t], (0, 1000)), f"full-size f{t}")
+
+
+def test_device_float_paths_wide_sweep():
+    """fastAtan2 and the glibc-exact cosf/sinf on far more arguments than frames produce."""
+    gpu = ORBextractor(100, 1.2, 1, 20, 7)
+    rng = np.random.default_rng(9)
+    m01 = rng.integers(-2_000_000, 2_000_000, 400_000).astype(np.float32)
+    m10 = rng.integers(-2_000_000, 2_000_000, 400_000).astype(np.float32)
+    m01[:1000] = 0; m10[1000:2000] = 0; m01[2000:2100] = m10[2000:2100]
+    ang, a, b = gpu.debug_trig(m01, m10)
+    L = po.lib()
+    import ctypes as C
+    for i in list(range(0, 4000)) + list(range(4000, 400_000, 37)):
+        ea = po.fast_atan2(float(m01[i]), float(m10[i]))
+        assert np.float32(ea).tobytes() == ang[i].tobytes(), (i, m01[i], m10[i], ea, ang[i])
+        ca, sb = po.cos_sin_deg(float(ang[i]))
+        assert np.float32(ca).tobytes() == a[i].tobytes() and np.float32(sb).tobytes() == b[i].tobytes(), (i, ang[i])
+    # dense sweep of angle values straight into cos/sin
+    deg = np.linspace(0, 360, 2_000_001, dtype=np.float64).astype(np.float32)
+    _, a, b = gpu.debug_trig(deg)
+    for i in range(0, len(deg), 997):
+        ca, sb = po.cos_sin_deg(float(deg[i]))
+        assert np.float32(ca).tobytes() == a[i].tobytes() and np.float32(sb).tobytes() == b[i].tobytes(), deg[i]

@@ -1,0 +1,103 @@
+"""GPU matcher primitives and bag of words against the oracle (which test_ref_fragments.py pins to the reference's
+own DBoW2 code): bit-exact integers, bit-identical doubles."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from orb_slam3_modified_amd import ORBextractor, ORBmatcher, ORBVocabulary, synth
+from tests.vocab_util import make_vocabulary
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def feats():
+    gpu = ORBextractor(1000, 1.2, 8, 20, 7)
+    fr = synth.make_stream(3)
+    out = [gpu(f, None, (0, 1000)) for f in fr]
+    return gpu, out
+
+
+def _grid_candidates(k0, k1, r=20.0, seed=0):
+    """CSR candidate lists like Frame::GetFeaturesInArea windows (src/Frame.cc:657-723)."""
+    rp, cand = [0], []
+    for p in k0:
+        m = np.nonzero((np.abs(k1["x"] - p["x"]) < r) & (np.abs(k1["y"] - p["y"]) < r))[0]
+        cand.extend(m.tolist()); rp.append(len(cand))
+    return np.array(rp, np.int32), np.array(cand, np.int32)
+
+
+def test_nn_csr_first_and_last_wins(feats):
+    gpu, out = feats
+    (_, k0, d0), (_, k1, d1) = out[0], out[1]
+    m = ORBmatcher(gpu)
+    rp, cand = _grid_candidates(k0, k1)
+    assert rp[-1] > 5 * len(k0)
+    for last in (False, True):
+        g = m.nn_csr(d0, d1, rp, cand, last, want_dist=True)
+        o = po.nn_csr(d0, d1, rp, cand, last)
+        for a, b, name in zip(g, o, ("best_idx", "best_dist", "second_idx", "second_dist", "dist")):
+            assert np.array_equal(a, b), (last, name)
+    # heavy ties: duplicate descriptors, long lists, empty lists
+    rng = np.random.default_rng(1)
+    t = np.repeat(d1[:50], 8, axis=0)
+    lens = rng.integers(0, 300, 200)
+    lens[::7] = 0
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    cand = rng.integers(0, len(t), rp[-1]).astype(np.int32)
+    for last in (False, True):
+        g = m.nn_csr(d0[:200], t, rp, cand, last)
+        o = po.nn_csr(d0[:200], t, rp, cand, last)
+        for a, b in zip(g, o[:4]):
+            assert np.array_equal(a, b)
+    assert (g[0][::7] == -1).all() and (g[1][::7] == 256).all()
+
+
+def test_knn2_allpairs(feats):
+    gpu, out = feats
+    m = ORBmatcher(gpu)
+    d0, d1 = out[0][2], out[2][2]
+    gi, gd = m.knn2(d0, d1)
+    oi, od = po.knn2(d0, d1)
+    assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+    gi, gd = m.knn2(d0[:5], d1[:1])      # fewer than 2 train rows
+    assert (gi[:, 1] == -1).all() and (gd[:, 1] == 256).all() and (gi[:, 0] == 0).all()
+    gi, gd = m.knn2(d0[:300], np.repeat(d1[:3], 100, axis=0))   # ties -> lower train index
+    oi, od = po.knn2(d0[:300], np.repeat(d1[:3], 100, axis=0))
+    assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+
+
+@pytest.mark.parametrize("k,L", [(10, 3), (10, 6), (3, 7), (20, 2)])
+def test_bow_transform_and_scores(feats, tmp_path, k, L):
+    gpu, out = feats
+    alld = np.concatenate([o[2] for o in out])
+    p = str(tmp_path / "voc.txt")
+    info = make_vocabulary(p, alld, k, L, seed=k * 10 + L)
+    gv = ORBVocabulary(gpu)
+    assert gv.loadFromTextFile(p)
+    assert gv.info()["words"] == info["words"] and gv.info()["nodes"] == info["nodes"] + 1
+    ov = po.OracleVocabulary(p)
+    bows = []
+    for ls in (0, 2, 4):
+        for o in out:
+            (gi, gvals), gfv = gv.transform(o[2], ls)
+            (oi, ovals), ofv = ov.transform(o[2], ls)
+            assert np.array_equal(gi, oi) and gvals.tobytes() == ovals.tobytes() and gfv == ofv
+            bows.append((gi, gvals))
+    for a in bows[:3]:
+        host = [gv.score(a, b) for b in bows]
+        dev = gv.score_batch(a, bows)
+        ref = [po.score_l1(a, b) for b in bows]
+        assert host == ref and dev.tolist() == ref
+
+
+def test_vocabulary_loader_rejects_garbage(feats, tmp_path):
+    gpu, _ = feats
+    p = tmp_path / "bad.txt"
+    p.write_text("99 1 0 0\n0 1 " + " ".join(["0"] * 32) + " 1.0")
+    assert not ORBVocabulary(gpu).loadFromTextFile(str(p))          # k > 20: TemplatedVocabulary.h:1359
+    assert not ORBVocabulary(gpu).loadFromTextFile(str(tmp_path / "missing.txt"))
+    good = tmp_path / "good.txt"
+    good.write_text("2 1 0 0\n0 1 " + " ".join(["0"] * 32) + " 1.5\n0 1 " + " ".join(["255"] * 32) + " 2.5\n\n")  # trailing blank lines
+    v = ORBVocabulary(gpu)
+    assert v.loadFromTextFile(str(good)) and v.info()["words"] == 2   # no phantom node

@@ -1,0 +1,193 @@
+"""Known-answer tests of the CPU oracle's primitives (hand-checkable micro-cases, SURVEY.md §8(c) golden (ii)-(iv))."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+
+
+def test_tables_match_survey():
+    t = po.OracleExtractor(1000, 1.2, 8, 20, 7).tables()
+    assert t["quota"].tolist() == [217, 181, 151, 126, 105, 87, 73, 60]
+    assert t["umax"].tolist() == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+    assert t["scale"][0] == 1.0 and abs(t["scale"][7] - 3.583182) < 1e-5
+    t5 = po.OracleExtractor(5000, 1.2, 8, 20, 7).tables()
+    assert t5["quota"].tolist() == [1086, 905, 754, 628, 524, 436, 364, 303]
+    t2 = po.OracleExtractor(2000, 1.2, 8, 20, 7).tables()
+    assert t2["quota"].tolist() == [434, 362, 302, 251, 209, 175, 145, 122]
+
+
+def test_gaussian_kernel_fixed_point():
+    assert po.gaussian_kernel7().tolist() == [18, 34, 48, 56, 48, 34, 18]
+
+
+def test_gaussian_blur_constant_and_impulse():
+    img = np.full((20, 24), 93, np.uint8)
+    assert (po.gaussian_blur7(img) == 93).all()
+    imp = np.zeros((21, 21), np.uint8)
+    imp[10, 10] = 255
+    out = po.gaussian_blur7(imp)
+    k = np.array([18, 34, 48, 56, 48, 34, 18], np.int64)
+    exp = (np.outer(k, k) * 255 + 32768) >> 16
+    assert np.array_equal(out[7:14, 7:14], exp)
+    # reflect-101 at the border: impulse at column 1 is mirrored into the kernel support twice for x=0..
+    imp = np.zeros((9, 9), np.uint8)
+    imp[4, 0] = 200
+    out = po.gaussian_blur7(imp)
+    # horizontal weights at x=0: taps -3..3 map to 3,2,1,0,1,2,3 -> only tap 0 hits column 0
+    assert out[4, 0] == ((56 * 200) * 56 + 32768) >> 16
+    assert out[4, 1] == ((48 * 200) * 56 + 32768) >> 16   # taps -1 -> col 0 (weight k[2]=48); tap -3 -> col 2
+
+
+def test_fast_known_corner():
+    # dark 9-arc: centre 100, circle pixels k=0..8 at 60, rest 100 -> A = 40, score 39
+    img = np.full((7, 7), 100, np.uint8)
+    circle = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1),
+              (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+    for k in range(9):
+        dx, dy = circle[k]
+        img[3 + dy, 3 + dx] = 60
+    kp = po.fast(img, 20)
+    assert len(kp) == 1 and kp[0]["x"] == 3 and kp[0]["y"] == 3 and kp[0]["response"] == 39
+    assert kp[0]["size"] == 7 and kp[0]["angle"] == -1 and kp[0]["class_id"] == -1
+    assert len(po.fast(img, 40)) == 0 and len(po.fast(img, 39)) == 1
+    img2 = img.copy()
+    dx, dy = circle[4]
+    img2[3 + dy, 3 + dx] = 100   # break the arc: 4 + 4 only
+    assert len(po.fast(img2, 7)) == 0
+    # bright arc
+    img3 = np.full((7, 7), 100, np.uint8)
+    for k in range(5, 14):
+        dx, dy = circle[k]
+        img3[3 + dy, 3 + dx] = 130
+    kp = po.fast(img3, 7)
+    assert len(kp) == 1 and kp[0]["response"] == 29
+
+
+def test_fast_constant_image_and_nms():
+    assert len(po.fast(np.full((40, 40), 50, np.uint8), 7)) == 0
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (48, 52)).astype(np.uint8)
+    all_c = po.fast(img, 10, nms=False)
+    nms = po.fast(img, 10, nms=True)
+    assert 0 < len(nms) < len(all_c)
+    pts = {(int(k["x"]), int(k["y"])) for k in nms}
+    for (x, y) in pts:   # survivors are never 8-adjacent
+        assert not any((x + dx, y + dy) in pts for dx in (-1, 0, 1) for dy in (-1, 0, 1) if (dx, dy) != (0, 0))
+    xs, ys = nms["x"], nms["y"]
+    assert xs.min() >= 3 and ys.min() >= 3 and xs.max() <= 52 - 4 and ys.max() <= 48 - 4
+    order = np.lexsort((xs, ys))
+    assert np.array_equal(order, np.arange(len(nms)))  # row-major emission
+
+
+def test_resize_linear_properties():
+    img = np.full((40, 60), 171, np.uint8)
+    assert (po.resize_linear(img, 50, 33) == 171).all()
+    ramp = np.tile(np.arange(120, dtype=np.uint8), (30, 1))
+    out = po.resize_linear(ramp, 100, 25)
+    # exact fixed-point arithmetic of one pixel: dx=10 -> fx=(10.5*1.2-0.5)=12.1
+    fx = np.float32((10 + 0.5) * (1.0 / (100 / 120)) - 0.5)
+    sx = int(math.floor(fx)); f = np.float32(fx - sx)
+    a0, a1 = int(np.rint((np.float32(1) - f) * np.float32(2048))), int(np.rint(f * np.float32(2048)))
+    h = sx * a0 + (sx + 1) * a1
+    fy = np.float32((3 + 0.5) * (1.0 / (25 / 30)) - 0.5)
+    fyf = np.float32(fy - math.floor(fy))
+    b0, b1 = int(np.rint((np.float32(1) - fyf) * np.float32(2048))), int(np.rint(fyf * np.float32(2048)))
+    exp = (((b0 * (h >> 4)) >> 16) + ((b1 * (h >> 4)) >> 16) + 2) >> 2
+    assert out[3, 10] == exp
+    assert (np.diff(out[0].astype(int)) >= 0).all()
+
+
+def test_fast_atan2_quadrants():
+    assert po.fast_atan2(0.0, 1.0) == 0.0
+    assert abs(po.fast_atan2(1.0, 0.0) - 90.0) < 1e-4
+    assert abs(po.fast_atan2(0.0, -1.0) - 180.0) < 1e-4
+    assert abs(po.fast_atan2(-1.0, 0.0) - 270.0) < 1e-4
+    for deg in range(0, 360, 7):
+        r = math.radians(deg)
+        a = po.fast_atan2(1000 * math.sin(r), 1000 * math.cos(r))
+        assert abs(((a - deg + 180) % 360) - 180) < 0.02  # polynomial accuracy ~0.01 deg
+    assert po.fast_atan2(0.0, 0.0) == 0.0
+
+
+def test_descriptor_axis_aligned_rotations():
+    """Steered BRIEF on a linear ramp: at angle 0 the test (x0,y0)<(x1,y1) reduces to comparing x (ramp along x)."""
+    pat = po.pattern().reshape(256, 4)
+    ex = po.OracleExtractor(50, 1.2, 1, 20, 7)
+    # build an image whose blurred version is still a ramp in the interior: I = 2*x (blur of a linear ramp is the ramp)
+    H, W = 96, 96
+    img = np.tile((np.arange(W) * 2).astype(np.uint8), (H, 1))
+    blurred = po.gaussian_blur7(img)
+    assert np.array_equal(blurred[10:-10, 10:-10], img[10:-10, 10:-10])
+    a, b = po.cos_sin_deg(0.0)
+    assert a == 1.0 and b == 0.0
+    bits = [(int(p[0]) < int(p[2])) for p in pat]   # tap0 < tap1 <=> x0 < x1 on I = 2x
+    exp = np.packbits(np.array(bits, np.uint8), bitorder="little")
+    assert exp.shape == (32,)
+    a90, b90 = po.cos_sin_deg(90.0)
+    assert abs(a90) < 1e-7 and b90 == 1.0
+
+
+def test_hamming_vectors():
+    z, o = np.zeros(32, np.uint8), np.full(32, 255, np.uint8)
+    assert po.hamming(z, o) == 256 and po.hamming(z, z) == 0
+    for bit in (0, 7, 100, 255):
+        v = z.copy()
+        v[bit // 8] |= 1 << (bit % 8)
+        assert po.hamming(z, v) == 1
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        a, b = rng.integers(0, 256, 32).astype(np.uint8), rng.integers(0, 256, 32).astype(np.uint8)
+        assert po.hamming(a, b) == int(np.unpackbits(a ^ b).sum())
+
+
+def test_quadtree_two_points_and_quota():
+    c = np.zeros(2, po.KP_DTYPE)
+    c["x"], c["y"], c["response"] = [10, 400], [10, 300], [30, 40]
+    r = po.distribute(c, 16, 16 + 608, 16, 16 + 448, 217)
+    assert len(r) == 2 and sorted(r["response"].tolist()) == [30, 40]
+    r1 = po.distribute(c, 16, 16 + 608, 16, 16 + 448, 1)   # N=1: still one full pass -> both survive in separate nodes
+    assert len(r1) == 2
+    # both points in the same quadrant: the first split yields ONE child, the list size does not change and the
+    # reference stops (src/ORBextractor.cc:685) -> a single node, best response wins
+    c["x"], c["y"] = [10, 300], [10, 200]
+    r3 = po.distribute(c, 16, 16 + 608, 16, 16 + 448, 217)
+    assert len(r3) == 1 and r3[0]["response"] == 40
+    same = np.zeros(3, po.KP_DTYPE)
+    same["x"], same["y"], same["response"] = [5, 6, 7], [5, 5, 5], [20, 50, 50]
+    r2 = po.distribute(same, 16, 16 + 608, 16, 16 + 448, 1)
+    assert len(r2) >= 1
+
+
+def test_bow_handbuilt_vocabulary(tmp_path):
+    """2-level k=2 vocabulary in the reference text format, no trailing newline."""
+    from orb_slam3_modified_amd.vocabulary import write_text_vocabulary
+    z = np.zeros(32, np.uint8); o = np.full(32, 255, np.uint8)
+    half = np.concatenate([np.zeros(12, np.uint8), np.full(20, 255, np.uint8)])
+    tie = np.concatenate([np.zeros(16, np.uint8), np.full(16, 255, np.uint8)])  # equidistant from z and o
+    q = np.concatenate([np.full(8, 255, np.uint8), np.zeros(24, np.uint8)])
+    # nodes: 1(z),2(o) children of root; 3(z),4(q) children of 1; 5(o),6(half) children of 2
+    parent = [0, 0, 1, 1, 2, 2]
+    leaf = [0, 0, 1, 1, 1, 1]
+    desc = [z, o, z, q, o, half]
+    w = [0, 0, 1.0, 2.0, 3.0, 0.5]
+    p = str(tmp_path / "voc.txt")
+    write_text_vocabulary(p, 2, 2, parent, leaf, desc, w)
+    assert not open(p).read().endswith("\n")
+    v = po.OracleVocabulary(p)
+    tw, _, tn = v.descend(tie[None], 1)
+    assert tw.tolist() == [0] and tn.tolist() == [1]   # strict `<`: the first minimum wins (TemplatedVocabulary.h:1243)
+    feats = np.stack([z, q, o, half, z])
+    word, weight, node = v.descend(feats, 1)
+    assert word.tolist() == [0, 1, 2, 3, 0] and weight.tolist() == [1.0, 2.0, 3.0, 0.5, 1.0]
+    assert node.tolist() == [1, 1, 2, 2, 1]
+    (ids, vals), fv = v.transform(feats, 1)
+    assert ids.tolist() == [0, 1, 2, 3]
+    assert np.allclose(vals, np.array([2.0, 2.0, 3.0, 0.5]) / 7.5) and abs(vals.sum() - 1) < 1e-15
+    assert fv == {1: [0, 1, 4], 2: [2, 3]}
+    assert abs(po.score_l1((ids, vals), (ids, vals)) - 1.0) < 1e-15
+    other = (np.array([0, 3], np.uint32), np.array([0.5, 0.5]))
+    s = po.score_l1((ids, vals), other)
+    exp = -0.5 * ((abs(vals[0] - 0.5) - vals[0] - 0.5) + (abs(vals[3] - 0.5) - vals[3] - 0.5))
+    assert abs(s - exp) < 1e-15

@@ -20,7 +20,7 @@ def _hamming_matrix(a: np.ndarray, b: np.ndarray) -> np.ndarray:
 def make_vocabulary(path: str, descriptors: np.ndarray, k: int = 10, L: int = 3, seed: int = 0, zero_weight_frac=0.02):
     rng = np.random.default_rng(seed)
     d = np.ascontiguousarray(descriptors, np.uint8).reshape(-1, 32)
-    parent, is_leaf, desc, weight = [], [], [], []
+    parent, is_leaf, desc, weight, depth = [], [], [], [], []
 
     def expand(pid: int, idx: np.ndarray, level: int):
         kk = min(k, len(idx))
@@ -32,7 +32,7 @@ def make_vocabulary(path: str, descriptors: np.ndarray, k: int = 10, L: int = 3,
         centers ^= (flip * (1 << rng.integers(0, 8, centers.shape))).astype(np.uint8)
         first = len(parent) + 1
         for c in range(kk):
-            parent.append(pid); is_leaf.append(0); desc.append(centers[c]); weight.append(0.0)
+            parent.append(pid); is_leaf.append(0); desc.append(centers[c]); weight.append(0.0); depth.append(level + 1)
         assign = _hamming_matrix(d[idx], centers).argmin(1)
         for c in range(kk):
             nid = first + c
@@ -49,4 +49,5 @@ def make_vocabulary(path: str, descriptors: np.ndarray, k: int = 10, L: int = 3,
 
     expand(0, np.arange(len(d)), 0)
     write_text_vocabulary(path, k, L, parent, is_leaf, desc, weight)
-    return dict(nodes=len(parent), words=int(sum(is_leaf)))
+    return dict(nodes=len(parent), words=int(sum(is_leaf)),
+                min_leaf_depth=min(dp for dp, lf in zip(depth, is_leaf) if lf))
