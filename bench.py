@@ -45,7 +45,8 @@ def algorithmic_bytes(rows, cols, n_keypoints_per_frame, n_candidates_per_frame)
         "k_fast_cells": P + 4 * n_candidates_per_frame,               # one read of the pyramid + packed candidates out
         "k_quadtree": 4 * n_candidates_per_frame * 2,                 # gather candidates + final read (points stay in L2)
         "k_assemble": 8 * n_keypoints_per_frame,
-        "k_describe": (43 * 43 + 60) * n_keypoints_per_frame,         # 43x43 u8 patch in, 32 B desc + 28 B keypoint out
+        "k_blur7": 2 * P,                                              # read every level once, write its blurred copy
+        "k_describe": (961 + 1369 + 60) * n_keypoints_per_frame,       # 31x31 patch + taps within 37x37 + 60 B out
     }
     return fused, staged
 
@@ -66,7 +67,7 @@ def cpu_baseline(frames, nfeatures, budget_s=20.0):
     dt1 = time.perf_counter() - t0
     v1 = n1 / (dt1 * 1e3)
     # all cores: frame-parallel pool, one oracle instance per thread (ctypes releases the GIL)
-    per = max(1, min(len(frames) // ncores, int(budget_s * 0.6 / max(dt1 / k1, 1e-3))))
+    per = max(1, int(round(budget_s * 0.7 / max(dt1 / k1, 1e-3) / ncores)))   # ~0.7*budget seconds of CPU work in total
     exs = [po.OracleExtractor(nfeatures, 1.2, 8, 20, 7) for _ in range(ncores)]
 
     def work(t):

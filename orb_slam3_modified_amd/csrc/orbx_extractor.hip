@@ -59,8 +59,8 @@ static int build_geometry(orbx_ctx* ctx, int rows, int cols, Geometry& geo) {
   geo.rows = rows; geo.cols = cols; geo.nlevels = ctx->nlevels;
   if (rows > kMaxDim || cols > kMaxDim) return set_err(ctx, ORBX_E_INVALID, "image larger than 4095 px per side");
   geo.lv.resize(ctx->nlevels);
-  int cand_off = 0, kp_off = 0;
-  int64_t plane_off = 0;
+  int cand_off = 0, kp_off = 0, btile = 0;
+  int64_t plane_off = 0, bplane_off = 0;
   for (int l = 0; l < ctx->nlevels; l++) {
     LevelGeom& L = geo.lv[l];
     std::memset(&L, 0, sizeof(L));
@@ -70,6 +70,10 @@ static int build_geometry(orbx_ctx* ctx, int rows, int cols, Geometry& geo) {
     L.pitch = round_up(L.w, 64);
     L.plane_off = plane_off;
     if (l > 0) plane_off += (int64_t)L.pitch * L.h;
+    L.bplane_off = bplane_off;
+    bplane_off += (int64_t)L.pitch * L.h;
+    L.btile_begin = btile; L.btiles_x = (L.w + 63) / 64; L.btiles_y = (L.h + 31) / 32;
+    btile += L.btiles_x * L.btiles_y;
     const int minB = kBorder, maxBX = L.w - kBorder, maxBY = L.h - kBorder;
     const float width = (float)(maxBX - minB), height = (float)(maxBY - minB);
     const float W = 35;
@@ -132,6 +136,8 @@ static int build_geometry(orbx_ctx* ctx, int rows, int cols, Geometry& geo) {
     }
   }
   geo.pyr_bytes = plane_off;
+  geo.blur_bytes = bplane_off;
+  geo.btiles_total = btile;
   geo.cand_total = cand_off;
   geo.kp_total = kp_off;
   return ORBX_OK;
@@ -140,7 +146,7 @@ static int build_geometry(orbx_ctx* ctx, int rows, int cols, Geometry& geo) {
 static void free_buffers(orbx_ctx* ctx) {
   auto fr = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
   fr(ctx->d_geo); fr(ctx->d_cells); fr(ctx->d_xtab); fr(ctx->d_ytab);
-  fr(ctx->d_pyr); fr(ctx->d_cand); fr(ctx->d_cell_cnt); fr(ctx->d_pts); fr(ctx->d_lvl_kp); fr(ctx->d_lvl_n); fr(ctx->d_outidx);
+  fr(ctx->d_pyr); fr(ctx->d_blur); fr(ctx->d_cand); fr(ctx->d_cell_cnt); fr(ctx->d_pts); fr(ctx->d_lvl_kp); fr(ctx->d_lvl_n); fr(ctx->d_outidx);
   ctx->batch_cap = 0;
 }
 
@@ -157,7 +163,7 @@ static int ensure_buffers(orbx_ctx* ctx, int rows, int cols, int nframes) {
   std::memset(&dg, 0, sizeof(dg));
   dg.nlevels = geo.nlevels; dg.rows = rows; dg.cols = cols;
   dg.ncells_total = (int)geo.cells.size(); dg.cand_total = geo.cand_total; dg.kp_total = geo.kp_total;
-  dg.out_cap = ctx->out_cap;
+  dg.out_cap = ctx->out_cap; dg.btiles_total = geo.btiles_total;
   for (int l = 0; l < geo.nlevels; l++) {
     const LevelGeom& L = geo.lv[l];
     DeviceLevel& D = dg.lv[l];
@@ -166,6 +172,7 @@ static int ensure_buffers(orbx_ctx* ctx, int rows, int cols, int nframes) {
     D.quota = L.quota; D.kp_off = L.kp_off; D.kp_cap = L.kp_cap; D.nroots = L.nroots;
     for (int i = 0; i < kMaxRoots; i++) { D.root_x0[i] = L.root_x0[i]; D.root_x1[i] = L.root_x1[i]; }
     D.hX = L.hX; D.scale = L.scale; D.scaled_patch = L.scaled_patch; D.xtab_off = L.xtab_off; D.ytab_off = L.ytab_off;
+    D.bplane_off = L.bplane_off; D.btile_begin = L.btile_begin; D.btiles_x = L.btiles_x; D.btiles_y = L.btiles_y; D.pad_ = 0;
   }
   ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_geo, sizeof(DeviceGeom)));
   ORBX_HIP(ctx, hipMemcpy(ctx->d_geo, &dg, sizeof(dg), hipMemcpyHostToDevice));
@@ -179,6 +186,7 @@ static int ensure_buffers(orbx_ctx* ctx, int rows, int cols, int nframes) {
   }
   const size_t B = (size_t)nframes;
   ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_pyr, std::max<size_t>(B * (size_t)geo.pyr_bytes, 64)));
+  ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_blur, B * (size_t)geo.blur_bytes));
   ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_cand, B * geo.cand_total * sizeof(uint32_t)));
   ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_cell_cnt, B * geo.cells.size() * sizeof(int32_t)));
   ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_pts, B * 2 * geo.cand_total * sizeof(uint32_t)));
@@ -239,13 +247,15 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int nframes, in
   // K2: FAST cells
   {
     ProfScope ps(ctx, 1, st);
-    const int tile_pitch = round_up(geo.max_cell_w, 4);
+    const int tile_pitch = round_up(geo.max_cell_w + 3, 4);  // +3: alignment shift of the dword-staged rows
     const int tile_rows = geo.max_cell_h;
-    const size_t lds = (size_t)tile_pitch * tile_rows * 3;
+    const int list_cap = round_up((geo.max_cell_w - 6) * (geo.max_cell_h - 6), 8);
+    if (list_cap > 8192) return set_err(ctx, ORBX_E_CAPACITY, "FAST cell larger than 8192 px");
+    const size_t lds = (size_t)tile_pitch * tile_rows * 2 + (size_t)list_cap * 2;
     dim3 grid((unsigned)geo.cells.size(), nframes, 1);
     hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), lds, st, ctx->d_geo, ctx->d_cells, d_imgs, (long long)row_stride,
                        (long long)frame_stride, ctx->d_pyr, (long long)geo.pyr_bytes, ctx->d_cand, ctx->d_cell_cnt,
-                       ctx->ini_th, ctx->min_th, tile_pitch, tile_rows);
+                       ctx->ini_th, ctx->min_th, tile_pitch, tile_rows, list_cap);
   }
   // K3: quadtree
   {
@@ -267,15 +277,28 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int nframes, in
     hipLaunchKernelGGL(k_assemble, dim3(nframes), dim3(256), (size_t)ctx->out_cap * 8 + 64, st, ctx->d_geo, ctx->d_lvl_kp,
                        ctx->d_lvl_n, ctx->d_outidx, d_counts, lap0, lap1);
   }
-  // K4: orientation + descriptors
+  // K4a: 7x7 fixed-point Gaussian of every level (the reference blurs each level that holds keypoints)
   {
     ProfScope ps(ctx, 4, st);
+    int gk[7];
+    gaussian_kernel7(gk);
+    BlurConsts bc;
+    bc.w0 = (uint32_t)gk[0] | ((uint32_t)gk[1] << 8) | ((uint32_t)gk[2] << 16) | ((uint32_t)gk[3] << 24);
+    bc.w1 = (uint32_t)gk[4] | ((uint32_t)gk[5] << 8) | ((uint32_t)gk[6] << 16);
+    for (int i = 0; i < 7; i++) bc.k[i] = gk[i];
+    dim3 grid(geo.btiles_total, nframes, 1);
+    hipLaunchKernelGGL(k_blur7, grid, dim3(256), 0, st, ctx->d_geo, d_imgs, (long long)row_stride, (long long)frame_stride,
+                       ctx->d_pyr, (long long)geo.pyr_bytes, ctx->d_blur, (long long)geo.blur_bytes, bc);
+  }
+  // K4b: orientation + descriptors
+  {
+    ProfScope ps(ctx, 5, st);
     DescConsts dc;
     for (int i = 0; i < 16; i++) dc.umax[i] = ctx->umax[i];
-    gaussian_kernel7(dc.gk);
     dim3 grid((ctx->out_cap + 3) / 4, nframes, 1);
     hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, st, ctx->d_geo, d_imgs, (long long)row_stride, (long long)frame_stride,
-                       ctx->d_pyr, (long long)geo.pyr_bytes, ctx->d_lvl_kp, ctx->d_lvl_n, ctx->d_outidx, d_kps, d_desc, dc);
+                       ctx->d_pyr, (long long)geo.pyr_bytes, ctx->d_blur, (long long)geo.blur_bytes, ctx->d_lvl_kp, ctx->d_lvl_n,
+                       ctx->d_outidx, d_kps, d_desc, dc);
   }
   ORBX_HIP(ctx, hipGetLastError());
   return ORBX_OK;
@@ -544,7 +567,7 @@ int orbx_debug_trig(orbx_ctx* ctx, const float* y, const float* x, int n, int an
 
 const char* orbx_kernel_name(int slot) {
   static const char* names[ORBX_NUM_KERNELS] = {"k_resize(pyramid chain)", "k_fast_cells", "k_quadtree", "k_assemble",
-                                                "k_describe", "reserved"};
+                                                "k_blur7", "k_describe"};
   return slot >= 0 && slot < ORBX_NUM_KERNELS ? names[slot] : "";
 }
 

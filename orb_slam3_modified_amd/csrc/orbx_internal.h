@@ -38,6 +38,8 @@ struct LevelGeom {
   float hX, scale;
   int scaled_patch;         // (int)(PATCH_SIZE*scale): KeyPoint::size
   int xtab_off, ytab_off;   // offsets into the device resize tables (entries)
+  int64_t bplane_off;       // byte offset of this level inside one frame's BLURRED pyramid block (all levels)
+  int btile_begin, btiles_x, btiles_y;  // 64x32 tiles of the blur kernel
 };
 
 struct CellGeom {
@@ -52,6 +54,8 @@ struct Geometry {
   std::vector<CellGeom> cells;
   std::vector<XTab> xtab, ytab;
   int64_t pyr_bytes = 0;      // per frame, levels >= 1
+  int64_t blur_bytes = 0;     // per frame, all levels
+  int btiles_total = 0;
   int cand_total = 0;         // per frame
   int kp_total = 0;           // per frame (sum of kp_cap)
   int max_cell_w = 0, max_cell_h = 0, max_cells_per_level = 0, max_quota = 0;
@@ -64,10 +68,12 @@ struct DeviceLevel {  // POD copy of LevelGeom fields the kernels need
   int root_x0[kMaxRoots], root_x1[kMaxRoots];
   float hX, scale;
   int scaled_patch, xtab_off, ytab_off;
+  long long bplane_off;
+  int btile_begin, btiles_x, btiles_y, pad_;
 };
 
 struct DeviceGeom {
-  int nlevels, rows, cols, ncells_total, cand_total, kp_total, out_cap;
+  int nlevels, rows, cols, ncells_total, cand_total, kp_total, out_cap, btiles_total;
   DeviceLevel lv[kMaxLevels];
 };
 
@@ -92,6 +98,7 @@ struct orbx_ctx {
   orbx::XTab* d_ytab = nullptr;
   int batch_cap = 0;
   uint8_t* d_pyr = nullptr;        // [batch][pyr_bytes]
+  uint8_t* d_blur = nullptr;       // [batch][blur_bytes] 7x7 Gaussian of every level
   uint32_t* d_cand = nullptr;      // [batch][cand_total]
   int32_t* d_cell_cnt = nullptr;   // [batch][ncells]
   uint32_t* d_pts = nullptr;       // [batch][2][cand_total]  quadtree ping-pong

@@ -6,8 +6,9 @@
 //   k_quadtree    : per (frame, level): DistributeOctTree as flat list + segment partition (ballot ranks),
 //                   libstdc++-exact sort for the tie order.
 //   k_assemble    : per frame: output slot of every keypoint (mono side ascending / lapping side descending).
-//   k_describe    : per keypoint (one wave): 43x43 patch in LDS -> IC angle -> 7x7 fixed-point blur of the
-//                   37x37 neighbourhood -> 256 steered tests, one wave ballot = 8 descriptor bytes.
+//   k_blur7       : 7x7 fixed-point Gaussian of every level, 64x32 LDS tiles, v_dot4_u32_u8 horizontal pass.
+//   k_describe    : per keypoint (one wave): 31x31 patch in LDS -> IC angle; 512 taps gathered from the blurred
+//                   level -> 256 steered tests, one wave ballot = 8 descriptor bytes.
 //
 // Float code relies on -ffp-contract=off (no FMA fusion) and IEEE division; see DESIGN.md "bit-exactness".
 #include <hip/hip_runtime.h>
@@ -74,17 +75,33 @@ __device__ __forceinline__ int fast_score16(int v, const int (&p)[16]) {
   return max(A, -B) - 1;
 }
 
+// pixel index inside the detection domain -> (row, column); exact for i < 2^23
+__device__ __forceinline__ void idx2d(int i, int dw, float inv_dw, int& y, int& x) {
+  y = (int)((float)i * inv_dw);
+  if (y * dw > i) y--;
+  if ((y + 1) * dw <= i) y++;
+  x = i - y * dw;
+}
+
+// Work-efficient structure: only ~5 % of the pixels are corners at minTh, so (1) every pixel takes a 5-read
+// necessary test (two opposite pairs of the circle: a 9-arc always contains one pixel of each opposite pair),
+// (2) the survivors (~20 %) are compacted into an LDS list and only they pay for the exact 16-pixel score,
+// (3) NMS and the iniTh/minTh selection run on the list, (4) the ordered (row-major) output order is rebuilt
+// from a bitmap + popcount prefix instead of a pass over all pixels.
 __global__ __launch_bounds__(256) void k_fast_cells(const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
                                                     const uint8_t* __restrict__ imgs, long long img_row_stride,
                                                     long long img_frame_stride, const uint8_t* __restrict__ pyr,
                                                     long long pyr_frame_bytes, uint32_t* __restrict__ cand,
                                                     int32_t* __restrict__ cell_cnt, int ini_th, int min_th, int tile_pitch,
-                                                    int tile_rows) {
+                                                    int tile_rows, int list_cap) {
   extern __shared__ __align__(16) uint8_t smem[];
-  uint8_t* tile = smem;                                  // [tile_rows][tile_pitch] raw pixels
-  uint8_t* sc = tile + tile_rows * tile_pitch;           // [tile_rows][tile_pitch] scores, 1-px zero frame
-  uint8_t* sv = sc + tile_rows * tile_pitch;             // survivors (score or 0), same layout
+  uint8_t* tile = smem;                                  // [tile_rows][tile_pitch] raw pixels (+ alignment shift xo)
+  uint8_t* sc = tile + tile_rows * tile_pitch;           // [tile_rows][tile_pitch] scores with a 1-px zero frame
+  uint16_t* list = (uint16_t*)(sc + tile_rows * tile_pitch);  // candidate pixel indices (bit 15: NMS survivor)
+  __shared__ uint32_t bitmap[256];
+  __shared__ int wpre[256];
   __shared__ int wave_tot[4];
+  __shared__ int s_cnt;
 
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int frame = blockIdx.y;
@@ -95,23 +112,52 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DeviceGeom* __restrict
   if (cg.level == 0) { img = imgs + (long long)frame * img_frame_stride; pitch = img_row_stride; }
   else { img = pyr + (long long)frame * pyr_frame_bytes + lv.plane_off; pitch = lv.pitch; }
   const int cw = cg.cw, ch = cg.ch, dw = cw - 6, dh = ch - 6;
-  const uint8_t* src = img + (long long)cg.y0 * pitch + cg.x0;
-  // stage the (cw x ch) sub-image; clear the score frame
-  for (int i = t; i < cw * ch; i += 256) {
-    const int r = i / cw, c = i - r * cw;
-    tile[r * tile_pitch + c] = src[(long long)r * pitch + c];
-  }
-  for (int i = t; i < (dh + 2) * tile_pitch; i += 256) sc[i] = 0;
-  __syncthreads();
   const int npx = dw * dh;
   const float inv_dw = 1.0f / (float)dw;
-  // score map over the detection domain (local x in [3,cw-4], y in [3,ch-4])
-  for (int i = t; i < npx; i += 256) {
-    int y = (int)((float)i * inv_dw);
-    if (y * dw > i) y--;
-    if ((y + 1) * dw <= i) y++;
-    const int x = i - y * dw;
-    const uint8_t* c0 = tile + (y + 3) * tile_pitch + (x + 3);
+  // ---- A: stage the sub-image with aligned dword loads when the source allows it
+  const bool al = ((pitch & 3) == 0) && ((((unsigned long long)img) & 3) == 0);
+  const int xo = al ? (cg.x0 & 3) : 0;
+  if (al) {
+    const uint8_t* src = img + (long long)cg.y0 * pitch + (cg.x0 - xo);
+    const int ndw = (xo + cw + 3) >> 2, tp4 = tile_pitch >> 2;
+    for (int r = t >> 4; r < ch; r += 16)
+      for (int c = t & 15; c < ndw; c += 16)
+        ((uint32_t*)tile)[r * tp4 + c] = *(const uint32_t*)(src + (long long)r * pitch + 4 * c);
+  } else {
+    const uint8_t* src = img + (long long)cg.y0 * pitch + cg.x0;
+    for (int r = t >> 6; r < ch; r += 4)
+      for (int c = lane; c < cw; c += 64) tile[r * tile_pitch + c] = src[(long long)r * pitch + c];
+  }
+  for (int i = t; i < ((dh + 2) * tile_pitch) >> 2; i += 256) ((uint32_t*)sc)[i] = 0;
+  bitmap[t] = 0;
+  if (t == 0) s_cnt = 0;
+  __syncthreads();
+  // ---- B: necessary test on two opposite pairs, compaction of the passing pixels (unordered)
+  for (int i0 = 0; i0 < npx; i0 += 256) {
+    const int i = i0 + t;
+    bool pass = false;
+    if (i < npx) {
+      int y, x;
+      idx2d(i, dw, inv_dw, y, x);
+      const uint8_t* c0 = tile + (y + 3) * tile_pitch + (x + 3 + xo);
+      const int v = c0[0], p0 = c0[3 * tile_pitch], p8 = c0[-3 * tile_pitch], p4 = c0[3], p12 = c0[-3];
+      const int lo = v - min_th, hi = v + min_th;
+      pass = (max(min(p0, p8), min(p4, p12)) < lo) || (min(max(p0, p8), max(p4, p12)) > hi);
+    }
+    const unsigned long long b = __ballot(pass);
+    int base = 0;
+    if (lane == 0 && b) base = atomicAdd(&s_cnt, __popcll(b));
+    base = __shfl(base, 0);
+    if (pass) list[base + __popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)i;
+  }
+  __syncthreads();
+  const int n1 = s_cnt;
+  // ---- C: exact score of the listed pixels
+  for (int e = t; e < n1; e += 256) {
+    const int i = list[e];
+    int y, x;
+    idx2d(i, dw, inv_dw, y, x);
+    const uint8_t* c0 = tile + (y + 3) * tile_pitch + (x + 3 + xo);
     const int v = c0[0];
     int p[16];
     p[0] = c0[3 * tile_pitch];       p[1] = c0[3 * tile_pitch + 1];   p[2] = c0[2 * tile_pitch + 2];
@@ -120,55 +166,67 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DeviceGeom* __restrict
     p[9] = c0[-3 * tile_pitch - 1];  p[10] = c0[-2 * tile_pitch - 2]; p[11] = c0[-tile_pitch - 3];
     p[12] = c0[-3];                  p[13] = c0[tile_pitch - 3];      p[14] = c0[2 * tile_pitch - 2];
     p[15] = c0[3 * tile_pitch - 1];
-    int s = fast_score16(v, p);
-    if (s < min_th) s = 0;
-    sc[(y + 1) * tile_pitch + (x + 1)] = (uint8_t)s;
+    const int s = fast_score16(v, p);
+    if (s >= min_th && s > 0) sc[(y + 1) * tile_pitch + (x + 1)] = (uint8_t)s;
   }
   __syncthreads();
-  // 3x3 strict NMS inside the cell (neighbours outside the detection domain are 0)
+  // ---- D: 3x3 strict NMS inside the cell (neighbours outside the detection domain are 0)
   int any_ini = 0;
-  for (int i = t; i < npx; i += 256) {
-    int y = (int)((float)i * inv_dw);
-    if (y * dw > i) y--;
-    if ((y + 1) * dw <= i) y++;
-    const int x = i - y * dw;
+  for (int e = t; e < n1; e += 256) {
+    const int i = list[e];
+    int y, x;
+    idx2d(i, dw, inv_dw, y, x);
     const uint8_t* q = sc + (y + 1) * tile_pitch + (x + 1);
     const int s = q[0];
-    int keep = 0;
-    if (s > 0) {
-      keep = s > q[-1] && s > q[1] && s > q[-tile_pitch - 1] && s > q[-tile_pitch] && s > q[-tile_pitch + 1] &&
-             s > q[tile_pitch - 1] && s > q[tile_pitch] && s > q[tile_pitch + 1];
+    if (s > 0 && s > q[-1] && s > q[1] && s > q[-tile_pitch - 1] && s > q[-tile_pitch] && s > q[-tile_pitch + 1] &&
+        s > q[tile_pitch - 1] && s > q[tile_pitch] && s > q[tile_pitch + 1]) {
+      list[e] = (uint16_t)(i | 0x8000);
+      any_ini |= s >= ini_th;
     }
-    sv[i] = keep ? (uint8_t)s : 0;
-    any_ini |= keep && s >= ini_th;
   }
   const int use_ini = __syncthreads_or(any_ini);
   const int T = use_ini ? ini_th : min_th;
-  // ordered compaction: pixel order == thread order inside every 256-chunk
-  uint32_t* slot = cand + (long long)frame * g->cand_total + cg.slot_off;
-  int base = 0;
-  for (int c0 = 0; c0 < npx; c0 += 256) {
-    const int i = c0 + t;
-    const int s = i < npx ? sv[i] : 0;
-    const int keep = s >= T && s > 0;
-    const unsigned long long b = __ballot(keep);
-    const int rank = __popcll(b & ((1ull << lane) - 1ull));
-    if (lane == 0) wave_tot[wv] = __popcll(b);
-    __syncthreads();
-    int pre = 0, tot = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) { const int wt = wave_tot[k]; pre += k < wv ? wt : 0; tot += wt; }
-    if (keep) {
-      int y = (int)((float)i * inv_dw);
-      if (y * dw > i) y--;
-      if ((y + 1) * dw <= i) y++;
-      const int x = i - y * dw;
-      slot[base + pre + rank] = pack_pt(x + 3 + cg.relx, y + 3 + cg.rely, s);
+  // ---- E: bitmap of the selected survivors
+  for (int e = t; e < n1; e += 256) {
+    const int le = list[e];
+    if (le & 0x8000) {
+      const int i = le & 0x7fff;
+      int y, x;
+      idx2d(i, dw, inv_dw, y, x);
+      if (sc[(y + 1) * tile_pitch + (x + 1)] >= T) atomicOr(&bitmap[i >> 5], 1u << (i & 31));
     }
-    base += tot;
-    __syncthreads();
   }
-  if (t == 0) cell_cnt[(long long)frame * g->ncells_total + blockIdx.x] = base;
+  __syncthreads();
+  // ---- F: exclusive popcount prefix over the bitmap words (thread t <-> word t)
+  {
+    const int c = __popc(bitmap[t]);
+    int inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+    if (lane == 63) wave_tot[wv] = inc;
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int wt = wave_tot[k]; off += k < wv ? wt : 0; tot += wt; }
+    wpre[t] = off + inc - c;
+    if (t == 0) cell_cnt[(long long)frame * g->ncells_total + blockIdx.x] = tot;
+  }
+  __syncthreads();
+  // ---- G: row-major rank of every selected survivor -> its slot
+  uint32_t* slot = cand + (long long)frame * g->cand_total + cg.slot_off;
+  for (int e = t; e < n1; e += 256) {
+    const int le = list[e];
+    if (le & 0x8000) {
+      const int i = le & 0x7fff;
+      int y, x;
+      idx2d(i, dw, inv_dw, y, x);
+      const int s = sc[(y + 1) * tile_pitch + (x + 1)];
+      if (s >= T) {
+        const int rank = wpre[i >> 5] + __popc(bitmap[i >> 5] & ((1u << (i & 31)) - 1u));
+        slot[rank] = pack_pt(x + 3 + cg.relx, y + 3 + cg.rely, s);
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -547,21 +605,112 @@ __global__ __launch_bounds__(256) void k_assemble(const DeviceGeom* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4: orientation + blurred patch + steered BRIEF, one wave per keypoint.
+// K4a: cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) of every pyramid level (src/ORBextractor.cc:1132-1133)
+// in 8.8 fixed point.  64x32 output tile per block, raw tile (+3 halo, origin at x0-4 so rows are
+// dword aligned) in LDS; horizontal pass with v_dot4_u32_u8 on byte-aligned windows (v_alignbyte), vertical pass
+// on u16 with exact 32-bit accumulation; one dword (4 px) store per lane.
 // ------------------------------------------------------------------------------------------------
-struct DescConsts { int umax[16]; int gk[7]; };
-
-constexpr int kR = 21;            // 18 (max rotated tap reach) + 3 (blur radius)
-constexpr int kRaw = 2 * kR + 1;  // 43
-constexpr int kRawP = 44;
-constexpr int kBl = 37;           // blurred neighbourhood: taps reach +-18
-constexpr int kBlP = 40;
-constexpr int kTmpP = 38;
+struct BlurConsts { uint32_t w0, w1; int k[7]; };
 
 __device__ __forceinline__ int reflect101(int p, int n) {
   while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
   return p;
 }
+
+constexpr int kBT_W = 64, kBT_H = 32, kBT_RP = 72, kBT_RR = kBT_H + 6;  // raw tile: 38 rows x 72 bytes
+
+template <int OFF>
+__device__ __forceinline__ uint32_t bytes4(uint32_t d0, uint32_t d1, uint32_t d2) {
+  // 4 bytes starting at byte OFF (0..7) of the 12-byte little-endian window d0,d1,d2
+  if (OFF == 0) return d0;
+  if (OFF < 4) return __builtin_amdgcn_alignbyte(d1, d0, OFF);
+  if (OFF == 4) return d1;
+  return __builtin_amdgcn_alignbyte(d2, d1, OFF - 4);
+}
+
+__global__ __launch_bounds__(256) void k_blur7(const DeviceGeom* __restrict__ g, const uint8_t* __restrict__ imgs,
+                                               long long img_row_stride, long long img_frame_stride,
+                                               const uint8_t* __restrict__ pyr, long long pyr_frame_bytes,
+                                               uint8_t* __restrict__ blur, long long blur_frame_bytes, BlurConsts bc) {
+  __shared__ __align__(16) uint8_t raw[kBT_RR * kBT_RP];
+  __shared__ __align__(16) uint16_t hb[kBT_RR * kBT_W];
+  const int t = threadIdx.x, frame = blockIdx.y;
+  int l = 0;
+  while (l + 1 < g->nlevels && (int)blockIdx.x >= g->lv[l + 1].btile_begin) l++;
+  const DeviceLevel& lv = g->lv[l];
+  const int tile = blockIdx.x - lv.btile_begin;
+  const int ty = tile / lv.btiles_x, tx = tile - ty * lv.btiles_x;
+  const int x0 = tx * kBT_W, y0 = ty * kBT_H;
+  const uint8_t* img;
+  long long pitch;
+  if (l == 0) { img = imgs + (long long)frame * img_frame_stride; pitch = img_row_stride; }
+  else { img = pyr + (long long)frame * pyr_frame_bytes + lv.plane_off; pitch = lv.pitch; }
+  const int w = lv.w, h = lv.h;
+  // raw[r][c] = level(reflect(y0-3+r), reflect(x0-4+c))
+  const bool interior = x0 - 4 >= 0 && x0 + kBT_RP - 4 <= w && y0 - 3 >= 0 && y0 + kBT_H + 3 <= h &&
+                        ((pitch & 3) == 0) && ((((unsigned long long)img) & 3) == 0);
+  if (interior) {
+    for (int i = t; i < kBT_RR * (kBT_RP / 4); i += 256) {
+      const int r = i / (kBT_RP / 4), c = i - r * (kBT_RP / 4);
+      ((uint32_t*)raw)[i] = *(const uint32_t*)(img + (long long)(y0 - 3 + r) * pitch + (x0 - 4) + 4 * c);
+    }
+  } else {
+    for (int i = t; i < kBT_RR * kBT_RP; i += 256) {
+      const int r = i / kBT_RP, c = i - r * kBT_RP;
+      raw[i] = img[(long long)reflect101(y0 - 3 + r, h) * pitch + reflect101(x0 - 4 + c, w)];
+    }
+  }
+  __syncthreads();
+  // horizontal: output x (tile coords) reads raw columns x+1 .. x+7
+  for (int i = t; i < kBT_RR * (kBT_W / 4); i += 256) {
+    const int r = i >> 4, j = i & 15;
+    const uint32_t* rw = (const uint32_t*)(raw + r * kBT_RP) + j;
+    const uint32_t d0 = rw[0], d1 = rw[1], d2 = rw[2];
+    const uint32_t a0 = __builtin_amdgcn_udot4(bytes4<1>(d0, d1, d2), bc.w0, __builtin_amdgcn_udot4(bytes4<5>(d0, d1, d2), bc.w1, 0u, false), false);
+    const uint32_t a1 = __builtin_amdgcn_udot4(bytes4<2>(d0, d1, d2), bc.w0, __builtin_amdgcn_udot4(bytes4<6>(d0, d1, d2), bc.w1, 0u, false), false);
+    const uint32_t a2 = __builtin_amdgcn_udot4(bytes4<3>(d0, d1, d2), bc.w0, __builtin_amdgcn_udot4(bytes4<7>(d0, d1, d2), bc.w1, 0u, false), false);
+    // x = 4j+3 needs raw bytes 4j+4 .. 4j+10 = d1 and the low 3 bytes of d2
+    const uint32_t a3 = __builtin_amdgcn_udot4(d1, bc.w0, __builtin_amdgcn_udot4(d2, bc.w1, 0u, false), false);
+    uint2 o;
+    o.x = a0 | (a1 << 16);
+    o.y = a2 | (a3 << 16);
+    *(uint2*)(hb + r * kBT_W + 4 * j) = o;
+  }
+  __syncthreads();
+  // vertical: lane = (x group j, row pair rg): rows 2rg, 2rg+1 of the tile
+  {
+    const int j = t & 15, rg = t >> 4;
+    uint32_t lo[8], hi[8];  // 8 source rows x 4 columns (u16 pairs)
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const uint2 v = *(const uint2*)(hb + (2 * rg + r) * kBT_W + 4 * j);
+      lo[r] = v.x; hi[r] = v.y;
+    }
+#pragma unroll
+    for (int yy = 0; yy < 2; yy++) {
+      uint32_t c0 = 32768u, c1 = 32768u, c2 = 32768u, c3 = 32768u;
+#pragma unroll
+      for (int k = 0; k < 7; k++) {
+        const uint32_t kk = (uint32_t)bc.k[k];
+        c0 += kk * (lo[yy + k] & 0xffffu); c1 += kk * (lo[yy + k] >> 16);
+        c2 += kk * (hi[yy + k] & 0xffffu); c3 += kk * (hi[yy + k] >> 16);
+      }
+      const int y = y0 + 2 * rg + yy, x = x0 + 4 * j;
+      if (y < h && x < w) {
+        const uint32_t px = (c0 >> 16) | ((c1 >> 16) << 8) | ((c2 >> 16) << 16) | ((c3 >> 16) << 24);
+        *(uint32_t*)(blur + (long long)frame * blur_frame_bytes + lv.bplane_off + (long long)y * lv.pitch + x) = px;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4b: orientation + steered BRIEF, one wave per keypoint: 31x31 raw patch staged in LDS for the intensity
+// centroid, 512 taps gathered from the blurred level, one wave ballot = 8 descriptor bytes.
+// ------------------------------------------------------------------------------------------------
+struct DescConsts { int umax[16]; };
+
+constexpr int kPP = 32;  // LDS pitch of the 31x31 patch
 
 // cv::fastAtan2, degrees; separate IEEE mul/add, correctly rounded division.
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
@@ -588,12 +737,11 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__ g, const uint8_t* __restrict__ imgs,
                                                   long long img_row_stride, long long img_frame_stride,
                                                   const uint8_t* __restrict__ pyr, long long pyr_frame_bytes,
+                                                  const uint8_t* __restrict__ blur, long long blur_frame_bytes,
                                                   const uint32_t* __restrict__ lvl_kp, const int32_t* __restrict__ lvl_n,
                                                   const int32_t* __restrict__ outidx, orbx_keypoint* __restrict__ out_kps,
                                                   uint8_t* __restrict__ out_desc, DescConsts dc) {
-  __shared__ __align__(16) uint8_t s_raw[4][kRaw * kRawP];
-  __shared__ __align__(16) uint16_t s_tmp[4][kRaw * kTmpP];
-  __shared__ __align__(16) uint8_t s_blur[4][kBl * kBlP];
+  __shared__ __align__(16) uint8_t s_raw[4][kPatchSize * kPP];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int frame = blockIdx.y;
   const int gi = blockIdx.x * 4 + w;
@@ -613,25 +761,21 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
   if (l == 0) { img = imgs + (long long)frame * img_frame_stride; pitch = img_row_stride; }
   else { img = pyr + (long long)frame * pyr_frame_bytes + lv.plane_off; pitch = lv.pitch; }
   uint8_t* raw = s_raw[w];
-  uint16_t* tmp = s_tmp[w];
-  uint8_t* blur = s_blur[w];
-  // 43x43 neighbourhood, BORDER_REFLECT_101 at the level edges (only the blur margin can cross them)
-  if (lane < kRaw) {
-    const int sxc = reflect101(kx - kR + lane, lv.w);
-    for (int r = 0; r < kRaw; r++) {
-      const int syc = reflect101(ky - kR + r, lv.h);
-      raw[r * kRawP + lane] = img[(long long)syc * pitch + sxc];
-    }
+  // 31x31 patch of the un-blurred level (keypoints sit >= 19 px inside the level: no border handling)
+  if (lane < kPatchSize) {
+    const uint8_t* src = img + (long long)(ky - kHalfPatch) * pitch + (kx - kHalfPatch) + lane;
+#pragma unroll
+    for (int r = 0; r < kPatchSize; r++) raw[r * kPP + lane] = src[(long long)r * pitch];
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  // intensity centroid on the un-blurred level (src/ORBextractor.cc:76-103)
+  // intensity centroid (src/ORBextractor.cc:76-103): exact int32 moments, any summation order
   int m10 = 0, m01 = 0;
   if (lane < kPatchSize) {
     const int v = lane - kHalfPatch;
     const int um = dc.umax[v < 0 ? -v : v];
-    const uint8_t* row = raw + (kR + v) * kRawP + kR;
+    const uint8_t* row = raw + lane * kPP + kHalfPatch;
     int rs = 0;
     for (int u = -um; u <= um; u++) { const int I = row[u]; m10 += u * I; rs += I; }
     m01 = v * rs;
@@ -639,36 +783,14 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
   const float angle = fast_atan2_deg((float)m01, (float)m10);
-  // separable 7x7 fixed-point Gaussian: rows 0..42 x cols 3..39 -> tmp, then 37x37 -> blur
-  for (int i = lane; i < kRaw * kBl; i += 64) {
-    const int r = i / kBl, c = i - r * kBl;
-    const uint8_t* s = raw + r * kRawP + c;
-    uint32_t a = 0;
-#pragma unroll
-    for (int k = 0; k < 7; k++) a += (uint32_t)dc.gk[k] * s[k];
-    tmp[r * kTmpP + c] = (uint16_t)a;
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  for (int i = lane; i < kBl * kBl; i += 64) {
-    const int r = i / kBl, c = i - r * kBl;
-    const uint16_t* s = tmp + r * kTmpP + c;
-    uint32_t a = 0;
-#pragma unroll
-    for (int k = 0; k < 7; k++) a += (uint32_t)dc.gk[k] * s[k * kTmpP];
-    blur[r * kBlP + c] = (uint8_t)((a + 32768u) >> 16);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  // steered BRIEF (src/ORBextractor.cc:107-146)
+  // steered BRIEF (src/ORBextractor.cc:107-146) on the blurred level
   const float factorPI = (float)(3.14159265358979323846 / 180.f);
   const float ang = __fmul_rn(angle, factorPI);
   const float a = orbx_glibc::cosf_exact(ang), b = orbx_glibc::sinf_exact(ang);
   const int slot = outidx[(long long)frame * g->out_cap + gi];
   uint8_t* dsc = out_desc + ((long long)frame * g->out_cap + slot) * 32;
-  const uint8_t* ctr = blur + 18 * kBlP + 18;
+  const uint8_t* ctr = blur + (long long)frame * blur_frame_bytes + lv.bplane_off + (long long)ky * lv.pitch + kx;
+  const int bp = lv.pitch;
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     const int tst = q * 64 + lane;
@@ -678,7 +800,7 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
     const int rx0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
     const int ry1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
     const int rx1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-    const int t0 = ctr[ry0 * kBlP + rx0], t1 = ctr[ry1 * kBlP + rx1];
+    const int t0 = ctr[ry0 * bp + rx0], t1 = ctr[ry1 * bp + rx1];
     const unsigned long long bits = __ballot(t0 < t1);
     if (lane == 0) *(unsigned long long*)(dsc + q * 8) = bits;
   }
@@ -691,7 +813,6 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
     out_kps[(long long)frame * g->out_cap + slot] = kp;
   }
 }
-
 
 // Debug/test kernel: the two float paths of K4 in isolation (fastAtan2, then glibc-exact cosf/sinf of
 // angle*factorPI) so tests can sweep far more arguments than real frames produce.
