@@ -97,6 +97,11 @@ int orbx_debug_level_points(orbx_ctx* ctx, int frame, int level, int stage, uint
 int orbx_debug_trig(orbx_ctx* ctx, const float* y, const float* x, int n, int angle_is_input, float* angle, float* a,
                     float* b);
 
+/* Counter-calibration hook: copies nbytes (multiple of 16) from d_src to d_dst on the device with `width` (1, 4 or
+ * 16) bytes per lane per access — a kernel with exactly known HBM traffic, used by tools/pmc_traffic.py to calibrate
+ * rocprofv3's FETCH_SIZE / WRITE_SIZE for the access widths the extractor kernels use.  Asynchronous on `stream`. */
+int orbx_debug_calib_copy(orbx_ctx* ctx, const void* d_src, void* d_dst, size_t nbytes, int width, void* stream);
+
 /* Per-kernel device time of the extractor, measured with HIP events on the launch stream.
  * orbx_profile_enable(ctx,1) makes every following extraction record events around each kernel;
  * orbx_profile_read returns, for kernel slot i < ORBX_NUM_KERNELS, accumulated milliseconds and launches. */

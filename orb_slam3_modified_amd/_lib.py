@@ -53,6 +53,7 @@ def lib() -> C.CDLL:
         "orbx_pyramid_level": (i32, [vp, i32, i32, vp, sz, ip, ip]),
         "orbx_debug_level_points": (i32, [vp, i32, i32, i32, vp, i32]),
         "orbx_debug_trig": (i32, [vp, vp, vp, i32, i32, vp, vp, vp]),
+        "orbx_debug_calib_copy": (i32, [vp, vp, vp, sz, i32, vp]),
         "orbx_profile_enable": (i32, [vp, i32]),
         "orbx_profile_read": (i32, [vp, vp, vp]),
         "orbx_kernel_name": (C.c_char_p, [i32]),

@@ -21,6 +21,7 @@ int set_err(orbx_ctx* ctx, int code, const std::string& msg) {
 static inline int cv_round(float v) { return (int)lrintf(v); }
 static inline int cv_round(double v) { return (int)lrint(v); }
 static inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
+static inline unsigned xcd_grid(int nitems) { return (unsigned)(8 * ((nitems + 7) / 8)); }  // see xcd_logical_block
 
 // resize tables (cv::resize INTER_LINEAR 8u): per destination index the two source
 // indices and the two 11-bit weights.  The clamped tail (`S[sx]*2048`) is encoded as weights (2048, 0).
@@ -146,7 +147,7 @@ static int build_geometry(orbx_ctx* ctx, int rows, int cols, Geometry& geo) {
 static void free_buffers(orbx_ctx* ctx) {
   auto fr = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
   fr(ctx->d_geo); fr(ctx->d_cells); fr(ctx->d_xtab); fr(ctx->d_ytab);
-  fr(ctx->d_pyr); fr(ctx->d_blur); fr(ctx->d_cand); fr(ctx->d_cell_cnt); fr(ctx->d_pts); fr(ctx->d_lvl_kp); fr(ctx->d_lvl_n); fr(ctx->d_outidx);
+  fr(ctx->d_pyr); fr(ctx->d_blur); fr(ctx->d_cand); fr(ctx->d_cell_cnt); fr(ctx->d_pts); fr(ctx->d_lvl_kp); fr(ctx->d_lvl_n); fr(ctx->d_kp_list);
   ctx->batch_cap = 0;
 }
 
@@ -192,7 +193,7 @@ static int ensure_buffers(orbx_ctx* ctx, int rows, int cols, int nframes) {
   ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_pts, B * 2 * geo.cand_total * sizeof(uint32_t)));
   ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_lvl_kp, B * geo.kp_total * sizeof(uint32_t)));
   ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_lvl_n, B * geo.nlevels * sizeof(int32_t)));
-  ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_outidx, B * ctx->out_cap * sizeof(int32_t)));
+  ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_kp_list, B * ctx->out_cap * sizeof(uint2)));
   ctx->batch_cap = nframes;
   return ORBX_OK;
 }
@@ -239,9 +240,10 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int nframes, in
       const uint8_t* src; long long sfs; int sp;
       if (l == 1) { src = d_imgs; sfs = (long long)frame_stride; sp = (int)row_stride; }
       else { src = ctx->d_pyr + S.plane_off; sfs = geo.pyr_bytes; sp = S.pitch; }
-      dim3 grid((D.w + 255) / 256, (D.h + 3) / 4, nframes), block(64, 4, 1);
+      const int nbx = (D.w + 255) / 256, nby = (D.h + 3) / 4, nitems = nbx * nby * nframes;
+      dim3 grid(xcd_grid(nitems)), block(64, 4, 1);
       hipLaunchKernelGGL(k_resize, grid, block, 0, st, src, sfs, sp, ctx->d_pyr + D.plane_off, (long long)geo.pyr_bytes,
-                         D.pitch, D.w, D.h, ctx->d_xtab + D.xtab_off, ctx->d_ytab + D.ytab_off);
+                         D.pitch, D.w, D.h, ctx->d_xtab + D.xtab_off, ctx->d_ytab + D.ytab_off, nbx, nby, nitems);
     }
   }
   // K2: FAST cells
@@ -252,10 +254,10 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int nframes, in
     const int list_cap = round_up((geo.max_cell_w - 6) * (geo.max_cell_h - 6), 8);
     if (list_cap > 8192) return set_err(ctx, ORBX_E_CAPACITY, "FAST cell larger than 8192 px");
     const size_t lds = (size_t)tile_pitch * tile_rows * 2 + (size_t)list_cap * 2;
-    dim3 grid((unsigned)geo.cells.size(), nframes, 1);
-    hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), lds, st, ctx->d_geo, ctx->d_cells, d_imgs, (long long)row_stride,
-                       (long long)frame_stride, ctx->d_pyr, (long long)geo.pyr_bytes, ctx->d_cand, ctx->d_cell_cnt,
-                       ctx->ini_th, ctx->min_th, tile_pitch, tile_rows, list_cap);
+    const int nitems = (int)geo.cells.size() * nframes;
+    hipLaunchKernelGGL(k_fast_cells, dim3(xcd_grid(nitems)), dim3(256), lds, st, ctx->d_geo, ctx->d_cells, d_imgs,
+                       (long long)row_stride, (long long)frame_stride, ctx->d_pyr, (long long)geo.pyr_bytes, ctx->d_cand,
+                       ctx->d_cell_cnt, ctx->ini_th, ctx->min_th, tile_pitch, tile_rows, list_cap, nitems);
   }
   // K3: quadtree
   {
@@ -275,7 +277,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int nframes, in
   {
     ProfScope ps(ctx, 3, st);
     hipLaunchKernelGGL(k_assemble, dim3(nframes), dim3(256), (size_t)ctx->out_cap * 8 + 64, st, ctx->d_geo, ctx->d_lvl_kp,
-                       ctx->d_lvl_n, ctx->d_outidx, d_counts, lap0, lap1);
+                       ctx->d_lvl_n, ctx->d_kp_list, d_counts, lap0, lap1);
   }
   // K4a: 7x7 fixed-point Gaussian of every level (the reference blurs each level that holds keypoints)
   {
@@ -286,19 +288,20 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int nframes, in
     bc.w0 = (uint32_t)gk[0] | ((uint32_t)gk[1] << 8) | ((uint32_t)gk[2] << 16) | ((uint32_t)gk[3] << 24);
     bc.w1 = (uint32_t)gk[4] | ((uint32_t)gk[5] << 8) | ((uint32_t)gk[6] << 16);
     for (int i = 0; i < 7; i++) bc.k[i] = gk[i];
-    dim3 grid(geo.btiles_total, nframes, 1);
-    hipLaunchKernelGGL(k_blur7, grid, dim3(256), 0, st, ctx->d_geo, d_imgs, (long long)row_stride, (long long)frame_stride,
-                       ctx->d_pyr, (long long)geo.pyr_bytes, ctx->d_blur, (long long)geo.blur_bytes, bc);
+    const int nitems = geo.btiles_total * nframes;
+    hipLaunchKernelGGL(k_blur7, dim3(xcd_grid(nitems)), dim3(256), 0, st, ctx->d_geo, d_imgs, (long long)row_stride,
+                       (long long)frame_stride, ctx->d_pyr, (long long)geo.pyr_bytes, ctx->d_blur, (long long)geo.blur_bytes, bc,
+                       nitems);
   }
   // K4b: orientation + descriptors
   {
     ProfScope ps(ctx, 5, st);
     DescConsts dc;
     for (int i = 0; i < 16; i++) dc.umax[i] = ctx->umax[i];
-    dim3 grid((ctx->out_cap + 3) / 4, nframes, 1);
-    hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, st, ctx->d_geo, d_imgs, (long long)row_stride, (long long)frame_stride,
-                       ctx->d_pyr, (long long)geo.pyr_bytes, ctx->d_blur, (long long)geo.blur_bytes, ctx->d_lvl_kp, ctx->d_lvl_n,
-                       ctx->d_outidx, d_kps, d_desc, dc);
+    const int gpf = (ctx->out_cap + 3) / 4, nitems = gpf * nframes;
+    hipLaunchKernelGGL(k_describe, dim3(xcd_grid(nitems)), dim3(256), 0, st, ctx->d_geo, d_imgs, (long long)row_stride,
+                       (long long)frame_stride, ctx->d_pyr, (long long)geo.pyr_bytes, ctx->d_blur, (long long)geo.blur_bytes,
+                       ctx->d_kp_list, d_counts, d_kps, d_desc, dc, gpf, nitems);
   }
   ORBX_HIP(ctx, hipGetLastError());
   return ORBX_OK;
@@ -562,6 +565,20 @@ int orbx_debug_trig(orbx_ctx* ctx, const float* y, const float* x, int n, int an
   ORBX_HIP(ctx, hipMemcpy(a, da, bytes, hipMemcpyDeviceToHost));
   ORBX_HIP(ctx, hipMemcpy(b, db, bytes, hipMemcpyDeviceToHost));
   (void)hipFree(dy); (void)hipFree(dx); (void)hipFree(dang); (void)hipFree(da); (void)hipFree(db);
+  return ORBX_OK;
+}
+
+int orbx_debug_calib_copy(orbx_ctx* ctx, const void* d_src, void* d_dst, size_t nbytes, int width, void* stream) {
+  if (!ctx || !d_src || !d_dst || (width != 1 && width != 4 && width != 16) || nbytes % 16 != 0) return ORBX_E_INVALID;
+  if (nbytes == 0) return ORBX_OK;
+  ORBX_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  const long long n = (long long)(nbytes / (size_t)width);
+  const unsigned blocks = (unsigned)std::min<long long>((n + 255) / 256, 256 * 32);
+  if (width == 1) hipLaunchKernelGGL(k_calib_copy<uint8_t>, dim3(blocks), dim3(256), 0, st, (const uint8_t*)d_src, (uint8_t*)d_dst, n);
+  else if (width == 4) hipLaunchKernelGGL(k_calib_copy<uint32_t>, dim3(blocks), dim3(256), 0, st, (const uint32_t*)d_src, (uint32_t*)d_dst, n);
+  else hipLaunchKernelGGL(k_calib_copy<uint4>, dim3(blocks), dim3(256), 0, st, (const uint4*)d_src, (uint4*)d_dst, n);
+  ORBX_HIP(ctx, hipGetLastError());
   return ORBX_OK;
 }
 

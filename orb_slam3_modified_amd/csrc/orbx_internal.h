@@ -104,7 +104,7 @@ struct orbx_ctx {
   uint32_t* d_pts = nullptr;       // [batch][2][cand_total]  quadtree ping-pong
   uint32_t* d_lvl_kp = nullptr;    // [batch][kp_total]
   int32_t* d_lvl_n = nullptr;      // [batch][nlevels]
-  int32_t* d_outidx = nullptr;     // [batch][out_cap]
+  uint2* d_kp_list = nullptr;      // [batch][out_cap] {packed point, level | output slot << 8}, level-major order
   // single-frame staging (orbx_extract)
   uint8_t* d_stage_img = nullptr; size_t stage_img_bytes = 0;
   orbx_keypoint* d_stage_kps = nullptr; uint8_t* d_stage_desc = nullptr; int32_t* d_stage_counts = nullptr;

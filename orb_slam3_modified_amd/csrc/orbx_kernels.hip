@@ -19,9 +19,19 @@
 
 namespace orbx {
 
-__constant__ int8_t c_pattern[1024] = {
+__constant__ __align__(16) int8_t c_pattern[1024] = {
 #include "orb_pattern.inc"
 };
+
+// XCD-aware block order.  Workgroup b of a 1-D grid runs on XCD b % 8 (observed dispatch rule, used for speed only)
+// and every XCD has its own 4 MiB L2, so neighbouring tiles / cells of one frame should share an XCD: the grid is
+// padded to 8*chunk blocks and block b works on logical item (b % 8) * chunk + b / 8, i.e. XCD k owns the contiguous
+// logical range [k*chunk, (k+1)*chunk) = a contiguous run of whole frames.  Returns -1 for the padding blocks.
+__device__ __forceinline__ int xcd_logical_block(int n_items) {
+  const int chunk = (int)(gridDim.x >> 3);
+  const int L = (int)(blockIdx.x & 7u) * chunk + (int)(blockIdx.x >> 3);
+  return L < n_items ? L : -1;
+}
 
 // ------------------------------------------------------------------------------------------------
 // K1: cv::resize INTER_LINEAR, CV_8UC1 (src/ORBextractor.cc:1183).  4 output pixels per thread.
@@ -29,13 +39,17 @@ __constant__ int8_t c_pattern[1024] = {
 __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src, long long src_frame_stride,
                                                 int src_pitch, uint8_t* __restrict__ dst, long long dst_frame_stride,
                                                 int dst_pitch, int dw, int dh, const XTab* __restrict__ xt,
-                                                const XTab* __restrict__ yt) {
-  const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
-  const int dy = blockIdx.y * 4 + threadIdx.y;
+                                                const XTab* __restrict__ yt, int nbx, int nby, int nitems) {
+  const int L = xcd_logical_block(nitems);
+  if (L < 0) return;
+  const int frame = L / (nbx * nby), rem = L - frame * (nbx * nby);
+  const int by = rem / nbx, bx = rem - by * nbx;
+  const int x4 = (bx * 64 + threadIdx.x) * 4;
+  const int dy = by * 4 + threadIdx.y;
   if (dy >= dh || x4 >= dw) return;
   const XTab ty = yt[dy];
-  const uint8_t* S0 = src + (long long)blockIdx.z * src_frame_stride + (long long)ty.s0 * src_pitch;
-  const uint8_t* S1 = src + (long long)blockIdx.z * src_frame_stride + (long long)ty.s1 * src_pitch;
+  const uint8_t* S0 = src + (long long)frame * src_frame_stride + (long long)ty.s0 * src_pitch;
+  const uint8_t* S1 = src + (long long)frame * src_frame_stride + (long long)ty.s1 * src_pitch;
   const int b0 = ty.a0, b1 = ty.a1;
   uint32_t packed = 0;
 #pragma unroll
@@ -47,7 +61,7 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
     const int v = ((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xff;
     packed |= (uint32_t)v << (8 * i);
   }
-  *(uint32_t*)(dst + (long long)blockIdx.z * dst_frame_stride + (long long)dy * dst_pitch + x4) = packed;
+  *(uint32_t*)(dst + (long long)frame * dst_frame_stride + (long long)dy * dst_pitch + x4) = packed;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -93,7 +107,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DeviceGeom* __restrict
                                                     long long img_frame_stride, const uint8_t* __restrict__ pyr,
                                                     long long pyr_frame_bytes, uint32_t* __restrict__ cand,
                                                     int32_t* __restrict__ cell_cnt, int ini_th, int min_th, int tile_pitch,
-                                                    int tile_rows, int list_cap) {
+                                                    int tile_rows, int list_cap, int nitems) {
   extern __shared__ __align__(16) uint8_t smem[];
   uint8_t* tile = smem;                                  // [tile_rows][tile_pitch] raw pixels (+ alignment shift xo)
   uint8_t* sc = tile + tile_rows * tile_pitch;           // [tile_rows][tile_pitch] scores with a 1-px zero frame
@@ -104,8 +118,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DeviceGeom* __restrict
   __shared__ int s_cnt;
 
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const int frame = blockIdx.y;
-  const CellGeom cg = cells[blockIdx.x];
+  const int L = xcd_logical_block(nitems);
+  if (L < 0) return;  // block-uniform
+  const int frame = L / g->ncells_total, cell = L - frame * g->ncells_total;
+  const CellGeom cg = cells[cell];
   const DeviceLevel& lv = g->lv[cg.level];
   const uint8_t* img;
   long long pitch;
@@ -209,7 +225,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DeviceGeom* __restrict
 #pragma unroll
     for (int k = 0; k < 4; k++) { const int wt = wave_tot[k]; off += k < wv ? wt : 0; tot += wt; }
     wpre[t] = off + inc - c;
-    if (t == 0) cell_cnt[(long long)frame * g->ncells_total + blockIdx.x] = tot;
+    if (t == 0) cell_cnt[(long long)frame * g->ncells_total + cell] = tot;
   }
   __syncthreads();
   // ---- G: row-major rank of every selected survivor -> its slot
@@ -566,7 +582,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const DeviceGeom* __restrict__
 // K3b: output slots (src/ORBextractor.cc:1122,1143-1164)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_assemble(const DeviceGeom* __restrict__ g, const uint32_t* __restrict__ lvl_kp,
-                                                  const int32_t* __restrict__ lvl_n, int32_t* __restrict__ outidx,
+                                                  const int32_t* __restrict__ lvl_n, uint2* __restrict__ kp_list,
                                                   int32_t* __restrict__ counts, int lap0, int lap1) {
   extern __shared__ __align__(16) uint8_t smem[];
   unsigned long long* scan = (unsigned long long*)smem;
@@ -599,7 +615,8 @@ __global__ __launch_bounds__(256) void k_assemble(const DeviceGeom* __restrict__
     if (l != 0) x = __fmul_rn(x, g->lv[l].scale);
     const bool st = x >= (float)lap0 && x <= (float)lap1;
     const int pre = (int)scan[i];
-    outidx[(long long)frame * g->out_cap + i] = st ? total - 1 - pre : i - pre;
+    const int slot = st ? total - 1 - pre : i - pre;
+    kp_list[(long long)frame * g->out_cap + i] = make_uint2(p, (uint32_t)l | ((uint32_t)slot << 8));
   }
   if (t == 0) { counts[frame * 2] = total; counts[frame * 2 + 1] = total - nst; }
 }
@@ -631,14 +648,17 @@ __device__ __forceinline__ uint32_t bytes4(uint32_t d0, uint32_t d1, uint32_t d2
 __global__ __launch_bounds__(256) void k_blur7(const DeviceGeom* __restrict__ g, const uint8_t* __restrict__ imgs,
                                                long long img_row_stride, long long img_frame_stride,
                                                const uint8_t* __restrict__ pyr, long long pyr_frame_bytes,
-                                               uint8_t* __restrict__ blur, long long blur_frame_bytes, BlurConsts bc) {
+                                               uint8_t* __restrict__ blur, long long blur_frame_bytes, BlurConsts bc, int nitems) {
   __shared__ __align__(16) uint8_t raw[kBT_RR * kBT_RP];
   __shared__ __align__(16) uint16_t hb[kBT_RR * kBT_W];
-  const int t = threadIdx.x, frame = blockIdx.y;
+  const int t = threadIdx.x;
+  const int L = xcd_logical_block(nitems);
+  if (L < 0) return;  // block-uniform
+  const int frame = L / g->btiles_total, bt = L - frame * g->btiles_total;
   int l = 0;
-  while (l + 1 < g->nlevels && (int)blockIdx.x >= g->lv[l + 1].btile_begin) l++;
+  while (l + 1 < g->nlevels && bt >= g->lv[l + 1].btile_begin) l++;
   const DeviceLevel& lv = g->lv[l];
-  const int tile = blockIdx.x - lv.btile_begin;
+  const int tile = bt - lv.btile_begin;
   const int ty = tile / lv.btiles_x, tx = tile - ty * lv.btiles_x;
   const int x0 = tx * kBT_W, y0 = ty * kBT_H;
   const uint8_t* img;
@@ -705,12 +725,14 @@ __global__ __launch_bounds__(256) void k_blur7(const DeviceGeom* __restrict__ g,
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4b: orientation + steered BRIEF, one wave per keypoint: 31x31 raw patch staged in LDS for the intensity
-// centroid, 512 taps gathered from the blurred level, one wave ballot = 8 descriptor bytes.
+// K4b: orientation + steered BRIEF, one wave per keypoint.  The kernel is latency-bound (a chain of dependent
+// gathers per keypoint), so it is built for few round trips and no LDS: (1) one 8-byte record per keypoint
+// (written by k_assemble) replaces the level search; (2) the 31x31 circular patch is read straight into registers
+// (two patch rows per wave access, 16 independent byte loads per lane) and the integer moments are reduced with
+// wave shuffles; (3) the rotated test pattern is a packed dword per lane, loaded before the angle is known;
+// (4) 512 taps gathered from the blurred level, one wave ballot = 8 descriptor bytes, one 8-byte store per lane 0..3.
 // ------------------------------------------------------------------------------------------------
 struct DescConsts { int umax[16]; };
-
-constexpr int kPP = 32;  // LDS pitch of the 31x31 patch
 
 // cv::fastAtan2, degrees; separate IEEE mul/add, correctly rounded division.
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
@@ -738,47 +760,51 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
                                                   long long img_row_stride, long long img_frame_stride,
                                                   const uint8_t* __restrict__ pyr, long long pyr_frame_bytes,
                                                   const uint8_t* __restrict__ blur, long long blur_frame_bytes,
-                                                  const uint32_t* __restrict__ lvl_kp, const int32_t* __restrict__ lvl_n,
-                                                  const int32_t* __restrict__ outidx, orbx_keypoint* __restrict__ out_kps,
-                                                  uint8_t* __restrict__ out_desc, DescConsts dc) {
-  __shared__ __align__(16) uint8_t s_raw[4][kPatchSize * kPP];
+                                                  const uint2* __restrict__ kp_list, const int32_t* __restrict__ counts,
+                                                  orbx_keypoint* __restrict__ out_kps, uint8_t* __restrict__ out_desc,
+                                                  DescConsts dc, int groups_per_frame, int nitems) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int frame = blockIdx.y;
-  const int gi = blockIdx.x * 4 + w;
-  int l = 0, acc = 0, total = 0;
-  for (int k = 0; k < g->nlevels; k++) {
-    const int nk = max(lvl_n[frame * g->nlevels + k], 0);
-    if (gi >= total + nk) { acc = total + nk; l = k + 1; }
-    total += nk;
-  }
-  total = min(total, g->out_cap);
-  if (gi >= total) return;  // wave-uniform; no block-level barrier below
+  const int L = xcd_logical_block(nitems);
+  if (L < 0) return;
+  const int frame = L / groups_per_frame;
+  const int gi = (L - frame * groups_per_frame) * 4 + w;
+  if (gi >= counts[frame * 2]) return;  // wave-uniform
+  const uint2 rec = kp_list[(long long)frame * g->out_cap + gi];
+  // rotated-pattern operands: independent of the keypoint, issued first
+  char4 pat[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) pat[q] = ((const char4*)c_pattern)[q * 64 + lane];
+  const uint32_t p = rec.x;
+  const int l = (int)(rec.y & 0xffu), slot = (int)(rec.y >> 8);
   const DeviceLevel& lv = g->lv[l];
-  const uint32_t p = lvl_kp[(long long)frame * g->kp_total + lv.kp_off + (gi - acc)];
   const int kx = pt_x(p), ky = pt_y(p);
   const uint8_t* img;
   long long pitch;
   if (l == 0) { img = imgs + (long long)frame * img_frame_stride; pitch = img_row_stride; }
   else { img = pyr + (long long)frame * pyr_frame_bytes + lv.plane_off; pitch = lv.pitch; }
-  uint8_t* raw = s_raw[w];
-  // 31x31 patch of the un-blurred level (keypoints sit >= 19 px inside the level: no border handling)
-  if (lane < kPatchSize) {
-    const uint8_t* src = img + (long long)(ky - kHalfPatch) * pitch + (kx - kHalfPatch) + lane;
-#pragma unroll
-    for (int r = 0; r < kPatchSize; r++) raw[r * kPP + lane] = src[(long long)r * pitch];
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  // intensity centroid (src/ORBextractor.cc:76-103): exact int32 moments, any summation order
+  // intensity centroid (src/ORBextractor.cc:76-103) over the circular patch of the un-blurred level: exact int32
+  // moments, any summation order.  Lane = (row parity r2, column c); keypoints sit >= 19 px inside the level.
   int m10 = 0, m01 = 0;
-  if (lane < kPatchSize) {
-    const int v = lane - kHalfPatch;
-    const int um = dc.umax[v < 0 ? -v : v];
-    const uint8_t* row = raw + lane * kPP + kHalfPatch;
-    int rs = 0;
-    for (int u = -um; u <= um; u++) { const int I = row[u]; m10 += u * I; rs += I; }
-    m01 = v * rs;
+  {
+    const int c = lane & 31, r2 = lane >> 5;
+    const int u = c - kHalfPatch;
+    const int au = u < 0 ? -u : u;
+    const uint8_t* src = img + (long long)(ky - kHalfPatch + r2) * pitch + (kx - kHalfPatch) + c;
+    int I[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int v0 = 2 * i - kHalfPatch, v1 = v0 + 1;  // rows of the two half-waves (compile-time)
+      const int um0 = dc.umax[v0 < 0 ? -v0 : v0];
+      const int um1 = v1 <= kHalfPatch ? dc.umax[v1 < 0 ? -v1 : v1] : -1;
+      const int um = r2 ? um1 : um0;
+      I[i] = (au <= um) ? (int)src[(long long)(2 * i) * pitch] : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int v = 2 * i - kHalfPatch + r2;
+      m10 += u * I[i];
+      m01 += v * I[i];
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
@@ -787,23 +813,26 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
   const float factorPI = (float)(3.14159265358979323846 / 180.f);
   const float ang = __fmul_rn(angle, factorPI);
   const float a = orbx_glibc::cosf_exact(ang), b = orbx_glibc::sinf_exact(ang);
-  const int slot = outidx[(long long)frame * g->out_cap + gi];
-  uint8_t* dsc = out_desc + ((long long)frame * g->out_cap + slot) * 32;
   const uint8_t* ctr = blur + (long long)frame * blur_frame_bytes + lv.bplane_off + (long long)ky * lv.pitch + kx;
   const int bp = lv.pitch;
+  int t0[4], t1[4];
 #pragma unroll
   for (int q = 0; q < 4; q++) {
-    const int tst = q * 64 + lane;
-    const float x0 = (float)c_pattern[tst * 4 + 0], y0 = (float)c_pattern[tst * 4 + 1];
-    const float x1 = (float)c_pattern[tst * 4 + 2], y1 = (float)c_pattern[tst * 4 + 3];
+    const float x0 = (float)pat[q].x, y0 = (float)pat[q].y, x1 = (float)pat[q].z, y1 = (float)pat[q].w;
     const int ry0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
     const int rx0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
     const int ry1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
     const int rx1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-    const int t0 = ctr[ry0 * bp + rx0], t1 = ctr[ry1 * bp + rx1];
-    const unsigned long long bits = __ballot(t0 < t1);
-    if (lane == 0) *(unsigned long long*)(dsc + q * 8) = bits;
+    t0[q] = ctr[ry0 * bp + rx0];
+    t1[q] = ctr[ry1 * bp + rx1];
   }
+  unsigned long long mine = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const unsigned long long bits = __ballot(t0[q] < t1[q]);
+    if (lane == q) mine = bits;
+  }
+  if (lane < 4) *(unsigned long long*)(out_desc + ((long long)frame * g->out_cap + slot) * 32 + lane * 8) = mine;
   if (lane == 0) {
     orbx_keypoint kp;
     float fx = (float)kx, fy = (float)ky;
@@ -826,6 +855,15 @@ __global__ void k_debug_trig(const float* __restrict__ y, const float* __restric
   angle[i] = ang;
   a[i] = orbx_glibc::cosf_exact(r);
   b[i] = orbx_glibc::sinf_exact(r);
+}
+
+// Calibration kernel for the rocprofv3 FETCH_SIZE / WRITE_SIZE counters (MI355X_MICROARCH.md "HBM": the counters
+// are only calibrated for wide streaming reads): copies n bytes with W bytes per lane per access (W = 1, 4, 16),
+// i.e. a kernel whose HBM traffic is known exactly, in the access widths the extractor kernels use.
+template <typename T>
+__global__ __launch_bounds__(256) void k_calib_copy(const T* __restrict__ src, T* __restrict__ dst, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    dst[i] = src[i];
 }
 
 }  // namespace orbx

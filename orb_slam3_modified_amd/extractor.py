@@ -125,6 +125,10 @@ class ORBextractor:
         check(self._L.orbx_debug_trig(self._ctx, ptr(y), ptr(xx), n, int(x is None), ptr(ang), ptr(a), ptr(b)), self._ctx)
         return ang[:n], a[:n], b[:n]
 
+    def debug_calib_copy(self, d_src: int, d_dst: int, nbytes: int, width: int, stream: int = 0):
+        """Known-traffic device copy (counter calibration, tools/pmc_traffic.py)."""
+        check(self._L.orbx_debug_calib_copy(self._ctx, ptr(d_src), ptr(d_dst), nbytes, width, ptr(stream)), self._ctx)
+
     def profile_enable(self, on: bool = True):
         check(self._L.orbx_profile_enable(self._ctx, int(on)), self._ctx)
 

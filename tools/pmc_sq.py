@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""SQ/TA counter passes over the extractor workload (diagnostics for kernel tuning):
+   python tools/pmc_sq.py "SQ_WAVES SQ_WAVE_CYCLES ..." "second pass counters" ...   -> gpurun_out/pmc_sq.md"""
+import csv, glob, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = os.path.join(ROOT, "gpurun_out", "pmc_sq")
+rows = {}
+order = []
+for i, cs in enumerate(sys.argv[1:]):
+    d = os.path.join(out, f"pass{i}")
+    os.makedirs(d, exist_ok=True)
+    cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + cs.split() + ["-f", "csv", "-d", d, "-o", "p", "--", sys.executable,
+           os.path.join(ROOT, "tools", "pmc_traffic.py"), "--workload"]
+    r = subprocess.run(cmd, env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        print(f"pass {i} failed: {cs}\n{r.stdout[-2000:]}")
+        continue
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            k = row["Kernel_Name"].split("(")[0].split("::")[-1]
+            if "calib" in k or not k.startswith("k_"):
+                continue
+            c = row["Counter_Name"]
+            if c not in order:
+                order.append(c)
+            a = rows.setdefault(k, {}).setdefault(c, [0.0, 0])
+            a[0] += float(row["Counter_Value"]); a[1] += 1
+lines = ["| kernel | " + " | ".join(order) + " |", "|---|" + "---:|" * len(order)]
+for k, cs in rows.items():
+    lines.append(f"| {k} | " + " | ".join(f"{cs[c][0] / cs[c][1]:.4g}" if c in cs else "-" for c in order) + " |")
+open(os.path.join(ROOT, "gpurun_out", "pmc_sq.md"), "w").write("per-dispatch averages\n\n" + "\n".join(lines) + "\n")
+print("\n".join(lines))
