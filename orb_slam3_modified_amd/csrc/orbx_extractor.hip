@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -12,6 +13,14 @@
 #include "orbx_kernels.hip"
 
 namespace orbx {
+
+// Workgroup size of k_fast_cells: 128 by default (measured best); ORBX_FAST_THREADS=64|128|256 in the environment overrides it
+// (tuning knob, read once per context).
+static int fast_threads_from_env() {
+  const char* e = getenv("ORBX_FAST_THREADS");
+  const int v = e ? atoi(e) : 128;
+  return (v == 64 || v == 128 || v == 256) ? v : 128;
+}
 
 int set_err(orbx_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->err = msg;
@@ -249,15 +258,20 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int nframes, in
   // K2: FAST cells
   {
     ProfScope ps(ctx, 1, st);
-    const int tile_pitch = round_up(geo.max_cell_w + 3, 4);  // +3: alignment shift of the dword-staged rows
+    const int need = geo.max_cell_w + 3;  // +3: alignment shift of the dword-staged rows
+    const int pitchB = need <= 64 ? 64 : 96;
     const int tile_rows = geo.max_cell_h;
     const int list_cap = round_up((geo.max_cell_w - 6) * (geo.max_cell_h - 6), 8);
-    if (list_cap > 8192) return set_err(ctx, ORBX_E_CAPACITY, "FAST cell larger than 8192 px");
-    const size_t lds = (size_t)tile_pitch * tile_rows * 2 + (size_t)list_cap * 2;
+    if (need > 96 || geo.max_cell_h > 127 + 6 || list_cap > 8192)
+      return set_err(ctx, ORBX_E_CAPACITY, "FAST cell larger than the kernel's LDS tile");
+    const size_t lds = 16 + (size_t)pitchB * tile_rows * 2 + (size_t)list_cap * 2;
     const int nitems = (int)geo.cells.size() * nframes;
-    hipLaunchKernelGGL(k_fast_cells, dim3(xcd_grid(nitems)), dim3(256), lds, st, ctx->d_geo, ctx->d_cells, d_imgs,
+    const int ft = ctx->fast_threads;
+    auto kern = pitchB == 64 ? (ft == 64 ? k_fast_cells<64, 64> : ft == 128 ? k_fast_cells<128, 64> : k_fast_cells<256, 64>)
+                             : (ft == 64 ? k_fast_cells<64, 96> : ft == 128 ? k_fast_cells<128, 96> : k_fast_cells<256, 96>);
+    hipLaunchKernelGGL(kern, dim3(xcd_grid(nitems)), dim3(ft), lds, st, ctx->d_geo, ctx->d_cells, d_imgs,
                        (long long)row_stride, (long long)frame_stride, ctx->d_pyr, (long long)geo.pyr_bytes, ctx->d_cand,
-                       ctx->d_cell_cnt, ctx->ini_th, ctx->min_th, tile_pitch, tile_rows, list_cap, nitems);
+                       ctx->d_cell_cnt, ctx->ini_th, ctx->min_th, tile_rows, nitems);
   }
   // K3: quadtree
   {
@@ -359,6 +373,7 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, 
       ++v0;
     }
   }
+  ctx->fast_threads = fast_threads_from_env();
   ctx->out_cap = 0;
   for (int l = 0; l < nlevels; l++) ctx->out_cap += std::max(ctx->quota[l] + 3, 4 * kMaxRoots);
   if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {

@@ -86,6 +86,7 @@ struct orbx_ctx {
   std::vector<int> quota;
   int umax[16];
   int out_cap;  // nfeatures + 3*nlevels
+  int fast_threads = 128;  // workgroup size of k_fast_cells
 
   hipStream_t stream = nullptr;
   std::string err;

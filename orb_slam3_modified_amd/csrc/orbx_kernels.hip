@@ -69,52 +69,61 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
 // ------------------------------------------------------------------------------------------------
 // S(p) = max over the 16 nine-pixel arcs of min(v - p_k), and the same for (p_k - v), minus 1:
 // the value OpenCV's cornerScore<16> returns for any threshold at which p is a corner.
-__device__ __forceinline__ int fast_score16(int v, const int (&p)[16]) {
-  int d[16];
-#pragma unroll
-  for (int k = 0; k < 16; k++) d[k] = v - p[k];
-  int mn2[16], mx2[16], mn4[16], mx4[16], mn8[16], mx8[16];
-#pragma unroll
-  for (int k = 0; k < 16; k++) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
-#pragma unroll
-  for (int k = 0; k < 16; k++) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
-#pragma unroll
-  for (int k = 0; k < 16; k++) { mn8[k] = min(mn4[k], mn4[(k + 4) & 15]); mx8[k] = max(mx4[k], mx4[(k + 4) & 15]); }
-  int A = -256, B = 256;
+// With d_k = v - p_k:  max_arc min d = v - min_arc max p  and  min_arc max d = v - max_arc min p, so the score is
+// max(v - minmax9(p), maxmin9(p) - v) - 1 and needs no subtraction per circle pixel; a 9-arc extremum is
+// 3-input extrema of 3-input extrema (v_min3_u32 / v_max3_u32): 16 + 16 + 8 instructions per polarity.
+__device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) { return min(min(a, b), c); }
+__device__ __forceinline__ uint32_t umax3(uint32_t a, uint32_t b, uint32_t c) { return max(max(a, b), c); }
+
+__device__ __forceinline__ int fast_score16(int v, const uint32_t (&p)[16]) {
+  uint32_t M3[16], m3[16];
 #pragma unroll
   for (int k = 0; k < 16; k++) {
-    A = max(A, min(mn8[k], d[(k + 8) & 15]));
-    B = min(B, max(mx8[k], d[(k + 8) & 15]));
+    M3[k] = umax3(p[k], p[(k + 1) & 15], p[(k + 2) & 15]);
+    m3[k] = umin3(p[k], p[(k + 1) & 15], p[(k + 2) & 15]);
   }
-  return max(A, -B) - 1;
+  uint32_t M9[16], m9[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    M9[k] = umax3(M3[k], M3[(k + 3) & 15], M3[(k + 6) & 15]);
+    m9[k] = umin3(m3[k], m3[(k + 3) & 15], m3[(k + 6) & 15]);
+  }
+  uint32_t minmax = umin3(M9[0], M9[1], M9[2]), maxmin = umax3(m9[0], m9[1], m9[2]);
+#pragma unroll
+  for (int k = 3; k < 15; k += 2) {
+    minmax = umin3(minmax, M9[k], M9[k + 1]);
+    maxmin = umax3(maxmin, m9[k], m9[k + 1]);
+  }
+  minmax = min(minmax, M9[15]);
+  maxmin = max(maxmin, m9[15]);
+  return max(v - (int)minmax, (int)maxmin - v) - 1;
 }
 
-// pixel index inside the detection domain -> (row, column); exact for i < 2^23
-__device__ __forceinline__ void idx2d(int i, int dw, float inv_dw, int& y, int& x) {
-  y = (int)((float)i * inv_dw);
-  if (y * dw > i) y--;
-  if ((y + 1) * dw <= i) y++;
-  x = i - y * dw;
-}
-
-// Work-efficient structure: only ~5 % of the pixels are corners at minTh, so (1) every pixel takes a 5-read
-// necessary test (two opposite pairs of the circle: a 9-arc always contains one pixel of each opposite pair),
-// (2) the survivors (~20 %) are compacted into an LDS list and only they pay for the exact 16-pixel score,
-// (3) NMS and the iniTh/minTh selection run on the list, (4) the ordered (row-major) output order is rebuilt
-// from a bitmap + popcount prefix instead of a pass over all pixels.
-__global__ __launch_bounds__(256) void k_fast_cells(const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
-                                                    const uint8_t* __restrict__ imgs, long long img_row_stride,
-                                                    long long img_frame_stride, const uint8_t* __restrict__ pyr,
-                                                    long long pyr_frame_bytes, uint32_t* __restrict__ cand,
-                                                    int32_t* __restrict__ cell_cnt, int ini_th, int min_th, int tile_pitch,
-                                                    int tile_rows, int list_cap, int nitems) {
+// Work-efficient structure (the kernel is VALU-bound): only ~5 % of the pixels are corners at minTh, so
+// (1) every pixel takes a 5-value necessary test (two opposite pairs of the circle: a 9-arc always contains one pixel
+//     of each opposite pair), evaluated for 4 horizontally adjacent pixels per lane from 5 aligned LDS dwords
+//     (byte windows via v_alignbyte), no per-pixel index arithmetic;
+// (2) the survivors (~20 %) are compacted into an LDS list of packed (y, x) and only they pay for the exact
+//     16-pixel score; (3) NMS and the iniTh/minTh selection run on the list; (4) the ordered (row-major) output
+//     order is rebuilt from a bitmap + popcount prefix instead of a pass over all pixels.
+// list entry: x | y << 7 (detection-domain coordinates, both < 128), bit 15 = NMS survivor.
+template <int T, int PITCH>
+__global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
+                                                  const uint8_t* __restrict__ imgs, long long img_row_stride,
+                                                  long long img_frame_stride, const uint8_t* __restrict__ pyr,
+                                                  long long pyr_frame_bytes, uint32_t* __restrict__ cand,
+                                                  int32_t* __restrict__ cell_cnt, int ini_th, int min_th, int tile_rows,
+                                                  int nitems) {
+  // LDS: [16 B pad][tile_rows][PITCH] raw pixels (+ alignment shift xo) | [tile_rows][PITCH] scores with a 1-px
+  // zero frame | list.  PITCH is a compile-time constant so every circle / neighbour access is an immediate offset.
   extern __shared__ __align__(16) uint8_t smem[];
-  uint8_t* tile = smem;                                  // [tile_rows][tile_pitch] raw pixels (+ alignment shift xo)
-  uint8_t* sc = tile + tile_rows * tile_pitch;           // [tile_rows][tile_pitch] scores with a 1-px zero frame
-  uint16_t* list = (uint16_t*)(sc + tile_rows * tile_pitch);  // candidate pixel indices (bit 15: NMS survivor)
+  uint8_t* tile = smem + 16;
+  uint8_t* sc = tile + tile_rows * PITCH;
+  uint16_t* list = (uint16_t*)(sc + tile_rows * PITCH);  // candidate pixels (bit 15: NMS survivor)
+  constexpr int NW = T / 64, WPT = 256 / T, P4 = PITCH / 4;
   __shared__ uint32_t bitmap[256];
   __shared__ int wpre[256];
-  __shared__ int wave_tot[4];
+  __shared__ int wave_tot[NW];
   __shared__ int s_cnt;
 
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -128,94 +137,119 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DeviceGeom* __restrict
   if (cg.level == 0) { img = imgs + (long long)frame * img_frame_stride; pitch = img_row_stride; }
   else { img = pyr + (long long)frame * pyr_frame_bytes + lv.plane_off; pitch = lv.pitch; }
   const int cw = cg.cw, ch = cg.ch, dw = cw - 6, dh = ch - 6;
-  const int npx = dw * dh;
-  const float inv_dw = 1.0f / (float)dw;
   // ---- A: stage the sub-image with aligned dword loads when the source allows it
   const bool al = ((pitch & 3) == 0) && ((((unsigned long long)img) & 3) == 0);
   const int xo = al ? (cg.x0 & 3) : 0;
   if (al) {
     const uint8_t* src = img + (long long)cg.y0 * pitch + (cg.x0 - xo);
-    const int ndw = (xo + cw + 3) >> 2, tp4 = tile_pitch >> 2;
-    for (int r = t >> 4; r < ch; r += 16)
+    const int ndw = (xo + cw + 3) >> 2;
+    for (int r = t >> 4; r < ch; r += T / 16)
       for (int c = t & 15; c < ndw; c += 16)
-        ((uint32_t*)tile)[r * tp4 + c] = *(const uint32_t*)(src + (long long)r * pitch + 4 * c);
+        ((uint32_t*)tile)[r * P4 + c] = *(const uint32_t*)(src + (long long)r * pitch + 4 * c);
   } else {
     const uint8_t* src = img + (long long)cg.y0 * pitch + cg.x0;
-    for (int r = t >> 6; r < ch; r += 4)
-      for (int c = lane; c < cw; c += 64) tile[r * tile_pitch + c] = src[(long long)r * pitch + c];
+    for (int r = wv; r < ch; r += NW)
+      for (int c = lane; c < cw; c += 64) tile[r * PITCH + c] = src[(long long)r * pitch + c];
   }
-  for (int i = t; i < ((dh + 2) * tile_pitch) >> 2; i += 256) ((uint32_t*)sc)[i] = 0;
-  bitmap[t] = 0;
+  for (int i = t; i < (dh + 2) * P4; i += T) ((uint32_t*)sc)[i] = 0;
+#pragma unroll
+  for (int k = 0; k < WPT; k++) bitmap[t * WPT + k] = 0;
   if (t == 0) s_cnt = 0;
   __syncthreads();
-  // ---- B: necessary test on two opposite pairs, compaction of the passing pixels (unordered)
-  for (int i0 = 0; i0 < npx; i0 += 256) {
-    const int i = i0 + t;
-    bool pass = false;
-    if (i < npx) {
-      int y, x;
-      idx2d(i, dw, inv_dw, y, x);
-      const uint8_t* c0 = tile + (y + 3) * tile_pitch + (x + 3 + xo);
-      const int v = c0[0], p0 = c0[3 * tile_pitch], p8 = c0[-3 * tile_pitch], p4 = c0[3], p12 = c0[-3];
-      const int lo = v - min_th, hi = v + min_th;
-      pass = (max(min(p0, p8), min(p4, p12)) < lo) || (min(max(p0, p8), max(p4, p12)) > hi);
+  // ---- B: necessary test, 4 pixels (one aligned LDS dword of centres) per lane and step; branch-free
+  {
+    const int kmin = (3 + xo) >> 2, kmax = (cw - 4 + xo) >> 2, ng = kmax - kmin + 1;
+    const int nit = dh * ng;
+    const uint32_t magic = (65536u + (uint32_t)ng - 1u) / (uint32_t)ng;  // i / ng == (i * magic) >> 16 for i < 65536 / ng
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int i0 = 0; i0 < nit; i0 += T) {
+      const int act = (i0 + t) < nit;
+      const int i = act ? i0 + t : nit - 1;
+      const int ry = (int)(((uint32_t)i * magic) >> 16);
+      const int k = kmin + (i - ry * ng);
+      const uint32_t* rowp = (const uint32_t*)tile + (ry + 3) * P4 + k;
+      const uint32_t dC = rowp[0], dL = rowp[-1], dR = rowp[1], dU = rowp[-3 * P4], dD = rowp[3 * P4];
+      const uint32_t Q4 = __builtin_amdgcn_alignbyte(dR, dC, 3);   // x+3 of pixel j in byte j
+      const uint32_t Q12 = __builtin_amdgcn_alignbyte(dC, dL, 1);  // x-3 of pixel j in byte j
+      const int c0 = 4 * k - xo - 3;                               // detection-domain x of pixel 0
+      int ps[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int v = (dC >> (8 * j)) & 0xff, p0 = (dD >> (8 * j)) & 0xff, p8 = (dU >> (8 * j)) & 0xff;
+        const int p4 = (Q4 >> (8 * j)) & 0xff, p12 = (Q12 >> (8 * j)) & 0xff;
+        const int dark = max(min(p0, p8), min(p4, p12)) < v - min_th;
+        const int bright = min(max(p0, p8), max(p4, p12)) > v + min_th;
+        const int valid = (unsigned)(c0 + j) < (unsigned)dw;
+        ps[j] = (dark | bright) & valid & act;
+      }
+      const unsigned long long b0 = __ballot(ps[0]), b1 = __ballot(ps[1]), b2 = __ballot(ps[2]), b3 = __ballot(ps[3]);
+      const int tot = __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
+      if (tot) {  // wave-uniform
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&s_cnt, tot);
+        base = __builtin_amdgcn_readfirstlane(base);
+        int off = base + __popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt);
+        const int ent = c0 + (ry << 7);  // c0 may be negative for the first group; pixel j is only listed when c0 + j >= 0
+        if (ps[0]) list[off] = (uint16_t)ent;
+        off += ps[0];
+        if (ps[1]) list[off] = (uint16_t)(ent + 1);
+        off += ps[1];
+        if (ps[2]) list[off] = (uint16_t)(ent + 2);
+        off += ps[2];
+        if (ps[3]) list[off] = (uint16_t)(ent + 3);
+      }
     }
-    const unsigned long long b = __ballot(pass);
-    int base = 0;
-    if (lane == 0 && b) base = atomicAdd(&s_cnt, __popcll(b));
-    base = __shfl(base, 0);
-    if (pass) list[base + __popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)i;
   }
   __syncthreads();
   const int n1 = s_cnt;
   // ---- C: exact score of the listed pixels
-  for (int e = t; e < n1; e += 256) {
-    const int i = list[e];
-    int y, x;
-    idx2d(i, dw, inv_dw, y, x);
-    const uint8_t* c0 = tile + (y + 3) * tile_pitch + (x + 3 + xo);
-    const int v = c0[0];
-    int p[16];
-    p[0] = c0[3 * tile_pitch];       p[1] = c0[3 * tile_pitch + 1];   p[2] = c0[2 * tile_pitch + 2];
-    p[3] = c0[tile_pitch + 3];       p[4] = c0[3];                    p[5] = c0[-tile_pitch + 3];
-    p[6] = c0[-2 * tile_pitch + 2];  p[7] = c0[-3 * tile_pitch + 1];  p[8] = c0[-3 * tile_pitch];
-    p[9] = c0[-3 * tile_pitch - 1];  p[10] = c0[-2 * tile_pitch - 2]; p[11] = c0[-tile_pitch - 3];
-    p[12] = c0[-3];                  p[13] = c0[tile_pitch - 3];      p[14] = c0[2 * tile_pitch - 2];
-    p[15] = c0[3 * tile_pitch - 1];
+  for (int e = t; e < n1; e += T) {
+    const int ent = list[e];
+    const int x = ent & 127, y = ent >> 7;
+    const uint8_t* c0 = tile + y * PITCH + (x + xo);  // top-left of the 7x7 window; centre = c0[3 * PITCH + 3]
+    const int v = c0[3 * PITCH + 3];
+    uint32_t p[16];
+    p[0] = c0[6 * PITCH + 3];  p[1] = c0[6 * PITCH + 4];  p[2] = c0[5 * PITCH + 5];  p[3] = c0[4 * PITCH + 6];
+    p[4] = c0[3 * PITCH + 6];  p[5] = c0[2 * PITCH + 6];  p[6] = c0[1 * PITCH + 5];  p[7] = c0[4];
+    p[8] = c0[3];              p[9] = c0[2];              p[10] = c0[1 * PITCH + 1]; p[11] = c0[2 * PITCH];
+    p[12] = c0[3 * PITCH];     p[13] = c0[4 * PITCH];     p[14] = c0[5 * PITCH + 1]; p[15] = c0[6 * PITCH + 2];
     const int s = fast_score16(v, p);
-    if (s >= min_th && s > 0) sc[(y + 1) * tile_pitch + (x + 1)] = (uint8_t)s;
+    if (s >= min_th && s > 0) sc[(y + 1) * PITCH + (x + 1)] = (uint8_t)s;
   }
   __syncthreads();
   // ---- D: 3x3 strict NMS inside the cell (neighbours outside the detection domain are 0)
   int any_ini = 0;
-  for (int e = t; e < n1; e += 256) {
-    const int i = list[e];
-    int y, x;
-    idx2d(i, dw, inv_dw, y, x);
-    const uint8_t* q = sc + (y + 1) * tile_pitch + (x + 1);
-    const int s = q[0];
-    if (s > 0 && s > q[-1] && s > q[1] && s > q[-tile_pitch - 1] && s > q[-tile_pitch] && s > q[-tile_pitch + 1] &&
-        s > q[tile_pitch - 1] && s > q[tile_pitch] && s > q[tile_pitch + 1]) {
-      list[e] = (uint16_t)(i | 0x8000);
-      any_ini |= s >= ini_th;
+  for (int e = t; e < n1; e += T) {
+    const int ent = list[e];
+    const int x = ent & 127, y = ent >> 7;
+    const uint8_t* q = sc + y * PITCH + x;  // top-left of the 3x3 window
+    const int s = q[PITCH + 1];
+    if (s > 0) {
+      const int m = max(max(max((int)q[0], (int)q[1]), max((int)q[2], (int)q[PITCH])),
+                        max(max((int)q[PITCH + 2], (int)q[2 * PITCH]), max((int)q[2 * PITCH + 1], (int)q[2 * PITCH + 2])));
+      if (s > m) {
+        list[e] = (uint16_t)(ent | 0x8000);
+        any_ini |= s >= ini_th;
+      }
     }
   }
   const int use_ini = __syncthreads_or(any_ini);
-  const int T = use_ini ? ini_th : min_th;
-  // ---- E: bitmap of the selected survivors
-  for (int e = t; e < n1; e += 256) {
+  const int TH = use_ini ? ini_th : min_th;
+  // ---- E: bitmap of the selected survivors (bit index = row-major pixel index)
+  for (int e = t; e < n1; e += T) {
     const int le = list[e];
     if (le & 0x8000) {
-      const int i = le & 0x7fff;
-      int y, x;
-      idx2d(i, dw, inv_dw, y, x);
-      if (sc[(y + 1) * tile_pitch + (x + 1)] >= T) atomicOr(&bitmap[i >> 5], 1u << (i & 31));
+      const int x = le & 127, y = (le >> 7) & 127;
+      const int i = y * dw + x;
+      if (sc[(y + 1) * PITCH + (x + 1)] >= TH) atomicOr(&bitmap[i >> 5], 1u << (i & 31));
     }
   }
   __syncthreads();
-  // ---- F: exclusive popcount prefix over the bitmap words (thread t <-> word t)
+  // ---- F: exclusive popcount prefix over the bitmap words (thread t <-> words t*WPT ..)
   {
-    const int c = __popc(bitmap[t]);
+    int cw_[WPT], c = 0;
+#pragma unroll
+    for (int k = 0; k < WPT; k++) { cw_[k] = __popc(bitmap[t * WPT + k]); c += cw_[k]; }
     int inc = c;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
@@ -223,21 +257,22 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DeviceGeom* __restrict
     __syncthreads();
     int off = 0, tot = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) { const int wt = wave_tot[k]; off += k < wv ? wt : 0; tot += wt; }
-    wpre[t] = off + inc - c;
+    for (int k = 0; k < NW; k++) { const int wt = wave_tot[k]; off += k < wv ? wt : 0; tot += wt; }
+    int run = off + inc - c;
+#pragma unroll
+    for (int k = 0; k < WPT; k++) { wpre[t * WPT + k] = run; run += cw_[k]; }
     if (t == 0) cell_cnt[(long long)frame * g->ncells_total + cell] = tot;
   }
   __syncthreads();
   // ---- G: row-major rank of every selected survivor -> its slot
   uint32_t* slot = cand + (long long)frame * g->cand_total + cg.slot_off;
-  for (int e = t; e < n1; e += 256) {
+  for (int e = t; e < n1; e += T) {
     const int le = list[e];
     if (le & 0x8000) {
-      const int i = le & 0x7fff;
-      int y, x;
-      idx2d(i, dw, inv_dw, y, x);
-      const int s = sc[(y + 1) * tile_pitch + (x + 1)];
-      if (s >= T) {
+      const int x = le & 127, y = (le >> 7) & 127;
+      const int s = sc[(y + 1) * PITCH + (x + 1)];
+      if (s >= TH) {
+        const int i = y * dw + x;
         const int rank = wpre[i >> 5] + __popc(bitmap[i >> 5] & ((1u << (i & 31)) - 1u));
         slot[rank] = pack_pt(x + 3 + cg.relx, y + 3 + cg.rely, s);
       }
