@@ -139,10 +139,25 @@ static int build_geometry(orbx_ctx* ctx, int rows, int cols, Geometry& geo) {
     L.scale = ctx->scale[l];
     L.scaled_patch = (int)(kPatchSize * ctx->scale[l]);
     if (l > 0) {
+      while (geo.xtab.size() % 4) geo.xtab.push_back(XTab{0, 0, 0, 0});  // 32-byte aligned level tables (uint4 loads)
       L.xtab_off = (int)geo.xtab.size();
       build_axis_table(geo.lv[l - 1].w, L.w, true, geo.xtab);
       L.ytab_off = (int)geo.ytab.size();
       build_axis_table(geo.lv[l - 1].h, L.h, false, geo.ytab);
+      // LDS tile of k_resize: the largest source rectangle any 64x16 output tile of this level needs
+      int mw = 1, mh = 1;
+      for (int x0 = 0; x0 < L.w; x0 += kRT_W) {
+        const XTab a = geo.xtab[L.xtab_off + x0], b = geo.xtab[L.xtab_off + std::min(x0 + kRT_W, L.w) - 1];
+        mw = std::max(mw, std::max((int)b.s0, (int)b.s1) - ((int)a.s0 & ~3) + 1);
+      }
+      for (int y0 = 0; y0 < L.h; y0 += kRT_H) {
+        const XTab a = geo.ytab[L.ytab_off + y0], b = geo.ytab[L.ytab_off + std::min(y0 + kRT_H, L.h) - 1];
+        mh = std::max(mh, std::max((int)b.s0, (int)b.s1) - (int)a.s0 + 1);
+      }
+      L.rs_lds_pitch = round_up(mw, 4);
+      L.rs_lds_rows = mh;
+      if ((size_t)L.rs_lds_pitch * L.rs_lds_rows > 60 * 1024)
+        return set_err(ctx, ORBX_E_CAPACITY, "scale factor too large for the resize kernel's LDS tile");
     }
   }
   geo.pyr_bytes = plane_off;
@@ -249,10 +264,10 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int nframes, in
       const uint8_t* src; long long sfs; int sp;
       if (l == 1) { src = d_imgs; sfs = (long long)frame_stride; sp = (int)row_stride; }
       else { src = ctx->d_pyr + S.plane_off; sfs = geo.pyr_bytes; sp = S.pitch; }
-      const int nbx = (D.w + 255) / 256, nby = (D.h + 3) / 4, nitems = nbx * nby * nframes;
-      dim3 grid(xcd_grid(nitems)), block(64, 4, 1);
-      hipLaunchKernelGGL(k_resize, grid, block, 0, st, src, sfs, sp, ctx->d_pyr + D.plane_off, (long long)geo.pyr_bytes,
-                         D.pitch, D.w, D.h, ctx->d_xtab + D.xtab_off, ctx->d_ytab + D.ytab_off, nbx, nby, nitems);
+      const int nbx = (D.w + kRT_W - 1) / kRT_W, nby = (D.h + kRT_H - 1) / kRT_H, nitems = nbx * nby * nframes;
+      hipLaunchKernelGGL(k_resize, dim3(xcd_grid(nitems)), dim3(256), (size_t)D.rs_lds_pitch * D.rs_lds_rows, st, src, sfs, sp,
+                         S.w, ctx->d_pyr + D.plane_off, (long long)geo.pyr_bytes, D.pitch, D.w, D.h, ctx->d_xtab + D.xtab_off,
+                         ctx->d_ytab + D.ytab_off, nbx, nby, nitems, D.rs_lds_pitch, D.rs_lds_rows);
     }
   }
   // K2: FAST cells

@@ -38,6 +38,7 @@ struct LevelGeom {
   float hX, scale;
   int scaled_patch;         // (int)(PATCH_SIZE*scale): KeyPoint::size
   int xtab_off, ytab_off;   // offsets into the device resize tables (entries)
+  int rs_lds_pitch, rs_lds_rows;  // LDS source tile of k_resize for this level (bytes per row, rows)
   int64_t bplane_off;       // byte offset of this level inside one frame's BLURRED pyramid block (all levels)
   int btile_begin, btiles_x, btiles_y;  // 64x32 tiles of the blur kernel
 };

@@ -34,30 +34,68 @@ __device__ __forceinline__ int xcd_logical_block(int n_items) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1: cv::resize INTER_LINEAR, CV_8UC1 (src/ORBextractor.cc:1183).  4 output pixels per thread.
+// K1: cv::resize INTER_LINEAR, CV_8UC1 (src/ORBextractor.cc:1183), one pyramid level from the previous one.
+// The byte-gather formulation is bound by the texture-address unit (one VMEM instruction per source byte), so a
+// workgroup stages the source rectangle of its 64x16 output tile into LDS with aligned dword loads and gathers the
+// four bilinear taps of every output pixel from LDS; each lane produces 4 horizontally adjacent pixels (one dword
+// store).  Arithmetic: int32 fixed point exactly as OpenCV.  A source whose rows are not dword
+// aligned is staged with byte loads instead (same LDS layout, same results).
 // ------------------------------------------------------------------------------------------------
+constexpr int kRT_W = 64, kRT_H = 16;  // output tile of k_resize
+
 __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src, long long src_frame_stride,
-                                                int src_pitch, uint8_t* __restrict__ dst, long long dst_frame_stride,
-                                                int dst_pitch, int dw, int dh, const XTab* __restrict__ xt,
-                                                const XTab* __restrict__ yt, int nbx, int nby, int nitems) {
+                                                int src_pitch, int sw, uint8_t* __restrict__ dst,
+                                                long long dst_frame_stride, int dst_pitch, int dw, int dh,
+                                                const XTab* __restrict__ xt, const XTab* __restrict__ yt, int nbx,
+                                                int nby, int nitems, int lds_pitch, int lds_rows) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  const int t = threadIdx.x;
   const int L = xcd_logical_block(nitems);
-  if (L < 0) return;
+  if (L < 0) return;  // block-uniform
   const int frame = L / (nbx * nby), rem = L - frame * (nbx * nby);
   const int by = rem / nbx, bx = rem - by * nbx;
-  const int x4 = (bx * 64 + threadIdx.x) * 4;
-  const int dy = by * 4 + threadIdx.y;
+  const int x0 = bx * kRT_W, y0 = by * kRT_H;
+  const int xl = min(x0 + kRT_W, dw) - 1, yl = min(y0 + kRT_H, dh) - 1;  // last output column / row of the tile
+  // source rectangle (tables are monotonic): columns [X0, X1], rows [Y0, Y1]
+  const XTab txa = xt[x0], txb = xt[xl], tya = yt[y0], tyb = yt[yl];
+  const int X0 = (int)txa.s0 & ~3, X1 = max((int)txb.s0, (int)txb.s1);
+  const int Y0 = tya.s0, Y1 = max((int)tyb.s0, (int)tyb.s1);
+  const int nrows = Y1 - Y0 + 1, ncolb = X1 - X0 + 1;
+  const uint8_t* S = src + (long long)frame * src_frame_stride + (long long)Y0 * src_pitch + X0;
+  const bool al = ((src_pitch & 3) == 0) && ((((unsigned long long)src) & 3) == 0) && ((src_frame_stride & 3) == 0);
+  if (nrows > lds_rows || ncolb > lds_pitch) return;  // host sized the tile from the same tables: cannot happen
+  if (al) {
+    const int ndw = (ncolb + 3) >> 2, lp4 = lds_pitch >> 2;
+    for (int i = t; i < nrows * ndw; i += 256) {
+      const int r = i / ndw, c = i - r * ndw;
+      ((uint32_t*)smem)[r * lp4 + c] = *(const uint32_t*)(S + (long long)r * src_pitch + 4 * c);
+    }
+  } else {
+    for (int i = t; i < nrows * ncolb; i += 256) {
+      const int r = i / ncolb, c = i - r * ncolb;
+      smem[r * lds_pitch + c] = S[(long long)r * src_pitch + c];
+    }
+  }
+  __syncthreads();
+  const int x4 = x0 + (t & 15) * 4, dy = y0 + (t >> 4);
   if (dy >= dh || x4 >= dw) return;
   const XTab ty = yt[dy];
-  const uint8_t* S0 = src + (long long)frame * src_frame_stride + (long long)ty.s0 * src_pitch;
-  const uint8_t* S1 = src + (long long)frame * src_frame_stride + (long long)ty.s1 * src_pitch;
+  const uint8_t* R0 = smem + ((int)ty.s0 - Y0) * lds_pitch - X0;
+  const uint8_t* R1 = smem + ((int)ty.s1 - Y0) * lds_pitch - X0;
   const int b0 = ty.a0, b1 = ty.a1;
+  XTab tx[4];
+  if (x4 + 3 < dw) {
+    const uint4 q0 = *(const uint4*)(xt + x4), q1 = *(const uint4*)(xt + x4 + 2);
+    tx[0] = *(const XTab*)&q0.x; tx[1] = *(const XTab*)&q0.z; tx[2] = *(const XTab*)&q1.x; tx[3] = *(const XTab*)&q1.z;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; i++) tx[i] = xt[min(x4 + i, dw - 1)];
+  }
   uint32_t packed = 0;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const int dx = min(x4 + i, dw - 1);
-    const XTab tx = xt[dx];
-    const int h0 = S0[tx.s0] * tx.a0 + S0[tx.s1] * tx.a1;
-    const int h1 = S1[tx.s0] * tx.a0 + S1[tx.s1] * tx.a1;
+    const int h0 = R0[tx[i].s0] * tx[i].a0 + R0[tx[i].s1] * tx[i].a1;
+    const int h1 = R1[tx[i].s0] * tx[i].a0 + R1[tx[i].s1] * tx[i].a1;
     const int v = ((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xff;
     packed |= (uint32_t)v << (8 * i);
   }
