@@ -27,7 +27,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if not (force or _stale()):
         return OUT
     hipcc = os.environ.get("HIPCC", "hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [hipcc] + FLAGS + os.environ.get("ORBX_EXTRA_FLAGS", "").split() + ["-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd, cwd=CSRC)

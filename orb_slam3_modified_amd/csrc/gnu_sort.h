@@ -180,4 +180,85 @@ ORBX_SORT_HD void gnu_sort(P v, int n) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Data-parallel formulation of the same permutation (what k_quadtree runs, one wave per segment):
+//
+//  * one Hoare partition step of libstdc++ (`__unguarded_partition(first+1, last, first)`) is a closed form of the
+//    ORIGINAL segment: with a[1] < a[2] < ... the positions in (first, last) whose key is >= the pivot key and
+//    b[1] > b[2] > ... the positions whose key is <= the pivot key (followed by the sentinel `first`), the loop swaps
+//    exactly the pairs (a[j], b[j]) for j < J, J = first j with a[j] >= b[j], and returns
+//    cut = a[J] if a[J] < b[J-1] (b[0] = last) else b[J-1]: between two swaps the pointers only scan untouched
+//    positions, and the only touched positions they can stop at are the previous swap partners.
+//  * `__final_insertion_sort` is a stable sort, and after the introsort loop every element already sits inside its
+//    final (<= 16 element, or heap-sorted) segment, so it equals a stable rank inside each such segment.
+//
+// gnu_sort_model is the sequential statement of that formulation (tests/support/check_gnu_sort.cpp checks it against
+// std::sort next to gnu_sort); partition_closed_form is shared with the device code.
+template <typename P, typename I>
+ORBX_SORT_HD int partition_closed_form(P v, int first, int last, I a, I r) {
+  // a, r: scratch index arrays with room for last - first entries
+  const uint32_t kp = (uint32_t)(v[first] >> 32);
+  int nL = 0, nR = 0;
+  for (int i = first + 1; i < last; i++) {
+    const uint32_t k = (uint32_t)(v[i] >> 32);
+    if (k >= kp) a[nL++] = i;
+    if (k <= kp) r[nR++] = i;
+  }
+  const int lim = nL < nR + 1 ? nL : nR + 1;
+  int cnt = 0;
+  for (int j = 1; j <= lim; j++) {
+    const int bj = j <= nR ? (int)r[nR - j] : first;
+    if ((int)a[j - 1] < bj) cnt++;
+  }
+  for (int j = 1; j <= cnt; j++) swap_at(v, (int)a[j - 1], (int)r[nR - j]);
+  const int J = cnt + 1;
+  const int rprev = J == 1 ? last : (int)r[nR - (J - 1)];
+  return (J <= nL && (int)a[J - 1] < rprev) ? (int)a[J - 1] : rprev;
+}
+
+template <typename P>
+ORBX_SORT_HD void gnu_sort_model(P v, int n, int* idx_a, int* idx_r, int* seg_lo, int* seg_hi, elem_t* tmp, int* work) {
+  // scratch: idx_a, idx_r, seg_lo, seg_hi, tmp hold n entries; work holds 6 * (n / 8 + 2) ints (pending segments)
+  if (n <= 0) return;
+  for (int i = 0; i < n; i++) { seg_lo[i] = 0; seg_hi[i] = n; }
+  if (n > 16) {
+    // level-synchronous introsort loop: every pending segment takes one partition step per round
+    const int cap = n / 8 + 2;  // segments of one round are disjoint and longer than 16
+    int *cur_f = work, *cur_l = work + cap, *cur_d = work + 2 * cap, ncur = 1;
+    int *nxt_f = work + 3 * cap, *nxt_l = work + 4 * cap, *nxt_d = work + 5 * cap;
+    cur_f[0] = 0; cur_l[0] = n; cur_d[0] = 2 * (31 - __builtin_clz((unsigned)n));
+    while (ncur > 0) {
+      int nn = 0;
+      for (int s = 0; s < ncur; s++) {
+        const int f = cur_f[s], l = cur_l[s], d = cur_d[s];
+        if (d == 0) {
+          heap_sort(v, f, l);
+          for (int i = f; i < l; i++) { seg_lo[i] = i; seg_hi[i] = i + 1; }  // already in final order
+          continue;
+        }
+        move_median_to_first(v, f, f + 1, f + (l - f) / 2, l - 1);
+        const int cut = partition_closed_form(v, f, l, idx_a, idx_r);
+        const int cf[2] = {f, cut}, cl[2] = {cut, l};
+        for (int c = 0; c < 2; c++) {
+          if (cl[c] - cf[c] > 16) { nxt_f[nn] = cf[c]; nxt_l[nn] = cl[c]; nxt_d[nn] = d - 1; nn++; }
+          else for (int i = cf[c]; i < cl[c]; i++) { seg_lo[i] = cf[c]; seg_hi[i] = cl[c]; }
+        }
+      }
+      for (int s = 0; s < nn; s++) { cur_f[s] = nxt_f[s]; cur_l[s] = nxt_l[s]; cur_d[s] = nxt_d[s]; }
+      ncur = nn;
+    }
+  }
+  // stable rank inside every final segment
+  for (int i = 0; i < n; i++) {
+    const uint32_t k = (uint32_t)(v[i] >> 32);
+    int rank = seg_lo[i];
+    for (int j = seg_lo[i]; j < seg_hi[i]; j++) {
+      const uint32_t kj = (uint32_t)(v[j] >> 32);
+      rank += (kj < k) || (kj == k && j < i);
+    }
+    tmp[rank] = v[i];
+  }
+  for (int i = 0; i < n; i++) v[i] = tmp[i];
+}
+
 }  // namespace orbx_sort

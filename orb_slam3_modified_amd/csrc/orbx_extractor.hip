@@ -16,6 +16,8 @@ namespace orbx {
 
 // Workgroup size of k_fast_cells: 128 by default (measured best); ORBX_FAST_THREADS=64|128|256 in the environment overrides it
 // (tuning knob, read once per context).
+constexpr int kQtLdsPoints = 2048;  // LDS-resident candidate capacity per (frame, level) of k_quadtree
+
 static int fast_threads_from_env() {
   const char* e = getenv("ORBX_FAST_THREADS");
   const int v = e ? atoi(e) : 128;
@@ -293,14 +295,18 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int nframes, in
     ProfScope ps(ctx, 2, st);
     const int node_cap = round_up(geo.max_quota + 4 * kMaxRoots + 8, 4);
     const int scan_cap = round_up(std::max(node_cap, geo.max_cells_per_level) + 8, 4);
-    const size_t lds = (size_t)node_cap * (2 * sizeof(QNode) + 2 * 8 + sizeof(int4) + 4) + (size_t)scan_cap * 8;
+    if (node_cap > 4095) return set_err(ctx, ORBX_E_CAPACITY, "nfeatures too large for the quadtree kernel");
+    // candidates of one (frame, level) live in LDS when they fit kQtLdsPoints (two ping-pong buffers), else in HBM
+    const int pts_cap = kQtLdsPoints;
+    const size_t lds = (size_t)node_cap * (2 * sizeof(QNode) + 2 * 8 + sizeof(int4) + 4) + (size_t)scan_cap * 8 +
+                       (size_t)pts_cap * 2 * sizeof(uint32_t);
     if (lds > 64 * 1024) {
       hipError_t e = hipFuncSetAttribute((const void*)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return set_err(ctx, ORBX_E_CAPACITY, "nfeatures too large for the quadtree kernel's LDS");
     }
     dim3 grid(geo.nlevels, nframes, 1);
     hipLaunchKernelGGL(k_quadtree, grid, dim3(256), lds, st, ctx->d_geo, ctx->d_cells, ctx->d_cand, ctx->d_cell_cnt,
-                       ctx->d_pts, ctx->d_lvl_kp, ctx->d_lvl_n, node_cap, scan_cap);
+                       ctx->d_pts, ctx->d_lvl_kp, ctx->d_lvl_n, node_cap, scan_cap, pts_cap);
   }
   // K3b: output slots
   {
@@ -611,6 +617,15 @@ int orbx_debug_calib_copy(orbx_ctx* ctx, const void* d_src, void* d_dst, size_t 
   ORBX_HIP(ctx, hipGetLastError());
   return ORBX_OK;
 }
+
+#ifdef ORBX_QT_PROFILE
+int orbx_debug_qt_profile(orbx_ctx* ctx, long long* out, int reset) {
+  (void)hipDeviceSynchronize();
+  if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qt_prof), sizeof(long long) * kMaxLevels * 8);
+  if (reset) { long long z[kMaxLevels * 8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_qt_prof), z, sizeof(z)); }
+  return 0;
+}
+#endif
 
 const char* orbx_kernel_name(int slot) {
   static const char* names[ORBX_NUM_KERNELS] = {"k_resize(pyramid chain)", "k_fast_cells", "k_quadtree", "k_assemble",

@@ -324,6 +324,15 @@ __global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__
 // ------------------------------------------------------------------------------------------------
 struct QNode { int16_t x0, y0, x1, y1; int32_t start, count; };
 
+#ifdef ORBX_QT_PROFILE  // temporary phase timing of frame 0 (cycles): [level][slot]
+__device__ long long g_qt_prof[kMaxLevels * 8];
+#define QT_T0() long long _qt_t = wall_clock64()
+#define QT_ACC(slot) do { if (threadIdx.x == 0 && blockIdx.y == 0) { const long long _n = wall_clock64(); g_qt_prof[blockIdx.x * 8 + (slot)] += _n - _qt_t; _qt_t = _n; } } while (0)
+#else
+#define QT_T0() do {} while (0)
+#define QT_ACC(slot) do {} while (0)
+#endif
+
 constexpr unsigned long long kM21 = (1ull << 21) - 1ull;
 
 __device__ __forceinline__ unsigned long long block_excl_scan(unsigned long long* a, int n, unsigned long long* wt) {
@@ -346,6 +355,117 @@ __device__ __forceinline__ unsigned long long block_excl_scan(unsigned long long
   for (int i = b; i < e; i++) { const unsigned long long v = a[i]; a[i] = run; run += v; }
   __syncthreads();
   return total;
+}
+
+// LDS written by some lanes of a wave and read by other lanes of the same wave: order the accesses.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One wave: the closed form of libstdc++'s Hoare partition step on v[first, last) with the pivot already moved to
+// v[first] (gnu_sort.h: partition_closed_form is the sequential statement).  ia / ir: per-wave LDS index scratch.
+__device__ __forceinline__ int wave_partition(unsigned long long* v, int first, int last, int16_t* ia, int16_t* ir) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const uint32_t kp = (uint32_t)(v[first] >> 32);
+  int nL = 0, nR = 0;
+  for (int base = first + 1; base < last; base += 64) {
+    const int i = base + lane;
+    const bool valid = i < last;
+    const uint32_t k = valid ? (uint32_t)(v[i] >> 32) : 0u;
+    const bool isL = valid && k >= kp, isR = valid && k <= kp;
+    const unsigned long long bL = __ballot(isL), bR = __ballot(isR);
+    if (isL) ia[nL + __popcll(bL & lt)] = (int16_t)i;
+    if (isR) ir[nR + __popcll(bR & lt)] = (int16_t)i;
+    nL += __popcll(bL);
+    nR += __popcll(bR);
+  }
+  wave_lds_sync();
+  const int lim = min(nL, nR + 1);
+  int cnt = 0;
+  for (int j0 = 1; j0 <= lim; j0 += 64) {
+    const int j = j0 + lane;
+    bool ok = false;
+    if (j <= lim) {
+      const int bj = j <= nR ? (int)ir[nR - j] : first;
+      ok = (int)ia[j - 1] < bj;
+    }
+    cnt += __popcll(__ballot(ok));
+  }
+  for (int j = 1 + lane; j <= cnt; j += 64) {
+    const int a = ia[j - 1], b = ir[nR - j];
+    const unsigned long long ta = v[a], tb = v[b];
+    v[a] = tb;
+    v[b] = ta;
+  }
+  const int J = cnt + 1;
+  const int rprev = J == 1 ? last : (int)ir[nR - (J - 1)];
+  const int cut = (J <= nL && (int)ia[J - 1] < rprev) ? (int)ia[J - 1] : rprev;
+  wave_lds_sync();
+  return cut;
+}
+
+// std::sort(v, v + n) with the reference's (count, UL.x) comparator, exact libstdc++ permutation (ties included),
+// by the whole workgroup: level-synchronous introsort loop (one wave per pending segment and round), then a stable
+// rank inside every final segment (== __final_insertion_sort).  tmp: n elements; seg: n words; q0/q1: n/8+2 words each;
+// idx: NW * 2 * n int16.  All in LDS.  Ends with a barrier.
+__device__ __forceinline__ void block_gnu_sort(unsigned long long* v, int n, unsigned long long* tmp, uint32_t* seg,
+                                               uint32_t* q0, uint32_t* q1, int16_t* idx, int* sh_cnt) {
+  const int T = blockDim.x, t = threadIdx.x, lane = t & 63, w = t >> 6, NW = T >> 6;
+  for (int i = t; i < n; i += T) seg[i] = (uint32_t)n << 16;  // lo = 0, hi = n
+  if (n > 16) {
+    if (t == 0) { q0[0] = (uint32_t)n << 12 | (uint32_t)(2 * (31 - __clz(n))) << 24; *sh_cnt = 0; }
+    __syncthreads();
+    int ncur = 1;
+    int16_t* ia = idx + (size_t)w * 2 * n;
+    int16_t* ir = ia + n;
+    while (ncur > 0) {
+      for (int sidx = w; sidx < ncur; sidx += NW) {
+        const uint32_t pk = q0[sidx];
+        const int f = (int)(pk & 0xfffu), l = (int)((pk >> 12) & 0xfffu), d = (int)(pk >> 24);
+        if (d == 0) {  // depth limit: heapsort fallback (practically never), result already in final order
+          if (lane == 0) orbx_sort::heap_sort(v, f, l);
+          for (int i = f + lane; i < l; i += 64) seg[i] = (uint32_t)i | (uint32_t)(i + 1) << 16;
+          continue;
+        }
+        if (lane == 0) orbx_sort::move_median_to_first(v, f, f + 1, f + (l - f) / 2, l - 1);
+        wave_lds_sync();
+        const int cut = wave_partition(v, f, l, ia, ir);
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+          const int cf = c ? cut : f, cl = c ? l : cut;
+          if (cl - cf > 16) {
+            if (lane == 0) q1[atomicAdd(sh_cnt, 1)] = (uint32_t)cf | (uint32_t)cl << 12 | (uint32_t)(d - 1) << 24;
+          } else {
+            for (int i = cf + lane; i < cl; i += 64) seg[i] = (uint32_t)cf | (uint32_t)cl << 16;
+          }
+        }
+      }
+      __syncthreads();
+      ncur = *sh_cnt;
+      __syncthreads();
+      if (t == 0) *sh_cnt = 0;
+      { uint32_t* tq = q0; q0 = q1; q1 = tq; }
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  for (int i = t; i < n; i += T) {
+    const unsigned long long e = v[i];
+    const uint32_t k = (uint32_t)(e >> 32), sg = seg[i];
+    const int lo = (int)(sg & 0xffffu), hi = (int)(sg >> 16);
+    int rank = lo;
+    for (int j = lo; j < hi; j++) {
+      const uint32_t kj = (uint32_t)(v[j] >> 32);
+      rank += (kj < k) || (kj == k && j < i);
+    }
+    tmp[rank] = e;
+  }
+  __syncthreads();
+  for (int i = t; i < n; i += T) v[i] = tmp[i];
+  __syncthreads();
 }
 
 // One wave: child counts of `nd` (DivideNode, src/ORBextractor.cc:480-536) and optional stable scatter cur->nxt.
@@ -405,11 +525,16 @@ __device__ __forceinline__ unsigned long long expand_elem(const QNode n, int pos
   return ((unsigned long long)key << 32) | (uint32_t)pos;
 }
 
-__global__ __launch_bounds__(256) void k_quadtree(const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
-                                                  const uint32_t* __restrict__ cand, const int32_t* __restrict__ cell_cnt,
-                                                  uint32_t* __restrict__ pts, uint32_t* __restrict__ lvl_kp,
-                                                  int32_t* __restrict__ lvl_n, int node_cap, int scan_cap) {
-  extern __shared__ __align__(16) uint8_t smem[];
+// Body of k_quadtree; cur / nxt are the two point buffers of this (frame, level): LDS when the level's candidates fit
+// (LP, the usual case: every access is then an LDS access instead of an L2 round trip), global memory otherwise.
+template <bool LP>
+__device__ __forceinline__ void quadtree_body(const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
+                                              const uint32_t* __restrict__ fcand, uint32_t* gcur, uint32_t* gnxt,
+                                              uint32_t* lcur, uint32_t* lnxt, uint32_t* __restrict__ lvl_kp,
+                                              int32_t* __restrict__ lvl_n, int node_cap, int scan_cap, uint8_t* smem, int n,
+                                              unsigned long long* wt, int* sh_cnt, int* sh_jstar_p) {
+  uint32_t* cur = LP ? lcur : gcur;
+  uint32_t* nxt = LP ? lnxt : gnxt;
   QNode* LA = (QNode*)smem;
   QNode* LB = LA + node_cap;
   unsigned long long* EA = (unsigned long long*)(LB + node_cap);
@@ -417,34 +542,25 @@ __global__ __launch_bounds__(256) void k_quadtree(const DeviceGeom* __restrict__
   unsigned long long* scan = EB + node_cap;
   int4* kids = (int4*)(scan + scan_cap);
   int* flag = (int*)(kids + node_cap);
-  __shared__ unsigned long long wt[8];
-  __shared__ int sh_cnt[kMaxRoots];
-  __shared__ int sh_jstar;
+  int& sh_jstar = *sh_jstar_p;
 
   const int T = blockDim.x, t = threadIdx.x, lane = t & 63, w = t >> 6, NW = T >> 6;
   const int level = blockIdx.x, frame = blockIdx.y;
   const DeviceLevel& lv = g->lv[level];
   const int N = lv.quota;
-  uint32_t* cur = pts + ((long long)frame * 2 + 0) * g->cand_total + lv.cand_off;
-  uint32_t* nxt = pts + ((long long)frame * 2 + 1) * g->cand_total + lv.cand_off;
-  const int32_t* ccnt = cell_cnt + (long long)frame * g->ncells_total + lv.cell_begin;
-  const uint32_t* fcand = cand + (long long)frame * g->cand_total;
-
-  // ---- gather the per-cell lists in cell order (vToDistributeKeys, src/ORBextractor.cc:863-868)
-  for (int c = t; c < lv.ncells; c += T) scan[c] = (unsigned long long)ccnt[c];
-  __syncthreads();
-  const int n = (int)block_excl_scan(scan, lv.ncells, wt);
-  for (int c = w; c < lv.ncells; c += NW) {
-    const int cnt = ccnt[c], off = (int)scan[c];
-    const uint32_t* s = fcand + cells[lv.cell_begin + c].slot_off;
-    for (int e = lane; e < cnt; e += 64) cur[off + e] = s[e];
+  QT_T0();
+  // ---- gather the per-cell lists in cell order (vToDistributeKeys, src/ORBextractor.cc:863-868): `scan` holds the
+  // exclusive prefix of the cell counts (computed by the kernel); element e finds its cell by binary search
+  for (int e = t; e < n; e += T) {
+    int lo = 0, hi = lv.ncells - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if ((int)scan[mid] <= e) lo = mid; else hi = mid - 1;
+    }
+    cur[e] = fcand[cells[lv.cell_begin + lo].slot_off + (e - (int)scan[lo])];
   }
   __syncthreads();
   int nL = 0, nE = 0;
-  if (n == 0) {
-    if (t == 0) lvl_n[frame * g->nlevels + level] = 0;
-    return;
-  }
   // ---- root nodes (src/ORBextractor.cc:559-601)
   const int H = lv.h - 2 * kBorder;
   if (lv.nroots == 1) {
@@ -493,6 +609,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const DeviceGeom* __restrict__
   }
   __syncthreads();
 
+  QT_ACC(0);
   bool finish = false, sorted_phase = false;
   while (!finish) {
     if (!sorted_phase) {
@@ -555,12 +672,13 @@ __global__ __launch_bounds__(256) void k_quadtree(const DeviceGeom* __restrict__
       nE = nToExpand;
       if (nL >= N || nL == prevSize) finish = true;
       else if (nL + 3 * nE > N) sorted_phase = true;
+      QT_ACC(1);
     } else {
       // ======== sorted expansion (src/ORBextractor.cc:692-753)
       const int prevSize = nL;
       const int m = nE;
-      if (t == 0) orbx_sort::gnu_sort(EA, m);
-      __syncthreads();
+      block_gnu_sort(EA, m, EB, (uint32_t*)flag, (uint32_t*)scan, (uint32_t*)scan + (scan_cap & ~1), (int16_t*)kids, sh_cnt);
+      QT_ACC(2);
       for (int j = w; j < m; j += NW) {
         const int4 c = wave_split(LA[(uint32_t)EA[j]], cur, nxt, false);
         if (lane == 0) kids[j] = c;
@@ -634,6 +752,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const DeviceGeom* __restrict__
       nL = front + keepTot;
       nE = qtot;
       if (nL >= N || nL == prevSize) finish = true;
+      QT_ACC(3);
     }
   }
   // ---- best point of every node, first maximum wins (src/ORBextractor.cc:757-776)
@@ -649,6 +768,38 @@ __global__ __launch_bounds__(256) void k_quadtree(const DeviceGeom* __restrict__
     out[i] = pack_pt(pt_x(best) + kBorder, pt_y(best) + kBorder, pt_s(best));
   }
   if (t == 0) lvl_n[frame * g->nlevels + level] = nL <= lv.kp_cap ? nL : -nL;  // negative = capacity overflow
+  QT_ACC(4);
+}
+
+__global__ __launch_bounds__(256) void k_quadtree(const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
+                                                  const uint32_t* __restrict__ cand, const int32_t* __restrict__ cell_cnt,
+                                                  uint32_t* __restrict__ pts, uint32_t* __restrict__ lvl_kp,
+                                                  int32_t* __restrict__ lvl_n, int node_cap, int scan_cap, int pts_cap) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  __shared__ unsigned long long wt[8];
+  __shared__ int sh_cnt[kMaxRoots];
+  __shared__ int sh_jstar;
+  // LDS carve-up (see quadtree_body): LA, LB, EA, EB, scan, kids, flag, then the two LDS point buffers
+  unsigned long long* scan = (unsigned long long*)(smem + (size_t)node_cap * (2 * sizeof(QNode) + 2 * 8));
+  uint32_t* lpts = (uint32_t*)(smem + (size_t)node_cap * (2 * sizeof(QNode) + 2 * 8 + sizeof(int4) + 4) + (size_t)scan_cap * 8);
+  const int T = blockDim.x, t = threadIdx.x;
+  const int level = blockIdx.x, frame = blockIdx.y;
+  const DeviceLevel& lv = g->lv[level];
+  uint32_t* gcur = pts + ((long long)frame * 2 + 0) * g->cand_total + lv.cand_off;
+  uint32_t* gnxt = pts + ((long long)frame * 2 + 1) * g->cand_total + lv.cand_off;
+  const int32_t* ccnt = cell_cnt + (long long)frame * g->ncells_total + lv.cell_begin;
+  const uint32_t* fcand = cand + (long long)frame * g->cand_total;
+  for (int c = t; c < lv.ncells; c += T) scan[c] = (unsigned long long)ccnt[c];
+  __syncthreads();
+  const int n = (int)block_excl_scan(scan, lv.ncells, wt);
+  if (n == 0) {
+    if (t == 0) lvl_n[frame * g->nlevels + level] = 0;
+    return;
+  }
+  if (n <= pts_cap)
+    quadtree_body<true>(g, cells, fcand, gcur, gnxt, lpts, lpts + pts_cap, lvl_kp, lvl_n, node_cap, scan_cap, smem, n, wt, sh_cnt, &sh_jstar);
+  else
+    quadtree_body<false>(g, cells, fcand, gcur, gnxt, lpts, lpts + pts_cap, lvl_kp, lvl_n, node_cap, scan_cap, smem, n, wt, sh_cnt, &sh_jstar);
 }
 
 // ------------------------------------------------------------------------------------------------

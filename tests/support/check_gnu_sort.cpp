@@ -31,7 +31,15 @@ static bool run_case(const std::vector<int>& cnt, const std::vector<int>& ulx) {
     mine[i] = ((uint64_t)key << 32) | (uint32_t)i;
   }
   std::sort(ref.begin(), ref.end(), cmp);
+  std::vector<orbx_sort::elem_t> model(mine), tmp(n + 1);
+  std::vector<int> ia(n + 1), ir(n + 1), slo(n + 1), shi(n + 1), work(6 * (n / 8 + 2));
   orbx_sort::gnu_sort(mine.data(), (int)n);
+  orbx_sort::gnu_sort_model(model.data(), (int)n, ia.data(), ir.data(), slo.data(), shi.data(), tmp.data(), work.data());
+  for (size_t i = 0; i < n; i++)
+    if (model[i] != mine[i]) {
+      fprintf(stderr, "MODEL MISMATCH n=%zu at %zu: serial %u parallel-model %u\n", n, i, (uint32_t)mine[i], (uint32_t)model[i]);
+      return false;
+    }
   for (size_t i = 0; i < n; i++) {
     size_t ri = (size_t)(ref[i].second - nodes.data());
     if (ri != (uint32_t)mine[i]) {
