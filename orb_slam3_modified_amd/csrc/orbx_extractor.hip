@@ -84,7 +84,7 @@ static int build_geometry(orbx_ctx* ctx, int rows, int cols, Geometry& geo) {
     if (l > 0) plane_off += (int64_t)L.pitch * L.h;
     L.bplane_off = bplane_off;
     bplane_off += (int64_t)L.pitch * L.h;
-    L.btile_begin = btile; L.btiles_x = (L.w + 63) / 64; L.btiles_y = (L.h + 31) / 32;
+    L.btile_begin = btile; L.btiles_x = (L.w + kBT_W - 1) / kBT_W; L.btiles_y = (L.h + kBT_H - 1) / kBT_H;
     btile += L.btiles_x * L.btiles_y;
     const int minB = kBorder, maxBX = L.w - kBorder, maxBY = L.h - kBorder;
     const float width = (float)(maxBX - minB), height = (float)(maxBY - minB);
@@ -322,7 +322,9 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int nframes, in
     BlurConsts bc;
     bc.w0 = (uint32_t)gk[0] | ((uint32_t)gk[1] << 8) | ((uint32_t)gk[2] << 16) | ((uint32_t)gk[3] << 24);
     bc.w1 = (uint32_t)gk[4] | ((uint32_t)gk[5] << 8) | ((uint32_t)gk[6] << 16);
-    for (int i = 0; i < 7; i++) bc.k[i] = gk[i];
+    const uint32_t k0 = gk[0], k1 = gk[1], k2 = gk[2], k3 = gk[3], k4 = gk[4], k5 = gk[5], k6 = gk[6];
+    bc.we[0] = k0 | k1 << 16; bc.we[1] = k2 | k3 << 16; bc.we[2] = k4 | k5 << 16; bc.we[3] = k6;
+    bc.wo[0] = k0 << 16; bc.wo[1] = k1 | k2 << 16; bc.wo[2] = k3 | k4 << 16; bc.wo[3] = k5 | k6 << 16;
     const int nitems = geo.btiles_total * nframes;
     hipLaunchKernelGGL(k_blur7, dim3(xcd_grid(nitems)), dim3(256), 0, st, ctx->d_geo, d_imgs, (long long)row_stride,
                        (long long)frame_stride, ctx->d_pyr, (long long)geo.pyr_bytes, ctx->d_blur, (long long)geo.blur_bytes, bc,

@@ -847,18 +847,23 @@ __global__ __launch_bounds__(256) void k_assemble(const DeviceGeom* __restrict__
 
 // ------------------------------------------------------------------------------------------------
 // K4a: cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) of every pyramid level (src/ORBextractor.cc:1132-1133)
-// in 8.8 fixed point.  64x32 output tile per block, raw tile (+3 halo, origin at x0-4 so rows are
-// dword aligned) in LDS; horizontal pass with v_dot4_u32_u8 on byte-aligned windows (v_alignbyte), vertical pass
-// on u16 with exact 32-bit accumulation; one dword (4 px) store per lane.
+// in 8.8 fixed point.  The kernel is VALU-bound, so both passes run on packed dot products:
+//   * 64x58 output tile per workgroup; raw tile of 64 rows x 72 bytes (3-px halo, origin at x0-4 so rows are dword
+//     aligned; LDS pitch 96 keeps the two row pairs of a 32-lane group on disjoint banks), staged with dword loads;
+//     reflect-101 is a row remap for y and a few patched bytes per row for x;
+//   * horizontal pass: v_dot4_u32_u8 on byte-aligned windows (v_alignbyte), one lane = 2 rows x 4 px, results
+//     stored as row-pair interleaved u16 (row 2p in the low half, row 2p+1 in the high half of a dword);
+//   * vertical pass: v_dot2_u32_u16 on those pairs (4 instructions per pixel, exact 32-bit accumulation,
+//     single rounding (acc + 2^15) >> 16), one lane = 2 rows x 4 px, one dword store per row.
 // ------------------------------------------------------------------------------------------------
-struct BlurConsts { uint32_t w0, w1; int k[7]; };
+struct BlurConsts { uint32_t w0, w1; uint32_t we[4], wo[4]; };
 
 __device__ __forceinline__ int reflect101(int p, int n) {
   while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
   return p;
 }
 
-constexpr int kBT_W = 64, kBT_H = 32, kBT_RP = 72, kBT_RR = kBT_H + 6;  // raw tile: 38 rows x 72 bytes
+constexpr int kBT_W = 64, kBT_H = 58, kBT_RR = 64, kBT_RP = 96, kBT_RB = 72;  // raw tile: 64 rows, 72 bytes used of 96
 
 template <int OFF>
 __device__ __forceinline__ uint32_t bytes4(uint32_t d0, uint32_t d1, uint32_t d2) {
@@ -869,12 +874,29 @@ __device__ __forceinline__ uint32_t bytes4(uint32_t d0, uint32_t d1, uint32_t d2
   return __builtin_amdgcn_alignbyte(d2, d1, OFF - 4);
 }
 
+typedef unsigned short v2u16_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {
+  v2u16_t va, vb;
+  __builtin_memcpy(&va, &a, 4);
+  __builtin_memcpy(&vb, &b, 4);
+  return __builtin_amdgcn_udot2(va, vb, c, false);
+}
+
+// horizontal 7-tap sums of 4 adjacent pixels: output x (tile coords 4j..4j+3) reads raw bytes x+1 .. x+7
+__device__ __forceinline__ void hrow4(const uint32_t* rw, const BlurConsts& bc, uint32_t (&a)[4]) {
+  const uint32_t d0 = rw[0], d1 = rw[1], d2 = rw[2];
+  a[0] = __builtin_amdgcn_udot4(bytes4<1>(d0, d1, d2), bc.w0, __builtin_amdgcn_udot4(bytes4<5>(d0, d1, d2), bc.w1, 0u, false), false);
+  a[1] = __builtin_amdgcn_udot4(bytes4<2>(d0, d1, d2), bc.w0, __builtin_amdgcn_udot4(bytes4<6>(d0, d1, d2), bc.w1, 0u, false), false);
+  a[2] = __builtin_amdgcn_udot4(bytes4<3>(d0, d1, d2), bc.w0, __builtin_amdgcn_udot4(bytes4<7>(d0, d1, d2), bc.w1, 0u, false), false);
+  a[3] = __builtin_amdgcn_udot4(d1, bc.w0, __builtin_amdgcn_udot4(d2, bc.w1, 0u, false), false);
+}
+
 __global__ __launch_bounds__(256) void k_blur7(const DeviceGeom* __restrict__ g, const uint8_t* __restrict__ imgs,
                                                long long img_row_stride, long long img_frame_stride,
                                                const uint8_t* __restrict__ pyr, long long pyr_frame_bytes,
                                                uint8_t* __restrict__ blur, long long blur_frame_bytes, BlurConsts bc, int nitems) {
   __shared__ __align__(16) uint8_t raw[kBT_RR * kBT_RP];
-  __shared__ __align__(16) uint16_t hb[kBT_RR * kBT_W];
+  __shared__ __align__(16) uint32_t hp[(kBT_RR / 2) * kBT_W];
   const int t = threadIdx.x;
   const int L = xcd_logical_block(nitems);
   if (L < 0) return;  // block-uniform
@@ -890,61 +912,74 @@ __global__ __launch_bounds__(256) void k_blur7(const DeviceGeom* __restrict__ g,
   if (l == 0) { img = imgs + (long long)frame * img_frame_stride; pitch = img_row_stride; }
   else { img = pyr + (long long)frame * pyr_frame_bytes + lv.plane_off; pitch = lv.pitch; }
   const int w = lv.w, h = lv.h;
-  // raw[r][c] = level(reflect(y0-3+r), reflect(x0-4+c))
-  const bool interior = x0 - 4 >= 0 && x0 + kBT_RP - 4 <= w && y0 - 3 >= 0 && y0 + kBT_H + 3 <= h &&
-                        ((pitch & 3) == 0) && ((((unsigned long long)img) & 3) == 0);
-  if (interior) {
-    for (int i = t; i < kBT_RR * (kBT_RP / 4); i += 256) {
-      const int r = i / (kBT_RP / 4), c = i - r * (kBT_RP / 4);
-      ((uint32_t*)raw)[i] = *(const uint32_t*)(img + (long long)(y0 - 3 + r) * pitch + (x0 - 4) + 4 * c);
+  // raw[r][c] = level(reflect(y0-3+r), reflect(x0-4+c)), c = 0..71
+  const bool al = ((pitch & 3) == 0) && ((((unsigned long long)img) & 3) == 0) && (w >= 8);
+  if (al) {
+    // dwords that start inside [0, w) are loaded (a row is readable up to its 4-byte rounded width), the others and the
+    // reflected columns are patched below
+    for (int i = t; i < kBT_RR * (kBT_RB / 4); i += 256) {
+      const int r = (int)(((uint32_t)i * 3641u) >> 16), c = i - r * (kBT_RB / 4);  // i / 18
+      const int sx = x0 - 4 + 4 * c;
+      uint32_t v = 0;
+      if (sx >= 0 && sx < w) v = *(const uint32_t*)(img + (long long)reflect101(y0 - 3 + r, h) * pitch + sx);
+      ((uint32_t*)raw)[r * (kBT_RP / 4) + c] = v;
+    }
+    const bool left = x0 == 0, right = x0 + kBT_W + 3 > w;  // block-uniform
+    if (left || right) {
+      __syncthreads();
+      // reflect-101 columns: raw col 4+x for x in {-3..-1} <- x' = -x; for x in {w .. w+2} <- x' = 2w-2-x (w >= 8)
+      for (int i = t; i < kBT_RR * 6; i += 256) {
+        const int r = i / 6, k = i - r * 6;
+        uint8_t* row = raw + r * kBT_RP;
+        if (k < 3) { if (left) row[4 - (k + 1)] = row[4 + (k + 1)]; }
+        else if (right) {
+          const int x = w + (k - 3);            // level column to synthesise
+          const int c = x - x0 + 4;
+          if (c < kBT_RB) row[c] = row[2 * w - 2 - x - x0 + 4];
+        }
+      }
     }
   } else {
-    for (int i = t; i < kBT_RR * kBT_RP; i += 256) {
-      const int r = i / kBT_RP, c = i - r * kBT_RP;
-      raw[i] = img[(long long)reflect101(y0 - 3 + r, h) * pitch + reflect101(x0 - 4 + c, w)];
+    for (int i = t; i < kBT_RR * kBT_RB; i += 256) {
+      const int r = i / kBT_RB, c = i - r * kBT_RB;
+      raw[r * kBT_RP + c] = img[(long long)reflect101(y0 - 3 + r, h) * pitch + reflect101(x0 - 4 + c, w)];
     }
   }
   __syncthreads();
-  // horizontal: output x (tile coords) reads raw columns x+1 .. x+7
-  for (int i = t; i < kBT_RR * (kBT_W / 4); i += 256) {
-    const int r = i >> 4, j = i & 15;
-    const uint32_t* rw = (const uint32_t*)(raw + r * kBT_RP) + j;
-    const uint32_t d0 = rw[0], d1 = rw[1], d2 = rw[2];
-    const uint32_t a0 = __builtin_amdgcn_udot4(bytes4<1>(d0, d1, d2), bc.w0, __builtin_amdgcn_udot4(bytes4<5>(d0, d1, d2), bc.w1, 0u, false), false);
-    const uint32_t a1 = __builtin_amdgcn_udot4(bytes4<2>(d0, d1, d2), bc.w0, __builtin_amdgcn_udot4(bytes4<6>(d0, d1, d2), bc.w1, 0u, false), false);
-    const uint32_t a2 = __builtin_amdgcn_udot4(bytes4<3>(d0, d1, d2), bc.w0, __builtin_amdgcn_udot4(bytes4<7>(d0, d1, d2), bc.w1, 0u, false), false);
-    // x = 4j+3 needs raw bytes 4j+4 .. 4j+10 = d1 and the low 3 bytes of d2
-    const uint32_t a3 = __builtin_amdgcn_udot4(d1, bc.w0, __builtin_amdgcn_udot4(d2, bc.w1, 0u, false), false);
-    uint2 o;
-    o.x = a0 | (a1 << 16);
-    o.y = a2 | (a3 << 16);
-    *(uint2*)(hb + r * kBT_W + 4 * j) = o;
+  // horizontal: item = (row pair rp, group j): rows 2rp, 2rp+1, output columns 4j..4j+3
+  for (int i = t; i < (kBT_RR / 2) * (kBT_W / 4); i += 256) {
+    const int rp = i >> 4, j = i & 15;
+    uint32_t a[4], b[4];
+    hrow4((const uint32_t*)(raw + (2 * rp) * kBT_RP) + j, bc, a);
+    hrow4((const uint32_t*)(raw + (2 * rp + 1) * kBT_RP) + j, bc, b);
+    uint4 o;
+    o.x = a[0] | (b[0] << 16); o.y = a[1] | (b[1] << 16); o.z = a[2] | (b[2] << 16); o.w = a[3] | (b[3] << 16);
+    *(uint4*)(hp + rp * kBT_W + 4 * j) = o;
   }
   __syncthreads();
-  // vertical: lane = (x group j, row pair rg): rows 2rg, 2rg+1 of the tile
-  {
-    const int j = t & 15, rg = t >> 4;
-    uint32_t lo[8], hi[8];  // 8 source rows x 4 columns (u16 pairs)
+  // vertical: item = (output row pair op, group j): tile rows 2op, 2op+1 read h rows 2op .. 2op+7 = pairs op .. op+3
+  uint8_t* bl = blur + (long long)frame * blur_frame_bytes + lv.bplane_off;
+  for (int i = t; i < (kBT_H / 2) * (kBT_W / 4); i += 256) {
+    const int op = i >> 4, j = i & 15;
+    const int y = y0 + 2 * op, x = x0 + 4 * j;
+    if (y >= h || x >= w) continue;
+    uint4 P[4];
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-      const uint2 v = *(const uint2*)(hb + (2 * rg + r) * kBT_W + 4 * j);
-      lo[r] = v.x; hi[r] = v.y;
+    for (int q = 0; q < 4; q++) P[q] = *(const uint4*)(hp + (op + q) * kBT_W + 4 * j);
+    uint32_t e[4], o[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const uint32_t p0 = c == 0 ? P[0].x : c == 1 ? P[0].y : c == 2 ? P[0].z : P[0].w;
+      const uint32_t p1 = c == 0 ? P[1].x : c == 1 ? P[1].y : c == 2 ? P[1].z : P[1].w;
+      const uint32_t p2 = c == 0 ? P[2].x : c == 1 ? P[2].y : c == 2 ? P[2].z : P[2].w;
+      const uint32_t p3 = c == 0 ? P[3].x : c == 1 ? P[3].y : c == 2 ? P[3].z : P[3].w;
+      e[c] = udot2(p3, bc.we[3], udot2(p2, bc.we[2], udot2(p1, bc.we[1], udot2(p0, bc.we[0], 32768u))));
+      o[c] = udot2(p3, bc.wo[3], udot2(p2, bc.wo[2], udot2(p1, bc.wo[1], udot2(p0, bc.wo[0], 32768u))));
     }
-#pragma unroll
-    for (int yy = 0; yy < 2; yy++) {
-      uint32_t c0 = 32768u, c1 = 32768u, c2 = 32768u, c3 = 32768u;
-#pragma unroll
-      for (int k = 0; k < 7; k++) {
-        const uint32_t kk = (uint32_t)bc.k[k];
-        c0 += kk * (lo[yy + k] & 0xffffu); c1 += kk * (lo[yy + k] >> 16);
-        c2 += kk * (hi[yy + k] & 0xffffu); c3 += kk * (hi[yy + k] >> 16);
-      }
-      const int y = y0 + 2 * rg + yy, x = x0 + 4 * j;
-      if (y < h && x < w) {
-        const uint32_t px = (c0 >> 16) | ((c1 >> 16) << 8) | ((c2 >> 16) << 16) | ((c3 >> 16) << 24);
-        *(uint32_t*)(blur + (long long)frame * blur_frame_bytes + lv.bplane_off + (long long)y * lv.pitch + x) = px;
-      }
-    }
+    const uint32_t pe = (e[0] >> 16) | ((e[1] >> 16) << 8) | ((e[2] >> 16) << 16) | ((e[3] >> 16) << 24);
+    const uint32_t po = (o[0] >> 16) | ((o[1] >> 16) << 8) | ((o[2] >> 16) << 16) | ((o[3] >> 16) << 24);
+    *(uint32_t*)(bl + (long long)y * lv.pitch + x) = pe;
+    if (y + 1 < h) *(uint32_t*)(bl + (long long)(y + 1) * lv.pitch + x) = po;
   }
 }
 
