@@ -253,10 +253,24 @@ static void gaussian_kernel7(int k[7]) {
   k[3] = 256 - 2 * s;
 }
 
-static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int nframes, int rows, int cols, size_t row_stride,
+// One pass of the hot path over frames [f0, f0 + nframes) of the batch, on stream `st`.  Every buffer is indexed by
+// frame, so a sub-batch is the same launch sequence on offset base pointers.
+static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nframes, int rows, int cols, size_t row_stride,
                            size_t frame_stride, int lap0, int lap1, orbx_keypoint* d_kps, uint8_t* d_desc,
                            int32_t* d_counts, hipStream_t st) {
   const Geometry& geo = ctx->geo;
+  d_imgs += (size_t)f0 * frame_stride;
+  d_kps += (size_t)f0 * ctx->out_cap;
+  d_desc += (size_t)f0 * ctx->out_cap * 32;
+  d_counts += (size_t)f0 * 2;
+  uint8_t* const b_pyr = ctx->d_pyr + (size_t)f0 * geo.pyr_bytes;
+  uint8_t* const b_blur = ctx->d_blur + (size_t)f0 * geo.blur_bytes;
+  uint32_t* const b_cand = ctx->d_cand + (size_t)f0 * geo.cand_total;
+  int32_t* const b_cell_cnt = ctx->d_cell_cnt + (size_t)f0 * geo.cells.size();
+  uint32_t* const b_pts = ctx->d_pts + (size_t)f0 * 2 * geo.cand_total;
+  uint32_t* const b_lvl_kp = ctx->d_lvl_kp + (size_t)f0 * geo.kp_total;
+  int32_t* const b_lvl_n = ctx->d_lvl_n + (size_t)f0 * geo.nlevels;
+  uint2* const b_kp_list = ctx->d_kp_list + (size_t)f0 * ctx->out_cap;
   // K1: pyramid chain (levels depend on each other: one launch per level over the whole batch)
   {
     ProfScope ps(ctx, 0, st);
@@ -265,10 +279,10 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int nframes, in
       const LevelGeom& S = geo.lv[l - 1];
       const uint8_t* src; long long sfs; int sp;
       if (l == 1) { src = d_imgs; sfs = (long long)frame_stride; sp = (int)row_stride; }
-      else { src = ctx->d_pyr + S.plane_off; sfs = geo.pyr_bytes; sp = S.pitch; }
+      else { src = b_pyr + S.plane_off; sfs = geo.pyr_bytes; sp = S.pitch; }
       const int nbx = (D.w + kRT_W - 1) / kRT_W, nby = (D.h + kRT_H - 1) / kRT_H, nitems = nbx * nby * nframes;
       hipLaunchKernelGGL(k_resize, dim3(xcd_grid(nitems)), dim3(256), (size_t)D.rs_lds_pitch * D.rs_lds_rows, st, src, sfs, sp,
-                         S.w, ctx->d_pyr + D.plane_off, (long long)geo.pyr_bytes, D.pitch, D.w, D.h, ctx->d_xtab + D.xtab_off,
+                         S.w, b_pyr + D.plane_off, (long long)geo.pyr_bytes, D.pitch, D.w, D.h, ctx->d_xtab + D.xtab_off,
                          ctx->d_ytab + D.ytab_off, nbx, nby, nitems, D.rs_lds_pitch, D.rs_lds_rows);
     }
   }
@@ -287,9 +301,35 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int nframes, in
     auto kern = pitchB == 64 ? (ft == 64 ? k_fast_cells<64, 64> : ft == 128 ? k_fast_cells<128, 64> : k_fast_cells<256, 64>)
                              : (ft == 64 ? k_fast_cells<64, 96> : ft == 128 ? k_fast_cells<128, 96> : k_fast_cells<256, 96>);
     hipLaunchKernelGGL(kern, dim3(xcd_grid(nitems)), dim3(ft), lds, st, ctx->d_geo, ctx->d_cells, d_imgs,
-                       (long long)row_stride, (long long)frame_stride, ctx->d_pyr, (long long)geo.pyr_bytes, ctx->d_cand,
-                       ctx->d_cell_cnt, ctx->ini_th, ctx->min_th, tile_rows, nitems);
+                       (long long)row_stride, (long long)frame_stride, b_pyr, (long long)geo.pyr_bytes, b_cand,
+                       b_cell_cnt, ctx->ini_th, ctx->min_th, tile_rows, nitems);
   }
+  // K4a: 7x7 fixed-point Gaussian of every level (the reference blurs each level that holds keypoints).  It only needs
+  // the pyramid, and it is VALU-bound while the quadtree that follows FAST is latency-bound with few workgroups, so it
+  // is forked onto a second stream behind FAST and joined before the descriptors (ORBX_FORK_BLUR=0 disables).
+  const bool fork_blur = ctx->fork_blur && !ctx->profiling;
+  hipStream_t bst = st;
+  if (fork_blur) {
+    bst = ctx->aux[orbx_ctx::kMaxAux - 1 - (f0 != 0)];
+    ORBX_HIP(ctx, hipEventRecord(ctx->ev_blur_fork[f0 != 0], st));
+    ORBX_HIP(ctx, hipStreamWaitEvent(bst, ctx->ev_blur_fork[f0 != 0], 0));
+  }
+  {
+    ProfScope ps(ctx, 4, bst);
+    int gk[7];
+    gaussian_kernel7(gk);
+    BlurConsts bc;
+    bc.w0 = (uint32_t)gk[0] | ((uint32_t)gk[1] << 8) | ((uint32_t)gk[2] << 16) | ((uint32_t)gk[3] << 24);
+    bc.w1 = (uint32_t)gk[4] | ((uint32_t)gk[5] << 8) | ((uint32_t)gk[6] << 16);
+    const uint32_t k0 = gk[0], k1 = gk[1], k2 = gk[2], k3 = gk[3], k4 = gk[4], k5 = gk[5], k6 = gk[6];
+    bc.we[0] = k0 | k1 << 16; bc.we[1] = k2 | k3 << 16; bc.we[2] = k4 | k5 << 16; bc.we[3] = k6;
+    bc.wo[0] = k0 << 16; bc.wo[1] = k1 | k2 << 16; bc.wo[2] = k3 | k4 << 16; bc.wo[3] = k5 | k6 << 16;
+    const int nitems = geo.btiles_total * nframes;
+    hipLaunchKernelGGL(k_blur7, dim3(xcd_grid(nitems)), dim3(256), 0, bst, ctx->d_geo, d_imgs, (long long)row_stride,
+                       (long long)frame_stride, b_pyr, (long long)geo.pyr_bytes, b_blur, (long long)geo.blur_bytes, bc,
+                       nitems);
+  }
+  if (fork_blur) ORBX_HIP(ctx, hipEventRecord(ctx->ev_blur_join[f0 != 0], bst));
   // K3: quadtree
   {
     ProfScope ps(ctx, 2, st);
@@ -305,40 +345,27 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int nframes, in
       if (e != hipSuccess) return set_err(ctx, ORBX_E_CAPACITY, "nfeatures too large for the quadtree kernel's LDS");
     }
     dim3 grid(geo.nlevels, nframes, 1);
-    hipLaunchKernelGGL(k_quadtree, grid, dim3(256), lds, st, ctx->d_geo, ctx->d_cells, ctx->d_cand, ctx->d_cell_cnt,
-                       ctx->d_pts, ctx->d_lvl_kp, ctx->d_lvl_n, node_cap, scan_cap, pts_cap);
+    hipLaunchKernelGGL(k_quadtree, grid, dim3(256), lds, st, ctx->d_geo, ctx->d_cells, b_cand, b_cell_cnt,
+                       b_pts, b_lvl_kp, b_lvl_n, node_cap, scan_cap, pts_cap);
   }
   // K3b: output slots
   {
     ProfScope ps(ctx, 3, st);
-    hipLaunchKernelGGL(k_assemble, dim3(nframes), dim3(256), (size_t)ctx->out_cap * 8 + 64, st, ctx->d_geo, ctx->d_lvl_kp,
-                       ctx->d_lvl_n, ctx->d_kp_list, d_counts, lap0, lap1);
-  }
-  // K4a: 7x7 fixed-point Gaussian of every level (the reference blurs each level that holds keypoints)
-  {
-    ProfScope ps(ctx, 4, st);
-    int gk[7];
-    gaussian_kernel7(gk);
-    BlurConsts bc;
-    bc.w0 = (uint32_t)gk[0] | ((uint32_t)gk[1] << 8) | ((uint32_t)gk[2] << 16) | ((uint32_t)gk[3] << 24);
-    bc.w1 = (uint32_t)gk[4] | ((uint32_t)gk[5] << 8) | ((uint32_t)gk[6] << 16);
-    const uint32_t k0 = gk[0], k1 = gk[1], k2 = gk[2], k3 = gk[3], k4 = gk[4], k5 = gk[5], k6 = gk[6];
-    bc.we[0] = k0 | k1 << 16; bc.we[1] = k2 | k3 << 16; bc.we[2] = k4 | k5 << 16; bc.we[3] = k6;
-    bc.wo[0] = k0 << 16; bc.wo[1] = k1 | k2 << 16; bc.wo[2] = k3 | k4 << 16; bc.wo[3] = k5 | k6 << 16;
-    const int nitems = geo.btiles_total * nframes;
-    hipLaunchKernelGGL(k_blur7, dim3(xcd_grid(nitems)), dim3(256), 0, st, ctx->d_geo, d_imgs, (long long)row_stride,
-                       (long long)frame_stride, ctx->d_pyr, (long long)geo.pyr_bytes, ctx->d_blur, (long long)geo.blur_bytes, bc,
-                       nitems);
+    hipLaunchKernelGGL(k_assemble, dim3(nframes), dim3(256), (size_t)ctx->out_cap * 8 + 64, st, ctx->d_geo, b_lvl_kp,
+                       b_lvl_n, b_kp_list, d_counts, lap0, lap1);
   }
   // K4b: orientation + descriptors
+  if (fork_blur) ORBX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_blur_join[f0 != 0], 0));
   {
     ProfScope ps(ctx, 5, st);
     DescConsts dc;
     for (int i = 0; i < 16; i++) dc.umax[i] = ctx->umax[i];
-    const int gpf = (ctx->out_cap + 3) / 4, nitems = gpf * nframes;
-    hipLaunchKernelGGL(k_describe, dim3(xcd_grid(nitems)), dim3(256), 0, st, ctx->d_geo, d_imgs, (long long)row_stride,
-                       (long long)frame_stride, ctx->d_pyr, (long long)geo.pyr_bytes, ctx->d_blur, (long long)geo.blur_bytes,
-                       ctx->d_kp_list, d_counts, d_kps, d_desc, dc, gpf, nitems);
+    const int K = ctx->desc_k;  // keypoints per wave
+    const int gpf = (ctx->out_cap + 4 * K - 1) / (4 * K), nitems = gpf * nframes;
+    auto kern = K == 1 ? k_describe<1> : K == 2 ? k_describe<2> : K == 4 ? k_describe<4> : K == 8 ? k_describe<8> : k_describe<16>;
+    hipLaunchKernelGGL(kern, dim3(xcd_grid(nitems)), dim3(256), 0, st, ctx->d_geo, d_imgs, (long long)row_stride,
+                       (long long)frame_stride, b_pyr, (long long)geo.pyr_bytes, b_blur, (long long)geo.blur_bytes,
+                       b_kp_list, d_counts, d_kps, d_desc, dc, gpf, nitems);
   }
   ORBX_HIP(ctx, hipGetLastError());
   return ORBX_OK;
@@ -397,11 +424,31 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, 
     }
   }
   ctx->fast_threads = fast_threads_from_env();
+  {
+    const char* e = getenv("ORBX_DESC_K");  // keypoints per wave of k_describe (tuning knob)
+    const int v = e ? atoi(e) : 4;
+    ctx->desc_k = (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ? v : 4;
+  }
   ctx->out_cap = 0;
   for (int l = 0; l < nlevels; l++) ctx->out_cap += std::max(ctx->quota[l] + 3, 4 * kMaxRoots);
   if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
     delete ctx;
     return ORBX_E_DEVICE;
+  }
+  {
+    const char* e = getenv("ORBX_STREAMS");  // concurrent sub-batches of the batch entry point (1..orbx_ctx::kMaxAux)
+    const int v = e ? atoi(e) : 1;
+    ctx->nstreams = std::min(std::max(v, 1), 2);  // the blur fork owns the last two aux streams
+    const char* fb = getenv("ORBX_FORK_BLUR");
+    ctx->fork_blur = fb ? atoi(fb) != 0 : true;
+    bool ok = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 2 && ok; i++)
+      ok = hipEventCreateWithFlags(&ctx->ev_blur_fork[i], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&ctx->ev_blur_join[i], hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < orbx_ctx::kMaxAux && ok; i++)
+      ok = hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking) == hipSuccess &&
+           hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { orbx_destroy(ctx); return ORBX_E_DEVICE; }
   }
   *out = ctx;
   return ORBX_OK;
@@ -414,6 +461,15 @@ void orbx_destroy(orbx_ctx* ctx) {
   free_buffers(ctx);
   auto fr = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
   fr(ctx->d_stage_img); fr(ctx->d_stage_kps); fr(ctx->d_stage_desc); fr(ctx->d_stage_counts);
+  for (int i = 0; i < orbx_ctx::kMaxAux; i++) {
+    if (ctx->aux[i]) { (void)hipStreamSynchronize(ctx->aux[i]); (void)hipStreamDestroy(ctx->aux[i]); }
+    if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
+  }
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  for (int i = 0; i < 2; i++) {
+    if (ctx->ev_blur_fork[i]) (void)hipEventDestroy(ctx->ev_blur_fork[i]);
+    if (ctx->ev_blur_join[i]) (void)hipEventDestroy(ctx->ev_blur_join[i]);
+  }
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -448,7 +504,25 @@ int orbx_extract_batch_device(orbx_ctx* ctx, const uint8_t* d_imgs, int nframes,
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
   ctx->last_imgs = d_imgs; ctx->last_row_stride = row_stride; ctx->last_frame_stride = frame_stride;
   ctx->last_nframes = nframes;
-  return launch_pipeline(ctx, d_imgs, nframes, rows, cols, row_stride, frame_stride, lap0, lap1, d_kps, d_desc, d_counts, st);
+  // Sub-batches on concurrent streams: frames are independent, and the pipeline alternates VALU-bound kernels
+  // (FAST, blur) with latency-bound ones (quadtree, descriptors, the pyramid chain), so two or more sub-batches in
+  // flight keep the CUs busy across kernel boundaries.  Fork/join with events on the caller's stream (capturable).
+  int ns = ctx->profiling ? 1 : std::min(ctx->nstreams, std::max(1, nframes / 32));
+  if (ns <= 1)
+    return launch_pipeline(ctx, d_imgs, 0, nframes, rows, cols, row_stride, frame_stride, lap0, lap1, d_kps, d_desc, d_counts, st);
+  ORBX_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
+  const int per = (nframes + ns - 1) / ns;
+  for (int i = 0; i < ns; i++) {
+    const int f0 = i * per, nf = std::min(per, nframes - f0);
+    if (nf <= 0) break;
+    hipStream_t s = ctx->aux[i];
+    ORBX_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_fork, 0));
+    rc = launch_pipeline(ctx, d_imgs, f0, nf, rows, cols, row_stride, frame_stride, lap0, lap1, d_kps, d_desc, d_counts, s);
+    if (rc != ORBX_OK) return rc;
+    ORBX_HIP(ctx, hipEventRecord(ctx->ev_join[i], s));
+    ORBX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[i], 0));
+  }
+  return ORBX_OK;
 }
 
 static int ensure_stage(orbx_ctx* ctx, int nframes, size_t img_bytes) {

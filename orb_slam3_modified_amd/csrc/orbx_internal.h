@@ -88,8 +88,15 @@ struct orbx_ctx {
   int umax[16];
   int out_cap;  // nfeatures + 3*nlevels
   int fast_threads = 128;  // workgroup size of k_fast_cells
+  int desc_k = 8;          // keypoints per wave of k_describe
 
   hipStream_t stream = nullptr;
+  static constexpr int kMaxAux = 8;
+  hipStream_t aux[kMaxAux] = {nullptr};     // sub-batch streams of orbx_extract_batch_device
+  hipEvent_t ev_fork = nullptr, ev_join[kMaxAux] = {nullptr};
+  hipEvent_t ev_blur_fork[2] = {nullptr, nullptr}, ev_blur_join[2] = {nullptr, nullptr};
+  int nstreams = 1;
+  bool fork_blur = true;
   std::string err;
 
   // geometry + device buffers for the current (rows, cols, batch capacity)

@@ -1015,6 +1015,20 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
   return a;
 }
 
+// Sum over the wave by DPP (no LDS traffic); the total lands in lane 63 (rows 2,3 of the last step).
+__device__ __forceinline__ int wave_sum_lane63(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);  // row_half_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);  // row_mirror: every lane = its row's sum
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast15 into rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast31 into rows 2, 3
+  return v;
+}
+
+// K keypoints per wave: the cos/sin/atan2 evaluation (the largest VALU block, identical in all 64 lanes for one
+// keypoint) is done once for K keypoints held in lanes 0..K-1.
+template <int K>
 __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__ g, const uint8_t* __restrict__ imgs,
                                                   long long img_row_stride, long long img_frame_stride,
                                                   const uint8_t* __restrict__ pyr, long long pyr_frame_bytes,
@@ -1026,79 +1040,118 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
   const int L = xcd_logical_block(nitems);
   if (L < 0) return;
   const int frame = L / groups_per_frame;
-  const int gi = (L - frame * groups_per_frame) * 4 + w;
-  if (gi >= counts[frame * 2]) return;  // wave-uniform
-  const uint2 rec = kp_list[(long long)frame * g->out_cap + gi];
-  // rotated-pattern operands: independent of the keypoint, issued first
+  const int g0 = ((L - frame * groups_per_frame) * 4 + w) * K;  // first keypoint (level-major index) of this wave
+  const int total = counts[frame * 2];
+  if (g0 >= total) return;  // wave-uniform
+  const int nk = min(K, total - g0);
+  uint2 rec = make_uint2(0u, 0u);
+  if (lane < nk) rec = kp_list[(long long)frame * g->out_cap + g0 + lane];
+  // rotated-pattern operands: independent of the keypoints, issued first
   char4 pat[4];
 #pragma unroll
   for (int q = 0; q < 4; q++) pat[q] = ((const char4*)c_pattern)[q * 64 + lane];
-  const uint32_t p = rec.x;
-  const int l = (int)(rec.y & 0xffu), slot = (int)(rec.y >> 8);
-  const DeviceLevel& lv = g->lv[l];
-  const int kx = pt_x(p), ky = pt_y(p);
-  const uint8_t* img;
-  long long pitch;
-  if (l == 0) { img = imgs + (long long)frame * img_frame_stride; pitch = img_row_stride; }
-  else { img = pyr + (long long)frame * pyr_frame_bytes + lv.plane_off; pitch = lv.pitch; }
-  // intensity centroid (src/ORBextractor.cc:76-103) over the circular patch of the un-blurred level: exact int32
-  // moments, any summation order.  Lane = (row parity r2, column c); keypoints sit >= 19 px inside the level.
-  int m10 = 0, m01 = 0;
-  {
-    const int c = lane & 31, r2 = lane >> 5;
-    const int u = c - kHalfPatch;
-    const int au = u < 0 ? -u : u;
-    const uint8_t* src = img + (long long)(ky - kHalfPatch + r2) * pitch + (kx - kHalfPatch) + c;
-    int I[16];
+  // umax[0..15] (each <= 15) packed 4 bits apiece
+  unsigned long long umpk = 0;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const int v0 = 2 * i - kHalfPatch, v1 = v0 + 1;  // rows of the two half-waves (compile-time)
-      const int um0 = dc.umax[v0 < 0 ? -v0 : v0];
-      const int um1 = v1 <= kHalfPatch ? dc.umax[v1 < 0 ? -v1 : v1] : -1;
-      const int um = r2 ? um1 : um0;
-      I[i] = (au <= um) ? (int)src[(long long)(2 * i) * pitch] : 0;
-    }
+  for (int i = 0; i < 16; i++) umpk |= (unsigned long long)(dc.umax[i] & 15) << (4 * i);
+  const bool al_img = ((img_row_stride & 3) == 0) && ((img_frame_stride & 3) == 0) && ((((unsigned long long)imgs) & 3) == 0);
+  // ---- intensity centroid of every keypoint (src/ORBextractor.cc:76-103): exact int32 moments, any summation order
+  int my_m01 = 0, my_m10 = 0;
+#pragma unroll 1
+  for (int k = 0; k < nk; k++) {
+    const uint32_t p = __builtin_amdgcn_readlane(rec.x, k);
+    const int l = (int)(__builtin_amdgcn_readlane(rec.y, k) & 0xffu);
+    const DeviceLevel& lv = g->lv[l];
+    const int kx = pt_x(p), ky = pt_y(p);
+    const uint8_t* img;
+    long long pitch;
+    bool al;
+    if (l == 0) { img = imgs + (long long)frame * img_frame_stride; pitch = img_row_stride; al = al_img; }
+    else { img = pyr + (long long)frame * pyr_frame_bytes + lv.plane_off; pitch = lv.pitch; al = true; }  // pyramid planes are 64-byte aligned
+    int m10 = 0, m01 = 0;
+    if (al) {
+      // 31 rows x 10 aligned dwords cover the patch columns [kx-15, kx+15]; per dword the valid bytes form a range
+      const int xs = kx - kHalfPatch, sh = xs & 3;
+      const uint8_t* src = img + (long long)(ky - kHalfPatch) * pitch + (xs - sh);
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const int v = 2 * i - kHalfPatch + r2;
-      m10 += u * I[i];
-      m01 += v * I[i];
+      for (int i = 0; i < 5; i++) {
+        const int it = lane + 64 * i;
+        const int r = (int)(((uint32_t)it * 6554u) >> 16), dcol = it - r * 10;  // it / 10
+        const int v = r - kHalfPatch;
+        const int um = (int)((umpk >> (4 * (v < 0 ? -v : v))) & 15ull);
+        const int u0 = 4 * dcol - sh - kHalfPatch;
+        const int lo = max(-um - u0, 0), hi = min(um - u0, 3);
+        uint32_t M = 0;
+        if (it < 31 * 10 && lo <= hi) M = (0x01010101u << (8 * lo)) & (0x01010101u >> (8 * (3 - hi)));
+        uint32_t dw = 0;
+        if (M) dw = *(const uint32_t*)(src + (long long)r * pitch + 4 * dcol);
+        const int S = (int)__builtin_amdgcn_udot4(dw, M, 0u, false);
+        const int Tt = (int)__builtin_amdgcn_udot4(dw, (M * 255u) & 0x03020100u, 0u, false);  // weights b on the valid bytes
+        m10 += u0 * S + Tt;
+        m01 += v * S;
+      }
+    } else {
+      const int c = lane & 31, r2 = lane >> 5;
+      const int u = c - kHalfPatch;
+      const int au = u < 0 ? -u : u;
+      const uint8_t* src = img + (long long)(ky - kHalfPatch + r2) * pitch + (kx - kHalfPatch) + c;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int v = 2 * i - kHalfPatch + r2;
+        const int um = v <= kHalfPatch ? (int)((umpk >> (4 * (v < 0 ? -v : v))) & 15ull) : -1;
+        const int I = (au <= um) ? (int)src[(long long)(2 * i) * pitch] : 0;
+        m10 += u * I;
+        m01 += v * I;
+      }
     }
+    m10 = __builtin_amdgcn_readlane(wave_sum_lane63(m10), 63);
+    m01 = __builtin_amdgcn_readlane(wave_sum_lane63(m01), 63);
+    if (lane == k) { my_m10 = m10; my_m01 = m01; }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
-  const float angle = fast_atan2_deg((float)m01, (float)m10);
-  // steered BRIEF (src/ORBextractor.cc:107-146) on the blurred level
+  // ---- angle, cos, sin of the K keypoints, one per lane
+  const float my_angle = fast_atan2_deg((float)my_m01, (float)my_m10);
   const float factorPI = (float)(3.14159265358979323846 / 180.f);
-  const float ang = __fmul_rn(angle, factorPI);
-  const float a = orbx_glibc::cosf_exact(ang), b = orbx_glibc::sinf_exact(ang);
-  const uint8_t* ctr = blur + (long long)frame * blur_frame_bytes + lv.bplane_off + (long long)ky * lv.pitch + kx;
-  const int bp = lv.pitch;
-  int t0[4], t1[4];
+  const float my_rad = __fmul_rn(my_angle, factorPI);
+  const float my_a = orbx_glibc::cosf_exact(my_rad), my_b = orbx_glibc::sinf_exact(my_rad);
+  // ---- steered BRIEF (src/ORBextractor.cc:107-146) on the blurred level
+#pragma unroll 1
+  for (int k = 0; k < nk; k++) {
+    const uint32_t p = __builtin_amdgcn_readlane(rec.x, k);
+    const uint32_t ry = __builtin_amdgcn_readlane(rec.y, k);
+    const int l = (int)(ry & 0xffu), slot = (int)(ry >> 8);
+    const float a = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_a), k));
+    const float b = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_b), k));
+    const float angle = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_angle), k));
+    const DeviceLevel& lv = g->lv[l];
+    const int kx = pt_x(p), ky = pt_y(p);
+    const uint8_t* ctr = blur + (long long)frame * blur_frame_bytes + lv.bplane_off + (long long)ky * lv.pitch + kx;
+    const int bp = lv.pitch;
+    int t0[4], t1[4];
 #pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const float x0 = (float)pat[q].x, y0 = (float)pat[q].y, x1 = (float)pat[q].z, y1 = (float)pat[q].w;
-    const int ry0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
-    const int rx0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-    const int ry1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
-    const int rx1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-    t0[q] = ctr[ry0 * bp + rx0];
-    t1[q] = ctr[ry1 * bp + rx1];
-  }
-  unsigned long long mine = 0;
+    for (int q = 0; q < 4; q++) {
+      const float x0 = (float)pat[q].x, y0 = (float)pat[q].y, x1 = (float)pat[q].z, y1 = (float)pat[q].w;
+      const int ry0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
+      const int rx0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+      const int ry1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
+      const int rx1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+      t0[q] = ctr[ry0 * bp + rx0];
+      t1[q] = ctr[ry1 * bp + rx1];
+    }
+    unsigned long long mine = 0;
 #pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const unsigned long long bits = __ballot(t0[q] < t1[q]);
-    if (lane == q) mine = bits;
-  }
-  if (lane < 4) *(unsigned long long*)(out_desc + ((long long)frame * g->out_cap + slot) * 32 + lane * 8) = mine;
-  if (lane == 0) {
-    orbx_keypoint kp;
-    float fx = (float)kx, fy = (float)ky;
-    if (l != 0) { fx = __fmul_rn(fx, lv.scale); fy = __fmul_rn(fy, lv.scale); }
-    kp.x = fx; kp.y = fy; kp.size = (float)lv.scaled_patch; kp.angle = angle; kp.response = (float)pt_s(p);
-    kp.octave = l; kp.class_id = -1;
-    out_kps[(long long)frame * g->out_cap + slot] = kp;
+    for (int q = 0; q < 4; q++) {
+      const unsigned long long bits = __ballot(t0[q] < t1[q]);
+      if (lane == q) mine = bits;
+    }
+    if (lane < 4) *(unsigned long long*)(out_desc + ((long long)frame * g->out_cap + slot) * 32 + lane * 8) = mine;
+    if (lane == 0) {
+      orbx_keypoint kp;
+      float fx = (float)kx, fy = (float)ky;
+      if (l != 0) { fx = __fmul_rn(fx, lv.scale); fy = __fmul_rn(fy, lv.scale); }
+      kp.x = fx; kp.y = fy; kp.size = (float)lv.scaled_patch; kp.angle = angle; kp.response = (float)pt_s(p);
+      kp.octave = l; kp.class_id = -1;
+      out_kps[(long long)frame * g->out_cap + slot] = kp;
+    }
   }
 }
 
