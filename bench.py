@@ -183,7 +183,10 @@ def main():
             try:
                 j = json.load(open(pmc))
                 if j.get("batch") == B and j.get("rows") == H and j.get("cols") == W:
-                    traffic = j.get("kernels", {}).get(dom.split("(")[0])
+                    ent = j.get("kernels", {}).get(dom.split("(")[0])
+                    # HBM bytes per launch of the dominant kernel: FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc
+                    # passes, corrected with the known-traffic calibration copy (tools/pmc_traffic.py)
+                    traffic = int(ent["hbm_bytes_per_launch"]) if ent else None
             except Exception:
                 traffic = None
         step_ms = dt / args.steps * 1e3

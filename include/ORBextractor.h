@@ -1,0 +1,118 @@
+/* orbx adapter — drop-in for the reference's include/ORBextractor.h (lturing/ORB_SLAM3_modified,
+ * include/ORBextractor.h:44-112): same class name, namespace, constructor, operator(), getters and the public
+ * mvImagePyramid member, so src/Frame.cc / src/Tracking.cc / src/CloudPoint.cc compile unchanged.  Header-only;
+ * every computation is a call into the C ABI of liborbx.so (include/orbx.h, HIP kernels for gfx950).
+ *
+ * Differences a caller cannot observe through this interface:
+ *   - the pyramid lives in persistent device buffers (the reference reallocates it per call);
+ *     mvImagePyramid[l] is a host copy made after each call (needed only by the stereo matcher,
+ *     src/Frame.cc:818,908-925) — switch it off for mono with SetKeepHostPyramid(false);
+ *   - the host copies are plain w x h images, not ROIs into an EDGE_THRESHOLD-padded buffer (nothing reads the pad).
+ * Errors: an empty image returns -1 like the reference (src/ORBextractor.cc:1090-1091); a missing GPU or a HIP
+ * failure throws std::runtime_error from the constructor / operator() (the reference has no failure path at all;
+ * there is deliberately no CPU fallback).
+ */
+#ifndef ORBEXTRACTOR_H
+#define ORBEXTRACTOR_H
+
+#include <cassert>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "orbx.h"
+#include "orbx_cv_compat.h"
+
+namespace ORB_SLAM3 {
+
+class ORBextractor {
+ public:
+  enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
+
+  ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int device_id = -1)
+      : nfeatures(nfeatures), scaleFactor(scaleFactor), nlevels(nlevels), iniThFAST(iniThFAST), minThFAST(minThFAST) {
+    const int rc = orbx_create(&ctx_, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device_id);
+    if (rc != ORBX_OK) throw std::runtime_error("ORBextractor: orbx_create failed with code " + std::to_string(rc) +
+                                                (rc == ORBX_E_DEVICE ? " (no MI355X / HIP device; there is no CPU fallback)" : ""));
+    mvScaleFactor.resize(nlevels); mvInvScaleFactor.resize(nlevels); mvLevelSigma2.resize(nlevels);
+    mvInvLevelSigma2.resize(nlevels); mnFeaturesPerLevel.resize(nlevels);
+    orbx_scale_tables(ctx_, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(), mvInvLevelSigma2.data(),
+                      mnFeaturesPerLevel.data());
+    cap_ = orbx_keypoint_capacity(ctx_);
+    kps_.resize(cap_);
+    desc_.resize((size_t)cap_ * 32);
+    mvImagePyramid.resize(nlevels);
+  }
+  ~ORBextractor() { orbx_destroy(ctx_); }
+  ORBextractor(const ORBextractor&) = delete;
+  ORBextractor& operator=(const ORBextractor&) = delete;
+
+  // Compute the ORB features and descriptors on an image; mask is ignored (as in the reference).
+  // Returns monoIndex, or -1 for an empty image (src/ORBextractor.cc:1086-1168).
+  int operator()(cv::InputArray _image, cv::InputArray /*_mask*/, std::vector<cv::KeyPoint>& _keypoints,
+                 cv::OutputArray _descriptors, std::vector<int>& vLappingArea) {
+    if (_image.empty()) return -1;
+    cv::Mat image = _image.getMat();
+    assert(image.type() == CV_8UC1);
+    int n = 0, mono = 0;
+    static_assert(sizeof(cv::KeyPoint) == sizeof(orbx_keypoint), "cv::KeyPoint must be the 28-byte POD orbx_keypoint mirrors");
+    const int rc = orbx_extract(ctx_, image.data, image.rows, image.cols, (size_t)image.step, vLappingArea[0], vLappingArea[1],
+                                kps_.data(), desc_.data(), &n, &mono);
+    if (rc == ORBX_E_EMPTY) return -1;
+    if (rc != ORBX_OK) throw std::runtime_error(std::string("ORBextractor: ") + orbx_last_error(ctx_));
+    if (n == 0) _descriptors.release();
+    else {
+      _descriptors.create(n, 32, CV_8U);
+      cv::Mat d = _descriptors.getMat();
+      for (int i = 0; i < n; i++) std::memcpy(d.ptr<unsigned char>(i), desc_.data() + (size_t)i * 32, 32);
+    }
+    _keypoints.resize(n);
+    if (n) std::memcpy((void*)_keypoints.data(), kps_.data(), (size_t)n * sizeof(orbx_keypoint));
+    if (keep_host_pyramid_) {
+      for (int l = 0; l < nlevels; l++) {
+        int w = 0, h = 0;
+        orbx_pyramid_level(ctx_, 0, l, nullptr, 0, &w, &h);
+        mvImagePyramid[l].create(h, w, CV_8UC1);
+        orbx_pyramid_level(ctx_, 0, l, mvImagePyramid[l].data, (size_t)mvImagePyramid[l].step, &w, &h);
+      }
+    }
+    return mono;
+  }
+
+  int inline GetLevels() { return nlevels; }
+  float inline GetScaleFactor() { return (float)scaleFactor; }
+  std::vector<float> inline GetScaleFactors() { return mvScaleFactor; }
+  std::vector<float> inline GetInverseScaleFactors() { return mvInvScaleFactor; }
+  std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
+  std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
+
+  std::vector<cv::Mat> mvImagePyramid;
+
+  // orbx extensions (not in the reference)
+  void SetKeepHostPyramid(bool on) { keep_host_pyramid_ = on; }
+  orbx_ctx* Context() { return ctx_; }
+
+ protected:
+  int nfeatures;
+  double scaleFactor;
+  int nlevels;
+  int iniThFAST;
+  int minThFAST;
+  std::vector<int> mnFeaturesPerLevel;
+  std::vector<float> mvScaleFactor;
+  std::vector<float> mvInvScaleFactor;
+  std::vector<float> mvLevelSigma2;
+  std::vector<float> mvInvLevelSigma2;
+
+ private:
+  orbx_ctx* ctx_ = nullptr;
+  int cap_ = 0;
+  bool keep_host_pyramid_ = true;
+  std::vector<orbx_keypoint> kps_;
+  std::vector<uint8_t> desc_;
+};
+
+}  // namespace ORB_SLAM3
+
+#endif  // ORBEXTRACTOR_H

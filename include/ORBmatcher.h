@@ -1,0 +1,89 @@
+/* orbx adapter — the Frame-independent part of the reference's include/ORBmatcher.h (:36-103): constructor,
+ * the public thresholds, static DescriptorDistance, ComputeThreeMaxima, plus the GPU candidate-list searches that
+ * replace the inner `for candidates: DescriptorDistance(...)` loops of the 12 Search.../Fuse routines
+ * (src/ORBmatcher.cc; per-routine tie and accept rules: SURVEY.md §3.3).
+ *
+ * The 12 routines themselves take Frame / KeyFrame / MapPoint / Sophus types that belong to the reference and are
+ * out of this repository's scope; INTEGRATION.md shows the few-line change that routes each routine's candidate
+ * loop through NearestInCandidates() below while the geometry and the greedy bookkeeping stay in src/ORBmatcher.cc.
+ */
+#ifndef ORBMATCHER_H
+#define ORBMATCHER_H
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "orbx.h"
+#include "orbx_cv_compat.h"
+
+namespace ORB_SLAM3 {
+
+class ORBmatcher {
+ public:
+  ORBmatcher(float nnratio = 0.6, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+
+  // src/ORBmatcher.cc:2058-2074: 256-bit Hamming distance of two 1x32 CV_8U rows
+  static int DescriptorDistance(const cv::Mat& a, const cv::Mat& b) {
+    return orbx_hamming(a.ptr<unsigned char>(), b.ptr<unsigned char>());
+  }
+
+  // src/ORBmatcher.cc:35-37
+  static constexpr int TH_LOW = 50;
+  static constexpr int TH_HIGH = 100;
+  static constexpr int HISTO_LENGTH = 30;
+
+  // Result of one query of a candidate-list search.
+  struct Nearest { int bestIdx, bestDist, secondIdx, secondDist; };
+
+  // The shared inner loop of the Search.../Fuse routines on the GPU: query q is compared with the train rows
+  // cand[rowPtr[q] .. rowPtr[q+1]); ties resolve to the FIRST candidate (strict `<`, e.g. src/ORBmatcher.cc:103-111)
+  // or, with lastWins, to the LAST one (SearchForTriangulation's `<=`, :1017).  allDist (optional) receives every
+  // candidate distance for the routines whose greedy bookkeeping must be replayed on the host in query order.
+  static std::vector<Nearest> NearestInCandidates(orbx_ctx* ctx, const cv::Mat& queryDesc, const cv::Mat& trainDesc,
+                                                  const std::vector<int>& rowPtr, const std::vector<int>& cand,
+                                                  bool lastWins = false, std::vector<int>* allDist = nullptr) {
+    const int nq = queryDesc.rows, nt = trainDesc.rows;
+    if (!queryDesc.isContinuous() || !trainDesc.isContinuous()) throw std::runtime_error("descriptor matrices must be continuous");
+    std::vector<int32_t> bi(nq), bd(nq), si(nq), sd(nq);
+    if (allDist) allDist->resize(cand.size());
+    const int rc = orbx_nn_csr(ctx, queryDesc.data, nq, trainDesc.data, nt, rowPtr.data(), cand.data(), lastWins ? 1 : 0, bi.data(),
+                               bd.data(), si.data(), sd.data(), allDist ? allDist->data() : nullptr);
+    if (rc != ORBX_OK) throw std::runtime_error(std::string("ORBmatcher: ") + orbx_last_error(ctx));
+    std::vector<Nearest> out(nq);
+    for (int q = 0; q < nq; q++) out[q] = Nearest{bi[q], bd[q], si[q], sd[q]};
+    return out;
+  }
+
+  // cv::BFMatcher(NORM_HAMMING).knnMatch(query, train, k = 2) as used by Frame::ComputeStereoFishEyeMatches
+  // (src/Frame.cc:43,1144): idx / dist hold 2 entries per query (-1 / 256 when there are fewer than 2 train rows).
+  static void KnnMatch2(orbx_ctx* ctx, const cv::Mat& queryDesc, const cv::Mat& trainDesc, std::vector<int>& idx,
+                        std::vector<int>& dist) {
+    idx.assign((size_t)queryDesc.rows * 2, -1);
+    dist.assign((size_t)queryDesc.rows * 2, 256);
+    if (queryDesc.rows == 0) return;
+    const int rc = orbx_knn2_allpairs(ctx, queryDesc.data, queryDesc.rows, trainDesc.data, trainDesc.rows, idx.data(), dist.data());
+    if (rc != ORBX_OK) throw std::runtime_error(std::string("ORBmatcher: ") + orbx_last_error(ctx));
+  }
+
+  // src/ORBmatcher.cc:2012-2053 (public here so the host-side replays can use it)
+  static void ComputeThreeMaxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3) {
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+      const int s = (int)histo[i].size();
+      if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+      else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+      else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+  }
+
+ protected:
+  float mfNNratio;
+  bool mbCheckOrientation;
+};
+
+}  // namespace ORB_SLAM3
+
+#endif  // ORBMATCHER_H

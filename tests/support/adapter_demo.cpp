@@ -1,0 +1,82 @@
+// Exercises the header-only C++ adapters (include/ORBextractor.h, ORBmatcher.h, ORBVocabulary.h) exactly the way
+// the reference's callers use those classes (src/Frame.cc:418-425 ExtractORB, :738-745 ComputeBoW), built WITHOUT
+// OpenCV (include/orbx_cv_compat.h).  Writes raw results for tests/test_adapters.py to compare with the oracle.
+//   adapter_demo probe
+//   adapter_demo run <img.raw> <rows> <cols> <nfeatures> <lap0> <lap1> <out.bin> [voc.txt]
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <vector>
+
+#include "ORBVocabulary.h"
+#include "ORBextractor.h"
+#include "ORBmatcher.h"
+
+using namespace ORB_SLAM3;
+
+int main(int argc, char** argv) {
+  if (argc < 2) return 2;
+  const std::string mode = argv[1];
+  try {
+    if (mode == "probe") {
+      ORBextractor ex(1000, 1.2f, 8, 20, 7);
+      std::printf("DEVICE_OK levels=%d\n", ex.GetLevels());
+      return 0;
+    }
+    if (mode != "run" || argc < 9) return 2;
+    const int rows = std::atoi(argv[3]), cols = std::atoi(argv[4]), nf = std::atoi(argv[5]);
+    std::vector<int> lap = {std::atoi(argv[6]), std::atoi(argv[7])};
+    std::vector<unsigned char> buf((size_t)rows * cols);
+    { std::ifstream f(argv[2], std::ios::binary); f.read((char*)buf.data(), (std::streamsize)buf.size()); }
+    cv::Mat im(rows, cols, CV_8UC1, buf.data());
+    ORBextractor* extractor = new ORBextractor(nf, 1.2f, 8, 20, 7);   // src/Tracking.cc:597-603
+    std::vector<cv::KeyPoint> keys;
+    cv::Mat descriptors;
+    const int mono = (*extractor)(im, cv::Mat(), keys, descriptors, lap);  // src/Frame.cc:421-424
+    const int n = (int)keys.size();
+    std::ofstream o(argv[8], std::ios::binary);
+    o.write((const char*)&n, 4); o.write((const char*)&mono, 4);
+    o.write((const char*)keys.data(), (std::streamsize)n * sizeof(cv::KeyPoint));
+    for (int i = 0; i < n; i++) o.write((const char*)descriptors.ptr<unsigned char>(i), 32);
+    // mvImagePyramid side channel (src/Frame.cc:818,908-925)
+    int np = (int)extractor->mvImagePyramid.size();
+    o.write((const char*)&np, 4);
+    for (int l = 0; l < np; l++) {
+      const cv::Mat& L = extractor->mvImagePyramid[l];
+      o.write((const char*)&L.rows, 4); o.write((const char*)&L.cols, 4);
+      for (int r = 0; r < L.rows; r++) o.write((const char*)L.ptr<unsigned char>(r), L.cols);
+    }
+    // matcher statics
+    int d01 = n >= 2 ? ORBmatcher::DescriptorDistance(descriptors.row(0), descriptors.row(1)) : -1;
+    o.write((const char*)&d01, 4);
+    // BoW (src/Frame.cc:738-745): Converter::toDescriptorVector then transform(..., 4)
+    int nb = 0;
+    if (argc >= 10) {
+      ORBVocabulary voc;
+      if (!voc.loadFromTextFile(argv[9])) { std::fprintf(stderr, "vocabulary load failed\n"); return 4; }
+      std::vector<cv::Mat> vdesc;
+      for (int i = 0; i < n; i++) vdesc.push_back(descriptors.row(i));
+      DBoW2::BowVector bow;
+      DBoW2::FeatureVector fv;
+      voc.transform(vdesc, bow, fv, 2);
+      nb = (int)bow.size();
+      o.write((const char*)&nb, 4);
+      for (auto& kv : bow) { o.write((const char*)&kv.first, 4); o.write((const char*)&kv.second, 8); }
+      int nfv = 0;
+      for (auto& kv : fv) nfv += (int)kv.second.size();
+      o.write((const char*)&nfv, 4);
+      for (auto& kv : fv) for (unsigned f : kv.second) { o.write((const char*)&kv.first, 4); o.write((const char*)&f, 4); }
+      const double self = voc.score(bow, bow);
+      o.write((const char*)&self, 8);
+    } else {
+      o.write((const char*)&nb, 4);
+    }
+    std::printf("OK n=%d mono=%d\n", n, mono);
+    delete extractor;
+    return 0;
+  } catch (const std::exception& e) {
+    std::printf("NO_DEVICE %s\n", e.what());
+    return 3;
+  }
+}
