@@ -32,6 +32,9 @@ int set_err(orbx_ctx* ctx, int code, const std::string& msg) {
 static inline int cv_round(float v) { return (int)lrintf(v); }
 static inline int cv_round(double v) { return (int)lrint(v); }
 static inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
+// fast_div magic: ceil(2^32 / d), 0 for d == 1; n / d == umulhi(n, M) while n * d < 2^32
+static inline uint32_t div_magic(uint32_t d) { return d <= 1 ? 0u : (uint32_t)(((1ull << 32) + d - 1) / d); }
+static inline bool div_ok(uint64_t nmax, uint64_t d) { return nmax * d < (1ull << 32); }
 static inline unsigned xcd_grid(int nitems) { return (unsigned)(8 * ((nitems + 7) / 8)); }  // see xcd_logical_block
 
 // resize tables (cv::resize INTER_LINEAR 8u): per destination index the two source
@@ -191,6 +194,7 @@ static int ensure_buffers(orbx_ctx* ctx, int rows, int cols, int nframes) {
   dg.nlevels = geo.nlevels; dg.rows = rows; dg.cols = cols;
   dg.ncells_total = (int)geo.cells.size(); dg.cand_total = geo.cand_total; dg.kp_total = geo.kp_total;
   dg.out_cap = ctx->out_cap; dg.btiles_total = geo.btiles_total;
+  dg.m_ncells = div_magic((uint32_t)geo.cells.size()); dg.m_btiles = div_magic((uint32_t)geo.btiles_total);
   for (int l = 0; l < geo.nlevels; l++) {
     const LevelGeom& L = geo.lv[l];
     DeviceLevel& D = dg.lv[l];
@@ -199,7 +203,7 @@ static int ensure_buffers(orbx_ctx* ctx, int rows, int cols, int nframes) {
     D.quota = L.quota; D.kp_off = L.kp_off; D.kp_cap = L.kp_cap; D.nroots = L.nroots;
     for (int i = 0; i < kMaxRoots; i++) { D.root_x0[i] = L.root_x0[i]; D.root_x1[i] = L.root_x1[i]; }
     D.hX = L.hX; D.scale = L.scale; D.scaled_patch = L.scaled_patch; D.xtab_off = L.xtab_off; D.ytab_off = L.ytab_off;
-    D.bplane_off = L.bplane_off; D.btile_begin = L.btile_begin; D.btiles_x = L.btiles_x; D.btiles_y = L.btiles_y; D.pad_ = 0;
+    D.bplane_off = L.bplane_off; D.btile_begin = L.btile_begin; D.btiles_x = L.btiles_x; D.btiles_y = L.btiles_y; D.m_btiles_x = div_magic(L.btiles_x);
   }
   ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_geo, sizeof(DeviceGeom)));
   ORBX_HIP(ctx, hipMemcpy(ctx->d_geo, &dg, sizeof(dg), hipMemcpyHostToDevice));
@@ -283,7 +287,12 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
       const int nbx = (D.w + kRT_W - 1) / kRT_W, nby = (D.h + kRT_H - 1) / kRT_H, nitems = nbx * nby * nframes;
       hipLaunchKernelGGL(k_resize, dim3(xcd_grid(nitems)), dim3(256), (size_t)D.rs_lds_pitch * D.rs_lds_rows, st, src, sfs, sp,
                          S.w, b_pyr + D.plane_off, (long long)geo.pyr_bytes, D.pitch, D.w, D.h, ctx->d_xtab + D.xtab_off,
-                         ctx->d_ytab + D.ytab_off, nbx, nby, nitems, D.rs_lds_pitch, D.rs_lds_rows);
+                         ctx->d_ytab + D.ytab_off, nbx, nby, nitems, D.rs_lds_pitch, D.rs_lds_rows,
+                         div_magic((uint32_t)(nbx * nby)), div_magic((uint32_t)nbx),
+                         (65536u + (uint32_t)(D.rs_lds_pitch / 4) - 1u) / (uint32_t)(D.rs_lds_pitch / 4));
+      if (D.rs_lds_rows * (D.rs_lds_pitch / 4) * (D.rs_lds_pitch / 4) >= 65536)
+        return set_err(ctx, ORBX_E_CAPACITY, "scale factor too large for the resize kernel's LDS tile");
+      if (!div_ok((uint64_t)nitems + 8, (uint64_t)nbx * nby)) return set_err(ctx, ORBX_E_CAPACITY, "batch too large for 32-bit tile indexing");
     }
   }
   // K2: FAST cells
@@ -303,6 +312,8 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
     hipLaunchKernelGGL(kern, dim3(xcd_grid(nitems)), dim3(ft), lds, st, ctx->d_geo, ctx->d_cells, d_imgs,
                        (long long)row_stride, (long long)frame_stride, b_pyr, (long long)geo.pyr_bytes, b_cand,
                        b_cell_cnt, ctx->ini_th, ctx->min_th, tile_rows, nitems);
+    if (!div_ok((uint64_t)nitems + 8, geo.cells.size()) || !div_ok((uint64_t)geo.btiles_total * nframes + 8, geo.btiles_total))
+      return set_err(ctx, ORBX_E_CAPACITY, "batch too large for 32-bit tile indexing");
   }
   // K4a: 7x7 fixed-point Gaussian of every level (the reference blurs each level that holds keypoints).  It only needs
   // the pyramid, and it is VALU-bound while the quadtree that follows FAST is latency-bound with few workgroups, so it
@@ -365,7 +376,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
     auto kern = K == 1 ? k_describe<1> : K == 2 ? k_describe<2> : K == 4 ? k_describe<4> : K == 8 ? k_describe<8> : k_describe<16>;
     hipLaunchKernelGGL(kern, dim3(xcd_grid(nitems)), dim3(256), 0, st, ctx->d_geo, d_imgs, (long long)row_stride,
                        (long long)frame_stride, b_pyr, (long long)geo.pyr_bytes, b_blur, (long long)geo.blur_bytes,
-                       b_kp_list, d_counts, d_kps, d_desc, dc, gpf, nitems);
+                       b_kp_list, d_counts, d_kps, d_desc, dc, gpf, nitems, div_magic((uint32_t)gpf));
   }
   ORBX_HIP(ctx, hipGetLastError());
   return ORBX_OK;

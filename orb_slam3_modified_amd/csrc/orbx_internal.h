@@ -70,11 +70,13 @@ struct DeviceLevel {  // POD copy of LevelGeom fields the kernels need
   float hX, scale;
   int scaled_patch, xtab_off, ytab_off;
   long long bplane_off;
-  int btile_begin, btiles_x, btiles_y, pad_;
+  int btile_begin, btiles_x, btiles_y;
+  uint32_t m_btiles_x;  // fast_div magic of btiles_x
 };
 
 struct DeviceGeom {
   int nlevels, rows, cols, ncells_total, cand_total, kp_total, out_cap, btiles_total;
+  uint32_t m_ncells, m_btiles;  // fast_div magics of ncells_total, btiles_total
   DeviceLevel lv[kMaxLevels];
 };
 

@@ -23,6 +23,10 @@ __constant__ __align__(16) int8_t c_pattern[1024] = {
 #include "orb_pattern.inc"
 };
 
+// n / d for block-uniform operands without the ~25-instruction VALU division sequence: M = ceil(2^32 / d) from the
+// host (0 encodes d == 1); exact while n * d < 2^32 (checked on the host for every use).
+__device__ __forceinline__ int fast_div(int n, uint32_t M) { return M ? (int)__umulhi((uint32_t)n, M) : n; }
+
 // XCD-aware block order.  Workgroup b of a 1-D grid runs on XCD b % 8 (observed dispatch rule, used for speed only)
 // and every XCD has its own 4 MiB L2, so neighbouring tiles / cells of one frame should share an XCD: the grid is
 // padded to 8*chunk blocks and block b works on logical item (b % 8) * chunk + b / 8, i.e. XCD k owns the contiguous
@@ -47,13 +51,14 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
                                                 int src_pitch, int sw, uint8_t* __restrict__ dst,
                                                 long long dst_frame_stride, int dst_pitch, int dw, int dh,
                                                 const XTab* __restrict__ xt, const XTab* __restrict__ yt, int nbx,
-                                                int nby, int nitems, int lds_pitch, int lds_rows) {
+                                                int nby, int nitems, int lds_pitch, int lds_rows, uint32_t m_tiles,
+                                                uint32_t m_nbx, uint32_t m_lp4) {
   extern __shared__ __align__(16) uint8_t smem[];
   const int t = threadIdx.x;
   const int L = xcd_logical_block(nitems);
   if (L < 0) return;  // block-uniform
-  const int frame = L / (nbx * nby), rem = L - frame * (nbx * nby);
-  const int by = rem / nbx, bx = rem - by * nbx;
+  const int frame = fast_div(L, m_tiles), rem = L - frame * (nbx * nby);
+  const int by = fast_div(rem, m_nbx), bx = rem - by * nbx;
   const int x0 = bx * kRT_W, y0 = by * kRT_H;
   const int xl = min(x0 + kRT_W, dw) - 1, yl = min(y0 + kRT_H, dh) - 1;  // last output column / row of the tile
   // source rectangle (tables are monotonic): columns [X0, X1], rows [Y0, Y1]
@@ -65,15 +70,17 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
   const bool al = ((src_pitch & 3) == 0) && ((((unsigned long long)src) & 3) == 0) && ((src_frame_stride & 3) == 0);
   if (nrows > lds_rows || ncolb > lds_pitch) return;  // host sized the tile from the same tables: cannot happen
   if (al) {
-    const int ndw = (ncolb + 3) >> 2, lp4 = lds_pitch >> 2;
-    for (int i = t; i < nrows * ndw; i += 256) {
-      const int r = i / ndw, c = i - r * ndw;
-      ((uint32_t*)smem)[r * lp4 + c] = *(const uint32_t*)(S + (long long)r * src_pitch + 4 * c);
+    // whole LDS rows (lds_pitch >= the widest source rectangle of the level): LDS dword index == loop index
+    const int lp4 = lds_pitch >> 2, swr = (sw + 3) & ~3;
+    for (int i = t; i < nrows * lp4; i += 256) {
+      const int r = (int)(((uint32_t)i * m_lp4) >> 16), c = i - r * lp4;  // i / lp4 (host magic, i < 65536 / lp4)
+      if (X0 + 4 * c < swr) ((uint32_t*)smem)[i] = *(const uint32_t*)(S + (long long)r * src_pitch + 4 * c);
     }
   } else {
-    for (int i = t; i < nrows * ncolb; i += 256) {
-      const int r = i / ncolb, c = i - r * ncolb;
-      smem[r * lds_pitch + c] = S[(long long)r * src_pitch + c];
+#pragma unroll 1  // cold path: keep it out of the register budget
+    for (int r = t >> 6; r < nrows; r += 4) {
+#pragma unroll 1
+      for (int c = t & 63; c < ncolb; c += 64) smem[r * lds_pitch + c] = S[(long long)r * src_pitch + c];
     }
   }
   __syncthreads();
@@ -167,7 +174,7 @@ __global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int L = xcd_logical_block(nitems);
   if (L < 0) return;  // block-uniform
-  const int frame = L / g->ncells_total, cell = L - frame * g->ncells_total;
+  const int frame = fast_div(L, g->m_ncells), cell = L - frame * g->ncells_total;
   const CellGeom cg = cells[cell];
   const DeviceLevel& lv = g->lv[cg.level];
   const uint8_t* img;
@@ -186,8 +193,11 @@ __global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__
         ((uint32_t*)tile)[r * P4 + c] = *(const uint32_t*)(src + (long long)r * pitch + 4 * c);
   } else {
     const uint8_t* src = img + (long long)cg.y0 * pitch + cg.x0;
-    for (int r = wv; r < ch; r += NW)
+#pragma unroll 1  // cold path: keep it out of the register budget
+    for (int r = wv; r < ch; r += NW) {
+#pragma unroll 1
       for (int c = lane; c < cw; c += 64) tile[r * PITCH + c] = src[(long long)r * pitch + c];
+    }
   }
   for (int i = t; i < (dh + 2) * P4; i += T) ((uint32_t*)sc)[i] = 0;
 #pragma unroll
@@ -900,12 +910,12 @@ __global__ __launch_bounds__(256) void k_blur7(const DeviceGeom* __restrict__ g,
   const int t = threadIdx.x;
   const int L = xcd_logical_block(nitems);
   if (L < 0) return;  // block-uniform
-  const int frame = L / g->btiles_total, bt = L - frame * g->btiles_total;
+  const int frame = fast_div(L, g->m_btiles), bt = L - frame * g->btiles_total;
   int l = 0;
   while (l + 1 < g->nlevels && bt >= g->lv[l + 1].btile_begin) l++;
   const DeviceLevel& lv = g->lv[l];
   const int tile = bt - lv.btile_begin;
-  const int ty = tile / lv.btiles_x, tx = tile - ty * lv.btiles_x;
+  const int ty = fast_div(tile, lv.m_btiles_x), tx = tile - ty * lv.btiles_x;
   const int x0 = tx * kBT_W, y0 = ty * kBT_H;
   const uint8_t* img;
   long long pitch;
@@ -928,8 +938,9 @@ __global__ __launch_bounds__(256) void k_blur7(const DeviceGeom* __restrict__ g,
     if (left || right) {
       __syncthreads();
       // reflect-101 columns: raw col 4+x for x in {-3..-1} <- x' = -x; for x in {w .. w+2} <- x' = 2w-2-x (w >= 8)
-      for (int i = t; i < kBT_RR * 6; i += 256) {
-        const int r = i / 6, k = i - r * 6;
+      for (int i = t; i < kBT_RR * 8; i += 256) {
+        const int r = i >> 3, k = i & 7;
+        if (k >= 6) continue;
         uint8_t* row = raw + r * kBT_RP;
         if (k < 3) { if (left) row[4 - (k + 1)] = row[4 + (k + 1)]; }
         else if (right) {
@@ -940,6 +951,7 @@ __global__ __launch_bounds__(256) void k_blur7(const DeviceGeom* __restrict__ g,
       }
     }
   } else {
+#pragma unroll 1  // cold path: keep it out of the register budget
     for (int i = t; i < kBT_RR * kBT_RB; i += 256) {
       const int r = i / kBT_RB, c = i - r * kBT_RB;
       raw[r * kBT_RP + c] = img[(long long)reflect101(y0 - 3 + r, h) * pitch + reflect101(x0 - 4 + c, w)];
@@ -1035,11 +1047,11 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
                                                   const uint8_t* __restrict__ blur, long long blur_frame_bytes,
                                                   const uint2* __restrict__ kp_list, const int32_t* __restrict__ counts,
                                                   orbx_keypoint* __restrict__ out_kps, uint8_t* __restrict__ out_desc,
-                                                  DescConsts dc, int groups_per_frame, int nitems) {
+                                                  DescConsts dc, int groups_per_frame, int nitems, uint32_t m_gpf) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int L = xcd_logical_block(nitems);
   if (L < 0) return;
-  const int frame = L / groups_per_frame;
+  const int frame = fast_div(L, m_gpf);
   const int g0 = ((L - frame * groups_per_frame) * 4 + w) * K;  // first keypoint (level-major index) of this wave
   const int total = counts[frame * 2];
   if (g0 >= total) return;  // wave-uniform
