@@ -199,7 +199,7 @@ __global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__
       for (int c = lane; c < cw; c += 64) tile[r * PITCH + c] = src[(long long)r * pitch + c];
     }
   }
-  for (int i = t; i < (dh + 2) * P4; i += T) ((uint32_t*)sc)[i] = 0;
+  for (int i = t; i < ((dh + 2) * P4 + 3) >> 2; i += T) ((uint4*)sc)[i] = make_uint4(0u, 0u, 0u, 0u);  // sc is 16-byte aligned
 #pragma unroll
   for (int k = 0; k < WPT; k++) bitmap[t * WPT + k] = 0;
   if (t == 0) s_cnt = 0;
@@ -209,7 +209,6 @@ __global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__
     const int kmin = (3 + xo) >> 2, kmax = (cw - 4 + xo) >> 2, ng = kmax - kmin + 1;
     const int nit = dh * ng;
     const uint32_t magic = (65536u + (uint32_t)ng - 1u) / (uint32_t)ng;  // i / ng == (i * magic) >> 16 for i < 65536 / ng
-    const unsigned long long lt = (1ull << lane) - 1ull;
     for (int i0 = 0; i0 < nit; i0 += T) {
       const int act = (i0 + t) < nit;
       const int i = act ? i0 + t : nit - 1;
@@ -220,31 +219,34 @@ __global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__
       const uint32_t Q4 = __builtin_amdgcn_alignbyte(dR, dC, 3);   // x+3 of pixel j in byte j
       const uint32_t Q12 = __builtin_amdgcn_alignbyte(dC, dL, 1);  // x-3 of pixel j in byte j
       const int c0 = 4 * k - xo - 3;                               // detection-domain x of pixel 0
-      int ps[4];
+      bool ps[4];
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const int v = (dC >> (8 * j)) & 0xff, p0 = (dD >> (8 * j)) & 0xff, p8 = (dU >> (8 * j)) & 0xff;
         const int p4 = (Q4 >> (8 * j)) & 0xff, p12 = (Q12 >> (8 * j)) & 0xff;
-        const int dark = max(min(p0, p8), min(p4, p12)) < v - min_th;
-        const int bright = min(max(p0, p8), max(p4, p12)) > v + min_th;
-        const int valid = (unsigned)(c0 + j) < (unsigned)dw;
-        ps[j] = (dark | bright) & valid & act;
+        const bool dark = max(min(p0, p8), min(p4, p12)) < v - min_th;
+        const bool bright = min(max(p0, p8), max(p4, p12)) > v + min_th;
+        const bool valid = (unsigned)(c0 + j) < (unsigned)dw;
+        ps[j] = (dark | bright) & valid & (act != 0);
       }
       const unsigned long long b0 = __ballot(ps[0]), b1 = __ballot(ps[1]), b2 = __ballot(ps[2]), b3 = __ballot(ps[3]);
-      const int tot = __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
+      const int n0 = __popcll(b0), n1_ = __popcll(b1), n2 = __popcll(b2), n3 = __popcll(b3);
+      const int tot = n0 + n1_ + n2 + n3;
       if (tot) {  // wave-uniform
         int base = 0;
         if (lane == 0) base = atomicAdd(&s_cnt, tot);
         base = __builtin_amdgcn_readfirstlane(base);
-        int off = base + __popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt);
+        // slot of pixel j of this lane: base + (passes of pixels < j in the wave) + (passes of pixel j in lower lanes);
+        // v_mbcnt accumulates onto a scalar start value, so each slot costs two VALU instructions
         const int ent = c0 + (ry << 7);  // c0 may be negative for the first group; pixel j is only listed when c0 + j >= 0
-        if (ps[0]) list[off] = (uint16_t)ent;
-        off += ps[0];
-        if (ps[1]) list[off] = (uint16_t)(ent + 1);
-        off += ps[1];
-        if (ps[2]) list[off] = (uint16_t)(ent + 2);
-        off += ps[2];
-        if (ps[3]) list[off] = (uint16_t)(ent + 3);
+        const int o0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, base));
+        const int o1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, base + n0));
+        const int o2 = __builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, base + n0 + n1_));
+        const int o3 = __builtin_amdgcn_mbcnt_hi((uint32_t)(b3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b3, base + n0 + n1_ + n2));
+        if (ps[0]) list[o0] = (uint16_t)ent;
+        if (ps[1]) list[o1] = (uint16_t)(ent + 1);
+        if (ps[2]) list[o2] = (uint16_t)(ent + 2);
+        if (ps[3]) list[o3] = (uint16_t)(ent + 3);
       }
     }
   }
