@@ -289,9 +289,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
                          S.w, b_pyr + D.plane_off, (long long)geo.pyr_bytes, D.pitch, D.w, D.h, ctx->d_xtab + D.xtab_off,
                          ctx->d_ytab + D.ytab_off, nbx, nby, nitems, D.rs_lds_pitch, D.rs_lds_rows,
                          div_magic((uint32_t)(nbx * nby)), div_magic((uint32_t)nbx),
-                         (65536u + (uint32_t)(D.rs_lds_pitch / 4) - 1u) / (uint32_t)(D.rs_lds_pitch / 4));
-      if (D.rs_lds_rows * (D.rs_lds_pitch / 4) * (D.rs_lds_pitch / 4) >= 65536)
-        return set_err(ctx, ORBX_E_CAPACITY, "scale factor too large for the resize kernel's LDS tile");
+                         div_magic((uint32_t)(D.rs_lds_pitch / 4)));
       if (!div_ok((uint64_t)nitems + 8, (uint64_t)nbx * nby)) return set_err(ctx, ORBX_E_CAPACITY, "batch too large for 32-bit tile indexing");
     }
   }

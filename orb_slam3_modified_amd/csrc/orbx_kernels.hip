@@ -40,12 +40,12 @@ __device__ __forceinline__ int xcd_logical_block(int n_items) {
 // ------------------------------------------------------------------------------------------------
 // K1: cv::resize INTER_LINEAR, CV_8UC1 (src/ORBextractor.cc:1183), one pyramid level from the previous one.
 // The byte-gather formulation is bound by the texture-address unit (one VMEM instruction per source byte), so a
-// workgroup stages the source rectangle of its 64x16 output tile into LDS with aligned dword loads and gathers the
-// four bilinear taps of every output pixel from LDS; each lane produces 4 horizontally adjacent pixels (one dword
-// store).  Arithmetic: int32 fixed point exactly as OpenCV.  A source whose rows are not dword
+// workgroup stages the source rectangle of its 64x64 output tile into LDS with aligned dword loads and gathers the
+// four bilinear taps of every output pixel from LDS; each lane produces 4 horizontally adjacent pixels of 4
+// consecutive rows (the decoded column table is reused, one dword store per row).  Arithmetic: int32 fixed point exactly as OpenCV.  A source whose rows are not dword
 // aligned is staged with byte loads instead (same LDS layout, same results).
 // ------------------------------------------------------------------------------------------------
-constexpr int kRT_W = 64, kRT_H = 16;  // output tile of k_resize
+constexpr int kRT_W = 64, kRT_H = 64, kRT_RPT = 4;  // output tile of k_resize; rows per thread
 
 __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src, long long src_frame_stride,
                                                 int src_pitch, int sw, uint8_t* __restrict__ dst,
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
     // whole LDS rows (lds_pitch >= the widest source rectangle of the level): LDS dword index == loop index
     const int lp4 = lds_pitch >> 2, swr = (sw + 3) & ~3;
     for (int i = t; i < nrows * lp4; i += 256) {
-      const int r = (int)(((uint32_t)i * m_lp4) >> 16), c = i - r * lp4;  // i / lp4 (host magic, i < 65536 / lp4)
+      const int r = fast_div(i, m_lp4), c = i - r * lp4;
       if (X0 + 4 * c < swr) ((uint32_t*)smem)[i] = *(const uint32_t*)(S + (long long)r * src_pitch + 4 * c);
     }
   } else {
@@ -84,12 +84,8 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
     }
   }
   __syncthreads();
-  const int x4 = x0 + (t & 15) * 4, dy = y0 + (t >> 4);
-  if (dy >= dh || x4 >= dw) return;
-  const XTab ty = yt[dy];
-  const uint8_t* R0 = smem + ((int)ty.s0 - Y0) * lds_pitch - X0;
-  const uint8_t* R1 = smem + ((int)ty.s1 - Y0) * lds_pitch - X0;
-  const int b0 = ty.a0, b1 = ty.a1;
+  const int x4 = x0 + (t & 15) * 4, dy0 = y0 + (t >> 4) * kRT_RPT;
+  if (dy0 >= dh || x4 >= dw) return;
   XTab tx[4];
   if (x4 + 3 < dw) {
     const uint4 q0 = *(const uint4*)(xt + x4), q1 = *(const uint4*)(xt + x4 + 2);
@@ -98,15 +94,29 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
 #pragma unroll
     for (int i = 0; i < 4; i++) tx[i] = xt[min(x4 + i, dw - 1)];
   }
-  uint32_t packed = 0;
+  int c0[4], c1[4], a0[4], a1[4];
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int h0 = R0[tx[i].s0] * tx[i].a0 + R0[tx[i].s1] * tx[i].a1;
-    const int h1 = R1[tx[i].s0] * tx[i].a0 + R1[tx[i].s1] * tx[i].a1;
-    const int v = ((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xff;
-    packed |= (uint32_t)v << (8 * i);
+  for (int i = 0; i < 4; i++) { c0[i] = (int)tx[i].s0 - X0; c1[i] = (int)tx[i].s1 - X0; a0[i] = tx[i].a0; a1[i] = tx[i].a1; }
+  uint8_t* out = dst + (long long)frame * dst_frame_stride + (long long)dy0 * dst_pitch + x4;
+#pragma unroll
+  for (int rr = 0; rr < kRT_RPT; rr++) {
+    const int dy = dy0 + rr;
+    if (dy < dh) {
+      const XTab ty = yt[dy];
+      const uint8_t* R0 = smem + ((int)ty.s0 - Y0) * lds_pitch;
+      const uint8_t* R1 = smem + ((int)ty.s1 - Y0) * lds_pitch;
+      const int b0 = ty.a0, b1 = ty.a1;
+      uint32_t packed = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int h0 = R0[c0[i]] * a0[i] + R0[c1[i]] * a1[i];
+        const int h1 = R1[c0[i]] * a0[i] + R1[c1[i]] * a1[i];
+        const int v = ((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xff;
+        packed |= (uint32_t)v << (8 * i);
+      }
+      *(uint32_t*)(out + (long long)rr * dst_pitch) = packed;
+    }
   }
-  *(uint32_t*)(dst + (long long)frame * dst_frame_stride + (long long)dy * dst_pitch + x4) = packed;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -932,8 +942,13 @@ __global__ __launch_bounds__(256) void k_blur7(const DeviceGeom* __restrict__ g,
     for (int i = t; i < kBT_RR * (kBT_RB / 4); i += 256) {
       const int r = (int)(((uint32_t)i * 3641u) >> 16), c = i - r * (kBT_RB / 4);  // i / 18
       const int sx = x0 - 4 + 4 * c;
+      // reflect-101 row: one reflection covers every row a stored output reads (h >= 67); rows further below the
+      // level (only in the last tile row, never stored) just need a valid address
+      int sy = y0 - 3 + r;
+      sy = sy < 0 ? -sy : (sy >= h ? 2 * h - 2 - sy : sy);
+      sy = max(sy, 0);
       uint32_t v = 0;
-      if (sx >= 0 && sx < w) v = *(const uint32_t*)(img + (long long)reflect101(y0 - 3 + r, h) * pitch + sx);
+      if (sx >= 0 && sx < w) v = *(const uint32_t*)(img + (long long)sy * pitch + sx);
       ((uint32_t*)raw)[r * (kBT_RP / 4) + c] = v;
     }
     const bool left = x0 == 0, right = x0 + kBT_W + 3 > w;  // block-uniform
