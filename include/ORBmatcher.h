@@ -3,9 +3,11 @@
  * replace the inner `for candidates: DescriptorDistance(...)` loops of the 12 Search.../Fuse routines
  * (src/ORBmatcher.cc; per-routine tie and accept rules: SURVEY.md §3.3).
  *
- * The 12 routines themselves take Frame / KeyFrame / MapPoint / Sophus types that belong to the reference and are
- * out of this repository's scope; INTEGRATION.md shows the few-line change that routes each routine's candidate
- * loop through NearestInCandidates() below while the geometry and the greedy bookkeeping stay in src/ORBmatcher.cc.
+ * SearchForInitialization (the heaviest Hamming workload of monocular tracking, src/ORBmatcher.cc:648-763) is provided
+ * in full as a template over the reference's Frame.  The other routines take KeyFrame / MapPoint / Sophus types that
+ * belong to the reference and are out of this repository's scope; INTEGRATION.md shows the few-line change that routes
+ * each routine's candidate loop through NearestInCandidates() below while the geometry and the greedy bookkeeping
+ * stay in src/ORBmatcher.cc.
  */
 #ifndef ORBMATCHER_H
 #define ORBMATCHER_H
@@ -64,6 +66,39 @@ class ORBmatcher {
     if (queryDesc.rows == 0) return;
     const int rc = orbx_knn2_allpairs(ctx, queryDesc.data, queryDesc.rows, trainDesc.data, trainDesc.rows, idx.data(), dist.data());
     if (rc != ORBX_OK) throw std::runtime_error(std::string("ORBmatcher: ") + orbx_last_error(ctx));
+  }
+
+  // A process-wide context for the stack-constructed matchers of the reference (`ORBmatcher matcher(0.9, true);`,
+  // src/Tracking.cc:2494): created on first use on the current HIP device.
+  static orbx_ctx* DefaultContext() {
+    static orbx_ctx* ctx = [] {
+      orbx_ctx* c = nullptr;
+      if (orbx_create(&c, 1, 1.2f, 1, 20, 7, -1) != ORBX_OK) throw std::runtime_error("ORBmatcher: no MI355X / HIP device");
+      return c;
+    }();
+    return ctx;
+  }
+
+  // Matching for the map initialisation (monocular), src/ORBmatcher.cc:648-763.  FrameT is the reference's Frame (or
+  // anything with mvKeysUn, mDescriptors and the static image bounds mnMinX / mnMinY / mnMaxX / mnMaxY): candidate
+  // windows (Frame::GetFeaturesInArea) and all Hamming distances run on the GPU, the greedy assignment is replayed on
+  // the host in the reference's order.  Same arguments, same return value, vbPrevMatched updated in place.
+  template <class FrameT>
+  int SearchForInitialization(FrameT& F1, FrameT& F2, std::vector<cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12,
+                              int windowSize = 10) {
+    const int n1 = (int)F1.mvKeysUn.size(), n2 = (int)F2.mvKeysUn.size();
+    vnMatches12.assign(n1, -1);
+    if (n1 == 0) return 0;
+    if (!F1.mDescriptors.isContinuous() || (n2 && !F2.mDescriptors.isContinuous()))
+      throw std::runtime_error("descriptor matrices must be continuous");
+    static_assert(sizeof(cv::KeyPoint) == sizeof(orbx_keypoint) && sizeof(cv::Point2f) == 8, "POD layouts");
+    int nmatches = 0;
+    const int rc = orbx_search_for_initialization(
+        DefaultContext(), (const orbx_keypoint*)F1.mvKeysUn.data(), F1.mDescriptors.data, n1, (const orbx_keypoint*)F2.mvKeysUn.data(),
+        n2 ? F2.mDescriptors.data : nullptr, n2, FrameT::mnMinX, FrameT::mnMinY, FrameT::mnMaxX, FrameT::mnMaxY,
+        (float*)vbPrevMatched.data(), windowSize, mfNNratio, mbCheckOrientation ? 1 : 0, vnMatches12.data(), &nmatches);
+    if (rc != ORBX_OK) throw std::runtime_error(std::string("ORBmatcher::SearchForInitialization: ") + orbx_last_error(DefaultContext()));
+    return nmatches;
   }
 
   // src/ORBmatcher.cc:2012-2053 (public here so the host-side replays can use it)

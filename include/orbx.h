@@ -142,6 +142,28 @@ int orbx_nn_csr_device(orbx_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t*
 int orbx_knn2_allpairs_device(orbx_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_idx,
                               int32_t* d_dist, void* stream);
 
+/* ---- frame grid + guided search (the callers' side of the matcher) --------------------- */
+
+/* Frame::AssignFeaturesToGrid + Frame::GetFeaturesInArea (src/Frame.cc:385-416, :657-735) for many queries at once,
+ * on the GPU: the 64 x 48 grid of the frame's keypoints `kps` (image bounds mnMinX..mnMaxY as in src/Frame.cc:153-160)
+ * is built once, then query q = (x, y, r, minLevel, maxLevel) returns the keypoint indices the reference returns, in
+ * the reference's order (cells x-major, then y, then insertion order — that order decides ties in the searches).
+ * CSR output: row_ptr [nq + 1], cand [cand_cap].  Returns the number of candidates (>= 0) or a negative error
+ * (ORBX_E_CAPACITY if cand_cap is too small; at most 8192 keypoints).  Host pointers. */
+int orbx_features_in_area(orbx_ctx* ctx, const orbx_keypoint* kps, int n, float min_x, float min_y, float max_x, float max_y,
+                          const float* qx, const float* qy, const float* qr, const int32_t* qmin_level, const int32_t* qmax_level,
+                          int nq, int32_t* row_ptr, int32_t* cand, int cand_cap);
+
+/* ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (src/ORBmatcher.cc:648-763):
+ * level-0 keypoints of F1 against F2's grid window around vbPrevMatched.  Candidate lists and all Hamming distances
+ * are computed on the GPU; the greedy, order-dependent assignment (a later query may steal an earlier match), the
+ * TH_LOW / nn_ratio tests and the rotation-histogram filter are replayed on the host in the reference's query order.
+ * prev_xy: [n1][2] in/out (vbPrevMatched); matches12: [n1] out (vnMatches12); *nmatches = return value of the
+ * reference routine.  kps are the frames' undistorted keypoints, desc their [n][32] descriptors.  Host pointers. */
+int orbx_search_for_initialization(orbx_ctx* ctx, const orbx_keypoint* kps1, const uint8_t* desc1, int n1, const orbx_keypoint* kps2,
+                                   const uint8_t* desc2, int n2, float min_x, float min_y, float max_x, float max_y, float* prev_xy,
+                                   int window_size, float nn_ratio, int check_orientation, int32_t* matches12, int* nmatches);
+
 /* ---- bag of words: replaces ORBVocabulary = DBoW2::TemplatedVocabulary<cv::Mat, FORB> ----------------- */
 
 /* TemplatedVocabulary::loadFromTextFile (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1424).

@@ -6,10 +6,13 @@
 //   * the candidate-loop pattern of the Search*/Fuse routines (best / second best, strict `<`, and the
 //     `<=` variant of SearchForTriangulation)            src/ORBmatcher.cc:96-118, :1010-1080
 //   * cv::BFMatcher(NORM_HAMMING).knnMatch(k=2)            as used at src/Frame.cc:1144
+//   * Frame::AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea          src/Frame.cc:385-416, :725-735, :657-723
+//   * ORBmatcher::SearchForInitialization + ComputeThreeMaxima             src/ORBmatcher.cc:648-763, :2012-2053
 //   * DBoW2 vocabulary: loadFromTextFile, transform, BowVector::addWeight/normalize, FeatureVector::addFeature,
 //     L1Scoring::score    Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1259,1338-1424, BowVector.cpp:34-85,
 //                         FeatureVector.cpp:30-45, ScoringObject.cpp:23-68
 #include <climits>
+#include <cassert>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -216,6 +219,153 @@ double mo_score_l1(const uint32_t* ida, const double* va, int na, const uint32_t
   }
   score = -score / 2.0;
   return score;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// Frame grid (include/Frame.h:44-45: FRAME_GRID_ROWS 48, FRAME_GRID_COLS 64)
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int kGridCols = 64, kGridRows = 48;
+struct MKeyPt { float x, y, size, angle, response; int32_t octave, class_id; };
+
+struct FrameGrid {
+  float minX, minY, invW, invH;
+  const MKeyPt* kps;
+  int n;
+  std::vector<size_t> cell[kGridCols][kGridRows];
+  // src/Frame.cc:153-160 (grid element inverses), :385-416 (AssignFeaturesToGrid), :725-735 (PosInGrid)
+  FrameGrid(const MKeyPt* k, int n_, float mnMinX, float mnMinY, float mnMaxX, float mnMaxY) : kps(k), n(n_) {
+    minX = mnMinX; minY = mnMinY;
+    invW = static_cast<float>(kGridCols) / static_cast<float>(mnMaxX - mnMinX);
+    invH = static_cast<float>(kGridRows) / static_cast<float>(mnMaxY - mnMinY);
+    for (int i = 0; i < n; i++) {
+      const int posX = (int)std::round((kps[i].x - minX) * invW);
+      const int posY = (int)std::round((kps[i].y - minY) * invH);
+      if (posX < 0 || posX >= kGridCols || posY < 0 || posY >= kGridRows) continue;
+      cell[posX][posY].push_back((size_t)i);
+    }
+  }
+  // src/Frame.cc:657-723
+  std::vector<size_t> area(const float& x, const float& y, const float& r, const int minLevel, const int maxLevel) const {
+    std::vector<size_t> out;
+    const float factorX = r, factorY = r;
+    const int nMinCellX = std::max(0, (int)std::floor((x - minX - factorX) * invW));
+    if (nMinCellX >= kGridCols) return out;
+    const int nMaxCellX = std::min(kGridCols - 1, (int)std::ceil((x - minX + factorX) * invW));
+    if (nMaxCellX < 0) return out;
+    const int nMinCellY = std::max(0, (int)std::floor((y - minY - factorY) * invH));
+    if (nMinCellY >= kGridRows) return out;
+    const int nMaxCellY = std::min(kGridRows - 1, (int)std::ceil((y - minY + factorY) * invH));
+    if (nMaxCellY < 0) return out;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+      for (int iy = nMinCellY; iy <= nMaxCellY; iy++)
+        for (size_t idx : cell[ix][iy]) {
+          const MKeyPt& kp = kps[idx];
+          if (bCheckLevels) {
+            if (kp.octave < minLevel) continue;
+            if (maxLevel >= 0 && kp.octave > maxLevel) continue;
+          }
+          const float distx = kp.x - x, disty = kp.y - y;
+          if (std::fabs(distx) < factorX && std::fabs(disty) < factorY) out.push_back(idx);
+        }
+    return out;
+  }
+};
+
+// src/ORBmatcher.cc:2012-2053
+void three_maxima(const std::vector<int>* histo, int L, int& ind1, int& ind2, int& ind3) {
+  int max1 = 0, max2 = 0, max3 = 0;
+  for (int i = 0; i < L; i++) {
+    const int s = (int)histo[i].size();
+    if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+    else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+    else if (s > max3) { max3 = s; ind3 = i; }
+  }
+  if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+  else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+}  // namespace
+
+extern "C" {
+
+// Frame::GetFeaturesInArea for a list of queries -> CSR (row_ptr [nq+1], cand [cap]); returns nnz (or -1 on overflow)
+int mo_features_in_area(const void* kps, int n, float mnMinX, float mnMinY, float mnMaxX, float mnMaxY, const float* qx,
+                        const float* qy, const float* qr, const int32_t* qmin, const int32_t* qmax, int nq, int32_t* row_ptr,
+                        int32_t* cand, int cap) {
+  FrameGrid g((const MKeyPt*)kps, n, mnMinX, mnMinY, mnMaxX, mnMaxY);
+  int nnz = 0;
+  row_ptr[0] = 0;
+  for (int q = 0; q < nq; q++) {
+    for (size_t i : g.area(qx[q], qy[q], qr[q], qmin[q], qmax[q])) {
+      if (nnz >= cap) return -1;
+      cand[nnz++] = (int32_t)i;
+    }
+    row_ptr[q + 1] = nnz;
+  }
+  return nnz;
+}
+
+// ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize), src/ORBmatcher.cc:648-763.
+// prev_xy: [n1][2] in/out (vbPrevMatched).  Returns nmatches.
+int mo_search_for_initialization(const void* kps1_, const uint8_t* desc1, int n1, const void* kps2_, const uint8_t* desc2, int n2,
+                                 float mnMinX, float mnMinY, float mnMaxX, float mnMaxY, float* prev_xy, int windowSize,
+                                 float mfNNratio, int mbCheckOrientation, int32_t* vnMatches12) {
+  const MKeyPt* kps1 = (const MKeyPt*)kps1_;
+  const MKeyPt* kps2 = (const MKeyPt*)kps2_;
+  const int TH_LOW = 50, HISTO_LENGTH = 30;
+  FrameGrid F2(kps2, n2, mnMinX, mnMinY, mnMaxX, mnMaxY);
+  int nmatches = 0;
+  for (int i = 0; i < n1; i++) vnMatches12[i] = -1;
+  std::vector<int> rotHist[30];
+  const float factor = 1.0f / HISTO_LENGTH;
+  std::vector<int> vMatchedDistance(n2, INT_MAX), vnMatches21(n2, -1);
+  for (int i1 = 0; i1 < n1; i1++) {
+    const MKeyPt kp1 = kps1[i1];
+    const int level1 = kp1.octave;
+    if (level1 > 0) continue;
+    const std::vector<size_t> vIndices2 = F2.area(prev_xy[2 * i1], prev_xy[2 * i1 + 1], (float)windowSize, level1, level1);
+    if (vIndices2.empty()) continue;
+    const uint8_t* d1 = desc1 + (size_t)i1 * 32;
+    int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+    for (size_t i2 : vIndices2) {
+      const int dist = descriptor_distance(d1, desc2 + i2 * 32);
+      if (vMatchedDistance[i2] <= dist) continue;
+      if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = (int)i2; }
+      else if (dist < bestDist2) { bestDist2 = dist; }
+    }
+    if (bestDist <= TH_LOW) {
+      if (bestDist < (float)bestDist2 * mfNNratio) {
+        if (vnMatches21[bestIdx2] >= 0) { vnMatches12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+        vnMatches12[i1] = bestIdx2;
+        vnMatches21[bestIdx2] = i1;
+        vMatchedDistance[bestIdx2] = bestDist;
+        nmatches++;
+        if (mbCheckOrientation) {
+          float rot = kps1[i1].angle - kps2[bestIdx2].angle;
+          if (rot < 0.0) rot += 360.0f;
+          int bin = (int)std::round(rot * factor);
+          if (bin == HISTO_LENGTH) bin = 0;
+          assert(bin >= 0 && bin < HISTO_LENGTH);
+          rotHist[bin].push_back(i1);
+        }
+      }
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int idx1 : rotHist[i])
+        if (vnMatches12[idx1] >= 0) { vnMatches12[idx1] = -1; nmatches--; }
+    }
+  }
+  for (int i1 = 0; i1 < n1; i1++)
+    if (vnMatches12[i1] >= 0) { prev_xy[2 * i1] = kps2[vnMatches12[i1]].x; prev_xy[2 * i1 + 1] = kps2[vnMatches12[i1]].y; }
+  return nmatches;
 }
 
 }  // extern "C"

@@ -184,6 +184,11 @@ def _mlib():
         L.mo_voc_transform.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, C.POINTER(C.c_int)]
         L.mo_score_l1.restype = C.c_double
         L.mo_score_l1.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int]
+        f32 = C.c_float
+        L.mo_features_in_area.restype = C.c_int
+        L.mo_features_in_area.argtypes = [vp, C.c_int, f32, f32, f32, f32, vp, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int]
+        L.mo_search_for_initialization.restype = C.c_int
+        L.mo_search_for_initialization.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, f32, f32, f32, f32, vp, C.c_int, f32, C.c_int, vp]
         L._mo_bound = True
     return L
 
@@ -201,6 +206,32 @@ def nn_csr(q, t, row_ptr, cand, last_wins=False):
     do = np.zeros(max(len(cd), 1), np.int32)
     _mlib().mo_nn_csr(_ptr(q), nq, _ptr(t), _ptr(rp), _ptr(cd), int(last_wins), _ptr(bi), _ptr(bd), _ptr(si), _ptr(sd), _ptr(do))
     return bi[:nq], bd[:nq], si[:nq], sd[:nq], do[:len(cd)]
+
+
+def features_in_area(kps, bounds, qx, qy, qr, qmin, qmax):
+    """Frame::GetFeaturesInArea (src/Frame.cc:657-723) over the frame grid of `kps` for a list of queries -> (row_ptr, cand)."""
+    k = np.ascontiguousarray(kps)
+    qx, qy, qr = (np.ascontiguousarray(v, np.float32) for v in (qx, qy, qr))
+    qmin, qmax = (np.ascontiguousarray(v, np.int32) for v in (qmin, qmax))
+    nq = len(qx)
+    cap = max(len(k) * max(nq, 1), 1)
+    rp = np.zeros(nq + 1, np.int32)
+    cand = np.zeros(cap, np.int32)
+    nnz = _mlib().mo_features_in_area(_ptr(k), len(k), *[float(b) for b in bounds], _ptr(qx), _ptr(qy), _ptr(qr), _ptr(qmin), _ptr(qmax),
+                                      nq, _ptr(rp), _ptr(cand), cap)
+    assert nnz >= 0
+    return rp, cand[:nnz].copy()
+
+
+def search_for_initialization(kps1, desc1, kps2, desc2, bounds, prev_xy, window_size=100, nnratio=0.9, check_ori=True):
+    """ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:648-763) -> (nmatches, vnMatches12, updated vbPrevMatched)."""
+    k1, k2 = np.ascontiguousarray(kps1), np.ascontiguousarray(kps2)
+    d1, d2 = np.ascontiguousarray(desc1, np.uint8), np.ascontiguousarray(desc2, np.uint8)
+    prev = np.ascontiguousarray(prev_xy, np.float32).copy()
+    m12 = np.zeros(max(len(k1), 1), np.int32)
+    n = _mlib().mo_search_for_initialization(_ptr(k1), _ptr(d1), len(k1), _ptr(k2), _ptr(d2), len(k2), *[float(b) for b in bounds],
+                                             _ptr(prev), int(window_size), float(nnratio), int(check_ori), _ptr(m12))
+    return int(n), m12[:len(k1)].copy(), prev
 
 
 def knn2(q, t):

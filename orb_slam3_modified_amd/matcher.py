@@ -51,6 +51,41 @@ class ORBmatcher:
         check(self._L.orbx_knn2_allpairs(self._ctx, ptr(q), len(q), ptr(t), len(t), ptr(idx), ptr(dist)), self._ctx)
         return idx[:len(q)], dist[:len(q)]
 
+    def GetFeaturesInArea(self, kps, bounds, qx, qy, qr, min_level, max_level):
+        """Frame::GetFeaturesInArea (src/Frame.cc:657-723) for many queries over the frame grid of `kps`
+        (Frame::AssignFeaturesToGrid, :385-416), built and queried on the GPU -> CSR (row_ptr, cand) in the
+        reference's candidate order.  bounds = (mnMinX, mnMinY, mnMaxX, mnMaxY)."""
+        k = np.ascontiguousarray(kps)
+        qx, qy, qr = (np.ascontiguousarray(v, np.float32) for v in (qx, qy, qr))
+        lo, hi = (np.ascontiguousarray(v, np.int32) for v in (min_level, max_level))
+        nq = len(qx)
+        rp = np.zeros(nq + 1, np.int32)
+        cap = 1 << 16
+        while True:
+            cand = np.zeros(cap, np.int32)
+            rc = self._L.orbx_features_in_area(self._ctx, ptr(k), len(k), *[float(b) for b in bounds], ptr(qx), ptr(qy), ptr(qr),
+                                               ptr(lo), ptr(hi), nq, ptr(rp), ptr(cand), cap)
+            if rc == -4 and cap < (1 << 28):   # ORBX_E_CAPACITY: grow and retry
+                cap *= 8
+                continue
+            check(rc, self._ctx)
+            return rp, cand[:rc].copy()
+
+    def SearchForInitialization(self, F1, F2, vbPrevMatched, windowSize: int = 10):
+        """src/ORBmatcher.cc:648-763.  F1 / F2: frame-like objects with `mvKeysUn` (KP_DTYPE array), `mDescriptors`
+        ([n,32] uint8) and `bounds` (mnMinX, mnMinY, mnMaxX, mnMaxY).  Returns (nmatches, vnMatches12) and updates
+        vbPrevMatched ([n1,2] float32) in place, like the reference."""
+        k1, k2 = np.ascontiguousarray(F1.mvKeysUn), np.ascontiguousarray(F2.mvKeysUn)
+        d1 = np.ascontiguousarray(F1.mDescriptors, np.uint8).reshape(-1, 32)
+        d2 = np.ascontiguousarray(F2.mDescriptors, np.uint8).reshape(-1, 32)
+        assert vbPrevMatched.dtype == np.float32 and vbPrevMatched.flags["C_CONTIGUOUS"] and vbPrevMatched.shape == (len(k1), 2)
+        m12 = np.zeros(max(len(k1), 1), np.int32)
+        n = C.c_int(0)
+        check(self._L.orbx_search_for_initialization(self._ctx, ptr(k1), ptr(d1), len(k1), ptr(k2), ptr(d2), len(k2),
+                                                     *[float(b) for b in F2.bounds], ptr(vbPrevMatched), int(windowSize),
+                                                     self.mfNNratio, int(self.mbCheckOrientation), ptr(m12), C.byref(n)), self._ctx)
+        return n.value, m12[:len(k1)].copy()
+
     @staticmethod
     def ComputeThreeMaxima(histo_counts):
         """src/ORBmatcher.cc:2012-2053 on bin populations."""

@@ -15,6 +15,14 @@
 
 using namespace ORB_SLAM3;
 
+// the members of ORB_SLAM3::Frame that ORBmatcher::SearchForInitialization touches (include/Frame.h)
+struct MiniFrame {
+  std::vector<cv::KeyPoint> mvKeysUn;
+  cv::Mat mDescriptors;
+  static float mnMinX, mnMinY, mnMaxX, mnMaxY;
+};
+float MiniFrame::mnMinX = 0, MiniFrame::mnMinY = 0, MiniFrame::mnMaxX = 0, MiniFrame::mnMaxY = 0;
+
 int main(int argc, char** argv) {
   if (argc < 2) return 2;
   const std::string mode = argv[1];
@@ -71,6 +79,20 @@ int main(int argc, char** argv) {
       o.write((const char*)&self, 8);
     } else {
       o.write((const char*)&nb, 4);
+    }
+    // SearchForInitialization of the frame against itself shifted by one row of the descriptor order (src/Tracking.cc:2494-2495)
+    {
+      MiniFrame::mnMaxX = (float)cols; MiniFrame::mnMaxY = (float)rows;
+      MiniFrame F1, F2;
+      F1.mvKeysUn = keys; F1.mDescriptors = descriptors.clone();
+      F2.mvKeysUn = keys; F2.mDescriptors = descriptors.clone();
+      std::vector<cv::Point2f> prev(n);
+      for (int i = 0; i < n; i++) prev[i] = keys[i].pt;
+      std::vector<int> m12;
+      ORBmatcher matcher(0.9f, true);
+      const int nm = n ? matcher.SearchForInitialization(F1, F2, prev, m12, 100) : 0;
+      o.write((const char*)&nm, 4);
+      o.write((const char*)m12.data(), (std::streamsize)m12.size() * 4);
     }
     std::printf("OK n=%d mono=%d\n", n, mono);
     delete extractor;

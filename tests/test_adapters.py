@@ -60,7 +60,9 @@ def _read(path):
     if nb:
         fv = [take("<II") for _ in range(take("<i"))]
         self_score = take("<d")
-    return mono, kps, desc, pyr, d01, bow, fv, self_score
+    nm = take("<i")
+    m12 = np.frombuffer(b, np.int32, n, off)
+    return mono, kps, desc, pyr, d01, bow, fv, self_score, nm, m12
 
 
 @pytest.mark.gpu
@@ -78,7 +80,7 @@ def test_adapter_results_equal_oracle(tmp_path, rows, cols, lap):
     make_vocabulary(vocp, odesc, 6, 3, seed=3)
     r = subprocess.run([exe, "run", raw, str(rows), str(cols), "1000", str(lap[0]), str(lap[1]), out, vocp], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    mono, kps, desc, pyr, d01, bow, fv, self_score = _read(out)
+    mono, kps, desc, pyr, d01, bow, fv, self_score, nm, m12 = _read(out)
     assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc)
     for l in range(8):
         assert np.array_equal(pyr[l], ora.level(l))
@@ -88,3 +90,6 @@ def test_adapter_results_equal_oracle(tmp_path, rows, cols, lap):
     flat = [(int(k), int(f)) for k, v in ofv.items() for f in v]
     assert fv == flat
     assert abs(self_score - 1.0) < 1e-12
+    prev = np.stack([okps["x"], okps["y"]], 1).astype(np.float32)
+    on, om12, _ = po.search_for_initialization(okps, odesc, okps, odesc, (0, 0, cols, rows), prev, 100, 0.9, True)
+    assert nm == on and np.array_equal(m12, om12)

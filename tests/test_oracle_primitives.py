@@ -191,3 +191,34 @@ def test_bow_handbuilt_vocabulary(tmp_path):
     s = po.score_l1((ids, vals), other)
     exp = -0.5 * ((abs(vals[0] - 0.5) - vals[0] - 0.5) + (abs(vals[3] - 0.5) - vals[3] - 0.5))
     assert abs(s - exp) < 1e-15
+
+
+def test_frame_grid_area_against_bruteforce():
+    """Frame::GetFeaturesInArea restatement: same SET as a brute-force window filter whenever the grid window covers the
+    query window (r > 0), candidates grouped by grid column then row, insertion order inside a cell."""
+    rng = np.random.default_rng(11)
+    n = 1500
+    kps = np.zeros(n, po.KP_DTYPE)
+    kps["x"] = rng.uniform(0, 640, n).astype(np.float32); kps["y"] = rng.uniform(0, 480, n).astype(np.float32)
+    kps["octave"] = rng.integers(0, 8, n)
+    qx = rng.uniform(0, 640, 200).astype(np.float32); qy = rng.uniform(0, 480, 200).astype(np.float32)
+    qr = rng.choice([5.0, 15.0, 60.0], 200).astype(np.float32)
+    lo = rng.choice([-1, 0, 2], 200).astype(np.int32); hi = rng.choice([-1, 1, 5], 200).astype(np.int32)
+    rp, cand = po.features_in_area(kps, (0, 0, 640, 480), qx, qy, qr, lo, hi)
+    invw, invh = np.float32(64) / np.float32(640), np.float32(48) / np.float32(480)
+    for q in range(200):
+        got = cand[rp[q]:rp[q + 1]]
+        ok = (np.abs(kps["x"] - qx[q]) < qr[q]) & (np.abs(kps["y"] - qy[q]) < qr[q])
+        if lo[q] > 0 or hi[q] >= 0:
+            ok &= kps["octave"] >= lo[q]
+            if hi[q] >= 0:
+                ok &= kps["octave"] <= hi[q]
+        # points whose ROUNDED cell falls outside the floor/ceil cell window are legitimately missed by the reference
+        cx = np.floor((kps["x"] * invw).astype(np.float32) + np.float32(0.5)); cy = np.floor((kps["y"] * invh).astype(np.float32) + np.float32(0.5))  # C round() for values >= 0
+        inwin = (cx >= max(0, np.floor((qx[q] - qr[q]) * invw))) & (cx <= min(63, np.ceil((qx[q] + qr[q]) * invw))) & \
+                (cy >= max(0, np.floor((qy[q] - qr[q]) * invh))) & (cy <= min(47, np.ceil((qy[q] + qr[q]) * invh))) & (cx < 64) & (cy < 48)
+        assert set(got.tolist()) == set(np.nonzero(ok & inwin)[0].tolist())
+        key = cx[got] * 48 + cy[got]
+        assert (np.diff(key) >= 0).all()                        # x-major, then y
+        same = np.diff(key) == 0
+        assert (np.diff(got)[same] > 0).all()                   # insertion order inside a cell

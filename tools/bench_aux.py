@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Secondary measurements (not the bench line): single-frame operator() latency incl. PCIe, matcher kernels, BoW.
+   python tools/bench_aux.py  -> gpurun_out/bench_aux.json"""
+import json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from orb_slam3_modified_amd import ORBextractor, ORBmatcher, ORBVocabulary, synth, _lib
+from orb_slam3_modified_amd._lib import ptr
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from vocab_util import make_vocabulary
+
+res = {}
+dev = torch.device("cuda", 0)
+ex = ORBextractor(1000, 1.2, 8, 20, 7)
+frames = synth.make_stream(16)
+for f in frames[:4]:
+    ex(f, None, (0, 1000))
+t0 = time.perf_counter()
+n = 0
+for rep in range(20):
+    for f in frames:
+        mono, k, d = ex(f, None, (0, 1000)); n += len(k)
+dt = time.perf_counter() - t0
+res["operator_call_640x480"] = {"ms_per_frame": dt / 320 * 1e3, "features_per_ms": n / dt / 1e3,
+                                "note": "host buffers: H2D 307 KB + launches + D2H keypoints/descriptors + sync, one frame per call, python ctypes caller"}
+# 1024x1024 / 2000 features batch (BASELINE config 4 shape), device-resident
+ex2 = ORBextractor(2000, 1.2, 8, 20, 7)
+f2 = torch.from_numpy(synth.make_stream(16, 1024, 1024)[np.arange(64) % 16]).to(dev)
+cap = ex2.capacity
+kps = torch.zeros(64 * cap * 28, dtype=torch.uint8, device=dev); dsc = torch.zeros(64 * cap * 32, dtype=torch.uint8, device=dev)
+cnt = torch.zeros(64 * 2, dtype=torch.int32, device=dev)
+side = torch.cuda.Stream()   # a real (non-NULL) stream: NULL would select the context's own stream
+st = side.cuda_stream
+def run2():
+    ex2.extract_batch_device(f2.data_ptr(), 64, 1024, 1024, f2.stride(1), f2.stride(0), kps.data_ptr(), dsc.data_ptr(), cnt.data_ptr(), (0, 1000), st)
+for _ in range(3): run2()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(10): run2()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+nf = int(cnt.view(64, 2)[:, 0].sum().item())
+res["batch_1024x1024_2000f"] = {"ms_per_64_frames": dt * 1e3, "frames_per_s": 64 / dt, "features_per_ms": nf / dt / 1e3}
+# matcher kernels, device resident
+out = [ex(f, None, (0, 1000)) for f in frames[:2]]
+d0 = torch.from_numpy(out[0][2]).to(dev); d1 = torch.from_numpy(out[1][2]).to(dev)
+k0, k1 = out[0][1], out[1][1]
+rp, cand = [0], []
+for p in k0:
+    m = np.nonzero((np.abs(k1["x"] - p["x"]) < 30) & (np.abs(k1["y"] - p["y"]) < 30))[0]
+    cand.extend(m.tolist()); rp.append(len(cand))
+rp_t = torch.tensor(rp, dtype=torch.int32, device=dev); cd_t = torch.tensor(cand, dtype=torch.int32, device=dev)
+nq = len(k0)
+o = [torch.zeros(nq, dtype=torch.int32, device=dev) for _ in range(4)]
+L = _lib.lib()
+def ev_time(fn, reps=50):
+    for _ in range(5): fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(side)
+    for _ in range(reps): fn()
+    b.record(side); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+t = ev_time(lambda: L.orbx_nn_csr_device(ex._ctx, ptr(d0.data_ptr()), nq, ptr(d1.data_ptr()), len(k1), ptr(rp_t.data_ptr()), ptr(cd_t.data_ptr()), 0,
+                                         ptr(o[0].data_ptr()), ptr(o[1].data_ptr()), ptr(o[2].data_ptr()), ptr(o[3].data_ptr()), ptr(0), ptr(st)))
+res["nn_csr"] = {"queries": nq, "candidates": len(cand), "us_per_call": t * 1e3, "pairs_per_s": len(cand) / (t * 1e-3)}
+i2 = torch.zeros(nq * 2, dtype=torch.int32, device=dev); dd2 = torch.zeros(nq * 2, dtype=torch.int32, device=dev)
+t = ev_time(lambda: L.orbx_knn2_allpairs_device(ex._ctx, ptr(d0.data_ptr()), nq, ptr(d1.data_ptr()), len(k1), ptr(i2.data_ptr()), ptr(dd2.data_ptr()), ptr(st)))
+res["knn2_allpairs"] = {"queries": nq, "train": len(k1), "us_per_call": t * 1e3, "pairs_per_s": nq * len(k1) / (t * 1e-3)}
+# big all-pairs (5000 x 5000) to see the kernel's rate without launch overhead
+big = torch.randint(0, 255, (8192, 32), dtype=torch.uint8, device=dev)
+i3 = torch.zeros(8192 * 2, dtype=torch.int32, device=dev); d3 = torch.zeros(8192 * 2, dtype=torch.int32, device=dev)
+t = ev_time(lambda: L.orbx_knn2_allpairs_device(ex._ctx, ptr(big.data_ptr()), 8192, ptr(big.data_ptr()), 8192, ptr(i3.data_ptr()), ptr(d3.data_ptr()), ptr(st)), 10)
+res["knn2_allpairs_8192"] = {"us_per_call": t * 1e3, "pairs_per_s": 8192 * 8192 / (t * 1e-3)}
+# BoW
+alld = np.concatenate([o_[2] for o_ in out] + [ex(f, None, (0, 1000))[2] for f in frames[2:10]])
+vp = "/tmp/voc_k10_L4.txt"
+info = make_vocabulary(vp, alld, 10, 4, seed=1)
+voc = ORBVocabulary(ex)
+assert voc.loadFromTextFile(vp)
+dw = torch.zeros(nq, dtype=torch.int32, device=dev); dwt = torch.zeros(nq, dtype=torch.float64, device=dev); dn = torch.zeros(nq, dtype=torch.int32, device=dev)
+t = ev_time(lambda: L.orbx_bow_transform_device(voc._voc, ptr(d0.data_ptr()), nq, 4, ptr(dw.data_ptr()), ptr(dwt.data_ptr()), ptr(dn.data_ptr()), ptr(st)))
+res["bow_descend"] = {"features": nq, "vocabulary": info, "us_per_call": t * 1e3, "features_per_s": nq / (t * 1e-3)}
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+json.dump(res, open(os.path.join(ROOT, "gpurun_out", "bench_aux.json"), "w"), indent=1)
+print(json.dumps(res, indent=1))
