@@ -83,6 +83,10 @@ int orbx_extract_batch(orbx_ctx* ctx, const uint8_t* imgs, int nframes, int rows
  * (the reference's stereo matcher reads it, src/Frame.cc:818,908-925).  dst may be NULL to query w/h. */
 int orbx_pyramid_level(orbx_ctx* ctx, int frame, int level, uint8_t* dst, size_t dst_stride, int* w, int* h);
 
+/* The 7x7 Gaussian-blurred copy of mvImagePyramid[level] the descriptors were sampled from
+ * (cv::GaussianBlur, src/ORBextractor.cc:1132-1133), for stage-level parity tests.  dst: h rows of w bytes. */
+int orbx_debug_blur_level(orbx_ctx* ctx, int frame, int level, uint8_t* dst, size_t dst_stride);
+
 /* Stage dumps of the last extraction, for parity tests.
  *  stage 0: FAST candidates handed to the quadtree, in the reference's order (vToDistributeKeys,
  *           src/ORBextractor.cc:863-868): packed x | y<<12 | score<<24, border-relative coordinates.

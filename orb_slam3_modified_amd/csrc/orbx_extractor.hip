@@ -609,6 +609,17 @@ int orbx_pyramid_level(orbx_ctx* ctx, int frame, int level, uint8_t* dst, size_t
   return ORBX_OK;
 }
 
+int orbx_debug_blur_level(orbx_ctx* ctx, int frame, int level, uint8_t* dst, size_t dst_stride) {
+  if (!ctx || !ctx->d_geo || !dst || level < 0 || level >= ctx->nlevels || frame < 0 || frame >= ctx->last_nframes)
+    return ctx ? set_err(ctx, ORBX_E_INVALID, "no such pyramid level") : ORBX_E_INVALID;
+  const LevelGeom& L = ctx->geo.lv[level];
+  ORBX_HIP(ctx, hipSetDevice(ctx->device));
+  ORBX_HIP(ctx, hipDeviceSynchronize());
+  ORBX_HIP(ctx, hipMemcpy2D(dst, dst_stride, ctx->d_blur + (size_t)frame * ctx->geo.blur_bytes + L.bplane_off, L.pitch, L.w, L.h,
+                            hipMemcpyDeviceToHost));
+  return ORBX_OK;
+}
+
 int orbx_debug_level_points(orbx_ctx* ctx, int frame, int level, int stage, uint32_t* dst, int cap) {
   if (!ctx || !ctx->d_geo || level < 0 || level >= ctx->nlevels || frame < 0 || frame >= ctx->last_nframes)
     return ctx ? set_err(ctx, ORBX_E_INVALID, "no such level") : ORBX_E_INVALID;

@@ -108,6 +108,14 @@ class ORBextractor:
     def mvImagePyramid(self) -> List[np.ndarray]:
         return [self.pyramid_level(l) for l in range(self.nlevels)]
 
+    def debug_blur_level(self, level: int, frame: int = 0) -> np.ndarray:
+        """The blurred copy of pyramid level `level` the descriptors sample (stage-level parity tests)."""
+        w, h = C.c_int(0), C.c_int(0)
+        check(self._L.orbx_pyramid_level(self._ctx, frame, level, None, 0, C.byref(w), C.byref(h)), self._ctx)
+        out = np.zeros((h.value, w.value), np.uint8)
+        check(self._L.orbx_debug_blur_level(self._ctx, frame, level, ptr(out), w.value), self._ctx)
+        return out
+
     # ---- stage dumps / profiling ------------------------------------------------------------------------
     def debug_level_points(self, level: int, stage: int, frame: int = 0):
         n = check(self._L.orbx_debug_level_points(self._ctx, frame, level, stage, None, 0), self._ctx)

@@ -72,6 +72,18 @@ def test_stage_parity_pyramid_candidates_quadtree():
         assert np.array_equal(gx, k["x"].astype(np.int32)) and np.array_equal(gy, k["y"].astype(np.int32)), f"quadtree level {l}"
 
 
+@pytest.mark.parametrize("rows,cols", [(480, 640), (350, 600), (134, 179), (480, 752)])
+def test_stage_parity_blurred_planes_full_frame_incl_borders(rows, cols):
+    """Every pixel of every blurred level (reflect-101 borders, partial last tiles) against cv::GaussianBlur's restatement:
+    the descriptors only sample >= 1 px inside, so the end-to-end test alone would not see a border mistake."""
+    frames = synth.make_stream(2, rows, cols)
+    gpu = ORBextractor(1000, 1.2, 4 if rows < 200 else 8, 20, 7)
+    gpu.extract_batch(frames, (0, 1000))
+    for f in range(2):
+        for l in range(gpu.nlevels):
+            assert np.array_equal(gpu.debug_blur_level(l, frame=f), po.gaussian_blur7(gpu.pyramid_level(l, frame=f))), (rows, cols, f, l)
+
+
 @pytest.mark.parametrize("name", ["constant", "noise", "checker", "gradient", "saturated"])
 def test_degenerate_images(name):
     rng = np.random.default_rng(5)
