@@ -189,6 +189,17 @@ def main():
                     traffic = int(ent["hbm_bytes_per_launch"]) if ent else None
             except Exception:
                 traffic = None
+        # issue-side evidence for the same kernel (SQ counters from a separate rocprofv3 --pmc run, tools/pmc_sq.py):
+        # the extractor kernels are integer-VALU bound, which is why the nominal HBM fraction is low
+        issue = None
+        sqp = os.path.join(ROOT, "profiles", "pmc_sq.json")
+        if os.path.exists(sqp):
+            try:
+                issue = json.load(open(sqp)).get("derived", {}).get(dom.split("(")[0])
+                if issue:
+                    issue = {k: round(float(v), 4) for k, v in issue.items()}
+            except Exception:
+                issue = None
         step_ms = dt / args.steps * 1e3
         result = {
             "metric": "ORB features/ms (+ frames/s), 640x480 8-level pyramid, 1000 features/frame",
@@ -207,6 +218,7 @@ def main():
                          "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4),
                          "pipeline_fused_ideal_bytes_per_frame": int(fused),
                          "pipeline_frac": round(fused * (B * world * args.steps / dt) / 1e9 / (HBM_PEAK_GBS * world), 5),
+                         "issue_limits_pmc": issue,
                          "kernels_ms_per_launch": {k: round(v, 4) for k, v in per_kernel.items()}},
         }
         if world == 1 and not args.no_cpu_baseline:
