@@ -194,3 +194,28 @@ def test_device_float_paths_wide_sweep():
     for i in range(0, len(deg), 997):
         ca, sb = po.cos_sin_deg(float(deg[i]))
         assert np.float32(ca).tobytes() == a[i].tobytes() and np.float32(sb).tobytes() == b[i].tobytes(), deg[i]
+
+
+def test_device_batch_with_unaligned_strides_and_base():
+    """orbx_extract_batch_device on frames whose row stride / base address are not multiples of 4: every kernel's
+    byte-staging path (resize, FAST cells, blur, descriptor patches) instead of the aligned dword path."""
+    import torch
+    from orb_slam3_modified_amd.replay import BlockLayout, unpack_block
+    dev = torch.device("cuda", 0)
+    frames = synth.make_stream(3, 240, 322)                      # 322-px rows inside a 327-byte pitch, base offset 1
+    B, H, W = frames.shape
+    pitch = 327
+    buf = torch.zeros(B * H * pitch + 8, dtype=torch.uint8, device=dev)
+    view = buf[1:1 + B * H * pitch].view(B, H, pitch)
+    view[:, :, :W] = torch.from_numpy(frames).to(dev)
+    gpu = ORBextractor(600, 1.2, 5, 20, 7)
+    lo = BlockLayout(B, gpu.capacity)
+    blk = torch.zeros(lo.nbytes, dtype=torch.uint8, device=dev)
+    base = blk.data_ptr()
+    assert view.data_ptr() % 4 == 1 and pitch % 4 != 0
+    gpu.extract_batch_device(view.data_ptr(), B, H, W, pitch, H * pitch, base, base + lo.desc_off, base + lo.counts_off, (0, 1000))
+    torch.cuda.synchronize()
+    res = unpack_block(blk.cpu().numpy(), lo)
+    ora = po.OracleExtractor(600, 1.2, 5, 20, 7)
+    for f in range(B):
+        assert_same(res[f], ora.extract(frames[f], (0, 1000)), f"unaligned f{f}")
