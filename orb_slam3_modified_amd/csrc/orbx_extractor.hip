@@ -275,6 +275,38 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
   uint32_t* const b_lvl_kp = ctx->d_lvl_kp + (size_t)f0 * geo.kp_total;
   int32_t* const b_lvl_n = ctx->d_lvl_n + (size_t)f0 * geo.nlevels;
   uint2* const b_kp_list = ctx->d_kp_list + (size_t)f0 * ctx->out_cap;
+  // K2 (level 0): FAST over the cells of level 0 only needs the input image, so it is forked onto a second stream and
+  // runs concurrently with the (latency-bound) pyramid chain; joined before the quadtree.  Off by default (ORBX_FORK_FAST0=1 enables): measured no gain, both kernels fill the CUs.
+  const int need = geo.max_cell_w + 3;  // +3: alignment shift of the dword-staged rows
+  const int pitchB = need <= 64 ? 64 : 96;
+  const int tile_rows = geo.max_cell_h;
+  const int list_cap = round_up((geo.max_cell_w - 6) * (geo.max_cell_h - 6), 8);
+  if (need > 96 || geo.max_cell_h > 127 + 6 || list_cap > 8192)
+    return set_err(ctx, ORBX_E_CAPACITY, "FAST cell larger than the kernel's LDS tile");
+  if (!div_ok((uint64_t)geo.cells.size() * nframes + 8, geo.cells.size()) ||
+      !div_ok((uint64_t)geo.btiles_total * nframes + 8, geo.btiles_total))
+    return set_err(ctx, ORBX_E_CAPACITY, "batch too large for 32-bit tile indexing");
+  const size_t fast_lds = 16 + (size_t)pitchB * tile_rows * 2 + (size_t)list_cap * 2;
+  const int ft = ctx->fast_threads;
+  auto fast_kern = pitchB == 64 ? (ft == 64 ? k_fast_cells<64, 64> : ft == 128 ? k_fast_cells<128, 64> : k_fast_cells<256, 64>)
+                                : (ft == 64 ? k_fast_cells<64, 96> : ft == 128 ? k_fast_cells<128, 96> : k_fast_cells<256, 96>);
+  auto launch_fast = [&](int cell_base, int ncells_sub, hipStream_t s) {
+    const int nitems = ncells_sub * nframes;
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL(fast_kern, dim3(xcd_grid(nitems)), dim3(ft), fast_lds, s, ctx->d_geo, ctx->d_cells, d_imgs,
+                       (long long)row_stride, (long long)frame_stride, b_pyr, (long long)geo.pyr_bytes, b_cand, b_cell_cnt,
+                       ctx->ini_th, ctx->min_th, tile_rows, nitems, cell_base, ncells_sub, div_magic((uint32_t)ncells_sub));
+  };
+  const int ncells0 = geo.lv[0].ncells, ncells_all = (int)geo.cells.size();
+  const bool fork_fast0 = ctx->fork_fast0 && !ctx->profiling && geo.nlevels > 1;
+  const int sb = f0 != 0;  // sub-batch slot of the fork events / streams
+  if (fork_fast0) {
+    hipStream_t fst = ctx->aux[orbx_ctx::kMaxAux - 3 - sb];
+    ORBX_HIP(ctx, hipEventRecord(ctx->ev_f0_fork[sb], st));
+    ORBX_HIP(ctx, hipStreamWaitEvent(fst, ctx->ev_f0_fork[sb], 0));
+    launch_fast(0, ncells0, fst);
+    ORBX_HIP(ctx, hipEventRecord(ctx->ev_f0_join[sb], fst));
+  }
   // K1: pyramid chain (levels depend on each other: one launch per level over the whole batch)
   {
     ProfScope ps(ctx, 0, st);
@@ -288,30 +320,15 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
       hipLaunchKernelGGL(k_resize, dim3(xcd_grid(nitems)), dim3(256), (size_t)D.rs_lds_pitch * D.rs_lds_rows, st, src, sfs, sp,
                          S.w, b_pyr + D.plane_off, (long long)geo.pyr_bytes, D.pitch, D.w, D.h, ctx->d_xtab + D.xtab_off,
                          ctx->d_ytab + D.ytab_off, nbx, nby, nitems, D.rs_lds_pitch, D.rs_lds_rows,
-                         div_magic((uint32_t)(nbx * nby)), div_magic((uint32_t)nbx),
-                         div_magic((uint32_t)(D.rs_lds_pitch / 4)));
+                         div_magic((uint32_t)(nbx * nby)), div_magic((uint32_t)nbx), div_magic((uint32_t)(D.rs_lds_pitch / 4)));
       if (!div_ok((uint64_t)nitems + 8, (uint64_t)nbx * nby)) return set_err(ctx, ORBX_E_CAPACITY, "batch too large for 32-bit tile indexing");
     }
   }
-  // K2: FAST cells
+  // K2: FAST cells of the remaining levels (or of all levels when level 0 is not forked)
   {
     ProfScope ps(ctx, 1, st);
-    const int need = geo.max_cell_w + 3;  // +3: alignment shift of the dword-staged rows
-    const int pitchB = need <= 64 ? 64 : 96;
-    const int tile_rows = geo.max_cell_h;
-    const int list_cap = round_up((geo.max_cell_w - 6) * (geo.max_cell_h - 6), 8);
-    if (need > 96 || geo.max_cell_h > 127 + 6 || list_cap > 8192)
-      return set_err(ctx, ORBX_E_CAPACITY, "FAST cell larger than the kernel's LDS tile");
-    const size_t lds = 16 + (size_t)pitchB * tile_rows * 2 + (size_t)list_cap * 2;
-    const int nitems = (int)geo.cells.size() * nframes;
-    const int ft = ctx->fast_threads;
-    auto kern = pitchB == 64 ? (ft == 64 ? k_fast_cells<64, 64> : ft == 128 ? k_fast_cells<128, 64> : k_fast_cells<256, 64>)
-                             : (ft == 64 ? k_fast_cells<64, 96> : ft == 128 ? k_fast_cells<128, 96> : k_fast_cells<256, 96>);
-    hipLaunchKernelGGL(kern, dim3(xcd_grid(nitems)), dim3(ft), lds, st, ctx->d_geo, ctx->d_cells, d_imgs,
-                       (long long)row_stride, (long long)frame_stride, b_pyr, (long long)geo.pyr_bytes, b_cand,
-                       b_cell_cnt, ctx->ini_th, ctx->min_th, tile_rows, nitems);
-    if (!div_ok((uint64_t)nitems + 8, geo.cells.size()) || !div_ok((uint64_t)geo.btiles_total * nframes + 8, geo.btiles_total))
-      return set_err(ctx, ORBX_E_CAPACITY, "batch too large for 32-bit tile indexing");
+    if (fork_fast0) launch_fast(ncells0, ncells_all - ncells0, st);
+    else launch_fast(0, ncells_all, st);
   }
   // K4a: 7x7 fixed-point Gaussian of every level (the reference blurs each level that holds keypoints).  It only needs
   // the pyramid, and it is VALU-bound while the quadtree that follows FAST is latency-bound with few workgroups, so it
@@ -340,6 +357,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
   }
   if (fork_blur) ORBX_HIP(ctx, hipEventRecord(ctx->ev_blur_join[f0 != 0], bst));
   // K3: quadtree
+  if (fork_fast0) ORBX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_f0_join[sb], 0));
   {
     ProfScope ps(ctx, 2, st);
     const int node_cap = round_up(geo.max_quota + 4 * kMaxRoots + 8, 4);
@@ -450,10 +468,14 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, 
     ctx->nstreams = std::min(std::max(v, 1), 2);  // the blur fork owns the last two aux streams
     const char* fb = getenv("ORBX_FORK_BLUR");
     ctx->fork_blur = fb ? atoi(fb) != 0 : true;
+    const char* ff = getenv("ORBX_FORK_FAST0");
+    ctx->fork_fast0 = ff ? atoi(ff) != 0 : false;  // measured: no gain (both kernels already fill the CUs), kept as a knob
     bool ok = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < 2 && ok; i++)
       ok = hipEventCreateWithFlags(&ctx->ev_blur_fork[i], hipEventDisableTiming) == hipSuccess &&
-           hipEventCreateWithFlags(&ctx->ev_blur_join[i], hipEventDisableTiming) == hipSuccess;
+           hipEventCreateWithFlags(&ctx->ev_blur_join[i], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&ctx->ev_f0_fork[i], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&ctx->ev_f0_join[i], hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < orbx_ctx::kMaxAux && ok; i++)
       ok = hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking) == hipSuccess &&
            hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming) == hipSuccess;
@@ -478,6 +500,8 @@ void orbx_destroy(orbx_ctx* ctx) {
   for (int i = 0; i < 2; i++) {
     if (ctx->ev_blur_fork[i]) (void)hipEventDestroy(ctx->ev_blur_fork[i]);
     if (ctx->ev_blur_join[i]) (void)hipEventDestroy(ctx->ev_blur_join[i]);
+    if (ctx->ev_f0_fork[i]) (void)hipEventDestroy(ctx->ev_f0_fork[i]);
+    if (ctx->ev_f0_join[i]) (void)hipEventDestroy(ctx->ev_f0_join[i]);
   }
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;

@@ -98,7 +98,8 @@ struct orbx_ctx {
   hipEvent_t ev_fork = nullptr, ev_join[kMaxAux] = {nullptr};
   hipEvent_t ev_blur_fork[2] = {nullptr, nullptr}, ev_blur_join[2] = {nullptr, nullptr};
   int nstreams = 1;
-  bool fork_blur = true;
+  hipEvent_t ev_f0_fork[2] = {nullptr, nullptr}, ev_f0_join[2] = {nullptr, nullptr};
+  bool fork_blur = true, fork_fast0 = false;
   std::string err;
 
   // geometry + device buffers for the current (rows, cols, batch capacity)

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__
                                                   long long img_frame_stride, const uint8_t* __restrict__ pyr,
                                                   long long pyr_frame_bytes, uint32_t* __restrict__ cand,
                                                   int32_t* __restrict__ cell_cnt, int ini_th, int min_th, int tile_rows,
-                                                  int nitems) {
+                                                  int nitems, int cell_base, int ncells_sub, uint32_t m_ncells_sub) {
   // LDS: [16 B pad][tile_rows][PITCH] raw pixels (+ alignment shift xo) | [tile_rows][PITCH] scores with a 1-px
   // zero frame | list.  PITCH is a compile-time constant so every circle / neighbour access is an immediate offset.
   extern __shared__ __align__(16) uint8_t smem[];
@@ -184,7 +184,9 @@ __global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int L = xcd_logical_block(nitems);
   if (L < 0) return;  // block-uniform
-  const int frame = fast_div(L, g->m_ncells), cell = L - frame * g->ncells_total;
+  // this launch covers cells [cell_base, cell_base + ncells_sub) of every frame (level 0 runs as its own launch,
+  // concurrently with the pyramid chain)
+  const int frame = fast_div(L, m_ncells_sub), cell = cell_base + (L - frame * ncells_sub);
   const CellGeom cg = cells[cell];
   const DeviceLevel& lv = g->lv[cg.level];
   const uint8_t* img;
