@@ -491,7 +491,7 @@ void orbx_destroy(orbx_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   free_buffers(ctx);
   auto fr = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
-  fr(ctx->d_stage_img); fr(ctx->d_stage_kps); fr(ctx->d_stage_desc); fr(ctx->d_stage_counts);
+  fr(ctx->d_stage_img); fr(ctx->d_stage_kps); fr(ctx->d_stage_desc); fr(ctx->d_stage_counts); fr(ctx->d_knn_ws);
   for (int i = 0; i < orbx_ctx::kMaxAux; i++) {
     if (ctx->aux[i]) { (void)hipStreamSynchronize(ctx->aux[i]); (void)hipStreamDestroy(ctx->aux[i]); }
     if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);

@@ -121,6 +121,7 @@ struct orbx_ctx {
   uint8_t* d_stage_img = nullptr; size_t stage_img_bytes = 0;
   orbx_keypoint* d_stage_kps = nullptr; uint8_t* d_stage_desc = nullptr; int32_t* d_stage_counts = nullptr;
   int stage_frames = 0;
+  unsigned long long* d_knn_ws = nullptr; size_t knn_ws_bytes = 0;  // per-segment partial top-2 of orbx_knn2_allpairs*
   // last extraction (for orbx_pyramid_level / debug dumps)
   const uint8_t* last_imgs = nullptr; size_t last_row_stride = 0, last_frame_stride = 0; int last_nframes = 0;
   // profiling

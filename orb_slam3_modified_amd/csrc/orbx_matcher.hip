@@ -90,8 +90,8 @@ __global__ __launch_bounds__(256) void k_nn_csr(const uint8_t* __restrict__ q, i
   }
 }
 
-// All-pairs 2-NN (cv::BFMatcher(NORM_HAMMING).knnMatch(k=2), src/Frame.cc:1144): wave per query; the train
-// set is streamed through LDS in tiles shared by the block's 4 queries.
+// All-pairs 2-NN, small problems (the SLAM sizes, ~1000 x 1000, are launch-bound): wave per query, the train set is
+// streamed through LDS in tiles shared by the block's 4 queries; one launch.
 __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ tr, int nt,
                                               int32_t* __restrict__ idx, int32_t* __restrict__ dist) {
   __shared__ uint4 tile[256 * 2];  // 256 train descriptors
@@ -123,6 +123,68 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, int
     idx[qi * 2 + 1] = k2 == kNoKey ? -1 : (int32_t)(uint32_t)k2;
     dist[qi * 2 + 1] = k2 == kNoKey ? 256 : (int32_t)(k2 >> 32);
   }
+}
+
+// All-pairs 2-NN (cv::BFMatcher(NORM_HAMMING).knnMatch(k=2), src/Frame.cc:1144).  Large problems: VALU-bound formulation: every lane
+// owns ONE query (its 32 bytes live in 8 VGPRs) and the whole wave walks the same train descriptor, whose address is
+// wave-uniform, so it arrives through the scalar cache and is used as SGPR operands: per pair 8 xor + 8 accumulating
+// popcounts + the top-2 update, no LDS and no per-lane memory traffic.  The train set is cut into segments
+// (blockIdx.y) for parallelism; k_knn2_merge takes, per query, the two smallest (distance, train index) keys of the
+// per-segment partial results (ties -> lower train index, like a sequential scan).
+constexpr int kKnnSeg = 64;  // train descriptors per segment
+
+__device__ __forceinline__ void knn2_merge_query(const unsigned long long* part, int nq, int nseg, int qi, int32_t* idx, int32_t* dist) {
+  unsigned long long k1 = kNoKey, k2 = kNoKey;
+  for (int s = 0; s < nseg; s++) {
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const unsigned long long key = part[((size_t)s * nq + qi) * 2 + j];
+      const bool lt = key < k1;
+      const unsigned long long hi = lt ? k1 : key;
+      k1 = lt ? key : k1;
+      k2 = hi < k2 ? hi : k2;
+    }
+  }
+  idx[qi * 2] = k1 == kNoKey ? -1 : (int32_t)(uint32_t)k1;
+  dist[qi * 2] = k1 == kNoKey ? 256 : (int32_t)(k1 >> 32);
+  idx[qi * 2 + 1] = k2 == kNoKey ? -1 : (int32_t)(uint32_t)k2;
+  dist[qi * 2 + 1] = k2 == kNoKey ? 256 : (int32_t)(k2 >> 32);
+}
+
+__global__ __launch_bounds__(256) void k_knn2_partial(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ tr,
+                                                      int nt, unsigned long long* __restrict__ part) {
+  const int qi = blockIdx.x * 256 + threadIdx.x;
+  const int seg = blockIdx.y, t0 = seg * kKnnSeg, t1 = min(t0 + kKnnSeg, nt);
+  uint32_t a[8];
+  {
+    const uint4* qp = (const uint4*)(q + (size_t)min(qi, nq - 1) * 32);
+    const uint4 lo = qp[0], hi = qp[1];
+    a[0] = lo.x; a[1] = lo.y; a[2] = lo.z; a[3] = lo.w; a[4] = hi.x; a[5] = hi.y; a[6] = hi.z; a[7] = hi.w;
+  }
+  // 32-bit keys: distance (0..256) << 22 | train index (< 2^22): the top-2 update is three min/max instructions
+  uint32_t k1 = 0xffffffffu, k2 = 0xffffffffu;
+#pragma unroll 4
+  for (int t = t0; t < t1; t++) {
+    const uint32_t* tp = (const uint32_t*)(tr + (size_t)t * 32);  // wave-uniform address -> scalar loads
+    uint32_t d = 0;
+#pragma unroll
+    for (int w = 0; w < 8; w++) d += __popc(a[w] ^ tp[w]);
+    const uint32_t key = (d << 22) | (uint32_t)t;
+    const uint32_t hi = max(k1, key);
+    k1 = min(k1, key);
+    k2 = min(k2, hi);
+  }
+  if (qi < nq) {
+    auto widen = [](uint32_t k) { return k == 0xffffffffu ? kNoKey : (((unsigned long long)(k >> 22)) << 32) | (k & 0x3fffffu); };
+    part[((size_t)seg * nq + qi) * 2] = widen(k1);
+    part[((size_t)seg * nq + qi) * 2 + 1] = widen(k2);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_knn2_merge(const unsigned long long* __restrict__ part, int nq, int nseg,
+                                                    int32_t* __restrict__ idx, int32_t* __restrict__ dist) {
+  const int qi = blockIdx.x * 256 + threadIdx.x;
+  if (qi < nq) knn2_merge_query(part, nq, nseg, qi, idx, dist);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -328,7 +390,23 @@ int orbx_knn2_allpairs_device(orbx_ctx* ctx, const uint8_t* d_q, int nq, const u
   if (nq == 0) return ORBX_OK;
   ORBX_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
-  hipLaunchKernelGGL(k_knn2, dim3((nq + 3) / 4), dim3(256), 0, st, d_q, nq, d_t, nt, d_idx, d_dist);
+  if (nt <= 2048) {  // launch-bound sizes: one launch, wave per query
+    hipLaunchKernelGGL(k_knn2, dim3((nq + 3) / 4), dim3(256), 0, st, d_q, nq, d_t, nt, d_idx, d_dist);
+    ORBX_HIP(ctx, hipGetLastError());
+    return ORBX_OK;
+  }
+  const int nseg = std::max(1, (nt + kKnnSeg - 1) / kKnnSeg), nqb = (nq + 255) / 256;
+  if (nseg > 65535 || nt >= (1 << 22)) return set_err(ctx, ORBX_E_CAPACITY, "knn2: more than 4 M train descriptors");
+  const size_t need = (size_t)nseg * nq * 2 * sizeof(unsigned long long);
+  if (need > ctx->knn_ws_bytes) {  // grow-only workspace for the per-segment partial top-2
+    ORBX_HIP(ctx, hipStreamSynchronize(st));
+    if (ctx->d_knn_ws) (void)hipFree(ctx->d_knn_ws);
+    ctx->d_knn_ws = nullptr; ctx->knn_ws_bytes = 0;
+    ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_knn_ws, need));
+    ctx->knn_ws_bytes = need;
+  }
+  hipLaunchKernelGGL(k_knn2_partial, dim3(nqb, nseg), dim3(256), 0, st, d_q, nq, d_t, nt, ctx->d_knn_ws);
+  hipLaunchKernelGGL(k_knn2_merge, dim3(nqb), dim3(256), 0, st, ctx->d_knn_ws, nq, nseg, d_idx, d_dist);
   ORBX_HIP(ctx, hipGetLastError());
   return ORBX_OK;
 }

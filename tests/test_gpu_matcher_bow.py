@@ -101,3 +101,17 @@ def test_vocabulary_loader_rejects_garbage(feats, tmp_path):
     good.write_text("2 1 0 0\n0 1 " + " ".join(["0"] * 32) + " 1.5\n0 1 " + " ".join(["255"] * 32) + " 2.5\n\n")  # trailing blank lines
     v = ORBVocabulary(gpu)
     assert v.loadFromTextFile(str(good)) and v.info()["words"] == 2   # no phantom node
+
+
+def test_knn2_large_train_set_segment_path(feats):
+    """nt > 2048 takes the query-in-registers / segmented path (partial top-2 per 64-train segment + merge)."""
+    gpu, out = feats
+    m = ORBmatcher(gpu)
+    rng = np.random.default_rng(4)
+    base = np.concatenate([o[2] for o in out])
+    t = base[rng.integers(0, len(base), 5000)] ^ (rng.random((5000, 32)) < 0.05).astype(np.uint8) * rng.integers(0, 256, (5000, 32)).astype(np.uint8)
+    t[100:140] = t[60:100]                       # exact duplicates: ties must resolve to the lower train index
+    q = base[:777]
+    gi, gd = m.knn2(q, t)
+    oi, od = po.knn2(q, t)
+    assert np.array_equal(gi, oi) and np.array_equal(gd, od)
