@@ -122,7 +122,7 @@ def main():
     idx = np.arange(B) % uniq
     frames = torch.from_numpy(host_frames[idx]).to(dev)
     ex = ORBextractor(args.nfeatures, 1.2, 8, 20, 7, device_id=local_rank)
-    eng = ReplayEngine(ex, frames, lapping=(0, 1000), gather=not args.no_gather)
+    eng = ReplayEngine(ex, frames, lapping=(0, 1000), gather=(world > 1 and not args.no_gather))
 
     def sync_all():
         torch.cuda.synchronize()

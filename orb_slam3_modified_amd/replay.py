@@ -70,7 +70,7 @@ class ReplayEngine:
         self.lap = lapping
         self.layout = BlockLayout(self.B, extractor.capacity)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.gather = gather and self.world > 1
+        self.gather = gather and dist.is_initialized()   # a 1-rank group still exercises the collective path (tests)
         self.pg = process_group
         dev = frames_dev.device
         self.blocks = [torch.zeros(self.layout.nbytes, dtype=torch.uint8, device=dev) for _ in range(2)]
@@ -78,29 +78,36 @@ class ReplayEngine:
                          for _ in range(2)]
         self.pending = [None, None]
         self.step_idx = 0
+        # One explicit (non-default) stream carries the kernels AND orders the collective behind them: the default
+        # stream's handle is NULL, which the C ABI reads as "use the context's own stream" — invisible to torch/RCCL.
+        self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
 
     def step(self):
         """One pass of the hot path over this rank's batch (+ async all-gather of the resulting block)."""
         torch = self.torch
         i = self.step_idx & 1
-        if self.pending[i] is not None:  # the gather that last read this buffer must be done before we overwrite it
-            self.pending[i].wait()
-            self.pending[i] = None
         blk = self.blocks[i]
         base = blk.data_ptr()
-        st = torch.cuda.current_stream().cuda_stream
-        self.ex.extract_batch_device(self.frames.data_ptr(), self.B, self.H, self.W, self.frames.stride(1), self.frames.stride(0),
-                                     base, base + self.layout.desc_off, base + self.layout.counts_off, self.lap, st)
-        if self.gather:
-            self.pending[i] = self.dist.all_gather_into_tensor(self.gathered[i], blk, group=self.pg, async_op=True)
+        with torch.cuda.stream(self.stream):
+            if self.pending[i] is not None:  # the gather that last read this buffer must be done before we overwrite it
+                self.pending[i].wait()       # (makes self.stream wait for the collective)
+                self.pending[i] = None
+            self.ex.extract_batch_device(self.frames.data_ptr(), self.B, self.H, self.W, self.frames.stride(1), self.frames.stride(0),
+                                         base, base + self.layout.desc_off, base + self.layout.counts_off, self.lap,
+                                         self.stream.cuda_stream)
+            if self.gather:  # enqueued behind the kernels of this step (same stream), overlaps the next step's kernels
+                self.pending[i] = self.dist.all_gather_into_tensor(self.gathered[i], blk, group=self.pg, async_op=True)
         self.step_idx += 1
         return i
 
     def drain(self):
-        for i in (0, 1):
-            if self.pending[i] is not None:
-                self.pending[i].wait()
-                self.pending[i] = None
+        with self.torch.cuda.stream(self.stream):
+            for i in (0, 1):
+                if self.pending[i] is not None:
+                    self.pending[i].wait()
+                    self.pending[i] = None
+        if self.stream is not None:
+            self.stream.synchronize()
 
     def counts(self, i: int):
         lo = self.layout
