@@ -307,8 +307,18 @@ __global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__
     }
   }
   __syncthreads();
-  // ---- F: exclusive popcount prefix over the bitmap words (thread t <-> words t*WPT ..)
-  {
+  // ---- F: exclusive popcount prefix over the bitmap words
+  const int npx = dw * dh;
+  if (npx <= 2048) {  // block-uniform; the usual case: <= 64 words, one wave scans them, the others go straight on
+    if (wv == 0) {
+      const int c = __popc(bitmap[lane]);  // words beyond the cell are zero
+      int inc = c;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+      wpre[lane] = inc - c;
+      if (lane == 63) cell_cnt[(long long)frame * g->ncells_total + cell] = inc;
+    }
+  } else {  // thread t <-> words t*WPT ..
     int cw_[WPT], c = 0;
 #pragma unroll
     for (int k = 0; k < WPT; k++) { cw_[k] = __popc(bitmap[t * WPT + k]); c += cw_[k]; }
