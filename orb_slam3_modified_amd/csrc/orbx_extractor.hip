@@ -16,7 +16,8 @@ namespace orbx {
 
 // Workgroup size of k_fast_cells: 128 by default (measured best); ORBX_FAST_THREADS=64|128|256 in the environment overrides it
 // (tuning knob, read once per context).
-constexpr int kQtLdsPoints = 2048;  // LDS-resident candidate capacity per (frame, level) of k_quadtree
+constexpr int kQtLdsPoints = 2048;  // LDS-resident candidate capacity per (frame, level) of k_quadtree (big levels)
+constexpr int kQtBigLevels = 2;     // levels launched with the large quadtree workgroup configuration
 
 static int fast_threads_from_env() {
   const char* e = getenv("ORBX_FAST_THREADS");
@@ -360,20 +361,43 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
   if (fork_fast0) ORBX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_f0_join[sb], 0));
   {
     ProfScope ps(ctx, 2, st);
-    const int node_cap = round_up(geo.max_quota + 4 * kMaxRoots + 8, 4);
-    const int scan_cap = round_up(std::max(node_cap, geo.max_cells_per_level) + 8, 4);
-    if (node_cap > 4095) return set_err(ctx, ORBX_E_CAPACITY, "nfeatures too large for the quadtree kernel");
-    // candidates of one (frame, level) live in LDS when they fit kQtLdsPoints (two ping-pong buffers), else in HBM
-    const int pts_cap = kQtLdsPoints;
-    const size_t lds = (size_t)node_cap * (2 * sizeof(QNode) + 2 * 8 + sizeof(int4) + 4) + (size_t)scan_cap * 8 +
-                       (size_t)pts_cap * 2 * sizeof(uint32_t);
-    if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute((const void*)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return set_err(ctx, ORBX_E_CAPACITY, "nfeatures too large for the quadtree kernel's LDS");
+    // The workgroup of (frame, level) is sized by the level's quota; one LDS size for all levels would let the big
+    // levels halve the residency of the small ones, so the levels run as two launches: the first kQtBigLevels levels
+    // (large quota, LDS points for 2048 candidates) and the rest (small node arrays, 1024 LDS points), the second one
+    // forked onto an aux stream so both fill the CUs together.  Candidates beyond the LDS capacity use HBM buffers.
+    auto launch_qt = [&](int l0, int l1, int pts_cap, hipStream_t s) -> int {
+      int mq = 1, mc = 1;
+      for (int l = l0; l < l1; l++) { mq = std::max(mq, geo.lv[l].quota); mc = std::max(mc, geo.lv[l].ncells); }
+      const int node_cap = round_up(mq + 4 * kMaxRoots + 8, 4);
+      const int scan_cap = round_up(std::max(node_cap, mc) + 8, 4);
+      if (node_cap > 4095) return set_err(ctx, ORBX_E_CAPACITY, "nfeatures too large for the quadtree kernel");
+      const size_t lds = (size_t)node_cap * (2 * sizeof(QNode) + 2 * 8 + sizeof(int4) + 4) + (size_t)scan_cap * 8 +
+                         (size_t)pts_cap * 2 * sizeof(uint32_t);
+      if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return set_err(ctx, ORBX_E_CAPACITY, "nfeatures too large for the quadtree kernel's LDS");
+      }
+      hipLaunchKernelGGL(k_quadtree, dim3(l1 - l0, nframes, 1), dim3(256), lds, s, ctx->d_geo, ctx->d_cells, b_cand, b_cell_cnt,
+                         b_pts, b_lvl_kp, b_lvl_n, node_cap, scan_cap, pts_cap, l0);
+      return ORBX_OK;
+    };
+    const int nbig = geo.nlevels >= 4 ? kQtBigLevels : geo.nlevels;
+    int qrc = ORBX_OK;
+    if (nbig < geo.nlevels && !ctx->profiling) {
+      hipStream_t qst = ctx->aux[orbx_ctx::kMaxAux - 5 - sb];
+      ORBX_HIP(ctx, hipEventRecord(ctx->ev_qt_fork[sb], st));
+      ORBX_HIP(ctx, hipStreamWaitEvent(qst, ctx->ev_qt_fork[sb], 0));
+      qrc = launch_qt(nbig, geo.nlevels, kQtLdsPoints / 2, qst);
+      if (qrc != ORBX_OK) return qrc;
+      ORBX_HIP(ctx, hipEventRecord(ctx->ev_qt_join[sb], qst));
+      qrc = launch_qt(0, nbig, kQtLdsPoints, st);
+      if (qrc != ORBX_OK) return qrc;
+      ORBX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_qt_join[sb], 0));
+    } else {
+      qrc = launch_qt(0, nbig, kQtLdsPoints, st);
+      if (qrc != ORBX_OK) return qrc;
+      if (nbig < geo.nlevels) { qrc = launch_qt(nbig, geo.nlevels, kQtLdsPoints / 2, st); if (qrc != ORBX_OK) return qrc; }
     }
-    dim3 grid(geo.nlevels, nframes, 1);
-    hipLaunchKernelGGL(k_quadtree, grid, dim3(256), lds, st, ctx->d_geo, ctx->d_cells, b_cand, b_cell_cnt,
-                       b_pts, b_lvl_kp, b_lvl_n, node_cap, scan_cap, pts_cap);
   }
   // K3b: output slots
   {
@@ -474,6 +498,8 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, 
     for (int i = 0; i < 2 && ok; i++)
       ok = hipEventCreateWithFlags(&ctx->ev_blur_fork[i], hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&ctx->ev_blur_join[i], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&ctx->ev_qt_fork[i], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&ctx->ev_qt_join[i], hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&ctx->ev_f0_fork[i], hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&ctx->ev_f0_join[i], hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < orbx_ctx::kMaxAux && ok; i++)
@@ -501,6 +527,8 @@ void orbx_destroy(orbx_ctx* ctx) {
     if (ctx->ev_blur_fork[i]) (void)hipEventDestroy(ctx->ev_blur_fork[i]);
     if (ctx->ev_blur_join[i]) (void)hipEventDestroy(ctx->ev_blur_join[i]);
     if (ctx->ev_f0_fork[i]) (void)hipEventDestroy(ctx->ev_f0_fork[i]);
+    if (ctx->ev_qt_fork[i]) (void)hipEventDestroy(ctx->ev_qt_fork[i]);
+    if (ctx->ev_qt_join[i]) (void)hipEventDestroy(ctx->ev_qt_join[i]);
     if (ctx->ev_f0_join[i]) (void)hipEventDestroy(ctx->ev_f0_join[i]);
   }
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -99,6 +99,7 @@ struct orbx_ctx {
   hipEvent_t ev_blur_fork[2] = {nullptr, nullptr}, ev_blur_join[2] = {nullptr, nullptr};
   int nstreams = 1;
   hipEvent_t ev_f0_fork[2] = {nullptr, nullptr}, ev_f0_join[2] = {nullptr, nullptr};
+  hipEvent_t ev_qt_fork[2] = {nullptr, nullptr}, ev_qt_join[2] = {nullptr, nullptr};
   bool fork_blur = true, fork_fast0 = false;
   std::string err;
 

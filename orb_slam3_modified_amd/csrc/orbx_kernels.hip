@@ -566,7 +566,7 @@ __device__ __forceinline__ void quadtree_body(const DeviceGeom* __restrict__ g, 
                                               const uint32_t* __restrict__ fcand, uint32_t* gcur, uint32_t* gnxt,
                                               uint32_t* lcur, uint32_t* lnxt, uint32_t* __restrict__ lvl_kp,
                                               int32_t* __restrict__ lvl_n, int node_cap, int scan_cap, uint8_t* smem, int n,
-                                              unsigned long long* wt, int* sh_cnt, int* sh_jstar_p) {
+                                              unsigned long long* wt, int* sh_cnt, int* sh_jstar_p, int level_base) {
   uint32_t* cur = LP ? lcur : gcur;
   uint32_t* nxt = LP ? lnxt : gnxt;
   QNode* LA = (QNode*)smem;
@@ -579,7 +579,7 @@ __device__ __forceinline__ void quadtree_body(const DeviceGeom* __restrict__ g, 
   int& sh_jstar = *sh_jstar_p;
 
   const int T = blockDim.x, t = threadIdx.x, lane = t & 63, w = t >> 6, NW = T >> 6;
-  const int level = blockIdx.x, frame = blockIdx.y;
+  const int level = level_base + blockIdx.x, frame = blockIdx.y;
   const DeviceLevel& lv = g->lv[level];
   const int N = lv.quota;
   QT_T0();
@@ -808,7 +808,7 @@ __device__ __forceinline__ void quadtree_body(const DeviceGeom* __restrict__ g, 
 __global__ __launch_bounds__(256) void k_quadtree(const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
                                                   const uint32_t* __restrict__ cand, const int32_t* __restrict__ cell_cnt,
                                                   uint32_t* __restrict__ pts, uint32_t* __restrict__ lvl_kp,
-                                                  int32_t* __restrict__ lvl_n, int node_cap, int scan_cap, int pts_cap) {
+                                                  int32_t* __restrict__ lvl_n, int node_cap, int scan_cap, int pts_cap, int level_base) {
   extern __shared__ __align__(16) uint8_t smem[];
   __shared__ unsigned long long wt[8];
   __shared__ int sh_cnt[kMaxRoots];
@@ -817,7 +817,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const DeviceGeom* __restrict__
   unsigned long long* scan = (unsigned long long*)(smem + (size_t)node_cap * (2 * sizeof(QNode) + 2 * 8));
   uint32_t* lpts = (uint32_t*)(smem + (size_t)node_cap * (2 * sizeof(QNode) + 2 * 8 + sizeof(int4) + 4) + (size_t)scan_cap * 8);
   const int T = blockDim.x, t = threadIdx.x;
-  const int level = blockIdx.x, frame = blockIdx.y;
+  const int level = level_base + blockIdx.x, frame = blockIdx.y;
   const DeviceLevel& lv = g->lv[level];
   uint32_t* gcur = pts + ((long long)frame * 2 + 0) * g->cand_total + lv.cand_off;
   uint32_t* gnxt = pts + ((long long)frame * 2 + 1) * g->cand_total + lv.cand_off;
@@ -831,9 +831,9 @@ __global__ __launch_bounds__(256) void k_quadtree(const DeviceGeom* __restrict__
     return;
   }
   if (n <= pts_cap)
-    quadtree_body<true>(g, cells, fcand, gcur, gnxt, lpts, lpts + pts_cap, lvl_kp, lvl_n, node_cap, scan_cap, smem, n, wt, sh_cnt, &sh_jstar);
+    quadtree_body<true>(g, cells, fcand, gcur, gnxt, lpts, lpts + pts_cap, lvl_kp, lvl_n, node_cap, scan_cap, smem, n, wt, sh_cnt, &sh_jstar, level_base);
   else
-    quadtree_body<false>(g, cells, fcand, gcur, gnxt, lpts, lpts + pts_cap, lvl_kp, lvl_n, node_cap, scan_cap, smem, n, wt, sh_cnt, &sh_jstar);
+    quadtree_body<false>(g, cells, fcand, gcur, gnxt, lpts, lpts + pts_cap, lvl_kp, lvl_n, node_cap, scan_cap, smem, n, wt, sh_cnt, &sh_jstar, level_base);
 }
 
 // ------------------------------------------------------------------------------------------------
