@@ -559,6 +559,8 @@ int orbx_extract_batch_device(orbx_ctx* ctx, const uint8_t* d_imgs, int nframes,
   if (!d_imgs || rows <= 0 || cols <= 0 || nframes <= 0) return set_err(ctx, ORBX_E_EMPTY, "empty image");
   if (!d_kps || !d_desc || !d_counts || row_stride < (size_t)cols || nframes > 65535)
     return set_err(ctx, ORBX_E_INVALID, "bad batch arguments");
+  if (row_stride >= (1u << 23) || (unsigned long long)row_stride * (unsigned long long)rows >= (1ull << 31))
+    return set_err(ctx, ORBX_E_INVALID, "row stride / frame size beyond the kernels' 32-bit in-frame offsets");
   ORBX_HIP(ctx, hipSetDevice(ctx->device));
   int rc = ensure_buffers(ctx, rows, cols, nframes);
   if (rc != ORBX_OK) return rc;

@@ -27,6 +27,14 @@ __constant__ __align__(16) int8_t c_pattern[1024] = {
 // host (0 encodes d == 1); exact while n * d < 2^32 (checked on the host for every use).
 __device__ __forceinline__ int fast_div(int n, uint32_t M) { return M ? (int)__umulhi((uint32_t)n, M) : n; }
 
+// Full-rate 24-bit multiply, pinned with inline asm: the compiler re-widens __mul24 to the quarter-rate v_mul_lo_u32
+// whenever it cannot prove the operand ranges itself.  Both operands must fit 24 signed bits.
+__device__ __forceinline__ int mul_i24(int a, int b) {
+  int r;
+  asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // XCD-aware block order.  Workgroup b of a 1-D grid runs on XCD b % 8 (observed dispatch rule, used for speed only)
 // and every XCD has its own 4 MiB L2, so neighbouring tiles / cells of one frame should share an XCD: the grid is
 // padded to 8*chunk blocks and block b works on logical item (b % 8) * chunk + b / 8, i.e. XCD k owns the contiguous
@@ -74,7 +82,7 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
     const int lp4 = lds_pitch >> 2, swr = (sw + 3) & ~3;
     for (int i = t; i < nrows * lp4; i += 256) {
       const int r = fast_div(i, m_lp4), c = i - r * lp4;
-      if (X0 + 4 * c < swr) ((uint32_t*)smem)[i] = *(const uint32_t*)(S + (long long)r * src_pitch + 4 * c);
+      if (X0 + 4 * c < swr) ((uint32_t*)smem)[i] = *(const uint32_t*)(S + (uint32_t)(__mul24(r, src_pitch) + 4 * c));
     }
   } else {
 #pragma unroll 1  // cold path: keep it out of the register budget
@@ -97,24 +105,26 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
   int c0[4], c1[4], a0[4], a1[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) { c0[i] = (int)tx[i].s0 - X0; c1[i] = (int)tx[i].s1 - X0; a0[i] = tx[i].a0; a1[i] = tx[i].a1; }
-  uint8_t* out = dst + (long long)frame * dst_frame_stride + (long long)dy0 * dst_pitch + x4;
+  uint8_t* outp = dst + (long long)frame * dst_frame_stride;  // uniform; per-lane offsets stay 32-bit (plane < 2^31 bytes)
 #pragma unroll
   for (int rr = 0; rr < kRT_RPT; rr++) {
     const int dy = dy0 + rr;
     if (dy < dh) {
       const XTab ty = yt[dy];
-      const uint8_t* R0 = smem + ((int)ty.s0 - Y0) * lds_pitch;
-      const uint8_t* R1 = smem + ((int)ty.s1 - Y0) * lds_pitch;
+      const uint8_t* R0 = smem + __mul24((int)ty.s0 - Y0, lds_pitch);
+      const uint8_t* R1 = smem + __mul24((int)ty.s1 - Y0, lds_pitch);
       const int b0 = ty.a0, b1 = ty.a1;
       uint32_t packed = 0;
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        const int h0 = R0[c0[i]] * a0[i] + R0[c1[i]] * a1[i];
-        const int h1 = R1[c0[i]] * a0[i] + R1[c1[i]] * a1[i];
-        const int v = ((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xff;
+        // every factor fits 24 bits (bytes, 12-bit weights, h >> 4 < 2^15): full-rate v_mul/mad_i32_i24, not the
+        // quarter-rate 32-bit multiply
+        const int h0 = __mul24((int)R0[c0[i]], a0[i]) + __mul24((int)R0[c1[i]], a1[i]);
+        const int h1 = __mul24((int)R1[c0[i]], a0[i]) + __mul24((int)R1[c1[i]], a1[i]);
+        const int v = (((mul_i24(b0, h0 >> 4) >> 16) + (mul_i24(b1, h1 >> 4) >> 16) + 2) >> 2) & 0xff;
         packed |= (uint32_t)v << (8 * i);
       }
-      *(uint32_t*)(out + (long long)rr * dst_pitch) = packed;
+      *(uint32_t*)(outp + (uint32_t)(__mul24(dy, dst_pitch) + x4)) = packed;
     }
   }
 }
@@ -190,8 +200,8 @@ __global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__
   const CellGeom cg = cells[cell];
   const DeviceLevel& lv = g->lv[cg.level];
   const uint8_t* img;
-  long long pitch;
-  if (cg.level == 0) { img = imgs + (long long)frame * img_frame_stride; pitch = img_row_stride; }
+  int pitch;  // < 2^23 (checked on the host): row offsets are 24-bit multiplies
+  if (cg.level == 0) { img = imgs + (long long)frame * img_frame_stride; pitch = (int)img_row_stride; }
   else { img = pyr + (long long)frame * pyr_frame_bytes + lv.plane_off; pitch = lv.pitch; }
   const int cw = cg.cw, ch = cg.ch, dw = cw - 6, dh = ch - 6;
   // ---- A: stage the sub-image with aligned dword loads when the source allows it
@@ -202,7 +212,7 @@ __global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__
     const int ndw = (xo + cw + 3) >> 2;
     for (int r = t >> 4; r < ch; r += T / 16)
       for (int c = t & 15; c < ndw; c += 16)
-        ((uint32_t*)tile)[r * P4 + c] = *(const uint32_t*)(src + (long long)r * pitch + 4 * c);
+        ((uint32_t*)tile)[r * P4 + c] = *(const uint32_t*)(src + (uint32_t)(__mul24(r, pitch) + 4 * c));
   } else {
     const uint8_t* src = img + (long long)cg.y0 * pitch + cg.x0;
 #pragma unroll 1  // cold path: keep it out of the register budget
@@ -942,8 +952,8 @@ __global__ __launch_bounds__(256) void k_blur7(const DeviceGeom* __restrict__ g,
   const int ty = fast_div(tile, lv.m_btiles_x), tx = tile - ty * lv.btiles_x;
   const int x0 = tx * kBT_W, y0 = ty * kBT_H;
   const uint8_t* img;
-  long long pitch;
-  if (l == 0) { img = imgs + (long long)frame * img_frame_stride; pitch = img_row_stride; }
+  int pitch;  // < 2^23 (checked on the host)
+  if (l == 0) { img = imgs + (long long)frame * img_frame_stride; pitch = (int)img_row_stride; }
   else { img = pyr + (long long)frame * pyr_frame_bytes + lv.plane_off; pitch = lv.pitch; }
   const int w = lv.w, h = lv.h;
   // raw[r][c] = level(reflect(y0-3+r), reflect(x0-4+c)), c = 0..71
@@ -960,7 +970,7 @@ __global__ __launch_bounds__(256) void k_blur7(const DeviceGeom* __restrict__ g,
       sy = sy < 0 ? -sy : (sy >= h ? 2 * h - 2 - sy : sy);
       sy = max(sy, 0);
       uint32_t v = 0;
-      if (sx >= 0 && sx < w) v = *(const uint32_t*)(img + (long long)sy * pitch + sx);
+      if (sx >= 0 && sx < w) v = *(const uint32_t*)(img + (uint32_t)(__mul24(sy, pitch) + sx));
       ((uint32_t*)raw)[r * (kBT_RP / 4) + c] = v;
     }
     const bool left = x0 == 0, right = x0 + kBT_W + 3 > w;  // block-uniform
@@ -1019,8 +1029,9 @@ __global__ __launch_bounds__(256) void k_blur7(const DeviceGeom* __restrict__ g,
     }
     const uint32_t pe = (e[0] >> 16) | ((e[1] >> 16) << 8) | ((e[2] >> 16) << 16) | ((e[3] >> 16) << 24);
     const uint32_t po = (o[0] >> 16) | ((o[1] >> 16) << 8) | ((o[2] >> 16) << 16) | ((o[3] >> 16) << 24);
-    *(uint32_t*)(bl + (long long)y * lv.pitch + x) = pe;
-    if (y + 1 < h) *(uint32_t*)(bl + (long long)(y + 1) * lv.pitch + x) = po;
+    const uint32_t o0 = (uint32_t)(__mul24(y, lv.pitch) + x);
+    *(uint32_t*)(bl + o0) = pe;
+    if (y + 1 < h) *(uint32_t*)(bl + o0 + (uint32_t)lv.pitch) = po;
   }
 }
 
@@ -1105,15 +1116,15 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
     const DeviceLevel& lv = g->lv[l];
     const int kx = pt_x(p), ky = pt_y(p);
     const uint8_t* img;
-    long long pitch;
+    int pitch;  // < 2^23 (checked on the host)
     bool al;
-    if (l == 0) { img = imgs + (long long)frame * img_frame_stride; pitch = img_row_stride; al = al_img; }
+    if (l == 0) { img = imgs + (long long)frame * img_frame_stride; pitch = (int)img_row_stride; al = al_img; }
     else { img = pyr + (long long)frame * pyr_frame_bytes + lv.plane_off; pitch = lv.pitch; al = true; }  // pyramid planes are 64-byte aligned
     int m10 = 0, m01 = 0;
     if (al) {
       // 31 rows x 10 aligned dwords cover the patch columns [kx-15, kx+15]; per dword the valid bytes form a range
       const int xs = kx - kHalfPatch, sh = xs & 3;
-      const uint8_t* src = img + (long long)(ky - kHalfPatch) * pitch + (xs - sh);
+      const uint32_t src0 = (uint32_t)(__mul24(ky - kHalfPatch, pitch) + (xs - sh));  // offset of the patch window in the plane
 #pragma unroll
       for (int i = 0; i < 5; i++) {
         const int it = lane + 64 * i;
@@ -1125,7 +1136,7 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
         uint32_t M = 0;
         if (it < 31 * 10 && lo <= hi) M = (0x01010101u << (8 * lo)) & (0x01010101u >> (8 * (3 - hi)));
         uint32_t dw = 0;
-        if (M) dw = *(const uint32_t*)(src + (long long)r * pitch + 4 * dcol);
+        if (M) dw = *(const uint32_t*)(img + (src0 + (uint32_t)(__mul24(r, pitch) + 4 * dcol)));
         const int S = (int)__builtin_amdgcn_udot4(dw, M, 0u, false);
         const int Tt = (int)__builtin_amdgcn_udot4(dw, (M * 255u) & 0x03020100u, 0u, false);  // weights b on the valid bytes
         m10 += u0 * S + Tt;
@@ -1135,12 +1146,12 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
       const int c = lane & 31, r2 = lane >> 5;
       const int u = c - kHalfPatch;
       const int au = u < 0 ? -u : u;
-      const uint8_t* src = img + (long long)(ky - kHalfPatch + r2) * pitch + (kx - kHalfPatch) + c;
+      const uint8_t* src = img + (uint32_t)(__mul24(ky - kHalfPatch + r2, pitch) + (kx - kHalfPatch) + c);
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         const int v = 2 * i - kHalfPatch + r2;
         const int um = v <= kHalfPatch ? (int)((umpk >> (4 * (v < 0 ? -v : v))) & 15ull) : -1;
-        const int I = (au <= um) ? (int)src[(long long)(2 * i) * pitch] : 0;
+        const int I = (au <= um) ? (int)src[(uint32_t)__mul24(2 * i, pitch)] : 0;
         m10 += u * I;
         m01 += v * I;
       }
@@ -1165,8 +1176,9 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
     const float angle = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_angle), k));
     const DeviceLevel& lv = g->lv[l];
     const int kx = pt_x(p), ky = pt_y(p);
-    const uint8_t* ctr = blur + (long long)frame * blur_frame_bytes + lv.bplane_off + (long long)ky * lv.pitch + kx;
+    const uint8_t* bplane = blur + (long long)frame * blur_frame_bytes + lv.bplane_off;  // uniform
     const int bp = lv.pitch;
+    const int ctr = __mul24(ky, bp) + kx;  // taps stay >= 1 px inside the plane: offsets are non-negative
     int t0[4], t1[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -1175,8 +1187,8 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
       const int rx0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
       const int ry1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
       const int rx1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-      t0[q] = ctr[ry0 * bp + rx0];
-      t1[q] = ctr[ry1 * bp + rx1];
+      t0[q] = bplane[(uint32_t)(ctr + __mul24(ry0, bp) + rx0)];
+      t1[q] = bplane[(uint32_t)(ctr + __mul24(ry1, bp) + rx1)];
     }
     unsigned long long mine = 0;
 #pragma unroll
