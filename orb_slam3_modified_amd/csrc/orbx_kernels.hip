@@ -165,10 +165,11 @@ __device__ __forceinline__ int fast_score16(int v, const uint32_t (&p)[16]) {
 }
 
 // Work-efficient structure (the kernel is VALU-bound): only ~5 % of the pixels are corners at minTh, so
-// (1) every pixel takes a 5-value necessary test (two opposite pairs of the circle: a 9-arc always contains one pixel
-//     of each opposite pair), evaluated for 4 horizontally adjacent pixels per lane from 5 aligned LDS dwords
-//     (byte windows via v_alignbyte), no per-pixel index arithmetic;
-// (2) the survivors (~20 %) are compacted into an LDS list of packed (y, x) and only they pay for the exact
+// (1) every pixel takes a 9-value necessary test (four opposite pairs of the circle — the compass and the diagonal
+//     ones: a 9-arc always contains one pixel of each opposite pair), evaluated for 4 horizontally adjacent pixels per
+//     lane from 11 aligned LDS dwords (byte windows via v_alignbyte), no per-pixel index arithmetic; it passes ~6 %
+//     of the pixels (two pairs alone pass ~11 %), which halves the exact-score work;
+// (2) the survivors are compacted into an LDS list of packed (y, x) and only they pay for the exact
 //     16-pixel score; (3) NMS and the iniTh/minTh selection run on the list; (4) the ordered (row-major) output
 //     order is rebuilt from a bitmap + popcount prefix instead of a pass over all pixels.
 // list entry: x | y << 7 (detection-domain coordinates, both < 128), bit 15 = NMS survivor.
@@ -240,14 +241,20 @@ __global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__
       const uint32_t dC = rowp[0], dL = rowp[-1], dR = rowp[1], dU = rowp[-3 * P4], dD = rowp[3 * P4];
       const uint32_t Q4 = __builtin_amdgcn_alignbyte(dR, dC, 3);   // x+3 of pixel j in byte j
       const uint32_t Q12 = __builtin_amdgcn_alignbyte(dC, dL, 1);  // x-3 of pixel j in byte j
+      // the two diagonal pairs (2,10) and (6,14): rows +-2, columns +-2
+      const uint32_t eC = rowp[2 * P4], eL = rowp[2 * P4 - 1], eR = rowp[2 * P4 + 1];
+      const uint32_t fC = rowp[-2 * P4], fL = rowp[-2 * P4 - 1], fR = rowp[-2 * P4 + 1];
+      const uint32_t Q2 = __builtin_amdgcn_alignbyte(eR, eC, 2), Q14 = __builtin_amdgcn_alignbyte(eC, eL, 2);
+      const uint32_t Q6 = __builtin_amdgcn_alignbyte(fR, fC, 2), Q10 = __builtin_amdgcn_alignbyte(fC, fL, 2);
       const int c0 = 4 * k - xo - 3;                               // detection-domain x of pixel 0
       bool ps[4];
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const int v = (dC >> (8 * j)) & 0xff, p0 = (dD >> (8 * j)) & 0xff, p8 = (dU >> (8 * j)) & 0xff;
         const int p4 = (Q4 >> (8 * j)) & 0xff, p12 = (Q12 >> (8 * j)) & 0xff;
-        const bool dark = max(min(p0, p8), min(p4, p12)) < v - min_th;
-        const bool bright = min(max(p0, p8), max(p4, p12)) > v + min_th;
+        const int p2 = (Q2 >> (8 * j)) & 0xff, p10 = (Q10 >> (8 * j)) & 0xff, p6 = (Q6 >> (8 * j)) & 0xff, p14 = (Q14 >> (8 * j)) & 0xff;
+        const bool dark = max(max(min(p0, p8), min(p4, p12)), max(min(p2, p10), min(p6, p14))) < v - min_th;
+        const bool bright = min(min(max(p0, p8), max(p4, p12)), min(max(p2, p10), max(p6, p14))) > v + min_th;
         const bool valid = (unsigned)(c0 + j) < (unsigned)dw;
         ps[j] = (dark | bright) & valid & (act != 0);
       }
