@@ -168,6 +168,15 @@ int orbx_search_for_initialization(orbx_ctx* ctx, const orbx_keypoint* kps1, con
                                    const uint8_t* desc2, int n2, float min_x, float min_y, float max_x, float max_y, float* prev_xy,
                                    int window_size, float nn_ratio, int check_orientation, int32_t* matches12, int* nmatches);
 
+/* Frame::ComputeStereoMatches (src/Frame.cc:811-981) on the DEVICE pyramids of the left and right extractor (the
+ * last frame each context extracted; both on one GPU, same image shape) — this is the reader of the reference's public
+ * ORBextractor::mvImagePyramid, so with it no pyramid has to be copied to the host.  kps / desc: the keypoints and
+ * descriptors the two extractors returned (host pointers); mb = baseline, mbf = baseline * fx (include/Frame.h).
+ * u_right / depth: mvuRight / mvDepth, -1 where no match; *nmatches = matches kept after the median filter. */
+int orbx_stereo_matches(orbx_ctx* left, orbx_ctx* right, const orbx_keypoint* kpsL, const uint8_t* descL, int nL,
+                        const orbx_keypoint* kpsR, const uint8_t* descR, int nR, float mb, float mbf, float* u_right, float* depth,
+                        int* nmatches);
+
 /* ---- bag of words: replaces ORBVocabulary = DBoW2::TemplatedVocabulary<cv::Mat, FORB> ----------------- */
 
 /* TemplatedVocabulary::loadFromTextFile (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1424).

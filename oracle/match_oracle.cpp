@@ -8,9 +8,11 @@
 //   * cv::BFMatcher(NORM_HAMMING).knnMatch(k=2)            as used at src/Frame.cc:1144
 //   * Frame::AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea          src/Frame.cc:385-416, :725-735, :657-723
 //   * ORBmatcher::SearchForInitialization + ComputeThreeMaxima             src/ORBmatcher.cc:648-763, :2012-2053
+//   * Frame::ComputeStereoMatches (row-band Hamming search + 11x11 SAD refinement on the pyramids)   src/Frame.cc:811-981
 //   * DBoW2 vocabulary: loadFromTextFile, transform, BowVector::addWeight/normalize, FeatureVector::addFeature,
 //     L1Scoring::score    Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1259,1338-1424, BowVector.cpp:34-85,
 //                         FeatureVector.cpp:30-45, ScoringObject.cpp:23-68
+#include <algorithm>
 #include <climits>
 #include <cassert>
 #include <cmath>
@@ -366,6 +368,118 @@ int mo_search_for_initialization(const void* kps1_, const uint8_t* desc1, int n1
   for (int i1 = 0; i1 < n1; i1++)
     if (vnMatches12[i1] >= 0) { prev_xy[2 * i1] = kps2[vnMatches12[i1]].x; prev_xy[2 * i1 + 1] = kps2[vnMatches12[i1]].y; }
   return nmatches;
+}
+
+}  // extern "C"
+
+extern "C" {
+
+// Frame::ComputeStereoMatches, src/Frame.cc:811-981.  Pyramid level l of the left / right extractor:
+// pyrL[l] / pyrR[l] point to w[l] x h[l] images with `pitch[l]` bytes per row (mvImagePyramid[l]).
+// Outputs mvuRight / mvDepth (n entries, -1 where unmatched).  Returns the number of matches kept.
+int mo_stereo_matches(const void* kpsL_, const uint8_t* descL, int N, const void* kpsR_, const uint8_t* descR, int Nr,
+                      const uint8_t* const* pyrL, const uint8_t* const* pyrR, const int32_t* w, const int32_t* h,
+                      const int32_t* pitch, const float* mvScaleFactors, const float* mvInvScaleFactors, float mb, float mbf,
+                      float* mvuRight, float* mvDepth) {
+  const MKeyPt* mvKeys = (const MKeyPt*)kpsL_;
+  const MKeyPt* mvKeysRight = (const MKeyPt*)kpsR_;
+  const int TH_HIGH = 100, TH_LOW = 50;
+  for (int i = 0; i < N; i++) { mvuRight[i] = -1.0f; mvDepth[i] = -1.0f; }
+  const int thOrbDist = (TH_HIGH + TH_LOW) / 2;
+  const int nRows = h[0];
+  std::vector<std::vector<size_t>> vRowIndices(nRows, std::vector<size_t>());
+  for (int iR = 0; iR < Nr; iR++) {
+    const MKeyPt& kp = mvKeysRight[iR];
+    const float& kpY = kp.y;
+    const float r = 2.0f * mvScaleFactors[mvKeysRight[iR].octave];
+    const int maxr = (int)std::ceil(kpY + r);
+    const int minr = (int)std::floor(kpY - r);
+    for (int yi = minr; yi <= maxr; yi++)
+      if (yi >= 0 && yi < nRows) vRowIndices[yi].push_back(iR);   // the reference indexes unchecked (keypoints sit >= 16 px inside)
+  }
+  const float minZ = mb;
+  const float minD = 0;
+  const float maxD = mbf / minZ;
+  std::vector<std::pair<int, int>> vDistIdx;
+  for (int iL = 0; iL < N; iL++) {
+    const MKeyPt& kpL = mvKeys[iL];
+    const int& levelL = kpL.octave;
+    const float& vL = kpL.y;
+    const float& uL = kpL.x;
+    const std::vector<size_t>& vCandidates = vRowIndices[(size_t)vL];
+    if (vCandidates.empty()) continue;
+    const float minU = uL - maxD;
+    const float maxU = uL - minD;
+    if (maxU < 0) continue;
+    int bestDist = TH_HIGH;
+    size_t bestIdxR = 0;
+    const uint8_t* dL = descL + (size_t)iL * 32;
+    for (size_t iC = 0; iC < vCandidates.size(); iC++) {
+      const size_t iR = vCandidates[iC];
+      const MKeyPt& kpR = mvKeysRight[iR];
+      if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
+      const float& uR = kpR.x;
+      if (uR >= minU && uR <= maxU) {
+        const int dist = descriptor_distance(dL, descR + iR * 32);
+        if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
+      }
+    }
+    if (bestDist < thOrbDist) {
+      const float uR0 = mvKeysRight[bestIdxR].x;
+      const float scaleFactor = mvInvScaleFactors[kpL.octave];
+      const float scaleduL = std::round(kpL.x * scaleFactor);
+      const float scaledvL = std::round(kpL.y * scaleFactor);
+      const float scaleduR0 = std::round(uR0 * scaleFactor);
+      const int wnd = 5;
+      const int lvl = kpL.octave;
+      const uint8_t* IL = pyrL[lvl];
+      const uint8_t* IRi = pyrR[lvl];
+      int bestDistS = INT_MAX;
+      int bestincR = 0;
+      const int L = 5;
+      std::vector<float> vDists(2 * L + 1);
+      const float iniu = scaleduR0 + L - wnd;
+      const float endu = scaleduR0 + L + wnd + 1;
+      if (iniu < 0 || endu >= w[lvl]) continue;
+      const int r0 = (int)(scaledvL - wnd), cL0 = (int)(scaleduL - wnd);
+      for (int incR = -L; incR <= +L; incR++) {
+        const int cR0 = (int)(scaleduR0 + incR - wnd);
+        double acc = 0;  // cv::norm(IL, IR, NORM_L1) on CV_8U: sum of absolute differences
+        for (int rr = 0; rr < 2 * wnd + 1; rr++)
+          for (int cc = 0; cc < 2 * wnd + 1; cc++)
+            acc += std::abs((int)IL[(size_t)(r0 + rr) * pitch[lvl] + cL0 + cc] - (int)IRi[(size_t)(r0 + rr) * pitch[lvl] + cR0 + cc]);
+        float dist = (float)acc;
+        if (dist < bestDistS) { bestDistS = (int)dist; bestincR = incR; }
+        vDists[L + incR] = dist;
+      }
+      if (bestincR == -L || bestincR == L) continue;
+      const float dist1 = vDists[L + bestincR - 1];
+      const float dist2 = vDists[L + bestincR];
+      const float dist3 = vDists[L + bestincR + 1];
+      const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+      if (deltaR < -1 || deltaR > 1) continue;
+      float bestuR = mvScaleFactors[kpL.octave] * ((float)scaleduR0 + (float)bestincR + deltaR);
+      float disparity = (uL - bestuR);
+      if (disparity >= minD && disparity < maxD) {
+        if (disparity <= 0) { disparity = 0.01; bestuR = uL - 0.01; }
+        mvDepth[iL] = mbf / disparity;
+        mvuRight[iL] = bestuR;
+        vDistIdx.push_back(std::pair<int, int>(bestDistS, iL));
+      }
+    }
+  }
+  if (vDistIdx.empty()) return 0;   // the reference reads vDistIdx[0] of an empty vector here (undefined); nothing to filter
+  std::sort(vDistIdx.begin(), vDistIdx.end());
+  const float median = vDistIdx[vDistIdx.size() / 2].first;
+  const float thDist = 1.5f * 1.4f * median;
+  int kept = (int)vDistIdx.size();
+  for (int i = (int)vDistIdx.size() - 1; i >= 0; i--) {
+    if (vDistIdx[i].first < thDist) break;
+    mvuRight[vDistIdx[i].second] = -1;
+    mvDepth[vDistIdx[i].second] = -1;
+    kept--;
+  }
+  return kept;
 }
 
 }  // extern "C"

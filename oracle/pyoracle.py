@@ -189,6 +189,8 @@ def _mlib():
         L.mo_features_in_area.argtypes = [vp, C.c_int, f32, f32, f32, f32, vp, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int]
         L.mo_search_for_initialization.restype = C.c_int
         L.mo_search_for_initialization.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, f32, f32, f32, f32, vp, C.c_int, f32, C.c_int, vp]
+        L.mo_stereo_matches.restype = C.c_int
+        L.mo_stereo_matches.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, f32, f32, vp, vp]
         L._mo_bound = True
     return L
 
@@ -232,6 +234,25 @@ def search_for_initialization(kps1, desc1, kps2, desc2, bounds, prev_xy, window_
     n = _mlib().mo_search_for_initialization(_ptr(k1), _ptr(d1), len(k1), _ptr(k2), _ptr(d2), len(k2), *[float(b) for b in bounds],
                                              _ptr(prev), int(window_size), float(nnratio), int(check_ori), _ptr(m12))
     return int(n), m12[:len(k1)].copy(), prev
+
+
+def stereo_matches(kpsL, descL, kpsR, descR, pyrL, pyrR, scale, inv_scale, mb, mbf):
+    """Frame::ComputeStereoMatches (src/Frame.cc:811-981) -> (mvuRight, mvDepth, number of matches kept)."""
+    kL, kR = np.ascontiguousarray(kpsL), np.ascontiguousarray(kpsR)
+    dL, dR = np.ascontiguousarray(descL, np.uint8), np.ascontiguousarray(descR, np.uint8)
+    pl = [np.ascontiguousarray(p) for p in pyrL]
+    pr = [np.ascontiguousarray(p) for p in pyrR]
+    n = len(pl)
+    PL = (C.c_void_p * n)(*[p.ctypes.data for p in pl])
+    PR = (C.c_void_p * n)(*[p.ctypes.data for p in pr])
+    w = np.array([p.shape[1] for p in pl], np.int32); h = np.array([p.shape[0] for p in pl], np.int32)
+    pitch = np.array([p.strides[0] for p in pl], np.int32)
+    assert all(a.shape == b.shape for a, b in zip(pl, pr))
+    sc, isc = np.ascontiguousarray(scale, np.float32), np.ascontiguousarray(inv_scale, np.float32)
+    ur = np.zeros(max(len(kL), 1), np.float32); dp = np.zeros(max(len(kL), 1), np.float32)
+    kept = _mlib().mo_stereo_matches(_ptr(kL), _ptr(dL), len(kL), _ptr(kR), _ptr(dR), len(kR), PL, PR, _ptr(w), _ptr(h), _ptr(pitch),
+                                     _ptr(sc), _ptr(isc), float(mb), float(mbf), _ptr(ur), _ptr(dp))
+    return ur[:len(kL)].copy(), dp[:len(kL)].copy(), int(kept)
 
 
 def knn2(q, t):

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 #include "orbx_internal.h"
@@ -133,6 +134,158 @@ __global__ __launch_bounds__(1024) void k_scan_excl(const int32_t* __restrict__ 
     __syncthreads();
   }
   if (t == 0) out[n] = carry_s;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Frame::ComputeStereoMatches (src/Frame.cc:811-981) on the device pyramids of the two extractors.
+// ---------------------------------------------------------------------------------------------------------
+struct StereoGeom {
+  const uint8_t* left[kMaxLevels];
+  const uint8_t* right[kMaxLevels];
+  int w[kMaxLevels], h[kMaxLevels], pitchL[kMaxLevels], pitchR[kMaxLevels];
+  float scale[kMaxLevels], inv_scale[kMaxLevels];
+  int nlevels;
+};
+
+// One wave per left keypoint: (1) best right keypoint among those whose row band contains the left row
+// (vRowIndices, :820-840), octave within +-1 and u in [uL - maxD, uL]; first minimum in right-index order wins (:873-889);
+// (2) 11 x 11 SAD over 11 horizontal shifts on the pyramid level of the left keypoint (:905-935), 121 (shift, row) items
+// spread over the lanes; (3) parabola refinement, disparity / depth (:937-966) by lane 0 with separate IEEE operations.
+// sad[iL] = best SAD of an accepted match, -1 otherwise (input of the median filter).
+__global__ __launch_bounds__(256) void k_stereo_match(StereoGeom sg, const orbx_keypoint* __restrict__ kpsL,
+                                                      const uint8_t* __restrict__ descL, int N,
+                                                      const orbx_keypoint* __restrict__ kpsR, const uint8_t* __restrict__ descR,
+                                                      int Nr, float mb, float mbf, float* __restrict__ uRight,
+                                                      float* __restrict__ depth, int32_t* __restrict__ sad) {
+  __shared__ int s_part[4][128];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int iL = blockIdx.x * 4 + wv;
+  if (iL >= N) return;
+  const orbx_keypoint kpL = kpsL[iL];
+  float out_u = -1.0f, out_d = -1.0f;
+  int out_sad = -1;
+  const int levelL = kpL.octave;
+  const float vL = kpL.y, uL = kpL.x;
+  const float minD = 0.0f, maxD = __fdiv_rn(mbf, mb);
+  const float minU = __fsub_rn(uL, maxD), maxU = __fsub_rn(uL, minD);
+  const int row = (int)vL;
+  unsigned long long best = ~0ull;
+  if (row >= 0 && row < sg.h[0] && !(maxU < 0)) {
+    const uint4* qp = (const uint4*)(descL + (size_t)iL * 32);
+    const uint4 qa = qp[0], qb = qp[1];
+    for (int iR = lane; iR < Nr; iR += 64) {
+      const orbx_keypoint kpR = kpsR[iR];
+      const float r = __fmul_rn(2.0f, sg.scale[kpR.octave]);
+      const int maxr = (int)ceilf(__fadd_rn(kpR.y, r)), minr = (int)floorf(__fsub_rn(kpR.y, r));
+      if (row < minr || row > maxr) continue;
+      if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
+      if (!(kpR.x >= minU && kpR.x <= maxU)) continue;
+      const uint4* tp = (const uint4*)(descR + (size_t)iR * 32);
+      const uint4 ta = tp[0], tb = tp[1];
+      const int d = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) + __popc(qa.w ^ ta.w) +
+                    __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
+      const unsigned long long key = ((unsigned long long)d << 32) | (uint32_t)iR;
+      best = key < best ? key : best;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const unsigned long long p = __shfl_xor(best, o); best = p < best ? p : best; }
+  const int bestDist = best == ~0ull ? 256 : (int)(best >> 32);
+  const int TH_HIGH = 100, thOrbDist = 75;
+  if (bestDist < TH_HIGH && bestDist < thOrbDist) {  // wave-uniform
+    const int bestIdxR = (int)(uint32_t)best;
+    const float uR0 = kpsR[bestIdxR].x;
+    const float scaleFactor = sg.inv_scale[levelL];
+    const float scaleduL = roundf(__fmul_rn(kpL.x, scaleFactor));
+    const float scaledvL = roundf(__fmul_rn(kpL.y, scaleFactor));
+    const float scaleduR0 = roundf(__fmul_rn(uR0, scaleFactor));
+    const int wnd = 5, Ls = 5;
+    const float iniu = __fsub_rn(__fadd_rn(scaleduR0, (float)Ls), (float)wnd);
+    const float endu = __fadd_rn(__fadd_rn(__fadd_rn(scaleduR0, (float)Ls), (float)wnd), 1.0f);
+    if (!(iniu < 0 || endu >= (float)sg.w[levelL])) {
+      const int r0 = (int)__fsub_rn(scaledvL, (float)wnd), cL0 = (int)__fsub_rn(scaleduL, (float)wnd);
+      const uint8_t* IL = sg.left[levelL];
+      const uint8_t* IR = sg.right[levelL];
+      const int pL = sg.pitchL[levelL], pR = sg.pitchR[levelL];
+      for (int it = lane; it < 121; it += 64) {
+        const int si = it / 11, rr = it - si * 11;
+        const int cR0 = (int)__fsub_rn(__fadd_rn(scaleduR0, (float)(si - Ls)), (float)wnd);
+        const uint8_t* a = IL + (size_t)(r0 + rr) * pL + cL0;
+        const uint8_t* b = IR + (size_t)(r0 + rr) * pR + cR0;
+        int acc = 0;
+#pragma unroll
+        for (int cc = 0; cc < 11; cc++) { const int d = (int)a[cc] - (int)b[cc]; acc += d < 0 ? -d : d; }
+        s_part[wv][it] = acc;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (lane == 0) {
+        float vDists[11];
+        int bestS = 0x7fffffff, bestincR = 0;
+        for (int si = 0; si < 11; si++) {
+          int acc = 0;
+          for (int rr = 0; rr < 11; rr++) acc += s_part[wv][si * 11 + rr];
+          const float dist = (float)acc;
+          if (dist < (float)bestS) { bestS = acc; bestincR = si - Ls; }
+          vDists[si] = dist;
+        }
+        if (!(bestincR == -Ls || bestincR == Ls)) {
+          const float dist1 = vDists[Ls + bestincR - 1], dist2 = vDists[Ls + bestincR], dist3 = vDists[Ls + bestincR + 1];
+          const float den = __fmul_rn(2.0f, __fsub_rn(__fadd_rn(dist1, dist3), __fmul_rn(2.0f, dist2)));
+          const float deltaR = __fdiv_rn(__fsub_rn(dist1, dist3), den);
+          if (!(deltaR < -1 || deltaR > 1)) {
+            float bestuR = __fmul_rn(sg.scale[levelL], __fadd_rn(__fadd_rn(scaleduR0, (float)bestincR), deltaR));
+            float disparity = __fsub_rn(uL, bestuR);
+            if (disparity >= minD && disparity < maxD) {
+              if (disparity <= 0) { disparity = (float)0.01; bestuR = (float)__dsub_rn((double)uL, 0.01); }
+              out_d = __fdiv_rn(mbf, disparity);
+              out_u = bestuR;
+              out_sad = bestS;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (lane == 0) { uRight[iL] = out_u; depth[iL] = out_d; sad[iL] = out_sad; }
+}
+
+// The median filter of the accepted matches (src/Frame.cc:969-981): only the value of the (n/2)-th smallest SAD
+// matters (all matches with SAD >= 1.5 * 1.4 * median are removed), so no sort is needed — one workgroup counts ranks.
+__global__ __launch_bounds__(1024) void k_stereo_filter(int N, float* __restrict__ uRight, float* __restrict__ depth,
+                                                        const int32_t* __restrict__ sad, int32_t* __restrict__ kept_out) {
+  __shared__ int s_n, s_median, s_kept;
+  const int t = threadIdx.x;
+  if (t == 0) { s_n = 0; s_median = -1; s_kept = 0; }
+  __syncthreads();
+  int mine = 0;
+  for (int i = t; i < N; i += 1024) mine += sad[i] >= 0;
+  if (mine) atomicAdd(&s_n, mine);
+  __syncthreads();
+  const int n = s_n;
+  if (n == 0) { if (t == 0) *kept_out = 0; return; }
+  const int k = n / 2;
+  for (int i = t; i < N; i += 1024) {
+    const int v = sad[i];
+    if (v < 0) continue;
+    int lo = 0, eq = 0;
+    for (int j = 0; j < N; j++) { const int u = sad[j]; lo += (u >= 0 && u < v); eq += (u == v); }
+    if (lo <= k && k < lo + eq) s_median = v;   // every thread that hits writes the same value
+  }
+  __syncthreads();
+  const float thDist = __fmul_rn(1.5f * 1.4f, (float)s_median);
+  int kept = 0;
+  for (int i = t; i < N; i += 1024) {
+    const int v = sad[i];
+    if (v < 0) continue;
+    if ((float)v < thDist) kept++;
+    else { uRight[i] = -1.0f; depth[i] = -1.0f; }
+  }
+  if (kept) atomicAdd(&s_kept, kept);
+  __syncthreads();
+  if (t == 0) *kept_out = s_kept;
 }
 
 template <typename T>
@@ -327,6 +480,60 @@ int orbx_search_for_initialization(orbx_ctx* ctx, const orbx_keypoint* kps1, con
   for (int i1 = 0; i1 < n1; i1++)
     if (matches12[i1] >= 0) { prev_xy[2 * i1] = kps2[matches12[i1]].x; prev_xy[2 * i1 + 1] = kps2[matches12[i1]].y; }
   *nmatches_out = nmatches;
+  return ORBX_OK;
+}
+
+int orbx_stereo_matches(orbx_ctx* left, orbx_ctx* right, const orbx_keypoint* kpsL, const uint8_t* descL, int nL,
+                        const orbx_keypoint* kpsR, const uint8_t* descR, int nR, float mb, float mbf, float* u_right, float* depth,
+                        int* nmatches) {
+  if (!left || !right || nL < 0 || nR < 0 || (nL > 0 && (!kpsL || !descL || !u_right || !depth)) || (nR > 0 && (!kpsR || !descR)) ||
+      !(mb > 0))
+    return left ? set_err(left, ORBX_E_INVALID, "orbx_stereo_matches: bad arguments") : ORBX_E_INVALID;
+  orbx_ctx* ctx = left;
+  if (nmatches) *nmatches = 0;
+  for (int i = 0; i < nL; i++) { u_right[i] = -1.0f; depth[i] = -1.0f; }
+  if (nL == 0 || nR == 0) return ORBX_OK;
+  if (!left->d_geo || !right->d_geo || left->last_nframes < 1 || right->last_nframes < 1 || left->device != right->device ||
+      left->geo.rows != right->geo.rows || left->geo.cols != right->geo.cols || left->nlevels != right->nlevels)
+    return set_err(ctx, ORBX_E_INVALID, "orbx_stereo_matches: both extractors must have processed a frame of the same shape on one GPU");
+  ORBX_HIP(ctx, hipSetDevice(ctx->device));
+  ORBX_HIP(ctx, hipStreamSynchronize(right->stream));   // the right pyramid was produced on the right context's stream
+  StereoGeom sg;
+  std::memset(&sg, 0, sizeof(sg));
+  sg.nlevels = left->nlevels;
+  for (int l = 0; l < left->nlevels; l++) {
+    const LevelGeom& L = left->geo.lv[l];
+    const LevelGeom& R = right->geo.lv[l];
+    sg.w[l] = L.w; sg.h[l] = L.h;
+    if (l == 0) {
+      sg.left[l] = left->last_imgs; sg.pitchL[l] = (int)left->last_row_stride;
+      sg.right[l] = right->last_imgs; sg.pitchR[l] = (int)right->last_row_stride;
+    } else {
+      sg.left[l] = left->d_pyr + L.plane_off; sg.pitchL[l] = L.pitch;
+      sg.right[l] = right->d_pyr + R.plane_off; sg.pitchR[l] = R.pitch;
+    }
+    sg.scale[l] = left->scale[l]; sg.inv_scale[l] = left->inv_scale[l];
+  }
+  DBuf<orbx_keypoint> dkl, dkr;
+  DBuf<uint8_t> ddl, ddr;
+  DBuf<float> du, dd;
+  DBuf<int32_t> dsad, dkept;
+  ORBX_HIP(ctx, dkl.alloc(nL)); ORBX_HIP(ctx, dkr.alloc(nR)); ORBX_HIP(ctx, ddl.alloc((size_t)nL * 32)); ORBX_HIP(ctx, ddr.alloc((size_t)nR * 32));
+  ORBX_HIP(ctx, du.alloc(nL)); ORBX_HIP(ctx, dd.alloc(nL)); ORBX_HIP(ctx, dsad.alloc(nL)); ORBX_HIP(ctx, dkept.alloc(1));
+  hipStream_t st = ctx->stream;
+  ORBX_HIP(ctx, hipMemcpyAsync(dkl.p, kpsL, sizeof(orbx_keypoint) * nL, hipMemcpyHostToDevice, st));
+  ORBX_HIP(ctx, hipMemcpyAsync(dkr.p, kpsR, sizeof(orbx_keypoint) * nR, hipMemcpyHostToDevice, st));
+  ORBX_HIP(ctx, hipMemcpyAsync(ddl.p, descL, (size_t)nL * 32, hipMemcpyHostToDevice, st));
+  ORBX_HIP(ctx, hipMemcpyAsync(ddr.p, descR, (size_t)nR * 32, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_stereo_match, dim3((nL + 3) / 4), dim3(256), 0, st, sg, dkl.p, ddl.p, nL, dkr.p, ddr.p, nR, mb, mbf, du.p, dd.p, dsad.p);
+  hipLaunchKernelGGL(k_stereo_filter, dim3(1), dim3(1024), 0, st, nL, du.p, dd.p, dsad.p, dkept.p);
+  ORBX_HIP(ctx, hipGetLastError());
+  int32_t kept = 0;
+  ORBX_HIP(ctx, hipMemcpyAsync(u_right, du.p, sizeof(float) * nL, hipMemcpyDeviceToHost, st));
+  ORBX_HIP(ctx, hipMemcpyAsync(depth, dd.p, sizeof(float) * nL, hipMemcpyDeviceToHost, st));
+  ORBX_HIP(ctx, hipMemcpyAsync(&kept, dkept.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  ORBX_HIP(ctx, hipStreamSynchronize(st));
+  if (nmatches) *nmatches = kept;
   return ORBX_OK;
 }
 

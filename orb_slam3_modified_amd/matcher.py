@@ -87,6 +87,20 @@ class ORBmatcher:
         return n.value, m12[:len(k1)].copy()
 
     @staticmethod
+    def ComputeStereoMatches(left_extractor, right_extractor, kpsL, descL, kpsR, descR, mb: float, mbf: float):
+        """Frame::ComputeStereoMatches (src/Frame.cc:811-981) on the device pyramids of the two extractors (each must
+        have just extracted its image).  Returns (mvuRight, mvDepth, number of matches kept)."""
+        kL, kR = np.ascontiguousarray(kpsL), np.ascontiguousarray(kpsR)
+        dL = np.ascontiguousarray(descL, np.uint8).reshape(-1, 32)
+        dR = np.ascontiguousarray(descR, np.uint8).reshape(-1, 32)
+        ur = np.zeros(max(len(kL), 1), np.float32)
+        dp = np.zeros(max(len(kL), 1), np.float32)
+        n = C.c_int(0)
+        check(lib().orbx_stereo_matches(left_extractor._ctx, right_extractor._ctx, ptr(kL), ptr(dL), len(kL), ptr(kR), ptr(dR), len(kR),
+                                        float(mb), float(mbf), ptr(ur), ptr(dp), C.byref(n)), left_extractor._ctx)
+        return ur[:len(kL)].copy(), dp[:len(kL)].copy(), n.value
+
+    @staticmethod
     def ComputeThreeMaxima(histo_counts):
         """src/ORBmatcher.cc:2012-2053 on bin populations."""
         max1 = max2 = max3 = 0

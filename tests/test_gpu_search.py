@@ -72,3 +72,37 @@ def test_search_for_initialization_degenerate(frames):
     assert n == on and np.array_equal(m12, om12)
     lvl0 = F1.mvKeysUn["octave"] == 0
     assert (m12[~lvl0] == -1).all() and (m12[lvl0] >= 0).sum() > 0.9 * lvl0.sum()
+
+
+@pytest.mark.parametrize("disp,noise", [(12, 2), (37, 0), (3, 4)])
+def test_compute_stereo_matches_equals_oracle(disp, noise):
+    """Frame::ComputeStereoMatches on the device pyramids of two extractor instances (stereo: src/Frame.cc:122-141)."""
+    rng = np.random.default_rng(disp)
+    L = synth.make_stream(1, 480, 752)[0]
+    R = np.roll(L, -disp, axis=1).copy()
+    if noise:
+        R = np.clip(R.astype(np.int32) + rng.integers(-noise, noise + 1, R.shape), 0, 255).astype(np.uint8)
+    exL, exR = ORBextractor(1200, 1.2, 8, 20, 7), ORBextractor(1200, 1.2, 8, 20, 7)
+    _, kL, dL = exL(L, None, (0, 0))
+    _, kR, dR = exR(R, None, (0, 0))
+    mb, mbf = 0.11, 47.90639384423901          # EuRoC: baseline, baseline * fx (Examples/Stereo/EuRoC.yaml)
+    ur, dp, kept = ORBmatcher.ComputeStereoMatches(exL, exR, kL, dL, kR, dR, mb, mbf)
+    our, odp, okept = po.stereo_matches(kL, dL, kR, dR, exL.mvImagePyramid, exR.mvImagePyramid, exL.GetScaleFactors(),
+                                        exL.GetInverseScaleFactors(), mb, mbf)
+    assert kept == okept and ur.tobytes() == our.tobytes() and dp.tobytes() == odp.tobytes()
+    m = ur >= 0
+    assert m.sum() == kept and kept > 200
+    assert abs(np.median((kL["x"] - ur)[m]) - disp) < 0.5
+
+
+def test_compute_stereo_matches_degenerate():
+    L = synth.make_stream(1, 480, 752)[0]
+    exL, exR = ORBextractor(1200, 1.2, 8, 20, 7), ORBextractor(1200, 1.2, 8, 20, 7)
+    _, kL, dL = exL(L, None, (0, 0))
+    _, kR, dR = exR(np.ascontiguousarray(L[:, ::-1]), None, (0, 0))        # mirrored right image: (almost) nothing matches
+    ur, dp, kept = ORBmatcher.ComputeStereoMatches(exL, exR, kL, dL, kR, dR, 0.11, 47.9)
+    our, odp, okept = po.stereo_matches(kL, dL, kR, dR, exL.mvImagePyramid, exR.mvImagePyramid, exL.GetScaleFactors(),
+                                        exL.GetInverseScaleFactors(), 0.11, 47.9)
+    assert kept == okept and ur.tobytes() == our.tobytes() and dp.tobytes() == odp.tobytes()
+    ur, dp, kept = ORBmatcher.ComputeStereoMatches(exL, exR, kL, dL, kR[:0], dR[:0], 0.11, 47.9)
+    assert kept == 0 and (ur == -1).all() and (dp == -1).all()
