@@ -81,6 +81,28 @@ assert voc.loadFromTextFile(vp)
 dw = torch.zeros(nq, dtype=torch.int32, device=dev); dwt = torch.zeros(nq, dtype=torch.float64, device=dev); dn = torch.zeros(nq, dtype=torch.int32, device=dev)
 t = ev_time(lambda: L.orbx_bow_transform_device(voc._voc, ptr(d0.data_ptr()), nq, 4, ptr(dw.data_ptr()), ptr(dwt.data_ptr()), ptr(dn.data_ptr()), ptr(st)))
 res["bow_descend"] = {"features": nq, "vocabulary": info, "us_per_call": t * 1e3, "features_per_s": nq / (t * 1e-3)}
+# widened rows (host-buffer entry points, per-call allocations included): SearchForInitialization, ComputeStereoMatches
+class F:
+    def __init__(self, k, d): self.mvKeysUn, self.mDescriptors, self.bounds = k, d, (0.0, 0.0, 640.0, 480.0)
+exi = ORBextractor(5000, 1.2, 8, 20, 7)
+fa = [exi(f, None, (0, 1000)) for f in frames[:2]]
+F1, F2 = F(fa[0][1], fa[0][2]), F(fa[1][1], fa[1][2])
+m = ORBmatcher(exi, 0.9, True)
+prev = np.stack([F1.mvKeysUn["x"], F1.mvKeysUn["y"]], 1).astype(np.float32)
+for _ in range(3): nm, _m = m.SearchForInitialization(F1, F2, prev.copy(), 100)
+t0 = time.perf_counter()
+for _ in range(20): nm, _m = m.SearchForInitialization(F1, F2, prev.copy(), 100)
+res["search_for_initialization"] = {"level0_queries": int((F1.mvKeysUn["octave"] == 0).sum()), "matches": int(nm),
+                                    "ms_per_call": (time.perf_counter() - t0) / 20 * 1e3,
+                                    "note": "host buffers; grid build + candidate CSR + distances on the GPU, greedy replay on the host"}
+Ls = synth.make_stream(1, 480, 752)[0]; Rs = np.roll(Ls, -12, axis=1).copy()
+exL, exR = ORBextractor(1200, 1.2, 8, 20, 7), ORBextractor(1200, 1.2, 8, 20, 7)
+_, kL, dL = exL(Ls, None, (0, 0)); _, kR, dR = exR(Rs, None, (0, 0))
+for _ in range(3): ORBmatcher.ComputeStereoMatches(exL, exR, kL, dL, kR, dR, 0.11, 47.9)
+t0 = time.perf_counter()
+for _ in range(20): ur, dp, kept = ORBmatcher.ComputeStereoMatches(exL, exR, kL, dL, kR, dR, 0.11, 47.9)
+res["compute_stereo_matches"] = {"left": len(kL), "right": len(kR), "kept": int(kept), "ms_per_call": (time.perf_counter() - t0) / 20 * 1e3,
+                                 "note": "host keypoints/descriptors in, device pyramids; per-call allocations included"}
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(res, open(os.path.join(ROOT, "gpurun_out", "bench_aux.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
