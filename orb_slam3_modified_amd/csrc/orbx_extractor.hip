@@ -373,9 +373,14 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
       if (node_cap > 4095) return set_err(ctx, ORBX_E_CAPACITY, "nfeatures too large for the quadtree kernel");
       const size_t lds = (size_t)node_cap * (2 * sizeof(QNode) + 2 * 8 + sizeof(int4) + 4) + (size_t)scan_cap * 8 +
                          (size_t)pts_cap * 2 * sizeof(uint32_t);
+      if (lds > 160 * 1024)  // one workgroup may use the whole 160 KiB LDS of a CU, not more
+        return set_err(ctx, ORBX_E_CAPACITY, "nfeatures too large for the quadtree kernel's LDS (a level quota above ~2300)");
       if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return set_err(ctx, ORBX_E_CAPACITY, "nfeatures too large for the quadtree kernel's LDS");
+        if (e != hipSuccess) {
+          (void)hipGetLastError();  // do not leave the sticky error for an unrelated later call
+          return set_err(ctx, ORBX_E_CAPACITY, "nfeatures too large for the quadtree kernel's LDS");
+        }
       }
       hipLaunchKernelGGL(k_quadtree, dim3(l1 - l0, nframes, 1), dim3(256), lds, s, ctx->d_geo, ctx->d_cells, b_cand, b_cell_cnt,
                          b_pts, b_lvl_kp, b_lvl_n, node_cap, scan_cap, pts_cap, l0);

@@ -219,3 +219,27 @@ def test_device_batch_with_unaligned_strides_and_base():
     ora = po.OracleExtractor(600, 1.2, 5, 20, 7)
     for f in range(B):
         assert_same(res[f], ora.extract(frames[f], (0, 1000)), f"unaligned f{f}")
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_shapes_and_parameters(seed):
+    """Randomised configurations: odd image sizes (all staging / tile edge cases), scale factors 1.1 .. 1.9, 1 .. 8 levels,
+    feature budgets from starved to saturated, arbitrary lapping intervals — always bit-exact against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    sf = float(np.float32(rng.choice([1.1, 1.15, 1.2, 1.25, 1.33, 1.5, 1.7, 1.9])))
+    nlev = int(rng.integers(1, 9))
+    min_side = int(np.ceil(70 * sf ** (nlev - 1))) + 2           # top level must keep >= 67 px
+    lo = max(min_side, 90)
+    rows = int(rng.integers(lo, max(700, lo + 200))); cols = int(rng.integers(lo, max(900, lo + 300)))
+    if cols > 8 * rows or rows > 2 * cols:
+        rows = cols = max(rows, cols) // 2 + min_side
+    nf = int(rng.choice([30, 150, 700, 1000, 2500, 6000]))
+    ini = int(rng.choice([12, 20, 35])); mn = int(rng.choice([3, 7, ini]))
+    lap = tuple(sorted(rng.integers(0, cols + 50, 2).tolist()))
+    img = synth.make_stream(1, rows, cols, 4242 + seed)[0]
+    try:
+        gpu = ORBextractor(nf, sf, nlev, ini, mn)
+        res = gpu(img, None, lap)
+    except OrbxError as e:
+        pytest.skip(f"configuration rejected loudly ({e}); rows={rows} cols={cols} sf={sf} L={nlev}")
+    assert_same(res, po.OracleExtractor(nf, sf, nlev, ini, mn).extract(img, lap), f"{cols}x{rows} sf{sf} L{nlev} nf{nf} th{ini}/{mn} lap{lap}")
