@@ -7,7 +7,9 @@
  *   - the pyramid lives in persistent device buffers (the reference reallocates it per call);
  *     mvImagePyramid[l] is a host copy made after each call (needed only by the stereo matcher,
  *     src/Frame.cc:818,908-925) — switch it off for mono with SetKeepHostPyramid(false);
- *   - the host copies are plain w x h images, not ROIs into an EDGE_THRESHOLD-padded buffer (nothing reads the pad).
+ *   - mvImagePyramid[0] is a header over the caller's image and mvImagePyramid[l >= 1] are headers over a pinned host
+ *     mirror that one asynchronous copy inside the call refreshes; there is no EDGE_THRESHOLD padding around them
+ *     (nothing reads the pad), and like the reference's they are valid until the next call.
  * Errors: an empty image returns -1 like the reference (src/ORBextractor.cc:1090-1091); a missing GPU or a HIP
  * failure throws std::runtime_error from the constructor / operator() (the reference has no failure path at all;
  * there is deliberately no CPU fallback).
@@ -39,6 +41,7 @@ class ORBextractor {
     mvInvLevelSigma2.resize(nlevels); mnFeaturesPerLevel.resize(nlevels);
     orbx_scale_tables(ctx_, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(), mvInvLevelSigma2.data(),
                       mnFeaturesPerLevel.data());
+    orbx_set_host_pyramid(ctx_, 1);
     cap_ = orbx_keypoint_capacity(ctx_);
     kps_.resize(cap_);
     desc_.resize((size_t)cap_ * 32);
@@ -70,11 +73,16 @@ class ORBextractor {
     _keypoints.resize(n);
     if (n) std::memcpy((void*)_keypoints.data(), kps_.data(), (size_t)n * sizeof(orbx_keypoint));
     if (keep_host_pyramid_) {
-      for (int l = 0; l < nlevels; l++) {
+      // level 0 is the caller's image (a header over it, like the reference's ROI into its padded copy); levels >= 1 are
+      // headers over the context's pinned host mirror, filled by one asynchronous copy inside orbx_extract
+      mvImagePyramid[0] = image;
+      for (int l = 1; l < nlevels; l++) {
+        const uint8_t* p = nullptr;
+        size_t stride = 0;
         int w = 0, h = 0;
-        orbx_pyramid_level(ctx_, 0, l, nullptr, 0, &w, &h);
-        mvImagePyramid[l].create(h, w, CV_8UC1);
-        orbx_pyramid_level(ctx_, 0, l, mvImagePyramid[l].data, (size_t)mvImagePyramid[l].step, &w, &h);
+        if (orbx_host_pyramid_level(ctx_, l, &p, &stride, &w, &h) != ORBX_OK)
+          throw std::runtime_error(std::string("ORBextractor: ") + orbx_last_error(ctx_));
+        mvImagePyramid[l] = cv::Mat(h, w, CV_8UC1, (void*)p, stride);
       }
     }
     return mono;
@@ -90,7 +98,7 @@ class ORBextractor {
   std::vector<cv::Mat> mvImagePyramid;
 
   // orbx extensions (not in the reference)
-  void SetKeepHostPyramid(bool on) { keep_host_pyramid_ = on; }
+  void SetKeepHostPyramid(bool on) { keep_host_pyramid_ = on; orbx_set_host_pyramid(ctx_, on ? 1 : 0); }
   orbx_ctx* Context() { return ctx_; }
 
  protected:

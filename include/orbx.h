@@ -83,6 +83,14 @@ int orbx_extract_batch(orbx_ctx* ctx, const uint8_t* imgs, int nframes, int rows
  * (the reference's stereo matcher reads it, src/Frame.cc:818,908-925).  dst may be NULL to query w/h. */
 int orbx_pyramid_level(orbx_ctx* ctx, int frame, int level, uint8_t* dst, size_t dst_stride, int* w, int* h);
 
+/* Host mirror of mvImagePyramid for the single-frame path: with orbx_set_host_pyramid(ctx, 1) every orbx_extract also
+ * copies the pyramid levels >= 1 of its frame into pinned host memory (one asynchronous copy inside the call);
+ * orbx_host_pyramid_level then returns a pointer into that mirror, valid until the next extraction of the context
+ * (the reference re-points mvImagePyramid on every call too).  Level 0 is the caller's own image:
+ * *data = NULL. */
+int orbx_set_host_pyramid(orbx_ctx* ctx, int on);
+int orbx_host_pyramid_level(orbx_ctx* ctx, int level, const uint8_t** data, size_t* stride, int* w, int* h);
+
 /* The 7x7 Gaussian-blurred copy of mvImagePyramid[level] the descriptors were sampled from
  * (cv::GaussianBlur, src/ORBextractor.cc:1132-1133), for stage-level parity tests.  dst: h rows of w bytes. */
 int orbx_debug_blur_level(orbx_ctx* ctx, int frame, int level, uint8_t* dst, size_t dst_stride);

@@ -51,6 +51,8 @@ def lib() -> C.CDLL:
         "orbx_extract_batch_device": (i32, [vp, vp, i32, i32, i32, sz, sz, i32, i32, vp, vp, vp, vp]),
         "orbx_extract_batch": (i32, [vp, vp, i32, i32, i32, sz, sz, i32, i32, vp, vp, vp]),
         "orbx_pyramid_level": (i32, [vp, i32, i32, vp, sz, ip, ip]),
+        "orbx_set_host_pyramid": (i32, [vp, i32]),
+        "orbx_host_pyramid_level": (i32, [vp, i32, C.POINTER(vp), C.POINTER(sz), ip, ip]),
         "orbx_debug_blur_level": (i32, [vp, i32, i32, vp, sz]),
         "orbx_debug_level_points": (i32, [vp, i32, i32, i32, vp, i32]),
         "orbx_debug_trig": (i32, [vp, vp, vp, i32, i32, vp, vp, vp]),

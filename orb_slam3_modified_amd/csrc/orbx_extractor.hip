@@ -523,6 +523,7 @@ void orbx_destroy(orbx_ctx* ctx) {
   free_buffers(ctx);
   auto fr = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
   fr(ctx->d_stage_img); fr(ctx->d_stage_kps); fr(ctx->d_stage_desc); fr(ctx->d_stage_counts); fr(ctx->d_knn_ws);
+  if (ctx->h_pyr) { (void)hipHostFree(ctx->h_pyr); ctx->h_pyr = nullptr; }
   for (int i = 0; i < orbx_ctx::kMaxAux; i++) {
     if (ctx->aux[i]) { (void)hipStreamSynchronize(ctx->aux[i]); (void)hipStreamDestroy(ctx->aux[i]); }
     if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
@@ -630,6 +631,18 @@ int orbx_extract_batch(orbx_ctx* ctx, const uint8_t* imgs, int nframes, int rows
   ORBX_HIP(ctx, hipMemcpyAsync(counts, ctx->d_stage_counts, (size_t)nframes * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   ORBX_HIP(ctx, hipMemcpyAsync(kps, ctx->d_stage_kps, (size_t)nframes * ctx->out_cap * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, ctx->stream));
   ORBX_HIP(ctx, hipMemcpyAsync(desc, ctx->d_stage_desc, (size_t)nframes * ctx->out_cap * 32, hipMemcpyDeviceToHost, ctx->stream));
+  ctx->h_pyr_valid = false;
+  if (ctx->keep_host_pyr && ctx->geo.pyr_bytes > 0) {  // frame 0's levels >= 1 in ONE pinned copy, overlapped with the rest
+    const size_t need = (size_t)ctx->geo.pyr_bytes;
+    if (need > ctx->h_pyr_bytes) {
+      if (ctx->h_pyr) (void)hipHostFree(ctx->h_pyr);
+      ctx->h_pyr = nullptr; ctx->h_pyr_bytes = 0;
+      ORBX_HIP(ctx, hipHostMalloc((void**)&ctx->h_pyr, need, hipHostMallocDefault));
+      ctx->h_pyr_bytes = need;
+    }
+    ORBX_HIP(ctx, hipMemcpyAsync(ctx->h_pyr, ctx->d_pyr, need, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->h_pyr_valid = true;
+  }
   ORBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   // a negative level count marks a quadtree capacity overflow (never expected; fail loudly)
   std::vector<int32_t> ln((size_t)nframes * ctx->nlevels);
@@ -665,6 +678,26 @@ int orbx_pyramid_level(orbx_ctx* ctx, int frame, int level, uint8_t* dst, size_t
   if (level == 0) { src = ctx->last_imgs + (size_t)frame * ctx->last_frame_stride; sp = ctx->last_row_stride; }
   else { src = ctx->d_pyr + (size_t)frame * ctx->geo.pyr_bytes + L.plane_off; sp = L.pitch; }
   ORBX_HIP(ctx, hipMemcpy2D(dst, dst_stride, src, sp, L.w, L.h, hipMemcpyDeviceToHost));
+  return ORBX_OK;
+}
+
+int orbx_set_host_pyramid(orbx_ctx* ctx, int on) {
+  if (!ctx) return ORBX_E_INVALID;
+  ctx->keep_host_pyr = on != 0;
+  if (!on) ctx->h_pyr_valid = false;
+  return ORBX_OK;
+}
+
+int orbx_host_pyramid_level(orbx_ctx* ctx, int level, const uint8_t** data, size_t* stride, int* w, int* h) {
+  if (!ctx || !data || !ctx->d_geo || level < 0 || level >= ctx->nlevels)
+    return ctx ? set_err(ctx, ORBX_E_INVALID, "no such pyramid level") : ORBX_E_INVALID;
+  const LevelGeom& L = ctx->geo.lv[level];
+  if (w) *w = L.w;
+  if (h) *h = L.h;
+  if (level == 0) { *data = nullptr; if (stride) *stride = 0; return ORBX_OK; }  // level 0 is the caller's own image
+  if (!ctx->h_pyr_valid) return set_err(ctx, ORBX_E_INVALID, "host pyramid not enabled (orbx_set_host_pyramid) or no extraction yet");
+  *data = ctx->h_pyr + L.plane_off;
+  if (stride) *stride = (size_t)L.pitch;
   return ORBX_OK;
 }
 

@@ -123,6 +123,9 @@ struct orbx_ctx {
   orbx_keypoint* d_stage_kps = nullptr; uint8_t* d_stage_desc = nullptr; int32_t* d_stage_counts = nullptr;
   int stage_frames = 0;
   unsigned long long* d_knn_ws = nullptr; size_t knn_ws_bytes = 0;  // per-segment partial top-2 of orbx_knn2_allpairs*
+  // host mirror of frame 0's pyramid levels >= 1 (pinned), refreshed by orbx_extract when keep_host_pyr is set
+  bool keep_host_pyr = false;
+  uint8_t* h_pyr = nullptr; size_t h_pyr_bytes = 0; bool h_pyr_valid = false;
   // last extraction (for orbx_pyramid_level / debug dumps)
   const uint8_t* last_imgs = nullptr; size_t last_row_stride = 0, last_frame_stride = 0; int last_nframes = 0;
   // profiling

@@ -3,6 +3,7 @@
 // OpenCV (include/orbx_cv_compat.h).  Writes raw results for tests/test_adapters.py to compare with the oracle.
 //   adapter_demo probe
 //   adapter_demo run <img.raw> <rows> <cols> <nfeatures> <lap0> <lap1> <out.bin> [voc.txt]
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -30,6 +31,33 @@ int main(int argc, char** argv) {
     if (mode == "probe") {
       ORBextractor ex(1000, 1.2f, 8, 20, 7);
       std::printf("DEVICE_OK levels=%d\n", ex.GetLevels());
+      return 0;
+    }
+    if (mode == "stream" && argc >= 6) {
+      // per-frame latency of ORBextractor::operator() the way Tracking sees it (steady_clock around the call, like
+      // Examples/Monocular/mono_euroc.cc:133-143): adapter_demo stream <imgs.raw> <rows> <cols> <nframes> [keep_pyramid]
+      const int rows = std::atoi(argv[3]), cols = std::atoi(argv[4]), nfr = std::atoi(argv[5]);
+      const bool keep = argc >= 7 ? std::atoi(argv[6]) != 0 : false;
+      std::vector<unsigned char> buf((size_t)rows * cols * nfr);
+      { std::ifstream f(argv[2], std::ios::binary); f.read((char*)buf.data(), (std::streamsize)buf.size()); }
+      ORBextractor ex(1000, 1.2f, 8, 20, 7);
+      ex.SetKeepHostPyramid(keep);
+      std::vector<int> lap = {0, 1000};
+      std::vector<cv::KeyPoint> keys;
+      cv::Mat desc;
+      long total = 0;
+      for (int pass = 0; pass < 2; pass++) {   // pass 0 = warm-up
+        total = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int rep = 0; rep < 20; rep++)
+          for (int f = 0; f < nfr; f++) {
+            cv::Mat im(rows, cols, CV_8UC1, buf.data() + (size_t)f * rows * cols);
+            ex(im, cv::Mat(), keys, desc, lap);
+            total += (long)keys.size();
+          }
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (pass == 1) std::printf("STREAM frames=%d ms_per_frame=%.4f features_per_ms=%.1f keep_pyramid=%d\n", 20 * nfr, ms / (20 * nfr), total / ms, (int)keep);
+      }
       return 0;
     }
     if (mode != "run" || argc < 9) return 2;

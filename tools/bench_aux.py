@@ -103,6 +103,20 @@ t0 = time.perf_counter()
 for _ in range(20): ur, dp, kept = ORBmatcher.ComputeStereoMatches(exL, exR, kL, dL, kR, dR, 0.11, 47.9)
 res["compute_stereo_matches"] = {"left": len(kL), "right": len(kR), "kept": int(kept), "ms_per_call": (time.perf_counter() - t0) / 20 * 1e3,
                                  "note": "host keypoints/descriptors in, device pyramids; per-call allocations included"}
+# C++ adapter, one frame per call (what Tracking sees): tests/support/adapter_demo.bin stream
+try:
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_adapters
+    exe = test_adapters._build()
+    raw = "/tmp/stream.raw"
+    frames[:16].tofile(raw)
+    for keep in (0, 1):
+        out = subprocess.run([exe, "stream", raw, "480", "640", "16", str(keep)], capture_output=True, text=True).stdout
+        kv = dict(t.split("=") for t in out.split() if "=" in t)
+        res[f"cpp_operator_call_keep_pyramid_{keep}"] = {"ms_per_frame": float(kv["ms_per_frame"]), "features_per_ms": float(kv["features_per_ms"])}
+except Exception as e:  # the aux bench must not die on this leg
+    res["cpp_operator_call"] = {"error": repr(e)}
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(res, open(os.path.join(ROOT, "gpurun_out", "bench_aux.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))

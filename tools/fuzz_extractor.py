@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the extractor against the oracle (same generator as
+tests/test_gpu_extractor.py::test_random_shapes_and_parameters, more seeds): python tools/fuzz_extractor.py [first] [count]"""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import pyoracle as po
+from orb_slam3_modified_amd import ORBextractor, OrbxError, synth
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+bad = rejected = 0
+for seed in range(first, first + count):
+    rng = np.random.default_rng(1000 + seed)
+    sf = float(np.float32(rng.choice([1.1, 1.15, 1.2, 1.25, 1.33, 1.5, 1.7, 1.9])))
+    nlev = int(rng.integers(1, 9))
+    lo = max(int(np.ceil(70 * sf ** (nlev - 1))) + 2, 90)
+    rows = int(rng.integers(lo, max(700, lo + 200))); cols = int(rng.integers(lo, max(900, lo + 300)))
+    if cols > 8 * rows or rows > 2 * cols:
+        rows = cols = max(rows, cols) // 2 + lo
+    nf = int(rng.choice([30, 150, 700, 1000, 2500, 6000]))
+    ini = int(rng.choice([12, 20, 35])); mn = int(rng.choice([3, 7, ini]))
+    lap = tuple(sorted(rng.integers(0, cols + 50, 2).tolist()))
+    kind = rng.choice(["synth", "noise", "smooth"])
+    if kind == "synth":
+        img = synth.make_stream(1, rows, cols, 4242 + seed)[0]
+    elif kind == "noise":
+        img = rng.integers(0, 256, (rows, cols)).astype(np.uint8)
+    else:
+        img = (synth.make_stream(1, rows, cols, 7 + seed)[0].astype(np.float32) * 0.25 + 90).astype(np.uint8)
+    tag = f"seed {seed}: {cols}x{rows} sf{sf:.2f} L{nlev} nf{nf} th{ini}/{mn} lap{lap} {kind}"
+    try:
+        mono, kps, desc = ORBextractor(nf, sf, nlev, ini, mn)(img, None, lap)
+    except OrbxError as e:
+        rejected += 1
+        print("REJECTED", tag, e)
+        continue
+    okps, odesc, omono = po.OracleExtractor(nf, sf, nlev, ini, mn).extract(img, lap)
+    ok = mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc)
+    if not ok:
+        bad += 1
+        print("MISMATCH", tag, len(kps), len(okps))
+print(f"{count} configurations: {bad} mismatches, {rejected} rejected")
+sys.exit(1 if bad else 0)
