@@ -382,7 +382,9 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
           return set_err(ctx, ORBX_E_CAPACITY, "nfeatures too large for the quadtree kernel's LDS");
         }
       }
-      hipLaunchKernelGGL(k_quadtree, dim3(l1 - l0, nframes, 1), dim3(256), lds, s, ctx->d_geo, ctx->d_cells, b_cand, b_cell_cnt,
+      // small batches are latency-bound on the big levels' workgroups: more waves split more nodes at a time
+      const int qthreads = (nframes * geo.nlevels <= 512) ? 512 : 256;
+      hipLaunchKernelGGL(k_quadtree, dim3(l1 - l0, nframes, 1), dim3(qthreads), lds, s, ctx->d_geo, ctx->d_cells, b_cand, b_cell_cnt,
                          b_pts, b_lvl_kp, b_lvl_n, node_cap, scan_cap, pts_cap, l0);
       return ORBX_OK;
     };

@@ -461,7 +461,7 @@ __device__ __forceinline__ int wave_partition(unsigned long long* v, int first, 
 // std::sort(v, v + n) with the reference's (count, UL.x) comparator, exact libstdc++ permutation (ties included),
 // by the whole workgroup: level-synchronous introsort loop (one wave per pending segment and round), then a stable
 // rank inside every final segment (== __final_insertion_sort).  tmp: n elements; seg: n words; q0/q1: n/8+2 words each;
-// idx: NW * 2 * n int16.  All in LDS.  Ends with a barrier.
+// idx: 2 * n int16.  All in LDS.  Ends with a barrier.
 __device__ __forceinline__ void block_gnu_sort(unsigned long long* v, int n, unsigned long long* tmp, uint32_t* seg,
                                                uint32_t* q0, uint32_t* q1, int16_t* idx, int* sh_cnt) {
   const int T = blockDim.x, t = threadIdx.x, lane = t & 63, w = t >> 6, NW = T >> 6;
@@ -470,8 +470,8 @@ __device__ __forceinline__ void block_gnu_sort(unsigned long long* v, int n, uns
     if (t == 0) { q0[0] = (uint32_t)n << 12 | (uint32_t)(2 * (31 - __clz(n))) << 24; *sh_cnt = 0; }
     __syncthreads();
     int ncur = 1;
-    int16_t* ia = idx + (size_t)w * 2 * n;
-    int16_t* ir = ia + n;
+    int16_t* ia = idx;       // segments of one round are disjoint: every wave indexes the shared scratch by position
+    int16_t* ir = idx + n;
     while (ncur > 0) {
       for (int sidx = w; sidx < ncur; sidx += NW) {
         const uint32_t pk = q0[sidx];
@@ -483,7 +483,7 @@ __device__ __forceinline__ void block_gnu_sort(unsigned long long* v, int n, uns
         }
         if (lane == 0) orbx_sort::move_median_to_first(v, f, f + 1, f + (l - f) / 2, l - 1);
         wave_lds_sync();
-        const int cut = wave_partition(v, f, l, ia, ir);
+        const int cut = wave_partition(v, f, l, ia + f, ir + f);
 #pragma unroll
         for (int c = 0; c < 2; c++) {
           const int cf = c ? cut : f, cl = c ? l : cut;
@@ -736,27 +736,34 @@ __device__ __forceinline__ void quadtree_body(const DeviceGeom* __restrict__ g, 
       }
       for (int i = t; i < nL; i += T) flag[i] = 0;
       __syncthreads();
-      if (t == 0) {
-        int running = nL, js = 0;
-        for (int j = m - 1; j >= 0; j--) {
-          const int4 c = kids[j];
-          running += (c.x > 0) + (c.y > 0) + (c.z > 0) + (c.w > 0) - 1;
-          if (running >= N) { js = j; break; }
-        }
-        sh_jstar = js;
+      // jstar = the sorted position at which the reference stops splitting (it walks j = m-1 down and stops as soon as
+      // the list would hold >= N nodes, :746-751): the inclusive prefix over r = m-1-j of (children - 1) is monotone,
+      // so the stop is the first r whose prefix reaches N - nL.
+      for (int r = t; r < m; r += T) {
+        const int4 c = kids[m - 1 - r];
+        scan[r] = (unsigned long long)((c.x > 0) + (c.y > 0) + (c.z > 0) + (c.w > 0) - 1);
+      }
+      if (t == 0) sh_jstar = 0;
+      __syncthreads();
+      block_excl_scan(scan, m, wt);
+      for (int r = t; r < m; r += T) {
+        const int4 c = kids[m - 1 - r];
+        const int before = nL + (int)scan[r];
+        const int after = before + (c.x > 0) + (c.y > 0) + (c.z > 0) + (c.w > 0) - 1;
+        if (after >= N && before < N) sh_jstar = m - 1 - r;
       }
       __syncthreads();
       const int jstar = sh_jstar;
       const int mp = m - jstar;  // processed nodes: sorted positions jstar..m-1 (largest first in time)
       for (int j = jstar + t; j < m; j += T) flag[(uint32_t)EA[j]] = j + 1;
       __syncthreads();
-      for (int i = w; i < nL; i += NW) {
-        const QNode nd = LA[i];
-        if (flag[i]) {
-          wave_split(nd, cur, nxt, true);
-        } else {
-          for (int e = lane; e < nd.count; e += 64) nxt[nd.start + e] = cur[nd.start + e];
-        }
+      // only the processed nodes move points: partition into the scratch buffer, then copy the segment back in place
+      // (the untouched nodes, the large majority in this phase, keep their points where they are: no buffer swap)
+      for (int jj = w; jj < mp; jj += NW) {
+        const QNode nd = LA[(uint32_t)EA[jstar + jj]];
+        wave_split(nd, cur, nxt, true);
+        wave_lds_sync();
+        for (int e = lane; e < nd.count; e += 64) cur[nd.start + e] = nxt[nd.start + e];
       }
       for (int jj = t; jj < mp; jj += T) {
         const int4 c = kids[jstar + jj];
@@ -799,7 +806,6 @@ __device__ __forceinline__ void quadtree_body(const DeviceGeom* __restrict__ g, 
       __syncthreads();
       { QNode* tl = LA; LA = LB; LB = tl; }
       { unsigned long long* te = EA; EA = EB; EB = te; }
-      { uint32_t* tp = cur; cur = nxt; nxt = tp; }
       nL = front + keepTot;
       nE = qtot;
       if (nL >= N || nL == prevSize) finish = true;
@@ -822,7 +828,7 @@ __device__ __forceinline__ void quadtree_body(const DeviceGeom* __restrict__ g, 
   QT_ACC(4);
 }
 
-__global__ __launch_bounds__(256) void k_quadtree(const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
+__global__ __launch_bounds__(512) void k_quadtree(const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
                                                   const uint32_t* __restrict__ cand, const int32_t* __restrict__ cell_cnt,
                                                   uint32_t* __restrict__ pts, uint32_t* __restrict__ lvl_kp,
                                                   int32_t* __restrict__ lvl_n, int node_cap, int scan_cap, int pts_cap, int level_base) {
