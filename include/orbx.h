@@ -69,7 +69,8 @@ int orbx_extract(orbx_ctx* ctx, const uint8_t* img, int rows, int cols, size_t s
  * HBM (the batch-replay / benchmark path; frames are independent).
  *   d_imgs   : frame f, row r at d_imgs + f*frame_stride + r*row_stride
  *   d_kps    : [nframes][capacity] orbx_keypoint      d_desc : [nframes][capacity][32] bytes
- *   d_counts : [nframes][2] int32 = {n keypoints, monoIndex}
+ *   d_counts : [nframes][2] int32 = {n keypoints, monoIndex}; n = -1 marks a frame whose quadtree overflowed a level's
+ *              capacity (never expected; the host entry points turn it into ORBX_E_CAPACITY)
  * Asynchronous on `stream`. */
 int orbx_extract_batch_device(orbx_ctx* ctx, const uint8_t* d_imgs, int nframes, int rows, int cols, size_t row_stride,
                               size_t frame_stride, int lap0, int lap1, orbx_keypoint* d_kps, uint8_t* d_desc,

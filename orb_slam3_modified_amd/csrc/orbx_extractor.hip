@@ -524,7 +524,8 @@ void orbx_destroy(orbx_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   free_buffers(ctx);
   auto fr = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
-  fr(ctx->d_stage_img); fr(ctx->d_stage_kps); fr(ctx->d_stage_desc); fr(ctx->d_stage_counts); fr(ctx->d_knn_ws);
+  fr(ctx->d_stage_img); fr(ctx->d_stage_out); fr(ctx->d_knn_ws);
+  if (ctx->h_stage_out) { (void)hipHostFree(ctx->h_stage_out); ctx->h_stage_out = nullptr; }
   if (ctx->h_pyr) { (void)hipHostFree(ctx->h_pyr); ctx->h_pyr = nullptr; }
   for (int i = 0; i < orbx_ctx::kMaxAux; i++) {
     if (ctx->aux[i]) { (void)hipStreamSynchronize(ctx->aux[i]); (void)hipStreamDestroy(ctx->aux[i]); }
@@ -596,6 +597,18 @@ int orbx_extract_batch_device(orbx_ctx* ctx, const uint8_t* d_imgs, int nframes,
   return ORBX_OK;
 }
 
+// Staging of the host-buffer entry points: one device block [keypoints | descriptors | counts] per call and a pinned
+// host mirror of it, so the results come back in ONE device-to-host copy.
+struct StageLayout { size_t kps_off, desc_off, counts_off, bytes; };
+static StageLayout stage_layout(const orbx_ctx* ctx, int nframes) {
+  StageLayout L;
+  L.kps_off = 0;
+  L.desc_off = ((size_t)nframes * ctx->out_cap * sizeof(orbx_keypoint) + 255) / 256 * 256;
+  L.counts_off = L.desc_off + ((size_t)nframes * ctx->out_cap * 32 + 255) / 256 * 256;
+  L.bytes = L.counts_off + ((size_t)nframes * 2 * sizeof(int32_t) + 255) / 256 * 256;
+  return L;
+}
+
 static int ensure_stage(orbx_ctx* ctx, int nframes, size_t img_bytes) {
   if (img_bytes > ctx->stage_img_bytes) {
     if (ctx->d_stage_img) (void)hipFree(ctx->d_stage_img);
@@ -604,12 +617,12 @@ static int ensure_stage(orbx_ctx* ctx, int nframes, size_t img_bytes) {
     ctx->stage_img_bytes = img_bytes;
   }
   if (nframes > ctx->stage_frames) {
-    auto fr = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
-    fr(ctx->d_stage_kps); fr(ctx->d_stage_desc); fr(ctx->d_stage_counts);
-    ctx->stage_frames = 0;
-    ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_stage_kps, (size_t)nframes * ctx->out_cap * sizeof(orbx_keypoint)));
-    ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_stage_desc, (size_t)nframes * ctx->out_cap * 32));
-    ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_stage_counts, (size_t)nframes * 2 * sizeof(int32_t)));
+    if (ctx->d_stage_out) (void)hipFree(ctx->d_stage_out);
+    if (ctx->h_stage_out) (void)hipHostFree(ctx->h_stage_out);
+    ctx->d_stage_out = nullptr; ctx->h_stage_out = nullptr; ctx->stage_frames = 0;
+    const StageLayout L = stage_layout(ctx, nframes);
+    ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_stage_out, L.bytes));
+    ORBX_HIP(ctx, hipHostMalloc((void**)&ctx->h_stage_out, L.bytes, hipHostMallocDefault));
     ctx->stage_frames = nframes;
   }
   return ORBX_OK;
@@ -624,15 +637,24 @@ int orbx_extract_batch(orbx_ctx* ctx, const uint8_t* imgs, int nframes, int rows
   const size_t pitch = (size_t)round_up(cols, 64), fbytes = pitch * rows;
   int rc = ensure_stage(ctx, nframes, fbytes * nframes);
   if (rc != ORBX_OK) return rc;
+  const StageLayout L = stage_layout(ctx, ctx->stage_frames);   // the block was laid out for its allocated capacity
   for (int f = 0; f < nframes; f++)
     ORBX_HIP(ctx, hipMemcpy2DAsync(ctx->d_stage_img + f * fbytes, pitch, imgs + f * frame_stride, row_stride, cols, rows,
                                    hipMemcpyHostToDevice, ctx->stream));
-  rc = orbx_extract_batch_device(ctx, ctx->d_stage_img, nframes, rows, cols, pitch, fbytes, lap0, lap1, ctx->d_stage_kps,
-                                 ctx->d_stage_desc, ctx->d_stage_counts, ctx->stream);
+  uint8_t* d = ctx->d_stage_out;
+  rc = orbx_extract_batch_device(ctx, ctx->d_stage_img, nframes, rows, cols, pitch, fbytes, lap0, lap1,
+                                 (orbx_keypoint*)(d + L.kps_off), d + L.desc_off, (int32_t*)(d + L.counts_off), ctx->stream);
   if (rc != ORBX_OK) return rc;
-  ORBX_HIP(ctx, hipMemcpyAsync(counts, ctx->d_stage_counts, (size_t)nframes * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-  ORBX_HIP(ctx, hipMemcpyAsync(kps, ctx->d_stage_kps, (size_t)nframes * ctx->out_cap * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, ctx->stream));
-  ORBX_HIP(ctx, hipMemcpyAsync(desc, ctx->d_stage_desc, (size_t)nframes * ctx->out_cap * 32, hipMemcpyDeviceToHost, ctx->stream));
+  // one copy for everything the caller gets back (sized by what this call produced)
+  const size_t kb = (size_t)nframes * ctx->out_cap * sizeof(orbx_keypoint), db = (size_t)nframes * ctx->out_cap * 32,
+               cb = (size_t)nframes * 2 * sizeof(int32_t);
+  if (nframes == ctx->stage_frames) {
+    ORBX_HIP(ctx, hipMemcpyAsync(ctx->h_stage_out, d, L.counts_off + cb, hipMemcpyDeviceToHost, ctx->stream));
+  } else {  // a smaller batch than the block was laid out for: three ranges
+    ORBX_HIP(ctx, hipMemcpyAsync(ctx->h_stage_out + L.kps_off, d + L.kps_off, kb, hipMemcpyDeviceToHost, ctx->stream));
+    ORBX_HIP(ctx, hipMemcpyAsync(ctx->h_stage_out + L.desc_off, d + L.desc_off, db, hipMemcpyDeviceToHost, ctx->stream));
+    ORBX_HIP(ctx, hipMemcpyAsync(ctx->h_stage_out + L.counts_off, d + L.counts_off, cb, hipMemcpyDeviceToHost, ctx->stream));
+  }
   ctx->h_pyr_valid = false;
   if (ctx->keep_host_pyr && ctx->geo.pyr_bytes > 0) {  // frame 0's levels >= 1 in ONE pinned copy, overlapped with the rest
     const size_t need = (size_t)ctx->geo.pyr_bytes;
@@ -646,10 +668,12 @@ int orbx_extract_batch(orbx_ctx* ctx, const uint8_t* imgs, int nframes, int rows
     ctx->h_pyr_valid = true;
   }
   ORBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  // a negative level count marks a quadtree capacity overflow (never expected; fail loudly)
-  std::vector<int32_t> ln((size_t)nframes * ctx->nlevels);
-  ORBX_HIP(ctx, hipMemcpy(ln.data(), ctx->d_lvl_n, ln.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-  for (int32_t v : ln) if (v < 0) return set_err(ctx, ORBX_E_CAPACITY, "quadtree produced more nodes than the level capacity");
+  std::memcpy(kps, ctx->h_stage_out + L.kps_off, kb);
+  std::memcpy(desc, ctx->h_stage_out + L.desc_off, db);
+  std::memcpy(counts, ctx->h_stage_out + L.counts_off, cb);
+  // k_assemble reports a quadtree capacity overflow (never expected) as a negative keypoint count: fail loudly
+  for (int f = 0; f < nframes; f++)
+    if (counts[2 * f] < 0) return set_err(ctx, ORBX_E_CAPACITY, "quadtree produced more nodes than the level capacity");
   return ORBX_OK;
 }
 

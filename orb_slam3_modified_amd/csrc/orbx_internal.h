@@ -120,7 +120,8 @@ struct orbx_ctx {
   uint2* d_kp_list = nullptr;      // [batch][out_cap] {packed point, level | output slot << 8}, level-major order
   // single-frame staging (orbx_extract)
   uint8_t* d_stage_img = nullptr; size_t stage_img_bytes = 0;
-  orbx_keypoint* d_stage_kps = nullptr; uint8_t* d_stage_desc = nullptr; int32_t* d_stage_counts = nullptr;
+  uint8_t* d_stage_out = nullptr;   // [keypoints | descriptors | counts] of the host-buffer entry points
+  uint8_t* h_stage_out = nullptr;   // pinned host mirror of d_stage_out (one D2H copy per call)
   int stage_frames = 0;
   unsigned long long* d_knn_ws = nullptr; size_t knn_ws_bytes = 0;  // per-segment partial top-2 of orbx_knn2_allpairs*
   // host mirror of frame 0's pyramid levels >= 1 (pinned), refreshed by orbx_extract when keep_host_pyr is set

@@ -870,10 +870,17 @@ __global__ __launch_bounds__(256) void k_assemble(const DeviceGeom* __restrict__
   __shared__ unsigned long long wt[8];
   __shared__ int loff[kMaxLevels + 1];
   const int t = threadIdx.x, T = blockDim.x, frame = blockIdx.x;
+  __shared__ int s_overflow;
   if (t == 0) {
-    int acc = 0;
-    for (int l = 0; l < g->nlevels; l++) { loff[l] = acc; acc += max(lvl_n[frame * g->nlevels + l], 0); }
+    int acc = 0, ovf = 0;
+    for (int l = 0; l < g->nlevels; l++) {
+      const int nl = lvl_n[frame * g->nlevels + l];   // negative = the quadtree overflowed this level's capacity
+      ovf |= nl < 0;
+      loff[l] = acc;
+      acc += max(nl, 0);
+    }
     loff[g->nlevels] = acc;
+    s_overflow = ovf;
   }
   __syncthreads();
   const int total = min(loff[g->nlevels], g->out_cap);
@@ -899,7 +906,7 @@ __global__ __launch_bounds__(256) void k_assemble(const DeviceGeom* __restrict__
     const int slot = st ? total - 1 - pre : i - pre;
     kp_list[(long long)frame * g->out_cap + i] = make_uint2(p, (uint32_t)l | ((uint32_t)slot << 8));
   }
-  if (t == 0) { counts[frame * 2] = total; counts[frame * 2 + 1] = total - nst; }
+  if (t == 0) { counts[frame * 2] = s_overflow ? -1 : total; counts[frame * 2 + 1] = total - nst; }
 }
 
 // ------------------------------------------------------------------------------------------------
