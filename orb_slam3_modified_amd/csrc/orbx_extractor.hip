@@ -334,7 +334,9 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
   // K4a: 7x7 fixed-point Gaussian of every level (the reference blurs each level that holds keypoints).  It only needs
   // the pyramid, and it is VALU-bound while the quadtree that follows FAST is latency-bound with few workgroups, so it
   // is forked onto a second stream behind FAST and joined before the descriptors (ORBX_FORK_BLUR=0 disables).
-  const bool fork_blur = ctx->fork_blur && !ctx->profiling;
+  // small batches (the single-frame operator() path) are latency-bound: a stream fork costs more than it hides there
+  const bool small_batch = nframes * geo.nlevels <= 512;
+  const bool fork_blur = ctx->fork_blur && !ctx->profiling && !small_batch;
   hipStream_t bst = st;
   if (fork_blur) {
     bst = ctx->aux[orbx_ctx::kMaxAux - 1 - (f0 != 0)];
@@ -388,7 +390,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
                          b_pts, b_lvl_kp, b_lvl_n, node_cap, scan_cap, pts_cap, l0);
       return ORBX_OK;
     };
-    const int nbig = geo.nlevels >= 4 ? kQtBigLevels : geo.nlevels;
+    const int nbig = (geo.nlevels >= 4 && !small_batch) ? kQtBigLevels : geo.nlevels;  // small batch: one launch, all levels
     int qrc = ORBX_OK;
     if (nbig < geo.nlevels && !ctx->profiling) {
       hipStream_t qst = ctx->aux[orbx_ctx::kMaxAux - 5 - sb];
