@@ -527,6 +527,7 @@ void orbx_destroy(orbx_ctx* ctx) {
   free_buffers(ctx);
   auto fr = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
   fr(ctx->d_stage_img); fr(ctx->d_stage_out); fr(ctx->d_knn_ws);
+  ctx->arena.release();
   if (ctx->h_stage_out) { (void)hipHostFree(ctx->h_stage_out); ctx->h_stage_out = nullptr; }
   if (ctx->h_pyr) { (void)hipHostFree(ctx->h_pyr); ctx->h_pyr = nullptr; }
   for (int i = 0; i < orbx_ctx::kMaxAux; i++) {

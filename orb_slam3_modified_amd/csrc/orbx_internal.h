@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/orbx.h"
@@ -82,6 +84,48 @@ struct DeviceGeom {
 
 }  // namespace orbx
 
+namespace orbx {
+// Grow-only device scratch for the host-buffer convenience entry points (grid / search / stereo): a bump allocator that
+// is rewound at the start of each call, so steady-state calls do no hipMalloc / hipFree.  Each of those entry points
+// synchronises its stream before returning, so nothing is in flight when the next call rewinds.
+struct DeviceArena {
+  std::vector<std::pair<uint8_t*, size_t>> blocks;
+  size_t off = 0, hint = 1 << 20;
+  void* alloc(size_t bytes, hipError_t* err) {
+    bytes = (bytes + 255) / 256 * 256;
+    if (bytes == 0) bytes = 256;
+    if (blocks.empty() || off + bytes > blocks.back().second) {
+      size_t total = 0;
+      for (auto& b : blocks) total += b.second;
+      const size_t sz = std::max(std::max(bytes, hint), 2 * total);
+      uint8_t* p = nullptr;
+      *err = hipMalloc((void**)&p, sz);
+      if (*err != hipSuccess) return nullptr;
+      blocks.push_back(std::make_pair(p, sz));
+      off = 0;
+    }
+    *err = hipSuccess;
+    void* r = blocks.back().first + off;
+    off += bytes;
+    return r;
+  }
+  void rewind() {
+    if (blocks.size() > 1) {   // consolidate: next call gets one block large enough for everything seen so far
+      size_t total = 0;
+      for (auto& b : blocks) { total += b.second; (void)hipFree(b.first); }
+      blocks.clear();
+      hint = std::max(hint, total);
+    }
+    off = 0;
+  }
+  void release() {
+    for (auto& b : blocks) (void)hipFree(b.first);
+    blocks.clear();
+    off = 0;
+  }
+};
+}  // namespace orbx
+
 struct orbx_ctx {
   int nfeatures, nlevels, ini_th, min_th, device;
   double scale_factor;
@@ -123,6 +167,7 @@ struct orbx_ctx {
   uint8_t* d_stage_out = nullptr;   // [keypoints | descriptors | counts] of the host-buffer entry points
   uint8_t* h_stage_out = nullptr;   // pinned host mirror of d_stage_out (one D2H copy per call)
   int stage_frames = 0;
+  orbx::DeviceArena arena;   // scratch of the grid / search / stereo entry points
   unsigned long long* d_knn_ws = nullptr; size_t knn_ws_bytes = 0;  // per-segment partial top-2 of orbx_knn2_allpairs*
   // host mirror of frame 0's pyramid levels >= 1 (pinned), refreshed by orbx_extract when keep_host_pyr is set
   bool keep_host_pyr = false;

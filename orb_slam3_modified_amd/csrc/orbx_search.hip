@@ -288,11 +288,20 @@ __global__ __launch_bounds__(1024) void k_stereo_filter(int N, float* __restrict
   if (t == 0) *kept_out = s_kept;
 }
 
+// Scratch buffers of one entry-point call: slices of the context's arena (rewound by ArenaScope at the call's start).
+static thread_local DeviceArena* t_arena = nullptr;
+struct ArenaScope {
+  explicit ArenaScope(orbx_ctx* ctx) { ctx->arena.rewind(); t_arena = &ctx->arena; }
+  ~ArenaScope() { t_arena = nullptr; }
+};
 template <typename T>
 struct DBuf {
   T* p = nullptr;
-  ~DBuf() { if (p) (void)hipFree(p); }
-  hipError_t alloc(size_t n) { return hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T)); }
+  hipError_t alloc(size_t n) {
+    hipError_t e = hipSuccess;
+    p = (T*)t_arena->alloc(std::max<size_t>(n, 1) * sizeof(T), &e);
+    return e;
+  }
 };
 
 struct GridOnDevice {
@@ -368,6 +377,7 @@ int orbx_features_in_area(orbx_ctx* ctx, const orbx_keypoint* kps, int n, float 
       !(max_x > min_x) || !(max_y > min_y))
     return ctx ? set_err(ctx, ORBX_E_INVALID, "orbx_features_in_area: bad arguments") : ORBX_E_INVALID;
   ORBX_HIP(ctx, hipSetDevice(ctx->device));
+  ArenaScope scope(ctx);
   GridOnDevice g;
   int rc = build_grid(ctx, kps, n, min_x, min_y, max_x, max_y, g);
   if (rc != ORBX_OK) return rc;
@@ -405,6 +415,7 @@ int orbx_search_for_initialization(orbx_ctx* ctx, const orbx_keypoint* kps1, con
   }
   const int nq = (int)qi.size();
   if (nq == 0) return ORBX_OK;
+  ArenaScope scope(ctx);
   GridOnDevice g;
   int rc = build_grid(ctx, kps2, n2, min_x, min_y, max_x, max_y, g);
   if (rc != ORBX_OK) return rc;
@@ -514,6 +525,7 @@ int orbx_stereo_matches(orbx_ctx* left, orbx_ctx* right, const orbx_keypoint* kp
     }
     sg.scale[l] = left->scale[l]; sg.inv_scale[l] = left->inv_scale[l];
   }
+  ArenaScope scope(ctx);
   DBuf<orbx_keypoint> dkl, dkr;
   DBuf<uint8_t> ddl, ddr;
   DBuf<float> du, dd;
