@@ -110,6 +110,11 @@ int orbx_debug_level_points(orbx_ctx* ctx, int frame, int level, int stage, uint
 int orbx_debug_trig(orbx_ctx* ctx, const float* y, const float* x, int n, int angle_is_input, float* angle, float* a,
                     float* b);
 
+/* Exhaustive test hook for the device cos/sin path: *hash = order-independent 64-bit digest of
+ * (cosf, sinf)(angle * pi/180) over the `count` float bit patterns starting at `first_bits`; the oracle computes the same
+ * digest with the host glibc, so one call covers every angle in [0, 360] (1.13e9 floats). */
+int orbx_debug_trig_hash(orbx_ctx* ctx, uint32_t first_bits, uint32_t count, uint64_t* hash);
+
 /* Counter-calibration hook: copies nbytes (multiple of 16) from d_src to d_dst on the device with `width` (1, 4 or
  * 16) bytes per lane per access — a kernel with exactly known HBM traffic, used by tools/pmc_traffic.py to calibrate
  * rocprofv3's FETCH_SIZE / WRITE_SIZE for the access widths the extractor kernels use.  Asynchronous on `stream`. */

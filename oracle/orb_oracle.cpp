@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <list>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -720,6 +721,35 @@ void orbo_cos_sin_deg(float angle_deg, float* a, float* b) {
   float r = angle_deg * factorPI;
   *a = p_cosf(r);
   *b = p_sinf(r);
+}
+// Order-independent 64-bit digest of (cosf, sinf)(angle * factorPI) over the float bit patterns [first, first + count):
+// the CPU side of the exhaustive device check (every angle fastAtan2 can return lies in [0, 360]).
+uint64_t orbo_trig_hash(uint32_t first, uint32_t count) {
+  const float factorPI = (float)(M_PI / 180.f);
+  unsigned nt = std::thread::hardware_concurrency();
+  if (nt == 0) nt = 1;
+  std::vector<uint64_t> part(nt, 0);
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; t++)
+    th.emplace_back([&, t] {
+      uint64_t h = 0;
+      for (uint64_t i = t; i < count; i += nt) {
+        const uint32_t bits = first + (uint32_t)i;
+        float ang;
+        std::memcpy(&ang, &bits, 4);
+        const float r = ang * factorPI;
+        const float a = p_cosf(r), b = p_sinf(r);
+        uint32_t ab, bb;
+        std::memcpy(&ab, &a, 4);
+        std::memcpy(&bb, &b, 4);
+        h += ((uint64_t)ab * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)bb * 0xC2B2AE3D27D4EB4Full + bits);
+      }
+      part[t] = h;
+    });
+  for (auto& x : th) x.join();
+  uint64_t h = 0;
+  for (uint64_t v : part) h += v;
+  return h;
 }
 int orbo_distribute(const void* cand, int n, int minX, int maxX, int minY, int maxY, int N, void* dst, int cap) {
   std::vector<KeyPt> c((const KeyPt*)cand, (const KeyPt*)cand + n);

@@ -57,6 +57,8 @@ def lib() -> C.CDLL:
         L.orbo_cos_sin_deg.argtypes = [C.c_float, fp, fp]
         L.orbo_distribute.restype = C.c_int
         L.orbo_distribute.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+        L.orbo_trig_hash.restype = C.c_uint64
+        L.orbo_trig_hash.argtypes = [C.c_uint32, C.c_uint32]
         L.orbo_pattern.restype = C.POINTER(C.c_int8)
         _lib = L
     return _lib
@@ -153,6 +155,11 @@ def cos_sin_deg(angle_deg: float):
     a, b = C.c_float(0), C.c_float(0)
     lib().orbo_cos_sin_deg(angle_deg, C.byref(a), C.byref(b))
     return a.value, b.value
+
+
+def trig_hash(first_bits: int, count: int) -> int:
+    """64-bit digest of (cosf, sinf)(angle * pi/180) over `count` consecutive float bit patterns (see orbx_debug_trig_hash)."""
+    return int(lib().orbo_trig_hash(first_bits, count))
 
 
 def distribute(cand: np.ndarray, minX, maxX, minY, maxY, N) -> np.ndarray:

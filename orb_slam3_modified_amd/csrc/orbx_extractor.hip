@@ -821,6 +821,22 @@ int orbx_debug_trig(orbx_ctx* ctx, const float* y, const float* x, int n, int an
   return ORBX_OK;
 }
 
+int orbx_debug_trig_hash(orbx_ctx* ctx, uint32_t first_bits, uint32_t count, uint64_t* hash) {
+  if (!ctx || !hash) return ORBX_E_INVALID;
+  ORBX_HIP(ctx, hipSetDevice(ctx->device));
+  unsigned long long* d = nullptr;
+  ORBX_HIP(ctx, hipMalloc((void**)&d, sizeof(unsigned long long)));
+  ORBX_HIP(ctx, hipMemsetAsync(d, 0, sizeof(unsigned long long), ctx->stream));
+  if (count) hipLaunchKernelGGL(k_debug_trig_hash, dim3(256 * 32), dim3(256), 0, ctx->stream, first_bits, count, d);
+  ORBX_HIP(ctx, hipGetLastError());
+  unsigned long long h = 0;
+  ORBX_HIP(ctx, hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  ORBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  (void)hipFree(d);
+  *hash = (uint64_t)h;
+  return ORBX_OK;
+}
+
 int orbx_debug_calib_copy(orbx_ctx* ctx, const void* d_src, void* d_dst, size_t nbytes, int width, void* stream) {
   if (!ctx || !d_src || !d_dst || (width != 1 && width != 4 && width != 16) || nbytes % 16 != 0) return ORBX_E_INVALID;
   if (nbytes == 0) return ORBX_OK;

@@ -1242,6 +1242,23 @@ __global__ void k_debug_trig(const float* __restrict__ y, const float* __restric
   b[i] = orbx_glibc::sinf_exact(r);
 }
 
+// Exhaustive check of the device cos/sin path: an order-independent 64-bit digest of (cos, sin)(angle * factorPI) over
+// the float bit patterns [first, first + count) — the oracle computes the same digest with the host glibc.
+__global__ __launch_bounds__(256) void k_debug_trig_hash(uint32_t first, uint32_t count, unsigned long long* __restrict__ out) {
+  const float factorPI = (float)(3.14159265358979323846 / 180.f);
+  unsigned long long h = 0;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += (unsigned long long)gridDim.x * blockDim.x) {
+    const uint32_t bits = first + (uint32_t)i;
+    const float r = __fmul_rn(__uint_as_float(bits), factorPI);
+    const uint32_t ab = __float_as_uint(orbx_glibc::cosf_exact(r)), bb = __float_as_uint(orbx_glibc::sinf_exact(r));
+    h += ((unsigned long long)ab * 0x9E3779B97F4A7C15ull) ^ ((unsigned long long)bb * 0xC2B2AE3D27D4EB4Full + bits);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, h);
+}
+
 // Calibration kernel for the rocprofv3 FETCH_SIZE / WRITE_SIZE counters (MI355X_MICROARCH.md "HBM": the counters
 // are only calibrated for wide streaming reads): copies n bytes with W bytes per lane per access (W = 1, 4, 16),
 // i.e. a kernel whose HBM traffic is known exactly, in the access widths the extractor kernels use.

@@ -133,6 +133,12 @@ class ORBextractor:
         check(self._L.orbx_debug_trig(self._ctx, ptr(y), ptr(xx), n, int(x is None), ptr(ang), ptr(a), ptr(b)), self._ctx)
         return ang[:n], a[:n], b[:n]
 
+    def debug_trig_hash(self, first_bits: int, count: int) -> int:
+        """Digest of the device (cos, sin)(angle * pi/180) over `count` consecutive float bit patterns (exhaustive test hook)."""
+        h = C.c_uint64(0)
+        check(self._L.orbx_debug_trig_hash(self._ctx, first_bits, count, C.byref(h)), self._ctx)
+        return int(h.value)
+
     def debug_calib_copy(self, d_src: int, d_dst: int, nbytes: int, width: int, stream: int = 0):
         """Known-traffic device copy (counter calibration, tools/pmc_traffic.py)."""
         check(self._L.orbx_debug_calib_copy(self._ctx, ptr(d_src), ptr(d_dst), nbytes, width, ptr(stream)), self._ctx)

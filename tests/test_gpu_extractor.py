@@ -243,3 +243,14 @@ def test_random_shapes_and_parameters(seed):
     except OrbxError as e:
         pytest.skip(f"configuration rejected loudly ({e}); rows={rows} cols={cols} sf={sf} L={nlev}")
     assert_same(res, po.OracleExtractor(nf, sf, nlev, ini, mn).extract(img, lap), f"{cols}x{rows} sf{sf} L{nlev} nf{nf} th{ini}/{mn} lap{lap}")
+
+
+def test_device_cos_sin_exhaustive_over_all_angles():
+    """Every float angle in [0, 360] (1 136 000 000 bit patterns): the device's glibc-exact cosf/sinf of angle * pi/180
+    against the host glibc, compared through an order-independent 64-bit digest computed on both sides."""
+    gpu = ORBextractor(100, 1.2, 1, 20, 7)
+    last = int(np.float32(360.0).view(np.uint32))
+    assert last + 1 == 1135869953
+    for first, count in ((0, 400_000_000), (400_000_000, 400_000_000), (800_000_000, last + 1 - 800_000_000)):
+        assert gpu.debug_trig_hash(first, count) == po.trig_hash(first, count), (first, count)
+    assert gpu.debug_trig_hash(5, 1000) != gpu.debug_trig_hash(6, 1000)        # the digest is input-sensitive
