@@ -115,6 +115,10 @@ int orbx_debug_trig(orbx_ctx* ctx, const float* y, const float* x, int n, int an
  * digest with the host glibc, so one call covers every angle in [0, 360] (1.13e9 floats). */
 int orbx_debug_trig_hash(orbx_ctx* ctx, uint32_t first_bits, uint32_t count, uint64_t* hash);
 
+/* The same for cv::fastAtan2: digest over `count` pseudo-random integer moment pairs (|m| <= 3e6, the range IC_Angle
+ * produces; every 16th pair has m10 = 0) generated from `seed` by a fixed integer mix on both sides. */
+int orbx_debug_atan_hash(orbx_ctx* ctx, uint32_t seed, uint32_t count, uint64_t* hash);
+
 /* Counter-calibration hook: copies nbytes (multiple of 16) from d_src to d_dst on the device with `width` (1, 4 or
  * 16) bytes per lane per access — a kernel with exactly known HBM traffic, used by tools/pmc_traffic.py to calibrate
  * rocprofv3's FETCH_SIZE / WRITE_SIZE for the access widths the extractor kernels use.  Asynchronous on `stream`. */

@@ -751,6 +751,32 @@ uint64_t orbo_trig_hash(uint32_t first, uint32_t count) {
   for (uint64_t v : part) h += v;
   return h;
 }
+// Digest of fastAtan2 over `count` pseudo-random integer moment pairs (m01, m10), |m| <= 3e6 (the range IC_Angle can
+// produce), derived from the index by a fixed integer mix — the CPU side of orbx_debug_atan_hash.
+static inline uint32_t mix32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+uint64_t orbo_atan_hash(uint32_t seed, uint32_t count) {
+  unsigned nt = std::thread::hardware_concurrency();
+  if (nt == 0) nt = 1;
+  std::vector<uint64_t> part(nt, 0);
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; t++)
+    th.emplace_back([&, t] {
+      uint64_t h = 0;
+      for (uint64_t i = t; i < count; i += nt) {
+        const uint32_t a = mix32(seed + 2u * (uint32_t)i), b = mix32(seed + 2u * (uint32_t)i + 1u);
+        const int m01 = (int)(a % 6000001u) - 3000000, m10 = (b & 15u) == 0 ? 0 : (int)(b % 6000001u) - 3000000;
+        const float ang = fast_atan2((float)m01, (float)m10);
+        uint32_t bits;
+        std::memcpy(&bits, &ang, 4);
+        h += ((uint64_t)bits * 0x9E3779B97F4A7C15ull) ^ (uint64_t)(uint32_t)i;
+      }
+      part[t] = h;
+    });
+  for (auto& x : th) x.join();
+  uint64_t h = 0;
+  for (uint64_t v : part) h += v;
+  return h;
+}
 int orbo_distribute(const void* cand, int n, int minX, int maxX, int minY, int maxY, int N, void* dst, int cap) {
   std::vector<KeyPt> c((const KeyPt*)cand, (const KeyPt*)cand + n);
   std::vector<KeyPt> r = distribute_octree(c, minX, maxX, minY, maxY, N, nullptr);

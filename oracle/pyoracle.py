@@ -59,6 +59,8 @@ def lib() -> C.CDLL:
         L.orbo_distribute.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
         L.orbo_trig_hash.restype = C.c_uint64
         L.orbo_trig_hash.argtypes = [C.c_uint32, C.c_uint32]
+        L.orbo_atan_hash.restype = C.c_uint64
+        L.orbo_atan_hash.argtypes = [C.c_uint32, C.c_uint32]
         L.orbo_pattern.restype = C.POINTER(C.c_int8)
         _lib = L
     return _lib
@@ -160,6 +162,11 @@ def cos_sin_deg(angle_deg: float):
 def trig_hash(first_bits: int, count: int) -> int:
     """64-bit digest of (cosf, sinf)(angle * pi/180) over `count` consecutive float bit patterns (see orbx_debug_trig_hash)."""
     return int(lib().orbo_trig_hash(first_bits, count))
+
+
+def atan_hash(seed: int, count: int) -> int:
+    """64-bit digest of fastAtan2 over `count` pseudo-random moment pairs (see orbx_debug_atan_hash)."""
+    return int(lib().orbo_atan_hash(seed, count))
 
 
 def distribute(cand: np.ndarray, minX, maxX, minY, maxY, N) -> np.ndarray:

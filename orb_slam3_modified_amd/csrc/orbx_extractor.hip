@@ -821,13 +821,25 @@ int orbx_debug_trig(orbx_ctx* ctx, const float* y, const float* x, int n, int an
   return ORBX_OK;
 }
 
+static int run_hash_kernel(orbx_ctx* ctx, int which, uint32_t a, uint32_t count, uint64_t* hash);
+
+int orbx_debug_atan_hash(orbx_ctx* ctx, uint32_t seed, uint32_t count, uint64_t* hash) {
+  if (!ctx || !hash) return ORBX_E_INVALID;
+  return run_hash_kernel(ctx, 1, seed, count, hash);
+}
+
 int orbx_debug_trig_hash(orbx_ctx* ctx, uint32_t first_bits, uint32_t count, uint64_t* hash) {
   if (!ctx || !hash) return ORBX_E_INVALID;
+  return run_hash_kernel(ctx, 0, first_bits, count, hash);
+}
+
+static int run_hash_kernel(orbx_ctx* ctx, int which, uint32_t first_bits, uint32_t count, uint64_t* hash) {
   ORBX_HIP(ctx, hipSetDevice(ctx->device));
   unsigned long long* d = nullptr;
   ORBX_HIP(ctx, hipMalloc((void**)&d, sizeof(unsigned long long)));
   ORBX_HIP(ctx, hipMemsetAsync(d, 0, sizeof(unsigned long long), ctx->stream));
-  if (count) hipLaunchKernelGGL(k_debug_trig_hash, dim3(256 * 32), dim3(256), 0, ctx->stream, first_bits, count, d);
+  if (count && which == 0) hipLaunchKernelGGL(k_debug_trig_hash, dim3(256 * 32), dim3(256), 0, ctx->stream, first_bits, count, d);
+  if (count && which == 1) hipLaunchKernelGGL(k_debug_atan_hash, dim3(256 * 32), dim3(256), 0, ctx->stream, first_bits, count, d);
   ORBX_HIP(ctx, hipGetLastError());
   unsigned long long h = 0;
   ORBX_HIP(ctx, hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));

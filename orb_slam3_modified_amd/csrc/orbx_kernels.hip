@@ -1259,6 +1259,23 @@ __global__ __launch_bounds__(256) void k_debug_trig_hash(uint32_t first, uint32_
   if ((threadIdx.x & 63) == 0) atomicAdd(out, h);
 }
 
+// The same for fastAtan2: digest over `count` pseudo-random integer moment pairs derived from the index by a fixed
+// integer mix (identical on the oracle side).
+__device__ __forceinline__ uint32_t mix32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+__global__ __launch_bounds__(256) void k_debug_atan_hash(uint32_t seed, uint32_t count, unsigned long long* __restrict__ out) {
+  unsigned long long h = 0;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += (unsigned long long)gridDim.x * blockDim.x) {
+    const uint32_t a = mix32(seed + 2u * (uint32_t)i), b = mix32(seed + 2u * (uint32_t)i + 1u);
+    const int m01 = (int)(a % 6000001u) - 3000000, m10 = (b & 15u) == 0 ? 0 : (int)(b % 6000001u) - 3000000;
+    const uint32_t bits = __float_as_uint(fast_atan2_deg((float)m01, (float)m10));
+    h += ((unsigned long long)bits * 0x9E3779B97F4A7C15ull) ^ (unsigned long long)(uint32_t)i;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, h);
+}
+
 // Calibration kernel for the rocprofv3 FETCH_SIZE / WRITE_SIZE counters (MI355X_MICROARCH.md "HBM": the counters
 // are only calibrated for wide streaming reads): copies n bytes with W bytes per lane per access (W = 1, 4, 16),
 // i.e. a kernel whose HBM traffic is known exactly, in the access widths the extractor kernels use.

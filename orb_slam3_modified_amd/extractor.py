@@ -139,6 +139,12 @@ class ORBextractor:
         check(self._L.orbx_debug_trig_hash(self._ctx, first_bits, count, C.byref(h)), self._ctx)
         return int(h.value)
 
+    def debug_atan_hash(self, seed: int, count: int) -> int:
+        """Digest of the device fastAtan2 over `count` pseudo-random moment pairs (test hook)."""
+        h = C.c_uint64(0)
+        check(self._L.orbx_debug_atan_hash(self._ctx, seed, count, C.byref(h)), self._ctx)
+        return int(h.value)
+
     def debug_calib_copy(self, d_src: int, d_dst: int, nbytes: int, width: int, stream: int = 0):
         """Known-traffic device copy (counter calibration, tools/pmc_traffic.py)."""
         check(self._L.orbx_debug_calib_copy(self._ctx, ptr(d_src), ptr(d_dst), nbytes, width, ptr(stream)), self._ctx)

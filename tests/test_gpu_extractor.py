@@ -254,3 +254,11 @@ def test_device_cos_sin_exhaustive_over_all_angles():
     for first, count in ((0, 400_000_000), (400_000_000, 400_000_000), (800_000_000, last + 1 - 800_000_000)):
         assert gpu.debug_trig_hash(first, count) == po.trig_hash(first, count), (first, count)
     assert gpu.debug_trig_hash(5, 1000) != gpu.debug_trig_hash(6, 1000)        # the digest is input-sensitive
+
+
+def test_device_fast_atan2_on_a_billion_moment_pairs():
+    """cv::fastAtan2 on 1e9 pseudo-random (m01, m10) moment pairs: device digest == oracle digest."""
+    gpu = ORBextractor(100, 1.2, 1, 20, 7)
+    for seed in (1, 0x9E3779B9):
+        assert gpu.debug_atan_hash(seed, 500_000_000) == po.atan_hash(seed, 500_000_000), seed
+    assert gpu.debug_atan_hash(3, 1000) != gpu.debug_atan_hash(4, 1000)
