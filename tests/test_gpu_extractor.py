@@ -262,3 +262,14 @@ def test_device_fast_atan2_on_a_billion_moment_pairs():
     for seed in (1, 0x9E3779B9):
         assert gpu.debug_atan_hash(seed, 500_000_000) == po.atan_hash(seed, 500_000_000), seed
     assert gpu.debug_atan_hash(3, 1000) != gpu.debug_atan_hash(4, 1000)
+
+
+def test_config4_tumvi_batch_all_frames():
+    """BASELINE config 4 shape (1024x1024, 2000 features) as a device batch: every frame bit-exact, both output branches."""
+    frames = synth.make_stream(12, 1024, 1024)
+    gpu = ORBextractor(2000, 1.2, 8, 20, 7)
+    res = gpu.extract_batch(frames, (0, 1000))
+    ora = po.OracleExtractor(2000, 1.2, 8, 20, 7)
+    for t in range(len(frames)):
+        assert_same(res[t], ora.extract(frames[t], (0, 1000)), f"1024^2 f{t}")
+        assert 0 < res[t][0] < len(res[t][1])
