@@ -189,6 +189,7 @@ static int ensure_buffers(orbx_ctx* ctx, int rows, int cols, int nframes) {
   int rc = build_geometry(ctx, rows, cols, geo);
   if (rc != ORBX_OK) return rc;
   free_buffers(ctx);
+  ctx->buf_epoch++;
   ctx->geo = geo;
   DeviceGeom dg;
   std::memset(&dg, 0, sizeof(dg));
@@ -499,6 +500,8 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, 
     const char* e = getenv("ORBX_STREAMS");  // concurrent sub-batches of the batch entry point (1..orbx_ctx::kMaxAux)
     const int v = e ? atoi(e) : 1;
     ctx->nstreams = std::min(std::max(v, 1), 2);  // the blur fork owns the last two aux streams
+    const char* gr = getenv("ORBX_GRAPH");   // 0 disables the replayed-graph single-frame path
+    ctx->use_graph = gr ? atoi(gr) != 0 : true;
     const char* fb = getenv("ORBX_FORK_BLUR");
     ctx->fork_blur = fb ? atoi(fb) != 0 : true;
     const char* ff = getenv("ORBX_FORK_FAST0");
@@ -528,6 +531,8 @@ void orbx_destroy(orbx_ctx* ctx) {
   auto fr = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
   fr(ctx->d_stage_img); fr(ctx->d_stage_out); fr(ctx->d_knn_ws);
   ctx->arena.release();
+  if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
+  if (ctx->h_in) { (void)hipHostFree(ctx->h_in); ctx->h_in = nullptr; }
   if (ctx->h_stage_out) { (void)hipHostFree(ctx->h_stage_out); ctx->h_stage_out = nullptr; }
   if (ctx->h_pyr) { (void)hipHostFree(ctx->h_pyr); ctx->h_pyr = nullptr; }
   for (int i = 0; i < orbx_ctx::kMaxAux; i++) {
@@ -618,6 +623,7 @@ static int ensure_stage(orbx_ctx* ctx, int nframes, size_t img_bytes) {
     ctx->d_stage_img = nullptr; ctx->stage_img_bytes = 0;
     ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_stage_img, img_bytes));
     ctx->stage_img_bytes = img_bytes;
+    ctx->buf_epoch++;
   }
   if (nframes > ctx->stage_frames) {
     if (ctx->d_stage_out) (void)hipFree(ctx->d_stage_out);
@@ -627,8 +633,72 @@ static int ensure_stage(orbx_ctx* ctx, int nframes, size_t img_bytes) {
     ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_stage_out, L.bytes));
     ORBX_HIP(ctx, hipHostMalloc((void**)&ctx->h_stage_out, L.bytes, hipHostMallocDefault));
     ctx->stage_frames = nframes;
+    ctx->buf_epoch++;
   }
   return ORBX_OK;
+}
+
+// The single-frame path as a replayed graph.  Returns 1 when it handled the frame, 0 when the caller must take the
+// ordinary path (graphs disabled or capture failed), < 0 on a real error.
+static int extract_one_graph(orbx_ctx* ctx, const uint8_t* img, int rows, int cols, size_t row_stride, int lap0, int lap1,
+                             size_t pitch, size_t fbytes, const StageLayout& L) {
+  if (!ctx->use_graph || ctx->profiling) return 0;
+  hipStream_t st = ctx->stream;
+  const size_t in_bytes = (size_t)rows * cols;
+  if (in_bytes > ctx->h_in_bytes) {
+    if (ctx->h_in) (void)hipHostFree(ctx->h_in);
+    ctx->h_in = nullptr; ctx->h_in_bytes = 0;
+    if (hipHostMalloc((void**)&ctx->h_in, in_bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->use_graph = false; return 0; }
+    ctx->h_in_bytes = in_bytes;
+    ctx->buf_epoch++;
+  }
+  const bool keep = ctx->keep_host_pyr;
+  int rc = ensure_buffers(ctx, rows, cols, 1);
+  if (rc != ORBX_OK) return rc;
+  if (keep && ctx->geo.pyr_bytes > 0 && (size_t)ctx->geo.pyr_bytes > ctx->h_pyr_bytes) {
+    if (ctx->h_pyr) (void)hipHostFree(ctx->h_pyr);
+    ctx->h_pyr = nullptr; ctx->h_pyr_bytes = 0;
+    ORBX_HIP(ctx, hipHostMalloc((void**)&ctx->h_pyr, (size_t)ctx->geo.pyr_bytes, hipHostMallocDefault));
+    ctx->h_pyr_bytes = (size_t)ctx->geo.pyr_bytes;
+    ctx->buf_epoch++;
+  }
+  const int key[6] = {rows, cols, lap0, lap1, keep ? 1 : 0, ctx->buf_epoch};
+  if (!ctx->graph_exec || std::memcmp(key, ctx->graph_key, sizeof(key)) != 0) {
+    if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
+    uint8_t* d = ctx->d_stage_out;
+    hipGraph_t graph = nullptr;
+    bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess;
+    if (ok) {
+      ok = hipMemcpy2DAsync(ctx->d_stage_img, pitch, ctx->h_in, (size_t)cols, (size_t)cols, (size_t)rows, hipMemcpyHostToDevice, st) == hipSuccess;
+      if (ok) ok = launch_pipeline(ctx, ctx->d_stage_img, 0, 1, rows, cols, pitch, fbytes, lap0, lap1, (orbx_keypoint*)(d + L.kps_off),
+                                   d + L.desc_off, (int32_t*)(d + L.counts_off), st) == ORBX_OK;
+      const size_t kb = (size_t)ctx->out_cap * sizeof(orbx_keypoint), db = (size_t)ctx->out_cap * 32, cb = 2 * sizeof(int32_t);
+      if (ok) ok = hipMemcpyAsync(ctx->h_stage_out + L.kps_off, d + L.kps_off, kb, hipMemcpyDeviceToHost, st) == hipSuccess;
+      if (ok) ok = hipMemcpyAsync(ctx->h_stage_out + L.desc_off, d + L.desc_off, db, hipMemcpyDeviceToHost, st) == hipSuccess;
+      if (ok) ok = hipMemcpyAsync(ctx->h_stage_out + L.counts_off, d + L.counts_off, cb, hipMemcpyDeviceToHost, st) == hipSuccess;
+      if (ok && keep && ctx->geo.pyr_bytes > 0)
+        ok = hipMemcpyAsync(ctx->h_pyr, ctx->d_pyr, (size_t)ctx->geo.pyr_bytes, hipMemcpyDeviceToHost, st) == hipSuccess;
+      const hipError_t ee = hipStreamEndCapture(st, &graph);   // always leave capture mode
+      ok = ok && ee == hipSuccess && graph != nullptr;
+    }
+    if (ok) ok = hipGraphInstantiate(&ctx->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess;
+    if (graph) (void)hipGraphDestroy(graph);
+    if (!ok) {
+      (void)hipGetLastError();
+      if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
+      ctx->use_graph = false;   // this runtime cannot capture the pipeline: fall back to plain launches for good
+      return 0;
+    }
+    std::memcpy(ctx->graph_key, key, sizeof(key));
+  }
+  if (row_stride == (size_t)cols) std::memcpy(ctx->h_in, img, in_bytes);
+  else for (int r = 0; r < rows; r++) std::memcpy(ctx->h_in + (size_t)r * cols, img + (size_t)r * row_stride, (size_t)cols);
+  ctx->last_imgs = ctx->d_stage_img; ctx->last_row_stride = pitch; ctx->last_frame_stride = fbytes; ctx->last_nframes = 1;
+  ctx->h_pyr_valid = false;
+  ORBX_HIP(ctx, hipGraphLaunch(ctx->graph_exec, st));
+  ORBX_HIP(ctx, hipStreamSynchronize(st));
+  ctx->h_pyr_valid = keep && ctx->geo.pyr_bytes > 0;
+  return 1;
 }
 
 int orbx_extract_batch(orbx_ctx* ctx, const uint8_t* imgs, int nframes, int rows, int cols, size_t row_stride,
@@ -641,6 +711,21 @@ int orbx_extract_batch(orbx_ctx* ctx, const uint8_t* imgs, int nframes, int rows
   int rc = ensure_stage(ctx, nframes, fbytes * nframes);
   if (rc != ORBX_OK) return rc;
   const StageLayout L = stage_layout(ctx, ctx->stage_frames);   // the block was laid out for its allocated capacity
+  const size_t kb = (size_t)nframes * ctx->out_cap * sizeof(orbx_keypoint), db = (size_t)nframes * ctx->out_cap * 32,
+               cb = (size_t)nframes * 2 * sizeof(int32_t);
+  if (nframes == 1) {   // the live-SLAM path: replay the captured graph
+    if (row_stride >= (1u << 23) || (unsigned long long)row_stride * (unsigned long long)rows >= (1ull << 31))
+      return set_err(ctx, ORBX_E_INVALID, "row stride / frame size beyond the kernels' 32-bit in-frame offsets");
+    rc = extract_one_graph(ctx, imgs, rows, cols, row_stride, lap0, lap1, pitch, fbytes, L);
+    if (rc < 0) return rc;
+    if (rc == 1) {
+      std::memcpy(kps, ctx->h_stage_out + L.kps_off, kb);
+      std::memcpy(desc, ctx->h_stage_out + L.desc_off, db);
+      std::memcpy(counts, ctx->h_stage_out + L.counts_off, cb);
+      if (counts[0] < 0) return set_err(ctx, ORBX_E_CAPACITY, "quadtree produced more nodes than the level capacity");
+      return ORBX_OK;
+    }
+  }
   for (int f = 0; f < nframes; f++)
     ORBX_HIP(ctx, hipMemcpy2DAsync(ctx->d_stage_img + f * fbytes, pitch, imgs + f * frame_stride, row_stride, cols, rows,
                                    hipMemcpyHostToDevice, ctx->stream));
@@ -649,8 +734,6 @@ int orbx_extract_batch(orbx_ctx* ctx, const uint8_t* imgs, int nframes, int rows
                                  (orbx_keypoint*)(d + L.kps_off), d + L.desc_off, (int32_t*)(d + L.counts_off), ctx->stream);
   if (rc != ORBX_OK) return rc;
   // one copy for everything the caller gets back (sized by what this call produced)
-  const size_t kb = (size_t)nframes * ctx->out_cap * sizeof(orbx_keypoint), db = (size_t)nframes * ctx->out_cap * 32,
-               cb = (size_t)nframes * 2 * sizeof(int32_t);
   if (nframes == ctx->stage_frames) {
     ORBX_HIP(ctx, hipMemcpyAsync(ctx->h_stage_out, d, L.counts_off + cb, hipMemcpyDeviceToHost, ctx->stream));
   } else {  // a smaller batch than the block was laid out for: three ranges
@@ -666,6 +749,7 @@ int orbx_extract_batch(orbx_ctx* ctx, const uint8_t* imgs, int nframes, int rows
       ctx->h_pyr = nullptr; ctx->h_pyr_bytes = 0;
       ORBX_HIP(ctx, hipHostMalloc((void**)&ctx->h_pyr, need, hipHostMallocDefault));
       ctx->h_pyr_bytes = need;
+      ctx->buf_epoch++;
     }
     ORBX_HIP(ctx, hipMemcpyAsync(ctx->h_pyr, ctx->d_pyr, need, hipMemcpyDeviceToHost, ctx->stream));
     ctx->h_pyr_valid = true;

@@ -168,6 +168,13 @@ struct orbx_ctx {
   uint8_t* h_stage_out = nullptr;   // pinned host mirror of d_stage_out (one D2H copy per call)
   int stage_frames = 0;
   orbx::DeviceArena arena;   // scratch of the grid / search / stereo entry points
+  // single-frame operator() path as a replayed hipGraph (H2D, the 13 launches, D2H): one graph launch per frame instead
+  // of ~16 API calls; re-captured when the shape / lapping area / buffers change, disabled on any capture failure
+  bool use_graph = true;
+  hipGraphExec_t graph_exec = nullptr;
+  int graph_key[6] = {0, 0, 0, 0, 0, 0};
+  int buf_epoch = 0;            // bumped whenever a buffer a captured graph points to is reallocated
+  uint8_t* h_in = nullptr; size_t h_in_bytes = 0;   // pinned copy of the caller's frame
   unsigned long long* d_knn_ws = nullptr; size_t knn_ws_bytes = 0;  // per-segment partial top-2 of orbx_knn2_allpairs*
   // host mirror of frame 0's pyramid levels >= 1 (pinned), refreshed by orbx_extract when keep_host_pyr is set
   bool keep_host_pyr = false;
