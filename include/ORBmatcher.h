@@ -3,15 +3,17 @@
  * replace the inner `for candidates: DescriptorDistance(...)` loops of the 12 Search.../Fuse routines
  * (src/ORBmatcher.cc; per-routine tie and accept rules: SURVEY.md §3.3).
  *
- * SearchForInitialization (the heaviest Hamming workload of monocular tracking, src/ORBmatcher.cc:648-763) is provided
- * in full as a template over the reference's Frame.  The other routines take KeyFrame / MapPoint / Sophus types that
- * belong to the reference and are out of this repository's scope; INTEGRATION.md shows the few-line change that routes
+ * SearchForInitialization (the heaviest Hamming workload of monocular tracking, src/ORBmatcher.cc:648-763) and
+ * SearchByProjection(Frame&, vector<MapPoint*>&, ...) (the per-frame local-map search, :43-141) are provided in full as
+ * templates over the reference's Frame / MapPoint.  The other routines take KeyFrame / Sophus types that belong to the
+ * reference and are out of this repository's scope; INTEGRATION.md shows the few-line change that routes
  * each routine's candidate loop through NearestInCandidates() below while the geometry and the greedy bookkeeping
  * stay in src/ORBmatcher.cc.
  */
 #ifndef ORBMATCHER_H
 #define ORBMATCHER_H
 
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -98,6 +100,45 @@ class ORBmatcher {
         n2 ? F2.mDescriptors.data : nullptr, n2, FrameT::mnMinX, FrameT::mnMinY, FrameT::mnMaxX, FrameT::mnMaxY,
         (float*)vbPrevMatched.data(), windowSize, mfNNratio, mbCheckOrientation ? 1 : 0, vnMatches12.data(), &nmatches);
     if (rc != ORBX_OK) throw std::runtime_error(std::string("ORBmatcher::SearchForInitialization: ") + orbx_last_error(DefaultContext()));
+    return nmatches;
+  }
+
+  // Tracking::SearchLocalPoints' projection search, src/ORBmatcher.cc:43-141 (same arguments, same return value, same
+  // F.mvpMapPoints afterwards).  FrameT / MapPointT are the reference's Frame / MapPoint (only the members the routine
+  // reads are used).  Windows, candidate gates and every Hamming distance run on the GPU in one call, the greedy part
+  // is replayed in the reference's order.  Two-camera rigs (F.Nleft != -1, :143-210) are not covered: they throw.
+  template <class FrameT, class MapPointT>
+  int SearchByProjection(FrameT& F, const std::vector<MapPointT*>& vpMapPoints, const float th = 3, const bool bFarPoints = false,
+                         const float thFarPoints = 50.0f) {
+    if (F.Nleft != -1) throw std::runtime_error("ORBmatcher::SearchByProjection: two-camera frames are not routed to the GPU");
+    const int n = (int)F.mvKeysUn.size(), nmp = (int)vpMapPoints.size();
+    if (n == 0 || nmp == 0) return 0;
+    if (!F.mDescriptors.isContinuous()) throw std::runtime_error("descriptor matrix must be continuous");
+    std::vector<int32_t> kpObs(n, -1), kpMatch(n, -1), lvl(nmp, 0), obs(nmp, 0);
+    for (int i = 0; i < n; i++)
+      if (F.mvpMapPoints[i]) kpObs[i] = F.mvpMapPoints[i]->Observations();
+    std::vector<unsigned char> inView(nmp, 0), mpDesc((size_t)nmp * 32, 0);
+    std::vector<float> px(nmp, 0.f), py(nmp, 0.f), pxr(nmp, 0.f), vc(nmp, 0.f);
+    for (int i = 0; i < nmp; i++) {
+      MapPointT* pMP = vpMapPoints[i];
+      if (!pMP->mbTrackInView) continue;                          // :52-53 (mbTrackInViewR belongs to the two-camera block)
+      if (bFarPoints && pMP->mTrackDepth > thFarPoints) continue;  // :55-56
+      if (pMP->isBad()) continue;                                  // :58-59
+      inView[i] = 1;
+      px[i] = pMP->mTrackProjX; py[i] = pMP->mTrackProjY; pxr[i] = pMP->mTrackProjXR; vc[i] = pMP->mTrackViewCos;
+      lvl[i] = pMP->mnTrackScaleLevel; obs[i] = pMP->Observations();
+      const cv::Mat d = pMP->GetDescriptor();
+      std::memcpy(&mpDesc[(size_t)i * 32], d.template ptr<unsigned char>(), 32);
+    }
+    const bool stereo = !F.mvuRight.empty();
+    int nmatches = 0;
+    const int rc = orbx_search_by_projection(
+        DefaultContext(), (const orbx_keypoint*)F.mvKeysUn.data(), F.mDescriptors.data, stereo ? F.mvuRight.data() : nullptr, kpObs.data(), n,
+        FrameT::mnMinX, FrameT::mnMinY, FrameT::mnMaxX, FrameT::mnMaxY, F.mvScaleFactors.data(), (int)F.mvScaleFactors.size(), inView.data(),
+        px.data(), py.data(), pxr.data(), vc.data(), lvl.data(), mpDesc.data(), obs.data(), nmp, th, mfNNratio, kpMatch.data(), &nmatches);
+    if (rc != ORBX_OK) throw std::runtime_error(std::string("ORBmatcher::SearchByProjection: ") + orbx_last_error(DefaultContext()));
+    for (int i = 0; i < n; i++)
+      if (kpMatch[i] >= 0) F.mvpMapPoints[i] = vpMapPoints[kpMatch[i]];
     return nmatches;
   }
 

@@ -186,6 +186,37 @@ int orbx_search_for_initialization(orbx_ctx* ctx, const orbx_keypoint* kps1, con
                                    const uint8_t* desc2, int n2, float min_x, float min_y, float max_x, float max_y, float* prev_xy,
                                    int window_size, float nn_ratio, int check_orientation, int32_t* matches12, int* nmatches);
 
+/* The shared core of the guided searches in ONE call (no candidate lists travelling host -> device): window query
+ * over the frame grid (as orbx_features_in_area), the searches' own candidate gates, the Hamming distance of every
+ * surviving candidate and the per-query best / second.  kp_skip [n] (optional): 1 = keypoint is never a candidate
+ * (e.g. already bound to an observed map point, src/ORBmatcher.cc:81-83).  kp_uright [n] + q_xr [nq] (optional, both or
+ * neither): rectified-stereo gate, candidate dropped when uRight > 0 and |q_xr - uRight| > r (:85-90).
+ * Out: CSR row_ptr [nq + 1], cand / dist [cand_cap] (either may be NULL), best / second idx / dist [nq] (any may be
+ * NULL; -1 / 256 when missing; ties -> first candidate).  Returns the number of candidates or a negative error. */
+int orbx_window_search(orbx_ctx* ctx, const orbx_keypoint* kps, const uint8_t* desc, int n, float min_x, float min_y, float max_x,
+                       float max_y, const uint8_t* kp_skip, const float* kp_uright, const float* qx, const float* qy, const float* qr,
+                       const int32_t* qmin_level, const int32_t* qmax_level, const uint8_t* q_desc, const float* q_xr, int nq,
+                       int32_t* row_ptr, int32_t* cand, int32_t* dist, int cand_cap, int32_t* best_idx, int32_t* best_dist,
+                       int32_t* second_idx, int32_t* second_dist);
+
+/* ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>&, th, bFarPoints, thFarPoints)
+ * (src/ORBmatcher.cc:43-141; Tracking::SearchLocalPoints' per-frame call) for single-camera / rectified-stereo frames
+ * (F.Nleft == -1), with the MapPoint / Frame state flattened into arrays:
+ *   frame:      kps_un = F.mvKeysUn, desc = F.mDescriptors, u_right = F.mvuRight (NULL for monocular),
+ *               kp_obs [n] in/out = F.mvpMapPoints[i] ? Observations() : -1, scale_factors = F.mvScaleFactors;
+ *   map points: mp_in_view = mbTrackInView && !isBad() && !(bFarPoints && mTrackDepth > thFarPoints), mp_proj_x/y/xr =
+ *               mTrackProjX/Y/XR, mp_view_cos = mTrackViewCos, mp_level = mnTrackScaleLevel, mp_desc = GetDescriptor(),
+ *               mp_obs = Observations().
+ * Windows, gates and all Hamming distances run on the GPU; the order-dependent part (a keypoint bound by an earlier map
+ * point of this call is no candidate for later ones) is replayed on the host in the reference's order.
+ * kp_match [n] out: index of the map point bound to keypoint i by this call (F.mvpMapPoints[i] = pMP), else -1;
+ * *nmatches = the reference's return value. */
+int orbx_search_by_projection(orbx_ctx* ctx, const orbx_keypoint* kps_un, const uint8_t* desc, const float* u_right, int32_t* kp_obs, int n,
+                              float min_x, float min_y, float max_x, float max_y, const float* scale_factors, int nlevels,
+                              const uint8_t* mp_in_view, const float* mp_proj_x, const float* mp_proj_y, const float* mp_proj_xr,
+                              const float* mp_view_cos, const int32_t* mp_level, const uint8_t* mp_desc, const int32_t* mp_obs, int nmp,
+                              float th, float nn_ratio, int32_t* kp_match, int* nmatches);
+
 /* Frame::ComputeStereoMatches (src/Frame.cc:811-981) on the DEVICE pyramids of the left and right extractor (the
  * last frame each context extracted; both on one GPU, same image shape) — this is the reader of the reference's public
  * ORBextractor::mvImagePyramid, so with it no pyramid has to be copied to the host.  kps / desc: the keypoints and

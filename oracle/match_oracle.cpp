@@ -370,6 +370,57 @@ int mo_search_for_initialization(const void* kps1_, const uint8_t* desc1, int n1
   return nmatches;
 }
 
+// ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th, bFarPoints, thFarPoints),
+// src/ORBmatcher.cc:43-141, for F.Nleft == -1 (the second block, :143-210, only runs for two-camera rigs).
+// The objects are flattened: kp_obs[i] = F.mvpMapPoints[i] ? Observations() : -1 (in/out), mp_* = the MapPoint fields the
+// routine reads; mp_skip[i] folds `!mbTrackInView`, `bFarPoints && mTrackDepth > thFarPoints` and `isBad()` (:53-60).
+// kp_match[i] = index of the map point written to F.mvpMapPoints[i] by this call (-1: untouched).  Returns nmatches.
+int mo_search_by_projection(const void* kps_, const uint8_t* desc, const float* mvuRight, int32_t* kp_obs, int n, float mnMinX,
+                            float mnMinY, float mnMaxX, float mnMaxY, const float* mvScaleFactors, const uint8_t* mp_skip,
+                            const float* mTrackProjX, const float* mTrackProjY, const float* mTrackProjXR, const float* mTrackViewCos,
+                            const int32_t* mnTrackScaleLevel, const uint8_t* mp_desc, const int32_t* mp_obs, int nmp, float th,
+                            float mfNNratio, int32_t* kp_match) {
+  const MKeyPt* kps = (const MKeyPt*)kps_;
+  const int TH_HIGH = 100;
+  FrameGrid F(kps, n, mnMinX, mnMinY, mnMaxX, mnMaxY);
+  for (int i = 0; i < n; i++) kp_match[i] = -1;
+  int nmatches = 0;
+  const bool bFactor = th != 1.0;
+  for (int iMP = 0; iMP < nmp; iMP++) {
+    if (mp_skip[iMP]) continue;
+    const int& nPredictedLevel = mnTrackScaleLevel[iMP];
+    float r = (mTrackViewCos[iMP] > 0.998) ? 2.5 : 4.0;   // RadiusByViewingCos, :214-220
+    if (bFactor) r *= th;
+    const std::vector<size_t> vIndices =
+        F.area(mTrackProjX[iMP], mTrackProjY[iMP], r * mvScaleFactors[nPredictedLevel], nPredictedLevel - 1, nPredictedLevel);
+    if (vIndices.empty()) continue;
+    const uint8_t* MPdescriptor = mp_desc + (size_t)iMP * 32;
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+    for (size_t idx : vIndices) {
+      if (kp_obs[idx] > 0) continue;   // F.mvpMapPoints[idx] && Observations() > 0
+      if (mvuRight && mvuRight[idx] > 0) {
+        const float er = fabs(mTrackProjXR[iMP] - mvuRight[idx]);
+        if (er > r * mvScaleFactors[nPredictedLevel]) continue;
+      }
+      const int dist = descriptor_distance(MPdescriptor, desc + idx * 32);
+      if (dist < bestDist) {
+        bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = kps[idx].octave; bestIdx = (int)idx;
+      } else if (dist < bestDist2) {
+        bestLevel2 = kps[idx].octave; bestDist2 = dist;
+      }
+    }
+    if (bestDist <= TH_HIGH) {
+      if (bestLevel == bestLevel2 && bestDist > mfNNratio * bestDist2) continue;
+      if (bestLevel != bestLevel2 || bestDist <= mfNNratio * bestDist2) {
+        kp_match[bestIdx] = iMP;           // F.mvpMapPoints[bestIdx] = pMP
+        kp_obs[bestIdx] = mp_obs[iMP];
+        nmatches++;
+      }
+    }
+  }
+  return nmatches;
+}
+
 }  // extern "C"
 
 extern "C" {

@@ -250,6 +250,30 @@ def search_for_initialization(kps1, desc1, kps2, desc2, bounds, prev_xy, window_
     return int(n), m12[:len(k1)].copy(), prev
 
 
+def search_by_projection(kps, desc, bounds, scale_factors, kp_obs, mp, th=1.0, nnratio=0.8, u_right=None):
+    """ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th, ...) (src/ORBmatcher.cc:43-141, Nleft == -1) on
+    flattened state -> (nmatches, kp_match, updated kp_obs)."""
+    k = np.ascontiguousarray(kps)
+    d = np.ascontiguousarray(desc, np.uint8)
+    obs = np.ascontiguousarray(kp_obs, np.int32).copy()
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    skip = np.ascontiguousarray(1 - np.asarray(mp["in_view"], np.uint8), np.uint8)
+    px, py, vc = (np.ascontiguousarray(mp[key], np.float32) for key in ("proj_x", "proj_y", "view_cos"))
+    pxr = np.ascontiguousarray(mp["proj_xr"] if mp.get("proj_xr") is not None else np.zeros(len(px)), np.float32)
+    lvl, mobs = (np.ascontiguousarray(mp[key], np.int32) for key in ("level", "obs"))
+    md = np.ascontiguousarray(mp["desc"], np.uint8)
+    ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    match = np.zeros(max(len(k), 1), np.int32)
+    L = _mlib()
+    L.mo_search_by_projection.restype = C.c_int
+    L.mo_search_by_projection.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_float] * 4 + [C.c_void_p] * 9 + [C.c_int, C.c_float, C.c_float,
+                                                                                                          C.c_void_p]
+    n = L.mo_search_by_projection(_ptr(k), _ptr(d), _ptr(ur) if ur is not None else None, _ptr(obs), len(k), *[float(b) for b in bounds],
+                                  _ptr(sf), _ptr(skip), _ptr(px), _ptr(py), _ptr(pxr), _ptr(vc), _ptr(lvl), _ptr(md), _ptr(mobs),
+                                  len(px), float(th), float(nnratio), _ptr(match))
+    return int(n), match[:len(k)].copy(), obs
+
+
 def stereo_matches(kpsL, descL, kpsR, descR, pyrL, pyrR, scale, inv_scale, mb, mbf):
     """Frame::ComputeStereoMatches (src/Frame.cc:811-981) -> (mvuRight, mvDepth, number of matches kept)."""
     kL, kR = np.ascontiguousarray(kpsL), np.ascontiguousarray(kpsR)

@@ -71,7 +71,8 @@ __global__ __launch_bounds__(256) void k_features_in_area(const orbx_keypoint* _
                                                           const float* __restrict__ qy, const float* __restrict__ qr,
                                                           const int32_t* __restrict__ qmin, const int32_t* __restrict__ qmax,
                                                           int nq, int32_t* __restrict__ counts, const int32_t* __restrict__ row_ptr,
-                                                          int32_t* __restrict__ cand) {
+                                                          int32_t* __restrict__ cand, const uint8_t* __restrict__ kp_skip,
+                                                          const float* __restrict__ kp_uright, const float* __restrict__ qxr) {
   const int lane = threadIdx.x & 63;
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= nq) return;
@@ -101,6 +102,13 @@ __global__ __launch_bounds__(256) void k_features_in_area(const orbx_keypoint* _
           }
           const float distx = __fsub_rn(kp.x, x), disty = __fsub_rn(kp.y, y);
           ok = ok && fabsf(distx) < r && fabsf(disty) < r;
+          // the searches' own candidate gates (src/ORBmatcher.cc:84-93): keypoint already bound to an observed map
+          // point; rectified-stereo consistency |projXR - uRight| <= r
+          if (kp_skip && kp_skip[idx]) ok = false;
+          if (kp_uright && qxr) {
+            const float ur = kp_uright[idx];
+            if (ur > 0.f && fabsf(__fsub_rn(qxr[q], ur)) > r) ok = false;
+          }
         }
         const unsigned long long bal = __ballot(ok);
         if (FILL && ok) cand[base_out + total + __popcll(bal & ((1ull << lane) - 1ull))] = idx;
@@ -327,6 +335,13 @@ static int build_grid(orbx_ctx* ctx, const orbx_keypoint* kps, int n, float min_
   return ORBX_OK;
 }
 
+struct AreaGates {   // optional per-keypoint / per-query gates, host pointers (nullptr = off)
+  const uint8_t* kp_skip = nullptr;
+  const float* kp_uright = nullptr;
+  const float* qxr = nullptr;
+  int n = 0;
+};
+
 struct AreaQueries {
   DBuf<float> x, y, r;
   DBuf<int32_t> lmin, lmax, counts, row_ptr, cand;
@@ -335,8 +350,18 @@ struct AreaQueries {
 
 // count -> scan -> fill; leaves row_ptr / cand on the device, nnz on the host
 static int run_area(orbx_ctx* ctx, const GridOnDevice& g, const float* qx, const float* qy, const float* qr, const int32_t* qmin,
-                    const int32_t* qmax, int nq, AreaQueries& a) {
+                    const int32_t* qmax, int nq, AreaQueries& a, const AreaGates& gates = AreaGates()) {
   a.nq = nq;
+  DBuf<uint8_t> d_skip; DBuf<float> d_ur, d_qxr;
+  if (gates.kp_skip && gates.n) {
+    ORBX_HIP(ctx, d_skip.alloc(gates.n));
+    ORBX_HIP(ctx, hipMemcpyAsync(d_skip.p, gates.kp_skip, gates.n, hipMemcpyHostToDevice, ctx->stream));
+  }
+  if (gates.kp_uright && gates.qxr && gates.n && nq) {
+    ORBX_HIP(ctx, d_ur.alloc(gates.n)); ORBX_HIP(ctx, d_qxr.alloc(nq));
+    ORBX_HIP(ctx, hipMemcpyAsync(d_ur.p, gates.kp_uright, sizeof(float) * gates.n, hipMemcpyHostToDevice, ctx->stream));
+    ORBX_HIP(ctx, hipMemcpyAsync(d_qxr.p, gates.qxr, sizeof(float) * nq, hipMemcpyHostToDevice, ctx->stream));
+  }
   ORBX_HIP(ctx, a.x.alloc(nq)); ORBX_HIP(ctx, a.y.alloc(nq)); ORBX_HIP(ctx, a.r.alloc(nq));
   ORBX_HIP(ctx, a.lmin.alloc(nq)); ORBX_HIP(ctx, a.lmax.alloc(nq)); ORBX_HIP(ctx, a.counts.alloc(nq)); ORBX_HIP(ctx, a.row_ptr.alloc(nq + 1));
   if (nq == 0) { ORBX_HIP(ctx, hipMemsetAsync(a.row_ptr.p, 0, sizeof(int32_t), ctx->stream)); a.nnz = 0; return ORBX_OK; }
@@ -348,7 +373,8 @@ static int run_area(orbx_ctx* ctx, const GridOnDevice& g, const float* qx, const
   ORBX_HIP(ctx, hipMemcpyAsync(a.lmax.p, qmax, ib, hipMemcpyHostToDevice, ctx->stream));
   const dim3 grid((nq + 3) / 4), block(256);
   hipLaunchKernelGGL(k_features_in_area<false>, grid, block, 0, ctx->stream, g.kps.p, g.sorted.p, g.cell_start.p, g.minX, g.minY, g.invW,
-                     g.invH, a.x.p, a.y.p, a.r.p, a.lmin.p, a.lmax.p, nq, a.counts.p, (const int32_t*)nullptr, (int32_t*)nullptr);
+                     g.invH, a.x.p, a.y.p, a.r.p, a.lmin.p, a.lmax.p, nq, a.counts.p, (const int32_t*)nullptr, (int32_t*)nullptr,
+                     (const uint8_t*)d_skip.p, (const float*)d_ur.p, (const float*)d_qxr.p);
   hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, ctx->stream, a.counts.p, nq, a.row_ptr.p);
   ORBX_HIP(ctx, hipGetLastError());
   int32_t nnz = 0;
@@ -358,9 +384,55 @@ static int run_area(orbx_ctx* ctx, const GridOnDevice& g, const float* qx, const
   ORBX_HIP(ctx, a.cand.alloc(nnz));
   if (nnz) {
     hipLaunchKernelGGL(k_features_in_area<true>, grid, block, 0, ctx->stream, g.kps.p, g.sorted.p, g.cell_start.p, g.minX, g.minY, g.invW,
-                       g.invH, a.x.p, a.y.p, a.r.p, a.lmin.p, a.lmax.p, nq, (int32_t*)nullptr, a.row_ptr.p, a.cand.p);
+                       g.invH, a.x.p, a.y.p, a.r.p, a.lmin.p, a.lmax.p, nq, (int32_t*)nullptr, a.row_ptr.p, a.cand.p,
+                       (const uint8_t*)d_skip.p, (const float*)d_ur.p, (const float*)d_qxr.p);
     ORBX_HIP(ctx, hipGetLastError());
   }
+  return ORBX_OK;
+}
+
+// Window query + every candidate's Hamming distance + per-query best / second, in one pass over the device: the shared
+// core of the guided searches.  Host vectors out.
+struct WindowResult {
+  std::vector<int32_t> row_ptr, cand, dist, best_idx, best_dist, second_idx, second_dist;
+  int nnz = 0;
+};
+
+static int window_search_core(orbx_ctx* ctx, const orbx_keypoint* kps, const uint8_t* desc, int n, float min_x, float min_y, float max_x,
+                              float max_y, const AreaGates& gates, const float* qx, const float* qy, const float* qr, const int32_t* qmin,
+                              const int32_t* qmax, const uint8_t* qdesc, int nq, bool want_best, WindowResult& out) {
+  out.row_ptr.assign(nq + 1, 0);
+  out.nnz = 0;
+  if (want_best) { out.best_idx.assign(nq, -1); out.best_dist.assign(nq, 256); out.second_idx.assign(nq, -1); out.second_dist.assign(nq, 256); }
+  if (nq == 0 || n == 0) return ORBX_OK;
+  GridOnDevice g;
+  int rc = build_grid(ctx, kps, n, min_x, min_y, max_x, max_y, g);
+  if (rc != ORBX_OK) return rc;
+  AreaQueries a;
+  rc = run_area(ctx, g, qx, qy, qr, qmin, qmax, nq, a, gates);
+  if (rc != ORBX_OK) return rc;
+  out.nnz = a.nnz;
+  out.cand.resize(std::max(a.nnz, 1)); out.dist.resize(std::max(a.nnz, 1));
+  ORBX_HIP(ctx, hipMemcpyAsync(out.row_ptr.data(), a.row_ptr.p, sizeof(int32_t) * (nq + 1), hipMemcpyDeviceToHost, ctx->stream));
+  if (a.nnz) {
+    DBuf<uint8_t> dq, dt;
+    DBuf<int32_t> ddist, dbi, dbd, dsi, dsd;
+    ORBX_HIP(ctx, dq.alloc((size_t)nq * 32)); ORBX_HIP(ctx, dt.alloc((size_t)n * 32)); ORBX_HIP(ctx, ddist.alloc(a.nnz));
+    if (want_best) { ORBX_HIP(ctx, dbi.alloc(nq)); ORBX_HIP(ctx, dbd.alloc(nq)); ORBX_HIP(ctx, dsi.alloc(nq)); ORBX_HIP(ctx, dsd.alloc(nq)); }
+    ORBX_HIP(ctx, hipMemcpyAsync(dq.p, qdesc, (size_t)nq * 32, hipMemcpyHostToDevice, ctx->stream));
+    ORBX_HIP(ctx, hipMemcpyAsync(dt.p, desc, (size_t)n * 32, hipMemcpyHostToDevice, ctx->stream));
+    rc = orbx_nn_csr_device(ctx, dq.p, nq, dt.p, n, a.row_ptr.p, a.cand.p, 0, dbi.p, dbd.p, dsi.p, dsd.p, ddist.p, ctx->stream);
+    if (rc != ORBX_OK) return rc;
+    ORBX_HIP(ctx, hipMemcpyAsync(out.cand.data(), a.cand.p, sizeof(int32_t) * a.nnz, hipMemcpyDeviceToHost, ctx->stream));
+    ORBX_HIP(ctx, hipMemcpyAsync(out.dist.data(), ddist.p, sizeof(int32_t) * a.nnz, hipMemcpyDeviceToHost, ctx->stream));
+    if (want_best) {
+      ORBX_HIP(ctx, hipMemcpyAsync(out.best_idx.data(), dbi.p, sizeof(int32_t) * nq, hipMemcpyDeviceToHost, ctx->stream));
+      ORBX_HIP(ctx, hipMemcpyAsync(out.best_dist.data(), dbd.p, sizeof(int32_t) * nq, hipMemcpyDeviceToHost, ctx->stream));
+      ORBX_HIP(ctx, hipMemcpyAsync(out.second_idx.data(), dsi.p, sizeof(int32_t) * nq, hipMemcpyDeviceToHost, ctx->stream));
+      ORBX_HIP(ctx, hipMemcpyAsync(out.second_dist.data(), dsd.p, sizeof(int32_t) * nq, hipMemcpyDeviceToHost, ctx->stream));
+    }
+  }
+  ORBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ORBX_OK;
 }
 
@@ -490,6 +562,107 @@ int orbx_search_for_initialization(orbx_ctx* ctx, const orbx_keypoint* kps1, con
   }
   for (int i1 = 0; i1 < n1; i1++)
     if (matches12[i1] >= 0) { prev_xy[2 * i1] = kps2[matches12[i1]].x; prev_xy[2 * i1 + 1] = kps2[matches12[i1]].y; }
+  *nmatches_out = nmatches;
+  return ORBX_OK;
+}
+
+int orbx_window_search(orbx_ctx* ctx, const orbx_keypoint* kps, const uint8_t* desc, int n, float min_x, float min_y, float max_x,
+                       float max_y, const uint8_t* kp_skip, const float* kp_uright, const float* qx, const float* qy, const float* qr,
+                       const int32_t* qmin_level, const int32_t* qmax_level, const uint8_t* q_desc, const float* q_xr, int nq,
+                       int32_t* row_ptr, int32_t* cand, int32_t* dist, int cand_cap, int32_t* best_idx, int32_t* best_dist,
+                       int32_t* second_idx, int32_t* second_dist) {
+  if (!ctx || n < 0 || nq < 0 || !row_ptr || (n > 0 && (!kps || !desc)) ||
+      (nq > 0 && (!qx || !qy || !qr || !qmin_level || !qmax_level || !q_desc)) || !(max_x > min_x) || !(max_y > min_y) || cand_cap < 0)
+    return ctx ? set_err(ctx, ORBX_E_INVALID, "orbx_window_search: bad arguments") : ORBX_E_INVALID;
+  ORBX_HIP(ctx, hipSetDevice(ctx->device));
+  ArenaScope scope(ctx);
+  AreaGates gates;
+  gates.kp_skip = kp_skip; gates.kp_uright = kp_uright; gates.qxr = q_xr; gates.n = n;
+  WindowResult w;
+  const bool want_best = best_idx || best_dist || second_idx || second_dist;
+  int rc = window_search_core(ctx, kps, desc, n, min_x, min_y, max_x, max_y, gates, qx, qy, qr, qmin_level, qmax_level, q_desc, nq,
+                              want_best, w);
+  if (rc != ORBX_OK) return rc;
+  std::memcpy(row_ptr, w.row_ptr.data(), sizeof(int32_t) * (nq + 1));
+  if ((cand || dist) && w.nnz > cand_cap) return set_err(ctx, ORBX_E_CAPACITY, "orbx_window_search: candidate buffer too small");
+  if (cand && w.nnz) std::memcpy(cand, w.cand.data(), sizeof(int32_t) * w.nnz);
+  if (dist && w.nnz) std::memcpy(dist, w.dist.data(), sizeof(int32_t) * w.nnz);
+  if (nq) {
+    if (best_idx) std::memcpy(best_idx, w.best_idx.data(), sizeof(int32_t) * nq);
+    if (best_dist) std::memcpy(best_dist, w.best_dist.data(), sizeof(int32_t) * nq);
+    if (second_idx) std::memcpy(second_idx, w.second_idx.data(), sizeof(int32_t) * nq);
+    if (second_dist) std::memcpy(second_dist, w.second_dist.data(), sizeof(int32_t) * nq);
+  }
+  return w.nnz;
+}
+
+int orbx_search_by_projection(orbx_ctx* ctx, const orbx_keypoint* kps_un, const uint8_t* desc, const float* u_right, int32_t* kp_obs, int n,
+                              float min_x, float min_y, float max_x, float max_y, const float* scale_factors, int nlevels,
+                              const uint8_t* mp_in_view, const float* mp_proj_x, const float* mp_proj_y, const float* mp_proj_xr,
+                              const float* mp_view_cos, const int32_t* mp_level, const uint8_t* mp_desc, const int32_t* mp_obs, int nmp,
+                              float th, float nn_ratio, int32_t* kp_match, int* nmatches_out) {
+  if (!ctx || n < 0 || nmp < 0 || nlevels <= 0 || !scale_factors || !nmatches_out || (n > 0 && (!kps_un || !desc || !kp_obs || !kp_match)) ||
+      (nmp > 0 && (!mp_in_view || !mp_proj_x || !mp_proj_y || !mp_view_cos || !mp_level || !mp_desc || !mp_obs)) || !(max_x > min_x) ||
+      !(max_y > min_y) || (u_right && nmp > 0 && !mp_proj_xr))
+    return ctx ? set_err(ctx, ORBX_E_INVALID, "orbx_search_by_projection: bad arguments") : ORBX_E_INVALID;
+  *nmatches_out = 0;
+  for (int i = 0; i < n; i++) kp_match[i] = -1;
+  if (n == 0 || nmp == 0) return ORBX_OK;
+  ORBX_HIP(ctx, hipSetDevice(ctx->device));
+  // one window query per map point in view (src/ORBmatcher.cc:49-74)
+  const bool bFactor = th != 1.0;
+  std::vector<int> qi;
+  std::vector<float> qx, qy, qr, qxr;
+  std::vector<int32_t> qlo, qhi;
+  std::vector<uint8_t> qd;
+  for (int i = 0; i < nmp; i++) {
+    if (!mp_in_view[i]) continue;
+    const int lvl = mp_level[i];
+    if (lvl < 0 || lvl >= nlevels) return set_err(ctx, ORBX_E_INVALID, "orbx_search_by_projection: predicted level out of range");
+    float r = mp_view_cos[i] > 0.998 ? 2.5f : 4.0f;   // RadiusByViewingCos, :214-220
+    if (bFactor) r *= th;
+    qi.push_back(i);
+    qx.push_back(mp_proj_x[i]); qy.push_back(mp_proj_y[i]); qr.push_back(r * scale_factors[lvl]);
+    qxr.push_back(mp_proj_xr ? mp_proj_xr[i] : 0.f);
+    qlo.push_back(lvl - 1); qhi.push_back(lvl);
+    qd.insert(qd.end(), mp_desc + (size_t)i * 32, mp_desc + (size_t)i * 32 + 32);
+  }
+  const int nq = (int)qi.size();
+  if (nq == 0) return ORBX_OK;
+  std::vector<uint8_t> skip(n);
+  for (int i = 0; i < n; i++) skip[i] = kp_obs[i] > 0;   // bound to an observed map point: never a candidate (:81-83)
+  ArenaScope scope(ctx);
+  AreaGates gates;
+  gates.kp_skip = skip.data(); gates.kp_uright = u_right; gates.qxr = u_right ? qxr.data() : nullptr; gates.n = n;
+  WindowResult w;
+  int rc = window_search_core(ctx, kps_un, desc, n, min_x, min_y, max_x, max_y, gates, qx.data(), qy.data(), qr.data(), qlo.data(),
+                              qhi.data(), qd.data(), nq, false, w);
+  if (rc != ORBX_OK) return rc;
+  // host replay of the order-dependent part (:76-140): a keypoint bound to an observed map point by an EARLIER query of
+  // this call is no candidate for the later ones
+  const int TH_HIGH = 100;
+  int nmatches = 0;
+  for (int q = 0; q < nq; q++) {
+    const int iMP = qi[q];
+    bool any = false;   // vIndices.empty() is decided before the occupancy / stereo gates; those only `continue`
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+    for (int c = w.row_ptr[q]; c < w.row_ptr[q + 1]; c++) {
+      const int idx = w.cand[c], d = w.dist[c];
+      any = true;
+      if (kp_obs[idx] > 0) continue;
+      if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = kps_un[idx].octave; bestIdx = idx; }
+      else if (d < bestDist2) { bestLevel2 = kps_un[idx].octave; bestDist2 = d; }
+    }
+    (void)any;
+    if (bestDist <= TH_HIGH) {
+      if (bestLevel == bestLevel2 && (float)bestDist > nn_ratio * (float)bestDist2) continue;
+      if (bestLevel != bestLevel2 || (float)bestDist <= nn_ratio * (float)bestDist2) {
+        kp_match[bestIdx] = iMP;
+        kp_obs[bestIdx] = mp_obs[iMP];
+        nmatches++;
+      }
+    }
+  }
   *nmatches_out = nmatches;
   return ORBX_OK;
 }

@@ -86,6 +86,55 @@ class ORBmatcher:
                                                      self.mfNNratio, int(self.mbCheckOrientation), ptr(m12), C.byref(n)), self._ctx)
         return n.value, m12[:len(k1)].copy()
 
+    def WindowSearch(self, kps, desc, bounds, qx, qy, qr, min_level, max_level, q_desc, kp_skip=None, kp_uright=None, q_xr=None):
+        """Window query + gates + every candidate's Hamming distance + best / second per query in one device pass
+        (orbx_window_search) -> dict(row_ptr, cand, dist, best_idx, best_dist, second_idx, second_dist)."""
+        k = np.ascontiguousarray(kps)
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        qx, qy, qr = (np.ascontiguousarray(v, np.float32) for v in (qx, qy, qr))
+        lo, hi = (np.ascontiguousarray(v, np.int32) for v in (min_level, max_level))
+        qd = np.ascontiguousarray(q_desc, np.uint8).reshape(-1, 32)
+        nq = len(qx)
+        skip = None if kp_skip is None else np.ascontiguousarray(kp_skip, np.uint8)
+        ur = None if kp_uright is None else np.ascontiguousarray(kp_uright, np.float32)
+        xr = None if q_xr is None else np.ascontiguousarray(q_xr, np.float32)
+        rp = np.zeros(nq + 1, np.int32)
+        bi, bd, si, sd = (np.zeros(max(nq, 1), np.int32) for _ in range(4))
+        cap = 1 << 16
+        while True:
+            cand, dist = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+            rc = self._L.orbx_window_search(self._ctx, ptr(k), ptr(d), len(k), *[float(b) for b in bounds], ptr(skip), ptr(ur),
+                                            ptr(qx), ptr(qy), ptr(qr), ptr(lo), ptr(hi), ptr(qd), ptr(xr), nq, ptr(rp), ptr(cand),
+                                            ptr(dist), cap, ptr(bi), ptr(bd), ptr(si), ptr(sd))
+            if rc == -4 and cap < (1 << 28):
+                cap *= 8
+                continue
+            check(rc, self._ctx)
+            return dict(row_ptr=rp, cand=cand[:rc].copy(), dist=dist[:rc].copy(), best_idx=bi[:nq], best_dist=bd[:nq],
+                        second_idx=si[:nq], second_dist=sd[:nq])
+
+    def SearchByProjection(self, F, mp, th: float = 1.0):
+        """ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th, ...) (src/ORBmatcher.cc:43-141), F.Nleft == -1.
+        F: frame-like with mvKeysUn, mDescriptors, bounds, mvScaleFactors, mvuRight (or None), kp_obs (int32 [n], updated in
+        place: Observations() of the bound map point, -1 = none).  mp: dict of arrays in_view, proj_x, proj_y, proj_xr (or
+        None), view_cos, level, desc, obs.  Returns (nmatches, kp_match [n])."""
+        k = np.ascontiguousarray(F.mvKeysUn)
+        d = np.ascontiguousarray(F.mDescriptors, np.uint8).reshape(-1, 32)
+        ur = None if getattr(F, "mvuRight", None) is None else np.ascontiguousarray(F.mvuRight, np.float32)
+        assert F.kp_obs.dtype == np.int32 and F.kp_obs.flags["C_CONTIGUOUS"] and len(F.kp_obs) == len(k)
+        sf = np.ascontiguousarray(F.mvScaleFactors, np.float32)
+        inv = np.ascontiguousarray(mp["in_view"], np.uint8)
+        px, py, vc = (np.ascontiguousarray(mp[key], np.float32) for key in ("proj_x", "proj_y", "view_cos"))
+        pxr = None if mp.get("proj_xr") is None else np.ascontiguousarray(mp["proj_xr"], np.float32)
+        lvl, obs = (np.ascontiguousarray(mp[key], np.int32) for key in ("level", "obs"))
+        md = np.ascontiguousarray(mp["desc"], np.uint8).reshape(-1, 32)
+        match = np.zeros(max(len(k), 1), np.int32)
+        n = C.c_int(0)
+        check(self._L.orbx_search_by_projection(self._ctx, ptr(k), ptr(d), ptr(ur), ptr(F.kp_obs), len(k), *[float(b) for b in F.bounds],
+                                                ptr(sf), len(sf), ptr(inv), ptr(px), ptr(py), ptr(pxr), ptr(vc), ptr(lvl), ptr(md),
+                                                ptr(obs), len(inv), float(th), self.mfNNratio, ptr(match), C.byref(n)), self._ctx)
+        return n.value, match[:len(k)].copy()
+
     @staticmethod
     def ComputeStereoMatches(left_extractor, right_extractor, kpsL, descL, kpsR, descR, mb: float, mbf: float):
         """Frame::ComputeStereoMatches (src/Frame.cc:811-981) on the device pyramids of the two extractors (each must

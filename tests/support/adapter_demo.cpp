@@ -24,6 +24,22 @@ struct MiniFrame {
 };
 float MiniFrame::mnMinX = 0, MiniFrame::mnMinY = 0, MiniFrame::mnMaxX = 0, MiniFrame::mnMaxY = 0;
 
+// ... and the members of Frame / MapPoint that ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, ...) touches
+struct MiniMapPoint {
+  bool mbTrackInView = true, mbTrackInViewR = false, bad = false;
+  float mTrackDepth = 1.f, mTrackProjX = 0, mTrackProjY = 0, mTrackProjXR = 0, mTrackViewCos = 1.f;
+  int mnTrackScaleLevel = 0, nObs = 1;
+  cv::Mat desc;
+  bool isBad() const { return bad; }
+  int Observations() const { return nObs; }
+  cv::Mat GetDescriptor() const { return desc.clone(); }
+};
+struct MiniFrame2 : MiniFrame {
+  int Nleft = -1;
+  std::vector<float> mvuRight, mvScaleFactors;
+  std::vector<MiniMapPoint*> mvpMapPoints;
+};
+
 int main(int argc, char** argv) {
   if (argc < 2) return 2;
   const std::string mode = argv[1];
@@ -121,6 +137,37 @@ int main(int argc, char** argv) {
       const int nm = n ? matcher.SearchForInitialization(F1, F2, prev, m12, 100) : 0;
       o.write((const char*)&nm, 4);
       o.write((const char*)m12.data(), (std::streamsize)m12.size() * 4);
+    }
+    // SearchByProjection: the frame's own keypoints as map points, projected 1.5 / 0.5 px away; every 3rd one unobserved,
+    // every 5th not in view, every 7th bad, every 11th keypoint already bound to an observed point
+    {
+      MiniFrame2 F;
+      F.mvKeysUn = keys; F.mDescriptors = descriptors.clone();
+      F.mvScaleFactors = extractor->GetScaleFactors();
+      F.mvpMapPoints.assign(n, nullptr);
+      std::vector<MiniMapPoint> mps(n), bound(n);
+      std::vector<MiniMapPoint*> vp(n);
+      for (int i = 0; i < n; i++) {
+        MiniMapPoint& m = mps[i];
+        m.mTrackProjX = keys[i].pt.x + 1.5f; m.mTrackProjY = keys[i].pt.y + 0.5f;
+        m.mTrackViewCos = (i & 1) ? 0.9f : 0.999f;
+        m.mnTrackScaleLevel = keys[i].octave;
+        m.nObs = (i % 3 == 0) ? 0 : 2;
+        m.mbTrackInView = i % 5 != 0;
+        m.bad = i % 7 == 0;
+        m.mTrackDepth = (i % 13 == 0) ? 100.f : 1.f;
+        m.desc = descriptors.row(i).clone();
+        vp[i] = &m;
+        if (i % 11 == 0) { bound[i].nObs = 4; F.mvpMapPoints[i] = &bound[i]; }
+      }
+      ORBmatcher matcher(0.8f, true);
+      const int nm = n ? matcher.SearchByProjection(F, vp, 3.0f, true, 50.0f) : 0;
+      o.write((const char*)&nm, 4);
+      for (int i = 0; i < n; i++) {
+        int who = -1;
+        if (F.mvpMapPoints[i] && F.mvpMapPoints[i] >= &mps[0] && F.mvpMapPoints[i] <= &mps[n - 1]) who = (int)(F.mvpMapPoints[i] - &mps[0]);
+        o.write((const char*)&who, 4);
+      }
     }
     std::printf("OK n=%d mono=%d\n", n, mono);
     delete extractor;

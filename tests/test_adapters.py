@@ -61,8 +61,10 @@ def _read(path):
         fv = [take("<II") for _ in range(take("<i"))]
         self_score = take("<d")
     nm = take("<i")
-    m12 = np.frombuffer(b, np.int32, n, off)
-    return mono, kps, desc, pyr, d01, bow, fv, self_score, nm, m12
+    m12 = np.frombuffer(b, np.int32, n, off); off += 4 * n
+    nproj = take("<i")
+    proj = np.frombuffer(b, np.int32, n, off)
+    return mono, kps, desc, pyr, d01, bow, fv, self_score, nm, m12, nproj, proj
 
 
 @pytest.mark.gpu
@@ -80,7 +82,7 @@ def test_adapter_results_equal_oracle(tmp_path, rows, cols, lap):
     make_vocabulary(vocp, odesc, 6, 3, seed=3)
     r = subprocess.run([exe, "run", raw, str(rows), str(cols), "1000", str(lap[0]), str(lap[1]), out, vocp], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    mono, kps, desc, pyr, d01, bow, fv, self_score, nm, m12 = _read(out)
+    mono, kps, desc, pyr, d01, bow, fv, self_score, nm, m12, nproj, proj = _read(out)
     assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc)
     for l in range(8):
         assert np.array_equal(pyr[l], ora.level(l))
@@ -93,3 +95,13 @@ def test_adapter_results_equal_oracle(tmp_path, rows, cols, lap):
     prev = np.stack([okps["x"], okps["y"]], 1).astype(np.float32)
     on, om12, _ = po.search_for_initialization(okps, odesc, okps, odesc, (0, 0, cols, rows), prev, 100, 0.9, True)
     assert nm == on and np.array_equal(m12, om12)
+    # SearchByProjection through the C++ template, same flattened state through the oracle (src/ORBmatcher.cc:43-141)
+    n = len(okps)
+    i = np.arange(n)
+    mp = dict(in_view=((i % 5 != 0) & (i % 7 != 0) & (i % 13 != 0)).astype(np.uint8), proj_x=(okps["x"] + np.float32(1.5)).astype(np.float32),
+              proj_y=(okps["y"] + np.float32(0.5)).astype(np.float32), view_cos=np.where(i & 1, 0.9, 0.999).astype(np.float32),
+              level=okps["octave"].astype(np.int32), desc=odesc, obs=np.where(i % 3 == 0, 0, 2).astype(np.int32), proj_xr=None)
+    kp_obs = np.where(i % 11 == 0, 4, -1).astype(np.int32)
+    sf = ora.tables()["scale"]
+    on, omatch, _ = po.search_by_projection(okps, odesc, (0, 0, cols, rows), sf, kp_obs, mp, 3.0, 0.8)
+    assert nproj == on and np.array_equal(proj, omatch) and on > 100

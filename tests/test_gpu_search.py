@@ -106,3 +106,74 @@ def test_compute_stereo_matches_degenerate():
     assert kept == okept and ur.tobytes() == our.tobytes() and dp.tobytes() == odp.tobytes()
     ur, dp, kept = ORBmatcher.ComputeStereoMatches(exL, exR, kL, dL, kR[:0], dR[:0], 0.11, 47.9)
     assert kept == 0 and (ur == -1).all() and (dp == -1).all()
+
+
+def _map_points(Fa, Fb, rng, stereo):
+    """Local-map stand-in: the keypoints of frame A seen as map points projected into frame B (small drift + noise)."""
+    ka = Fa.mvKeysUn
+    n = len(ka)
+    mp = dict(
+        in_view=(rng.random(n) < 0.9).astype(np.uint8),
+        proj_x=(ka["x"] + 1.5 + rng.normal(0, 1.0, n)).astype(np.float32),
+        proj_y=(ka["y"] + 0.5 + rng.normal(0, 1.0, n)).astype(np.float32),
+        view_cos=rng.choice([0.9, 0.9979, 0.998, 0.9981, 1.0], n).astype(np.float32),
+        level=np.clip(ka["octave"] + rng.integers(-1, 2, n), 0, 7).astype(np.int32),
+        desc=Fa.mDescriptors.copy(),
+        obs=rng.choice([0, 0, 1, 3, 7], n).astype(np.int32),
+    )
+    mp["proj_xr"] = (mp["proj_x"] - rng.uniform(0.5, 30, n)).astype(np.float32) if stereo else None
+    return mp
+
+
+@pytest.mark.parametrize("th,ratio,stereo", [(1.0, 0.8, False), (3.0, 0.8, False), (1.0, 0.8, True), (5.0, 0.6, True), (15.0, 0.9, False)])
+def test_search_by_projection_equals_oracle(frames, th, ratio, stereo):
+    gpu, fr = frames
+    m = ORBmatcher(gpu, ratio, True)
+    rng = np.random.default_rng(int(th * 10) + stereo)
+    sf = gpu.GetScaleFactors()
+    total = 0
+    for Fa, Fb in ((fr[0], fr[1]), (fr[1], fr[2])):
+        mp = _map_points(Fa, Fb, rng, stereo)
+        nb = len(Fb.mvKeysUn)
+        kp_obs = rng.choice([-1, -1, -1, 0, 2], nb).astype(np.int32)            # some keypoints are already bound
+        u_right = np.where(rng.random(nb) < 0.6, Fb.mvKeysUn["x"] - rng.uniform(0.5, 30, nb), -1.0).astype(np.float32) if stereo else None
+        Fb.mvScaleFactors, Fb.mvuRight, Fb.kp_obs = sf, u_right, kp_obs.copy()
+        n, match = m.SearchByProjection(Fb, mp, th)
+        on, omatch, oobs = po.search_by_projection(Fb.mvKeysUn, Fb.mDescriptors, Fb.bounds, sf, kp_obs, mp, th, ratio, u_right)
+        assert n == on and np.array_equal(match, omatch) and np.array_equal(Fb.kp_obs, oobs)
+        assert n >= (match >= 0).sum()       # a keypoint bound to an unobserved map point may be re-bound (counted twice)
+        total += n
+    assert total > 200
+
+
+def test_window_search_gates_and_best_second(frames):
+    gpu, fr = frames
+    m = ORBmatcher(gpu)
+    Fa, Fb = fr[0], fr[1]
+    k, d = Fb.mvKeysUn, Fb.mDescriptors
+    rng = np.random.default_rng(11)
+    nq = min(len(Fa.mvKeysUn), 1500)
+    qx, qy = Fa.mvKeysUn["x"][:nq].copy(), Fa.mvKeysUn["y"][:nq].copy()
+    qr = rng.choice([4.0, 12.0, 30.0], nq).astype(np.float32)
+    lo = np.maximum(Fa.mvKeysUn["octave"][:nq] - 1, 0).astype(np.int32); hi = (lo + 1).astype(np.int32)
+    skip = (rng.random(len(k)) < 0.3).astype(np.uint8)
+    ur = np.where(rng.random(len(k)) < 0.5, k["x"] - 5.0, -1.0).astype(np.float32)
+    qxr = (qx - rng.uniform(0, 12, nq)).astype(np.float32)
+    w = m.WindowSearch(k, d, Fb.bounds, qx, qy, qr, lo, hi, Fa.mDescriptors[:nq], skip, ur, qxr)
+    # oracle: plain window lists, then the gates and the scan in the reference's order
+    orp, ocand = po.features_in_area(k, Fb.bounds, qx, qy, qr, lo, hi)
+    rp, cand = [0], []
+    for q in range(nq):
+        for c in ocand[orp[q]:orp[q + 1]]:
+            if skip[c]:
+                continue
+            if ur[c] > 0 and abs(np.float32(qxr[q] - ur[c])) > qr[q]:
+                continue
+            cand.append(c)
+        rp.append(len(cand))
+    assert np.array_equal(w["row_ptr"], np.array(rp, np.int32)) and np.array_equal(w["cand"], np.array(cand, np.int32))
+    bi, bd, si, sd, do = po.nn_csr(Fa.mDescriptors[:nq], d, w["row_ptr"], w["cand"])
+    assert np.array_equal(w["dist"], do)
+    assert np.array_equal(w["best_idx"], bi) and np.array_equal(w["best_dist"], bd)
+    assert np.array_equal(w["second_idx"], si) and np.array_equal(w["second_dist"], sd)
+    assert len(cand) > 2000

@@ -222,3 +222,51 @@ def test_frame_grid_area_against_bruteforce():
         assert (np.diff(key) >= 0).all()                        # x-major, then y
         same = np.diff(key) == 0
         assert (np.diff(got)[same] > 0).all()                   # insertion order inside a cell
+
+
+def test_search_by_projection_hand_case():
+    """src/ORBmatcher.cc:43-141 on a case small enough to follow by hand: ratio test only within one level, a keypoint
+    bound to an observed map point disappears for later map points, one bound to an unobserved one can be re-bound."""
+    from orb_slam3_modified_amd._lib import KP_DTYPE
+    kps = np.zeros(3, KP_DTYPE)
+    kps["x"] = [100.0, 102.0, 300.0]; kps["y"] = [100.0, 100.0, 200.0]; kps["octave"] = [0, 0, 1]
+    desc = np.zeros((3, 32), np.uint8)
+    desc[1, 0] = 0x0f            # 4 bits from keypoint 0
+    desc[2, :8] = 0xff           # far away
+    sf = (1.2 ** np.arange(8)).astype(np.float32)
+    bounds = (0.0, 0.0, 640.0, 480.0)
+
+    def mp(n, **kw):
+        d = dict(in_view=np.ones(n, np.uint8), proj_x=np.full(n, 101.0, np.float32), proj_y=np.full(n, 100.0, np.float32),
+                 view_cos=np.ones(n, np.float32), level=np.zeros(n, np.int32), desc=np.zeros((n, 32), np.uint8), obs=np.ones(n, np.int32),
+                 proj_xr=None)
+        d.update(kw)
+        return d
+
+    free = np.full(3, -1, np.int32)
+    # one map point, descriptor == keypoint 0: best 0 (d=0), second keypoint 1 (d=4), same level: 0 > 0.8*4 is false -> bound
+    n, match, obs = po.search_by_projection(kps, desc, bounds, sf, free, mp(1), 1.0, 0.8)
+    assert n == 1 and match.tolist() == [0, -1, -1] and obs.tolist() == [1, -1, -1]
+    # descriptor half way (2 bits from kp 0, 2 from kp 1): ratio test 2 > 0.8*2 rejects it
+    half = np.zeros((1, 32), np.uint8); half[0, 0] = 0x03
+    n, match, _ = po.search_by_projection(kps, desc, bounds, sf, free, mp(1, desc=half), 1.0, 0.8)
+    assert n == 0 and match.tolist() == [-1, -1, -1]
+    # two identical observed map points: the first takes keypoint 0, the second then only sees keypoint 1 (d=4 <= TH_HIGH)
+    n, match, obs = po.search_by_projection(kps, desc, bounds, sf, free, mp(2), 1.0, 0.8)
+    assert n == 2 and match.tolist() == [0, 1, -1]
+    # ... but if the first one has no observations the keypoint stays available and is re-bound (counted twice)
+    n, match, obs = po.search_by_projection(kps, desc, bounds, sf, free, mp(2, obs=np.array([0, 5], np.int32)), 1.0, 0.8)
+    assert n == 2 and match.tolist() == [1, -1, -1] and obs.tolist() == [5, -1, -1]
+    # a keypoint already bound to an observed point is never a candidate
+    n, match, _ = po.search_by_projection(kps, desc, bounds, sf, np.array([3, -1, -1], np.int32), mp(1), 1.0, 0.8)
+    assert n == 1 and match.tolist() == [-1, 0, -1]
+    # window radius: 4.0 px at view_cos <= 0.998, 2.5 px above (kp 0 at 1 px, kp 1 at 1 px) ; th scales it
+    far = mp(1, proj_x=np.array([104.2], np.float32))          # 4.2 / 2.2 px away
+    assert po.search_by_projection(kps, desc, bounds, sf, free, far, 1.0, 0.8)[1].tolist() == [-1, 0, -1]   # only kp 1 (2.2 < 2.5)
+    assert po.search_by_projection(kps, desc, bounds, sf, free, far, 2.0, 0.8)[1].tolist() == [0, -1, -1]   # r = 5: both, kp 0 wins
+    # rectified-stereo gate: uRight of keypoint 0 disagrees with the projection by more than r
+    ur = np.array([50.0, -1.0, -1.0], np.float32)
+    n, match, _ = po.search_by_projection(kps, desc, bounds, sf, free, mp(1, proj_xr=np.array([60.0], np.float32)), 1.0, 0.8, ur)
+    assert match.tolist() == [-1, 0, -1]
+    # not in view -> nothing
+    assert po.search_by_projection(kps, desc, bounds, sf, free, mp(1, in_view=np.zeros(1, np.uint8)), 1.0, 0.8)[0] == 0

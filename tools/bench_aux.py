@@ -95,6 +95,23 @@ for _ in range(20): nm, _m = m.SearchForInitialization(F1, F2, prev.copy(), 100)
 res["search_for_initialization"] = {"level0_queries": int((F1.mvKeysUn["octave"] == 0).sum()), "matches": int(nm),
                                     "ms_per_call": (time.perf_counter() - t0) / 20 * 1e3,
                                     "note": "host buffers; grid build + candidate CSR + distances on the GPU, greedy replay on the host"}
+# SearchByProjection(Frame, local map points): frame 0's 1000-feature keypoints as 1000 map points projected into frame 1
+ex1k = ORBextractor(1000, 1.2, 8, 20, 7)
+fb = [ex1k(f, None, (0, 1000)) for f in frames[:2]]
+Fp = F(fb[1][1], fb[1][2]); Fp.mvScaleFactors = ex1k.GetScaleFactors(); Fp.mvuRight = None
+ka = fb[0][1]
+mp = dict(in_view=np.ones(len(ka), np.uint8), proj_x=(ka["x"] + np.float32(1.5)).astype(np.float32), proj_y=(ka["y"] + np.float32(0.5)).astype(np.float32),
+          view_cos=np.ones(len(ka), np.float32), level=ka["octave"].astype(np.int32), desc=fb[0][2], obs=np.full(len(ka), 3, np.int32), proj_xr=None)
+m8 = ORBmatcher(ex1k, 0.8, True)
+def _sbp():
+    Fp.kp_obs = np.full(len(Fp.mvKeysUn), -1, np.int32)
+    return m8.SearchByProjection(Fp, mp, 3.0)
+for _ in range(3): _sbp()
+t0 = time.perf_counter()
+for _ in range(20): nmp_, _m = _sbp()
+res["search_by_projection_mappoints"] = {"map_points": len(ka), "keypoints": len(Fp.mvKeysUn), "matches": int(nmp_),
+                                         "ms_per_call": (time.perf_counter() - t0) / 20 * 1e3,
+                                         "note": "host buffers; one device pass (grid, windows, gates, distances), greedy replay on the host"}
 Ls = synth.make_stream(1, 480, 752)[0]; Rs = np.roll(Ls, -12, axis=1).copy()
 exL, exR = ORBextractor(1200, 1.2, 8, 20, 7), ORBextractor(1200, 1.2, 8, 20, 7)
 _, kL, dL = exL(Ls, None, (0, 0)); _, kR, dR = exR(Rs, None, (0, 0))
