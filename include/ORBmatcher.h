@@ -4,7 +4,8 @@
  * (src/ORBmatcher.cc; per-routine tie and accept rules: SURVEY.md §3.3).
  *
  * SearchForInitialization (the heaviest Hamming workload of monocular tracking, src/ORBmatcher.cc:648-763) and
- * SearchByProjection(Frame&, vector<MapPoint*>&, ...) (the per-frame local-map search, :43-141) are provided in full as
+ * SearchByProjection(Frame&, vector<MapPoint*>&, ...) (the per-frame local-map search, :43-141) and
+ * SearchByProjection(CurrentFrame, LastFrame, th, bMono) (the motion-model search, :1676-1885) are provided in full as
  * templates over the reference's Frame / MapPoint.  The other routines take KeyFrame / Sophus types that belong to the
  * reference and are out of this repository's scope; INTEGRATION.md shows the few-line change that routes
  * each routine's candidate loop through NearestInCandidates() below while the geometry and the greedy bookkeeping
@@ -139,6 +140,59 @@ class ORBmatcher {
     if (rc != ORBX_OK) throw std::runtime_error(std::string("ORBmatcher::SearchByProjection: ") + orbx_last_error(DefaultContext()));
     for (int i = 0; i < n; i++)
       if (kpMatch[i] >= 0) F.mvpMapPoints[i] = vpMapPoints[kpMatch[i]];
+    return nmatches;
+  }
+
+  // Tracking::TrackWithMotionModel's projection search, src/ORBmatcher.cc:1676-1885 (same arguments, same return value,
+  // same CurrentFrame.mvpMapPoints afterwards).  The pose / camera arithmetic (:1686-1718) runs here through the
+  // reference's own types (Sophus::SE3f, GeometricCamera — whatever FrameT provides); windows, gates and Hamming
+  // distances run on the GPU, the greedy part and the rotation filter are replayed in the reference's order.
+  template <class FrameT>
+  int SearchByProjection(FrameT& CurrentFrame, const FrameT& LastFrame, const float th, const bool bMono) {
+    if (CurrentFrame.Nleft != -1 || LastFrame.Nleft != -1)
+      throw std::runtime_error("ORBmatcher::SearchByProjection: two-camera frames are not routed to the GPU");
+    const auto Tcw = CurrentFrame.GetPose();
+    const auto twc = Tcw.inverse().translation();
+    const auto Tlw = LastFrame.GetPose();
+    const auto tlc = Tlw * twc;
+    const bool bForward = tlc(2) > CurrentFrame.mb && !bMono;
+    const bool bBackward = -tlc(2) > CurrentFrame.mb && !bMono;
+    const int n = (int)CurrentFrame.mvKeysUn.size(), nlast = LastFrame.N;
+    if (n == 0 || nlast == 0) return 0;
+    if (!CurrentFrame.mDescriptors.isContinuous()) throw std::runtime_error("descriptor matrix must be continuous");
+    std::vector<unsigned char> valid(nlast, 0), lpDesc((size_t)nlast * 32, 0);
+    std::vector<float> u(nlast, 0.f), v(nlast, 0.f), invz(nlast, 0.f), ang(nlast, 0.f);
+    std::vector<int32_t> oct(nlast, 0), obs(nlast, 0), kpObs(n, -1), kpMatch(n, -1);
+    for (int i = 0; i < nlast; i++) {
+      auto* pMP = LastFrame.mvpMapPoints[i];
+      if (!pMP || LastFrame.mvbOutlier[i]) continue;
+      const auto x3Dw = pMP->GetWorldPos();
+      const auto x3Dc = Tcw * x3Dw;
+      const float invzc = 1.0 / x3Dc(2);
+      if (invzc < 0) continue;
+      const auto uv = CurrentFrame.mpCamera->project(x3Dc);
+      if (uv(0) < FrameT::mnMinX || uv(0) > FrameT::mnMaxX) continue;
+      if (uv(1) < FrameT::mnMinY || uv(1) > FrameT::mnMaxY) continue;
+      valid[i] = 1; u[i] = uv(0); v[i] = uv(1); invz[i] = invzc;
+      oct[i] = LastFrame.mvKeys[i].octave; ang[i] = LastFrame.mvKeysUn[i].angle; obs[i] = pMP->Observations();
+      const cv::Mat d = pMP->GetDescriptor();
+      std::memcpy(&lpDesc[(size_t)i * 32], d.template ptr<unsigned char>(), 32);
+    }
+    for (int i = 0; i < n; i++)
+      if (CurrentFrame.mvpMapPoints[i]) kpObs[i] = CurrentFrame.mvpMapPoints[i]->Observations();
+    const bool stereo = !CurrentFrame.mvuRight.empty();
+    int nmatches = 0;
+    const int rc = orbx_search_by_projection_last(
+        DefaultContext(), (const orbx_keypoint*)CurrentFrame.mvKeysUn.data(), CurrentFrame.mDescriptors.data,
+        stereo ? CurrentFrame.mvuRight.data() : nullptr, kpObs.data(), n, FrameT::mnMinX, FrameT::mnMinY, FrameT::mnMaxX, FrameT::mnMaxY,
+        CurrentFrame.mvScaleFactors.data(), (int)CurrentFrame.mvScaleFactors.size(), CurrentFrame.mbf, valid.data(), u.data(), v.data(),
+        invz.data(), oct.data(), ang.data(), lpDesc.data(), obs.data(), nlast, th, bForward ? 1 : (bBackward ? 2 : 0),
+        mbCheckOrientation ? 1 : 0, kpMatch.data(), &nmatches);
+    if (rc != ORBX_OK) throw std::runtime_error(std::string("ORBmatcher::SearchByProjection: ") + orbx_last_error(DefaultContext()));
+    for (int i = 0; i < n; i++) {
+      if (kpMatch[i] >= 0) CurrentFrame.mvpMapPoints[i] = LastFrame.mvpMapPoints[kpMatch[i]];
+      else if (kpMatch[i] == -2) CurrentFrame.mvpMapPoints[i] = nullptr;
+    }
     return nmatches;
   }
 

@@ -217,6 +217,21 @@ int orbx_search_by_projection(orbx_ctx* ctx, const orbx_keypoint* kps_un, const 
                               const float* mp_view_cos, const int32_t* mp_level, const uint8_t* mp_desc, const int32_t* mp_obs, int nmp,
                               float th, float nn_ratio, int32_t* kp_match, int* nmatches);
 
+/* ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) (src/ORBmatcher.cc:1676-1885;
+ * Tracking::TrackWithMotionModel's per-frame call) for CurrentFrame.Nleft == -1, from the point where the last frame's
+ * map points have been projected (:1705-1718 are the caller's pose / camera-model arithmetic):
+ *   lp_valid [nlast] = pMP && !mvbOutlier[i] && invzc >= 0 && uv inside the image bounds; lp_u / lp_v = uv; lp_invz = invzc
+ *   (read only when u_right is given); lp_octave = nLastOctave; lp_angle = the last frame's keypoint angle; lp_desc =
+ *   pMP->GetDescriptor(); lp_obs = pMP->Observations().  direction: 0 neither, 1 bForward, 2 bBackward (:1691-1692).
+ * Frame arrays as in orbx_search_by_projection; mbf = CurrentFrame.mbf.
+ * kp_match [n] out: -1 untouched, >= 0 index i of the last-frame point now bound to the keypoint, -2 set to NULL by the
+ * rotation-consistency filter; kp_obs updated accordingly; *nmatches = the reference's return value. */
+int orbx_search_by_projection_last(orbx_ctx* ctx, const orbx_keypoint* kps_un, const uint8_t* desc, const float* u_right, int32_t* kp_obs,
+                                   int n, float min_x, float min_y, float max_x, float max_y, const float* scale_factors, int nlevels,
+                                   float mbf, const uint8_t* lp_valid, const float* lp_u, const float* lp_v, const float* lp_invz,
+                                   const int32_t* lp_octave, const float* lp_angle, const uint8_t* lp_desc, const int32_t* lp_obs, int nlast,
+                                   float th, int direction, int check_orientation, int32_t* kp_match, int* nmatches);
+
 /* Frame::ComputeStereoMatches (src/Frame.cc:811-981) on the DEVICE pyramids of the left and right extractor (the
  * last frame each context extracted; both on one GPU, same image shape) — this is the reader of the reference's public
  * ORBextractor::mvImagePyramid, so with it no pyramid has to be copied to the host.  kps / desc: the keypoints and

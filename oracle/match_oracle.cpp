@@ -421,6 +421,78 @@ int mo_search_by_projection(const void* kps_, const uint8_t* desc, const float* 
   return nmatches;
 }
 
+// ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono), src/ORBmatcher.cc:1676-1885,
+// for CurrentFrame.Nleft == -1, from the point where the last frame's map point i has been projected (:1705-1718 are the
+// caller's Sophus / camera-model arithmetic): lp_valid[i] folds `pMP && !mvbOutlier[i] && invzc >= 0 && uv inside the
+// image bounds`; lp_u / lp_v = uv, lp_invz = invzc, lp_octave = nLastOctave, lp_angle = the last frame's keypoint angle.
+// direction: 0 = neither, 1 = bForward, 2 = bBackward (:1691-1692).  kp_obs as in mo_search_by_projection.
+// kp_match[i2]: -1 untouched, >= 0 index i of the last-frame point now in CurrentFrame.mvpMapPoints[i2], -2 set to NULL by
+// the rotation filter.  Returns nmatches.
+int mo_search_by_projection_last(const void* kps_, const uint8_t* desc, const float* mvuRight, int32_t* kp_obs, int n, float mnMinX,
+                                 float mnMinY, float mnMaxX, float mnMaxY, const float* mvScaleFactors, float mbf,
+                                 const uint8_t* lp_valid, const float* lp_u, const float* lp_v, const float* lp_invz,
+                                 const int32_t* lp_octave, const float* lp_angle, const uint8_t* lp_desc, const int32_t* lp_obs, int nlast,
+                                 float th, int direction, int mbCheckOrientation, int32_t* kp_match) {
+  const MKeyPt* kps = (const MKeyPt*)kps_;
+  const int TH_HIGH = 100, HISTO_LENGTH = 30;
+  FrameGrid Cur(kps, n, mnMinX, mnMinY, mnMaxX, mnMaxY);
+  for (int i = 0; i < n; i++) kp_match[i] = -1;
+  int nmatches = 0;
+  std::vector<int> rotHist[30];
+  const float factor = 1.0f / HISTO_LENGTH;
+  const bool bForward = direction == 1, bBackward = direction == 2;
+  for (int i = 0; i < nlast; i++) {
+    if (!lp_valid[i]) continue;
+    const float u = lp_u[i], v = lp_v[i], invzc = lp_invz[i];
+    const int nLastOctave = lp_octave[i];
+    float radius = th * mvScaleFactors[nLastOctave];
+    std::vector<size_t> vIndices2;
+    if (bForward) vIndices2 = Cur.area(u, v, radius, nLastOctave, -1);
+    else if (bBackward) vIndices2 = Cur.area(u, v, radius, 0, nLastOctave);
+    else vIndices2 = Cur.area(u, v, radius, nLastOctave - 1, nLastOctave + 1);
+    if (vIndices2.empty()) continue;
+    const uint8_t* dMP = lp_desc + (size_t)i * 32;
+    int bestDist = 256, bestIdx2 = -1;
+    for (size_t i2 : vIndices2) {
+      if (kp_obs[i2] > 0) continue;
+      if (mvuRight && mvuRight[i2] > 0) {
+        const float ur = u - mbf * invzc;
+        const float er = fabs(ur - mvuRight[i2]);
+        if (er > radius) continue;
+      }
+      const int dist = descriptor_distance(dMP, desc + i2 * 32);
+      if (dist < bestDist) { bestDist = dist; bestIdx2 = (int)i2; }
+    }
+    if (bestDist <= TH_HIGH) {
+      kp_match[bestIdx2] = i;
+      kp_obs[bestIdx2] = lp_obs[i];
+      nmatches++;
+      if (mbCheckOrientation) {
+        float rot = lp_angle[i] - kps[bestIdx2].angle;
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)round(rot * factor);
+        if (bin == HISTO_LENGTH) bin = 0;
+        assert(bin >= 0 && bin < HISTO_LENGTH);
+        rotHist[bin].push_back(bestIdx2);
+      }
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i != ind1 && i != ind2 && i != ind3) {
+        for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+          kp_match[rotHist[i][j]] = -2;   // CurrentFrame.mvpMapPoints[...] = NULL
+          kp_obs[rotHist[i][j]] = -1;
+          nmatches--;
+        }
+      }
+    }
+  }
+  return nmatches;
+}
+
 }  // extern "C"
 
 extern "C" {

@@ -274,6 +274,29 @@ def search_by_projection(kps, desc, bounds, scale_factors, kp_obs, mp, th=1.0, n
     return int(n), match[:len(k)].copy(), obs
 
 
+def search_by_projection_last(kps, desc, bounds, scale_factors, kp_obs, lp, th, direction=0, check_ori=True, u_right=None, mbf=0.0):
+    """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (src/ORBmatcher.cc:1676-1885, Nleft == -1) after
+    the projection step, on flattened state -> (nmatches, kp_match, updated kp_obs)."""
+    k = np.ascontiguousarray(kps)
+    d = np.ascontiguousarray(desc, np.uint8)
+    obs = np.ascontiguousarray(kp_obs, np.int32).copy()
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    valid = np.ascontiguousarray(lp["valid"], np.uint8)
+    u, v, invz, ang = (np.ascontiguousarray(lp[key], np.float32) for key in ("u", "v", "invz", "angle"))
+    octv, lobs = (np.ascontiguousarray(lp[key], np.int32) for key in ("octave", "obs"))
+    ld = np.ascontiguousarray(lp["desc"], np.uint8)
+    ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    match = np.zeros(max(len(k), 1), np.int32)
+    L = _mlib()
+    vp, f32 = C.c_void_p, C.c_float
+    L.mo_search_by_projection_last.restype = C.c_int
+    L.mo_search_by_projection_last.argtypes = [vp] * 4 + [C.c_int] + [f32] * 4 + [vp, f32] + [vp] * 8 + [C.c_int, f32, C.c_int, C.c_int, vp]
+    n = L.mo_search_by_projection_last(_ptr(k), _ptr(d), _ptr(ur) if ur is not None else None, _ptr(obs), len(k), *[float(b) for b in bounds],
+                                       _ptr(sf), float(mbf), _ptr(valid), _ptr(u), _ptr(v), _ptr(invz), _ptr(octv), _ptr(ang), _ptr(ld),
+                                       _ptr(lobs), len(u), float(th), int(direction), int(check_ori), _ptr(match))
+    return int(n), match[:len(k)].copy(), obs
+
+
 def stereo_matches(kpsL, descL, kpsR, descR, pyrL, pyrR, scale, inv_scale, mb, mbf):
     """Frame::ComputeStereoMatches (src/Frame.cc:811-981) -> (mvuRight, mvDepth, number of matches kept)."""
     kL, kR = np.ascontiguousarray(kpsL), np.ascontiguousarray(kpsR)

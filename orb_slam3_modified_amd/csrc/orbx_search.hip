@@ -667,6 +667,92 @@ int orbx_search_by_projection(orbx_ctx* ctx, const orbx_keypoint* kps_un, const 
   return ORBX_OK;
 }
 
+int orbx_search_by_projection_last(orbx_ctx* ctx, const orbx_keypoint* kps_un, const uint8_t* desc, const float* u_right, int32_t* kp_obs,
+                                   int n, float min_x, float min_y, float max_x, float max_y, const float* scale_factors, int nlevels,
+                                   float mbf, const uint8_t* lp_valid, const float* lp_u, const float* lp_v, const float* lp_invz,
+                                   const int32_t* lp_octave, const float* lp_angle, const uint8_t* lp_desc, const int32_t* lp_obs, int nlast,
+                                   float th, int direction, int check_orientation, int32_t* kp_match, int* nmatches_out) {
+  if (!ctx || n < 0 || nlast < 0 || nlevels <= 0 || !scale_factors || !nmatches_out || direction < 0 || direction > 2 ||
+      (n > 0 && (!kps_un || !desc || !kp_obs || !kp_match)) ||
+      (nlast > 0 && (!lp_valid || !lp_u || !lp_v || !lp_octave || !lp_angle || !lp_desc || !lp_obs)) || (u_right && nlast > 0 && !lp_invz) ||
+      !(max_x > min_x) || !(max_y > min_y))
+    return ctx ? set_err(ctx, ORBX_E_INVALID, "orbx_search_by_projection_last: bad arguments") : ORBX_E_INVALID;
+  *nmatches_out = 0;
+  for (int i = 0; i < n; i++) kp_match[i] = -1;
+  if (n == 0 || nlast == 0) return ORBX_OK;
+  ORBX_HIP(ctx, hipSetDevice(ctx->device));
+  std::vector<int> qi;
+  std::vector<float> qx, qy, qr, qxr;
+  std::vector<int32_t> qlo, qhi;
+  std::vector<uint8_t> qd;
+  for (int i = 0; i < nlast; i++) {
+    if (!lp_valid[i]) continue;
+    const int oct = lp_octave[i];
+    if (oct < 0 || oct >= nlevels) return set_err(ctx, ORBX_E_INVALID, "orbx_search_by_projection_last: octave out of range");
+    qi.push_back(i);
+    qx.push_back(lp_u[i]); qy.push_back(lp_v[i]); qr.push_back(th * scale_factors[oct]);   // :1724
+    qxr.push_back(u_right ? lp_u[i] - mbf * lp_invz[i] : 0.f);                              // :1754
+    if (direction == 1) { qlo.push_back(oct); qhi.push_back(-1); }                           // :1728-1733
+    else if (direction == 2) { qlo.push_back(0); qhi.push_back(oct); }
+    else { qlo.push_back(oct - 1); qhi.push_back(oct + 1); }
+    qd.insert(qd.end(), lp_desc + (size_t)i * 32, lp_desc + (size_t)i * 32 + 32);
+  }
+  const int nq = (int)qi.size();
+  if (nq == 0) return ORBX_OK;
+  std::vector<uint8_t> skip(n);
+  for (int i = 0; i < n; i++) skip[i] = kp_obs[i] > 0;
+  ArenaScope scope(ctx);
+  AreaGates gates;
+  gates.kp_skip = skip.data(); gates.kp_uright = u_right; gates.qxr = u_right ? qxr.data() : nullptr; gates.n = n;
+  WindowResult w;
+  int rc = window_search_core(ctx, kps_un, desc, n, min_x, min_y, max_x, max_y, gates, qx.data(), qy.data(), qr.data(), qlo.data(),
+                              qhi.data(), qd.data(), nq, false, w);
+  if (rc != ORBX_OK) return rc;
+  // host replay in the last frame's keypoint order (:1738-1790), then the rotation filter (:1862-1882)
+  const int TH_HIGH = 100, HISTO_LENGTH = 30;
+  const float factor = 1.0f / HISTO_LENGTH;
+  std::vector<int> rotHist[30];
+  int nmatches = 0;
+  for (int q = 0; q < nq; q++) {
+    const int i = qi[q];
+    int bestDist = 256, bestIdx2 = -1;
+    for (int c = w.row_ptr[q]; c < w.row_ptr[q + 1]; c++) {
+      const int i2 = w.cand[c], d = w.dist[c];
+      if (kp_obs[i2] > 0) continue;
+      if (d < bestDist) { bestDist = d; bestIdx2 = i2; }
+    }
+    if (bestDist <= TH_HIGH) {
+      kp_match[bestIdx2] = i;
+      kp_obs[bestIdx2] = lp_obs[i];
+      nmatches++;
+      if (check_orientation) {
+        float rot = lp_angle[i] - kps_un[bestIdx2].angle;
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)std::round(rot * factor);
+        if (bin == HISTO_LENGTH) bin = 0;
+        if (bin >= 0 && bin < HISTO_LENGTH) rotHist[bin].push_back(bestIdx2);
+      }
+    }
+  }
+  if (check_orientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < HISTO_LENGTH; i++) {  // ComputeThreeMaxima, src/ORBmatcher.cc:2012-2053
+      const int s = (int)rotHist[i].size();
+      if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+      else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+      else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int idx : rotHist[i]) { kp_match[idx] = -2; kp_obs[idx] = -1; nmatches--; }
+    }
+  }
+  *nmatches_out = nmatches;
+  return ORBX_OK;
+}
+
 int orbx_stereo_matches(orbx_ctx* left, orbx_ctx* right, const orbx_keypoint* kpsL, const uint8_t* descL, int nL,
                         const orbx_keypoint* kpsR, const uint8_t* descR, int nR, float mb, float mbf, float* u_right, float* depth,
                         int* nmatches) {

@@ -135,6 +135,27 @@ class ORBmatcher:
                                                 ptr(obs), len(inv), float(th), self.mfNNratio, ptr(match), C.byref(n)), self._ctx)
         return n.value, match[:len(k)].copy()
 
+    def SearchByProjectionLastFrame(self, F, lp, th: float, direction: int = 0, mbf: float = 0.0):
+        """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (src/ORBmatcher.cc:1676-1885), Nleft == -1, after
+        the caller's projection step.  F as in SearchByProjection; lp: dict of arrays valid, u, v, invz, octave, angle, desc, obs
+        (one entry per last-frame keypoint).  Returns (nmatches, kp_match [n]: -1 untouched / i bound / -2 cleared)."""
+        k = np.ascontiguousarray(F.mvKeysUn)
+        d = np.ascontiguousarray(F.mDescriptors, np.uint8).reshape(-1, 32)
+        ur = None if getattr(F, "mvuRight", None) is None else np.ascontiguousarray(F.mvuRight, np.float32)
+        assert F.kp_obs.dtype == np.int32 and F.kp_obs.flags["C_CONTIGUOUS"] and len(F.kp_obs) == len(k)
+        sf = np.ascontiguousarray(F.mvScaleFactors, np.float32)
+        valid = np.ascontiguousarray(lp["valid"], np.uint8)
+        u, v, invz, ang = (np.ascontiguousarray(lp[key], np.float32) for key in ("u", "v", "invz", "angle"))
+        octv, obs = (np.ascontiguousarray(lp[key], np.int32) for key in ("octave", "obs"))
+        ld = np.ascontiguousarray(lp["desc"], np.uint8).reshape(-1, 32)
+        match = np.zeros(max(len(k), 1), np.int32)
+        n = C.c_int(0)
+        check(self._L.orbx_search_by_projection_last(self._ctx, ptr(k), ptr(d), ptr(ur), ptr(F.kp_obs), len(k), *[float(b) for b in F.bounds],
+                                                     ptr(sf), len(sf), float(mbf), ptr(valid), ptr(u), ptr(v), ptr(invz), ptr(octv), ptr(ang),
+                                                     ptr(ld), ptr(obs), len(valid), float(th), int(direction), int(self.mbCheckOrientation),
+                                                     ptr(match), C.byref(n)), self._ctx)
+        return n.value, match[:len(k)].copy()
+
     @staticmethod
     def ComputeStereoMatches(left_extractor, right_extractor, kpsL, descL, kpsR, descR, mb: float, mbf: float):
         """Frame::ComputeStereoMatches (src/Frame.cc:811-981) on the device pyramids of the two extractors (each must

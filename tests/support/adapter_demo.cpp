@@ -25,6 +25,8 @@ struct MiniFrame {
 float MiniFrame::mnMinX = 0, MiniFrame::mnMinY = 0, MiniFrame::mnMaxX = 0, MiniFrame::mnMaxY = 0;
 
 // ... and the members of Frame / MapPoint that ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, ...) touches
+struct V3 { float v[3]; float operator()(int k) const { return v[k]; } };
+struct V2 { float v[2]; float operator()(int k) const { return v[k]; } };
 struct MiniMapPoint {
   bool mbTrackInView = true, mbTrackInViewR = false, bad = false;
   float mTrackDepth = 1.f, mTrackProjX = 0, mTrackProjY = 0, mTrackProjXR = 0, mTrackViewCos = 1.f;
@@ -33,11 +35,30 @@ struct MiniMapPoint {
   bool isBad() const { return bad; }
   int Observations() const { return nObs; }
   cv::Mat GetDescriptor() const { return desc.clone(); }
+  V3 world{{0, 0, 1}};
+  V3 GetWorldPos() const { return world; }
+};
+// stand-ins for Eigen::Vector3f / Vector2f, Sophus::SE3f (identity rotation) and GeometricCamera (pinhole)
+struct MiniSE3 {
+  V3 t{{0, 0, 0}};
+  MiniSE3 inverse() const { MiniSE3 r; r.t = V3{{-t.v[0], -t.v[1], -t.v[2]}}; return r; }
+  V3 translation() const { return t; }
+  V3 operator*(const V3& p) const { return V3{{p.v[0] + t.v[0], p.v[1] + t.v[1], p.v[2] + t.v[2]}}; }
+};
+struct MiniCamera {
+  float fx = 500.f, cx = 320.f, cy = 240.f;
+  V2 project(const V3& p) const { return V2{{fx * (p(0) / p(2)) + cx, fx * (p(1) / p(2)) + cy}}; }
 };
 struct MiniFrame2 : MiniFrame {
-  int Nleft = -1;
+  int Nleft = -1, N = 0;
+  float mb = 0.1f, mbf = 50.f;
   std::vector<float> mvuRight, mvScaleFactors;
   std::vector<MiniMapPoint*> mvpMapPoints;
+  std::vector<bool> mvbOutlier;
+  std::vector<cv::KeyPoint> mvKeys;
+  MiniSE3 pose;
+  MiniCamera cam, *mpCamera = &cam;
+  MiniSE3 GetPose() const { return pose; }
 };
 
 int main(int argc, char** argv) {
@@ -166,6 +187,35 @@ int main(int argc, char** argv) {
       for (int i = 0; i < n; i++) {
         int who = -1;
         if (F.mvpMapPoints[i] && F.mvpMapPoints[i] >= &mps[0] && F.mvpMapPoints[i] <= &mps[n - 1]) who = (int)(F.mvpMapPoints[i] - &mps[0]);
+        o.write((const char*)&who, 4);
+      }
+    }
+    // SearchByProjection(CurrentFrame, LastFrame): the frame against itself, its keypoints back-projected at depths 2..8 m
+    // and seen from a camera moved by (0.01, 0.005, 0.3) -> forward motion for the stereo case (tlc.z > mb)
+    {
+      MiniFrame2 Last, Cur;
+      Last.mvKeysUn = keys; Last.mvKeys = keys; Last.N = n; Last.mDescriptors = descriptors.clone();
+      Cur.mvKeysUn = keys; Cur.mvKeys = keys; Cur.N = n; Cur.mDescriptors = descriptors.clone();
+      Cur.mvScaleFactors = extractor->GetScaleFactors(); Last.mvScaleFactors = Cur.mvScaleFactors;
+      Cur.pose.t = V3{{-0.01f, -0.005f, -0.3f}};
+      Cur.mvpMapPoints.assign(n, nullptr);
+      Last.mvpMapPoints.assign(n, nullptr); Last.mvbOutlier.assign(n, false);
+      Cur.mvuRight.resize(n);
+      std::vector<MiniMapPoint> mps(n);
+      for (int i = 0; i < n; i++) {
+        const float z = 2.0f + (float)(i % 7);
+        mps[i].world = V3{{((keys[i].pt.x - 320.f) * z) / 500.f, ((keys[i].pt.y - 240.f) * z) / 500.f, z}};
+        mps[i].nObs = (i % 3 == 0) ? 0 : 2;
+        mps[i].desc = descriptors.row(i).clone();
+        if (i % 6 != 0) Last.mvpMapPoints[i] = &mps[i];
+        Last.mvbOutlier[i] = i % 10 == 0;
+        Cur.mvuRight[i] = (i % 4 == 0) ? -1.f : keys[i].pt.x - 50.f / (2.0f + (float)(i % 7));
+      }
+      ORBmatcher matcher(0.9f, true);
+      const int nm = n ? matcher.SearchByProjection(Cur, Last, 15.0f, false) : 0;
+      o.write((const char*)&nm, 4);
+      for (int i = 0; i < n; i++) {
+        int who = Cur.mvpMapPoints[i] ? (int)(Cur.mvpMapPoints[i] - &mps[0]) : -1;
         o.write((const char*)&who, 4);
       }
     }

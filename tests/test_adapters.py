@@ -63,8 +63,10 @@ def _read(path):
     nm = take("<i")
     m12 = np.frombuffer(b, np.int32, n, off); off += 4 * n
     nproj = take("<i")
-    proj = np.frombuffer(b, np.int32, n, off)
-    return mono, kps, desc, pyr, d01, bow, fv, self_score, nm, m12, nproj, proj
+    proj = np.frombuffer(b, np.int32, n, off); off += 4 * n
+    nlast = take("<i")
+    last = np.frombuffer(b, np.int32, n, off)
+    return mono, kps, desc, pyr, d01, bow, fv, self_score, nm, m12, nproj, proj, nlast, last
 
 
 @pytest.mark.gpu
@@ -82,7 +84,7 @@ def test_adapter_results_equal_oracle(tmp_path, rows, cols, lap):
     make_vocabulary(vocp, odesc, 6, 3, seed=3)
     r = subprocess.run([exe, "run", raw, str(rows), str(cols), "1000", str(lap[0]), str(lap[1]), out, vocp], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    mono, kps, desc, pyr, d01, bow, fv, self_score, nm, m12, nproj, proj = _read(out)
+    mono, kps, desc, pyr, d01, bow, fv, self_score, nm, m12, nproj, proj, nlast, last = _read(out)
     assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc)
     for l in range(8):
         assert np.array_equal(pyr[l], ora.level(l))
@@ -105,3 +107,19 @@ def test_adapter_results_equal_oracle(tmp_path, rows, cols, lap):
     sf = ora.tables()["scale"]
     on, omatch, _ = po.search_by_projection(okps, odesc, (0, 0, cols, rows), sf, kp_obs, mp, 3.0, 0.8)
     assert nproj == on and np.array_equal(proj, omatch) and on > 100
+    # SearchByProjection(CurrentFrame, LastFrame) through the C++ template: the test redoes the demo's float32 pose / pinhole
+    # arithmetic (src/ORBmatcher.cc:1686-1718) and hands the projections to the oracle's restatement of :1720-1885
+    f32 = np.float32
+    z = (f32(2.0) + (i % 7).astype(f32)).astype(f32)
+    xw = (((okps["x"] - f32(320.0)) * z) / f32(500.0)).astype(f32); yw = (((okps["y"] - f32(240.0)) * z) / f32(500.0)).astype(f32)
+    xc, yc, zc = (xw + f32(-0.01)).astype(f32), (yw + f32(-0.005)).astype(f32), (z + f32(-0.3)).astype(f32)
+    invz = (1.0 / zc.astype(np.float64)).astype(f32)
+    u = (f32(500.0) * (xc / zc) + f32(320.0)).astype(f32); v = (f32(500.0) * (yc / zc) + f32(240.0)).astype(f32)
+    valid = (i % 6 != 0) & (i % 10 != 0) & ~(invz < 0) & ~((u < 0) | (u > cols)) & ~((v < 0) | (v > rows))
+    lp = dict(valid=valid.astype(np.uint8), u=u, v=v, invz=invz, octave=okps["octave"].astype(np.int32), angle=okps["angle"], desc=odesc,
+              obs=np.where(i % 3 == 0, 0, 2).astype(np.int32))
+    ur = np.where(i % 4 == 0, f32(-1.0), okps["x"] - (f32(50.0) / z)).astype(f32)
+    # tlc = Tlw * twc = -t_cur = (0.01, 0.005, 0.3): 0.3 > mb = 0.1 and !bMono -> bForward
+    on, omatch, _ = po.search_by_projection_last(okps, odesc, (0, 0, cols, rows), sf, np.full(n, -1, np.int32), lp, 15.0, 1, True, ur, 50.0)
+    want = np.where(omatch >= 0, omatch, -1)          # the demo reports the bound map point or -1 (NULL)
+    assert nlast == on and np.array_equal(last, want) and on > 100

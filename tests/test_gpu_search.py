@@ -177,3 +177,31 @@ def test_window_search_gates_and_best_second(frames):
     assert np.array_equal(w["best_idx"], bi) and np.array_equal(w["best_dist"], bd)
     assert np.array_equal(w["second_idx"], si) and np.array_equal(w["second_dist"], sd)
     assert len(cand) > 2000
+
+
+@pytest.mark.parametrize("th,direction,stereo,ori", [(15.0, 0, False, True), (7.0, 0, True, True), (15.0, 1, True, True), (15.0, 2, True, False),
+                                                     (30.0, 0, False, True)])
+def test_search_by_projection_last_frame_equals_oracle(frames, th, direction, stereo, ori):
+    """Tracking::TrackWithMotionModel's call (src/Tracking.cc:2889,2897): last frame's points projected into the current one."""
+    gpu, fr = frames
+    m = ORBmatcher(gpu, 0.9, ori)
+    rng = np.random.default_rng(int(th) * 8 + direction * 2 + stereo)
+    sf = gpu.GetScaleFactors()
+    total = 0
+    for Fl, Fc in ((fr[0], fr[1]), (fr[1], fr[2])):
+        kl = Fl.mvKeysUn
+        nl, nc = len(kl), len(Fc.mvKeysUn)
+        lp = dict(valid=(rng.random(nl) < 0.85).astype(np.uint8), u=(kl["x"] + 1.5 + rng.normal(0, 2.0, nl)).astype(np.float32),
+                  v=(kl["y"] + 0.5 + rng.normal(0, 2.0, nl)).astype(np.float32), invz=rng.uniform(0.02, 1.0, nl).astype(np.float32),
+                  octave=kl["octave"].astype(np.int32), angle=(kl["angle"] + rng.choice([0.0, 0.0, 0.0, 45.0, 200.0], nl)).astype(np.float32) % np.float32(360),
+                  desc=Fl.mDescriptors, obs=rng.choice([0, 1, 4], nl).astype(np.int32))
+        kp_obs = rng.choice([-1, -1, -1, 0, 2], nc).astype(np.int32)
+        u_right = np.where(rng.random(nc) < 0.6, Fc.mvKeysUn["x"] - rng.uniform(0.5, 40, nc), -1.0).astype(np.float32) if stereo else None
+        Fc.mvScaleFactors, Fc.mvuRight, Fc.kp_obs = sf, u_right, kp_obs.copy()
+        n, match = m.SearchByProjectionLastFrame(Fc, lp, th, direction, mbf=38.5)
+        on, omatch, oobs = po.search_by_projection_last(Fc.mvKeysUn, Fc.mDescriptors, Fc.bounds, sf, kp_obs, lp, th, direction, ori, u_right, 38.5)
+        assert n == on and np.array_equal(match, omatch) and np.array_equal(Fc.kp_obs, oobs)
+        total += n
+        if ori:
+            assert (match == -2).sum() > 0      # the rotation filter removed something
+    assert total > 200
