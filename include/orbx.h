@@ -274,6 +274,29 @@ double orbx_bow_score_l1(const uint32_t* ida, const double* va, int na, const ui
 int orbx_bow_score_l1_batch(orbx_ctx* ctx, const uint32_t* q_ids, const double* q_vals, int nq, const int32_t* db_ptr,
                             const uint32_t* db_ids, const double* db_vals, int ndb, double* scores);
 
+/* ---- keyframe database ------------------------------------------------------------------
+ * KeyFrameDatabase (src/KeyFrameDatabase.cc) with the keyframes' BowVectors resident in HBM as CSR.  add / erase / clear
+ * mirror :39-45 / :47-66 / :68-72.  orbx_kfdb_query is the first two phases shared by DetectLoopCandidates (:100-165),
+ * DetectCandidates (:228-310, :355-398), DetectBestCandidates (:468-535), DetectNBestCandidates (:604-665) and
+ * DetectRelocalizationCandidates (:733-790): every keyframe sharing at least one word with the query, in the order of the
+ * reference's lKFsSharingWords list (query words ascending; inside one word's inverted list, the order of add()), its
+ * number of common words, maxCommonWords, minCommonWords = (int)(maxCommonWords * 0.8f) (raised to min_words_floor =
+ * DetectBestCandidates' nMinWords, 0 elsewhere) and, for the keyframes with MORE than minCommonWords common words,
+ * mpVoc->score(query, keyframe) as a double (callers narrow to float); -1.0 for the others.
+ * exclude: keyframe ids that must not enter the list (the query's connected keyframes, keyframes of another map, ...).
+ * The covisibility accumulation that follows in each Detect* routine is graph logic of the caller.
+ * kf ids are the caller's (KeyFrame::mnId).  Not thread-safe; one database belongs to one context. */
+typedef struct orbx_kfdb orbx_kfdb;
+int orbx_kfdb_create(orbx_ctx* ctx, orbx_kfdb** out);
+void orbx_kfdb_destroy(orbx_kfdb* db);
+int orbx_kfdb_add(orbx_kfdb* db, int64_t kf_id, const uint32_t* ids, const double* vals, int n);
+int orbx_kfdb_erase(orbx_kfdb* db, int64_t kf_id);
+int orbx_kfdb_clear(orbx_kfdb* db);
+int orbx_kfdb_size(const orbx_kfdb* db);
+int orbx_kfdb_query(orbx_kfdb* db, const uint32_t* q_ids, const double* q_vals, int nq, const int64_t* exclude, int n_exclude,
+                    int min_words_floor, int64_t* kf_ids, int32_t* common_words, double* scores, int cap, int* n_sharing,
+                    int* max_common_words, int* min_common_words);
+
 #ifdef __cplusplus
 }
 #endif

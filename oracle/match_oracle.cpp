@@ -606,3 +606,101 @@ int mo_stereo_matches(const void* kpsL_, const uint8_t* descL, int N, const void
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// KeyFrameDatabase (src/KeyFrameDatabase.cc), the part every Detect* routine starts with.
+// ---------------------------------------------------------------------------------------------------------
+#include <list>
+#include <map>
+#include <set>
+namespace {
+struct OKeyFrame {
+  long mnId;
+  std::vector<uint32_t> ids;      // mBowVec (ordered map: ascending word id)
+  std::vector<double> vals;
+  long mnQuery = -1;              // mnRelocQuery / mnLoopQuery / mnPlaceRecognitionQuery
+  int mnWords = 0;                // mnRelocWords / ...
+};
+struct OKfDb {
+  std::map<uint32_t, std::list<OKeyFrame*>> mvInvertedFile;   // word -> keyframes in insertion order
+  std::map<long, OKeyFrame*> kfs;
+  long next_query = 1;
+};
+}  // namespace
+
+extern "C" {
+
+void* mo_kfdb_new() { return new OKfDb(); }
+void mo_kfdb_free(void* h) {
+  OKfDb* db = (OKfDb*)h;
+  for (auto& kv : db->kfs) delete kv.second;
+  delete db;
+}
+// KeyFrameDatabase::add, :39-45
+void mo_kfdb_add(void* h, long kf_id, const uint32_t* ids, const double* vals, int n) {
+  OKfDb* db = (OKfDb*)h;
+  OKeyFrame* pKF = new OKeyFrame();
+  pKF->mnId = kf_id; pKF->ids.assign(ids, ids + n); pKF->vals.assign(vals, vals + n);
+  db->kfs[kf_id] = pKF;
+  for (int i = 0; i < n; i++) db->mvInvertedFile[ids[i]].push_back(pKF);
+}
+// KeyFrameDatabase::erase, :47-66
+void mo_kfdb_erase(void* h, long kf_id) {
+  OKfDb* db = (OKfDb*)h;
+  auto it = db->kfs.find(kf_id);
+  if (it == db->kfs.end()) return;
+  OKeyFrame* pKF = it->second;
+  for (uint32_t w : pKF->ids) {
+    std::list<OKeyFrame*>& lKFs = db->mvInvertedFile[w];
+    for (auto lit = lKFs.begin(), lend = lKFs.end(); lit != lend; lit++)
+      if (pKF == *lit) { lKFs.erase(lit); break; }
+  }
+  db->kfs.erase(it);
+  delete pKF;
+}
+// The common opening of DetectLoopCandidates (:100-165), DetectBestCandidates (:468-535), DetectNBestCandidates (:604-665)
+// and DetectRelocalizationCandidates (:733-790): share-a-word list, maxCommonWords, minCommonWords, scores.
+// exclude = spConnectedKeyFrames (and, for the loop / merge split, the keyframes of the other map).  Returns the list length.
+int mo_kfdb_query(void* h, const uint32_t* q_ids, const double* q_vals, int nq, const long* exclude, int n_exclude, int nMinWords,
+                  long* out_kf, int32_t* out_words, double* out_score, int* maxCommon, int* minCommon) {
+  OKfDb* db = (OKfDb*)h;
+  const long query_id = db->next_query++;
+  std::set<long> spConnected(exclude, exclude + n_exclude);
+  std::list<OKeyFrame*> lKFsSharingWords;
+  for (int i = 0; i < nq; i++) {
+    auto f = db->mvInvertedFile.find(q_ids[i]);
+    if (f == db->mvInvertedFile.end()) continue;
+    std::list<OKeyFrame*>& lKFs = f->second;
+    for (auto lit = lKFs.begin(), lend = lKFs.end(); lit != lend; lit++) {
+      OKeyFrame* pKFi = *lit;
+      if (pKFi->mnQuery != query_id) {
+        pKFi->mnWords = 0;
+        if (!spConnected.count(pKFi->mnId)) {
+          pKFi->mnQuery = query_id;
+          lKFsSharingWords.push_back(pKFi);
+        }
+      }
+      pKFi->mnWords++;
+    }
+  }
+  *maxCommon = 0; *minCommon = 0;
+  if (lKFsSharingWords.empty()) return 0;
+  int maxCommonWords = 0;
+  for (OKeyFrame* p : lKFsSharingWords)
+    if (p->mnWords > maxCommonWords) maxCommonWords = p->mnWords;
+  int minCommonWords = maxCommonWords * 0.8f;
+  if (minCommonWords < nMinWords) minCommonWords = nMinWords;   // :514-517 (nMinWords = 0 in the other routines)
+  int k = 0;
+  for (OKeyFrame* pKFi : lKFsSharingWords) {
+    out_kf[k] = pKFi->mnId;
+    out_words[k] = pKFi->mnWords;
+    out_score[k] = -1.0;
+    if (pKFi->mnWords > minCommonWords)
+      out_score[k] = mo_score_l1(q_ids, q_vals, nq, pKFi->ids.data(), pKFi->vals.data(), (int)pKFi->ids.size());
+    k++;
+  }
+  *maxCommon = maxCommonWords; *minCommon = minCommonWords;
+  return k;
+}
+
+}  // extern "C"

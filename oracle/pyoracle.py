@@ -423,3 +423,45 @@ class RefVocabulary:
         ia, va = np.ascontiguousarray(a[0], np.uint32), np.ascontiguousarray(a[1], np.float64)
         ib, vb = np.ascontiguousarray(b[0], np.uint32), np.ascontiguousarray(b[1], np.float64)
         return float(ref_lib().ref_voc_score(self._h, _ptr(ia), _ptr(va), len(ia), _ptr(ib), _ptr(vb), len(ib)))
+
+
+class OracleKeyFrameDatabase:
+    """KeyFrameDatabase (src/KeyFrameDatabase.cc) with the reference's inverted file; `query` = the opening shared by the
+    Detect* routines (share-a-word list in list order, common-word counts, thresholds, L1 scores)."""
+
+    def __init__(self):
+        L = _mlib()
+        vp = C.c_void_p
+        L.mo_kfdb_new.restype = vp
+        L.mo_kfdb_free.argtypes = [vp]
+        L.mo_kfdb_add.argtypes = [vp, C.c_long, vp, vp, C.c_int]
+        L.mo_kfdb_erase.argtypes = [vp, C.c_long]
+        L.mo_kfdb_query.restype = C.c_int
+        L.mo_kfdb_query.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        self._L, self._h, self._n = L, vp(L.mo_kfdb_new()), 0
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.mo_kfdb_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def add(self, kf_id, bow):
+        ids = np.ascontiguousarray(bow[0], np.uint32); vals = np.ascontiguousarray(bow[1], np.float64)
+        self._L.mo_kfdb_add(self._h, int(kf_id), _ptr(ids), _ptr(vals), len(ids))
+        self._n += 1
+
+    def erase(self, kf_id):
+        self._L.mo_kfdb_erase(self._h, int(kf_id))
+
+    def query(self, bow, exclude=(), min_words_floor=0):
+        ids = np.ascontiguousarray(bow[0], np.uint32); vals = np.ascontiguousarray(bow[1], np.float64)
+        ex = np.ascontiguousarray(list(exclude), np.int64)
+        cap = max(self._n, 1)
+        kf = np.zeros(cap, np.int64); words = np.zeros(cap, np.int32); score = np.zeros(cap, np.float64)
+        mx, mn = C.c_int(0), C.c_int(0)
+        k = self._L.mo_kfdb_query(self._h, _ptr(ids), _ptr(vals), len(ids), _ptr(ex), len(ex), int(min_words_floor), _ptr(kf), _ptr(words),
+                                  _ptr(score), C.byref(mx), C.byref(mn))
+        return dict(kf=kf[:k].copy(), words=words[:k].copy(), score=score[:k].copy(), max_common=mx.value, min_common=mn.value)

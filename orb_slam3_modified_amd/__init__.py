@@ -3,4 +3,5 @@ ORBextractor / ORBmatcher / ORBVocabulary interfaces.  All compute lives in libo
 from .extractor import ORBextractor  # noqa: F401
 from .matcher import ORBmatcher  # noqa: F401
 from .vocabulary import ORBVocabulary  # noqa: F401
+from .kfdb import KeyFrameDatabase  # noqa: F401
 from ._lib import KP_DTYPE, OrbxError  # noqa: F401

@@ -84,6 +84,13 @@ def lib() -> C.CDLL:
         "orbx_bow_finalize": (i32, [vp, vp, vp, i32, vp, vp, ip]),
         "orbx_bow_score_l1": (C.c_double, [vp, vp, i32, vp, vp, i32]),
         "orbx_bow_score_l1_batch": (i32, [vp, vp, vp, i32, vp, vp, vp, i32, vp]),
+        "orbx_kfdb_create": (i32, [vp, C.POINTER(vp)]),
+        "orbx_kfdb_destroy": (None, [vp]),
+        "orbx_kfdb_add": (i32, [vp, C.c_int64, vp, vp, i32]),
+        "orbx_kfdb_erase": (i32, [vp, C.c_int64]),
+        "orbx_kfdb_clear": (i32, [vp]),
+        "orbx_kfdb_size": (i32, [vp]),
+        "orbx_kfdb_query": (i32, [vp, vp, vp, i32, vp, i32, i32, vp, vp, vp, i32, ip, ip, ip]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here == header/library mismatch: fail loudly

@@ -270,3 +270,29 @@ def test_search_by_projection_hand_case():
     assert match.tolist() == [-1, 0, -1]
     # not in view -> nothing
     assert po.search_by_projection(kps, desc, bounds, sf, free, mp(1, in_view=np.zeros(1, np.uint8)), 1.0, 0.8)[0] == 0
+
+
+def test_kfdb_hand_case():
+    """src/KeyFrameDatabase.cc:733-790 on three keyframes: list order = query words ascending, then insertion order inside a
+    word's list; minCommonWords = (int)(max * 0.8f); only keyframes with MORE common words than that are scored."""
+    db = po.OracleKeyFrameDatabase()
+    w = lambda ids: (np.array(ids, np.uint32), np.full(len(ids), 1.0 / len(ids)))
+    db.add(10, w([5, 6, 7, 8, 9]))        # shares 5 words with the query below
+    db.add(20, w([1, 5, 6, 7, 30]))       # shares 4 (1, 5, 6, 7): first shared word 1 -> listed before keyframe 10
+    db.add(30, w([9, 40, 41]))            # shares 1
+    q = w([1, 5, 6, 7, 8, 9])
+    r = db.query(q)
+    assert r["kf"].tolist() == [20, 10, 30] and r["words"].tolist() == [4, 5, 1]
+    assert r["max_common"] == 5 and r["min_common"] == 4           # (int)(5 * 0.8f) = 4
+    assert r["score"][0] == -1.0 and r["score"][2] == -1.0         # 4 > 4 is false
+    want = po.score_l1(q, w([5, 6, 7, 8, 9]))
+    assert r["score"][1] == want and 0 < want < 1
+    # excluded keyframes never enter the list and do not raise maxCommonWords
+    r = db.query(q, exclude=[10])
+    assert r["kf"].tolist() == [20, 30] and r["max_common"] == 4 and r["min_common"] == 3 and r["score"][0] > 0
+    # erase + re-add moves a keyframe to the back of the word lists
+    db.erase(20); db.add(21, w([1, 5, 6, 7, 30])); db.add(22, w([1, 2]))
+    assert db.query(q)["kf"].tolist() == [21, 22, 10, 30]
+    # nMinWords floor (DetectBestCandidates, :514-517)
+    r = db.query(q, min_words_floor=5)
+    assert r["min_common"] == 5 and (r["score"] == -1.0).all()

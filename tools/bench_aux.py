@@ -112,6 +112,25 @@ for _ in range(20): nmp_, _m = _sbp()
 res["search_by_projection_mappoints"] = {"map_points": len(ka), "keypoints": len(Fp.mvKeysUn), "matches": int(nmp_),
                                          "ms_per_call": (time.perf_counter() - t0) / 20 * 1e3,
                                          "note": "host buffers; one device pass (grid, windows, gates, distances), greedy replay on the host"}
+# KeyFrameDatabase: 2000 keyframes x ~800 words resident in HBM, one place-recognition query
+from orb_slam3_modified_amd import KeyFrameDatabase
+rngk = np.random.default_rng(9)
+def _bowv(place):
+    n = 800
+    ids = np.unique(np.concatenate([(place * 1500 + rngk.integers(0, 2500, 640)) % 60000, rngk.integers(0, 60000, 160)])).astype(np.uint32)
+    v = rngk.uniform(0.1, 8.0, len(ids)); return ids, v / v.sum()
+kdb = KeyFrameDatabase(ex1k)
+kdb_entries = 0
+for i in range(2000):
+    _b = _bowv(i % 40); kdb_entries += len(_b[0]); kdb.add(i, _b)
+qb = _bowv(7)
+for _ in range(3): rk = kdb.query(qb, range(0, 20))
+t0 = time.perf_counter()
+for _ in range(20): rk = kdb.query(qb, range(0, 20))
+res["keyframe_database_query"] = {"keyframes": 2000, "db_entries": int(kdb_entries), "query_words": int(len(qb[0])),
+                                  "sharing": int(len(rk["kf"])), "scored": int((rk["score"] >= 0).sum()),
+                                  "ms_per_call": (time.perf_counter() - t0) / 20 * 1e3,
+                                  "note": "host query in, full scan of the resident CSR (wave per keyframe), list + counts + scores back"}
 Ls = synth.make_stream(1, 480, 752)[0]; Rs = np.roll(Ls, -12, axis=1).copy()
 exL, exR = ORBextractor(1200, 1.2, 8, 20, 7), ORBextractor(1200, 1.2, 8, 20, 7)
 _, kL, dL = exL(Ls, None, (0, 0)); _, kR, dR = exR(Rs, None, (0, 0))
