@@ -70,6 +70,19 @@ class ORBVocabulary {
     voc_ = nullptr;
     return orbx_voc_load_text(ctx_, filename.c_str(), &voc_) == ORBX_OK;
   }
+  // TemplatedVocabulary.h:1428-1449
+  void saveToTextFile(const std::string& filename) const {
+    if (!voc_ || orbx_voc_save_text(voc_, filename.c_str()) != ORBX_OK) throw std::runtime_error("ORBVocabulary::saveToTextFile failed");
+  }
+  // exact binary cache (orbx format; loads at file-read speed instead of parsing 1.08 M text lines)
+  bool loadFromBinaryFile(const std::string& filename) {
+    orbx_voc_destroy(voc_);
+    voc_ = nullptr;
+    return orbx_voc_load_binary(ctx_, filename.c_str(), &voc_) == ORBX_OK;
+  }
+  void saveToBinaryFile(const std::string& filename) const {
+    if (!voc_ || orbx_voc_save_binary(voc_, filename.c_str()) != ORBX_OK) throw std::runtime_error("ORBVocabulary::saveToBinaryFile failed");
+  }
   unsigned int size() const { int w = 0; if (voc_) orbx_voc_info(voc_, nullptr, nullptr, nullptr, &w); return (unsigned)w; }
   bool empty() const { return size() == 0; }
 

@@ -76,6 +76,13 @@ int orbx_extract_batch_device(orbx_ctx* ctx, const uint8_t* d_imgs, int nframes,
                               size_t frame_stride, int lap0, int lap1, orbx_keypoint* d_kps, uint8_t* d_desc,
                               int32_t* d_counts, void* stream);
 
+/* Image ingestion fused behind the upload: what Tracking::GrabImageMonocular does before the extractor
+ * sees the frame (src/Tracking.cc:1572-1585, cv::cvtColor COLOR_RGB2GRAY / BGR2GRAY / RGBA2GRAY / BGRA2GRAY) runs on the
+ * device; img is interleaved, channels = 3 or 4, rgb_order != 0 when R comes first (mbRGB).  OpenCV's 8-bit formula
+ * (R*9798 + G*19235 + B*3735 + 2^14) >> 15.  The grey plane is level 0 of the pyramid afterwards.  Otherwise as orbx_extract. */
+int orbx_extract_color(orbx_ctx* ctx, const uint8_t* img, int rows, int cols, size_t stride, int channels, int rgb_order, int lap0,
+                       int lap1, orbx_keypoint* kps, uint8_t* desc, int* n_out, int* mono_index_out);
+
 /* Host-buffer convenience over the batch path (H2D all frames, extract, D2H). counts: [nframes][2]. */
 int orbx_extract_batch(orbx_ctx* ctx, const uint8_t* imgs, int nframes, int rows, int cols, size_t row_stride,
                        size_t frame_stride, int lap0, int lap1, orbx_keypoint* kps, uint8_t* desc, int32_t* counts);
@@ -251,6 +258,11 @@ int orbx_voc_load_text(orbx_ctx* ctx, const char* path, orbx_voc** out);
 int orbx_voc_create(orbx_ctx* ctx, int k, int L, int scoring, int weighting, int nnodes_excl_root, const int32_t* parent,
                     const uint8_t* is_leaf, const uint8_t* desc, const double* weight, orbx_voc** out);
 void orbx_voc_destroy(orbx_voc* voc);
+/* TemplatedVocabulary::saveToTextFile (TemplatedVocabulary.h:1428-1449), byte-identical output (6-digit weights). */
+int orbx_voc_save_text(const orbx_voc* voc, const char* path);
+/* Exact binary cache of a vocabulary (SURVEY.md §8(f).4 "binary cache"): "ORBXVOC1" + k, L, scoring, weighting + arrays. */
+int orbx_voc_save_binary(const orbx_voc* voc, const char* path);
+int orbx_voc_load_binary(orbx_ctx* ctx, const char* path, orbx_voc** out);
 int orbx_voc_info(const orbx_voc* voc, int* k, int* L, int* nnodes, int* nwords);
 
 /* The per-feature part of TemplatedVocabulary::transform(features, BowVector&, FeatureVector&, levelsup)

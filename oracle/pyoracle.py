@@ -70,6 +70,15 @@ def _ptr(a: np.ndarray):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def cvt_color_to_gray(img: np.ndarray, rgb: bool) -> np.ndarray:
+    """cv::cvtColor(COLOR_RGB2GRAY / BGR2GRAY / RGBA2GRAY / BGRA2GRAY) for CV_8U as OpenCV 4.x computes it (recalled, like
+    the other OpenCV primitives — parity unpinned): 15-bit fixed point, (R*9798 + G*19235 + B*3735 + 2^14) >> 15."""
+    assert img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] in (3, 4)
+    a = img.astype(np.int64)
+    r, g, b = (a[..., 0], a[..., 1], a[..., 2]) if rgb else (a[..., 2], a[..., 1], a[..., 0])
+    return ((r * 9798 + g * 19235 + b * 3735 + (1 << 14)) >> 15).astype(np.uint8)
+
+
 class OracleExtractor:
     """Mirror of ORB_SLAM3::ORBextractor (include/ORBextractor.h:49-83) over the oracle."""
 
@@ -404,6 +413,12 @@ class RefVocabulary:
         if getattr(self, "_h", None):
             ref_lib().ref_voc_free(self._h)
             self._h = None
+
+    def saveToTextFile(self, path: str) -> None:
+        """The reference's own TemplatedVocabulary::saveToTextFile."""
+        L = ref_lib()
+        L.ref_voc_save.argtypes = [C.c_void_p, C.c_char_p]
+        L.ref_voc_save(self._h, path.encode())
 
     def size(self) -> int:
         return ref_lib().ref_voc_size(self._h)

@@ -26,6 +26,7 @@ void* ref_voc_load(const char* path) {
   if (!v->loadFromTextFile(path)) { delete v; return nullptr; }
   return v;
 }
+void ref_voc_save(void* h, const char* path) { ((RefVocabulary*)h)->saveToTextFile(path); }   // TemplatedVocabulary.h:1428-1449
 void ref_voc_free(void* h) { delete (RefVocabulary*)h; }
 int ref_voc_size(void* h) { return (int)((RefVocabulary*)h)->size(); }
 

@@ -48,6 +48,7 @@ def lib() -> C.CDLL:
         "orbx_levels": (i32, [vp]),
         "orbx_scale_tables": (i32, [vp, vp, vp, vp, vp, vp]),
         "orbx_extract": (i32, [vp, vp, i32, i32, sz, i32, i32, vp, vp, ip, ip]),
+        "orbx_extract_color": (i32, [vp, vp, i32, i32, C.c_size_t, i32, i32, i32, i32, vp, vp, ip, ip]),
         "orbx_extract_batch_device": (i32, [vp, vp, i32, i32, i32, sz, sz, i32, i32, vp, vp, vp, vp]),
         "orbx_extract_batch": (i32, [vp, vp, i32, i32, i32, sz, sz, i32, i32, vp, vp, vp]),
         "orbx_pyramid_level": (i32, [vp, i32, i32, vp, sz, ip, ip]),
@@ -77,6 +78,9 @@ def lib() -> C.CDLL:
         "orbx_stereo_matches": (i32, [vp, vp, vp, vp, i32, vp, vp, i32, f32, f32, vp, vp, ip]),
         "orbx_voc_load_text": (i32, [vp, C.c_char_p, C.POINTER(vp)]),
         "orbx_voc_create": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, C.POINTER(vp)]),
+        "orbx_voc_save_text": (i32, [vp, C.c_char_p]),
+        "orbx_voc_save_binary": (i32, [vp, C.c_char_p]),
+        "orbx_voc_load_binary": (i32, [vp, C.c_char_p, C.POINTER(vp)]),
         "orbx_voc_destroy": (None, [vp]),
         "orbx_voc_info": (i32, [vp, ip, ip, ip, ip]),
         "orbx_bow_transform": (i32, [vp, vp, i32, i32, vp, vp, vp]),

@@ -533,6 +533,7 @@ void orbx_destroy(orbx_ctx* ctx) {
   ctx->arena.release();
   if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
   if (ctx->h_in) { (void)hipHostFree(ctx->h_in); ctx->h_in = nullptr; }
+  if (ctx->d_color) { (void)hipFree(ctx->d_color); ctx->d_color = nullptr; }
   if (ctx->h_stage_out) { (void)hipHostFree(ctx->h_stage_out); ctx->h_stage_out = nullptr; }
   if (ctx->h_pyr) { (void)hipHostFree(ctx->h_pyr); ctx->h_pyr = nullptr; }
   for (int i = 0; i < orbx_ctx::kMaxAux; i++) {
@@ -701,11 +702,14 @@ static int extract_one_graph(orbx_ctx* ctx, const uint8_t* img, int rows, int co
   return 1;
 }
 
-int orbx_extract_batch(orbx_ctx* ctx, const uint8_t* imgs, int nframes, int rows, int cols, size_t row_stride,
-                       size_t frame_stride, int lap0, int lap1, orbx_keypoint* kps, uint8_t* desc, int32_t* counts) {
+// channels == 1: grey frames.  channels == 3 / 4: interleaved colour frames, converted on the device behind the upload
+// (rgb_order != 0: R first, else B first).
+static int extract_batch_impl(orbx_ctx* ctx, const uint8_t* imgs, int nframes, int rows, int cols, size_t row_stride,
+                              size_t frame_stride, int channels, int rgb_order, int lap0, int lap1, orbx_keypoint* kps, uint8_t* desc,
+                              int32_t* counts) {
   if (!ctx) return ORBX_E_INVALID;
   if (!imgs || rows <= 0 || cols <= 0 || nframes <= 0) return set_err(ctx, ORBX_E_EMPTY, "empty image");
-  if (!kps || !desc || !counts || row_stride < (size_t)cols) return set_err(ctx, ORBX_E_INVALID, "bad arguments");
+  if (!kps || !desc || !counts || row_stride < (size_t)cols * channels) return set_err(ctx, ORBX_E_INVALID, "bad arguments");
   ORBX_HIP(ctx, hipSetDevice(ctx->device));
   const size_t pitch = (size_t)round_up(cols, 64), fbytes = pitch * rows;
   int rc = ensure_stage(ctx, nframes, fbytes * nframes);
@@ -713,7 +717,7 @@ int orbx_extract_batch(orbx_ctx* ctx, const uint8_t* imgs, int nframes, int rows
   const StageLayout L = stage_layout(ctx, ctx->stage_frames);   // the block was laid out for its allocated capacity
   const size_t kb = (size_t)nframes * ctx->out_cap * sizeof(orbx_keypoint), db = (size_t)nframes * ctx->out_cap * 32,
                cb = (size_t)nframes * 2 * sizeof(int32_t);
-  if (nframes == 1) {   // the live-SLAM path: replay the captured graph
+  if (nframes == 1 && channels == 1) {   // the live-SLAM path: replay the captured graph
     if (row_stride >= (1u << 23) || (unsigned long long)row_stride * (unsigned long long)rows >= (1ull << 31))
       return set_err(ctx, ORBX_E_INVALID, "row stride / frame size beyond the kernels' 32-bit in-frame offsets");
     rc = extract_one_graph(ctx, imgs, rows, cols, row_stride, lap0, lap1, pitch, fbytes, L);
@@ -726,9 +730,28 @@ int orbx_extract_batch(orbx_ctx* ctx, const uint8_t* imgs, int nframes, int rows
       return ORBX_OK;
     }
   }
-  for (int f = 0; f < nframes; f++)
-    ORBX_HIP(ctx, hipMemcpy2DAsync(ctx->d_stage_img + f * fbytes, pitch, imgs + f * frame_stride, row_stride, cols, rows,
-                                   hipMemcpyHostToDevice, ctx->stream));
+  if (channels == 1) {
+    for (int f = 0; f < nframes; f++)
+      ORBX_HIP(ctx, hipMemcpy2DAsync(ctx->d_stage_img + f * fbytes, pitch, imgs + f * frame_stride, row_stride, cols, rows,
+                                     hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    const size_t cpitch = (size_t)round_up(cols * channels, 64), cbytes = cpitch * rows;
+    if (cpitch >= (1u << 23)) return set_err(ctx, ORBX_E_INVALID, "colour row beyond the kernels' offsets");
+    if (cbytes * nframes > ctx->color_bytes) {
+      ORBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (ctx->d_color) (void)hipFree(ctx->d_color);
+      ctx->d_color = nullptr; ctx->color_bytes = 0;
+      ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_color, cbytes * nframes));
+      ctx->color_bytes = cbytes * nframes;
+    }
+    for (int f = 0; f < nframes; f++)
+      ORBX_HIP(ctx, hipMemcpy2DAsync(ctx->d_color + f * cbytes, cpitch, imgs + f * frame_stride, row_stride, (size_t)cols * channels, rows,
+                                     hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_color_to_gray, dim3((cols + 255) / 256, (rows + 3) / 4, nframes), dim3(256), 0, ctx->stream, ctx->d_color,
+                       (long long)cbytes, (int)cpitch, channels, rgb_order ? 0 : 2, rgb_order ? 2 : 0, ctx->d_stage_img, (long long)fbytes,
+                       (int)pitch, rows, cols);
+    ORBX_HIP(ctx, hipGetLastError());
+  }
   uint8_t* d = ctx->d_stage_out;
   rc = orbx_extract_batch_device(ctx, ctx->d_stage_img, nframes, rows, cols, pitch, fbytes, lap0, lap1,
                                  (orbx_keypoint*)(d + L.kps_off), d + L.desc_off, (int32_t*)(d + L.counts_off), ctx->stream);
@@ -761,6 +784,26 @@ int orbx_extract_batch(orbx_ctx* ctx, const uint8_t* imgs, int nframes, int rows
   // k_assemble reports a quadtree capacity overflow (never expected) as a negative keypoint count: fail loudly
   for (int f = 0; f < nframes; f++)
     if (counts[2 * f] < 0) return set_err(ctx, ORBX_E_CAPACITY, "quadtree produced more nodes than the level capacity");
+  return ORBX_OK;
+}
+
+int orbx_extract_batch(orbx_ctx* ctx, const uint8_t* imgs, int nframes, int rows, int cols, size_t row_stride,
+                       size_t frame_stride, int lap0, int lap1, orbx_keypoint* kps, uint8_t* desc, int32_t* counts) {
+  return extract_batch_impl(ctx, imgs, nframes, rows, cols, row_stride, frame_stride, 1, 0, lap0, lap1, kps, desc, counts);
+}
+
+int orbx_extract_color(orbx_ctx* ctx, const uint8_t* img, int rows, int cols, size_t stride, int channels, int rgb_order, int lap0,
+                       int lap1, orbx_keypoint* kps, uint8_t* desc, int* n_out, int* mono_index_out) {
+  if (n_out) *n_out = 0;
+  if (mono_index_out) *mono_index_out = 0;
+  if (!ctx) return ORBX_E_INVALID;
+  if (channels != 3 && channels != 4) return set_err(ctx, ORBX_E_INVALID, "orbx_extract_color: 3 or 4 interleaved channels expected");
+  if (!img || rows <= 0 || cols <= 0) return set_err(ctx, ORBX_E_EMPTY, "empty image");
+  int32_t counts[2] = {0, 0};
+  int rc = extract_batch_impl(ctx, img, 1, rows, cols, stride, stride * rows, channels, rgb_order, lap0, lap1, kps, desc, counts);
+  if (rc != ORBX_OK) return rc;
+  if (n_out) *n_out = counts[0];
+  if (mono_index_out) *mono_index_out = counts[1];
   return ORBX_OK;
 }
 

@@ -164,6 +164,7 @@ struct orbx_ctx {
   uint2* d_kp_list = nullptr;      // [batch][out_cap] {packed point, level | output slot << 8}, level-major order
   // single-frame staging (orbx_extract)
   uint8_t* d_stage_img = nullptr; size_t stage_img_bytes = 0;
+  uint8_t* d_color = nullptr; size_t color_bytes = 0;   // interleaved colour frames of orbx_extract_color, before conversion
   uint8_t* d_stage_out = nullptr;   // [keypoints | descriptors | counts] of the host-buffer entry points
   uint8_t* h_stage_out = nullptr;   // pinned host mirror of d_stage_out (one D2H copy per call)
   int stage_frames = 0;

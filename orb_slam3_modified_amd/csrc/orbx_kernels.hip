@@ -1279,6 +1279,27 @@ __global__ __launch_bounds__(256) void k_debug_atan_hash(uint32_t seed, uint32_t
 // Calibration kernel for the rocprofv3 FETCH_SIZE / WRITE_SIZE counters (MI355X_MICROARCH.md "HBM": the counters
 // are only calibrated for wide streaming reads): copies n bytes with W bytes per lane per access (W = 1, 4, 16),
 // i.e. a kernel whose HBM traffic is known exactly, in the access widths the extractor kernels use.
+// Image ingestion: cv::cvtColor(COLOR_RGB2GRAY / BGR2GRAY / RGBA2GRAY / BGRA2GRAY) of
+// src/Tracking.cc:1572-1585 fused behind the upload — OpenCV (>= 4.x) 8-bit path: 15-bit fixed point,
+// gray = (R * 9798 + G * 19235 + B * 3735 + 2^14) >> 15.  Each lane converts 4 pixels and stores one dword.
+__global__ __launch_bounds__(256) void k_color_to_gray(const uint8_t* __restrict__ src, long long src_frame_stride, int src_pitch,
+                                                       int channels, int r_off, int b_off, uint8_t* __restrict__ dst,
+                                                       long long dst_frame_stride, int dst_pitch, int rows, int cols) {
+  const int x4 = 4 * (blockIdx.x * 64 + (threadIdx.x & 63)), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (y >= rows || x4 >= cols) return;
+  const uint8_t* s = src + (long long)blockIdx.z * src_frame_stride + (long long)y * src_pitch;
+  uint32_t packed = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    if (x4 + i < cols) {
+      const uint8_t* p = s + (long long)(x4 + i) * channels;
+      const int g = ((int)p[r_off] * 9798 + (int)p[1] * 19235 + (int)p[b_off] * 3735 + (1 << 14)) >> 15;
+      packed |= (uint32_t)g << (8 * i);
+    }
+  }
+  *(uint32_t*)(dst + (long long)blockIdx.z * dst_frame_stride + (long long)y * dst_pitch + x4) = packed;  // pitch is a multiple of 64
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_calib_copy(const T* __restrict__ src, T* __restrict__ dst, long long n) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)

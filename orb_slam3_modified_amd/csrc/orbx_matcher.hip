@@ -485,6 +485,67 @@ int orbx_voc_load_text(orbx_ctx* ctx, const char* path, orbx_voc** out) {
   return orbx_voc_create(ctx, k, L, n1, n2, (int)parent.size(), parent.data(), leaf.data(), desc.data(), weight.data(), out);
 }
 
+// TemplatedVocabulary::saveToTextFile (TemplatedVocabulary.h:1428-1449): same bytes — the header with its double blank,
+// "parent isLeaf b0 .. b31  weight" per node with the stream's default 6-significant-digit doubles (the format is lossy
+// in the weights; that is the reference's format, not a choice made here).
+int orbx_voc_save_text(const orbx_voc* v, const char* path) {
+  if (!v || !path) return ORBX_E_INVALID;
+  std::ofstream f(path);
+  if (!f.is_open()) return set_err(v->ctx, ORBX_E_FORMAT, std::string("cannot open ") + path);
+  f << v->k << " " << v->L << " " << " " << v->scoring << " " << v->weighting << std::endl;
+  for (size_t i = 1; i < v->parent.size(); i++) {
+    f << (unsigned int)v->parent[i] << " " << (v->is_leaf[i] ? 1 : 0) << " ";
+    for (int b = 0; b < 32; b++) f << (int)v->desc[i * 32 + b] << " ";
+    f << " " << v->weight[i] << std::endl;
+  }
+  f.close();
+  return f.fail() ? set_err(v->ctx, ORBX_E_FORMAT, std::string("write failed: ") + path) : ORBX_OK;
+}
+
+// Binary cache of a loaded vocabulary: the text format costs seconds for ORBvoc's 1.08 M nodes and
+// rounds the weights to 6 digits; the cache is exact and loads at file-read speed.  Layout (little endian):
+// "ORBXVOC1", int32 k, L, scoring, weighting, int64 n, then parent[n] int32, is_leaf[n] u8, desc[n][32] u8, weight[n] f64.
+static const char kVocMagic[8] = {'O', 'R', 'B', 'X', 'V', 'O', 'C', '1'};
+
+int orbx_voc_save_binary(const orbx_voc* v, const char* path) {
+  if (!v || !path) return ORBX_E_INVALID;
+  std::ofstream f(path, std::ios::binary);
+  if (!f.is_open()) return set_err(v->ctx, ORBX_E_FORMAT, std::string("cannot open ") + path);
+  const int32_t hdr[4] = {v->k, v->L, v->scoring, v->weighting};
+  const int64_t n = (int64_t)v->parent.size() - 1;
+  f.write(kVocMagic, 8); f.write((const char*)hdr, sizeof(hdr)); f.write((const char*)&n, 8);
+  if (n > 0) {
+    f.write((const char*)(v->parent.data() + 1), n * sizeof(int32_t));
+    f.write((const char*)(v->is_leaf.data() + 1), n);
+    f.write((const char*)(v->desc.data() + 32), n * 32);
+    f.write((const char*)(v->weight.data() + 1), n * sizeof(double));
+  }
+  f.close();
+  return f.fail() ? set_err(v->ctx, ORBX_E_FORMAT, std::string("write failed: ") + path) : ORBX_OK;
+}
+
+int orbx_voc_load_binary(orbx_ctx* ctx, const char* path, orbx_voc** out) {
+  if (!ctx || !path || !out) return ORBX_E_INVALID;
+  *out = nullptr;
+  std::ifstream f(path, std::ios::binary);
+  if (!f.is_open()) return set_err(ctx, ORBX_E_FORMAT, std::string("cannot open ") + path);
+  char magic[8]; int32_t hdr[4]; int64_t n = -1;
+  f.read(magic, 8); f.read((char*)hdr, sizeof(hdr)); f.read((char*)&n, 8);
+  if (f.fail() || std::memcmp(magic, kVocMagic, 8) != 0 || n < 0 || n > (1ll << 28))
+    return set_err(ctx, ORBX_E_FORMAT, "not an orbx vocabulary cache");
+  std::vector<int32_t> parent((size_t)n);
+  std::vector<uint8_t> leaf((size_t)n), desc((size_t)n * 32);
+  std::vector<double> weight((size_t)n);
+  if (n > 0) {
+    f.read((char*)parent.data(), n * sizeof(int32_t)); f.read((char*)leaf.data(), n); f.read((char*)desc.data(), n * 32);
+    f.read((char*)weight.data(), n * sizeof(double));
+  }
+  if (f.fail()) return set_err(ctx, ORBX_E_FORMAT, "vocabulary cache truncated");
+  f.peek();
+  if (!f.eof()) return set_err(ctx, ORBX_E_FORMAT, "vocabulary cache has trailing bytes");
+  return orbx_voc_create(ctx, hdr[0], hdr[1], hdr[2], hdr[3], (int)n, parent.data(), leaf.data(), desc.data(), weight.data(), out);
+}
+
 void orbx_voc_destroy(orbx_voc* v) {
   if (!v) return;
   if (v->d_nodes) (void)hipFree(v->d_nodes);

@@ -72,6 +72,21 @@ class ORBextractor:
         self._last_frames = 1
         return mono.value, kps[:n.value].copy(), desc[:n.value].copy()
 
+    def extract_color(self, image: np.ndarray, rgb: bool, vLappingArea: Sequence[int] = (0, 0)):
+        """Tracking::GrabImageMonocular's cvtColor (src/Tracking.cc:1572-1585) fused behind the upload: image is [H, W, 3|4]
+        uint8, rgb = mbRGB.  Returns (monoIndex, keypoints, descriptors); the grey plane is pyramid level 0 afterwards."""
+        assert image.dtype == np.uint8 and image.ndim == 3 and image.shape[2] in (3, 4)
+        if image.strides[2] != 1 or image.strides[1] != image.shape[2]:
+            image = np.ascontiguousarray(image)
+        kps = np.zeros(self.capacity, KP_DTYPE)
+        desc = np.zeros((self.capacity, 32), np.uint8)
+        n, mono = C.c_int(0), C.c_int(0)
+        check(self._L.orbx_extract_color(self._ctx, ptr(image), image.shape[0], image.shape[1], image.strides[0], image.shape[2], int(rgb),
+                                         int(vLappingArea[0]), int(vLappingArea[1]), ptr(kps), ptr(desc), C.byref(n), C.byref(mono)),
+              self._ctx)
+        self._last_frames = 1
+        return mono.value, kps[:n.value].copy(), desc[:n.value].copy()
+
     def extract_batch(self, images: np.ndarray, vLappingArea: Sequence[int] = (0, 0)
                       ) -> List[Tuple[int, np.ndarray, np.ndarray]]:
         """Batch replay over host frames [B, H, W] (frames are independent: SURVEY.md §8(e))."""

@@ -33,6 +33,23 @@ class ORBVocabulary:
         self._voc = v
         return True
 
+    def saveToTextFile(self, filename: str) -> None:
+        """TemplatedVocabulary.h:1428-1449 (byte-identical to the reference's writer)."""
+        check(self._L.orbx_voc_save_text(self._voc, filename.encode()), self._ctx)
+
+    def saveBinary(self, filename: str) -> None:
+        """Exact binary cache (not a reference format)."""
+        check(self._L.orbx_voc_save_binary(self._voc, filename.encode()), self._ctx)
+
+    def loadBinary(self, filename: str) -> bool:
+        v = C.c_void_p(0)
+        if self._L.orbx_voc_load_binary(self._ctx, filename.encode(), C.byref(v)) != 0:
+            return False
+        if self._voc and self._voc.value:
+            self._L.orbx_voc_destroy(self._voc)
+        self._voc = v
+        return True
+
     def info(self):
         k, L, n, w = (C.c_int(0) for _ in range(4))
         check(self._L.orbx_voc_info(self._voc, C.byref(k), C.byref(L), C.byref(n), C.byref(w)), self._ctx)

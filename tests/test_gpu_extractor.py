@@ -273,3 +273,33 @@ def test_config4_tumvi_batch_all_frames():
     for t in range(len(frames)):
         assert_same(res[t], ora.extract(frames[t], (0, 1000)), f"1024^2 f{t}")
         assert 0 < res[t][0] < len(res[t][1])
+
+
+@pytest.mark.parametrize("channels,rgb,stride_pad", [(3, True, 0), (3, False, 5), (4, True, 0), (4, False, 12)])
+def test_color_ingestion_equals_oracle(channels, rgb, stride_pad):
+    """cvtColor fused behind the upload (src/Tracking.cc:1572-1585): grey plane and features equal the oracle's."""
+    rng = np.random.default_rng(channels * 2 + rgb)
+    base = synth.make_stream(1, 480, 640)[0].astype(np.int32)
+    planes = [np.clip(base + rng.integers(-40, 41, base.shape) + s, 0, 255).astype(np.uint8) for s in (0, 17, -23)]
+    if channels == 4:
+        planes.append(rng.integers(0, 256, base.shape).astype(np.uint8))          # alpha: ignored
+    wide = np.zeros((480, 640 * channels + stride_pad), np.uint8)
+    img = np.lib.stride_tricks.as_strided(wide, (480, 640, channels), (wide.strides[0], channels, 1))
+    img[...] = np.stack(planes, -1)
+    gray = po.cvt_color_to_gray(img, rgb)
+    assert abs(gray.astype(int) - planes[1].astype(int)).max() < 60 and gray.std() > 10
+    gpu = ORBextractor(1000, 1.2, 8, 20, 7)
+    mono, kps, desc = gpu.extract_color(img, rgb, (0, 1000))
+    assert np.array_equal(gpu.pyramid_level(0), gray)
+    okps, odesc, omono = po.OracleExtractor(1000, 1.2, 8, 20, 7).extract(gray, (0, 1000))
+    assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc)
+    # the grey path still works on the same context afterwards (graph path + staging buffers untouched)
+    mono2, kps2, desc2 = gpu(gray, None, (0, 1000))
+    assert mono2 == omono and kps2.tobytes() == okps.tobytes() and np.array_equal(desc2, odesc)
+
+
+def test_color_ingestion_formula_extremes():
+    assert po.cvt_color_to_gray(np.full((1, 1, 3), 255, np.uint8), True)[0, 0] == 255
+    assert po.cvt_color_to_gray(np.zeros((1, 1, 3), np.uint8), True)[0, 0] == 0
+    px = np.array([[[255, 0, 0]]], np.uint8)
+    assert po.cvt_color_to_gray(px, True)[0, 0] == 76 and po.cvt_color_to_gray(px, False)[0, 0] == 29   # 0.299 / 0.114

@@ -115,3 +115,38 @@ def test_knn2_large_train_set_segment_path(feats):
     gi, gd = m.knn2(q, t)
     oi, od = po.knn2(q, t)
     assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+
+
+def test_vocabulary_writers_and_binary_cache(feats, tmp_path):
+    """saveToTextFile: byte-identical to the REFERENCE's own writer (oracle/_ref, TemplatedVocabulary.h:1428-1449);
+    the binary cache round-trips every field exactly (the text format keeps 6 digits of each weight)."""
+    gpu, out = feats
+    alld = np.concatenate([o[2] for o in out])
+    p, p2, p3, pb = (str(tmp_path / n) for n in ("voc.txt", "saved.txt", "ref_saved.txt", "voc.bin"))
+    make_vocabulary(p, alld, 6, 4, seed=77)
+    gv = ORBVocabulary(gpu)
+    assert gv.loadFromTextFile(p)
+    gv.saveToTextFile(p2)
+    if po.ref_available():
+        po.RefVocabulary(p).saveToTextFile(p3)
+        assert open(p2, "rb").read() == open(p3, "rb").read()
+    # what was written loads again and is a fixed point of load -> save
+    g2 = ORBVocabulary(gpu)
+    assert g2.loadFromTextFile(p2) and g2.info() == gv.info()
+    g2.saveToTextFile(str(tmp_path / "again.txt"))
+    assert open(p2, "rb").read() == open(str(tmp_path / "again.txt"), "rb").read()
+    # binary cache: exact
+    gv.saveBinary(pb)
+    g3 = ORBVocabulary(gpu)
+    assert g3.loadBinary(pb) and g3.info() == gv.info()
+    for o in out[:2]:
+        (ai, av), afv = gv.transform(o[2], 2)
+        (bi, bv), bfv = g3.transform(o[2], 2)
+        assert np.array_equal(ai, bi) and av.tobytes() == bv.tobytes() and afv == bfv
+    # corrupt / truncated caches are rejected
+    raw = open(pb, "rb").read()
+    for bad in (raw[:-5], b"XXXXVOC1" + raw[8:], raw + b"\0"):
+        pbad = str(tmp_path / "bad.bin")
+        open(pbad, "wb").write(bad)
+        assert not ORBVocabulary(gpu).loadBinary(pbad)
+    assert not ORBVocabulary(gpu).loadBinary(str(tmp_path / "missing.bin"))
