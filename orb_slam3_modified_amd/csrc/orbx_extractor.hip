@@ -184,7 +184,7 @@ static void free_buffers(orbx_ctx* ctx) {
 static int ensure_buffers(orbx_ctx* ctx, int rows, int cols, int nframes) {
   const bool same_shape = ctx->geo.rows == rows && ctx->geo.cols == cols && ctx->d_geo;
   if (same_shape && nframes <= ctx->batch_cap) return ORBX_OK;
-  ORBX_HIP(ctx, hipDeviceSynchronize());
+  ORBX_HIP(ctx, sync_ctx(ctx));
   Geometry geo;
   int rc = build_geometry(ctx, rows, cols, geo);
   if (rc != ORBX_OK) return rc;
@@ -208,14 +208,14 @@ static int ensure_buffers(orbx_ctx* ctx, int rows, int cols, int nframes) {
     D.bplane_off = L.bplane_off; D.btile_begin = L.btile_begin; D.btiles_x = L.btiles_x; D.btiles_y = L.btiles_y; D.m_btiles_x = div_magic(L.btiles_x);
   }
   ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_geo, sizeof(DeviceGeom)));
-  ORBX_HIP(ctx, hipMemcpy(ctx->d_geo, &dg, sizeof(dg), hipMemcpyHostToDevice));
+  ORBX_HIP(ctx, copy_sync(ctx, ctx->d_geo, &dg, sizeof(dg), hipMemcpyHostToDevice));
   ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_cells, sizeof(CellGeom) * geo.cells.size()));
-  ORBX_HIP(ctx, hipMemcpy(ctx->d_cells, geo.cells.data(), sizeof(CellGeom) * geo.cells.size(), hipMemcpyHostToDevice));
+  ORBX_HIP(ctx, copy_sync(ctx, ctx->d_cells, geo.cells.data(), sizeof(CellGeom) * geo.cells.size(), hipMemcpyHostToDevice));
   ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_xtab, sizeof(XTab) * std::max<size_t>(geo.xtab.size(), 1)));
   ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_ytab, sizeof(XTab) * std::max<size_t>(geo.ytab.size(), 1)));
   if (!geo.xtab.empty()) {
-    ORBX_HIP(ctx, hipMemcpy(ctx->d_xtab, geo.xtab.data(), sizeof(XTab) * geo.xtab.size(), hipMemcpyHostToDevice));
-    ORBX_HIP(ctx, hipMemcpy(ctx->d_ytab, geo.ytab.data(), sizeof(XTab) * geo.ytab.size(), hipMemcpyHostToDevice));
+    ORBX_HIP(ctx, copy_sync(ctx, ctx->d_xtab, geo.xtab.data(), sizeof(XTab) * geo.xtab.size(), hipMemcpyHostToDevice));
+    ORBX_HIP(ctx, copy_sync(ctx, ctx->d_ytab, geo.ytab.data(), sizeof(XTab) * geo.ytab.size(), hipMemcpyHostToDevice));
   }
   const size_t B = (size_t)nframes;
   ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_pyr, std::max<size_t>(B * (size_t)geo.pyr_bytes, 64)));
@@ -583,6 +583,7 @@ int orbx_extract_batch_device(orbx_ctx* ctx, const uint8_t* d_imgs, int nframes,
   int rc = ensure_buffers(ctx, rows, cols, nframes);
   if (rc != ORBX_OK) return rc;
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  ctx->last_ext_stream = stream ? (hipStream_t)stream : nullptr;
   ctx->last_imgs = d_imgs; ctx->last_row_stride = row_stride; ctx->last_frame_stride = frame_stride;
   ctx->last_nframes = nframes;
   // Sub-batches on concurrent streams: frames are independent, and the pipeline alternates VALU-bound kernels
@@ -833,7 +834,7 @@ int orbx_pyramid_level(orbx_ctx* ctx, int frame, int level, uint8_t* dst, size_t
   const uint8_t* src; size_t sp;
   if (level == 0) { src = ctx->last_imgs + (size_t)frame * ctx->last_frame_stride; sp = ctx->last_row_stride; }
   else { src = ctx->d_pyr + (size_t)frame * ctx->geo.pyr_bytes + L.plane_off; sp = L.pitch; }
-  ORBX_HIP(ctx, hipMemcpy2D(dst, dst_stride, src, sp, L.w, L.h, hipMemcpyDeviceToHost));
+  ORBX_HIP(ctx, copy2d_sync(ctx, dst, dst_stride, src, sp, L.w, L.h, hipMemcpyDeviceToHost));
   return ORBX_OK;
 }
 
@@ -862,8 +863,8 @@ int orbx_debug_blur_level(orbx_ctx* ctx, int frame, int level, uint8_t* dst, siz
     return ctx ? set_err(ctx, ORBX_E_INVALID, "no such pyramid level") : ORBX_E_INVALID;
   const LevelGeom& L = ctx->geo.lv[level];
   ORBX_HIP(ctx, hipSetDevice(ctx->device));
-  ORBX_HIP(ctx, hipDeviceSynchronize());
-  ORBX_HIP(ctx, hipMemcpy2D(dst, dst_stride, ctx->d_blur + (size_t)frame * ctx->geo.blur_bytes + L.bplane_off, L.pitch, L.w, L.h,
+  ORBX_HIP(ctx, sync_ctx(ctx));
+  ORBX_HIP(ctx, copy2d_sync(ctx, dst, dst_stride, ctx->d_blur + (size_t)frame * ctx->geo.blur_bytes + L.bplane_off, L.pitch, L.w, L.h,
                             hipMemcpyDeviceToHost));
   return ORBX_OK;
 }
@@ -872,15 +873,15 @@ int orbx_debug_level_points(orbx_ctx* ctx, int frame, int level, int stage, uint
   if (!ctx || !ctx->d_geo || level < 0 || level >= ctx->nlevels || frame < 0 || frame >= ctx->last_nframes)
     return ctx ? set_err(ctx, ORBX_E_INVALID, "no such level") : ORBX_E_INVALID;
   ORBX_HIP(ctx, hipSetDevice(ctx->device));
-  ORBX_HIP(ctx, hipDeviceSynchronize());
+  ORBX_HIP(ctx, sync_ctx(ctx));
   const Geometry& geo = ctx->geo;
   const LevelGeom& L = geo.lv[level];
   if (stage == 0) {
     std::vector<int32_t> cnt(L.ncells);
-    ORBX_HIP(ctx, hipMemcpy(cnt.data(), ctx->d_cell_cnt + (size_t)frame * geo.cells.size() + L.cell_begin,
+    ORBX_HIP(ctx, copy_sync(ctx, cnt.data(), ctx->d_cell_cnt + (size_t)frame * geo.cells.size() + L.cell_begin,
                             sizeof(int32_t) * L.ncells, hipMemcpyDeviceToHost));
     std::vector<uint32_t> slots(L.cand_cap);
-    ORBX_HIP(ctx, hipMemcpy(slots.data(), ctx->d_cand + (size_t)frame * geo.cand_total + L.cand_off,
+    ORBX_HIP(ctx, copy_sync(ctx, slots.data(), ctx->d_cand + (size_t)frame * geo.cand_total + L.cand_off,
                             sizeof(uint32_t) * L.cand_cap, hipMemcpyDeviceToHost));
     int n = 0;
     for (int c = 0; c < L.ncells; c++) {
@@ -893,10 +894,10 @@ int orbx_debug_level_points(orbx_ctx* ctx, int frame, int level, int stage, uint
     return n;
   }
   int32_t n = 0;
-  ORBX_HIP(ctx, hipMemcpy(&n, ctx->d_lvl_n + (size_t)frame * geo.nlevels + level, sizeof(int32_t), hipMemcpyDeviceToHost));
+  ORBX_HIP(ctx, copy_sync(ctx, &n, ctx->d_lvl_n + (size_t)frame * geo.nlevels + level, sizeof(int32_t), hipMemcpyDeviceToHost));
   if (n < 0) return set_err(ctx, ORBX_E_CAPACITY, "quadtree level overflow");
   if (dst && n > 0)
-    ORBX_HIP(ctx, hipMemcpy(dst, ctx->d_lvl_kp + (size_t)frame * geo.kp_total + L.kp_off, sizeof(uint32_t) * std::min(n, cap),
+    ORBX_HIP(ctx, copy_sync(ctx, dst, ctx->d_lvl_kp + (size_t)frame * geo.kp_total + L.kp_off, sizeof(uint32_t) * std::min(n, cap),
                             hipMemcpyDeviceToHost));
   return n;
 }
@@ -910,7 +911,7 @@ int orbx_profile_enable(orbx_ctx* ctx, int on) {
 int orbx_profile_read(orbx_ctx* ctx, double ms[ORBX_NUM_KERNELS], int64_t launches[ORBX_NUM_KERNELS]) {
   if (!ctx) return ORBX_E_INVALID;
   ORBX_HIP(ctx, hipSetDevice(ctx->device));
-  ORBX_HIP(ctx, hipDeviceSynchronize());
+  ORBX_HIP(ctx, sync_ctx(ctx));
   for (size_t i = 0; i + 3 <= ctx->ev_pool.size(); i += 3) {
     hipEvent_t e0 = ctx->ev_pool[i], e1 = ctx->ev_pool[i + 1];
     const int slot = (int)(intptr_t)ctx->ev_pool[i + 2] - 1;
@@ -936,14 +937,14 @@ int orbx_debug_trig(orbx_ctx* ctx, const float* y, const float* x, int n, int an
   const size_t bytes = (size_t)n * sizeof(float);
   ORBX_HIP(ctx, hipMalloc((void**)&dy, bytes)); ORBX_HIP(ctx, hipMalloc((void**)&dx, bytes));
   ORBX_HIP(ctx, hipMalloc((void**)&dang, bytes)); ORBX_HIP(ctx, hipMalloc((void**)&da, bytes)); ORBX_HIP(ctx, hipMalloc((void**)&db, bytes));
-  ORBX_HIP(ctx, hipMemcpy(dy, y, bytes, hipMemcpyHostToDevice));
-  if (x) ORBX_HIP(ctx, hipMemcpy(dx, x, bytes, hipMemcpyHostToDevice));
+  ORBX_HIP(ctx, copy_sync(ctx, dy, y, bytes, hipMemcpyHostToDevice));
+  if (x) ORBX_HIP(ctx, copy_sync(ctx, dx, x, bytes, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k_debug_trig, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, dy, dx, n, angle_is_input, dang, da, db);
   ORBX_HIP(ctx, hipGetLastError());
   ORBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  ORBX_HIP(ctx, hipMemcpy(angle, dang, bytes, hipMemcpyDeviceToHost));
-  ORBX_HIP(ctx, hipMemcpy(a, da, bytes, hipMemcpyDeviceToHost));
-  ORBX_HIP(ctx, hipMemcpy(b, db, bytes, hipMemcpyDeviceToHost));
+  ORBX_HIP(ctx, copy_sync(ctx, angle, dang, bytes, hipMemcpyDeviceToHost));
+  ORBX_HIP(ctx, copy_sync(ctx, a, da, bytes, hipMemcpyDeviceToHost));
+  ORBX_HIP(ctx, copy_sync(ctx, b, db, bytes, hipMemcpyDeviceToHost));
   (void)hipFree(dy); (void)hipFree(dx); (void)hipFree(dang); (void)hipFree(da); (void)hipFree(db);
   return ORBX_OK;
 }
@@ -992,7 +993,7 @@ int orbx_debug_calib_copy(orbx_ctx* ctx, const void* d_src, void* d_dst, size_t 
 
 #ifdef ORBX_QT_PROFILE
 int orbx_debug_qt_profile(orbx_ctx* ctx, long long* out, int reset) {
-  (void)hipDeviceSynchronize();
+  (void)sync_ctx(ctx);
   if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qt_prof), sizeof(long long) * kMaxLevels * 8);
   if (reset) { long long z[kMaxLevels * 8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_qt_prof), z, sizeof(z)); }
   return 0;

@@ -182,6 +182,7 @@ struct orbx_ctx {
   uint8_t* h_pyr = nullptr; size_t h_pyr_bytes = 0; bool h_pyr_valid = false;
   // last extraction (for orbx_pyramid_level / debug dumps)
   const uint8_t* last_imgs = nullptr; size_t last_row_stride = 0, last_frame_stride = 0; int last_nframes = 0;
+  hipStream_t last_ext_stream = nullptr;   // caller's stream of the last orbx_extract_batch_device (its work may still use our buffers)
   // profiling
   bool profiling = false;
   double prof_ms[ORBX_NUM_KERNELS] = {0};
@@ -191,6 +192,28 @@ struct orbx_ctx {
 
 namespace orbx {
 int set_err(orbx_ctx* ctx, int code, const std::string& msg);
+
+// No entry point touches the legacy (null) stream: a null-stream copy or a device-wide sync issued by one thread while
+// ANOTHER context captures its single-frame graph is rejected by the runtime and poisons that capture (two extractors
+// run from two threads in stereo, src/Frame.cc:122-125).  Synchronous copies go through the context's own stream.
+inline hipError_t copy_sync(orbx_ctx* ctx, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, ctx->stream);
+  return e != hipSuccess ? e : hipStreamSynchronize(ctx->stream);
+}
+inline hipError_t copy2d_sync(orbx_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height,
+                              hipMemcpyKind kind) {
+  hipError_t e = hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, kind, ctx->stream);
+  return e != hipSuccess ? e : hipStreamSynchronize(ctx->stream);
+}
+// everything this context may have in flight: its stream, its aux streams, and the caller's stream of the last
+// device-resident batch
+inline hipError_t sync_ctx(orbx_ctx* ctx) {
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  for (int i = 0; i < orbx_ctx::kMaxAux && e == hipSuccess; i++)
+    if (ctx->aux[i]) e = hipStreamSynchronize(ctx->aux[i]);
+  if (e == hipSuccess && ctx->last_ext_stream) e = hipStreamSynchronize(ctx->last_ext_stream);
+  return e;
+}
 #define ORBX_HIP(ctx, expr)                                                                          \
   do {                                                                                               \
     hipError_t _e = (expr);                                                                          \

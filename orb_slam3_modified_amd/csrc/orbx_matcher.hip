@@ -291,12 +291,12 @@ int upload_voc(orbx_voc* v) {
   }
   ORBX_HIP(ctx, hipSetDevice(ctx->device));
   ORBX_HIP(ctx, hipMalloc((void**)&v->d_nodes, sizeof(DevNode) * nn));
-  ORBX_HIP(ctx, hipMemcpy(v->d_nodes, nodes.data(), sizeof(DevNode) * nn, hipMemcpyHostToDevice));
+  ORBX_HIP(ctx, copy_sync(ctx, v->d_nodes, nodes.data(), sizeof(DevNode) * nn, hipMemcpyHostToDevice));
   ORBX_HIP(ctx, hipMalloc((void**)&v->d_slot_desc, std::max<size_t>(sdesc.size(), 32)));
   ORBX_HIP(ctx, hipMalloc((void**)&v->d_slot_node, std::max<size_t>(snode.size(), 1) * sizeof(int32_t)));
   if (!snode.empty()) {
-    ORBX_HIP(ctx, hipMemcpy(v->d_slot_desc, sdesc.data(), sdesc.size(), hipMemcpyHostToDevice));
-    ORBX_HIP(ctx, hipMemcpy(v->d_slot_node, snode.data(), snode.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    ORBX_HIP(ctx, copy_sync(ctx, v->d_slot_desc, sdesc.data(), sdesc.size(), hipMemcpyHostToDevice));
+    ORBX_HIP(ctx, copy_sync(ctx, v->d_slot_node, snode.data(), snode.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   }
   return ORBX_OK;
 }
@@ -368,19 +368,19 @@ int orbx_nn_csr(orbx_ctx* ctx, const uint8_t* q_desc, int nq, const uint8_t* t_d
   ORBX_HIP(ctx, drp.alloc(nq + 1)); ORBX_HIP(ctx, dc.alloc(nnz));
   ORBX_HIP(ctx, dbi.alloc(nq)); ORBX_HIP(ctx, dbd.alloc(nq)); ORBX_HIP(ctx, dsi.alloc(nq)); ORBX_HIP(ctx, dsd.alloc(nq));
   ORBX_HIP(ctx, ddo.alloc(nnz));
-  ORBX_HIP(ctx, hipMemcpy(dq.p, q_desc, (size_t)nq * 32, hipMemcpyHostToDevice));
-  if (nt) ORBX_HIP(ctx, hipMemcpy(dt.p, t_desc, (size_t)nt * 32, hipMemcpyHostToDevice));
-  ORBX_HIP(ctx, hipMemcpy(drp.p, row_ptr, sizeof(int32_t) * (nq + 1), hipMemcpyHostToDevice));
-  if (nnz) ORBX_HIP(ctx, hipMemcpy(dc.p, cand, sizeof(int32_t) * nnz, hipMemcpyHostToDevice));
+  ORBX_HIP(ctx, copy_sync(ctx, dq.p, q_desc, (size_t)nq * 32, hipMemcpyHostToDevice));
+  if (nt) ORBX_HIP(ctx, copy_sync(ctx, dt.p, t_desc, (size_t)nt * 32, hipMemcpyHostToDevice));
+  ORBX_HIP(ctx, copy_sync(ctx, drp.p, row_ptr, sizeof(int32_t) * (nq + 1), hipMemcpyHostToDevice));
+  if (nnz) ORBX_HIP(ctx, copy_sync(ctx, dc.p, cand, sizeof(int32_t) * nnz, hipMemcpyHostToDevice));
   int rc = orbx_nn_csr_device(ctx, dq.p, nq, dt.p, nt, drp.p, dc.p, last_wins, dbi.p, dbd.p, dsi.p, dsd.p,
                               dist_out ? ddo.p : nullptr, ctx->stream);
   if (rc != ORBX_OK) return rc;
   ORBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (best_idx) ORBX_HIP(ctx, hipMemcpy(best_idx, dbi.p, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
-  if (best_dist) ORBX_HIP(ctx, hipMemcpy(best_dist, dbd.p, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
-  if (second_idx) ORBX_HIP(ctx, hipMemcpy(second_idx, dsi.p, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
-  if (second_dist) ORBX_HIP(ctx, hipMemcpy(second_dist, dsd.p, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
-  if (dist_out && nnz) ORBX_HIP(ctx, hipMemcpy(dist_out, ddo.p, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost));
+  if (best_idx) ORBX_HIP(ctx, copy_sync(ctx, best_idx, dbi.p, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
+  if (best_dist) ORBX_HIP(ctx, copy_sync(ctx, best_dist, dbd.p, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
+  if (second_idx) ORBX_HIP(ctx, copy_sync(ctx, second_idx, dsi.p, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
+  if (second_dist) ORBX_HIP(ctx, copy_sync(ctx, second_dist, dsd.p, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
+  if (dist_out && nnz) ORBX_HIP(ctx, copy_sync(ctx, dist_out, ddo.p, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost));
   return ORBX_OK;
 }
 
@@ -420,13 +420,13 @@ int orbx_knn2_allpairs(orbx_ctx* ctx, const uint8_t* q_desc, int nq, const uint8
   DevBuf<int32_t> di, dd;
   ORBX_HIP(ctx, dq.alloc((size_t)nq * 32)); ORBX_HIP(ctx, dt.alloc((size_t)nt * 32));
   ORBX_HIP(ctx, di.alloc((size_t)nq * 2)); ORBX_HIP(ctx, dd.alloc((size_t)nq * 2));
-  ORBX_HIP(ctx, hipMemcpy(dq.p, q_desc, (size_t)nq * 32, hipMemcpyHostToDevice));
-  if (nt) ORBX_HIP(ctx, hipMemcpy(dt.p, t_desc, (size_t)nt * 32, hipMemcpyHostToDevice));
+  ORBX_HIP(ctx, copy_sync(ctx, dq.p, q_desc, (size_t)nq * 32, hipMemcpyHostToDevice));
+  if (nt) ORBX_HIP(ctx, copy_sync(ctx, dt.p, t_desc, (size_t)nt * 32, hipMemcpyHostToDevice));
   int rc = orbx_knn2_allpairs_device(ctx, dq.p, nq, dt.p, nt, di.p, dd.p, ctx->stream);
   if (rc != ORBX_OK) return rc;
   ORBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  ORBX_HIP(ctx, hipMemcpy(idx, di.p, sizeof(int32_t) * nq * 2, hipMemcpyDeviceToHost));
-  ORBX_HIP(ctx, hipMemcpy(dist, dd.p, sizeof(int32_t) * nq * 2, hipMemcpyDeviceToHost));
+  ORBX_HIP(ctx, copy_sync(ctx, idx, di.p, sizeof(int32_t) * nq * 2, hipMemcpyDeviceToHost));
+  ORBX_HIP(ctx, copy_sync(ctx, dist, dd.p, sizeof(int32_t) * nq * 2, hipMemcpyDeviceToHost));
   return ORBX_OK;
 }
 
@@ -584,13 +584,13 @@ int orbx_bow_transform(orbx_voc* v, const uint8_t* desc, int n, int levelsup, ui
   ORBX_HIP(ctx, hipSetDevice(ctx->device));
   DevBuf<uint8_t> dd; DevBuf<uint32_t> dw, dn; DevBuf<double> dwt;
   ORBX_HIP(ctx, dd.alloc((size_t)n * 32)); ORBX_HIP(ctx, dw.alloc(n)); ORBX_HIP(ctx, dn.alloc(n)); ORBX_HIP(ctx, dwt.alloc(n));
-  ORBX_HIP(ctx, hipMemcpy(dd.p, desc, (size_t)n * 32, hipMemcpyHostToDevice));
+  ORBX_HIP(ctx, copy_sync(ctx, dd.p, desc, (size_t)n * 32, hipMemcpyHostToDevice));
   int rc = orbx_bow_transform_device(v, dd.p, n, levelsup, dw.p, dwt.p, dn.p, ctx->stream);
   if (rc != ORBX_OK) return rc;
   ORBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  ORBX_HIP(ctx, hipMemcpy(word, dw.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
-  ORBX_HIP(ctx, hipMemcpy(weight, dwt.p, sizeof(double) * n, hipMemcpyDeviceToHost));
-  ORBX_HIP(ctx, hipMemcpy(node, dn.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+  ORBX_HIP(ctx, copy_sync(ctx, word, dw.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+  ORBX_HIP(ctx, copy_sync(ctx, weight, dwt.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+  ORBX_HIP(ctx, copy_sync(ctx, node, dn.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
   return ORBX_OK;
 }
 
@@ -649,16 +649,16 @@ int orbx_bow_score_l1_batch(orbx_ctx* ctx, const uint32_t* q_ids, const double* 
   DevBuf<uint32_t> dqi, ddi; DevBuf<double> dqv, ddv, dsc; DevBuf<int32_t> dp;
   ORBX_HIP(ctx, dqi.alloc(nq)); ORBX_HIP(ctx, dqv.alloc(nq)); ORBX_HIP(ctx, ddi.alloc(nnz)); ORBX_HIP(ctx, ddv.alloc(nnz));
   ORBX_HIP(ctx, dsc.alloc(ndb)); ORBX_HIP(ctx, dp.alloc(ndb + 1));
-  if (nq) { ORBX_HIP(ctx, hipMemcpy(dqi.p, q_ids, sizeof(uint32_t) * nq, hipMemcpyHostToDevice));
-            ORBX_HIP(ctx, hipMemcpy(dqv.p, q_vals, sizeof(double) * nq, hipMemcpyHostToDevice)); }
-  if (nnz) { ORBX_HIP(ctx, hipMemcpy(ddi.p, db_ids, sizeof(uint32_t) * nnz, hipMemcpyHostToDevice));
-             ORBX_HIP(ctx, hipMemcpy(ddv.p, db_vals, sizeof(double) * nnz, hipMemcpyHostToDevice)); }
-  ORBX_HIP(ctx, hipMemcpy(dp.p, db_ptr, sizeof(int32_t) * (ndb + 1), hipMemcpyHostToDevice));
+  if (nq) { ORBX_HIP(ctx, copy_sync(ctx, dqi.p, q_ids, sizeof(uint32_t) * nq, hipMemcpyHostToDevice));
+            ORBX_HIP(ctx, copy_sync(ctx, dqv.p, q_vals, sizeof(double) * nq, hipMemcpyHostToDevice)); }
+  if (nnz) { ORBX_HIP(ctx, copy_sync(ctx, ddi.p, db_ids, sizeof(uint32_t) * nnz, hipMemcpyHostToDevice));
+             ORBX_HIP(ctx, copy_sync(ctx, ddv.p, db_vals, sizeof(double) * nnz, hipMemcpyHostToDevice)); }
+  ORBX_HIP(ctx, copy_sync(ctx, dp.p, db_ptr, sizeof(int32_t) * (ndb + 1), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k_bow_score_l1, dim3((ndb + 255) / 256), dim3(256), 0, ctx->stream, dqi.p, dqv.p, nq, dp.p, ddi.p, ddv.p,
                      ndb, dsc.p);
   ORBX_HIP(ctx, hipGetLastError());
   ORBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  ORBX_HIP(ctx, hipMemcpy(scores, dsc.p, sizeof(double) * ndb, hipMemcpyDeviceToHost));
+  ORBX_HIP(ctx, copy_sync(ctx, scores, dsc.p, sizeof(double) * ndb, hipMemcpyDeviceToHost));
   return ORBX_OK;
 }
 

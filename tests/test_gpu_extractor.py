@@ -303,3 +303,34 @@ def test_color_ingestion_formula_extremes():
     assert po.cvt_color_to_gray(np.zeros((1, 1, 3), np.uint8), True)[0, 0] == 0
     px = np.array([[[255, 0, 0]]], np.uint8)
     assert po.cvt_color_to_gray(px, True)[0, 0] == 76 and po.cvt_color_to_gray(px, False)[0, 0] == 29   # 0.299 / 0.114
+
+
+def test_two_extractors_from_two_threads_like_stereo():
+    """src/Frame.cc:122-125: the left and right extractor run concurrently from two std::threads.  Two contexts, two
+    threads (ctypes drops the GIL during the calls), different image shapes so both capture / re-capture their graphs while
+    the other one is running; every result must equal the single-threaded one."""
+    import threading
+    imgs_l = synth.make_stream(6, 480, 752, synth.DEFAULT_SEED + 5)
+    imgs_r = synth.make_stream(6, 480, 640, synth.DEFAULT_SEED + 6)
+    exl, exr = ORBextractor(1200, 1.2, 8, 20, 7), ORBextractor(1000, 1.2, 8, 20, 7)
+    want_l = [exl(f, None, (0, 0)) for f in imgs_l]
+    want_r = [exr(f, None, (0, 0)) for f in imgs_r]
+    errors = []
+
+    def run(ex, imgs, want, tag):
+        try:
+            for rep in range(15):
+                for i, f in enumerate(imgs):
+                    view = f[: 480 - 8 * (rep % 2)]                     # alternate shapes: forces graph re-capture
+                    mono, k, d = ex(view, None, (0, 0))
+                    if rep % 2 == 0:
+                        wm, wk, wd = want[i]
+                        if mono != wm or k.tobytes() != wk.tobytes() or not np.array_equal(d, wd):
+                            errors.append((tag, rep, i))
+        except Exception as e:   # noqa: BLE001
+            errors.append((tag, repr(e)))
+
+    ts = [threading.Thread(target=run, args=(exl, imgs_l, want_l, "L")), threading.Thread(target=run, args=(exr, imgs_r, want_r, "R"))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors[:5]
