@@ -26,6 +26,8 @@ class ORBextractor:
         if rc != 0:
             raise _lib.OrbxError(rc, "orbx_create failed (no HIP device?)" if rc == _lib.ORBX_E_DEVICE else "bad arguments")
         self.nfeatures, self.nlevels, self.scaleFactor = nfeatures, nlevels, float(np.float32(scaleFactor))
+        self.iniThFAST, self.minThFAST, self.device_id = iniThFAST, minThFAST, device_id
+        self._ctor_scale = scaleFactor
         self.capacity = self._L.orbx_keypoint_capacity(self._ctx)
         n = nlevels
         self._scale, self._inv, self._s2, self._is2 = (np.zeros(n, np.float32) for _ in range(4))
@@ -33,6 +35,11 @@ class ORBextractor:
         check(self._L.orbx_scale_tables(self._ctx, ptr(self._scale), ptr(self._inv), ptr(self._s2), ptr(self._is2),
                                         ptr(self._quota)), self._ctx)
         self._last_frames = 0
+
+    def clone(self) -> "ORBextractor":
+        """A second context with the same parameters (own stream, own buffers): contexts are independent, so two of them
+        can work on two halves of a batch concurrently (replay lanes, stereo)."""
+        return ORBextractor(self.nfeatures, self._ctor_scale, self.nlevels, self.iniThFAST, self.minThFAST, self.device_id)
 
     def close(self):
         if getattr(self, "_ctx", None) and self._ctx.value:

