@@ -97,6 +97,10 @@ int orbx_pyramid_level(orbx_ctx* ctx, int frame, int level, uint8_t* dst, size_t
  * (the reference re-points mvImagePyramid on every call too).  Level 0 is the caller's own image:
  * *data = NULL. */
 int orbx_set_host_pyramid(orbx_ctx* ctx, int on);
+/* Scheduling / launch-shape knobs of one context (results never depend on them); the ORBX_* environment variables set
+ * the defaults at orbx_create.  name: "fork_blur" | "fork_fast0" | "fork_qt" (0|1: run that kernel on a second stream
+ * beside its neighbour), "graph" (0|1), "fast_threads" (64|128|256), "desc_k" (1|2|4|8|16), "streams" (1|2). */
+int orbx_set_option(orbx_ctx* ctx, const char* name, int value);
 int orbx_host_pyramid_level(orbx_ctx* ctx, int level, const uint8_t** data, size_t* stride, int* w, int* h);
 
 /* The 7x7 Gaussian-blurred copy of mvImagePyramid[level] the descriptors were sampled from

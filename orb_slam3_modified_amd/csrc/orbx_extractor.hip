@@ -278,7 +278,8 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
   int32_t* const b_lvl_n = ctx->d_lvl_n + (size_t)f0 * geo.nlevels;
   uint2* const b_kp_list = ctx->d_kp_list + (size_t)f0 * ctx->out_cap;
   // K2 (level 0): FAST over the cells of level 0 only needs the input image, so it is forked onto a second stream and
-  // runs concurrently with the (latency-bound) pyramid chain; joined before the quadtree.  Off by default (ORBX_FORK_FAST0=1 enables): measured no gain, both kernels fill the CUs.
+  // runs concurrently with the (latency-bound) pyramid chain; joined before the quadtree.  Off by default for a lone
+  // context (no gain: both kernels fill the CUs); the replay lanes switch it on (orbx_set_option), where it pays.
   const int need = geo.max_cell_w + 3;  // +3: alignment shift of the dword-staged rows
   const int pitchB = need <= 64 ? 64 : 96;
   const int tile_rows = geo.max_cell_h;
@@ -300,7 +301,9 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
                        ctx->ini_th, ctx->min_th, tile_rows, nitems, cell_base, ncells_sub, div_magic((uint32_t)ncells_sub));
   };
   const int ncells0 = geo.lv[0].ncells, ncells_all = (int)geo.cells.size();
-  const bool fork_fast0 = ctx->fork_fast0 && !ctx->profiling && geo.nlevels > 1;
+  // small batches (the single-frame operator() path) are latency-bound: a stream fork costs more than it hides there
+  const bool small_batch = nframes * geo.nlevels <= 512;
+  const bool fork_fast0 = ctx->fork_fast0 && !ctx->profiling && geo.nlevels > 1 && !small_batch;
   const int sb = f0 != 0;  // sub-batch slot of the fork events / streams
   if (fork_fast0) {
     hipStream_t fst = ctx->aux[orbx_ctx::kMaxAux - 3 - sb];
@@ -335,8 +338,6 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
   // K4a: 7x7 fixed-point Gaussian of every level (the reference blurs each level that holds keypoints).  It only needs
   // the pyramid, and it is VALU-bound while the quadtree that follows FAST is latency-bound with few workgroups, so it
   // is forked onto a second stream behind FAST and joined before the descriptors (ORBX_FORK_BLUR=0 disables).
-  // small batches (the single-frame operator() path) are latency-bound: a stream fork costs more than it hides there
-  const bool small_batch = nframes * geo.nlevels <= 512;
   const bool fork_blur = ctx->fork_blur && !ctx->profiling && !small_batch;
   hipStream_t bst = st;
   if (fork_blur) {
@@ -393,7 +394,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
     };
     const int nbig = (geo.nlevels >= 4 && !small_batch) ? kQtBigLevels : geo.nlevels;  // small batch: one launch, all levels
     int qrc = ORBX_OK;
-    if (nbig < geo.nlevels && !ctx->profiling) {
+    if (nbig < geo.nlevels && !ctx->profiling && ctx->fork_qt) {
       hipStream_t qst = ctx->aux[orbx_ctx::kMaxAux - 5 - sb];
       ORBX_HIP(ctx, hipEventRecord(ctx->ev_qt_fork[sb], st));
       ORBX_HIP(ctx, hipStreamWaitEvent(qst, ctx->ev_qt_fork[sb], 0));
@@ -505,6 +506,8 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, 
     const char* fb = getenv("ORBX_FORK_BLUR");
     ctx->fork_blur = fb ? atoi(fb) != 0 : true;
     const char* ff = getenv("ORBX_FORK_FAST0");
+    const char* fq = getenv("ORBX_FORK_QT");
+    ctx->fork_qt = fq ? atoi(fq) != 0 : true;
     ctx->fork_fast0 = ff ? atoi(ff) != 0 : false;  // measured: no gain (both kernels already fill the CUs), kept as a knob
     bool ok = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < 2 && ok; i++)
@@ -835,6 +838,20 @@ int orbx_pyramid_level(orbx_ctx* ctx, int frame, int level, uint8_t* dst, size_t
   if (level == 0) { src = ctx->last_imgs + (size_t)frame * ctx->last_frame_stride; sp = ctx->last_row_stride; }
   else { src = ctx->d_pyr + (size_t)frame * ctx->geo.pyr_bytes + L.plane_off; sp = L.pitch; }
   ORBX_HIP(ctx, copy2d_sync(ctx, dst, dst_stride, src, sp, L.w, L.h, hipMemcpyDeviceToHost));
+  return ORBX_OK;
+}
+
+int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
+  if (!ctx || !name) return ORBX_E_INVALID;
+  const std::string n(name);
+  if (n == "fork_blur") ctx->fork_blur = value != 0;
+  else if (n == "fork_fast0") ctx->fork_fast0 = value != 0;
+  else if (n == "fork_qt") ctx->fork_qt = value != 0;
+  else if (n == "graph") ctx->use_graph = value != 0;
+  else if (n == "fast_threads" && (value == 64 || value == 128 || value == 256)) ctx->fast_threads = value;
+  else if (n == "desc_k" && (value == 1 || value == 2 || value == 4 || value == 8 || value == 16)) ctx->desc_k = value;
+  else if (n == "streams" && value >= 1 && value <= 2) ctx->nstreams = value;
+  else return set_err(ctx, ORBX_E_INVALID, "orbx_set_option: unknown option or value out of range: " + n);
   return ORBX_OK;
 }
 

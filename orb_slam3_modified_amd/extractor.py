@@ -171,6 +171,10 @@ class ORBextractor:
         """Known-traffic device copy (counter calibration, tools/pmc_traffic.py)."""
         check(self._L.orbx_debug_calib_copy(self._ctx, ptr(d_src), ptr(d_dst), nbytes, width, ptr(stream)), self._ctx)
 
+    def set_option(self, name: str, value: int) -> None:
+        """Scheduling knob of this context (orbx_set_option); never changes results."""
+        check(self._L.orbx_set_option(self._ctx, name.encode(), int(value)), self._ctx)
+
     def profile_enable(self, on: bool = True):
         check(self._L.orbx_profile_enable(self._ctx, int(on)), self._ctx)
 

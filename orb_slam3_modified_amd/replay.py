@@ -90,6 +90,15 @@ class ReplayEngine:
         per = (self.B + lanes - 1) // lanes
         self.lane_ranges = [(j * per, min(self.B, (j + 1) * per)) for j in range(lanes) if j * per < self.B]
         self.exs = [extractor] + [extractor.clone() for _ in self.lane_ranges[1:]]
+        if len(self.lane_ranges) > 1:
+            # with a second lane filling the idle issue slots, the in-lane forks that pay are different from the single-lane
+            # ones (measured, 2 lanes x 128 frames: blur in line, level-0 FAST beside the pyramid chain, quadtree levels
+            # split: 1.095 ms vs 1.17 ms with the single-lane defaults); ORBX_* environment variables still win
+            import os
+            for ex in self.exs:
+                for name, env, val in (("fork_blur", "ORBX_FORK_BLUR", 0), ("fork_fast0", "ORBX_FORK_FAST0", 1), ("fork_qt", "ORBX_FORK_QT", 1)):
+                    if env not in os.environ:
+                        ex.set_option(name, val)
         cuda = dev.type == "cuda"
         self.streams = [torch.cuda.Stream(device=dev) if cuda else None for _ in self.lane_ranges]
         self.stream = self.streams[0]
