@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liborbx.so")
+LIB_PATH = os.environ.get("ORBX_LIB", os.path.join(_HERE, "liborbx.so"))   # ORBX_LIB: experiment builds (tools/)
 
 ORBX_OK, ORBX_E_INVALID, ORBX_E_EMPTY, ORBX_E_DEVICE, ORBX_E_CAPACITY, ORBX_E_FORMAT = 0, -1, -2, -3, -4, -5
 NUM_KERNELS = 6

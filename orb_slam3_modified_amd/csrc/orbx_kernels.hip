@@ -227,6 +227,10 @@ __global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__
   for (int k = 0; k < WPT; k++) bitmap[t * WPT + k] = 0;
   if (t == 0) s_cnt = 0;
   __syncthreads();
+#ifdef ORBX_FAST_STOP_AFTER_A   // timing experiment only
+  if (t == 0) cell_cnt[(long long)frame * g->ncells_total + cell] = 0;
+  return;
+#endif
   // ---- B: necessary test, 4 pixels (one aligned LDS dword of centres) per lane and step; branch-free
   {
     const int kmin = (3 + xo) >> 2, kmax = (cw - 4 + xo) >> 2, ng = kmax - kmin + 1;
@@ -280,6 +284,10 @@ __global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__
     }
   }
   __syncthreads();
+#ifdef ORBX_FAST_STOP_AFTER_B   // timing experiment only
+  if (t == 0) cell_cnt[(long long)frame * g->ncells_total + cell] = 0;
+  return;
+#endif
   const int n1 = s_cnt;
   // ---- C: exact score of the listed pixels
   for (int e = t; e < n1; e += T) {
