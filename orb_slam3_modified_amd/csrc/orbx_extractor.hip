@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -111,13 +112,14 @@ static int build_geometry(orbx_ctx* ctx, int rows, int cols, Geometry& geo) {
         float maxX = iniX + L.wcell + 6;
         if (iniX >= maxBX - 6) continue;
         if (maxX > maxBX) maxX = (float)maxBX;
-        CellGeom c;
+        CellGeom c{};
         c.level = (int16_t)l;
         c.x0 = (int16_t)iniX; c.y0 = (int16_t)iniY;
         c.cw = (int16_t)((int)maxX - (int)iniX); c.ch = (int16_t)((int)maxY - (int)iniY);
         c.relx = (int16_t)(j * L.wcell); c.rely = (int16_t)(i * L.hcell);
         const int dw = c.cw - 6, dh = c.ch - 6;
         if (dw <= 0 || dh <= 0) continue;  // FAST has no interior pixel: the reference gets no keypoint here
+        c.pitch = L.pitch; c.plane_off = L.plane_off;
         c.slot_off = cand_off;
         c.slot_cap = ((dw + 1) / 2) * ((dh + 1) / 2);  // strict 3x3 NMS: survivors are never 8-adjacent
         cand_off += c.slot_cap;
@@ -197,6 +199,7 @@ static int ensure_buffers(orbx_ctx* ctx, int rows, int cols, int nframes) {
   dg.ncells_total = (int)geo.cells.size(); dg.cand_total = geo.cand_total; dg.kp_total = geo.kp_total;
   dg.out_cap = ctx->out_cap; dg.btiles_total = geo.btiles_total;
   dg.m_ncells = div_magic((uint32_t)geo.cells.size()); dg.m_btiles = div_magic((uint32_t)geo.btiles_total);
+  for (int l = 0; l < kMaxLevels; l++) dg.btile_begin_all[l] = l < geo.nlevels ? geo.lv[l].btile_begin : INT_MAX;
   for (int l = 0; l < geo.nlevels; l++) {
     const LevelGeom& L = geo.lv[l];
     DeviceLevel& D = dg.lv[l];

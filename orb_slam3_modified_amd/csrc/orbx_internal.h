@@ -49,6 +49,8 @@ struct CellGeom {
   int16_t level, x0, y0, cw, ch;  // sub-image origin (level coords) and size incl. the +6 margin
   int16_t relx, rely;             // j*wCell, i*hCell (added to FAST coordinates, src/ORBextractor.cc:865-866)
   int32_t slot_off, slot_cap;     // range in one frame's candidate-slot array
+  int32_t pitch;                  // of the cell's pyramid plane (levels >= 1), copied here so that the FAST workgroup needs one
+  int64_t plane_off;              // dependent scalar load less before its first pixel fetch
 };
 
 struct Geometry {
@@ -79,6 +81,7 @@ struct DeviceLevel {  // POD copy of LevelGeom fields the kernels need
 struct DeviceGeom {
   int nlevels, rows, cols, ncells_total, cand_total, kp_total, out_cap, btiles_total;
   uint32_t m_ncells, m_btiles;  // fast_div magics of ncells_total, btiles_total
+  int btile_begin_all[kMaxLevels];  // lv[l].btile_begin side by side (INT_MAX beyond nlevels): the level of a blur tile from ONE scalar load
   DeviceLevel lv[kMaxLevels];
 };
 

@@ -199,11 +199,10 @@ __global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__
   // concurrently with the pyramid chain)
   const int frame = fast_div(L, m_ncells_sub), cell = cell_base + (L - frame * ncells_sub);
   const CellGeom cg = cells[cell];
-  const DeviceLevel& lv = g->lv[cg.level];
   const uint8_t* img;
   int pitch;  // < 2^23 (checked on the host): row offsets are 24-bit multiplies
   if (cg.level == 0) { img = imgs + (long long)frame * img_frame_stride; pitch = (int)img_row_stride; }
-  else { img = pyr + (long long)frame * pyr_frame_bytes + lv.plane_off; pitch = lv.pitch; }
+  else { img = pyr + (long long)frame * pyr_frame_bytes + cg.plane_off; pitch = cg.pitch; }
   const int cw = cg.cw, ch = cg.ch, dw = cw - 6, dh = ch - 6;
   // ---- A: stage the sub-image with aligned dword loads when the source allows it
   const bool al = ((pitch & 3) == 0) && ((((unsigned long long)img) & 3) == 0);
@@ -974,7 +973,8 @@ __global__ __launch_bounds__(256) void k_blur7(const DeviceGeom* __restrict__ g,
   if (L < 0) return;  // block-uniform
   const int frame = fast_div(L, g->m_btiles), bt = L - frame * g->btiles_total;
   int l = 0;
-  while (l + 1 < g->nlevels && bt >= g->lv[l + 1].btile_begin) l++;
+#pragma unroll
+  for (int i = 1; i < kMaxLevels; i++) l += bt >= g->btile_begin_all[i] ? 1 : 0;  // one scalar load, no dependent chain
   const DeviceLevel& lv = g->lv[l];
   const int tile = bt - lv.btile_begin;
   const int ty = fast_div(tile, lv.m_btiles_x), tx = tile - ty * lv.btiles_x;
