@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <new>
 
 #include "orbx_internal.h"
@@ -179,8 +180,18 @@ static int build_geometry(orbx_ctx* ctx, int rows, int cols, Geometry& geo) {
 static void free_buffers(orbx_ctx* ctx) {
   auto fr = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
   fr(ctx->d_geo); fr(ctx->d_cells); fr(ctx->d_xtab); fr(ctx->d_ytab);
-  fr(ctx->d_pyr); fr(ctx->d_blur); fr(ctx->d_cand); fr(ctx->d_cell_cnt); fr(ctx->d_pts); fr(ctx->d_lvl_kp); fr(ctx->d_lvl_n); fr(ctx->d_kp_list);
+  fr(ctx->d_pyr); fr(ctx->d_blur); fr(ctx->d_cand); fr(ctx->d_cell_cnt); fr(ctx->d_pts); fr(ctx->d_lvl_kp); fr(ctx->d_lvl_n); fr(ctx->d_kp_list); fr(ctx->d_qt_nodes);
   ctx->batch_cap = 0;
+}
+
+// LDS bytes of one quadtree workgroup over levels with at most `mq` quota and `mc` cells (see k_quadtree's carve-up)
+constexpr size_t kLdsMax = 160 * 1024;   // one workgroup may use the whole LDS of a CU, not more
+static void qt_caps(int mq, int mc, int& node_cap, int& scan_cap) {
+  node_cap = round_up(mq + 4 * kMaxRoots + 8, 4);
+  scan_cap = round_up(std::max(node_cap, mc) + 8, 4);
+}
+static size_t qt_node_bytes(int node_cap, int scan_cap) {
+  return (size_t)node_cap * (2 * sizeof(QNode) + 2 * 8 + sizeof(int4) + 4) + (size_t)scan_cap * 8;
 }
 
 static int ensure_buffers(orbx_ctx* ctx, int rows, int cols, int nframes) {
@@ -229,6 +240,18 @@ static int ensure_buffers(orbx_ctx* ctx, int rows, int cols, int nframes) {
   ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_lvl_kp, B * geo.kp_total * sizeof(uint32_t)));
   ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_lvl_n, B * geo.nlevels * sizeof(int32_t)));
   ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_kp_list, B * ctx->out_cap * sizeof(uint2)));
+  // levels whose node arrays do not fit the LDS even with the points in HBM get an HBM slice per (level, frame)
+  ctx->qt_node_stride = 0; ctx->qt_node_slots = 0;
+  for (int l = 0; l < geo.nlevels; l++) {
+    int nc, sc;
+    qt_caps(geo.lv[l].quota, geo.lv[l].ncells, nc, sc);
+    ctx->qt_node_slot[l] = -1;
+    if (qt_node_bytes(nc, sc) > kLdsMax) {
+      ctx->qt_node_slot[l] = ctx->qt_node_slots++;
+      ctx->qt_node_stride = std::max(ctx->qt_node_stride, (size_t)round_up((int)qt_node_bytes(nc, sc), 256));
+    }
+  }
+  if (ctx->qt_node_slots) ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_qt_nodes, B * ctx->qt_node_slots * ctx->qt_node_stride));
   ctx->batch_cap = nframes;
   return ORBX_OK;
 }
@@ -372,16 +395,27 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
     // levels halve the residency of the small ones, so the levels run as two launches: the first kQtBigLevels levels
     // (large quota, LDS points for 2048 candidates) and the rest (small node arrays, 1024 LDS points), the second one
     // forked onto an aux stream so both fill the CUs together.  Candidates beyond the LDS capacity use HBM buffers.
-    auto launch_qt = [&](int l0, int l1, int pts_cap, hipStream_t s) -> int {
+    std::function<int(int, int, int, hipStream_t)> launch_qt = [&](int l0, int l1, int pts_cap, hipStream_t s) -> int {
       int mq = 1, mc = 1;
       for (int l = l0; l < l1; l++) { mq = std::max(mq, geo.lv[l].quota); mc = std::max(mc, geo.lv[l].ncells); }
-      const int node_cap = round_up(mq + 4 * kMaxRoots + 8, 4);
-      const int scan_cap = round_up(std::max(node_cap, mc) + 8, 4);
-      if (node_cap > 4095) return set_err(ctx, ORBX_E_CAPACITY, "nfeatures too large for the quadtree kernel");
-      const size_t lds = (size_t)node_cap * (2 * sizeof(QNode) + 2 * 8 + sizeof(int4) + 4) + (size_t)scan_cap * 8 +
-                         (size_t)pts_cap * 2 * sizeof(uint32_t);
-      if (lds > 160 * 1024)  // one workgroup may use the whole 160 KiB LDS of a CU, not more
-        return set_err(ctx, ORBX_E_CAPACITY, "nfeatures too large for the quadtree kernel's LDS (a level quota above ~2300)");
+      int node_cap, scan_cap;
+      qt_caps(mq, mc, node_cap, scan_cap);
+      if (node_cap > 4095) return set_err(ctx, ORBX_E_CAPACITY, "nfeatures too large for the quadtree kernel (a level quota above ~4000)");
+      size_t lds = qt_node_bytes(node_cap, scan_cap) + (size_t)pts_cap * 2 * sizeof(uint32_t);
+      uint8_t* gnodes = nullptr;
+      if (lds > kLdsMax) {
+        if (l1 - l0 > 1) {   // let every level of the group choose for itself
+          for (int l = l0; l < l1; l++) { const int rc = launch_qt(l, l + 1, pts_cap, s); if (rc != ORBX_OK) return rc; }
+          return ORBX_OK;
+        }
+        pts_cap = 0;         // points in HBM
+        lds = qt_node_bytes(node_cap, scan_cap);
+        if (lds > kLdsMax) {  // node arrays in HBM too (slow, but the level is served)
+          if (ctx->qt_node_slot[l0] < 0 || !ctx->d_qt_nodes) return set_err(ctx, ORBX_E_CAPACITY, "quadtree node scratch missing");
+          gnodes = ctx->d_qt_nodes + ((size_t)ctx->qt_node_slot[l0] * ctx->batch_cap + f0) * ctx->qt_node_stride;
+          lds = 0;
+        }
+      }
       if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
@@ -392,7 +426,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
       // small batches are latency-bound on the big levels' workgroups: more waves split more nodes at a time
       const int qthreads = (nframes * geo.nlevels <= 512) ? 512 : 256;
       hipLaunchKernelGGL(k_quadtree, dim3(l1 - l0, nframes, 1), dim3(qthreads), lds, s, ctx->d_geo, ctx->d_cells, b_cand, b_cell_cnt,
-                         b_pts, b_lvl_kp, b_lvl_n, node_cap, scan_cap, pts_cap, l0);
+                         b_pts, b_lvl_kp, b_lvl_n, node_cap, scan_cap, pts_cap, l0, gnodes, (long long)ctx->qt_node_stride);
       return ORBX_OK;
     };
     const int nbig = (geo.nlevels >= 4 && !small_batch) ? kQtBigLevels : geo.nlevels;  // small batch: one launch, all levels

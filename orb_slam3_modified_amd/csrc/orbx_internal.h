@@ -162,6 +162,8 @@ struct orbx_ctx {
   uint32_t* d_cand = nullptr;      // [batch][cand_total]
   int32_t* d_cell_cnt = nullptr;   // [batch][ncells]
   uint32_t* d_pts = nullptr;       // [batch][2][cand_total]  quadtree ping-pong
+  uint8_t* d_qt_nodes = nullptr;   // node arrays of the levels whose quota does not fit the LDS: [level slot][batch][qt_node_stride]
+  size_t qt_node_stride = 0; int qt_node_slot[orbx::kMaxLevels] = {0}; int qt_node_slots = 0;
   uint32_t* d_lvl_kp = nullptr;    // [batch][kp_total]
   int32_t* d_lvl_n = nullptr;      // [batch][nlevels]
   uint2* d_kp_list = nullptr;      // [batch][out_cap] {packed point, level | output slot << 8}, level-major order

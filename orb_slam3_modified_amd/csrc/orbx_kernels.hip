@@ -835,17 +835,17 @@ __device__ __forceinline__ void quadtree_body(const DeviceGeom* __restrict__ g, 
   QT_ACC(4);
 }
 
-__global__ __launch_bounds__(512) void k_quadtree(const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
-                                                  const uint32_t* __restrict__ cand, const int32_t* __restrict__ cell_cnt,
-                                                  uint32_t* __restrict__ pts, uint32_t* __restrict__ lvl_kp,
-                                                  int32_t* __restrict__ lvl_n, int node_cap, int scan_cap, int pts_cap, int level_base) {
-  extern __shared__ __align__(16) uint8_t smem[];
-  __shared__ unsigned long long wt[8];
-  __shared__ int sh_cnt[kMaxRoots];
-  __shared__ int sh_jstar;
-  // LDS carve-up (see quadtree_body): LA, LB, EA, EB, scan, kids, flag, then the two LDS point buffers
-  unsigned long long* scan = (unsigned long long*)(smem + (size_t)node_cap * (2 * sizeof(QNode) + 2 * 8));
-  uint32_t* lpts = (uint32_t*)(smem + (size_t)node_cap * (2 * sizeof(QNode) + 2 * 8 + sizeof(int4) + 4) + (size_t)scan_cap * 8);
+// The part of k_quadtree that touches the node arrays, instantiated once with the arrays in LDS (`nb` = the dynamic LDS
+// block) and once with them in HBM (`nb` = this workgroup's slice of the context's node scratch): levels whose quota
+// does not fit one CU's LDS (mpIniORBextractor of a 2000-feature configuration: 10 000 features, level-0 quota 2172)
+// take the slow HBM instantiation instead of being refused.
+template <bool GN>
+__device__ __forceinline__ void quadtree_main(const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
+                                              const uint32_t* __restrict__ cand, const int32_t* __restrict__ cell_cnt,
+                                              uint32_t* __restrict__ pts, uint32_t* __restrict__ lvl_kp, int32_t* __restrict__ lvl_n,
+                                              int node_cap, int scan_cap, int pts_cap, int level_base, uint8_t* nb, uint32_t* lpts,
+                                              unsigned long long* wt, int* sh_cnt, int* sh_jstar) {
+  unsigned long long* scan = (unsigned long long*)(nb + (size_t)node_cap * (2 * sizeof(QNode) + 2 * 8));
   const int T = blockDim.x, t = threadIdx.x;
   const int level = level_base + blockIdx.x, frame = blockIdx.y;
   const DeviceLevel& lv = g->lv[level];
@@ -860,10 +860,29 @@ __global__ __launch_bounds__(512) void k_quadtree(const DeviceGeom* __restrict__
     if (t == 0) lvl_n[frame * g->nlevels + level] = 0;
     return;
   }
-  if (n <= pts_cap)
-    quadtree_body<true>(g, cells, fcand, gcur, gnxt, lpts, lpts + pts_cap, lvl_kp, lvl_n, node_cap, scan_cap, smem, n, wt, sh_cnt, &sh_jstar, level_base);
+  if (!GN && n <= pts_cap)
+    quadtree_body<true>(g, cells, fcand, gcur, gnxt, lpts, lpts + pts_cap, lvl_kp, lvl_n, node_cap, scan_cap, nb, n, wt, sh_cnt, sh_jstar, level_base);
   else
-    quadtree_body<false>(g, cells, fcand, gcur, gnxt, lpts, lpts + pts_cap, lvl_kp, lvl_n, node_cap, scan_cap, smem, n, wt, sh_cnt, &sh_jstar, level_base);
+    quadtree_body<false>(g, cells, fcand, gcur, gnxt, lpts, lpts + pts_cap, lvl_kp, lvl_n, node_cap, scan_cap, nb, n, wt, sh_cnt, sh_jstar, level_base);
+}
+
+__global__ __launch_bounds__(512) void k_quadtree(const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
+                                                  const uint32_t* __restrict__ cand, const int32_t* __restrict__ cell_cnt,
+                                                  uint32_t* __restrict__ pts, uint32_t* __restrict__ lvl_kp,
+                                                  int32_t* __restrict__ lvl_n, int node_cap, int scan_cap, int pts_cap, int level_base,
+                                                  uint8_t* __restrict__ gnodes, long long gnode_stride) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  __shared__ unsigned long long wt[8];
+  __shared__ int sh_cnt[kMaxRoots];
+  __shared__ int sh_jstar;
+  // LDS carve-up (see quadtree_body): LA, LB, EA, EB, scan, kids, flag, then the two LDS point buffers
+  if (gnodes == nullptr) {  // block-uniform (kernel argument)
+    uint32_t* lpts = (uint32_t*)(smem + (size_t)node_cap * (2 * sizeof(QNode) + 2 * 8 + sizeof(int4) + 4) + (size_t)scan_cap * 8);
+    quadtree_main<false>(g, cells, cand, cell_cnt, pts, lvl_kp, lvl_n, node_cap, scan_cap, pts_cap, level_base, smem, lpts, wt, sh_cnt, &sh_jstar);
+  } else {
+    uint8_t* nb = gnodes + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * gnode_stride;
+    quadtree_main<true>(g, cells, cand, cell_cnt, pts, lvl_kp, lvl_n, node_cap, scan_cap, 0, level_base, nb, (uint32_t*)nullptr, wt, sh_cnt, &sh_jstar);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

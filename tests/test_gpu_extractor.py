@@ -334,3 +334,25 @@ def test_two_extractors_from_two_threads_like_stereo():
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errors, errors[:5]
+
+
+@pytest.mark.parametrize("nf,sf,nlev,rows,cols,kind", [(10000, 1.2, 8, 376, 1241, "noise"),      # KITTI: mpIniORBextractor = 5 x 2000
+                                                       (6000, 1.33, 3, 327, 454, "synth"),
+                                                       (6000, 1.5, 2, 480, 640, "noise")])
+def test_level_quotas_beyond_the_lds_are_served_from_hbm(nf, sf, nlev, rows, cols, kind):
+    """Quadtree node arrays of a level live in one CU's LDS; a quota that does not fit (above ~2100) falls back to HBM node
+    arrays — slower, same results (src/ORBextractor.cc:555-779 has no such limit)."""
+    rng = np.random.default_rng(nf)
+    img = rng.integers(0, 256, (rows, cols)).astype(np.uint8) if kind == "noise" else synth.make_stream(1, rows, cols, 99)[0]
+    gpu = ORBextractor(nf, sf, nlev, 20, 7)
+    ora = po.OracleExtractor(nf, sf, nlev, 20, 7)
+    assert ora.tables()["quota"].max() > 2150
+    mono, kps, desc = gpu(img, None, (0, 0))
+    okps, odesc, omono = ora.extract(img, (0, 0))
+    assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc)
+    assert len(kps) > (2500 if kind == "noise" else 500)
+    # and as a device batch (sub-batch offsets of the HBM node scratch)
+    res = gpu.extract_batch(np.stack([img, img[::-1].copy(), img]), (0, 0))
+    assert res[0][1].tobytes() == okps.tobytes() and res[2][1].tobytes() == okps.tobytes()
+    o2 = ora.extract(img[::-1].copy(), (0, 0))
+    assert res[1][1].tobytes() == o2[0].tobytes() and np.array_equal(res[1][2], o2[1])

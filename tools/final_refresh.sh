@@ -1,0 +1,23 @@
+#!/bin/bash
+# End-of-round evidence refresh on the GPU box: everything lands in gpurun_out/ (merged back), then copied into profiles/.
+# usage (from the repo root on the box): bash tools/final_refresh.sh r1h
+TAG=${1:-r1x}
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 600 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu_$TAG.log 2>&1; tail -2 gpurun_out/pytest_gpu_$TAG.log
+# HBM traffic (separate FETCH_SIZE / WRITE_SIZE passes) and issue-side counters, full-batch launches
+timeout 600 python tools/pmc_traffic.py > /dev/null 2>&1 && cp gpurun_out/pmc_traffic.json profiles/pmc_traffic.json
+timeout 900 python tools/pmc_sq.py "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS" \
+   "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT TA_BUSY_avr" > /dev/null 2>&1
+[ -f gpurun_out/pmc_sq.json ] && cp gpurun_out/pmc_sq.json profiles/pmc_sq.json
+# the bench line (reads profiles/pmc_*.json refreshed above)
+python bench.py 2> gpurun_out/bench_$TAG.err | tail -1 > gpurun_out/bench_$TAG.json; cat gpurun_out/bench_$TAG.json | cut -c1-400
+# kernel trace of the same command (without the CPU leg)
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$TAG -o $TAG -- python bench.py --no-cpu-baseline > gpurun_out/prof_$TAG.log 2>&1
+DB=$(ls gpurun_out/prof_$TAG/*/${TAG}_results.db gpurun_out/prof_$TAG/${TAG}_results.db 2>/dev/null | head -1)
+{ python tools/rocpd_summary.py "$DB" --title "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline ($TAG): all launches";
+  echo; python tools/rocpd_summary.py "$DB" --by-grid --title "the same run, one row per launch shape (timed region: 2 lanes x 128 frames, overlapping; roofline passes: 256 frames, back to back)"; } > gpurun_out/${TAG}_kernel_stats.md
+head -12 gpurun_out/${TAG}_kernel_stats.md
+rm -rf gpurun_out/prof_$TAG/*/*.db gpurun_out/prof_$TAG/*.db   # keep the merge-back small
+timeout 300 python tools/bench_aux.py > /dev/null 2>&1; ls -la gpurun_out/bench_aux.json
+timeout 400 python tools/fuzz_extractor.py 400 150 2>&1 | tail -3 | tee gpurun_out/fuzz_$TAG.log
