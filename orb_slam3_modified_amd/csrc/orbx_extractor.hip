@@ -180,14 +180,17 @@ static int build_geometry(orbx_ctx* ctx, int rows, int cols, Geometry& geo) {
 static void free_buffers(orbx_ctx* ctx) {
   auto fr = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
   fr(ctx->d_geo); fr(ctx->d_cells); fr(ctx->d_xtab); fr(ctx->d_ytab);
-  fr(ctx->d_pyr); fr(ctx->d_blur); fr(ctx->d_cand); fr(ctx->d_cell_cnt); fr(ctx->d_pts); fr(ctx->d_lvl_kp); fr(ctx->d_lvl_n); fr(ctx->d_kp_list); fr(ctx->d_qt_nodes);
+  fr(ctx->d_pyr); fr(ctx->d_blur); fr(ctx->d_cand); fr(ctx->d_cell_cnt); fr(ctx->d_pts); fr(ctx->d_lvl_kp); fr(ctx->d_lvl_n); fr(ctx->d_kp_list); fr(ctx->d_qt_nodes); fr(ctx->d_asm_scan);
   ctx->batch_cap = 0;
 }
 
 // LDS bytes of one quadtree workgroup over levels with at most `mq` quota and `mc` cells (see k_quadtree's carve-up)
 constexpr size_t kLdsMax = 160 * 1024;   // one workgroup may use the whole LDS of a CU, not more
-static void qt_caps(int mq, int mc, int& node_cap, int& scan_cap) {
-  node_cap = round_up(mq + 4 * kMaxRoots + 8, 4);
+constexpr int kQtMaxNodes = 65532;        // 16-bit positions in the exact sort
+// mq: largest quota, mc: most cells, mp: most candidate slots of the levels served (a node keeps >= 1 point, so the list is
+// never longer than the candidates either)
+static void qt_caps(int mq, int mc, int mp, int& node_cap, int& scan_cap) {
+  node_cap = std::min(round_up(std::min(mq, mp) + 4 * kMaxRoots + 8, 4), kQtMaxNodes);
   scan_cap = round_up(std::max(node_cap, mc) + 8, 4);
 }
 static size_t qt_node_bytes(int node_cap, int scan_cap) {
@@ -244,7 +247,7 @@ static int ensure_buffers(orbx_ctx* ctx, int rows, int cols, int nframes) {
   ctx->qt_node_stride = 0; ctx->qt_node_slots = 0;
   for (int l = 0; l < geo.nlevels; l++) {
     int nc, sc;
-    qt_caps(geo.lv[l].quota, geo.lv[l].ncells, nc, sc);
+    qt_caps(geo.lv[l].quota, geo.lv[l].ncells, geo.lv[l].cand_cap, nc, sc);
     ctx->qt_node_slot[l] = -1;
     if (qt_node_bytes(nc, sc) > kLdsMax) {
       ctx->qt_node_slot[l] = ctx->qt_node_slots++;
@@ -252,6 +255,7 @@ static int ensure_buffers(orbx_ctx* ctx, int rows, int cols, int nframes) {
     }
   }
   if (ctx->qt_node_slots) ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_qt_nodes, B * ctx->qt_node_slots * ctx->qt_node_stride));
+  if ((size_t)ctx->out_cap * 8 + 64 > kLdsMax) ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_asm_scan, B * (size_t)ctx->out_cap * 8));
   ctx->batch_cap = nframes;
   return ORBX_OK;
 }
@@ -396,11 +400,12 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
     // (large quota, LDS points for 2048 candidates) and the rest (small node arrays, 1024 LDS points), the second one
     // forked onto an aux stream so both fill the CUs together.  Candidates beyond the LDS capacity use HBM buffers.
     std::function<int(int, int, int, hipStream_t)> launch_qt = [&](int l0, int l1, int pts_cap, hipStream_t s) -> int {
-      int mq = 1, mc = 1;
-      for (int l = l0; l < l1; l++) { mq = std::max(mq, geo.lv[l].quota); mc = std::max(mc, geo.lv[l].ncells); }
+      int mq = 1, mc = 1, mp = 1;
+      for (int l = l0; l < l1; l++) {
+        mq = std::max(mq, geo.lv[l].quota); mc = std::max(mc, geo.lv[l].ncells); mp = std::max(mp, geo.lv[l].cand_cap);
+      }
       int node_cap, scan_cap;
-      qt_caps(mq, mc, node_cap, scan_cap);
-      if (node_cap > 4095) return set_err(ctx, ORBX_E_CAPACITY, "nfeatures too large for the quadtree kernel (a level quota above ~4000)");
+      qt_caps(mq, mc, mp, node_cap, scan_cap);   // beyond 65 532 nodes the kernel refuses at run time (never seen: that many corners on one level)
       size_t lds = qt_node_bytes(node_cap, scan_cap) + (size_t)pts_cap * 2 * sizeof(uint32_t);
       uint8_t* gnodes = nullptr;
       if (lds > kLdsMax) {
@@ -450,8 +455,9 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
   // K3b: output slots
   {
     ProfScope ps(ctx, 3, st);
-    hipLaunchKernelGGL(k_assemble, dim3(nframes), dim3(256), (size_t)ctx->out_cap * 8 + 64, st, ctx->d_geo, b_lvl_kp,
-                       b_lvl_n, b_kp_list, d_counts, lap0, lap1);
+    const bool gs = ctx->d_asm_scan != nullptr;
+    hipLaunchKernelGGL(k_assemble, dim3(nframes), dim3(256), gs ? 0 : (size_t)ctx->out_cap * 8 + 64, st, ctx->d_geo, b_lvl_kp,
+                       b_lvl_n, b_kp_list, d_counts, lap0, lap1, gs ? ctx->d_asm_scan + (size_t)f0 * ctx->out_cap : nullptr);
   }
   // K4b: orientation + descriptors
   if (fork_blur) ORBX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_blur_join[f0 != 0], 0));

@@ -164,6 +164,7 @@ struct orbx_ctx {
   uint32_t* d_pts = nullptr;       // [batch][2][cand_total]  quadtree ping-pong
   uint8_t* d_qt_nodes = nullptr;   // node arrays of the levels whose quota does not fit the LDS: [level slot][batch][qt_node_stride]
   size_t qt_node_stride = 0; int qt_node_slot[orbx::kMaxLevels] = {0}; int qt_node_slots = 0;
+  unsigned long long* d_asm_scan = nullptr;   // k_assemble's scan array when capacity * 8 B does not fit the LDS: [batch][out_cap]
   uint32_t* d_lvl_kp = nullptr;    // [batch][kp_total]
   int32_t* d_lvl_n = nullptr;      // [batch][nlevels]
   uint2* d_kp_list = nullptr;      // [batch][out_cap] {packed point, level | output slot << 8}, level-major order

@@ -424,7 +424,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 // One wave: the closed form of libstdc++'s Hoare partition step on v[first, last) with the pivot already moved to
 // v[first] (gnu_sort.h: partition_closed_form is the sequential statement).  ia / ir: per-wave LDS index scratch.
-__device__ __forceinline__ int wave_partition(unsigned long long* v, int first, int last, int16_t* ia, int16_t* ir) {
+__device__ __forceinline__ int wave_partition(unsigned long long* v, int first, int last, uint16_t* ia, uint16_t* ir) {
   const int lane = threadIdx.x & 63;
   const unsigned long long lt = (1ull << lane) - 1ull;
   const uint32_t kp = (uint32_t)(v[first] >> 32);
@@ -435,8 +435,8 @@ __device__ __forceinline__ int wave_partition(unsigned long long* v, int first, 
     const uint32_t k = valid ? (uint32_t)(v[i] >> 32) : 0u;
     const bool isL = valid && k >= kp, isR = valid && k <= kp;
     const unsigned long long bL = __ballot(isL), bR = __ballot(isR);
-    if (isL) ia[nL + __popcll(bL & lt)] = (int16_t)i;
-    if (isR) ir[nR + __popcll(bR & lt)] = (int16_t)i;
+    if (isL) ia[nL + __popcll(bL & lt)] = (uint16_t)i;
+    if (isR) ir[nR + __popcll(bR & lt)] = (uint16_t)i;
     nL += __popcll(bL);
     nR += __popcll(bR);
   }
@@ -467,22 +467,22 @@ __device__ __forceinline__ int wave_partition(unsigned long long* v, int first, 
 
 // std::sort(v, v + n) with the reference's (count, UL.x) comparator, exact libstdc++ permutation (ties included),
 // by the whole workgroup: level-synchronous introsort loop (one wave per pending segment and round), then a stable
-// rank inside every final segment (== __final_insertion_sort).  tmp: n elements; seg: n words; q0/q1: n/8+2 words each;
-// idx: 2 * n int16.  All in LDS.  Ends with a barrier.
+// rank inside every final segment (== __final_insertion_sort).  tmp: n elements; seg: n words; q0/q1: n/16+2 entries each;
+// idx: 2 * n uint16 (n < 65536).  In the workgroup's node scratch (LDS, or HBM for huge levels).  Ends with a barrier.
 __device__ __forceinline__ void block_gnu_sort(unsigned long long* v, int n, unsigned long long* tmp, uint32_t* seg,
-                                               uint32_t* q0, uint32_t* q1, int16_t* idx, int* sh_cnt) {
+                                               unsigned long long* q0, unsigned long long* q1, uint16_t* idx, int* sh_cnt) {
   const int T = blockDim.x, t = threadIdx.x, lane = t & 63, w = t >> 6, NW = T >> 6;
   for (int i = t; i < n; i += T) seg[i] = (uint32_t)n << 16;  // lo = 0, hi = n
   if (n > 16) {
-    if (t == 0) { q0[0] = (uint32_t)n << 12 | (uint32_t)(2 * (31 - __clz(n))) << 24; *sh_cnt = 0; }
+    if (t == 0) { q0[0] = (unsigned long long)n << 16 | (unsigned long long)(2 * (31 - __clz(n))) << 32; *sh_cnt = 0; }  // first | last << 16 | depth << 32
     __syncthreads();
     int ncur = 1;
-    int16_t* ia = idx;       // segments of one round are disjoint: every wave indexes the shared scratch by position
-    int16_t* ir = idx + n;
+    uint16_t* ia = idx;      // segments of one round are disjoint: every wave indexes the shared scratch by position
+    uint16_t* ir = idx + n;
     while (ncur > 0) {
       for (int sidx = w; sidx < ncur; sidx += NW) {
-        const uint32_t pk = q0[sidx];
-        const int f = (int)(pk & 0xfffu), l = (int)((pk >> 12) & 0xfffu), d = (int)(pk >> 24);
+        const unsigned long long pk = q0[sidx];
+        const int f = (int)(pk & 0xffffull), l = (int)((pk >> 16) & 0xffffull), d = (int)(pk >> 32);
         if (d == 0) {  // depth limit: heapsort fallback (practically never), result already in final order
           if (lane == 0) orbx_sort::heap_sort(v, f, l);
           for (int i = f + lane; i < l; i += 64) seg[i] = (uint32_t)i | (uint32_t)(i + 1) << 16;
@@ -495,7 +495,7 @@ __device__ __forceinline__ void block_gnu_sort(unsigned long long* v, int n, uns
         for (int c = 0; c < 2; c++) {
           const int cf = c ? cut : f, cl = c ? l : cut;
           if (cl - cf > 16) {
-            if (lane == 0) q1[atomicAdd(sh_cnt, 1)] = (uint32_t)cf | (uint32_t)cl << 12 | (uint32_t)(d - 1) << 24;
+            if (lane == 0) q1[atomicAdd(sh_cnt, 1)] = (unsigned long long)cf | (unsigned long long)cl << 16 | (unsigned long long)(d - 1) << 32;
           } else {
             for (int i = cf + lane; i < cl; i += 64) seg[i] = (uint32_t)cf | (uint32_t)cl << 16;
           }
@@ -505,7 +505,7 @@ __device__ __forceinline__ void block_gnu_sort(unsigned long long* v, int n, uns
       ncur = *sh_cnt;
       __syncthreads();
       if (t == 0) *sh_cnt = 0;
-      { uint32_t* tq = q0; q0 = q1; q1 = tq; }
+      { unsigned long long* tq = q0; q0 = q1; q1 = tq; }
       __syncthreads();
     }
   }
@@ -606,6 +606,13 @@ __device__ __forceinline__ void quadtree_body(const DeviceGeom* __restrict__ g, 
   const int level = level_base + blockIdx.x, frame = blockIdx.y;
   const DeviceLevel& lv = g->lv[level];
   const int N = lv.quota;
+  // node arrays hold node_cap entries; the list never grows beyond min(N + 3, n) nodes (it stops at N, and every node
+  // keeps at least one point).  The host may have clamped node_cap (16-bit positions in the sort): refuse, loudly, what
+  // does not fit (negative count -> ORBX_E_CAPACITY)
+  if (min(N + 4 * kMaxRoots + 8, n + 4 * kMaxRoots + 8) > node_cap) {  // block-uniform
+    if (t == 0) lvl_n[frame * g->nlevels + level] = -max(n, 1);
+    return;
+  }
   QT_T0();
   // ---- gather the per-cell lists in cell order (vToDistributeKeys, src/ORBextractor.cc:863-868): `scan` holds the
   // exclusive prefix of the cell counts (computed by the kernel); element e finds its cell by binary search
@@ -735,7 +742,7 @@ __device__ __forceinline__ void quadtree_body(const DeviceGeom* __restrict__ g, 
       // ======== sorted expansion (src/ORBextractor.cc:692-753)
       const int prevSize = nL;
       const int m = nE;
-      block_gnu_sort(EA, m, EB, (uint32_t*)flag, (uint32_t*)scan, (uint32_t*)scan + (scan_cap & ~1), (int16_t*)kids, sh_cnt);
+      block_gnu_sort(EA, m, EB, (uint32_t*)flag, scan, scan + (scan_cap >> 1), (uint16_t*)kids, sh_cnt);
       QT_ACC(2);
       for (int j = w; j < m; j += NW) {
         const int4 c = wave_split(LA[(uint32_t)EA[j]], cur, nxt, false);
@@ -888,15 +895,12 @@ __global__ __launch_bounds__(512) void k_quadtree(const DeviceGeom* __restrict__
 // ------------------------------------------------------------------------------------------------
 // K3b: output slots (src/ORBextractor.cc:1122,1143-1164)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_assemble(const DeviceGeom* __restrict__ g, const uint32_t* __restrict__ lvl_kp,
-                                                  const int32_t* __restrict__ lvl_n, uint2* __restrict__ kp_list,
-                                                  int32_t* __restrict__ counts, int lap0, int lap1) {
-  extern __shared__ __align__(16) uint8_t smem[];
-  unsigned long long* scan = (unsigned long long*)smem;
-  __shared__ unsigned long long wt[8];
-  __shared__ int loff[kMaxLevels + 1];
+template <bool GS>
+__device__ __forceinline__ void assemble_main(const DeviceGeom* __restrict__ g, const uint32_t* __restrict__ lvl_kp,
+                                              const int32_t* __restrict__ lvl_n, uint2* __restrict__ kp_list,
+                                              int32_t* __restrict__ counts, int lap0, int lap1, unsigned long long* scan,
+                                              unsigned long long* wt, int* loff, int* s_overflow) {
   const int t = threadIdx.x, T = blockDim.x, frame = blockIdx.x;
-  __shared__ int s_overflow;
   if (t == 0) {
     int acc = 0, ovf = 0;
     for (int l = 0; l < g->nlevels; l++) {
@@ -906,7 +910,7 @@ __global__ __launch_bounds__(256) void k_assemble(const DeviceGeom* __restrict__
       acc += max(nl, 0);
     }
     loff[g->nlevels] = acc;
-    s_overflow = ovf;
+    *s_overflow = ovf;
   }
   __syncthreads();
   const int total = min(loff[g->nlevels], g->out_cap);
@@ -932,7 +936,20 @@ __global__ __launch_bounds__(256) void k_assemble(const DeviceGeom* __restrict__
     const int slot = st ? total - 1 - pre : i - pre;
     kp_list[(long long)frame * g->out_cap + i] = make_uint2(p, (uint32_t)l | ((uint32_t)slot << 8));
   }
-  if (t == 0) { counts[frame * 2] = s_overflow ? -1 : total; counts[frame * 2 + 1] = total - nst; }
+  if (t == 0) { counts[frame * 2] = *s_overflow ? -1 : total; counts[frame * 2 + 1] = total - nst; }
+}
+
+// gscan: per-frame scan scratch in HBM for capacities whose scan array does not fit the LDS (nullptr: LDS)
+__global__ __launch_bounds__(256) void k_assemble(const DeviceGeom* __restrict__ g, const uint32_t* __restrict__ lvl_kp,
+                                                  const int32_t* __restrict__ lvl_n, uint2* __restrict__ kp_list,
+                                                  int32_t* __restrict__ counts, int lap0, int lap1,
+                                                  unsigned long long* __restrict__ gscan) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  __shared__ unsigned long long wt[8];
+  __shared__ int loff[kMaxLevels + 1];
+  __shared__ int s_overflow;
+  if (gscan == nullptr) assemble_main<false>(g, lvl_kp, lvl_n, kp_list, counts, lap0, lap1, (unsigned long long*)smem, wt, loff, &s_overflow);
+  else assemble_main<true>(g, lvl_kp, lvl_n, kp_list, counts, lap0, lap1, gscan + (long long)blockIdx.x * g->out_cap, wt, loff, &s_overflow);
 }
 
 // ------------------------------------------------------------------------------------------------

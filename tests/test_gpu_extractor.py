@@ -338,7 +338,10 @@ def test_two_extractors_from_two_threads_like_stereo():
 
 @pytest.mark.parametrize("nf,sf,nlev,rows,cols,kind", [(10000, 1.2, 8, 376, 1241, "noise"),      # KITTI: mpIniORBextractor = 5 x 2000
                                                        (6000, 1.33, 3, 327, 454, "synth"),
-                                                       (6000, 1.5, 2, 480, 640, "noise")])
+                                                       (6000, 1.5, 2, 480, 640, "noise"),
+                                                       (20000, 1.2, 1, 800, 600, "noise"),       # the fork's own Examples/Monocular/mi.yaml
+                                                       (20000, 1.2, 1, 800, 600, "synth"),
+                                                       (100000, 1.2, 1, 800, 600, "noise")])     # ... and its 5x initialisation extractor
 def test_level_quotas_beyond_the_lds_are_served_from_hbm(nf, sf, nlev, rows, cols, kind):
     """Quadtree node arrays of a level live in one CU's LDS; a quota that does not fit (above ~2100) falls back to HBM node
     arrays — slower, same results (src/ORBextractor.cc:555-779 has no such limit)."""
@@ -351,6 +354,8 @@ def test_level_quotas_beyond_the_lds_are_served_from_hbm(nf, sf, nlev, rows, col
     okps, odesc, omono = ora.extract(img, (0, 0))
     assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc)
     assert len(kps) > (2500 if kind == "noise" else 500)
+    if nf >= 20000:
+        return
     # and as a device batch (sub-batch offsets of the HBM node scratch)
     res = gpu.extract_batch(np.stack([img, img[::-1].copy(), img]), (0, 0))
     assert res[0][1].tobytes() == okps.tobytes() and res[2][1].tobytes() == okps.tobytes()

@@ -112,6 +112,18 @@ for _ in range(20): nmp_, _m = _sbp()
 res["search_by_projection_mappoints"] = {"map_points": len(ka), "keypoints": len(Fp.mvKeysUn), "matches": int(nmp_),
                                          "ms_per_call": (time.perf_counter() - t0) / 20 * 1e3,
                                          "note": "host buffers; one device pass (grid, windows, gates, distances), greedy replay on the host"}
+# the fork's own configuration (Examples/Monocular/mi.yaml): 600x800, 20 000 features on one level -> quadtree nodes in HBM
+try:
+    exm = ORBextractor(20000, 1.2, 1, 20, 7)
+    imm = synth.make_stream(1, 800, 600, synth.DEFAULT_SEED + 77)[0]
+    for _ in range(3): rm = exm(imm, None, (0, 0))
+    t0 = time.perf_counter()
+    for _ in range(20): rm = exm(imm, None, (0, 0))
+    res["mi_yaml_single_level_20000"] = {"shape": [800, 600], "features": int(len(rm[1])), "ms_per_frame": (time.perf_counter() - t0) / 20 * 1e3,
+                                         "note": "level quota 20 000: quadtree node arrays and the assemble scan in HBM (slow path)"}
+    exm.close()
+except Exception as e:   # noqa: BLE001
+    res["mi_yaml_single_level_20000"] = {"error": repr(e)}
 # KeyFrameDatabase: 2000 keyframes x ~800 words resident in HBM, one place-recognition query
 from orb_slam3_modified_amd import KeyFrameDatabase
 rngk = np.random.default_rng(9)
