@@ -182,7 +182,7 @@ int orbx_knn2_allpairs_device(orbx_ctx* ctx, const uint8_t* d_q, int nq, const u
  * is built once, then query q = (x, y, r, minLevel, maxLevel) returns the keypoint indices the reference returns, in
  * the reference's order (cells x-major, then y, then insertion order — that order decides ties in the searches).
  * CSR output: row_ptr [nq + 1], cand [cand_cap].  Returns the number of candidates (>= 0) or a negative error
- * (ORBX_E_CAPACITY if cand_cap is too small; at most 8192 keypoints).  Host pointers. */
+ * (ORBX_E_CAPACITY if cand_cap is too small; at most 32 768 keypoints).  Host pointers. */
 int orbx_features_in_area(orbx_ctx* ctx, const orbx_keypoint* kps, int n, float min_x, float min_y, float max_x, float max_y,
                           const float* qx, const float* qy, const float* qr, const int32_t* qmin_level, const int32_t* qmax_level,
                           int nq, int32_t* row_ptr, int32_t* cand, int cand_cap);

@@ -15,7 +15,7 @@
 namespace orbx {
 
 constexpr int kGridCols = 64, kGridRows = 48, kGridCells = kGridCols * kGridRows;  // include/Frame.h:44-45
-constexpr int kGridMaxPts = 8192;
+constexpr int kGridMaxPts = 32768;   // keys of the LDS bitonic sort: 4 B each, 128 KiB of the CU's 160
 
 // One workgroup: cell of every keypoint (Frame::PosInGrid, src/Frame.cc:725-735), then a bitonic sort of
 // (cell << 16 | index) in LDS.  Cell id = posX * 48 + posY, so ascending keys list the cells in the order
@@ -321,7 +321,7 @@ struct GridOnDevice {
 
 static int build_grid(orbx_ctx* ctx, const orbx_keypoint* kps, int n, float min_x, float min_y, float max_x, float max_y,
                       GridOnDevice& g) {
-  if (n > kGridMaxPts) return set_err(ctx, ORBX_E_CAPACITY, "frame grid: more than 8192 keypoints");
+  if (n > kGridMaxPts) return set_err(ctx, ORBX_E_CAPACITY, "frame grid: more than 32768 keypoints");
   g.minX = min_x; g.minY = min_y;
   g.invW = (float)kGridCols / (float)(max_x - min_x);   // src/Frame.cc:159-160
   g.invH = (float)kGridRows / (float)(max_y - min_y);
@@ -329,6 +329,10 @@ static int build_grid(orbx_ctx* ctx, const orbx_keypoint* kps, int n, float min_
   if (n) ORBX_HIP(ctx, hipMemcpyAsync(g.kps.p, kps, sizeof(orbx_keypoint) * n, hipMemcpyHostToDevice, ctx->stream));
   int npad = 2;
   while (npad < n) npad <<= 1;
+  if ((size_t)npad * 4 > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_frame_grid, hipFuncAttributeMaxDynamicSharedMemorySize, npad * 4);
+    if (e != hipSuccess) { (void)hipGetLastError(); return set_err(ctx, ORBX_E_CAPACITY, "frame grid: keypoints do not fit the LDS sort"); }
+  }
   hipLaunchKernelGGL(k_frame_grid, dim3(1), dim3(1024), (size_t)npad * 4, ctx->stream, g.kps.p, n, g.minX, g.minY, g.invW, g.invH,
                      npad, g.sorted.p, g.cell_start.p);
   ORBX_HIP(ctx, hipGetLastError());

@@ -205,3 +205,21 @@ def test_search_by_projection_last_frame_equals_oracle(frames, th, direction, st
         if ori:
             assert (match == -2).sum() > 0      # the rotation filter removed something
     assert total > 200
+
+
+def test_frame_grid_with_twenty_thousand_keypoints():
+    """The fork's Examples/Monocular/mi.yaml extracts 20 000 features on one level: the frame grid sorts them in LDS (128 KiB)."""
+    rng = np.random.default_rng(21)
+    img = rng.integers(0, 256, (800, 600)).astype(np.uint8)
+    ex = ORBextractor(20000, 1.2, 1, 20, 7)
+    _, k, d = ex(img, None, (0, 0))
+    assert 16384 < len(k) <= 32768
+    m = ORBmatcher(ex)
+    nq = 500
+    qx = rng.uniform(0, 600, nq).astype(np.float32); qy = rng.uniform(0, 800, nq).astype(np.float32)
+    qr = rng.choice([5.0, 15.0, 40.0], nq).astype(np.float32)
+    lo = np.full(nq, -1, np.int32); hi = np.full(nq, -1, np.int32)
+    bounds = (0.0, 0.0, 600.0, 800.0)
+    rp, cand = m.GetFeaturesInArea(k, bounds, qx, qy, qr, lo, hi)
+    orp, ocand = po.features_in_area(k, bounds, qx, qy, qr, lo, hi)
+    assert np.array_equal(rp, orp) and np.array_equal(cand, ocand) and len(cand) > 20000
