@@ -5,7 +5,8 @@
  *
  * SearchForInitialization (the heaviest Hamming workload of monocular tracking, src/ORBmatcher.cc:648-763) and
  * SearchByProjection(Frame&, vector<MapPoint*>&, ...) (the per-frame local-map search, :43-141) and
- * SearchByProjection(CurrentFrame, LastFrame, th, bMono) (the motion-model search, :1676-1885) are provided in full as
+ * SearchByProjection(CurrentFrame, LastFrame, th, bMono) (the motion-model search, :1676-1885) and
+ * SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (reference-keyframe tracking / relocalisation, :223-425) are provided in full as
  * templates over the reference's Frame / MapPoint.  The other routines take KeyFrame / Sophus types that belong to the
  * reference and are out of this repository's scope; INTEGRATION.md shows the few-line change that routes
  * each routine's candidate loop through NearestInCandidates() below while the geometry and the greedy bookkeeping
@@ -193,6 +194,48 @@ class ORBmatcher {
       if (kpMatch[i] >= 0) CurrentFrame.mvpMapPoints[i] = LastFrame.mvpMapPoints[kpMatch[i]];
       else if (kpMatch[i] == -2) CurrentFrame.mvpMapPoints[i] = nullptr;
     }
+    return nmatches;
+  }
+
+  // Matching by vocabulary node (TrackReferenceKeyFrame, Relocalization), src/ORBmatcher.cc:223-425 — same arguments, same
+  // return value, same vpMapPointMatches.  KeyFrameT / FrameT / MapPointT are the reference's types (mFeatVec is a
+  // DBoW2::FeatureVector, i.e. an ordered map node -> feature indices).  Single-camera only: a two-camera rig throws.
+  template <class KeyFrameT, class FrameT, class MapPointT>
+  int SearchByBoW(KeyFrameT* pKF, FrameT& F, std::vector<MapPointT*>& vpMapPointMatches) {
+    if (F.Nleft != -1 || pKF->mpCamera2)
+      throw std::runtime_error("ORBmatcher::SearchByBoW: two-camera frames are not routed to the GPU");
+    const std::vector<MapPointT*> vpMapPointsKF = pKF->GetMapPointMatches();
+    vpMapPointMatches = std::vector<MapPointT*>(F.N, static_cast<MapPointT*>(nullptr));
+    const int nkf = (int)vpMapPointsKF.size(), nf = F.N;
+    if (nkf == 0 || nf == 0) return 0;
+    if (!pKF->mDescriptors.isContinuous() || !F.mDescriptors.isContinuous()) throw std::runtime_error("descriptor matrices must be continuous");
+    std::vector<unsigned char> valid(nkf, 0);
+    std::vector<float> kfAngle(nkf), fAngle(nf);
+    for (int i = 0; i < nkf; i++) {
+      valid[i] = vpMapPointsKF[i] && !vpMapPointsKF[i]->isBad();
+      kfAngle[i] = pKF->mvKeysUn[i].angle;
+    }
+    for (int i = 0; i < nf; i++) fAngle[i] = F.mvKeys[i].angle;
+    auto flatten = [](const auto& fv, std::vector<uint32_t>& node, std::vector<int32_t>& ptr, std::vector<uint32_t>& idx) {
+      ptr.push_back(0);
+      for (const auto& kv : fv) {
+        node.push_back((uint32_t)kv.first);
+        for (unsigned f : kv.second) idx.push_back(f);
+        ptr.push_back((int32_t)idx.size());
+      }
+    };
+    std::vector<uint32_t> kn, ki, fn, fi;
+    std::vector<int32_t> kp, fp;
+    flatten(pKF->mFeatVec, kn, kp, ki);
+    flatten(F.mFeatVec, fn, fp, fi);
+    std::vector<int32_t> match(nf, -1);
+    int nmatches = 0;
+    const int rc = orbx_search_by_bow(DefaultContext(), pKF->mDescriptors.data, kfAngle.data(), valid.data(), nkf, kn.data(), kp.data(),
+                                      ki.data(), (int)kn.size(), F.mDescriptors.data, fAngle.data(), nf, fn.data(), fp.data(), fi.data(),
+                                      (int)fn.size(), mfNNratio, mbCheckOrientation ? 1 : 0, match.data(), &nmatches);
+    if (rc != ORBX_OK) throw std::runtime_error(std::string("ORBmatcher::SearchByBoW: ") + orbx_last_error(DefaultContext()));
+    for (int i = 0; i < nf; i++)
+      if (match[i] >= 0) vpMapPointMatches[i] = vpMapPointsKF[match[i]];
     return nmatches;
   }
 

@@ -243,6 +243,20 @@ int orbx_search_by_projection_last(orbx_ctx* ctx, const orbx_keypoint* kps_un, c
                                    const int32_t* lp_octave, const float* lp_angle, const uint8_t* lp_desc, const int32_t* lp_obs, int nlast,
                                    float th, int direction, int check_orientation, int32_t* kp_match, int* nmatches);
 
+/* ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches) (src/ORBmatcher.cc:223-425;
+ * TrackReferenceKeyFrame, Relocalization) for single-camera frames / keyframes (F.Nleft == -1, pKF->mpCamera2 == NULL).
+ * Keyframe side: kf_desc [nkf][32], kf_angle = mvKeysUn[i].angle, kf_valid [nkf] = map point non-NULL && !isBad(), the
+ * FeatureVector as CSR (kf_fv_node ascending [n_kf_nodes], kf_fv_ptr [n_kf_nodes + 1], kf_fv_idx = the vectors' contents in
+ * order).  Frame side likewise (f_angle = F.mvKeys[i].angle).  All Hamming distances between features of the same
+ * vocabulary node run on the GPU (one launch); the greedy part (a frame feature taken by an earlier keyframe feature is
+ * no candidate any more), TH_LOW / ratio tests and the rotation filter are replayed in the reference's order.
+ * match_kf [nf] out: keyframe feature whose map point lands in vpMapPointMatches[i], -1 for NULL; *nmatches = return value. */
+int orbx_search_by_bow(orbx_ctx* ctx, const uint8_t* kf_desc, const float* kf_angle, const uint8_t* kf_valid, int nkf,
+                       const uint32_t* kf_fv_node, const int32_t* kf_fv_ptr, const uint32_t* kf_fv_idx, int n_kf_nodes,
+                       const uint8_t* f_desc, const float* f_angle, int nf, const uint32_t* f_fv_node, const int32_t* f_fv_ptr,
+                       const uint32_t* f_fv_idx, int n_f_nodes, float nn_ratio, int check_orientation, int32_t* match_kf,
+                       int* nmatches);
+
 /* Frame::ComputeStereoMatches (src/Frame.cc:811-981) on the DEVICE pyramids of the left and right extractor (the
  * last frame each context extracted; both on one GPU, same image shape) — this is the reader of the reference's public
  * ORBextractor::mvImagePyramid, so with it no pyramid has to be copied to the host.  kps / desc: the keypoints and

@@ -607,6 +607,75 @@ int mo_stereo_matches(const void* kpsL_, const uint8_t* descL, int N, const void
 
 }  // extern "C"
 
+// ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches), src/ORBmatcher.cc:223-425, for
+// F.Nleft == -1 and a single-camera keyframe (pKF->mpCamera2 == nullptr).  Flattened state: kf_valid[i] = vpMapPointsKF[i] &&
+// !isBad(); feature vectors as (node, index) pair lists in map iteration order (nodes ascending, indices in insertion order).
+// match_kf[iF] = index of the keyframe feature whose map point ends up in vpMapPointMatches[iF], -1 for NULL.  Returns nmatches.
+#include <map>
+extern "C" int mo_search_by_bow(const uint8_t* kf_desc, const float* kf_angle, const uint8_t* kf_valid, int nkf,
+                                const uint32_t* kf_fv_node, const uint32_t* kf_fv_idx, int n_kf_fv, const uint8_t* f_desc,
+                                const float* f_angle, int nf, const uint32_t* f_fv_node, const uint32_t* f_fv_idx, int n_f_fv,
+                                float mfNNratio, int mbCheckOrientation, int32_t* match_kf) {
+  const int TH_LOW = 50, HISTO_LENGTH = 30;
+  std::map<unsigned, std::vector<unsigned>> vFeatVecKF, FFeatVec;   // DBoW2::FeatureVector
+  for (int i = 0; i < n_kf_fv; i++) vFeatVecKF[kf_fv_node[i]].push_back(kf_fv_idx[i]);
+  for (int i = 0; i < n_f_fv; i++) FFeatVec[f_fv_node[i]].push_back(f_fv_idx[i]);
+  for (int i = 0; i < nf; i++) match_kf[i] = -1;
+  int nmatches = 0;
+  std::vector<int> rotHist[30];
+  const float factor = 1.0f / HISTO_LENGTH;
+  auto KFit = vFeatVecKF.begin(), KFend = vFeatVecKF.end();
+  auto Fit = FFeatVec.begin(), Fend = FFeatVec.end();
+  while (KFit != KFend && Fit != Fend) {
+    if (KFit->first == Fit->first) {
+      const std::vector<unsigned> vIndicesKF = KFit->second;
+      const std::vector<unsigned> vIndicesF = Fit->second;
+      for (size_t iKF = 0; iKF < vIndicesKF.size(); iKF++) {
+        const unsigned realIdxKF = vIndicesKF[iKF];
+        if (!kf_valid[realIdxKF]) continue;   // !pMP || pMP->isBad()
+        const uint8_t* dKF = kf_desc + (size_t)realIdxKF * 32;
+        int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+        for (size_t iF = 0; iF < vIndicesF.size(); iF++) {
+          const unsigned realIdxF = vIndicesF[iF];
+          if (match_kf[realIdxF] >= 0) continue;   // vpMapPointMatches[realIdxF]
+          const int dist = descriptor_distance(dKF, f_desc + (size_t)realIdxF * 32);
+          if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = (int)realIdxF; }
+          else if (dist < bestDist2) { bestDist2 = dist; }
+        }
+        if (bestDist1 <= TH_LOW) {
+          if (static_cast<float>(bestDist1) < mfNNratio * static_cast<float>(bestDist2)) {
+            match_kf[bestIdxF] = (int)realIdxKF;
+            if (mbCheckOrientation) {
+              float rot = kf_angle[realIdxKF] - f_angle[bestIdxF];
+              if (rot < 0.0) rot += 360.0f;
+              int bin = (int)round(rot * factor);
+              if (bin == HISTO_LENGTH) bin = 0;
+              assert(bin >= 0 && bin < HISTO_LENGTH);
+              rotHist[bin].push_back(bestIdxF);
+            }
+            nmatches++;
+          }
+        }
+      }
+      KFit++;
+      Fit++;
+    } else if (KFit->first < Fit->first) {
+      KFit = vFeatVecKF.lower_bound(Fit->first);
+    } else {
+      Fit = FFeatVec.lower_bound(KFit->first);
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) { match_kf[rotHist[i][j]] = -1; nmatches--; }
+    }
+  }
+  return nmatches;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // KeyFrameDatabase (src/KeyFrameDatabase.cc), the part every Detect* routine starts with.
 // ---------------------------------------------------------------------------------------------------------

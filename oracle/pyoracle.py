@@ -306,6 +306,29 @@ def search_by_projection_last(kps, desc, bounds, scale_factors, kp_obs, lp, th, 
     return int(n), match[:len(k)].copy(), obs
 
 
+def search_by_bow(kf_desc, kf_angle, kf_valid, kf_fv, f_desc, f_angle, f_fv, nnratio=0.7, check_ori=True):
+    """ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) (src/ORBmatcher.cc:223-425, Nleft == -1).  kf_fv / f_fv: feature vectors as
+    dict node -> list of feature indices.  Returns (nmatches, match_kf [nf])."""
+    def flat(fv):
+        nodes, idx = [], []
+        for k in sorted(fv):
+            for i in fv[k]:
+                nodes.append(k); idx.append(i)
+        return np.array(nodes, np.uint32), np.array(idx, np.uint32)
+    kd, fd = np.ascontiguousarray(kf_desc, np.uint8), np.ascontiguousarray(f_desc, np.uint8)
+    ka, fa = np.ascontiguousarray(kf_angle, np.float32), np.ascontiguousarray(f_angle, np.float32)
+    kv = np.ascontiguousarray(kf_valid, np.uint8)
+    kn, ki = flat(kf_fv); fn, fi = flat(f_fv)
+    match = np.zeros(max(len(fd), 1), np.int32)
+    L = _mlib()
+    vp, f32 = C.c_void_p, C.c_float
+    L.mo_search_by_bow.restype = C.c_int
+    L.mo_search_by_bow.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, f32, C.c_int, vp]
+    n = L.mo_search_by_bow(_ptr(kd), _ptr(ka), _ptr(kv), len(kd), _ptr(kn), _ptr(ki), len(kn), _ptr(fd), _ptr(fa), len(fd), _ptr(fn), _ptr(fi),
+                           len(fn), float(nnratio), int(check_ori), _ptr(match))
+    return int(n), match[:len(fd)].copy()
+
+
 def stereo_matches(kpsL, descL, kpsR, descR, pyrL, pyrR, scale, inv_scale, mb, mbf):
     """Frame::ComputeStereoMatches (src/Frame.cc:811-981) -> (mvuRight, mvDepth, number of matches kept)."""
     kL, kR = np.ascontiguousarray(kpsL), np.ascontiguousarray(kpsR)

@@ -75,6 +75,7 @@ def lib() -> C.CDLL:
                                             vp, ip]),
         "orbx_search_by_projection_last": (i32, [vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, vp, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp, i32,
                                                  f32, i32, i32, vp, ip]),
+        "orbx_search_by_bow": (i32, [vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, i32, f32, i32, vp, ip]),
         "orbx_stereo_matches": (i32, [vp, vp, vp, vp, i32, vp, vp, i32, f32, f32, vp, vp, ip]),
         "orbx_voc_load_text": (i32, [vp, C.c_char_p, C.POINTER(vp)]),
         "orbx_voc_create": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, C.POINTER(vp)]),

@@ -757,6 +757,105 @@ int orbx_search_by_projection_last(orbx_ctx* ctx, const orbx_keypoint* kps_un, c
   return ORBX_OK;
 }
 
+int orbx_search_by_bow(orbx_ctx* ctx, const uint8_t* kf_desc, const float* kf_angle, const uint8_t* kf_valid, int nkf,
+                       const uint32_t* kf_fv_node, const int32_t* kf_fv_ptr, const uint32_t* kf_fv_idx, int n_kf_nodes,
+                       const uint8_t* f_desc, const float* f_angle, int nf, const uint32_t* f_fv_node, const int32_t* f_fv_ptr,
+                       const uint32_t* f_fv_idx, int n_f_nodes, float nn_ratio, int check_orientation, int32_t* match_kf,
+                       int* nmatches_out) {
+  if (!ctx || nkf < 0 || nf < 0 || n_kf_nodes < 0 || n_f_nodes < 0 || !nmatches_out || (nf > 0 && (!f_desc || !f_angle || !match_kf)) ||
+      (nkf > 0 && (!kf_desc || !kf_angle || !kf_valid)) || (n_kf_nodes > 0 && (!kf_fv_node || !kf_fv_ptr || !kf_fv_idx)) ||
+      (n_f_nodes > 0 && (!f_fv_node || !f_fv_ptr || !f_fv_idx)))
+    return ctx ? set_err(ctx, ORBX_E_INVALID, "orbx_search_by_bow: bad arguments") : ORBX_E_INVALID;
+  *nmatches_out = 0;
+  for (int i = 0; i < nf; i++) match_kf[i] = -1;
+  if (nkf == 0 || nf == 0 || n_kf_nodes == 0 || n_f_nodes == 0) return ORBX_OK;
+  for (int i = 1; i < n_kf_nodes; i++) if (kf_fv_node[i] <= kf_fv_node[i - 1]) return set_err(ctx, ORBX_E_INVALID, "orbx_search_by_bow: keyframe nodes must ascend");
+  for (int i = 1; i < n_f_nodes; i++) if (f_fv_node[i] <= f_fv_node[i - 1]) return set_err(ctx, ORBX_E_INVALID, "orbx_search_by_bow: frame nodes must ascend");
+  // queries in the reference's order (:244-262): common nodes ascending, the keyframe's features of the node in list order,
+  // those with a good map point; candidates = the frame's features of the same node, in list order
+  std::vector<int32_t> qkf, row_ptr(1, 0), cand;
+  std::vector<uint8_t> qd;
+  int a = 0, b = 0;
+  while (a < n_kf_nodes && b < n_f_nodes) {
+    if (kf_fv_node[a] == f_fv_node[b]) {
+      for (int i = kf_fv_ptr[a]; i < kf_fv_ptr[a + 1]; i++) {
+        const uint32_t k = kf_fv_idx[i];
+        if (k >= (uint32_t)nkf) return set_err(ctx, ORBX_E_INVALID, "orbx_search_by_bow: keyframe feature index out of range");
+        if (!kf_valid[k]) continue;
+        qkf.push_back((int32_t)k);
+        qd.insert(qd.end(), kf_desc + (size_t)k * 32, kf_desc + (size_t)k * 32 + 32);
+        for (int j = f_fv_ptr[b]; j < f_fv_ptr[b + 1]; j++) {
+          if (f_fv_idx[j] >= (uint32_t)nf) return set_err(ctx, ORBX_E_INVALID, "orbx_search_by_bow: frame feature index out of range");
+          cand.push_back((int32_t)f_fv_idx[j]);
+        }
+        row_ptr.push_back((int32_t)cand.size());
+      }
+      a++; b++;
+    } else if (kf_fv_node[a] < f_fv_node[b]) a++;
+    else b++;
+  }
+  const int nq = (int)qkf.size(), nnz = (int)cand.size();
+  if (nq == 0 || nnz == 0) return ORBX_OK;
+  ORBX_HIP(ctx, hipSetDevice(ctx->device));
+  ArenaScope scope(ctx);
+  DBuf<uint8_t> dq, dt;
+  DBuf<int32_t> drp, dc, dd;
+  ORBX_HIP(ctx, dq.alloc((size_t)nq * 32)); ORBX_HIP(ctx, dt.alloc((size_t)nf * 32)); ORBX_HIP(ctx, drp.alloc(nq + 1));
+  ORBX_HIP(ctx, dc.alloc(nnz)); ORBX_HIP(ctx, dd.alloc(nnz));
+  hipStream_t st = ctx->stream;
+  ORBX_HIP(ctx, hipMemcpyAsync(dq.p, qd.data(), (size_t)nq * 32, hipMemcpyHostToDevice, st));
+  ORBX_HIP(ctx, hipMemcpyAsync(dt.p, f_desc, (size_t)nf * 32, hipMemcpyHostToDevice, st));
+  ORBX_HIP(ctx, hipMemcpyAsync(drp.p, row_ptr.data(), sizeof(int32_t) * (nq + 1), hipMemcpyHostToDevice, st));
+  ORBX_HIP(ctx, hipMemcpyAsync(dc.p, cand.data(), sizeof(int32_t) * nnz, hipMemcpyHostToDevice, st));
+  int rc = orbx_nn_csr_device(ctx, dq.p, nq, dt.p, nf, drp.p, dc.p, 0, nullptr, nullptr, nullptr, nullptr, dd.p, st);
+  if (rc != ORBX_OK) return rc;
+  std::vector<int32_t> dist(nnz);
+  ORBX_HIP(ctx, hipMemcpyAsync(dist.data(), dd.p, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost, st));
+  ORBX_HIP(ctx, hipStreamSynchronize(st));
+  // host replay (:264-330): a frame feature matched by an earlier keyframe feature is no candidate any more
+  const int TH_LOW = 50, HISTO_LENGTH = 30;
+  const float factor = 1.0f / HISTO_LENGTH;
+  std::vector<int> rotHist[30];
+  int nmatches = 0;
+  for (int q = 0; q < nq; q++) {
+    int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+    for (int c = row_ptr[q]; c < row_ptr[q + 1]; c++) {
+      const int iF = cand[c], d = dist[c];
+      if (match_kf[iF] >= 0) continue;
+      if (d < bestDist1) { bestDist2 = bestDist1; bestDist1 = d; bestIdxF = iF; }
+      else if (d < bestDist2) { bestDist2 = d; }
+    }
+    if (bestDist1 <= TH_LOW && (float)bestDist1 < nn_ratio * (float)bestDist2) {
+      match_kf[bestIdxF] = qkf[q];
+      if (check_orientation) {
+        float rot = kf_angle[qkf[q]] - f_angle[bestIdxF];
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)std::round(rot * factor);
+        if (bin == HISTO_LENGTH) bin = 0;
+        if (bin >= 0 && bin < HISTO_LENGTH) rotHist[bin].push_back(bestIdxF);
+      }
+      nmatches++;
+    }
+  }
+  if (check_orientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < HISTO_LENGTH; i++) {  // ComputeThreeMaxima, src/ORBmatcher.cc:2012-2053
+      const int s = (int)rotHist[i].size();
+      if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+      else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+      else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int idx : rotHist[i]) { match_kf[idx] = -1; nmatches--; }
+    }
+  }
+  *nmatches_out = nmatches;
+  return ORBX_OK;
+}
+
 int orbx_stereo_matches(orbx_ctx* left, orbx_ctx* right, const orbx_keypoint* kpsL, const uint8_t* descL, int nL,
                         const orbx_keypoint* kpsR, const uint8_t* descR, int nR, float mb, float mbf, float* u_right, float* depth,
                         int* nmatches) {

@@ -156,6 +156,26 @@ class ORBmatcher:
                                                      ptr(match), C.byref(n)), self._ctx)
         return n.value, match[:len(k)].copy()
 
+    def SearchByBoW(self, kf_desc, kf_angle, kf_valid, kf_fv, f_desc, f_angle, f_fv):
+        """ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (src/ORBmatcher.cc:223-425), single-camera.
+        kf_fv / f_fv: DBoW2::FeatureVector as dict node -> list of feature indices.  Returns (nmatches, match_kf [nf])."""
+        def csr(fv):
+            nodes = sorted(fv)
+            ptr_, idx = [0], []
+            for k in nodes:
+                idx.extend(fv[k]); ptr_.append(len(idx))
+            return np.array(nodes, np.uint32), np.array(ptr_, np.int32), np.array(idx, np.uint32)
+        kd = np.ascontiguousarray(kf_desc, np.uint8).reshape(-1, 32); fd = np.ascontiguousarray(f_desc, np.uint8).reshape(-1, 32)
+        ka, fa = np.ascontiguousarray(kf_angle, np.float32), np.ascontiguousarray(f_angle, np.float32)
+        kv = np.ascontiguousarray(kf_valid, np.uint8)
+        kn, kp, ki = csr(kf_fv); fn, fp, fi = csr(f_fv)
+        match = np.zeros(max(len(fd), 1), np.int32)
+        n = C.c_int(0)
+        check(self._L.orbx_search_by_bow(self._ctx, ptr(kd), ptr(ka), ptr(kv), len(kd), ptr(kn), ptr(kp), ptr(ki), len(kn), ptr(fd), ptr(fa),
+                                         len(fd), ptr(fn), ptr(fp), ptr(fi), len(fn), self.mfNNratio, int(self.mbCheckOrientation),
+                                         ptr(match), C.byref(n)), self._ctx)
+        return n.value, match[:len(fd)].copy()
+
     @staticmethod
     def ComputeStereoMatches(left_extractor, right_extractor, kpsL, descL, kpsR, descR, mb: float, mbf: float):
         """Frame::ComputeStereoMatches (src/Frame.cc:811-981) on the device pyramids of the two extractors (each must

@@ -219,6 +219,38 @@ int main(int argc, char** argv) {
         o.write((const char*)&who, 4);
       }
     }
+    // SearchByBoW(KeyFrame*, Frame&, matches): the frame against itself as a keyframe, feature vectors from the vocabulary
+    // (levelsup 2); every 4th keyframe feature has no map point, every 9th a bad one
+    if (argc >= 10 && n) {
+      ORBVocabulary voc;
+      voc.loadFromTextFile(argv[9]);
+      std::vector<cv::Mat> vdesc;
+      for (int i = 0; i < n; i++) vdesc.push_back(descriptors.row(i));
+      DBoW2::BowVector bow;
+      struct MiniKF {
+        std::vector<MiniMapPoint*> mps;
+        DBoW2::FeatureVector mFeatVec;
+        cv::Mat mDescriptors;
+        std::vector<cv::KeyPoint> mvKeysUn;
+        void* mpCamera2 = nullptr;
+        std::vector<MiniMapPoint*> GetMapPointMatches() const { return mps; }
+      } kf;
+      struct MiniF { int N = 0, Nleft = -1; DBoW2::FeatureVector mFeatVec; cv::Mat mDescriptors; std::vector<cv::KeyPoint> mvKeys; } Fb;
+      voc.transform(vdesc, bow, kf.mFeatVec, 2);
+      Fb.mFeatVec = kf.mFeatVec;
+      kf.mDescriptors = descriptors.clone(); kf.mvKeysUn = keys;
+      Fb.mDescriptors = descriptors.clone(); Fb.mvKeys = keys; Fb.N = n;
+      std::vector<MiniMapPoint> mps(n);
+      kf.mps.assign(n, nullptr);
+      for (int i = 0; i < n; i++) { mps[i].bad = i % 9 == 0; if (i % 4 != 0) kf.mps[i] = &mps[i]; }
+      std::vector<MiniMapPoint*> matches;
+      ORBmatcher matcher(0.7f, true);
+      const int nm = matcher.SearchByBoW(&kf, Fb, matches);
+      o.write((const char*)&nm, 4);
+      for (int i = 0; i < n; i++) { int who = matches[i] ? (int)(matches[i] - &mps[0]) : -1; o.write((const char*)&who, 4); }
+    } else {
+      int nm = -1; o.write((const char*)&nm, 4);
+    }
     std::printf("OK n=%d mono=%d\n", n, mono);
     delete extractor;
     return 0;

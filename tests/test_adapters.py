@@ -65,8 +65,10 @@ def _read(path):
     nproj = take("<i")
     proj = np.frombuffer(b, np.int32, n, off); off += 4 * n
     nlast = take("<i")
-    last = np.frombuffer(b, np.int32, n, off)
-    return mono, kps, desc, pyr, d01, bow, fv, self_score, nm, m12, nproj, proj, nlast, last
+    last = np.frombuffer(b, np.int32, n, off); off += 4 * n
+    nbow = take("<i")
+    bowm = np.frombuffer(b, np.int32, n, off) if nbow >= 0 else None
+    return mono, kps, desc, pyr, d01, bow, fv, self_score, nm, m12, nproj, proj, nlast, last, nbow, bowm
 
 
 @pytest.mark.gpu
@@ -84,7 +86,7 @@ def test_adapter_results_equal_oracle(tmp_path, rows, cols, lap):
     make_vocabulary(vocp, odesc, 6, 3, seed=3)
     r = subprocess.run([exe, "run", raw, str(rows), str(cols), "1000", str(lap[0]), str(lap[1]), out, vocp], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    mono, kps, desc, pyr, d01, bow, fv, self_score, nm, m12, nproj, proj, nlast, last = _read(out)
+    mono, kps, desc, pyr, d01, bow, fv, self_score, nm, m12, nproj, proj, nlast, last, nbow, bowm = _read(out)
     assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc)
     for l in range(8):
         assert np.array_equal(pyr[l], ora.level(l))
@@ -123,3 +125,7 @@ def test_adapter_results_equal_oracle(tmp_path, rows, cols, lap):
     on, omatch, _ = po.search_by_projection_last(okps, odesc, (0, 0, cols, rows), sf, np.full(n, -1, np.int32), lp, 15.0, 1, True, ur, 50.0)
     want = np.where(omatch >= 0, omatch, -1)          # the demo reports the bound map point or -1 (NULL)
     assert nlast == on and np.array_equal(last, want) and on > 100
+    # SearchByBoW through the C++ template (src/ORBmatcher.cc:223-425): the frame as its own keyframe
+    valid = ((i % 4 != 0) & (i % 9 != 0)).astype(np.uint8)
+    on, omatch = po.search_by_bow(odesc, okps["angle"], valid, ofv, odesc, okps["angle"], ofv, 0.7, True)
+    assert nbow == on and np.array_equal(bowm, omatch) and on > 100

@@ -296,3 +296,22 @@ def test_kfdb_hand_case():
     # nMinWords floor (DetectBestCandidates, :514-517)
     r = db.query(q, min_words_floor=5)
     assert r["min_common"] == 5 and (r["score"] == -1.0).all()
+
+
+def test_search_by_bow_hand_case():
+    """src/ORBmatcher.cc:223-425: only features of the same node are compared; an earlier match removes the candidate."""
+    kd = np.zeros((3, 32), np.uint8); fd = np.zeros((3, 32), np.uint8)
+    fd[1, 0] = 0x01; fd[2, :] = 0xff                       # frame feature 1 is 1 bit from the keyframe features, 2 is far
+    ka = np.zeros(3, np.float32); fa = np.zeros(3, np.float32)
+    valid = np.ones(3, np.uint8)
+    # node 7 holds keyframe features 0, 1 and frame features 0, 1; node 9 holds keyframe feature 2 and frame feature 2
+    n, m = po.search_by_bow(kd, ka, valid, {7: [0, 1], 9: [2]}, fd, fa, {7: [0, 1], 9: [2]}, 0.7, False)
+    # kf 0: best frame 0 (d=0) vs second 1 (d=1): 0 < 0.7 -> frame 0 <- kf 0.  kf 1: frame 0 is taken, only frame 1 (d=1, second 256)
+    # -> frame 1 <- kf 1.  kf 2 vs frame 2: d = 256 > TH_LOW
+    assert n == 2 and m.tolist() == [0, 1, -1]
+    # an invalid (no map point / bad) keyframe feature is skipped: frame 0 goes to kf 1
+    n, m = po.search_by_bow(kd, ka, np.array([0, 1, 1], np.uint8), {7: [0, 1], 9: [2]}, fd, fa, {7: [0, 1], 9: [2]}, 0.7, False)
+    assert n == 1 and m.tolist() == [1, -1, -1]
+    # different nodes: never compared
+    n, m = po.search_by_bow(kd, ka, valid, {7: [0, 1]}, fd, fa, {8: [0, 1]}, 0.7, False)
+    assert n == 0
