@@ -15,6 +15,7 @@
 
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -96,8 +97,11 @@ class ORBVocabulary {
     for (int i = 0; i < n; i++) std::memcpy(&desc[(size_t)i * 32], features[i].ptr<unsigned char>(), 32);
     std::vector<uint32_t> word(n), node(n), ids(n);
     std::vector<double> weight(n), vals(n);
-    if (orbx_bow_transform(voc_, desc.data(), n, levelsup, word.data(), weight.data(), node.data()) != ORBX_OK)
-      throw std::runtime_error(std::string("ORBVocabulary::transform: ") + orbx_last_error(ctx_));
+    {  // Tracking, LocalMapping and LoopClosing all call transform on the one vocabulary: one caller at a time on its context
+      std::lock_guard<std::mutex> lock(mu_);
+      if (orbx_bow_transform(voc_, desc.data(), n, levelsup, word.data(), weight.data(), node.data()) != ORBX_OK)
+        throw std::runtime_error(std::string("ORBVocabulary::transform: ") + orbx_last_error(ctx_));
+    }
     int nnz = 0;
     orbx_bow_finalize(voc_, word.data(), weight.data(), n, ids.data(), vals.data(), &nnz);
     for (int k = 0; k < nnz; k++) v.insert(v.end(), DBoW2::BowVector::value_type(ids[k], vals[k]));
@@ -119,6 +123,7 @@ class ORBVocabulary {
 
  private:
   orbx_ctx* ctx_ = nullptr;
+  mutable std::mutex mu_;
   orbx_voc* voc_ = nullptr;
 };
 

@@ -72,15 +72,21 @@ class ORBmatcher {
     if (rc != ORBX_OK) throw std::runtime_error(std::string("ORBmatcher: ") + orbx_last_error(ctx));
   }
 
-  // A process-wide context for the stack-constructed matchers of the reference (`ORBmatcher matcher(0.9, true);`,
-  // src/Tracking.cc:2494): created on first use on the current HIP device.
+  // The context of the stack-constructed matchers of the reference (`ORBmatcher matcher(0.9, true);`,
+  // src/Tracking.cc:2494).  One per THREAD: Tracking, LocalMapping and LoopClosing run matchers concurrently, and an orbx
+  // context (stream, scratch arena) serves one caller at a time.  Created on first use on the thread's current HIP device,
+  // destroyed when the thread ends.
   static orbx_ctx* DefaultContext() {
-    static orbx_ctx* ctx = [] {
+    struct Holder {
       orbx_ctx* c = nullptr;
-      if (orbx_create(&c, 1, 1.2f, 1, 20, 7, -1) != ORBX_OK) throw std::runtime_error("ORBmatcher: no MI355X / HIP device");
-      return c;
-    }();
-    return ctx;
+      ~Holder() { if (c) orbx_destroy(c); }
+    };
+    static thread_local Holder h;
+    if (!h.c && orbx_create(&h.c, 1, 1.2f, 1, 20, 7, -1) != ORBX_OK) {
+      h.c = nullptr;
+      throw std::runtime_error("ORBmatcher: no MI355X / HIP device");
+    }
+    return h.c;
   }
 
   // Matching for the map initialisation (monocular), src/ORBmatcher.cc:648-763.  FrameT is the reference's Frame (or

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
+#include <thread>
 #include <vector>
 
 #include "ORBVocabulary.h"
@@ -96,6 +97,58 @@ int main(int argc, char** argv) {
         if (pass == 1) std::printf("STREAM frames=%d ms_per_frame=%.4f features_per_ms=%.1f keep_pyramid=%d\n", 20 * nfr, ms / (20 * nfr), total / ms, (int)keep);
       }
       return 0;
+    }
+    if (mode == "mt" && argc >= 6) {
+      // Tracking / LocalMapping / LoopClosing use matchers and the vocabulary concurrently: three threads, each with
+      // stack-constructed matchers, one shared vocabulary; every thread must reproduce the single-threaded results.
+      //   adapter_demo mt <img.raw> <rows> <cols> <voc.txt>
+      const int rows = std::atoi(argv[3]), cols = std::atoi(argv[4]);
+      std::vector<unsigned char> buf((size_t)rows * cols);
+      { std::ifstream f(argv[2], std::ios::binary); f.read((char*)buf.data(), (std::streamsize)buf.size()); }
+      cv::Mat im(rows, cols, CV_8UC1, buf.data());
+      ORBextractor ex(1000, 1.2f, 8, 20, 7);
+      std::vector<cv::KeyPoint> keys;
+      cv::Mat descriptors;
+      std::vector<int> lap = {0, 0};
+      ex(im, cv::Mat(), keys, descriptors, lap);
+      const int n = (int)keys.size();
+      ORBVocabulary voc;
+      if (!voc.loadFromTextFile(argv[5])) return 4;
+      MiniFrame::mnMaxX = (float)cols; MiniFrame::mnMaxY = (float)rows;
+      auto work = [&](std::vector<int>& m12, int& nm, std::vector<double>& bowv) {
+        MiniFrame F1, F2;
+        F1.mvKeysUn = keys; F1.mDescriptors = descriptors.clone();
+        F2.mvKeysUn = keys; F2.mDescriptors = descriptors.clone();
+        std::vector<cv::Point2f> prev(n);
+        for (int i = 0; i < n; i++) prev[i] = keys[i].pt;
+        ORBmatcher matcher(0.9f, true);
+        nm = matcher.SearchForInitialization(F1, F2, prev, m12, 100);
+        std::vector<cv::Mat> vdesc;
+        for (int i = 0; i < n; i++) vdesc.push_back(descriptors.row(i));
+        DBoW2::BowVector bow; DBoW2::FeatureVector fv;
+        voc.transform(vdesc, bow, fv, 2);
+        bowv.clear();
+        for (auto& kv : bow) { bowv.push_back((double)kv.first); bowv.push_back(kv.second); }
+      };
+      std::vector<int> ref_m12; int ref_nm = 0; std::vector<double> ref_bow;
+      work(ref_m12, ref_nm, ref_bow);
+      int bad = 0;
+      std::vector<std::thread> ths;
+      std::vector<int> bads(3, 0);
+      for (int t = 0; t < 3; t++)
+        ths.emplace_back([&, t] {
+          try {
+            for (int rep = 0; rep < 25; rep++) {
+              std::vector<int> m12; int nm = 0; std::vector<double> bowv;
+              work(m12, nm, bowv);
+              if (nm != ref_nm || m12 != ref_m12 || bowv != ref_bow) bads[t]++;
+            }
+          } catch (const std::exception& e) { std::fprintf(stderr, "thread %d: %s\n", t, e.what()); bads[t] += 1000; }
+        });
+      for (auto& th : ths) th.join();
+      for (int b : bads) bad += b;
+      std::printf(bad ? "MT_FAIL %d\n" : "MT_OK n=%d matches=%d\n", bad ? bad : n, ref_nm);
+      return bad ? 5 : 0;
     }
     if (mode != "run" || argc < 9) return 2;
     const int rows = std::atoi(argv[3]), cols = std::atoi(argv[4]), nf = std::atoi(argv[5]);

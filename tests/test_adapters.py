@@ -20,7 +20,7 @@ def _build():
     src = os.path.join(SUP, "adapter_demo.cpp")
     deps = [src] + [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
     if not os.path.exists(EXE) or any(os.path.getmtime(d) > os.path.getmtime(EXE) for d in deps):
-        subprocess.check_call(["g++", "-O1", "-std=c++14", "-Wall", "-DORBX_FORCE_CV_COMPAT", "-I", os.path.join(ROOT, "include"),
+        subprocess.check_call(["g++", "-O1", "-std=c++14", "-Wall", "-pthread", "-DORBX_FORCE_CV_COMPAT", "-I", os.path.join(ROOT, "include"),
                                src, "-o", EXE, "-L", PKG, "-lorbx", "-Wl,-rpath," + PKG, "-Wl,--allow-shlib-undefined"])
     return EXE
 
@@ -129,3 +129,20 @@ def test_adapter_results_equal_oracle(tmp_path, rows, cols, lap):
     valid = ((i % 4 != 0) & (i % 9 != 0)).astype(np.uint8)
     on, omatch = po.search_by_bow(odesc, okps["angle"], valid, ofv, odesc, okps["angle"], ofv, 0.7, True)
     assert nbow == on and np.array_equal(bowm, omatch) and on > 100
+
+
+@pytest.mark.gpu
+def test_matchers_and_vocabulary_from_three_threads(tmp_path):
+    """Tracking, LocalMapping and LoopClosing construct matchers and call the shared vocabulary concurrently
+    (SURVEY §8(b) threading): per-thread default contexts, serialised vocabulary context — results equal the serial ones."""
+    from oracle import pyoracle as po
+    from orb_slam3_modified_amd import synth
+    from tests.vocab_util import make_vocabulary
+    exe = _build()
+    img = synth.make_stream(1, 480, 640)[0]
+    raw, vocp = str(tmp_path / "im.raw"), str(tmp_path / "voc.txt")
+    img.tofile(raw)
+    okps, odesc, _ = po.OracleExtractor(1000, 1.2, 8, 20, 7).extract(img, (0, 0))
+    make_vocabulary(vocp, odesc, 6, 3, seed=3)
+    r = subprocess.run([exe, "mt", raw, "480", "640", vocp], capture_output=True, text=True)
+    assert r.returncode == 0 and "MT_OK" in r.stdout, r.stdout + r.stderr
