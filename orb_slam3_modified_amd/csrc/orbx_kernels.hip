@@ -29,9 +29,18 @@ __device__ __forceinline__ int fast_div(int n, uint32_t M) { return M ? (int)__u
 
 // Full-rate 24-bit multiply, pinned with inline asm: the compiler re-widens __mul24 to the quarter-rate v_mul_lo_u32
 // whenever it cannot prove the operand ranges itself.  Both operands must fit 24 signed bits.
+// CAUTION (measured the hard way): the hazard recogniser does not look inside inline asm.  Feed these helpers only values
+// produced by plain VALU arithmetic — never the direct result of v_dot4 / v_dot2, a transcendental or a DPP / readlane op,
+// whose consumers need wait states the compiler will not insert in front of an asm statement.
 __device__ __forceinline__ int mul_i24(int a, int b) {
   int r;
   asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+__device__ __forceinline__ uint32_t mul_u24(uint32_t a, uint32_t b) {   // low 32 bits of a 24 x 24-bit product, full rate
+  uint32_t r;
+  asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
 
@@ -238,7 +247,7 @@ __global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__
     for (int i0 = 0; i0 < nit; i0 += T) {
       const int act = (i0 + t) < nit;
       const int i = act ? i0 + t : nit - 1;
-      const int ry = (int)(((uint32_t)i * magic) >> 16);
+      const int ry = (int)(mul_u24((uint32_t)i, magic) >> 16);   // i < 2^16, magic <= 2^16
       const int k = kmin + (i - ry * ng);
       const uint32_t* rowp = (const uint32_t*)tile + (ry + 3) * P4 + k;
       const uint32_t dC = rowp[0], dL = rowp[-1], dR = rowp[1], dU = rowp[-3 * P4], dD = rowp[3 * P4];
@@ -1197,14 +1206,21 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
         const int um = (int)((umpk >> (4 * (v < 0 ? -v : v))) & 15ull);
         const int u0 = 4 * dcol - sh - kHalfPatch;
         const int lo = max(-um - u0, 0), hi = min(um - u0, 3);
-        uint32_t M = 0;
-        if (it < 31 * 10 && lo <= hi) M = (0x01010101u << (8 * lo)) & (0x01010101u >> (8 * (3 - hi)));
+        uint32_t F = 0;   // 0xff on the valid bytes of this dword
+        if (it < 31 * 10 && lo <= hi) F = (0xffffffffu << (8 * lo)) & (0xffffffffu >> (8 * (3 - hi)));
         uint32_t dw = 0;
-        if (M) dw = *(const uint32_t*)(img + (src0 + (uint32_t)(__mul24(r, pitch) + 4 * dcol)));
-        const int S = (int)__builtin_amdgcn_udot4(dw, M, 0u, false);
-        const int Tt = (int)__builtin_amdgcn_udot4(dw, (M * 255u) & 0x03020100u, 0u, false);  // weights b on the valid bytes
-        m10 += u0 * S + Tt;
-        m01 += v * S;
+        if (F) dw = *(const uint32_t*)(img + (src0 + (uint32_t)(__mul24(r, pitch) + 4 * dcol)));   // the kernel is TA-bound: no load for masked-out dwords
+        // S <= 4 * 255: the (no-op) mask lets the compiler prove 24-bit operands and pick the full-rate v_mad_i32_i24
+        // instead of the quarter-rate v_mul_lo_u32.  (Not the inline-asm mul_i24 here: the hazard recogniser does not see
+        // that an asm statement reads a VGPR a v_dot4 has just written, and the multiply then reads the stale value.)
+        const int S = (int)(__builtin_amdgcn_udot4(dw, F & 0x01010101u, 0u, false) & 0x7ffu);
+        const int Tt = (int)__builtin_amdgcn_udot4(dw, F & 0x03020100u, 0u, false);  // weights b on the valid bytes
+        int u0o = u0;
+        asm("" : "+v"(u0o));   // opaque to the optimiser, or it drops the sign extension below as redundant — and instruction
+                               // selection, which only sees this basic block, then cannot prove the 24-bit range any more
+        const int u0s = __builtin_amdgcn_sbfe(u0o, 0, 12), vs = (v << 20) >> 20;   // |u0| <= 31, |v| <= 15
+        m10 += u0s * S + Tt;
+        m01 += vs * S;
       }
     } else {
       const int c = lane & 31, r2 = lane >> 5;
