@@ -323,6 +323,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
   const int ft = ctx->fast_threads;
   auto fast_kern = pitchB == 64 ? (ft == 64 ? k_fast_cells<64, 64> : ft == 128 ? k_fast_cells<128, 64> : k_fast_cells<256, 64>)
                                 : (ft == 64 ? k_fast_cells<64, 96> : ft == 128 ? k_fast_cells<128, 96> : k_fast_cells<256, 96>);
+  if (ctx->fast_pk && ft == 128) fast_kern = pitchB == 64 ? k_fast_cells<128, 64, true> : k_fast_cells<128, 96, true>;
   auto launch_fast = [&](int cell_base, int ncells_sub, hipStream_t s) {
     const int nitems = ncells_sub * nframes;
     if (nitems <= 0) return;
@@ -549,6 +550,8 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, 
     const char* fb = getenv("ORBX_FORK_BLUR");
     ctx->fork_blur = fb ? atoi(fb) != 0 : true;
     const char* ff = getenv("ORBX_FORK_FAST0");
+    const char* fpk = getenv("ORBX_FAST_PK");   // packed 16-bit necessary test in k_fast_cells (128-thread workgroups)
+    ctx->fast_pk = fpk ? atoi(fpk) != 0 : true;
     const char* fq = getenv("ORBX_FORK_QT");
     ctx->fork_qt = fq ? atoi(fq) != 0 : true;
     ctx->fork_fast0 = ff ? atoi(ff) != 0 : false;  // measured: no gain (both kernels already fill the CUs), kept as a knob
@@ -891,6 +894,7 @@ int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
   else if (n == "fork_fast0") ctx->fork_fast0 = value != 0;
   else if (n == "fork_qt") ctx->fork_qt = value != 0;
   else if (n == "graph") ctx->use_graph = value != 0;
+  else if (n == "fast_pk") ctx->fast_pk = value != 0;
   else if (n == "fast_threads" && (value == 64 || value == 128 || value == 256)) ctx->fast_threads = value;
   else if (n == "desc_k" && (value == 1 || value == 2 || value == 4 || value == 8 || value == 16)) ctx->desc_k = value;
   else if (n == "streams" && value >= 1 && value <= 2) ctx->nstreams = value;

@@ -182,7 +182,32 @@ __device__ __forceinline__ int fast_score16(int v, const uint32_t (&p)[16]) {
 //     16-pixel score; (3) NMS and the iniTh/minTh selection run on the list; (4) the ordered (row-major) output
 //     order is rebuilt from a bitmap + popcount prefix instead of a pass over all pixels.
 // list entry: x | y << 7 (detection-domain coordinates, both < 128), bit 15 = NMS survivor.
-template <int T, int PITCH>
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2_t as_u16x2(uint32_t x) { u16x2_t r; __builtin_memcpy(&r, &x, 4); return r; }
+__device__ __forceinline__ uint32_t as_u32(u16x2_t x) { uint32_t r; __builtin_memcpy(&r, &x, 4); return r; }
+
+// The necessary test of stage B for TWO pixels at once on packed 16-bit lanes (v_pk_min/max_u16, saturating v_pk_add/sub).
+// Every operand carries its pixel in the HIGH byte of each 16-bit lane; the low byte may hold anything: min / max of such
+// lanes order by the high byte first, and the two threshold comparisons are arranged so that the low byte cannot flip them
+// (dark: (v - t) << 8 > lane  <=>  v - t > pixel;  bright: lane > ((v + t) << 8 | 0xff)  <=>  pixel > v + t, with v + t saturating).
+// Returns a dword whose 16-bit lanes are non-zero exactly for the pixels that pass.
+__device__ __forceinline__ uint32_t fast_pretest_pk(uint32_t c, uint32_t p0, uint32_t p8, uint32_t p4, uint32_t p12, uint32_t p2,
+                                                    uint32_t p10, uint32_t p6, uint32_t p14, uint32_t t_hi) {
+  const u16x2_t a0 = as_u16x2(p0), a8 = as_u16x2(p8), a4 = as_u16x2(p4), a12 = as_u16x2(p12);
+  const u16x2_t a2 = as_u16x2(p2), a10 = as_u16x2(p10), a6 = as_u16x2(p6), a14 = as_u16x2(p14);
+  const u16x2_t maxmin = __builtin_elementwise_max(
+      __builtin_elementwise_max(__builtin_elementwise_min(a0, a8), __builtin_elementwise_min(a4, a12)),
+      __builtin_elementwise_max(__builtin_elementwise_min(a2, a10), __builtin_elementwise_min(a6, a14)));
+  const u16x2_t minmax = __builtin_elementwise_min(
+      __builtin_elementwise_min(__builtin_elementwise_max(a0, a8), __builtin_elementwise_max(a4, a12)),
+      __builtin_elementwise_min(__builtin_elementwise_max(a2, a10), __builtin_elementwise_max(a6, a14)));
+  const u16x2_t T = as_u16x2(t_hi);
+  const u16x2_t lo = __builtin_elementwise_sub_sat(as_u16x2(c & 0xff00ff00u), T);   // max(v - t, 0) << 8
+  const u16x2_t hi = __builtin_elementwise_add_sat(as_u16x2(c | 0x00ff00ffu), T);   // min(v + t, 255) << 8 | 0xff  (0xffff when v + t > 255)
+  return as_u32(__builtin_elementwise_sub_sat(lo, maxmin)) | as_u32(__builtin_elementwise_sub_sat(minmax, hi));
+}
+
+template <int T, int PITCH, bool PK = false>
 __global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
                                                   const uint8_t* __restrict__ imgs, long long img_row_stride,
                                                   long long img_frame_stride, const uint8_t* __restrict__ pyr,
@@ -260,6 +285,22 @@ __global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__
       const uint32_t Q6 = __builtin_amdgcn_alignbyte(fR, fC, 2), Q10 = __builtin_amdgcn_alignbyte(fC, fL, 2);
       const int c0 = 4 * k - xo - 3;                               // detection-domain x of pixel 0
       bool ps[4];
+      if constexpr (PK) {
+        // pixels 1 and 3 sit in the high bytes of the raw dwords' 16-bit lanes, pixels 0 and 2 after a shift by one byte
+        const uint32_t t_hi = (uint32_t)min_th * 0x01000100u;
+        uint32_t rO = fast_pretest_pk(dC, dD, dU, Q4, Q12, Q2, Q10, Q6, Q14, t_hi);
+        uint32_t rE = fast_pretest_pk(dC << 8, dD << 8, dU << 8, Q4 << 8, Q12 << 8, Q2 << 8, Q10 << 8, Q6 << 8, Q14 << 8, t_hi);
+        // validity (x inside the detection domain, lane active) on the same lanes: (unsigned)(c0 + j) < dw, c0 >= -3
+        const uint32_t c0a = act ? (uint32_t)c0 : 0x4000u;
+        const u16x2_t C0 = as_u16x2(__builtin_amdgcn_perm(c0a, c0a, 0x01000100u));
+        const u16x2_t DW = as_u16x2((uint32_t)dw * 0x10001u);
+        const u16x2_t vE = __builtin_elementwise_sub_sat(DW, C0 + as_u16x2(0x00020000u));   // x = c0, c0 + 2
+        const u16x2_t vO = __builtin_elementwise_sub_sat(DW, C0 + as_u16x2(0x00030001u));   // x = c0 + 1, c0 + 3
+        rE = as_u32(__builtin_elementwise_min(as_u16x2(rE), vE));
+        rO = as_u32(__builtin_elementwise_min(as_u16x2(rO), vO));
+        ps[0] = (rE & 0xffffu) != 0; ps[2] = rE > 0xffffu;
+        ps[1] = (rO & 0xffffu) != 0; ps[3] = rO > 0xffffu;
+      } else
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const int v = (dC >> (8 * j)) & 0xff, p0 = (dD >> (8 * j)) & 0xff, p8 = (dU >> (8 * j)) & 0xff;
