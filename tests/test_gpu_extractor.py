@@ -361,3 +361,23 @@ def test_level_quotas_beyond_the_lds_are_served_from_hbm(nf, sf, nlev, rows, col
     assert res[0][1].tobytes() == okps.tobytes() and res[2][1].tobytes() == okps.tobytes()
     o2 = ora.extract(img[::-1].copy(), (0, 0))
     assert res[1][1].tobytes() == o2[0].tobytes() and np.array_equal(res[1][2], o2[1])
+
+
+def test_single_frame_graph_survives_buffer_reallocation():
+    """The single-frame path replays a captured graph; a batch call in between reallocates the staging buffers the graph
+    points to, a different shape re-sizes the pyramid: the next single-frame calls must re-capture and stay correct."""
+    a = synth.make_stream(2, 480, 640, 11)
+    b = synth.make_stream(1, 376, 1241, 12)[0]
+    gpu = ORBextractor(1000, 1.2, 8, 20, 7)
+    ora = po.OracleExtractor(1000, 1.2, 8, 20, 7)
+    wa0, wa1, wb = ora.extract(a[0], (0, 0)), ora.extract(a[1], (0, 0)), ora.extract(b, (0, 0))
+    for _ in range(2):
+        assert_same(gpu(a[0], None, (0, 0)), wa0, "single a0")
+        res = gpu.extract_batch(np.stack([a[1], a[0], a[1], a[0], a[1]]), (0, 0))        # grows the staging block
+        assert res[0][1].tobytes() == wa1[0].tobytes() and res[3][1].tobytes() == wa0[0].tobytes()
+        assert_same(gpu(a[1], None, (0, 0)), wa1, "single a1 after batch")
+        assert_same(gpu(b, None, (0, 0)), wb, "other shape")
+        assert_same(gpu(a[0], None, (0, 1000)), ora.extract(a[0], (0, 1000)), "other lapping area")
+        gpu.set_option("graph", 0)
+        assert_same(gpu(a[0], None, (0, 0)), wa0, "graph off")
+        gpu.set_option("graph", 1)
