@@ -1,14 +1,19 @@
 // orbx extractor kernels for gfx950 (CDNA4, wave64).  Integer/bitwise work, no MFMA.
 //
-//   k_resize      : one pyramid level from the previous one (OpenCV INTER_LINEAR 8u fixed point).
-//   k_fast_cells  : per (frame, 35-px cell): LDS-staged tile -> FAST-9/16 score -> 3x3 NMS inside the cell
-//                   -> iniTh/minTh selection -> ordered compaction (wave ballot + popcount prefix).
-//   k_quadtree    : per (frame, level): DistributeOctTree as flat list + segment partition (ballot ranks),
-//                   libstdc++-exact sort for the tie order.
+//   k_resize      : one pyramid level from the previous one (OpenCV INTER_LINEAR 8u fixed point), 64x64 output tiles,
+//                   source rectangle staged in LDS.
+//   k_fast_cells  : per (frame, 35-px cell): LDS-staged tile -> necessary test on packed 16-bit lanes -> exact FAST-9/16
+//                   score of the survivors -> 3x3 NMS inside the cell -> iniTh/minTh selection -> ordered compaction
+//                   (bitmap + popcount prefix).
+//   k_quadtree    : per (frame, level): DistributeOctTree as flat node list + segment partition (ballot ranks),
+//                   libstdc++-exact sort for the tie order; node arrays in LDS, or in HBM for huge level quotas.
 //   k_assemble    : per frame: output slot of every keypoint (mono side ascending / lapping side descending).
-//   k_blur7       : 7x7 fixed-point Gaussian of every level, 64x32 LDS tiles, v_dot4_u32_u8 horizontal pass.
-//   k_describe    : per keypoint (one wave): 31x31 patch in LDS -> IC angle; 512 taps gathered from the blurred
-//                   level -> 256 steered tests, one wave ballot = 8 descriptor bytes.
+//   k_blur7       : 7x7 fixed-point Gaussian of every level, 64x58 tiles, v_dot4_u32_u8 horizontal and v_dot2_u32_u16
+//                   vertical pass.
+//   k_describe    : K keypoints per wave: IC moments from dword rows (v_dot4 with byte masks, DPP reduction) -> angle,
+//                   cos/sin once per K; 512 taps gathered from the blurred level -> 256 steered tests, one wave ballot =
+//                   8 descriptor bytes.
+//   k_color_to_gray: cv::cvtColor(...2GRAY) behind the upload.
 //
 // Float code relies on -ffp-contract=off (no FMA fusion) and IEEE division; see DESIGN.md "bit-exactness".
 #include <hip/hip_runtime.h>
@@ -1150,12 +1155,12 @@ __global__ __launch_bounds__(256) void k_blur7(const DeviceGeom* __restrict__ g,
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4b: orientation + steered BRIEF, one wave per keypoint.  The kernel is latency-bound (a chain of dependent
-// gathers per keypoint), so it is built for few round trips and no LDS: (1) one 8-byte record per keypoint
-// (written by k_assemble) replaces the level search; (2) the 31x31 circular patch is read straight into registers
-// (two patch rows per wave access, 16 independent byte loads per lane) and the integer moments are reduced with
-// wave shuffles; (3) the rotated test pattern is a packed dword per lane, loaded before the angle is known;
-// (4) 512 taps gathered from the blurred level, one wave ballot = 8 descriptor bytes, one 8-byte store per lane 0..3.
+// K4b: orientation + steered BRIEF.  A wave serves K keypoints one after the other (the cos/sin of all K are computed once,
+// one per lane).  Built for few round trips and no LDS: (1) one 8-byte record per keypoint (written by k_assemble) replaces
+// the level search; (2) the 31x31 circular patch is read as 31 rows x 10 aligned dwords straight into registers, the
+// integer moments are v_dot4 sums with byte masks, reduced over the wave by DPP; (3) the rotated test pattern is a packed
+// dword per lane, loaded before the angle is known; (4) 512 taps gathered from the blurred level, one wave ballot = 8
+// descriptor bytes, one 8-byte store per lane 0..3.  Measured: texture-addresser bound (TA 80 %), VALU 76 %.
 // ------------------------------------------------------------------------------------------------
 struct DescConsts { int umax[16]; };
 
