@@ -6,7 +6,8 @@
  * SearchForInitialization (the heaviest Hamming workload of monocular tracking, src/ORBmatcher.cc:648-763) and
  * SearchByProjection(Frame&, vector<MapPoint*>&, ...) (the per-frame local-map search, :43-141) and
  * SearchByProjection(CurrentFrame, LastFrame, th, bMono) (the motion-model search, :1676-1885) and
- * SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (reference-keyframe tracking / relocalisation, :223-425) are provided in full as
+ * SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (reference-keyframe tracking / relocalisation, :223-425) and
+ * SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse) (LocalMapping, :907-1146) are provided in full as
  * templates over the reference's Frame / MapPoint.  The other routines take KeyFrame / Sophus types that belong to the
  * reference and are out of this repository's scope; INTEGRATION.md shows the few-line change that routes
  * each routine's candidate loop through NearestInCandidates() below while the geometry and the greedy bookkeeping
@@ -15,9 +16,11 @@
 #ifndef ORBMATCHER_H
 #define ORBMATCHER_H
 
+#include <cmath>
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "orbx.h"
@@ -242,6 +245,121 @@ class ORBmatcher {
     if (rc != ORBX_OK) throw std::runtime_error(std::string("ORBmatcher::SearchByBoW: ") + orbx_last_error(DefaultContext()));
     for (int i = 0; i < nf; i++)
       if (match[i] >= 0) vpMapPointMatches[i] = vpMapPointsKF[match[i]];
+    return nmatches;
+  }
+
+  // LocalMapping::CreateNewMapPoints' matcher, src/ORBmatcher.cc:907-1146 (same arguments, same return value, same
+  // vMatchedPairs) for single-camera keyframes.  Every Hamming distance between features of the same vocabulary node is
+  // computed on the GPU in one launch; the epipole test and pCamera1->epipolarConstrain(...) run here through the
+  // reference's own camera objects, only for the candidates the distance tests let through, in the reference's order.
+  template <class KeyFrameT>
+  int SearchForTriangulation(KeyFrameT* pKF1, KeyFrameT* pKF2, std::vector<std::pair<size_t, size_t> >& vMatchedPairs,
+                             const bool bOnlyStereo, const bool bCoarse = false) {
+    if (pKF1->mpCamera2 || pKF2->mpCamera2)
+      throw std::runtime_error("ORBmatcher::SearchForTriangulation: two-camera keyframes are not routed to the GPU");
+    const auto T1w = pKF1->GetPose();
+    const auto T2w = pKF2->GetPose();
+    const auto Tw2 = pKF2->GetPoseInverse();
+    const auto Cw = pKF1->GetCameraCenter();
+    const auto C2 = T2w * Cw;
+    const auto ep = pKF2->mpCamera->project(C2);
+    const auto T12 = T1w * Tw2;
+    const auto R12 = T12.rotationMatrix();
+    const auto t12 = T12.translation();
+    auto* pCamera1 = pKF1->mpCamera;
+    auto* pCamera2 = pKF2->mpCamera;
+    const int n1 = pKF1->N, n2 = pKF2->N;
+    vMatchedPairs.clear();
+    if (n1 == 0 || n2 == 0) return 0;
+    if (!pKF1->mDescriptors.isContinuous() || !pKF2->mDescriptors.isContinuous()) throw std::runtime_error("descriptor matrices must be continuous");
+    // rows: features of KF1 without a map point (and stereo ones only, if asked), in the reference's visiting order;
+    // candidates: the features of KF2 in the same node that have no map point either (:968-996)
+    std::vector<int> q1;
+    std::vector<int32_t> rowPtr(1, 0), cand;
+    std::vector<unsigned char> qd;
+    auto f1it = pKF1->mFeatVec.begin(), f1end = pKF1->mFeatVec.end();
+    auto f2it = pKF2->mFeatVec.begin(), f2end = pKF2->mFeatVec.end();
+    while (f1it != f1end && f2it != f2end) {
+      if (f1it->first == f2it->first) {
+        for (size_t i1 = 0; i1 < f1it->second.size(); i1++) {
+          const size_t idx1 = f1it->second[i1];
+          if (pKF1->GetMapPoint(idx1)) continue;
+          const bool bStereo1 = pKF1->mvuRight[idx1] >= 0;
+          if (bOnlyStereo && !bStereo1) continue;
+          q1.push_back((int)idx1);
+          const unsigned char* d = pKF1->mDescriptors.template ptr<unsigned char>((int)idx1);
+          qd.insert(qd.end(), d, d + 32);
+          for (size_t i2 = 0; i2 < f2it->second.size(); i2++) {
+            const size_t idx2 = f2it->second[i2];
+            if (pKF2->GetMapPoint(idx2)) continue;
+            if (bOnlyStereo && !(pKF2->mvuRight[idx2] >= 0)) continue;
+            cand.push_back((int32_t)idx2);
+          }
+          rowPtr.push_back((int32_t)cand.size());
+        }
+        ++f1it; ++f2it;
+      } else if (f1it->first < f2it->first) {
+        f1it = pKF1->mFeatVec.lower_bound(f2it->first);
+      } else {
+        f2it = pKF2->mFeatVec.lower_bound(f1it->first);
+      }
+    }
+    const int nq = (int)q1.size();
+    std::vector<int32_t> dist(cand.size());
+    if (nq && !cand.empty()) {
+      const int rc = orbx_nn_csr(DefaultContext(), qd.data(), nq, pKF2->mDescriptors.data, n2, rowPtr.data(), cand.data(), 1, nullptr,
+                                 nullptr, nullptr, nullptr, dist.data());
+      if (rc != ORBX_OK) throw std::runtime_error(std::string("ORBmatcher::SearchForTriangulation: ") + orbx_last_error(DefaultContext()));
+    }
+    int nmatches = 0;
+    std::vector<int> vMatches12(n1, -1);
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int q = 0; q < nq; q++) {
+      const size_t idx1 = (size_t)q1[q];
+      const bool bStereo1 = pKF1->mvuRight[idx1] >= 0;
+      const cv::KeyPoint& kp1 = pKF1->mvKeysUn[idx1];
+      int bestDist = TH_LOW, bestIdx2 = -1;
+      for (int c = rowPtr[q]; c < rowPtr[q + 1]; c++) {
+        const size_t idx2 = (size_t)cand[c];
+        const int d = dist[c];
+        if (d > TH_LOW || d > bestDist) continue;
+        const bool bStereo2 = pKF2->mvuRight[idx2] >= 0;
+        const cv::KeyPoint& kp2 = pKF2->mvKeysUn[idx2];
+        if (!bStereo1 && !bStereo2) {
+          const float distex = ep(0) - kp2.pt.x;
+          const float distey = ep(1) - kp2.pt.y;
+          if (distex * distex + distey * distey < 100 * pKF2->mvScaleFactors[kp2.octave]) continue;
+        }
+        if (bCoarse || pCamera1->epipolarConstrain(pCamera2, kp1, kp2, R12, t12, pKF1->mvLevelSigma2[kp1.octave], pKF2->mvLevelSigma2[kp2.octave])) {
+          bestIdx2 = (int)idx2;
+          bestDist = d;
+        }
+      }
+      if (bestIdx2 >= 0) {
+        const cv::KeyPoint& kp2 = pKF2->mvKeysUn[bestIdx2];
+        vMatches12[idx1] = bestIdx2;
+        nmatches++;
+        if (mbCheckOrientation) {
+          float rot = kp1.angle - kp2.angle;
+          if (rot < 0.0) rot += 360.0f;
+          int bin = (int)std::round(rot * factor);
+          if (bin == HISTO_LENGTH) bin = 0;
+          if (bin >= 0 && bin < HISTO_LENGTH) rotHist[bin].push_back((int)idx1);
+        }
+      }
+    }
+    if (mbCheckOrientation) {
+      int ind1 = -1, ind2 = -1, ind3 = -1;
+      ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+      for (int i = 0; i < HISTO_LENGTH; i++) {
+        if (i == ind1 || i == ind2 || i == ind3) continue;
+        for (size_t j = 0; j < rotHist[i].size(); j++) { vMatches12[rotHist[i][j]] = -1; nmatches--; }
+      }
+    }
+    vMatchedPairs.reserve(nmatches);
+    for (size_t i = 0; i < vMatches12.size(); i++)
+      if (vMatches12[i] >= 0) vMatchedPairs.push_back(std::make_pair(i, (size_t)vMatches12[i]));
     return nmatches;
   }
 

@@ -4,6 +4,7 @@
 //   adapter_demo probe
 //   adapter_demo run <img.raw> <rows> <cols> <nfeatures> <lap0> <lap1> <out.bin> [voc.txt]
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -301,6 +302,68 @@ int main(int argc, char** argv) {
       const int nm = matcher.SearchByBoW(&kf, Fb, matches);
       o.write((const char*)&nm, 4);
       for (int i = 0; i < n; i++) { int who = matches[i] ? (int)(matches[i] - &mps[0]) : -1; o.write((const char*)&who, 4); }
+    } else {
+      int nm = -1; o.write((const char*)&nm, 4);
+    }
+    // SearchForTriangulation(pKF1, pKF2, pairs, bOnlyStereo, bCoarse): the frame as two keyframes; a stand-in camera whose
+    // epipolarConstrain accepts rows closer than 3 px (the real ones are the reference's GeometricCamera classes)
+    if (argc >= 10 && n) {
+      ORBVocabulary voc;
+      voc.loadFromTextFile(argv[9]);
+      std::vector<cv::Mat> vdesc;
+      for (int i = 0; i < n; i++) vdesc.push_back(descriptors.row(i));
+      struct TriCam {
+        V2 project(const V3& p) const { return V2{{500.f * (p(0) / p(2)) + 320.f, 500.f * (p(1) / p(2)) + 240.f}}; }
+        bool epipolarConstrain(TriCam*, const cv::KeyPoint& kp1, const cv::KeyPoint& kp2, const int&, const V3&, float, float) const {
+          return std::fabs(kp1.pt.y - kp2.pt.y) < 3.0f;
+        }
+      };
+      struct TriSE3 : MiniSE3 {
+        int rotationMatrix() const { return 0; }
+        TriSE3 operator*(const TriSE3& o) const { TriSE3 r; r.t = V3{{t.v[0] + o.t.v[0], t.v[1] + o.t.v[1], t.v[2] + o.t.v[2]}}; return r; }
+        V3 operator*(const V3& p) const { return MiniSE3::operator*(p); }
+      };
+      struct TriKF {
+        int N = 0;
+        void* mpCamera2 = nullptr;
+        TriCam cam, *mpCamera = &cam;
+        TriSE3 pose;
+        DBoW2::FeatureVector mFeatVec;
+        cv::Mat mDescriptors;
+        std::vector<cv::KeyPoint> mvKeysUn;
+        std::vector<float> mvuRight, mvScaleFactors, mvLevelSigma2;
+        std::vector<MiniMapPoint*> mps;
+        TriSE3 GetPose() const { return pose; }
+        TriSE3 GetPoseInverse() const { TriSE3 r; r.t = V3{{-pose.t.v[0], -pose.t.v[1], -pose.t.v[2]}}; return r; }
+        V3 GetCameraCenter() const { return V3{{-pose.t.v[0], -pose.t.v[1], -pose.t.v[2]}}; }
+        MiniMapPoint* GetMapPoint(size_t i) const { return mps[i]; }
+      } k1, k2;
+      DBoW2::BowVector bow;
+      voc.transform(vdesc, bow, k1.mFeatVec, 2);
+      k2.mFeatVec = k1.mFeatVec;
+      MiniMapPoint some;
+      for (TriKF* k : {&k1, &k2}) {
+        k->N = n; k->mDescriptors = descriptors.clone(); k->mvKeysUn = keys;
+        k->mvScaleFactors = extractor->GetScaleFactors(); k->mvLevelSigma2 = extractor->GetScaleSigmaSquares();
+        k->mvuRight.assign(n, -1.f); k->mps.assign(n, nullptr);
+      }
+      k2.pose.t = V3{{0.2f, 0.f, 2.0f}};   // epipole of camera 1 in image 2: (0.2/2*500+320, 240) = (370, 240)
+      for (int i = 0; i < n; i++) {
+        if (i % 5 == 0) k1.mps[i] = &some;      // already has a map point
+        if (i % 7 == 0) k2.mps[i] = &some;
+        if (i % 3 == 0) k1.mvuRight[i] = 10.f;  // stereo observation
+        if (i % 4 == 0) k2.mvuRight[i] = 10.f;
+        k2.mvKeysUn[i].pt.y += (float)(i % 6) - 2.0f;   // so that the epipolar stand-in rejects some pairs
+      }
+      for (int pass = 0; pass < 2; pass++) {
+        std::vector<std::pair<size_t, size_t> > pairs;
+        ORBmatcher matcher(0.6f, pass == 0);
+        const int nm = matcher.SearchForTriangulation(&k1, &k2, pairs, pass == 1, false);
+        o.write((const char*)&nm, 4);
+        const int np = (int)pairs.size();
+        o.write((const char*)&np, 4);
+        for (auto& pr : pairs) { int a = (int)pr.first, b = (int)pr.second; o.write((const char*)&a, 4); o.write((const char*)&b, 4); }
+      }
     } else {
       int nm = -1; o.write((const char*)&nm, 4);
     }

@@ -67,8 +67,19 @@ def _read(path):
     nlast = take("<i")
     last = np.frombuffer(b, np.int32, n, off); off += 4 * n
     nbow = take("<i")
-    bowm = np.frombuffer(b, np.int32, n, off) if nbow >= 0 else None
-    return mono, kps, desc, pyr, d01, bow, fv, self_score, nm, m12, nproj, proj, nlast, last, nbow, bowm
+    bowm = None
+    if nbow >= 0:
+        bowm = np.frombuffer(b, np.int32, n, off); off += 4 * n
+    tri = []
+    ntri = take("<i")
+    if ntri >= 0:
+        for p in range(2):
+            if p:
+                ntri = take("<i")
+            npairs = take("<i")
+            pairs = np.frombuffer(b, np.int32, 2 * npairs, off).reshape(npairs, 2); off += 8 * npairs
+            tri.append((ntri, pairs))
+    return mono, kps, desc, pyr, d01, bow, fv, self_score, nm, m12, nproj, proj, nlast, last, nbow, bowm, tri
 
 
 @pytest.mark.gpu
@@ -86,7 +97,7 @@ def test_adapter_results_equal_oracle(tmp_path, rows, cols, lap):
     make_vocabulary(vocp, odesc, 6, 3, seed=3)
     r = subprocess.run([exe, "run", raw, str(rows), str(cols), "1000", str(lap[0]), str(lap[1]), out, vocp], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    mono, kps, desc, pyr, d01, bow, fv, self_score, nm, m12, nproj, proj, nlast, last, nbow, bowm = _read(out)
+    mono, kps, desc, pyr, d01, bow, fv, self_score, nm, m12, nproj, proj, nlast, last, nbow, bowm, tri = _read(out)
     assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc)
     for l in range(8):
         assert np.array_equal(pyr[l], ora.level(l))
@@ -129,6 +140,62 @@ def test_adapter_results_equal_oracle(tmp_path, rows, cols, lap):
     valid = ((i % 4 != 0) & (i % 9 != 0)).astype(np.uint8)
     on, omatch = po.search_by_bow(odesc, okps["angle"], valid, ofv, odesc, okps["angle"], ofv, 0.7, True)
     assert nbow == on and np.array_equal(bowm, omatch) and on > 100
+    # SearchForTriangulation through the C++ template (src/ORBmatcher.cc:907-1146), restated here on the same stand-in geometry
+    f32 = np.float32
+    y2 = (okps["y"] + ((i % 6).astype(f32) - f32(2.0))).astype(f32)
+    has1, has2 = i % 5 == 0, i % 7 == 0
+    st1, st2 = i % 3 == 0, i % 4 == 0
+    epx, epy = f32(500.0) * (f32(0.2) / f32(2.0)) + f32(320.0), f32(500.0) * (f32(0.0) / f32(2.0)) + f32(240.0)
+    for (ntri, pairs), (ori, only_stereo) in zip(tri, ((True, False), (False, True))):
+        m12w = np.full(n, -1)
+        hist = [[] for _ in range(30)]
+        cnt = 0
+        for node in sorted(ofv):
+            for idx1 in ofv[node]:
+                if has1[idx1] or (only_stereo and not st1[idx1]):
+                    continue
+                best, bidx = 50, -1
+                for idx2 in ofv[node]:
+                    if has2[idx2] or (only_stereo and not st2[idx2]):
+                        continue
+                    d = po.hamming(odesc[idx1], odesc[idx2])
+                    if d > 50 or d > best:
+                        continue
+                    if not st1[idx1] and not st2[idx2]:
+                        dx, dy = f32(epx - okps["x"][idx2]), f32(epy - y2[idx2])
+                        if f32(f32(dx * dx) + f32(dy * dy)) < f32(100) * sf[okps["octave"][idx2]]:
+                            continue
+                    if abs(f32(okps["y"][idx1] - y2[idx2])) < f32(3.0):
+                        bidx, best = idx2, d
+                if bidx >= 0:
+                    m12w[idx1] = bidx; cnt += 1
+                    if ori:
+                        rot = f32(okps["angle"][idx1] - okps["angle"][bidx])
+                        if rot < 0:
+                            rot = f32(rot + f32(360.0))
+                        b_ = int(np.floor(float(f32(rot * f32(1.0 / 30))) + 0.5))      # C round(): half away from zero, rot >= 0
+                        hist[0 if b_ == 30 else b_].append(idx1)
+        if ori:
+            sizes = [len(h) for h in hist]
+            i1 = i2 = i3 = -1; m1 = m2 = m3 = 0
+            for k_, s_ in enumerate(sizes):
+                if s_ > m1:
+                    m3, m2, m1, i3, i2, i1 = m2, m1, s_, i2, i1, k_
+                elif s_ > m2:
+                    m3, m2, i3, i2 = m2, s_, i2, k_
+                elif s_ > m3:
+                    m3, i3 = s_, k_
+            if m2 < f32(0.1) * f32(m1):
+                i2 = i3 = -1
+            elif m3 < f32(0.1) * f32(m1):
+                i3 = -1
+            for k_ in range(30):
+                if k_ in (i1, i2, i3):
+                    continue
+                for idx1 in hist[k_]:
+                    m12w[idx1] = -1; cnt -= 1
+        want = np.array([(a, m12w[a]) for a in range(n) if m12w[a] >= 0], np.int32).reshape(-1, 2)
+        assert ntri == cnt and np.array_equal(pairs, want) and cnt > 20
 
 
 @pytest.mark.gpu
