@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--nfeatures", type=int, default=1000)
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the batch-replay RCCL all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the cpu_baseline leg")
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("ORBX_LANES", "2")),
                     help="extractor contexts per GPU, each on its own free-running stream over 1/lanes of the batch")
     args = ap.parse_args()
@@ -232,7 +233,7 @@ def main():
                          "kernels_ms_per_launch": {k: round(v, 4) for k, v in per_kernel.items()}},
         }
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(host_frames, args.nfeatures)
+            result["cpu_baseline"] = cpu_baseline(host_frames, args.nfeatures, args.cpu_budget)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

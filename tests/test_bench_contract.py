@@ -1,0 +1,41 @@
+"""bench.py's contract with the driver: without a GPU it refuses loudly (there is no CPU fallback); on a GPU it prints
+exactly one JSON line with the agreed keys, the roofline object and the cpu_baseline object."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_refuses_without_gpu():
+    from tests.conftest import HAS_GPU
+    if HAS_GPU:
+        pytest.skip("GPU present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode != 0 and "no CPU fallback" in (r.stdout + r.stderr)
+
+
+@pytest.mark.gpu
+def test_bench_json_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--cpu-budget", "2"],
+                       capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["unit"] == "features/ms" and j["n_gpus"] == 1 and j["steps"] == 4 and j["warmup"] == 1 and j["higher_is_better"] is True
+    assert j["scaling"] == "weak" and j["vs_baseline"] is None and j["dtype"] == "u8" and j["data"] == "synthetic"
+    assert "workload" in j["config"] and "model" not in j["config"]
+    assert j["value"] > 50000 and abs(j["value"] * j["ms_per_step"] - 256 * j["config"]["features_per_frame"]) < 0.01 * 256 * 1005
+    rf = j["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and 0 < rf["frac"] < 1
+    assert rf["traffic"] is None or rf["traffic"] > 0
+    cb = j["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "features/ms" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
