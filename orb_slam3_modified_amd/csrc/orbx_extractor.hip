@@ -469,6 +469,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
     const int K = ctx->desc_k;  // keypoints per wave
     const int gpf = (ctx->out_cap + 4 * K - 1) / (4 * K), nitems = gpf * nframes;
     auto kern = K == 1 ? k_describe<1> : K == 2 ? k_describe<2> : K == 4 ? k_describe<4> : K == 8 ? k_describe<8> : k_describe<16>;
+    if (ctx->desc_lds && (K == 2 || K == 4 || K == 8)) kern = K == 2 ? k_describe<2, true> : K == 4 ? k_describe<4, true> : k_describe<8, true>;
     hipLaunchKernelGGL(kern, dim3(xcd_grid(nitems)), dim3(256), 0, st, ctx->d_geo, d_imgs, (long long)row_stride,
                        (long long)frame_stride, b_pyr, (long long)geo.pyr_bytes, b_blur, (long long)geo.blur_bytes,
                        b_kp_list, d_counts, d_kps, d_desc, dc, gpf, nitems, div_magic((uint32_t)gpf));
@@ -552,6 +553,8 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, 
     const char* ff = getenv("ORBX_FORK_FAST0");
     const char* fpk = getenv("ORBX_FAST_PK");   // packed 16-bit necessary test in k_fast_cells (128-thread workgroups)
     ctx->fast_pk = fpk ? atoi(fpk) != 0 : true;
+    const char* dl = getenv("ORBX_DESC_LDS");   // blurred 37x37 window staged in LDS for the descriptor taps
+    ctx->desc_lds = dl ? atoi(dl) != 0 : true;
     const char* fq = getenv("ORBX_FORK_QT");
     ctx->fork_qt = fq ? atoi(fq) != 0 : true;
     ctx->fork_fast0 = ff ? atoi(ff) != 0 : false;  // measured: no gain (both kernels already fill the CUs), kept as a knob
@@ -895,6 +898,7 @@ int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
   else if (n == "fork_qt") ctx->fork_qt = value != 0;
   else if (n == "graph") ctx->use_graph = value != 0;
   else if (n == "fast_pk") ctx->fast_pk = value != 0;
+  else if (n == "desc_lds") ctx->desc_lds = value != 0;
   else if (n == "fast_threads" && (value == 64 || value == 128 || value == 256)) ctx->fast_threads = value;
   else if (n == "desc_k" && (value == 1 || value == 2 || value == 4 || value == 8 || value == 16)) ctx->desc_k = value;
   else if (n == "streams" && value >= 1 && value <= 2) ctx->nstreams = value;

@@ -1156,11 +1156,13 @@ __global__ __launch_bounds__(256) void k_blur7(const DeviceGeom* __restrict__ g,
 
 // ------------------------------------------------------------------------------------------------
 // K4b: orientation + steered BRIEF.  A wave serves K keypoints one after the other (the cos/sin of all K are computed once,
-// one per lane).  Built for few round trips and no LDS: (1) one 8-byte record per keypoint (written by k_assemble) replaces
-// the level search; (2) the 31x31 circular patch is read as 31 rows x 10 aligned dwords straight into registers, the
-// integer moments are v_dot4 sums with byte masks, reduced over the wave by DPP; (3) the rotated test pattern is a packed
-// dword per lane, loaded before the angle is known; (4) 512 taps gathered from the blurred level, one wave ballot = 8
-// descriptor bytes, one 8-byte store per lane 0..3.  Measured: texture-addresser bound (TA 80 %), VALU 76 %.
+// one per lane).  (1) One 8-byte record per keypoint (written by k_assemble) replaces the level search; (2) the 31x31
+// circular patch of the UNBLURRED level is read once, as 31 rows x 10 aligned dwords straight into registers — the integer
+// moments are v_dot4 sums with byte masks, reduced over the wave by DPP; (3) the rotated test pattern is a packed dword per
+// lane, loaded before the angle is known; (4) the 37x37 window of the BLURRED level the 512 taps fall into is staged in
+// the wave's LDS slice with 6 coalesced dword loads and the taps are LDS byte reads (LDSP; without it they are 8 scattered
+// byte gathers per lane, which made the kernel texture-addresser bound: TA 80 %, 0.222 ms -> 0.198 ms with the window in
+// LDS); one wave ballot = 8 descriptor bytes, one 8-byte store per lane 0..3.
 // ------------------------------------------------------------------------------------------------
 struct DescConsts { int umax[16]; };
 
@@ -1199,7 +1201,7 @@ __device__ __forceinline__ int wave_sum_lane63(int v) {
 
 // K keypoints per wave: the cos/sin/atan2 evaluation (the largest VALU block, identical in all 64 lanes for one
 // keypoint) is done once for K keypoints held in lanes 0..K-1.
-template <int K>
+template <int K, bool LDSP = false>
 __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__ g, const uint8_t* __restrict__ imgs,
                                                   long long img_row_stride, long long img_frame_stride,
                                                   const uint8_t* __restrict__ pyr, long long pyr_frame_bytes,
@@ -1306,6 +1308,34 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
     const int bp = lv.pitch;
     const int ctr = __mul24(ky, bp) + kx;  // taps stay >= 1 px inside the plane: offsets are non-negative
     int t0[4], t1[4];
+    if constexpr (LDSP) {
+      // Variant: the 37 x 37 window of the blurred level staged in this wave's LDS slice (37 rows x 10 aligned dwords,
+      // coalesced loads), the 512 taps read from LDS instead of 8 scattered byte gathers per lane.  The window starts at
+      // the dword below kx - 18: at most 2 bytes before / after the row, inside the plane's pitch or the neighbouring row.
+      __shared__ __align__(16) uint8_t s_patch[4][37 * 40];
+      uint8_t* sp = s_patch[w];
+      const int sh2 = (kx - 18) & 3;
+      const uint32_t wbase = (uint32_t)(__mul24(ky - 18, bp) + (kx - 18 - sh2));
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        const int it = lane + 64 * i;
+        const int r = (int)(((uint32_t)it * 6554u) >> 16), dcol = it - r * 10;  // it / 10
+        if (it < 370) ((uint32_t*)sp)[it] = *(const uint32_t*)(bplane + (wbase + (uint32_t)(__mul24(r, bp) + 4 * dcol)));
+      }
+      wave_lds_sync();
+      const int lctr = 18 * 40 + 18 + sh2;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const float x0 = (float)pat[q].x, y0 = (float)pat[q].y, x1 = (float)pat[q].z, y1 = (float)pat[q].w;
+        const int ry0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
+        const int rx0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+        const int ry1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
+        const int rx1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+        t0[q] = sp[lctr + __mul24(ry0, 40) + rx0];
+        t1[q] = sp[lctr + __mul24(ry1, 40) + rx1];
+      }
+      wave_lds_sync();   // the next keypoint overwrites the slice
+    } else
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const float x0 = (float)pat[q].x, y0 = (float)pat[q].y, x1 = (float)pat[q].z, y1 = (float)pat[q].w;
