@@ -1215,8 +1215,10 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
   const int frame = fast_div(L, m_gpf);
   const int g0 = ((L - frame * groups_per_frame) * 4 + w) * K;  // first keypoint (level-major index) of this wave
   const int total = counts[frame * 2];
-  if (g0 >= total) return;  // wave-uniform
-  const int nk = min(K, total - g0);
+  // the block's first wave always has work (or the whole block is past the frame's keypoints): later waves without keypoints
+  // still take part in the two workgroup barriers below
+  if (((L - frame * groups_per_frame) * 4) * K >= total) return;  // block-uniform
+  const int nk = max(0, min(K, total - g0));
   uint2 rec = make_uint2(0u, 0u);
   if (lane < nk) rec = kp_list[(long long)frame * g->out_cap + g0 + lane];
   // rotated-pattern operands: independent of the keypoints, issued first
@@ -1288,11 +1290,21 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
     m01 = __builtin_amdgcn_readlane(wave_sum_lane63(m01), 63);
     if (lane == k) { my_m10 = m10; my_m01 = m01; }
   }
-  // ---- angle, cos, sin of the K keypoints, one per lane
-  const float my_angle = fast_atan2_deg((float)my_m01, (float)my_m10);
-  const float factorPI = (float)(3.14159265358979323846 / 180.f);
-  const float my_rad = __fmul_rn(my_angle, factorPI);
-  const float my_a = orbx_glibc::cosf_exact(my_rad), my_b = orbx_glibc::sinf_exact(my_rad);
+  // ---- angle, cos, sin: ONE pass of the (long, glibc-exact) trig code per workgroup — wave 0 computes them for the 4 K
+  // keypoints of all four waves, one per lane, instead of every wave running the pass for its own K lanes
+  __shared__ int s_mom[4 * K][2];
+  __shared__ float s_trig[4 * K][3];
+  if (lane < nk) { s_mom[w * K + lane][0] = my_m01; s_mom[w * K + lane][1] = my_m10; }
+  __syncthreads();
+  if (w == 0 && lane < 4 * K) {   // entries of waves without keypoints hold garbage; nobody reads their results
+    const float ang = fast_atan2_deg((float)s_mom[lane][0], (float)s_mom[lane][1]);
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    const float rad = __fmul_rn(ang, factorPI);
+    s_trig[lane][0] = ang; s_trig[lane][1] = orbx_glibc::cosf_exact(rad); s_trig[lane][2] = orbx_glibc::sinf_exact(rad);
+  }
+  __syncthreads();
+  float my_angle = 0.f, my_a = 0.f, my_b = 0.f;
+  if (lane < nk) { my_angle = s_trig[w * K + lane][0]; my_a = s_trig[w * K + lane][1]; my_b = s_trig[w * K + lane][2]; }
   // ---- steered BRIEF (src/ORBextractor.cc:107-146) on the blurred level
 #pragma unroll 1
   for (int k = 0; k < nk; k++) {
