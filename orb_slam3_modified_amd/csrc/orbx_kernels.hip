@@ -1080,17 +1080,27 @@ __global__ __launch_bounds__(256) void k_blur7(const DeviceGeom* __restrict__ g,
   if (al) {
     // dwords that start inside [0, w) are loaded (a row is readable up to its 4-byte rounded width), the others and the
     // reflected columns are patched below
-    for (int i = t; i < kBT_RR * (kBT_RB / 4); i += 256) {
-      const int r = (int)(((uint32_t)i * 3641u) >> 16), c = i - r * (kBT_RB / 4);  // i / 18
+    // thread = (column c of 18 dwords, row phase of 14): everything that depends on the column only is computed once,
+    // the thread then walks down its column 14 rows at a time (252 of the 256 threads take part)
+    if (t < 14 * (kBT_RB / 4)) {
+      const int rph = (int)(((uint32_t)t * 3641u) >> 16), c = t - rph * (kBT_RB / 4);  // t / 18
       const int sx = x0 - 4 + 4 * c;
-      // reflect-101 row: one reflection covers every row a stored output reads (h >= 67); rows further below the
-      // level (only in the last tile row, never stored) just need a valid address
-      int sy = y0 - 3 + r;
-      sy = sy < 0 ? -sy : (sy >= h ? 2 * h - 2 - sy : sy);
-      sy = max(sy, 0);
-      uint32_t v = 0;
-      if (sx >= 0 && sx < w) v = *(const uint32_t*)(img + (uint32_t)(__mul24(sy, pitch) + sx));
-      ((uint32_t*)raw)[r * (kBT_RP / 4) + c] = v;
+      const bool inx = sx >= 0 && sx < w;
+      uint32_t* dstp = (uint32_t*)raw + rph * (kBT_RP / 4) + c;
+#pragma unroll
+      for (int k = 0; k < (kBT_RR + 13) / 14; k++) {
+        const int r = rph + 14 * k;
+        if (r < kBT_RR) {
+          // reflect-101 row: one reflection covers every row a stored output reads (h >= 67); rows further below the
+          // level (only in the last tile row, never stored) just need a valid address
+          int sy = y0 - 3 + r;
+          sy = sy < 0 ? -sy : (sy >= h ? 2 * h - 2 - sy : sy);
+          sy = max(sy, 0);
+          uint32_t v = 0;
+          if (inx) v = *(const uint32_t*)(img + (uint32_t)(__mul24(sy, pitch) + sx));
+          dstp[k * 14 * (kBT_RP / 4)] = v;
+        }
+      }
     }
     const bool left = x0 == 0, right = x0 + kBT_W + 3 > w;  // block-uniform
     if (left || right) {
@@ -1146,8 +1156,9 @@ __global__ __launch_bounds__(256) void k_blur7(const DeviceGeom* __restrict__ g,
       e[c] = udot2(p3, bc.we[3], udot2(p2, bc.we[2], udot2(p1, bc.we[1], udot2(p0, bc.we[0], 32768u))));
       o[c] = udot2(p3, bc.wo[3], udot2(p2, bc.wo[2], udot2(p1, bc.wo[1], udot2(p0, bc.wo[0], 32768u))));
     }
-    const uint32_t pe = (e[0] >> 16) | ((e[1] >> 16) << 8) | ((e[2] >> 16) << 16) | ((e[3] >> 16) << 24);
-    const uint32_t po = (o[0] >> 16) | ((o[1] >> 16) << 8) | ((o[2] >> 16) << 16) | ((o[3] >> 16) << 24);
+    // byte 2 of each 32-bit sum is the rounded pixel ((acc + 2^15) >> 16 <= 255): three byte permutes pack four of them
+    const uint32_t pe = __builtin_amdgcn_perm(__builtin_amdgcn_perm(e[3], e[2], 0x0c0c0602u), __builtin_amdgcn_perm(e[1], e[0], 0x0c0c0602u), 0x05040100u);
+    const uint32_t po = __builtin_amdgcn_perm(__builtin_amdgcn_perm(o[3], o[2], 0x0c0c0602u), __builtin_amdgcn_perm(o[1], o[0], 0x0c0c0602u), 0x05040100u);
     const uint32_t o0 = (uint32_t)(__mul24(y, lv.pitch) + x);
     *(uint32_t*)(bl + o0) = pe;
     if (y + 1 < h) *(uint32_t*)(bl + o0 + (uint32_t)lv.pitch) = po;
