@@ -356,7 +356,8 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
       hipLaunchKernelGGL(k_resize, dim3(xcd_grid(nitems)), dim3(256), (size_t)D.rs_lds_pitch * D.rs_lds_rows, st, src, sfs, sp,
                          S.w, b_pyr + D.plane_off, (long long)geo.pyr_bytes, D.pitch, D.w, D.h, ctx->d_xtab + D.xtab_off,
                          ctx->d_ytab + D.ytab_off, nbx, nby, nitems, D.rs_lds_pitch, D.rs_lds_rows,
-                         div_magic((uint32_t)(nbx * nby)), div_magic((uint32_t)nbx), div_magic((uint32_t)(D.rs_lds_pitch / 4)));
+                         div_magic((uint32_t)(nbx * nby)), div_magic((uint32_t)nbx), div_magic((uint32_t)(D.rs_lds_pitch / 4)),
+                         256 / (D.rs_lds_pitch / 4));
       if (!div_ok((uint64_t)nitems + 8, (uint64_t)nbx * nby)) return set_err(ctx, ORBX_E_CAPACITY, "batch too large for 32-bit tile indexing");
     }
   }

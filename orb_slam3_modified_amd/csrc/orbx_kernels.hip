@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
                                                 long long dst_frame_stride, int dst_pitch, int dw, int dh,
                                                 const XTab* __restrict__ xt, const XTab* __restrict__ yt, int nbx,
                                                 int nby, int nitems, int lds_pitch, int lds_rows, uint32_t m_tiles,
-                                                uint32_t m_nbx, uint32_t m_lp4) {
+                                                uint32_t m_nbx, uint32_t m_lp4, int nph) {
   extern __shared__ __align__(16) uint8_t smem[];
   const int t = threadIdx.x;
   const int L = xcd_logical_block(nitems);
@@ -93,10 +93,13 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
   if (nrows > lds_rows || ncolb > lds_pitch) return;  // host sized the tile from the same tables: cannot happen
   if (al) {
     // whole LDS rows (lds_pitch >= the widest source rectangle of the level): LDS dword index == loop index
+    // thread = (dword column c, row phase of nph = 256 / lp4): the column-only work once, then down the column nph rows at a time
     const int lp4 = lds_pitch >> 2, swr = (sw + 3) & ~3;
-    for (int i = t; i < nrows * lp4; i += 256) {
-      const int r = fast_div(i, m_lp4), c = i - r * lp4;
-      if (X0 + 4 * c < swr) ((uint32_t*)smem)[i] = *(const uint32_t*)(S + (uint32_t)(__mul24(r, src_pitch) + 4 * c));
+    const int rph = fast_div(t, m_lp4), c = t - rph * lp4;
+    if (rph < nph && X0 + 4 * c < swr) {
+      const uint8_t* sp = S + 4 * c;
+      uint32_t* dp = (uint32_t*)smem + c;
+      for (int r = rph; r < nrows; r += nph) dp[__mul24(r, lp4)] = *(const uint32_t*)(sp + (uint32_t)__mul24(r, src_pitch));
     }
   } else {
 #pragma unroll 1  // cold path: keep it out of the register budget
