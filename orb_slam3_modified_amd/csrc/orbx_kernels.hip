@@ -1342,11 +1342,18 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
       uint8_t* sp = s_patch[w];
       const int sh2 = (kx - 18) & 3;
       const uint32_t wbase = (uint32_t)(__mul24(ky - 18, bp) + (kx - 18 - sh2));
+      {  // lane = (dword column of 10, row phase of 6): walks down its column six rows at a time (60 lanes take part)
+        const int rph = (int)(((uint32_t)lane * 6554u) >> 16), dcol = lane - rph * 10;  // lane / 10
+        uint32_t off = wbase + (uint32_t)(__mul24(rph, bp) + 4 * dcol);
+        const uint32_t step = 6u * (uint32_t)bp;
+        uint32_t* lp = (uint32_t*)sp + lane;   // row rph, column dcol
+        if (lane < 60) {
 #pragma unroll
-      for (int i = 0; i < 6; i++) {
-        const int it = lane + 64 * i;
-        const int r = (int)(((uint32_t)it * 6554u) >> 16), dcol = it - r * 10;  // it / 10
-        if (it < 370) ((uint32_t*)sp)[it] = *(const uint32_t*)(bplane + (wbase + (uint32_t)(__mul24(r, bp) + 4 * dcol)));
+          for (int k = 0; k < 7; k++) {
+            if (rph + 6 * k < 37) lp[60 * k] = *(const uint32_t*)(bplane + off);
+            off += step;
+          }
+        }
       }
       wave_lds_sync();
       const int lctr = 18 * 40 + 18 + sh2;
