@@ -99,7 +99,8 @@ int orbx_pyramid_level(orbx_ctx* ctx, int frame, int level, uint8_t* dst, size_t
 int orbx_set_host_pyramid(orbx_ctx* ctx, int on);
 /* Scheduling / launch-shape knobs of one context (results never depend on them); the ORBX_* environment variables set
  * the defaults at orbx_create.  name: "fork_blur" | "fork_fast0" | "fork_qt" (0|1: run that kernel on a second stream
- * beside its neighbour), "graph" (0|1), "fast_threads" (64|128|256), "desc_k" (1|2|4|8|16), "streams" (1|2). */
+ * beside its neighbour), "graph" (0|1), "fast_threads" (64|128|256), "fast_pk" (0|1), "desc_k" (1|2|4|8|16),
+ * "desc_lds" (0|1), "streams" (1|2). */
 int orbx_set_option(orbx_ctx* ctx, const char* name, int value);
 int orbx_host_pyramid_level(orbx_ctx* ctx, int level, const uint8_t** data, size_t* stride, int* w, int* h);
 
