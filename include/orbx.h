@@ -97,6 +97,9 @@ int orbx_pyramid_level(orbx_ctx* ctx, int frame, int level, uint8_t* dst, size_t
  * (the reference re-points mvImagePyramid on every call too).  Level 0 is the caller's own image:
  * *data = NULL. */
 int orbx_set_host_pyramid(orbx_ctx* ctx, int on);
+/* Allocate the context's device buffers for batches of up to `nframes` frames of rows x cols now instead of inside the
+ * first extraction call (the buffers are persistent and grow-only; a later call with another shape re-sizes them). */
+int orbx_reserve(orbx_ctx* ctx, int rows, int cols, int nframes);
 /* Scheduling / launch-shape knobs of one context (results never depend on them); the ORBX_* environment variables set
  * the defaults at orbx_create.  name: "fork_blur" | "fork_fast0" | "fork_qt" (0|1: run that kernel on a second stream
  * beside its neighbour), "graph" (0|1), "fast_threads" (64|128|256), "fast_pk" (0|1), "desc_k" (1|2|4|8|16),

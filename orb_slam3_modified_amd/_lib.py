@@ -80,6 +80,7 @@ def lib() -> C.CDLL:
         "orbx_voc_load_text": (i32, [vp, C.c_char_p, C.POINTER(vp)]),
         "orbx_voc_create": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, C.POINTER(vp)]),
         "orbx_set_option": (i32, [vp, C.c_char_p, i32]),
+        "orbx_reserve": (i32, [vp, i32, i32, i32]),
         "orbx_voc_save_text": (i32, [vp, C.c_char_p]),
         "orbx_voc_save_binary": (i32, [vp, C.c_char_p]),
         "orbx_voc_load_binary": (i32, [vp, C.c_char_p, C.POINTER(vp)]),

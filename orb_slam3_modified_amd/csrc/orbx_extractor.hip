@@ -891,6 +891,12 @@ int orbx_pyramid_level(orbx_ctx* ctx, int frame, int level, uint8_t* dst, size_t
   return ORBX_OK;
 }
 
+int orbx_reserve(orbx_ctx* ctx, int rows, int cols, int nframes) {
+  if (!ctx || rows <= 0 || cols <= 0 || nframes <= 0 || nframes > 65535) return ctx ? set_err(ctx, ORBX_E_INVALID, "orbx_reserve: bad arguments") : ORBX_E_INVALID;
+  ORBX_HIP(ctx, hipSetDevice(ctx->device));
+  return ensure_buffers(ctx, rows, cols, nframes);
+}
+
 int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
   if (!ctx || !name) return ORBX_E_INVALID;
   const std::string n(name);

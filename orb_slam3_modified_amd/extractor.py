@@ -171,6 +171,10 @@ class ORBextractor:
         """Known-traffic device copy (counter calibration, tools/pmc_traffic.py)."""
         check(self._L.orbx_debug_calib_copy(self._ctx, ptr(d_src), ptr(d_dst), nbytes, width, ptr(stream)), self._ctx)
 
+    def reserve(self, rows: int, cols: int, nframes: int) -> None:
+        """Allocate the device buffers for batches of this shape now (orbx_reserve) rather than in the first call."""
+        check(self._L.orbx_reserve(self._ctx, int(rows), int(cols), int(nframes)), self._ctx)
+
     def set_option(self, name: str, value: int) -> None:
         """Scheduling knob of this context (orbx_set_option); never changes results."""
         check(self._L.orbx_set_option(self._ctx, name.encode(), int(value)), self._ctx)

