@@ -23,6 +23,10 @@
 #include "orbx.h"
 #include "orbx_cv_compat.h"
 
+// Same include guards as the reference's Thirdparty/DBoW2/DBoW2/BowVector.h / FeatureVector.h: where those (or a stand-in
+// for them) were included first, their classes are the ones used.
+#ifndef __D_T_BOW_VECTOR__
+#define __D_T_BOW_VECTOR__
 namespace DBoW2 {
 
 typedef unsigned int WordId;
@@ -39,6 +43,12 @@ class BowVector : public std::map<WordId, WordValue> {
   }
 };
 
+}  // namespace DBoW2
+#endif
+#ifndef __D_T_FEATURE_VECTOR__
+#define __D_T_FEATURE_VECTOR__
+namespace DBoW2 {
+
 class FeatureVector : public std::map<NodeId, std::vector<unsigned int> > {
  public:
   // FeatureVector.cpp:30-45
@@ -53,6 +63,7 @@ class FeatureVector : public std::map<NodeId, std::vector<unsigned int> > {
 };
 
 }  // namespace DBoW2
+#endif
 
 namespace ORB_SLAM3 {
 

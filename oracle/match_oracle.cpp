@@ -773,3 +773,130 @@ int mo_kfdb_query(void* h, const uint32_t* q_ids, const double* q_vals, int nq, 
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// Generic window primitives over a caller-held grid (the device entry points orbx_window_search_grid /
+// orbx_window_nearest compute the same): Frame::GetFeaturesInArea (src/Frame.cc:657-723) == KeyFrame::GetFeaturesInArea
+// (src/KeyFrame.cc:704-748, no level filter there: pass -1 / -1) for a list of queries, every candidate's
+// DescriptorDistance, and the running best / second of the candidate loops (src/ORBmatcher.cc:96-118).
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+struct MoGrid {   // == orbx_grid (include/orbx.h)
+  float min_x, min_y, inv_w, inv_h;
+  const int32_t* cell_start;   // [64*48 + 1] over cells in mGrid[ix][iy] order (ix major), or NULL: assign here
+  const int32_t* cell_idx;
+};
+
+struct GridCells {
+  std::vector<int32_t> start, idx;
+  float minX, minY, invW, invH;
+  const MKeyPt* kps;
+  GridCells(const MKeyPt* k, int n, const MoGrid& g) : minX(g.min_x), minY(g.min_y), invW(g.inv_w), invH(g.inv_h), kps(k) {
+    const int ncell = kGridCols * kGridRows;
+    if (g.cell_start) {
+      start.assign(g.cell_start, g.cell_start + ncell + 1);
+      idx.assign(g.cell_idx, g.cell_idx + start[ncell]);
+      return;
+    }
+    // Frame::AssignFeaturesToGrid / PosInGrid (src/Frame.cc:385-416, :725-735)
+    std::vector<std::vector<int32_t> > cell(ncell);
+    for (int i = 0; i < n; i++) {
+      const int posX = (int)std::round((kps[i].x - minX) * invW);
+      const int posY = (int)std::round((kps[i].y - minY) * invH);
+      if (posX < 0 || posX >= kGridCols || posY < 0 || posY >= kGridRows) continue;
+      cell[posX * kGridRows + posY].push_back(i);
+    }
+    start.assign(1, 0);
+    for (int c = 0; c < ncell; c++) { idx.insert(idx.end(), cell[c].begin(), cell[c].end()); start.push_back((int32_t)idx.size()); }
+  }
+  template <class Fn>
+  void area(float x, float y, float r, int minLevel, int maxLevel, Fn&& fn) const {
+    const float factorX = r, factorY = r;
+    const int nMinCellX = std::max(0, (int)std::floor((x - minX - factorX) * invW));
+    if (nMinCellX >= kGridCols) return;
+    const int nMaxCellX = std::min(kGridCols - 1, (int)std::ceil((x - minX + factorX) * invW));
+    if (nMaxCellX < 0) return;
+    const int nMinCellY = std::max(0, (int)std::floor((y - minY - factorY) * invH));
+    if (nMinCellY >= kGridRows) return;
+    const int nMaxCellY = std::min(kGridRows - 1, (int)std::ceil((y - minY + factorY) * invH));
+    if (nMaxCellY < 0) return;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+      for (int iy = nMinCellY; iy <= nMaxCellY; iy++)
+        for (int j = start[ix * kGridRows + iy]; j < start[ix * kGridRows + iy + 1]; j++) {
+          const MKeyPt& kp = kps[idx[j]];
+          if (bCheckLevels) {
+            if (kp.octave < minLevel) continue;
+            if (maxLevel >= 0 && kp.octave > maxLevel) continue;
+          }
+          const float distx = kp.x - x, disty = kp.y - y;
+          if (std::fabs(distx) < factorX && std::fabs(disty) < factorY) fn(idx[j]);
+        }
+  }
+};
+}  // namespace
+
+extern "C" {
+
+// CSR of window candidates + distances + best / second (first minimum wins).  kp_skip / kp_uright + q_xr: the optional gates
+// of orbx_window_search (src/ORBmatcher.cc:81-93).  Returns nnz, or -1 when cand_cap is too small (row_ptr is complete then).
+int mo_window_search_grid(const void* kps_, const uint8_t* desc, int n, const void* grid, const uint8_t* kp_skip, const float* kp_uright,
+                          const float* qx, const float* qy, const float* qr, const int32_t* qmin, const int32_t* qmax,
+                          const uint8_t* q_desc, const float* q_xr, int nq, int32_t* row_ptr, int32_t* cand, int32_t* dist, int cand_cap,
+                          int32_t* best_idx, int32_t* best_dist, int32_t* second_idx, int32_t* second_dist) {
+  GridCells G((const MKeyPt*)kps_, n, *(const MoGrid*)grid);
+  int nnz = 0;
+  bool overflow = false;
+  row_ptr[0] = 0;
+  for (int q = 0; q < nq; q++) {
+    int bd = 256, bd2 = 256, bi = -1, bi2 = -1;
+    G.area(qx[q], qy[q], qr[q], qmin[q], qmax[q], [&](int idx) {
+      if (kp_skip && kp_skip[idx]) return;
+      if (kp_uright && q_xr && kp_uright[idx] > 0.f && std::fabs(q_xr[q] - kp_uright[idx]) > qr[q]) return;
+      const int d = descriptor_distance(q_desc + (size_t)q * 32, desc + (size_t)idx * 32);
+      if (nnz < cand_cap) { if (cand) cand[nnz] = idx; if (dist) dist[nnz] = d; } else overflow = true;
+      nnz++;
+      if (d < bd) { bd2 = bd; bi2 = bi; bd = d; bi = idx; }
+      else if (d < bd2) { bd2 = d; bi2 = idx; }
+    });
+    row_ptr[q + 1] = nnz;
+    if (best_idx) best_idx[q] = bi;
+    if (best_dist) best_dist[q] = bd;
+    if (second_idx) second_idx[q] = bi2;
+    if (second_dist) second_dist[q] = bd2;
+  }
+  return (overflow && (cand || dist)) ? -1 : nnz;
+}
+
+// arg-min only, with the optional reprojection gate of ORBmatcher::Fuse (src/ORBmatcher.cc:1269-1296): a candidate with a
+// right coordinate (kp_uright >= 0) must satisfy (ex^2 + ey^2 + er^2) * invSigma2[level] <= 7.8, a monocular one
+// (ex^2 + ey^2) * invSigma2[level] <= 5.99; float products, comparison in double as in the reference.
+void mo_window_nearest(const void* kps_, const uint8_t* desc, int n, const void* grid, const float* kp_uright, const float* inv_level_sigma2,
+                       const float* qx, const float* qy, const float* qr, const int32_t* qmin, const int32_t* qmax, const float* q_ur,
+                       const uint8_t* q_desc, int nq, int32_t* best_idx, int32_t* best_dist) {
+  const MKeyPt* kps = (const MKeyPt*)kps_;
+  GridCells G(kps, n, *(const MoGrid*)grid);
+  for (int q = 0; q < nq; q++) {
+    int bd = 256, bi = -1;
+    G.area(qx[q], qy[q], qr[q], qmin[q], qmax[q], [&](int idx) {
+      if (inv_level_sigma2) {
+        const MKeyPt& kp = kps[idx];
+        const int kpLevel = kp.octave;
+        if (kp_uright[idx] >= 0) {
+          const float ex = qx[q] - kp.x, ey = qy[q] - kp.y, er = q_ur[q] - kp_uright[idx];
+          const float e2 = ex * ex + ey * ey + er * er;
+          if (e2 * inv_level_sigma2[kpLevel] > 7.8) return;
+        } else {
+          const float ex = qx[q] - kp.x, ey = qy[q] - kp.y;
+          const float e2 = ex * ex + ey * ey;
+          if (e2 * inv_level_sigma2[kpLevel] > 5.99) return;
+        }
+      }
+      const int d = descriptor_distance(q_desc + (size_t)q * 32, desc + (size_t)idx * 32);
+      if (d < bd) { bd = d; bi = idx; }
+    });
+    best_idx[q] = bi; best_dist[q] = bd;
+  }
+}
+
+}  // extern "C"

@@ -248,6 +248,85 @@ def features_in_area(kps, bounds, qx, qy, qr, qmin, qmax):
     return rp, cand[:nnz].copy()
 
 
+class _MoGrid(C.Structure):
+    _fields_ = [("min_x", C.c_float), ("min_y", C.c_float), ("inv_w", C.c_float), ("inv_h", C.c_float),
+                ("cell_start", C.c_void_p), ("cell_idx", C.c_void_p)]
+
+
+def _mogrid(grid):
+    cs = None if grid.get("cell_start") is None else np.ascontiguousarray(grid["cell_start"], np.int32)
+    ci = None if cs is None else np.ascontiguousarray(np.concatenate([grid["cell_idx"], [0]]), np.int32)
+    g = _MoGrid(float(grid["min_x"]), float(grid["min_y"]), float(grid["inv_w"]), float(grid["inv_h"]),
+                None if cs is None else cs.ctypes.data, None if ci is None else ci.ctypes.data)
+    return g, (cs, ci)
+
+
+def assign_grid(kps, min_x, min_y, inv_w, inv_h):
+    """Frame::AssignFeaturesToGrid / PosInGrid (src/Frame.cc:385-416, :725-735) -> (cell_start [64*48+1], cell_idx), numpy float32."""
+    k = np.ascontiguousarray(kps)
+    f32 = np.float32
+    px = ((k["x"].astype(f32) - f32(min_x)).astype(f32) * f32(inv_w)).astype(f32)
+    py = ((k["y"].astype(f32) - f32(min_y)).astype(f32) * f32(inv_h)).astype(f32)
+    rnd = lambda v: np.where(v >= 0, np.floor(v.astype(np.float64) + 0.5), np.ceil(v.astype(np.float64) - 0.5)).astype(np.int64)  # C round()
+    posx, posy = rnd(px), rnd(py)
+    ok = (posx >= 0) & (posx < 64) & (posy >= 0) & (posy < 48)
+    cell = np.where(ok, posx * 48 + posy, -1)
+    order = np.argsort(cell, kind="stable")
+    order = order[cell[order] >= 0]
+    counts = np.bincount(cell[order], minlength=64 * 48)
+    start = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    return start, order.astype(np.int32)
+
+
+def window_search_grid(kps, desc, grid, qx, qy, qr, qmin, qmax, q_desc, kp_skip=None, kp_uright=None, q_xr=None):
+    """The generic window primitive (mo_window_search_grid) -> dict like ORBmatcher.WindowSearchGrid."""
+    k = np.ascontiguousarray(kps); d = np.ascontiguousarray(desc, np.uint8)
+    qx, qy, qr = (np.ascontiguousarray(v, np.float32) for v in (qx, qy, qr))
+    qmin, qmax = (np.ascontiguousarray(v, np.int32) for v in (qmin, qmax))
+    qd = np.ascontiguousarray(q_desc, np.uint8)
+    skip = None if kp_skip is None else np.ascontiguousarray(kp_skip, np.uint8)
+    ur = None if kp_uright is None else np.ascontiguousarray(kp_uright, np.float32)
+    xr = None if q_xr is None else np.ascontiguousarray(q_xr, np.float32)
+    nq = len(qx)
+    g, keep = _mogrid(grid)
+    L = _mlib()
+    vp = C.c_void_p
+    L.mo_window_search_grid.restype = C.c_int
+    L.mo_window_search_grid.argtypes = [vp, vp, C.c_int, vp] + [vp] * 9 + [C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp]
+    rp = np.zeros(nq + 1, np.int32)
+    bi, bd, si, sd = (np.zeros(max(nq, 1), np.int32) for _ in range(4))
+    cap = max(len(k) * max(nq, 1), 1)
+    cand, dist = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+    pp = lambda a: None if a is None else _ptr(a)
+    nnz = L.mo_window_search_grid(_ptr(k), _ptr(d), len(k), C.addressof(g), pp(skip), pp(ur), _ptr(qx), _ptr(qy), _ptr(qr), _ptr(qmin),
+                                  _ptr(qmax), _ptr(qd), pp(xr), nq, _ptr(rp), _ptr(cand), _ptr(dist), cap, _ptr(bi), _ptr(bd), _ptr(si), _ptr(sd))
+    assert nnz >= 0
+    return dict(row_ptr=rp, cand=cand[:nnz].copy(), dist=dist[:nnz].copy(), best_idx=bi[:nq], best_dist=bd[:nq], second_idx=si[:nq],
+                second_dist=sd[:nq])
+
+
+def window_nearest(kps, desc, grid, qx, qy, qr, qmin, qmax, q_desc, kp_uright=None, inv_level_sigma2=None, q_ur=None):
+    """mo_window_nearest: arg-min with Fuse's optional reprojection gate (src/ORBmatcher.cc:1262-1309) -> (best_idx, best_dist)."""
+    k = np.ascontiguousarray(kps); d = np.ascontiguousarray(desc, np.uint8)
+    qx, qy, qr = (np.ascontiguousarray(v, np.float32) for v in (qx, qy, qr))
+    qmin, qmax = (np.ascontiguousarray(v, np.int32) for v in (qmin, qmax))
+    qd = np.ascontiguousarray(q_desc, np.uint8)
+    ur = None if kp_uright is None else np.ascontiguousarray(kp_uright, np.float32)
+    sig = None if inv_level_sigma2 is None else np.ascontiguousarray(inv_level_sigma2, np.float32)
+    qu = None if q_ur is None else np.ascontiguousarray(q_ur, np.float32)
+    nq = len(qx)
+    g, keep = _mogrid(grid)
+    L = _mlib()
+    vp = C.c_void_p
+    L.mo_window_nearest.restype = None
+    L.mo_window_nearest.argtypes = [vp, vp, C.c_int, vp] + [vp] * 9 + [C.c_int, vp, vp]
+    bi, bd = np.zeros(max(nq, 1), np.int32), np.zeros(max(nq, 1), np.int32)
+    pp = lambda a: None if a is None else _ptr(a)
+    L.mo_window_nearest(_ptr(k), _ptr(d), len(k), C.addressof(g), pp(ur), pp(sig), _ptr(qx), _ptr(qy), _ptr(qr), _ptr(qmin), _ptr(qmax), pp(qu),
+                        _ptr(qd), nq, _ptr(bi), _ptr(bd))
+    return bi[:nq], bd[:nq]
+
+
 def search_for_initialization(kps1, desc1, kps2, desc2, bounds, prev_xy, window_size=100, nnratio=0.9, check_ori=True):
     """ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:648-763) -> (nmatches, vnMatches12, updated vbPrevMatched)."""
     k1, k2 = np.ascontiguousarray(kps1), np.ascontiguousarray(kps2)

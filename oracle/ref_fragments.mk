@@ -1,15 +1,32 @@
-# Compiles the parts of the REFERENCE that build from their own few source files (vendored DBoW2: vocabulary
-# tree, BowVector, FeatureVector, scoring, FORB Hamming distance) straight from /root/reference, with shim
-# headers for the two absent third-party packages (oracle/ref_shims: a minimal cv::Mat and a Boost.Serialization
-# stub).  Output: oracle/_ref/libref_dbow2.so (git-ignored; travels to the GPU box).  Reference sources are
-# never copied into this repository.  src/ORBextractor.cc and src/ORBmatcher.cc are NOT buildable this way
-# (they call into OpenCV's algorithms / Eigen / Sophus; DESIGN.md "oracle").
-REF ?= /root/reference/Thirdparty/DBoW2
+# Compiles the parts of the REFERENCE that build from their own few source files straight from /root/reference, with
+# shim headers for the absent third-party packages.  Outputs only into oracle/_ref/ (git-ignored; travels to the GPU box).
+# Reference sources are never copied into this repository.
+#   _ref/libref_dbow2.so        vendored DBoW2 (vocabulary tree, BowVector, FeatureVector, scoring, FORB distance) +
+#                               oracle/ref_wrap.cpp; shims: oracle/ref_shims (container-only cv::Mat, Boost.Serialization stub)
+#   _ref/ref_matcher_world      src/ORBmatcher.cc + include/ORBmatcher.h, unmodified, against the object model of
+#                               tests/support/ref_world (Frame / KeyFrame / MapPoint / Eigen / Sophus stand-ins holding the
+#                               members the matcher touches) + the scenario driver tests/support/matcher_world.cpp
+#   _ref/libref_orbextractor.so src/ORBextractor.cc + include/ORBextractor.h, unmodified, against the container shim; the five
+#                               OpenCV algorithms it calls forward to the oracle's isolated primitives (liborb_oracle.so)
+REFROOT ?= /root/reference
+REF ?= $(REFROOT)/Thirdparty/DBoW2
 CXX ?= g++
 CXXFLAGS ?= -O2 -std=c++14 -fPIC -ffp-contract=off -w
 SRCS := $(REF)/DBoW2/BowVector.cpp $(REF)/DBoW2/FeatureVector.cpp $(REF)/DBoW2/ScoringObject.cpp $(REF)/DBoW2/FORB.cpp \
         $(REF)/DUtils/Random.cpp $(REF)/DUtils/Timestamp.cpp ref_wrap.cpp
+WORLD := ../tests/support/ref_world
+WORLD_HDRS := $(wildcard $(WORLD)/*.h $(WORLD)/*/* $(WORLD)/*/*/*/*) $(wildcard ref_shims/opencv2/*/*.hpp)
+
+all: _ref/libref_dbow2.so _ref/ref_matcher_world
 
 _ref/libref_dbow2.so: $(SRCS) ref_shims/opencv2/core/core.hpp ref_shims/boost/serialization/serialization.hpp
 	mkdir -p _ref
 	$(CXX) $(CXXFLAGS) -Iref_shims -I$(REF) -shared -o $@ $(SRCS)
+
+# -include ref_world.h: defines the include guards of the reference's Frame.h / KeyFrame.h / MapPoint.h before its
+# ORBmatcher.h includes them from its own directory, so the object model of tests/support/ref_world is the one seen
+_ref/ref_matcher_world: $(REFROOT)/src/ORBmatcher.cc $(REFROOT)/include/ORBmatcher.h ../tests/support/matcher_world.cpp $(WORLD_HDRS)
+	mkdir -p _ref
+	$(CXX) -O1 -std=c++17 -ffp-contract=off -w -include $(WORLD)/ref_world.h -I$(WORLD) -Iref_shims -I$(REFROOT)/include \
+	    $(REFROOT)/src/ORBmatcher.cc ../tests/support/matcher_world.cpp -o $@
+.PHONY: all

@@ -71,6 +71,8 @@ def lib() -> C.CDLL:
         "orbx_features_in_area": (i32, [vp, vp, i32, f32, f32, f32, f32, vp, vp, vp, vp, vp, i32, vp, vp, i32]),
         "orbx_search_for_initialization": (i32, [vp, vp, vp, i32, vp, vp, i32, f32, f32, f32, f32, vp, i32, f32, i32, vp, ip]),
         "orbx_window_search": (i32, [vp, vp, vp, i32, f32, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
+        "orbx_window_search_grid": (i32, [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
+        "orbx_window_nearest": (i32, [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]),
         "orbx_search_by_projection": (i32, [vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32,
                                             vp, ip]),
         "orbx_search_by_projection_last": (i32, [vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, vp, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp, i32,
@@ -106,6 +108,12 @@ def lib() -> C.CDLL:
     L._orbx_symbols = tuple(sig)
     _lib = L
     return L
+
+
+class OrbxGrid(C.Structure):
+    """orbx_grid (include/orbx.h): a Frame's / KeyFrame's feature grid as the caller holds it."""
+    _fields_ = [("min_x", C.c_float), ("min_y", C.c_float), ("inv_w", C.c_float), ("inv_h", C.c_float),
+                ("cell_start", C.c_void_p), ("cell_idx", C.c_void_p)]
 
 
 def ptr(a) -> C.c_void_p:

@@ -586,6 +586,7 @@ void orbx_destroy(orbx_ctx* ctx) {
   ctx->arena.release();
   if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
   if (ctx->h_in) { (void)hipHostFree(ctx->h_in); ctx->h_in = nullptr; }
+  if (ctx->h_call) { (void)hipHostFree(ctx->h_call); ctx->h_call = nullptr; }
   if (ctx->d_color) { (void)hipFree(ctx->d_color); ctx->d_color = nullptr; }
   if (ctx->h_stage_out) { (void)hipHostFree(ctx->h_stage_out); ctx->h_stage_out = nullptr; }
   if (ctx->h_pyr) { (void)hipHostFree(ctx->h_pyr); ctx->h_pyr = nullptr; }

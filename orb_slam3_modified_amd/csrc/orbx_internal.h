@@ -175,6 +175,8 @@ struct orbx_ctx {
   uint8_t* h_stage_out = nullptr;   // pinned host mirror of d_stage_out (one D2H copy per call)
   int stage_frames = 0;
   orbx::DeviceArena arena;   // scratch of the grid / search / stereo entry points
+  uint8_t* h_call = nullptr; size_t h_call_bytes = 0;   // pinned [inputs | outputs] blob of the window / nn entry points (orbx_window.hip)
+  int win_guess = 0;            // candidates of the last window call: how much of the pool the first read-back copy takes
   // single-frame operator() path as a replayed hipGraph (H2D, the 13 launches, D2H): one graph launch per frame instead
   // of ~16 API calls; re-captured when the shape / lapping area / buffers change, disabled on any capture failure
   bool use_graph = true;
@@ -220,6 +222,13 @@ inline hipError_t sync_ctx(orbx_ctx* ctx) {
   if (e == hipSuccess && ctx->last_ext_stream) e = hipStreamSynchronize(ctx->last_ext_stream);
   return e;
 }
+// orbx_window.hip: pinned staging (grow-only) and the fused window pass behind orbx_window_search* / orbx_window_nearest
+hipError_t host_stage(orbx_ctx* ctx, size_t bytes, uint8_t** p);
+int window_call(orbx_ctx* ctx, const char* who, const orbx_keypoint* kps, const uint8_t* desc, int n, const orbx_grid* grid,
+                const uint8_t* kp_skip, const float* kp_uright, const float* inv_sigma2, int nlevels, const float* qx, const float* qy,
+                const float* qr, const int32_t* qlo, const int32_t* qhi, const float* qaux, const uint8_t* q_desc, int nq, bool lists,
+                int32_t* row_ptr, int32_t* cand, int32_t* dist, int cand_cap, int32_t* best_idx, int32_t* best_dist, int32_t* second_idx,
+                int32_t* second_dist);
 #define ORBX_HIP(ctx, expr)                                                                          \
   do {                                                                                               \
     hipError_t _e = (expr);                                                                          \

@@ -409,34 +409,24 @@ static int window_search_core(orbx_ctx* ctx, const orbx_keypoint* kps, const uin
   out.nnz = 0;
   if (want_best) { out.best_idx.assign(nq, -1); out.best_dist.assign(nq, 256); out.second_idx.assign(nq, -1); out.second_dist.assign(nq, 256); }
   if (nq == 0 || n == 0) return ORBX_OK;
-  GridOnDevice g;
-  int rc = build_grid(ctx, kps, n, min_x, min_y, max_x, max_y, g);
-  if (rc != ORBX_OK) return rc;
-  AreaQueries a;
-  rc = run_area(ctx, g, qx, qy, qr, qmin, qmax, nq, a, gates);
-  if (rc != ORBX_OK) return rc;
-  out.nnz = a.nnz;
-  out.cand.resize(std::max(a.nnz, 1)); out.dist.resize(std::max(a.nnz, 1));
-  ORBX_HIP(ctx, hipMemcpyAsync(out.row_ptr.data(), a.row_ptr.p, sizeof(int32_t) * (nq + 1), hipMemcpyDeviceToHost, ctx->stream));
-  if (a.nnz) {
-    DBuf<uint8_t> dq, dt;
-    DBuf<int32_t> ddist, dbi, dbd, dsi, dsd;
-    ORBX_HIP(ctx, dq.alloc((size_t)nq * 32)); ORBX_HIP(ctx, dt.alloc((size_t)n * 32)); ORBX_HIP(ctx, ddist.alloc(a.nnz));
-    if (want_best) { ORBX_HIP(ctx, dbi.alloc(nq)); ORBX_HIP(ctx, dbd.alloc(nq)); ORBX_HIP(ctx, dsi.alloc(nq)); ORBX_HIP(ctx, dsd.alloc(nq)); }
-    ORBX_HIP(ctx, hipMemcpyAsync(dq.p, qdesc, (size_t)nq * 32, hipMemcpyHostToDevice, ctx->stream));
-    ORBX_HIP(ctx, hipMemcpyAsync(dt.p, desc, (size_t)n * 32, hipMemcpyHostToDevice, ctx->stream));
-    rc = orbx_nn_csr_device(ctx, dq.p, nq, dt.p, n, a.row_ptr.p, a.cand.p, 0, dbi.p, dbd.p, dsi.p, dsd.p, ddist.p, ctx->stream);
-    if (rc != ORBX_OK) return rc;
-    ORBX_HIP(ctx, hipMemcpyAsync(out.cand.data(), a.cand.p, sizeof(int32_t) * a.nnz, hipMemcpyDeviceToHost, ctx->stream));
-    ORBX_HIP(ctx, hipMemcpyAsync(out.dist.data(), ddist.p, sizeof(int32_t) * a.nnz, hipMemcpyDeviceToHost, ctx->stream));
-    if (want_best) {
-      ORBX_HIP(ctx, hipMemcpyAsync(out.best_idx.data(), dbi.p, sizeof(int32_t) * nq, hipMemcpyDeviceToHost, ctx->stream));
-      ORBX_HIP(ctx, hipMemcpyAsync(out.best_dist.data(), dbd.p, sizeof(int32_t) * nq, hipMemcpyDeviceToHost, ctx->stream));
-      ORBX_HIP(ctx, hipMemcpyAsync(out.second_idx.data(), dsi.p, sizeof(int32_t) * nq, hipMemcpyDeviceToHost, ctx->stream));
-      ORBX_HIP(ctx, hipMemcpyAsync(out.second_dist.data(), dsd.p, sizeof(int32_t) * nq, hipMemcpyDeviceToHost, ctx->stream));
-    }
+  // the grid of Frame::AssignFeaturesToGrid is assigned on the device (src/Frame.cc:159-160 for the cell sizes)
+  orbx_grid g;
+  g.min_x = min_x; g.min_y = min_y;
+  g.inv_w = (float)kGridCols / (float)(max_x - min_x);
+  g.inv_h = (float)kGridRows / (float)(max_y - min_y);
+  g.cell_start = nullptr; g.cell_idx = nullptr;
+  const bool stereo_gate = gates.kp_uright && gates.qxr;
+  size_t cap = std::max<size_t>(out.cand.size(), 16384);
+  for (int attempt = 0; attempt < 2; attempt++) {
+    out.cand.resize(cap); out.dist.resize(cap);
+    const int rc = window_call(ctx, "window search", kps, desc, n, &g, gates.kp_skip, stereo_gate ? gates.kp_uright : nullptr, nullptr, 0, qx, qy,
+                               qr, qmin, qmax, stereo_gate ? gates.qxr : nullptr, qdesc, nq, true, out.row_ptr.data(), out.cand.data(),
+                               out.dist.data(), (int)cap, want_best ? out.best_idx.data() : nullptr, want_best ? out.best_dist.data() : nullptr,
+                               want_best ? out.second_idx.data() : nullptr, want_best ? out.second_dist.data() : nullptr);
+    if (rc >= 0) { out.nnz = rc; return ORBX_OK; }
+    if (rc != ORBX_E_CAPACITY || attempt) return rc;
+    cap = (size_t)out.row_ptr[nq] + 64;   // complete on ORBX_E_CAPACITY
   }
-  ORBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ORBX_OK;
 }
 
@@ -578,26 +568,15 @@ int orbx_window_search(orbx_ctx* ctx, const orbx_keypoint* kps, const uint8_t* d
   if (!ctx || n < 0 || nq < 0 || !row_ptr || (n > 0 && (!kps || !desc)) ||
       (nq > 0 && (!qx || !qy || !qr || !qmin_level || !qmax_level || !q_desc)) || !(max_x > min_x) || !(max_y > min_y) || cand_cap < 0)
     return ctx ? set_err(ctx, ORBX_E_INVALID, "orbx_window_search: bad arguments") : ORBX_E_INVALID;
-  ORBX_HIP(ctx, hipSetDevice(ctx->device));
-  ArenaScope scope(ctx);
-  AreaGates gates;
-  gates.kp_skip = kp_skip; gates.kp_uright = kp_uright; gates.qxr = q_xr; gates.n = n;
-  WindowResult w;
-  const bool want_best = best_idx || best_dist || second_idx || second_dist;
-  int rc = window_search_core(ctx, kps, desc, n, min_x, min_y, max_x, max_y, gates, qx, qy, qr, qmin_level, qmax_level, q_desc, nq,
-                              want_best, w);
-  if (rc != ORBX_OK) return rc;
-  std::memcpy(row_ptr, w.row_ptr.data(), sizeof(int32_t) * (nq + 1));
-  if ((cand || dist) && w.nnz > cand_cap) return set_err(ctx, ORBX_E_CAPACITY, "orbx_window_search: candidate buffer too small");
-  if (cand && w.nnz) std::memcpy(cand, w.cand.data(), sizeof(int32_t) * w.nnz);
-  if (dist && w.nnz) std::memcpy(dist, w.dist.data(), sizeof(int32_t) * w.nnz);
-  if (nq) {
-    if (best_idx) std::memcpy(best_idx, w.best_idx.data(), sizeof(int32_t) * nq);
-    if (best_dist) std::memcpy(best_dist, w.best_dist.data(), sizeof(int32_t) * nq);
-    if (second_idx) std::memcpy(second_idx, w.second_idx.data(), sizeof(int32_t) * nq);
-    if (second_dist) std::memcpy(second_dist, w.second_dist.data(), sizeof(int32_t) * nq);
-  }
-  return w.nnz;
+  orbx_grid g;
+  g.min_x = min_x; g.min_y = min_y;
+  g.inv_w = (float)kGridCols / (float)(max_x - min_x);   // src/Frame.cc:159-160
+  g.inv_h = (float)kGridRows / (float)(max_y - min_y);
+  g.cell_start = nullptr; g.cell_idx = nullptr;
+  const bool stereo_gate = kp_uright && q_xr;
+  return window_call(ctx, "orbx_window_search", kps, desc, n, &g, kp_skip, stereo_gate ? kp_uright : nullptr, nullptr, 0, qx, qy, qr, qmin_level,
+                     qmax_level, stereo_gate ? q_xr : nullptr, q_desc, nq, cand || dist, row_ptr, cand, dist, cand_cap, best_idx, best_dist,
+                     second_idx, second_dist);
 }
 
 int orbx_search_by_projection(orbx_ctx* ctx, const orbx_keypoint* kps_un, const uint8_t* desc, const float* u_right, int32_t* kp_obs, int n,

@@ -1,0 +1,405 @@
+// orbx window pass — the device part shared by the guided searches of ORBmatcher (src/ORBmatcher.cc): for a batch of
+// queries (centre, radius, level range, descriptor) over ONE feature grid
+//   * the window of Frame::GetFeaturesInArea (src/Frame.cc:657-723) / KeyFrame::GetFeaturesInArea (src/KeyFrame.cc:704-748),
+//     candidates in the reference's order (grid cells x-major, then y, then insertion order — that order decides ties),
+//   * the routines' static candidate gates (keypoint excluded, rectified-stereo consistency :85-90, Fuse's reprojection
+//     test :1269-1296),
+//   * ORBmatcher::DescriptorDistance of every surviving candidate,
+//   * the running best / second of the candidate loops (:96-118; first minimum wins),
+// in ONE kernel, one wave per query.  Host-buffer entry points move their inputs in one pinned blob (one H2D copy), launch,
+// and read the results back in one copy: no per-call allocation, no mid-call synchronisation.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "orbx_internal.h"
+
+namespace orbx {
+
+constexpr int kWinCols = 64, kWinRows = 48, kWinCells = kWinCols * kWinRows;   // include/Frame.h:44-45
+
+struct WinQueryOut { int32_t start, count, best_idx, best_dist, second_idx, second_dist, pad0, pad1; };
+
+struct WinArgs {
+  const orbx_keypoint* kps;
+  const uint8_t* desc;
+  const int32_t* cell_start;   // [kWinCells + 1]
+  const int32_t* cell_idx;
+  float minX, minY, invW, invH;
+  const float *qx, *qy, *qr, *qaux;
+  const int32_t *qlo, *qhi;
+  const uint8_t* qdesc;
+  int nq;
+  const uint8_t* kp_skip;
+  const float* kp_uright;
+  const float* inv_sigma2;
+  WinQueryOut* out;
+  int2* pool;          // {candidate index, distance}, one contiguous segment per query
+  int pool_cap;
+  int32_t* total;      // candidates of all queries (also when the pool is too small: the host then reports the capacity needed)
+};
+
+struct WDesc { unsigned long long w[4]; };
+__device__ __forceinline__ WDesc wload(const uint8_t* p) {
+  const uint4* q = (const uint4*)p;
+  const uint4 a = q[0], b = q[1];
+  WDesc d;
+  d.w[0] = (unsigned long long)a.x | ((unsigned long long)a.y << 32);
+  d.w[1] = (unsigned long long)a.z | ((unsigned long long)a.w << 32);
+  d.w[2] = (unsigned long long)b.x | ((unsigned long long)b.y << 32);
+  d.w[3] = (unsigned long long)b.z | ((unsigned long long)b.w << 32);
+  return d;
+}
+__device__ __forceinline__ int wham(const WDesc& a, const WDesc& b) {
+  return __popcll(a.w[0] ^ b.w[0]) + __popcll(a.w[1] ^ b.w[1]) + __popcll(a.w[2] ^ b.w[2]) + __popcll(a.w[3] ^ b.w[3]);
+}
+
+// key = distance << 48 | position in the candidate list << 24 | keypoint index: ascending keys = the reference's
+// "strict <, first candidate wins" order; position and index below 2^24
+constexpr unsigned long long kNoWinKey = ~0ull;
+
+template <bool LISTS, bool CHI2>
+__global__ __launch_bounds__(256) void k_window(const WinArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= a.nq) return;
+  const float x = a.qx[q], y = a.qy[q], r = a.qr[q];
+  const int minLevel = a.qlo[q], maxLevel = a.qhi[q];
+  const float aux = a.qaux ? a.qaux[q] : 0.f;
+  const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+  // src/Frame.cc:665-687 with separately rounded float operations
+  const int nMinCellX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, a.minX), r), a.invW)));
+  const int nMaxCellX = min(kWinCols - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, a.minX), r), a.invW)));
+  const int nMinCellY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, a.minY), r), a.invH)));
+  const int nMaxCellY = min(kWinRows - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, a.minY), r), a.invH)));
+  const bool any = nMinCellX < kWinCols && nMaxCellX >= 0 && nMinCellY < kWinRows && nMaxCellY >= 0;
+
+  auto passes = [&](int j, int& idx) -> bool {
+    idx = a.cell_idx[j];
+    const orbx_keypoint* kp = a.kps + idx;
+    const int octave = kp->octave;
+    const float kx = kp->x, ky = kp->y;
+    bool ok = true;
+    if (bCheckLevels) {
+      if (octave < minLevel) ok = false;
+      if (maxLevel >= 0 && octave > maxLevel) ok = false;
+    }
+    ok = ok && fabsf(__fsub_rn(kx, x)) < r && fabsf(__fsub_rn(ky, y)) < r;
+    if (a.kp_skip && a.kp_skip[idx]) ok = false;
+    if (CHI2) {
+      if (ok) {
+        const float ur = a.kp_uright[idx];
+        const float ex = __fsub_rn(x, kx), ey = __fsub_rn(y, ky);
+        float e2 = __fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey));
+        double lim = 5.99;
+        if (ur >= 0.f) { const float er = __fsub_rn(aux, ur); e2 = __fadd_rn(e2, __fmul_rn(er, er)); lim = 7.8; }
+        if ((double)__fmul_rn(e2, a.inv_sigma2[octave]) > lim) ok = false;
+      }
+    } else if (a.kp_uright && a.qaux) {
+      const float ur = a.kp_uright[idx];
+      if (ur > 0.f && fabsf(__fsub_rn(aux, ur)) > r) ok = false;
+    }
+    return ok;
+  };
+
+  int count = 0, base = 0;
+  if (LISTS) {   // pass 1: how many, so that the query's candidates get one contiguous segment of the pool
+    if (any)
+      for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
+        const int s = a.cell_start[ix * kWinRows + nMinCellY], e = a.cell_start[ix * kWinRows + nMaxCellY + 1];
+        for (int b0 = s; b0 < e; b0 += 64) {
+          const int j = b0 + lane;
+          int idx = 0;
+          const bool ok = j < e && passes(j, idx);
+          count += __popcll(__ballot(ok));
+        }
+      }
+    if (lane == 0 && count) base = atomicAdd(a.total, count);
+    base = __shfl(base, 0);
+  }
+  const bool write = LISTS && count && base + count <= a.pool_cap;
+  const WDesc dq = wload(a.qdesc + (size_t)q * 32);
+  unsigned long long k1 = kNoWinKey, k2 = kNoWinKey;
+  int pos = 0;
+  if (any)
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
+      const int s = a.cell_start[ix * kWinRows + nMinCellY], e = a.cell_start[ix * kWinRows + nMaxCellY + 1];
+      for (int b0 = s; b0 < e; b0 += 64) {
+        const int j = b0 + lane;
+        int idx = 0;
+        const bool ok = j < e && passes(j, idx);
+        const unsigned long long bal = __ballot(ok);
+        if (ok) {
+          const int my = pos + __popcll(bal & ((1ull << lane) - 1ull));
+          const int d = wham(dq, wload(a.desc + (size_t)idx * 32));
+          const unsigned long long key = ((unsigned long long)d << 48) | ((unsigned long long)my << 24) | (unsigned long long)idx;
+          if (key < k1) { k2 = k1; k1 = key; }
+          else if (key < k2) k2 = key;
+          if (write) a.pool[base + my] = make_int2(idx, d);
+        }
+        pos += __popcll(bal);
+      }
+    }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long p1 = __shfl_xor(k1, o), p2 = __shfl_xor(k2, o);
+    const unsigned long long lo = k1 < p1 ? k1 : p1, hi = k1 < p1 ? p1 : k1;
+    const unsigned long long s2 = k2 < p2 ? k2 : p2;
+    k1 = lo;
+    k2 = hi < s2 ? hi : s2;
+  }
+  if (lane == 0) {
+    WinQueryOut o;
+    o.start = base; o.count = LISTS ? count : pos;
+    o.best_idx = k1 == kNoWinKey ? -1 : (int)(k1 & 0xffffffu);
+    o.best_dist = k1 == kNoWinKey ? 256 : (int)(k1 >> 48);
+    o.second_idx = k2 == kNoWinKey ? -1 : (int)(k2 & 0xffffffu);
+    o.second_dist = k2 == kNoWinKey ? 256 : (int)(k2 >> 48);
+    o.pad0 = o.pad1 = 0;
+    a.out[q] = o;
+  }
+}
+
+// Frame::AssignFeaturesToGrid on the device (src/Frame.cc:385-416, PosInGrid :725-735) for grids the caller does not hold:
+// cell of every keypoint, then an LDS bitonic sort of (cell << 16 | index); ascending keys list the cells in mGrid[ix][iy]
+// order and, inside a cell, the keypoints in insertion order.  One workgroup, at most 32 768 keypoints.
+__global__ __launch_bounds__(1024) void k_window_grid(const orbx_keypoint* __restrict__ kps, int n, float minX, float minY, float invW,
+                                                      float invH, int npad, int32_t* __restrict__ cell_idx, int32_t* __restrict__ cell_start) {
+  extern __shared__ uint32_t wkeys[];
+  const int t = threadIdx.x, T = blockDim.x;
+  for (int i = t; i < npad; i += T) {
+    uint32_t key = 0xffffffffu;
+    if (i < n) {
+      const int posX = (int)roundf(__fmul_rn(__fsub_rn(kps[i].x, minX), invW));
+      const int posY = (int)roundf(__fmul_rn(__fsub_rn(kps[i].y, minY), invH));
+      const bool in = posX >= 0 && posX < kWinCols && posY >= 0 && posY < kWinRows;
+      key = ((in ? (uint32_t)(posX * kWinRows + posY) : 0xfffeu) << 16) | (uint32_t)i;
+    }
+    wkeys[i] = key;
+  }
+  __syncthreads();
+  for (int k = 2; k <= npad; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = t; i < npad; i += T) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const uint32_t a = wkeys[i], b = wkeys[ixj];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) { wkeys[i] = b; wkeys[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = t; i < n; i += T) cell_idx[i] = (int32_t)(wkeys[i] & 0xffffu);
+  for (int c = t; c <= kWinCells; c += T) {
+    const uint32_t want = (uint32_t)c << 16;
+    int lo = 0, hi = n;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (wkeys[mid] < want) lo = mid + 1; else hi = mid;
+    }
+    cell_start[c] = lo;
+  }
+}
+
+// pinned host staging of the host-buffer entry points, grow-only
+hipError_t host_stage(orbx_ctx* ctx, size_t bytes, uint8_t** p) {
+  if (bytes > ctx->h_call_bytes) {
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return e;
+    if (ctx->h_call) (void)hipHostFree(ctx->h_call);
+    ctx->h_call = nullptr; ctx->h_call_bytes = 0;
+    const size_t want = std::max<size_t>(bytes + bytes / 2, 1 << 20);
+    e = hipHostMalloc((void**)&ctx->h_call, want, hipHostMallocDefault);
+    if (e != hipSuccess) return e;
+    ctx->h_call_bytes = want;
+  }
+  *p = ctx->h_call;
+  return hipSuccess;
+}
+
+namespace {
+struct Layout {
+  size_t size = 0;
+  size_t add(size_t bytes) { const size_t o = size; size = (size + bytes + 255) & ~(size_t)255; return o; }
+};
+}  // namespace
+
+// The whole call: pack -> one H2D -> [grid assignment] -> k_window -> one D2H (+ one more for a long tail) -> scatter.
+int window_call(orbx_ctx* ctx, const char* who, const orbx_keypoint* kps, const uint8_t* desc, int n, const orbx_grid* grid,
+                const uint8_t* kp_skip, const float* kp_uright, const float* inv_sigma2, int nlevels, const float* qx, const float* qy,
+                const float* qr, const int32_t* qlo, const int32_t* qhi, const float* qaux, const uint8_t* q_desc, int nq, bool lists,
+                int32_t* row_ptr, int32_t* cand, int32_t* dist, int cand_cap, int32_t* best_idx, int32_t* best_dist, int32_t* second_idx,
+                int32_t* second_dist) {
+  if (row_ptr) for (int q = 0; q <= nq; q++) row_ptr[q] = 0;
+  for (int q = 0; q < nq; q++) {
+    if (best_idx) best_idx[q] = -1;
+    if (best_dist) best_dist[q] = 256;
+    if (second_idx) second_idx[q] = -1;
+    if (second_dist) second_dist[q] = 256;
+  }
+  if (nq == 0 || n == 0) return 0;
+  if (n >= (1 << 24)) return set_err(ctx, ORBX_E_CAPACITY, std::string(who) + ": more than 16 M keypoints");
+  const bool have_grid = grid->cell_start != nullptr;
+  if (have_grid) {
+    if (!grid->cell_idx) return set_err(ctx, ORBX_E_INVALID, std::string(who) + ": grid without cell_idx");
+    if (grid->cell_start[0] != 0) return set_err(ctx, ORBX_E_INVALID, std::string(who) + ": grid cell_start[0] != 0");
+    for (int c = 0; c < kWinCells; c++)
+      if (grid->cell_start[c + 1] < grid->cell_start[c]) return set_err(ctx, ORBX_E_INVALID, std::string(who) + ": grid cell_start not ascending");
+    const int m = grid->cell_start[kWinCells];
+    for (int i = 0; i < m; i++)
+      if (grid->cell_idx[i] < 0 || grid->cell_idx[i] >= n) return set_err(ctx, ORBX_E_INVALID, std::string(who) + ": grid index out of range");
+  } else if (n > 32768) {
+    return set_err(ctx, ORBX_E_CAPACITY, std::string(who) + ": more than 32768 keypoints need a caller-held grid");
+  }
+  if (inv_sigma2)
+    for (int i = 0; i < n; i++)
+      if (kps[i].octave < 0 || kps[i].octave >= nlevels) return set_err(ctx, ORBX_E_INVALID, std::string(who) + ": keypoint octave outside inv_level_sigma2");
+  ORBX_HIP(ctx, hipSetDevice(ctx->device));
+  const int ngrid = have_grid ? grid->cell_start[kWinCells] : n;
+  const int pool_cap = lists ? std::max(cand_cap, 0) : 0;
+  // ---- layouts: input blob (host -> device) and output blob (device -> host)
+  Layout in;
+  const size_t o_total = in.add(16);
+  const size_t o_kps = in.add(sizeof(orbx_keypoint) * (size_t)n), o_desc = in.add((size_t)n * 32);
+  const size_t o_qx = in.add(4 * (size_t)nq), o_qy = in.add(4 * (size_t)nq), o_qr = in.add(4 * (size_t)nq), o_qaux = in.add(4 * (size_t)nq);
+  const size_t o_qlo = in.add(4 * (size_t)nq), o_qhi = in.add(4 * (size_t)nq), o_qd = in.add((size_t)nq * 32);
+  const size_t o_skip = in.add(kp_skip ? (size_t)n : 0), o_ur = in.add(kp_uright ? 4 * (size_t)n : 0);
+  const size_t o_sig = in.add(inv_sigma2 ? 4 * (size_t)nlevels : 0);
+  const size_t o_cs = in.add(4 * (size_t)(kWinCells + 1)), o_ci = in.add(4 * (size_t)std::max(ngrid, 1));
+  const size_t in_upload = have_grid ? in.size : o_cs;   // without a caller grid the two grid arrays are produced on the device
+  Layout out;
+  const size_t p_hdr = out.add(16), p_q = out.add(sizeof(WinQueryOut) * (size_t)nq), p_pool = out.add(8 * (size_t)pool_cap);
+  uint8_t* h = nullptr;
+  ORBX_HIP(ctx, host_stage(ctx, in.size + out.size, &h));
+  uint8_t* hin = h;
+  uint8_t* hout = h + in.size;
+  std::memset(hin + o_total, 0, 16);
+  std::memcpy(hin + o_kps, kps, sizeof(orbx_keypoint) * (size_t)n);
+  std::memcpy(hin + o_desc, desc, (size_t)n * 32);
+  std::memcpy(hin + o_qx, qx, 4 * (size_t)nq); std::memcpy(hin + o_qy, qy, 4 * (size_t)nq); std::memcpy(hin + o_qr, qr, 4 * (size_t)nq);
+  if (qaux) std::memcpy(hin + o_qaux, qaux, 4 * (size_t)nq);
+  std::memcpy(hin + o_qlo, qlo, 4 * (size_t)nq); std::memcpy(hin + o_qhi, qhi, 4 * (size_t)nq);
+  std::memcpy(hin + o_qd, q_desc, (size_t)nq * 32);
+  if (kp_skip) std::memcpy(hin + o_skip, kp_skip, (size_t)n);
+  if (kp_uright) std::memcpy(hin + o_ur, kp_uright, 4 * (size_t)n);
+  if (inv_sigma2) std::memcpy(hin + o_sig, inv_sigma2, 4 * (size_t)nlevels);
+  if (have_grid) {
+    std::memcpy(hin + o_cs, grid->cell_start, 4 * (size_t)(kWinCells + 1));
+    if (ngrid) std::memcpy(hin + o_ci, grid->cell_idx, 4 * (size_t)ngrid);
+  }
+  ctx->arena.rewind();
+  hipError_t aerr = hipSuccess;
+  uint8_t* din = (uint8_t*)ctx->arena.alloc(in.size, &aerr);
+  ORBX_HIP(ctx, aerr);
+  uint8_t* dout = (uint8_t*)ctx->arena.alloc(out.size, &aerr);
+  ORBX_HIP(ctx, aerr);
+  hipStream_t st = ctx->stream;
+  ORBX_HIP(ctx, hipMemcpyAsync(din, hin, in_upload, hipMemcpyHostToDevice, st));
+  if (!have_grid) {
+    int npad = 2;
+    while (npad < n) npad <<= 1;
+    if ((size_t)npad * 4 > 64 * 1024) {
+      static bool attr_set = false;   // process-wide function attribute: raised once to the kernel's maximum
+      if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_window_grid, hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4);
+        if (e != hipSuccess) { (void)hipGetLastError(); return set_err(ctx, ORBX_E_CAPACITY, std::string(who) + ": LDS for the grid sort unavailable"); }
+        attr_set = true;
+      }
+    }
+    hipLaunchKernelGGL(k_window_grid, dim3(1), dim3(1024), (size_t)npad * 4, st, (const orbx_keypoint*)(din + o_kps), n, grid->min_x, grid->min_y,
+                       grid->inv_w, grid->inv_h, npad, (int32_t*)(din + o_ci), (int32_t*)(din + o_cs));
+  }
+  WinArgs a;
+  a.kps = (const orbx_keypoint*)(din + o_kps); a.desc = din + o_desc;
+  a.cell_start = (const int32_t*)(din + o_cs); a.cell_idx = (const int32_t*)(din + o_ci);
+  a.minX = grid->min_x; a.minY = grid->min_y; a.invW = grid->inv_w; a.invH = grid->inv_h;
+  a.qx = (const float*)(din + o_qx); a.qy = (const float*)(din + o_qy); a.qr = (const float*)(din + o_qr);
+  a.qaux = qaux ? (const float*)(din + o_qaux) : nullptr;
+  a.qlo = (const int32_t*)(din + o_qlo); a.qhi = (const int32_t*)(din + o_qhi); a.qdesc = din + o_qd; a.nq = nq;
+  a.kp_skip = kp_skip ? din + o_skip : nullptr;
+  a.kp_uright = kp_uright ? (const float*)(din + o_ur) : nullptr;
+  a.inv_sigma2 = inv_sigma2 ? (const float*)(din + o_sig) : nullptr;
+  a.out = (WinQueryOut*)(dout + p_q); a.pool = (int2*)(dout + p_pool); a.pool_cap = pool_cap; a.total = (int32_t*)(din + o_total);
+  const dim3 gridDim((nq + 3) / 4), block(256);
+  if (inv_sigma2) hipLaunchKernelGGL((k_window<false, true>), gridDim, block, 0, st, a);
+  else if (lists) hipLaunchKernelGGL((k_window<true, false>), gridDim, block, 0, st, a);
+  else hipLaunchKernelGGL((k_window<false, false>), gridDim, block, 0, st, a);
+  ORBX_HIP(ctx, hipGetLastError());
+  // ---- results: header + per-query records + the head of the pool in one copy; a long tail in a second one
+  ORBX_HIP(ctx, hipMemcpyAsync(dout + p_hdr, din + o_total, 16, hipMemcpyDeviceToDevice, st));
+  const int guess = std::min(pool_cap, std::max(ctx->win_guess, 8192));
+  ORBX_HIP(ctx, hipMemcpyAsync(hout, dout, p_pool + 8 * (size_t)guess, hipMemcpyDeviceToHost, st));
+  ORBX_HIP(ctx, hipStreamSynchronize(st));
+  const int total = *(const int32_t*)(hout + p_hdr);
+  const WinQueryOut* qo = (const WinQueryOut*)(hout + p_q);
+  if (lists) {
+    ctx->win_guess = total + total / 4 + 1024;
+    int acc = 0;
+    for (int q = 0; q < nq; q++) { acc += qo[q].count; row_ptr[q + 1] = acc; }
+    if (total > pool_cap) return set_err(ctx, ORBX_E_CAPACITY, std::string(who) + ": candidate buffer too small");
+    if (total > guess) {
+      ORBX_HIP(ctx, hipMemcpyAsync(hout + p_pool + 8 * (size_t)guess, dout + p_pool + 8 * (size_t)guess, 8 * (size_t)(total - guess),
+                                   hipMemcpyDeviceToHost, st));
+      ORBX_HIP(ctx, hipStreamSynchronize(st));
+    }
+    const int2* pool = (const int2*)(hout + p_pool);
+    for (int q = 0; q < nq; q++) {
+      const int2* seg = pool + qo[q].start;
+      const int o = row_ptr[q];
+      for (int c = 0; c < qo[q].count; c++) {
+        if (cand) cand[o + c] = seg[c].x;
+        if (dist) dist[o + c] = seg[c].y;
+      }
+    }
+  } else if (row_ptr) {
+    int acc = 0;
+    for (int q = 0; q < nq; q++) { acc += qo[q].count; row_ptr[q + 1] = acc; }
+  }
+  for (int q = 0; q < nq; q++) {
+    if (best_idx) best_idx[q] = qo[q].best_idx;
+    if (best_dist) best_dist[q] = qo[q].best_dist;
+    if (second_idx) second_idx[q] = qo[q].second_idx;
+    if (second_dist) second_dist[q] = qo[q].second_dist;
+  }
+  return lists ? total : (row_ptr ? row_ptr[nq] : 0);
+}
+
+}  // namespace orbx
+
+using namespace orbx;
+
+extern "C" {
+
+int orbx_window_search_grid(orbx_ctx* ctx, const orbx_keypoint* kps, const uint8_t* desc, int n, const orbx_grid* grid,
+                            const uint8_t* kp_skip, const float* kp_uright, const float* qx, const float* qy, const float* qr,
+                            const int32_t* qmin_level, const int32_t* qmax_level, const uint8_t* q_desc, const float* q_xr, int nq,
+                            int32_t* row_ptr, int32_t* cand, int32_t* dist, int cand_cap, int32_t* best_idx, int32_t* best_dist,
+                            int32_t* second_idx, int32_t* second_dist) {
+  if (!ctx || !grid || n < 0 || nq < 0 || !row_ptr || (n > 0 && (!kps || !desc)) ||
+      (nq > 0 && (!qx || !qy || !qr || !qmin_level || !qmax_level || !q_desc)) || cand_cap < 0 || ((kp_uright != nullptr) != (q_xr != nullptr)) ||
+      !(grid->inv_w > 0.f) || !(grid->inv_h > 0.f))
+    return ctx ? set_err(ctx, ORBX_E_INVALID, "orbx_window_search_grid: bad arguments") : ORBX_E_INVALID;
+  return window_call(ctx, "orbx_window_search_grid", kps, desc, n, grid, kp_skip, kp_uright, nullptr, 0, qx, qy, qr, qmin_level, qmax_level, q_xr,
+                     q_desc, nq, cand || dist, row_ptr, cand, dist, cand_cap, best_idx, best_dist, second_idx, second_dist);
+}
+
+int orbx_window_nearest(orbx_ctx* ctx, const orbx_keypoint* kps, const uint8_t* desc, int n, const orbx_grid* grid,
+                        const float* kp_uright, const float* inv_level_sigma2, int nlevels, const float* qx, const float* qy,
+                        const float* qr, const int32_t* qmin_level, const int32_t* qmax_level, const float* q_ur,
+                        const uint8_t* q_desc, int nq, int32_t* best_idx, int32_t* best_dist) {
+  if (!ctx || !grid || n < 0 || nq < 0 || (n > 0 && (!kps || !desc)) ||
+      (nq > 0 && (!qx || !qy || !qr || !qmin_level || !qmax_level || !q_desc || !best_idx || !best_dist)) ||
+      (inv_level_sigma2 && (!kp_uright || !q_ur || nlevels <= 0)) || !(grid->inv_w > 0.f) || !(grid->inv_h > 0.f))
+    return ctx ? set_err(ctx, ORBX_E_INVALID, "orbx_window_nearest: bad arguments") : ORBX_E_INVALID;
+  const int rc = window_call(ctx, "orbx_window_nearest", kps, desc, n, grid, nullptr, inv_level_sigma2 ? kp_uright : nullptr, inv_level_sigma2,
+                             nlevels, qx, qy, qr, qmin_level, qmax_level, inv_level_sigma2 ? q_ur : nullptr, q_desc, nq, false, nullptr, nullptr,
+                             nullptr, 0, best_idx, best_dist, nullptr, nullptr);
+  return rc < 0 ? rc : ORBX_OK;
+}
+
+}  // extern "C"

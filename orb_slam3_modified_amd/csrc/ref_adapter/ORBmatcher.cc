@@ -1,0 +1,1187 @@
+// orbx adapter — replaces src/ORBmatcher.cc of the reference (lturing/ORB_SLAM3_modified) behind the unchanged class
+// interface of include/ORBmatcher.h.  Every routine has the same three phases:
+//
+//   1. a host pre-pass over the reference's own objects (MapPoint / KeyFrame / Frame, Sophus / Eigen, GeometricCamera) that
+//      evaluates the per-query gates and geometry exactly as the reference's loop head does and flattens the survivors into
+//      query arrays (centre, radius, level range, descriptor);
+//   2. ONE device pass per camera (include/orbx.h): the grid window of every query (Frame / KeyFrame::GetFeaturesInArea), the
+//      Hamming distance of every candidate and — for the routines whose queries are independent (Fuse x2, SearchBySim3,
+//      SURVEY.md §3.3) — the arg-min itself; vocabulary-node routines send their CSR candidate lists to orbx_nn_csr;
+//   3. a host replay in the reference's query order of whatever depends on earlier queries (occupancy of keypoints, stolen
+//      matches, map mutation) and the rotation-consistency filter, written with the reference's own comparison operators
+//      (each routine has its own accept test: `<= TH_HIGH`, `<= TH_LOW`, `< TH_LOW`, `<= TH_LOW*ratioHamming`, ...).
+//
+// Citations `:n` are lines of the reference's src/ORBmatcher.cc.  Two-camera rigs (Frame::Nleft != -1, KeyFrame::NLeft != -1)
+// are handled like the reference handles them: the left and the right camera are two grids over two keypoint arrays that share
+// one descriptor matrix and one map-point vector.
+#include "ORBmatcher.h"
+
+#include <climits>
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+using namespace std;
+
+namespace ORB_SLAM3 {
+
+const int ORBmatcher::TH_HIGH = 100;
+const int ORBmatcher::TH_LOW = 50;
+const int ORBmatcher::HISTO_LENGTH = 30;
+
+static_assert(sizeof(cv::KeyPoint) == sizeof(orbx_keypoint), "cv::KeyPoint must be the 28-byte POD orbx_keypoint mirrors");
+
+namespace {
+
+constexpr int kCols = 64, kRows = 48;   // FRAME_GRID_COLS x FRAME_GRID_ROWS (include/Frame.h:44-45); the device grid is built for these
+
+[[noreturn]] void fail(const char* routine, orbx_ctx* ctx) {
+  throw std::runtime_error(std::string("ORBmatcher::") + routine + ": " + (ctx ? orbx_last_error(ctx) : "no orbx context"));
+}
+
+// mGrid[ix][iy] flattened cell by cell — the lists exactly as AssignFeaturesToGrid left them
+struct FlatGrid {
+  std::vector<int32_t> start, idx;
+  orbx_grid g;
+  template <class CellFn>
+  void build(float minX, float minY, float invW, float invH, int expected, CellFn cell) {
+    start.clear(); idx.clear();
+    start.reserve(kCols * kRows + 1); idx.reserve(expected);
+    start.push_back(0);
+    for (int ix = 0; ix < kCols; ix++)
+      for (int iy = 0; iy < kRows; iy++) {
+        const std::vector<size_t>& c = cell(ix, iy);
+        for (size_t v : c) idx.push_back((int32_t)v);
+        start.push_back((int32_t)idx.size());
+      }
+    g.min_x = minX; g.min_y = minY; g.inv_w = invW; g.inv_h = invH;
+    g.cell_start = start.data(); g.cell_idx = idx.data();
+  }
+};
+
+void frame_grid(const Frame& F, bool bRight, FlatGrid& fg) {
+  fg.build(Frame::mnMinX, Frame::mnMinY, Frame::mfGridElementWidthInv, Frame::mfGridElementHeightInv, F.N,
+           [&](int ix, int iy) -> const std::vector<size_t>& { return bRight ? F.mGridRight[ix][iy] : F.mGrid[ix][iy]; });
+}
+void keyframe_grid(KeyFrame* pKF, bool bRight, FlatGrid& fg) {
+  if (pKF->mnGridCols != kCols || pKF->mnGridRows != kRows) throw std::runtime_error("ORBmatcher: keyframe grid is not 64 x 48");
+  fg.build((float)pKF->mnMinX, (float)pKF->mnMinY, pKF->mfGridElementWidthInv, pKF->mfGridElementHeightInv, pKF->N,
+           [&](int ix, int iy) -> const std::vector<size_t>& { return bRight ? pKF->mGridRight[ix][iy] : pKF->mGrid[ix][iy]; });
+}
+
+// The keypoints a grid is searched over.  GetFeaturesInArea tests the window on mvKeysUn (single camera) or on mvKeys /
+// mvKeysRight (rig); the level a candidate loop reads may come from another array (`levels`), so for rigs a merged copy is
+// made: position from `pos`, octave from `levels`.
+struct KeyView {
+  const orbx_keypoint* p = nullptr;
+  int n = 0;
+  std::vector<cv::KeyPoint> merged;
+  void direct(const std::vector<cv::KeyPoint>& v) { p = (const orbx_keypoint*)v.data(); n = (int)v.size(); }
+  void merge(const std::vector<cv::KeyPoint>& pos, const std::vector<cv::KeyPoint>& levels) {
+    merged = pos;
+    for (size_t i = 0; i < merged.size() && i < levels.size(); i++) merged[i].octave = levels[i].octave;
+    direct(merged);
+  }
+};
+
+// rows of a descriptor matrix as one contiguous block
+struct DescView {
+  const unsigned char* p = nullptr;
+  std::vector<unsigned char> copy;
+  explicit DescView(const cv::Mat& m) {
+    if (m.rows == 0) return;
+    if (m.isContinuous()) { p = m.ptr<unsigned char>(0); return; }
+    copy.resize((size_t)m.rows * 32);
+    for (int r = 0; r < m.rows; r++) std::memcpy(&copy[(size_t)r * 32], m.ptr<unsigned char>(r), 32);
+    p = copy.data();
+  }
+};
+
+struct Queries {
+  std::vector<float> x, y, r, aux;
+  std::vector<int32_t> lo, hi;
+  std::vector<unsigned char> desc;
+  int size() const { return (int)x.size(); }
+  int add(float qx, float qy, float qr, int qlo, int qhi, const cv::Mat& d, float qaux = 0.f) {
+    x.push_back(qx); y.push_back(qy); r.push_back(qr); aux.push_back(qaux); lo.push_back(qlo); hi.push_back(qhi);
+    const unsigned char* s = d.ptr<unsigned char>(0);
+    desc.insert(desc.end(), s, s + 32);
+    return size() - 1;
+  }
+};
+
+struct Lists {   // CSR candidate lists of a query batch, in GetFeaturesInArea's order, with the distances
+  std::vector<int32_t> row_ptr, cand, dist;
+  int begin(int q) const { return row_ptr[q]; }
+  int end(int q) const { return row_ptr[q + 1]; }
+};
+
+void window_lists(const char* routine, const orbx_keypoint* kps, const unsigned char* desc, int n, const orbx_grid& g, const Queries& Q,
+                  Lists& L) {
+  const int nq = Q.size();
+  L.row_ptr.assign(nq + 1, 0);
+  if (nq == 0 || n == 0) return;
+  orbx_ctx* ctx = ORBmatcher::DefaultContext();
+  if (L.cand.size() < 4096) { L.cand.resize(4096); L.dist.resize(4096); }
+  for (int attempt = 0; attempt < 2; attempt++) {
+    const int rc = orbx_window_search_grid(ctx, kps, desc, n, &g, nullptr, nullptr, Q.x.data(), Q.y.data(), Q.r.data(), Q.lo.data(),
+                                           Q.hi.data(), Q.desc.data(), nullptr, nq, L.row_ptr.data(), L.cand.data(), L.dist.data(),
+                                           (int)L.cand.size(), nullptr, nullptr, nullptr, nullptr);
+    if (rc >= 0) return;
+    if (rc != ORBX_E_CAPACITY || attempt) fail(routine, ctx);
+    const size_t need = (size_t)L.row_ptr[nq] + 64;   // row_ptr is complete on ORBX_E_CAPACITY
+    L.cand.resize(need); L.dist.resize(need);
+  }
+}
+
+void window_best(const char* routine, const orbx_keypoint* kps, const unsigned char* desc, int n, const orbx_grid& g, const float* kp_uright,
+                 const float* inv_sigma2, int nlevels, const Queries& Q, std::vector<int32_t>& bestIdx, std::vector<int32_t>& bestDist) {
+  const int nq = Q.size();
+  bestIdx.assign(nq, -1); bestDist.assign(nq, 256);
+  if (nq == 0 || n == 0) return;
+  orbx_ctx* ctx = ORBmatcher::DefaultContext();
+  const int rc = orbx_window_nearest(ctx, kps, desc, n, &g, kp_uright, inv_sigma2, nlevels, Q.x.data(), Q.y.data(), Q.r.data(), Q.lo.data(),
+                                     Q.hi.data(), inv_sigma2 ? Q.aux.data() : nullptr, Q.desc.data(), nq, bestIdx.data(), bestDist.data());
+  if (rc != ORBX_OK) fail(routine, ctx);
+}
+
+// feature vectors of two frames walked node by node (the while-loop shared by the three vocabulary routines, e.g. :244-262,
+// :396-408): fn(indices1, indices2) for every common node, ascending
+template <class Fn>
+void common_nodes(const DBoW2::FeatureVector& a, const DBoW2::FeatureVector& b, Fn fn) {
+  DBoW2::FeatureVector::const_iterator ia = a.begin(), ib = b.begin();
+  while (ia != a.end() && ib != b.end()) {
+    if (ia->first == ib->first) { fn(ia->second, ib->second); ++ia; ++ib; }
+    else if (ia->first < ib->first) ia = a.lower_bound(ib->first);
+    else ib = b.lower_bound(ia->first);
+  }
+}
+
+// rotation-consistency histogram (e.g. :345-352): bin = round(rot / 30) over rot in [0, 360)
+struct RotHist {
+  std::vector<int> bins[30];
+  RotHist() { for (auto& b : bins) b.reserve(500); }
+  void add(float angle1, float angle2, int what) {
+    const float factor = 1.0f / ORBmatcher::HISTO_LENGTH;
+    float rot = angle1 - angle2;
+    if (rot < 0.0) rot += 360.0f;
+    int bin = round(rot * factor);
+    if (bin == ORBmatcher::HISTO_LENGTH) bin = 0;
+    if (bin >= 0 && bin < ORBmatcher::HISTO_LENGTH) bins[bin].push_back(what);
+  }
+};
+
+struct ContextHolder {
+  orbx_ctx* c = nullptr;
+  ~ContextHolder() { if (c) orbx_destroy(c); }
+};
+
+}  // namespace
+
+ORBmatcher::ORBmatcher(float nnratio, bool checkOri) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+
+orbx_ctx* ORBmatcher::DefaultContext() {
+  static thread_local ContextHolder h;
+  if (!h.c && orbx_create(&h.c, 1, 1.2f, 1, 20, 7, -1) != ORBX_OK) {
+    h.c = nullptr;
+    throw std::runtime_error("ORBmatcher: no MI355X / HIP device");
+  }
+  return h.c;
+}
+
+int ORBmatcher::DescriptorDistance(const cv::Mat& a, const cv::Mat& b) { return orbx_hamming(a.ptr<unsigned char>(), b.ptr<unsigned char>()); }
+
+void ORBmatcher::KnnMatch2(const cv::Mat& queryDesc, const cv::Mat& trainDesc, std::vector<int>& idx, std::vector<int>& dist) {
+  idx.assign((size_t)queryDesc.rows * 2, -1);
+  dist.assign((size_t)queryDesc.rows * 2, 256);
+  if (queryDesc.rows == 0) return;
+  DescView q(queryDesc), t(trainDesc);
+  orbx_ctx* ctx = DefaultContext();
+  if (orbx_knn2_allpairs(ctx, q.p, queryDesc.rows, t.p, trainDesc.rows, idx.data(), dist.data()) != ORBX_OK) fail("KnnMatch2", ctx);
+}
+
+float ORBmatcher::RadiusByViewingCos(const float& viewCos) {   // :212-218
+  if (viewCos > 0.998) return 2.5;
+  else return 4.0;
+}
+
+void ORBmatcher::ComputeThreeMaxima(vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3) {   // :2012-2053
+  int max1 = 0, max2 = 0, max3 = 0;
+  for (int i = 0; i < L; i++) {
+    const int s = histo[i].size();
+    if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+    else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+    else if (s > max3) { max3 = s; ind3 = i; }
+  }
+  if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+  else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// SearchByProjection(Frame&, map points)  :43-210
+// ---------------------------------------------------------------------------------------------------------------------
+int ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, const float th, const bool bFarPoints, const float thFarPoints) {
+  int nmatches = 0;
+  const bool bFactor = th != 1.0;
+  const bool rig = F.Nleft != -1;
+  const int nMP = (int)vpMapPoints.size();
+  // phase 1 (:49-74, :143-149): one window per map point and camera it is predicted in
+  Queries QL, QR;
+  std::vector<int> qLeft(nMP, -1), qRight(nMP, -1);
+  for (int iMP = 0; iMP < nMP; iMP++) {
+    MapPoint* pMP = vpMapPoints[iMP];
+    if (!pMP->mbTrackInView && !pMP->mbTrackInViewR) continue;
+    if (bFarPoints && pMP->mTrackDepth > thFarPoints) continue;
+    if (pMP->isBad()) continue;
+    if (pMP->mbTrackInView) {
+      const int& nPredictedLevel = pMP->mnTrackScaleLevel;
+      float r = RadiusByViewingCos(pMP->mTrackViewCos);
+      if (bFactor) r *= th;
+      qLeft[iMP] = QL.add(pMP->mTrackProjX, pMP->mTrackProjY, r * F.mvScaleFactors[nPredictedLevel], nPredictedLevel - 1, nPredictedLevel,
+                          pMP->GetDescriptor(), pMP->mTrackProjXR);
+    }
+    if (rig && pMP->mbTrackInViewR) {
+      const int& nPredictedLevel = pMP->mnTrackScaleLevelR;
+      if (nPredictedLevel != -1) {
+        float r = RadiusByViewingCos(pMP->mTrackViewCosR);
+        qRight[iMP] = QR.add(pMP->mTrackProjXR, pMP->mTrackProjYR, r * F.mvScaleFactors[nPredictedLevel], nPredictedLevel - 1, nPredictedLevel,
+                             pMP->GetDescriptor());
+      }
+    }
+  }
+  if (QL.size() == 0 && QR.size() == 0) return 0;
+  // phase 2
+  DescView D(F.mDescriptors);
+  const std::vector<cv::KeyPoint>& keysL = rig ? F.mvKeys : F.mvKeysUn;
+  FlatGrid gL, gR;
+  Lists LL, LR;
+  if (QL.size()) {
+    frame_grid(F, false, gL);
+    window_lists("SearchByProjection", (const orbx_keypoint*)keysL.data(), D.p, (int)keysL.size(), gL.g, QL, LL);
+  }
+  if (QR.size()) {
+    frame_grid(F, true, gR);
+    window_lists("SearchByProjection", (const orbx_keypoint*)F.mvKeysRight.data(), D.p + (size_t)F.Nleft * 32, (int)F.mvKeysRight.size(), gR.g, QR, LR);
+  }
+  // phase 3 (:76-140, :151-207): a keypoint bound to an observed map point — before the call or by an earlier map point of
+  // this call — is no candidate
+  for (int iMP = 0; iMP < nMP; iMP++) {
+    if (qLeft[iMP] < 0 && qRight[iMP] < 0) continue;
+    MapPoint* pMP = vpMapPoints[iMP];
+    if (qLeft[iMP] >= 0) {
+      const int q = qLeft[iMP];
+      if (LL.begin(q) != LL.end(q)) {
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int c = LL.begin(q); c < LL.end(q); c++) {
+          const size_t idx = LL.cand[c];
+          if (F.mvpMapPoints[idx])
+            if (F.mvpMapPoints[idx]->Observations() > 0) continue;
+          if (F.Nleft == -1 && F.mvuRight[idx] > 0) {
+            const float er = fabs(pMP->mTrackProjXR - F.mvuRight[idx]);
+            if (er > QL.r[q]) continue;
+          }
+          const int dist = LL.dist[c];
+          if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = keysL[idx].octave; bestIdx = idx; }
+          else if (dist < bestDist2) { bestLevel2 = keysL[idx].octave; bestDist2 = dist; }
+        }
+        if (bestDist <= TH_HIGH) {
+          if (bestLevel == bestLevel2 && bestDist > mfNNratio * bestDist2) continue;   // (also skips the right camera, like :125-126)
+          if (bestLevel != bestLevel2 || bestDist <= mfNNratio * bestDist2) {
+            F.mvpMapPoints[bestIdx] = pMP;
+            if (F.Nleft != -1 && F.mvLeftToRightMatch[bestIdx] != -1) { F.mvpMapPoints[F.mvLeftToRightMatch[bestIdx] + F.Nleft] = pMP; nmatches++; }
+            nmatches++;
+          }
+        }
+      }
+    }
+    if (qRight[iMP] >= 0) {
+      const int q = qRight[iMP];
+      if (LR.begin(q) == LR.end(q)) continue;
+      int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+      for (int c = LR.begin(q); c < LR.end(q); c++) {
+        const size_t idx = LR.cand[c];
+        if (F.mvpMapPoints[idx + F.Nleft])
+          if (F.mvpMapPoints[idx + F.Nleft]->Observations() > 0) continue;
+        const int dist = LR.dist[c];
+        if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = F.mvKeysRight[idx].octave; bestIdx = idx; }
+        else if (dist < bestDist2) { bestLevel2 = F.mvKeysRight[idx].octave; bestDist2 = dist; }
+      }
+      if (bestDist <= TH_HIGH) {
+        if (bestLevel == bestLevel2 && bestDist > mfNNratio * bestDist2) continue;
+        if (F.Nleft != -1 && F.mvRightToLeftMatch[bestIdx] != -1) { F.mvpMapPoints[F.mvRightToLeftMatch[bestIdx]] = pMP; nmatches++; }
+        F.mvpMapPoints[bestIdx + F.Nleft] = pMP;
+        nmatches++;
+      }
+    }
+  }
+  return nmatches;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// SearchByBoW(KeyFrame*, Frame&)  :223-425
+// ---------------------------------------------------------------------------------------------------------------------
+int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches) {
+  const vector<MapPoint*> vpMapPointsKF = pKF->GetMapPointMatches();
+  vpMapPointMatches = vector<MapPoint*>(F.N, static_cast<MapPoint*>(NULL));
+  int nmatches = 0;
+  // phase 1: keyframe features with a good map point, node by node; candidates = the frame's features of the node
+  std::vector<unsigned int> qKF;
+  std::vector<int32_t> rowPtr(1, 0), cand;
+  std::vector<unsigned char> qd;
+  common_nodes(pKF->mFeatVec, F.mFeatVec, [&](const vector<unsigned int>& vIndicesKF, const vector<unsigned int>& vIndicesF) {
+    for (size_t iKF = 0; iKF < vIndicesKF.size(); iKF++) {
+      const unsigned int realIdxKF = vIndicesKF[iKF];
+      MapPoint* pMP = vpMapPointsKF[realIdxKF];
+      if (!pMP) continue;
+      if (pMP->isBad()) continue;
+      qKF.push_back(realIdxKF);
+      const unsigned char* d = pKF->mDescriptors.ptr<unsigned char>((int)realIdxKF);
+      qd.insert(qd.end(), d, d + 32);
+      for (size_t iF = 0; iF < vIndicesF.size(); iF++) cand.push_back((int32_t)vIndicesF[iF]);
+      rowPtr.push_back((int32_t)cand.size());
+    }
+  });
+  const int nq = (int)qKF.size();
+  if (nq == 0) return 0;
+  // phase 2
+  std::vector<int32_t> dist(cand.size() + 1);
+  if (!cand.empty()) {
+    DescView D(F.mDescriptors);
+    orbx_ctx* ctx = DefaultContext();
+    if (orbx_nn_csr(ctx, qd.data(), nq, D.p, F.mDescriptors.rows, rowPtr.data(), cand.data(), 0, nullptr, nullptr, nullptr, nullptr, dist.data()) != ORBX_OK)
+      fail("SearchByBoW", ctx);
+  }
+  // phase 3 (:264-391): a frame feature taken by an earlier keyframe feature is no candidate
+  RotHist rot;
+  auto kfKey = [&](unsigned int i) -> const cv::KeyPoint& {
+    return (!pKF->mpCamera2) ? pKF->mvKeysUn[i] : (i >= (unsigned int)pKF->NLeft) ? pKF->mvKeysRight[i - pKF->NLeft] : pKF->mvKeys[i];
+  };
+  for (int q = 0; q < nq; q++) {
+    const unsigned int realIdxKF = qKF[q];
+    MapPoint* pMP = vpMapPointsKF[realIdxKF];
+    int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+    int bestDist1R = 256, bestIdxFR = -1, bestDist2R = 256;
+    for (int c = rowPtr[q]; c < rowPtr[q + 1]; c++) {
+      const unsigned int realIdxF = cand[c];
+      if (vpMapPointMatches[realIdxF]) continue;
+      const int d = dist[c];
+      if (F.Nleft == -1) {
+        if (d < bestDist1) { bestDist2 = bestDist1; bestDist1 = d; bestIdxF = realIdxF; }
+        else if (d < bestDist2) { bestDist2 = d; }
+      } else {
+        if (realIdxF < (unsigned int)F.Nleft && d < bestDist1) { bestDist2 = bestDist1; bestDist1 = d; bestIdxF = realIdxF; }
+        else if (realIdxF < (unsigned int)F.Nleft && d < bestDist2) { bestDist2 = d; }
+        if (realIdxF >= (unsigned int)F.Nleft && d < bestDist1R) { bestDist2R = bestDist1R; bestDist1R = d; bestIdxFR = realIdxF; }
+        else if (realIdxF >= (unsigned int)F.Nleft && d < bestDist2R) { bestDist2R = d; }
+      }
+    }
+    if (bestDist1 <= TH_LOW) {
+      if (static_cast<float>(bestDist1) < mfNNratio * static_cast<float>(bestDist2)) {
+        vpMapPointMatches[bestIdxF] = pMP;
+        if (mbCheckOrientation) {
+          const cv::KeyPoint& Fkp = (!pKF->mpCamera2 || F.Nleft == -1) ? F.mvKeys[bestIdxF]
+                                    : (bestIdxF >= F.Nleft) ? F.mvKeysRight[bestIdxF - F.Nleft] : F.mvKeys[bestIdxF];
+          rot.add(kfKey(realIdxKF).angle, Fkp.angle, bestIdxF);
+        }
+        nmatches++;
+      }
+      if (bestDist1R <= TH_LOW) {   // the right camera's best is accepted without the ratio test (`|| true`, :359)
+        vpMapPointMatches[bestIdxFR] = pMP;
+        if (mbCheckOrientation) {
+          const cv::KeyPoint& Fkp = (!F.mpCamera2) ? F.mvKeys[bestIdxFR] : (bestIdxFR >= F.Nleft) ? F.mvKeysRight[bestIdxFR - F.Nleft] : F.mvKeys[bestIdxFR];
+          rot.add(kfKey(realIdxKF).angle, Fkp.angle, bestIdxFR);
+        }
+        nmatches++;
+      }
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(rot.bins, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0, jend = rot.bins[i].size(); j < jend; j++) { vpMapPointMatches[rot.bins[i][j]] = static_cast<MapPoint*>(NULL); nmatches--; }
+    }
+  }
+  return nmatches;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// SearchByProjection(KeyFrame*, Sim3, points[, their keyframes])  :427-532, :534-646 — one body, two projections
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+struct KeyFrameTarget {   // what the KeyFrame-side routines search: mvKeysUn-levels over the grid the keyframe holds
+  KeyView keys;
+  FlatGrid grid;
+  void set(KeyFrame* pKF) {
+    if (pKF->NLeft == -1) keys.direct(pKF->mvKeysUn);
+    else keys.merge(pKF->mvKeys, pKF->mvKeysUn);   // window on mvKeys (src/KeyFrame.cc:735-737), level from mvKeysUn (e.g. :508)
+    keyframe_grid(pKF, false, grid);
+  }
+};
+}  // namespace
+
+static int SearchByProjectionSim3(const char* routine, KeyFrame* pKF, Sophus::Sim3f& Scw, const vector<MapPoint*>& vpPoints,
+                                  const vector<KeyFrame*>* vpPointsKFs, vector<MapPoint*>& vpMatched, vector<KeyFrame*>* vpMatchedKF, int th,
+                                  float ratioHamming) {
+  const float& fx = pKF->fx;
+  const float& fy = pKF->fy;
+  const float& cx = pKF->cx;
+  const float& cy = pKF->cy;
+  Sophus::SE3f Tcw = Sophus::SE3f(Scw.rotationMatrix(), Scw.translation() / Scw.scale());
+  Eigen::Vector3f Ow = Tcw.inverse().translation();
+  set<MapPoint*> spAlreadyFound(vpMatched.begin(), vpMatched.end());
+  spAlreadyFound.erase(static_cast<MapPoint*>(NULL));
+  // phase 1 (:445-491 / :553-610)
+  Queries Q;
+  std::vector<int> owner;
+  for (int iMP = 0, iendMP = vpPoints.size(); iMP < iendMP; iMP++) {
+    MapPoint* pMP = vpPoints[iMP];
+    if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+    Eigen::Vector3f p3Dw = pMP->GetWorldPos();
+    Eigen::Vector3f p3Dc = Tcw * p3Dw;
+    if (p3Dc(2) < 0.0) continue;
+    float u, v;
+    if (!vpPointsKFs) {
+      const Eigen::Vector2f uv = pKF->mpCamera->project(p3Dc);   // :461
+      u = uv(0); v = uv(1);
+    } else {
+      const float invz = 1 / p3Dc(2);                            // :571-576
+      const float x = p3Dc(0) * invz;
+      const float y = p3Dc(1) * invz;
+      u = fx * x + cx;
+      v = fy * y + cy;
+    }
+    if (!pKF->IsInImage(u, v)) continue;
+    const float maxDistance = pMP->GetMaxDistanceInvariance();
+    const float minDistance = pMP->GetMinDistanceInvariance();
+    Eigen::Vector3f PO = p3Dw - Ow;
+    const float dist = PO.norm();
+    if (dist < minDistance || dist > maxDistance) continue;
+    Eigen::Vector3f Pn = pMP->GetNormal();
+    if (PO.dot(Pn) < 0.5 * dist) continue;
+    int nPredictedLevel = pMP->PredictScale(dist, pKF);
+    const float radius = th * pKF->mvScaleFactors[nPredictedLevel];
+    Q.add(u, v, radius, nPredictedLevel - 1, nPredictedLevel, pMP->GetDescriptor());
+    owner.push_back(iMP);
+  }
+  if (Q.size() == 0) return 0;
+  // phase 2
+  KeyFrameTarget T;
+  T.set(pKF);
+  DescView D(pKF->mDescriptors);
+  Lists L;
+  window_lists(routine, T.keys.p, D.p, T.keys.n, T.grid.g, Q, L);
+  // phase 3 (:497-528): a keypoint matched before, or by an earlier point of this call, is taken
+  int nmatches = 0;
+  for (int q = 0; q < Q.size(); q++) {
+    int bestDist = 256, bestIdx = -1;
+    for (int c = L.begin(q); c < L.end(q); c++) {
+      const size_t idx = L.cand[c];
+      if (vpMatched[idx]) continue;
+      const int dist = L.dist[c];
+      if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+    }
+    if (bestDist <= ORBmatcher::TH_LOW * ratioHamming) {
+      vpMatched[bestIdx] = vpPoints[owner[q]];
+      if (vpMatchedKF) (*vpMatchedKF)[bestIdx] = (*vpPointsKFs)[owner[q]];
+      nmatches++;
+    }
+  }
+  return nmatches;
+}
+
+int ORBmatcher::SearchByProjection(KeyFrame* pKF, Sophus::Sim3f& Scw, const vector<MapPoint*>& vpPoints, vector<MapPoint*>& vpMatched, int th,
+                                   float ratioHamming) {
+  return SearchByProjectionSim3("SearchByProjection", pKF, Scw, vpPoints, nullptr, vpMatched, nullptr, th, ratioHamming);
+}
+
+int ORBmatcher::SearchByProjection(KeyFrame* pKF, Sophus::Sim3<float>& Scw, const std::vector<MapPoint*>& vpPoints,
+                                   const std::vector<KeyFrame*>& vpPointsKFs, std::vector<MapPoint*>& vpMatched,
+                                   std::vector<KeyFrame*>& vpMatchedKF, int th, float ratioHamming) {
+  return SearchByProjectionSim3("SearchByProjection", pKF, Scw, vpPoints, &vpPointsKFs, vpMatched, &vpMatchedKF, th, ratioHamming);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// SearchForInitialization  :648-763
+// ---------------------------------------------------------------------------------------------------------------------
+int ORBmatcher::SearchForInitialization(Frame& F1, Frame& F2, vector<cv::Point2f>& vbPrevMatched, vector<int>& vnMatches12, int windowSize) {
+  int nmatches = 0;
+  vnMatches12 = vector<int>(F1.mvKeysUn.size(), -1);
+  // phase 1: the level-0 keypoints of F1, each around its previous match
+  Queries Q;
+  std::vector<int> owner;
+  for (size_t i1 = 0, iend1 = F1.mvKeysUn.size(); i1 < iend1; i1++) {
+    const int level1 = F1.mvKeysUn[i1].octave;
+    if (level1 > 0) continue;
+    Q.add(vbPrevMatched[i1].x, vbPrevMatched[i1].y, windowSize, level1, level1, F1.mDescriptors.row(i1));
+    owner.push_back((int)i1);
+  }
+  if (Q.size() == 0) return 0;
+  // phase 2
+  const std::vector<cv::KeyPoint>& keys2 = F2.Nleft == -1 ? F2.mvKeysUn : F2.mvKeys;
+  FlatGrid g2;
+  frame_grid(F2, false, g2);
+  DescView D2(F2.mDescriptors);
+  Lists L;
+  window_lists("SearchForInitialization", (const orbx_keypoint*)keys2.data(), D2.p, (int)keys2.size(), g2.g, Q, L);
+  // phase 3 (:676-763): a later keypoint may take a match from an earlier one
+  RotHist rot;
+  vector<int> vMatchedDistance(F2.mvKeysUn.size(), INT_MAX);
+  vector<int> vnMatches21(F2.mvKeysUn.size(), -1);
+  for (int q = 0; q < Q.size(); q++) {
+    const int i1 = owner[q];
+    if (L.begin(q) == L.end(q)) continue;
+    int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+    for (int c = L.begin(q); c < L.end(q); c++) {
+      const size_t i2 = L.cand[c];
+      const int dist = L.dist[c];
+      if (vMatchedDistance[i2] <= dist) continue;
+      if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+      else if (dist < bestDist2) { bestDist2 = dist; }
+    }
+    if (bestDist <= TH_LOW) {
+      if (bestDist < (float)bestDist2 * mfNNratio) {
+        if (vnMatches21[bestIdx2] >= 0) { vnMatches12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+        vnMatches12[i1] = bestIdx2;
+        vnMatches21[bestIdx2] = i1;
+        vMatchedDistance[bestIdx2] = bestDist;
+        nmatches++;
+        if (mbCheckOrientation) rot.add(F1.mvKeysUn[i1].angle, F2.mvKeysUn[bestIdx2].angle, i1);
+      }
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(rot.bins, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0, jend = rot.bins[i].size(); j < jend; j++) {
+        const int idx1 = rot.bins[i][j];
+        if (vnMatches12[idx1] >= 0) { vnMatches12[idx1] = -1; nmatches--; }
+      }
+    }
+  }
+  for (size_t i1 = 0, iend1 = vnMatches12.size(); i1 < iend1; i1++)
+    if (vnMatches12[i1] >= 0) vbPrevMatched[i1] = F2.mvKeysUn[vnMatches12[i1]].pt;
+  return nmatches;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// SearchByBoW(KeyFrame*, KeyFrame*)  :765-905
+// ---------------------------------------------------------------------------------------------------------------------
+int ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12) {
+  const vector<cv::KeyPoint>& vKeysUn1 = pKF1->mvKeysUn;
+  const vector<MapPoint*> vpMapPoints1 = pKF1->GetMapPointMatches();
+  const vector<cv::KeyPoint>& vKeysUn2 = pKF2->mvKeysUn;
+  const vector<MapPoint*> vpMapPoints2 = pKF2->GetMapPointMatches();
+  vpMatches12 = vector<MapPoint*>(vpMapPoints1.size(), static_cast<MapPoint*>(NULL));
+  vector<bool> vbMatched2(vpMapPoints2.size(), false);
+  int nmatches = 0;
+  // phase 1 (:797-833): features with a good map point on both sides (right-camera features of a rig are skipped)
+  std::vector<size_t> q1;
+  std::vector<int32_t> rowPtr(1, 0), cand;
+  std::vector<unsigned char> qd;
+  common_nodes(pKF1->mFeatVec, pKF2->mFeatVec, [&](const vector<unsigned int>& v1, const vector<unsigned int>& v2) {
+    for (size_t i1 = 0, iend1 = v1.size(); i1 < iend1; i1++) {
+      const size_t idx1 = v1[i1];
+      if (pKF1->NLeft != -1 && idx1 >= pKF1->mvKeysUn.size()) continue;
+      MapPoint* pMP1 = vpMapPoints1[idx1];
+      if (!pMP1) continue;
+      if (pMP1->isBad()) continue;
+      q1.push_back(idx1);
+      const unsigned char* d = pKF1->mDescriptors.ptr<unsigned char>((int)idx1);
+      qd.insert(qd.end(), d, d + 32);
+      for (size_t i2 = 0, iend2 = v2.size(); i2 < iend2; i2++) {
+        const size_t idx2 = v2[i2];
+        if (pKF2->NLeft != -1 && idx2 >= pKF2->mvKeysUn.size()) continue;
+        MapPoint* pMP2 = vpMapPoints2[idx2];
+        if (!pMP2) continue;
+        if (pMP2->isBad()) continue;
+        cand.push_back((int32_t)idx2);
+      }
+      rowPtr.push_back((int32_t)cand.size());
+    }
+  });
+  const int nq = (int)q1.size();
+  if (nq == 0) return 0;
+  // phase 2
+  std::vector<int32_t> dist(cand.size() + 1);
+  if (!cand.empty()) {
+    DescView D2(pKF2->mDescriptors);
+    orbx_ctx* ctx = DefaultContext();
+    if (orbx_nn_csr(ctx, qd.data(), nq, D2.p, pKF2->mDescriptors.rows, rowPtr.data(), cand.data(), 0, nullptr, nullptr, nullptr, nullptr, dist.data()) != ORBX_OK)
+      fail("SearchByBoW", ctx);
+  }
+  // phase 3 (:821-867): strict `< TH_LOW` here
+  RotHist rot;
+  for (int q = 0; q < nq; q++) {
+    const size_t idx1 = q1[q];
+    int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+    for (int c = rowPtr[q]; c < rowPtr[q + 1]; c++) {
+      const size_t idx2 = cand[c];
+      if (vbMatched2[idx2]) continue;
+      const int d = dist[c];
+      if (d < bestDist1) { bestDist2 = bestDist1; bestDist1 = d; bestIdx2 = idx2; }
+      else if (d < bestDist2) { bestDist2 = d; }
+    }
+    if (bestDist1 < TH_LOW) {
+      if (static_cast<float>(bestDist1) < mfNNratio * static_cast<float>(bestDist2)) {
+        vpMatches12[idx1] = vpMapPoints2[bestIdx2];
+        vbMatched2[bestIdx2] = true;
+        if (mbCheckOrientation) rot.add(vKeysUn1[idx1].angle, vKeysUn2[bestIdx2].angle, idx1);
+        nmatches++;
+      }
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(rot.bins, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0, jend = rot.bins[i].size(); j < jend; j++) { vpMatches12[rot.bins[i][j]] = static_cast<MapPoint*>(NULL); nmatches--; }
+    }
+  }
+  return nmatches;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// SearchForTriangulation  :907-1146
+// ---------------------------------------------------------------------------------------------------------------------
+int ORBmatcher::SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, vector<pair<size_t, size_t> >& vMatchedPairs, const bool bOnlyStereo,
+                                       const bool bCoarse) {
+  // epipole of the first camera in the second image and the relative poses (:913-943)
+  Sophus::SE3f T1w = pKF1->GetPose();
+  Sophus::SE3f T2w = pKF2->GetPose();
+  Sophus::SE3f Tw2 = pKF2->GetPoseInverse();
+  Eigen::Vector3f Cw = pKF1->GetCameraCenter();
+  Eigen::Vector3f C2 = T2w * Cw;
+  Eigen::Vector2f ep = pKF2->mpCamera->project(C2);
+  Sophus::SE3f T12;
+  Sophus::SE3f Tll, Tlr, Trl, Trr;
+  Eigen::Matrix3f R12;
+  Eigen::Vector3f t12;
+  GeometricCamera *pCamera1 = pKF1->mpCamera, *pCamera2 = pKF2->mpCamera;
+  if (!pKF1->mpCamera2 && !pKF2->mpCamera2) {
+    T12 = T1w * Tw2;
+    R12 = T12.rotationMatrix();
+    t12 = T12.translation();
+  } else {
+    Sophus::SE3f Tr1w = pKF1->GetRightPose();
+    Sophus::SE3f Twr2 = pKF2->GetRightPoseInverse();
+    Tll = T1w * Tw2;
+    Tlr = T1w * Twr2;
+    Trl = Tr1w * Tw2;
+    Trr = Tr1w * Twr2;
+  }
+  Eigen::Matrix3f Rll = Tll.rotationMatrix(), Rlr = Tlr.rotationMatrix(), Rrl = Trl.rotationMatrix(), Rrr = Trr.rotationMatrix();
+  Eigen::Vector3f tll = Tll.translation(), tlr = Tlr.translation(), trl = Trl.translation(), trr = Trr.translation();
+  // phase 1 (:963-996): features of KF1 without a map point against the ones of KF2 in the same node that have none either
+  auto key1 = [&](size_t i) -> const cv::KeyPoint& {
+    return (pKF1->NLeft == -1) ? pKF1->mvKeysUn[i] : (i < (size_t)pKF1->NLeft) ? pKF1->mvKeys[i] : pKF1->mvKeysRight[i - pKF1->NLeft];
+  };
+  auto key2 = [&](size_t i) -> const cv::KeyPoint& {
+    return (pKF2->NLeft == -1) ? pKF2->mvKeysUn[i] : (i < (size_t)pKF2->NLeft) ? pKF2->mvKeys[i] : pKF2->mvKeysRight[i - pKF2->NLeft];
+  };
+  std::vector<size_t> q1;
+  std::vector<int32_t> rowPtr(1, 0), cand;
+  std::vector<unsigned char> qd;
+  common_nodes(pKF1->mFeatVec, pKF2->mFeatVec, [&](const vector<unsigned int>& v1, const vector<unsigned int>& v2) {
+    for (size_t i1 = 0, iend1 = v1.size(); i1 < iend1; i1++) {
+      const size_t idx1 = v1[i1];
+      if (pKF1->GetMapPoint(idx1)) continue;
+      const bool bStereo1 = (!pKF1->mpCamera2 && pKF1->mvuRight[idx1] >= 0);
+      if (bOnlyStereo)
+        if (!bStereo1) continue;
+      q1.push_back(idx1);
+      const unsigned char* d = pKF1->mDescriptors.ptr<unsigned char>((int)idx1);
+      qd.insert(qd.end(), d, d + 32);
+      for (size_t i2 = 0, iend2 = v2.size(); i2 < iend2; i2++) {
+        const size_t idx2 = v2[i2];
+        if (pKF2->GetMapPoint(idx2)) continue;   // (vbMatched2 is never set in this routine)
+        const bool bStereo2 = (!pKF2->mpCamera2 && pKF2->mvuRight[idx2] >= 0);
+        if (bOnlyStereo)
+          if (!bStereo2) continue;
+        cand.push_back((int32_t)idx2);
+      }
+      rowPtr.push_back((int32_t)cand.size());
+    }
+  });
+  const int nq = (int)q1.size();
+  // phase 2
+  std::vector<int32_t> dist(cand.size() + 1);
+  if (nq && !cand.empty()) {
+    DescView D2(pKF2->mDescriptors);
+    orbx_ctx* ctx = DefaultContext();
+    if (orbx_nn_csr(ctx, qd.data(), nq, D2.p, pKF2->mDescriptors.rows, rowPtr.data(), cand.data(), 1, nullptr, nullptr, nullptr, nullptr, dist.data()) != ORBX_OK)
+      fail("SearchForTriangulation", ctx);
+  }
+  // phase 3 (:1010-1100): among the candidates that pass the distance tests, the LAST one that also passes the epipole and
+  // epipolar tests wins (`dist>bestDist -> continue`, then `<=` replaces)
+  int nmatches = 0;
+  vector<int> vMatches12(pKF1->N, -1);
+  RotHist rot;
+  for (int q = 0; q < nq; q++) {
+    const size_t idx1 = q1[q];
+    const bool bStereo1 = (!pKF1->mpCamera2 && pKF1->mvuRight[idx1] >= 0);
+    const cv::KeyPoint& kp1 = key1(idx1);
+    const bool bRight1 = (pKF1->NLeft == -1 || idx1 < (size_t)pKF1->NLeft) ? false : true;
+    int bestDist = TH_LOW;
+    int bestIdx2 = -1;
+    for (int c = rowPtr[q]; c < rowPtr[q + 1]; c++) {
+      const size_t idx2 = cand[c];
+      const int d = dist[c];
+      if (d > TH_LOW || d > bestDist) continue;
+      const bool bStereo2 = (!pKF2->mpCamera2 && pKF2->mvuRight[idx2] >= 0);
+      const cv::KeyPoint& kp2 = key2(idx2);
+      const bool bRight2 = (pKF2->NLeft == -1 || idx2 < (size_t)pKF2->NLeft) ? false : true;
+      if (!bStereo1 && !bStereo2 && !pKF1->mpCamera2) {
+        const float distex = ep(0) - kp2.pt.x;
+        const float distey = ep(1) - kp2.pt.y;
+        if (distex * distex + distey * distey < 100 * pKF2->mvScaleFactors[kp2.octave]) continue;
+      }
+      if (pKF1->mpCamera2 && pKF2->mpCamera2) {
+        if (bRight1 && bRight2) { R12 = Rrr; t12 = trr; T12 = Trr; pCamera1 = pKF1->mpCamera2; pCamera2 = pKF2->mpCamera2; }
+        else if (bRight1 && !bRight2) { R12 = Rrl; t12 = trl; T12 = Trl; pCamera1 = pKF1->mpCamera2; pCamera2 = pKF2->mpCamera; }
+        else if (!bRight1 && bRight2) { R12 = Rlr; t12 = tlr; T12 = Tlr; pCamera1 = pKF1->mpCamera; pCamera2 = pKF2->mpCamera2; }
+        else { R12 = Rll; t12 = tll; T12 = Tll; pCamera1 = pKF1->mpCamera; pCamera2 = pKF2->mpCamera; }
+      }
+      if (bCoarse || pCamera1->epipolarConstrain(pCamera2, kp1, kp2, R12, t12, pKF1->mvLevelSigma2[kp1.octave], pKF2->mvLevelSigma2[kp2.octave])) {
+        bestIdx2 = idx2;
+        bestDist = d;
+      }
+    }
+    if (bestIdx2 >= 0) {
+      const cv::KeyPoint& kp2 = key2(bestIdx2);
+      vMatches12[idx1] = bestIdx2;
+      nmatches++;
+      if (mbCheckOrientation) rot.add(kp1.angle, kp2.angle, idx1);
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(rot.bins, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0, jend = rot.bins[i].size(); j < jend; j++) { vMatches12[rot.bins[i][j]] = -1; nmatches--; }
+    }
+  }
+  vMatchedPairs.clear();
+  vMatchedPairs.reserve(nmatches);
+  for (size_t i = 0, iend = vMatches12.size(); i < iend; i++) {
+    if (vMatches12[i] < 0) continue;
+    vMatchedPairs.push_back(make_pair(i, vMatches12[i]));
+  }
+  return nmatches;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fuse(KeyFrame*, map points, th, bRight)  :1148-1338 — the arg-min comes from the device, nothing is replayed
+// ---------------------------------------------------------------------------------------------------------------------
+int ORBmatcher::Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, const float th, const bool bRight) {
+  GeometricCamera* pCamera;
+  Sophus::SE3f Tcw;
+  Eigen::Vector3f Ow;
+  if (bRight) { Tcw = pKF->GetRightPose(); Ow = pKF->GetRightCameraCenter(); pCamera = pKF->mpCamera2; }
+  else { Tcw = pKF->GetPose(); Ow = pKF->GetCameraCenter(); pCamera = pKF->mpCamera; }
+  const float& bf = pKF->mbf;
+  const int nMPs = vpMapPoints.size();
+  // the geometry of one point (:1193-1243); false when a test of the loop head rejects it
+  struct Proj { float u, v, ur, radius; int level; };
+  auto project = [&](MapPoint* pMP, Proj& o) -> bool {
+    Eigen::Vector3f p3Dw = pMP->GetWorldPos();
+    Eigen::Vector3f p3Dc = Tcw * p3Dw;
+    if (p3Dc(2) < 0.0f) return false;
+    const float invz = 1 / p3Dc(2);
+    const Eigen::Vector2f uv = pCamera->project(p3Dc);
+    if (!pKF->IsInImage(uv(0), uv(1))) return false;
+    const float ur = uv(0) - bf * invz;
+    const float maxDistance = pMP->GetMaxDistanceInvariance();
+    const float minDistance = pMP->GetMinDistanceInvariance();
+    Eigen::Vector3f PO = p3Dw - Ow;
+    const float dist3D = PO.norm();
+    if (dist3D < minDistance || dist3D > maxDistance) return false;
+    Eigen::Vector3f Pn = pMP->GetNormal();
+    if (PO.dot(Pn) < 0.5 * dist3D) return false;
+    int nPredictedLevel = pMP->PredictScale(dist3D, pKF);
+    o.u = uv(0); o.v = uv(1); o.ur = ur; o.level = nPredictedLevel;
+    o.radius = th * pKF->mvScaleFactors[nPredictedLevel];
+    return true;
+  };
+  // phase 1: every point that passes the loop head NOW.  A point that fails isBad() / IsInKeyFrame() now fails them later too
+  // (both only ever become true); the tests are repeated at its turn in phase 3 because the fusions before it may make them true.
+  Queries Q;
+  std::vector<int> qOf(nMPs, -1);
+  for (int i = 0; i < nMPs; i++) {
+    MapPoint* pMP = vpMapPoints[i];
+    if (!pMP) continue;
+    if (pMP->isBad()) continue;
+    else if (pMP->IsInKeyFrame(pKF)) continue;
+    Proj p;
+    if (!project(pMP, p)) continue;
+    qOf[i] = Q.add(p.u, p.v, p.radius, p.level - 1, p.level, pMP->GetDescriptor(), p.ur);
+  }
+  if (Q.size() == 0) return 0;
+  // phase 2: window (KeyFrame::GetFeaturesInArea(..., bRight)), level and reprojection gates (:1262-1296), arg-min
+  KeyView keys;
+  if (pKF->NLeft == -1) keys.direct(pKF->mvKeysUn);
+  else keys.direct(bRight ? pKF->mvKeysRight : pKF->mvKeys);
+  FlatGrid grid;
+  keyframe_grid(pKF, bRight, grid);
+  DescView D(pKF->mDescriptors);
+  const unsigned char* desc = D.p + (bRight ? (size_t)pKF->NLeft * 32 : 0);
+  const int nlevels = (int)pKF->mvInvLevelSigma2.size();
+  std::vector<int32_t> bestIdx, bestDist;
+  window_best("Fuse", keys.p, desc, keys.n, grid.g, pKF->mvuRight.data(), pKF->mvInvLevelSigma2.data(), nlevels, Q, bestIdx, bestDist);
+  // phase 3 (:1176-1192, :1311-1335): the map is changed point by point, in order
+  std::set<MapPoint*> touched;   // points whose descriptor a Replace() of this call recomputed
+  int nFused = 0;
+  for (int i = 0; i < nMPs; i++) {
+    MapPoint* pMP = vpMapPoints[i];
+    if (!pMP) continue;
+    if (pMP->isBad()) continue;
+    else if (pMP->IsInKeyFrame(pKF)) continue;
+    if (qOf[i] < 0) continue;
+    int best = bestIdx[qOf[i]], bestD = bestDist[qOf[i]];
+    if (touched.count(pMP)) {   // its descriptor changed since phase 1: redo this one query
+      Proj p;
+      if (!project(pMP, p)) continue;
+      Queries one;
+      one.add(p.u, p.v, p.radius, p.level - 1, p.level, pMP->GetDescriptor(), p.ur);
+      std::vector<int32_t> bi, bd;
+      window_best("Fuse", keys.p, desc, keys.n, grid.g, pKF->mvuRight.data(), pKF->mvInvLevelSigma2.data(), nlevels, one, bi, bd);
+      best = bi[0]; bestD = bd[0];
+    }
+    if (bestD <= TH_LOW) {
+      const int bestIdxKF = bRight ? best + pKF->NLeft : best;   // (`if(bRight) idx += pKF->NLeft`, :1298)
+      MapPoint* pMPinKF = pKF->GetMapPoint(bestIdxKF);
+      if (pMPinKF) {
+        if (!pMPinKF->isBad()) {
+          if (pMPinKF->Observations() > pMP->Observations()) { pMP->Replace(pMPinKF); touched.insert(pMPinKF); }
+          else { pMPinKF->Replace(pMP); touched.insert(pMP); }
+        }
+      } else {
+        pMP->AddObservation(pKF, bestIdxKF);
+        pKF->AddMapPoint(pMP, bestIdxKF);
+      }
+      nFused++;
+    }
+  }
+  return nFused;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fuse(KeyFrame*, Sim3, points, th, vpReplacePoint)  :1340-1455
+// ---------------------------------------------------------------------------------------------------------------------
+int ORBmatcher::Fuse(KeyFrame* pKF, Sophus::Sim3f& Scw, const vector<MapPoint*>& vpPoints, float th, vector<MapPoint*>& vpReplacePoint) {
+  Sophus::SE3f Tcw = Sophus::SE3f(Scw.rotationMatrix(), Scw.translation() / Scw.scale());
+  Eigen::Vector3f Ow = Tcw.inverse().translation();
+  const set<MapPoint*> spAlreadyFound = pKF->GetMapPoints();
+  const int nPoints = vpPoints.size();
+  // phase 1 (:1358-1405)
+  Queries Q;
+  std::vector<int> owner;
+  for (int iMP = 0; iMP < nPoints; iMP++) {
+    MapPoint* pMP = vpPoints[iMP];
+    if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+    Eigen::Vector3f p3Dw = pMP->GetWorldPos();
+    Eigen::Vector3f p3Dc = Tcw * p3Dw;
+    if (p3Dc(2) < 0.0f) continue;
+    const Eigen::Vector2f uv = pKF->mpCamera->project(p3Dc);
+    if (!pKF->IsInImage(uv(0), uv(1))) continue;
+    const float maxDistance = pMP->GetMaxDistanceInvariance();
+    const float minDistance = pMP->GetMinDistanceInvariance();
+    Eigen::Vector3f PO = p3Dw - Ow;
+    const float dist3D = PO.norm();
+    if (dist3D < minDistance || dist3D > maxDistance) continue;
+    Eigen::Vector3f Pn = pMP->GetNormal();
+    if (PO.dot(Pn) < 0.5 * dist3D) continue;
+    const int nPredictedLevel = pMP->PredictScale(dist3D, pKF);
+    const float radius = th * pKF->mvScaleFactors[nPredictedLevel];
+    Q.add(uv(0), uv(1), radius, nPredictedLevel - 1, nPredictedLevel, pMP->GetDescriptor());
+    owner.push_back(iMP);
+  }
+  if (Q.size() == 0) return 0;
+  // phase 2 (:1411-1433)
+  KeyFrameTarget T;
+  T.set(pKF);
+  DescView D(pKF->mDescriptors);
+  std::vector<int32_t> bestIdx, bestDist;
+  window_best("Fuse", T.keys.p, D.p, T.keys.n, T.grid.g, nullptr, nullptr, 0, Q, bestIdx, bestDist);
+  // phase 3 (:1436-1451)
+  int nFused = 0;
+  for (int q = 0; q < Q.size(); q++) {
+    if (bestDist[q] <= TH_LOW) {
+      const int iMP = owner[q];
+      MapPoint* pMP = vpPoints[iMP];
+      MapPoint* pMPinKF = pKF->GetMapPoint(bestIdx[q]);
+      if (pMPinKF) {
+        if (!pMPinKF->isBad()) vpReplacePoint[iMP] = pMPinKF;
+      } else {
+        pMP->AddObservation(pKF, bestIdx[q]);
+        pKF->AddMapPoint(pMP, bestIdx[q]);
+      }
+      nFused++;
+    }
+  }
+  return nFused;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// SearchBySim3  :1457-1674
+// ---------------------------------------------------------------------------------------------------------------------
+int ORBmatcher::SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const Sophus::Sim3f& S12, const float th) {
+  const float& fx = pKF1->fx;
+  const float& fy = pKF1->fy;
+  const float& cx = pKF1->cx;
+  const float& cy = pKF1->cy;
+  Sophus::SE3f T1w = pKF1->GetPose();
+  Sophus::SE3f T2w = pKF2->GetPose();
+  Sophus::Sim3f S21 = S12.inverse();
+  const vector<MapPoint*> vpMapPoints1 = pKF1->GetMapPointMatches();
+  const int N1 = vpMapPoints1.size();
+  const vector<MapPoint*> vpMapPoints2 = pKF2->GetMapPointMatches();
+  const int N2 = vpMapPoints2.size();
+  vector<bool> vbAlreadyMatched1(N1, false);
+  vector<bool> vbAlreadyMatched2(N2, false);
+  for (int i = 0; i < N1; i++) {
+    MapPoint* pMP = vpMatches12[i];
+    if (pMP) {
+      vbAlreadyMatched1[i] = true;
+      int idx2 = get<0>(pMP->GetIndexInKeyFrame(pKF2));
+      if (idx2 >= 0 && idx2 < N2) vbAlreadyMatched2[idx2] = true;
+    }
+  }
+  // one direction: the points of `from` (seen from camera Tfw) moved by S into the camera of `to` (:1493-1573 / :1576-1653)
+  auto direction = [&](const vector<MapPoint*>& points, const vector<bool>& already, const Sophus::SE3f& Tfw, const Sophus::Sim3f& S,
+                       KeyFrame* pTo, vector<int>& vnMatch) {
+    Queries Q;
+    std::vector<int> owner;
+    for (int i = 0, n = points.size(); i < n; i++) {
+      MapPoint* pMP = points[i];
+      if (!pMP || already[i]) continue;
+      if (pMP->isBad()) continue;
+      Eigen::Vector3f p3Dw = pMP->GetWorldPos();
+      Eigen::Vector3f p3Dcf = Tfw * p3Dw;
+      Eigen::Vector3f p3Dct = S * p3Dcf;
+      if (p3Dct(2) < 0.0) continue;
+      const float invz = 1.0 / p3Dct(2);
+      const float x = p3Dct(0) * invz;
+      const float y = p3Dct(1) * invz;
+      const float u = fx * x + cx;
+      const float v = fy * y + cy;
+      if (!pTo->IsInImage(u, v)) continue;
+      const float maxDistance = pMP->GetMaxDistanceInvariance();
+      const float minDistance = pMP->GetMinDistanceInvariance();
+      const float dist3D = p3Dct.norm();
+      if (dist3D < minDistance || dist3D > maxDistance) continue;
+      const int nPredictedLevel = pMP->PredictScale(dist3D, pTo);
+      const float radius = th * pTo->mvScaleFactors[nPredictedLevel];
+      Q.add(u, v, radius, nPredictedLevel - 1, nPredictedLevel, pMP->GetDescriptor());
+      owner.push_back(i);
+    }
+    if (Q.size() == 0) return;
+    KeyFrameTarget T;
+    T.set(pTo);
+    DescView D(pTo->mDescriptors);
+    std::vector<int32_t> bestIdx, bestDist;
+    window_best("SearchBySim3", T.keys.p, D.p, T.keys.n, T.grid.g, nullptr, nullptr, 0, Q, bestIdx, bestDist);
+    for (int q = 0; q < Q.size(); q++)
+      if (bestDist[q] <= TH_HIGH) vnMatch[owner[q]] = bestIdx[q];
+  };
+  vector<int> vnMatch1(N1, -1);
+  vector<int> vnMatch2(N2, -1);
+  direction(vpMapPoints1, vbAlreadyMatched1, T1w, S21, pKF2, vnMatch1);
+  direction(vpMapPoints2, vbAlreadyMatched2, T2w, S12, pKF1, vnMatch2);
+  // agreement of the two directions (:1655-1673)
+  int nFound = 0;
+  for (int i1 = 0; i1 < N1; i1++) {
+    int idx2 = vnMatch1[i1];
+    if (idx2 >= 0) {
+      int idx1 = vnMatch2[idx2];
+      if (idx1 == i1) { vpMatches12[i1] = vpMapPoints2[idx2]; nFound++; }
+    }
+  }
+  return nFound;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// SearchByProjection(CurrentFrame, LastFrame, th, bMono)  :1676-1885
+// ---------------------------------------------------------------------------------------------------------------------
+int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono) {
+  int nmatches = 0;
+  const Sophus::SE3f Tcw = CurrentFrame.GetPose();
+  const Eigen::Vector3f twc = Tcw.inverse().translation();
+  const Sophus::SE3f Tlw = LastFrame.GetPose();
+  const Eigen::Vector3f tlc = Tlw * twc;
+  const bool bForward = tlc(2) > CurrentFrame.mb && !bMono;
+  const bool bBackward = -tlc(2) > CurrentFrame.mb && !bMono;
+  const bool rig = CurrentFrame.Nleft != -1;
+  // phase 1 (:1694-1733, :1792-1809): project the last frame's map points into the current camera(s)
+  Queries QL, QR;
+  std::vector<int> qLeft(LastFrame.N, -1), qRight(LastFrame.N, -1);
+  for (int i = 0; i < LastFrame.N; i++) {
+    MapPoint* pMP = LastFrame.mvpMapPoints[i];
+    if (!pMP) continue;
+    if (LastFrame.mvbOutlier[i]) continue;
+    Eigen::Vector3f x3Dw = pMP->GetWorldPos();
+    Eigen::Vector3f x3Dc = Tcw * x3Dw;
+    const float invzc = 1.0 / x3Dc(2);
+    if (invzc < 0) continue;
+    Eigen::Vector2f uv = CurrentFrame.mpCamera->project(x3Dc);
+    if (uv(0) < CurrentFrame.mnMinX || uv(0) > CurrentFrame.mnMaxX) continue;
+    if (uv(1) < CurrentFrame.mnMinY || uv(1) > CurrentFrame.mnMaxY) continue;
+    int nLastOctave = (LastFrame.Nleft == -1 || i < LastFrame.Nleft) ? LastFrame.mvKeys[i].octave : LastFrame.mvKeysRight[i - LastFrame.Nleft].octave;
+    float radius = th * CurrentFrame.mvScaleFactors[nLastOctave];
+    const int lo = bForward ? nLastOctave : bBackward ? 0 : nLastOctave - 1;
+    const int hi = bForward ? -1 : bBackward ? nLastOctave : nLastOctave + 1;
+    const float ur = uv(0) - CurrentFrame.mbf * invzc;
+    qLeft[i] = QL.add(uv(0), uv(1), radius, lo, hi, pMP->GetDescriptor(), ur);
+    if (rig) {
+      Eigen::Vector3f x3Dr = CurrentFrame.GetRelativePoseTrl() * x3Dc;
+      Eigen::Vector2f uvr = CurrentFrame.mpCamera->project(x3Dr);
+      qRight[i] = QR.add(uvr(0), uvr(1), radius, lo, hi, pMP->GetDescriptor());
+    }
+  }
+  if (QL.size() == 0) return 0;
+  // phase 2
+  DescView D(CurrentFrame.mDescriptors);
+  const std::vector<cv::KeyPoint>& keysL = rig ? CurrentFrame.mvKeys : CurrentFrame.mvKeysUn;
+  FlatGrid gL, gR;
+  Lists LL, LR;
+  frame_grid(CurrentFrame, false, gL);
+  window_lists("SearchByProjection", (const orbx_keypoint*)keysL.data(), D.p, (int)keysL.size(), gL.g, QL, LL);
+  if (rig) {
+    frame_grid(CurrentFrame, true, gR);
+    window_lists("SearchByProjection", (const orbx_keypoint*)CurrentFrame.mvKeysRight.data(), D.p + (size_t)CurrentFrame.Nleft * 32,
+                 (int)CurrentFrame.mvKeysRight.size(), gR.g, QR, LR);
+  }
+  // phase 3 (:1735-1858)
+  RotHist rot;
+  auto lastKey = [&](int i) -> const cv::KeyPoint& {
+    return (LastFrame.Nleft == -1) ? LastFrame.mvKeysUn[i] : (i < LastFrame.Nleft) ? LastFrame.mvKeys[i] : LastFrame.mvKeysRight[i - LastFrame.Nleft];
+  };
+  for (int i = 0; i < LastFrame.N; i++) {
+    if (qLeft[i] < 0) continue;
+    MapPoint* pMP = LastFrame.mvpMapPoints[i];
+    const int q = qLeft[i];
+    if (LL.begin(q) == LL.end(q)) continue;   // (`if(vIndices2.empty()) continue;` skips the right camera too, :1735-1736)
+    int bestDist = 256, bestIdx2 = -1;
+    for (int c = LL.begin(q); c < LL.end(q); c++) {
+      const size_t i2 = LL.cand[c];
+      if (CurrentFrame.mvpMapPoints[i2])
+        if (CurrentFrame.mvpMapPoints[i2]->Observations() > 0) continue;
+      if (CurrentFrame.Nleft == -1 && CurrentFrame.mvuRight[i2] > 0) {
+        const float er = fabs(QL.aux[q] - CurrentFrame.mvuRight[i2]);
+        if (er > QL.r[q]) continue;
+      }
+      const int dist = LL.dist[c];
+      if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+    }
+    if (bestDist <= TH_HIGH) {
+      CurrentFrame.mvpMapPoints[bestIdx2] = pMP;
+      nmatches++;
+      if (mbCheckOrientation) {
+        const cv::KeyPoint& kpCF = (CurrentFrame.Nleft == -1) ? CurrentFrame.mvKeysUn[bestIdx2]
+                                   : (bestIdx2 < CurrentFrame.Nleft) ? CurrentFrame.mvKeys[bestIdx2] : CurrentFrame.mvKeysRight[bestIdx2 - CurrentFrame.Nleft];
+        rot.add(lastKey(i).angle, kpCF.angle, bestIdx2);
+      }
+    }
+    if (rig) {
+      const int qr = qRight[i];
+      int bestDistR = 256, bestIdxR = -1;
+      for (int c = LR.begin(qr); c < LR.end(qr); c++) {
+        const size_t i2 = LR.cand[c];
+        if (CurrentFrame.mvpMapPoints[i2 + CurrentFrame.Nleft])
+          if (CurrentFrame.mvpMapPoints[i2 + CurrentFrame.Nleft]->Observations() > 0) continue;
+        const int dist = LR.dist[c];
+        if (dist < bestDistR) { bestDistR = dist; bestIdxR = i2; }
+      }
+      if (bestDistR <= TH_HIGH) {
+        CurrentFrame.mvpMapPoints[bestIdxR + CurrentFrame.Nleft] = pMP;
+        nmatches++;
+        if (mbCheckOrientation) rot.add(lastKey(i).angle, CurrentFrame.mvKeysRight[bestIdxR].angle, bestIdxR + CurrentFrame.Nleft);
+      }
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(rot.bins, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i != ind1 && i != ind2 && i != ind3) {
+        for (size_t j = 0, jend = rot.bins[i].size(); j < jend; j++) { CurrentFrame.mvpMapPoints[rot.bins[i][j]] = static_cast<MapPoint*>(NULL); nmatches--; }
+      }
+    }
+  }
+  return nmatches;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// SearchByProjection(CurrentFrame, KeyFrame*, sAlreadyFound, th, ORBdist)  :1887-2010
+// ---------------------------------------------------------------------------------------------------------------------
+int ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, const float th, const int ORBdist) {
+  int nmatches = 0;
+  const Sophus::SE3f Tcw = CurrentFrame.GetPose();
+  Eigen::Vector3f Ow = Tcw.inverse().translation();
+  const vector<MapPoint*> vpMPs = pKF->GetMapPointMatches();
+  // phase 1 (:1904-1934)
+  Queries Q;
+  std::vector<int> owner;
+  for (size_t i = 0, iend = vpMPs.size(); i < iend; i++) {
+    MapPoint* pMP = vpMPs[i];
+    if (!pMP) continue;
+    if (pMP->isBad() || sAlreadyFound.count(pMP)) continue;
+    Eigen::Vector3f x3Dw = pMP->GetWorldPos();
+    Eigen::Vector3f x3Dc = Tcw * x3Dw;
+    const Eigen::Vector2f uv = CurrentFrame.mpCamera->project(x3Dc);
+    if (uv(0) < CurrentFrame.mnMinX || uv(0) > CurrentFrame.mnMaxX) continue;
+    if (uv(1) < CurrentFrame.mnMinY || uv(1) > CurrentFrame.mnMaxY) continue;
+    Eigen::Vector3f PO = x3Dw - Ow;
+    float dist3D = PO.norm();
+    const float maxDistance = pMP->GetMaxDistanceInvariance();
+    const float minDistance = pMP->GetMinDistanceInvariance();
+    if (dist3D < minDistance || dist3D > maxDistance) continue;
+    int nPredictedLevel = pMP->PredictScale(dist3D, &CurrentFrame);
+    const float radius = th * CurrentFrame.mvScaleFactors[nPredictedLevel];
+    Q.add(uv(0), uv(1), radius, nPredictedLevel - 1, nPredictedLevel + 1, pMP->GetDescriptor());
+    owner.push_back((int)i);
+  }
+  if (Q.size() == 0) return 0;
+  // phase 2
+  const std::vector<cv::KeyPoint>& keys = CurrentFrame.Nleft == -1 ? CurrentFrame.mvKeysUn : CurrentFrame.mvKeys;
+  FlatGrid g;
+  frame_grid(CurrentFrame, false, g);
+  DescView D(CurrentFrame.mDescriptors);
+  Lists L;
+  window_lists("SearchByProjection", (const orbx_keypoint*)keys.data(), D.p, (int)keys.size(), g.g, Q, L);
+  // phase 3 (:1941-1982): any keypoint that already has a map point is taken
+  RotHist rot;
+  for (int q = 0; q < Q.size(); q++) {
+    const int i = owner[q];
+    int bestDist = 256, bestIdx2 = -1;
+    for (int c = L.begin(q); c < L.end(q); c++) {
+      const size_t i2 = L.cand[c];
+      if (CurrentFrame.mvpMapPoints[i2]) continue;
+      const int dist = L.dist[c];
+      if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+    }
+    if (bestDist <= ORBdist) {
+      CurrentFrame.mvpMapPoints[bestIdx2] = vpMPs[i];
+      nmatches++;
+      if (mbCheckOrientation) rot.add(pKF->mvKeysUn[i].angle, CurrentFrame.mvKeysUn[bestIdx2].angle, bestIdx2);
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(rot.bins, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i != ind1 && i != ind2 && i != ind3) {
+        for (size_t j = 0, jend = rot.bins[i].size(); j < jend; j++) { CurrentFrame.mvpMapPoints[rot.bins[i][j]] = NULL; nmatches--; }
+      }
+    }
+  }
+  return nmatches;
+}
+
+}  // namespace ORB_SLAM3

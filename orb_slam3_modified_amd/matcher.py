@@ -11,7 +11,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import check, lib, ptr
+from ._lib import OrbxGrid, check, lib, ptr
 
 
 class ORBmatcher:
@@ -112,6 +112,65 @@ class ORBmatcher:
             check(rc, self._ctx)
             return dict(row_ptr=rp, cand=cand[:rc].copy(), dist=dist[:rc].copy(), best_idx=bi[:nq], best_dist=bd[:nq],
                         second_idx=si[:nq], second_dist=sd[:nq])
+
+    @staticmethod
+    def _grid(grid):
+        """grid: dict(min_x, min_y, inv_w, inv_h[, cell_start, cell_idx]) -> (OrbxGrid, keep-alive arrays)."""
+        cs = None if grid.get("cell_start") is None else np.ascontiguousarray(grid["cell_start"], np.int32)
+        ci = None if cs is None else np.ascontiguousarray(grid["cell_idx"], np.int32)
+        g = OrbxGrid(float(grid["min_x"]), float(grid["min_y"]), float(grid["inv_w"]), float(grid["inv_h"]),
+                     None if cs is None else cs.ctypes.data, None if ci is None or len(ci) == 0 else ci.ctypes.data)
+        if cs is not None and len(ci) == 0:
+            ci = np.zeros(1, np.int32)
+            g.cell_idx = ci.ctypes.data
+        return g, (cs, ci)
+
+    def WindowSearchGrid(self, kps, desc, grid, qx, qy, qr, min_level, max_level, q_desc, kp_skip=None, kp_uright=None, q_xr=None,
+                         want_lists=True):
+        """orbx_window_search_grid: orbx_window_search over a caller-held grid (Frame / KeyFrame::GetFeaturesInArea)."""
+        k = np.ascontiguousarray(kps)
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        qx, qy, qr = (np.ascontiguousarray(v, np.float32) for v in (qx, qy, qr))
+        lo, hi = (np.ascontiguousarray(v, np.int32) for v in (min_level, max_level))
+        qd = np.ascontiguousarray(q_desc, np.uint8).reshape(-1, 32)
+        nq = len(qx)
+        skip = None if kp_skip is None else np.ascontiguousarray(kp_skip, np.uint8)
+        ur = None if kp_uright is None else np.ascontiguousarray(kp_uright, np.float32)
+        xr = None if q_xr is None else np.ascontiguousarray(q_xr, np.float32)
+        g, keep = self._grid(grid)
+        rp = np.zeros(nq + 1, np.int32)
+        bi, bd, si, sd = (np.zeros(max(nq, 1), np.int32) for _ in range(4))
+        cap = 1 << 12
+        while True:
+            cand, dist = (np.zeros(cap, np.int32), np.zeros(cap, np.int32)) if want_lists else (None, None)
+            rc = self._L.orbx_window_search_grid(self._ctx, ptr(k), ptr(d), len(k), C.byref(g), ptr(skip), ptr(ur), ptr(qx), ptr(qy), ptr(qr),
+                                                 ptr(lo), ptr(hi), ptr(qd), ptr(xr), nq, ptr(rp), ptr(cand), ptr(dist), cap if want_lists else 0,
+                                                 ptr(bi), ptr(bd), ptr(si), ptr(sd))
+            if rc == -4 and want_lists:   # ORBX_E_CAPACITY: row_ptr[nq] is the capacity needed
+                cap = int(rp[nq]) + 16
+                continue
+            check(rc, self._ctx)
+            out = dict(row_ptr=rp, best_idx=bi[:nq], best_dist=bd[:nq], second_idx=si[:nq], second_dist=sd[:nq])
+            if want_lists:
+                out.update(cand=cand[:rc].copy(), dist=dist[:rc].copy())
+            return out
+
+    def WindowNearest(self, kps, desc, grid, qx, qy, qr, min_level, max_level, q_desc, kp_uright=None, inv_level_sigma2=None, q_ur=None):
+        """orbx_window_nearest: the device arg-min of Fuse x2 / SearchBySim3 (optionally with Fuse's reprojection gate)."""
+        k = np.ascontiguousarray(kps)
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        qx, qy, qr = (np.ascontiguousarray(v, np.float32) for v in (qx, qy, qr))
+        lo, hi = (np.ascontiguousarray(v, np.int32) for v in (min_level, max_level))
+        qd = np.ascontiguousarray(q_desc, np.uint8).reshape(-1, 32)
+        nq = len(qx)
+        ur = None if kp_uright is None else np.ascontiguousarray(kp_uright, np.float32)
+        sig = None if inv_level_sigma2 is None else np.ascontiguousarray(inv_level_sigma2, np.float32)
+        qu = None if q_ur is None else np.ascontiguousarray(q_ur, np.float32)
+        g, keep = self._grid(grid)
+        bi, bd = np.zeros(max(nq, 1), np.int32), np.zeros(max(nq, 1), np.int32)
+        check(self._L.orbx_window_nearest(self._ctx, ptr(k), ptr(d), len(k), C.byref(g), ptr(ur), ptr(sig), 0 if sig is None else len(sig), ptr(qx),
+                                          ptr(qy), ptr(qr), ptr(lo), ptr(hi), ptr(qu), ptr(qd), nq, ptr(bi), ptr(bd)), self._ctx)
+        return bi[:nq], bd[:nq]
 
     def SearchByProjection(self, F, mp, th: float = 1.0):
         """ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th, ...) (src/ORBmatcher.cc:43-141), F.Nleft == -1.

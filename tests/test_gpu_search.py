@@ -256,3 +256,77 @@ def test_search_by_bow_equals_oracle(frames, tmp_path, ratio, ori, levelsup):
     assert n == 0
     with pytest.raises(Exception):     # feature indices beyond the descriptor matrix are refused, not read
         m.SearchByBoW(KF.mDescriptors[:10], KF.mvKeysUn["angle"][:10], valid[:10], kfv, F_.mDescriptors, F_.mvKeysUn["angle"], ffv)
+
+
+def _kf_grid(kps, fbounds, truncate):
+    """A KeyFrame's grid: assigned with the Frame's float bounds (Frame::AssignFeaturesToGrid), queried with the bounds the
+    KeyFrame keeps — truncated to int (include/KeyFrame.h:403-406) — and the Frame's cell sizes."""
+    mnx, mny, mxx, mxy = (np.float32(b) for b in fbounds)
+    inv_w = np.float32(64) / np.float32(mxx - mnx); inv_h = np.float32(48) / np.float32(mxy - mny)
+    cs, ci = po.assign_grid(kps, mnx, mny, inv_w, inv_h)
+    qmx, qmy = (float(int(mnx)), float(int(mny))) if truncate else (float(mnx), float(mny))
+    return dict(min_x=qmx, min_y=qmy, inv_w=float(inv_w), inv_h=float(inv_h), cell_start=cs, cell_idx=ci)
+
+
+@pytest.mark.parametrize("fbounds,truncate,held", [((0.0, 0.0, 640.0, 480.0), False, True), ((-12.7, -9.4, 653.2, 488.9), True, True),
+                                                   ((-12.7, -9.4, 653.2, 488.9), False, False)])
+def test_window_search_grid_equals_oracle(frames, fbounds, truncate, held):
+    """orbx_window_search_grid (the device pass of the KeyFrame-side routines and the two-camera blocks): candidate lists in
+    the reference's order, every distance, best / second — over a grid the caller holds, and over one assigned on the device."""
+    gpu, fr = frames
+    m = ORBmatcher(gpu)
+    k2, d2, d1 = fr[1].mvKeysUn, fr[1].mDescriptors, fr[0].mDescriptors
+    rng = np.random.default_rng(11)
+    nq = min(len(d1), 900)
+    src = rng.integers(0, len(k2), nq)
+    qx = (k2["x"][src] + rng.normal(0, 4, nq)).astype(np.float32); qy = (k2["y"][src] + rng.normal(0, 4, nq)).astype(np.float32)
+    qr = rng.choice([0.0, 2.5, 7.0, 15.0, 36.0, 120.0], nq).astype(np.float32)
+    lo = rng.choice([-1, 0, 1, 3], nq).astype(np.int32); hi = rng.choice([-1, 0, 2, 7], nq).astype(np.int32)
+    grid = _kf_grid(k2, fbounds, truncate)
+    if not held:
+        grid = dict(grid, cell_start=None, cell_idx=None)
+    skip = (rng.random(len(k2)) < 0.2).astype(np.uint8)
+    ur = np.where(rng.random(len(k2)) < 0.3, -1.0, k2["x"] - rng.uniform(1, 40, len(k2))).astype(np.float32)
+    xr = (qx - rng.uniform(1, 40, nq)).astype(np.float32)
+    for kw in (dict(), dict(kp_skip=skip), dict(kp_skip=skip, kp_uright=ur, q_xr=xr)):
+        got = m.WindowSearchGrid(k2, d2, grid, qx, qy, qr, lo, hi, d1[:nq], **kw)
+        want = po.window_search_grid(k2, d2, grid, qx, qy, qr, lo, hi, d1[:nq], **kw)
+        for key in ("row_ptr", "cand", "dist", "best_idx", "best_dist", "second_idx", "second_dist"):
+            assert np.array_equal(got[key], want[key]), (key, kw.keys())
+        assert got["row_ptr"][-1] > 5000
+        best_only = m.WindowSearchGrid(k2, d2, grid, qx, qy, qr, lo, hi, d1[:nq], want_lists=False, **kw)
+        assert np.array_equal(best_only["best_idx"], want["best_idx"]) and np.array_equal(best_only["second_dist"], want["second_dist"])
+        assert np.array_equal(best_only["row_ptr"], want["row_ptr"])
+    # empty sides
+    e = m.WindowSearchGrid(k2[:0], d2[:0], dict(grid, cell_start=None, cell_idx=None), qx[:3], qy[:3], qr[:3], lo[:3], hi[:3], d1[:3])
+    assert e["row_ptr"].tolist() == [0, 0, 0, 0] and e["best_idx"].tolist() == [-1, -1, -1] and e["best_dist"].tolist() == [256] * 3
+    e = m.WindowSearchGrid(k2, d2, grid, qx[:0], qy[:0], qr[:0], lo[:0], hi[:0], d1[:0])
+    assert e["row_ptr"].tolist() == [0] and len(e["cand"]) == 0
+
+
+@pytest.mark.parametrize("chi2", [False, True])
+def test_window_nearest_equals_oracle(frames, chi2):
+    """orbx_window_nearest: the arg-min Fuse x2 / SearchBySim3 take from the device, with Fuse's reprojection gate
+    (src/ORBmatcher.cc:1269-1296: stereo 7.8 / monocular 5.99, float products compared in double)."""
+    gpu, fr = frames
+    m = ORBmatcher(gpu)
+    k2, d2, d1 = fr[1].mvKeysUn, fr[1].mDescriptors, fr[0].mDescriptors
+    rng = np.random.default_rng(12)
+    nq = min(len(d1), 2000)
+    src = rng.integers(0, len(k2), nq)
+    qx = (k2["x"][src] + rng.normal(0, 2.0, nq)).astype(np.float32); qy = (k2["y"][src] + rng.normal(0, 2.0, nq)).astype(np.float32)
+    lvl = k2["octave"][src].astype(np.int32)
+    sf = np.float32(1.2) ** np.arange(8, dtype=np.float32)
+    qr = (np.float32(3.0) * sf[lvl]).astype(np.float32)
+    inv_sigma2 = (1.0 / (sf * sf)).astype(np.float32)
+    ur = np.where(rng.random(len(k2)) < 0.4, -1.0, k2["x"] - rng.uniform(1, 40, len(k2))).astype(np.float32)
+    q_ur = np.where(ur[src] >= 0, ur[src] + rng.normal(0, 1.5, nq), qx - 5).astype(np.float32)
+    grid = _kf_grid(k2, (-12.7, -9.4, 653.2, 488.9), True)
+    kw = dict(kp_uright=ur, inv_level_sigma2=inv_sigma2, q_ur=q_ur) if chi2 else {}
+    bi, bd = m.WindowNearest(k2, d2, grid, qx, qy, qr, lvl - 1, lvl, d1[:nq], **kw)
+    obi, obd = po.window_nearest(k2, d2, grid, qx, qy, qr, lvl - 1, lvl, d1[:nq], **kw)
+    assert np.array_equal(bi, obi) and np.array_equal(bd, obd)
+    assert (bi >= 0).sum() > nq // 3
+    if chi2:   # the gate must bite: without it more queries find a candidate
+        bi0, _ = po.window_nearest(k2, d2, grid, qx, qy, qr, lvl - 1, lvl, d1[:nq])
+        assert (bi0 >= 0).sum() > (obi >= 0).sum()

@@ -1,0 +1,107 @@
+"""Inputs and builds of tests/support/matcher_world.cpp (see its header): the world file (four views of one synthetic
+stream: keypoints, descriptors, feature vectors) and the two executables — the reference's src/ORBmatcher.cc
+(oracle/_ref/ref_matcher_world, built by oracle/ref_fragments.mk where /root/reference exists; prebuilt elsewhere) and
+this repository's drop-in (tests/support/matcher_world*.bin)."""
+from __future__ import annotations
+
+import os
+import struct
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SUP = os.path.join(ROOT, "tests", "support")
+PKG = os.path.join(ROOT, "orb_slam3_modified_amd")
+REF_EXE = os.path.join(ROOT, "oracle", "_ref", "ref_matcher_world")
+ADAPTER_SRC = os.path.join(PKG, "csrc", "ref_adapter", "ORBmatcher.cc")
+INCLUDES = ["-I", os.path.join(ROOT, "include"), "-I", os.path.join(SUP, "ref_world"), "-I", os.path.join(ROOT, "oracle", "ref_shims")]
+CXXFLAGS = ["-O1", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-pthread"]
+
+
+def write_world(path: str, rows: int = 480, cols: int = 752, nfeatures: int = 1000, steps=(0, 2, 4, 6), seed: int = 20260925,
+                levelsup: int = 2) -> dict:
+    """Views = frames `steps` of one synthetic stream, extracted by the oracle; vocabulary k=8, L=3 over their descriptors."""
+    from oracle import pyoracle as po
+    from orb_slam3_modified_amd import synth
+    from tests.vocab_util import make_vocabulary
+    frames = synth.make_stream(max(steps) + 1, rows, cols, seed)
+    ora = po.OracleExtractor(nfeatures, 1.2, 8, 20, 7)
+    views = []
+    for t in steps:
+        kps, desc, _ = ora.extract(frames[t], (0, 0))
+        views.append((kps, desc))
+    vocp = path + ".voc.txt"
+    make_vocabulary(vocp, np.concatenate([d for _, d in views]), 8, 3, seed=5)
+    voc = po.OracleVocabulary(vocp)
+    tb = ora.tables()
+    with open(path, "wb") as f:
+        f.write(struct.pack("<iiii", 0x0b5e55ed, rows, cols, 8))
+        f.write(tb["scale"].astype("<f4").tobytes())
+        f.write(tb["sigma2"].astype("<f4").tobytes())
+        f.write(tb["inv_sigma2"].astype("<f4").tobytes())
+        f.write(struct.pack("<ff", np.float32(1.2), np.float32(np.log(np.float32(1.2)))))
+        f.write(struct.pack("<i", len(views)))
+        for kps, desc in views:
+            _, fv = voc.transform(desc, levelsup)
+            f.write(struct.pack("<i", len(kps)))
+            f.write(kps.tobytes())
+            f.write(np.ascontiguousarray(desc).tobytes())
+            pairs = [(k, i) for k in sorted(fv) for i in fv[k]]
+            f.write(struct.pack("<i", len(pairs)))
+            f.write(np.array(pairs, "<u4").reshape(-1, 2).tobytes())
+    return dict(n=[len(k) for k, _ in views])
+
+
+def _stale(out: str, deps) -> bool:
+    return not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps if os.path.exists(d))
+
+
+def _deps():
+    d = [os.path.join(SUP, "matcher_world.cpp"), ADAPTER_SRC]
+    for base in (os.path.join(ROOT, "include"), os.path.join(SUP, "ref_world"), os.path.join(ROOT, "oracle", "ref_shims", "opencv2", "core")):
+        for dp, _, fs in os.walk(base):
+            d += [os.path.join(dp, f) for f in fs]
+    return d
+
+
+def build_adapter_world(backend: str) -> str:
+    """backend 'orbx': link the drop-in against liborbx.so (needs a GPU to run); 'oracle': against the oracle-backed stub
+    of the C-ABI (tests/support/orbx_oracle_stub.cpp) — the drop-in's host logic on a CPU."""
+    out = os.path.join(SUP, f"matcher_world_{backend}.bin")
+    srcs = [os.path.join(SUP, "matcher_world.cpp"), ADAPTER_SRC]
+    if backend == "orbx":
+        from orb_slam3_modified_amd import build
+        build.build()
+        link = ["-L", PKG, "-lorbx", "-Wl,-rpath," + PKG, "-Wl,--allow-shlib-undefined"]
+        deps = _deps() + [os.path.join(PKG, "liborbx.so")]
+    else:
+        from oracle import pyoracle
+        pyoracle.build()
+        srcs.append(os.path.join(SUP, "orbx_oracle_stub.cpp"))
+        odir = os.path.join(ROOT, "oracle")
+        link = ["-L", odir, "-lorb_oracle", "-Wl,-rpath," + odir]
+        deps = _deps() + [srcs[-1], os.path.join(odir, "liborb_oracle.so")]
+    if _stale(out, deps):
+        subprocess.check_call(["g++"] + CXXFLAGS + INCLUDES + srcs + ["-o", out] + link)
+    return out
+
+
+def run_world(exe: str, world: str, out: str, only: str = "") -> str:
+    r = subprocess.run([exe, world, out] + ([only] if only else []), capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"{exe} failed ({r.returncode}): {r.stdout}{r.stderr}")
+    return open(out).read()
+
+
+def first_difference(a: str, b: str) -> str:
+    la, lb = a.splitlines(), b.splitlines()
+    scen = ""
+    for i, (x, y) in enumerate(zip(la, lb)):
+        if not x.startswith("  "):
+            scen = x
+        if x != y:
+            xs, ys = x.split(), y.split()
+            k = next((j for j, (p, q) in enumerate(zip(xs, ys)) if p != q), min(len(xs), len(ys)))
+            return f"scenario '{scen}', line {i}: token {k}: {xs[k:k + 6]} != {ys[k:k + 6]} ({x[:60]}...)"
+    return f"lengths differ: {len(la)} vs {len(lb)} lines" if len(la) != len(lb) else ""
