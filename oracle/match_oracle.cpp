@@ -1,5 +1,9 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see orb_oracle.cpp header).  **parity unpinned**: the reference holds no
-// tests or golden vectors for the matcher / DBoW2 path.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see orb_oracle.cpp header).  PARITY STATUS: pinned.  The reference holds no tests or
+// golden vectors for the matcher / DBoW2 path, but its own code is compiled here (oracle/ref_fragments.mk):
+// the vendored DBoW2 (oracle/_ref/libref_dbow2.so; tests/test_ref_fragments.py compares the vocabulary / scoring
+// functions below with it) and src/ORBmatcher.cc itself (oracle/_ref/ref_matcher_world, against the object model of
+// tests/support/ref_world; tests/test_matcher_world.py compares the drop-in matcher — running on the window / nn
+// primitives at the end of this file — with it on all 12 routines).
 //
 // CPU restatement of
 //   * ORBmatcher::DescriptorDistance                     src/ORBmatcher.cc:2058-2074 (== FORB::distance, FORB.cpp:77-96)

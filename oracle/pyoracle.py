@@ -582,3 +582,70 @@ class OracleKeyFrameDatabase:
         k = self._L.mo_kfdb_query(self._h, _ptr(ids), _ptr(vals), len(ids), _ptr(ex), len(ex), int(min_words_floor), _ptr(kf), _ptr(words),
                                   _ptr(score), C.byref(mx), C.byref(mn))
         return dict(kf=kf[:k].copy(), words=words[:k].copy(), score=score[:k].copy(), max_common=mx.value, min_common=mn.value)
+
+
+# ---- the REFERENCE's own ORBextractor (oracle/_ref/libref_orbextractor.so: src/ORBextractor.cc compiled where it lies) ----
+_REF_EXT_PATH = os.path.join(_HERE, "_ref", "libref_orbextractor.so")
+_ref_ext = None
+
+
+def ref_extractor_available() -> bool:
+    return os.path.exists(_REF_EXT_PATH)
+
+
+def _ref_ext_lib():
+    global _ref_ext
+    if _ref_ext is None:
+        lib()   # liborb_oracle.so provides the five forwarded OpenCV primitives
+        R = C.CDLL(_REF_EXT_PATH)
+        vp = C.c_void_p
+        R.ref_ext_create.restype = vp
+        R.ref_ext_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        R.ref_ext_destroy.argtypes = [vp]
+        R.ref_ext_extract.restype = C.c_int
+        R.ref_ext_extract.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_int)]
+        R.ref_ext_tables.argtypes = [vp, vp, vp, vp, vp]
+        R.ref_ext_level.restype = C.c_int
+        R.ref_ext_level.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        _ref_ext = R
+    return _ref_ext
+
+
+class RefExtractor:
+    """ORB_SLAM3::ORBextractor — the reference's own class (include/ORBextractor.h:49-83)."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        self.nfeatures, self.nlevels = nfeatures, nlevels
+        self._h = _ref_ext_lib().ref_ext_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        self.cap = nfeatures + 3 * nlevels + 64
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _ref_ext_lib().ref_ext_destroy(self._h)
+            self._h = None
+
+    def tables(self):
+        n = self.nlevels
+        sc, isc, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        _ref_ext_lib().ref_ext_tables(self._h, _ptr(sc), _ptr(isc), _ptr(s2), _ptr(is2))
+        return dict(scale=sc, inv_scale=isc, sigma2=s2, inv_sigma2=is2)
+
+    def extract(self, img: np.ndarray, lapping=(0, 0)):
+        """operator()(image, mask, keypoints, descriptors, vLappingArea) -> (keypoints, descriptors, return value)."""
+        assert img.dtype == np.uint8 and img.ndim == 2 and img.strides[1] == 1
+        kps = np.zeros(self.cap, KP_DTYPE)
+        desc = np.zeros((self.cap, 32), np.uint8)
+        n = C.c_int(0)
+        mono = _ref_ext_lib().ref_ext_extract(self._h, img.ctypes.data, img.shape[0], img.shape[1], img.strides[0], int(lapping[0]),
+                                              int(lapping[1]), _ptr(kps), _ptr(desc), self.cap, C.byref(n))
+        if mono == -100000:
+            raise RuntimeError(f"reference extractor returned {n.value} keypoints, more than the capacity {self.cap}")
+        return kps[:n.value].copy(), desc[:n.value].copy(), mono
+
+    def level(self, level: int, with_border: bool = False) -> np.ndarray:
+        w, h = C.c_int(0), C.c_int(0)
+        assert _ref_ext_lib().ref_ext_level(self._h, level, 0, None, C.byref(w), C.byref(h)) == 0
+        b = 19 if with_border else 0
+        out = np.zeros((h.value + 2 * b, w.value + 2 * b), np.uint8)
+        assert _ref_ext_lib().ref_ext_level(self._h, level, int(with_border), _ptr(out), C.byref(w), C.byref(h)) == 0
+        return out

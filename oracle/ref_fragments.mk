@@ -17,7 +17,7 @@ SRCS := $(REF)/DBoW2/BowVector.cpp $(REF)/DBoW2/FeatureVector.cpp $(REF)/DBoW2/S
 WORLD := ../tests/support/ref_world
 WORLD_HDRS := $(wildcard $(WORLD)/*.h $(WORLD)/*/* $(WORLD)/*/*/*/*) $(wildcard ref_shims/opencv2/*/*.hpp)
 
-all: _ref/libref_dbow2.so _ref/ref_matcher_world
+all: _ref/libref_dbow2.so _ref/ref_matcher_world _ref/libref_orbextractor.so
 
 _ref/libref_dbow2.so: $(SRCS) ref_shims/opencv2/core/core.hpp ref_shims/boost/serialization/serialization.hpp
 	mkdir -p _ref
@@ -29,4 +29,10 @@ _ref/ref_matcher_world: $(REFROOT)/src/ORBmatcher.cc $(REFROOT)/include/ORBmatch
 	mkdir -p _ref
 	$(CXX) -O1 -std=c++17 -ffp-contract=off -w -include $(WORLD)/ref_world.h -I$(WORLD) -Iref_shims -I$(REFROOT)/include \
 	    $(REFROOT)/src/ORBmatcher.cc ../tests/support/matcher_world.cpp -o $@
+
+# the five OpenCV algorithm calls resolve to orbo_* in liborb_oracle.so (built by oracle/Makefile)
+_ref/libref_orbextractor.so: $(REFROOT)/src/ORBextractor.cc $(REFROOT)/include/ORBextractor.h ref_wrap_extractor.cpp liborb_oracle.so $(wildcard ref_shims/opencv2/*/*.hpp)
+	mkdir -p _ref
+	$(CXX) -O2 -std=c++14 -fPIC -ffp-contract=off -w -Iref_shims -I$(REFROOT)/include -shared -o $@ $(REFROOT)/src/ORBextractor.cc ref_wrap_extractor.cpp \
+	    -L. -lorb_oracle -Wl,-rpath,'$$ORIGIN/..'
 .PHONY: all

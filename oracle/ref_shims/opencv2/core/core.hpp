@@ -9,6 +9,7 @@
 // isolated primitives (orbo_*), which remain "recalled OpenCV semantics" (DESIGN.md §2).
 // cv::FileStorage/FileNode only have to parse (DBoW2's YAML save/load members are never called).
 #pragma once
+#include <algorithm>
 #include <cassert>
 #include <cmath>
 #include <cstdint>
@@ -72,6 +73,8 @@ struct KeyPoint {
 };
 static_assert(sizeof(KeyPoint) == 28, "cv::KeyPoint layout");
 
+class _OutputArray;
+
 class Mat {
  public:
   int rows = 0, cols = 0;
@@ -117,6 +120,7 @@ class Mat {
     dst.create(rows, cols, type_);
     for (int r = 0; r < rows; r++) std::memmove(dst.data + (size_t)r * dst.step, data + (size_t)r * step, (size_t)cols * esz());
   }
+  inline void copyTo(const _OutputArray& dst) const;   // cv::Mat::copyTo(OutputArray): also takes a temporary header (a row view)
   static Mat zeros(int r, int c, int type) {
     Mat m(r, c, type);
     std::memset(m.data, 0, (size_t)r * m.step);
@@ -148,12 +152,14 @@ class _InputArray {
 class _OutputArray {
  public:
   _OutputArray(Mat& m) : m_(&m) {}
+  _OutputArray(const Mat& m) : m_(const_cast<Mat*>(&m)) {}   // like OpenCV: a header whose buffer is written through
   void create(int r, int c, int type) const { m_->create(r, c, type); }
   void release() const { m_->release(); }
   Mat getMat() const { return *m_; }
  private:
   Mat* m_;
 };
+inline void Mat::copyTo(const _OutputArray& dst) const { Mat d = dst.getMat(); copyTo(d); }
 typedef const _InputArray& InputArray;
 typedef const _OutputArray& OutputArray;
 

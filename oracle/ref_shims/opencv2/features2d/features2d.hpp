@@ -15,4 +15,7 @@ static inline void FAST(const Mat& image, std::vector<KeyPoint>& keypoints, int 
   keypoints.resize(n < 0 ? 0 : n);
 }
 
+// only named by the dead ComputeKeyPointsOld (src/ORBextractor.cc:898-1075, its call is commented out at :1101)
+struct KeyPointsFilter { static void retainBest(std::vector<KeyPoint>&, int) { std::abort(); } };
+
 }  // namespace cv

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/*.npz (run in the build container: needs oracle/_ref/libref_dbow2.so, i.e. the reference).
+"""Generates tests/golden/*.npz (run in the build container: needs oracle/_ref/*.so, i.e. the reference).
 
-  extractor_small.npz : oracle outputs for three small seeded frames (the reference extractor cannot run here:
-                        OpenCV is absent -> these pin the oracle, not the reference; "parity unpinned")
+  extractor_small.npz : outputs of the REFERENCE'S OWN src/ORBextractor.cc (oracle/_ref/libref_orbextractor.so, compiled where
+                        it lies against the container shim; its five OpenCV algorithm calls are the oracle's isolated
+                        primitives) for three small seeded frames
   bow_reference.npz   : outputs of the REFERENCE'S OWN DBoW2 code (loadFromTextFile / transform / score) on a small
                         vocabulary -> a true reference golden
 """
@@ -24,7 +25,7 @@ frames = {"g320": synth.make_stream(2, 240, 320, 777), "g376": synth.make_stream
 alld = []
 for key, fr in frames.items():
     for t, img in enumerate(fr):
-        kps, desc, mono = po.OracleExtractor(300, 1.2, 5, 20, 7).extract(img, (0, 1000))
+        kps, desc, mono = po.RefExtractor(300, 1.2, 5, 20, 7).extract(img, (0, 1000))
         out[f"{key}_{t}_imgsha"] = hashlib.sha256(img.tobytes()).hexdigest()
         out[f"{key}_{t}_kps"], out[f"{key}_{t}_desc"], out[f"{key}_{t}_mono"] = kps, desc, mono
         alld.append(desc)
