@@ -2,19 +2,29 @@
 """ORB front-end throughput on MI355X: features/ms and frames/s of the extractor hot path.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one pass of the hot path (pyramid -> FAST cells -> quadtree -> orientation -> rBRIEF) over one batch
-of B synthetic 640x480 frames per GPU that are already resident in HBM; results stay in HBM.  Workload =
-BASELINE.json configs[1] shape (S-EuRoC-640: 640x480, 8 levels, 1000 features) replayed in batches; every rank
-replays its own camera stream (seed + 1000*rank), i.e. weak scaling, and for N > 1 the per-step feature blocks
-are all-gathered over RCCL asynchronously (batch-replay mode).
+Started without WORLD_SIZE and with N > 1, the script re-executes itself under `torch.distributed.run` with one rank per
+visible GPU (min(N, visible); the line reports the world size RCCL actually saw).  Started by a launcher (RANK / LOCAL_RANK /
+WORLD_SIZE set) it is one rank of that job.
+
+A "step" is one pass of the hot path (pyramid -> FAST cells -> quadtree -> orientation -> rBRIEF) over one batch of B synthetic
+640x480 frames per GPU that are already resident in HBM; results stay in HBM.  Workload = BASELINE.json configs[1] shape
+(S-EuRoC-640: 640x480, 8 levels, 1000 features) replayed in batches; the steps rotate through several DISTINCT batches (more
+input than the 256 MB Infinity Cache holds); every rank replays its own camera stream (seed + 1000*rank), i.e. weak scaling,
+and for N > 1 the per-step feature blocks are all-gathered over RCCL asynchronously (batch-replay mode).
+After the timed region frames of the last step are compared with the CPU oracle ("verified_frames"); a mismatch fails the run.
+At N = 1 the same line also carries: the end-to-end latency of ORBextractor::operator() through the C++ adapter (host buffers),
+a secondary measurement of BASELINE config 4 (1024x1024, 2000 features) with its own roofline, and the CPU baseline.
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -51,38 +61,123 @@ def algorithmic_bytes(rows, cols, n_keypoints_per_frame, n_candidates_per_frame)
     return fused, staged
 
 
-def cpu_baseline(frames, nfeatures, budget_s=20.0):
-    """The oracle (CPU restatement of src/ORBextractor.cc) timed on the host cores: a REPORTED baseline."""
-    from concurrent.futures import ThreadPoolExecutor
+def cpu_baseline(frames, nfeatures, budget_s=24.0):
+    """The oracle (CPU restatement of src/ORBextractor.cc, pinned to the reference's own file by tests/test_ref_fragments.py)
+    timed on the host cores: a REPORTED baseline.  The timing copy is built here with -O3 -march=native -ffp-contract=off
+    (SURVEY.md §8(d)); the frame-parallel leg is a std::thread pool inside the library (orbo_extract_many)."""
     from oracle import pyoracle as po
     ncores = os.cpu_count() or 1
-    one = po.OracleExtractor(nfeatures, 1.2, 8, 20, 7)
-    one.extract(frames[0], (0, 1000))
+    po.build()
+    libpath, flags = os.path.join(ROOT, "oracle", "liborb_oracle.so"), "portable build (-O3, no -march=native: native build failed)"
+    tmp = tempfile.mkdtemp(prefix="orbx_native_")
+    try:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "native", f"OUT={tmp}"], stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL)
+        libpath, flags = os.path.join(tmp, "liborb_oracle_native.so"), "-O3 -march=native -ffp-contract=off"
+    except Exception:
+        pass
+    L = C.CDLL(libpath)
+    L.orbo_extract_many.restype = C.c_double
+    L.orbo_extract_many.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 6 + [C.c_double, C.POINTER(C.c_longlong),
+                                                                                                              C.POINTER(C.c_longlong)]
+    fr = np.ascontiguousarray(frames)
+    n, rows, cols = fr.shape
+
+    def run(threads, seconds):
+        f, k = C.c_longlong(0), C.c_longlong(0)
+        dt = L.orbo_extract_many(nfeatures, 1.2, 8, 20, 7, fr.ctypes.data, n, rows, cols, 0, 1000, threads, seconds, C.byref(f), C.byref(k))
+        return f.value / (dt * 1e3), k.value, dt
+
+    v1, k1, dt1 = run(1, budget_s * 0.4)
+    va, ka, dta = run(ncores, budget_s * 0.6)
+    return {"value": round(va, 3), "unit": "features/ms", "cores": ncores, "kind": "port", "value_1core": round(v1, 3),
+            "ms_per_frame_1core": round(dt1 * 1e3 / max(k1, 1), 3), "scaling_efficiency": round(va / (v1 * ncores), 3), "build": flags,
+            "sample": f"{ka} frames of the same {cols}x{rows} stream on {ncores} std::threads ({dta:.1f} s); 1-core figure from {k1} frames "
+                      f"({dt1:.1f} s); CPU path = this repo's restatement of src/ORBextractor.cc, checked bit for bit against the reference's "
+                      "own file compiled over a container shim; its five OpenCV primitives are scalar restatements (real OpenCV SIMD "
+                      "FAST / blur / resize is typically faster)"}
+
+
+def e2e_operator(host_frames, nfeatures):
+    """ORBextractor::operator() per frame through the C++ adapter, host buffers (tools/e2e_operator.cpp built here)."""
+    pkg = os.path.join(ROOT, "orb_slam3_modified_amd")
+    tmp = tempfile.mkdtemp(prefix="orbx_e2e_")
+    exe, raw = os.path.join(tmp, "e2e_operator"), os.path.join(tmp, "frames.raw")
+    try:
+        subprocess.check_call(["g++", "-O2", "-std=c++14", "-DORBX_FORCE_CV_COMPAT", "-I", os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "tools", "e2e_operator.cpp"), "-o", exe, "-L", pkg, "-lorbx", "-Wl,-rpath," + pkg,
+                               "-Wl,--allow-shlib-undefined"], stderr=subprocess.DEVNULL)
+        fr = np.ascontiguousarray(host_frames[:32])
+        fr.tofile(raw)
+        r = subprocess.run([exe, raw, str(fr.shape[1]), str(fr.shape[2]), str(len(fr)), str(nfeatures), "30"], capture_output=True, text=True,
+                           timeout=120)
+        if r.returncode != 0:
+            return {"error": (r.stderr or r.stdout).strip()[:200]}
+        out = json.loads(r.stdout.strip().splitlines()[-1])
+        out["what"] = ("ORB_SLAM3::ORBextractor::operator() through include/ORBextractor.h, one frame per call, host buffers: H2D image, "
+                       "kernels, D2H keypoints + descriptors (PCIe-inclusive, latency-bound; never the headline value)")
+        return out
+    except Exception as e:   # noqa: BLE001 — a missing compiler must not fail the benchmark line
+        return {"error": str(e)[:200]}
+
+
+def verify_block(eng, block_index, host_frames, frame_ids, nfeatures, lap):
+    """Frames of one finished step against the CPU oracle, bit for bit.  Returns the number verified; raises on mismatch."""
+    from oracle import pyoracle as po
+    from orb_slam3_modified_amd.replay import unpack_block
+    res = unpack_block(eng.blocks[block_index].cpu().numpy(), eng.layout)
+    ora = po.OracleExtractor(nfeatures, 1.2, 8, 20, 7)
+    for f in frame_ids:
+        okps, odesc, omono = ora.extract(host_frames[f], lap)
+        mono, kps, desc = res[f]
+        if not (mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc)):
+            raise SystemExit(f"bench.py: frame {f} of the last timed step differs from the CPU oracle "
+                             f"({len(kps)} vs {len(okps)} keypoints) — the measured path is WRONG, no number reported")
+    return len(frame_ids)
+
+
+def kernel_roofline(ex, eng, frames, B, H, W, counts, world, steps, dt, nprof=5):
+    """HIP-event time of every kernel (passes after the timed region: whole per-GPU batch on one context, kernels back to back)
+    -> roofline object of the dominant kernel."""
+    import torch
+    ex.profile_enable(True)
+    for _ in range(nprof):
+        ex.extract_batch_device(frames.data_ptr(), B, H, W, frames.stride(1), frames.stride(0), eng.blocks[0].data_ptr(),
+                                eng.blocks[0].data_ptr() + eng.layout.desc_off, eng.blocks[0].data_ptr() + eng.layout.counts_off,
+                                (0, 1000), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    prof = ex.profile_read()
+    ex.profile_enable(False)
+    ncand = sum(len(ex.debug_level_points(l, 0, frame=0)[0]) for l in range(8))
+    nkp = float(counts[:, 0].mean())
+    fused, staged = algorithmic_bytes(H, W, nkp, float(ncand))
+    per_kernel = {k: (ms / max(n, 1)) for k, (ms, n) in prof.items() if n}
+    dom = max(per_kernel, key=per_kernel.get)
+    dom_ms = per_kernel[dom]
+    dom_bytes = staged[dom] * B
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+    return dom, nkp, fused, {
+        "bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+        "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4), "frames_per_launch": B,
+        "launch_conditions": "whole per-GPU batch in one launch, kernels back to back (passes after the timed region)",
+        "pipeline_fused_ideal_bytes_per_frame": int(fused),
+        "pipeline_frac": round(fused * (B * world * steps / dt) / 1e9 / (HBM_PEAK_GBS * world), 5),
+        "kernels_ms_per_launch": {k: round(v, 4) for k, v in per_kernel.items()}}
+
+
+def timed_replay(eng, steps, warmup, sync_all):
+    for _ in range(warmup):
+        eng.step()
+    eng.drain()
+    sync_all()
     t0 = time.perf_counter()
-    n1 = 0
-    k1 = 0
-    while time.perf_counter() - t0 < budget_s * 0.3:   # ~6 s of single-core work, looping over the stream
-        n1 += len(one.extract(frames[k1 % len(frames)], (0, 1000))[0])
-        k1 += 1
-    dt1 = time.perf_counter() - t0
-    v1 = n1 / (dt1 * 1e3)
-    # all cores: frame-parallel pool, one oracle instance per thread (ctypes releases the GIL)
-    per = max(1, int(round(budget_s * 0.7 / max(dt1 / k1, 1e-3) / ncores)))   # ~0.7*budget seconds of CPU work in total
-    exs = [po.OracleExtractor(nfeatures, 1.2, 8, 20, 7) for _ in range(ncores)]
-
-    def work(t):
-        return sum(len(exs[t].extract(frames[(t * per + i) % len(frames)], (0, 1000))[0]) for i in range(per))
-
-    with ThreadPoolExecutor(ncores) as pool:
-        list(pool.map(lambda t: exs[t].extract(frames[0], (0, 1000)), range(ncores)))
-        t0 = time.perf_counter()
-        nall = sum(pool.map(work, range(ncores)))
-        dta = time.perf_counter() - t0
-    return {"value": round(nall / (dta * 1e3), 3), "unit": "features/ms", "cores": ncores, "kind": "port",
-            "value_1core": round(v1, 3),
-            "sample": f"{per * ncores} frames of the same 640x480 stream on {ncores} threads ({dta:.1f} s); "
-                      f"1-core figure from {k1} frames ({dt1:.1f} s); CPU path = this repo's restatement of "
-                      "src/ORBextractor.cc + OpenCV primitive semantics (scalar; real OpenCV SIMD FAST/blur is typically faster)"}
+    last = 0
+    for _ in range(steps):
+        last = eng.step()
+    eng.drain()
+    sync_all()
+    return time.perf_counter() - t0, last
 
 
 def main():
@@ -91,23 +186,32 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU")
+    ap.add_argument("--batches", type=int, default=4, help="distinct batches the steps rotate through")
     ap.add_argument("--rows", type=int, default=480)
     ap.add_argument("--cols", type=int, default=640)
     ap.add_argument("--nfeatures", type=int, default=1000)
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the batch-replay RCCL all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the cpu_baseline leg")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the config-4 (1024x1024, 2000 features) leg and the operator() leg")
+    ap.add_argument("--cpu-budget", type=float, default=24.0, help="seconds of CPU work for the cpu_baseline leg")
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("ORBX_LANES", "2")),
                     help="extractor contexts per GPU, each on its own free-running stream over 1/lanes of the batch")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    requested = max(1, args.gpus)
+    if "WORLD_SIZE" not in os.environ and requested > 1:
+        n = min(requested, torch.cuda.device_count())
+        if n > 1:   # become the launcher: one rank per GPU over RCCL
+            s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+            os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+                                      "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -118,14 +222,13 @@ def main():
     from orb_slam3_modified_amd.replay import ReplayEngine
 
     B, H, W = args.batch, args.rows, args.cols
-    # S-8cam: camera `rank` = S-EuRoC-640 stream with seed + 1000*rank; the stream is 64 distinct frames replayed
-    # to fill the batch (generation cost only; every frame in the batch is processed in full)
-    uniq = min(B, 64)
-    host_frames = synth.make_stream(uniq, H, W, synth.DEFAULT_SEED + 1000 * rank)
-    idx = np.arange(B) % uniq
-    frames = torch.from_numpy(host_frames[idx]).to(dev)
+    # S-8cam: camera `rank` = S-EuRoC-640 stream with seed + 1000*rank: `batches` x B consecutive frames of one stream, every
+    # frame distinct (4 x 256 x 300 KB = 315 MB of level-0 input, more than the 256 MB Infinity Cache)
+    nsets = max(1, args.batches)
+    host_frames = synth.make_stream(nsets * B, H, W, synth.DEFAULT_SEED + 1000 * rank)
+    frame_sets = [torch.from_numpy(host_frames[k * B:(k + 1) * B]).to(dev) for k in range(nsets)]
     ex = ORBextractor(args.nfeatures, 1.2, 8, 20, 7, device_id=local_rank)
-    eng = ReplayEngine(ex, frames, lapping=(0, 1000), gather=(world > 1 and not args.no_gather), lanes=args.lanes)
+    eng = ReplayEngine(ex, frame_sets, lapping=(0, 1000), gather=(world > 1 and not args.no_gather), lanes=args.lanes)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -133,17 +236,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        eng.step()
-    eng.drain()
-    sync_all()
-    t0 = time.perf_counter()
-    last = 0
-    for _ in range(args.steps):
-        last = eng.step()
-    eng.drain()
-    sync_all()
-    dt = time.perf_counter() - t0
+    dt, last = timed_replay(eng, args.steps, args.warmup, sync_all)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -153,61 +246,41 @@ def main():
     feats_step = torch.tensor([int(counts[:, 0].sum())], dtype=torch.int64, device=dev)
     if world > 1:
         dist.all_reduce(feats_step, op=dist.ReduceOp.SUM)
+    # every step processes a different batch of the rotation; the count of the last step stands for all (+-0.5 %)
     feats_step = int(feats_step.item())
     total_feats = feats_step * args.steps
     total_frames = B * world * args.steps
     value = total_feats / (dt * 1e3)
 
-    result = None
+    # ---- the measured path must be the right path: frames of the last timed step against the CPU oracle (every rank its own)
+    last_set = (eng.step_idx - 1) % nsets
+    lane_edges = sorted({0, B - 1} | {f for (f0, f1) in eng.lane_ranges for f in (f0, f1 - 1)} | {B // 3})
+    verified = verify_block(eng, last, host_frames[last_set * B:(last_set + 1) * B], lane_edges, args.nfeatures, (0, 1000))
+    vt = torch.tensor([verified], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(vt, op=dist.ReduceOp.SUM)
+
     if rank == 0:
-        # per-kernel device time: HIP events on the launch stream around each kernel, in separate passes after the timed
-        # region (the event pairs would perturb the timed steps).  These passes launch the WHOLE per-GPU batch on one context,
-        # kernels back to back — the kernel alone on the GPU, which is what a roofline fraction describes.  (In the timed
-        # region each lane launches its share of the batch and the lanes' kernels overlap; the rocprof summary under
-        # profiles/ lists both launch shapes separately.)
-        ex.profile_enable(True)
-        nprof = 5
-        for _ in range(nprof):
-            ex.extract_batch_device(frames.data_ptr(), B, H, W, frames.stride(1), frames.stride(0), eng.blocks[0].data_ptr(),
-                                    eng.blocks[0].data_ptr() + eng.layout.desc_off, eng.blocks[0].data_ptr() + eng.layout.counts_off,
-                                    (0, 1000), torch.cuda.current_stream().cuda_stream)
-        torch.cuda.synchronize()
-        prof = ex.profile_read()
-        ex.profile_enable(False)
-        lane_frames = B
-        ncand = 0
-        for l in range(8):
-            ncand += len(ex.debug_level_points(l, 0, frame=0)[0])
-        nkp = counts[:, 0].mean()
-        fused, staged = algorithmic_bytes(H, W, float(nkp), float(ncand))
-        per_kernel = {k: (ms / max(n, 1)) for k, (ms, n) in prof.items() if n}
-        dom = max(per_kernel, key=per_kernel.get)
-        dom_ms = per_kernel[dom]
-        dom_bytes = staged[dom] * lane_frames
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-        traffic = None
+        dom, nkp, fused, roof = kernel_roofline(ex, eng, frame_sets[0], B, H, W, counts, world, args.steps, dt)
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
-                if j.get("batch") == lane_frames and j.get("rows") == H and j.get("cols") == W:
+                if j.get("batch") == B and j.get("rows") == H and j.get("cols") == W:
                     ent = j.get("kernels", {}).get(dom.split("(")[0])
                     # HBM bytes per launch of the dominant kernel: FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc
                     # passes, corrected with the known-traffic calibration copy (tools/pmc_traffic.py)
-                    traffic = int(ent["hbm_bytes_per_launch"]) if ent else None
+                    roof["traffic"] = int(ent["hbm_bytes_per_launch"]) if ent else None
             except Exception:
-                traffic = None
-        # issue-side evidence for the same kernel (SQ counters from a separate rocprofv3 --pmc run, tools/pmc_sq.py):
-        # the extractor kernels are integer-VALU bound, which is why the nominal HBM fraction is low
-        issue = None
+                pass
+        # issue-side evidence for the same kernel (SQ counters from a separate rocprofv3 --pmc run, tools/pmc_sq.py)
         sqp = os.path.join(ROOT, "profiles", "pmc_sq.json")
         if os.path.exists(sqp):
             try:
                 issue = json.load(open(sqp)).get("derived", {}).get(dom.split("(")[0])
-                if issue:
-                    issue = {k: round(float(v), 4) for k, v in issue.items()}
+                roof["issue_limits_pmc"] = {k: round(float(v), 4) for k, v in issue.items()} if issue else None
             except Exception:
-                issue = None
+                pass
         step_ms = dt / args.steps * 1e3
         result = {
             "metric": "ORB features/ms (+ frames/s), 640x480 8-level pyramid, 1000 features/frame",
@@ -215,25 +288,35 @@ def main():
             "ms_per_step": round(step_ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "frames_per_s": round(total_frames / dt, 1),
+            "verified_frames": int(vt.item()),
             "config": {"workload": f"S-EuRoC-640 batch replay: {B} frames/step/GPU of {W}x{H} u8, 8 levels sf 1.2, "
                                    f"nfeatures {args.nfeatures}, iniTh 20 minTh 7, mono lapping [0,1000]; frames resident in HBM, "
-                                   "results left in HBM",
-                       "frames_per_step_per_gpu": B, "features_per_frame": round(float(nkp), 1),
+                                   f"results left in HBM; the steps rotate through {nsets} distinct batches ({nsets * B} distinct frames per GPU)",
+                       "frames_per_step_per_gpu": B, "distinct_batches": nsets, "features_per_frame": round(float(nkp), 1),
                        "exchange": ("rccl_all_gather(feature blocks), async/overlapped" if eng.gather else "none"),
-                       "lanes_per_gpu": len(eng.lane_ranges),
+                       "lanes_per_gpu": len(eng.lane_ranges), "requested_gpus": requested,
                        "parallelism": f"one camera stream per GPU x{world}"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4),
-                         "frames_per_launch": lane_frames,
-                         "launch_conditions": "whole per-GPU batch in one launch, kernels back to back (passes after the timed region)",
-                         "pipeline_fused_ideal_bytes_per_frame": int(fused),
-                         "pipeline_frac": round(fused * (B * world * args.steps / dt) / 1e9 / (HBM_PEAK_GBS * world), 5),
-                         "issue_limits_pmc": issue,
-                         "kernels_ms_per_launch": {k: round(v, 4) for k, v in per_kernel.items()}},
+            "roofline": roof,
         }
+        if world == 1 and not args.no_secondary:
+            result["end_to_end_operator"] = e2e_operator(host_frames, args.nfeatures)
+            # ---- BASELINE config 4: TUM-VI shape, 1024x1024, 2000 features (large-image configuration)
+            B4, H4, W4, NF4, steps4 = 64, 1024, 1024, 2000, 12
+            host4 = synth.make_stream(B4, H4, W4, synth.DEFAULT_SEED + 77)
+            frames4 = torch.from_numpy(host4).to(dev)
+            ex4 = ORBextractor(NF4, 1.2, 8, 20, 7, device_id=local_rank)
+            eng4 = ReplayEngine(ex4, frames4, lapping=(0, 1000), gather=False, lanes=args.lanes)
+            dt4, last4 = timed_replay(eng4, steps4, 3, sync_all)
+            c4 = eng4.counts(last4).cpu().numpy()
+            v4 = verify_block(eng4, last4, host4, [0, B4 // 2, B4 - 1], NF4, (0, 1000))
+            _, nkp4, _, roof4 = kernel_roofline(ex4, eng4, frames4, B4, H4, W4, c4, 1, steps4, dt4, nprof=3)
+            result["secondary"] = {"workload": f"S-TUMVI-1024 batch replay (BASELINE config 4): {B4} frames/step of {W4}x{H4} u8, nfeatures {NF4}",
+                                   "value": round(float(c4[:, 0].sum()) * steps4 / (dt4 * 1e3), 1), "unit": "features/ms",
+                                   "frames_per_s": round(B4 * steps4 / dt4, 1), "ms_per_step": round(dt4 / steps4 * 1e3, 4), "steps": steps4,
+                                   "features_per_frame": round(nkp4, 1), "verified_frames": v4, "roofline": roof4}
+            del eng4, ex4, frames4
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(host_frames, args.nfeatures, args.cpu_budget)
+            result["cpu_baseline"] = cpu_baseline(host_frames[:64], args.nfeatures, args.cpu_budget)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

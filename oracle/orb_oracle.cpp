@@ -25,7 +25,9 @@
 // Each function cites the reference file:line it follows.
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -704,6 +706,46 @@ int orbo_level_keypoints(void* h, int level, int stage, void* dst, int cap) {
   return n;
 }
 int orbo_sorted_phase_count(void* h) { return ((Extractor*)h)->sorted_phase_count; }
+
+// CPU-baseline leg of bench.py: a frame-parallel std::thread pool (SURVEY.md §8(d) "CPU timing plan"), `nthreads` workers with
+// one extractor each pulling frames off a shared counter (frame i = frames[i % nframes], src/ORBextractor.cc is
+// single-threaded per image) until `seconds` have passed.  Returns the wall time from the common start to the last join;
+// *features_out / *frames_out = totals.
+double orbo_extract_many(int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh, const uint8_t* frames, int nframes, int rows,
+                         int cols, int lap0, int lap1, int nthreads, double seconds, long long* features_out, long long* frames_out) {
+  if (nthreads < 1) nthreads = 1;
+  std::atomic<long long> next(0), feats(0), done(0);
+  std::atomic<int> ready(0);
+  std::atomic<bool> go(false);
+  std::chrono::steady_clock::time_point t0;
+  auto worker = [&]() {
+    Extractor ex(nfeatures, scaleFactor, nlevels, iniTh, minTh);
+    const int cap = nfeatures + 3 * nlevels + 64;
+    std::vector<KeyPt> kps(cap);
+    std::vector<uint8_t> desc((size_t)cap * 32);
+    int n = 0, mono = 0;
+    ex.extract(frames, rows, cols, cols, lap0, lap1, kps.data(), desc.data(), cap, &n, &mono);   // warm-up (allocations, page faults)
+    ready.fetch_add(1);
+    while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+    long long mine = 0, nf = 0;
+    for (;;) {
+      const long long i = next.fetch_add(1);
+      ex.extract(frames + (size_t)(i % nframes) * rows * cols, rows, cols, cols, lap0, lap1, kps.data(), desc.data(), cap, &n, &mono);
+      mine += n; nf++;
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() >= seconds) break;
+    }
+    feats.fetch_add(mine); done.fetch_add(nf);
+  };
+  std::vector<std::thread> th;
+  for (int t = 0; t < nthreads; t++) th.emplace_back(worker);
+  while (ready.load() < nthreads) std::this_thread::yield();
+  t0 = std::chrono::steady_clock::now();
+  go.store(true, std::memory_order_release);
+  for (auto& t : th) t.join();
+  const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  *features_out = feats.load(); *frames_out = done.load();
+  return dt;
+}
 
 // isolated primitives
 void orbo_resize_linear(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh, int dstride) {

@@ -71,7 +71,12 @@ class ReplayEngine:
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.ex = extractor
-        self.frames = frames_dev  # torch uint8 [B, H, W] on this rank's GPU
+        # frames_dev: torch uint8 [B, H, W] on this rank's GPU, or a list of such batches (same shape) that the steps rotate
+        # through — step k processes batch k mod len
+        self.frame_sets = list(frames_dev) if isinstance(frames_dev, (list, tuple)) else [frames_dev]
+        frames_dev = self.frame_sets[0]
+        assert all(f.shape == frames_dev.shape and f.stride() == frames_dev.stride() for f in self.frame_sets)
+        self.frames = frames_dev
         self.B, self.H, self.W = frames_dev.shape
         self.lap = lapping
         self.layout = BlockLayout(self.B, extractor.capacity)
@@ -117,12 +122,13 @@ class ReplayEngine:
         base = blk.data_ptr()
         lo = self.layout
         pend = self.pending[i]
+        frames = self.frame_sets[self.step_idx % len(self.frame_sets)]
         for j, (f0, f1) in enumerate(self.lane_ranges):
             with torch.cuda.stream(self.streams[j]):
                 if pend is not None:  # the gather that last read this buffer must be done before a lane overwrites it
                     pend.wait()       # (makes this lane's stream wait for the collective)
-                fr = self.frames[f0:f1]
-                self.exs[j].extract_batch_device(fr.data_ptr(), f1 - f0, self.H, self.W, self.frames.stride(1), self.frames.stride(0),
+                fr = frames[f0:f1]
+                self.exs[j].extract_batch_device(fr.data_ptr(), f1 - f0, self.H, self.W, frames.stride(1), frames.stride(0),
                                                  base + f0 * lo.cap * KP_BYTES, base + lo.desc_off + f0 * lo.cap * 32,
                                                  base + lo.counts_off + f0 * 8, self.lap, self.streams[j].cuda_stream)
                 if self.gather and len(self.lane_ranges) > 1:

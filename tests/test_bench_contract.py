@@ -20,15 +20,25 @@ def test_bench_refuses_without_gpu():
 
 @pytest.mark.gpu
 def test_bench_json_line():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--cpu-budget", "2"],
+    # --gpus 2 on a 1-GPU box: bench.py must start min(2, visible) ranks itself and label the line with the world size it ran
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--cpu-budget", "2"],
                        capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     j = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-              "data", "config", "roofline", "cpu_baseline"):
+              "data", "config", "roofline", "cpu_baseline", "verified_frames", "end_to_end_operator", "secondary"):
         assert k in j, k
+    import torch
+    ngpu = min(2, torch.cuda.device_count())
+    if ngpu > 1:
+        pytest.skip("multi-GPU box: the N = 1 extras are not part of the line")
+    assert j["config"]["requested_gpus"] == 2 and j["config"]["distinct_batches"] == 4
+    assert j["verified_frames"] >= 4 and j["secondary"]["verified_frames"] >= 2
+    assert 0.02 < j["end_to_end_operator"]["ms_per_frame"] < 5.0
+    s2 = j["secondary"]
+    assert "1024x1024" in s2["workload"] and s2["value"] > 20000 and 0 < s2["roofline"]["frac"] < 1
     assert j["unit"] == "features/ms" and j["n_gpus"] == 1 and j["steps"] == 4 and j["warmup"] == 1 and j["higher_is_better"] is True
     assert j["scaling"] == "weak" and j["vs_baseline"] is None and j["dtype"] == "u8" and j["data"] == "synthetic"
     assert "workload" in j["config"] and "model" not in j["config"]
@@ -39,3 +49,4 @@ def test_bench_json_line():
     assert rf["traffic"] is None or rf["traffic"] > 0
     cb = j["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "features/ms" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    assert 0 < cb["scaling_efficiency"] <= 1.2 and cb["value_1core"] > 0

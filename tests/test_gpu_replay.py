@@ -44,3 +44,82 @@ def test_replay_engine_gather_matches_block_and_oracle(lanes):
             assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc)
     finally:
         dist.destroy_process_group()
+
+
+def _check_every_frame(block, layout, host, ora, lap):
+    from orb_slam3_modified_amd.replay import unpack_block
+    res = unpack_block(block, layout)
+    cache = {}
+    for f in range(layout.frames):
+        key = f % len(host)
+        if key not in cache:
+            cache[key] = ora.extract(host[key], lap)
+        okps, odesc, omono = cache[key]
+        mono, kps, desc = res[f]
+        assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc), f"frame {f}"
+
+
+def test_the_configuration_bench_times_is_bit_exact_on_every_frame():
+    """bench.py's replay: 2 lanes x 130 frames (past the `small batch` cut-off of the in-lane forks, orbx_extractor.hip), the lanes'
+    options fork_fast0 = 1 / fork_blur = 0 / fork_qt = 1 as ReplayEngine sets them, rotating batches, several steps in flight —
+    EVERY frame of the last two steps against the oracle."""
+    import torch
+    from oracle import pyoracle as po
+    from orb_slam3_modified_amd import ORBextractor, synth
+    from orb_slam3_modified_amd.replay import ReplayEngine
+    dev = torch.device("cuda", 0)
+    host = synth.make_stream(24)
+    nfr = 260
+    sets_host = [host[(np.arange(nfr) + 7 * k) % 24] for k in range(3)]
+    sets = [torch.from_numpy(h).to(dev) for h in sets_host]
+    ex = ORBextractor(1000, 1.2, 8, 20, 7, device_id=0)
+    eng = ReplayEngine(ex, sets, lapping=(0, 1000), gather=False, lanes=2)
+    assert len(eng.lane_ranges) == 2 and eng.lane_ranges[0][1] - eng.lane_ranges[0][0] == 130
+    ora = po.OracleExtractor(1000, 1.2, 8, 20, 7)
+    last = 0
+    for _ in range(7):
+        last = eng.step()
+    eng.drain()
+    torch.cuda.synchronize()
+    for back in (0, 1):     # the last step and the one before it (the other block buffer)
+        k = (eng.step_idx - 1 - back) % 3
+        blk = eng.blocks[last ^ back].cpu().numpy()
+        cache_host = sets_host[k]
+        from orb_slam3_modified_amd.replay import unpack_block
+        res = unpack_block(blk, eng.layout)
+        memo = {}
+        for f in range(nfr):
+            key = int((f + 7 * k) % 24)
+            if key not in memo:
+                memo[key] = ora.extract(host[key], (0, 1000))
+            okps, odesc, omono = memo[key]
+            mono, kps, desc = res[f]
+            assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc), (back, f)
+        assert cache_host.shape[0] == nfr
+
+
+@pytest.mark.parametrize("opts", [dict(fork_fast0=1, fork_blur=0, fork_qt=0), dict(fork_fast0=0, fork_blur=1, fork_qt=0),
+                                  dict(fork_fast0=0, fork_blur=0, fork_qt=1), dict(fork_fast0=1, fork_blur=1, fork_qt=1),
+                                  dict(fork_fast0=0, fork_blur=0, fork_qt=0)])
+def test_each_stream_fork_alone_is_bit_exact_on_every_frame(opts):
+    """The in-context stream forks (level-0 FAST beside the pyramid chain, blur behind FAST, quadtree level groups) one at a
+    time on ONE context with a batch large enough for them to engage: results never depend on the launch shape."""
+    import torch
+    from oracle import pyoracle as po
+    from orb_slam3_modified_amd import ORBextractor, synth
+    from orb_slam3_modified_amd.replay import BlockLayout
+    dev = torch.device("cuda", 0)
+    host = synth.make_stream(12)
+    nfr = 132
+    frames = torch.from_numpy(host[np.arange(nfr) % 12]).to(dev)
+    ex = ORBextractor(1000, 1.2, 8, 20, 7, device_id=0)
+    for k, v in opts.items():
+        ex.set_option(k, v)
+    lo = BlockLayout(nfr, ex.capacity)
+    blk = torch.zeros(lo.nbytes, dtype=torch.uint8, device=dev)
+    st = torch.cuda.Stream(device=dev)
+    for _ in range(3):
+        ex.extract_batch_device(frames.data_ptr(), nfr, 480, 640, frames.stride(1), frames.stride(0), blk.data_ptr(), blk.data_ptr() + lo.desc_off,
+                                blk.data_ptr() + lo.counts_off, (0, 1000), st.cuda_stream)
+    st.synchronize()
+    _check_every_frame(blk.cpu().numpy(), lo, host, po.OracleExtractor(1000, 1.2, 8, 20, 7), (0, 1000))

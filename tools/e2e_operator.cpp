@@ -1,0 +1,43 @@
+// End-to-end latency of ORB_SLAM3::ORBextractor::operator() through the C++ adapter (include/ORBextractor.h), host
+// buffers in and out — what Tracking sees per frame (steady_clock around the call, like
+// Examples/Monocular/mono_euroc.cc:133-143): H2D image, the kernels, D2H keypoints + descriptors.  Built and run by bench.py.
+//   e2e_operator <frames.raw> <rows> <cols> <nframes> <nfeatures> <reps>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <vector>
+
+#include "ORBextractor.h"
+
+int main(int argc, char** argv) {
+  if (argc < 7) return 2;
+  const int rows = std::atoi(argv[2]), cols = std::atoi(argv[3]), nfr = std::atoi(argv[4]), nfeat = std::atoi(argv[5]), reps = std::atoi(argv[6]);
+  std::vector<unsigned char> buf((size_t)rows * cols * nfr);
+  { std::ifstream f(argv[1], std::ios::binary); f.read((char*)buf.data(), (std::streamsize)buf.size()); if (!f) return 2; }
+  try {
+    ORB_SLAM3::ORBextractor ex(nfeat, 1.2f, 8, 20, 7);
+    std::vector<int> lap = {0, 1000};
+    std::vector<cv::KeyPoint> keys;
+    cv::Mat desc;
+    long total = 0;
+    double ms = 0;
+    for (int pass = 0; pass < 2; pass++) {   // pass 0 = warm-up
+      total = 0;
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int rep = 0; rep < (pass ? reps : 2); rep++)
+        for (int f = 0; f < nfr; f++) {
+          cv::Mat im(rows, cols, CV_8UC1, buf.data() + (size_t)f * rows * cols);
+          ex(im, cv::Mat(), keys, desc, lap);
+          total += (long)keys.size();
+        }
+      ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    std::printf("{\"frames\": %d, \"ms_per_frame\": %.5f, \"features_per_ms\": %.2f, \"features_per_frame\": %.1f}\n", reps * nfr, ms / (reps * nfr),
+                total / ms, (double)total / (reps * nfr));
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "e2e_operator: %s\n", e.what());
+    return 3;
+  }
+  return 0;
+}
