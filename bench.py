@@ -61,12 +61,38 @@ def algorithmic_bytes(rows, cols, n_keypoints_per_frame, n_candidates_per_frame)
     return fused, staged
 
 
+def usable_cores():
+    """CPU cores this process may actually use: the affinity mask and the cgroup CPU quota, not the host's core count (a
+    container on a 256-thread host is typically limited to a few cores' worth of time: threads beyond the quota only throttle)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]           # cgroup v2
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())       # cgroup v1
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota:
+        n = max(1, min(n, int(quota)))
+    return n, (os.cpu_count() or 1), quota
+
+
 def cpu_baseline(frames, nfeatures, budget_s=24.0):
     """The oracle (CPU restatement of src/ORBextractor.cc, pinned to the reference's own file by tests/test_ref_fragments.py)
     timed on the host cores: a REPORTED baseline.  The timing copy is built here with -O3 -march=native -ffp-contract=off
     (SURVEY.md §8(d)); the frame-parallel leg is a std::thread pool inside the library (orbo_extract_many)."""
     from oracle import pyoracle as po
-    ncores = os.cpu_count() or 1
+    ncores, host_threads, quota = usable_cores()
     po.build()
     libpath, flags = os.path.join(ROOT, "oracle", "liborb_oracle.so"), "portable build (-O3, no -march=native: native build failed)"
     tmp = tempfile.mkdtemp(prefix="orbx_native_")
@@ -92,6 +118,7 @@ def cpu_baseline(frames, nfeatures, budget_s=24.0):
     va, ka, dta = run(ncores, budget_s * 0.6)
     return {"value": round(va, 3), "unit": "features/ms", "cores": ncores, "kind": "port", "value_1core": round(v1, 3),
             "ms_per_frame_1core": round(dt1 * 1e3 / max(k1, 1), 3), "scaling_efficiency": round(va / (v1 * ncores), 3), "build": flags,
+            "host_hw_threads": host_threads, "cgroup_cpu_quota": quota,
             "sample": f"{ka} frames of the same {cols}x{rows} stream on {ncores} std::threads ({dta:.1f} s); 1-core figure from {k1} frames "
                       f"({dt1:.1f} s); CPU path = this repo's restatement of src/ORBextractor.cc, checked bit for bit against the reference's "
                       "own file compiled over a container shim; its five OpenCV primitives are scalar restatements (real OpenCV SIMD "

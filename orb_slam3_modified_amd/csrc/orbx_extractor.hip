@@ -3,6 +3,9 @@
 // produces features needs a HIP device and reports ORBX_E_DEVICE otherwise.
 #include <hip/hip_runtime.h>
 
+#include <map>
+#include <mutex>
+
 #include <algorithm>
 #include <climits>
 #include <cmath>
@@ -25,6 +28,18 @@ static int fast_threads_from_env() {
   const char* e = getenv("ORBX_FAST_THREADS");
   const int v = e ? atoi(e) : 128;
   return (v == 64 || v == 128 || v == 256) ? v : 128;
+}
+
+hipError_t ensure_dynamic_lds(const void* kernel, int bytes) {
+  static std::mutex mu;
+  static std::map<const void*, int> raised;
+  std::lock_guard<std::mutex> lock(mu);
+  int& cur = raised[kernel];
+  if (bytes <= cur) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) cur = bytes;
+  else (void)hipGetLastError();   // do not leave the sticky error for an unrelated later call
+  return e;
 }
 
 int set_err(orbx_ctx* ctx, int code, const std::string& msg) {
@@ -334,12 +349,28 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
   const int ncells0 = geo.lv[0].ncells, ncells_all = (int)geo.cells.size();
   // small batches (the single-frame operator() path) are latency-bound: a stream fork costs more than it hides there
   const bool small_batch = nframes * geo.nlevels <= 512;
+  // every aux stream forked off `st` below is joined back into it when this function returns — also on an error return, so
+  // that a caller's stream capture stays valid and no buffer is reused while forked work is pending
+  struct ForkGuard {
+    hipStream_t st;
+    std::vector<std::pair<hipStream_t, hipEvent_t> > open;
+    void forked(hipStream_t s, hipEvent_t join_ev) { open.push_back(std::make_pair(s, join_ev)); }
+    void joined(hipStream_t s) { for (size_t i = 0; i < open.size(); i++) if (open[i].first == s) { open.erase(open.begin() + i); break; } }
+    ~ForkGuard() { for (auto& o : open) { (void)hipEventRecord(o.second, o.first); (void)hipStreamWaitEvent(st, o.second, 0); } }
+  } forks{st, {}};
+  // checks that can fail come before the first fork
+  for (int l = 1; l < geo.nlevels; l++) {
+    const LevelGeom& D = geo.lv[l];
+    const int nbx = (D.w + kRT_W - 1) / kRT_W, nby = (D.h + kRT_H - 1) / kRT_H;
+    if (!div_ok((uint64_t)nbx * nby * nframes + 8, (uint64_t)nbx * nby)) return set_err(ctx, ORBX_E_CAPACITY, "batch too large for 32-bit tile indexing");
+  }
   const bool fork_fast0 = ctx->fork_fast0 && !ctx->profiling && geo.nlevels > 1 && !small_batch;
   const int sb = f0 != 0;  // sub-batch slot of the fork events / streams
   if (fork_fast0) {
     hipStream_t fst = ctx->aux[orbx_ctx::kMaxAux - 3 - sb];
     ORBX_HIP(ctx, hipEventRecord(ctx->ev_f0_fork[sb], st));
     ORBX_HIP(ctx, hipStreamWaitEvent(fst, ctx->ev_f0_fork[sb], 0));
+    forks.forked(fst, ctx->ev_f0_join[sb]);
     launch_fast(0, ncells0, fst);
     ORBX_HIP(ctx, hipEventRecord(ctx->ev_f0_join[sb], fst));
   }
@@ -358,7 +389,6 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
                          ctx->d_ytab + D.ytab_off, nbx, nby, nitems, D.rs_lds_pitch, D.rs_lds_rows,
                          div_magic((uint32_t)(nbx * nby)), div_magic((uint32_t)nbx), div_magic((uint32_t)(D.rs_lds_pitch / 4)),
                          256 / (D.rs_lds_pitch / 4));
-      if (!div_ok((uint64_t)nitems + 8, (uint64_t)nbx * nby)) return set_err(ctx, ORBX_E_CAPACITY, "batch too large for 32-bit tile indexing");
     }
   }
   // K2: FAST cells of the remaining levels (or of all levels when level 0 is not forked)
@@ -376,6 +406,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
     bst = ctx->aux[orbx_ctx::kMaxAux - 1 - (f0 != 0)];
     ORBX_HIP(ctx, hipEventRecord(ctx->ev_blur_fork[f0 != 0], st));
     ORBX_HIP(ctx, hipStreamWaitEvent(bst, ctx->ev_blur_fork[f0 != 0], 0));
+    forks.forked(bst, ctx->ev_blur_join[f0 != 0]);
   }
   {
     ProfScope ps(ctx, 4, bst);
@@ -394,7 +425,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
   }
   if (fork_blur) ORBX_HIP(ctx, hipEventRecord(ctx->ev_blur_join[f0 != 0], bst));
   // K3: quadtree
-  if (fork_fast0) ORBX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_f0_join[sb], 0));
+  if (fork_fast0) { ORBX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_f0_join[sb], 0)); forks.joined(ctx->aux[orbx_ctx::kMaxAux - 3 - sb]); }
   {
     ProfScope ps(ctx, 2, st);
     // The workgroup of (frame, level) is sized by the level's quota; one LDS size for all levels would let the big
@@ -424,11 +455,8 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
         }
       }
       if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-          (void)hipGetLastError();  // do not leave the sticky error for an unrelated later call
+        if (ensure_dynamic_lds((const void*)k_quadtree, (int)lds) != hipSuccess)
           return set_err(ctx, ORBX_E_CAPACITY, "nfeatures too large for the quadtree kernel's LDS");
-        }
       }
       // small batches are latency-bound on the big levels' workgroups: more waves split more nodes at a time
       const int qthreads = (nframes * geo.nlevels <= 512) ? 512 : 256;
@@ -442,12 +470,14 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
       hipStream_t qst = ctx->aux[orbx_ctx::kMaxAux - 5 - sb];
       ORBX_HIP(ctx, hipEventRecord(ctx->ev_qt_fork[sb], st));
       ORBX_HIP(ctx, hipStreamWaitEvent(qst, ctx->ev_qt_fork[sb], 0));
+      forks.forked(qst, ctx->ev_qt_join[sb]);
       qrc = launch_qt(nbig, geo.nlevels, kQtLdsPoints / 2, qst);
       if (qrc != ORBX_OK) return qrc;
       ORBX_HIP(ctx, hipEventRecord(ctx->ev_qt_join[sb], qst));
       qrc = launch_qt(0, nbig, kQtLdsPoints, st);
       if (qrc != ORBX_OK) return qrc;
       ORBX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_qt_join[sb], 0));
+      forks.joined(qst);
     } else {
       qrc = launch_qt(0, nbig, kQtLdsPoints, st);
       if (qrc != ORBX_OK) return qrc;
@@ -462,7 +492,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
                        b_lvl_n, b_kp_list, d_counts, lap0, lap1, gs ? ctx->d_asm_scan + (size_t)f0 * ctx->out_cap : nullptr);
   }
   // K4b: orientation + descriptors
-  if (fork_blur) ORBX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_blur_join[f0 != 0], 0));
+  if (fork_blur) { ORBX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_blur_join[f0 != 0], 0)); forks.joined(bst); }
   {
     ProfScope ps(ctx, 5, st);
     DescConsts dc;
@@ -654,9 +684,11 @@ int orbx_extract_batch_device(orbx_ctx* ctx, const uint8_t* d_imgs, int nframes,
     hipStream_t s = ctx->aux[i];
     ORBX_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_fork, 0));
     rc = launch_pipeline(ctx, d_imgs, f0, nf, rows, cols, row_stride, frame_stride, lap0, lap1, d_kps, d_desc, d_counts, s);
+    // the sub-batch's stream is joined back into the caller's stream whether or not its launches succeeded
+    const hipError_t e1 = hipEventRecord(ctx->ev_join[i], s), e2 = hipStreamWaitEvent(st, ctx->ev_join[i], 0);
     if (rc != ORBX_OK) return rc;
-    ORBX_HIP(ctx, hipEventRecord(ctx->ev_join[i], s));
-    ORBX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[i], 0));
+    ORBX_HIP(ctx, e1);
+    ORBX_HIP(ctx, e2);
   }
   return ORBX_OK;
 }
@@ -884,7 +916,7 @@ int orbx_pyramid_level(orbx_ctx* ctx, int frame, int level, uint8_t* dst, size_t
   if (h) *h = L.h;
   if (!dst) return ORBX_OK;
   ORBX_HIP(ctx, hipSetDevice(ctx->device));
-  ORBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ORBX_HIP(ctx, sync_ctx(ctx));   // the pyramid may still be in flight on an aux stream or on the caller's stream of the last batch
   const uint8_t* src; size_t sp;
   if (level == 0) { src = ctx->last_imgs + (size_t)frame * ctx->last_frame_stride; sp = ctx->last_row_stride; }
   else { src = ctx->d_pyr + (size_t)frame * ctx->geo.pyr_bytes + L.plane_off; sp = L.pitch; }

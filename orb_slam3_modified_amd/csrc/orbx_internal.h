@@ -222,6 +222,10 @@ inline hipError_t sync_ctx(orbx_ctx* ctx) {
   if (e == hipSuccess && ctx->last_ext_stream) e = hipStreamSynchronize(ctx->last_ext_stream);
   return e;
 }
+// hipFuncAttributeMaxDynamicSharedMemorySize is process-wide state of a kernel: contexts on different threads (two stereo
+// extractors, the replay lanes, the per-thread matcher contexts) must never lower it under a launch that needs more, so the
+// value is only ever raised, under a mutex (orbx_extractor.hip).
+hipError_t ensure_dynamic_lds(const void* kernel, int bytes);
 // orbx_window.hip: pinned staging (grow-only) and the fused window pass behind orbx_window_search* / orbx_window_nearest
 hipError_t host_stage(orbx_ctx* ctx, size_t bytes, uint8_t** p);
 int window_call(orbx_ctx* ctx, const char* who, const orbx_keypoint* kps, const uint8_t* desc, int n, const orbx_grid* grid,

@@ -21,7 +21,7 @@ namespace orbx {
 
 struct KfRow { int32_t start, len; };
 
-constexpr int kKfdbMaxQuery = 8192;   // query words staged in LDS: 4 B ids + 8 B values each
+constexpr int kKfdbMaxQuery = 8192;   // query words staged in LDS (4 B ids + 8 B values each); longer queries are read from HBM / L2
 
 // position of `id` in the ascending array a[0, n), or -1
 __device__ __forceinline__ int find_sorted(const uint32_t* a, int n, uint32_t id) {
@@ -35,13 +35,18 @@ __device__ __forceinline__ int find_sorted(const uint32_t* a, int n, uint32_t id
 
 // Phase 1: per keyframe row the number of words shared with the query and the smallest shared word id (which decides
 // the row's place in the reference's lKFsSharingWords list); the maximum count over the active rows.
+template <bool INLDS>
 __global__ __launch_bounds__(256) void k_kfdb_common(const uint32_t* __restrict__ qid, int nq, const KfRow* __restrict__ rows,
                                                      const uint8_t* __restrict__ active, int nrows, const uint32_t* __restrict__ ids,
                                                      int32_t* __restrict__ common, uint32_t* __restrict__ first_word,
                                                      int32_t* __restrict__ max_common) {
-  extern __shared__ __align__(16) uint32_t s_q[];
-  for (int i = threadIdx.x; i < nq; i += blockDim.x) s_q[i] = qid[i];
-  __syncthreads();
+  extern __shared__ __align__(16) uint32_t s_qbuf[];
+  const uint32_t* s_q = qid;
+  if (INLDS) {
+    for (int i = threadIdx.x; i < nq; i += blockDim.x) s_qbuf[i] = qid[i];
+    __syncthreads();
+    s_q = s_qbuf;
+  }
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= nrows) return;
@@ -74,15 +79,21 @@ __global__ __launch_bounds__(256) void k_kfdb_common(const uint32_t* __restrict_
 // Phase 2: L1 score of the rows with more than minCommonWords = (int)(maxCommonWords * 0.8f) common words (at least
 // `min_words_floor`, DetectBestCandidates' nMinWords, :514-517).  The matched terms are added in ascending word order by a
 // wave-uniform serial loop over the ballot bits, which reproduces the double rounding of the reference's merge loop.
+template <bool INLDS>
 __global__ __launch_bounds__(256) void k_kfdb_score(const uint32_t* __restrict__ qid, const double* __restrict__ qv, int nq,
                                                     const KfRow* __restrict__ rows, int nrows, const uint32_t* __restrict__ ids,
                                                     const double* __restrict__ vals, const int32_t* __restrict__ common,
                                                     const int32_t* __restrict__ max_common, int min_words_floor,
                                                     double* __restrict__ scores) {
-  extern __shared__ __align__(16) uint32_t s_q[];
-  double* s_v = (double*)(s_q + ((nq + 1) & ~1));
-  for (int i = threadIdx.x; i < nq; i += blockDim.x) { s_q[i] = qid[i]; s_v[i] = qv[i]; }
-  __syncthreads();
+  extern __shared__ __align__(16) uint32_t s_qbuf[];
+  const uint32_t* s_q = qid;
+  const double* s_v = qv;
+  if (INLDS) {
+    double* vbuf = (double*)(s_qbuf + ((nq + 1) & ~1));
+    for (int i = threadIdx.x; i < nq; i += blockDim.x) { s_qbuf[i] = qid[i]; vbuf[i] = qv[i]; }
+    __syncthreads();
+    s_q = s_qbuf; s_v = vbuf;
+  }
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= nrows) return;
@@ -283,7 +294,6 @@ int orbx_kfdb_query(orbx_kfdb* db, const uint32_t* q_ids, const double* q_vals, 
   *n_sharing = 0;
   if (max_common_words) *max_common_words = 0;
   if (min_common_words) *min_common_words = 0;
-  if (nq > kKfdbMaxQuery) return set_err(ctx, ORBX_E_CAPACITY, "orbx_kfdb_query: more than 8192 query words");
   for (int i = 1; i < nq; i++)
     if (q_ids[i] <= q_ids[i - 1]) return set_err(ctx, ORBX_E_INVALID, "orbx_kfdb_query: word ids must ascend strictly");
   const int nrows = (int)db->rows.size();
@@ -314,15 +324,24 @@ int orbx_kfdb_query(orbx_kfdb* db, const uint32_t* q_ids, const double* q_vals, 
   ORBX_HIP(ctx, hipMemcpyAsync(db->d_active, active.data(), (size_t)nrows, hipMemcpyHostToDevice, st));
   ORBX_HIP(ctx, hipMemsetAsync(db->d_max, 0, sizeof(int32_t), st));
   const dim3 grid((nrows + 3) / 4), block(256);
-  const size_t lds1 = (size_t)nq * sizeof(uint32_t), lds2 = (size_t)((nq + 1) & ~1) * sizeof(uint32_t) + (size_t)nq * sizeof(double);
-  if (lds2 > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_kfdb_score, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-    if (e != hipSuccess) { (void)hipGetLastError(); return set_err(ctx, ORBX_E_CAPACITY, "orbx_kfdb_query: query does not fit the LDS"); }
+  // a query of up to 8192 words (every configuration of the reference's yaml files) is staged in LDS; a longer one (the
+  // 20 000-feature frames of Examples/Monocular/mi.yaml) is searched where it lies, in HBM / L2
+  bool inlds = nq <= kKfdbMaxQuery;
+  const size_t lds1 = inlds ? (size_t)nq * sizeof(uint32_t) : 0;
+  const size_t lds2 = inlds ? (size_t)((nq + 1) & ~1) * sizeof(uint32_t) + (size_t)nq * sizeof(double) : 0;
+  if (lds2 > 64 * 1024 && ensure_dynamic_lds((const void*)k_kfdb_score<true>, (int)lds2) != hipSuccess)
+    return set_err(ctx, ORBX_E_CAPACITY, "orbx_kfdb_query: query does not fit the LDS");
+  if (inlds) {
+    hipLaunchKernelGGL(k_kfdb_common<true>, grid, block, lds1, st, db->d_qid, nq, db->d_rows, db->d_active, nrows, db->d_ids, db->d_common,
+                       db->d_first, db->d_max);
+    hipLaunchKernelGGL(k_kfdb_score<true>, grid, block, lds2, st, db->d_qid, db->d_qv, nq, db->d_rows, nrows, db->d_ids, db->d_vals, db->d_common,
+                       db->d_max, min_words_floor, db->d_scores);
+  } else {
+    hipLaunchKernelGGL(k_kfdb_common<false>, grid, block, 0, st, db->d_qid, nq, db->d_rows, db->d_active, nrows, db->d_ids, db->d_common,
+                       db->d_first, db->d_max);
+    hipLaunchKernelGGL(k_kfdb_score<false>, grid, block, 0, st, db->d_qid, db->d_qv, nq, db->d_rows, nrows, db->d_ids, db->d_vals, db->d_common,
+                       db->d_max, min_words_floor, db->d_scores);
   }
-  hipLaunchKernelGGL(k_kfdb_common, grid, block, lds1, st, db->d_qid, nq, db->d_rows, db->d_active, nrows, db->d_ids, db->d_common,
-                     db->d_first, db->d_max);
-  hipLaunchKernelGGL(k_kfdb_score, grid, block, lds2, st, db->d_qid, db->d_qv, nq, db->d_rows, nrows, db->d_ids, db->d_vals, db->d_common,
-                     db->d_max, min_words_floor, db->d_scores);
   ORBX_HIP(ctx, hipGetLastError());
   std::vector<int32_t> common(nrows);
   std::vector<uint32_t> first(nrows);

@@ -330,8 +330,8 @@ static int build_grid(orbx_ctx* ctx, const orbx_keypoint* kps, int n, float min_
   int npad = 2;
   while (npad < n) npad <<= 1;
   if ((size_t)npad * 4 > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_frame_grid, hipFuncAttributeMaxDynamicSharedMemorySize, npad * 4);
-    if (e != hipSuccess) { (void)hipGetLastError(); return set_err(ctx, ORBX_E_CAPACITY, "frame grid: keypoints do not fit the LDS sort"); }
+    if (ensure_dynamic_lds((const void*)k_frame_grid, npad * 4) != hipSuccess)
+      return set_err(ctx, ORBX_E_CAPACITY, "frame grid: keypoints do not fit the LDS sort");
   }
   hipLaunchKernelGGL(k_frame_grid, dim3(1), dim3(1024), (size_t)npad * 4, ctx->stream, g.kps.p, n, g.minX, g.minY, g.invW, g.invH,
                      npad, g.sorted.p, g.cell_start.p);
@@ -849,7 +849,9 @@ int orbx_stereo_matches(orbx_ctx* left, orbx_ctx* right, const orbx_keypoint* kp
       left->geo.rows != right->geo.rows || left->geo.cols != right->geo.cols || left->nlevels != right->nlevels)
     return set_err(ctx, ORBX_E_INVALID, "orbx_stereo_matches: both extractors must have processed a frame of the same shape on one GPU");
   ORBX_HIP(ctx, hipSetDevice(ctx->device));
-  ORBX_HIP(ctx, hipStreamSynchronize(right->stream));   // the right pyramid was produced on the right context's stream
+  // both pyramids may still be in flight (context stream, aux streams, or the caller's stream of a device-resident batch)
+  ORBX_HIP(ctx, sync_ctx(left));
+  ORBX_HIP(ctx, sync_ctx(right));
   StereoGeom sg;
   std::memset(&sg, 0, sizeof(sg));
   sg.nlevels = left->nlevels;

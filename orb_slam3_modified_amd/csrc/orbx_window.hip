@@ -304,12 +304,8 @@ int window_call(orbx_ctx* ctx, const char* who, const orbx_keypoint* kps, const 
     int npad = 2;
     while (npad < n) npad <<= 1;
     if ((size_t)npad * 4 > 64 * 1024) {
-      static bool attr_set = false;   // process-wide function attribute: raised once to the kernel's maximum
-      if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_window_grid, hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4);
-        if (e != hipSuccess) { (void)hipGetLastError(); return set_err(ctx, ORBX_E_CAPACITY, std::string(who) + ": LDS for the grid sort unavailable"); }
-        attr_set = true;
-      }
+      if (ensure_dynamic_lds((const void*)k_window_grid, 32768 * 4) != hipSuccess)
+        return set_err(ctx, ORBX_E_CAPACITY, std::string(who) + ": LDS for the grid sort unavailable");
     }
     hipLaunchKernelGGL(k_window_grid, dim3(1), dim3(1024), (size_t)npad * 4, st, (const orbx_keypoint*)(din + o_kps), n, grid->min_x, grid->min_y,
                        grid->inv_w, grid->inv_h, npad, (int32_t*)(din + o_ci), (int32_t*)(din + o_cs));

@@ -13,6 +13,7 @@ from ._lib import check, lib, ptr
 class KeyFrameDatabase:
     def __init__(self, extractor_or_ctx):
         self._L = lib()
+        self._owner = extractor_or_ctx   # keeps the extractor (and with it the orbx context) alive for as long as this object uses it
         self._ctx = getattr(extractor_or_ctx, "_ctx", extractor_or_ctx)
         self._db = C.c_void_p(0)
         check(self._L.orbx_kfdb_create(self._ctx, C.byref(self._db)), self._ctx)

@@ -19,6 +19,7 @@ class ORBmatcher:
 
     def __init__(self, extractor_or_ctx, nnratio: float = 0.6, checkOri: bool = True):
         self._L = lib()
+        self._owner = extractor_or_ctx   # keeps the extractor (and with it the orbx context) alive for as long as this object uses it
         self._ctx = getattr(extractor_or_ctx, "_ctx", extractor_or_ctx)
         self.mfNNratio, self.mbCheckOrientation = float(nnratio), bool(checkOri)
 

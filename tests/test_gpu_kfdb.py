@@ -93,6 +93,22 @@ def test_kfdb_rejects_bad_input():
         db.add(1, (np.array([5, 9], np.uint32), np.ones(2)))   # duplicate id
     with pytest.raises(OrbxError):
         db.query((ids, vals))
-    big = np.arange(9000, dtype=np.uint32)
-    with pytest.raises(OrbxError):
-        db.query((big, np.ones(9000)))         # > 8192 query words: reported, not truncated
+
+
+def test_kfdb_long_queries_are_served_from_hbm():
+    """A BowVector of more than 8192 words (the 20 000-feature frames of the fork's Examples/Monocular/mi.yaml) no longer fits
+    the kernels' LDS staging; the query is then searched where it lies.  The keyframe owns an extractor that is otherwise
+    unreferenced: the database keeps it alive (KeyFrameDatabase(ORBextractor(...)))."""
+    rng = np.random.default_rng(9)
+    db, odb = KeyFrameDatabase(ORBextractor(1000, 1.2, 8, 20, 7)), po.OracleKeyFrameDatabase()
+    import gc
+    gc.collect()
+    for kid in range(40):
+        b = _bow(rng, kid % 5, nwords=200000, n=int(rng.integers(9000, 14000)))
+        db.add(kid, b); odb.add(kid, b)
+    for _ in range(4):
+        q = _bow(rng, int(rng.integers(0, 5)), nwords=200000, n=int(rng.integers(8500, 15000)))
+        assert len(q[0]) > 8192
+        a, b = db.query(q, [3, 17], 0), odb.query(q, [3, 17], 0)
+        _same(a, b)
+        assert (a["score"] >= 0).sum() > 0
