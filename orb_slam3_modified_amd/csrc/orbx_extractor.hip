@@ -344,7 +344,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
     if (nitems <= 0) return;
     hipLaunchKernelGGL(fast_kern, dim3(xcd_grid(nitems)), dim3(ft), fast_lds, s, ctx->d_geo, ctx->d_cells, d_imgs,
                        (long long)row_stride, (long long)frame_stride, b_pyr, (long long)geo.pyr_bytes, b_cand, b_cell_cnt,
-                       ctx->ini_th, ctx->min_th, tile_rows, nitems, cell_base, ncells_sub, div_magic((uint32_t)ncells_sub));
+                       ctx->ini_th, ctx->min_th, tile_rows, nitems, cell_base, ncells_sub, div_magic((uint32_t)ncells_sub), ctx->fast_stop);
   };
   const int ncells0 = geo.lv[0].ncells, ncells_all = (int)geo.cells.size();
   // small batches (the single-frame operator() path) are latency-bound: a stream fork costs more than it hides there
@@ -584,6 +584,8 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, 
     const char* ff = getenv("ORBX_FORK_FAST0");
     const char* fpk = getenv("ORBX_FAST_PK");   // packed 16-bit necessary test in k_fast_cells (128-thread workgroups)
     ctx->fast_pk = fpk ? atoi(fpk) != 0 : true;
+    const char* fs = getenv("ORBX_FAST_STOP");
+    ctx->fast_stop = fs ? atoi(fs) : 0;
     const char* dl = getenv("ORBX_DESC_LDS");   // blurred 37x37 window staged in LDS for the descriptor taps
     ctx->desc_lds = dl ? atoi(dl) != 0 : true;
     const char* fq = getenv("ORBX_FORK_QT");
@@ -938,6 +940,7 @@ int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
   else if (n == "fork_qt") ctx->fork_qt = value != 0;
   else if (n == "graph") ctx->use_graph = value != 0;
   else if (n == "fast_pk") ctx->fast_pk = value != 0;
+  else if (n == "fast_stop") ctx->fast_stop = value;   // timing experiment: FAST returns after staging (1) / after the necessary test (2); results are void
   else if (n == "desc_lds") ctx->desc_lds = value != 0;
   else if (n == "fast_threads" && (value == 64 || value == 128 || value == 256)) ctx->fast_threads = value;
   else if (n == "desc_k" && (value == 1 || value == 2 || value == 4 || value == 8 || value == 16)) ctx->desc_k = value;

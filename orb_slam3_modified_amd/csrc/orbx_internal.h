@@ -148,6 +148,7 @@ struct orbx_ctx {
   hipEvent_t ev_f0_fork[2] = {nullptr, nullptr}, ev_f0_join[2] = {nullptr, nullptr};
   hipEvent_t ev_qt_fork[2] = {nullptr, nullptr}, ev_qt_join[2] = {nullptr, nullptr};
   bool fork_blur = true, fork_fast0 = false, fork_qt = true, fast_pk = true, desc_lds = true;
+  int fast_stop = 0;          // timing experiment only (orbx_set_option "fast_stop"): results are void when set
   std::string err;
 
   // geometry + device buffers for the current (rows, cols, batch capacity)

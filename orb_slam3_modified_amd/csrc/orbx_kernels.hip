@@ -221,7 +221,7 @@ __global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__
                                                   long long img_frame_stride, const uint8_t* __restrict__ pyr,
                                                   long long pyr_frame_bytes, uint32_t* __restrict__ cand,
                                                   int32_t* __restrict__ cell_cnt, int ini_th, int min_th, int tile_rows,
-                                                  int nitems, int cell_base, int ncells_sub, uint32_t m_ncells_sub) {
+                                                  int nitems, int cell_base, int ncells_sub, uint32_t m_ncells_sub, int stop_after) {
   // LDS: [16 B pad][tile_rows][PITCH] raw pixels (+ alignment shift xo) | [tile_rows][PITCH] scores with a 1-px
   // zero frame | list.  PITCH is a compile-time constant so every circle / neighbour access is an immediate offset.
   extern __shared__ __align__(16) uint8_t smem[];
@@ -268,10 +268,10 @@ __global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__
   for (int k = 0; k < WPT; k++) bitmap[t * WPT + k] = 0;
   if (t == 0) s_cnt = 0;
   __syncthreads();
-#ifdef ORBX_FAST_STOP_AFTER_A   // timing experiment only
-  if (t == 0) cell_cnt[(long long)frame * g->ncells_total + cell] = 0;
-  return;
-#endif
+  if (stop_after == 1) {   // timing experiment only ("fast_stop" option): the cell reports no keypoint
+    if (t == 0) cell_cnt[(long long)frame * g->ncells_total + cell] = 0;
+    return;
+  }
   // ---- B: necessary test, 4 pixels (one aligned LDS dword of centres) per lane and step; branch-free
   {
     const int kmin = (3 + xo) >> 2, kmax = (cw - 4 + xo) >> 2, ng = kmax - kmin + 1;
@@ -341,10 +341,10 @@ __global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__
     }
   }
   __syncthreads();
-#ifdef ORBX_FAST_STOP_AFTER_B   // timing experiment only
-  if (t == 0) cell_cnt[(long long)frame * g->ncells_total + cell] = 0;
-  return;
-#endif
+  if (stop_after == 2) {
+    if (t == 0) cell_cnt[(long long)frame * g->ncells_total + cell] = 0;
+    return;
+  }
   const int n1 = s_cnt;
   // ---- C: exact score of the listed pixels
   for (int e = t; e < n1; e += T) {
