@@ -83,6 +83,13 @@ int orbx_extract_batch_device(orbx_ctx* ctx, const uint8_t* d_imgs, int nframes,
 int orbx_extract_color(orbx_ctx* ctx, const uint8_t* img, int rows, int cols, size_t stride, int channels, int rgb_order, int lap0,
                        int lap1, orbx_keypoint* kps, uint8_t* desc, int* n_out, int* mono_index_out);
 
+/* The other ingestion step: System::TrackMonocular / TrackStereo / TrackRGBD resize the incoming image to the configured size
+ * before tracking (cv::resize(im, resizedIm, settings_->newImSize()), src/System.cc:441-446, INTER_LINEAR; an exact 2 x 2
+ * downscale is OpenCV's INTER_AREA shortcut).  img: CV_8UC1 rows x cols; new_rows x new_cols = newImSize; the resize runs on
+ * the device behind the upload (the pyramid's fixed-point bilinear kernel) and its output is level 0.  Otherwise as orbx_extract. */
+int orbx_extract_resized(orbx_ctx* ctx, const uint8_t* img, int rows, int cols, size_t stride, int new_rows, int new_cols, int lap0, int lap1,
+                         orbx_keypoint* kps, uint8_t* desc, int* n_out, int* mono_index_out);
+
 /* Host-buffer convenience over the batch path (H2D all frames, extract, D2H). counts: [nframes][2]. */
 int orbx_extract_batch(orbx_ctx* ctx, const uint8_t* imgs, int nframes, int rows, int cols, size_t row_stride,
                        size_t frame_stride, int lap0, int lap1, orbx_keypoint* kps, uint8_t* desc, int32_t* counts);
@@ -248,6 +255,18 @@ int orbx_window_nearest(orbx_ctx* ctx, const orbx_keypoint* kps, const uint8_t* 
                         const float* kp_uright, const float* inv_level_sigma2, int nlevels, const float* qx, const float* qy,
                         const float* qr, const int32_t* qmin_level, const int32_t* qmax_level, const float* q_ur,
                         const uint8_t* q_desc, int nq, int32_t* best_idx, int32_t* best_dist);
+
+/* Frame::UndistortKeyPoints (src/Frame.cc:747-780): kps_un = kps when dist_coef[0] == 0, otherwise the coordinates go through
+ * cv::undistortPoints(pts, pts, K, distCoef, Mat(), K) — OpenCV 4.x's 5-iteration fixed point of the radial (k1 k2 [k3]) +
+ * tangential (p1 p2) model in double, as recalled (no OpenCV to pin it against: unpinned like the extractor's five OpenCV
+ * primitives); every other keypoint field is copied.  dist_coef = mDistCoef (k1 k2 p1 p2 [k3]), n_coef = 4 or 5; fx fy cx cy =
+ * the entries of mK.  The _device form works on resident arrays laid out like the outputs of orbx_extract_batch_device
+ * ([nframes][capacity] keypoints, [nframes][2] counts), asynchronously on `stream`: the keypoints never leave HBM between the
+ * extraction and the frame grid / guided searches. */
+int orbx_undistort_keypoints(orbx_ctx* ctx, const orbx_keypoint* kps, int n, float fx, float fy, float cx, float cy, const float* dist_coef,
+                             int n_coef, orbx_keypoint* kps_un);
+int orbx_undistort_keypoints_device(orbx_ctx* ctx, const orbx_keypoint* d_kps, const int32_t* d_counts, int nframes, int capacity, float fx,
+                                    float fy, float cx, float cy, const float* dist_coef, int n_coef, orbx_keypoint* d_kps_un, void* stream);
 
 /* ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>&, th, bFarPoints, thFarPoints)
  * (src/ORBmatcher.cc:43-141; Tracking::SearchLocalPoints' per-frame call) for single-camera / rectified-stereo frames

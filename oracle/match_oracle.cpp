@@ -904,3 +904,42 @@ void mo_window_nearest(const void* kps_, const uint8_t* desc, int n, const void*
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// Frame::UndistortKeyPoints (src/Frame.cc:747-780): mvKeysUn = mvKeys when mDistCoef[0] == 0, else
+// cv::undistortPoints(points, points, K, distCoef, cv::Mat(), K) on the keypoint coordinates.
+// **parity unpinned**: the loop below restates OpenCV 4.x's cvUndistortPointsInternal from recollection (calib3d /
+// imgproc undistort.dispatch.cpp) — K and the coefficients widened from CV_32F to double, the default termination
+// criteria of the 6-argument overload (MAX_ITER, 5 iterations), no tilt model (k[12] = k[13] = 0), R = I, P = K:
+//   x = (u - cx) / fx via ifx = 1./fx ... 5 fixed-point iterations of the radial (k1 k2 k3) + tangential (p1 p2) model
+//   ... (xx, yy, ww) = K * (x, y, 1), result narrowed to float.
+// ---------------------------------------------------------------------------------------------------------
+extern "C" void mo_undistort_points(const float* xy_in, int n, float fx_, float fy_, float cx_, float cy_, const float* dist, int ndist,
+                                    float* xy_out) {
+  double k[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < ndist && i < 14; i++) k[i] = (double)dist[i];   // k1 k2 p1 p2 [k3 ...]
+  const double fx = fx_, fy = fy_, cx = cx_, cy = cy_;
+  const double ifx = 1. / fx, ify = 1. / fy;
+  const double RR[3][3] = {{fx, 0, cx}, {0, fy, cy}, {0, 0, 1}};      // P * R with R = I, P = K
+  for (int i = 0; i < n; i++) {
+    double x = xy_in[2 * i], y = xy_in[2 * i + 1];
+    const double u = x, v = y;
+    x = (x - cx) * ifx;
+    y = (y - cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+      const double r2 = x * x + y * y;
+      const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+      if (icdist < 0) { x = (u - cx) * ifx; y = (v - cy) * ify; break; }
+      const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+      const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+      x = (x0 - deltaX) * icdist;
+      y = (y0 - deltaY) * icdist;
+    }
+    const double xx = RR[0][0] * x + RR[0][1] * y + RR[0][2];
+    const double yy = RR[1][0] * x + RR[1][1] * y + RR[1][2];
+    const double ww = 1. / (RR[2][0] * x + RR[2][1] * y + RR[2][2]);
+    xy_out[2 * i] = (float)(xx * ww);
+    xy_out[2 * i + 1] = (float)(yy * ww);
+  }
+}

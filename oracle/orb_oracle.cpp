@@ -747,6 +747,22 @@ double orbo_extract_many(int nfeatures, float scaleFactor, int nlevels, int iniT
   return dt;
 }
 
+// cv::resize(src, dst, dsize) as System::TrackMonocular calls it on the incoming image (src/System.cc:441-446, INTER_LINEAR by
+// default): the fixed-point bilinear path above, except that OpenCV turns an EXACT 2 x 2 downscale into INTER_AREA
+// (imgproc/src/resize.cpp: `interpolation == INTER_LINEAR && is_area_fast && iscale_x == 2 && iscale_y == 2`), i.e. the
+// rounded mean of each 2 x 2 block.  Recalled OpenCV semantics like the other primitives.
+void orbo_cv_resize(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh, int dstride) {
+  if (sw == 2 * dw && sh == 2 * dh) {
+    for (int y = 0; y < dh; y++)
+      for (int x = 0; x < dw; x++) {
+        const uint8_t* S = src + (size_t)(2 * y) * sstride + 2 * x;
+        dst[(size_t)y * dstride + x] = (uint8_t)((S[0] + S[1] + S[sstride] + S[sstride + 1] + 2) >> 2);
+      }
+    return;
+  }
+  resize_linear_u8(src, sw, sh, sstride, dst, dw, dh, dstride);
+}
+
 // isolated primitives
 void orbo_resize_linear(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh, int dstride) {
   resize_linear_u8(src, sw, sh, sstride, dst, dw, dh, dstride);

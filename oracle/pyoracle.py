@@ -137,6 +137,14 @@ def resize_linear(src: np.ndarray, dw: int, dh: int) -> np.ndarray:
     return dst
 
 
+def cv_resize(src: np.ndarray, dw: int, dh: int) -> np.ndarray:
+    """cv::resize(src, dst, Size(dw, dh)) (INTER_LINEAR default; an exact 2 x 2 downscale becomes INTER_AREA), src/System.cc:441-446."""
+    src = np.ascontiguousarray(src)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().orbo_cv_resize(_ptr(src), src.shape[1], src.shape[0], src.strides[0], _ptr(dst), dw, dh, dw)
+    return dst
+
+
 def fast(img: np.ndarray, threshold: int, nms: bool = True) -> np.ndarray:
     img = np.ascontiguousarray(img)
     cap = img.size
@@ -246,6 +254,22 @@ def features_in_area(kps, bounds, qx, qy, qr, qmin, qmax):
                                       nq, _ptr(rp), _ptr(cand), cap)
     assert nnz >= 0
     return rp, cand[:nnz].copy()
+
+
+def undistort_keypoints(kps, fx, fy, cx, cy, dist):
+    """Frame::UndistortKeyPoints (src/Frame.cc:747-780) -> undistorted copy of the keypoints (only pt changes)."""
+    k = np.ascontiguousarray(kps).copy()
+    dist = np.ascontiguousarray(dist, np.float32)
+    if len(k) == 0 or dist[0] == 0.0:
+        return k
+    xy = np.ascontiguousarray(np.stack([k["x"], k["y"]], 1), np.float32)
+    out = np.zeros_like(xy)
+    L = _mlib()
+    L.mo_undistort_points.restype = None
+    L.mo_undistort_points.argtypes = [C.c_void_p, C.c_int] + [C.c_float] * 4 + [C.c_void_p, C.c_int, C.c_void_p]
+    L.mo_undistort_points(_ptr(xy), len(k), float(fx), float(fy), float(cx), float(cy), _ptr(dist), len(dist), _ptr(out))
+    k["x"], k["y"] = out[:, 0], out[:, 1]
+    return k
 
 
 class _MoGrid(C.Structure):

@@ -27,7 +27,7 @@ _ref/libref_dbow2.so: $(SRCS) ref_shims/opencv2/core/core.hpp ref_shims/boost/se
 # ORBmatcher.h includes them from its own directory, so the object model of tests/support/ref_world is the one seen
 _ref/ref_matcher_world: $(REFROOT)/src/ORBmatcher.cc $(REFROOT)/include/ORBmatcher.h ../tests/support/matcher_world.cpp $(WORLD_HDRS)
 	mkdir -p _ref
-	$(CXX) -O1 -std=c++17 -ffp-contract=off -w -include $(WORLD)/ref_world.h -I$(WORLD) -Iref_shims -I$(REFROOT)/include \
+	$(CXX) -O2 -std=c++17 -ffp-contract=off -w -include $(WORLD)/ref_world.h -I$(WORLD) -Iref_shims -I$(REFROOT)/include \
 	    $(REFROOT)/src/ORBmatcher.cc ../tests/support/matcher_world.cpp -o $@
 
 # the five OpenCV algorithm calls resolve to orbo_* in liborb_oracle.so (built by oracle/Makefile)

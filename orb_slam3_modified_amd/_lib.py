@@ -49,6 +49,7 @@ def lib() -> C.CDLL:
         "orbx_scale_tables": (i32, [vp, vp, vp, vp, vp, vp]),
         "orbx_extract": (i32, [vp, vp, i32, i32, sz, i32, i32, vp, vp, ip, ip]),
         "orbx_extract_color": (i32, [vp, vp, i32, i32, C.c_size_t, i32, i32, i32, i32, vp, vp, ip, ip]),
+        "orbx_extract_resized": (i32, [vp, vp, i32, i32, sz, i32, i32, i32, i32, vp, vp, ip, ip]),
         "orbx_extract_batch_device": (i32, [vp, vp, i32, i32, i32, sz, sz, i32, i32, vp, vp, vp, vp]),
         "orbx_extract_batch": (i32, [vp, vp, i32, i32, i32, sz, sz, i32, i32, vp, vp, vp]),
         "orbx_pyramid_level": (i32, [vp, i32, i32, vp, sz, ip, ip]),
@@ -73,6 +74,8 @@ def lib() -> C.CDLL:
         "orbx_window_search": (i32, [vp, vp, vp, i32, f32, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
         "orbx_window_search_grid": (i32, [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
         "orbx_window_nearest": (i32, [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]),
+        "orbx_undistort_keypoints": (i32, [vp, vp, i32, f32, f32, f32, f32, vp, i32, vp]),
+        "orbx_undistort_keypoints_device": (i32, [vp, vp, vp, i32, i32, f32, f32, f32, f32, vp, i32, vp, vp]),
         "orbx_search_by_projection": (i32, [vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32,
                                             vp, ip]),
         "orbx_search_by_projection_last": (i32, [vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, vp, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp, i32,

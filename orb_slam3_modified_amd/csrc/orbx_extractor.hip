@@ -620,6 +620,7 @@ void orbx_destroy(orbx_ctx* ctx) {
   if (ctx->h_in) { (void)hipHostFree(ctx->h_in); ctx->h_in = nullptr; }
   if (ctx->h_call) { (void)hipHostFree(ctx->h_call); ctx->h_call = nullptr; }
   if (ctx->d_color) { (void)hipFree(ctx->d_color); ctx->d_color = nullptr; }
+  if (ctx->d_ingest_tab) { (void)hipFree(ctx->d_ingest_tab); ctx->d_ingest_tab = nullptr; }
   if (ctx->h_stage_out) { (void)hipHostFree(ctx->h_stage_out); ctx->h_stage_out = nullptr; }
   if (ctx->h_pyr) { (void)hipHostFree(ctx->h_pyr); ctx->h_pyr = nullptr; }
   for (int i = 0; i < orbx_ctx::kMaxAux; i++) {
@@ -791,14 +792,72 @@ static int extract_one_graph(orbx_ctx* ctx, const uint8_t* img, int rows, int co
   return 1;
 }
 
+// cv::resize(im, resizedIm, settings_->newImSize()) of System::TrackMonocular / TrackStereo / TrackRGBD (src/System.cc:441-446)
+// fused behind the upload: the caller's grey image lands in d_color, k_resize (the pyramid's INTER_LINEAR kernel, with tables
+// for this source / destination size) or k_box2 (OpenCV's INTER_AREA shortcut for an exact 2 x 2 downscale) writes level 0.
+static int ingest_resized(orbx_ctx* ctx, const uint8_t* img, int src_rows, int src_cols, size_t row_stride, int rows, int cols, size_t pitch) {
+  if (src_rows > 65535 || src_cols > 65535) return set_err(ctx, ORBX_E_INVALID, "orbx_extract_resized: source image side beyond 65535 px");
+  const size_t spitch = (size_t)round_up(src_cols, 64), sbytes = spitch * src_rows;
+  if (spitch >= (1u << 23)) return set_err(ctx, ORBX_E_INVALID, "orbx_extract_resized: source row beyond the kernels' offsets");
+  if (sbytes > ctx->color_bytes) {
+    ORBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_color) (void)hipFree(ctx->d_color);
+    ctx->d_color = nullptr; ctx->color_bytes = 0;
+    ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_color, sbytes));
+    ctx->color_bytes = sbytes;
+  }
+  hipStream_t st = ctx->stream;
+  ORBX_HIP(ctx, hipMemcpy2DAsync(ctx->d_color, spitch, img, row_stride, (size_t)src_cols, (size_t)src_rows, hipMemcpyHostToDevice, st));
+  if (src_cols == 2 * cols && src_rows == 2 * rows) {
+    hipLaunchKernelGGL(k_box2, dim3((cols + 63) / 64, (rows + 3) / 4), dim3(256), 0, st, ctx->d_color, (int)spitch, ctx->d_stage_img, (int)pitch, cols, rows);
+    ORBX_HIP(ctx, hipGetLastError());
+    return ORBX_OK;
+  }
+  const int key[4] = {src_rows, src_cols, rows, cols};
+  if (!ctx->d_ingest_tab || std::memcmp(key, ctx->ingest_key, sizeof(key)) != 0) {
+    std::vector<XTab> xt, yt;
+    build_axis_table(src_cols, cols, true, xt);
+    while (xt.size() % 4) xt.push_back(XTab{0, 0, 0, 0});   // the kernel reads the column table four entries at a time
+    build_axis_table(src_rows, rows, false, yt);
+    int mw = 1, mh = 1;   // LDS tile: the largest source rectangle any 64 x 64 output tile needs (as for the pyramid levels)
+    for (int x0 = 0; x0 < cols; x0 += kRT_W) {
+      const XTab a = xt[x0], b = xt[std::min(x0 + kRT_W, cols) - 1];
+      mw = std::max(mw, std::max((int)b.s0, (int)b.s1) - ((int)a.s0 & ~3) + 1);
+    }
+    for (int y0 = 0; y0 < rows; y0 += kRT_H) {
+      const XTab a = yt[y0], b = yt[std::min(y0 + kRT_H, rows) - 1];
+      mh = std::max(mh, std::max((int)b.s0, (int)b.s1) - (int)a.s0 + 1);
+    }
+    const int lp = round_up(mw, 4);
+    if ((size_t)lp * mh > 60 * 1024 || lp / 4 > 256) return set_err(ctx, ORBX_E_CAPACITY, "orbx_extract_resized: scale too large for the resize kernel's LDS tile");
+    ORBX_HIP(ctx, hipStreamSynchronize(st));
+    if (ctx->d_ingest_tab) (void)hipFree(ctx->d_ingest_tab);
+    ctx->d_ingest_tab = nullptr;
+    ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_ingest_tab, sizeof(XTab) * (xt.size() + yt.size())));
+    ORBX_HIP(ctx, copy_sync(ctx, ctx->d_ingest_tab, xt.data(), sizeof(XTab) * xt.size(), hipMemcpyHostToDevice));
+    ORBX_HIP(ctx, copy_sync(ctx, ctx->d_ingest_tab + xt.size(), yt.data(), sizeof(XTab) * yt.size(), hipMemcpyHostToDevice));
+    std::memcpy(ctx->ingest_key, key, sizeof(key));
+    ctx->ingest_ytab_off = (int)xt.size(); ctx->ingest_lds_pitch = lp; ctx->ingest_lds_rows = mh;
+  }
+  const int nbx = (cols + kRT_W - 1) / kRT_W, nby = (rows + kRT_H - 1) / kRT_H, nitems = nbx * nby;
+  const int lp = ctx->ingest_lds_pitch, lr = ctx->ingest_lds_rows;
+  hipLaunchKernelGGL(k_resize, dim3(xcd_grid(nitems)), dim3(256), (size_t)lp * lr, st, ctx->d_color, (long long)sbytes, (int)spitch, src_cols,
+                     ctx->d_stage_img, (long long)(pitch * rows), (int)pitch, cols, rows, ctx->d_ingest_tab, ctx->d_ingest_tab + ctx->ingest_ytab_off,
+                     nbx, nby, nitems, lp, lr, div_magic((uint32_t)(nbx * nby)), div_magic((uint32_t)nbx), div_magic((uint32_t)(lp / 4)),
+                     256 / (lp / 4));
+  ORBX_HIP(ctx, hipGetLastError());
+  return ORBX_OK;
+}
+
 // channels == 1: grey frames.  channels == 3 / 4: interleaved colour frames, converted on the device behind the upload
 // (rgb_order != 0: R first, else B first).
 static int extract_batch_impl(orbx_ctx* ctx, const uint8_t* imgs, int nframes, int rows, int cols, size_t row_stride,
                               size_t frame_stride, int channels, int rgb_order, int lap0, int lap1, orbx_keypoint* kps, uint8_t* desc,
-                              int32_t* counts) {
+                              int32_t* counts, int src_rows = 0, int src_cols = 0) {
   if (!ctx) return ORBX_E_INVALID;
   if (!imgs || rows <= 0 || cols <= 0 || nframes <= 0) return set_err(ctx, ORBX_E_EMPTY, "empty image");
-  if (!kps || !desc || !counts || row_stride < (size_t)cols * channels) return set_err(ctx, ORBX_E_INVALID, "bad arguments");
+  const bool resized = src_rows > 0;   // rows x cols = the size AFTER cv::resize; the caller's image is src_rows x src_cols
+  if (!kps || !desc || !counts || row_stride < (size_t)(resized ? src_cols : cols) * channels) return set_err(ctx, ORBX_E_INVALID, "bad arguments");
   ORBX_HIP(ctx, hipSetDevice(ctx->device));
   const size_t pitch = (size_t)round_up(cols, 64), fbytes = pitch * rows;
   int rc = ensure_stage(ctx, nframes, fbytes * nframes);
@@ -806,7 +865,7 @@ static int extract_batch_impl(orbx_ctx* ctx, const uint8_t* imgs, int nframes, i
   const StageLayout L = stage_layout(ctx, ctx->stage_frames);   // the block was laid out for its allocated capacity
   const size_t kb = (size_t)nframes * ctx->out_cap * sizeof(orbx_keypoint), db = (size_t)nframes * ctx->out_cap * 32,
                cb = (size_t)nframes * 2 * sizeof(int32_t);
-  if (nframes == 1 && channels == 1) {   // the live-SLAM path: replay the captured graph
+  if (nframes == 1 && channels == 1 && !resized) {   // the live-SLAM path: replay the captured graph
     if (row_stride >= (1u << 23) || (unsigned long long)row_stride * (unsigned long long)rows >= (1ull << 31))
       return set_err(ctx, ORBX_E_INVALID, "row stride / frame size beyond the kernels' 32-bit in-frame offsets");
     rc = extract_one_graph(ctx, imgs, rows, cols, row_stride, lap0, lap1, pitch, fbytes, L);
@@ -819,7 +878,10 @@ static int extract_batch_impl(orbx_ctx* ctx, const uint8_t* imgs, int nframes, i
       return ORBX_OK;
     }
   }
-  if (channels == 1) {
+  if (resized) {
+    rc = ingest_resized(ctx, imgs, src_rows, src_cols, row_stride, rows, cols, pitch);
+    if (rc != ORBX_OK) return rc;
+  } else if (channels == 1) {
     for (int f = 0; f < nframes; f++)
       ORBX_HIP(ctx, hipMemcpy2DAsync(ctx->d_stage_img + f * fbytes, pitch, imgs + f * frame_stride, row_stride, cols, rows,
                                      hipMemcpyHostToDevice, ctx->stream));
@@ -890,6 +952,21 @@ int orbx_extract_color(orbx_ctx* ctx, const uint8_t* img, int rows, int cols, si
   if (!img || rows <= 0 || cols <= 0) return set_err(ctx, ORBX_E_EMPTY, "empty image");
   int32_t counts[2] = {0, 0};
   int rc = extract_batch_impl(ctx, img, 1, rows, cols, stride, stride * rows, channels, rgb_order, lap0, lap1, kps, desc, counts);
+  if (rc != ORBX_OK) return rc;
+  if (n_out) *n_out = counts[0];
+  if (mono_index_out) *mono_index_out = counts[1];
+  return ORBX_OK;
+}
+
+int orbx_extract_resized(orbx_ctx* ctx, const uint8_t* img, int rows, int cols, size_t stride, int new_rows, int new_cols, int lap0, int lap1,
+                         orbx_keypoint* kps, uint8_t* desc, int* n_out, int* mono_index_out) {
+  if (n_out) *n_out = 0;
+  if (mono_index_out) *mono_index_out = 0;
+  if (!ctx) return ORBX_E_INVALID;
+  if (!img || rows <= 0 || cols <= 0 || new_rows <= 0 || new_cols <= 0) return set_err(ctx, ORBX_E_EMPTY, "empty image");
+  if (new_rows == rows && new_cols == cols) return orbx_extract(ctx, img, rows, cols, stride, lap0, lap1, kps, desc, n_out, mono_index_out);
+  int32_t counts[2] = {0, 0};
+  int rc = extract_batch_impl(ctx, img, 1, new_rows, new_cols, stride, stride * rows, 1, 0, lap0, lap1, kps, desc, counts, rows, cols);
   if (rc != ORBX_OK) return rc;
   if (n_out) *n_out = counts[0];
   if (mono_index_out) *mono_index_out = counts[1];

@@ -171,6 +171,7 @@ struct orbx_ctx {
   uint2* d_kp_list = nullptr;      // [batch][out_cap] {packed point, level | output slot << 8}, level-major order
   // single-frame staging (orbx_extract)
   uint8_t* d_stage_img = nullptr; size_t stage_img_bytes = 0;
+  orbx::XTab* d_ingest_tab = nullptr; int ingest_key[4] = {0, 0, 0, 0}; int ingest_ytab_off = 0, ingest_lds_pitch = 0, ingest_lds_rows = 0;   // resize ingestion (orbx_extract_resized)
   uint8_t* d_color = nullptr; size_t color_bytes = 0;   // interleaved colour frames of orbx_extract_color, before conversion
   uint8_t* d_stage_out = nullptr;   // [keypoints | descriptors | counts] of the host-buffer entry points
   uint8_t* h_stage_out = nullptr;   // pinned host mirror of d_stage_out (one D2H copy per call)
@@ -229,6 +230,11 @@ inline hipError_t sync_ctx(orbx_ctx* ctx) {
 hipError_t ensure_dynamic_lds(const void* kernel, int bytes);
 // orbx_window.hip: pinned staging (grow-only) and the fused window pass behind orbx_window_search* / orbx_window_nearest
 hipError_t host_stage(orbx_ctx* ctx, size_t bytes, uint8_t** p);
+// offsets of the pieces of one packed blob (256-byte aligned pieces)
+struct BlobLayout {
+  size_t size = 0;
+  size_t add(size_t bytes) { const size_t o = size; size = (size + bytes + 255) & ~(size_t)255; return o; }
+};
 int window_call(orbx_ctx* ctx, const char* who, const orbx_keypoint* kps, const uint8_t* desc, int n, const orbx_grid* grid,
                 const uint8_t* kp_skip, const float* kp_uright, const float* inv_sigma2, int nlevels, const float* qx, const float* qy,
                 const float* qr, const int32_t* qlo, const int32_t* qhi, const float* qaux, const uint8_t* q_desc, int nq, bool lists,

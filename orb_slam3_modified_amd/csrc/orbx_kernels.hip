@@ -1445,9 +1445,16 @@ __global__ __launch_bounds__(256) void k_debug_atan_hash(uint32_t seed, uint32_t
   if ((threadIdx.x & 63) == 0) atomicAdd(out, h);
 }
 
-// Calibration kernel for the rocprofv3 FETCH_SIZE / WRITE_SIZE counters (MI355X_MICROARCH.md "HBM": the counters
-// are only calibrated for wide streaming reads): copies n bytes with W bytes per lane per access (W = 1, 4, 16),
-// i.e. a kernel whose HBM traffic is known exactly, in the access widths the extractor kernels use.
+// cv::resize's INTER_AREA shortcut for an exact 2 x 2 downscale (the rounded mean of each block): image ingestion only
+// (src/System.cc:441-446); the pyramid's scale factor never hits it.
+__global__ __launch_bounds__(256) void k_box2(const uint8_t* __restrict__ src, int src_pitch, uint8_t* __restrict__ dst, int dst_pitch, int dw,
+                                              int dh) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= dw || y >= dh) return;
+  const uint8_t* S = src + (size_t)(2 * y) * src_pitch + 2 * x;
+  dst[(size_t)y * dst_pitch + x] = (uint8_t)(((int)S[0] + (int)S[1] + (int)S[src_pitch] + (int)S[src_pitch + 1] + 2) >> 2);
+}
+
 // Image ingestion: cv::cvtColor(COLOR_RGB2GRAY / BGR2GRAY / RGBA2GRAY / BGRA2GRAY) of
 // src/Tracking.cc:1572-1585 fused behind the upload — OpenCV (>= 4.x) 8-bit path: 15-bit fixed point,
 // gray = (R * 9798 + G * 19235 + B * 3735 + 2^14) >> 15.  Each lane converts 4 pixels and stores one dword.
@@ -1469,6 +1476,9 @@ __global__ __launch_bounds__(256) void k_color_to_gray(const uint8_t* __restrict
   *(uint32_t*)(dst + (long long)blockIdx.z * dst_frame_stride + (long long)y * dst_pitch + x4) = packed;  // pitch is a multiple of 64
 }
 
+// Calibration kernel for the rocprofv3 FETCH_SIZE / WRITE_SIZE counters (MI355X_MICROARCH.md "HBM": the counters
+// are only calibrated for wide streaming reads): copies n bytes with W bytes per lane per access (W = 1, 4, 16),
+// i.e. a kernel whose HBM traffic is known exactly, in the access widths the extractor kernels use.
 template <typename T>
 __global__ __launch_bounds__(256) void k_calib_copy(const T* __restrict__ src, T* __restrict__ dst, long long n) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)

@@ -359,28 +359,44 @@ int orbx_nn_csr(orbx_ctx* ctx, const uint8_t* q_desc, int nq, const uint8_t* t_d
   if (!ctx || nq < 0 || nt < 0 || (nq > 0 && (!q_desc || !row_ptr))) return ORBX_E_INVALID;
   if (nq == 0) return ORBX_OK;
   const int nnz = row_ptr[nq];
+  if (nnz < 0 || (nnz > 0 && (!cand || !t_desc))) return set_err(ctx, ORBX_E_INVALID, "orbx_nn_csr: bad candidate lists");
   for (int i = 0; i < nnz; i++)
     if (cand[i] < 0 || cand[i] >= nt) return set_err(ctx, ORBX_E_INVALID, "candidate index out of range");
   ORBX_HIP(ctx, hipSetDevice(ctx->device));
-  DevBuf<uint8_t> dq, dt;
-  DevBuf<int32_t> drp, dc, dbi, dbd, dsi, dsd, ddo;
-  ORBX_HIP(ctx, dq.alloc((size_t)nq * 32)); ORBX_HIP(ctx, dt.alloc((size_t)nt * 32));
-  ORBX_HIP(ctx, drp.alloc(nq + 1)); ORBX_HIP(ctx, dc.alloc(nnz));
-  ORBX_HIP(ctx, dbi.alloc(nq)); ORBX_HIP(ctx, dbd.alloc(nq)); ORBX_HIP(ctx, dsi.alloc(nq)); ORBX_HIP(ctx, dsd.alloc(nq));
-  ORBX_HIP(ctx, ddo.alloc(nnz));
-  ORBX_HIP(ctx, copy_sync(ctx, dq.p, q_desc, (size_t)nq * 32, hipMemcpyHostToDevice));
-  if (nt) ORBX_HIP(ctx, copy_sync(ctx, dt.p, t_desc, (size_t)nt * 32, hipMemcpyHostToDevice));
-  ORBX_HIP(ctx, copy_sync(ctx, drp.p, row_ptr, sizeof(int32_t) * (nq + 1), hipMemcpyHostToDevice));
-  if (nnz) ORBX_HIP(ctx, copy_sync(ctx, dc.p, cand, sizeof(int32_t) * nnz, hipMemcpyHostToDevice));
-  int rc = orbx_nn_csr_device(ctx, dq.p, nq, dt.p, nt, drp.p, dc.p, last_wins, dbi.p, dbd.p, dsi.p, dsd.p,
-                              dist_out ? ddo.p : nullptr, ctx->stream);
+  // one packed blob in (one H2D copy), one launch, one blob out (one D2H copy): no per-call allocation
+  const bool want_best = best_idx || best_dist || second_idx || second_dist;
+  BlobLayout in, out;
+  const size_t o_q = in.add((size_t)nq * 32), o_t = in.add((size_t)nt * 32), o_rp = in.add(4 * (size_t)(nq + 1)), o_c = in.add(4 * (size_t)nnz);
+  const size_t p_b = out.add(want_best ? 16 * (size_t)nq : 0), p_d = out.add(dist_out ? 4 * (size_t)nnz : 0);
+  uint8_t* h = nullptr;
+  ORBX_HIP(ctx, host_stage(ctx, in.size + out.size, &h));
+  uint8_t* hin = h;
+  uint8_t* hout = h + in.size;
+  std::memcpy(hin + o_q, q_desc, (size_t)nq * 32);
+  if (nt) std::memcpy(hin + o_t, t_desc, (size_t)nt * 32);
+  std::memcpy(hin + o_rp, row_ptr, 4 * (size_t)(nq + 1));
+  if (nnz) std::memcpy(hin + o_c, cand, 4 * (size_t)nnz);
+  ctx->arena.rewind();
+  hipError_t aerr = hipSuccess;
+  uint8_t* din = (uint8_t*)ctx->arena.alloc(in.size, &aerr);
+  ORBX_HIP(ctx, aerr);
+  uint8_t* dout = (uint8_t*)ctx->arena.alloc(std::max<size_t>(out.size, 256), &aerr);
+  ORBX_HIP(ctx, aerr);
+  hipStream_t st = ctx->stream;
+  ORBX_HIP(ctx, hipMemcpyAsync(din, hin, in.size, hipMemcpyHostToDevice, st));
+  int32_t* db = (int32_t*)(dout + p_b);
+  int rc = orbx_nn_csr_device(ctx, din + o_q, nq, din + o_t, nt, (const int32_t*)(din + o_rp), (const int32_t*)(din + o_c), last_wins,
+                              want_best ? db : nullptr, want_best ? db + nq : nullptr, want_best ? db + 2 * (size_t)nq : nullptr,
+                              want_best ? db + 3 * (size_t)nq : nullptr, dist_out ? (int32_t*)(dout + p_d) : nullptr, st);
   if (rc != ORBX_OK) return rc;
-  ORBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (best_idx) ORBX_HIP(ctx, copy_sync(ctx, best_idx, dbi.p, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
-  if (best_dist) ORBX_HIP(ctx, copy_sync(ctx, best_dist, dbd.p, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
-  if (second_idx) ORBX_HIP(ctx, copy_sync(ctx, second_idx, dsi.p, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
-  if (second_dist) ORBX_HIP(ctx, copy_sync(ctx, second_dist, dsd.p, sizeof(int32_t) * nq, hipMemcpyDeviceToHost));
-  if (dist_out && nnz) ORBX_HIP(ctx, copy_sync(ctx, dist_out, ddo.p, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost));
+  if (out.size) ORBX_HIP(ctx, hipMemcpyAsync(hout, dout, out.size, hipMemcpyDeviceToHost, st));
+  ORBX_HIP(ctx, hipStreamSynchronize(st));
+  const int32_t* hb = (const int32_t*)(hout + p_b);
+  if (best_idx) std::memcpy(best_idx, hb, 4 * (size_t)nq);
+  if (best_dist) std::memcpy(best_dist, hb + nq, 4 * (size_t)nq);
+  if (second_idx) std::memcpy(second_idx, hb + 2 * (size_t)nq, 4 * (size_t)nq);
+  if (second_dist) std::memcpy(second_dist, hb + 3 * (size_t)nq, 4 * (size_t)nq);
+  if (dist_out && nnz) std::memcpy(dist_out, hout + p_d, 4 * (size_t)nnz);
   return ORBX_OK;
 }
 

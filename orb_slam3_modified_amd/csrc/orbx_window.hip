@@ -11,7 +11,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -39,8 +42,13 @@ struct WinArgs {
   WinQueryOut* out;
   int2* pool;          // {candidate index, distance}, one contiguous segment per query
   int pool_cap;
-  int32_t* total;      // candidates of all queries (also when the pool is too small: the host then reports the capacity needed)
+  int32_t* total;      // [0] candidates of all queries (also when the pool is too small: the host then reports the capacity needed),
+                       // [1] queries finished; both zeroed by the input upload
+  int32_t* out_hdr;    // the wave that finishes last copies the total here, so that header + records + pool leave in ONE copy
+  int compact;         // 1: only {start, count} per query are written (the caller did not ask for best / second)
 };
+
+struct WinQueryShort { int32_t start, count; };
 
 struct WDesc { unsigned long long w[4]; };
 __device__ __forceinline__ WDesc wload(const uint8_t* p) {
@@ -152,14 +160,23 @@ __global__ __launch_bounds__(256) void k_window(const WinArgs a) {
     k2 = hi < s2 ? hi : s2;
   }
   if (lane == 0) {
-    WinQueryOut o;
-    o.start = base; o.count = LISTS ? count : pos;
-    o.best_idx = k1 == kNoWinKey ? -1 : (int)(k1 & 0xffffffu);
-    o.best_dist = k1 == kNoWinKey ? 256 : (int)(k1 >> 48);
-    o.second_idx = k2 == kNoWinKey ? -1 : (int)(k2 & 0xffffffu);
-    o.second_dist = k2 == kNoWinKey ? 256 : (int)(k2 >> 48);
-    o.pad0 = o.pad1 = 0;
-    a.out[q] = o;
+    if (a.compact) {
+      WinQueryShort o;
+      o.start = base; o.count = LISTS ? count : pos;
+      ((WinQueryShort*)a.out)[q] = o;
+    } else {
+      WinQueryOut o;
+      o.start = base; o.count = LISTS ? count : pos;
+      o.best_idx = k1 == kNoWinKey ? -1 : (int)(k1 & 0xffffffu);
+      o.best_dist = k1 == kNoWinKey ? 256 : (int)(k1 >> 48);
+      o.second_idx = k2 == kNoWinKey ? -1 : (int)(k2 & 0xffffffu);
+      o.second_dist = k2 == kNoWinKey ? 256 : (int)(k2 >> 48);
+      o.pad0 = o.pad1 = 0;
+      a.out[q] = o;
+    }
+    // the query that finishes last publishes the total (its own atomicAdd on the total is ordered before this counter)
+    __threadfence();
+    if (atomicAdd(a.total + 1, 1) == a.nq - 1) { __threadfence(); a.out_hdr[0] = atomicAdd(a.total, 0); }
   }
 }
 
@@ -206,6 +223,59 @@ __global__ __launch_bounds__(1024) void k_window_grid(const orbx_keypoint* __res
   }
 }
 
+// Frame::UndistortKeyPoints (src/Frame.cc:747-780): cv::undistortPoints(pts, pts, K, distCoef, Mat(), K) on the keypoint
+// coordinates, OpenCV 4.x's iteration in double with separately rounded operations (5 iterations, radial k1 k2 k3 +
+// tangential p1 p2; no tilt, R = I, P = K).  One thread per keypoint; everything but pt is copied.
+struct UndistortParams { double fx, fy, cx, cy, ifx, ify, k[14]; };
+__global__ __launch_bounds__(256) void k_undistort(const orbx_keypoint* __restrict__ in, const int32_t* __restrict__ counts, int cap, int n_fixed,
+                                                   UndistortParams P, orbx_keypoint* __restrict__ out) {
+  const int f = blockIdx.y;
+  const int n = counts ? counts[2 * f] : n_fixed;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  orbx_keypoint kp = in[(size_t)f * cap + i];
+  double x = (double)kp.x, y = (double)kp.y;
+  const double u = x, v = y;
+  x = __dmul_rn(__dsub_rn(x, P.cx), P.ifx);
+  y = __dmul_rn(__dsub_rn(y, P.cy), P.ify);
+  const double x0 = x, y0 = y;
+  const double* k = P.k;
+  for (int j = 0; j < 5; j++) {
+    const double r2 = __dadd_rn(__dmul_rn(x, x), __dmul_rn(y, y));
+    const double num = __dadd_rn(1.0, __dmul_rn(__dadd_rn(__dmul_rn(__dadd_rn(__dmul_rn(k[7], r2), k[6]), r2), k[5]), r2));
+    const double den = __dadd_rn(1.0, __dmul_rn(__dadd_rn(__dmul_rn(__dadd_rn(__dmul_rn(k[4], r2), k[1]), r2), k[0]), r2));
+    const double icdist = __ddiv_rn(num, den);
+    if (icdist < 0) { x = __dmul_rn(__dsub_rn(u, P.cx), P.ifx); y = __dmul_rn(__dsub_rn(v, P.cy), P.ify); break; }
+    // 2*k[2]*x*y + k[3]*(r2 + 2*x*x) + k[8]*r2 + k[9]*r2*r2, left to right
+    const double dX = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(__dmul_rn(__dmul_rn(2.0, k[2]), x), y),
+                                                    __dmul_rn(k[3], __dadd_rn(r2, __dmul_rn(__dmul_rn(2.0, x), x)))),
+                                          __dmul_rn(k[8], r2)),
+                                __dmul_rn(__dmul_rn(k[9], r2), r2));
+    // k[2]*(r2 + 2*y*y) + 2*k[3]*x*y + k[10]*r2 + k[11]*r2*r2
+    const double dY = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(k[2], __dadd_rn(r2, __dmul_rn(__dmul_rn(2.0, y), y))),
+                                                    __dmul_rn(__dmul_rn(__dmul_rn(2.0, k[3]), x), y)),
+                                          __dmul_rn(k[10], r2)),
+                                __dmul_rn(__dmul_rn(k[11], r2), r2));
+    x = __dmul_rn(__dsub_rn(x0, dX), icdist);
+    y = __dmul_rn(__dsub_rn(y0, dY), icdist);
+  }
+  // (xx, yy, ww) = K * (x, y, 1): RR[0][0]*x + RR[0][1]*y + RR[0][2] with RR[0][1] = 0 etc.
+  const double xx = __dadd_rn(__dadd_rn(__dmul_rn(P.fx, x), __dmul_rn(0.0, y)), P.cx);
+  const double yy = __dadd_rn(__dadd_rn(__dmul_rn(0.0, x), __dmul_rn(P.fy, y)), P.cy);
+  const double ww = __ddiv_rn(1.0, __dadd_rn(__dadd_rn(__dmul_rn(0.0, x), __dmul_rn(0.0, y)), 1.0));
+  kp.x = (float)__dmul_rn(xx, ww);
+  kp.y = (float)__dmul_rn(yy, ww);
+  out[(size_t)f * cap + i] = kp;
+}
+
+static bool undistort_params(float fx, float fy, float cx, float cy, const float* dist, int ndist, UndistortParams& P) {
+  std::memset(&P, 0, sizeof(P));
+  P.fx = fx; P.fy = fy; P.cx = cx; P.cy = cy;
+  P.ifx = 1. / P.fx; P.ify = 1. / P.fy;
+  for (int i = 0; i < ndist && i < 14; i++) P.k[i] = (double)dist[i];
+  return ndist > 0 && dist[0] != 0.0f;
+}
+
 // pinned host staging of the host-buffer entry points, grow-only
 hipError_t host_stage(orbx_ctx* ctx, size_t bytes, uint8_t** p) {
   if (bytes > ctx->h_call_bytes) {
@@ -222,12 +292,7 @@ hipError_t host_stage(orbx_ctx* ctx, size_t bytes, uint8_t** p) {
   return hipSuccess;
 }
 
-namespace {
-struct Layout {
-  size_t size = 0;
-  size_t add(size_t bytes) { const size_t o = size; size = (size + bytes + 255) & ~(size_t)255; return o; }
-};
-}  // namespace
+typedef BlobLayout Layout;
 
 // The whole call: pack -> one H2D -> [grid assignment] -> k_window -> one D2H (+ one more for a long tail) -> scatter.
 int window_call(orbx_ctx* ctx, const char* who, const orbx_keypoint* kps, const uint8_t* desc, int n, const orbx_grid* grid,
@@ -259,6 +324,9 @@ int window_call(orbx_ctx* ctx, const char* who, const orbx_keypoint* kps, const 
   if (inv_sigma2)
     for (int i = 0; i < n; i++)
       if (kps[i].octave < 0 || kps[i].octave >= nlevels) return set_err(ctx, ORBX_E_INVALID, std::string(who) + ": keypoint octave outside inv_level_sigma2");
+  static const bool trace = getenv("ORBX_TRACE_WINDOW") != nullptr;   // phase times of every call on stderr (diagnostics)
+  const auto tr0 = std::chrono::steady_clock::now();
+  auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count(); };
   ORBX_HIP(ctx, hipSetDevice(ctx->device));
   const int ngrid = have_grid ? grid->cell_start[kWinCells] : n;
   const int pool_cap = lists ? std::max(cand_cap, 0) : 0;
@@ -273,7 +341,9 @@ int window_call(orbx_ctx* ctx, const char* who, const orbx_keypoint* kps, const 
   const size_t o_cs = in.add(4 * (size_t)(kWinCells + 1)), o_ci = in.add(4 * (size_t)std::max(ngrid, 1));
   const size_t in_upload = have_grid ? in.size : o_cs;   // without a caller grid the two grid arrays are produced on the device
   Layout out;
-  const size_t p_hdr = out.add(16), p_q = out.add(sizeof(WinQueryOut) * (size_t)nq), p_pool = out.add(8 * (size_t)pool_cap);
+  const bool compact = !(best_idx || best_dist || second_idx || second_dist);
+  const size_t qrec = compact ? sizeof(WinQueryShort) : sizeof(WinQueryOut);
+  const size_t p_hdr = out.add(16), p_q = out.add(qrec * (size_t)nq), p_pool = out.add(8 * (size_t)pool_cap);
   uint8_t* h = nullptr;
   ORBX_HIP(ctx, host_stage(ctx, in.size + out.size, &h));
   uint8_t* hin = h;
@@ -292,6 +362,7 @@ int window_call(orbx_ctx* ctx, const char* who, const orbx_keypoint* kps, const 
     std::memcpy(hin + o_cs, grid->cell_start, 4 * (size_t)(kWinCells + 1));
     if (ngrid) std::memcpy(hin + o_ci, grid->cell_idx, 4 * (size_t)ngrid);
   }
+  const double us_pack = since(tr0);
   ctx->arena.rewind();
   hipError_t aerr = hipSuccess;
   uint8_t* din = (uint8_t*)ctx->arena.alloc(in.size, &aerr);
@@ -321,22 +392,27 @@ int window_call(orbx_ctx* ctx, const char* who, const orbx_keypoint* kps, const 
   a.kp_uright = kp_uright ? (const float*)(din + o_ur) : nullptr;
   a.inv_sigma2 = inv_sigma2 ? (const float*)(din + o_sig) : nullptr;
   a.out = (WinQueryOut*)(dout + p_q); a.pool = (int2*)(dout + p_pool); a.pool_cap = pool_cap; a.total = (int32_t*)(din + o_total);
+  a.out_hdr = (int32_t*)(dout + p_hdr); a.compact = compact ? 1 : 0;
   const dim3 gridDim((nq + 3) / 4), block(256);
   if (inv_sigma2) hipLaunchKernelGGL((k_window<false, true>), gridDim, block, 0, st, a);
   else if (lists) hipLaunchKernelGGL((k_window<true, false>), gridDim, block, 0, st, a);
   else hipLaunchKernelGGL((k_window<false, false>), gridDim, block, 0, st, a);
   ORBX_HIP(ctx, hipGetLastError());
   // ---- results: header + per-query records + the head of the pool in one copy; a long tail in a second one
-  ORBX_HIP(ctx, hipMemcpyAsync(dout + p_hdr, din + o_total, 16, hipMemcpyDeviceToDevice, st));
-  const int guess = std::min(pool_cap, std::max(ctx->win_guess, 8192));
+  const int guess = std::min(pool_cap, ctx->win_guess > 0 ? ctx->win_guess : 2048);
   ORBX_HIP(ctx, hipMemcpyAsync(hout, dout, p_pool + 8 * (size_t)guess, hipMemcpyDeviceToHost, st));
+  const double us_issue = since(tr0);
   ORBX_HIP(ctx, hipStreamSynchronize(st));
+  const double us_sync = since(tr0);
   const int total = *(const int32_t*)(hout + p_hdr);
   const WinQueryOut* qo = (const WinQueryOut*)(hout + p_q);
+  const WinQueryShort* qs = (const WinQueryShort*)(hout + p_q);
+  auto q_start = [&](int q) { return compact ? qs[q].start : qo[q].start; };
+  auto q_count = [&](int q) { return compact ? qs[q].count : qo[q].count; };
   if (lists) {
-    ctx->win_guess = total + total / 4 + 1024;
+    ctx->win_guess = total + total / 4 + 256;
     int acc = 0;
-    for (int q = 0; q < nq; q++) { acc += qo[q].count; row_ptr[q + 1] = acc; }
+    for (int q = 0; q < nq; q++) { acc += q_count(q); row_ptr[q + 1] = acc; }
     if (total > pool_cap) return set_err(ctx, ORBX_E_CAPACITY, std::string(who) + ": candidate buffer too small");
     if (total > guess) {
       ORBX_HIP(ctx, hipMemcpyAsync(hout + p_pool + 8 * (size_t)guess, dout + p_pool + 8 * (size_t)guess, 8 * (size_t)(total - guess),
@@ -345,23 +421,27 @@ int window_call(orbx_ctx* ctx, const char* who, const orbx_keypoint* kps, const 
     }
     const int2* pool = (const int2*)(hout + p_pool);
     for (int q = 0; q < nq; q++) {
-      const int2* seg = pool + qo[q].start;
+      const int2* seg = pool + q_start(q);
       const int o = row_ptr[q];
-      for (int c = 0; c < qo[q].count; c++) {
+      const int cnt = q_count(q);
+      for (int c = 0; c < cnt; c++) {
         if (cand) cand[o + c] = seg[c].x;
         if (dist) dist[o + c] = seg[c].y;
       }
     }
   } else if (row_ptr) {
     int acc = 0;
-    for (int q = 0; q < nq; q++) { acc += qo[q].count; row_ptr[q + 1] = acc; }
+    for (int q = 0; q < nq; q++) { acc += q_count(q); row_ptr[q + 1] = acc; }
   }
-  for (int q = 0; q < nq; q++) {
+  if (!compact) for (int q = 0; q < nq; q++) {
     if (best_idx) best_idx[q] = qo[q].best_idx;
     if (best_dist) best_dist[q] = qo[q].best_dist;
     if (second_idx) second_idx[q] = qo[q].second_idx;
     if (second_dist) second_dist[q] = qo[q].second_dist;
   }
+  if (trace)
+    std::fprintf(stderr, "[orbx window] %s n=%d nq=%d total=%d in=%zu B out=%zu B: pack %.1f us, issue %.1f, wait %.1f, scatter %.1f\n", who, n, nq, total,
+                 in_upload, p_pool + 8 * (size_t)guess, us_pack, us_issue - us_pack, us_sync - us_issue, since(tr0) - us_sync);
   return lists ? total : (row_ptr ? row_ptr[nq] : 0);
 }
 
@@ -382,6 +462,52 @@ int orbx_window_search_grid(orbx_ctx* ctx, const orbx_keypoint* kps, const uint8
     return ctx ? set_err(ctx, ORBX_E_INVALID, "orbx_window_search_grid: bad arguments") : ORBX_E_INVALID;
   return window_call(ctx, "orbx_window_search_grid", kps, desc, n, grid, kp_skip, kp_uright, nullptr, 0, qx, qy, qr, qmin_level, qmax_level, q_xr,
                      q_desc, nq, cand || dist, row_ptr, cand, dist, cand_cap, best_idx, best_dist, second_idx, second_dist);
+}
+
+int orbx_undistort_keypoints_device(orbx_ctx* ctx, const orbx_keypoint* d_kps, const int32_t* d_counts, int nframes, int capacity, float fx,
+                                    float fy, float cx, float cy, const float* dist_coef, int n_coef, orbx_keypoint* d_kps_un, void* stream) {
+  if (!ctx || !d_kps || !d_counts || !d_kps_un || nframes <= 0 || capacity <= 0 || !dist_coef || n_coef < 4 || !(fx != 0.f) || !(fy != 0.f))
+    return ctx ? set_err(ctx, ORBX_E_INVALID, "orbx_undistort_keypoints_device: bad arguments") : ORBX_E_INVALID;
+  ORBX_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  UndistortParams P;
+  if (!undistort_params(fx, fy, cx, cy, dist_coef, n_coef, P)) {   // mDistCoef[0] == 0: mvKeysUn = mvKeys (src/Frame.cc:749-753)
+    ORBX_HIP(ctx, hipMemcpyAsync(d_kps_un, d_kps, sizeof(orbx_keypoint) * (size_t)nframes * capacity, hipMemcpyDeviceToDevice, st));
+    return ORBX_OK;
+  }
+  hipLaunchKernelGGL(k_undistort, dim3((capacity + 255) / 256, nframes), dim3(256), 0, st, d_kps, d_counts, capacity, 0, P, d_kps_un);
+  ORBX_HIP(ctx, hipGetLastError());
+  return ORBX_OK;
+}
+
+int orbx_undistort_keypoints(orbx_ctx* ctx, const orbx_keypoint* kps, int n, float fx, float fy, float cx, float cy, const float* dist_coef,
+                             int n_coef, orbx_keypoint* kps_un) {
+  if (!ctx || n < 0 || (n > 0 && (!kps || !kps_un)) || !dist_coef || n_coef < 4 || !(fx != 0.f) || !(fy != 0.f))
+    return ctx ? set_err(ctx, ORBX_E_INVALID, "orbx_undistort_keypoints: bad arguments") : ORBX_E_INVALID;
+  if (n == 0) return ORBX_OK;
+  UndistortParams P;
+  if (!undistort_params(fx, fy, cx, cy, dist_coef, n_coef, P)) { std::memcpy(kps_un, kps, sizeof(orbx_keypoint) * (size_t)n); return ORBX_OK; }
+  ORBX_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t bytes = sizeof(orbx_keypoint) * (size_t)n;
+  uint8_t* h = nullptr;
+  ORBX_HIP(ctx, host_stage(ctx, 2 * bytes + 512, &h));
+  std::memcpy(h, kps, bytes);
+  ctx->arena.rewind();
+  hipError_t aerr = hipSuccess;
+  uint8_t* din = (uint8_t*)ctx->arena.alloc(bytes, &aerr);
+  ORBX_HIP(ctx, aerr);
+  uint8_t* dout = (uint8_t*)ctx->arena.alloc(bytes, &aerr);
+  ORBX_HIP(ctx, aerr);
+  hipStream_t st = ctx->stream;
+  ORBX_HIP(ctx, hipMemcpyAsync(din, h, bytes, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256, 1), dim3(256), 0, st, (const orbx_keypoint*)din, (const int32_t*)nullptr, n, n, P,
+                     (orbx_keypoint*)dout);
+  ORBX_HIP(ctx, hipGetLastError());
+  uint8_t* hout = h + ((bytes + 255) & ~(size_t)255);
+  ORBX_HIP(ctx, hipMemcpyAsync(hout, dout, bytes, hipMemcpyDeviceToHost, st));
+  ORBX_HIP(ctx, hipStreamSynchronize(st));
+  std::memcpy(kps_un, hout, bytes);
+  return ORBX_OK;
 }
 
 int orbx_window_nearest(orbx_ctx* ctx, const orbx_keypoint* kps, const uint8_t* desc, int n, const orbx_grid* grid,

@@ -94,6 +94,17 @@ class ORBextractor:
         self._last_frames = 1
         return mono.value, kps[:n.value].copy(), desc[:n.value].copy()
 
+    def extract_resized(self, image: np.ndarray, new_size: Tuple[int, int], vLappingArea: Sequence[int] = (0, 0)):
+        """cv::resize(im, ., newImSize) (src/System.cc:441-446) fused behind the upload, then operator().  new_size = (rows, cols)."""
+        img = np.ascontiguousarray(image)
+        assert img.dtype == np.uint8 and img.ndim == 2
+        kps = np.zeros(self.capacity, KP_DTYPE)
+        desc = np.zeros((self.capacity, 32), np.uint8)
+        n, mono = C.c_int(0), C.c_int(0)
+        check(self._L.orbx_extract_resized(self._ctx, ptr(img), img.shape[0], img.shape[1], img.strides[0], int(new_size[0]), int(new_size[1]),
+                                           int(vLappingArea[0]), int(vLappingArea[1]), ptr(kps), ptr(desc), C.byref(n), C.byref(mono)), self._ctx)
+        return mono.value, kps[:n.value].copy(), desc[:n.value].copy()
+
     def extract_batch(self, images: np.ndarray, vLappingArea: Sequence[int] = (0, 0)
                       ) -> List[Tuple[int, np.ndarray, np.ndarray]]:
         """Batch replay over host frames [B, H, W] (frames are independent: SURVEY.md §8(e))."""
@@ -170,6 +181,19 @@ class ORBextractor:
     def debug_calib_copy(self, d_src: int, d_dst: int, nbytes: int, width: int, stream: int = 0):
         """Known-traffic device copy (counter calibration, tools/pmc_traffic.py)."""
         check(self._L.orbx_debug_calib_copy(self._ctx, ptr(d_src), ptr(d_dst), nbytes, width, ptr(stream)), self._ctx)
+
+    def UndistortKeyPoints(self, kps: np.ndarray, fx: float, fy: float, cx: float, cy: float, dist_coef) -> np.ndarray:
+        """Frame::UndistortKeyPoints (src/Frame.cc:747-780) on the GPU: mvKeys -> mvKeysUn."""
+        k = np.ascontiguousarray(kps)
+        dc = np.ascontiguousarray(dist_coef, np.float32)
+        out = np.zeros(max(len(k), 1), KP_DTYPE)
+        check(self._L.orbx_undistort_keypoints(self._ctx, ptr(k), len(k), float(fx), float(fy), float(cx), float(cy), ptr(dc), len(dc), ptr(out)), self._ctx)
+        return out[:len(k)]
+
+    def undistort_keypoints_device(self, d_kps: int, d_counts: int, nframes: int, fx, fy, cx, cy, dist_coef, d_kps_un: int, stream: int = 0) -> None:
+        dc = np.ascontiguousarray(dist_coef, np.float32)
+        check(self._L.orbx_undistort_keypoints_device(self._ctx, ptr(d_kps), ptr(d_counts), int(nframes), self.capacity, float(fx), float(fy),
+                                                      float(cx), float(cy), ptr(dc), len(dc), ptr(d_kps_un), ptr(stream)), self._ctx)
 
     def reserve(self, rows: int, cols: int, nframes: int) -> None:
         """Allocate the device buffers for batches of this shape now (orbx_reserve) rather than in the first call."""

@@ -8,7 +8,8 @@
 // src/LoopClosing.cc:662,755,777,964,2133,2178; src/CloudPoint.cc:160) and writes every observable result as text.
 // tests/test_matcher_world.py compares the two outputs line by line.
 //
-//   matcher_world <world.bin> <out.txt> [only-scenarios-containing-this-substring]
+//   matcher_world <world.bin> <out.txt> [only-scenarios-containing-this-substring] [--time <timings.json>]
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -307,13 +308,28 @@ void prebind(Scene& s, Frame& F, int every, int salt) {   // keypoints that alre
 
 typedef std::function<void(Out&)> Fn;
 
+// --time: wall time of the matcher calls alone (steady_clock around each call, like the reference's callers would see it)
+struct CallTimer { double ms = 0; int calls = 0; } g_timer;
+template <class F>
+auto timed(F&& f) -> decltype(f()) {
+  const auto t0 = std::chrono::steady_clock::now();
+  auto r = f();
+  g_timer.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  g_timer.calls++;
+  return r;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
   if (argc < 3) { std::fprintf(stderr, "usage: matcher_world <world.bin> <out.txt> [filter]\n"); return 2; }
   World w;
   if (!load_world(argv[1], w) || w.views.size() < 4) { std::fprintf(stderr, "cannot read %s\n", argv[1]); return 2; }
-  const std::string filter = argc >= 4 ? argv[3] : "";
+  std::string filter, time_path;
+  for (int a = 3; a < argc; a++) {
+    if (std::string(argv[a]) == "--time" && a + 1 < argc) time_path = argv[++a];
+    else filter = argv[a];
+  }
   Out o{std::fopen(argv[2], "w")};
   if (!o.f) return 2;
   std::vector<std::pair<std::string, Fn> > scenarios;
@@ -330,8 +346,8 @@ int main(int argc, char** argv) {
       for (size_t i = 0; i < prev.size(); i++) prev[i] = F1.mvKeysUn[i].pt;
       std::vector<int> m12;
       int ret;
-      if (variant) { ORBmatcher matcher(0.95, false); ret = matcher.SearchForInitialization(F1, F2, prev, m12, 200); }
-      else { ORBmatcher matcher(0.9, true); ret = matcher.SearchForInitialization(F1, F2, prev, m12, 100); }
+      if (variant) { ORBmatcher matcher(0.95, false); ret = timed([&] { return matcher.SearchForInitialization(F1, F2, prev, m12, 200); }); }
+      else { ORBmatcher matcher(0.9, true); ret = timed([&] { return matcher.SearchForInitialization(F1, F2, prev, m12, 100); }); }
       o.line(variant ? "init_cloudpoint" : "init_tracking", ret);
       o.ints("vnMatches12", std::vector<long>(m12.begin(), m12.end()));
       std::vector<long> pv;
@@ -353,8 +369,10 @@ int main(int argc, char** argv) {
       std::vector<MapPoint*> vp;
       for (MapPoint& m : s.mps) vp.push_back(&m);
       ORBmatcher matcher(0.8);
-      const int ret = variant == 1 ? matcher.SearchByProjection(F, vp, 3, true, 5.0f) : variant == 0 ? matcher.SearchByProjection(F, vp, 1, false, 50.0f)
-                                                                                                     : matcher.SearchByProjection(F, vp, 3, false, 50.0f);
+      const int ret = timed([&] {
+        return variant == 1 ? matcher.SearchByProjection(F, vp, 3, true, 5.0f)
+               : variant == 0 ? matcher.SearchByProjection(F, vp, 1, false, 50.0f) : matcher.SearchByProjection(F, vp, 3, false, 50.0f);
+      });
       o.line(names[variant], ret);
       o.ints("mvpMapPoints", ids_of(F.mvpMapPoints));
     });
@@ -385,12 +403,12 @@ int main(int argc, char** argv) {
       ORBmatcher matcher(0.9, variant != 5);
       const float th = stereo ? 7.f : 15.f;
       const bool bMono = !stereo && !rig;
-      const int ret = matcher.SearchByProjection(Cur, Last, th, bMono);
+      const int ret = timed([&] { return matcher.SearchByProjection(Cur, Last, th, bMono); });
       o.line(names[variant], ret);
       o.ints("mvpMapPoints", ids_of(Cur.mvpMapPoints));
       // the retry with a wider window (src/Tracking.cc:2893-2897)
       std::fill(Cur.mvpMapPoints.begin(), Cur.mvpMapPoints.end(), static_cast<MapPoint*>(NULL));
-      const int ret2 = matcher.SearchByProjection(Cur, Last, 2 * th, bMono);
+      const int ret2 = timed([&] { return matcher.SearchByProjection(Cur, Last, 2 * th, bMono); });
       o.line(std::string(names[variant]) + "_wide", ret2);
       o.ints("mvpMapPoints", ids_of(Cur.mvpMapPoints));
     });
@@ -414,7 +432,7 @@ int main(int argc, char** argv) {
       }
       std::vector<MapPoint*> matches;
       ORBmatcher matcher(variant == 2 ? 0.75 : 0.7, variant != 2);
-      const int ret = matcher.SearchByBoW(K, F, matches);
+      const int ret = timed([&] { return matcher.SearchByBoW(K, F, matches); });
       o.line(names[variant], ret);
       o.ints("vpMapPointMatches", ids_of(matches));
     });
@@ -440,7 +458,7 @@ int main(int argc, char** argv) {
       }
       std::vector<MapPoint*> m12;
       ORBmatcher matcherBoW(0.9, true);
-      const int ret = matcherBoW.SearchByBoW(K1, K2, m12);
+      const int ret = timed([&] { return matcherBoW.SearchByBoW(K1, K2, m12); });
       o.line(names[variant], ret);
       o.ints("vpMatches12", ids_of(m12));
     });
@@ -461,7 +479,7 @@ int main(int argc, char** argv) {
       for (int i = 0; i < K2->N; i++) if (H(i, 71) % 7 == 0) K2->mvpMapPoints[i] = &s.mps[i % s.mps.size()];
       std::vector<std::pair<size_t, size_t> > pairs;
       ORBmatcher matcher(0.6f, variant == 1);
-      const int ret = matcher.SearchForTriangulation(K1, K2, pairs, variant == 1, variant == 2);
+      const int ret = timed([&] { return matcher.SearchForTriangulation(K1, K2, pairs, variant == 1, variant == 2); });
       o.line(names[variant], ret);
       std::vector<long> v;
       for (auto& p : pairs) { v.push_back((long)p.first); v.push_back((long)p.second); }
@@ -498,9 +516,9 @@ int main(int argc, char** argv) {
         if (H(i, 85) % 37 == 0) vp.push_back(&s.mpsB[i % s.mpsB.size()]);                 // a point of the keyframe itself
       }
       ORBmatcher matcher;
-      const int ret = matcher.Fuse(K, vp);
+      const int ret = timed([&] { return matcher.Fuse(K, vp); });
       o.line(names[variant], ret);
-      if (K->NLeft != -1) { const int ret2 = matcher.Fuse(K, vp, 3.0, true); o.line(std::string(names[variant]) + "_right", ret2); }
+      if (K->NLeft != -1) { const int ret2 = timed([&] { return matcher.Fuse(K, vp, 3.0, true); }); o.line(std::string(names[variant]) + "_right", ret2); }
       o.ints("kf_points", ids_of(K->mvpMapPoints));
       o.ints("kf0_points", ids_of(K0->mvpMapPoints));
       dump_points(o, "mps", s.mps);
@@ -525,7 +543,7 @@ int main(int argc, char** argv) {
       Sophus::Sim3f Scw(1.02f, T.rotationMatrix(), T.translation() * 1.02f);
       std::vector<MapPoint*> vpReplace(vp.size(), static_cast<MapPoint*>(NULL));
       ORBmatcher matcher(0.8);
-      const int ret = matcher.Fuse(K, Scw, vp, 4, vpReplace);
+      const int ret = timed([&] { return matcher.Fuse(K, Scw, vp, 4, vpReplace); });
       o.line(names[variant], ret);
       o.ints("vpReplacePoint", ids_of(vpReplace));
       o.ints("kf_points", ids_of(K->mvpMapPoints));
@@ -551,7 +569,7 @@ int main(int argc, char** argv) {
       const Sophus::SE3f T12 = K1->GetPose() * K2->GetPoseInverse();
       const Sophus::Sim3f S12(1.0f, T12.rotationMatrix(), T12.translation());
       ORBmatcher matcher(0.75, true);
-      const int ret = matcher.SearchBySim3(K1, K2, m12, S12, 7.5f);
+      const int ret = timed([&] { return matcher.SearchBySim3(K1, K2, m12, S12, 7.5f); });
       o.line(names[variant], ret);
       o.ints("vpMatches12", ids_of(m12));
     });
@@ -581,9 +599,9 @@ int main(int argc, char** argv) {
       Sophus::Sim3f Scw(sc, T.rotationMatrix(), T.translation() * sc);
       ORBmatcher matcher(0.75, true);
       int ret;
-      if (variant == 0) ret = matcher.SearchByProjection(K, Scw, vp, vpKFs, vpMatched, vpMatchedKF, 8, 1.5);
-      else if (variant == 2) ret = matcher.SearchByProjection(K, Scw, vp, vpMatched, 3, 1.5);
-      else ret = matcher.SearchByProjection(K, Scw, vp, vpMatched, 5, 1.0);
+      if (variant == 0) ret = timed([&] { return matcher.SearchByProjection(K, Scw, vp, vpKFs, vpMatched, vpMatchedKF, 8, 1.5); });
+      else if (variant == 2) ret = timed([&] { return matcher.SearchByProjection(K, Scw, vp, vpMatched, 3, 1.5); });
+      else ret = timed([&] { return matcher.SearchByProjection(K, Scw, vp, vpMatched, 5, 1.0); });
       o.line(names[variant], ret);
       o.ints("vpMatched", ids_of(vpMatched));
       if (variant == 0) { std::vector<long> v; for (KeyFrame* k : vpMatchedKF) v.push_back(k ? (long)k->mnId : -1); o.ints("vpMatchedKF", v); }
@@ -605,12 +623,12 @@ int main(int argc, char** argv) {
       std::set<MapPoint*> sFound;
       for (int i = 0; i < (int)s.mps.size(); i++) if (H(i, 112) % 6 == 0) sFound.insert(&s.mps[i]);
       ORBmatcher matcher2(0.9, variant == 0);
-      const int ret = matcher2.SearchByProjection(Cur, K, sFound, 10, 100);
+      const int ret = timed([&] { return matcher2.SearchByProjection(Cur, K, sFound, 10, 100); });
       o.line(names[variant], ret);
       o.ints("mvpMapPoints", ids_of(Cur.mvpMapPoints));
       sFound.clear();
       for (int ip = 0; ip < Cur.N; ip++) if (Cur.mvpMapPoints[ip]) sFound.insert(Cur.mvpMapPoints[ip]);
-      const int ret2 = matcher2.SearchByProjection(Cur, K, sFound, 3, 64);
+      const int ret2 = timed([&] { return matcher2.SearchByProjection(Cur, K, sFound, 3, 64); });
       o.line(std::string(names[variant]) + "_narrow", ret2);
       o.ints("mvpMapPoints", ids_of(Cur.mvpMapPoints));
     });
@@ -626,16 +644,30 @@ int main(int argc, char** argv) {
   });
 
   int rc = 0;
+  FILE* tf = time_path.empty() ? nullptr : std::fopen(time_path.c_str(), "w");
+  if (tf) std::fprintf(tf, "{");
+  bool first_t = true;
   for (auto& sc : scenarios) {
     if (!filter.empty() && sc.first.find(filter) == std::string::npos) continue;
     try {
       sc.second(o);
+      if (tf) {   // the scenario again, timed: 3 warm-up runs, 15 measured (results go to a scratch stream)
+        Out scratch{std::fopen("/dev/null", "w")};
+        for (int rep = 0; rep < 3; rep++) sc.second(scratch);
+        g_timer = CallTimer();
+        for (int rep = 0; rep < 15; rep++) sc.second(scratch);
+        std::fclose(scratch.f);
+        std::fprintf(tf, "%s\n \"%s\": {\"ms_per_call\": %.5f, \"calls_per_run\": %d}", first_t ? "" : ",", sc.first.c_str(),
+                     g_timer.calls ? g_timer.ms / g_timer.calls : 0.0, g_timer.calls / 15);
+        first_t = false;
+      }
     } catch (const std::exception& e) {
       std::fprintf(o.f, "%s EXCEPTION %s\n", sc.first.c_str(), e.what());
       std::fprintf(stderr, "%s: %s\n", sc.first.c_str(), e.what());
       rc = 3;
     }
   }
+  if (tf) { std::fprintf(tf, "\n}\n"); std::fclose(tf); }
   std::fclose(o.f);
   return rc;
 }

@@ -103,11 +103,16 @@ def test_kfdb_long_queries_are_served_from_hbm():
     db, odb = KeyFrameDatabase(ORBextractor(1000, 1.2, 8, 20, 7)), po.OracleKeyFrameDatabase()
     import gc
     gc.collect()
+    def long_bow(n):
+        ids = np.unique(rng.integers(0, 60000, n + n // 3))[:n].astype(np.uint32)   # dense enough to share thousands of words
+        vals = rng.uniform(0.1, 8.0, len(ids))
+        return ids, (vals / vals.sum()).astype(np.float64)
+
     for kid in range(40):
-        b = _bow(rng, kid % 5, nwords=200000, n=int(rng.integers(9000, 14000)))
+        b = long_bow(int(rng.integers(9000, 14000)))
         db.add(kid, b); odb.add(kid, b)
     for _ in range(4):
-        q = _bow(rng, int(rng.integers(0, 5)), nwords=200000, n=int(rng.integers(8500, 15000)))
+        q = long_bow(int(rng.integers(8500, 15000)))
         assert len(q[0]) > 8192
         a, b = db.query(q, [3, 17], 0), odb.query(q, [3, 17], 0)
         _same(a, b)

@@ -16,7 +16,7 @@ PKG = os.path.join(ROOT, "orb_slam3_modified_amd")
 REF_EXE = os.path.join(ROOT, "oracle", "_ref", "ref_matcher_world")
 ADAPTER_SRC = os.path.join(PKG, "csrc", "ref_adapter", "ORBmatcher.cc")
 INCLUDES = ["-I", os.path.join(ROOT, "include"), "-I", os.path.join(SUP, "ref_world"), "-I", os.path.join(ROOT, "oracle", "ref_shims")]
-CXXFLAGS = ["-O1", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-pthread"]
+CXXFLAGS = ["-O2", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-pthread"]
 
 
 def write_world(path: str, rows: int = 480, cols: int = 752, nfeatures: int = 1000, steps=(0, 2, 4, 6), seed: int = 20260925,
@@ -87,8 +87,8 @@ def build_adapter_world(backend: str) -> str:
     return out
 
 
-def run_world(exe: str, world: str, out: str, only: str = "") -> str:
-    r = subprocess.run([exe, world, out] + ([only] if only else []), capture_output=True, text=True)
+def run_world(exe: str, world: str, out: str, only: str = "", time_json: str = "") -> str:
+    r = subprocess.run([exe, world, out] + ([only] if only else []) + (["--time", time_json] if time_json else []), capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"{exe} failed ({r.returncode}): {r.stdout}{r.stderr}")
     return open(out).read()
