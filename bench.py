@@ -250,10 +250,11 @@ def main():
     from orb_slam3_modified_amd.replay import ReplayEngine
 
     B, H, W = args.batch, args.rows, args.cols
-    # S-8cam: camera `rank` = S-EuRoC-640 stream with seed + 1000*rank: `batches` x B consecutive frames of one stream, every
-    # frame distinct (4 x 256 x 300 KB = 315 MB of level-0 input, more than the 256 MB Infinity Cache)
+    # S-8cam: camera `rank` = S-EuRoC-640 streams with seed + 1000*rank (+ 101*k for batch k): `batches` x B frames, every frame
+    # distinct (4 x 256 x 300 KB = 315 MB of level-0 input, more than the 256 MB Infinity Cache).  One generator run per batch:
+    # a single longer stream would wander into the scene's flat quarter and lose the configuration's ~1000 features per frame
     nsets = max(1, args.batches)
-    host_frames = synth.make_stream(nsets * B, H, W, synth.DEFAULT_SEED + 1000 * rank)
+    host_frames = np.concatenate([synth.make_stream(B, H, W, synth.DEFAULT_SEED + 1000 * rank + 101 * k) for k in range(nsets)])
     frame_sets = [torch.from_numpy(host_frames[k * B:(k + 1) * B]).to(dev) for k in range(nsets)]
     ex = ORBextractor(args.nfeatures, 1.2, 8, 20, 7, device_id=local_rank)
     eng = ReplayEngine(ex, frame_sets, lapping=(0, 1000), gather=(world > 1 and not args.no_gather), lanes=args.lanes)
@@ -271,17 +272,26 @@ def main():
     dt = float(tmax.item())
 
     counts = eng.counts(last).cpu().numpy()
-    feats_step = torch.tensor([int(counts[:, 0].sum())], dtype=torch.int64, device=dev)
+    # ---- the measured path must be the right path: frames of the last timed step against the CPU oracle (every rank its own)
+    last_set = (eng.step_idx - 1) % nsets
+    last_block = eng.blocks[last].clone()
+    # keypoints of every batch of the rotation (one untimed step each): timed step s processed batch s mod nsets
+    per_set = [0] * nsets
+    for _ in range(nsets):
+        k = eng.step_idx % nsets
+        i = eng.step()
+        eng.drain()
+        torch.cuda.synchronize()
+        per_set[k] = int(eng.counts(i)[:, 0].sum().item())
+    eng.blocks[last].copy_(last_block)
+    first_timed = args.warmup
+    total_feats = torch.tensor([sum(per_set[(first_timed + s) % nsets] for s in range(args.steps))], dtype=torch.int64, device=dev)
     if world > 1:
-        dist.all_reduce(feats_step, op=dist.ReduceOp.SUM)
-    # every step processes a different batch of the rotation; the count of the last step stands for all (+-0.5 %)
-    feats_step = int(feats_step.item())
-    total_feats = feats_step * args.steps
+        dist.all_reduce(total_feats, op=dist.ReduceOp.SUM)
+    total_feats = int(total_feats.item())
     total_frames = B * world * args.steps
     value = total_feats / (dt * 1e3)
 
-    # ---- the measured path must be the right path: frames of the last timed step against the CPU oracle (every rank its own)
-    last_set = (eng.step_idx - 1) % nsets
     lane_edges = sorted({0, B - 1} | {f for (f0, f1) in eng.lane_ranges for f in (f0, f1 - 1)} | {B // 3})
     verified = 0 if args.no_verify else verify_block(eng, last, host_frames[last_set * B:(last_set + 1) * B], lane_edges, args.nfeatures, (0, 1000))
     vt = torch.tensor([verified], dtype=torch.int64, device=dev)

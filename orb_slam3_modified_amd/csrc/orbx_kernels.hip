@@ -215,6 +215,25 @@ __device__ __forceinline__ uint32_t fast_pretest_pk(uint32_t c, uint32_t p0, uin
   return as_u32(__builtin_elementwise_sub_sat(lo, maxmin)) | as_u32(__builtin_elementwise_sub_sat(minmax, hi));
 }
 
+// The same test with every pixel in the LOW byte of its 16-bit lane (high byte zero): the even pixels of a dword are isolated with
+// one v_and_b32 (a full-rate instruction on gfx950, profiles/valu_ceiling_r2.txt) instead of the half-rate shift that would move
+// them into the high byte; v + t cannot overflow 16 bits, so only v - t saturates.
+__device__ __forceinline__ uint32_t fast_pretest_pk_lo(uint32_t c, uint32_t p0, uint32_t p8, uint32_t p4, uint32_t p12, uint32_t p2,
+                                                       uint32_t p10, uint32_t p6, uint32_t p14, uint32_t t_lo) {
+  const u16x2_t a0 = as_u16x2(p0), a8 = as_u16x2(p8), a4 = as_u16x2(p4), a12 = as_u16x2(p12);
+  const u16x2_t a2 = as_u16x2(p2), a10 = as_u16x2(p10), a6 = as_u16x2(p6), a14 = as_u16x2(p14);
+  const u16x2_t maxmin = __builtin_elementwise_max(
+      __builtin_elementwise_max(__builtin_elementwise_min(a0, a8), __builtin_elementwise_min(a4, a12)),
+      __builtin_elementwise_max(__builtin_elementwise_min(a2, a10), __builtin_elementwise_min(a6, a14)));
+  const u16x2_t minmax = __builtin_elementwise_min(
+      __builtin_elementwise_min(__builtin_elementwise_max(a0, a8), __builtin_elementwise_max(a4, a12)),
+      __builtin_elementwise_min(__builtin_elementwise_max(a2, a10), __builtin_elementwise_max(a6, a14)));
+  const u16x2_t T = as_u16x2(t_lo);
+  const u16x2_t lo = __builtin_elementwise_sub_sat(as_u16x2(c), T);   // max(v - t, 0)
+  const u16x2_t hi = as_u16x2(c) + T;                                  // v + t <= 510
+  return as_u32(__builtin_elementwise_sub_sat(lo, maxmin)) | as_u32(__builtin_elementwise_sub_sat(minmax, hi));
+}
+
 template <int T, int PITCH, bool PK = false>
 __global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
                                                   const uint8_t* __restrict__ imgs, long long img_row_stride,
@@ -294,10 +313,12 @@ __global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__
       const int c0 = 4 * k - xo - 3;                               // detection-domain x of pixel 0
       bool ps[4];
       if constexpr (PK) {
-        // pixels 1 and 3 sit in the high bytes of the raw dwords' 16-bit lanes, pixels 0 and 2 after a shift by one byte
-        const uint32_t t_hi = (uint32_t)min_th * 0x01000100u;
+        // pixels 1 and 3 sit in the high bytes of the raw dwords' 16-bit lanes (the low bytes are don't-cares there); pixels 0
+        // and 2 are the low bytes, isolated by a mask
+        const uint32_t t_hi = (uint32_t)min_th * 0x01000100u, t_lo = (uint32_t)min_th * 0x00010001u;
+        constexpr uint32_t LO = 0x00ff00ffu;
         uint32_t rO = fast_pretest_pk(dC, dD, dU, Q4, Q12, Q2, Q10, Q6, Q14, t_hi);
-        uint32_t rE = fast_pretest_pk(dC << 8, dD << 8, dU << 8, Q4 << 8, Q12 << 8, Q2 << 8, Q10 << 8, Q6 << 8, Q14 << 8, t_hi);
+        uint32_t rE = fast_pretest_pk_lo(dC & LO, dD & LO, dU & LO, Q4 & LO, Q12 & LO, Q2 & LO, Q10 & LO, Q6 & LO, Q14 & LO, t_lo);
         // validity (x inside the detection domain, lane active) on the same lanes: (unsigned)(c0 + j) < dw, c0 >= -3
         const uint32_t c0a = act ? (uint32_t)c0 : 0x4000u;
         const u16x2_t C0 = as_u16x2(__builtin_amdgcn_perm(c0a, c0a, 0x01000100u));
