@@ -4,7 +4,7 @@
 TAG=${1:-r1x}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu_$TAG.log 2>&1; tail -2 gpurun_out/pytest_gpu_$TAG.log
+timeout 900 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu_$TAG.log 2>&1; grep -E "passed|failed" gpurun_out/pytest_gpu_$TAG.log | tail -1
 # HBM traffic (separate FETCH_SIZE / WRITE_SIZE passes) and issue-side counters, full-batch launches
 timeout 600 python tools/pmc_traffic.py > /dev/null 2>&1 && cp gpurun_out/pmc_traffic.json profiles/pmc_traffic.json
 timeout 900 python tools/pmc_sq.py "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS" \
@@ -20,4 +20,6 @@ DB=$(ls gpurun_out/prof_$TAG/*/${TAG}_results.db gpurun_out/prof_$TAG/${TAG}_res
 head -12 gpurun_out/${TAG}_kernel_stats.md
 rm -rf gpurun_out/prof_$TAG/*/*.db gpurun_out/prof_$TAG/*.db   # keep the merge-back small
 timeout 300 python tools/bench_aux.py > /dev/null 2>&1; ls -la gpurun_out/bench_aux.json
+timeout 300 python tools/matcher_times.py > gpurun_out/matcher_times_$TAG.md 2>&1; tail -2 gpurun_out/matcher_times_$TAG.md
+hipcc --offload-arch=gfx950 -O3 tools/valu_ceiling.hip -o /tmp/valu_ceiling && /tmp/valu_ceiling > gpurun_out/valu_ceiling_$TAG.txt
 timeout 400 python tools/fuzz_extractor.py 400 150 2>&1 | tail -3 | tee gpurun_out/fuzz_$TAG.log
