@@ -141,6 +141,11 @@ int orbx_debug_trig_hash(orbx_ctx* ctx, uint32_t first_bits, uint32_t count, uin
  * produces; every 16th pair has m10 = 0) generated from `seed` by a fixed integer mix on both sides. */
 int orbx_debug_atan_hash(orbx_ctx* ctx, uint32_t seed, uint32_t count, uint64_t* hash);
 
+/* Test hook for the quadtree's exact std::sort: sorts elems[0..n) (n <= 2048; key = high 32 bits, payload = low 32 bits) with
+ * the workgroup-parallel restatement of libstdc++'s introsort the kernel uses (src/ORBextractor.cc:697-701 sorts with
+ * std::sort and a comparator that leaves ties to the library's internals), one workgroup of `threads` (64..512) threads. */
+int orbx_debug_gnu_sort(orbx_ctx* ctx, uint64_t* elems, int n, int threads);
+
 /* Counter-calibration hook: copies nbytes (multiple of 16) from d_src to d_dst on the device with `width` (1, 4 or
  * 16) bytes per lane per access — a kernel with exactly known HBM traffic, used by tools/pmc_traffic.py to calibrate
  * rocprofv3's FETCH_SIZE / WRITE_SIZE for the access widths the extractor kernels use.  Asynchronous on `stream`. */

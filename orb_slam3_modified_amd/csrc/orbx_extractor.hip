@@ -22,6 +22,7 @@ namespace orbx {
 // Workgroup size of k_fast_cells: 128 by default (measured best); ORBX_FAST_THREADS=64|128|256 in the environment overrides it
 // (tuning knob, read once per context).
 constexpr int kQtLdsPoints = 2048;  // LDS-resident candidate capacity per (frame, level) of k_quadtree (big levels)
+static_assert(kQtLdsPoints <= 4096, "the chunk prefix of the quadtree full pass is one wave wide");
 constexpr int kQtBigLevels = 2;     // levels launched with the large quadtree workgroup configuration
 
 static int fast_threads_from_env() {
@@ -210,6 +211,11 @@ static void qt_caps(int mq, int mc, int mp, int& node_cap, int& scan_cap) {
 }
 static size_t qt_node_bytes(int node_cap, int scan_cap) {
   return (size_t)node_cap * (2 * sizeof(QNode) + 2 * 8 + sizeof(int4) + 4) + (size_t)scan_cap * 8;
+}
+// LDS-resident points of one quadtree workgroup: two point buffers, two node-index buffers (16 bit) and the chunk tables of
+// the thread-per-point full passes (counts, prefix and four class ballots per 64 positions, one spare entry); pts_cap <= 4096
+static size_t qt_point_bytes(int pts_cap) {
+  return pts_cap ? (size_t)pts_cap * (2 * sizeof(uint32_t) + 2 * sizeof(uint16_t)) + (size_t)(pts_cap / 64 + 1) * 6 * 8 : 0;
 }
 
 static int ensure_buffers(orbx_ctx* ctx, int rows, int cols, int nframes) {
@@ -439,7 +445,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
       }
       int node_cap, scan_cap;
       qt_caps(mq, mc, mp, node_cap, scan_cap);   // beyond 65 532 nodes the kernel refuses at run time (never seen: that many corners on one level)
-      size_t lds = qt_node_bytes(node_cap, scan_cap) + (size_t)pts_cap * 2 * sizeof(uint32_t);
+      size_t lds = qt_node_bytes(node_cap, scan_cap) + qt_point_bytes(pts_cap);
       uint8_t* gnodes = nullptr;
       if (lds > kLdsMax) {
         if (l1 - l0 > 1) {   // let every level of the group choose for itself
@@ -459,7 +465,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
           return set_err(ctx, ORBX_E_CAPACITY, "nfeatures too large for the quadtree kernel's LDS");
       }
       // small batches are latency-bound on the big levels' workgroups: more waves split more nodes at a time
-      const int qthreads = (nframes * geo.nlevels <= 512) ? 512 : 256;
+      const int qthreads = ctx->qt_threads ? ctx->qt_threads : (nframes * geo.nlevels <= 512) ? 512 : 256;
       hipLaunchKernelGGL(k_quadtree, dim3(l1 - l0, nframes, 1), dim3(qthreads), lds, s, ctx->d_geo, ctx->d_cells, b_cand, b_cell_cnt,
                          b_pts, b_lvl_kp, b_lvl_n, node_cap, scan_cap, pts_cap, l0, gnodes, (long long)ctx->qt_node_stride);
       return ORBX_OK;
@@ -562,6 +568,7 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, 
     }
   }
   ctx->fast_threads = fast_threads_from_env();
+  { const char* e = getenv("ORBX_QT_THREADS"); const int v = e ? atoi(e) : 0; ctx->qt_threads = (v == 64 || v == 128 || v == 256 || v == 512) ? v : 0; }
   {
     const char* e = getenv("ORBX_DESC_K");  // keypoints per wave of k_describe (tuning knob)
     const int v = e ? atoi(e) : 4;
@@ -1020,6 +1027,7 @@ int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
   else if (n == "fast_stop") ctx->fast_stop = value;   // timing experiment: FAST returns after staging (1) / after the necessary test (2); results are void
   else if (n == "desc_lds") ctx->desc_lds = value != 0;
   else if (n == "fast_threads" && (value == 64 || value == 128 || value == 256)) ctx->fast_threads = value;
+  else if (n == "qt_threads" && (value == 0 || value == 64 || value == 128 || value == 256 || value == 512)) ctx->qt_threads = value;   // 0: chosen by batch size
   else if (n == "desc_k" && (value == 1 || value == 2 || value == 4 || value == 8 || value == 16)) ctx->desc_k = value;
   else if (n == "streams" && value >= 1 && value <= 2) ctx->nstreams = value;
   else return set_err(ctx, ORBX_E_INVALID, "orbx_set_option: unknown option or value out of range: " + n);
@@ -1134,6 +1142,21 @@ int orbx_debug_trig(orbx_ctx* ctx, const float* y, const float* x, int n, int an
   ORBX_HIP(ctx, copy_sync(ctx, a, da, bytes, hipMemcpyDeviceToHost));
   ORBX_HIP(ctx, copy_sync(ctx, b, db, bytes, hipMemcpyDeviceToHost));
   (void)hipFree(dy); (void)hipFree(dx); (void)hipFree(dang); (void)hipFree(da); (void)hipFree(db);
+  return ORBX_OK;
+}
+
+int orbx_debug_gnu_sort(orbx_ctx* ctx, uint64_t* elems, int n, int threads) {
+  if (!ctx || n < 0 || n > 2048 || (n && !elems) || threads < 64 || threads > 512 || (threads & 63)) return ORBX_E_INVALID;
+  if (n == 0) return ORBX_OK;
+  ORBX_HIP(ctx, hipSetDevice(ctx->device));
+  unsigned long long* d = nullptr;
+  ORBX_HIP(ctx, hipMalloc((void**)&d, (size_t)n * 8));
+  ORBX_HIP(ctx, copy_sync(ctx, d, elems, (size_t)n * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_debug_gnu_sort, dim3(1), dim3(threads), 0, ctx->stream, d, n);
+  ORBX_HIP(ctx, hipGetLastError());
+  ORBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ORBX_HIP(ctx, copy_sync(ctx, elems, d, (size_t)n * 8, hipMemcpyDeviceToHost));
+  (void)hipFree(d);
   return ORBX_OK;
 }
 

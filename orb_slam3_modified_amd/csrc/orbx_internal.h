@@ -137,6 +137,7 @@ struct orbx_ctx {
   int umax[16];
   int out_cap;  // nfeatures + 3*nlevels
   int fast_threads = 128;  // workgroup size of k_fast_cells
+  int qt_threads = 0;      // workgroup size of k_quadtree (0: by batch size)
   int desc_k = 8;          // keypoints per wave of k_describe
 
   hipStream_t stream = nullptr;

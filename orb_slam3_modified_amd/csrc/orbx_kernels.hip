@@ -297,6 +297,7 @@ __global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__
     const int nit = dh * ng;
     const uint32_t magic = (65536u + (uint32_t)ng - 1u) / (uint32_t)ng;  // i / ng == (i * magic) >> 16 for i < 65536 / ng
     for (int i0 = 0; i0 < nit; i0 += T) {
+      if (i0 + (wv << 6) >= nit) break;  // wave-uniform: the remainder trip (nit is rarely a multiple of T) costs only the waves it reaches
       const int act = (i0 + t) < nit;
       const int i = act ? i0 + t : nit - 1;
       const int ry = (int)(mul_u24((uint32_t)i, magic) >> 16);   // i < 2^16, magic <= 2^16
@@ -494,6 +495,25 @@ __device__ __forceinline__ unsigned long long block_excl_scan(unsigned long long
   return total;
 }
 
+// One value per thread: exclusive prefix over the workgroup and the total, ONE barrier.  wt2 holds two sets of wave totals and
+// `par` selects one; consecutive calls alternate, so a wave still reading the previous call's totals is never overwritten.
+__device__ __forceinline__ unsigned long long block_scan1(unsigned long long v, unsigned long long* wt2, int par, unsigned long long& total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, NW = blockDim.x >> 6;
+  unsigned long long inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned long long u = __shfl_up(inc, o);
+    if (lane >= o) inc += u;
+  }
+  unsigned long long* wt = wt2 + (par << 3);
+  if (lane == 63) wt[w] = inc;
+  __syncthreads();
+  unsigned long long off = 0, tot = 0;
+  for (int k = 0; k < NW; k++) { const unsigned long long x = wt[k]; off += k < w ? x : 0; tot += x; }
+  total = tot;
+  return off + inc - v;
+}
+
 // LDS written by some lanes of a wave and read by other lanes of the same wave: order the accesses.
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -544,6 +564,163 @@ __device__ __forceinline__ int wave_partition(unsigned long long* v, int first, 
   return cut;
 }
 
+// One wave, one introsort step (median-of-3 + Hoare partition, returns the cut) of a segment with at most 256 interior
+// elements held in four registers per lane (register r, lane e <-> position first + 1 + 64 r + e): the ranks of the closed form
+// come from per-register ballots and their scalar popcounts, the swap partners meet through the ia / ir scratch.
+__device__ __forceinline__ int wave_step_regs(unsigned long long* v, int first, int last, uint16_t* ia, uint16_t* ir) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long ltm = (1ull << lane) - 1ull, gtm = ~(ltm | (1ull << lane));
+  const int f = __builtin_amdgcn_readfirstlane(first), l = __builtin_amdgcn_readfirstlane(last);
+  unsigned long long mine[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) { const int i = f + 1 + 64 * r + lane; mine[r] = i < l ? v[i] : 0ull; }
+  const int pa = f + 1, pb = f + ((l - f) >> 1), pc = l - 1;
+  const unsigned long long vf = v[f], va = v[pa], vb = v[pb], vc = v[pc];
+  const uint32_t ka = (uint32_t)(va >> 32), kb = (uint32_t)(vb >> 32), kc = (uint32_t)(vc >> 32);
+  int pm;
+  if (ka < kb) pm = kb < kc ? pb : (ka < kc ? pc : pa);
+  else pm = ka < kc ? pa : (kb < kc ? pc : pb);
+  const unsigned long long piv = pm == pa ? va : (pm == pb ? vb : vc);
+  const uint32_t kp = (uint32_t)(piv >> 32);
+  unsigned long long bL[4], bR[4];
+  bool isL[4], isR[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int i = f + 1 + 64 * r + lane;
+    if (i == pm) mine[r] = vf;
+    const uint32_t k = (uint32_t)(mine[r] >> 32);
+    isL[r] = i < l && k >= kp;
+    isR[r] = i < l && k <= kp;
+    bL[r] = __ballot(isL[r]);
+    bR[r] = __ballot(isR[r]);
+  }
+  int preL[4], sufR[4];
+  preL[0] = 0; preL[1] = __popcll(bL[0]); preL[2] = preL[1] + __popcll(bL[1]); preL[3] = preL[2] + __popcll(bL[2]);
+  sufR[3] = 0; sufR[2] = __popcll(bR[3]); sufR[1] = sufR[2] + __popcll(bR[2]); sufR[0] = sufR[1] + __popcll(bR[1]);
+  int rankL[4], rankR[4];
+  bool partL[4], partR[4];
+  unsigned long long pL[4], pR[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int i = f + 1 + 64 * r + lane;
+    rankL[r] = preL[r] + __popcll(bL[r] & ltm);   // a's before me
+    rankR[r] = sufR[r] + __popcll(bR[r] & gtm);   // b's after me
+    partL[r] = isL[r] && rankR[r] >= rankL[r] + 1;
+    partR[r] = isR[r] && rankL[r] >= rankR[r] + 1;
+    pL[r] = __ballot(partL[r]);
+    pR[r] = __ballot(partR[r]);
+    if (partL[r]) ia[rankL[r]] = (uint16_t)i;
+    if (partR[r]) ir[rankR[r]] = (uint16_t)i;
+    if (i < l) v[i] = mine[r];   // the arrangement after the median swap: what the partners read
+  }
+  if (lane == 0) v[f] = piv;
+  wave_lds_sync();
+  unsigned long long other[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    other[r] = 0ull;
+    if (partL[r]) other[r] = v[ir[rankL[r]]];
+    if (partR[r]) other[r] = v[ia[rankR[r]]];
+  }
+  wave_lds_sync();
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int i = f + 1 + 64 * r + lane;
+    if (partL[r] || partR[r]) v[i] = other[r];
+  }
+  int aJ = 0x7fffffff, rprev = l;
+#pragma unroll
+  for (int r = 3; r >= 0; r--) {
+    const unsigned long long rest = bL[r] & ~pL[r];
+    if (rest) aJ = f + 64 * r + __ffsll((long long)rest);
+    if (pR[r]) rprev = f + 64 * r + __ffsll((long long)pR[r]);
+  }
+  wave_lds_sync();
+  return aJ < rprev ? aJ : rprev;
+}
+
+// One wave runs the whole introsort loop of a segment whose interior (first, last) fits the wave (last - first - 1 <= 64):
+// lane e <-> position first + 1 + e, the elements live in registers.  Median-of-3 by three lane reads; the Hoare step from
+// two ballots — with a[j] the j-th position (from the left) whose key is >= the pivot's and b[j] the j-th (from the right) whose
+// key is <= it, the pair (a[j], b[j]) is swapped iff a[j] < b[j], which for the lane at a[j] reads "at least j such b after me"
+// and for the lane at b[j] "at least j such a before me" (an element equal to the pivot is both, but cannot take part as both);
+// the cut is the first a that did not swap, or the last b that did, whichever comes first (gnu_sort.h, partition_closed_form).
+// Sub-segments longer than 16 are taken up by the same wave (at most two can be pending inside 65 positions); the others get
+// their final-segment marks.  ia / ir: per-segment LDS scratch (last - first entries each), seg: as in block_gnu_sort.
+__device__ __forceinline__ void wave_introsort_small(unsigned long long* v, int first, int last, int depth, uint32_t* seg,
+                                                     uint16_t* ia0, uint16_t* ir0, int seg0) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long ltm = (1ull << lane) - 1ull, gtm = ~(ltm | (1ull << lane));
+  int f = __builtin_amdgcn_readfirstlane(first), l = __builtin_amdgcn_readfirstlane(last), d = __builtin_amdgcn_readfirstlane(depth);
+  unsigned long long st0 = 0, st1 = 0;  // pending (f | l << 16 | d << 32)
+  int sp = 0;
+  while (true) {
+    if (d == 0) {  // depth limit: heapsort fallback, result in final order
+      if (lane == 0) orbx_sort::heap_sort(v, f, l);
+      for (int i = f + lane; i < l; i += 64) seg[i] = (uint32_t)i | (uint32_t)(i + 1) << 16;
+      wave_lds_sync();
+    } else {
+      d--;
+      uint16_t* ia = ia0 + (f - seg0);
+      uint16_t* ir = ir0 + (f - seg0);
+      const int i = f + 1 + lane;
+      const bool valid = i < l;
+      unsigned long long mine = valid ? v[i] : 0ull;
+      const unsigned long long vf = v[f];
+      // std::__move_median_to_first(first, first + 1, mid, last - 1)
+      const int lb = ((l - f) >> 1) - 1, lc = l - f - 2;
+      const uint32_t mk = (uint32_t)(mine >> 32), ml = (uint32_t)mine;
+      const uint32_t ka = __builtin_amdgcn_readlane(mk, 0), kb = __builtin_amdgcn_readlane(mk, lb), kc = __builtin_amdgcn_readlane(mk, lc);
+      int lm;
+      if (ka < kb) lm = kb < kc ? lb : (ka < kc ? lc : 0);
+      else lm = ka < kc ? 0 : (kb < kc ? lc : lb);
+      const uint32_t kp = __builtin_amdgcn_readlane(mk, lm);
+      const unsigned long long piv = (unsigned long long)kp << 32 | __builtin_amdgcn_readlane(ml, lm);
+      if (lane == lm) mine = vf;
+      // std::__unguarded_partition(first + 1, last, first), closed form
+      const uint32_t k = (uint32_t)(mine >> 32);
+      const bool isL = valid && k >= kp, isR = valid && k <= kp;
+      const unsigned long long bL = __ballot(isL), bR = __ballot(isR);
+      const int nLbefore = __popcll(bL & ltm), nRafter = __popcll(bR & gtm);
+      const bool partL = isL && nRafter >= nLbefore + 1;
+      const bool partR = isR && nLbefore >= nRafter + 1;
+      const unsigned long long pL = __ballot(partL), pR = __ballot(partR);
+      if (partL) ia[nLbefore] = (uint16_t)lane;
+      if (partR) ir[nRafter] = (uint16_t)lane;
+      wave_lds_sync();
+      int partner = lane;
+      if (partL) partner = ir[nLbefore];
+      if (partR) partner = ia[nRafter];
+      const unsigned long long other = __shfl(mine, partner);
+      if (partL || partR) mine = other;
+      const unsigned long long rest = bL & ~pL;
+      const int aJ = rest ? f + __ffsll((long long)rest) : 0x7fffffff;
+      const int rprev = pR ? f + __ffsll((long long)pR) : l;
+      const int cut = aJ < rprev ? aJ : rprev;
+      if (valid) v[i] = mine;
+      if (lane == 0) v[f] = piv;
+      // children [f, cut) and [cut, l)
+      const bool bigL = cut - f > 16, bigR = l - cut > 16;
+      if (!bigL) for (int q = f + lane; q < cut; q += 64) seg[q] = (uint32_t)f | (uint32_t)cut << 16;
+      if (!bigR) for (int q = cut + lane; q < l; q += 64) seg[q] = (uint32_t)cut | (uint32_t)l << 16;
+      wave_lds_sync();
+      if (bigL && bigR) {
+        const unsigned long long e = (unsigned long long)cut | (unsigned long long)l << 16 | (unsigned long long)d << 32;
+        if (sp == 0) st0 = e; else st1 = e;
+        sp++;
+        l = cut;
+        continue;
+      }
+      if (bigL) { l = cut; continue; }
+      if (bigR) { f = cut; continue; }
+    }
+    if (sp == 0) break;
+    sp--;
+    const unsigned long long e = sp == 0 ? st0 : st1;
+    f = (int)(e & 0xffffull); l = (int)((e >> 16) & 0xffffull); d = (int)(e >> 32);
+  }
+}
+
 // std::sort(v, v + n) with the reference's (count, UL.x) comparator, exact libstdc++ permutation (ties included),
 // by the whole workgroup: level-synchronous introsort loop (one wave per pending segment and round), then a stable
 // rank inside every final segment (== __final_insertion_sort).  tmp: n elements; seg: n words; q0/q1: n/16+2 entries each;
@@ -551,6 +728,7 @@ __device__ __forceinline__ int wave_partition(unsigned long long* v, int first, 
 __device__ __forceinline__ void block_gnu_sort(unsigned long long* v, int n, unsigned long long* tmp, uint32_t* seg,
                                                unsigned long long* q0, unsigned long long* q1, uint16_t* idx, int* sh_cnt) {
   const int T = blockDim.x, t = threadIdx.x, lane = t & 63, w = t >> 6, NW = T >> 6;
+  QT_T0();
   for (int i = t; i < n; i += T) seg[i] = (uint32_t)n << 16;  // lo = 0, hi = n
   if (n > 16) {
     if (t == 0) { q0[0] = (unsigned long long)n << 16 | (unsigned long long)(2 * (31 - __clz(n))) << 32; *sh_cnt = 0; }  // first | last << 16 | depth << 32
@@ -562,14 +740,23 @@ __device__ __forceinline__ void block_gnu_sort(unsigned long long* v, int n, uns
       for (int sidx = w; sidx < ncur; sidx += NW) {
         const unsigned long long pk = q0[sidx];
         const int f = (int)(pk & 0xffffull), l = (int)((pk >> 16) & 0xffffull), d = (int)(pk >> 32);
+        if (l - f <= 65) {  // fits a wave's registers: this wave finishes the segment and everything below it
+          wave_introsort_small(v, f, l, d, seg, ia, ir, 0);
+          continue;
+        }
         if (d == 0) {  // depth limit: heapsort fallback (practically never), result already in final order
           if (lane == 0) orbx_sort::heap_sort(v, f, l);
           for (int i = f + lane; i < l; i += 64) seg[i] = (uint32_t)i | (uint32_t)(i + 1) << 16;
           continue;
         }
-        if (lane == 0) orbx_sort::move_median_to_first(v, f, f + 1, f + (l - f) / 2, l - 1);
-        wave_lds_sync();
-        const int cut = wave_partition(v, f, l, ia + f, ir + f);
+        int cut;
+        if (l - f <= 257) {
+          cut = wave_step_regs(v, f, l, ia + f, ir + f);
+        } else {
+          if (lane == 0) orbx_sort::move_median_to_first(v, f, f + 1, f + (l - f) / 2, l - 1);
+          wave_lds_sync();
+          cut = wave_partition(v, f, l, ia + f, ir + f);
+        }
 #pragma unroll
         for (int c = 0; c < 2; c++) {
           const int cf = c ? cut : f, cl = c ? l : cut;
@@ -589,20 +776,31 @@ __device__ __forceinline__ void block_gnu_sort(unsigned long long* v, int n, uns
     }
   }
   __syncthreads();
+  QT_ACC(5);
   for (int i = t; i < n; i += T) {
     const unsigned long long e = v[i];
     const uint32_t k = (uint32_t)(e >> 32), sg = seg[i];
     const int lo = (int)(sg & 0xffffu), hi = (int)(sg >> 16);
+    // a final segment holds at most 16 elements: sixteen independent reads (clamped past its end) instead of a dependent loop
+    uint32_t kj[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) kj[u] = (uint32_t)(v[min(lo + u, hi - 1)] >> 32);
     int rank = lo;
-    for (int j = lo; j < hi; j++) {
-      const uint32_t kj = (uint32_t)(v[j] >> 32);
-      rank += (kj < k) || (kj == k && j < i);
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int j = lo + u;
+      rank += (j < hi) && ((kj[u] < k) || (kj[u] == k && j < i));
     }
     tmp[rank] = e;
   }
   __syncthreads();
   for (int i = t; i < n; i += T) v[i] = tmp[i];
+  if (t == 0) *sh_cnt = 0;   // callers count on it
   __syncthreads();
+  QT_ACC(6);
+#ifdef ORBX_QT_PROFILE
+  if (threadIdx.x == 0 && blockIdx.y == 0) g_qt_prof[blockIdx.x * 8 + 7] += 100;   // number of sorts (x 1 us in the tool's print)
+#endif
 }
 
 // One wave: child counts of `nd` (DivideNode, src/ORBextractor.cc:480-536) and optional stable scatter cur->nxt.
@@ -657,6 +855,53 @@ __device__ __forceinline__ QNode child_node(const QNode nd, int c, int start, in
   return r;
 }
 
+// One thread: the same child counts / stable scatter for a small node (count <= kQtThreadNode).  In the sorted phase the
+// list holds many nodes of a few points each; a wave per node would spend a whole ballot round trip on every one of them.
+constexpr int kQtThreadNode = 16;
+__device__ __forceinline__ int4 thread_split_count(const QNode nd, const uint32_t* cur) {
+  const int sx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1);
+  const int sy = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
+  uint32_t acc = 0;  // four 8-bit counters
+  uint32_t p[kQtThreadNode];  // every read issued before the first use: one LDS round trip, not one per point
+#pragma unroll
+  for (int e = 0; e < kQtThreadNode; e++) p[e] = cur[nd.start + min(e, nd.count - 1)];
+#pragma unroll
+  for (int e = 0; e < kQtThreadNode; e++) {
+    const int chd = (pt_x(p[e]) < sx ? 0 : 1) + (pt_y(p[e]) < sy ? 0 : 2);
+    acc += e < nd.count ? 1u << (chd << 3) : 0u;
+  }
+  return make_int4((int)(acc & 0xffu), (int)((acc >> 8) & 0xffu), (int)((acc >> 16) & 0xffu), (int)(acc >> 24));
+}
+__device__ __forceinline__ void thread_split_scatter(const QNode nd, const int4 c, uint32_t* cur, uint32_t* nxt) {
+  const int sx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1);
+  const int sy = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
+  uint32_t run = ((uint32_t)c.x << 8) | ((uint32_t)(c.x + c.y) << 16) | ((uint32_t)(c.x + c.y + c.z) << 24);  // next free offset of each child
+  // the node's points live in registers between the read and the two writes: no scratch buffer, no copy back
+  uint32_t p[kQtThreadNode];
+#pragma unroll
+  for (int e = 0; e < kQtThreadNode; e++) p[e] = cur[nd.start + min(e, nd.count - 1)];
+#pragma unroll
+  for (int e = 0; e < kQtThreadNode; e++) {
+    if (e < nd.count) {
+      const int sh = ((pt_x(p[e]) < sx ? 0 : 1) + (pt_y(p[e]) < sy ? 0 : 2)) << 3;
+      cur[nd.start + (int)((run >> sh) & 0xffu)] = p[e];
+      run += 1u << sh;
+    }
+  }
+}
+
+// Full pass over LDS-resident points, thread per point: the packed (4 x 16 bit) exclusive count of the four child classes over
+// the points [0, pos) of the current arrangement, from the per-chunk prefix `cpre` and the per-chunk class ballots `cbal`
+// (chunk = 64 consecutive positions).  pos may equal n: chunk index n >> 6 is then one past the last written chunk, whose
+// ballots are masked out by lt = 0 (the tables hold one spare entry).
+__device__ __forceinline__ unsigned long long qt_prefix_at(const unsigned long long* cpre, const unsigned long long* cbal, int pos) {
+  const int c = pos >> 6, l = pos & 63;
+  const unsigned long long lt = (1ull << l) - 1ull;
+  const unsigned long long* b = cbal + 4 * c;
+  return cpre[c] + ((unsigned long long)__popcll(b[0] & lt) | (unsigned long long)__popcll(b[1] & lt) << 16 |
+                    (unsigned long long)__popcll(b[2] & lt) << 32 | (unsigned long long)__popcll(b[3] & lt) << 48);
+}
+
 __device__ __forceinline__ unsigned long long expand_elem(const QNode n, int pos) {
   const uint32_t key = ((uint32_t)n.count << 13) | (uint32_t)(n.x0 & 0x1fff);
   return ((unsigned long long)key << 32) | (uint32_t)pos;
@@ -669,9 +914,16 @@ __device__ __forceinline__ void quadtree_body(const DeviceGeom* __restrict__ g, 
                                               const uint32_t* __restrict__ fcand, uint32_t* gcur, uint32_t* gnxt,
                                               uint32_t* lcur, uint32_t* lnxt, uint32_t* __restrict__ lvl_kp,
                                               int32_t* __restrict__ lvl_n, int node_cap, int scan_cap, uint8_t* smem, int n,
-                                              unsigned long long* wt, int* sh_cnt, int* sh_jstar_p, int level_base) {
+                                              unsigned long long* wt, int* sh_cnt, int* sh_jstar_p, int level_base, int pts_cap) {
   uint32_t* cur = LP ? lcur : gcur;
   uint32_t* nxt = LP ? lnxt : gnxt;
+  // LP only: node index of every point (list position of the node that holds it) and the chunk tables of the full passes
+  uint16_t* nid = (uint16_t*)(lnxt + pts_cap);
+  uint16_t* nidn = nid + pts_cap;
+  unsigned long long* cpre = (unsigned long long*)(nidn + pts_cap);
+  unsigned long long* cbal = cpre + (pts_cap >> 6) + 1;
+  unsigned long long* cpx = cbal + 4 * ((pts_cap >> 6) + 1);   // fused pass: exclusive chunk prefix (cpre then keeps the raw counts)
+  int spar = 0;                                                // parity of block_scan1's wave-total buffer
   QNode* LA = (QNode*)smem;
   QNode* LB = LA + node_cap;
   unsigned long long* EA = (unsigned long long*)(LB + node_cap);
@@ -695,14 +947,18 @@ __device__ __forceinline__ void quadtree_body(const DeviceGeom* __restrict__ g, 
   QT_T0();
   // ---- gather the per-cell lists in cell order (vToDistributeKeys, src/ORBextractor.cc:863-868): `scan` holds the
   // exclusive prefix of the cell counts (computed by the kernel); element e finds its cell by binary search
-  for (int e = t; e < n; e += T) {
-    int lo = 0, hi = lv.ncells - 1;
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if ((int)scan[mid] <= e) lo = mid; else hi = mid - 1;
+  for (int c = t; c < lv.ncells; c += T) {   // a thread per cell copies the cell's (few) candidates
+    const int base = (int)scan[c], cnt = (c + 1 < lv.ncells ? (int)scan[c + 1] : n) - base;
+    const uint32_t* src = fcand + cells[lv.cell_begin + c].slot_off;
+    for (int k0 = 0; k0 < cnt; k0 += 8) {   // eight independent loads, then the stores (a plain copy loop would wait for each load)
+      uint32_t r[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) r[k] = src[min(k0 + k, cnt - 1)];
+#pragma unroll
+      for (int k = 0; k < 8; k++) if (k0 + k < cnt) cur[base + k0 + k] = r[k];
     }
-    cur[e] = fcand[cells[lv.cell_begin + lo].slot_off + (e - (int)scan[lo])];
   }
+  if constexpr (LP) for (int e = t; e < n; e += T) nid[e] = 0;
   __syncthreads();
   int nL = 0, nE = 0;
   // ---- root nodes (src/ORBextractor.cc:559-601)
@@ -719,9 +975,9 @@ __device__ __forceinline__ void quadtree_body(const DeviceGeom* __restrict__ g, 
     }
     __syncthreads();
     if (w == 0) {  // stable bucket scatter by one wave
-      int run[kMaxRoots];
-      int acc = 0;
-      for (int b = 0; b < lv.nroots; b++) { run[b] = acc; acc += sh_cnt[b]; }
+      int run[kMaxRoots], kix[kMaxRoots];
+      int acc = 0, kk = 0;
+      for (int b = 0; b < lv.nroots; b++) { run[b] = acc; acc += sh_cnt[b]; kix[b] = kk; kk += sh_cnt[b] > 0; }
       const unsigned long long lt = (1ull << lane) - 1ull;
       for (int o = 0; o < n; o += 64) {
         const int e = o + lane;
@@ -730,7 +986,11 @@ __device__ __forceinline__ void quadtree_body(const DeviceGeom* __restrict__ g, 
         if (e < n) { p = cur[e]; bk = (int)__fdiv_rn((float)pt_x(p), lv.hX); }
         for (int b = 0; b < lv.nroots; b++) {
           const unsigned long long m = __ballot(bk == b);
-          if (bk == b) nxt[run[b] + __popcll(m & lt)] = p;
+          if (bk == b) {
+            const int dst = run[b] + __popcll(m & lt);
+            nxt[dst] = p;
+            if constexpr (LP) nidn[dst] = (uint16_t)kix[b];
+          }
           run[b] += __popcll(m);
         }
       }
@@ -749,6 +1009,7 @@ __device__ __forceinline__ void quadtree_body(const DeviceGeom* __restrict__ g, 
     __syncthreads();
     nL = sh_jstar;
     { uint32_t* tmp = cur; cur = nxt; nxt = tmp; }
+    { uint16_t* tn = nid; nid = nidn; nidn = tn; }
     __syncthreads();
   }
   __syncthreads();
@@ -759,6 +1020,182 @@ __device__ __forceinline__ void quadtree_body(const DeviceGeom* __restrict__ g, 
     if (!sorted_phase) {
       // ======== full pass: split every node holding more than one point (src/ORBextractor.cc:612-681)
       const int prevSize = nL;
+      const int nch = (n + 63) >> 6;
+      if (LP && nL <= T) {   // block-uniform
+        // ---- the usual case, four barriers: at most one node per thread, so the node's scan value, its prefix and its children
+        // stay in that thread's registers (no scan arrays, no separate prefix pass over the chunks)
+        for (int c = w; c < nch; c += NW) {
+          const int i = (c << 6) + lane;
+          int chd = 4;
+          if (i < n) {
+            const QNode nd = LA[nid[i]];
+            if (nd.count > 1) {
+              const uint32_t p = cur[i];
+              chd = (pt_x(p) < nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1) ? 0 : 1) + (pt_y(p) < nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1) ? 0 : 2);
+            }
+          }
+          const unsigned long long b0 = __ballot(chd == 0), b1 = __ballot(chd == 1), b2 = __ballot(chd == 2), b3 = __ballot(chd == 3);
+          if (lane == 0) {
+            cbal[4 * c] = b0; cbal[4 * c + 1] = b1; cbal[4 * c + 2] = b2; cbal[4 * c + 3] = b3;
+            cpre[c] = (unsigned long long)__popcll(b0) | (unsigned long long)__popcll(b1) << 16 |
+                      (unsigned long long)__popcll(b2) << 32 | (unsigned long long)__popcll(b3) << 48;
+          }
+        }
+        __syncthreads();
+        // every wave scans the (<= 64) chunk counts for itself; wave 0 leaves the exclusive prefix in LDS for the scatter below
+        const unsigned long long cv = lane < nch ? cpre[lane] : 0ull;
+        unsigned long long cinc = cv;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const unsigned long long u = __shfl_up(cinc, o);
+          if (lane >= o) cinc += u;
+        }
+        const unsigned long long cex = cinc - cv;
+        if (w == 0 && lane < nch) cpx[lane] = cex;
+        QNode nd;
+        nd.count = 0;
+        unsigned long long sv = 0, s0 = 0, dcnt = 0;
+        {
+          int ps = 0, pe = 0;
+          if (t < nL) { nd = LA[t]; ps = nd.start; pe = nd.start + nd.count; }
+          // prefix at both ends of the node (all lanes take part in the lane reads; position n lies one chunk past the last)
+          const int c0i = ps >> 6, c1i = pe >> 6;
+          const unsigned long long e0 = __shfl(cex, min(c0i, nch - 1)), e1a = __shfl(cex, min(c1i, nch - 1)), tot = __shfl(cinc, nch - 1);
+          if (t < nL) {
+            sv = 1ull << 42;
+            if (nd.count > 1) {
+              const unsigned long long l0 = (1ull << (ps & 63)) - 1ull, l1 = (1ull << (pe & 63)) - 1ull;
+              const unsigned long long* q0 = cbal + 4 * c0i;
+              const unsigned long long* q1 = cbal + 4 * c1i;   // may be the spare entry: masked by l1 = 0
+              s0 = e0 + ((unsigned long long)__popcll(q0[0] & l0) | (unsigned long long)__popcll(q0[1] & l0) << 16 |
+                         (unsigned long long)__popcll(q0[2] & l0) << 32 | (unsigned long long)__popcll(q0[3] & l0) << 48);
+              const unsigned long long s1 = (c1i < nch ? e1a : tot) +
+                        ((unsigned long long)__popcll(q1[0] & l1) | (unsigned long long)__popcll(q1[1] & l1) << 16 |
+                         (unsigned long long)__popcll(q1[2] & l1) << 32 | (unsigned long long)__popcll(q1[3] & l1) << 48);
+              dcnt = s1 - s0;
+              const int c0 = (int)(dcnt & 0xffffu), c1 = (int)((dcnt >> 16) & 0xffffu), c2 = (int)((dcnt >> 32) & 0xffffu), c3 = (int)(dcnt >> 48);
+              const unsigned long long k = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
+              const unsigned long long q = (c0 > 1) + (c1 > 1) + (c2 > 1) + (c3 > 1);
+              sv = k | (q << 21);
+            }
+          }
+        }
+        unsigned long long tot;
+        const unsigned long long pre = block_scan1(sv, wt, spar, tot);
+        spar ^= 1;
+        const int totalKids = (int)(tot & kM21), nToExpand = (int)((tot >> 21) & kM21), nNoMore = (int)(tot >> 42);
+        if (t < nL) {
+          const int kpre = (int)(pre & kM21), qpre = (int)((pre >> 21) & kM21), spre = (int)(pre >> 42);
+          unsigned long long cpos = 0;
+          if (nd.count > 1) {
+            const int cnt[4] = {(int)(dcnt & 0xffffu), (int)((dcnt >> 16) & 0xffffu), (int)((dcnt >> 32) & 0xffffu), (int)(dcnt >> 48)};
+            const int k = (cnt[0] > 0) + (cnt[1] > 0) + (cnt[2] > 0) + (cnt[3] > 0);
+            int ci = 0, qi = 0, st = nd.start;
+#pragma unroll
+            for (int ch = 0; ch < 4; ch++) {
+              if (cnt[ch] > 0) {
+                const int pos = totalKids - (kpre + k) + (k - 1 - ci);
+                const QNode cn = child_node(nd, ch, st, cnt[ch]);
+                LB[pos] = cn;
+                cpos |= (unsigned long long)pos << (16 * ch);
+                if (cnt[ch] > 1) { EB[qpre + qi] = expand_elem(cn, pos); qi++; }
+                ci++;
+              }
+              st += cnt[ch];
+            }
+            kids[t] = make_int4((int)(uint32_t)dcnt, (int)(uint32_t)(dcnt >> 32), (int)(uint32_t)s0, (int)(uint32_t)(s0 >> 32));
+          } else {
+            LB[totalKids + spre] = nd;
+            cpos = (unsigned long long)(totalKids + spre);
+          }
+          scan[t] = cpos;
+        }
+        __syncthreads();
+        for (int i = t; i < n; i += T) {
+          const int id = nid[i];
+          const QNode pn = LA[id];
+          const uint32_t p = cur[i];
+          const unsigned long long cpos = scan[id];
+          if (pn.count > 1) {
+            const int chd = (pt_x(p) < pn.x0 + ((pn.x1 - pn.x0 + 1) >> 1) ? 0 : 1) + (pt_y(p) < pn.y0 + ((pn.y1 - pn.y0 + 1) >> 1) ? 0 : 2);
+            const int sh = chd << 4;
+            const int4 kp = kids[id];
+            const unsigned long long cnts = (unsigned long long)(uint32_t)kp.x | (unsigned long long)(uint32_t)kp.y << 32;
+            const unsigned long long base = (unsigned long long)(uint32_t)kp.z | (unsigned long long)(uint32_t)kp.w << 32;
+            const int c = i >> 6;
+            const int mine = (int)((cpx[c] >> sh) & 0xffffu) + __popcll(cbal[4 * c + chd] & ((1ull << (i & 63)) - 1ull));
+            const unsigned long long below = cnts & ((1ull << sh) - 1ull);
+            const int off = (int)(below & 0xffffu) + (int)((below >> 16) & 0xffffu) + (int)((below >> 32) & 0xffffu);
+            const int dst = pn.start + off + mine - (int)((base >> sh) & 0xffffu);
+            nxt[dst] = p;
+            nidn[dst] = (uint16_t)(cpos >> sh);
+          } else {
+            nxt[i] = p;
+            nidn[i] = (uint16_t)cpos;
+          }
+        }
+        __syncthreads();
+        { uint16_t* tn = nid; nid = nidn; nidn = tn; }
+        { QNode* tl = LA; LA = LB; LB = tl; }
+        { unsigned long long* te = EA; EA = EB; EB = te; }
+        { uint32_t* tp = cur; cur = nxt; nxt = tp; }
+        nL = totalKids + nNoMore;
+        nE = nToExpand;
+        if (nL >= N || nL == prevSize) finish = true;
+        else if (nL + 3 * nE > N) sorted_phase = true;
+        QT_ACC(1);
+        continue;
+      }
+      if constexpr (LP) {
+        // thread per point.  Class ballots and counts of every 64-position chunk ...
+        for (int c = w; c < nch; c += NW) {
+          const int i = (c << 6) + lane;
+          int chd = 4;
+          if (i < n) {
+            const QNode nd = LA[nid[i]];
+            if (nd.count > 1) {
+              const uint32_t p = cur[i];
+              chd = (pt_x(p) < nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1) ? 0 : 1) + (pt_y(p) < nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1) ? 0 : 2);
+            }
+          }
+          const unsigned long long b0 = __ballot(chd == 0), b1 = __ballot(chd == 1), b2 = __ballot(chd == 2), b3 = __ballot(chd == 3);
+          if (lane == 0) {
+            cbal[4 * c] = b0; cbal[4 * c + 1] = b1; cbal[4 * c + 2] = b2; cbal[4 * c + 3] = b3;
+            cpre[c] = (unsigned long long)__popcll(b0) | (unsigned long long)__popcll(b1) << 16 |
+                      (unsigned long long)__popcll(b2) << 32 | (unsigned long long)__popcll(b3) << 48;
+          }
+        }
+        __syncthreads();
+        // ... their exclusive prefix over the chunks (at most 64 of them: one wave) ...
+        if (w == 0) {
+          const unsigned long long v = lane < nch ? cpre[lane] : 0ull;
+          unsigned long long inc = v;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long u = __shfl_up(inc, o);
+            if (lane >= o) inc += u;
+          }
+          if (lane < nch) cpre[lane] = inc - v;
+          if (lane == nch - 1) cpre[nch] = inc;
+        }
+        __syncthreads();
+        // ... give every node its child counts (difference of the prefix at its two ends) and the prefix at its start
+        for (int i = t; i < nL; i += T) {
+          const QNode nd = LA[i];
+          unsigned long long v = 1ull << 42;
+          if (nd.count > 1) {
+            const unsigned long long s0 = qt_prefix_at(cpre, cbal, nd.start), s1 = qt_prefix_at(cpre, cbal, nd.start + nd.count);
+            const unsigned long long d = s1 - s0;  // no field borrows: every class count is monotone in the position
+            kids[i] = make_int4((int)(uint32_t)d, (int)(uint32_t)(d >> 32), (int)(uint32_t)s0, (int)(uint32_t)(s0 >> 32));
+            const int c0 = (int)(d & 0xffffu), c1 = (int)((d >> 16) & 0xffffu), c2 = (int)((d >> 32) & 0xffffu), c3 = (int)(d >> 48);
+            const unsigned long long k = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
+            const unsigned long long q = (c0 > 1) + (c1 > 1) + (c2 > 1) + (c3 > 1);
+            v = k | (q << 21);
+          }
+          scan[i] = v;
+        }
+        __syncthreads();
+      } else {
       for (int i = w; i < nL; i += NW) {
         const QNode nd = LA[i];
         if (nd.count > 1) {
@@ -782,16 +1219,20 @@ __device__ __forceinline__ void quadtree_body(const DeviceGeom* __restrict__ g, 
         scan[i] = v;
       }
       __syncthreads();
+      }
       const unsigned long long tot = block_excl_scan(scan, nL, wt);
       const int totalKids = (int)(tot & kM21), nToExpand = (int)((tot >> 21) & kM21), nNoMore = (int)(tot >> 42);
       for (int i = t; i < nL; i += T) {
         const unsigned long long pre = scan[i];
         const int kpre = (int)(pre & kM21), qpre = (int)((pre >> 21) & kM21), spre = (int)(pre >> 42);
         const QNode nd = LA[i];
+        unsigned long long cpos = 0;  // LP: list positions of the four children (16 bits each), or of the node itself
         if (nd.count > 1) {
           const int4 c = kids[i];
-          const int cnt[4] = {c.x, c.y, c.z, c.w};
-          const int k = (c.x > 0) + (c.y > 0) + (c.z > 0) + (c.w > 0);
+          int cnt[4];
+          if constexpr (LP) { cnt[0] = c.x & 0xffff; cnt[1] = (int)((uint32_t)c.x >> 16); cnt[2] = c.y & 0xffff; cnt[3] = (int)((uint32_t)c.y >> 16); }
+          else { cnt[0] = c.x; cnt[1] = c.y; cnt[2] = c.z; cnt[3] = c.w; }
+          const int k = (cnt[0] > 0) + (cnt[1] > 0) + (cnt[2] > 0) + (cnt[3] > 0);
           int ci = 0, qi = 0, st = nd.start;
 #pragma unroll
           for (int ch = 0; ch < 4; ch++) {
@@ -799,6 +1240,7 @@ __device__ __forceinline__ void quadtree_body(const DeviceGeom* __restrict__ g, 
               const int pos = totalKids - (kpre + k) + (k - 1 - ci);
               const QNode cn = child_node(nd, ch, st, cnt[ch]);
               LB[pos] = cn;
+              cpos |= (unsigned long long)pos << (16 * ch);
               if (cnt[ch] > 1) { EB[qpre + qi] = expand_elem(cn, pos); qi++; }
               ci++;
             }
@@ -806,9 +1248,40 @@ __device__ __forceinline__ void quadtree_body(const DeviceGeom* __restrict__ g, 
           }
         } else {
           LB[totalKids + spre] = nd;
+          cpos = (unsigned long long)(totalKids + spre);
         }
+        if constexpr (LP) scan[i] = cpos;  // this thread was the only reader of scan[i]
       }
       __syncthreads();
+      if constexpr (LP) {
+        // every point moves to its child's segment (stable: rank among the node's points of the same class) and learns the
+        // child's list position
+        for (int i = t; i < n; i += T) {
+          const int id = nid[i];
+          const QNode nd = LA[id];
+          const uint32_t p = cur[i];
+          const unsigned long long cpos = scan[id];
+          if (nd.count > 1) {
+            const int chd = (pt_x(p) < nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1) ? 0 : 1) + (pt_y(p) < nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1) ? 0 : 2);
+            const int sh = chd << 4;
+            const int4 kp = kids[id];
+            const unsigned long long cnts = (unsigned long long)(uint32_t)kp.x | (unsigned long long)(uint32_t)kp.y << 32;
+            const unsigned long long base = (unsigned long long)(uint32_t)kp.z | (unsigned long long)(uint32_t)kp.w << 32;
+            const int c = i >> 6;
+            const int mine = (int)((cpre[c] >> sh) & 0xffffu) + __popcll(cbal[4 * c + chd] & ((1ull << (i & 63)) - 1ull));
+            const unsigned long long below = cnts & ((1ull << sh) - 1ull);
+            const int off = (int)(below & 0xffffu) + (int)((below >> 16) & 0xffffu) + (int)((below >> 32) & 0xffffu);
+            const int dst = nd.start + off + mine - (int)((base >> sh) & 0xffffu);
+            nxt[dst] = p;
+            nidn[dst] = (uint16_t)(cpos >> sh);
+          } else {
+            nxt[i] = p;
+            nidn[i] = (uint16_t)cpos;
+          }
+        }
+        __syncthreads();
+        { uint16_t* tn = nid; nid = nidn; nidn = tn; }
+      }
       { QNode* tl = LA; LA = LB; LB = tl; }
       { unsigned long long* te = EA; EA = EB; EB = te; }
       { uint32_t* tp = cur; cur = nxt; nxt = tp; }
@@ -823,11 +1296,109 @@ __device__ __forceinline__ void quadtree_body(const DeviceGeom* __restrict__ g, 
       const int m = nE;
       block_gnu_sort(EA, m, EB, (uint32_t*)flag, scan, scan + (scan_cap >> 1), (uint16_t*)kids, sh_cnt);
       QT_ACC(2);
-      for (int j = w; j < m; j += NW) {
+      int* big = (int*)EB;
+      if (m <= T && nL <= T) {   // block-uniform
+        // ---- the usual case, six barriers: thread t owns the node at sorted position m - 1 - t (the order in which the reference
+        // walks them) and list position t; counts, scan values and prefixes stay in registers
+        const int j = m - 1 - t;
+        QNode nd;
+        nd.count = 0;
+        int4 c = make_int4(0, 0, 0, 0);
+        bool isbig = false;
+        if (t == 0) sh_jstar = 0;
+        if (t < nL) flag[t] = 0;
+        if (t < m) {
+          nd = LA[(uint32_t)EA[j]];
+          isbig = nd.count > kQtThreadNode;
+          if (isbig) big[atomicAdd(&sh_cnt[0], 1)] = j;   // the sort left sh_cnt[0] = 0
+          else c = thread_split_count(nd, cur);
+        }
+        int nbig = 0;
+        if (__syncthreads_or(isbig)) {   // large nodes (rare in this phase) take a wave each
+          nbig = sh_cnt[0];
+          for (int b = w; b < nbig; b += NW) {
+            const int jb = big[b];
+            const int4 cb = wave_split(LA[(uint32_t)EA[jb]], cur, nxt, false);
+            if (lane == 0) kids[jb] = cb;
+          }
+          __syncthreads();
+          if (isbig) c = kids[j];
+        }
+        const int kc = (c.x > 0) + (c.y > 0) + (c.z > 0) + (c.w > 0);
+        const int qc = (c.x > 1) + (c.y > 1) + (c.z > 1) + (c.w > 1);
+        unsigned long long tot1, tot2, tot3;
+        const unsigned long long pre1 = block_scan1(t < m ? (unsigned long long)(kc - 1) : 0ull, wt, spar, tot1);
+        spar ^= 1;
+        if (t < m) {  // the reference stops as soon as the list holds N nodes (:746-751): the first position whose split gets there
+          const int before = nL + (int)pre1, after = before + kc - 1;
+          if (after >= N && before < N) sh_jstar = j;
+        }
+        __syncthreads();
+        const int jstar = sh_jstar;
+        const bool proc = t < m && j >= jstar;
+        if (proc) {
+          flag[(uint32_t)EA[j]] = j + 1;
+          if (!isbig) thread_split_scatter(nd, c, cur, nxt);
+        }
+        for (int b = w; b < nbig; b += NW) {
+          const int jb = big[b];
+          if (jb < jstar) continue;  // wave-uniform
+          const QNode bn = LA[(uint32_t)EA[jb]];
+          wave_split(bn, cur, nxt, true);
+          wave_lds_sync();
+          for (int e = lane; e < bn.count; e += 64) cur[bn.start + e] = nxt[bn.start + e];
+        }
+        const unsigned long long pre2 = block_scan1(proc ? ((unsigned long long)kc | (unsigned long long)qc << 21) : 0ull, wt, spar, tot2);
+        spar ^= 1;
+        const int front = (int)(tot2 & kM21), qtot = (int)((tot2 >> 21) & kM21);
+        if (proc) {
+          // the scan ran in processing order (j descending): children enter the list in front of everything created before
+          // them, their expandable ones join the next round's vector in creation order
+          const int basep = front - ((int)(pre2 & kM21) + kc), eoff = (int)((pre2 >> 21) & kM21);
+          const int cnt[4] = {c.x, c.y, c.z, c.w};
+          int ci = 0, qi = 0, st = nd.start;
+#pragma unroll
+          for (int ch = 0; ch < 4; ch++) {
+            if (cnt[ch] > 0) {
+              const int pos = basep + (kc - 1 - ci);
+              const QNode cn = child_node(nd, ch, st, cnt[ch]);
+              LB[pos] = cn;
+              if (cnt[ch] > 1) { EB[eoff + qi] = expand_elem(cn, pos); qi++; }
+              ci++;
+            }
+            st += cnt[ch];
+          }
+        }
+        const bool keep = t < nL && !flag[t];
+        const unsigned long long pre3 = block_scan1(keep ? 1ull : 0ull, wt, spar, tot3);
+        spar ^= 1;
+        if (keep) LB[front + (int)pre3] = LA[t];
+        __syncthreads();
+        { QNode* tl = LA; LA = LB; LB = tl; }
+        { unsigned long long* te = EA; EA = EB; EB = te; }
+        nL = front + (int)tot3;
+        nE = qtot;
+        if (nL >= N || nL == prevSize) finish = true;
+        QT_ACC(3);
+        continue;
+      }
+      // child counts of every expandable node: a thread walks a small node's points, the few large ones are listed (in EB, free
+      // until the children are created) and take a wave each
+      if (t == 0) sh_cnt[0] = 0;
+      __syncthreads();
+      for (int j = t; j < m; j += T) {
+        const QNode nd = LA[(uint32_t)EA[j]];
+        if (nd.count <= kQtThreadNode) kids[j] = thread_split_count(nd, cur);
+        else big[atomicAdd(&sh_cnt[0], 1)] = j;
+      }
+      for (int i = t; i < nL; i += T) flag[i] = 0;
+      __syncthreads();
+      const int nbig = sh_cnt[0];
+      for (int b = w; b < nbig; b += NW) {
+        const int j = big[b];
         const int4 c = wave_split(LA[(uint32_t)EA[j]], cur, nxt, false);
         if (lane == 0) kids[j] = c;
       }
-      for (int i = t; i < nL; i += T) flag[i] = 0;
       __syncthreads();
       // jstar = the sorted position at which the reference stops splitting (it walks j = m-1 down and stops as soon as
       // the list would hold >= N nodes, :746-751): the inclusive prefix over r = m-1-j of (children - 1) is monotone,
@@ -852,8 +1423,14 @@ __device__ __forceinline__ void quadtree_body(const DeviceGeom* __restrict__ g, 
       __syncthreads();
       // only the processed nodes move points: partition into the scratch buffer, then copy the segment back in place
       // (the untouched nodes, the large majority in this phase, keep their points where they are: no buffer swap)
-      for (int jj = w; jj < mp; jj += NW) {
+      for (int jj = t; jj < mp; jj += T) {
         const QNode nd = LA[(uint32_t)EA[jstar + jj]];
+        if (nd.count <= kQtThreadNode) thread_split_scatter(nd, kids[jstar + jj], cur, nxt);
+      }
+      for (int b = w; b < nbig; b += NW) {
+        const int j = big[b];
+        if (j < jstar) continue;  // wave-uniform
+        const QNode nd = LA[(uint32_t)EA[j]];
         wave_split(nd, cur, nxt, true);
         wave_lds_sync();
         for (int e = lane; e < nd.count; e += 64) cur[nd.start + e] = nxt[nd.start + e];
@@ -947,18 +1524,21 @@ __device__ __forceinline__ void quadtree_main(const DeviceGeom* __restrict__ g, 
     return;
   }
   if (!GN && n <= pts_cap)
-    quadtree_body<true>(g, cells, fcand, gcur, gnxt, lpts, lpts + pts_cap, lvl_kp, lvl_n, node_cap, scan_cap, nb, n, wt, sh_cnt, sh_jstar, level_base);
+    quadtree_body<true>(g, cells, fcand, gcur, gnxt, lpts, lpts + pts_cap, lvl_kp, lvl_n, node_cap, scan_cap, nb, n, wt, sh_cnt, sh_jstar, level_base, pts_cap);
   else
-    quadtree_body<false>(g, cells, fcand, gcur, gnxt, lpts, lpts + pts_cap, lvl_kp, lvl_n, node_cap, scan_cap, nb, n, wt, sh_cnt, sh_jstar, level_base);
+    quadtree_body<false>(g, cells, fcand, gcur, gnxt, lpts, lpts + pts_cap, lvl_kp, lvl_n, node_cap, scan_cap, nb, n, wt, sh_cnt, sh_jstar, level_base, pts_cap);
 }
 
-__global__ __launch_bounds__(512) void k_quadtree(const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
+#ifndef ORBX_QT_WPE
+#define ORBX_QT_WPE 4   // <= 128 VGPRs: four 256-thread workgroups per CU where the LDS allows it (measured best of 1, 3, 4, 5)
+#endif
+__global__ __launch_bounds__(512, ORBX_QT_WPE) void k_quadtree(const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
                                                   const uint32_t* __restrict__ cand, const int32_t* __restrict__ cell_cnt,
                                                   uint32_t* __restrict__ pts, uint32_t* __restrict__ lvl_kp,
                                                   int32_t* __restrict__ lvl_n, int node_cap, int scan_cap, int pts_cap, int level_base,
                                                   uint8_t* __restrict__ gnodes, long long gnode_stride) {
   extern __shared__ __align__(16) uint8_t smem[];
-  __shared__ unsigned long long wt[8];
+  __shared__ unsigned long long wt[16];   // block_excl_scan uses the first 8, block_scan1 alternates between the halves
   __shared__ int sh_cnt[kMaxRoots];
   __shared__ int sh_jstar;
   // LDS carve-up (see quadtree_body): LA, LB, EA, EB, scan, kids, flag, then the two LDS point buffers
@@ -969,6 +1549,18 @@ __global__ __launch_bounds__(512) void k_quadtree(const DeviceGeom* __restrict__
     uint8_t* nb = gnodes + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * gnode_stride;
     quadtree_main<true>(g, cells, cand, cell_cnt, pts, lvl_kp, lvl_n, node_cap, scan_cap, 0, level_base, nb, (uint32_t*)nullptr, wt, sh_cnt, &sh_jstar);
   }
+}
+
+// Test hook: block_gnu_sort on caller data (n <= 2048), one workgroup.
+__global__ __launch_bounds__(512) void k_debug_gnu_sort(unsigned long long* __restrict__ data, int n) {
+  __shared__ unsigned long long sv[2048], stmp[2048], sq[2 * (2048 / 16 + 2)];
+  __shared__ uint32_t sseg[2048];
+  __shared__ uint16_t sidx[4096];
+  __shared__ int scnt;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) sv[i] = data[i];
+  __syncthreads();
+  block_gnu_sort(sv, n, stmp, sseg, sq, sq + (2048 / 16 + 2), sidx, &scnt);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) data[i] = sv[i];
 }
 
 // ------------------------------------------------------------------------------------------------

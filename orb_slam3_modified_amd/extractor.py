@@ -166,6 +166,12 @@ class ORBextractor:
         check(self._L.orbx_debug_trig(self._ctx, ptr(y), ptr(xx), n, int(x is None), ptr(ang), ptr(a), ptr(b)), self._ctx)
         return ang[:n], a[:n], b[:n]
 
+    def debug_gnu_sort(self, elems: np.ndarray, threads: int = 256) -> np.ndarray:
+        """Test hook: the kernel's workgroup-parallel restatement of libstdc++'s std::sort on 64-bit (key << 32 | payload) words."""
+        v = np.ascontiguousarray(elems, np.uint64).copy()
+        check(self._L.orbx_debug_gnu_sort(self._ctx, ptr(v), len(v), int(threads)), self._ctx)
+        return v
+
     def debug_trig_hash(self, first_bits: int, count: int) -> int:
         """Digest of the device (cos, sin)(angle * pi/180) over `count` consecutive float bit patterns (exhaustive test hook)."""
         h = C.c_uint64(0)

@@ -439,3 +439,47 @@ def test_resize_ingestion_equals_oracle(src, dst):
     sub = np.ascontiguousarray(img[:, :src[1] - 8][:, 3:])
     small2 = po.cv_resize(sub, dst[1] - 16, dst[0])
     assert_same(res2, po.OracleExtractor(1000, 1.2, 8, 20, 7).extract(small2, (0, 1000)), "strided source")
+
+
+def test_device_std_sort_restatement_equals_the_host_permutation():
+    """The quadtree kernel's workgroup-parallel std::sort (level-synchronous introsort for long segments, one wave in registers for
+    segments of <= 65 elements, stable rank inside the final <= 16-element segments) against csrc/gnu_sort.h run on the host —
+    which tests/test_support_models.py checks against the host's own std::sort: identical permutation, ties included, on the
+    adversarial shapes of that test (few distinct keys, runs, organ pipes, median-of-3 killers that reach the heapsort fallback)."""
+    import ctypes as C
+    from tests.test_support_models import _model
+    L = _model()
+    ex = ORBextractor(500, 1.2, 4, 20, 7)
+    rng = np.random.default_rng(5)
+
+    def killer(n):
+        v = np.zeros(n, np.int64)
+        k = n // 2
+        for i in range(1, k + 1):
+            if i % 2:
+                v[i - 1] = i
+                if i < n: v[i] = k + i
+            if k + i - 1 < n: v[k + i - 1] = 2 * i
+        return v
+
+    cases = 0
+    for rep in range(260):
+        n = int(rng.integers(0, 90)) if rep < 120 else int(rng.integers(0, 400)) if rep < 220 else int(rng.integers(400, 2049))
+        kc, kx = int(rng.integers(1, 7)), int(rng.integers(1, 9))
+        mode = rep % 6
+        i = np.arange(n)
+        c = 2 + rng.integers(0, kc, n)
+        x = rng.integers(0, kx, n) * 37
+        if mode == 1: c = 2 + i * kc // max(n, 1)
+        if mode == 2: c = 2 + (n - i) * kc // max(n, 1)
+        if mode == 3: c = 2 + np.minimum(i, n - i) % (kc + 1)
+        if mode == 4: c, x = 2 + killer(n), np.zeros(n, np.int64)
+        key = (c.astype(np.uint64) << np.uint64(13)) | x.astype(np.uint64)
+        v = (key << np.uint64(32)) | i.astype(np.uint64)
+        want = np.ascontiguousarray(v).copy()
+        L.qtm_sort(want.ctypes.data_as(C.c_void_p), C.c_int(n))
+        for threads in ((64, 256, 512) if rep % 3 == 0 else (256,)):
+            got = ex.debug_gnu_sort(v, threads)
+            assert np.array_equal(got, want), (rep, n, mode, threads, int(np.flatnonzero(got != want)[0]))
+        cases += 1
+    assert cases == 260

@@ -12,8 +12,16 @@ buf = (C.c_longlong * (16 * 8))()
 L.orbx_debug_qt_profile(ex._ctx, buf, 1)
 ex.extract_batch(frames, (0, 1000))
 L.orbx_debug_qt_profile(ex._ctx, buf, 1)
-a = np.array(buf[:]).reshape(16, 8)[:8, :5]
-print("cycles (100 MHz wall clock -> x10 ns): gather, full passes, sort, sorted rest, final")
+a = np.array(buf[:]).reshape(16, 8)[:8, :8]
+print("cycles (100 MHz wall clock -> x10 ns): gather, full passes, sort, sorted rest, final | sort: rounds, final rank, number of sorts")
 print(a * 10 / 1000.0, "us")
+one = frames[:1]
+ex.extract_batch(one, (0, 1000))
+L.orbx_debug_qt_profile(ex._ctx, buf, 1)
+ex.extract_batch(one, (0, 1000))
+L.orbx_debug_qt_profile(ex._ctx, buf, 1)
+b = np.array(buf[:]).reshape(16, 8)[:8, :8]
+print("single frame:")
+print(b * 10 / 1000.0, "us")
 for l in range(8):
     print(l, len(ex.debug_level_points(l, 0)[0]), len(ex.debug_level_points(l, 1)[0]))
