@@ -297,7 +297,6 @@ __global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__
     const int nit = dh * ng;
     const uint32_t magic = (65536u + (uint32_t)ng - 1u) / (uint32_t)ng;  // i / ng == (i * magic) >> 16 for i < 65536 / ng
     for (int i0 = 0; i0 < nit; i0 += T) {
-      if (i0 + (wv << 6) >= nit) break;  // wave-uniform: the remainder trip (nit is rarely a multiple of T) costs only the waves it reaches
       const int act = (i0 + t) < nit;
       const int i = act ? i0 + t : nit - 1;
       const int ry = (int)(mul_u24((uint32_t)i, magic) >> 16);   // i < 2^16, magic <= 2^16
