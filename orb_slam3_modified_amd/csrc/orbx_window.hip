@@ -44,7 +44,8 @@ struct WinArgs {
   int pool_cap;
   int32_t* total;      // [0] candidates of all queries (also when the pool is too small: the host then reports the capacity needed),
                        // [1] queries finished; both zeroed by the input upload
-  int32_t* out_hdr;    // the wave that finishes last copies the total here, so that header + records + pool leave in ONE copy
+  int32_t* out_hdr;    // the wave that finishes last copies the total here (and sets word 1), so that header + records + pool leave in ONE copy
+  int host_out;        // out / pool / out_hdr are mapped host memory
   int compact;         // 1: only {start, count} per query are written (the caller did not ask for best / second)
 };
 
@@ -174,9 +175,17 @@ __global__ __launch_bounds__(256) void k_window(const WinArgs a) {
       o.pad0 = o.pad1 = 0;
       a.out[q] = o;
     }
-    // the query that finishes last publishes the total (its own atomicAdd on the total is ordered before this counter)
-    __threadfence();
-    if (atomicAdd(a.total + 1, 1) == a.nq - 1) { __threadfence(); a.out_hdr[0] = atomicAdd(a.total, 0); }
+    // the query that finishes last publishes the total (its own atomicAdd on the total is ordered before this counter).  The
+    // records and the pool may live in mapped host memory (a.host_out): every wave makes its stores visible to the host before
+    // it counts itself, and the last one sets the done flag in the same 8-byte store as the total — the host polls that word
+    // instead of waiting for a copy and a stream synchronisation.
+    if (a.host_out) __threadfence_system(); else __threadfence();
+    if (atomicAdd(a.total + 1, 1) == a.nq - 1) {
+      __threadfence();
+      const unsigned long long hdr = (unsigned long long)(uint32_t)atomicAdd(a.total, 0) | 1ull << 32;
+      if (a.host_out) { __atomic_store_n((unsigned long long*)a.out_hdr, hdr, __ATOMIC_RELEASE); __threadfence_system(); }
+      else *(unsigned long long*)a.out_hdr = hdr;
+    }
   }
 }
 
@@ -284,7 +293,8 @@ hipError_t host_stage(orbx_ctx* ctx, size_t bytes, uint8_t** p) {
     if (ctx->h_call) (void)hipHostFree(ctx->h_call);
     ctx->h_call = nullptr; ctx->h_call_bytes = 0;
     const size_t want = std::max<size_t>(bytes + bytes / 2, 1 << 20);
-    e = hipHostMalloc((void**)&ctx->h_call, want, hipHostMallocDefault);
+    e = hipHostMalloc((void**)&ctx->h_call, want, hipHostMallocMapped | hipHostMallocCoherent);   // kernels read and write it directly
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipHostMalloc((void**)&ctx->h_call, want, hipHostMallocDefault); }
     if (e != hipSuccess) return e;
     ctx->h_call_bytes = want;
   }
@@ -293,6 +303,12 @@ hipError_t host_stage(orbx_ctx* ctx, size_t bytes, uint8_t** p) {
 }
 
 typedef BlobLayout Layout;
+
+// Input blob from mapped pinned host memory into HBM, 16 bytes per lane (the window kernel gathers keypoints and descriptors at
+// random: those reads must not cross PCIe one by one).  One launch costs less than a hipMemcpyAsync of the same 100 KB.
+__global__ __launch_bounds__(256) void k_stage_in(const uint4* __restrict__ src, uint4* __restrict__ dst, int n16) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = src[i];
+}
 
 // The whole call: pack -> one H2D -> [grid assignment] -> k_window -> one D2H (+ one more for a long tail) -> scatter.
 int window_call(orbx_ctx* ctx, const char* who, const orbx_keypoint* kps, const uint8_t* desc, int n, const orbx_grid* grid,
@@ -370,7 +386,19 @@ int window_call(orbx_ctx* ctx, const char* who, const orbx_keypoint* kps, const 
   uint8_t* dout = (uint8_t*)ctx->arena.alloc(out.size, &aerr);
   ORBX_HIP(ctx, aerr);
   hipStream_t st = ctx->stream;
-  ORBX_HIP(ctx, hipMemcpyAsync(din, hin, in_upload, hipMemcpyHostToDevice, st));
+  // direct mode (default): the kernels read the input blob from, and write the results to, the mapped pinned blob; the host
+  // polls the done word.  ORBX_WINDOW_DIRECT=0 selects copies + stream synchronisation (same results; A/B and fallback).
+  static const bool direct_wanted = !(getenv("ORBX_WINDOW_DIRECT") && atoi(getenv("ORBX_WINDOW_DIRECT")) == 0);
+  uint8_t* hdev = nullptr;
+  const bool direct = direct_wanted && hipHostGetDevicePointer((void**)&hdev, h, 0) == hipSuccess && hdev != nullptr;
+  if (!direct) (void)hipGetLastError();
+  std::memset(hout + p_hdr, 0, 16);
+  if (direct) {
+    const int n16 = (int)((in_upload + 15) / 16);
+    hipLaunchKernelGGL(k_stage_in, dim3(std::min((n16 + 255) / 256, 256)), dim3(256), 0, st, (const uint4*)hdev, (uint4*)din, n16);
+  } else {
+    ORBX_HIP(ctx, hipMemcpyAsync(din, hin, in_upload, hipMemcpyHostToDevice, st));
+  }
   if (!have_grid) {
     int npad = 2;
     while (npad < n) npad <<= 1;
@@ -391,18 +419,40 @@ int window_call(orbx_ctx* ctx, const char* who, const orbx_keypoint* kps, const 
   a.kp_skip = kp_skip ? din + o_skip : nullptr;
   a.kp_uright = kp_uright ? (const float*)(din + o_ur) : nullptr;
   a.inv_sigma2 = inv_sigma2 ? (const float*)(din + o_sig) : nullptr;
-  a.out = (WinQueryOut*)(dout + p_q); a.pool = (int2*)(dout + p_pool); a.pool_cap = pool_cap; a.total = (int32_t*)(din + o_total);
-  a.out_hdr = (int32_t*)(dout + p_hdr); a.compact = compact ? 1 : 0;
+  uint8_t* const res = direct ? hdev + in.size : dout;
+  a.out = (WinQueryOut*)(res + p_q); a.pool = (int2*)(res + p_pool); a.pool_cap = pool_cap; a.total = (int32_t*)(din + o_total);
+  a.out_hdr = (int32_t*)(res + p_hdr); a.compact = compact ? 1 : 0; a.host_out = direct ? 1 : 0;
   const dim3 gridDim((nq + 3) / 4), block(256);
   if (inv_sigma2) hipLaunchKernelGGL((k_window<false, true>), gridDim, block, 0, st, a);
   else if (lists) hipLaunchKernelGGL((k_window<true, false>), gridDim, block, 0, st, a);
   else hipLaunchKernelGGL((k_window<false, false>), gridDim, block, 0, st, a);
   ORBX_HIP(ctx, hipGetLastError());
   // ---- results: header + per-query records + the head of the pool in one copy; a long tail in a second one
-  const int guess = std::min(pool_cap, ctx->win_guess > 0 ? ctx->win_guess : 2048);
-  ORBX_HIP(ctx, hipMemcpyAsync(hout, dout, p_pool + 8 * (size_t)guess, hipMemcpyDeviceToHost, st));
-  const double us_issue = since(tr0);
-  ORBX_HIP(ctx, hipStreamSynchronize(st));
+  const int guess = direct ? pool_cap : std::min(pool_cap, ctx->win_guess > 0 ? ctx->win_guess : 2048);
+  double us_issue;
+  if (direct) {
+    us_issue = since(tr0);
+    // poll the done word; look at the stream now and then so that a failed launch or a device fault ends the wait
+    const volatile unsigned long long* hdr = (const volatile unsigned long long*)(hout + p_hdr);
+    for (unsigned spin = 1;; spin++) {
+      if (__atomic_load_n(hdr, __ATOMIC_ACQUIRE) >> 32) break;
+      if ((spin & 0x3fff) == 0) {
+        const hipError_t qe = hipStreamQuery(st);
+        if (qe == hipSuccess) {   // everything retired: the word must be there now
+          if (__atomic_load_n(hdr, __ATOMIC_ACQUIRE) >> 32) break;
+          return set_err(ctx, ORBX_E_DEVICE, std::string(who) + ": window pass finished without publishing its results");
+        }
+        if (qe != hipErrorNotReady) { ORBX_HIP(ctx, qe); }
+      }
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+  } else {
+    ORBX_HIP(ctx, hipMemcpyAsync(hout, dout, p_pool + 8 * (size_t)guess, hipMemcpyDeviceToHost, st));
+    us_issue = since(tr0);
+    ORBX_HIP(ctx, hipStreamSynchronize(st));
+  }
   const double us_sync = since(tr0);
   const int total = *(const int32_t*)(hout + p_hdr);
   const WinQueryOut* qo = (const WinQueryOut*)(hout + p_q);

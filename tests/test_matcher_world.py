@@ -59,3 +59,40 @@ def test_dropin_on_gpu_equals_reference(tmp_path):
     exe = wu.build_adapter_world("orbx")
     out = wu.run_world(exe, world, str(tmp_path / "gpu.txt"))
     assert out == gold, wu.first_difference(gold, out)
+
+
+# Other worlds than the committed golden one: image shapes, feature counts, view spacings and seeds the golden does not have.
+# There is no committed output for these — the reference's own file (oracle/_ref/ref_matcher_world, which travels to the GPU
+# box as a built binary) is run on the same world next to the drop-in.
+OTHER_WORLDS = [
+    dict(rows=480, cols=640, nfeatures=700, steps=(0, 1, 3, 5), seed=7),
+    dict(rows=376, cols=1241, nfeatures=1500, steps=(0, 3, 5, 8), seed=11),     # KITTI aspect: three quadtree roots, dense frames
+    dict(rows=512, cols=512, nfeatures=400, steps=(0, 2, 3, 4), seed=3),         # sparse frames, small windows
+]
+
+
+def _other_world(tmp_path, kw):
+    if not os.path.exists(wu.REF_EXE):
+        pytest.skip("oracle/_ref/ref_matcher_world not built (needs /root/reference)")
+    world = str(tmp_path / "world.bin")
+    wu.write_world(world, **kw)
+    ref = wu.run_world(wu.REF_EXE, world, str(tmp_path / "ref.txt"))
+    records = [l for l in ref.splitlines() if not l.startswith("  ")]
+    assert len(records) >= 45 and all("EXCEPTION" not in r for r in records)
+    assert sum(int(r.split("ret=")[1]) > 0 for r in records) >= 40   # the world exercises (nearly) every routine
+    return world, ref
+
+
+@pytest.mark.parametrize("kw", OTHER_WORLDS, ids=lambda kw: f"{kw['cols']}x{kw['rows']}-{kw['nfeatures']}")
+def test_dropin_host_logic_equals_reference_on_other_worlds(tmp_path, kw):
+    world, ref = _other_world(tmp_path, kw)
+    out = wu.run_world(wu.build_adapter_world("oracle"), world, str(tmp_path / "cpu.txt"))
+    assert out == ref, wu.first_difference(ref, out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", OTHER_WORLDS, ids=lambda kw: f"{kw['cols']}x{kw['rows']}-{kw['nfeatures']}")
+def test_dropin_on_gpu_equals_reference_on_other_worlds(tmp_path, kw):
+    world, ref = _other_world(tmp_path, kw)
+    out = wu.run_world(wu.build_adapter_world("orbx"), world, str(tmp_path / "gpu.txt"))
+    assert out == ref, wu.first_difference(ref, out)
