@@ -10,6 +10,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <functional>
 #include <new>
@@ -353,7 +354,9 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
                        ctx->ini_th, ctx->min_th, tile_rows, nitems, cell_base, ncells_sub, div_magic((uint32_t)ncells_sub), ctx->fast_stop);
   };
   const int ncells0 = geo.lv[0].ncells, ncells_all = (int)geo.cells.size();
-  // small batches (the single-frame operator() path) are latency-bound: a stream fork costs more than it hides there
+  // small batches (the single-frame operator() path) are latency-bound: a stream fork costs more than it hides there — also
+  // inside the captured graph, where the runtime pays for a multi-stream graph on the host (measured: launch call 8 -> 56 us,
+  // operator() 0.175 -> 0.187 ms with level-0 FAST and the blur on side branches)
   const bool small_batch = nframes * geo.nlevels <= 512;
   // every aux stream forked off `st` below is joined back into it when this function returns — also on an error return, so
   // that a caller's stream capture stays valid and no buffer is reused while forked work is pending
@@ -789,12 +792,19 @@ static int extract_one_graph(orbx_ctx* ctx, const uint8_t* img, int rows, int co
     }
     std::memcpy(ctx->graph_key, key, sizeof(key));
   }
+  static const bool trace = getenv("ORBX_TRACE_EXTRACT") != nullptr;   // phase times of every call on stderr (diagnostics)
+  const auto tr0 = std::chrono::steady_clock::now();
+  auto since = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr0).count(); };
   if (row_stride == (size_t)cols) std::memcpy(ctx->h_in, img, in_bytes);
   else for (int r = 0; r < rows; r++) std::memcpy(ctx->h_in + (size_t)r * cols, img + (size_t)r * row_stride, (size_t)cols);
+  const double us_in = since();
   ctx->last_imgs = ctx->d_stage_img; ctx->last_row_stride = pitch; ctx->last_frame_stride = fbytes; ctx->last_nframes = 1;
   ctx->h_pyr_valid = false;
   ORBX_HIP(ctx, hipGraphLaunch(ctx->graph_exec, st));
+  const double us_launch = since();
   ORBX_HIP(ctx, hipStreamSynchronize(st));
+  if (trace) std::fprintf(stderr, "[orbx extract] %dx%d: image into the pinned buffer %.1f us, graph launch %.1f, wait %.1f\n", cols, rows, us_in,
+                          us_launch - us_in, since() - us_launch);
   ctx->h_pyr_valid = keep && ctx->geo.pyr_bytes > 0;
   return 1;
 }
