@@ -183,9 +183,26 @@ def kernel_roofline(ex, eng, frames, B, H, W, counts, world, steps, dt, nprof=5)
     dom_ms = per_kernel[dom]
     dom_bytes = staged[dom] * B
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+    # the bandwidth a plain device copy reaches on this GPU, as a second denominator next to the 8 TB/s of the spec
+    copy_gbs = None
+    try:
+        nb = 1 << 29
+        src = torch.empty(nb, dtype=torch.uint8, device=frames.device); dst = torch.empty_like(src); src.zero_()
+        st = torch.cuda.current_stream().cuda_stream
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for it in range(4):
+            if it == 1: e0.record()
+            ex.debug_calib_copy(src.data_ptr(), dst.data_ptr(), nb, 16, st)
+        e1.record(); torch.cuda.synchronize()
+        copy_gbs = 2.0 * nb * 3 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
+    except Exception:   # noqa: BLE001 — a diagnostic, never a reason to lose the bench line
+        copy_gbs = None
     return dom, nkp, fused, {
         "bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+        "device_copy_GBs": None if copy_gbs is None else round(copy_gbs, 1),
+        "frac_of_device_copy": None if not copy_gbs else round(achieved / copy_gbs, 5),
         "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4), "frames_per_launch": B,
         "launch_conditions": "whole per-GPU batch in one launch, kernels back to back (passes after the timed region)",
         "pipeline_fused_ideal_bytes_per_frame": int(fused),
