@@ -188,12 +188,13 @@ def kernel_roofline(ex, eng, frames, B, H, W, counts, world, steps, dt, nprof=5)
     try:
         nb = 1 << 29
         src = torch.empty(nb, dtype=torch.uint8, device=frames.device); dst = torch.empty_like(src); src.zero_()
-        st = torch.cuda.current_stream().cuda_stream
+        torch.cuda.synchronize()
+        cs = torch.cuda.Stream()   # an explicit stream: handle 0 would mean "the context's own stream" to the C ABI
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for it in range(4):
-            if it == 1: e0.record()
-            ex.debug_calib_copy(src.data_ptr(), dst.data_ptr(), nb, 16, st)
-        e1.record(); torch.cuda.synchronize()
+            if it == 1: e0.record(cs)
+            ex.debug_calib_copy(src.data_ptr(), dst.data_ptr(), nb, 16, cs.cuda_stream)
+        e1.record(cs); torch.cuda.synchronize()
         copy_gbs = 2.0 * nb * 3 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del src, dst
     except Exception:   # noqa: BLE001 — a diagnostic, never a reason to lose the bench line

@@ -334,24 +334,60 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
   // context (no gain: both kernels fill the CUs); the replay lanes switch it on (orbx_set_option), where it pays.
   const int need = geo.max_cell_w + 3;  // +3: alignment shift of the dword-staged rows
   const int pitchB = need <= 64 ? 64 : 96;
-  const int tile_rows = geo.max_cell_h;
-  const int list_cap = round_up((geo.max_cell_w - 6) * (geo.max_cell_h - 6), 8);
-  if (need > 96 || geo.max_cell_h > 127 + 6 || list_cap > 8192)
+  if (need > 96 || geo.max_cell_h > 127 + 6 || round_up((geo.max_cell_w - 6) * (geo.max_cell_h - 6), 8) > 8192)
     return set_err(ctx, ORBX_E_CAPACITY, "FAST cell larger than the kernel's LDS tile");
   if (!div_ok((uint64_t)geo.cells.size() * nframes + 8, geo.cells.size()) ||
       !div_ok((uint64_t)geo.btiles_total * nframes + 8, geo.btiles_total))
     return set_err(ctx, ORBX_E_CAPACITY, "batch too large for 32-bit tile indexing");
-  const size_t fast_lds = 16 + (size_t)pitchB * tile_rows * 2 + (size_t)list_cap * 2;
   const int ft = ctx->fast_threads;
+  // LDS of a FAST workgroup over cells [c0, c1): tile + score plane of the tallest cell, list for the largest detection domain,
+  // bitmap + word prefix (64 words up to 2048 pixels, 256 beyond)
+  struct FastLds { int tile_rows, list_cap, nwords; size_t bytes; };
+  auto fast_lds_of = [&](int c0, int c1) {
+    FastLds f{1, 8, 64, 0};
+    for (int c = c0; c < c1; c++) {
+      const CellGeom& cg = geo.cells[c];
+      f.tile_rows = std::max(f.tile_rows, (int)cg.ch);
+      const int npx = (cg.cw - 6) * (cg.ch - 6);
+      f.list_cap = std::max(f.list_cap, round_up(npx, 8));
+      if (npx > 2048) f.nwords = 256;
+    }
+    f.bytes = 16 + (size_t)pitchB * f.tile_rows * 2 + (size_t)f.list_cap * 2 + (size_t)f.nwords * 8;
+    return f;
+  };
   auto fast_kern = pitchB == 64 ? (ft == 64 ? k_fast_cells<64, 64> : ft == 128 ? k_fast_cells<128, 64> : k_fast_cells<256, 64>)
                                 : (ft == 64 ? k_fast_cells<64, 96> : ft == 128 ? k_fast_cells<128, 96> : k_fast_cells<256, 96>);
   if (ctx->fast_pk && ft == 128) fast_kern = pitchB == 64 ? k_fast_cells<128, 64, true> : k_fast_cells<128, 96, true>;
-  auto launch_fast = [&](int cell_base, int ncells_sub, hipStream_t s) {
+  auto launch_fast_range = [&](int cell_base, int ncells_sub, hipStream_t s) {
     const int nitems = ncells_sub * nframes;
     if (nitems <= 0) return;
-    hipLaunchKernelGGL(fast_kern, dim3(xcd_grid(nitems)), dim3(ft), fast_lds, s, ctx->d_geo, ctx->d_cells, d_imgs,
+    const FastLds f = fast_lds_of(cell_base, cell_base + ncells_sub);
+    hipLaunchKernelGGL(fast_kern, dim3(xcd_grid(nitems)), dim3(ft), f.bytes, s, ctx->d_geo, ctx->d_cells, d_imgs,
                        (long long)row_stride, (long long)frame_stride, b_pyr, (long long)geo.pyr_bytes, b_cand, b_cell_cnt,
-                       ctx->ini_th, ctx->min_th, tile_rows, nitems, cell_base, ncells_sub, div_magic((uint32_t)ncells_sub), ctx->fast_stop);
+                       ctx->ini_th, ctx->min_th, f.tile_rows, nitems, cell_base, ncells_sub, div_magic((uint32_t)ncells_sub), ctx->fast_stop,
+                       f.list_cap, f.nwords);
+  };
+  // The cells of the small levels are taller (fewer rows of cells share the same height): one launch over all levels would give
+  // every workgroup the LDS of the tallest cell and cost the many cells of the large levels their residency.  A range of cells
+  // is therefore split once, at the level boundary that maximises (cells x workgroups per CU), when that gains >= 5 %
+  // (batch calls only: a single frame is bound by the number of launches).
+  auto wgs_per_cu = [&](size_t bytes) { return (int)std::min<size_t>(32 / (ft / 64), (160 * 1024) / (bytes + 64 + 512)); };
+  auto launch_fast = [&](int cell_base, int ncells_sub, hipStream_t s) {
+    const int cend = cell_base + ncells_sub;
+    int best_split = -1;
+    if (nframes * geo.nlevels > 512 && ctx->fast_split) {
+      const long whole = (long)ncells_sub * wgs_per_cu(fast_lds_of(cell_base, cend).bytes);
+      long best = whole + whole / 20;
+      for (int l = 0; l + 1 < geo.nlevels; l++) {
+        const int b = geo.lv[l].cell_begin + geo.lv[l].ncells;   // first cell of level l + 1
+        if (b <= cell_base || b >= cend) continue;
+        const long sc = (long)(b - cell_base) * wgs_per_cu(fast_lds_of(cell_base, b).bytes) + (long)(cend - b) * wgs_per_cu(fast_lds_of(b, cend).bytes);
+        if (sc > best) { best = sc; best_split = b; }
+      }
+    }
+    if (best_split < 0) { launch_fast_range(cell_base, ncells_sub, s); return; }
+    launch_fast_range(cell_base, best_split - cell_base, s);
+    launch_fast_range(best_split, cend - best_split, s);
   };
   const int ncells0 = geo.lv[0].ncells, ncells_all = (int)geo.cells.size();
   // small batches (the single-frame operator() path) are latency-bound: a stream fork costs more than it hides there — also
@@ -571,6 +607,7 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, 
     }
   }
   ctx->fast_threads = fast_threads_from_env();
+  { const char* e = getenv("ORBX_FAST_SPLIT"); ctx->fast_split = e ? atoi(e) != 0 : true; }
   { const char* e = getenv("ORBX_QT_THREADS"); const int v = e ? atoi(e) : 0; ctx->qt_threads = (v == 64 || v == 128 || v == 256 || v == 512) ? v : 0; }
   {
     const char* e = getenv("ORBX_DESC_K");  // keypoints per wave of k_describe (tuning knob)
@@ -1034,6 +1071,7 @@ int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
   else if (n == "fork_qt") ctx->fork_qt = value != 0;
   else if (n == "graph") ctx->use_graph = value != 0;
   else if (n == "fast_pk") ctx->fast_pk = value != 0;
+  else if (n == "fast_split") ctx->fast_split = value != 0;   // FAST launched per group of levels with its own LDS size (batch calls)
   else if (n == "fast_stop") ctx->fast_stop = value;   // timing experiment: FAST returns after staging (1) / after the necessary test (2); results are void
   else if (n == "desc_lds") ctx->desc_lds = value != 0;
   else if (n == "fast_threads" && (value == 64 || value == 128 || value == 256)) ctx->fast_threads = value;

@@ -138,6 +138,7 @@ struct orbx_ctx {
   int out_cap;  // nfeatures + 3*nlevels
   int fast_threads = 128;  // workgroup size of k_fast_cells
   int qt_threads = 0;      // workgroup size of k_quadtree (0: by batch size)
+  bool fast_split = true;  // k_fast_cells launched per group of levels, each with its own LDS footprint
   int desc_k = 8;          // keypoints per wave of k_describe
 
   hipStream_t stream = nullptr;

@@ -240,16 +240,19 @@ __global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__
                                                   long long img_frame_stride, const uint8_t* __restrict__ pyr,
                                                   long long pyr_frame_bytes, uint32_t* __restrict__ cand,
                                                   int32_t* __restrict__ cell_cnt, int ini_th, int min_th, int tile_rows,
-                                                  int nitems, int cell_base, int ncells_sub, uint32_t m_ncells_sub, int stop_after) {
+                                                  int nitems, int cell_base, int ncells_sub, uint32_t m_ncells_sub, int stop_after,
+                                                  int list_cap, int nwords) {
   // LDS: [16 B pad][tile_rows][PITCH] raw pixels (+ alignment shift xo) | [tile_rows][PITCH] scores with a 1-px
-  // zero frame | list.  PITCH is a compile-time constant so every circle / neighbour access is an immediate offset.
+  // zero frame | list | bitmap | word prefix.  PITCH is a compile-time constant so every circle / neighbour access is an
+  // immediate offset.  Everything is sized by the launch for the cells it covers (tile_rows, list_cap, nwords = 64 or 256): the
+  // LDS footprint of a workgroup decides how many of them a CU holds, and this kernel lives on residency.
   extern __shared__ __align__(16) uint8_t smem[];
   uint8_t* tile = smem + 16;
   uint8_t* sc = tile + tile_rows * PITCH;
   uint16_t* list = (uint16_t*)(sc + tile_rows * PITCH);  // candidate pixels (bit 15: NMS survivor)
+  uint32_t* bitmap = (uint32_t*)(list + list_cap);        // list_cap is a multiple of 8
+  int* wpre = (int*)(bitmap + nwords);
   constexpr int NW = T / 64, WPT = 256 / T, P4 = PITCH / 4;
-  __shared__ uint32_t bitmap[256];
-  __shared__ int wpre[256];
   __shared__ int wave_tot[NW];
   __shared__ int s_cnt;
 
@@ -283,8 +286,7 @@ __global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__
     }
   }
   for (int i = t; i < ((dh + 2) * P4 + 3) >> 2; i += T) ((uint4*)sc)[i] = make_uint4(0u, 0u, 0u, 0u);  // sc is 16-byte aligned
-#pragma unroll
-  for (int k = 0; k < WPT; k++) bitmap[t * WPT + k] = 0;
+  for (int i = t; i < nwords; i += T) bitmap[i] = 0;
   if (t == 0) s_cnt = 0;
   __syncthreads();
   if (stop_after == 1) {   // timing experiment only ("fast_stop" option): the cell reports no keypoint
