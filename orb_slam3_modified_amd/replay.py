@@ -97,11 +97,13 @@ class ReplayEngine:
         self.exs = [extractor] + [extractor.clone() for _ in self.lane_ranges[1:]]
         if len(self.lane_ranges) > 1:
             # with a second lane filling the idle issue slots, the in-lane forks that pay are different from the single-lane
-            # ones (measured, 2 lanes x 128 frames: blur in line, level-0 FAST beside the pyramid chain, quadtree levels
-            # split: 1.095 ms vs 1.17 ms with the single-lane defaults); ORBX_* environment variables still win
+            # ones.  Measured on all eight combinations, 2 lanes x 128 frames, three repetitions (round 2, after FAST reached
+            # full residency): blur forked behind FAST + level-0 FAST beside the pyramid chain + the quadtree as one launch
+            # = 0.985 ms per step against 0.999 for round 1's choice (blur in line, quadtree levels split) and 1.03 with no
+            # fork at all; ORBX_* environment variables still win
             import os
             for ex in self.exs:
-                for name, env, val in (("fork_blur", "ORBX_FORK_BLUR", 0), ("fork_fast0", "ORBX_FORK_FAST0", 1), ("fork_qt", "ORBX_FORK_QT", 1)):
+                for name, env, val in (("fork_blur", "ORBX_FORK_BLUR", 1), ("fork_fast0", "ORBX_FORK_FAST0", 1), ("fork_qt", "ORBX_FORK_QT", 0)):
                     if env not in os.environ:
                         ex.set_option(name, val)
         if dev.type == "cuda":   # buffers of every lane now, not inside the first (possibly timed) step

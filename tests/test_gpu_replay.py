@@ -61,7 +61,7 @@ def _check_every_frame(block, layout, host, ora, lap):
 
 def test_the_configuration_bench_times_is_bit_exact_on_every_frame():
     """bench.py's replay: 2 lanes x 130 frames (past the `small batch` cut-off of the in-lane forks, orbx_extractor.hip), the lanes'
-    options fork_fast0 = 1 / fork_blur = 0 / fork_qt = 1 as ReplayEngine sets them, rotating batches, several steps in flight —
+    options fork_fast0 = 1 / fork_blur = 1 / fork_qt = 0 as ReplayEngine sets them, rotating batches, several steps in flight —
     EVERY frame of the last two steps against the oracle."""
     import torch
     from oracle import pyoracle as po
@@ -100,6 +100,7 @@ def test_the_configuration_bench_times_is_bit_exact_on_every_frame():
 
 @pytest.mark.parametrize("opts", [dict(fork_fast0=1, fork_blur=0, fork_qt=0), dict(fork_fast0=0, fork_blur=1, fork_qt=0),
                                   dict(fork_fast0=0, fork_blur=0, fork_qt=1), dict(fork_fast0=1, fork_blur=1, fork_qt=1),
+                                  dict(fork_fast0=1, fork_blur=0, fork_qt=1),
                                   dict(fork_fast0=0, fork_blur=0, fork_qt=0)])
 def test_each_stream_fork_alone_is_bit_exact_on_every_frame(opts):
     """The in-context stream forks (level-0 FAST beside the pyramid chain, blur behind FAST, quadtree level groups) one at a
