@@ -1531,7 +1531,7 @@ __device__ __forceinline__ void quadtree_main(const DeviceGeom* __restrict__ g, 
 }
 
 #ifndef ORBX_QT_WPE
-#define ORBX_QT_WPE 4   // <= 128 VGPRs: four 256-thread workgroups per CU where the LDS allows it (measured best of 1, 3, 4, 5)
+#define ORBX_QT_WPE 1   // no register cap: capping at 128 VGPRs (4 waves per SIMD) is 5 % faster in a batch but spills 36 bytes to scratch, and a kernel with a private segment pays a scratch set-up on every queue that first runs it
 #endif
 __global__ __launch_bounds__(512, ORBX_QT_WPE) void k_quadtree(const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
                                                   const uint32_t* __restrict__ cand, const int32_t* __restrict__ cell_cnt,

@@ -39,20 +39,24 @@ __device__ __forceinline__ int hamming(const Desc& a, const Desc& b) {
 
 constexpr unsigned long long kNoKey = ~0ull;
 
-// keep the two smallest keys
-__device__ __forceinline__ void top2_push(unsigned long long& k1, unsigned long long& k2, unsigned long long k) {
-  if (k < k1) { k2 = k1; k1 = k; }
-  else if (k < k2) k2 = k;
+// keep the two smallest keys.  By value: with reference parameters the pair ended up in scratch memory (a private segment of
+// 24 bytes on k_nn_csr / k_knn2, and a kernel with a private segment pays a scratch set-up on every queue that first runs it).
+struct Top2 { unsigned long long k1, k2; };
+__device__ __forceinline__ Top2 top2_push(Top2 t, unsigned long long k) {
+  if (k < t.k1) { t.k2 = t.k1; t.k1 = k; }
+  else if (k < t.k2) t.k2 = k;
+  return t;
 }
-__device__ __forceinline__ void top2_wave_reduce(unsigned long long& k1, unsigned long long& k2) {
+__device__ __forceinline__ Top2 top2_wave_reduce(Top2 t) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
-    const unsigned long long p1 = __shfl_xor(k1, o), p2 = __shfl_xor(k2, o);
-    const unsigned long long lo = k1 < p1 ? k1 : p1, hi = k1 < p1 ? p1 : k1;
-    const unsigned long long s2 = k2 < p2 ? k2 : p2;
-    k1 = lo;
-    k2 = hi < s2 ? hi : s2;
+    const unsigned long long p1 = __shfl_xor(t.k1, o), p2 = __shfl_xor(t.k2, o);
+    const unsigned long long lo = t.k1 < p1 ? t.k1 : p1, hi = t.k1 < p1 ? p1 : t.k1;
+    const unsigned long long s2 = t.k2 < p2 ? t.k2 : p2;
+    t.k1 = lo;
+    t.k2 = hi < s2 ? hi : s2;
   }
+  return t;
 }
 
 // Guided NN over CSR candidate lists: one wave per query, lanes stride the candidates.
@@ -68,25 +72,28 @@ __global__ __launch_bounds__(256) void k_nn_csr(const uint8_t* __restrict__ q, i
   if (qi >= nq) return;
   const Desc dq = load_desc(q + (size_t)qi * 32);
   const int b = row_ptr[qi], e = row_ptr[qi + 1];
-  unsigned long long k1 = kNoKey, k2 = kNoKey;
+  Top2 t2{kNoKey, kNoKey};
   for (int c = b + lane; c < e; c += 64) {
     const int ti = cand[c];
     const int d = hamming(dq, load_desc(tr + (size_t)ti * 32));
     if (dist_out) dist_out[c] = d;
     const uint32_t pos = (uint32_t)(c - b);
-    top2_push(k1, k2, ((unsigned long long)d << 32) | (last_wins ? (0xffffffffu - pos) : pos));
+    t2 = top2_push(t2, ((unsigned long long)d << 32) | (last_wins ? (0xffffffffu - pos) : pos));
   }
-  top2_wave_reduce(k1, k2);
+  t2 = top2_wave_reduce(t2);
+  const unsigned long long k1 = t2.k1, k2 = t2.k2;
   if (lane == 0) {
-    auto decode = [&](unsigned long long k, int32_t* oi, int32_t* od) {
-      if (k == kNoKey) { if (oi) oi[qi] = -1; if (od) od[qi] = 256; return; }
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const unsigned long long k = r ? k2 : k1;
+      int32_t* oi = r ? second_idx : best_idx;
+      int32_t* od = r ? second_dist : best_dist;
+      if (k == kNoKey) { if (oi) oi[qi] = -1; if (od) od[qi] = 256; continue; }
       uint32_t pos = (uint32_t)k;
       if (last_wins) pos = 0xffffffffu - pos;
       if (oi) oi[qi] = cand[b + (int)pos];
       if (od) od[qi] = (int32_t)(k >> 32);
-    };
-    decode(k1, best_idx, best_dist);
-    decode(k2, second_idx, second_dist);
+    }
   }
 }
 
@@ -100,7 +107,7 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, int
   Desc dq;
   if (qi < nq) dq = load_desc(q + (size_t)qi * 32);
   else dq.w[0] = dq.w[1] = dq.w[2] = dq.w[3] = 0;
-  unsigned long long k1 = kNoKey, k2 = kNoKey;
+  Top2 t2{kNoKey, kNoKey};
   for (int t0 = 0; t0 < nt; t0 += 256) {
     const int nload = min(256, nt - t0);
     __syncthreads();
@@ -113,10 +120,11 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, int
       dt.w[1] = (unsigned long long)a.z | ((unsigned long long)a.w << 32);
       dt.w[2] = (unsigned long long)b.x | ((unsigned long long)b.y << 32);
       dt.w[3] = (unsigned long long)b.z | ((unsigned long long)b.w << 32);
-      top2_push(k1, k2, ((unsigned long long)hamming(dq, dt) << 32) | (uint32_t)(t0 + c));
+      t2 = top2_push(t2, ((unsigned long long)hamming(dq, dt) << 32) | (uint32_t)(t0 + c));
     }
   }
-  top2_wave_reduce(k1, k2);
+  t2 = top2_wave_reduce(t2);
+  const unsigned long long k1 = t2.k1, k2 = t2.k2;
   if (lane == 0 && qi < nq) {
     idx[qi * 2] = k1 == kNoKey ? -1 : (int32_t)(uint32_t)k1;
     dist[qi * 2] = k1 == kNoKey ? 256 : (int32_t)(k1 >> 32);
