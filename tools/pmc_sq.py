@@ -30,17 +30,23 @@ for k, cs in rows.items():
     lines.append(f"| {k} | " + " | ".join(f"{cs[c][0] / cs[c][1]:.4g}" if c in cs else "-" for c in order) + " |")
 import json
 derived = {}
+# "launch" = one pass of a kernel over the batch (7 level launches of the pyramid chain, the residency groups of k_fast_cells, the level
+# groups of k_quadtree summed); k_assemble runs once per pass and so counts the passes
+npass = max((cs[c][1] for k, cs in rows.items() if k.startswith("k_assemble") for c in cs), default=1)
 for k, cs in rows.items():
-    avg = {c: v[0] / v[1] for c, v in cs.items()}
+    avg = {c: v[0] / npass for c, v in cs.items()}
     if "GRBM_GUI_ACTIVE" in avg and "SQ_ACTIVE_INST_VALU" in avg:
         cyc = avg["GRBM_GUI_ACTIVE"] / 8.0                      # the counter is summed over the 8 XCDs
-        d = {"cycles_per_launch": cyc, "valu_busy": avg["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cyc)}   # quad-cycles, 1024 SIMDs
+        d = {"dispatches_per_launch": cs["GRBM_GUI_ACTIVE"][1] / npass, "cycles_per_launch": cyc,
+             "valu_busy": avg["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cyc)}   # quad-cycles, 1024 SIMDs
         if "SQ_ACTIVE_INST_LDS" in avg:
             d["lds_busy"] = avg["SQ_ACTIVE_INST_LDS"] * 4.0 / (256.0 * cyc)
         if "TA_BUSY_avr" in avg:
             d["ta_busy"] = avg["TA_BUSY_avr"] / cyc
         if "SQ_INSTS_VALU" in avg:
             d["valu_insts_per_launch"] = avg["SQ_INSTS_VALU"]
+        if "SQ_WAVE_CYCLES" in avg:
+            d["waves_per_simd"] = avg["SQ_WAVE_CYCLES"] * 4.0 / (1024.0 * cyc)   # average residency
         derived[k.split("<")[0]] = d
 json.dump({"derived": derived, "raw_per_dispatch_avg": {k: {c: v[0] / v[1] for c, v in cs.items()} for k, cs in rows.items()}},
           open(os.path.join(ROOT, "gpurun_out", "pmc_sq.json"), "w"), indent=1)

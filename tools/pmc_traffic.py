@@ -100,14 +100,13 @@ def main():
             continue
         short = n.split("::")[-1].split("<")[0]
         fv, wv = fetch.get(n, []), write.get(n, [])
-        fpl = sum(fv) / max(len(fv), 1) * 1024.0
-        wpl = sum(wv) / max(len(wv), 1) * 1024.0
-        ent = {"dispatches_per_pass": len(fv), "fetch_raw_bytes_per_launch": fpl, "write_raw_bytes_per_launch": wpl,
+        # "launch" = one pass of the kernel over the batch: the 7 level launches of the pyramid chain, the two residency groups of
+        # k_fast_cells, the two level groups of k_quadtree are summed (STEPS passes were run)
+        fpl = sum(fv) / STEPS * 1024.0
+        wpl = sum(wv) / STEPS * 1024.0
+        ent = {"dispatches_per_pass": len(fv) / STEPS, "fetch_raw_bytes_per_launch": fpl, "write_raw_bytes_per_launch": wpl,
                "fetch_bytes_per_launch": fpl * f4, "write_bytes_per_launch": wpl * w4,
                "hbm_bytes_per_launch": fpl * f4 + wpl * w4}
-        if short == "k_resize":   # 7 launches (levels 1..7) make one pyramid chain: report the chain
-            ent = {k: (v * 7 if k != "dispatches_per_pass" else v) for k, v in ent.items()}
-            ent["note"] = "sum over the 7 level launches of one batch"
         kernels[short] = ent
     res = {"batch": B, "rows": H, "cols": W, "steps": STEPS,
            "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE in separate passes; KiB -> bytes; corrected by the "
