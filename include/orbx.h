@@ -250,6 +250,32 @@ int orbx_window_search_grid(orbx_ctx* ctx, const orbx_keypoint* kps, const uint8
                             int32_t* row_ptr, int32_t* cand, int32_t* dist, int cand_cap, int32_t* best_idx, int32_t* best_dist,
                             int32_t* second_idx, int32_t* second_dist);
 
+/* A search target resident in HBM.  A Frame / KeyFrame is searched many times (Tracking: two or three calls per frame;
+ * LocalMapping / LoopClosing: every keyframe against many others) while its keypoints, descriptors and grid never change after
+ * construction: orbx_target_create uploads them ONCE (arguments as orbx_window_search_grid / orbx_window_nearest; kp_uright and
+ * inv_level_sigma2 may be NULL), orbx_target_search / orbx_target_nearest then move only the queries — no re-upload of the frame,
+ * no device-to-host copy, no stream synchronisation: one kernel that reads the queries from, and writes the results to, mapped
+ * pinned memory, the host polls a done word.  Results are those of the host-buffer entry points.  A target belongs to the context
+ * that created it (one context per thread); destroy it before the context. */
+typedef struct orbx_target orbx_target;
+int orbx_target_create(orbx_ctx* ctx, const orbx_keypoint* kps, const uint8_t* desc, int n, const orbx_grid* grid, const float* kp_uright,
+                       const float* inv_level_sigma2, int nlevels, orbx_target** target);
+/* replaces the contents of an existing target (its device block is kept when large enough: a cache of frames recycles targets
+ * without allocating) */
+int orbx_target_assign(orbx_ctx* ctx, orbx_target* target, const orbx_keypoint* kps, const uint8_t* desc, int n, const orbx_grid* grid,
+                       const float* kp_uright, const float* inv_level_sigma2, int nlevels);
+void orbx_target_destroy(orbx_target* target);
+int orbx_target_size(const orbx_target* target);   /* number of keypoints */
+/* = orbx_window_search_grid on the target; q_xr needs a target created with kp_uright */
+int orbx_target_search(orbx_ctx* ctx, const orbx_target* target, const uint8_t* kp_skip, const float* qx, const float* qy, const float* qr,
+                       const int32_t* qmin_level, const int32_t* qmax_level, const uint8_t* q_desc, const float* q_xr, int nq, int32_t* row_ptr,
+                       int32_t* cand, int32_t* dist, int cand_cap, int32_t* best_idx, int32_t* best_dist, int32_t* second_idx,
+                       int32_t* second_dist);
+/* = orbx_window_nearest on the target; reprojection_gate != 0 needs a target created with kp_uright + inv_level_sigma2, and q_ur */
+int orbx_target_nearest(orbx_ctx* ctx, const orbx_target* target, int reprojection_gate, const float* qx, const float* qy, const float* qr,
+                        const int32_t* qmin_level, const int32_t* qmax_level, const float* q_ur, const uint8_t* q_desc, int nq, int32_t* best_idx,
+                        int32_t* best_dist);
+
 /* Arg-min only — the routines whose queries are independent: Fuse x2 (src/ORBmatcher.cc:1148, :1340) and
  * SearchBySim3 (:1457) take best_idx / best_dist straight from the device, nothing is replayed.  Window + level range as
  * above; first minimum in candidate order wins; -1 / 256 without a candidate.  inv_level_sigma2 != NULL (nlevels entries,

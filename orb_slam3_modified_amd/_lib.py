@@ -75,6 +75,12 @@ def lib() -> C.CDLL:
         "orbx_window_search": (i32, [vp, vp, vp, i32, f32, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
         "orbx_window_search_grid": (i32, [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
         "orbx_window_nearest": (i32, [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]),
+        "orbx_target_create": (i32, [vp, vp, vp, i32, vp, vp, vp, i32, C.POINTER(C.c_void_p)]),
+        "orbx_target_assign": (i32, [vp, vp, vp, vp, i32, vp, vp, vp, i32]),
+        "orbx_target_destroy": (None, [vp]),
+        "orbx_target_size": (i32, [vp]),
+        "orbx_target_search": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
+        "orbx_target_nearest": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]),
         "orbx_undistort_keypoints": (i32, [vp, vp, i32, f32, f32, f32, f32, vp, i32, vp]),
         "orbx_undistort_keypoints_device": (i32, [vp, vp, vp, i32, i32, f32, f32, f32, f32, vp, i32, vp, vp]),
         "orbx_search_by_projection": (i32, [vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32,

@@ -609,6 +609,7 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, 
   }
   ctx->fast_threads = fast_threads_from_env();
   { const char* e = getenv("ORBX_FAST_SPLIT"); ctx->fast_split = e ? atoi(e) != 0 : true; }
+  { const char* e = getenv("ORBX_WINDOW_DIRECT"); ctx->window_direct = e ? atoi(e) != 0 : true; }
   { const char* e = getenv("ORBX_QT_THREADS"); const int v = e ? atoi(e) : 0; ctx->qt_threads = (v == 64 || v == 128 || v == 256 || v == 512) ? v : 0; }
   {
     const char* e = getenv("ORBX_DESC_K");  // keypoints per wave of k_describe (tuning knob)
@@ -667,6 +668,9 @@ void orbx_destroy(orbx_ctx* ctx) {
   if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
   if (ctx->h_in) { (void)hipHostFree(ctx->h_in); ctx->h_in = nullptr; }
   if (ctx->h_call) { (void)hipHostFree(ctx->h_call); ctx->h_call = nullptr; }
+  if (ctx->d_win_ctr) { (void)hipFree(ctx->d_win_ctr); ctx->d_win_ctr = nullptr; }
+  if (ctx->h_tgt) { (void)hipHostFree(ctx->h_tgt); ctx->h_tgt = nullptr; }
+  if (ctx->ev_tgt) { (void)hipEventDestroy(ctx->ev_tgt); ctx->ev_tgt = nullptr; }
   if (ctx->d_color) { (void)hipFree(ctx->d_color); ctx->d_color = nullptr; }
   if (ctx->d_ingest_tab) { (void)hipFree(ctx->d_ingest_tab); ctx->d_ingest_tab = nullptr; }
   if (ctx->h_stage_out) { (void)hipHostFree(ctx->h_stage_out); ctx->h_stage_out = nullptr; }
@@ -1072,6 +1076,7 @@ int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
   else if (n == "fork_qt") ctx->fork_qt = value != 0;
   else if (n == "graph") ctx->use_graph = value != 0;
   else if (n == "fast_pk") ctx->fast_pk = value != 0;
+  else if (n == "window_direct") ctx->window_direct = value != 0;
   else if (n == "fast_split") ctx->fast_split = value != 0;   // FAST launched per group of levels with its own LDS size (batch calls)
   else if (n == "fast_stop") ctx->fast_stop = value;   // timing experiment: FAST returns after staging (1) / after the necessary test (2); results are void
   else if (n == "desc_lds") ctx->desc_lds = value != 0;

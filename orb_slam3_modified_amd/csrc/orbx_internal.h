@@ -179,6 +179,9 @@ struct orbx_ctx {
   uint8_t* h_stage_out = nullptr;   // pinned host mirror of d_stage_out (one D2H copy per call)
   int stage_frames = 0;
   orbx::DeviceArena arena;   // scratch of the grid / search / stereo entry points
+  bool window_direct = true;   // window passes write their results into mapped pinned memory and the host polls (ORBX_WINDOW_DIRECT=0 / "window_direct": copies + sync)
+  uint8_t* h_tgt = nullptr; size_t h_tgt_bytes = 0; hipEvent_t ev_tgt = nullptr;   // pinned staging of orbx_target uploads + "staging free again"
+  int32_t* d_win_ctr = nullptr; bool win_ctr_dirty = true;   // the two self-resetting counters of resident-target window passes
   uint8_t* h_call = nullptr; size_t h_call_bytes = 0;   // pinned [inputs | outputs] blob of the window / nn entry points (orbx_window.hip)
   int win_guess = 0;            // candidates of the last window call: how much of the pool the first read-back copy takes
   // single-frame operator() path as a replayed hipGraph (H2D, the 13 launches, D2H): one graph launch per frame instead
@@ -232,6 +235,17 @@ inline hipError_t sync_ctx(orbx_ctx* ctx) {
 hipError_t ensure_dynamic_lds(const void* kernel, int bytes);
 // orbx_window.hip: pinned staging (grow-only) and the fused window pass behind orbx_window_search* / orbx_window_nearest
 hipError_t host_stage(orbx_ctx* ctx, size_t bytes, uint8_t** p);
+}  // namespace orbx
+// A Frame's / KeyFrame's keypoints, descriptors and grid resident in HBM (orbx_target_create, orbx_window.hip)
+struct orbx_target {
+  orbx_ctx* ctx = nullptr;
+  uint8_t* dev = nullptr;
+  size_t cap = 0, bytes = 0, o_kps = 0, o_desc = 0, o_ur = 0, o_sig = 0, o_cs = 0, o_ci = 0;
+  int n = 0, ngrid = 0, nlevels = 0;
+  bool has_ur = false, has_sig = false;
+  float min_x = 0, min_y = 0, inv_w = 0, inv_h = 0;
+};
+namespace orbx {
 // offsets of the pieces of one packed blob (256-byte aligned pieces)
 struct BlobLayout {
   size_t size = 0;

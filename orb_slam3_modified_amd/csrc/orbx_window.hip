@@ -46,6 +46,9 @@ struct WinArgs {
                        // [1] queries finished; both zeroed by the input upload
   int32_t* out_hdr;    // the wave that finishes last copies the total here (and sets word 1), so that header + records + pool leave in ONE copy
   int host_out;        // out / pool / out_hdr are mapped host memory
+  const uint8_t* skip_map;   // kp_skip in mapped host memory: staged into LDS by every workgroup (n_skip bytes, n_skip % 4 == 0)
+  int n_skip;
+  int self_reset;      // the last wave zeroes `total` again (resident-target calls keep the two counters in the context)
   int compact;         // 1: only {start, count} per query are written (the caller did not ask for best / second)
 };
 
@@ -72,6 +75,11 @@ constexpr unsigned long long kNoWinKey = ~0ull;
 
 template <bool LISTS, bool CHI2>
 __global__ __launch_bounds__(256) void k_window(const WinArgs a) {
+  extern __shared__ __align__(16) uint8_t lskip[];
+  if (a.skip_map) {   // block-uniform; the flags change with every call and are gathered at random: over PCIe once per workgroup, then LDS
+    for (int i = threadIdx.x * 4; i < a.n_skip; i += 256 * 4) *(uint32_t*)(lskip + i) = *(const uint32_t*)(a.skip_map + i);
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63;
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= a.nq) return;
@@ -97,7 +105,7 @@ __global__ __launch_bounds__(256) void k_window(const WinArgs a) {
       if (maxLevel >= 0 && octave > maxLevel) ok = false;
     }
     ok = ok && fabsf(__fsub_rn(kx, x)) < r && fabsf(__fsub_rn(ky, y)) < r;
-    if (a.kp_skip && a.kp_skip[idx]) ok = false;
+    if (a.skip_map ? lskip[idx] != 0 : (a.kp_skip && a.kp_skip[idx])) ok = false;
     if (CHI2) {
       if (ok) {
         const float ur = a.kp_uright[idx];
@@ -183,6 +191,7 @@ __global__ __launch_bounds__(256) void k_window(const WinArgs a) {
     if (atomicAdd(a.total + 1, 1) == a.nq - 1) {
       __threadfence();
       const unsigned long long hdr = (unsigned long long)(uint32_t)atomicAdd(a.total, 0) | 1ull << 32;
+      if (a.self_reset) { a.total[0] = 0; a.total[1] = 0; __threadfence(); }   // every other wave has left the counters
       if (a.host_out) { __atomic_store_n((unsigned long long*)a.out_hdr, hdr, __ATOMIC_RELEASE); __threadfence_system(); }
       else *(unsigned long long*)a.out_hdr = hdr;
     }
@@ -388,7 +397,7 @@ int window_call(orbx_ctx* ctx, const char* who, const orbx_keypoint* kps, const 
   hipStream_t st = ctx->stream;
   // direct mode (default): the kernels read the input blob from, and write the results to, the mapped pinned blob; the host
   // polls the done word.  ORBX_WINDOW_DIRECT=0 selects copies + stream synchronisation (same results; A/B and fallback).
-  static const bool direct_wanted = !(getenv("ORBX_WINDOW_DIRECT") && atoi(getenv("ORBX_WINDOW_DIRECT")) == 0);
+  const bool direct_wanted = ctx->window_direct;
   uint8_t* hdev = nullptr;
   const bool direct = direct_wanted && hipHostGetDevicePointer((void**)&hdev, h, 0) == hipSuccess && hdev != nullptr;
   if (!direct) (void)hipGetLastError();
@@ -410,6 +419,7 @@ int window_call(orbx_ctx* ctx, const char* who, const orbx_keypoint* kps, const 
                        grid->inv_w, grid->inv_h, npad, (int32_t*)(din + o_ci), (int32_t*)(din + o_cs));
   }
   WinArgs a;
+  std::memset(&a, 0, sizeof(a));
   a.kps = (const orbx_keypoint*)(din + o_kps); a.desc = din + o_desc;
   a.cell_start = (const int32_t*)(din + o_cs); a.cell_idx = (const int32_t*)(din + o_ci);
   a.minX = grid->min_x; a.minY = grid->min_y; a.invW = grid->inv_w; a.invH = grid->inv_h;
@@ -495,6 +505,255 @@ int window_call(orbx_ctx* ctx, const char* who, const orbx_keypoint* kps, const 
   return lists ? total : (row_ptr ? row_ptr[nq] : 0);
 }
 
+// ---- resident targets ---------------------------------------------------------------------------------------------------------
+// A Frame / KeyFrame is searched many times (Tracking: two or three calls per frame; LocalMapping / LoopClosing: every keyframe
+// against many others) while its keypoints, descriptors and grid never change after construction.  orbx_target_create uploads
+// them once; a search then moves only the queries, and — with everything it gathers at random already in HBM — needs ONE kernel:
+// the queries are read straight from the mapped pinned blob, the per-call kp_skip flags are staged into LDS by every workgroup,
+// the results are written into the mapped blob and the host polls the done word.
+static int validate_grid(orbx_ctx* ctx, const char* who, const orbx_grid* grid, int n) {
+  if (!grid->cell_idx) return set_err(ctx, ORBX_E_INVALID, std::string(who) + ": grid without cell_idx");
+  if (grid->cell_start[0] != 0) return set_err(ctx, ORBX_E_INVALID, std::string(who) + ": grid cell_start[0] != 0");
+  for (int c = 0; c < kWinCells; c++)
+    if (grid->cell_start[c + 1] < grid->cell_start[c]) return set_err(ctx, ORBX_E_INVALID, std::string(who) + ": grid cell_start not ascending");
+  const int m = grid->cell_start[kWinCells];
+  for (int i = 0; i < m; i++)
+    if (grid->cell_idx[i] < 0 || grid->cell_idx[i] >= n) return set_err(ctx, ORBX_E_INVALID, std::string(who) + ": grid index out of range");
+  return ORBX_OK;
+}
+
+// (re)fills a target: `reuse` keeps its device block when that is large enough (the adapters' LRU of frames recycles targets, so that
+// the steady state allocates nothing)
+int target_assign(orbx_ctx* ctx, orbx_target* reuse, const orbx_keypoint* kps, const uint8_t* desc, int n, const orbx_grid* grid,
+                  const float* kp_uright, const float* inv_sigma2, int nlevels, orbx_target** out) {
+  const char* who = reuse ? "orbx_target_assign" : "orbx_target_create";
+  if (out) *out = nullptr;
+  if (n >= (1 << 24)) return set_err(ctx, ORBX_E_CAPACITY, std::string(who) + ": more than 16 M keypoints");
+  const bool have_grid = grid->cell_start != nullptr;
+  if (have_grid) { const int rc = validate_grid(ctx, who, grid, n); if (rc != ORBX_OK) return rc; }
+  else if (n > 32768) return set_err(ctx, ORBX_E_CAPACITY, std::string(who) + ": more than 32768 keypoints need a caller-held grid");
+  if (inv_sigma2)
+    for (int i = 0; i < n; i++)
+      if (kps[i].octave < 0 || kps[i].octave >= nlevels) return set_err(ctx, ORBX_E_INVALID, std::string(who) + ": keypoint octave outside inv_level_sigma2");
+  ORBX_HIP(ctx, hipSetDevice(ctx->device));
+  orbx_target* T = reuse ? reuse : new orbx_target();
+  T->ctx = ctx; T->n = n; T->nlevels = inv_sigma2 ? nlevels : 0;
+  T->has_ur = kp_uright != nullptr; T->has_sig = inv_sigma2 != nullptr;
+  T->min_x = grid->min_x; T->min_y = grid->min_y; T->inv_w = grid->inv_w; T->inv_h = grid->inv_h;
+  T->ngrid = have_grid ? grid->cell_start[kWinCells] : n;
+  Layout L;
+  T->o_kps = L.add(sizeof(orbx_keypoint) * (size_t)std::max(n, 1)); T->o_desc = L.add((size_t)std::max(n, 1) * 32);
+  T->o_ur = L.add(kp_uright ? 4 * (size_t)n : 0); T->o_sig = L.add(inv_sigma2 ? 4 * (size_t)nlevels : 0);
+  T->o_cs = L.add(4 * (size_t)(kWinCells + 1)); T->o_ci = L.add(4 * (size_t)std::max(T->ngrid, 1));
+  T->bytes = L.size;
+  const size_t upload = have_grid ? L.size : T->o_cs;
+  // the upload is staged in its own pinned buffer (not the per-call blob: the search that follows packs its queries there while
+  // the copy kernel may still be reading) and is asynchronous: the stream orders every later search behind it
+  uint8_t* h = nullptr;
+  hipError_t e = hipSuccess;
+  if (ctx->ev_tgt) e = hipEventSynchronize(ctx->ev_tgt);   // the previous upload has left the staging buffer (it almost always has)
+  if (e == hipSuccess && L.size > ctx->h_tgt_bytes) {
+    if (ctx->h_tgt) (void)hipHostFree(ctx->h_tgt);
+    ctx->h_tgt = nullptr; ctx->h_tgt_bytes = 0;
+    const size_t want = std::max<size_t>(L.size + L.size / 2, 256 << 10);
+    e = hipHostMalloc((void**)&ctx->h_tgt, want, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipHostMalloc((void**)&ctx->h_tgt, want, hipHostMallocDefault); }
+    if (e == hipSuccess) ctx->h_tgt_bytes = want;
+  }
+  if (e == hipSuccess && !ctx->ev_tgt) e = hipEventCreateWithFlags(&ctx->ev_tgt, hipEventDisableTiming);
+  h = ctx->h_tgt;
+  if (e == hipSuccess && L.size > T->cap) {
+    if (T->dev) { (void)hipFree(T->dev); T->dev = nullptr; T->cap = 0; }
+    const size_t want = (std::max<size_t>(L.size, 192 << 10) + 0xffff) & ~(size_t)0xffff;
+    e = hipMalloc((void**)&T->dev, want);
+    if (e == hipSuccess) T->cap = want;
+  }
+  if (e != hipSuccess) { T->n = 0; if (!reuse) { if (T->dev) (void)hipFree(T->dev); delete T; } ORBX_HIP(ctx, e); }
+  if (n) { std::memcpy(h + T->o_kps, kps, sizeof(orbx_keypoint) * (size_t)n); std::memcpy(h + T->o_desc, desc, (size_t)n * 32); }
+  if (kp_uright) std::memcpy(h + T->o_ur, kp_uright, 4 * (size_t)n);
+  if (inv_sigma2) std::memcpy(h + T->o_sig, inv_sigma2, 4 * (size_t)nlevels);
+  if (have_grid) {
+    std::memcpy(h + T->o_cs, grid->cell_start, 4 * (size_t)(kWinCells + 1));
+    if (T->ngrid) std::memcpy(h + T->o_ci, grid->cell_idx, 4 * (size_t)T->ngrid);
+  }
+  hipStream_t st = ctx->stream;
+  uint8_t* hdev = nullptr;
+  if (ctx->window_direct && hipHostGetDevicePointer((void**)&hdev, h, 0) == hipSuccess && hdev) {
+    const int n16 = (int)((upload + 15) / 16);   // the block is a multiple of 256 bytes
+    hipLaunchKernelGGL(k_stage_in, dim3(std::min((n16 + 255) / 256, 256)), dim3(256), 0, st, (const uint4*)hdev, (uint4*)T->dev, n16);
+    e = hipGetLastError();
+  } else {
+    (void)hipGetLastError();
+    e = hipMemcpyAsync(T->dev, h, upload, hipMemcpyHostToDevice, st);
+  }
+  if (e == hipSuccess && !have_grid) {
+    if (n == 0) {
+      e = hipMemsetAsync(T->dev + T->o_cs, 0, 4 * (size_t)(kWinCells + 1), st);
+    } else {
+      int npad = 2;
+      while (npad < n) npad <<= 1;
+      if ((size_t)npad * 4 > 64 * 1024) e = ensure_dynamic_lds((const void*)k_window_grid, 32768 * 4);
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_window_grid, dim3(1), dim3(1024), (size_t)npad * 4, st, (const orbx_keypoint*)(T->dev + T->o_kps), n, grid->min_x,
+                           grid->min_y, grid->inv_w, grid->inv_h, npad, (int32_t*)(T->dev + T->o_ci), (int32_t*)(T->dev + T->o_cs));
+        e = hipGetLastError();
+      }
+    }
+  }
+  if (e == hipSuccess) e = hipEventRecord(ctx->ev_tgt, st);
+  if (e != hipSuccess) { T->n = 0; if (!reuse) { (void)hipFree(T->dev); delete T; } ORBX_HIP(ctx, e); }
+  if (out) *out = T;
+  return ORBX_OK;
+}
+
+void target_destroy(orbx_target* T) {
+  if (!T) return;
+  if (T->dev) { (void)hipSetDevice(T->ctx->device); (void)hipStreamSynchronize(T->ctx->stream); (void)hipFree(T->dev); }
+  delete T;
+}
+
+int window_call_target(orbx_ctx* ctx, const char* who, const orbx_target* T, const uint8_t* kp_skip, bool chi2, const float* qx, const float* qy,
+                       const float* qr, const int32_t* qlo, const int32_t* qhi, const float* qaux, const uint8_t* q_desc, int nq, bool lists,
+                       int32_t* row_ptr, int32_t* cand, int32_t* dist, int cand_cap, int32_t* best_idx, int32_t* best_dist, int32_t* second_idx,
+                       int32_t* second_dist) {
+  if (row_ptr) for (int q = 0; q <= nq; q++) row_ptr[q] = 0;
+  for (int q = 0; q < nq; q++) {
+    if (best_idx) best_idx[q] = -1;
+    if (best_dist) best_dist[q] = 256;
+    if (second_idx) second_idx[q] = -1;
+    if (second_dist) second_dist[q] = 256;
+  }
+  const int n = T->n;
+  if (nq == 0 || n == 0) return 0;
+  if (chi2 && !(T->has_sig && T->has_ur)) return set_err(ctx, ORBX_E_INVALID, std::string(who) + ": the target holds no kp_uright / inv_level_sigma2");
+  static const bool trace = getenv("ORBX_TRACE_WINDOW") != nullptr;
+  const auto tr0 = std::chrono::steady_clock::now();
+  auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count(); };
+  ORBX_HIP(ctx, hipSetDevice(ctx->device));
+  const int pool_cap = lists ? std::max(cand_cap, 0) : 0;
+  const int nskip = kp_skip ? (n + 3) & ~3 : 0;
+  Layout in;
+  const size_t o_qx = in.add(4 * (size_t)nq), o_qy = in.add(4 * (size_t)nq), o_qr = in.add(4 * (size_t)nq), o_qaux = in.add(4 * (size_t)nq);
+  const size_t o_qlo = in.add(4 * (size_t)nq), o_qhi = in.add(4 * (size_t)nq), o_qd = in.add((size_t)nq * 32), o_skip = in.add((size_t)nskip);
+  Layout out;
+  const bool compact = !(best_idx || best_dist || second_idx || second_dist);
+  const size_t qrec = compact ? sizeof(WinQueryShort) : sizeof(WinQueryOut);
+  const size_t p_hdr = out.add(16), p_q = out.add(qrec * (size_t)nq), p_pool = out.add(8 * (size_t)pool_cap);
+  uint8_t* h = nullptr;
+  ORBX_HIP(ctx, host_stage(ctx, in.size + out.size, &h));
+  uint8_t* hin = h;
+  uint8_t* hout = h + in.size;
+  std::memcpy(hin + o_qx, qx, 4 * (size_t)nq); std::memcpy(hin + o_qy, qy, 4 * (size_t)nq); std::memcpy(hin + o_qr, qr, 4 * (size_t)nq);
+  if (qaux) std::memcpy(hin + o_qaux, qaux, 4 * (size_t)nq);
+  std::memcpy(hin + o_qlo, qlo, 4 * (size_t)nq); std::memcpy(hin + o_qhi, qhi, 4 * (size_t)nq);
+  std::memcpy(hin + o_qd, q_desc, (size_t)nq * 32);
+  if (kp_skip) { std::memcpy(hin + o_skip, kp_skip, (size_t)n); std::memset(hin + o_skip + n, 0, (size_t)(nskip - n)); }
+  std::memset(hout + p_hdr, 0, 16);
+  const double us_pack = since(tr0);
+  hipStream_t st = ctx->stream;
+  if (!ctx->d_win_ctr) {
+    ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_win_ctr, 64));
+    ctx->win_ctr_dirty = true;
+  }
+  if (ctx->win_ctr_dirty) {   // first use, or a call that did not finish: the self-resetting counters start from zero
+    ORBX_HIP(ctx, hipMemsetAsync(ctx->d_win_ctr, 0, 64, st));
+    ctx->win_ctr_dirty = false;
+  }
+  const bool direct_wanted = ctx->window_direct;
+  uint8_t* hdev = nullptr;
+  const bool direct = direct_wanted && nskip <= 48 * 1024 && hipHostGetDevicePointer((void**)&hdev, h, 0) == hipSuccess && hdev != nullptr;
+  if (!direct) (void)hipGetLastError();
+  uint8_t* qbase = hdev;   // where the kernel reads the per-call inputs
+  uint8_t* dout = nullptr;
+  if (!direct) {           // copies + stream synchronisation (ORBX_WINDOW_DIRECT=0, or a target too large for the LDS flags)
+    ctx->arena.rewind();
+    hipError_t aerr = hipSuccess;
+    qbase = (uint8_t*)ctx->arena.alloc(in.size, &aerr);
+    ORBX_HIP(ctx, aerr);
+    dout = (uint8_t*)ctx->arena.alloc(out.size, &aerr);
+    ORBX_HIP(ctx, aerr);
+    ORBX_HIP(ctx, hipMemcpyAsync(qbase, hin, in.size, hipMemcpyHostToDevice, st));
+  }
+  ctx->win_ctr_dirty = true;   // cleared again once the results are in
+  WinArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.kps = (const orbx_keypoint*)(T->dev + T->o_kps); a.desc = T->dev + T->o_desc;
+  a.cell_start = (const int32_t*)(T->dev + T->o_cs); a.cell_idx = (const int32_t*)(T->dev + T->o_ci);
+  a.minX = T->min_x; a.minY = T->min_y; a.invW = T->inv_w; a.invH = T->inv_h;
+  a.qx = (const float*)(qbase + o_qx); a.qy = (const float*)(qbase + o_qy); a.qr = (const float*)(qbase + o_qr);
+  a.qaux = qaux ? (const float*)(qbase + o_qaux) : nullptr;
+  a.qlo = (const int32_t*)(qbase + o_qlo); a.qhi = (const int32_t*)(qbase + o_qhi); a.qdesc = qbase + o_qd; a.nq = nq;
+  if (kp_skip) { if (direct) { a.skip_map = qbase + o_skip; a.n_skip = nskip; } else a.kp_skip = qbase + o_skip; }
+  a.kp_uright = T->has_ur ? (const float*)(T->dev + T->o_ur) : nullptr;
+  a.inv_sigma2 = chi2 ? (const float*)(T->dev + T->o_sig) : nullptr;
+  uint8_t* const res = direct ? hdev + in.size : dout;
+  a.out = (WinQueryOut*)(res + p_q); a.pool = (int2*)(res + p_pool); a.pool_cap = pool_cap; a.total = ctx->d_win_ctr;
+  a.out_hdr = (int32_t*)(res + p_hdr); a.compact = compact ? 1 : 0; a.host_out = direct ? 1 : 0; a.self_reset = 1;
+  const dim3 gridDim((nq + 3) / 4), block(256);
+  const size_t lds = a.skip_map ? (size_t)nskip : 0;
+  if (chi2) hipLaunchKernelGGL((k_window<false, true>), gridDim, block, lds, st, a);
+  else if (lists) hipLaunchKernelGGL((k_window<true, false>), gridDim, block, lds, st, a);
+  else hipLaunchKernelGGL((k_window<false, false>), gridDim, block, lds, st, a);
+  ORBX_HIP(ctx, hipGetLastError());
+  double us_issue;
+  if (direct) {
+    us_issue = since(tr0);
+    const volatile unsigned long long* hdr = (const volatile unsigned long long*)(hout + p_hdr);
+    for (unsigned spin = 1;; spin++) {
+      if (__atomic_load_n(hdr, __ATOMIC_ACQUIRE) >> 32) break;
+      if ((spin & 0x3fff) == 0) {
+        const hipError_t qe = hipStreamQuery(st);
+        if (qe == hipSuccess) {
+          if (__atomic_load_n(hdr, __ATOMIC_ACQUIRE) >> 32) break;
+          return set_err(ctx, ORBX_E_DEVICE, std::string(who) + ": window pass finished without publishing its results");
+        }
+        if (qe != hipErrorNotReady) { ORBX_HIP(ctx, qe); }
+      }
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+  } else {
+    ORBX_HIP(ctx, hipMemcpyAsync(hout, dout, out.size, hipMemcpyDeviceToHost, st));
+    us_issue = since(tr0);
+    ORBX_HIP(ctx, hipStreamSynchronize(st));
+  }
+  ctx->win_ctr_dirty = false;
+  const double us_sync = since(tr0);
+  const int total = *(const int32_t*)(hout + p_hdr);
+  const WinQueryOut* qo = (const WinQueryOut*)(hout + p_q);
+  const WinQueryShort* qs = (const WinQueryShort*)(hout + p_q);
+  auto q_start = [&](int q) { return compact ? qs[q].start : qo[q].start; };
+  auto q_count = [&](int q) { return compact ? qs[q].count : qo[q].count; };
+  if (row_ptr) {
+    int acc = 0;
+    for (int q = 0; q < nq; q++) { acc += q_count(q); row_ptr[q + 1] = acc; }
+  }
+  if (lists) {
+    if (total > pool_cap) return set_err(ctx, ORBX_E_CAPACITY, std::string(who) + ": candidate buffer too small");
+    const int2* pool = (const int2*)(hout + p_pool);
+    for (int q = 0; q < nq; q++) {
+      const int2* seg = pool + q_start(q);
+      const int o = row_ptr[q];
+      const int cnt = q_count(q);
+      for (int c = 0; c < cnt; c++) {
+        if (cand) cand[o + c] = seg[c].x;
+        if (dist) dist[o + c] = seg[c].y;
+      }
+    }
+  }
+  if (!compact) for (int q = 0; q < nq; q++) {
+    if (best_idx) best_idx[q] = qo[q].best_idx;
+    if (best_dist) best_dist[q] = qo[q].best_dist;
+    if (second_idx) second_idx[q] = qo[q].second_idx;
+    if (second_dist) second_dist[q] = qo[q].second_dist;
+  }
+  if (trace)
+    std::fprintf(stderr, "[orbx window] %s (resident target) n=%d nq=%d total=%d in=%zu B: pack %.1f us, issue %.1f, wait %.1f, scatter %.1f\n", who, n, nq,
+                 total, in.size, us_pack, us_issue - us_pack, us_sync - us_issue, since(tr0) - us_sync);
+  return lists ? total : (row_ptr ? row_ptr[nq] : 0);
+}
+
 }  // namespace orbx
 
 using namespace orbx;
@@ -571,6 +830,50 @@ int orbx_window_nearest(orbx_ctx* ctx, const orbx_keypoint* kps, const uint8_t* 
   const int rc = window_call(ctx, "orbx_window_nearest", kps, desc, n, grid, nullptr, inv_level_sigma2 ? kp_uright : nullptr, inv_level_sigma2,
                              nlevels, qx, qy, qr, qmin_level, qmax_level, inv_level_sigma2 ? q_ur : nullptr, q_desc, nq, false, nullptr, nullptr,
                              nullptr, 0, best_idx, best_dist, nullptr, nullptr);
+  return rc < 0 ? rc : ORBX_OK;
+}
+
+int orbx_target_create(orbx_ctx* ctx, const orbx_keypoint* kps, const uint8_t* desc, int n, const orbx_grid* grid, const float* kp_uright,
+                       const float* inv_level_sigma2, int nlevels, orbx_target** target) {
+  if (!ctx || !target || !grid || n < 0 || (n > 0 && (!kps || !desc)) || (inv_level_sigma2 && (!kp_uright || nlevels <= 0)) ||
+      !(grid->inv_w > 0.f) || !(grid->inv_h > 0.f))
+    return ctx ? set_err(ctx, ORBX_E_INVALID, "orbx_target_create: bad arguments") : ORBX_E_INVALID;
+  return target_assign(ctx, nullptr, kps, desc, n, grid, kp_uright, inv_level_sigma2, nlevels, target);
+}
+
+int orbx_target_assign(orbx_ctx* ctx, orbx_target* target, const orbx_keypoint* kps, const uint8_t* desc, int n, const orbx_grid* grid,
+                       const float* kp_uright, const float* inv_level_sigma2, int nlevels) {
+  if (!ctx || !target || target->ctx != ctx || !grid || n < 0 || (n > 0 && (!kps || !desc)) || (inv_level_sigma2 && (!kp_uright || nlevels <= 0)) ||
+      !(grid->inv_w > 0.f) || !(grid->inv_h > 0.f))
+    return ctx ? set_err(ctx, ORBX_E_INVALID, "orbx_target_assign: bad arguments") : ORBX_E_INVALID;
+  return target_assign(ctx, target, kps, desc, n, grid, kp_uright, inv_level_sigma2, nlevels, nullptr);
+}
+
+void orbx_target_destroy(orbx_target* target) { target_destroy(target); }
+
+int orbx_target_size(const orbx_target* target) { return target ? target->n : ORBX_E_INVALID; }
+
+int orbx_target_search(orbx_ctx* ctx, const orbx_target* target, const uint8_t* kp_skip, const float* qx, const float* qy, const float* qr,
+                       const int32_t* qmin_level, const int32_t* qmax_level, const uint8_t* q_desc, const float* q_xr, int nq, int32_t* row_ptr,
+                       int32_t* cand, int32_t* dist, int cand_cap, int32_t* best_idx, int32_t* best_dist, int32_t* second_idx,
+                       int32_t* second_dist) {
+  if (!ctx || !target || target->ctx != ctx || nq < 0 || !row_ptr ||
+      (nq > 0 && (!qx || !qy || !qr || !qmin_level || !qmax_level || !q_desc)) || (q_xr && !target->has_ur) || cand_cap < 0)
+    return ctx ? set_err(ctx, ORBX_E_INVALID, "orbx_target_search: bad arguments") : ORBX_E_INVALID;
+  const bool lists = cand != nullptr || dist != nullptr;
+  return window_call_target(ctx, "orbx_target_search", target, kp_skip, false, qx, qy, qr, qmin_level, qmax_level, q_xr, q_desc, nq, lists, row_ptr,
+                            cand, dist, cand_cap, best_idx, best_dist, second_idx, second_dist);
+}
+
+int orbx_target_nearest(orbx_ctx* ctx, const orbx_target* target, int reprojection_gate, const float* qx, const float* qy, const float* qr,
+                        const int32_t* qmin_level, const int32_t* qmax_level, const float* q_ur, const uint8_t* q_desc, int nq, int32_t* best_idx,
+                        int32_t* best_dist) {
+  if (!ctx || !target || target->ctx != ctx || nq < 0 ||
+      (nq > 0 && (!qx || !qy || !qr || !qmin_level || !qmax_level || !q_desc || !best_idx || !best_dist)) || (reprojection_gate && !q_ur))
+    return ctx ? set_err(ctx, ORBX_E_INVALID, "orbx_target_nearest: bad arguments") : ORBX_E_INVALID;
+  const int rc = window_call_target(ctx, "orbx_target_nearest", target, nullptr, reprojection_gate != 0, qx, qy, qr, qmin_level, qmax_level,
+                                    reprojection_gate ? q_ur : nullptr, q_desc, nq, false, nullptr, nullptr, nullptr, 0, best_idx, best_dist, nullptr,
+                                    nullptr);
   return rc < 0 ? rc : ORBX_OK;
 }
 

@@ -117,17 +117,121 @@ struct Lists {   // CSR candidate lists of a query batch, in GetFeaturesInArea's
   int end(int q) const { return row_ptr[q + 1]; }
 };
 
-void window_lists(const char* routine, const orbx_keypoint* kps, const unsigned char* desc, int n, const orbx_grid& g, const Queries& Q,
-                  Lists& L) {
+// ---- resident search targets -----------------------------------------------------------------------------------------------------
+// A Frame / KeyFrame is searched many times and never changes after construction: what a routine searches — keypoints, descriptor
+// rows, the flattened grid and, for Fuse, mvuRight + mvInvLevelSigma2 — is uploaded once per thread context (orbx_target_*) and kept
+// in a small LRU keyed by the object's id (Frame::mnId / KeyFrame::mnId are unique per process; a copy of a Frame shares both the
+// id and the contents).  A hit costs neither the flattening of the grid nor an upload; the LRU recycles the evicted target's
+// device block, so the steady state allocates nothing.
+struct TargetSpec {
+  const orbx_keypoint* kps = nullptr;
+  const unsigned char* desc = nullptr;
+  int n = 0;
+  FlatGrid grid;
+  const float* ur = nullptr;
+  const float* sig = nullptr;
+  int nlevels = 0;
+  KeyView keys;      // owns a merged copy when the routine needs one
+  DescView* dview = nullptr;
+};
+
+struct TargetCache {
+  struct Entry { int kind; unsigned long id; int variant; int n; const void* dptr; orbx_target* t; unsigned long stamp; };
+  static constexpr size_t kMax = 64;
+  std::vector<Entry> e;
+  unsigned long clock = 0;
+  void clear() { for (Entry& x : e) orbx_target_destroy(x.t); e.clear(); }
+  template <class Build>
+  orbx_target* get(orbx_ctx* ctx, const char* routine, int kind, unsigned long id, int variant, int n, const void* dptr, Build build) {
+    for (Entry& x : e)
+      if (x.kind == kind && x.id == id && x.variant == variant && x.n == n && x.dptr == dptr) { x.stamp = ++clock; return x.t; }
+    TargetSpec sp;
+    build(sp);
+    Entry* slot = nullptr;
+    if (e.size() < kMax) {
+      orbx_target* t = nullptr;
+      if (orbx_target_create(ctx, sp.kps, sp.desc, sp.n, &sp.grid.g, sp.ur, sp.sig, sp.nlevels, &t) != ORBX_OK) fail(routine, ctx);
+      e.push_back(Entry{kind, id, variant, n, dptr, t, 0});
+      slot = &e.back();
+    } else {
+      slot = &e[0];
+      for (Entry& x : e) if (x.stamp < slot->stamp) slot = &x;
+      slot->n = -1;   // not a valid key while it is refilled
+      if (orbx_target_assign(ctx, slot->t, sp.kps, sp.desc, sp.n, &sp.grid.g, sp.ur, sp.sig, sp.nlevels) != ORBX_OK) fail(routine, ctx);
+      slot->kind = kind; slot->id = id; slot->variant = variant; slot->n = n; slot->dptr = dptr;
+    }
+    slot->stamp = ++clock;
+    return slot->t;
+  }
+};
+
+struct ContextHolder {
+  orbx_ctx* c = nullptr;
+  TargetCache cache;
+  ~ContextHolder() { cache.clear(); if (c) orbx_destroy(c); }   // targets before their context
+};
+ContextHolder& holder() {
+  static thread_local ContextHolder h;
+  return h;
+}
+
+enum { kFrameLeft = 0, kFrameRight = 1, kKeyFrameUn = 2, kFuseLeft = 3, kFuseRight = 4 };
+
+// a Frame's left camera (mvKeysUn, or mvKeys of a rig: Frame::GetFeaturesInArea tests the window on those) / right camera of a rig
+orbx_target* frame_target(const char* routine, const Frame& F, bool bRight) {
+  orbx_ctx* ctx = ORBmatcher::DefaultContext();
+  const std::vector<cv::KeyPoint>& keys = bRight ? F.mvKeysRight : (F.Nleft == -1 ? F.mvKeysUn : F.mvKeys);
+  return holder().cache.get(ctx, routine, 'F', F.mnId, bRight ? kFrameRight : kFrameLeft, (int)keys.size(), F.mDescriptors.data, [&](TargetSpec& sp) {
+    static thread_local std::vector<unsigned char> rows;
+    DescView D(F.mDescriptors);
+    const unsigned char* d = D.p ? D.p + (bRight ? (size_t)F.Nleft * 32 : 0) : nullptr;
+    if (!D.copy.empty()) { rows = D.copy; d = rows.data() + (bRight ? (size_t)F.Nleft * 32 : 0); }
+    sp.kps = (const orbx_keypoint*)keys.data(); sp.desc = d; sp.n = (int)keys.size();
+    frame_grid(F, bRight, sp.grid);
+  });
+}
+
+// what the KeyFrame-side routines search: mvKeysUn-levels over the grid the keyframe holds (a rig: window on mvKeys,
+// src/KeyFrame.cc:735-737, level from mvKeysUn, e.g. :508)
+orbx_target* keyframe_target(const char* routine, KeyFrame* pKF) {
+  orbx_ctx* ctx = ORBmatcher::DefaultContext();
+  return holder().cache.get(ctx, routine, 'K', pKF->mnId, kKeyFrameUn, (int)pKF->mvKeysUn.size(), pKF->mDescriptors.data, [&](TargetSpec& sp) {
+    static thread_local std::vector<unsigned char> rows;
+    if (pKF->NLeft == -1) sp.keys.direct(pKF->mvKeysUn);
+    else sp.keys.merge(pKF->mvKeys, pKF->mvKeysUn);
+    DescView D(pKF->mDescriptors);
+    const unsigned char* d = D.p;
+    if (!D.copy.empty()) { rows = D.copy; d = rows.data(); }
+    sp.kps = sp.keys.p; sp.desc = d; sp.n = sp.keys.n;
+    keyframe_grid(pKF, false, sp.grid);
+  });
+}
+
+// Fuse(KeyFrame*, points): KeyFrame::GetFeaturesInArea(..., bRight) with the level and reprojection gates (:1262-1296)
+orbx_target* fuse_target(const char* routine, KeyFrame* pKF, bool bRight) {
+  orbx_ctx* ctx = ORBmatcher::DefaultContext();
+  const std::vector<cv::KeyPoint>& keys = pKF->NLeft == -1 ? pKF->mvKeysUn : (bRight ? pKF->mvKeysRight : pKF->mvKeys);
+  return holder().cache.get(ctx, routine, 'K', pKF->mnId, bRight ? kFuseRight : kFuseLeft, (int)keys.size(), pKF->mDescriptors.data, [&](TargetSpec& sp) {
+    static thread_local std::vector<unsigned char> rows;
+    DescView D(pKF->mDescriptors);
+    const unsigned char* d = D.p;
+    if (!D.copy.empty()) { rows = D.copy; d = rows.data(); }
+    sp.kps = (const orbx_keypoint*)keys.data(); sp.n = (int)keys.size();
+    sp.desc = d ? d + (bRight ? (size_t)pKF->NLeft * 32 : 0) : nullptr;
+    keyframe_grid(pKF, bRight, sp.grid);
+    sp.ur = pKF->mvuRight.data(); sp.sig = pKF->mvInvLevelSigma2.data(); sp.nlevels = (int)pKF->mvInvLevelSigma2.size();
+  });
+}
+
+void window_lists(const char* routine, orbx_target* T, const Queries& Q, Lists& L) {
   const int nq = Q.size();
   L.row_ptr.assign(nq + 1, 0);
-  if (nq == 0 || n == 0) return;
+  if (nq == 0 || orbx_target_size(T) == 0) return;
   orbx_ctx* ctx = ORBmatcher::DefaultContext();
   if (L.cand.size() < 4096) { L.cand.resize(4096); L.dist.resize(4096); }
   for (int attempt = 0; attempt < 2; attempt++) {
-    const int rc = orbx_window_search_grid(ctx, kps, desc, n, &g, nullptr, nullptr, Q.x.data(), Q.y.data(), Q.r.data(), Q.lo.data(),
-                                           Q.hi.data(), Q.desc.data(), nullptr, nq, L.row_ptr.data(), L.cand.data(), L.dist.data(),
-                                           (int)L.cand.size(), nullptr, nullptr, nullptr, nullptr);
+    const int rc = orbx_target_search(ctx, T, nullptr, Q.x.data(), Q.y.data(), Q.r.data(), Q.lo.data(), Q.hi.data(), Q.desc.data(), nullptr, nq,
+                                      L.row_ptr.data(), L.cand.data(), L.dist.data(), (int)L.cand.size(), nullptr, nullptr, nullptr, nullptr);
     if (rc >= 0) return;
     if (rc != ORBX_E_CAPACITY || attempt) fail(routine, ctx);
     const size_t need = (size_t)L.row_ptr[nq] + 64;   // row_ptr is complete on ORBX_E_CAPACITY
@@ -135,14 +239,14 @@ void window_lists(const char* routine, const orbx_keypoint* kps, const unsigned 
   }
 }
 
-void window_best(const char* routine, const orbx_keypoint* kps, const unsigned char* desc, int n, const orbx_grid& g, const float* kp_uright,
-                 const float* inv_sigma2, int nlevels, const Queries& Q, std::vector<int32_t>& bestIdx, std::vector<int32_t>& bestDist) {
+void window_best(const char* routine, orbx_target* T, bool reprojection_gate, const Queries& Q, std::vector<int32_t>& bestIdx,
+                 std::vector<int32_t>& bestDist) {
   const int nq = Q.size();
   bestIdx.assign(nq, -1); bestDist.assign(nq, 256);
-  if (nq == 0 || n == 0) return;
+  if (nq == 0 || orbx_target_size(T) == 0) return;
   orbx_ctx* ctx = ORBmatcher::DefaultContext();
-  const int rc = orbx_window_nearest(ctx, kps, desc, n, &g, kp_uright, inv_sigma2, nlevels, Q.x.data(), Q.y.data(), Q.r.data(), Q.lo.data(),
-                                     Q.hi.data(), inv_sigma2 ? Q.aux.data() : nullptr, Q.desc.data(), nq, bestIdx.data(), bestDist.data());
+  const int rc = orbx_target_nearest(ctx, T, reprojection_gate ? 1 : 0, Q.x.data(), Q.y.data(), Q.r.data(), Q.lo.data(), Q.hi.data(),
+                                     reprojection_gate ? Q.aux.data() : nullptr, Q.desc.data(), nq, bestIdx.data(), bestDist.data());
   if (rc != ORBX_OK) fail(routine, ctx);
 }
 
@@ -172,17 +276,12 @@ struct RotHist {
   }
 };
 
-struct ContextHolder {
-  orbx_ctx* c = nullptr;
-  ~ContextHolder() { if (c) orbx_destroy(c); }
-};
-
 }  // namespace
 
 ORBmatcher::ORBmatcher(float nnratio, bool checkOri) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
 
 orbx_ctx* ORBmatcher::DefaultContext() {
-  static thread_local ContextHolder h;
+  ContextHolder& h = holder();
   if (!h.c && orbx_create(&h.c, 1, 1.2f, 1, 20, 7, -1) != ORBX_OK) {
     h.c = nullptr;
     throw std::runtime_error("ORBmatcher: no MI355X / HIP device");
@@ -252,18 +351,10 @@ int ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoint
   }
   if (QL.size() == 0 && QR.size() == 0) return 0;
   // phase 2
-  DescView D(F.mDescriptors);
   const std::vector<cv::KeyPoint>& keysL = rig ? F.mvKeys : F.mvKeysUn;
-  FlatGrid gL, gR;
   Lists LL, LR;
-  if (QL.size()) {
-    frame_grid(F, false, gL);
-    window_lists("SearchByProjection", (const orbx_keypoint*)keysL.data(), D.p, (int)keysL.size(), gL.g, QL, LL);
-  }
-  if (QR.size()) {
-    frame_grid(F, true, gR);
-    window_lists("SearchByProjection", (const orbx_keypoint*)F.mvKeysRight.data(), D.p + (size_t)F.Nleft * 32, (int)F.mvKeysRight.size(), gR.g, QR, LR);
-  }
+  if (QL.size()) window_lists("SearchByProjection", frame_target("SearchByProjection", F, false), QL, LL);
+  if (QR.size()) window_lists("SearchByProjection", frame_target("SearchByProjection", F, true), QR, LR);
   // phase 3 (:76-140, :151-207): a keypoint bound to an observed map point — before the call or by an earlier map point of
   // this call — is no candidate
   for (int iMP = 0; iMP < nMP; iMP++) {
@@ -410,17 +501,6 @@ int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPoi
 // ---------------------------------------------------------------------------------------------------------------------
 // SearchByProjection(KeyFrame*, Sim3, points[, their keyframes])  :427-532, :534-646 — one body, two projections
 // ---------------------------------------------------------------------------------------------------------------------
-namespace {
-struct KeyFrameTarget {   // what the KeyFrame-side routines search: mvKeysUn-levels over the grid the keyframe holds
-  KeyView keys;
-  FlatGrid grid;
-  void set(KeyFrame* pKF) {
-    if (pKF->NLeft == -1) keys.direct(pKF->mvKeysUn);
-    else keys.merge(pKF->mvKeys, pKF->mvKeysUn);   // window on mvKeys (src/KeyFrame.cc:735-737), level from mvKeysUn (e.g. :508)
-    keyframe_grid(pKF, false, grid);
-  }
-};
-}  // namespace
 
 static int SearchByProjectionSim3(const char* routine, KeyFrame* pKF, Sophus::Sim3f& Scw, const vector<MapPoint*>& vpPoints,
                                   const vector<KeyFrame*>* vpPointsKFs, vector<MapPoint*>& vpMatched, vector<KeyFrame*>* vpMatchedKF, int th,
@@ -468,11 +548,8 @@ static int SearchByProjectionSim3(const char* routine, KeyFrame* pKF, Sophus::Si
   }
   if (Q.size() == 0) return 0;
   // phase 2
-  KeyFrameTarget T;
-  T.set(pKF);
-  DescView D(pKF->mDescriptors);
   Lists L;
-  window_lists(routine, T.keys.p, D.p, T.keys.n, T.grid.g, Q, L);
+  window_lists(routine, keyframe_target(routine, pKF), Q, L);
   // phase 3 (:497-528): a keypoint matched before, or by an earlier point of this call, is taken
   int nmatches = 0;
   for (int q = 0; q < Q.size(); q++) {
@@ -520,12 +597,8 @@ int ORBmatcher::SearchForInitialization(Frame& F1, Frame& F2, vector<cv::Point2f
   }
   if (Q.size() == 0) return 0;
   // phase 2
-  const std::vector<cv::KeyPoint>& keys2 = F2.Nleft == -1 ? F2.mvKeysUn : F2.mvKeys;
-  FlatGrid g2;
-  frame_grid(F2, false, g2);
-  DescView D2(F2.mDescriptors);
   Lists L;
-  window_lists("SearchForInitialization", (const orbx_keypoint*)keys2.data(), D2.p, (int)keys2.size(), g2.g, Q, L);
+  window_lists("SearchForInitialization", frame_target("SearchForInitialization", F2, false), Q, L);
   // phase 3 (:676-763): a later keypoint may take a match from an earlier one
   RotHist rot;
   vector<int> vMatchedDistance(F2.mvKeysUn.size(), INT_MAX);
@@ -824,16 +897,9 @@ int ORBmatcher::Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, const 
   }
   if (Q.size() == 0) return 0;
   // phase 2: window (KeyFrame::GetFeaturesInArea(..., bRight)), level and reprojection gates (:1262-1296), arg-min
-  KeyView keys;
-  if (pKF->NLeft == -1) keys.direct(pKF->mvKeysUn);
-  else keys.direct(bRight ? pKF->mvKeysRight : pKF->mvKeys);
-  FlatGrid grid;
-  keyframe_grid(pKF, bRight, grid);
-  DescView D(pKF->mDescriptors);
-  const unsigned char* desc = D.p + (bRight ? (size_t)pKF->NLeft * 32 : 0);
-  const int nlevels = (int)pKF->mvInvLevelSigma2.size();
+  orbx_target* target = fuse_target("Fuse", pKF, bRight);
   std::vector<int32_t> bestIdx, bestDist;
-  window_best("Fuse", keys.p, desc, keys.n, grid.g, pKF->mvuRight.data(), pKF->mvInvLevelSigma2.data(), nlevels, Q, bestIdx, bestDist);
+  window_best("Fuse", target, true, Q, bestIdx, bestDist);
   // phase 3 (:1176-1192, :1311-1335): the map is changed point by point, in order
   std::set<MapPoint*> touched;   // points whose descriptor a Replace() of this call recomputed
   int nFused = 0;
@@ -850,7 +916,7 @@ int ORBmatcher::Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, const 
       Queries one;
       one.add(p.u, p.v, p.radius, p.level - 1, p.level, pMP->GetDescriptor(), p.ur);
       std::vector<int32_t> bi, bd;
-      window_best("Fuse", keys.p, desc, keys.n, grid.g, pKF->mvuRight.data(), pKF->mvInvLevelSigma2.data(), nlevels, one, bi, bd);
+      window_best("Fuse", target, true, one, bi, bd);
       best = bi[0]; bestD = bd[0];
     }
     if (bestD <= TH_LOW) {
@@ -904,11 +970,8 @@ int ORBmatcher::Fuse(KeyFrame* pKF, Sophus::Sim3f& Scw, const vector<MapPoint*>&
   }
   if (Q.size() == 0) return 0;
   // phase 2 (:1411-1433)
-  KeyFrameTarget T;
-  T.set(pKF);
-  DescView D(pKF->mDescriptors);
   std::vector<int32_t> bestIdx, bestDist;
-  window_best("Fuse", T.keys.p, D.p, T.keys.n, T.grid.g, nullptr, nullptr, 0, Q, bestIdx, bestDist);
+  window_best("Fuse", keyframe_target("Fuse", pKF), false, Q, bestIdx, bestDist);
   // phase 3 (:1436-1451)
   int nFused = 0;
   for (int q = 0; q < Q.size(); q++) {
@@ -982,11 +1045,8 @@ int ORBmatcher::SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoin
       owner.push_back(i);
     }
     if (Q.size() == 0) return;
-    KeyFrameTarget T;
-    T.set(pTo);
-    DescView D(pTo->mDescriptors);
     std::vector<int32_t> bestIdx, bestDist;
-    window_best("SearchBySim3", T.keys.p, D.p, T.keys.n, T.grid.g, nullptr, nullptr, 0, Q, bestIdx, bestDist);
+    window_best("SearchBySim3", keyframe_target("SearchBySim3", pTo), false, Q, bestIdx, bestDist);
     for (int q = 0; q < Q.size(); q++)
       if (bestDist[q] <= TH_HIGH) vnMatch[owner[q]] = bestIdx[q];
   };
@@ -1046,17 +1106,9 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
   }
   if (QL.size() == 0) return 0;
   // phase 2
-  DescView D(CurrentFrame.mDescriptors);
-  const std::vector<cv::KeyPoint>& keysL = rig ? CurrentFrame.mvKeys : CurrentFrame.mvKeysUn;
-  FlatGrid gL, gR;
   Lists LL, LR;
-  frame_grid(CurrentFrame, false, gL);
-  window_lists("SearchByProjection", (const orbx_keypoint*)keysL.data(), D.p, (int)keysL.size(), gL.g, QL, LL);
-  if (rig) {
-    frame_grid(CurrentFrame, true, gR);
-    window_lists("SearchByProjection", (const orbx_keypoint*)CurrentFrame.mvKeysRight.data(), D.p + (size_t)CurrentFrame.Nleft * 32,
-                 (int)CurrentFrame.mvKeysRight.size(), gR.g, QR, LR);
-  }
+  window_lists("SearchByProjection", frame_target("SearchByProjection", CurrentFrame, false), QL, LL);
+  if (rig) window_lists("SearchByProjection", frame_target("SearchByProjection", CurrentFrame, true), QR, LR);
   // phase 3 (:1735-1858)
   RotHist rot;
   auto lastKey = [&](int i) -> const cv::KeyPoint& {
@@ -1149,12 +1201,8 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set
   }
   if (Q.size() == 0) return 0;
   // phase 2
-  const std::vector<cv::KeyPoint>& keys = CurrentFrame.Nleft == -1 ? CurrentFrame.mvKeysUn : CurrentFrame.mvKeys;
-  FlatGrid g;
-  frame_grid(CurrentFrame, false, g);
-  DescView D(CurrentFrame.mDescriptors);
   Lists L;
-  window_lists("SearchByProjection", (const orbx_keypoint*)keys.data(), D.p, (int)keys.size(), g.g, Q, L);
+  window_lists("SearchByProjection", frame_target("SearchByProjection", CurrentFrame, false), Q, L);
   // phase 3 (:1941-1982): any keypoint that already has a map point is taken
   RotHist rot;
   for (int q = 0; q < Q.size(); q++) {

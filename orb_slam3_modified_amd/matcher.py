@@ -23,6 +23,10 @@ class ORBmatcher:
         self._ctx = getattr(extractor_or_ctx, "_ctx", extractor_or_ctx)
         self.mfNNratio, self.mbCheckOrientation = float(nnratio), bool(checkOri)
 
+    def set_option(self, name: str, value: int) -> None:
+        """Scheduling knob of the underlying context (orbx_set_option); never changes results."""
+        check(self._L.orbx_set_option(self._ctx, name.encode(), int(value)), self._ctx)
+
     @staticmethod
     def DescriptorDistance(a: np.ndarray, b: np.ndarray) -> int:
         """src/ORBmatcher.cc:2058-2074"""
@@ -156,6 +160,10 @@ class ORBmatcher:
                 out.update(cand=cand[:rc].copy(), dist=dist[:rc].copy())
             return out
 
+    def Target(self, kps, desc, grid, kp_uright=None, inv_level_sigma2=None) -> "SearchTarget":
+        """orbx_target_create: keypoints, descriptors and grid of a Frame / KeyFrame resident in HBM for repeated searches."""
+        return SearchTarget(self, kps, desc, grid, kp_uright, inv_level_sigma2)
+
     def WindowNearest(self, kps, desc, grid, qx, qy, qr, min_level, max_level, q_desc, kp_uright=None, inv_level_sigma2=None, q_ur=None):
         """orbx_window_nearest: the device arg-min of Fuse x2 / SearchBySim3 (optionally with Fuse's reprojection gate)."""
         k = np.ascontiguousarray(kps)
@@ -270,3 +278,70 @@ class ORBmatcher:
         elif max3 < 0.1 * float(max1):
             ind3 = -1
         return ind1, ind2, ind3
+
+
+class SearchTarget:
+    """A search target resident in HBM (orbx_target_*): uploaded once, searched many times; results equal those of
+    ORBmatcher.WindowSearchGrid / WindowNearest on the same arrays."""
+
+    def __init__(self, matcher: "ORBmatcher", kps, desc, grid, kp_uright=None, inv_level_sigma2=None):
+        self._m = matcher           # keeps the context alive
+        self._L = matcher._L
+        self._ctx = matcher._ctx
+        k = np.ascontiguousarray(kps)
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        ur = None if kp_uright is None else np.ascontiguousarray(kp_uright, np.float32)
+        sig = None if inv_level_sigma2 is None else np.ascontiguousarray(inv_level_sigma2, np.float32)
+        g, keep = matcher._grid(grid)
+        h = C.c_void_p()
+        check(self._L.orbx_target_create(self._ctx, ptr(k), ptr(d), len(k), C.byref(g), ptr(ur), ptr(sig), 0 if sig is None else len(sig), C.byref(h)),
+              self._ctx)
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.orbx_target_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return int(self._L.orbx_target_size(self._h))
+
+    def search(self, qx, qy, qr, min_level, max_level, q_desc, kp_skip=None, q_xr=None, want_lists=True):
+        qx, qy, qr = (np.ascontiguousarray(v, np.float32) for v in (qx, qy, qr))
+        lo, hi = (np.ascontiguousarray(v, np.int32) for v in (min_level, max_level))
+        qd = np.ascontiguousarray(q_desc, np.uint8).reshape(-1, 32)
+        nq = len(qx)
+        skip = None if kp_skip is None else np.ascontiguousarray(kp_skip, np.uint8)
+        xr = None if q_xr is None else np.ascontiguousarray(q_xr, np.float32)
+        rp = np.zeros(nq + 1, np.int32)
+        bi, bd, si, sd = (np.zeros(max(nq, 1), np.int32) for _ in range(4))
+        cap = 1 << 12
+        while True:
+            cand, dist = (np.zeros(cap, np.int32), np.zeros(cap, np.int32)) if want_lists else (None, None)
+            rc = self._L.orbx_target_search(self._ctx, self._h, ptr(skip), ptr(qx), ptr(qy), ptr(qr), ptr(lo), ptr(hi), ptr(qd), ptr(xr), nq, ptr(rp),
+                                            ptr(cand), ptr(dist), cap if want_lists else 0, ptr(bi), ptr(bd), ptr(si), ptr(sd))
+            if rc == -4 and want_lists:   # ORBX_E_CAPACITY: row_ptr[nq] is the capacity needed
+                cap = int(rp[nq]) + 16
+                continue
+            check(rc, self._ctx)
+            out = dict(row_ptr=rp, best_idx=bi[:nq], best_dist=bd[:nq], second_idx=si[:nq], second_dist=sd[:nq])
+            if want_lists:
+                out.update(cand=cand[:rc].copy(), dist=dist[:rc].copy())
+            return out
+
+    def nearest(self, qx, qy, qr, min_level, max_level, q_desc, q_ur=None):
+        qx, qy, qr = (np.ascontiguousarray(v, np.float32) for v in (qx, qy, qr))
+        lo, hi = (np.ascontiguousarray(v, np.int32) for v in (min_level, max_level))
+        qd = np.ascontiguousarray(q_desc, np.uint8).reshape(-1, 32)
+        nq = len(qx)
+        qu = None if q_ur is None else np.ascontiguousarray(q_ur, np.float32)
+        bi, bd = np.zeros(max(nq, 1), np.int32), np.zeros(max(nq, 1), np.int32)
+        check(self._L.orbx_target_nearest(self._ctx, self._h, 0 if qu is None else 1, ptr(qx), ptr(qy), ptr(qr), ptr(lo), ptr(hi), ptr(qu), ptr(qd), nq,
+                                          ptr(bi), ptr(bd)), self._ctx)
+        return bi[:nq], bd[:nq]

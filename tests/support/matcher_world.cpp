@@ -102,9 +102,12 @@ struct Scene {
   std::vector<MapPoint> mpsB;    // map points created from another view (keyframe-2 side of the two-keyframe routines)
   std::vector<MapPoint> extra;   // points bound to frames before a call ("already there")
   std::vector<KeyFrame*> kfs;
-  unsigned long nextKfId = 1;
+  // KeyFrame::nNextId / Frame::nNextId are process-wide statics in the reference: ids never repeat, also across scenes
+  static unsigned long nextKfId, nextFrameId;
+  static unsigned long kfIdBase;   // first keyframe id of this scene: results print ids relative to it (a scene may be run many times)
 
   explicit Scene(const World& w_, bool distorted) : w(w_) {
+    kfIdBase = nextKfId;
     for (TestPinhole* c : {(TestPinhole*)&cams.pinL, (TestPinhole*)&cams.pinR, (TestPinhole*)&cams.fishL, (TestPinhole*)&cams.fishR}) {
       c->fx = 458.f; c->fy = 457.f; c->cx = 0.5f * w.cols + 3.5f; c->cy = 0.5f * w.rows - 2.25f;
     }
@@ -163,6 +166,7 @@ struct Scene {
   void make_frame(Frame& F, int v, bool stereo, const Sophus::SE3f& Tcw) {
     const View& V = w.views[v];
     fill_common(F);
+    F.mnId = nextFrameId++;   // Frame::Frame: mnId = nNextId++ (src/Frame.cc)
     F.N = V.n; F.Nleft = -1; F.Nright = -1;
     F.mvKeys = V.kps; F.mvKeysUn = V.kps; F.mDescriptors = V.desc.clone(); F.mFeatVec = V.fv;
     F.mvpMapPoints.assign(V.n, static_cast<MapPoint*>(NULL));
@@ -180,6 +184,7 @@ struct Scene {
   void make_rig_frame(Frame& F, int vl, int vr, const Sophus::SE3f& Tcw) {
     const View &L = w.views[vl], &R = w.views[vr];
     fill_common(F);
+    F.mnId = nextFrameId++;
     F.Nleft = L.n; F.Nright = R.n; F.N = L.n + R.n;
     F.mvKeys = L.kps; F.mvKeysRight = R.kps; F.mvKeysUn = L.kps;
     F.mDescriptors = cv::Mat(F.N, 32, CV_8U);
@@ -237,6 +242,7 @@ struct Scene {
   // bind map point m to feature idx of K, both directions (LocalMapping / Tracking::CreateNewKeyFrame do this)
   static void bind(KeyFrame* K, MapPoint* m, int idx) { K->AddMapPoint(m, idx); m->AddObservation(K, idx); }
 };
+unsigned long Scene::nextKfId = 1, Scene::nextFrameId = 1, Scene::kfIdBase = 1;
 
 struct Out {
   FILE* f;
@@ -259,7 +265,7 @@ void dump_points(Out& o, const char* what, std::vector<MapPoint>& pts) {
     for (int i = 0; i < 32; i++) sum = sum * 131u + d[i];
     v.push_back(m.mbBad); v.push_back(m.nObs); v.push_back(mp_id(m.mpReplaced)); v.push_back((long)(sum & 0xffffff));
     v.push_back((long)m.mObservations.size());
-    for (auto& kv : m.mObservations) { v.push_back((long)kv.first->mnId); v.push_back(std::get<0>(kv.second)); v.push_back(std::get<1>(kv.second)); }
+    for (auto& kv : m.mObservations) { v.push_back((long)(kv.first->mnId - Scene::kfIdBase + 1)); v.push_back(std::get<0>(kv.second)); v.push_back(std::get<1>(kv.second)); }
   }
   o.ints(what, v);
 }
@@ -604,7 +610,7 @@ int main(int argc, char** argv) {
       else ret = timed([&] { return matcher.SearchByProjection(K, Scw, vp, vpMatched, 5, 1.0); });
       o.line(names[variant], ret);
       o.ints("vpMatched", ids_of(vpMatched));
-      if (variant == 0) { std::vector<long> v; for (KeyFrame* k : vpMatchedKF) v.push_back(k ? (long)k->mnId : -1); o.ints("vpMatchedKF", v); }
+      if (variant == 0) { std::vector<long> v; for (KeyFrame* k : vpMatchedKF) v.push_back(k ? (long)(k->mnId - Scene::kfIdBase + 1) : -1); o.ints("vpMatchedKF", v); }
     });
   }
 

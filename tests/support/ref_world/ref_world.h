@@ -161,6 +161,7 @@ inline bool KeyFrameIdLess::operator()(const KeyFrame* a, const KeyFrame* b) con
 
 class Frame {
  public:
+  long unsigned int mnId = 0;   // include/Frame.h:271-272: unique per frame (nNextId++ in the constructors), shared by copies
   float mbf = 0, mb = 0;
   int N = 0;
   std::vector<cv::KeyPoint> mvKeys, mvKeysRight, mvKeysUn;

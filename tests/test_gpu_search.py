@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import pyoracle as po
-from orb_slam3_modified_amd import ORBextractor, ORBmatcher, synth
+from orb_slam3_modified_amd import ORBextractor, ORBmatcher, OrbxError, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -271,10 +271,20 @@ def _kf_grid(kps, fbounds, truncate):
 @pytest.mark.parametrize("fbounds,truncate,held", [((0.0, 0.0, 640.0, 480.0), False, True), ((-12.7, -9.4, 653.2, 488.9), True, True),
                                                    ((-12.7, -9.4, 653.2, 488.9), False, False)])
 def test_window_search_grid_equals_oracle(frames, fbounds, truncate, held):
+    _window_search_grid_case(frames, fbounds, truncate, held, 1)
+
+
+def test_window_search_grid_with_copies_and_synchronisation(frames):
+    """The same pass with `window_direct` off: input copy, result copy and a stream synchronisation instead of mapped pinned memory + polling."""
+    _window_search_grid_case(frames, (0.0, 0.0, 640.0, 480.0), False, True, 0)
+
+
+def _window_search_grid_case(frames, fbounds, truncate, held, direct):
     """orbx_window_search_grid (the device pass of the KeyFrame-side routines and the two-camera blocks): candidate lists in
     the reference's order, every distance, best / second — over a grid the caller holds, and over one assigned on the device."""
     gpu, fr = frames
     m = ORBmatcher(gpu)
+    m.set_option("window_direct", direct)
     k2, d2, d1 = fr[1].mvKeysUn, fr[1].mDescriptors, fr[0].mDescriptors
     rng = np.random.default_rng(11)
     nq = min(len(d1), 900)
@@ -302,6 +312,7 @@ def test_window_search_grid_equals_oracle(frames, fbounds, truncate, held):
     assert e["row_ptr"].tolist() == [0, 0, 0, 0] and e["best_idx"].tolist() == [-1, -1, -1] and e["best_dist"].tolist() == [256] * 3
     e = m.WindowSearchGrid(k2, d2, grid, qx[:0], qy[:0], qr[:0], lo[:0], hi[:0], d1[:0])
     assert e["row_ptr"].tolist() == [0] and len(e["cand"]) == 0
+    m.set_option("window_direct", 1)
 
 
 @pytest.mark.parametrize("chi2", [False, True])
@@ -330,3 +341,63 @@ def test_window_nearest_equals_oracle(frames, chi2):
     if chi2:   # the gate must bite: without it more queries find a candidate
         bi0, _ = po.window_nearest(k2, d2, grid, qx, qy, qr, lvl - 1, lvl, d1[:nq])
         assert (bi0 >= 0).sum() > (obi >= 0).sum()
+
+
+@pytest.mark.parametrize("held", [True, False])
+@pytest.mark.parametrize("direct", [1, 0])
+def test_resident_target_searches_equal_oracle(frames, held, direct):
+    """orbx_target_*: the frame uploaded once, searched repeatedly with different queries / skip flags / gates — every search equals the
+    oracle (and therefore the host-buffer entry points), in the single-kernel direct mode and with copies + synchronisation."""
+    gpu, fr = frames
+    m = ORBmatcher(gpu)
+    m.set_option("window_direct", direct)
+    k2, d2, d1 = fr[1].mvKeysUn, fr[1].mDescriptors, fr[0].mDescriptors
+    rng = np.random.default_rng(21)
+    grid = _kf_grid(k2, (-12.7, -9.4, 653.2, 488.9), True)
+    if not held:
+        grid = dict(grid, cell_start=None, cell_idx=None)
+    sf = np.float32(1.2) ** np.arange(8, dtype=np.float32)
+    inv_sigma2 = (1.0 / (sf * sf)).astype(np.float32)
+    ur = np.where(rng.random(len(k2)) < 0.3, -1.0, k2["x"] - rng.uniform(1, 40, len(k2))).astype(np.float32)
+    tgt = m.Target(k2, d2, grid, kp_uright=ur, inv_level_sigma2=inv_sigma2)
+    plain = m.Target(k2, d2, grid)
+    assert len(tgt) == len(k2) == len(plain)
+    for rep in range(4):
+        nq = int(rng.integers(300, min(len(d1), 900)))
+        src = rng.integers(0, len(k2), nq)
+        qx = (k2["x"][src] + rng.normal(0, 4, nq)).astype(np.float32); qy = (k2["y"][src] + rng.normal(0, 4, nq)).astype(np.float32)
+        qr = rng.choice([0.0, 2.5, 7.0, 15.0, 36.0, 120.0], nq).astype(np.float32)
+        lo = rng.choice([-1, 0, 1, 3], nq).astype(np.int32); hi = rng.choice([-1, 0, 2, 7], nq).astype(np.int32)
+        skip = (rng.random(len(k2)) < 0.2).astype(np.uint8)
+        xr = (qx - rng.uniform(1, 40, nq)).astype(np.float32)
+        qd = d1[rng.integers(0, len(d1), nq)]
+        for T, kw, okw in ((plain, dict(), dict()), (tgt, dict(kp_skip=skip), dict(kp_skip=skip)),
+                           (tgt, dict(kp_skip=skip, q_xr=xr), dict(kp_skip=skip, kp_uright=ur, q_xr=xr))):
+            got = T.search(qx, qy, qr, lo, hi, qd, **kw)
+            want = po.window_search_grid(k2, d2, grid, qx, qy, qr, lo, hi, qd, **okw)
+            for key in ("row_ptr", "cand", "dist", "best_idx", "best_dist", "second_idx", "second_dist"):
+                assert np.array_equal(got[key], want[key]), (rep, key, kw.keys())
+            best_only = T.search(qx, qy, qr, lo, hi, qd, want_lists=False, **kw)
+            assert np.array_equal(best_only["best_idx"], want["best_idx"]) and np.array_equal(best_only["row_ptr"], want["row_ptr"])
+        lvl = k2["octave"][src].astype(np.int32)
+        q_ur = np.where(ur[src] >= 0, ur[src] + rng.normal(0, 1.5, nq), qx - 5).astype(np.float32)
+        r3 = (np.float32(3.0) * sf[lvl]).astype(np.float32)
+        bi, bd = tgt.nearest(qx, qy, r3, lvl - 1, lvl, qd, q_ur=q_ur)
+        obi, obd = po.window_nearest(k2, d2, grid, qx, qy, r3, lvl - 1, lvl, qd, kp_uright=ur, inv_level_sigma2=inv_sigma2, q_ur=q_ur)
+        assert np.array_equal(bi, obi) and np.array_equal(bd, obd)
+        bi, bd = plain.nearest(qx, qy, r3, lvl - 1, lvl, qd)
+        obi, obd = po.window_nearest(k2, d2, grid, qx, qy, r3, lvl - 1, lvl, qd)
+        assert np.array_equal(bi, obi) and np.array_equal(bd, obd)
+    # a target without kp_uright refuses the gates that need it; empty queries and empty targets behave like the host-buffer calls
+    with pytest.raises(OrbxError):
+        plain.search(qx, qy, qr, lo, hi, qd, q_xr=xr)
+    with pytest.raises(OrbxError):
+        plain.nearest(qx, qy, qr, lo, hi, qd, q_ur=xr)
+    e = tgt.search(qx[:0], qy[:0], qr[:0], lo[:0], hi[:0], qd[:0])
+    assert e["row_ptr"].tolist() == [0] and len(e["cand"]) == 0
+    empty = m.Target(k2[:0], d2[:0], dict(grid, cell_start=None, cell_idx=None))
+    e = empty.search(qx[:3], qy[:3], qr[:3], lo[:3], hi[:3], qd[:3])
+    assert e["row_ptr"].tolist() == [0, 0, 0, 0] and e["best_idx"].tolist() == [-1, -1, -1]
+    for T in (tgt, plain, empty):
+        T.close()
+    m.set_option("window_direct", 1)
