@@ -25,6 +25,8 @@ namespace orbx {
 constexpr int kWinCols = 64, kWinRows = 48, kWinCells = kWinCols * kWinRows;   // include/Frame.h:44-45
 
 struct WinQueryOut { int32_t start, count, best_idx, best_dist, second_idx, second_dist, pad0, pad1; };
+struct WinQueryIn { float x, y, r, aux; int32_t lo, hi, pad0, pad1; uint32_t desc[8]; };   // 64 bytes
+static_assert(sizeof(WinQueryIn) == 64, "one cache line per query");
 
 struct WinArgs {
   const orbx_keypoint* kps;
@@ -32,9 +34,9 @@ struct WinArgs {
   const int32_t* cell_start;   // [kWinCells + 1]
   const int32_t* cell_idx;
   float minX, minY, invW, invH;
-  const float *qx, *qy, *qr, *qaux;
-  const int32_t *qlo, *qhi;
-  const uint8_t* qdesc;
+  const WinQueryIn* qin;   // one 64-byte record per query: a wave fetches its query in ONE coalesced read (the records may sit in mapped host
+                           // memory, where nine small reads per query cost nine PCIe transactions each)
+  int has_aux;             // the records carry q_xr / q_ur
   int nq;
   const uint8_t* kp_skip;
   const float* kp_uright;
@@ -83,9 +85,11 @@ __global__ __launch_bounds__(256) void k_window(const WinArgs a) {
   const int lane = threadIdx.x & 63;
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= a.nq) return;
-  const float x = a.qx[q], y = a.qy[q], r = a.qr[q];
-  const int minLevel = a.qlo[q], maxLevel = a.qhi[q];
-  const float aux = a.qaux ? a.qaux[q] : 0.f;
+  const uint32_t rec = ((const uint32_t*)(a.qin + q))[lane & 15];   // 64 bytes, one request
+  const float x = __uint_as_float(__builtin_amdgcn_readlane(rec, 0)), y = __uint_as_float(__builtin_amdgcn_readlane(rec, 1));
+  const float r = __uint_as_float(__builtin_amdgcn_readlane(rec, 2));
+  const float aux = a.has_aux ? __uint_as_float(__builtin_amdgcn_readlane(rec, 3)) : 0.f;
+  const int minLevel = (int)__builtin_amdgcn_readlane(rec, 4), maxLevel = (int)__builtin_amdgcn_readlane(rec, 5);
   const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
   // src/Frame.cc:665-687 with separately rounded float operations
   const int nMinCellX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, a.minX), r), a.invW)));
@@ -115,51 +119,88 @@ __global__ __launch_bounds__(256) void k_window(const WinArgs a) {
         if (ur >= 0.f) { const float er = __fsub_rn(aux, ur); e2 = __fadd_rn(e2, __fmul_rn(er, er)); lim = 7.8; }
         if ((double)__fmul_rn(e2, a.inv_sigma2[octave]) > lim) ok = false;
       }
-    } else if (a.kp_uright && a.qaux) {
+    } else if (a.kp_uright && a.has_aux) {
       const float ur = a.kp_uright[idx];
       if (ur > 0.f && fabsf(__fsub_rn(aux, ur)) > r) ok = false;
     }
     return ok;
   };
 
+  // The window is a short list of CSR segments — one per grid column, the rows of a column are contiguous — and everything about a
+  // candidate hangs on a chain of dependent loads (segment bounds -> keypoint index -> keypoint -> descriptor).  Walking the columns
+  // one after the other pays that chain per column (a latency-bound kernel: ~1 us per link on a GPU that idles between calls), so
+  // the segments are laid end to end instead: lane c fetches the bounds of column c (one round trip for all columns), a wave scan
+  // gives every segment its offset in the concatenated list, and the lanes then stride that list — one chain per 64 candidates.
+  __shared__ int seg_off[4][kWinCols + 1], seg_beg[4][kWinCols];
+  int* soff = seg_off[threadIdx.x >> 6];
+  int* sbeg = seg_beg[threadIdx.x >> 6];
+  const int ncol = any ? max(nMaxCellX - nMinCellX + 1, 0) : 0;   // <= 64
+  int len = 0, beg = 0;
+  if (lane < ncol) {
+    const int ix = nMinCellX + lane;
+    beg = a.cell_start[ix * kWinRows + nMinCellY];
+    len = max(a.cell_start[ix * kWinRows + nMaxCellY + 1] - beg, 0);   // (an inverted row range, like the reference's empty loop)
+  }
+  int inc = len;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+  const int ntot = __shfl(inc, 63);
+  if (lane < ncol) { soff[lane] = inc - len; sbeg[lane] = beg; }
+  if (lane == 0) soff[ncol] = ntot;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  auto cell_slot = [&](int p) -> int {   // position p of the concatenated list -> index into cell_idx
+    int lo = 0, hi = ncol - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (soff[mid] <= p) lo = mid; else hi = mid - 1;
+    }
+    return sbeg[lo] + (p - soff[lo]);
+  };
+
   int count = 0, base = 0;
-  if (LISTS) {   // pass 1: how many, so that the query's candidates get one contiguous segment of the pool
-    if (any)
-      for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
-        const int s = a.cell_start[ix * kWinRows + nMinCellY], e = a.cell_start[ix * kWinRows + nMaxCellY + 1];
-        for (int b0 = s; b0 < e; b0 += 64) {
-          const int j = b0 + lane;
-          int idx = 0;
-          const bool ok = j < e && passes(j, idx);
-          count += __popcll(__ballot(ok));
-        }
+  const bool one_round = ntot <= 64;   // wave-uniform; the usual case: everything about the candidates stays in registers
+  bool ok1 = false;
+  int idx1 = 0;
+  if (LISTS) {   // how many, so that the query's candidates get one contiguous segment of the pool
+    if (one_round) {
+      ok1 = lane < ntot && passes(cell_slot(lane), idx1);
+      count = __popcll(__ballot(ok1));
+    } else {
+      for (int p0 = 0; p0 < ntot; p0 += 64) {
+        const int p = p0 + lane;
+        int idx = 0;
+        const bool ok = p < ntot && passes(cell_slot(p), idx);
+        count += __popcll(__ballot(ok));
       }
+    }
     if (lane == 0 && count) base = atomicAdd(a.total, count);
     base = __shfl(base, 0);
   }
   const bool write = LISTS && count && base + count <= a.pool_cap;
-  const WDesc dq = wload(a.qdesc + (size_t)q * 32);
+  WDesc dq;
+#pragma unroll
+  for (int w = 0; w < 4; w++)
+    dq.w[w] = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane(rec, 8 + 2 * w) |   // (the builtin returns int: no sign extension)
+              (unsigned long long)(uint32_t)__builtin_amdgcn_readlane(rec, 9 + 2 * w) << 32;
   unsigned long long k1 = kNoWinKey, k2 = kNoWinKey;
   int pos = 0;
-  if (any)
-    for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
-      const int s = a.cell_start[ix * kWinRows + nMinCellY], e = a.cell_start[ix * kWinRows + nMaxCellY + 1];
-      for (int b0 = s; b0 < e; b0 += 64) {
-        const int j = b0 + lane;
-        int idx = 0;
-        const bool ok = j < e && passes(j, idx);
-        const unsigned long long bal = __ballot(ok);
-        if (ok) {
-          const int my = pos + __popcll(bal & ((1ull << lane) - 1ull));
-          const int d = wham(dq, wload(a.desc + (size_t)idx * 32));
-          const unsigned long long key = ((unsigned long long)d << 48) | ((unsigned long long)my << 24) | (unsigned long long)idx;
-          if (key < k1) { k2 = k1; k1 = key; }
-          else if (key < k2) k2 = key;
-          if (write) a.pool[base + my] = make_int2(idx, d);
-        }
-        pos += __popcll(bal);
-      }
+  for (int p0 = 0; p0 < ntot; p0 += 64) {
+    const int p = p0 + lane;
+    int idx = idx1;
+    const bool ok = (LISTS && one_round) ? ok1 : (p < ntot && passes(cell_slot(p), idx));
+    const unsigned long long bal = __ballot(ok);
+    if (ok) {
+      const int my = pos + __popcll(bal & ((1ull << lane) - 1ull));
+      const int d = wham(dq, wload(a.desc + (size_t)idx * 32));
+      const unsigned long long key = ((unsigned long long)d << 48) | ((unsigned long long)my << 24) | (unsigned long long)idx;
+      if (key < k1) { k2 = k1; k1 = key; }
+      else if (key < k2) k2 = key;
+      if (write) a.pool[base + my] = make_int2(idx, d);
     }
+    pos += __popcll(bal);
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const unsigned long long p1 = __shfl_xor(k1, o), p2 = __shfl_xor(k2, o);
@@ -313,6 +354,16 @@ hipError_t host_stage(orbx_ctx* ctx, size_t bytes, uint8_t** p) {
 
 typedef BlobLayout Layout;
 
+static void pack_queries(uint8_t* dst, const float* qx, const float* qy, const float* qr, const float* qaux, const int32_t* qlo, const int32_t* qhi,
+                         const uint8_t* q_desc, int nq) {
+  WinQueryIn* o = (WinQueryIn*)dst;
+  for (int q = 0; q < nq; q++) {
+    o[q].x = qx[q]; o[q].y = qy[q]; o[q].r = qr[q]; o[q].aux = qaux ? qaux[q] : 0.f;
+    o[q].lo = qlo[q]; o[q].hi = qhi[q]; o[q].pad0 = o[q].pad1 = 0;
+    std::memcpy(o[q].desc, q_desc + (size_t)q * 32, 32);
+  }
+}
+
 // Input blob from mapped pinned host memory into HBM, 16 bytes per lane (the window kernel gathers keypoints and descriptors at
 // random: those reads must not cross PCIe one by one).  One launch costs less than a hipMemcpyAsync of the same 100 KB.
 __global__ __launch_bounds__(256) void k_stage_in(const uint4* __restrict__ src, uint4* __restrict__ dst, int n16) {
@@ -359,8 +410,7 @@ int window_call(orbx_ctx* ctx, const char* who, const orbx_keypoint* kps, const 
   Layout in;
   const size_t o_total = in.add(16);
   const size_t o_kps = in.add(sizeof(orbx_keypoint) * (size_t)n), o_desc = in.add((size_t)n * 32);
-  const size_t o_qx = in.add(4 * (size_t)nq), o_qy = in.add(4 * (size_t)nq), o_qr = in.add(4 * (size_t)nq), o_qaux = in.add(4 * (size_t)nq);
-  const size_t o_qlo = in.add(4 * (size_t)nq), o_qhi = in.add(4 * (size_t)nq), o_qd = in.add((size_t)nq * 32);
+  const size_t o_q = in.add(sizeof(WinQueryIn) * (size_t)nq);
   const size_t o_skip = in.add(kp_skip ? (size_t)n : 0), o_ur = in.add(kp_uright ? 4 * (size_t)n : 0);
   const size_t o_sig = in.add(inv_sigma2 ? 4 * (size_t)nlevels : 0);
   const size_t o_cs = in.add(4 * (size_t)(kWinCells + 1)), o_ci = in.add(4 * (size_t)std::max(ngrid, 1));
@@ -376,10 +426,7 @@ int window_call(orbx_ctx* ctx, const char* who, const orbx_keypoint* kps, const 
   std::memset(hin + o_total, 0, 16);
   std::memcpy(hin + o_kps, kps, sizeof(orbx_keypoint) * (size_t)n);
   std::memcpy(hin + o_desc, desc, (size_t)n * 32);
-  std::memcpy(hin + o_qx, qx, 4 * (size_t)nq); std::memcpy(hin + o_qy, qy, 4 * (size_t)nq); std::memcpy(hin + o_qr, qr, 4 * (size_t)nq);
-  if (qaux) std::memcpy(hin + o_qaux, qaux, 4 * (size_t)nq);
-  std::memcpy(hin + o_qlo, qlo, 4 * (size_t)nq); std::memcpy(hin + o_qhi, qhi, 4 * (size_t)nq);
-  std::memcpy(hin + o_qd, q_desc, (size_t)nq * 32);
+  pack_queries(hin + o_q, qx, qy, qr, qaux, qlo, qhi, q_desc, nq);
   if (kp_skip) std::memcpy(hin + o_skip, kp_skip, (size_t)n);
   if (kp_uright) std::memcpy(hin + o_ur, kp_uright, 4 * (size_t)n);
   if (inv_sigma2) std::memcpy(hin + o_sig, inv_sigma2, 4 * (size_t)nlevels);
@@ -423,9 +470,7 @@ int window_call(orbx_ctx* ctx, const char* who, const orbx_keypoint* kps, const 
   a.kps = (const orbx_keypoint*)(din + o_kps); a.desc = din + o_desc;
   a.cell_start = (const int32_t*)(din + o_cs); a.cell_idx = (const int32_t*)(din + o_ci);
   a.minX = grid->min_x; a.minY = grid->min_y; a.invW = grid->inv_w; a.invH = grid->inv_h;
-  a.qx = (const float*)(din + o_qx); a.qy = (const float*)(din + o_qy); a.qr = (const float*)(din + o_qr);
-  a.qaux = qaux ? (const float*)(din + o_qaux) : nullptr;
-  a.qlo = (const int32_t*)(din + o_qlo); a.qhi = (const int32_t*)(din + o_qhi); a.qdesc = din + o_qd; a.nq = nq;
+  a.qin = (const WinQueryIn*)(din + o_q); a.has_aux = qaux ? 1 : 0; a.nq = nq;
   a.kp_skip = kp_skip ? din + o_skip : nullptr;
   a.kp_uright = kp_uright ? (const float*)(din + o_ur) : nullptr;
   a.inv_sigma2 = inv_sigma2 ? (const float*)(din + o_sig) : nullptr;
@@ -633,8 +678,7 @@ int window_call_target(orbx_ctx* ctx, const char* who, const orbx_target* T, con
   const int pool_cap = lists ? std::max(cand_cap, 0) : 0;
   const int nskip = kp_skip ? (n + 3) & ~3 : 0;
   Layout in;
-  const size_t o_qx = in.add(4 * (size_t)nq), o_qy = in.add(4 * (size_t)nq), o_qr = in.add(4 * (size_t)nq), o_qaux = in.add(4 * (size_t)nq);
-  const size_t o_qlo = in.add(4 * (size_t)nq), o_qhi = in.add(4 * (size_t)nq), o_qd = in.add((size_t)nq * 32), o_skip = in.add((size_t)nskip);
+  const size_t o_q = in.add(sizeof(WinQueryIn) * (size_t)nq), o_skip = in.add((size_t)nskip);
   Layout out;
   const bool compact = !(best_idx || best_dist || second_idx || second_dist);
   const size_t qrec = compact ? sizeof(WinQueryShort) : sizeof(WinQueryOut);
@@ -643,10 +687,7 @@ int window_call_target(orbx_ctx* ctx, const char* who, const orbx_target* T, con
   ORBX_HIP(ctx, host_stage(ctx, in.size + out.size, &h));
   uint8_t* hin = h;
   uint8_t* hout = h + in.size;
-  std::memcpy(hin + o_qx, qx, 4 * (size_t)nq); std::memcpy(hin + o_qy, qy, 4 * (size_t)nq); std::memcpy(hin + o_qr, qr, 4 * (size_t)nq);
-  if (qaux) std::memcpy(hin + o_qaux, qaux, 4 * (size_t)nq);
-  std::memcpy(hin + o_qlo, qlo, 4 * (size_t)nq); std::memcpy(hin + o_qhi, qhi, 4 * (size_t)nq);
-  std::memcpy(hin + o_qd, q_desc, (size_t)nq * 32);
+  pack_queries(hin + o_q, qx, qy, qr, qaux, qlo, qhi, q_desc, nq);
   if (kp_skip) { std::memcpy(hin + o_skip, kp_skip, (size_t)n); std::memset(hin + o_skip + n, 0, (size_t)(nskip - n)); }
   std::memset(hout + p_hdr, 0, 16);
   const double us_pack = since(tr0);
@@ -680,9 +721,7 @@ int window_call_target(orbx_ctx* ctx, const char* who, const orbx_target* T, con
   a.kps = (const orbx_keypoint*)(T->dev + T->o_kps); a.desc = T->dev + T->o_desc;
   a.cell_start = (const int32_t*)(T->dev + T->o_cs); a.cell_idx = (const int32_t*)(T->dev + T->o_ci);
   a.minX = T->min_x; a.minY = T->min_y; a.invW = T->inv_w; a.invH = T->inv_h;
-  a.qx = (const float*)(qbase + o_qx); a.qy = (const float*)(qbase + o_qy); a.qr = (const float*)(qbase + o_qr);
-  a.qaux = qaux ? (const float*)(qbase + o_qaux) : nullptr;
-  a.qlo = (const int32_t*)(qbase + o_qlo); a.qhi = (const int32_t*)(qbase + o_qhi); a.qdesc = qbase + o_qd; a.nq = nq;
+  a.qin = (const WinQueryIn*)(qbase + o_q); a.has_aux = qaux ? 1 : 0; a.nq = nq;
   if (kp_skip) { if (direct) { a.skip_map = qbase + o_skip; a.n_skip = nskip; } else a.kp_skip = qbase + o_skip; }
   a.kp_uright = T->has_ur ? (const float*)(T->dev + T->o_ur) : nullptr;
   a.inv_sigma2 = chi2 ? (const float*)(T->dev + T->o_sig) : nullptr;

@@ -114,6 +114,22 @@ for _ in range(20): nmp_, _m = _sbp()
 res["search_by_projection_mappoints"] = {"map_points": len(ka), "keypoints": len(Fp.mvKeysUn), "matches": int(nmp_),
                                          "ms_per_call": (time.perf_counter() - t0) / 20 * 1e3,
                                          "note": "host buffers; one device pass (grid, windows, gates, distances), greedy replay on the host"}
+# the same windows on a RESIDENT target (orbx_target_*): the frame uploaded once, then searched — what the second and later matcher calls on a frame cost
+try:
+    kT, dT = Fp.mvKeysUn, Fp.mDescriptors
+    gridT = dict(min_x=0.0, min_y=0.0, inv_w=64.0 / 640.0, inv_h=48.0 / 480.0, cell_start=None, cell_idx=None)
+    Tg = m8.Target(kT, dT, gridT)
+    lvlq = mp["level"]
+    qrT = (np.float32(3.0) * np.float32(1.2) ** lvlq).astype(np.float32)
+    for want_lists, key in ((True, "target_search_resident_lists"), (False, "target_search_resident_best_only")):
+        for _ in range(5): Tg.search(mp["proj_x"], mp["proj_y"], qrT, lvlq - 1, lvlq, mp["desc"], want_lists=want_lists)
+        t0 = time.perf_counter()
+        for _ in range(100): rT = Tg.search(mp["proj_x"], mp["proj_y"], qrT, lvlq - 1, lvlq, mp["desc"], want_lists=want_lists)
+        res[key] = {"queries": len(lvlq), "keypoints": len(kT), "candidates": int(rT["row_ptr"][-1]), "us_per_call": (time.perf_counter() - t0) / 100 * 1e6,
+                    "note": "python ctypes caller; one kernel: queries read from mapped pinned memory, results written there, host polls"}
+    Tg.close()
+except Exception as e:  # noqa: BLE001
+    res["target_search_resident"] = {"error": str(e)[:200]}
 # the fork's own configuration (Examples/Monocular/mi.yaml): 600x800, 20 000 features on one level -> quadtree nodes in HBM
 try:
     exm = ORBextractor(20000, 1.2, 1, 20, 7)
