@@ -458,8 +458,14 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
     int gk[7];
     gaussian_kernel7(gk);
     BlurConsts bc;
-    bc.w0 = (uint32_t)gk[0] | ((uint32_t)gk[1] << 8) | ((uint32_t)gk[2] << 16) | ((uint32_t)gk[3] << 24);
-    bc.w1 = (uint32_t)gk[4] | ((uint32_t)gk[5] << 8) | ((uint32_t)gk[6] << 16);
+    auto b4 = [&](int a, int b, int c, int d) {   // weights of the four bytes of a dword; index -1 = no tap
+      auto w = [&](int i) { return i < 0 ? 0u : (uint32_t)gk[i]; };
+      return w(a) | (w(b) << 8) | (w(c) << 16) | (w(d) << 24);
+    };
+    bc.hw[0] = b4(-1, 0, 1, 2); bc.hw[1] = b4(3, 4, 5, 6);                              // output x: bytes x+1 .. x+7 of d0 d1 d2
+    bc.hw[2] = b4(-1, -1, 0, 1); bc.hw[3] = b4(2, 3, 4, 5); bc.hw[4] = b4(6, -1, -1, -1);
+    bc.hw[5] = b4(-1, -1, -1, 0); bc.hw[6] = b4(1, 2, 3, 4); bc.hw[7] = b4(5, 6, -1, -1);
+    bc.hw[8] = b4(0, 1, 2, 3); bc.hw[9] = b4(4, 5, 6, -1);
     const uint32_t k0 = gk[0], k1 = gk[1], k2 = gk[2], k3 = gk[3], k4 = gk[4], k5 = gk[5], k6 = gk[6];
     bc.we[0] = k0 | k1 << 16; bc.we[1] = k2 | k3 << 16; bc.we[2] = k4 | k5 << 16; bc.we[3] = k6;
     bc.wo[0] = k0 << 16; bc.wo[1] = k1 | k2 << 16; bc.wo[2] = k3 | k4 << 16; bc.wo[3] = k5 | k6 << 16;

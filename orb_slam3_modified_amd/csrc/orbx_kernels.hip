@@ -1635,7 +1635,7 @@ __global__ __launch_bounds__(256) void k_assemble(const DeviceGeom* __restrict__
 //   * vertical pass: v_dot2_u32_u16 on those pairs (4 instructions per pixel, exact 32-bit accumulation,
 //     single rounding (acc + 2^15) >> 16), one lane = 2 rows x 4 px, one dword store per row.
 // ------------------------------------------------------------------------------------------------
-struct BlurConsts { uint32_t w0, w1; uint32_t we[4], wo[4]; };
+struct BlurConsts { uint32_t hw[10]; uint32_t we[4], wo[4]; };   // hw: the 7 horizontal weights at the four byte alignments (hrow4)
 
 __device__ __forceinline__ int reflect101(int p, int n) {
   while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
@@ -1661,13 +1661,15 @@ __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {
   return __builtin_amdgcn_udot2(va, vb, c, false);
 }
 
-// horizontal 7-tap sums of 4 adjacent pixels: output x (tile coords 4j..4j+3) reads raw bytes x+1 .. x+7
+// horizontal 7-tap sums of 4 adjacent pixels: output x (tile coords 4j..4j+3) reads raw bytes x+1 .. x+7 of the 12-byte window
+// d0 d1 d2.  The window is not shifted to the weights (six v_alignbyte per row): the WEIGHTS come pre-shifted to the four alignments,
+// zero where a dword holds no tap — ten v_dot4 per row and no byte shuffling (exact u32 sums, same result).
 __device__ __forceinline__ void hrow4(const uint32_t* rw, const BlurConsts& bc, uint32_t (&a)[4]) {
   const uint32_t d0 = rw[0], d1 = rw[1], d2 = rw[2];
-  a[0] = __builtin_amdgcn_udot4(bytes4<1>(d0, d1, d2), bc.w0, __builtin_amdgcn_udot4(bytes4<5>(d0, d1, d2), bc.w1, 0u, false), false);
-  a[1] = __builtin_amdgcn_udot4(bytes4<2>(d0, d1, d2), bc.w0, __builtin_amdgcn_udot4(bytes4<6>(d0, d1, d2), bc.w1, 0u, false), false);
-  a[2] = __builtin_amdgcn_udot4(bytes4<3>(d0, d1, d2), bc.w0, __builtin_amdgcn_udot4(bytes4<7>(d0, d1, d2), bc.w1, 0u, false), false);
-  a[3] = __builtin_amdgcn_udot4(d1, bc.w0, __builtin_amdgcn_udot4(d2, bc.w1, 0u, false), false);
+  a[0] = __builtin_amdgcn_udot4(d0, bc.hw[0], __builtin_amdgcn_udot4(d1, bc.hw[1], 0u, false), false);
+  a[1] = __builtin_amdgcn_udot4(d0, bc.hw[2], __builtin_amdgcn_udot4(d1, bc.hw[3], __builtin_amdgcn_udot4(d2, bc.hw[4], 0u, false), false), false);
+  a[2] = __builtin_amdgcn_udot4(d0, bc.hw[5], __builtin_amdgcn_udot4(d1, bc.hw[6], __builtin_amdgcn_udot4(d2, bc.hw[7], 0u, false), false), false);
+  a[3] = __builtin_amdgcn_udot4(d1, bc.hw[8], __builtin_amdgcn_udot4(d2, bc.hw[9], 0u, false), false);
 }
 
 __global__ __launch_bounds__(256) void k_blur7(const DeviceGeom* __restrict__ g, const uint8_t* __restrict__ imgs,
@@ -1704,18 +1706,31 @@ __global__ __launch_bounds__(256) void k_blur7(const DeviceGeom* __restrict__ g,
       const int sx = x0 - 4 + 4 * c;
       const bool inx = sx >= 0 && sx < w;
       uint32_t* dstp = (uint32_t*)raw + rph * (kBT_RP / 4) + c;
+      if (y0 >= 3 && y0 - 3 + kBT_RR <= h) {   // block-uniform: every source row exists (all tiles but the first and last rows of tiles)
+        const uint8_t* colp = img + (uint32_t)(__mul24(y0 - 3 + rph, pitch) + sx);
+        const uint32_t step = (uint32_t)__mul24(14, pitch);
 #pragma unroll
-      for (int k = 0; k < (kBT_RR + 13) / 14; k++) {
-        const int r = rph + 14 * k;
-        if (r < kBT_RR) {
-          // reflect-101 row: one reflection covers every row a stored output reads (h >= 67); rows further below the
-          // level (only in the last tile row, never stored) just need a valid address
-          int sy = y0 - 3 + r;
-          sy = sy < 0 ? -sy : (sy >= h ? 2 * h - 2 - sy : sy);
-          sy = max(sy, 0);
-          uint32_t v = 0;
-          if (inx) v = *(const uint32_t*)(img + (uint32_t)(__mul24(sy, pitch) + sx));
-          dstp[k * 14 * (kBT_RP / 4)] = v;
+        for (int k = 0; k < (kBT_RR + 13) / 14; k++) {
+          if (rph + 14 * k < kBT_RR) {
+            uint32_t v = 0;
+            if (inx) v = *(const uint32_t*)(colp + k * step);
+            dstp[k * 14 * (kBT_RP / 4)] = v;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < (kBT_RR + 13) / 14; k++) {
+          const int r = rph + 14 * k;
+          if (r < kBT_RR) {
+            // reflect-101 row: one reflection covers every row a stored output reads (h >= 67); rows further below the
+            // level (only in the last tile row, never stored) just need a valid address
+            int sy = y0 - 3 + r;
+            sy = sy < 0 ? -sy : (sy >= h ? 2 * h - 2 - sy : sy);
+            sy = max(sy, 0);
+            uint32_t v = 0;
+            if (inx) v = *(const uint32_t*)(img + (uint32_t)(__mul24(sy, pitch) + sx));
+            dstp[k * 14 * (kBT_RP / 4)] = v;
+          }
         }
       }
     }
