@@ -2,6 +2,10 @@
 // DBoW2 vocabulary descent / L1 scoring, behind the C ABI of include/orbx.h.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -370,6 +374,9 @@ int orbx_nn_csr(orbx_ctx* ctx, const uint8_t* q_desc, int nq, const uint8_t* t_d
   if (nnz < 0 || (nnz > 0 && (!cand || !t_desc))) return set_err(ctx, ORBX_E_INVALID, "orbx_nn_csr: bad candidate lists");
   for (int i = 0; i < nnz; i++)
     if (cand[i] < 0 || cand[i] >= nt) return set_err(ctx, ORBX_E_INVALID, "candidate index out of range");
+  static const bool trace = getenv("ORBX_TRACE_WINDOW") != nullptr;   // phase times of every call on stderr (diagnostics)
+  const auto tr0 = std::chrono::steady_clock::now();
+  auto since = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr0).count(); };
   ORBX_HIP(ctx, hipSetDevice(ctx->device));
   // one packed blob in (one H2D copy), one launch, one blob out (one D2H copy): no per-call allocation
   const bool want_best = best_idx || best_dist || second_idx || second_dist;
@@ -384,6 +391,7 @@ int orbx_nn_csr(orbx_ctx* ctx, const uint8_t* q_desc, int nq, const uint8_t* t_d
   if (nt) std::memcpy(hin + o_t, t_desc, (size_t)nt * 32);
   std::memcpy(hin + o_rp, row_ptr, 4 * (size_t)(nq + 1));
   if (nnz) std::memcpy(hin + o_c, cand, 4 * (size_t)nnz);
+  const double us_pack = since();
   ctx->arena.rewind();
   hipError_t aerr = hipSuccess;
   uint8_t* din = (uint8_t*)ctx->arena.alloc(in.size, &aerr);
@@ -398,13 +406,18 @@ int orbx_nn_csr(orbx_ctx* ctx, const uint8_t* q_desc, int nq, const uint8_t* t_d
                               want_best ? db + 3 * (size_t)nq : nullptr, dist_out ? (int32_t*)(dout + p_d) : nullptr, st);
   if (rc != ORBX_OK) return rc;
   if (out.size) ORBX_HIP(ctx, hipMemcpyAsync(hout, dout, out.size, hipMemcpyDeviceToHost, st));
+  const double us_issue = since();
   ORBX_HIP(ctx, hipStreamSynchronize(st));
+  const double us_sync = since();
   const int32_t* hb = (const int32_t*)(hout + p_b);
   if (best_idx) std::memcpy(best_idx, hb, 4 * (size_t)nq);
   if (best_dist) std::memcpy(best_dist, hb + nq, 4 * (size_t)nq);
   if (second_idx) std::memcpy(second_idx, hb + 2 * (size_t)nq, 4 * (size_t)nq);
   if (second_dist) std::memcpy(second_dist, hb + 3 * (size_t)nq, 4 * (size_t)nq);
   if (dist_out && nnz) std::memcpy(dist_out, hout + p_d, 4 * (size_t)nnz);
+  if (trace)
+    std::fprintf(stderr, "[orbx window] orbx_nn_csr nq=%d nt=%d pairs=%d in=%zu B out=%zu B: pack %.1f us, issue %.1f, wait %.1f, scatter %.1f\n", nq, nt, nnz,
+                 in.size, out.size, us_pack, us_issue - us_pack, us_sync - us_issue, since() - us_sync);
   return ORBX_OK;
 }
 
