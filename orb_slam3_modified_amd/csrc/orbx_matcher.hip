@@ -70,7 +70,8 @@ __global__ __launch_bounds__(256) void k_nn_csr(const uint8_t* __restrict__ q, i
                                                 const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ cand,
                                                 int last_wins, int32_t* __restrict__ best_idx, int32_t* __restrict__ best_dist,
                                                 int32_t* __restrict__ second_idx, int32_t* __restrict__ second_dist,
-                                                int32_t* __restrict__ dist_out) {
+                                                int32_t* __restrict__ dist_out, unsigned* __restrict__ ctr,
+                                                unsigned long long* __restrict__ done_host) {
   const int lane = threadIdx.x & 63;
   const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (qi >= nq) return;
@@ -97,6 +98,16 @@ __global__ __launch_bounds__(256) void k_nn_csr(const uint8_t* __restrict__ q, i
       if (last_wins) pos = 0xffffffffu - pos;
       if (oi) oi[qi] = cand[b + (int)pos];
       if (od) od[qi] = (int32_t)(k >> 32);
+    }
+  }
+  // host-buffer calls write their results into mapped pinned memory: every wave makes its stores visible to the host before it
+  // counts itself, the last one raises the done word the host polls (the counter wraps back to zero for the next call)
+  if (done_host) {
+    __threadfence_system();
+    if (lane == 0 && atomicInc(ctr, (unsigned)nq - 1u) == (unsigned)nq - 1u) {
+      __threadfence();
+      __atomic_store_n(done_host, 1ull, __ATOMIC_RELEASE);
+      __threadfence_system();
     }
   }
 }
@@ -360,9 +371,14 @@ int orbx_nn_csr_device(orbx_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t*
   ORBX_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
   hipLaunchKernelGGL(k_nn_csr, dim3((nq + 3) / 4), dim3(256), 0, st, d_q, nq, d_t, d_row_ptr, d_cand, last_wins, d_best_idx,
-                     d_best_dist, d_second_idx, d_second_dist, d_dist_out);
+                     d_best_dist, d_second_idx, d_second_dist, d_dist_out, (unsigned*)nullptr, (unsigned long long*)nullptr);
   ORBX_HIP(ctx, hipGetLastError());
   return ORBX_OK;
+}
+
+// input blob from mapped pinned memory into HBM (the kernel gathers train descriptors at random); cheaper than a hipMemcpyAsync
+__global__ __launch_bounds__(256) void k_nn_stage_in(const uint4* __restrict__ src, uint4* __restrict__ dst, int n16) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = src[i];
 }
 
 int orbx_nn_csr(orbx_ctx* ctx, const uint8_t* q_desc, int nq, const uint8_t* t_desc, int nt, const int32_t* row_ptr,
@@ -382,7 +398,7 @@ int orbx_nn_csr(orbx_ctx* ctx, const uint8_t* q_desc, int nq, const uint8_t* t_d
   const bool want_best = best_idx || best_dist || second_idx || second_dist;
   BlobLayout in, out;
   const size_t o_q = in.add((size_t)nq * 32), o_t = in.add((size_t)nt * 32), o_rp = in.add(4 * (size_t)(nq + 1)), o_c = in.add(4 * (size_t)nnz);
-  const size_t p_b = out.add(want_best ? 16 * (size_t)nq : 0), p_d = out.add(dist_out ? 4 * (size_t)nnz : 0);
+  const size_t p_b = out.add(want_best ? 16 * (size_t)nq : 0), p_d = out.add(dist_out ? 4 * (size_t)nnz : 0), p_done = out.add(16);
   uint8_t* h = nullptr;
   ORBX_HIP(ctx, host_stage(ctx, in.size + out.size, &h));
   uint8_t* hin = h;
@@ -399,15 +415,53 @@ int orbx_nn_csr(orbx_ctx* ctx, const uint8_t* q_desc, int nq, const uint8_t* t_d
   uint8_t* dout = (uint8_t*)ctx->arena.alloc(std::max<size_t>(out.size, 256), &aerr);
   ORBX_HIP(ctx, aerr);
   hipStream_t st = ctx->stream;
-  ORBX_HIP(ctx, hipMemcpyAsync(din, hin, in.size, hipMemcpyHostToDevice, st));
-  int32_t* db = (int32_t*)(dout + p_b);
-  int rc = orbx_nn_csr_device(ctx, din + o_q, nq, din + o_t, nt, (const int32_t*)(din + o_rp), (const int32_t*)(din + o_c), last_wins,
-                              want_best ? db : nullptr, want_best ? db + nq : nullptr, want_best ? db + 2 * (size_t)nq : nullptr,
-                              want_best ? db + 3 * (size_t)nq : nullptr, dist_out ? (int32_t*)(dout + p_d) : nullptr, st);
-  if (rc != ORBX_OK) return rc;
-  if (out.size) ORBX_HIP(ctx, hipMemcpyAsync(hout, dout, out.size, hipMemcpyDeviceToHost, st));
-  const double us_issue = since();
-  ORBX_HIP(ctx, hipStreamSynchronize(st));
+  // direct mode (as the window pass, orbx_window.hip): inputs pulled by a copy kernel from the mapped pinned blob, results written
+  // into it, the host polls a done word; "window_direct" = 0 selects copies + stream synchronisation
+  uint8_t* hdev = nullptr;
+  const bool direct = ctx->window_direct && hipHostGetDevicePointer((void**)&hdev, h, 0) == hipSuccess && hdev != nullptr;
+  if (!direct) (void)hipGetLastError();
+  double us_issue;
+  if (direct) {
+    if (!ctx->d_win_ctr) { ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_win_ctr, 64)); ctx->win_ctr_dirty = true; }
+    if (ctx->win_ctr_dirty) { ORBX_HIP(ctx, hipMemsetAsync(ctx->d_win_ctr, 0, 64, st)); ctx->win_ctr_dirty = false; }
+    volatile unsigned long long* done = (volatile unsigned long long*)(hout + p_done);
+    __atomic_store_n(done, 0ull, __ATOMIC_RELEASE);
+    const int n16 = (int)((in.size + 15) / 16);
+    hipLaunchKernelGGL(k_nn_stage_in, dim3(std::min((n16 + 255) / 256, 512)), dim3(256), 0, st, (const uint4*)hdev, (uint4*)din, n16);
+    int32_t* rb = (int32_t*)(hdev + in.size + p_b);
+    ctx->win_ctr_dirty = true;
+    hipLaunchKernelGGL(k_nn_csr, dim3((nq + 3) / 4), dim3(256), 0, st, din + o_q, nq, din + o_t, (const int32_t*)(din + o_rp),
+                       (const int32_t*)(din + o_c), last_wins, want_best ? rb : nullptr, want_best ? rb + nq : nullptr,
+                       want_best ? rb + 2 * (size_t)nq : nullptr, want_best ? rb + 3 * (size_t)nq : nullptr,
+                       dist_out ? (int32_t*)(hdev + in.size + p_d) : nullptr, (unsigned*)ctx->d_win_ctr + 8, (unsigned long long*)(hdev + in.size + p_done));
+    ORBX_HIP(ctx, hipGetLastError());
+    us_issue = since();
+    for (unsigned spin = 1;; spin++) {
+      if (__atomic_load_n(done, __ATOMIC_ACQUIRE)) break;
+      if ((spin & 0x3fff) == 0) {
+        const hipError_t qe = hipStreamQuery(st);
+        if (qe == hipSuccess) {
+          if (__atomic_load_n(done, __ATOMIC_ACQUIRE)) break;
+          return set_err(ctx, ORBX_E_DEVICE, "orbx_nn_csr: the pass finished without publishing its results");
+        }
+        if (qe != hipErrorNotReady) { ORBX_HIP(ctx, qe); }
+      }
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+    ctx->win_ctr_dirty = false;
+  } else {
+    ORBX_HIP(ctx, hipMemcpyAsync(din, hin, in.size, hipMemcpyHostToDevice, st));
+    int32_t* db = (int32_t*)(dout + p_b);
+    int rc = orbx_nn_csr_device(ctx, din + o_q, nq, din + o_t, nt, (const int32_t*)(din + o_rp), (const int32_t*)(din + o_c), last_wins,
+                                want_best ? db : nullptr, want_best ? db + nq : nullptr, want_best ? db + 2 * (size_t)nq : nullptr,
+                                want_best ? db + 3 * (size_t)nq : nullptr, dist_out ? (int32_t*)(dout + p_d) : nullptr, st);
+    if (rc != ORBX_OK) return rc;
+    if (out.size) ORBX_HIP(ctx, hipMemcpyAsync(hout, dout, out.size, hipMemcpyDeviceToHost, st));
+    us_issue = since();
+    ORBX_HIP(ctx, hipStreamSynchronize(st));
+  }
   const double us_sync = since();
   const int32_t* hb = (const int32_t*)(hout + p_b);
   if (best_idx) std::memcpy(best_idx, hb, 4 * (size_t)nq);
