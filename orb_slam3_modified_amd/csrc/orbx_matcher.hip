@@ -74,6 +74,11 @@ __global__ __launch_bounds__(256) void k_nn_csr(const uint8_t* __restrict__ q, i
                                                 unsigned long long* __restrict__ done_host) {
   const int lane = threadIdx.x & 63;
   const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  __shared__ int wg_done;
+  if (done_host) {   // block-uniform
+    if (threadIdx.x == 0) wg_done = 0;
+    __syncthreads();
+  }
   if (qi >= nq) return;
   const Desc dq = load_desc(q + (size_t)qi * 32);
   const int b = row_ptr[qi], e = row_ptr[qi + 1];
@@ -100,14 +105,20 @@ __global__ __launch_bounds__(256) void k_nn_csr(const uint8_t* __restrict__ q, i
       if (od) od[qi] = (int32_t)(k >> 32);
     }
   }
-  // host-buffer calls write their results into mapped pinned memory: every wave makes its stores visible to the host before it
-  // counts itself, the last one raises the done word the host polls (the counter wraps back to zero for the next call)
+  // host-buffer calls write their results into mapped pinned memory: the last wave of every workgroup makes the workgroup's stores visible to the host
+  // before it counts the workgroup, the last workgroup raises the done word the host polls (the counter wraps back to zero)
+  // (a system-scope release writes the L2 back: once per workgroup, by the last of its waves, not once per query — orbx_window.hip)
   if (done_host) {
-    __threadfence_system();
-    if (lane == 0 && atomicInc(ctr, (unsigned)nq - 1u) == (unsigned)nq - 1u) {
-      __threadfence();
-      __atomic_store_n(done_host, 1ull, __ATOMIC_RELEASE);
+    const int nactive = min(4, nq - (int)blockIdx.x * 4);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0 && atomicAdd(&wg_done, 1) == nactive - 1) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       __threadfence_system();
+      if (atomicInc(ctr, gridDim.x - 1) == gridDim.x - 1) {
+        __threadfence();
+        __atomic_store_n(done_host, 1ull, __ATOMIC_RELEASE);
+        __threadfence_system();
+      }
     }
   }
 }

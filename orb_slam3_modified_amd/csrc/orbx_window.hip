@@ -75,16 +75,27 @@ __device__ __forceinline__ int wham(const WDesc& a, const WDesc& b) {
 // "strict <, first candidate wins" order; position and index below 2^24
 constexpr unsigned long long kNoWinKey = ~0ull;
 
+#ifndef ORBX_WIN_WPG
+#define ORBX_WIN_WPG 16   // measured 4 / 8 / 16: 13.7 / 11.8 / 10.6 us per 800-query pass (best and second only)
+#endif
+constexpr int kWinWPG = ORBX_WIN_WPG;   // queries (waves) per workgroup: the wide fence and the two global atomics are paid once per workgroup
+
 template <bool LISTS, bool CHI2>
-__global__ __launch_bounds__(256) void k_window(const WinArgs a) {
+__global__ __launch_bounds__(64 * kWinWPG) void k_window(const WinArgs a) {
   extern __shared__ __align__(16) uint8_t lskip[];
+  // One global atomic per WORKGROUP, not per query, for the pool reservation and for the completion count: 800 waves hitting one
+  // address serialise in the L2 (measured: 20 of this kernel's 23 us); the waves of a workgroup meet in LDS first.
+  __shared__ int wg_cnt, wg_base, wg_done;
+  if (threadIdx.x == 0) { wg_cnt = 0; wg_done = 0; }
   if (a.skip_map) {   // block-uniform; the flags change with every call and are gathered at random: over PCIe once per workgroup, then LDS
-    for (int i = threadIdx.x * 4; i < a.n_skip; i += 256 * 4) *(uint32_t*)(lskip + i) = *(const uint32_t*)(a.skip_map + i);
-    __syncthreads();
+    for (int i = threadIdx.x * 4; i < a.n_skip; i += 64 * kWinWPG * 4) *(uint32_t*)(lskip + i) = *(const uint32_t*)(a.skip_map + i);
   }
+  __syncthreads();
   const int lane = threadIdx.x & 63;
-  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (q >= a.nq) return;
+  const int q0 = blockIdx.x * kWinWPG + (threadIdx.x >> 6);
+  const bool active = q0 < a.nq;               // the spare waves of the last workgroup shadow its last query (they take part in the
+  const int q = active ? q0 : a.nq - 1;        // workgroup barriers) and write nothing
+  const int nactive = min(kWinWPG, a.nq - (int)blockIdx.x * kWinWPG);
   const uint32_t rec = ((const uint32_t*)(a.qin + q))[lane & 15];   // 64 bytes, one request
   const float x = __uint_as_float(__builtin_amdgcn_readlane(rec, 0)), y = __uint_as_float(__builtin_amdgcn_readlane(rec, 1));
   const float r = __uint_as_float(__builtin_amdgcn_readlane(rec, 2));
@@ -98,8 +109,7 @@ __global__ __launch_bounds__(256) void k_window(const WinArgs a) {
   const int nMaxCellY = min(kWinRows - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, a.minY), r), a.invH)));
   const bool any = nMinCellX < kWinCols && nMaxCellX >= 0 && nMinCellY < kWinRows && nMaxCellY >= 0;
 
-  auto passes = [&](int j, int& idx) -> bool {
-    idx = a.cell_idx[j];
+  auto passes = [&](int idx) -> bool {
     const orbx_keypoint* kp = a.kps + idx;
     const int octave = kp->octave;
     const float kx = kp->x, ky = kp->y;
@@ -131,7 +141,7 @@ __global__ __launch_bounds__(256) void k_window(const WinArgs a) {
   // one after the other pays that chain per column (a latency-bound kernel: ~1 us per link on a GPU that idles between calls), so
   // the segments are laid end to end instead: lane c fetches the bounds of column c (one round trip for all columns), a wave scan
   // gives every segment its offset in the concatenated list, and the lanes then stride that list — one chain per 64 candidates.
-  __shared__ int seg_off[4][kWinCols + 1], seg_beg[4][kWinCols];
+  __shared__ int seg_off[kWinWPG][kWinCols + 1], seg_beg[kWinWPG][kWinCols];
   int* soff = seg_off[threadIdx.x >> 6];
   int* sbeg = seg_beg[threadIdx.x >> 6];
   const int ncol = any ? max(nMaxCellX - nMinCellX + 1, 0) : 0;   // <= 64
@@ -159,26 +169,37 @@ __global__ __launch_bounds__(256) void k_window(const WinArgs a) {
     return sbeg[lo] + (p - soff[lo]);
   };
 
+  // keypoint index first; the candidate's descriptor is then requested TOGETHER with its keypoint (both hang on the index only), before
+  // the gates are known: one link less in the chain of dependent loads, at the price of the descriptors of the gated-out candidates
   int count = 0, base = 0;
   const bool one_round = ntot <= 64;   // wave-uniform; the usual case: everything about the candidates stays in registers
   bool ok1 = false;
   int idx1 = 0;
+  WDesc dt1;
+  dt1.w[0] = dt1.w[1] = dt1.w[2] = dt1.w[3] = 0;
   if (LISTS) {   // how many, so that the query's candidates get one contiguous segment of the pool
     if (one_round) {
-      ok1 = lane < ntot && passes(cell_slot(lane), idx1);
+      if (lane < ntot) {
+        idx1 = a.cell_idx[cell_slot(lane)];
+        dt1 = wload(a.desc + (size_t)idx1 * 32);
+        ok1 = passes(idx1);
+      }
       count = __popcll(__ballot(ok1));
     } else {
       for (int p0 = 0; p0 < ntot; p0 += 64) {
         const int p = p0 + lane;
-        int idx = 0;
-        const bool ok = p < ntot && passes(cell_slot(p), idx);
+        const bool ok = p < ntot && passes(a.cell_idx[cell_slot(p)]);
         count += __popcll(__ballot(ok));
       }
     }
-    if (lane == 0 && count) base = atomicAdd(a.total, count);
-    base = __shfl(base, 0);
+    int off = 0;
+    if (lane == 0 && active && count) off = atomicAdd(&wg_cnt, count);   // LDS: this query's offset inside the workgroup's segment
+    __syncthreads();
+    if (threadIdx.x == 0) wg_base = wg_cnt ? atomicAdd(a.total, wg_cnt) : 0;
+    __syncthreads();
+    base = wg_base + __shfl(off, 0);
   }
-  const bool write = LISTS && count && base + count <= a.pool_cap;
+  const bool write = LISTS && active && count && base + count <= a.pool_cap;
   WDesc dq;
 #pragma unroll
   for (int w = 0; w < 4; w++)
@@ -189,11 +210,20 @@ __global__ __launch_bounds__(256) void k_window(const WinArgs a) {
   for (int p0 = 0; p0 < ntot; p0 += 64) {
     const int p = p0 + lane;
     int idx = idx1;
-    const bool ok = (LISTS && one_round) ? ok1 : (p < ntot && passes(cell_slot(p), idx));
+    bool ok = ok1;
+    WDesc dt = dt1;
+    if (!(LISTS && one_round)) {
+      ok = false;
+      if (p < ntot) {
+        idx = a.cell_idx[cell_slot(p)];
+        dt = wload(a.desc + (size_t)idx * 32);
+        ok = passes(idx);
+      }
+    }
     const unsigned long long bal = __ballot(ok);
     if (ok) {
       const int my = pos + __popcll(bal & ((1ull << lane) - 1ull));
-      const int d = wham(dq, wload(a.desc + (size_t)idx * 32));
+      const int d = wham(dq, dt);
       const unsigned long long key = ((unsigned long long)d << 48) | ((unsigned long long)my << 24) | (unsigned long long)idx;
       if (key < k1) { k2 = k1; k1 = key; }
       else if (key < k2) k2 = key;
@@ -209,7 +239,7 @@ __global__ __launch_bounds__(256) void k_window(const WinArgs a) {
     k1 = lo;
     k2 = hi < s2 ? hi : s2;
   }
-  if (lane == 0) {
+  if (lane == 0 && active) {
     if (a.compact) {
       WinQueryShort o;
       o.start = base; o.count = LISTS ? count : pos;
@@ -228,8 +258,16 @@ __global__ __launch_bounds__(256) void k_window(const WinArgs a) {
     // records and the pool may live in mapped host memory (a.host_out): every wave makes its stores visible to the host before
     // it counts itself, and the last one sets the done flag in the same 8-byte store as the total — the host polls that word
     // instead of waiting for a copy and a stream synchronisation.
-    if (a.host_out) __threadfence_system(); else __threadfence();
-    if (atomicAdd(a.total + 1, 1) == a.nq - 1) {
+    // (a system- or agent-scope release writes the L2 back and is far too expensive to do per query: the waves of a workgroup
+    // order their stores at workgroup scope around the LDS counter, and only the last of them — its L2 is the one they all
+    // wrote to — pays for the wide fence)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    const bool wg_last = atomicAdd(&wg_done, 1) == nactive - 1;
+    if (wg_last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if (a.host_out) __threadfence_system(); else __threadfence();
+    }
+    if (wg_last && atomicAdd(a.total + 1, 1) == (int)gridDim.x - 1) {
       __threadfence();
       const unsigned long long hdr = (unsigned long long)(uint32_t)atomicAdd(a.total, 0) | 1ull << 32;
       if (a.self_reset) { a.total[0] = 0; a.total[1] = 0; __threadfence(); }   // every other wave has left the counters
@@ -477,7 +515,7 @@ int window_call(orbx_ctx* ctx, const char* who, const orbx_keypoint* kps, const 
   uint8_t* const res = direct ? hdev + in.size : dout;
   a.out = (WinQueryOut*)(res + p_q); a.pool = (int2*)(res + p_pool); a.pool_cap = pool_cap; a.total = (int32_t*)(din + o_total);
   a.out_hdr = (int32_t*)(res + p_hdr); a.compact = compact ? 1 : 0; a.host_out = direct ? 1 : 0;
-  const dim3 gridDim((nq + 3) / 4), block(256);
+  const dim3 gridDim((nq + kWinWPG - 1) / kWinWPG), block(64 * kWinWPG);
   if (inv_sigma2) hipLaunchKernelGGL((k_window<false, true>), gridDim, block, 0, st, a);
   else if (lists) hipLaunchKernelGGL((k_window<true, false>), gridDim, block, 0, st, a);
   else hipLaunchKernelGGL((k_window<false, false>), gridDim, block, 0, st, a);
@@ -728,7 +766,7 @@ int window_call_target(orbx_ctx* ctx, const char* who, const orbx_target* T, con
   uint8_t* const res = direct ? hdev + in.size : dout;
   a.out = (WinQueryOut*)(res + p_q); a.pool = (int2*)(res + p_pool); a.pool_cap = pool_cap; a.total = ctx->d_win_ctr;
   a.out_hdr = (int32_t*)(res + p_hdr); a.compact = compact ? 1 : 0; a.host_out = direct ? 1 : 0; a.self_reset = 1;
-  const dim3 gridDim((nq + 3) / 4), block(256);
+  const dim3 gridDim((nq + kWinWPG - 1) / kWinWPG), block(64 * kWinWPG);
   const size_t lds = a.skip_map ? (size_t)nskip : 0;
   if (chi2) hipLaunchKernelGGL((k_window<false, true>), gridDim, block, lds, st, a);
   else if (lists) hipLaunchKernelGGL((k_window<true, false>), gridDim, block, lds, st, a);
