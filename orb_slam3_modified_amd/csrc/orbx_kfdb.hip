@@ -41,18 +41,19 @@ __global__ __launch_bounds__(256) void k_kfdb_common(const uint32_t* __restrict_
                                                      int32_t* __restrict__ common, uint32_t* __restrict__ first_word,
                                                      int32_t* __restrict__ max_common) {
   extern __shared__ __align__(16) uint32_t s_qbuf[];
+  __shared__ int wg_max;   // one global atomicMax per workgroup: thousands of them on one address serialise in the L2
   const uint32_t* s_q = qid;
+  if (threadIdx.x == 0) wg_max = 0;
   if (INLDS) {
     for (int i = threadIdx.x; i < nq; i += blockDim.x) s_qbuf[i] = qid[i];
-    __syncthreads();
     s_q = s_qbuf;
   }
+  __syncthreads();
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= nrows) return;
   int cnt = 0;
   uint32_t first = 0xffffffffu;
-  if (active[r]) {
+  if (r < nrows && active[r]) {
     const KfRow row = rows[r];
     for (int b0 = 0; b0 < row.len; b0 += 64) {
       const int j = b0 + lane;
@@ -69,11 +70,13 @@ __global__ __launch_bounds__(256) void k_kfdb_common(const uint32_t* __restrict_
       }
     }
   }
-  if (lane == 0) {
+  if (lane == 0 && r < nrows) {
     common[r] = cnt;
     first_word[r] = first;
-    if (cnt) atomicMax(max_common, cnt);
+    if (cnt) atomicMax(&wg_max, cnt);
   }
+  __syncthreads();
+  if (threadIdx.x == 0 && wg_max) atomicMax(max_common, wg_max);
 }
 
 // Phase 2: L1 score of the rows with more than minCommonWords = (int)(maxCommonWords * 0.8f) common words (at least
