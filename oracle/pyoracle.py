@@ -85,7 +85,7 @@ class OracleExtractor:
     def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
         self.nfeatures, self.nlevels = nfeatures, nlevels
         self._h = lib().orbo_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
-        self.cap = nfeatures + 3 * nlevels + 64
+        self.cap = nfeatures + 35 * nlevels + 64   # a level returns up to max(quota + 3, 4 x root nodes) keypoints (<= 8 roots)
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -641,7 +641,7 @@ class RefExtractor:
     def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
         self.nfeatures, self.nlevels = nfeatures, nlevels
         self._h = _ref_ext_lib().ref_ext_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
-        self.cap = nfeatures + 3 * nlevels + 64
+        self.cap = nfeatures + 35 * nlevels + 64   # a level returns up to max(quota + 3, 4 x root nodes) keypoints (<= 8 roots)
 
     def __del__(self):
         if getattr(self, "_h", None):
