@@ -23,23 +23,96 @@
 #include "orbx.h"
 #include "orbx_cv_compat.h"
 
-// Same include guards as the reference's Thirdparty/DBoW2/DBoW2/BowVector.h / FeatureVector.h: where those (or a stand-in
-// for them) were included first, their classes are the ones used.
+// ---- DBoW2::BowVector / DBoW2::FeatureVector ---------------------------------------------------------------------------------
+// Inside the reference's tree (its root on the include path, as its CMakeLists.txt:83 has it) the reference's OWN two headers
+// are used, so every translation unit — whichever of KeyFrame.h:24-25 / Frame.h:25-26 / this header it reaches first — sees one
+// definition, Boost serialize() members included (BowVector.h:62-67, FeatureVector.h:27-32; archived by KeyFrame.h:130-131,
+// instantiated from System.cc:1464-1468).  Their out-of-line members come from Thirdparty/DBoW2/lib/libDBoW2.so, which the
+// reference links anyway (CMakeLists.txt:126).  Define ORBX_OWN_DBOW2_TYPES to force the self-contained classes below.
+#if !defined(ORBX_OWN_DBOW2_TYPES) && defined(__has_include)
+#if __has_include("Thirdparty/DBoW2/DBoW2/BowVector.h") && __has_include("Thirdparty/DBoW2/DBoW2/FeatureVector.h") && \
+    __has_include(<boost/serialization/serialization.hpp>)
+#include "Thirdparty/DBoW2/DBoW2/BowVector.h"
+#include "Thirdparty/DBoW2/DBoW2/FeatureVector.h"
+#endif
+#endif
+
+// Stand-alone builds (no reference tree): the same two classes, header-only, member for member — with the same include guards,
+// so that a later include of the reference's headers is a no-op, and with serialize() whenever Boost.Serialization exists.
+#if defined(__has_include)
+#if __has_include(<boost/serialization/serialization.hpp>) && __has_include(<boost/serialization/map.hpp>)
+#include <boost/serialization/serialization.hpp>
+#include <boost/serialization/map.hpp>
+#define ORBX_HAVE_BOOST_SERIALIZATION 1
+#endif
+#endif
+
 #ifndef __D_T_BOW_VECTOR__
 #define __D_T_BOW_VECTOR__
+#include <cmath>
+#include <fstream>
+#include <iostream>
 namespace DBoW2 {
 
 typedef unsigned int WordId;
 typedef double WordValue;
 typedef unsigned int NodeId;
 
+enum LNorm { L1, L2 };                                                                  // BowVector.h:33-37
+enum WeightingType { TF_IDF, TF, IDF, BINARY };                                        // :40-46
+enum ScoringType { L1_NORM, L2_NORM, CHI_SQUARE, KL, BHATTACHARYYA, DOT_PRODUCT };     // :49-57
+
 class BowVector : public std::map<WordId, WordValue> {
+#ifdef ORBX_HAVE_BOOST_SERIALIZATION
+  friend class boost::serialization::access;
+  template <class Archive>
+  void serialize(Archive& ar, const int /*version*/) {   // BowVector.h:62-67: the map base, nothing else
+    ar& boost::serialization::base_object<std::map<WordId, WordValue> >(*this);
+  }
+#endif
+
  public:
+  BowVector() {}
+  ~BowVector() {}
   // BowVector.cpp:34-46
   void addWeight(WordId id, WordValue v) {
     iterator vit = this->lower_bound(id);
     if (vit != this->end() && !(this->key_comp()(id, vit->first))) vit->second += v;
     else this->insert(vit, value_type(id, v));
+  }
+  // BowVector.cpp:50-58
+  void addIfNotExist(WordId id, WordValue v) {
+    iterator vit = this->lower_bound(id);
+    if (vit == this->end() || this->key_comp()(id, vit->first)) this->insert(vit, value_type(id, v));
+  }
+  // BowVector.cpp:62-84: ascending-id accumulation of |v| (L1) or v*v then sqrt (L2); divides when the norm is positive
+  void normalize(LNorm norm_type) {
+    double norm = 0.0;
+    if (norm_type == DBoW2::L1) {
+      for (iterator it = begin(); it != end(); ++it) norm += std::fabs(it->second);
+    } else {
+      for (iterator it = begin(); it != end(); ++it) norm += it->second * it->second;
+      norm = std::sqrt(norm);
+    }
+    if (norm > 0.0)
+      for (iterator it = begin(); it != end(); ++it) it->second /= norm;
+  }
+  // BowVector.cpp:88-102: "<id, value>, <id, value>"
+  friend std::ostream& operator<<(std::ostream& out, const BowVector& v) {
+    const char* sep = "";
+    for (const_iterator it = v.begin(); it != v.end(); ++it, sep = ", ") out << sep << "<" << it->first << ", " << it->second << ">";
+    return out;
+  }
+  // BowVector.cpp:106-126: the dense row of W values, zeros spelled "0 "
+  void saveM(const std::string& filename, size_t W) const {
+    std::fstream f(filename.c_str(), std::ios::out);
+    WordId next = 0;
+    for (const_iterator it = begin(); it != end(); ++it) {
+      for (; next < it->first; ++next) f << "0 ";
+      f << it->second << " ";
+      next = it->first + 1;
+    }
+    for (; next < (WordId)W; ++next) f << "0 ";
   }
 };
 
@@ -47,10 +120,21 @@ class BowVector : public std::map<WordId, WordValue> {
 #endif
 #ifndef __D_T_FEATURE_VECTOR__
 #define __D_T_FEATURE_VECTOR__
+#include <iostream>
 namespace DBoW2 {
 
 class FeatureVector : public std::map<NodeId, std::vector<unsigned int> > {
+#ifdef ORBX_HAVE_BOOST_SERIALIZATION
+  friend class boost::serialization::access;
+  template <class Archive>
+  void serialize(Archive& ar, const int /*version*/) {   // FeatureVector.h:27-32
+    ar& boost::serialization::base_object<std::map<NodeId, std::vector<unsigned int> > >(*this);
+  }
+#endif
+
  public:
+  FeatureVector() {}
+  ~FeatureVector() {}
   // FeatureVector.cpp:30-45
   void addFeature(NodeId id, unsigned int i_feature) {
     iterator vit = this->lower_bound(id);
@@ -59,6 +143,16 @@ class FeatureVector : public std::map<NodeId, std::vector<unsigned int> > {
       vit = this->insert(vit, value_type(id, std::vector<unsigned int>()));
       vit->second.push_back(i_feature);
     }
+  }
+  // FeatureVector.cpp:49-82: "<node: [f, f, ...]>, <node: [...]>"
+  friend std::ostream& operator<<(std::ostream& out, const FeatureVector& v) {
+    const char* sep = "";
+    for (const_iterator it = v.begin(); it != v.end(); ++it, sep = ", ") {
+      out << sep << "<" << it->first << ": [";
+      for (size_t i = 0; i < it->second.size(); i++) out << (i ? ", " : "") << it->second[i];
+      out << "]>";
+    }
+    return out;
   }
 };
 

@@ -85,6 +85,12 @@ class ORBmatcher {
   // cv::BFMatcher(NORM_HAMMING).knnMatch(query, train, k = 2) as Frame::ComputeStereoFishEyeMatches uses it
   // (src/Frame.cc:43,1144): idx / dist hold 2 entries per query (-1 / 256 when there are fewer than 2 train rows).
   static void KnnMatch2(const cv::Mat& queryDesc, const cv::Mat& trainDesc, std::vector<int>& idx, std::vector<int>& dist);
+  // Resident search targets of the calling thread.  A cached target is only used when the 64-bit digest of the
+  // object's keypoints / descriptors / mvuRight still matches, so recycled ids (Tracking::Reset(), src/Tracking.cc:3819-3820) are
+  // safe without any call; InvalidateTargets() drops the calling thread's cache explicitly (optional hook for Reset paths),
+  // RecycledIdsSeen() counts how often a recycled (id, count, address) with different contents was met on this thread.
+  static void InvalidateTargets();
+  static unsigned long RecycledIdsSeen();
 
  protected:
   float RadiusByViewingCos(const float& viewCos);

@@ -120,9 +120,12 @@ struct Lists {   // CSR candidate lists of a query batch, in GetFeaturesInArea's
 // ---- resident search targets -----------------------------------------------------------------------------------------------------
 // A Frame / KeyFrame is searched many times and never changes after construction: what a routine searches — keypoints, descriptor
 // rows, the flattened grid and, for Fuse, mvuRight + mvInvLevelSigma2 — is uploaded once per thread context (orbx_target_*) and kept
-// in a small LRU keyed by the object's id (Frame::mnId / KeyFrame::mnId are unique per process; a copy of a Frame shares both the
-// id and the contents).  A hit costs neither the flattening of the grid nor an upload; the LRU recycles the evicted target's
-// device block, so the steady state allocates nothing.
+// in a small LRU.  The key is (kind, mnId, variant, count, descriptor address) PLUS a 64-bit digest of the contents (every keypoint,
+// every descriptor byte, mvuRight): ids are NOT unique per process — Tracking::Reset() sets KeyFrame::nNextId = Frame::nNextId = 0
+// (src/Tracking.cc:3819-3820, reached from System.cc:327,402,477) and an Atlas load restores the counters — so a later Frame can
+// carry a recycled id, the same count and a recycled malloc address.  A hit therefore has to match the digest; an entry whose key
+// matches but whose digest does not proves that ids were recycled, and everything cached before that moment is dropped (refilled,
+// not freed: the device blocks are reused).  A hit costs the digest (≈ 60 KB of host reads, 2-3 µs), no grid flattening, no upload.
 struct TargetSpec {
   const orbx_keypoint* kps = nullptr;
   const unsigned char* desc = nullptr;
@@ -135,30 +138,83 @@ struct TargetSpec {
   DescView* dview = nullptr;
 };
 
+// 64-bit digest of a byte block: four independent multiply-xorshift lanes over 8-byte words (order-sensitive)
+inline uint64_t digest_bytes(const void* p, size_t bytes, uint64_t seed) {
+  const unsigned char* b = (const unsigned char*)p;
+  uint64_t a0 = seed ^ 0x9e3779b97f4a7c15ull, a1 = seed + 0xc2b2ae3d27d4eb4full, a2 = ~seed * 0x165667b19e3779f9ull, a3 = seed ^ (uint64_t)bytes;
+  size_t i = 0;
+  for (; i + 32 <= bytes; i += 32) {
+    uint64_t w[4];
+    std::memcpy(w, b + i, 32);
+    a0 = (a0 ^ w[0]) * 0xff51afd7ed558ccdull; a0 ^= a0 >> 29;
+    a1 = (a1 ^ w[1]) * 0xc4ceb9fe1a85ec53ull; a1 ^= a1 >> 31;
+    a2 = (a2 ^ w[2]) * 0x9fb21c651e98df25ull; a2 ^= a2 >> 30;
+    a3 = (a3 ^ w[3]) * 0xd6e8feb86659fd93ull; a3 ^= a3 >> 32;
+  }
+  for (; i < bytes; i++) { a0 = (a0 ^ b[i]) * 0xff51afd7ed558ccdull; a0 ^= a0 >> 29; }
+  uint64_t h = a0 ^ (a1 * 0x9e3779b97f4a7c15ull) ^ (a2 << 1 | a2 >> 63) ^ (a3 * 0xc2b2ae3d27d4eb4full);
+  h ^= h >> 33; h *= 0xff51afd7ed558ccdull; h ^= h >> 33;
+  return h;
+}
+
+// everything a target is made of, as the caller's objects hold it (the grid and the merged rig keypoints derive from these)
+struct TargetContent {
+  const std::vector<cv::KeyPoint>* keys[2] = {nullptr, nullptr};
+  const cv::Mat* desc = nullptr;
+  const std::vector<float>* ur = nullptr;
+  const std::vector<float>* sig = nullptr;
+  float bounds[4] = {0, 0, 0, 0};   // grid origin and inverse cell size: a grid is a function of (keypoints, bounds)
+  uint64_t digest() const {
+    uint64_t h = digest_bytes(bounds, sizeof(bounds), 0x0b5e55edull);
+    for (const std::vector<cv::KeyPoint>* k : keys)
+      if (k && !k->empty()) h = digest_bytes(k->data(), k->size() * sizeof(cv::KeyPoint), h);
+    if (desc && desc->rows > 0) {
+      if (desc->isContinuous()) h = digest_bytes(desc->ptr<unsigned char>(0), (size_t)desc->rows * 32, h);
+      else for (int r = 0; r < desc->rows; r++) h = digest_bytes(desc->ptr<unsigned char>(r), 32, h);
+    }
+    if (ur && !ur->empty()) h = digest_bytes(ur->data(), ur->size() * sizeof(float), h);
+    if (sig && !sig->empty()) h = digest_bytes(sig->data(), sig->size() * sizeof(float), h);
+    return h;
+  }
+};
+
 struct TargetCache {
-  struct Entry { int kind; unsigned long id; int variant; int n; const void* dptr; orbx_target* t; unsigned long stamp; };
+  struct Entry { int kind; unsigned long id; int variant; int n; const void* dptr; uint64_t tag; orbx_target* t; unsigned long stamp; };
   static constexpr size_t kMax = 64;
   std::vector<Entry> e;
   unsigned long clock = 0;
+  unsigned long recycled_ids = 0;   // how often a recycled id was detected (diagnostics, tests)
   void clear() { for (Entry& x : e) orbx_target_destroy(x.t); e.clear(); }
+  // nothing cached so far may be trusted any more; the device blocks stay and are refilled by later misses
+  void invalidate() { for (Entry& x : e) { x.n = -1; x.stamp = 0; } }
   template <class Build>
-  orbx_target* get(orbx_ctx* ctx, const char* routine, int kind, unsigned long id, int variant, int n, const void* dptr, Build build) {
+  orbx_target* get(orbx_ctx* ctx, const char* routine, int kind, unsigned long id, int variant, int n, const void* dptr, const TargetContent& content,
+                   Build build) {
+    const uint64_t tag = content.digest();
     for (Entry& x : e)
-      if (x.kind == kind && x.id == id && x.variant == variant && x.n == n && x.dptr == dptr) { x.stamp = ++clock; return x.t; }
+      if (x.kind == kind && x.id == id && x.variant == variant && x.n == n && x.dptr == dptr) {
+        if (x.tag == tag) { x.stamp = ++clock; return x.t; }
+        recycled_ids++;
+        invalidate();
+        break;
+      }
     TargetSpec sp;
     build(sp);
     Entry* slot = nullptr;
-    if (e.size() < kMax) {
+    for (Entry& x : e) if (x.n < 0) { slot = &x; break; }   // an invalidated block first
+    if (!slot && e.size() < kMax) {
       orbx_target* t = nullptr;
       if (orbx_target_create(ctx, sp.kps, sp.desc, sp.n, &sp.grid.g, sp.ur, sp.sig, sp.nlevels, &t) != ORBX_OK) fail(routine, ctx);
-      e.push_back(Entry{kind, id, variant, n, dptr, t, 0});
+      e.push_back(Entry{kind, id, variant, n, dptr, tag, t, 0});
       slot = &e.back();
     } else {
-      slot = &e[0];
-      for (Entry& x : e) if (x.stamp < slot->stamp) slot = &x;
+      if (!slot) {
+        slot = &e[0];
+        for (Entry& x : e) if (x.stamp < slot->stamp) slot = &x;
+      }
       slot->n = -1;   // not a valid key while it is refilled
       if (orbx_target_assign(ctx, slot->t, sp.kps, sp.desc, sp.n, &sp.grid.g, sp.ur, sp.sig, sp.nlevels) != ORBX_OK) fail(routine, ctx);
-      slot->kind = kind; slot->id = id; slot->variant = variant; slot->n = n; slot->dptr = dptr;
+      slot->kind = kind; slot->id = id; slot->variant = variant; slot->n = n; slot->dptr = dptr; slot->tag = tag;
     }
     slot->stamp = ++clock;
     return slot->t;
@@ -181,7 +237,10 @@ enum { kFrameLeft = 0, kFrameRight = 1, kKeyFrameUn = 2, kFuseLeft = 3, kFuseRig
 orbx_target* frame_target(const char* routine, const Frame& F, bool bRight) {
   orbx_ctx* ctx = ORBmatcher::DefaultContext();
   const std::vector<cv::KeyPoint>& keys = bRight ? F.mvKeysRight : (F.Nleft == -1 ? F.mvKeysUn : F.mvKeys);
-  return holder().cache.get(ctx, routine, 'F', F.mnId, bRight ? kFrameRight : kFrameLeft, (int)keys.size(), F.mDescriptors.data, [&](TargetSpec& sp) {
+  TargetContent tc;
+  tc.keys[0] = &keys; tc.desc = &F.mDescriptors;
+  tc.bounds[0] = Frame::mnMinX; tc.bounds[1] = Frame::mnMinY; tc.bounds[2] = Frame::mfGridElementWidthInv; tc.bounds[3] = Frame::mfGridElementHeightInv;
+  return holder().cache.get(ctx, routine, 'F', F.mnId, bRight ? kFrameRight : kFrameLeft, (int)keys.size(), F.mDescriptors.data, tc, [&](TargetSpec& sp) {
     static thread_local std::vector<unsigned char> rows;
     DescView D(F.mDescriptors);
     const unsigned char* d = D.p ? D.p + (bRight ? (size_t)F.Nleft * 32 : 0) : nullptr;
@@ -195,7 +254,11 @@ orbx_target* frame_target(const char* routine, const Frame& F, bool bRight) {
 // src/KeyFrame.cc:735-737, level from mvKeysUn, e.g. :508)
 orbx_target* keyframe_target(const char* routine, KeyFrame* pKF) {
   orbx_ctx* ctx = ORBmatcher::DefaultContext();
-  return holder().cache.get(ctx, routine, 'K', pKF->mnId, kKeyFrameUn, (int)pKF->mvKeysUn.size(), pKF->mDescriptors.data, [&](TargetSpec& sp) {
+  TargetContent tc;
+  tc.keys[0] = &pKF->mvKeysUn; if (pKF->NLeft != -1) tc.keys[1] = &pKF->mvKeys;
+  tc.desc = &pKF->mDescriptors;
+  tc.bounds[0] = (float)pKF->mnMinX; tc.bounds[1] = (float)pKF->mnMinY; tc.bounds[2] = pKF->mfGridElementWidthInv; tc.bounds[3] = pKF->mfGridElementHeightInv;
+  return holder().cache.get(ctx, routine, 'K', pKF->mnId, kKeyFrameUn, (int)pKF->mvKeysUn.size(), pKF->mDescriptors.data, tc, [&](TargetSpec& sp) {
     static thread_local std::vector<unsigned char> rows;
     if (pKF->NLeft == -1) sp.keys.direct(pKF->mvKeysUn);
     else sp.keys.merge(pKF->mvKeys, pKF->mvKeysUn);
@@ -211,7 +274,10 @@ orbx_target* keyframe_target(const char* routine, KeyFrame* pKF) {
 orbx_target* fuse_target(const char* routine, KeyFrame* pKF, bool bRight) {
   orbx_ctx* ctx = ORBmatcher::DefaultContext();
   const std::vector<cv::KeyPoint>& keys = pKF->NLeft == -1 ? pKF->mvKeysUn : (bRight ? pKF->mvKeysRight : pKF->mvKeys);
-  return holder().cache.get(ctx, routine, 'K', pKF->mnId, bRight ? kFuseRight : kFuseLeft, (int)keys.size(), pKF->mDescriptors.data, [&](TargetSpec& sp) {
+  TargetContent tc;
+  tc.keys[0] = &keys; tc.desc = &pKF->mDescriptors; tc.ur = &pKF->mvuRight; tc.sig = &pKF->mvInvLevelSigma2;
+  tc.bounds[0] = (float)pKF->mnMinX; tc.bounds[1] = (float)pKF->mnMinY; tc.bounds[2] = pKF->mfGridElementWidthInv; tc.bounds[3] = pKF->mfGridElementHeightInv;
+  return holder().cache.get(ctx, routine, 'K', pKF->mnId, bRight ? kFuseRight : kFuseLeft, (int)keys.size(), pKF->mDescriptors.data, tc, [&](TargetSpec& sp) {
     static thread_local std::vector<unsigned char> rows;
     DescView D(pKF->mDescriptors);
     const unsigned char* d = D.p;
@@ -288,6 +354,9 @@ orbx_ctx* ORBmatcher::DefaultContext() {
   }
   return h.c;
 }
+
+void ORBmatcher::InvalidateTargets() { holder().cache.invalidate(); }
+unsigned long ORBmatcher::RecycledIdsSeen() { return holder().cache.recycled_ids; }
 
 int ORBmatcher::DescriptorDistance(const cv::Mat& a, const cv::Mat& b) { return orbx_hamming(a.ptr<unsigned char>(), b.ptr<unsigned char>()); }
 

@@ -17,6 +17,7 @@
 #include <fstream>
 #include <functional>
 #include <set>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -311,6 +312,37 @@ void prebind(Scene& s, Frame& F, int every, int salt) {   // keypoints that alre
     s.extra[i].nObs = (H(i, salt) % 3 == 0) ? 0 : 4;
     if (i % every == 0) F.mvpMapPoints[i] = &s.extra[i];
   }
+}
+
+// ---- id reuse (src/Tracking.cc:3819-3820: Tracking::Reset() sets KeyFrame::nNextId = 0 and Frame::nNextId = 0; Atlas.cc:242 deletes the
+// keyframes): a later Frame / KeyFrame carries a recycled id, and the allocator may hand back the same buffers.  The worst case is
+// produced deterministically here: the SAME object (same mnId, same count, same mvKeysUn / mDescriptors addresses) is refilled in
+// place with the first n features of another view.
+void refill_frame(Scene& s, Frame& F, int v, bool stereo) {
+  const View& V = s.w.views[v];
+  const int n = F.N;
+  for (int i = 0; i < n; i++) { F.mvKeys[i] = V.kps[i]; F.mvKeysUn[i] = V.kps[i]; }
+  std::memcpy(F.mDescriptors.data, V.desc.data, (size_t)n * 32);
+  F.mvpMapPoints.assign(n, static_cast<MapPoint*>(NULL));
+  F.mvbOutlier.assign(n, false);
+  for (int i = 0; i < n; i++)
+    F.mvuRight[i] = (stereo && i % 4 != 0) ? V.kps[i].pt.x - F.mbf / s.depth_of(i, 0) + 0.25f * (float)((int)(H(i, 11) % 9) - 4) : -1.f;
+  F.AssignFeaturesToGrid();
+}
+void truncate_frame(Frame& F, int n) {   // keep the first n features (before any search)
+  F.N = n;
+  F.mvKeys.resize(n); F.mvKeysUn.resize(n); F.mvpMapPoints.resize(n); F.mvbOutlier.resize(n); F.mvuRight.resize(n);
+  cv::Mat d(n, 32, CV_8U);
+  std::memcpy(d.data, F.mDescriptors.data, (size_t)n * 32);
+  F.mDescriptors = d;
+  F.AssignFeaturesToGrid();
+}
+void refill_keyframe(KeyFrame* K, const Frame& F) {   // K <- F, in place (same id, same buffers)
+  for (int i = 0; i < K->N; i++) { K->mvKeys[i] = F.mvKeys[i]; K->mvKeysUn[i] = F.mvKeysUn[i]; K->mvuRight[i] = F.mvuRight[i]; }
+  std::memcpy(K->mDescriptors.data, F.mDescriptors.data, (size_t)K->N * 32);
+  for (int i = 0; i < K->mnGridCols; i++)
+    for (int j = 0; j < K->mnGridRows; j++) K->mGrid[i][j] = F.mGrid[i][j];
+  K->mvpMapPoints.assign(K->N, static_cast<MapPoint*>(NULL));
 }
 
 typedef std::function<void(Out&)> Fn;
@@ -640,6 +672,65 @@ int main(int argc, char** argv) {
       o.ints("mvpMapPoints", ids_of(Cur.mvpMapPoints));
     });
   }
+
+  // ---- recycled ids: the same Frame object refilled in place between two searches (see refill_frame)
+  for (int variant = 0; variant < 2; variant++) {
+    static const char* names[] = {"reuse_frame_mono", "reuse_frame_stereo"};
+    add(names[variant], [&w, variant](Out& o) {
+      Scene s(w, false);
+      const bool stereo = variant == 1;
+      const int n = std::min(w.views[2].n, w.views[3].n) - 7;
+      Frame F;
+      s.make_frame(F, 2, stereo, s.pose(4));
+      truncate_frame(F, n);
+      s.make_points(s.mps, 0, s.pose(0), 0, 0);
+      std::vector<MapPoint*> vp;
+      for (MapPoint& m : s.mps) vp.push_back(&m);
+      ORBmatcher matcher(0.8);
+#ifdef ORBX_H   // drop-in builds only: the recycled id must have been noticed, not survived by luck
+      const unsigned long seen0 = ORBmatcher::RecycledIdsSeen();
+#endif
+      for (int round = 0; round < 3; round++) {
+        // round 1: contents of view 3 under the id / count / addresses of round 0; round 2: back to view 2
+        if (round) refill_frame(s, F, round == 1 ? 3 : 2, stereo);
+        set_track_fields(s, F, s.mps, false);
+        const int ret = timed([&] { return matcher.SearchByProjection(F, vp, 3, stereo, 5.0f); });
+        o.line(std::string(names[variant]) + "_round" + std::to_string(round), ret);
+        o.ints("mvpMapPoints", ids_of(F.mvpMapPoints));
+      }
+#ifdef ORBX_H
+      if (ORBmatcher::RecycledIdsSeen() < seen0 + 2) throw std::runtime_error("a recycled Frame id went unnoticed by the target cache");
+#endif
+    });
+  }
+  // ---- recycled ids on the keyframe side: Fuse's target (keypoints + mvuRight + level sigmas) and the Sim3 projection target
+  add("reuse_keyframe", [&w](Out& o) {
+    Scene s(w, false);
+    const int n = std::min(w.views[2].n, w.views[1].n) - 5;
+    Frame Fa, Fb;
+    s.make_frame(Fa, 2, true, s.pose(4, 0.01f, 0.005f, 0.02f));
+    truncate_frame(Fa, n);
+    s.make_frame(Fb, 1, true, s.pose(4, 0.01f, 0.005f, 0.02f));
+    truncate_frame(Fb, n);
+    KeyFrame* K = s.make_keyframe(Fa);
+    s.make_points(s.mps, 0, s.pose(0), 0, 0);
+    for (int round = 0; round < 2; round++) {
+      if (round) refill_keyframe(K, Fb);
+      std::vector<MapPoint*> vp;
+      for (MapPoint& m : s.mps) { m.nObs = 0; m.mObservations.clear(); m.mbBad = false; m.mpReplaced = nullptr; vp.push_back(&m); }
+      const Sophus::SE3f T = K->GetPose();
+      Sophus::Sim3f Scw(1.01f, T.rotationMatrix(), T.translation() * 1.01f);
+      std::vector<MapPoint*> vpMatched(K->N, static_cast<MapPoint*>(NULL));
+      ORBmatcher matcher(0.75, true);
+      const int ret = timed([&] { return matcher.SearchByProjection(K, Scw, vp, vpMatched, 5, 1.0); });
+      o.line("reuse_keyframe_proj_round" + std::to_string(round), ret);
+      o.ints("vpMatched", ids_of(vpMatched));
+      ORBmatcher fuser;
+      const int ret2 = timed([&] { return fuser.Fuse(K, vp); });
+      o.line("reuse_keyframe_fuse_round" + std::to_string(round), ret2);
+      o.ints("kf_points", ids_of(K->mvpMapPoints));
+    }
+  });
 
   // ---- statics
   add("statics", [&w](Out& o) {

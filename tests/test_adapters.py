@@ -45,6 +45,32 @@ def test_adapters_compile_link_and_fail_loudly_without_gpu():
         assert r.returncode == 3 and "NO_DEVICE" in r.stdout, r.stdout + r.stderr
 
 
+def _serialize_check(tmp_path, name, extra):
+    exe = str(tmp_path / name)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I",
+                           os.path.join(ROOT, "oracle", "ref_shims")] + extra[0] + [os.path.join(SUP, "serialize_check.cpp"), "-o", exe] + extra[1])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "roundtrip=1" in r.stdout, r.stdout + r.stderr
+    return r.stdout.split(None, 1)
+
+
+def test_bow_and_feature_vectors_archive_like_keyframe_h_does(tmp_path):
+    """`ar & mBowVec; ar & mFeatVec;` (reference include/KeyFrame.h:130-131, instantiated by src/System.cc:1464-1468) compiles and
+    round-trips through boost::serialization::access with the DBoW2 classes include/ORBVocabulary.h provides on its own; the other
+    members of the reference's classes (addIfNotExist, normalize, operator<<) are there as well."""
+    which, rest = _serialize_check(tmp_path, "ser_own.bin", (["-DORBX_OWN_DBOW2_TYPES"], []))
+    assert which == "own" and "words=301 nodes=37" in rest and "<3, 0.5>, <7, 0.25> | <2: [5, 6]>, <9: [1]>" in rest
+    if not os.path.isdir("/root/reference/Thirdparty/DBoW2/DBoW2"):
+        return
+    # inside the reference's tree the header defers to the reference's own BowVector.h / FeatureVector.h (one definition in every
+    # translation unit); their out-of-line members come from the DBoW2 library (here: oracle/_ref/libref_dbow2.so)
+    refdir = os.path.join(ROOT, "oracle", "_ref")
+    if not os.path.exists(os.path.join(refdir, "libref_dbow2.so")):
+        pytest.skip("oracle/_ref/libref_dbow2.so not built")
+    which2, rest2 = _serialize_check(tmp_path, "ser_tree.bin", (["-w", "-I", "/root/reference"], ["-L", refdir, "-lref_dbow2", "-Wl,-rpath," + refdir]))
+    assert which2 == "tree" and rest2 == rest   # same bytes, same values, same printed form as the reference's classes
+
+
 def _read(path):
     b = open(path, "rb").read()
     off = 0
