@@ -261,11 +261,12 @@ typedef struct orbx_target orbx_target;
 int orbx_target_create(orbx_ctx* ctx, const orbx_keypoint* kps, const uint8_t* desc, int n, const orbx_grid* grid, const float* kp_uright,
                        const float* inv_level_sigma2, int nlevels, orbx_target** target);
 /* replaces the contents of an existing target (its device block is kept when large enough: a cache of frames recycles targets
- * without allocating) */
+ * without allocating).  If the call fails the target is INVALID until a later assign succeeds: orbx_target_search / _nearest /
+ * _size on it return ORBX_E_INVALID (never the results of an empty or of the previous target). */
 int orbx_target_assign(orbx_ctx* ctx, orbx_target* target, const orbx_keypoint* kps, const uint8_t* desc, int n, const orbx_grid* grid,
                        const float* kp_uright, const float* inv_level_sigma2, int nlevels);
 void orbx_target_destroy(orbx_target* target);
-int orbx_target_size(const orbx_target* target);   /* number of keypoints */
+int orbx_target_size(const orbx_target* target);   /* number of keypoints; ORBX_E_INVALID for an invalid target */
 /* = orbx_window_search_grid on the target; q_xr needs a target created with kp_uright */
 int orbx_target_search(orbx_ctx* ctx, const orbx_target* target, const uint8_t* kp_skip, const float* qx, const float* qy, const float* qr,
                        const int32_t* qmin_level, const int32_t* qmax_level, const uint8_t* q_desc, const float* q_xr, int nq, int32_t* row_ptr,

@@ -34,9 +34,12 @@ static int fast_threads_from_env() {
 
 hipError_t ensure_dynamic_lds(const void* kernel, int bytes) {
   static std::mutex mu;
-  static std::map<const void*, int> raised;
+  // the attribute belongs to the function ON THE CURRENT DEVICE: one process may drive several GPUs (contexts carry their device)
+  static std::map<std::pair<int, const void*>, int> raised;
   std::lock_guard<std::mutex> lock(mu);
-  int& cur = raised[kernel];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+  int& cur = raised[std::make_pair(dev, kernel)];
   if (bytes <= cur) return hipSuccess;
   const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e == hipSuccess) cur = bytes;

@@ -243,6 +243,7 @@ struct orbx_target {
   size_t cap = 0, bytes = 0, o_kps = 0, o_desc = 0, o_ur = 0, o_sig = 0, o_cs = 0, o_ci = 0;
   int n = 0, ngrid = 0, nlevels = 0;
   bool has_ur = false, has_sig = false;
+  bool valid = false;   // false after a failed (re)fill: searches return ORBX_E_INVALID instead of treating it as an empty target
   float min_x = 0, min_y = 0, inv_w = 0, inv_h = 0;
 };
 namespace orbx {

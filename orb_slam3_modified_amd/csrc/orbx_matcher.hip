@@ -110,6 +110,9 @@ __global__ __launch_bounds__(256) void k_nn_csr(const uint8_t* __restrict__ q, i
   // (a system-scope release writes the L2 back: once per workgroup, by the last of its waves, not once per query — orbx_window.hip)
   if (done_host) {
     const int nactive = min(4, nq - (int)blockIdx.x * 4);
+    // a workgroup-scope release emits no vmcnt wait on gfx9 outside tgsplit mode: drain this wave's own stores (records, pool entries)
+    // before it counts itself — the last wave's wide fence below only waits for ITS outstanding stores
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0 && atomicAdd(&wg_done, 1) == nactive - 1) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");

@@ -261,6 +261,9 @@ __global__ __launch_bounds__(64 * kWinWPG) void k_window(const WinArgs a) {
     // (a system- or agent-scope release writes the L2 back and is far too expensive to do per query: the waves of a workgroup
     // order their stores at workgroup scope around the LDS counter, and only the last of them — its L2 is the one they all
     // wrote to — pays for the wide fence)
+    // a workgroup-scope release emits no vmcnt wait on gfx9 outside tgsplit mode: drain this wave's own stores (records, pool entries)
+    // before it counts itself — the last wave's wide fence below only waits for ITS outstanding stores
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     const bool wg_last = atomicAdd(&wg_done, 1) == nactive - 1;
     if (wg_last) {
@@ -487,6 +490,10 @@ int window_call(orbx_ctx* ctx, const char* who, const orbx_keypoint* kps, const 
   const bool direct = direct_wanted && hipHostGetDevicePointer((void**)&hdev, h, 0) == hipSuccess && hdev != nullptr;
   if (!direct) (void)hipGetLastError();
   std::memset(hout + p_hdr, 0, 16);
+  if (!have_grid && n > 16384) {   // npad * 4 > 64 KB: checked BEFORE anything is queued on the stream
+    if (ensure_dynamic_lds((const void*)k_window_grid, 32768 * 4) != hipSuccess)
+      return set_err(ctx, ORBX_E_CAPACITY, std::string(who) + ": LDS for the grid sort unavailable");
+  }
   if (direct) {
     const int n16 = (int)((in_upload + 15) / 16);
     hipLaunchKernelGGL(k_stage_in, dim3(std::min((n16 + 255) / 256, 256)), dim3(256), 0, st, (const uint4*)hdev, (uint4*)din, n16);
@@ -496,10 +503,6 @@ int window_call(orbx_ctx* ctx, const char* who, const orbx_keypoint* kps, const 
   if (!have_grid) {
     int npad = 2;
     while (npad < n) npad <<= 1;
-    if ((size_t)npad * 4 > 64 * 1024) {
-      if (ensure_dynamic_lds((const void*)k_window_grid, 32768 * 4) != hipSuccess)
-        return set_err(ctx, ORBX_E_CAPACITY, std::string(who) + ": LDS for the grid sort unavailable");
-    }
     hipLaunchKernelGGL(k_window_grid, dim3(1), dim3(1024), (size_t)npad * 4, st, (const orbx_keypoint*)(din + o_kps), n, grid->min_x, grid->min_y,
                        grid->inv_w, grid->inv_h, npad, (int32_t*)(din + o_ci), (int32_t*)(din + o_cs));
   }
@@ -611,6 +614,7 @@ int target_assign(orbx_ctx* ctx, orbx_target* reuse, const orbx_keypoint* kps, c
                   const float* kp_uright, const float* inv_sigma2, int nlevels, orbx_target** out) {
   const char* who = reuse ? "orbx_target_assign" : "orbx_target_create";
   if (out) *out = nullptr;
+  if (reuse) reuse->valid = false;   // until this refill has succeeded: a failed assign must not leave a target that looks searchable
   if (n >= (1 << 24)) return set_err(ctx, ORBX_E_CAPACITY, std::string(who) + ": more than 16 M keypoints");
   const bool have_grid = grid->cell_start != nullptr;
   if (have_grid) { const int rc = validate_grid(ctx, who, grid, n); if (rc != ORBX_OK) return rc; }
@@ -685,6 +689,7 @@ int target_assign(orbx_ctx* ctx, orbx_target* reuse, const orbx_keypoint* kps, c
   }
   if (e == hipSuccess) e = hipEventRecord(ctx->ev_tgt, st);
   if (e != hipSuccess) { T->n = 0; if (!reuse) { (void)hipFree(T->dev); delete T; } ORBX_HIP(ctx, e); }
+  T->valid = true;
   if (out) *out = T;
   return ORBX_OK;
 }
@@ -706,6 +711,7 @@ int window_call_target(orbx_ctx* ctx, const char* who, const orbx_target* T, con
     if (second_idx) second_idx[q] = -1;
     if (second_dist) second_dist[q] = 256;
   }
+  if (!T->valid) return set_err(ctx, ORBX_E_INVALID, std::string(who) + ": the target's last orbx_target_assign failed; assign it again");
   const int n = T->n;
   if (nq == 0 || n == 0) return 0;
   if (chi2 && !(T->has_sig && T->has_ur)) return set_err(ctx, ORBX_E_INVALID, std::string(who) + ": the target holds no kp_uright / inv_level_sigma2");
@@ -928,7 +934,7 @@ int orbx_target_assign(orbx_ctx* ctx, orbx_target* target, const orbx_keypoint* 
 
 void orbx_target_destroy(orbx_target* target) { target_destroy(target); }
 
-int orbx_target_size(const orbx_target* target) { return target ? target->n : ORBX_E_INVALID; }
+int orbx_target_size(const orbx_target* target) { return target && target->valid ? target->n : ORBX_E_INVALID; }
 
 int orbx_target_search(orbx_ctx* ctx, const orbx_target* target, const uint8_t* kp_skip, const float* qx, const float* qy, const float* qr,
                        const int32_t* qmin_level, const int32_t* qmax_level, const uint8_t* q_desc, const float* q_xr, int nq, int32_t* row_ptr,

@@ -298,6 +298,17 @@ class SearchTarget:
               self._ctx)
         self._h = h
 
+    def assign(self, kps, desc, grid, kp_uright=None, inv_level_sigma2=None):
+        """orbx_target_assign: new contents in the same device block.  A failed assign leaves the target INVALID (searches raise
+        OrbxError) until a later assign succeeds."""
+        k = np.ascontiguousarray(kps)
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        ur = None if kp_uright is None else np.ascontiguousarray(kp_uright, np.float32)
+        sig = None if inv_level_sigma2 is None else np.ascontiguousarray(inv_level_sigma2, np.float32)
+        g, keep = self._m._grid(grid)
+        check(self._L.orbx_target_assign(self._ctx, self._h, ptr(k), ptr(d), len(k), C.byref(g), ptr(ur), ptr(sig), 0 if sig is None else len(sig)),
+              self._ctx)
+
     def close(self):
         if getattr(self, "_h", None):
             self._L.orbx_target_destroy(self._h)
@@ -310,7 +321,7 @@ class SearchTarget:
             pass
 
     def __len__(self):
-        return int(self._L.orbx_target_size(self._h))
+        return check(int(self._L.orbx_target_size(self._h)), self._ctx)
 
     def search(self, qx, qy, qr, min_level, max_level, q_desc, kp_skip=None, q_xr=None, want_lists=True):
         qx, qy, qr = (np.ascontiguousarray(v, np.float32) for v in (qx, qy, qr))

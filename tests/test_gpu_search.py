@@ -401,3 +401,33 @@ def test_resident_target_searches_equal_oracle(frames, held, direct):
     for T in (tgt, plain, empty):
         T.close()
     m.set_option("window_direct", 1)
+
+
+def test_failed_target_assign_leaves_an_invalid_target_not_an_empty_one(frames):
+    """orbx_target_assign that fails (here: a grid whose indices point past the keypoints) must not leave a target that answers
+    searches with 0 candidates and ORBX_OK: it is invalid until a later assign succeeds."""
+    gpu, fr = frames
+    m = ORBmatcher(gpu)
+    k2, d2, d1 = fr[1].mvKeysUn, fr[1].mDescriptors, fr[0].mDescriptors
+    grid = _kf_grid(k2, (0.0, 0.0, 640.0, 480.0), False)
+    T = m.Target(k2, d2, grid)
+    nq = 200
+    qx, qy = k2["x"][:nq].copy(), k2["y"][:nq].copy()
+    qr = np.full(nq, 15.0, np.float32)
+    lo = np.full(nq, -1, np.int32); hi = np.full(nq, -1, np.int32)
+    want = po.window_search_grid(k2, d2, grid, qx, qy, qr, lo, hi, d1[:nq])
+    assert np.array_equal(T.search(qx, qy, qr, lo, hi, d1[:nq])["cand"], want["cand"]) and len(want["cand"]) > nq
+    bad = dict(grid, cell_idx=np.where(np.arange(len(grid["cell_idx"])) == 5, len(k2) + 3, grid["cell_idx"]).astype(np.int32))
+    with pytest.raises(OrbxError):
+        T.assign(k2, d2, bad)
+    with pytest.raises(OrbxError):
+        T.search(qx, qy, qr, lo, hi, d1[:nq])
+    with pytest.raises(OrbxError):
+        T.nearest(qx, qy, qr, lo, hi, d1[:nq])
+    with pytest.raises(OrbxError):
+        len(T)
+    T.assign(k2[:500], d2[:500], _kf_grid(k2[:500], (0.0, 0.0, 640.0, 480.0), False))
+    want = po.window_search_grid(k2[:500], d2[:500], _kf_grid(k2[:500], (0.0, 0.0, 640.0, 480.0), False), qx, qy, qr, lo, hi, d1[:nq])
+    got = T.search(qx, qy, qr, lo, hi, d1[:nq])
+    assert len(T) == 500 and np.array_equal(got["cand"], want["cand"]) and np.array_equal(got["dist"], want["dist"])
+    T.close()
