@@ -14,7 +14,10 @@ input than the 256 MB Infinity Cache holds); every rank replays its own camera s
 and for N > 1 the per-step feature blocks are all-gathered over RCCL asynchronously (batch-replay mode).
 After the timed region frames of the last step are compared with the CPU oracle ("verified_frames"); a mismatch fails the run.
 At N = 1 the same line also carries: the end-to-end latency of ORBextractor::operator() through the C++ adapter (host buffers),
-a secondary measurement of BASELINE config 4 (1024x1024, 2000 features) with its own roofline, and the CPU baseline.
+the streamed front-end (operator() + BoW transform + the two per-frame guided searches as one loop, next to the same loop on the
+reference-compiled CPU code), a secondary measurement of BASELINE config 4 (1024x1024, 2000 features) with its own roofline, and the
+CPU baseline (the reference's own src/ORBextractor.cc compiled where it lies + this repository's port).
+--streams 8 selects SURVEY 8(e)'s curve (the same 8 camera streams on G GPUs); N > 1 lines report the all-gather's device time.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -87,7 +90,50 @@ def usable_cores():
     return n, (os.cpu_count() or 1), quota
 
 
-def cpu_baseline(frames, nfeatures, budget_s=24.0):
+def cpu_reference(frames, nfeatures, budget_s):
+    """The reference's OWN src/ORBextractor.cc (oracle/_ref/libref_orbextractor.so: compiled where it lies by oracle/ref_fragments.mk,
+    -O2, portable flags — the binary travels to the GPU box) timed on the host cores: one ORBextractor instance per thread, frames
+    dealt round-robin, ctypes releases the GIL for the 10 ms a call takes.  Its five OpenCV primitives are the oracle's scalar
+    restatements (no OpenCV exists in this image).  None when the library was not built."""
+    import threading
+    from oracle import pyoracle as po
+    if not po.ref_extractor_available():
+        return None
+    ncores, host_threads, quota = usable_cores()
+    fr = np.ascontiguousarray(frames)
+
+    def run(threads, seconds):
+        exs = [po.RefExtractor(nfeatures, 1.2, 8, 20, 7) for _ in range(threads)]
+        done = [[0, 0] for _ in range(threads)]
+        exs[0].extract(fr[0], (0, 1000))   # first-touch outside the clock
+        t_end = time.perf_counter() + seconds
+
+        def work(j):
+            i = j
+            while time.perf_counter() < t_end:
+                kps, _, _ = exs[j].extract(fr[i % len(fr)], (0, 1000))
+                done[j][0] += 1; done[j][1] += len(kps)
+                i += threads
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=work, args=(j,)) for j in range(threads)]
+        for t in th: t.start()
+        for t in th: t.join()
+        dt = time.perf_counter() - t0
+        return sum(d[1] for d in done) / (dt * 1e3), sum(d[0] for d in done), dt
+
+    v1, k1, dt1 = run(1, budget_s * 0.4)
+    va, ka, dta = run(ncores, budget_s * 0.6)
+    return {"value": round(va, 3), "unit": "features/ms", "cores": ncores, "kind": "reference",
+            "what": "the reference's src/ORBextractor.cc compiled where it lies (oracle/_ref/libref_orbextractor.so, g++ -O2 -ffp-contract=off, "
+                    "portable); the five OpenCV primitives it calls (resize, FAST, GaussianBlur, copyMakeBorder, fastAtan2) are scalar "
+                    "restatements — real OpenCV SIMD kernels are faster per core",
+            "value_1core": round(v1, 3), "ms_per_frame_1core": round(dt1 * 1e3 / max(k1, 1), 3), "scaling_efficiency": round(va / (v1 * ncores), 3),
+            "host_hw_threads": host_threads, "cgroup_cpu_quota": quota,
+            "sample": f"{ka} frames of the same {fr.shape[2]}x{fr.shape[1]} stream on {ncores} threads ({dta:.1f} s), one ORBextractor per thread; "
+                      f"1-core figure from {k1} frames ({dt1:.1f} s)"}
+
+
+def cpu_port(frames, nfeatures, budget_s=12.0):
     """The oracle (CPU restatement of src/ORBextractor.cc, pinned to the reference's own file by tests/test_ref_fragments.py)
     timed on the host cores: a REPORTED baseline.  The timing copy is built here with -O3 -march=native -ffp-contract=off
     (SURVEY.md §8(d)); the frame-parallel leg is a std::thread pool inside the library (orbo_extract_many)."""
@@ -123,6 +169,59 @@ def cpu_baseline(frames, nfeatures, budget_s=24.0):
                       f"({dt1:.1f} s); CPU path = this repo's restatement of src/ORBextractor.cc, checked bit for bit against the reference's "
                       "own file compiled over a container shim; its five OpenCV primitives are scalar restatements (real OpenCV SIMD "
                       "FAST / blur / resize is typically faster)"}
+
+
+def cpu_baseline(frames, nfeatures, budget_s=24.0):
+    """north_star: "the reference src/ORBextractor.cc timed on the host cores (core count stated) in the same run".  The reference's
+    own file where its build exists (kind "reference"); this repository's restatement (kind "port", -O3 -march=native) beside it."""
+    ref = None
+    try:
+        ref = cpu_reference(frames, nfeatures, budget_s * 0.5)
+    except Exception as e:   # noqa: BLE001 — the reported baseline must not cost the bench line
+        ref = None
+        err = str(e)[:200]
+    port = cpu_port(frames, nfeatures, budget_s * (0.5 if ref else 1.0))
+    if ref is None:
+        return port
+    ref["port"] = port
+    return ref
+
+
+def streamed_frontend(host_frames, nfeatures, voc_descriptors, nframes=48):
+    """BASELINE config 3's stand-in: the per-frame sequence Tracking runs — ORBextractor::operator() (src/Frame.cc:311,418-425) ->
+    ORBVocabulary::transform (Frame::ComputeBoW, :738-745) -> SearchByProjection(Cur, Last) (src/Tracking.cc:2889) ->
+    SearchByProjection(F, local points) (:3416) — as ONE loop over a stream, one frame at a time, host buffers in and out, through the
+    C++ adapters on tests/support/ref_world objects (tools/streamed_frontend.cpp, built here), next to the SAME loop on the
+    reference's own CPU code (oracle/_ref/ref_streamed_frontend, prebuilt) with the digest of all results compared."""
+    from tests import world_util as wu
+    tmp = tempfile.mkdtemp(prefix="orbx_front_")
+    try:
+        fr = np.ascontiguousarray(host_frames[:nframes])
+        n, rows, cols = fr.shape
+        raw, vocp = os.path.join(tmp, "frames.raw"), os.path.join(tmp, "voc.txt")
+        fr.tofile(raw)
+        from tests.vocab_util import make_vocabulary
+        voc_info = make_vocabulary(vocp, np.concatenate(voc_descriptors), 10, 5, seed=9)
+        exe = wu.build_frontend("orbx", tmp)
+        out = wu.run_frontend(exe, raw, rows, cols, n, nfeatures, vocp, passes=3, timeout=300)
+        out["vocabulary"] = f"synthetic k=10 L=5 ({voc_info['nodes']} nodes, {voc_info['words']} words) over the stream's own descriptors; levelsup 4"
+        out["what"] = ("per frame, one at a time, host buffers: operator() + transform + SearchByProjection(Cur, Last, 15) + "
+                       "SearchByProjection(F, ~2000 local points, th 1) through include/ORBextractor.h / ORBVocabulary.h / ORBmatcher.h; "
+                       "ms_per_frame = the four calls, the host parts of Frame::Frame / isInFrustum are listed separately")
+        if os.path.exists(wu.REF_FRONTEND_EXE):
+            nref = min(n, 24)
+            ref = wu.run_frontend(wu.REF_FRONTEND_EXE, raw, rows, cols, nref, nfeatures, vocp, passes=1, timeout=300)
+            chk = wu.run_frontend(exe, raw, rows, cols, nref, nfeatures, vocp, passes=1, timeout=300) if nref != n else out
+            ref["identical_results"] = bool(ref["results_digest"] == chk["results_digest"])
+            ref["cores"] = 1
+            out["cpu"] = ref
+            if not ref["identical_results"]:
+                raise SystemExit("bench.py: the streamed front-end on the GPU and the reference-compiled CPU loop DISAGREE — no number reported")
+        return out
+    except SystemExit:
+        raise
+    except Exception as e:   # noqa: BLE001
+        return {"error": str(e)[:300]}
 
 
 def e2e_operator(host_frames, nfeatures):
@@ -241,6 +340,12 @@ def main():
     ap.add_argument("--cols", type=int, default=640)
     ap.add_argument("--nfeatures", type=int, default=1000)
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the batch-replay RCCL all-gather")
+    ap.add_argument("--gather", choices=["descriptors", "blocks"], default="descriptors",
+                    help="what the per-step all-gather moves: descriptor rows + counts (north_star) or whole feature blocks incl. keypoints")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="SURVEY 8(e)'s curve: a FIXED set of S camera streams (S-8cam: --streams 8) sharded stream c -> GPU c mod G, "
+                         "--batch frames per stream and step (strong scaling).  0 (default): one stream per GPU (weak scaling)")
+    ap.add_argument("--no-frontend", action="store_true", help="skip the streamed front-end leg (operator() + BoW + two guided searches per frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config-4 (1024x1024, 2000 features) leg and the operator() leg")
     ap.add_argument("--no-verify", action="store_true", help="timing experiments only: skip the oracle check of the last step")
@@ -272,15 +377,25 @@ def main():
     from orb_slam3_modified_amd import ORBextractor, synth
     from orb_slam3_modified_amd.replay import ReplayEngine
 
-    B, H, W = args.batch, args.rows, args.cols
-    # S-8cam: camera `rank` = S-EuRoC-640 streams with seed + 1000*rank (+ 101*k for batch k): `batches` x B frames, every frame
+    from orb_slam3_modified_amd.replay import shard_streams
+    H, W = args.rows, args.cols
+    # S-8cam: camera c = S-EuRoC-640 stream with seed + 1000*c (+ 101*k for batch k): `batches` x B frames per camera, every frame
     # distinct (4 x 256 x 300 KB = 315 MB of level-0 input, more than the 256 MB Infinity Cache).  One generator run per batch:
-    # a single longer stream would wander into the scene's flat quarter and lose the configuration's ~1000 features per frame
+    # a single longer stream would wander into the scene's flat quarter and lose the configuration's ~1000 features per frame.
+    # Default (weak scaling): camera `rank` on GPU `rank`.  --streams S (strong scaling): the same S cameras for every G,
+    # camera c on GPU c mod G, so a rank steps through (its cameras) x --batch frames.
     nsets = max(1, args.batches)
-    host_frames = np.concatenate([synth.make_stream(B, H, W, synth.DEFAULT_SEED + 1000 * rank + 101 * k) for k in range(nsets)])
+    if args.streams > 0:
+        if args.streams % world:
+            raise SystemExit(f"bench.py: --streams {args.streams} does not divide over {world} ranks evenly")
+        cams = shard_streams(args.streams, world, rank)
+    else:
+        cams = [rank]
+    B = args.batch * len(cams)                       # frames per step on this rank
+    host_frames = np.concatenate([synth.make_stream(args.batch, H, W, synth.DEFAULT_SEED + 1000 * c + 101 * k) for k in range(nsets) for c in cams])
     frame_sets = [torch.from_numpy(host_frames[k * B:(k + 1) * B]).to(dev) for k in range(nsets)]
     ex = ORBextractor(args.nfeatures, 1.2, 8, 20, 7, device_id=local_rank)
-    eng = ReplayEngine(ex, frame_sets, lapping=(0, 1000), gather=(world > 1 and not args.no_gather), lanes=args.lanes)
+    eng = ReplayEngine(ex, frame_sets, lapping=(0, 1000), gather=(world > 1 and not args.no_gather), lanes=args.lanes, gather_what=args.gather)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -288,11 +403,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    eng.reset_gather_timing()
     dt, last = timed_replay(eng, args.steps, args.warmup, sync_all)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    # the exchange: device time of one step's collective (HIP events on the gather stream, all timed + warm-up steps), and the same
+    # timed loop without it -> how much of the collective the next step's kernels hide
+    exchange = None
+    if eng.gather:
+        g_ms = eng.gather_ms()
+        eng.gather = False
+        dt_ng, _ = timed_replay(eng, args.steps, 2, sync_all)
+        eng.gather = True
+        tng = torch.tensor([dt_ng, g_ms or 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(tng, op=dist.ReduceOp.MAX)
+        dt_ng, g_ms = float(tng[0].item()), float(tng[1].item())
+        exposed = max(0.0, (dt - dt_ng) / args.steps * 1e3)
+        exchange = {"collective": f"rccl all_gather_into_tensor({args.gather}), one per step, async on its own stream, double-buffered",
+                    "bytes_per_rank_per_step": int(eng.send_bytes), "bytes_received_per_rank_per_step": int(eng.send_bytes * (world - 1)),
+                    "gather_ms": round(g_ms, 4), "step_ms_without_gather": round(dt_ng / args.steps * 1e3, 4),
+                    "exposed_ms_per_step": round(exposed, 4), "overlap_frac": round(1.0 - min(1.0, exposed / g_ms), 4) if g_ms else None}
+        eng.step(); eng.drain(); sync_all()          # a fresh gathered step so that `last` below refers to real data again
+        last = (eng.step_idx - 1) & 1
 
     counts = eng.counts(last).cpu().numpy()
     # ---- the measured path must be the right path: frames of the last timed step against the CPU oracle (every rank its own)
@@ -332,6 +466,9 @@ def main():
                     # HBM bytes per launch of the dominant kernel: FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc
                     # passes, corrected with the known-traffic calibration copy (tools/pmc_traffic.py)
                     roof["traffic"] = int(ent["hbm_bytes_per_launch"]) if ent else None
+                    if ent:
+                        roof["traffic_source"] = ("profiles/pmc_traffic.json: builder-run rocprofv3 --pmc passes of tools/pmc_traffic.py on this "
+                                                  "workload, committed; NOT measured in this run")
             except Exception:
                 pass
         # issue-side evidence for the same kernel (SQ counters from a separate rocprofv3 --pmc run, tools/pmc_sq.py)
@@ -340,13 +477,15 @@ def main():
             try:
                 issue = json.load(open(sqp)).get("derived", {}).get(dom.split("(")[0])
                 roof["issue_limits_pmc"] = {k: round(float(v), 4) for k, v in issue.items()} if issue else None
+                if issue:
+                    roof["issue_limits_pmc"]["source"] = "profiles/pmc_sq.json: builder-run rocprofv3 --pmc pass (tools/pmc_sq.py), committed; NOT measured in this run"
             except Exception:
                 pass
         step_ms = dt / args.steps * 1e3
         result = {
             "metric": "ORB features/ms (+ frames/s), 640x480 8-level pyramid, 1000 features/frame",
             "value": round(value, 1), "unit": "features/ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(step_ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(step_ms, 4), "higher_is_better": True, "scaling": "strong" if args.streams > 0 else "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "frames_per_s": round(total_frames / dt, 1),
             "verified_frames": int(vt.item()),
@@ -354,11 +493,26 @@ def main():
                                    f"nfeatures {args.nfeatures}, iniTh 20 minTh 7, mono lapping [0,1000]; frames resident in HBM, "
                                    f"results left in HBM; the steps rotate through {nsets} distinct batches ({nsets * B} distinct frames per GPU)",
                        "frames_per_step_per_gpu": B, "distinct_batches": nsets, "features_per_frame": round(float(nkp), 1),
-                       "exchange": ("rccl_all_gather(feature blocks), async/overlapped" if eng.gather else "none"),
+                       "exchange": (f"rccl_all_gather({args.gather}), async/overlapped" if eng.gather else "none"),
                        "lanes_per_gpu": len(eng.lane_ranges), "requested_gpus": requested,
-                       "parallelism": f"one camera stream per GPU x{world}"},
+                       "streams": (args.streams if args.streams > 0 else world), "frames_per_stream_per_step": args.batch,
+                       "scaling_mode": (f"strong: the same {args.streams} camera streams for every G, stream c -> GPU c mod G (SURVEY 8(e))" if args.streams > 0
+                                        else "weak: one camera stream per GPU, per-GPU work fixed (--streams 8 selects SURVEY 8(e)'s fixed-8-stream curve)"),
+                       "parallelism": (f"{args.streams} camera streams over {world} GPUs" if args.streams > 0 else f"one camera stream per GPU x{world}")},
             "roofline": roof,
         }
+        if exchange is not None:
+            result["exchange"] = exchange
+        if world == 1 and not args.no_frontend:
+            try:
+                fex = ORBextractor(args.nfeatures, 1.2, 8, 20, 7, device_id=local_rank)
+                vdesc = [fex(host_frames[t], None, (0, 1000))[2] for t in range(0, 48, 8)]
+                del fex
+                result["streamed_frontend"] = streamed_frontend(host_frames, args.nfeatures, vdesc)
+            except SystemExit:
+                raise
+            except Exception as e:   # noqa: BLE001
+                result["streamed_frontend"] = {"error": str(e)[:300]}
         if world == 1 and not args.no_secondary:
             result["end_to_end_operator"] = e2e_operator(host_frames, args.nfeatures)
             # ---- BASELINE config 4: TUM-VI shape, 1024x1024, 2000 features (large-image configuration)

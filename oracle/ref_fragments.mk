@@ -6,6 +6,8 @@
 #   _ref/ref_matcher_world      src/ORBmatcher.cc + include/ORBmatcher.h, unmodified, against the object model of
 #                               tests/support/ref_world (Frame / KeyFrame / MapPoint / Eigen / Sophus stand-ins holding the
 #                               members the matcher touches) + the scenario driver tests/support/matcher_world.cpp
+#   _ref/ref_streamed_frontend  src/ORBextractor.cc + src/ORBmatcher.cc, unmodified, + the DBoW2 library above behind tools/streamed_frontend.cpp:
+#                               the per-frame Tracking sequence on the reference's own CPU code (bench.py's streamed_frontend.cpu leg)
 #   _ref/libref_orbextractor.so src/ORBextractor.cc + include/ORBextractor.h, unmodified, against the container shim; the five
 #                               OpenCV algorithms it calls forward to the oracle's isolated primitives (liborb_oracle.so)
 REFROOT ?= /root/reference
@@ -17,7 +19,7 @@ SRCS := $(REF)/DBoW2/BowVector.cpp $(REF)/DBoW2/FeatureVector.cpp $(REF)/DBoW2/S
 WORLD := ../tests/support/ref_world
 WORLD_HDRS := $(wildcard $(WORLD)/*.h $(WORLD)/*/* $(WORLD)/*/*/*/*) $(wildcard ref_shims/opencv2/*/*.hpp)
 
-all: _ref/libref_dbow2.so _ref/ref_matcher_world _ref/libref_orbextractor.so
+all: _ref/libref_dbow2.so _ref/ref_matcher_world _ref/libref_orbextractor.so _ref/ref_streamed_frontend
 
 _ref/libref_dbow2.so: $(SRCS) ref_shims/opencv2/core/core.hpp ref_shims/boost/serialization/serialization.hpp
 	mkdir -p _ref
@@ -25,7 +27,7 @@ _ref/libref_dbow2.so: $(SRCS) ref_shims/opencv2/core/core.hpp ref_shims/boost/se
 
 # -include ref_world.h: defines the include guards of the reference's Frame.h / KeyFrame.h / MapPoint.h before its
 # ORBmatcher.h includes them from its own directory, so the object model of tests/support/ref_world is the one seen
-_ref/ref_matcher_world: $(REFROOT)/src/ORBmatcher.cc $(REFROOT)/include/ORBmatcher.h ../tests/support/matcher_world.cpp $(WORLD_HDRS)
+_ref/ref_matcher_world: $(REFROOT)/src/ORBmatcher.cc $(REFROOT)/include/ORBmatcher.h ../tests/support/matcher_world.cpp ../tests/support/world_scene.h $(WORLD_HDRS)
 	mkdir -p _ref
 	$(CXX) -O2 -std=c++17 -ffp-contract=off -w -include $(WORLD)/ref_world.h -I$(WORLD) -Iref_shims -I$(REFROOT)/include \
 	    $(REFROOT)/src/ORBmatcher.cc ../tests/support/matcher_world.cpp -o $@
@@ -35,4 +37,12 @@ _ref/libref_orbextractor.so: $(REFROOT)/src/ORBextractor.cc $(REFROOT)/include/O
 	mkdir -p _ref
 	$(CXX) -O2 -std=c++14 -fPIC -ffp-contract=off -w -Iref_shims -I$(REFROOT)/include -shared -o $@ $(REFROOT)/src/ORBextractor.cc ref_wrap_extractor.cpp \
 	    -L. -lorb_oracle -Wl,-rpath,'$$ORIGIN/..'
+
+# -O3 like the reference's own CMAKE_CXX_FLAGS_RELEASE (CMakeLists.txt:13-15; -march=native left out: the binary travels to the GPU box)
+_ref/ref_streamed_frontend: $(REFROOT)/src/ORBextractor.cc $(REFROOT)/src/ORBmatcher.cc ../tools/streamed_frontend.cpp ../tests/support/world_scene.h \
+                            $(WORLD_HDRS) _ref/libref_dbow2.so liborb_oracle.so
+	mkdir -p _ref
+	$(CXX) -O3 -std=c++17 -ffp-contract=off -w -include $(WORLD)/ref_world.h -I$(WORLD) -Iref_shims -I$(REFROOT)/include \
+	    $(REFROOT)/src/ORBextractor.cc $(REFROOT)/src/ORBmatcher.cc ../tools/streamed_frontend.cpp -o $@ \
+	    -L. -lorb_oracle -L_ref -lref_dbow2 -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,'$$ORIGIN'
 .PHONY: all

@@ -66,10 +66,13 @@ class ReplayEngine:
     256 x 640x480, 4 lanes less).  Results are identical: frames are independent and each lane writes its own rows of
     the step's feature block."""
 
-    def __init__(self, extractor, frames_dev, lapping=(0, 1000), gather: bool = True, process_group=None, lanes: int = 1):
+    def __init__(self, extractor, frames_dev, lapping=(0, 1000), gather: bool = True, process_group=None, lanes: int = 1,
+                 gather_what: str = "descriptors"):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
+        assert gather_what in ("descriptors", "blocks")
+        self.gather_what = gather_what
         self.ex = extractor
         # frames_dev: torch uint8 [B, H, W] on this rank's GPU, or a list of such batches (same shape) that the steps rotate
         # through — step k processes batch k mod len
@@ -85,9 +88,22 @@ class ReplayEngine:
         self.pg = process_group
         dev = frames_dev.device
         self.blocks = [torch.zeros(self.layout.nbytes, dtype=torch.uint8, device=dev) for _ in range(2)]
-        self.gathered = [torch.zeros(self.layout.nbytes * self.world, dtype=torch.uint8, device=dev) if self.gather else None
+        # what every rank receives from every other rank per step: the descriptor rows + the per-frame counts (north_star: "RCCL
+        # all-gather of descriptors"; [B][cap][32] + [B][2] int32 — the tail of the block, contiguous), or the whole block with the
+        # 28-byte keypoints as well (SURVEY.md §8(e)'s block).  Fixed size, so the collective is regular.
+        self.send_off = self.layout.desc_off if gather_what == "descriptors" else 0
+        self.send_bytes = self.layout.nbytes - self.send_off
+        self.gathered = [torch.zeros(self.send_bytes * self.world, dtype=torch.uint8, device=dev) if self.gather else None
                          for _ in range(2)]
         self.pending = [None, None]
+        # transport: RCCL ("nccl") moves device buffers asynchronously on the gather stream; any other backend (gloo: the CPU suite and the
+        # two-ranks-on-one-GPU test, where RCCL refuses a shared device) stages through pinned host buffers, synchronously
+        self.device_collective = self.gather and dist.get_backend(process_group) == "nccl"
+        if self.gather and not self.device_collective:
+            pin = dev.type == "cuda"
+            self.h_send = torch.zeros(self.send_bytes, dtype=torch.uint8, pin_memory=pin)
+            self.h_recv = torch.zeros(self.send_bytes * self.world, dtype=torch.uint8, pin_memory=pin)
+        self.gather_events = []   # (start, end) timing events of the collectives since reset_gather_timing()
         self.step_idx = 0
         # Explicit (non-default) streams carry the kernels AND order the collective behind them: the default stream's
         # handle is NULL, which the C ABI reads as "use the context's own stream" — invisible to torch/RCCL.
@@ -137,13 +153,56 @@ class ReplayEngine:
                     self.lane_done[i][j].record(self.streams[j])
         self.pending[i] = None
         if self.gather:  # enqueued behind the kernels of this step, overlaps the next step's kernels
+            send = blk[self.send_off:]
             with torch.cuda.stream(self.gstream):
                 if len(self.lane_ranges) > 1:
                     for ev in self.lane_done[i]:
                         self.gstream.wait_event(ev)
-                self.pending[i] = self.dist.all_gather_into_tensor(self.gathered[i], blk, group=self.pg, async_op=True)
+                if self.device_collective:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(self.gstream)
+                    self.pending[i] = self.dist.all_gather_into_tensor(self.gathered[i], send, group=self.pg, async_op=True)
+                    self.pending[i].wait()   # orders the gather stream behind the collective (no host wait)
+                    e1.record(self.gstream)
+                    if len(self.gather_events) < 4096:
+                        self.gather_events.append((e0, e1))
+                else:
+                    self.h_send.copy_(send, non_blocking=True)
+                    self.gstream.synchronize()
+                    self._host_all_gather()
+                    self.gathered[i].copy_(self.h_recv, non_blocking=True)
         self.step_idx += 1
         return i
+
+    def _host_all_gather(self):
+        dist = self.dist
+        try:
+            dist.all_gather_into_tensor(self.h_recv, self.h_send, group=self.pg)
+        except (RuntimeError, AttributeError, NotImplementedError):   # a backend without the flat form
+            parts = list(self.h_recv.view(self.world, self.send_bytes).unbind(0))
+            dist.all_gather(parts, self.h_send, group=self.pg)
+
+    def reset_gather_timing(self):
+        self.gather_events = []
+
+    def gather_ms(self):
+        """Average device time of one step's collective (HIP events on the gather stream) since reset_gather_timing(); None without one."""
+        if not self.gather_events:
+            return None
+        self.drain()
+        return sum(a.elapsed_time(b) for a, b in self.gather_events) / len(self.gather_events)
+
+    def gathered_view(self, i: int, rank: int):
+        """Rank `rank`'s contribution inside gathered buffer i, as (descriptor rows [B][cap][32], counts [B][2]) device views
+        (gather_what == "blocks": the whole block as uint8)."""
+        lo = self.layout
+        part = self.gathered[i][rank * self.send_bytes:(rank + 1) * self.send_bytes]
+        if self.gather_what == "blocks":
+            return part
+        desc = part[:lo.desc_bytes].view(self.B, lo.cap, 32)
+        c0 = lo.counts_off - lo.desc_off
+        counts = part[c0:c0 + lo.counts_bytes].view(self.torch.int32).reshape(self.B, 2)
+        return desc, counts
 
     def drain(self):
         if self.gstream is not None:

@@ -1,4 +1,5 @@
-// TEST INFRASTRUCTURE: the C-ABI entry points the drop-in ORBmatcher (csrc/ref_adapter/ORBmatcher.cc) calls, served by the
+// TEST INFRASTRUCTURE: the C-ABI entry points the drop-in ORBmatcher (csrc/ref_adapter/ORBmatcher.cc) — and, for
+// tools/streamed_frontend.cpp, the extractor / vocabulary adapters of include/ — call, served by the
 // CPU oracle (oracle/liborb_oracle.so) instead of liborbx.so.  It exists so that the HOST logic of the drop-in — the
 // geometry pre-passes, the replays, the bookkeeping — can be compared with the reference's src/ORBmatcher.cc in the CPU
 // suite (tests/test_matcher_world.py::test_dropin_host_logic_equals_reference).  Never linked into the product; the GPU test
@@ -23,12 +24,68 @@ void mo_window_nearest(const void* kps, const uint8_t* desc, int n, const void* 
                        const uint8_t* q_desc, int nq, int32_t* best_idx, int32_t* best_dist);
 }
 
-struct orbx_ctx { int dummy; };
+extern "C" {
+void* orbo_create(int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh);
+void orbo_destroy(void* h);
+int orbo_extract(void* h, const uint8_t* img, int rows, int cols, int stride, int lap0, int lap1, void* kps, uint8_t* desc, int cap, int* n_out,
+                 int* mono_out);
+void orbo_tables(void* h, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2, int* quota, int* umax16);
+void* mo_voc_load(const char* path);
+void mo_voc_free(void* h);
+void mo_voc_descend(void* h, const uint8_t* desc, int n, int levelsup, uint32_t* word, double* weight, uint32_t* node);
+int mo_voc_transform(void* h, const uint8_t* desc, int n, int levelsup, uint32_t* ids, double* vals, uint32_t* fv_node, uint32_t* fv_feat, int* n_fv);
+double mo_score_l1(const uint32_t* ida, const double* va, int na, const uint32_t* idb, const double* vb, int nb);
+}
+
+struct orbx_ctx { void* ora = nullptr; int nfeatures = 0, nlevels = 0; };
+struct orbx_voc { void* h = nullptr; std::vector<uint8_t> last_desc; int last_levelsup = 0; };
 
 extern "C" {
 
-int orbx_create(orbx_ctx** out, int, float, int, int, int, int) { *out = new orbx_ctx(); return ORBX_OK; }
-void orbx_destroy(orbx_ctx* c) { delete c; }
+int orbx_create(orbx_ctx** out, int nfeatures, float sf, int nlevels, int iniTh, int minTh, int) {
+  orbx_ctx* c = new orbx_ctx();
+  c->ora = orbo_create(nfeatures, sf, nlevels, iniTh, minTh); c->nfeatures = nfeatures; c->nlevels = nlevels;
+  *out = c;
+  return ORBX_OK;
+}
+void orbx_destroy(orbx_ctx* c) { if (c) { orbo_destroy(c->ora); delete c; } }
+// ---- extractor / vocabulary adapters (include/ORBextractor.h, ORBVocabulary.h) over the oracle
+int orbx_keypoint_capacity(const orbx_ctx* c) { return c->nfeatures + 35 * c->nlevels + 64; }
+int orbx_scale_tables(const orbx_ctx* c, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2, int32_t* quota) {
+  orbo_tables(c->ora, scale, inv_scale, sigma2, inv_sigma2, quota, nullptr);
+  return ORBX_OK;
+}
+int orbx_set_host_pyramid(orbx_ctx*, int) { return ORBX_OK; }
+int orbx_host_pyramid_level(orbx_ctx*, int, const uint8_t**, size_t*, int*, int*) { return ORBX_E_INVALID; }
+int orbx_extract(orbx_ctx* c, const uint8_t* img, int rows, int cols, size_t stride, int lap0, int lap1, orbx_keypoint* kps, uint8_t* desc, int* n_out,
+                 int* mono_out) {
+  if (!img || rows <= 0 || cols <= 0) return ORBX_E_EMPTY;
+  return orbo_extract(c->ora, img, rows, cols, (int)stride, lap0, lap1, kps, desc, orbx_keypoint_capacity(c), n_out, mono_out) == 0 ? ORBX_OK : ORBX_E_INVALID;
+}
+int orbx_voc_load_text(orbx_ctx*, const char* path, orbx_voc** out) {
+  void* h = mo_voc_load(path);
+  if (!h) return ORBX_E_INVALID;
+  *out = new orbx_voc();
+  (*out)->h = h;
+  return ORBX_OK;
+}
+void orbx_voc_destroy(orbx_voc* v) { if (v) { mo_voc_free(v->h); delete v; } }
+int orbx_voc_info(const orbx_voc*, int*, int*, int*, int* nwords) { if (nwords) *nwords = 1; return ORBX_OK; }
+int orbx_voc_save_text(const orbx_voc*, const char*) { return ORBX_E_INVALID; }
+int orbx_voc_save_binary(const orbx_voc*, const char*) { return ORBX_E_INVALID; }
+int orbx_voc_load_binary(orbx_ctx*, const char*, orbx_voc**) { return ORBX_E_INVALID; }
+int orbx_bow_transform(orbx_voc* v, const uint8_t* desc, int n, int levelsup, uint32_t* word, double* weight, uint32_t* node) {
+  mo_voc_descend(v->h, desc, n, levelsup, word, weight, node);
+  v->last_desc.assign(desc, desc + (size_t)n * 32); v->last_levelsup = levelsup;   // orbx_bow_finalize below re-derives the vector from these
+  return ORBX_OK;
+}
+int orbx_bow_finalize(const orbx_voc* v, const uint32_t*, const double*, int n, uint32_t* ids, double* vals, int* n_out) {
+  std::vector<uint32_t> fn(n + 1), ff(n + 1);
+  int nfv = 0;
+  *n_out = mo_voc_transform(v->h, v->last_desc.data(), n, v->last_levelsup, ids, vals, fn.data(), ff.data(), &nfv);
+  return ORBX_OK;
+}
+double orbx_bow_score_l1(const uint32_t* ida, const double* va, int na, const uint32_t* idb, const double* vb, int nb) { return mo_score_l1(ida, va, na, idb, vb, nb); }
 const char* orbx_last_error(const orbx_ctx*) { return "oracle stub"; }
 int orbx_hamming(const uint8_t a[32], const uint8_t b[32]) { return mo_hamming(a, b); }
 

@@ -28,7 +28,7 @@ def test_bench_json_line():
     assert len(lines) == 1
     j = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-              "data", "config", "roofline", "cpu_baseline", "verified_frames", "end_to_end_operator", "secondary"):
+              "data", "config", "roofline", "cpu_baseline", "verified_frames", "end_to_end_operator", "secondary", "streamed_frontend"):
         assert k in j, k
     import torch
     ngpu = min(2, torch.cuda.device_count())
@@ -48,5 +48,13 @@ def test_bench_json_line():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and 0 < rf["frac"] < 1
     assert rf["traffic"] is None or rf["traffic"] > 0
     cb = j["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["unit"] == "features/ms" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    # the reference's own src/ORBextractor.cc (oracle/_ref/libref_orbextractor.so, prebuilt) where it travelled, with the port beside it
+    assert cb["kind"] in ("reference", "port") and cb["unit"] == "features/ms" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert 0 < cb["scaling_efficiency"] <= 1.2 and cb["value_1core"] > 0
+    if cb["kind"] == "reference":
+        assert cb["port"]["kind"] == "port" and cb["port"]["value"] > 0
+    sf = j["streamed_frontend"]
+    assert "error" not in sf, sf
+    assert 0.05 < sf["ms_per_frame"] < 20 and sf["features_per_frame"] > 900 and sf["matches_last_per_frame"] > 100
+    if "cpu" in sf:   # the same loop on the reference-compiled CPU code: same results, and slower
+        assert sf["cpu"]["identical_results"] is True and sf["cpu"]["ms_per_frame"] > sf["ms_per_frame"]

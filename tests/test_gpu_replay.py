@@ -9,8 +9,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("lanes", [1, 2])
-def test_replay_engine_gather_matches_block_and_oracle(lanes):
+@pytest.mark.parametrize("lanes,what", [(1, "blocks"), (2, "blocks"), (2, "descriptors")])
+def test_replay_engine_gather_matches_block_and_oracle(lanes, what):
     import torch
     import torch.distributed as dist
     from oracle import pyoracle as po
@@ -26,16 +26,23 @@ def test_replay_engine_gather_matches_block_and_oracle(lanes):
         nfr = 32 if lanes == 1 else 96            # lanes need >= 32 frames each
         frames = torch.from_numpy(host[np.arange(nfr) % 4]).to(dev)
         ex = ORBextractor(1000, 1.2, 8, 20, 7, device_id=0)
-        eng = ReplayEngine(ex, frames, lapping=(0, 1000), gather=True, lanes=lanes)
-        assert eng.gather and len(eng.lane_ranges) == lanes
+        eng = ReplayEngine(ex, frames, lapping=(0, 1000), gather=True, lanes=lanes, gather_what=what)
+        assert eng.gather and eng.device_collective and len(eng.lane_ranges) == lanes
         last = 0
         for _ in range(5):
             last = eng.step()
         eng.drain()
         torch.cuda.synchronize()
+        assert eng.gather_ms() is not None and eng.gather_ms() > 0
         blk = eng.blocks[last].cpu().numpy()
         gat = eng.gathered[last].cpu().numpy()
-        assert np.array_equal(blk, gat[:len(blk)])
+        assert len(gat) == eng.send_bytes and np.array_equal(blk[eng.send_off:], gat)
+        if what == "descriptors":   # descriptor rows + counts travel; the keypoints stay on their rank
+            desc, counts = eng.gathered_view(last, 0)
+            lo = eng.layout
+            assert np.array_equal(desc.cpu().numpy().reshape(-1), blk[lo.desc_off:lo.desc_off + lo.desc_bytes])
+            assert np.array_equal(counts.cpu().numpy(), eng.counts(last).cpu().numpy())
+            gat = blk
         res = unpack_block(gat[:eng.layout.nbytes], eng.layout)
         ora = po.OracleExtractor(1000, 1.2, 8, 20, 7)
         for f in (0, 1, 2, 3, 17, 31, nfr // 2 - 1, nfr // 2, nfr - 1):
@@ -124,3 +131,86 @@ def test_each_stream_fork_alone_is_bit_exact_on_every_frame(opts):
                                 blk.data_ptr() + lo.counts_off, (0, 1000), st.cuda_stream)
     st.synchronize()
     _check_every_frame(blk.cpu().numpy(), lo, host, po.OracleExtractor(1000, 1.2, 8, 20, 7), (0, 1000))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _world2_worker(rank, world, port, what, q):
+    """One rank of a 2-rank job; both ranks share cuda:0 (RCCL refuses a shared device, so the exchange takes ReplayEngine's host-staged
+    transport over gloo — everything else is the engine bench.py runs: lanes, rotating batches, double-buffered blocks, the gather
+    ordered behind the lanes of its step)."""
+    import hashlib
+    import torch
+    import torch.distributed as dist
+    from oracle import pyoracle as po
+    from orb_slam3_modified_amd import ORBextractor, synth
+    from orb_slam3_modified_amd.replay import ReplayEngine, shard_streams, unpack_block
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        B, nsets, steps = 64, 3, 6
+        cams = shard_streams(world, world, rank)           # stream c -> GPU c mod G: one camera per rank here
+        assert cams == [rank]
+        host = {r: [synth.make_stream(B, 480, 640, synth.DEFAULT_SEED + 1000 * r + 101 * k) for k in range(nsets)] for r in range(world)}
+        sets = [torch.from_numpy(h).to(dev) for h in host[rank]]
+        ex = ORBextractor(1000, 1.2, 8, 20, 7, device_id=0)
+        eng = ReplayEngine(ex, sets, lapping=(0, 1000), gather=True, lanes=2, gather_what=what)
+        assert eng.gather and not eng.device_collective and eng.world == world and len(eng.lane_ranges) == 2
+        ora = po.OracleExtractor(1000, 1.2, 8, 20, 7)
+        lo = eng.layout
+        ok, notes = True, []
+        for step in range(steps):
+            i = eng.step()
+            if step < steps - 2:
+                continue                                   # let the double buffers be reused before anything is checked
+            eng.drain()
+            torch.cuda.synchronize()
+            k = step % nsets
+            mine = eng.blocks[i].cpu().numpy()
+            gat = eng.gathered[i].cpu().numpy().reshape(world, eng.send_bytes)
+            ok &= bool(np.array_equal(gat[rank], mine[eng.send_off:]))          # my own contribution, every frame, bit for bit
+            # both ranks must hold the same gathered buffer
+            digests = [None] * world
+            dist.all_gather_object(digests, hashlib.sha256(gat.tobytes()).hexdigest())
+            ok &= digests[0] == digests[1]
+            for r in range(world):                         # every rank's part against the oracle on that rank's frames of this step
+                for f in (0, B // 2 - 1, B // 2, B - 1):
+                    okps, odesc, omono = ora.extract(host[r][k][f], (0, 1000))
+                    if what == "blocks":
+                        mono, kps, desc = unpack_block(gat[r], lo)[f]
+                        good = mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc)
+                    else:
+                        desc_all, counts = eng.gathered_view(i, r)
+                        n, mono = (int(v) for v in counts[f].cpu().numpy())
+                        good = n == len(okps) and mono == omono and np.array_equal(desc_all[f, :n].cpu().numpy(), odesc)
+                    if not good:
+                        notes.append((step, r, f))
+                    ok &= good
+        q.put((rank, bool(ok), notes))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("what", ["descriptors", "blocks"])
+def test_replay_engine_world2_every_rank_holds_both_ranks_results(what):
+    """The N > 1 path with a real ReplayEngine on every rank: two ranks, two different camera streams, several steps
+    so that both block buffers and both gathered buffers are reused; every rank's gathered buffer must hold BOTH ranks' results,
+    bit-exact against the oracle, and be identical on both ranks."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_world2_worker, args=(r, 2, port, what, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(r for r, _, _ in res) == [0, 1]
+    assert all(ok for _, ok, _ in res), res

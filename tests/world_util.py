@@ -58,7 +58,7 @@ def _stale(out: str, deps) -> bool:
 
 
 def _deps():
-    d = [os.path.join(SUP, "matcher_world.cpp"), ADAPTER_SRC]
+    d = [os.path.join(SUP, "matcher_world.cpp"), os.path.join(SUP, "world_scene.h"), ADAPTER_SRC]
     for base in (os.path.join(ROOT, "include"), os.path.join(SUP, "ref_world"), os.path.join(ROOT, "oracle", "ref_shims", "opencv2", "core")):
         for dp, _, fs in os.walk(base):
             d += [os.path.join(dp, f) for f in fs]
@@ -105,3 +105,52 @@ def first_difference(a: str, b: str) -> str:
             k = next((j for j, (p, q) in enumerate(zip(xs, ys)) if p != q), min(len(xs), len(ys)))
             return f"scenario '{scen}', line {i}: token {k}: {xs[k:k + 6]} != {ys[k:k + 6]} ({x[:60]}...)"
     return f"lengths differ: {len(la)} vs {len(lb)} lines" if len(la) != len(lb) else ""
+
+
+# ---- tools/streamed_frontend.cpp: the per-frame Tracking sequence (extract -> BoW -> SearchByProjection x2) as one loop ----
+FRONTEND_SRC = os.path.join(ROOT, "tools", "streamed_frontend.cpp")
+REF_FRONTEND_EXE = os.path.join(ROOT, "oracle", "_ref", "ref_streamed_frontend")
+
+
+def build_frontend(backend: str, outdir: str = SUP) -> str:
+    """The drop-in build of tools/streamed_frontend.cpp: backend 'orbx' links liborbx.so, 'oracle' the oracle-backed C-ABI stub."""
+    out = os.path.join(outdir, f"streamed_frontend_{backend}.bin")
+    srcs = [FRONTEND_SRC, ADAPTER_SRC]
+    if backend == "orbx":
+        from orb_slam3_modified_amd import build
+        build.build()
+        link = ["-L", PKG, "-lorbx", "-Wl,-rpath," + PKG, "-Wl,--allow-shlib-undefined"]
+        deps = _deps() + [FRONTEND_SRC, os.path.join(PKG, "liborbx.so")]
+    else:
+        from oracle import pyoracle
+        pyoracle.build()
+        srcs.append(os.path.join(SUP, "orbx_oracle_stub.cpp"))
+        odir = os.path.join(ROOT, "oracle")
+        link = ["-DORBX_STUB_BACKEND", "-L", odir, "-lorb_oracle", "-Wl,-rpath," + odir]
+        deps = _deps() + [FRONTEND_SRC, srcs[-1], os.path.join(odir, "liborb_oracle.so")]
+    if _stale(out, deps):
+        subprocess.check_call(["g++"] + CXXFLAGS + INCLUDES + srcs + ["-o", out] + link)
+    return out
+
+
+def frontend_inputs(tmpdir: str, nframes: int = 12, rows: int = 480, cols: int = 640, nfeatures: int = 1000, seed: int = 20260925, k: int = 10,
+                    L: int = 4):
+    """frames.raw of one synthetic stream + a k-ary vocabulary over the descriptors of a few of its frames."""
+    from oracle import pyoracle as po
+    from orb_slam3_modified_amd import synth
+    from tests.vocab_util import make_vocabulary
+    frames = synth.make_stream(nframes, rows, cols, seed)
+    raw, vocp = os.path.join(tmpdir, "frames.raw"), os.path.join(tmpdir, "voc.txt")
+    np.ascontiguousarray(frames).tofile(raw)
+    ora = po.OracleExtractor(nfeatures, 1.2, 8, 20, 7)
+    descs = [ora.extract(frames[t], (0, 1000))[1] for t in range(0, nframes, max(1, nframes // 4))]
+    make_vocabulary(vocp, np.concatenate(descs), k, L, seed=9)
+    return raw, vocp
+
+
+def run_frontend(exe: str, raw: str, rows: int, cols: int, nframes: int, nfeatures: int, vocp: str, passes: int = 1, timeout: int = 600) -> dict:
+    import json
+    r = subprocess.run([exe, raw, str(rows), str(cols), str(nframes), str(nfeatures), vocp, str(passes)], capture_output=True, text=True, timeout=timeout)
+    if r.returncode != 0:
+        raise RuntimeError(f"{exe} failed ({r.returncode}): {r.stdout}{r.stderr}")
+    return json.loads(r.stdout.strip().splitlines()[-1])
