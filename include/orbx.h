@@ -416,6 +416,14 @@ int orbx_kfdb_size(const orbx_kfdb* db);
 int orbx_kfdb_query(orbx_kfdb* db, const uint32_t* q_ids, const double* q_vals, int nq, const int64_t* exclude, int n_exclude,
                     int min_words_floor, int64_t* kf_ids, int32_t* common_words, double* scores, int cap, int* n_sharing,
                     int* max_common_words, int* min_common_words);
+/* The two phases on their own, as the drop-in KeyFrameDatabase class uses them (include/KeyFrameDatabase.h,
+ * orb_slam3_modified_amd/csrc/ref_adapter/KeyFrameDatabase.cc): orbx_kfdb_sharing = EVERY keyframe sharing a word with the query,
+ * in the reference's list order, with its number of common words (no exclusion: which of them enter a routine's list — same map,
+ * other map, not connected — and what happens to the others is decided over the caller's own objects); *n_sharing is set even when
+ * cap is too small (ORBX_E_CAPACITY).  orbx_kfdb_score = mpVoc->score(query, keyframe) (L1Scoring::score) for exactly the listed
+ * keyframes, doubles bit-identical to the reference's. */
+int orbx_kfdb_sharing(orbx_kfdb* db, const uint32_t* q_ids, int nq, int64_t* kf_ids, int32_t* common_words, int cap, int* n_sharing);
+int orbx_kfdb_score(orbx_kfdb* db, const uint32_t* q_ids, const double* q_vals, int nq, const int64_t* kf_ids, int n, double* scores);
 
 #ifdef __cplusplus
 }

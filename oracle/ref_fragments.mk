@@ -8,6 +8,10 @@
 #                               members the matcher touches) + the scenario driver tests/support/matcher_world.cpp
 #   _ref/ref_streamed_frontend  src/ORBextractor.cc + src/ORBmatcher.cc, unmodified, + the DBoW2 library above behind tools/streamed_frontend.cpp:
 #                               the per-frame Tracking sequence on the reference's own CPU code (bench.py's streamed_frontend.cpu leg)
+#   _ref/ref_kfdb_world         src/KeyFrameDatabase.cc + include/KeyFrameDatabase.h + include/ORBVocabulary.h (the DBoW2 template), unmodified,
+#                               against the same object model (KeyFrame's database fields, covisibility accessors, a Map stand-in) + the
+#                               scenario driver tests/support/kfdb_world.cpp; the reference's own BowVector.h / FeatureVector.h are
+#                               force-included first so that ONE definition of the two DBoW2 classes is seen
 #   _ref/libref_orbextractor.so src/ORBextractor.cc + include/ORBextractor.h, unmodified, against the container shim; the five
 #                               OpenCV algorithms it calls forward to the oracle's isolated primitives (liborb_oracle.so)
 REFROOT ?= /root/reference
@@ -19,7 +23,7 @@ SRCS := $(REF)/DBoW2/BowVector.cpp $(REF)/DBoW2/FeatureVector.cpp $(REF)/DBoW2/S
 WORLD := ../tests/support/ref_world
 WORLD_HDRS := $(wildcard $(WORLD)/*.h $(WORLD)/*/* $(WORLD)/*/*/*/*) $(wildcard ref_shims/opencv2/*/*.hpp)
 
-all: _ref/libref_dbow2.so _ref/ref_matcher_world _ref/libref_orbextractor.so _ref/ref_streamed_frontend
+all: _ref/libref_dbow2.so _ref/ref_matcher_world _ref/libref_orbextractor.so _ref/ref_streamed_frontend _ref/ref_kfdb_world
 
 _ref/libref_dbow2.so: $(SRCS) ref_shims/opencv2/core/core.hpp ref_shims/boost/serialization/serialization.hpp
 	mkdir -p _ref
@@ -45,4 +49,11 @@ _ref/ref_streamed_frontend: $(REFROOT)/src/ORBextractor.cc $(REFROOT)/src/ORBmat
 	$(CXX) -O3 -std=c++17 -ffp-contract=off -w -include $(WORLD)/ref_world.h -I$(WORLD) -Iref_shims -I$(REFROOT)/include \
 	    $(REFROOT)/src/ORBextractor.cc $(REFROOT)/src/ORBmatcher.cc ../tools/streamed_frontend.cpp -o $@ \
 	    -L. -lorb_oracle -L_ref -lref_dbow2 -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,'$$ORIGIN'
+
+_ref/ref_kfdb_world: $(REFROOT)/src/KeyFrameDatabase.cc $(REFROOT)/include/KeyFrameDatabase.h $(REFROOT)/include/ORBVocabulary.h \
+                     ../tests/support/kfdb_world.cpp ../tests/support/world_scene.h $(WORLD_HDRS) _ref/libref_dbow2.so
+	mkdir -p _ref
+	$(CXX) -O2 -std=c++17 -ffp-contract=off -w -include $(REF)/DBoW2/BowVector.h -include $(REF)/DBoW2/FeatureVector.h -include $(WORLD)/ref_world.h \
+	    -I$(WORLD) -Iref_shims -I$(REFROOT)/include -I$(REFROOT) $(REFROOT)/src/KeyFrameDatabase.cc ../tests/support/kfdb_world.cpp -o $@ \
+	    -L_ref -lref_dbow2 -Wl,-rpath,'$$ORIGIN'
 .PHONY: all

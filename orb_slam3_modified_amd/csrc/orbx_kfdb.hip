@@ -287,22 +287,17 @@ int orbx_kfdb_clear(orbx_kfdb* db) {
   return ORBX_OK;
 }
 
-int orbx_kfdb_query(orbx_kfdb* db, const uint32_t* q_ids, const double* q_vals, int nq, const int64_t* exclude, int n_exclude,
-                    int min_words_floor, int64_t* kf_ids, int32_t* common_words, double* scores, int cap, int* n_sharing,
-                    int* max_common_words, int* min_common_words) {
-  if (!db || nq < 0 || n_exclude < 0 || cap < 0 || !n_sharing || (nq > 0 && (!q_ids || !q_vals)) || (n_exclude > 0 && !exclude) ||
-      (cap > 0 && (!kf_ids || !common_words || !scores)))
-    return db ? set_err(db->ctx, ORBX_E_INVALID, "orbx_kfdb_query: bad arguments") : ORBX_E_INVALID;
+}  // extern "C"
+
+namespace {
+
+// shared front of the query entry points: arguments, device copy up to date, query words (and values) uploaded
+int kfdb_begin(orbx_kfdb* db, const char* who, const uint32_t* q_ids, const double* q_vals, int nq) {
   orbx_ctx* ctx = db->ctx;
-  *n_sharing = 0;
-  if (max_common_words) *max_common_words = 0;
-  if (min_common_words) *min_common_words = 0;
   for (int i = 1; i < nq; i++)
-    if (q_ids[i] <= q_ids[i - 1]) return set_err(ctx, ORBX_E_INVALID, "orbx_kfdb_query: word ids must ascend strictly");
-  const int nrows = (int)db->rows.size();
-  if (nrows == 0 || nq == 0 || db->row_of.empty()) return ORBX_OK;
+    if (q_ids[i] <= q_ids[i - 1]) return set_err(ctx, ORBX_E_INVALID, std::string(who) + ": word ids must ascend strictly");
   ORBX_HIP(ctx, hipSetDevice(ctx->device));
-  int rc = kfdb_sync(db);
+  const int rc = kfdb_sync(db);
   if (rc != ORBX_OK) return rc;
   hipStream_t st = ctx->stream;
   if ((size_t)nq > db->d_q_cap) {
@@ -315,37 +310,89 @@ int orbx_kfdb_query(orbx_kfdb* db, const uint32_t* q_ids, const double* q_vals, 
     ORBX_HIP(ctx, hipMalloc((void**)&db->d_qv, qc * sizeof(double)));
     db->d_q_cap = qc;
   }
-  // rows taking part: alive and not excluded by the caller (connected keyframes, other maps, ...)
+  ORBX_HIP(ctx, hipMemcpyAsync(db->d_qid, q_ids, (size_t)nq * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  if (q_vals) ORBX_HIP(ctx, hipMemcpyAsync(db->d_qv, q_vals, (size_t)nq * sizeof(double), hipMemcpyHostToDevice, st));
+  return ORBX_OK;
+}
+
+// a query of up to 8192 words (every configuration of the reference's yaml files) is staged in LDS; a longer one (the
+// 20 000-feature frames of Examples/Monocular/mi.yaml) is searched where it lies, in HBM / L2
+int kfdb_launch_common(orbx_kfdb* db, int nq, int nrows) {
+  hipStream_t st = db->ctx->stream;
+  const dim3 grid((nrows + 3) / 4), block(256);
+  if (nq <= kKfdbMaxQuery)
+    hipLaunchKernelGGL(k_kfdb_common<true>, grid, block, (size_t)nq * sizeof(uint32_t), st, db->d_qid, nq, db->d_rows, db->d_active, nrows, db->d_ids,
+                       db->d_common, db->d_first, db->d_max);
+  else
+    hipLaunchKernelGGL(k_kfdb_common<false>, grid, block, 0, st, db->d_qid, nq, db->d_rows, db->d_active, nrows, db->d_ids, db->d_common, db->d_first,
+                       db->d_max);
+  ORBX_HIP(db->ctx, hipGetLastError());
+  return ORBX_OK;
+}
+
+int kfdb_launch_score(orbx_kfdb* db, const char* who, int nq, int nrows, int min_words_floor) {
+  orbx_ctx* ctx = db->ctx;
+  hipStream_t st = ctx->stream;
+  const dim3 grid((nrows + 3) / 4), block(256);
+  const bool inlds = nq <= kKfdbMaxQuery;
+  const size_t lds2 = inlds ? (size_t)((nq + 1) & ~1) * sizeof(uint32_t) + (size_t)nq * sizeof(double) : 0;
+  if (lds2 > 64 * 1024 && ensure_dynamic_lds((const void*)k_kfdb_score<true>, (int)lds2) != hipSuccess)
+    return set_err(ctx, ORBX_E_CAPACITY, std::string(who) + ": query does not fit the LDS");
+  if (inlds)
+    hipLaunchKernelGGL(k_kfdb_score<true>, grid, block, lds2, st, db->d_qid, db->d_qv, nq, db->d_rows, nrows, db->d_ids, db->d_vals, db->d_common,
+                       db->d_max, min_words_floor, db->d_scores);
+  else
+    hipLaunchKernelGGL(k_kfdb_score<false>, grid, block, 0, st, db->d_qid, db->d_qv, nq, db->d_rows, nrows, db->d_ids, db->d_vals, db->d_common,
+                       db->d_max, min_words_floor, db->d_scores);
+  ORBX_HIP(ctx, hipGetLastError());
+  return ORBX_OK;
+}
+
+// the reference's list order: query words ascending, inside one word's inverted list the order of add() (:39-45)
+void kfdb_list_order(const orbx_kfdb* db, const std::vector<int32_t>& common, const std::vector<uint32_t>& first, std::vector<int>& order) {
+  order.clear();
+  for (int r = 0; r < (int)common.size(); r++)
+    if (common[r] > 0) order.push_back(r);
+  std::sort(order.begin(), order.end(), [&](int a, int b) {
+    if (first[a] != first[b]) return first[a] < first[b];
+    return db->rows[a].seq < db->rows[b].seq;
+  });
+}
+
+}  // namespace
+
+extern "C" {
+
+int orbx_kfdb_query(orbx_kfdb* db, const uint32_t* q_ids, const double* q_vals, int nq, const int64_t* exclude, int n_exclude,
+                    int min_words_floor, int64_t* kf_ids, int32_t* common_words, double* scores, int cap, int* n_sharing,
+                    int* max_common_words, int* min_common_words) {
+  if (!db || nq < 0 || n_exclude < 0 || cap < 0 || !n_sharing || (nq > 0 && (!q_ids || !q_vals)) || (n_exclude > 0 && !exclude) ||
+      (cap > 0 && (!kf_ids || !common_words || !scores)))
+    return db ? set_err(db->ctx, ORBX_E_INVALID, "orbx_kfdb_query: bad arguments") : ORBX_E_INVALID;
+  orbx_ctx* ctx = db->ctx;
+  *n_sharing = 0;
+  if (max_common_words) *max_common_words = 0;
+  if (min_common_words) *min_common_words = 0;
+  const int nrows = (int)db->rows.size();
+  if (nrows == 0 || nq == 0 || db->row_of.empty()) {
+    for (int i = 1; i < nq; i++)
+      if (q_ids[i] <= q_ids[i - 1]) return set_err(ctx, ORBX_E_INVALID, "orbx_kfdb_query: word ids must ascend strictly");
+    return ORBX_OK;
+  }
+  int rc = kfdb_begin(db, "orbx_kfdb_query", q_ids, q_vals, nq);
+  if (rc != ORBX_OK) return rc;
+  hipStream_t st = ctx->stream;
+  // rows taking part: alive and not excluded by the caller (connected keyframes, keyframes of another map, ...)
   std::vector<uint8_t> active(nrows);
   for (int r = 0; r < nrows; r++) active[r] = db->rows[r].alive;
   for (int i = 0; i < n_exclude; i++) {
     auto it = db->row_of.find(exclude[i]);
     if (it != db->row_of.end()) active[it->second] = 0;
   }
-  ORBX_HIP(ctx, hipMemcpyAsync(db->d_qid, q_ids, (size_t)nq * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-  ORBX_HIP(ctx, hipMemcpyAsync(db->d_qv, q_vals, (size_t)nq * sizeof(double), hipMemcpyHostToDevice, st));
   ORBX_HIP(ctx, hipMemcpyAsync(db->d_active, active.data(), (size_t)nrows, hipMemcpyHostToDevice, st));
   ORBX_HIP(ctx, hipMemsetAsync(db->d_max, 0, sizeof(int32_t), st));
-  const dim3 grid((nrows + 3) / 4), block(256);
-  // a query of up to 8192 words (every configuration of the reference's yaml files) is staged in LDS; a longer one (the
-  // 20 000-feature frames of Examples/Monocular/mi.yaml) is searched where it lies, in HBM / L2
-  bool inlds = nq <= kKfdbMaxQuery;
-  const size_t lds1 = inlds ? (size_t)nq * sizeof(uint32_t) : 0;
-  const size_t lds2 = inlds ? (size_t)((nq + 1) & ~1) * sizeof(uint32_t) + (size_t)nq * sizeof(double) : 0;
-  if (lds2 > 64 * 1024 && ensure_dynamic_lds((const void*)k_kfdb_score<true>, (int)lds2) != hipSuccess)
-    return set_err(ctx, ORBX_E_CAPACITY, "orbx_kfdb_query: query does not fit the LDS");
-  if (inlds) {
-    hipLaunchKernelGGL(k_kfdb_common<true>, grid, block, lds1, st, db->d_qid, nq, db->d_rows, db->d_active, nrows, db->d_ids, db->d_common,
-                       db->d_first, db->d_max);
-    hipLaunchKernelGGL(k_kfdb_score<true>, grid, block, lds2, st, db->d_qid, db->d_qv, nq, db->d_rows, nrows, db->d_ids, db->d_vals, db->d_common,
-                       db->d_max, min_words_floor, db->d_scores);
-  } else {
-    hipLaunchKernelGGL(k_kfdb_common<false>, grid, block, 0, st, db->d_qid, nq, db->d_rows, db->d_active, nrows, db->d_ids, db->d_common,
-                       db->d_first, db->d_max);
-    hipLaunchKernelGGL(k_kfdb_score<false>, grid, block, 0, st, db->d_qid, db->d_qv, nq, db->d_rows, nrows, db->d_ids, db->d_vals, db->d_common,
-                       db->d_max, min_words_floor, db->d_scores);
-  }
-  ORBX_HIP(ctx, hipGetLastError());
+  if ((rc = kfdb_launch_common(db, nq, nrows)) != ORBX_OK) return rc;
+  if ((rc = kfdb_launch_score(db, "orbx_kfdb_query", nq, nrows, min_words_floor)) != ORBX_OK) return rc;
   std::vector<int32_t> common(nrows);
   std::vector<uint32_t> first(nrows);
   std::vector<double> sc(nrows);
@@ -355,14 +402,8 @@ int orbx_kfdb_query(orbx_kfdb* db, const uint32_t* q_ids, const double* q_vals, 
   ORBX_HIP(ctx, hipMemcpyAsync(sc.data(), db->d_scores, (size_t)nrows * sizeof(double), hipMemcpyDeviceToHost, st));
   ORBX_HIP(ctx, hipMemcpyAsync(&maxc, db->d_max, sizeof(int32_t), hipMemcpyDeviceToHost, st));
   ORBX_HIP(ctx, hipStreamSynchronize(st));
-  // the reference's list order: query words ascending, inside one word's inverted list the order of add() (:39-45)
   std::vector<int> order;
-  for (int r = 0; r < nrows; r++)
-    if (common[r] > 0) order.push_back(r);
-  std::sort(order.begin(), order.end(), [&](int a, int b) {
-    if (first[a] != first[b]) return first[a] < first[b];
-    return db->rows[a].seq < db->rows[b].seq;
-  });
+  kfdb_list_order(db, common, first, order);
   int minc = (int)((float)maxc * 0.8f);
   if (minc < min_words_floor) minc = min_words_floor;
   if ((int)order.size() > cap) return set_err(ctx, ORBX_E_CAPACITY, "orbx_kfdb_query: output capacity below the number of keyframes sharing a word");
@@ -375,6 +416,70 @@ int orbx_kfdb_query(orbx_kfdb* db, const uint32_t* q_ids, const double* q_vals, 
   *n_sharing = (int)order.size();
   if (max_common_words) *max_common_words = maxc;
   if (min_common_words) *min_common_words = minc;
+  return ORBX_OK;
+}
+
+// ---- the two phases on their own: what a drop-in KeyFrameDatabase needs (csrc/ref_adapter/KeyFrameDatabase.cc).  The five Detect*
+// routines differ in WHICH sharing keyframes enter their list (same map / other map / not connected) and in side effects on the ones
+// that do not; with the full list in hand that is host logic over the caller's own objects, and the thresholds follow from the
+// filtered list, so the scores are asked for afterwards, for exactly the keyframes the routine selected.
+int orbx_kfdb_sharing(orbx_kfdb* db, const uint32_t* q_ids, int nq, int64_t* kf_ids, int32_t* common_words, int cap, int* n_sharing) {
+  if (!db || nq < 0 || cap < 0 || !n_sharing || (nq > 0 && !q_ids) || (cap > 0 && (!kf_ids || !common_words)))
+    return db ? set_err(db->ctx, ORBX_E_INVALID, "orbx_kfdb_sharing: bad arguments") : ORBX_E_INVALID;
+  orbx_ctx* ctx = db->ctx;
+  *n_sharing = 0;
+  const int nrows = (int)db->rows.size();
+  if (nrows == 0 || nq == 0 || db->row_of.empty()) return ORBX_OK;
+  int rc = kfdb_begin(db, "orbx_kfdb_sharing", q_ids, nullptr, nq);
+  if (rc != ORBX_OK) return rc;
+  hipStream_t st = ctx->stream;
+  std::vector<uint8_t> active(nrows);
+  for (int r = 0; r < nrows; r++) active[r] = db->rows[r].alive;
+  ORBX_HIP(ctx, hipMemcpyAsync(db->d_active, active.data(), (size_t)nrows, hipMemcpyHostToDevice, st));
+  ORBX_HIP(ctx, hipMemsetAsync(db->d_max, 0, sizeof(int32_t), st));
+  if ((rc = kfdb_launch_common(db, nq, nrows)) != ORBX_OK) return rc;
+  std::vector<int32_t> common(nrows);
+  std::vector<uint32_t> first(nrows);
+  ORBX_HIP(ctx, hipMemcpyAsync(common.data(), db->d_common, (size_t)nrows * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  ORBX_HIP(ctx, hipMemcpyAsync(first.data(), db->d_first, (size_t)nrows * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  ORBX_HIP(ctx, hipStreamSynchronize(st));
+  std::vector<int> order;
+  kfdb_list_order(db, common, first, order);
+  *n_sharing = (int)order.size();
+  if ((int)order.size() > cap) return set_err(ctx, ORBX_E_CAPACITY, "orbx_kfdb_sharing: output capacity below the number of keyframes sharing a word");
+  for (size_t i = 0; i < order.size(); i++) { kf_ids[i] = db->rows[order[i]].kf_id; common_words[i] = common[order[i]]; }
+  return ORBX_OK;
+}
+
+int orbx_kfdb_score(orbx_kfdb* db, const uint32_t* q_ids, const double* q_vals, int nq, const int64_t* kf_ids, int n, double* scores) {
+  if (!db || nq < 0 || n < 0 || (nq > 0 && (!q_ids || !q_vals)) || (n > 0 && (!kf_ids || !scores)))
+    return db ? set_err(db->ctx, ORBX_E_INVALID, "orbx_kfdb_score: bad arguments") : ORBX_E_INVALID;
+  orbx_ctx* ctx = db->ctx;
+  if (n == 0) return ORBX_OK;
+  const int nrows = (int)db->rows.size();
+  std::vector<int32_t> sel(nrows, 0);
+  std::vector<int> row(n);
+  for (int i = 0; i < n; i++) {
+    auto it = db->row_of.find(kf_ids[i]);
+    if (it == db->row_of.end()) return set_err(ctx, ORBX_E_INVALID, "orbx_kfdb_score: keyframe id not in the database");
+    row[i] = it->second;
+    sel[it->second] = 1;
+  }
+  if (nq == 0) {   // L1Scoring::score of an empty vector against anything: no common term, -0.0 / 2 -> the reference returns -0 = 0
+    for (int i = 0; i < n; i++) scores[i] = 0.0;
+    return ORBX_OK;
+  }
+  int rc = kfdb_begin(db, "orbx_kfdb_score", q_ids, q_vals, nq);
+  if (rc != ORBX_OK) return rc;
+  hipStream_t st = ctx->stream;
+  // k_kfdb_score scores the rows with common > (int)(max * 0.8f): selected rows carry 1, the others 0, max = 0
+  ORBX_HIP(ctx, hipMemcpyAsync(db->d_common, sel.data(), (size_t)nrows * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  ORBX_HIP(ctx, hipMemsetAsync(db->d_max, 0, sizeof(int32_t), st));
+  if ((rc = kfdb_launch_score(db, "orbx_kfdb_score", nq, nrows, 0)) != ORBX_OK) return rc;
+  std::vector<double> sc(nrows);
+  ORBX_HIP(ctx, hipMemcpyAsync(sc.data(), db->d_scores, (size_t)nrows * sizeof(double), hipMemcpyDeviceToHost, st));
+  ORBX_HIP(ctx, hipStreamSynchronize(st));
+  for (int i = 0; i < n; i++) scores[i] = sc[row[i]];
   return ORBX_OK;
 }
 

@@ -58,3 +58,20 @@ class KeyFrameDatabase:
                                       ptr(kf), ptr(words), ptr(score), cap, C.byref(n), C.byref(mx), C.byref(mn)), self._ctx)
         k = n.value
         return dict(kf=kf[:k].copy(), words=words[:k].copy(), score=score[:k].copy(), max_common=mx.value, min_common=mn.value)
+
+    def sharing(self, word_ids) -> Tuple[np.ndarray, np.ndarray]:
+        """orbx_kfdb_sharing: (keyframe ids in the reference's list order, common word counts) of EVERY keyframe sharing a word."""
+        ids = np.ascontiguousarray(word_ids, np.uint32)
+        cap = max(len(self), 1)
+        kf = np.zeros(cap, np.int64); words = np.zeros(cap, np.int32)
+        n = C.c_int(0)
+        check(self._L.orbx_kfdb_sharing(self._db, ptr(ids), len(ids), ptr(kf), ptr(words), cap, C.byref(n)), self._ctx)
+        return kf[:n.value].copy(), words[:n.value].copy()
+
+    def score(self, bow: Tuple[np.ndarray, np.ndarray], kf_ids) -> np.ndarray:
+        """orbx_kfdb_score: mpVoc->score(query, keyframe) (L1) for the listed keyframes."""
+        ids = np.ascontiguousarray(bow[0], np.uint32); vals = np.ascontiguousarray(bow[1], np.float64)
+        kf = np.ascontiguousarray(list(kf_ids), np.int64)
+        out = np.zeros(max(len(kf), 1), np.float64)
+        check(self._L.orbx_kfdb_score(self._db, ptr(ids), ptr(vals), len(ids), ptr(kf) if len(kf) else None, len(kf), ptr(out)), self._ctx)
+        return out[:len(kf)].copy()

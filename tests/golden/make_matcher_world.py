@@ -23,4 +23,10 @@ with tempfile.TemporaryDirectory() as td:
         f.write(open(world, "rb").read())
     with gzip.GzipFile(os.path.join(HERE, "matcher_world_ref.txt.gz"), "wb", 9, mtime=0) as f:
         f.write(txt.encode())
+    # the same world through the REFERENCE'S OWN src/KeyFrameDatabase.cc (oracle/_ref/ref_kfdb_world); its vocabulary is the
+    # world's (world.bin.voc.txt, regenerated deterministically by tests/world_util.write_world)
+    ktxt = wu.run_kfdb_world(wu.REF_KFDB_EXE, world, os.path.join(td, "kfdb.txt"))
+    with gzip.GzipFile(os.path.join(HERE, "kfdb_world_ref.txt.gz"), "wb", 9, mtime=0) as f:
+        f.write(ktxt.encode())
+    print("kfdb world golden written:", sum(1 for l in ktxt.splitlines() if not l.startswith("  ")), "result records")
 print("matcher world golden written:", sum(1 for l in txt.splitlines() if not l.startswith("  ")), "result records")

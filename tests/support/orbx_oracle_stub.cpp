@@ -35,9 +35,19 @@ void mo_voc_free(void* h);
 void mo_voc_descend(void* h, const uint8_t* desc, int n, int levelsup, uint32_t* word, double* weight, uint32_t* node);
 int mo_voc_transform(void* h, const uint8_t* desc, int n, int levelsup, uint32_t* ids, double* vals, uint32_t* fv_node, uint32_t* fv_feat, int* n_fv);
 double mo_score_l1(const uint32_t* ida, const double* va, int na, const uint32_t* idb, const double* vb, int nb);
+void* mo_kfdb_new();
+void mo_kfdb_free(void* h);
+void mo_kfdb_add(void* h, long kf_id, const uint32_t* ids, const double* vals, int n);
+void mo_kfdb_erase(void* h, long kf_id);
+int mo_kfdb_query(void* h, const uint32_t* q_ids, const double* q_vals, int nq, const long* exclude, int n_exclude, int nMinWords, long* out_kf,
+                  int32_t* out_words, double* out_score, int* maxCommon, int* minCommon);
 }
 
+#include <map>
+#include <utility>
+
 struct orbx_ctx { void* ora = nullptr; int nfeatures = 0, nlevels = 0; };
+struct orbx_kfdb { void* h = nullptr; std::map<int64_t, std::pair<std::vector<uint32_t>, std::vector<double> > > rows; };
 struct orbx_voc { void* h = nullptr; std::vector<uint8_t> last_desc; int last_levelsup = 0; };
 
 extern "C" {
@@ -83,6 +93,37 @@ int orbx_bow_finalize(const orbx_voc* v, const uint32_t*, const double*, int n, 
   std::vector<uint32_t> fn(n + 1), ff(n + 1);
   int nfv = 0;
   *n_out = mo_voc_transform(v->h, v->last_desc.data(), n, v->last_levelsup, ids, vals, fn.data(), ff.data(), &nfv);
+  return ORBX_OK;
+}
+// ---- keyframe database (include/KeyFrameDatabase.h drop-in) over the oracle's inverted-file restatement
+int orbx_kfdb_create(orbx_ctx*, orbx_kfdb** out) { *out = new orbx_kfdb(); (*out)->h = mo_kfdb_new(); return ORBX_OK; }
+void orbx_kfdb_destroy(orbx_kfdb* db) { if (db) { mo_kfdb_free(db->h); delete db; } }
+int orbx_kfdb_size(const orbx_kfdb* db) { return (int)db->rows.size(); }
+int orbx_kfdb_add(orbx_kfdb* db, int64_t id, const uint32_t* ids, const double* vals, int n) {
+  if (db->rows.count(id)) return ORBX_E_INVALID;
+  db->rows[id] = std::make_pair(std::vector<uint32_t>(ids, ids + n), std::vector<double>(vals, vals + n));
+  mo_kfdb_add(db->h, (long)id, ids, vals, n);
+  return ORBX_OK;
+}
+int orbx_kfdb_erase(orbx_kfdb* db, int64_t id) { if (db->rows.erase(id)) mo_kfdb_erase(db->h, (long)id); return ORBX_OK; }
+int orbx_kfdb_clear(orbx_kfdb* db) { mo_kfdb_free(db->h); db->h = mo_kfdb_new(); db->rows.clear(); return ORBX_OK; }
+int orbx_kfdb_sharing(orbx_kfdb* db, const uint32_t* q_ids, int nq, int64_t* kf_ids, int32_t* common_words, int cap, int* n_sharing) {
+  std::vector<double> qv(nq + 1, 1.0), sc(db->rows.size() + 1);
+  std::vector<long> kf(db->rows.size() + 1);
+  std::vector<int32_t> w(db->rows.size() + 1);
+  int mx = 0, mn = 0;
+  const int n = mo_kfdb_query(db->h, q_ids, qv.data(), nq, nullptr, 0, 0, kf.data(), w.data(), sc.data(), &mx, &mn);
+  *n_sharing = n;
+  if (n > cap) return ORBX_E_CAPACITY;
+  for (int i = 0; i < n; i++) { kf_ids[i] = kf[i]; common_words[i] = w[i]; }
+  return ORBX_OK;
+}
+int orbx_kfdb_score(orbx_kfdb* db, const uint32_t* q_ids, const double* q_vals, int nq, const int64_t* kf_ids, int n, double* scores) {
+  for (int i = 0; i < n; i++) {
+    auto it = db->rows.find(kf_ids[i]);
+    if (it == db->rows.end()) return ORBX_E_INVALID;
+    scores[i] = mo_score_l1(q_ids, q_vals, nq, it->second.first.data(), it->second.second.data(), (int)it->second.first.size());
+  }
   return ORBX_OK;
 }
 double orbx_bow_score_l1(const uint32_t* ida, const double* va, int na, const uint32_t* idb, const double* vb, int nb) { return mo_score_l1(ida, va, na, idb, vb, nb); }

@@ -11,6 +11,7 @@
 #define FRAME_H
 #define KEYFRAME_H
 #define MAPPOINT_H
+#define MAP_H
 
 #include <algorithm>
 #include <cmath>
@@ -38,6 +39,15 @@ namespace ORB_SLAM3 {
 
 class KeyFrame;
 class Frame;
+
+// include/Map.h: what src/KeyFrameDatabase.cc asks of a map (:74-98 clearMap, :253, :714 IsBad)
+class Map {
+ public:
+  long unsigned int mnId = 0;
+  bool mbBad = false;
+  bool IsBad() { return mbBad; }
+  long unsigned int GetId() { return mnId; }
+};
 
 struct KeyFrameIdLess { bool operator()(const KeyFrame* a, const KeyFrame* b) const; };
 
@@ -95,7 +105,22 @@ class KeyFrame {
   std::vector<cv::KeyPoint> mvKeys, mvKeysUn, mvKeysRight;
   std::vector<float> mvuRight;
   cv::Mat mDescriptors;
+  DBoW2::BowVector mBowVec;
   DBoW2::FeatureVector mFeatVec;
+  // include/KeyFrame.h:335-346 — variables used by the keyframe database (the reference leaves them uninitialised until the first
+  // query; 0 here, and the scenario drivers only print fields a query has written or that start from this 0)
+  long unsigned int mnLoopQuery = 0;
+  int mnLoopWords = 0;
+  float mLoopScore = 0;
+  long unsigned int mnRelocQuery = 0;
+  int mnRelocWords = 0;
+  float mRelocScore = 0;
+  long unsigned int mnMergeQuery = 0;
+  int mnMergeWords = 0;
+  float mMergeScore = 0;
+  long unsigned int mnPlaceRecognitionQuery = 0;
+  int mnPlaceRecognitionWords = 0;
+  float mPlaceRecognitionScore = 0;
   int mnScaleLevels = 0;
   float mfScaleFactor = 0, mfLogScaleFactor = 0;
   std::vector<float> mvScaleFactors, mvLevelSigma2, mvInvLevelSigma2;
@@ -152,9 +177,26 @@ class KeyFrame {
     return vIndices;
   }
 
+  // covisibility graph and map as src/KeyFrameDatabase.cc reads them (src/KeyFrame.cc:228-251, :1140)
+  std::set<KeyFrame*> GetConnectedKeyFrames() {
+    std::set<KeyFrame*> s;
+    for (std::map<KeyFrame*, int>::iterator mit = mConnectedKeyFrameWeights.begin(); mit != mConnectedKeyFrameWeights.end(); mit++) s.insert(mit->first);
+    return s;
+  }
+  std::vector<KeyFrame*> GetBestCovisibilityKeyFrames(const int& N) {
+    if ((int)mvpOrderedConnectedKeyFrames.size() < N) return mvpOrderedConnectedKeyFrames;
+    return std::vector<KeyFrame*>(mvpOrderedConnectedKeyFrames.begin(), mvpOrderedConnectedKeyFrames.begin() + N);
+  }
+  Map* GetMap() { return mpMap; }
+  bool isBad() { return mbBad; }
+
   // test-side state
   Sophus::SE3f mTcw, mTrl;
   std::vector<MapPoint*> mvpMapPoints;
+  std::map<KeyFrame*, int> mConnectedKeyFrameWeights;
+  std::vector<KeyFrame*> mvpOrderedConnectedKeyFrames;
+  Map* mpMap = nullptr;
+  bool mbBad = false;
 };
 
 inline bool KeyFrameIdLess::operator()(const KeyFrame* a, const KeyFrame* b) const { return a->mnId < b->mnId; }

@@ -117,3 +117,37 @@ def test_kfdb_long_queries_are_served_from_hbm():
         a, b = db.query(q, [3, 17], 0), odb.query(q, [3, 17], 0)
         _same(a, b)
         assert (a["score"] >= 0).sum() > 0
+
+
+def test_kfdb_two_phase_entry_points_equal_oracle():
+    """orbx_kfdb_sharing / orbx_kfdb_score — the passes the drop-in KeyFrameDatabase class is made of: the full sharing list in the
+    inverted file's order (no exclusion) and the L1 score of an arbitrary selection, both against the oracle; interleaved with
+    erase / re-add (a re-added keyframe moves to the end of every list)."""
+    rng = np.random.default_rng(17)
+    ex = ORBextractor(1000, 1.2, 8, 20, 7)
+    db, odb = KeyFrameDatabase(ex), po.OracleKeyFrameDatabase()
+    bows = {}
+    for kid in range(5, 5 + 240):
+        bows[kid] = _bow(rng, int(rng.integers(0, 10)))
+        db.add(kid, bows[kid]); odb.add(kid, bows[kid])
+    for rnd in range(3):
+        for _ in range(6):
+            q = _bow(rng, int(rng.integers(0, 10)))
+            kf, words = db.sharing(q[0])
+            want = odb.query(q, [], 0)
+            assert np.array_equal(kf, want["kf"]) and np.array_equal(words, want["words"]) and len(kf) > 50
+            sel = [int(k) for k in kf[rng.permutation(len(kf))[:40]]]          # any selection, any order
+            got = db.score(q, sel)
+            ref = np.array([po.score_l1(q, bows[k]) for k in sel])
+            assert got.tobytes() == ref.tobytes()
+            assert db.score(q, []).size == 0
+        gone = [int(k) for k in rng.choice(sorted(bows), 25, replace=False)]
+        for k in gone:
+            db.erase(k); odb.erase(k)
+        back = gone[:10]
+        for k in back:
+            db.add(k, bows[k]); odb.add(k, bows[k])
+        for k in gone[10:]:
+            del bows[k]
+    with pytest.raises(Exception):
+        db.score(_bow(rng, 1), [10 ** 9])          # not in the database: refused, not scored as something else
