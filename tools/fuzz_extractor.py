@@ -22,8 +22,17 @@ for seed in range(first, first + count):
     nf = int(rng.choice([30, 150, 700, 1000, 2500, 6000]))
     ini = int(rng.choice([12, 20, 35])); mn = int(rng.choice([3, 7, ini]))
     lap = tuple(sorted(rng.integers(0, cols + 50, 2).tolist()))
-    kind = rng.choice(["synth", "noise", "smooth"])
-    if kind == "synth":
+    kind = rng.choice(["synth", "noise", "smooth", "natural"])
+    if kind == "natural":   # a window of one of the committed crops of the reference's own images (tests/golden/natural_crops.npz)
+        g = np.load(os.path.join(ROOT, "tests", "golden", "natural_crops.npz"))
+        big = g[str(rng.choice(["pineapple_1024x1024_img", "result_752x480_img", "teaser_752x480_img", "result_640x480_img"]))]
+        rows, cols = min(rows, big.shape[0]), min(cols, big.shape[1])
+        if rows < lo or cols < lo:
+            big = g["pineapple_1024x1024_img"]; rows, cols = min(max(rows, lo), 1024), min(max(cols, lo), 1024)
+        y0 = int(rng.integers(0, big.shape[0] - rows + 1)); x0 = int(rng.integers(0, big.shape[1] - cols + 1))
+        img = big[y0:y0 + rows, x0:x0 + cols]
+        lap = tuple(sorted(rng.integers(0, cols + 50, 2).tolist()))
+    elif kind == "synth":
         img = synth.make_stream(1, rows, cols, 4242 + seed)[0]
     elif kind == "noise":
         img = rng.integers(0, 256, (rows, cols)).astype(np.uint8)
