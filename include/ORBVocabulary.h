@@ -13,6 +13,10 @@
 #ifndef ORBVOCABULARY_H
 #define ORBVOCABULARY_H
 
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -198,20 +202,43 @@ class ORBVocabulary {
     fv.clear();
     const int n = (int)features.size();
     if (!voc_ || n == 0) return;
-    std::vector<uint8_t> desc((size_t)n * 32);
-    for (int i = 0; i < n; i++) std::memcpy(&desc[(size_t)i * 32], features[i].ptr<unsigned char>(), 32);
-    std::vector<uint32_t> word(n), node(n), ids(n);
-    std::vector<double> weight(n), vals(n);
+    static const bool trace = std::getenv("ORBX_TRACE_BOW") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto us = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); };
+    Scratch& s = scratch();
+    s.desc.resize((size_t)n * 32);
+    for (int i = 0; i < n; i++) std::memcpy(&s.desc[(size_t)i * 32], features[i].ptr<unsigned char>(), 32);
+    s.word.resize(n); s.node.resize(n); s.ids.resize(n); s.weight.resize(n); s.vals.resize(n);
+    const double t_pack = us();
     {  // Tracking, LocalMapping and LoopClosing all call transform on the one vocabulary: one caller at a time on its context
       std::lock_guard<std::mutex> lock(mu_);
-      if (orbx_bow_transform(voc_, desc.data(), n, levelsup, word.data(), weight.data(), node.data()) != ORBX_OK)
+      if (orbx_bow_transform(voc_, s.desc.data(), n, levelsup, s.word.data(), s.weight.data(), s.node.data()) != ORBX_OK)
         throw std::runtime_error(std::string("ORBVocabulary::transform: ") + orbx_last_error(ctx_));
     }
+    const double t_dev = us();
     int nnz = 0;
-    orbx_bow_finalize(voc_, word.data(), weight.data(), n, ids.data(), vals.data(), &nnz);
-    for (int k = 0; k < nnz; k++) v.insert(v.end(), DBoW2::BowVector::value_type(ids[k], vals[k]));
+    orbx_bow_finalize(voc_, s.word.data(), s.weight.data(), n, s.ids.data(), s.vals.data(), &nnz);
+    const double t_fin = us();
+    for (int k = 0; k < nnz; k++) v.insert(v.end(), DBoW2::BowVector::value_type(s.ids[k], s.vals[k]));   // ascending ids: O(1) hinted inserts
+    // FeatureVector: the reference appends feature i to node[i]'s list in feature order (TemplatedVocabulary.h:1166-1170); grouping the
+    // (node, i) pairs by a stable sort first gives every list in the same order with ONE hinted map insert per node instead of a
+    // tree lookup per feature
+    s.order.clear();
     for (int i = 0; i < n; i++)
-      if (weight[i] > 0) fv.addFeature(node[i], (unsigned)i);
+      if (s.weight[i] > 0) s.order.push_back(((uint64_t)s.node[i] << 32) | (uint32_t)i);
+    std::sort(s.order.begin(), s.order.end());   // keys are unique (i is part of the key): feature order inside a node is ascending i
+    for (size_t a = 0; a < s.order.size();) {
+      const uint32_t nid = (uint32_t)(s.order[a] >> 32);
+      size_t b = a;
+      while (b < s.order.size() && (uint32_t)(s.order[b] >> 32) == nid) b++;
+      DBoW2::FeatureVector::iterator it = fv.insert(fv.end(), DBoW2::FeatureVector::value_type(nid, std::vector<unsigned int>()));
+      it->second.reserve(b - a);
+      for (size_t k = a; k < b; k++) it->second.push_back((unsigned int)(uint32_t)s.order[k]);
+      a = b;
+    }
+    if (trace)
+      std::fprintf(stderr, "[orbx bow] n=%d nnz=%d: pack %.1f us, device call %.1f, finalize %.1f, maps %.1f\n", n, nnz, t_pack, t_dev - t_pack, t_fin - t_dev,
+                   us() - t_fin);
   }
 
   // score(a, b): L1Scoring::score, ScoringObject.cpp:23-68 (ORBvoc.txt is an L1-norm vocabulary)
@@ -227,6 +254,13 @@ class ORBVocabulary {
   orbx_ctx* Context() { return ctx_; }
 
  private:
+  struct Scratch {   // per calling thread: transform runs once per frame / keyframe, its buffers are reused
+    std::vector<uint8_t> desc;
+    std::vector<uint32_t> word, node, ids;
+    std::vector<double> weight, vals;
+    std::vector<uint64_t> order;
+  };
+  static Scratch& scratch() { static thread_local Scratch s; return s; }
   orbx_ctx* ctx_ = nullptr;
   mutable std::mutex mu_;
   orbx_voc* voc_ = nullptr;

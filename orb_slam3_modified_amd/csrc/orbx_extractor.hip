@@ -25,6 +25,7 @@ namespace orbx {
 constexpr int kQtLdsPoints = 2048;  // LDS-resident candidate capacity per (frame, level) of k_quadtree (big levels)
 static_assert(kQtLdsPoints <= 4096, "the chunk prefix of the quadtree full pass is one wave wide");
 constexpr int kQtBigLevels = 2;     // levels launched with the large quadtree workgroup configuration
+constexpr int kSmallBatchFrames = 512;   // a small batch is nframes * nlevels <= 512
 
 static int fast_threads_from_env() {
   const char* e = getenv("ORBX_FAST_THREADS");
@@ -439,8 +440,34 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
                          256 / (D.rs_lds_pitch / 4));
     }
   }
-  // K2: FAST cells of the remaining levels (or of all levels when level 0 is not forked)
+  // small batches (the single-frame graph): every launch costs about 5 us of device time whatever it does, so FAST and the blur —
+  // both only read the finished pyramid — share one launch, and the assembly runs as the tail of the quadtree launch
+  const bool small_fused = small_batch && ctx->small_fused && !ctx->profiling && ctx->fast_stop == 0;
+  BlurConsts bc;
   {
+    int gk[7];
+    gaussian_kernel7(gk);
+    auto b4 = [&](int a, int b, int c, int d) {   // weights of the four bytes of a dword; index -1 = no tap
+      auto w = [&](int i) { return i < 0 ? 0u : (uint32_t)gk[i]; };
+      return w(a) | (w(b) << 8) | (w(c) << 16) | (w(d) << 24);
+    };
+    bc.hw[0] = b4(-1, 0, 1, 2); bc.hw[1] = b4(3, 4, 5, 6);                              // output x: bytes x+1 .. x+7 of d0 d1 d2
+    bc.hw[2] = b4(-1, -1, 0, 1); bc.hw[3] = b4(2, 3, 4, 5); bc.hw[4] = b4(6, -1, -1, -1);
+    bc.hw[5] = b4(-1, -1, -1, 0); bc.hw[6] = b4(1, 2, 3, 4); bc.hw[7] = b4(5, 6, -1, -1);
+    bc.hw[8] = b4(0, 1, 2, 3); bc.hw[9] = b4(4, 5, 6, -1);
+    const uint32_t k0 = gk[0], k1 = gk[1], k2 = gk[2], k3 = gk[3], k4 = gk[4], k5 = gk[5], k6 = gk[6];
+    bc.we[0] = k0 | k1 << 16; bc.we[1] = k2 | k3 << 16; bc.we[2] = k4 | k5 << 16; bc.we[3] = k6;
+    bc.wo[0] = k0 << 16; bc.wo[1] = k1 | k2 << 16; bc.wo[2] = k3 | k4 << 16; bc.wo[3] = k5 | k6 << 16;
+  }
+  // K2: FAST cells of the remaining levels (or of all levels when level 0 is not forked)
+  if (small_fused) {
+    const FastLds f = fast_lds_of(0, ncells_all);
+    const int nfast = ncells_all * nframes, nblur = geo.btiles_total * nframes;
+    auto fk = pitchB == 64 ? (ctx->fast_pk ? k_fast_blur<64, true> : k_fast_blur<64, false>) : (ctx->fast_pk ? k_fast_blur<96, true> : k_fast_blur<96, false>);
+    hipLaunchKernelGGL(fk, dim3(nfast + nblur), dim3(256), f.bytes, st, ctx->d_geo, ctx->d_cells, d_imgs, (long long)row_stride, (long long)frame_stride,
+                       b_pyr, (long long)geo.pyr_bytes, b_cand, b_cell_cnt, ctx->ini_th, ctx->min_th, f.tile_rows, nfast, ncells_all,
+                       div_magic((uint32_t)ncells_all), 0, f.list_cap, f.nwords, b_blur, (long long)geo.blur_bytes, bc);
+  } else {
     ProfScope ps(ctx, 1, st);
     if (fork_fast0) launch_fast(ncells0, ncells_all - ncells0, st);
     else launch_fast(0, ncells_all, st);
@@ -456,22 +483,8 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
     ORBX_HIP(ctx, hipStreamWaitEvent(bst, ctx->ev_blur_fork[f0 != 0], 0));
     forks.forked(bst, ctx->ev_blur_join[f0 != 0]);
   }
-  {
+  if (!small_fused) {
     ProfScope ps(ctx, 4, bst);
-    int gk[7];
-    gaussian_kernel7(gk);
-    BlurConsts bc;
-    auto b4 = [&](int a, int b, int c, int d) {   // weights of the four bytes of a dword; index -1 = no tap
-      auto w = [&](int i) { return i < 0 ? 0u : (uint32_t)gk[i]; };
-      return w(a) | (w(b) << 8) | (w(c) << 16) | (w(d) << 24);
-    };
-    bc.hw[0] = b4(-1, 0, 1, 2); bc.hw[1] = b4(3, 4, 5, 6);                              // output x: bytes x+1 .. x+7 of d0 d1 d2
-    bc.hw[2] = b4(-1, -1, 0, 1); bc.hw[3] = b4(2, 3, 4, 5); bc.hw[4] = b4(6, -1, -1, -1);
-    bc.hw[5] = b4(-1, -1, -1, 0); bc.hw[6] = b4(1, 2, 3, 4); bc.hw[7] = b4(5, 6, -1, -1);
-    bc.hw[8] = b4(0, 1, 2, 3); bc.hw[9] = b4(4, 5, 6, -1);
-    const uint32_t k0 = gk[0], k1 = gk[1], k2 = gk[2], k3 = gk[3], k4 = gk[4], k5 = gk[5], k6 = gk[6];
-    bc.we[0] = k0 | k1 << 16; bc.we[1] = k2 | k3 << 16; bc.we[2] = k4 | k5 << 16; bc.we[3] = k6;
-    bc.wo[0] = k0 << 16; bc.wo[1] = k1 | k2 << 16; bc.wo[2] = k3 | k4 << 16; bc.wo[3] = k5 | k6 << 16;
     const int nitems = geo.btiles_total * nframes;
     hipLaunchKernelGGL(k_blur7, dim3(xcd_grid(nitems)), dim3(256), 0, bst, ctx->d_geo, d_imgs, (long long)row_stride,
                        (long long)frame_stride, b_pyr, (long long)geo.pyr_bytes, b_blur, (long long)geo.blur_bytes, bc,
@@ -479,6 +492,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
   }
   if (fork_blur) ORBX_HIP(ctx, hipEventRecord(ctx->ev_blur_join[f0 != 0], bst));
   // K3: quadtree
+  bool assembled = false;
   if (fork_fast0) { ORBX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_f0_join[sb], 0)); forks.joined(ctx->aux[orbx_ctx::kMaxAux - 3 - sb]); }
   {
     ProfScope ps(ctx, 2, st);
@@ -521,7 +535,24 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
     const int qt_pts = kQtLdsPoints;   // measured: 1024 ... 2048 points make no difference to the launch (128 VGPRs hold it at four workgroups per CU)
     const int nbig = (geo.nlevels >= 4 && !small_batch) ? kQtBigLevels : geo.nlevels;  // small batch: one launch, all levels
     int qrc = ORBX_OK;
-    if (nbig < geo.nlevels && !ctx->profiling && ctx->fork_qt) {
+    if (small_fused && ctx->d_qt_fin && !ctx->d_asm_scan && nframes <= kSmallBatchFrames) {
+      // all levels in one launch with the assembly as its tail (k_quadtree_assemble), when everything is LDS-resident
+      int mq = 1, mc = 1, mp = 1;
+      for (int l = 0; l < geo.nlevels; l++) { mq = std::max(mq, geo.lv[l].quota); mc = std::max(mc, geo.lv[l].ncells); mp = std::max(mp, geo.lv[l].cand_cap); }
+      int node_cap, scan_cap;
+      qt_caps(mq, mc, mp, node_cap, scan_cap);
+      const size_t lds = std::max(qt_node_bytes(node_cap, scan_cap) + qt_point_bytes(qt_pts), (size_t)ctx->out_cap * 8 + 64);
+      if (lds <= kLdsMax && (lds <= 64 * 1024 || ensure_dynamic_lds((const void*)k_quadtree_assemble, (int)lds) == hipSuccess)) {
+        QtaArgs qa;
+        qa.g = ctx->d_geo; qa.cells = ctx->d_cells; qa.cand = b_cand; qa.cell_cnt = b_cell_cnt; qa.pts = b_pts; qa.lvl_kp = b_lvl_kp; qa.lvl_n = b_lvl_n;
+        qa.node_cap = node_cap; qa.scan_cap = scan_cap; qa.pts_cap = qt_pts;
+        qa.kp_list = b_kp_list; qa.counts = d_counts; qa.lap0 = lap0; qa.lap1 = lap1; qa.fin = ctx->d_qt_fin;
+        hipLaunchKernelGGL(k_quadtree_assemble, dim3(geo.nlevels, nframes, 1), dim3(ctx->qt_threads ? ctx->qt_threads : 512), lds, st, qa);
+        assembled = true;
+      }
+    }
+    if (assembled) {
+    } else if (nbig < geo.nlevels && !ctx->profiling && ctx->fork_qt) {
       hipStream_t qst = ctx->aux[orbx_ctx::kMaxAux - 5 - sb];
       ORBX_HIP(ctx, hipEventRecord(ctx->ev_qt_fork[sb], st));
       ORBX_HIP(ctx, hipStreamWaitEvent(qst, ctx->ev_qt_fork[sb], 0));
@@ -540,7 +571,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
     }
   }
   // K3b: output slots
-  {
+  if (!assembled) {
     ProfScope ps(ctx, 3, st);
     const bool gs = ctx->d_asm_scan != nullptr;
     hipLaunchKernelGGL(k_assemble, dim3(nframes), dim3(256), gs ? 0 : (size_t)ctx->out_cap * 8 + 64, st, ctx->d_geo, b_lvl_kp,
@@ -617,6 +648,7 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, 
     }
   }
   ctx->fast_threads = fast_threads_from_env();
+  { const char* e = getenv("ORBX_SMALL_FUSED"); ctx->small_fused = e ? atoi(e) != 0 : true; }
   { const char* e = getenv("ORBX_FAST_SPLIT"); ctx->fast_split = e ? atoi(e) != 0 : true; }
   { const char* e = getenv("ORBX_WINDOW_DIRECT"); ctx->window_direct = e ? atoi(e) != 0 : true; }
   { const char* e = getenv("ORBX_QT_THREADS"); const int v = e ? atoi(e) : 0; ctx->qt_threads = (v == 64 || v == 128 || v == 256 || v == 512) ? v : 0; }
@@ -630,6 +662,12 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, 
   if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
     delete ctx;
     return ORBX_E_DEVICE;
+  }
+  if (hipMalloc((void**)&ctx->d_qt_fin, kSmallBatchFrames * sizeof(int32_t)) != hipSuccess ||
+      hipMemset(ctx->d_qt_fin, 0, kSmallBatchFrames * sizeof(int32_t)) != hipSuccess) {
+    (void)hipGetLastError();
+    if (ctx->d_qt_fin) (void)hipFree(ctx->d_qt_fin);
+    ctx->d_qt_fin = nullptr;   // the separate launches serve instead
   }
   {
     const char* e = getenv("ORBX_STREAMS");  // concurrent sub-batches of the batch entry point (1..orbx_ctx::kMaxAux)
@@ -678,6 +716,7 @@ void orbx_destroy(orbx_ctx* ctx) {
   if (ctx->h_in) { (void)hipHostFree(ctx->h_in); ctx->h_in = nullptr; }
   if (ctx->h_call) { (void)hipHostFree(ctx->h_call); ctx->h_call = nullptr; }
   if (ctx->d_win_ctr) { (void)hipFree(ctx->d_win_ctr); ctx->d_win_ctr = nullptr; }
+  if (ctx->d_qt_fin) { (void)hipFree(ctx->d_qt_fin); ctx->d_qt_fin = nullptr; }
   if (ctx->h_tgt) { (void)hipHostFree(ctx->h_tgt); ctx->h_tgt = nullptr; }
   if (ctx->ev_tgt) { (void)hipEventDestroy(ctx->ev_tgt); ctx->ev_tgt = nullptr; }
   if (ctx->d_color) { (void)hipFree(ctx->d_color); ctx->d_color = nullptr; }
@@ -824,10 +863,9 @@ static int extract_one_graph(orbx_ctx* ctx, const uint8_t* img, int rows, int co
       ok = hipMemcpy2DAsync(ctx->d_stage_img, pitch, ctx->h_in, (size_t)cols, (size_t)cols, (size_t)rows, hipMemcpyHostToDevice, st) == hipSuccess;
       if (ok) ok = launch_pipeline(ctx, ctx->d_stage_img, 0, 1, rows, cols, pitch, fbytes, lap0, lap1, (orbx_keypoint*)(d + L.kps_off),
                                    d + L.desc_off, (int32_t*)(d + L.counts_off), st) == ORBX_OK;
-      const size_t kb = (size_t)ctx->out_cap * sizeof(orbx_keypoint), db = (size_t)ctx->out_cap * 32, cb = 2 * sizeof(int32_t);
-      if (ok) ok = hipMemcpyAsync(ctx->h_stage_out + L.kps_off, d + L.kps_off, kb, hipMemcpyDeviceToHost, st) == hipSuccess;
-      if (ok) ok = hipMemcpyAsync(ctx->h_stage_out + L.desc_off, d + L.desc_off, db, hipMemcpyDeviceToHost, st) == hipSuccess;
-      if (ok) ok = hipMemcpyAsync(ctx->h_stage_out + L.counts_off, d + L.counts_off, cb, hipMemcpyDeviceToHost, st) == hipSuccess;
+      // keypoints | descriptors | counts are one staging block with the same layout on both sides: ONE copy node (every node of
+      // the graph costs about 5 us of device time, whatever it moves: three copies were 15 us of a 140 us frame)
+      if (ok) ok = hipMemcpyAsync(ctx->h_stage_out, d, L.bytes, hipMemcpyDeviceToHost, st) == hipSuccess;
       if (ok && keep && ctx->geo.pyr_bytes > 0)
         ok = hipMemcpyAsync(ctx->h_pyr, ctx->d_pyr, (size_t)ctx->geo.pyr_bytes, hipMemcpyDeviceToHost, st) == hipSuccess;
       const hipError_t ee = hipStreamEndCapture(st, &graph);   // always leave capture mode
@@ -1085,6 +1123,7 @@ int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
   else if (n == "fork_qt") ctx->fork_qt = value != 0;
   else if (n == "graph") ctx->use_graph = value != 0;
   else if (n == "fast_pk") ctx->fast_pk = value != 0;
+  else if (n == "small_fused") ctx->small_fused = value != 0;
   else if (n == "window_direct") ctx->window_direct = value != 0;
   else if (n == "fast_split") ctx->fast_split = value != 0;   // FAST launched per group of levels with its own LDS size (batch calls)
   else if (n == "fast_stop") ctx->fast_stop = value;   // timing experiment: FAST returns after staging (1) / after the necessary test (2); results are void
@@ -1094,6 +1133,7 @@ int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
   else if (n == "desc_k" && (value == 1 || value == 2 || value == 4 || value == 8 || value == 16)) ctx->desc_k = value;
   else if (n == "streams" && value >= 1 && value <= 2) ctx->nstreams = value;
   else return set_err(ctx, ORBX_E_INVALID, "orbx_set_option: unknown option or value out of range: " + n);
+  ctx->buf_epoch++;   // a captured single-frame graph holds the launch shape of the old options: capture again
   return ORBX_OK;
 }
 

@@ -69,16 +69,14 @@ __device__ __forceinline__ int xcd_logical_block(int n_items) {
 // ------------------------------------------------------------------------------------------------
 constexpr int kRT_W = 64, kRT_H = 64, kRT_RPT = 4;  // output tile of k_resize; rows per thread
 
-__global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src, long long src_frame_stride,
-                                                int src_pitch, int sw, uint8_t* __restrict__ dst,
-                                                long long dst_frame_stride, int dst_pitch, int dw, int dh,
-                                                const XTab* __restrict__ xt, const XTab* __restrict__ yt, int nbx,
-                                                int nby, int nitems, int lds_pitch, int lds_rows, uint32_t m_tiles,
-                                                uint32_t m_nbx, uint32_t m_lp4, int nph) {
-  extern __shared__ __align__(16) uint8_t smem[];
+// one 64x64 output tile (logical item L of the launch: frame-major, then tile rows); 256 threads; `smem` = the workgroup's dynamic LDS
+__device__ __forceinline__ void resize_tile(uint8_t* smem, const int L, const uint8_t* __restrict__ src, long long src_frame_stride,
+                                            int src_pitch, int sw, uint8_t* __restrict__ dst,
+                                            long long dst_frame_stride, int dst_pitch, int dw, int dh,
+                                            const XTab* __restrict__ xt, const XTab* __restrict__ yt, int nbx,
+                                            int nby, int lds_pitch, int lds_rows, uint32_t m_tiles,
+                                            uint32_t m_nbx, uint32_t m_lp4, int nph) {
   const int t = threadIdx.x;
-  const int L = xcd_logical_block(nitems);
-  if (L < 0) return;  // block-uniform
   const int frame = fast_div(L, m_tiles), rem = L - frame * (nbx * nby);
   const int by = fast_div(rem, m_nbx), bx = rem - by * nbx;
   const int x0 = bx * kRT_W, y0 = by * kRT_H;
@@ -144,6 +142,19 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
       *(uint32_t*)(outp + (uint32_t)(__mul24(dy, dst_pitch) + x4)) = packed;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src, long long src_frame_stride,
+                                                int src_pitch, int sw, uint8_t* __restrict__ dst,
+                                                long long dst_frame_stride, int dst_pitch, int dw, int dh,
+                                                const XTab* __restrict__ xt, const XTab* __restrict__ yt, int nbx,
+                                                int nby, int nitems, int lds_pitch, int lds_rows, uint32_t m_tiles,
+                                                uint32_t m_nbx, uint32_t m_lp4, int nph) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  const int L = xcd_logical_block(nitems);
+  if (L < 0) return;  // block-uniform
+  resize_tile(smem, L, src, src_frame_stride, src_pitch, sw, dst, dst_frame_stride, dst_pitch, dw, dh, xt, yt, nbx, nby, lds_pitch, lds_rows,
+                     m_tiles, m_nbx, m_lp4, nph);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -234,19 +245,19 @@ __device__ __forceinline__ uint32_t fast_pretest_pk_lo(uint32_t c, uint32_t p0, 
   return as_u32(__builtin_elementwise_sub_sat(lo, maxmin)) | as_u32(__builtin_elementwise_sub_sat(minmax, hi));
 }
 
-template <int T, int PITCH, bool PK = false>
-__global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
-                                                  const uint8_t* __restrict__ imgs, long long img_row_stride,
-                                                  long long img_frame_stride, const uint8_t* __restrict__ pyr,
-                                                  long long pyr_frame_bytes, uint32_t* __restrict__ cand,
-                                                  int32_t* __restrict__ cell_cnt, int ini_th, int min_th, int tile_rows,
-                                                  int nitems, int cell_base, int ncells_sub, uint32_t m_ncells_sub, int stop_after,
-                                                  int list_cap, int nwords) {
+// one cell (logical item L of a launch over cells [cell_base, cell_base + ncells_sub) of every frame); T threads
+template <int T, int PITCH, bool PK>
+__device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
+                                          const uint8_t* __restrict__ imgs, long long img_row_stride,
+                                          long long img_frame_stride, const uint8_t* __restrict__ pyr,
+                                          long long pyr_frame_bytes, uint32_t* __restrict__ cand,
+                                          int32_t* __restrict__ cell_cnt, int ini_th, int min_th, int tile_rows,
+                                          int cell_base, int ncells_sub, uint32_t m_ncells_sub, int stop_after,
+                                          int list_cap, int nwords) {
   // LDS: [16 B pad][tile_rows][PITCH] raw pixels (+ alignment shift xo) | [tile_rows][PITCH] scores with a 1-px
   // zero frame | list | bitmap | word prefix.  PITCH is a compile-time constant so every circle / neighbour access is an
   // immediate offset.  Everything is sized by the launch for the cells it covers (tile_rows, list_cap, nwords = 64 or 256): the
   // LDS footprint of a workgroup decides how many of them a CU holds, and this kernel lives on residency.
-  extern __shared__ __align__(16) uint8_t smem[];
   uint8_t* tile = smem + 16;
   uint8_t* sc = tile + tile_rows * PITCH;
   uint16_t* list = (uint16_t*)(sc + tile_rows * PITCH);  // candidate pixels (bit 15: NMS survivor)
@@ -257,8 +268,6 @@ __global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__
   __shared__ int s_cnt;
 
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const int L = xcd_logical_block(nitems);
-  if (L < 0) return;  // block-uniform
   // this launch covers cells [cell_base, cell_base + ncells_sub) of every frame (level 0 runs as its own launch,
   // concurrently with the pyramid chain)
   const int frame = fast_div(L, m_ncells_sub), cell = cell_base + (L - frame * ncells_sub);
@@ -455,6 +464,21 @@ __global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__
       }
     }
   }
+}
+
+template <int T, int PITCH, bool PK = false>
+__global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
+                                                  const uint8_t* __restrict__ imgs, long long img_row_stride,
+                                                  long long img_frame_stride, const uint8_t* __restrict__ pyr,
+                                                  long long pyr_frame_bytes, uint32_t* __restrict__ cand,
+                                                  int32_t* __restrict__ cell_cnt, int ini_th, int min_th, int tile_rows,
+                                                  int nitems, int cell_base, int ncells_sub, uint32_t m_ncells_sub, int stop_after,
+                                                  int list_cap, int nwords) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  const int L = xcd_logical_block(nitems);
+  if (L < 0) return;  // block-uniform
+  fast_cell<T, PITCH, PK>(smem, L, g, cells, imgs, img_row_stride, img_frame_stride, pyr, pyr_frame_bytes, cand, cell_cnt, ini_th, min_th, tile_rows,
+                          cell_base, ncells_sub, m_ncells_sub, stop_after, list_cap, nwords);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1571,8 +1595,8 @@ template <bool GS>
 __device__ __forceinline__ void assemble_main(const DeviceGeom* __restrict__ g, const uint32_t* __restrict__ lvl_kp,
                                               const int32_t* __restrict__ lvl_n, uint2* __restrict__ kp_list,
                                               int32_t* __restrict__ counts, int lap0, int lap1, unsigned long long* scan,
-                                              unsigned long long* wt, int* loff, int* s_overflow) {
-  const int t = threadIdx.x, T = blockDim.x, frame = blockIdx.x;
+                                              unsigned long long* wt, int* loff, int* s_overflow, const int frame) {
+  const int t = threadIdx.x, T = blockDim.x;
   if (t == 0) {
     int acc = 0, ovf = 0;
     for (int l = 0; l < g->nlevels; l++) {
@@ -1620,8 +1644,48 @@ __global__ __launch_bounds__(256) void k_assemble(const DeviceGeom* __restrict__
   __shared__ unsigned long long wt[8];
   __shared__ int loff[kMaxLevels + 1];
   __shared__ int s_overflow;
-  if (gscan == nullptr) assemble_main<false>(g, lvl_kp, lvl_n, kp_list, counts, lap0, lap1, (unsigned long long*)smem, wt, loff, &s_overflow);
-  else assemble_main<true>(g, lvl_kp, lvl_n, kp_list, counts, lap0, lap1, gscan + (long long)blockIdx.x * g->out_cap, wt, loff, &s_overflow);
+  if (gscan == nullptr) assemble_main<false>(g, lvl_kp, lvl_n, kp_list, counts, lap0, lap1, (unsigned long long*)smem, wt, loff, &s_overflow, (int)blockIdx.x);
+  else assemble_main<true>(g, lvl_kp, lvl_n, kp_list, counts, lap0, lap1, gscan + (long long)blockIdx.x * g->out_cap, wt, loff, &s_overflow, (int)blockIdx.x);
+}
+
+// k_quadtree of ALL levels of a small batch with k_assemble as its tail: the last level-workgroup of a frame to finish (a counter per
+// frame, zero between launches) assembles the frame.  One launch less in the single-frame graph, where every launch costs about 5 us
+// whatever it does.  The other workgroups' keypoint lists reach the assembling one through an agent-scope release / acquire pair —
+// once per workgroup (eight per frame), which is affordable.  LDS-resident node arrays only (the host takes the separate launches
+// otherwise); `smem` is free again when quadtree_main returns and holds the scan array of the assembly.
+struct QtaArgs {
+  const DeviceGeom* g; const CellGeom* cells; const uint32_t* cand; const int32_t* cell_cnt; uint32_t* pts; uint32_t* lvl_kp; int32_t* lvl_n;
+  int node_cap, scan_cap, pts_cap;
+  // the tail's own arguments: read from the kernel-argument segment AFTER the quadtree (see below)
+  uint2* kp_list; int32_t* counts; int lap0, lap1; int* fin;
+};
+__global__ __launch_bounds__(512, ORBX_QT_WPE) void k_quadtree_assemble(const QtaArgs a) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  __shared__ unsigned long long wt[16];
+  __shared__ int sh_cnt[kMaxRoots];
+  __shared__ int sh_jstar;
+  __shared__ int loff[kMaxLevels + 1];
+  __shared__ int s_overflow, s_last;
+  uint32_t* lpts = (uint32_t*)(smem + (size_t)a.node_cap * (2 * sizeof(QNode) + 2 * 8 + sizeof(int4) + 4) + (size_t)a.scan_cap * 8);
+  quadtree_main<false>(a.g, a.cells, a.cand, a.cell_cnt, a.pts, a.lvl_kp, a.lvl_n, a.node_cap, a.scan_cap, a.pts_cap, 0, smem, lpts, wt, sh_cnt, &sh_jstar);
+  // The quadtree runs at the edge of the scalar register file: arguments that stay live across it for the tail's sake spill (36
+  // bytes of private segment, and a kernel with a private segment pays a scratch set-up on every queue that first runs it).  The
+  // tail therefore reads its arguments from the kernel-argument segment through a pointer the compiler cannot see through.
+  const QtaArgs* ap = (const QtaArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(ap));
+  const int frame = (int)blockIdx.y;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave's list entries have left before the workgroup reports
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int* fin = ap->fin;
+    const int done = __hip_atomic_fetch_add(fin + frame, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = done == (int)gridDim.x - 1;
+    if (s_last) __hip_atomic_store(fin + frame, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+  }
+  __syncthreads();
+  if (!s_last) return;   // block-uniform
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  assemble_main<false>(ap->g, ap->lvl_kp, ap->lvl_n, ap->kp_list, ap->counts, ap->lap0, ap->lap1, (unsigned long long*)smem, wt, loff, &s_overflow, frame);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1672,15 +1736,14 @@ __device__ __forceinline__ void hrow4(const uint32_t* rw, const BlurConsts& bc, 
   a[3] = __builtin_amdgcn_udot4(d1, bc.hw[8], __builtin_amdgcn_udot4(d2, bc.hw[9], 0u, false), false);
 }
 
-__global__ __launch_bounds__(256) void k_blur7(const DeviceGeom* __restrict__ g, const uint8_t* __restrict__ imgs,
-                                               long long img_row_stride, long long img_frame_stride,
-                                               const uint8_t* __restrict__ pyr, long long pyr_frame_bytes,
-                                               uint8_t* __restrict__ blur, long long blur_frame_bytes, BlurConsts bc, int nitems) {
+// one blur tile (logical item L: frame-major, then the tiles of all levels); 256 threads
+__device__ __forceinline__ void blur_tile(const int L, const DeviceGeom* __restrict__ g, const uint8_t* __restrict__ imgs,
+                                          long long img_row_stride, long long img_frame_stride,
+                                          const uint8_t* __restrict__ pyr, long long pyr_frame_bytes,
+                                          uint8_t* __restrict__ blur, long long blur_frame_bytes, const BlurConsts& bc) {
   __shared__ __align__(16) uint8_t raw[kBT_RR * kBT_RP];
   __shared__ __align__(16) uint32_t hp[(kBT_RR / 2) * kBT_W];
   const int t = threadIdx.x;
-  const int L = xcd_logical_block(nitems);
-  if (L < 0) return;  // block-uniform
   const int frame = fast_div(L, g->m_btiles), bt = L - frame * g->btiles_total;
   int l = 0;
 #pragma unroll
@@ -1795,6 +1858,34 @@ __global__ __launch_bounds__(256) void k_blur7(const DeviceGeom* __restrict__ g,
     *(uint32_t*)(bl + o0) = pe;
     if (y + 1 < h) *(uint32_t*)(bl + o0 + (uint32_t)lv.pitch) = po;
   }
+}
+
+__global__ __launch_bounds__(256) void k_blur7(const DeviceGeom* __restrict__ g, const uint8_t* __restrict__ imgs,
+                                               long long img_row_stride, long long img_frame_stride,
+                                               const uint8_t* __restrict__ pyr, long long pyr_frame_bytes,
+                                               uint8_t* __restrict__ blur, long long blur_frame_bytes, BlurConsts bc, int nitems) {
+  const int L = xcd_logical_block(nitems);
+  if (L < 0) return;  // block-uniform
+  blur_tile(L, g, imgs, img_row_stride, img_frame_stride, pyr, pyr_frame_bytes, blur, blur_frame_bytes, bc);
+}
+
+// FAST cells and blur tiles of a SMALL batch (the single-frame operator() path) in one launch: both only read the finished pyramid,
+// and inside the replayed graph every launch costs about 5 us of device time whatever it does.  Blocks [0, nfast) are cells (256
+// threads each), the rest blur tiles; results are those of the two separate launches (the same bodies on the same items).
+template <int PITCH, bool PK>
+__global__ __launch_bounds__(256) void k_fast_blur(const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
+                                                   const uint8_t* __restrict__ imgs, long long img_row_stride, long long img_frame_stride,
+                                                   const uint8_t* __restrict__ pyr, long long pyr_frame_bytes, uint32_t* __restrict__ cand,
+                                                   int32_t* __restrict__ cell_cnt, int ini_th, int min_th, int tile_rows, int nfast, int ncells,
+                                                   uint32_t m_ncells, int stop_after, int list_cap, int nwords, uint8_t* __restrict__ blur,
+                                                   long long blur_frame_bytes, BlurConsts bc) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  const int b = (int)blockIdx.x;
+  if (b < nfast)   // block-uniform
+    fast_cell<256, PITCH, PK>(smem, b, g, cells, imgs, img_row_stride, img_frame_stride, pyr, pyr_frame_bytes, cand, cell_cnt, ini_th, min_th, tile_rows, 0,
+                              ncells, m_ncells, stop_after, list_cap, nwords);
+  else
+    blur_tile(b - nfast, g, imgs, img_row_stride, img_frame_stride, pyr, pyr_frame_bytes, blur, blur_frame_bytes, bc);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -230,14 +230,9 @@ __global__ __launch_bounds__(256) void k_knn2_merge(const unsigned long long* __
 struct DevNode { int32_t child_begin, nchild, word_id, pad; double weight; };
 
 // wave per feature: lanes < nchild evaluate one child each; first minimum wins (TemplatedVocabulary.h:1238-1249)
-__global__ __launch_bounds__(256) void k_bow_descend(const DevNode* __restrict__ nodes, const uint8_t* __restrict__ slot_desc,
-                                                     const int32_t* __restrict__ slot_node, const uint8_t* __restrict__ desc,
-                                                     int n, int L, int levelsup, uint32_t* __restrict__ word,
-                                                     double* __restrict__ weight, uint32_t* __restrict__ node_out) {
-  const int lane = threadIdx.x & 63;
-  const int fi = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (fi >= n) return;
-  const Desc df = load_desc(desc + (size_t)fi * 32);
+struct BowLeaf { int word_id; uint32_t nid; double weight; };
+__device__ __forceinline__ BowLeaf bow_descend_wave(const DevNode* __restrict__ nodes, const uint8_t* __restrict__ slot_desc,
+                                                    const int32_t* __restrict__ slot_node, const Desc df, int L, int levelsup, int lane) {
   const int nid_level = L - levelsup;
   uint32_t nid = 0;
   int final_id = 0, level = 0;
@@ -256,10 +251,51 @@ __global__ __launch_bounds__(256) void k_bow_descend(const DevNode* __restrict__
     if (level == nid_level) nid = (uint32_t)final_id;
     nd = nodes[final_id];
   }
+  return BowLeaf{nd.word_id, nid, nd.weight};
+}
+
+__global__ __launch_bounds__(256) void k_bow_descend(const DevNode* __restrict__ nodes, const uint8_t* __restrict__ slot_desc,
+                                                     const int32_t* __restrict__ slot_node, const uint8_t* __restrict__ desc,
+                                                     int n, int L, int levelsup, uint32_t* __restrict__ word,
+                                                     double* __restrict__ weight, uint32_t* __restrict__ node_out) {
+  const int lane = threadIdx.x & 63;
+  const int fi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (fi >= n) return;
+  const BowLeaf lf = bow_descend_wave(nodes, slot_desc, slot_node, load_desc(desc + (size_t)fi * 32), L, levelsup, lane);
   if (lane == 0) {
-    word[fi] = (uint32_t)nd.word_id;
-    weight[fi] = nd.weight;
-    node_out[fi] = nid;
+    word[fi] = (uint32_t)lf.word_id;
+    weight[fi] = lf.weight;
+    node_out[fi] = lf.nid;
+  }
+}
+
+// The host-buffer form (orbx_bow_transform): descriptors read from, and {word, node, weight} records written to, the call's mapped
+// pinned blob; the last workgroup raises the done word the host polls (publication protocol of k_nn_csr above).  One launch, no copy
+// operation, no stream synchronisation: what is left of a call is the launch and the PCIe round trip.
+struct BowRecord { uint32_t word, node; double weight; };
+__global__ __launch_bounds__(256) void k_bow_descend_direct(const DevNode* __restrict__ nodes, const uint8_t* __restrict__ slot_desc,
+                                                            const int32_t* __restrict__ slot_node, const uint8_t* __restrict__ desc_host, int n,
+                                                            int L, int levelsup, BowRecord* __restrict__ rec_host, unsigned* __restrict__ ctr,
+                                                            unsigned long long* __restrict__ done_host) {
+  const int lane = threadIdx.x & 63;
+  const int fi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  __shared__ int wg_done;
+  if (threadIdx.x == 0) wg_done = 0;
+  __syncthreads();
+  if (fi >= n) return;
+  const BowLeaf lf = bow_descend_wave(nodes, slot_desc, slot_node, load_desc(desc_host + (size_t)fi * 32), L, levelsup, lane);
+  if (lane == 0) rec_host[fi] = BowRecord{(uint32_t)lf.word_id, lf.nid, lf.weight};
+  const int nactive = min(4, n - (int)blockIdx.x * 4);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's record has left before the wave counts itself
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0 && atomicAdd(&wg_done, 1) == nactive - 1) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __threadfence_system();
+    if (atomicInc(ctr, gridDim.x - 1) == gridDim.x - 1) {
+      __threadfence();
+      __atomic_store_n(done_host, 1ull, __ATOMIC_RELEASE);
+      __threadfence_system();
+    }
   }
 }
 
@@ -686,16 +722,64 @@ int orbx_bow_transform(orbx_voc* v, const uint8_t* desc, int n, int levelsup, ui
   if (!v || n < 0 || (n > 0 && (!desc || !word || !weight || !node))) return ORBX_E_INVALID;
   if (n == 0) return ORBX_OK;
   orbx_ctx* ctx = v->ctx;
+  if (v->parent.size() <= 1) return set_err(ctx, ORBX_E_INVALID, "empty vocabulary");
   ORBX_HIP(ctx, hipSetDevice(ctx->device));
-  DevBuf<uint8_t> dd; DevBuf<uint32_t> dw, dn; DevBuf<double> dwt;
-  ORBX_HIP(ctx, dd.alloc((size_t)n * 32)); ORBX_HIP(ctx, dw.alloc(n)); ORBX_HIP(ctx, dn.alloc(n)); ORBX_HIP(ctx, dwt.alloc(n));
-  ORBX_HIP(ctx, copy_sync(ctx, dd.p, desc, (size_t)n * 32, hipMemcpyHostToDevice));
-  int rc = orbx_bow_transform_device(v, dd.p, n, levelsup, dw.p, dwt.p, dn.p, ctx->stream);
+  hipStream_t st = ctx->stream;
+  // one pinned, mapped blob per call: [descriptors | records | done word]
+  BlobLayout lay;
+  const size_t o_d = lay.add((size_t)n * 32), o_r = lay.add(sizeof(BowRecord) * (size_t)n), o_done = lay.add(16);
+  uint8_t* h = nullptr;
+  ORBX_HIP(ctx, host_stage(ctx, lay.size, &h));
+  std::memcpy(h + o_d, desc, (size_t)n * 32);
+  uint8_t* hdev = nullptr;
+  const bool direct = ctx->window_direct && hipHostGetDevicePointer((void**)&hdev, h, 0) == hipSuccess && hdev != nullptr;
+  if (!direct) (void)hipGetLastError();
+  const BowRecord* rec = (const BowRecord*)(h + o_r);
+  if (direct) {
+    if (!ctx->d_win_ctr) { ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_win_ctr, 64)); ctx->win_ctr_dirty = true; }
+    if (ctx->win_ctr_dirty) { ORBX_HIP(ctx, hipMemsetAsync(ctx->d_win_ctr, 0, 64, st)); ctx->win_ctr_dirty = false; }
+    volatile unsigned long long* done = (volatile unsigned long long*)(h + o_done);
+    __atomic_store_n(done, 0ull, __ATOMIC_RELEASE);
+    ctx->win_ctr_dirty = true;
+    hipLaunchKernelGGL(k_bow_descend_direct, dim3((n + 3) / 4), dim3(256), 0, st, v->d_nodes, v->d_slot_desc, v->d_slot_node, hdev + o_d, n, v->L,
+                       levelsup, (BowRecord*)(hdev + o_r), (unsigned*)ctx->d_win_ctr + 9, (unsigned long long*)(hdev + o_done));
+    ORBX_HIP(ctx, hipGetLastError());
+    for (unsigned spin = 1;; spin++) {
+      if (__atomic_load_n(done, __ATOMIC_ACQUIRE)) break;
+      if ((spin & 0x3fff) == 0) {
+        const hipError_t qe = hipStreamQuery(st);
+        if (qe == hipSuccess) {
+          if (__atomic_load_n(done, __ATOMIC_ACQUIRE)) break;
+          return set_err(ctx, ORBX_E_DEVICE, "orbx_bow_transform: the pass finished without publishing its results");
+        }
+        if (qe != hipErrorNotReady) { ORBX_HIP(ctx, qe); }
+      }
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+    ctx->win_ctr_dirty = false;
+    for (int i = 0; i < n; i++) { word[i] = rec[i].word; node[i] = rec[i].node; weight[i] = rec[i].weight; }
+    return ORBX_OK;
+  }
+  // copies + stream synchronisation ("window_direct" = 0, or no mapped host memory): same results
+  ctx->arena.rewind();
+  hipError_t aerr = hipSuccess;
+  uint8_t* dd = (uint8_t*)ctx->arena.alloc((size_t)n * 32, &aerr);
+  ORBX_HIP(ctx, aerr);
+  uint32_t* dw = (uint32_t*)ctx->arena.alloc(4 * (size_t)n, &aerr);
+  ORBX_HIP(ctx, aerr);
+  uint32_t* dn = (uint32_t*)ctx->arena.alloc(4 * (size_t)n, &aerr);
+  ORBX_HIP(ctx, aerr);
+  double* dwt = (double*)ctx->arena.alloc(8 * (size_t)n, &aerr);
+  ORBX_HIP(ctx, aerr);
+  ORBX_HIP(ctx, hipMemcpyAsync(dd, h + o_d, (size_t)n * 32, hipMemcpyHostToDevice, st));
+  const int rc = orbx_bow_transform_device(v, dd, n, levelsup, dw, dwt, dn, st);
   if (rc != ORBX_OK) return rc;
-  ORBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  ORBX_HIP(ctx, copy_sync(ctx, word, dw.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
-  ORBX_HIP(ctx, copy_sync(ctx, weight, dwt.p, sizeof(double) * n, hipMemcpyDeviceToHost));
-  ORBX_HIP(ctx, copy_sync(ctx, node, dn.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+  ORBX_HIP(ctx, hipMemcpyAsync(word, dw, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, st));
+  ORBX_HIP(ctx, hipMemcpyAsync(weight, dwt, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+  ORBX_HIP(ctx, hipMemcpyAsync(node, dn, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, st));
+  ORBX_HIP(ctx, hipStreamSynchronize(st));
   return ORBX_OK;
 }
 
@@ -704,29 +788,37 @@ int orbx_bow_transform(orbx_voc* v, const uint8_t* desc, int n, int levelsup, ui
 int orbx_bow_finalize(const orbx_voc* v, const uint32_t* word, const double* weight, int n, uint32_t* ids, double* vals,
                       int* n_out) {
   if (!v || n < 0 || !n_out || (n > 0 && (!word || !weight || !ids || !vals))) return ORBX_E_INVALID;
-  std::map<uint32_t, double> bow;
+  // the reference accumulates into an ordered map feature by feature (addWeight: `vit->second += v` in feature order); sorting
+  // (word, feature index) keys gives the same words in ascending order and, inside a word, the same order of additions
   const bool tf = v->weighting == 0 /*TF_IDF*/ || v->weighting == 1 /*TF*/;
-  for (int i = 0; i < n; i++) {
-    if (!(weight[i] > 0)) continue;
-    auto it = bow.lower_bound(word[i]);
-    if (it != bow.end() && it->first == word[i]) { if (tf) it->second += weight[i]; }
-    else bow.insert(it, std::make_pair(word[i], weight[i]));
+  static thread_local std::vector<uint64_t> keys;
+  keys.clear();
+  for (int i = 0; i < n; i++)
+    if (weight[i] > 0) keys.push_back(((uint64_t)word[i] << 32) | (uint32_t)i);
+  std::sort(keys.begin(), keys.end());
+  int k = 0;
+  for (size_t a = 0; a < keys.size();) {
+    const uint32_t w = (uint32_t)(keys[a] >> 32);
+    double acc = weight[(uint32_t)keys[a]];
+    size_t b = a + 1;
+    for (; b < keys.size() && (uint32_t)(keys[b] >> 32) == w; b++)
+      if (tf) acc += weight[(uint32_t)keys[b]];      // IDF / BINARY: addIfNotExist keeps the first value
+    ids[k] = w; vals[k] = acc; k++;
+    a = b;
   }
   // mustNormalize: L1_NORM->L1, L2_NORM->L2, CHI_SQUARE/KL/BHATTACHARYYA->L1, DOT_PRODUCT->none (ScoringObject.h)
   const bool must = v->scoring != 5;
   const bool l2 = v->scoring == 1;
-  if (tf && !bow.empty() && !must) {
-    const double nd = (double)bow.size();
-    for (auto& kv : bow) kv.second /= nd;
+  if (tf && k > 0 && !must) {
+    const double nd = (double)k;
+    for (int j = 0; j < k; j++) vals[j] /= nd;
   }
   if (must) {
     double norm = 0.0;
-    if (!l2) { for (auto& kv : bow) norm += std::fabs(kv.second); }
-    else { for (auto& kv : bow) norm += kv.second * kv.second; norm = std::sqrt(norm); }
-    if (norm > 0.0) for (auto& kv : bow) kv.second /= norm;
+    if (!l2) { for (int j = 0; j < k; j++) norm += std::fabs(vals[j]); }
+    else { for (int j = 0; j < k; j++) norm += vals[j] * vals[j]; norm = std::sqrt(norm); }
+    if (norm > 0.0) for (int j = 0; j < k; j++) vals[j] /= norm;
   }
-  int k = 0;
-  for (auto& kv : bow) { ids[k] = kv.first; vals[k] = kv.second; k++; }
   *n_out = k;
   return ORBX_OK;
 }
