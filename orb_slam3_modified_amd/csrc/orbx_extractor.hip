@@ -532,7 +532,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
                          b_pts, b_lvl_kp, b_lvl_n, node_cap, scan_cap, pts_cap, l0, gnodes, (long long)ctx->qt_node_stride);
       return ORBX_OK;
     };
-    const int qt_pts = kQtLdsPoints;   // measured: 1024 ... 2048 points make no difference to the launch (128 VGPRs hold it at four workgroups per CU)
+    const int qt_pts = ctx->qt_points;   // measured: 1024 ... 2048 points make no difference to the launch (128 VGPRs hold it at four workgroups per CU)
     const int nbig = (geo.nlevels >= 4 && !small_batch) ? kQtBigLevels : geo.nlevels;  // small batch: one launch, all levels
     int qrc = ORBX_OK;
     if (small_fused && ctx->d_qt_fin && !ctx->d_asm_scan && nframes <= kSmallBatchFrames) {
@@ -649,6 +649,7 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, 
   }
   ctx->fast_threads = fast_threads_from_env();
   { const char* e = getenv("ORBX_SMALL_FUSED"); ctx->small_fused = e ? atoi(e) != 0 : true; }
+  { const char* e = getenv("ORBX_QT_POINTS"); const int v = e ? atoi(e) : kQtLdsPoints; ctx->qt_points = (v >= 256 && v <= 4096 && v % 128 == 0) ? v : kQtLdsPoints; }
   { const char* e = getenv("ORBX_FAST_SPLIT"); ctx->fast_split = e ? atoi(e) != 0 : true; }
   { const char* e = getenv("ORBX_WINDOW_DIRECT"); ctx->window_direct = e ? atoi(e) != 0 : true; }
   { const char* e = getenv("ORBX_QT_THREADS"); const int v = e ? atoi(e) : 0; ctx->qt_threads = (v == 64 || v == 128 || v == 256 || v == 512) ? v : 0; }
@@ -1123,6 +1124,7 @@ int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
   else if (n == "fork_qt") ctx->fork_qt = value != 0;
   else if (n == "graph") ctx->use_graph = value != 0;
   else if (n == "fast_pk") ctx->fast_pk = value != 0;
+  else if (n == "qt_points" && value >= 256 && value <= 4096 && value % 128 == 0) ctx->qt_points = value;   // LDS-resident candidates per (frame, level) of the big quadtree levels (half of it for the small ones)
   else if (n == "small_fused") ctx->small_fused = value != 0;
   else if (n == "window_direct") ctx->window_direct = value != 0;
   else if (n == "fast_split") ctx->fast_split = value != 0;   // FAST launched per group of levels with its own LDS size (batch calls)
