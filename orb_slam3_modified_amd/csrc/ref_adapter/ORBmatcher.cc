@@ -16,8 +16,11 @@
 // one descriptor matrix and one map-point vector.
 #include "ORBmatcher.h"
 
+#include <chrono>
 #include <climits>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -35,6 +38,25 @@ static_assert(sizeof(cv::KeyPoint) == sizeof(orbx_keypoint), "cv::KeyPoint must 
 namespace {
 
 constexpr int kCols = 64, kRows = 48;   // FRAME_GRID_COLS x FRAME_GRID_ROWS (include/Frame.h:44-45); the device grid is built for these
+
+// ORBX_TRACE_MATCHER=1: phase times of the two per-frame routines on stderr (diagnostics)
+struct PhaseTrace {
+  static bool on() { static const bool v = std::getenv("ORBX_TRACE_MATCHER") != nullptr; return v; }
+  const char* what;
+  std::chrono::steady_clock::time_point t0, last;
+  char buf[256];
+  int len = 0;
+  explicit PhaseTrace(const char* w) : what(w) { if (on()) t0 = last = std::chrono::steady_clock::now(); }
+  void mark(const char* phase) {
+    if (!on()) return;
+    const auto now = std::chrono::steady_clock::now();
+    len += std::snprintf(buf + len, sizeof(buf) - len, " %s %.1f", phase, std::chrono::duration<double, std::micro>(now - last).count());
+    last = now;
+  }
+  ~PhaseTrace() {
+    if (on()) std::fprintf(stderr, "[orbx matcher] %s:%s us (total %.1f)\n", what, buf, std::chrono::duration<double, std::micro>(last - t0).count());
+  }
+};
 
 [[noreturn]] void fail(const char* routine, orbx_ctx* ctx) {
   throw std::runtime_error(std::string("ORBmatcher::") + routine + ": " + (ctx ? orbx_last_error(ctx) : "no orbx context"));
@@ -102,6 +124,7 @@ struct Queries {
   std::vector<float> x, y, r, aux;
   std::vector<int32_t> lo, hi;
   std::vector<unsigned char> desc;
+  void reserve(size_t n) { x.reserve(n); y.reserve(n); r.reserve(n); aux.reserve(n); lo.reserve(n); hi.reserve(n); desc.reserve(n * 32); }
   int size() const { return (int)x.size(); }
   int add(float qx, float qy, float qr, int qlo, int qhi, const cv::Mat& d, float qaux = 0.f) {
     x.push_back(qx); y.push_back(qy); r.push_back(qr); aux.push_back(qaux); lo.push_back(qlo); hi.push_back(qhi);
@@ -246,7 +269,15 @@ orbx_target* frame_target(const char* routine, const Frame& F, bool bRight) {
     const unsigned char* d = D.p ? D.p + (bRight ? (size_t)F.Nleft * 32 : 0) : nullptr;
     if (!D.copy.empty()) { rows = D.copy; d = rows.data() + (bRight ? (size_t)F.Nleft * 32 : 0); }
     sp.kps = (const orbx_keypoint*)keys.data(); sp.desc = d; sp.n = (int)keys.size();
-    frame_grid(F, bRight, sp.grid);
+    // A Frame's grid is a pure function of these keypoints and the static bounds (Frame::AssignFeaturesToGrid, src/Frame.cc:385-416:
+    // every keypoint in index order into the cell PosInGrid names) — so it is rebuilt on the device from the uploaded keypoints
+    // (k_window_grid, the same cell arithmetic, lists in the same order) instead of being flattened on the host, checked and
+    // uploaded: the assign is asynchronous and hides behind the host pre-pass of the search that needs it.  Up to 32 768 keypoints
+    // (the device sort's capacity); beyond that the host lists are sent.
+    if ((int)keys.size() <= 32768) {
+      sp.grid.g.min_x = Frame::mnMinX; sp.grid.g.min_y = Frame::mnMinY; sp.grid.g.inv_w = Frame::mfGridElementWidthInv; sp.grid.g.inv_h = Frame::mfGridElementHeightInv;
+      sp.grid.g.cell_start = nullptr; sp.grid.g.cell_idx = nullptr;
+    } else frame_grid(F, bRight, sp.grid);
   });
 }
 
@@ -330,8 +361,12 @@ void common_nodes(const DBoW2::FeatureVector& a, const DBoW2::FeatureVector& b, 
 
 // rotation-consistency histogram (e.g. :345-352): bin = round(rot / 30) over rot in [0, 360)
 struct RotHist {
-  std::vector<int> bins[30];
-  RotHist() { for (auto& b : bins) b.reserve(500); }
+  std::vector<int>* bins;   // [30], per-thread storage reused from call to call (the reference reserves 30 x 500 ints per call)
+  RotHist() {
+    static thread_local std::vector<int> store[30];
+    bins = store;
+    for (int i = 0; i < 30; i++) { store[i].clear(); if (store[i].capacity() < 500) store[i].reserve(500); }
+  }
   void add(float angle1, float angle2, int what) {
     const float factor = 1.0f / ORBmatcher::HISTO_LENGTH;
     float rot = angle1 - angle2;
@@ -391,11 +426,13 @@ void ORBmatcher::ComputeThreeMaxima(vector<int>* histo, const int L, int& ind1, 
 // ---------------------------------------------------------------------------------------------------------------------
 int ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, const float th, const bool bFarPoints, const float thFarPoints) {
   int nmatches = 0;
+  PhaseTrace tr("SearchByProjection(F, points)");
   const bool bFactor = th != 1.0;
   const bool rig = F.Nleft != -1;
   const int nMP = (int)vpMapPoints.size();
   // phase 1 (:49-74, :143-149): one window per map point and camera it is predicted in
   Queries QL, QR;
+  QL.reserve(nMP);
   std::vector<int> qLeft(nMP, -1), qRight(nMP, -1);
   for (int iMP = 0; iMP < nMP; iMP++) {
     MapPoint* pMP = vpMapPoints[iMP];
@@ -419,11 +456,16 @@ int ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoint
     }
   }
   if (QL.size() == 0 && QR.size() == 0) return 0;
+  tr.mark("prepass");
   // phase 2
   const std::vector<cv::KeyPoint>& keysL = rig ? F.mvKeys : F.mvKeysUn;
   Lists LL, LR;
-  if (QL.size()) window_lists("SearchByProjection", frame_target("SearchByProjection", F, false), QL, LL);
-  if (QR.size()) window_lists("SearchByProjection", frame_target("SearchByProjection", F, true), QR, LR);
+  orbx_target* TL = QL.size() ? frame_target("SearchByProjection", F, false) : nullptr;
+  orbx_target* TR = QR.size() ? frame_target("SearchByProjection", F, true) : nullptr;
+  tr.mark("target");
+  if (TL) window_lists("SearchByProjection", TL, QL, LL);
+  if (TR) window_lists("SearchByProjection", TR, QR, LR);
+  tr.mark("device");
   // phase 3 (:76-140, :151-207): a keypoint bound to an observed map point — before the call or by an earlier map point of
   // this call — is no candidate
   for (int iMP = 0; iMP < nMP; iMP++) {
@@ -475,6 +517,7 @@ int ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoint
       }
     }
   }
+  tr.mark("replay");
   return nmatches;
 }
 
@@ -1140,6 +1183,7 @@ int ORBmatcher::SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoin
 // ---------------------------------------------------------------------------------------------------------------------
 int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono) {
   int nmatches = 0;
+  PhaseTrace tr("SearchByProjection(Cur, Last)");
   const Sophus::SE3f Tcw = CurrentFrame.GetPose();
   const Eigen::Vector3f twc = Tcw.inverse().translation();
   const Sophus::SE3f Tlw = LastFrame.GetPose();
@@ -1147,8 +1191,14 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
   const bool bForward = tlc(2) > CurrentFrame.mb && !bMono;
   const bool bBackward = -tlc(2) > CurrentFrame.mb && !bMono;
   const bool rig = CurrentFrame.Nleft != -1;
+  // the current frame becomes resident FIRST: its upload and the device-side grid build are asynchronous and run under the host
+  // pre-pass below (TrackWithMotionModel is the first search of a new frame)
+  orbx_target* TL = frame_target("SearchByProjection", CurrentFrame, false);
+  orbx_target* TR = rig ? frame_target("SearchByProjection", CurrentFrame, true) : nullptr;
+  tr.mark("target");
   // phase 1 (:1694-1733, :1792-1809): project the last frame's map points into the current camera(s)
   Queries QL, QR;
+  QL.reserve(LastFrame.N);
   std::vector<int> qLeft(LastFrame.N, -1), qRight(LastFrame.N, -1);
   for (int i = 0; i < LastFrame.N; i++) {
     MapPoint* pMP = LastFrame.mvpMapPoints[i];
@@ -1174,10 +1224,12 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
     }
   }
   if (QL.size() == 0) return 0;
+  tr.mark("prepass");
   // phase 2
   Lists LL, LR;
-  window_lists("SearchByProjection", frame_target("SearchByProjection", CurrentFrame, false), QL, LL);
-  if (rig) window_lists("SearchByProjection", frame_target("SearchByProjection", CurrentFrame, true), QR, LR);
+  window_lists("SearchByProjection", TL, QL, LL);
+  if (rig) window_lists("SearchByProjection", TR, QR, LR);
+  tr.mark("device");
   // phase 3 (:1735-1858)
   RotHist rot;
   auto lastKey = [&](int i) -> const cv::KeyPoint& {
@@ -1235,6 +1287,7 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
       }
     }
   }
+  tr.mark("replay");
   return nmatches;
 }
 
