@@ -98,6 +98,14 @@ int orbx_extract_batch(orbx_ctx* ctx, const uint8_t* imgs, int nframes, int rows
  * (the reference's stereo matcher reads it, src/Frame.cc:818,908-925).  dst may be NULL to query w/h. */
 int orbx_pyramid_level(orbx_ctx* ctx, int frame, int level, uint8_t* dst, size_t dst_stride, int* w, int* h);
 
+/* Hand-over extractor -> search target without a host round trip.  After orbx_extract / orbx_extract_color /
+ * orbx_extract_resized the context still holds the frame's descriptor rows in HBM.  An adapter that has copied those rows into the
+ * caller's own buffer (Frame::mDescriptors) names that buffer here; when orbx_target_create / orbx_target_assign are later given the
+ * very same `desc` pointer and count (on the same device, before this context extracts again), the target takes the rows from HBM
+ * inside its staging kernel instead of reading the host copy over PCIe.  Contract (the reference's own): nobody writes into the
+ * buffer between the extraction and the first search.  n = the extraction's keypoint count; a mismatch simply disables the hand-over. */
+int orbx_publish_descriptors(orbx_ctx* ctx, const void* host_desc, int n);
+
 /* Host mirror of mvImagePyramid for the single-frame path: with orbx_set_host_pyramid(ctx, 1) every orbx_extract also
  * copies the pyramid levels >= 1 of its frame into pinned host memory (one asynchronous copy inside the call);
  * orbx_host_pyramid_level then returns a pointer into that mirror, valid until the next extraction of the context

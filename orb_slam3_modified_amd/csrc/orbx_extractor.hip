@@ -597,6 +597,50 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
 
 }  // namespace orbx
 
+// ---- hand-over of an extraction's descriptor rows to the searches that follow (no D2H -> H2D ping-pong) -------------
+// The extractor adapter copies the rows it got from orbx_extract into the caller's cv::Mat (Frame::mDescriptors) and tells the library
+// which host buffer now holds the rows of the context's last extraction.  When a search target is later filled from that very
+// buffer, orbx_target_create / _assign copy the rows device to device from the extractor's staging block instead of sending the host
+// bytes up again.  Valid only while the publishing context has not extracted again (sequence number) — and that context's next
+// extraction waits for a copy still in flight.  Contract, as in the reference: nobody writes into mDescriptors after ExtractORB.
+namespace {
+struct Published { const void* host; orbx_ctx* ctx; unsigned long long seq; int n; const uint8_t* d_desc; };
+std::mutex g_pub_mu;
+Published g_pub[8];
+int g_pub_next = 0;
+}  // namespace
+
+const uint8_t* orbx::published_descriptors(const void* host_desc, int n, int device, orbx_ctx** src) {
+  std::lock_guard<std::mutex> lock(g_pub_mu);
+  for (const Published& p : g_pub)
+    if (p.host == host_desc && p.ctx && p.n == n && p.ctx->device == device && p.ctx->extract_seq == p.seq && p.ctx->last_d_desc == p.d_desc) {
+      if (src) *src = p.ctx;
+      return p.d_desc;
+    }
+  return nullptr;
+}
+// a new extraction begins on ctx: its staging block is about to be overwritten.  Returns true when a hand-over copy may still be reading it.
+static bool handover_begin_extraction(orbx_ctx* ctx) {
+  std::lock_guard<std::mutex> lock(g_pub_mu);
+  ctx->extract_seq++;
+  ctx->last_d_desc = nullptr; ctx->last_n0 = 0;
+  const bool pending = ctx->handover_pending && ctx->ev_handover;
+  ctx->handover_pending = false;
+  return pending;
+}
+// a search target on `stream` has queued a device-to-device copy out of src's staging block
+hipError_t orbx::handover_copied(orbx_ctx* src, hipStream_t stream) {
+  std::lock_guard<std::mutex> lock(g_pub_mu);
+  if (!src->ev_handover) { const hipError_t e = hipEventCreateWithFlags(&src->ev_handover, hipEventDisableTiming); if (e != hipSuccess) return e; }
+  const hipError_t e = hipEventRecord(src->ev_handover, stream);
+  if (e == hipSuccess) src->handover_pending = true;
+  return e;
+}
+void orbx::unpublish_context(orbx_ctx* ctx) {
+  std::lock_guard<std::mutex> lock(g_pub_mu);
+  for (Published& p : g_pub) if (p.ctx == ctx) p = Published{nullptr, nullptr, 0, 0, nullptr};
+}
+
 using namespace orbx;
 
 extern "C" {
@@ -716,6 +760,8 @@ void orbx_destroy(orbx_ctx* ctx) {
   if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
   if (ctx->h_in) { (void)hipHostFree(ctx->h_in); ctx->h_in = nullptr; }
   if (ctx->h_call) { (void)hipHostFree(ctx->h_call); ctx->h_call = nullptr; }
+  unpublish_context(ctx);
+  if (ctx->ev_handover) { (void)hipEventDestroy(ctx->ev_handover); ctx->ev_handover = nullptr; }
   if (ctx->d_win_ctr) { (void)hipFree(ctx->d_win_ctr); ctx->d_win_ctr = nullptr; }
   if (ctx->d_qt_fin) { (void)hipFree(ctx->d_qt_fin); ctx->d_qt_fin = nullptr; }
   if (ctx->h_tgt) { (void)hipHostFree(ctx->h_tgt); ctx->h_tgt = nullptr; }
@@ -854,7 +900,7 @@ static int extract_one_graph(orbx_ctx* ctx, const uint8_t* img, int rows, int co
     ctx->h_pyr_bytes = (size_t)ctx->geo.pyr_bytes;
     ctx->buf_epoch++;
   }
-  const int key[6] = {rows, cols, lap0, lap1, keep ? 1 : 0, ctx->buf_epoch};
+  const int key[6] = {rows, cols, lap0, lap1, (keep ? 1 : 0) | (ctx->stage_frames == 1 ? 2 : 0), ctx->buf_epoch};
   if (!ctx->graph_exec || std::memcmp(key, ctx->graph_key, sizeof(key)) != 0) {
     if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
     uint8_t* d = ctx->d_stage_out;
@@ -866,7 +912,14 @@ static int extract_one_graph(orbx_ctx* ctx, const uint8_t* img, int rows, int co
                                    d + L.desc_off, (int32_t*)(d + L.counts_off), st) == ORBX_OK;
       // keypoints | descriptors | counts are one staging block with the same layout on both sides: ONE copy node (every node of
       // the graph costs about 5 us of device time, whatever it moves: three copies were 15 us of a 140 us frame)
-      if (ok) ok = hipMemcpyAsync(ctx->h_stage_out, d, L.bytes, hipMemcpyDeviceToHost, st) == hipSuccess;
+      const size_t kb = (size_t)ctx->out_cap * sizeof(orbx_keypoint), db = (size_t)ctx->out_cap * 32, cb = 2 * sizeof(int32_t);
+      if (ctx->stage_frames == 1) {
+        if (ok) ok = hipMemcpyAsync(ctx->h_stage_out, d, L.counts_off + cb, hipMemcpyDeviceToHost, st) == hipSuccess;
+      } else {   // the staging block was laid out for an earlier, larger batch: this frame's three ranges
+        if (ok) ok = hipMemcpyAsync(ctx->h_stage_out + L.kps_off, d + L.kps_off, kb, hipMemcpyDeviceToHost, st) == hipSuccess;
+        if (ok) ok = hipMemcpyAsync(ctx->h_stage_out + L.desc_off, d + L.desc_off, db, hipMemcpyDeviceToHost, st) == hipSuccess;
+        if (ok) ok = hipMemcpyAsync(ctx->h_stage_out + L.counts_off, d + L.counts_off, cb, hipMemcpyDeviceToHost, st) == hipSuccess;
+      }
       if (ok && keep && ctx->geo.pyr_bytes > 0)
         ok = hipMemcpyAsync(ctx->h_pyr, ctx->d_pyr, (size_t)ctx->geo.pyr_bytes, hipMemcpyDeviceToHost, st) == hipSuccess;
       const hipError_t ee = hipStreamEndCapture(st, &graph);   // always leave capture mode
@@ -956,6 +1009,16 @@ static int ingest_resized(orbx_ctx* ctx, const uint8_t* img, int src_rows, int s
   return ORBX_OK;
 }
 
+int orbx_publish_descriptors(orbx_ctx* ctx, const void* host_desc, int n) {
+  if (!ctx || !host_desc || n < 0) return ORBX_E_INVALID;
+  if (!ctx->last_d_desc || n != ctx->last_n0) return ORBX_OK;   // nothing resident that matches: the host bytes will be used
+  std::lock_guard<std::mutex> lock(g_pub_mu);
+  for (Published& p : g_pub) if (p.host == host_desc) p = Published{nullptr, nullptr, 0, 0, nullptr};   // a reused buffer: the old entry dies
+  g_pub[g_pub_next] = Published{host_desc, ctx, ctx->extract_seq, n, ctx->last_d_desc};
+  g_pub_next = (g_pub_next + 1) % 8;
+  return ORBX_OK;
+}
+
 // channels == 1: grey frames.  channels == 3 / 4: interleaved colour frames, converted on the device behind the upload
 // (rgb_order != 0: R first, else B first).
 static int extract_batch_impl(orbx_ctx* ctx, const uint8_t* imgs, int nframes, int rows, int cols, size_t row_stride,
@@ -966,6 +1029,7 @@ static int extract_batch_impl(orbx_ctx* ctx, const uint8_t* imgs, int nframes, i
   const bool resized = src_rows > 0;   // rows x cols = the size AFTER cv::resize; the caller's image is src_rows x src_cols
   if (!kps || !desc || !counts || row_stride < (size_t)(resized ? src_cols : cols) * channels) return set_err(ctx, ORBX_E_INVALID, "bad arguments");
   ORBX_HIP(ctx, hipSetDevice(ctx->device));
+  if (handover_begin_extraction(ctx)) ORBX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_handover, 0));   // a search target is still copying the last rows
   const size_t pitch = (size_t)round_up(cols, 64), fbytes = pitch * rows;
   int rc = ensure_stage(ctx, nframes, fbytes * nframes);
   if (rc != ORBX_OK) return rc;
@@ -982,6 +1046,7 @@ static int extract_batch_impl(orbx_ctx* ctx, const uint8_t* imgs, int nframes, i
       std::memcpy(desc, ctx->h_stage_out + L.desc_off, db);
       std::memcpy(counts, ctx->h_stage_out + L.counts_off, cb);
       if (counts[0] < 0) return set_err(ctx, ORBX_E_CAPACITY, "quadtree produced more nodes than the level capacity");
+      ctx->last_d_desc = ctx->d_stage_out + L.desc_off; ctx->last_n0 = counts[0];
       return ORBX_OK;
     }
   }
@@ -1042,6 +1107,7 @@ static int extract_batch_impl(orbx_ctx* ctx, const uint8_t* imgs, int nframes, i
   // k_assemble reports a quadtree capacity overflow (never expected) as a negative keypoint count: fail loudly
   for (int f = 0; f < nframes; f++)
     if (counts[2 * f] < 0) return set_err(ctx, ORBX_E_CAPACITY, "quadtree produced more nodes than the level capacity");
+  ctx->last_d_desc = ctx->d_stage_out + L.desc_off; ctx->last_n0 = counts[0];
   return ORBX_OK;
 }
 

@@ -201,6 +201,11 @@ struct orbx_ctx {
   uint8_t* h_pyr = nullptr; size_t h_pyr_bytes = 0; bool h_pyr_valid = false;
   // last extraction (for orbx_pyramid_level / debug dumps)
   const uint8_t* last_imgs = nullptr; size_t last_row_stride = 0, last_frame_stride = 0; int last_nframes = 0;
+  // hand-over of the last host-buffer extraction's descriptor rows (orbx_publish_descriptors): which extraction the staging block holds,
+  // and the event of the last device-to-device copy that read it (the next extraction of this context waits for it)
+  unsigned long long extract_seq = 0;
+  const uint8_t* last_d_desc = nullptr; int last_n0 = 0;
+  hipEvent_t ev_handover = nullptr; bool handover_pending = false;
   hipStream_t last_ext_stream = nullptr;   // caller's stream of the last orbx_extract_batch_device (its work may still use our buffers)
   // profiling
   bool profiling = false;
@@ -239,6 +244,11 @@ inline hipError_t sync_ctx(orbx_ctx* ctx) {
 hipError_t ensure_dynamic_lds(const void* kernel, int bytes);
 // orbx_window.hip: pinned staging (grow-only) and the fused window pass behind orbx_window_search* / orbx_window_nearest
 hipError_t host_stage(orbx_ctx* ctx, size_t bytes, uint8_t** p);
+// descriptor rows published by an extractor context for the host buffer `host_desc` (orbx_publish_descriptors): device address when the
+// publishing context still holds that extraction on `device`, else nullptr; *src = the publishing context
+const uint8_t* published_descriptors(const void* host_desc, int n, int device, orbx_ctx** src);
+void unpublish_context(orbx_ctx* ctx);
+hipError_t handover_copied(orbx_ctx* src, hipStream_t stream);
 }  // namespace orbx
 // A Frame's / KeyFrame's keypoints, descriptors and grid resident in HBM (orbx_target_create, orbx_window.hip)
 struct orbx_target {

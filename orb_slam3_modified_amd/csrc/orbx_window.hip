@@ -410,6 +410,12 @@ static void pack_queries(uint8_t* dst, const float* qx, const float* qy, const f
 __global__ __launch_bounds__(256) void k_stage_in(const uint4* __restrict__ src, uint4* __restrict__ dst, int n16) {
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = src[i];
 }
+// the same with the 16-byte units [lo, hi) — a target's descriptor rows — taken from `dev_src` (rows an extractor context left in HBM,
+// orbx_publish_descriptors) instead of the mapped host blob: the hand-over costs no extra launch and the rows never cross PCIe again
+__global__ __launch_bounds__(256) void k_stage_in_handover(const uint4* __restrict__ src, uint4* __restrict__ dst, int n16, int lo, int hi,
+                                                           const uint4* __restrict__ dev_src) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = (i >= lo && i < hi) ? dev_src[i - lo] : src[i];
+}
 
 // The whole call: pack -> one H2D -> [grid assignment] -> k_window -> one D2H (+ one more for a long tail) -> scatter.
 int window_call(orbx_ctx* ctx, const char* who, const orbx_keypoint* kps, const uint8_t* desc, int n, const orbx_grid* grid,
@@ -656,7 +662,12 @@ int target_assign(orbx_ctx* ctx, orbx_target* reuse, const orbx_keypoint* kps, c
     if (e == hipSuccess) T->cap = want;
   }
   if (e != hipSuccess) { T->n = 0; if (!reuse) { if (T->dev) (void)hipFree(T->dev); delete T; } ORBX_HIP(ctx, e); }
-  if (n) { std::memcpy(h + T->o_kps, kps, sizeof(orbx_keypoint) * (size_t)n); std::memcpy(h + T->o_desc, desc, (size_t)n * 32); }
+  // descriptor rows an extractor context published for this very host buffer are taken from HBM (k_stage_in_handover); both blocks
+  // are 256-byte aligned, rows are 32 bytes
+  orbx_ctx* pub_ctx = nullptr;
+  const uint8_t* d_rows = (n > 0 && ctx->window_direct) ? published_descriptors(desc, n, ctx->device, &pub_ctx) : nullptr;
+  if (d_rows && ((uintptr_t)d_rows & 15)) d_rows = nullptr;
+  if (n) { std::memcpy(h + T->o_kps, kps, sizeof(orbx_keypoint) * (size_t)n); if (!d_rows) std::memcpy(h + T->o_desc, desc, (size_t)n * 32); }
   if (kp_uright) std::memcpy(h + T->o_ur, kp_uright, 4 * (size_t)n);
   if (inv_sigma2) std::memcpy(h + T->o_sig, inv_sigma2, 4 * (size_t)nlevels);
   if (have_grid) {
@@ -667,10 +678,18 @@ int target_assign(orbx_ctx* ctx, orbx_target* reuse, const orbx_keypoint* kps, c
   uint8_t* hdev = nullptr;
   if (ctx->window_direct && hipHostGetDevicePointer((void**)&hdev, h, 0) == hipSuccess && hdev) {
     const int n16 = (int)((upload + 15) / 16);   // the block is a multiple of 256 bytes
-    hipLaunchKernelGGL(k_stage_in, dim3(std::min((n16 + 255) / 256, 256)), dim3(256), 0, st, (const uint4*)hdev, (uint4*)T->dev, n16);
-    e = hipGetLastError();
+    if (d_rows) {
+      hipLaunchKernelGGL(k_stage_in_handover, dim3(std::min((n16 + 255) / 256, 256)), dim3(256), 0, st, (const uint4*)hdev, (uint4*)T->dev, n16,
+                         (int)(T->o_desc / 16), (int)((T->o_desc + (size_t)n * 32) / 16), (const uint4*)d_rows);
+      e = hipGetLastError();
+      if (e == hipSuccess) e = handover_copied(pub_ctx, st);   // the publishing context's next extraction waits for this copy
+    } else {
+      hipLaunchKernelGGL(k_stage_in, dim3(std::min((n16 + 255) / 256, 256)), dim3(256), 0, st, (const uint4*)hdev, (uint4*)T->dev, n16);
+      e = hipGetLastError();
+    }
   } else {
     (void)hipGetLastError();
+    if (d_rows && n) std::memcpy(h + T->o_desc, desc, (size_t)n * 32);   // no mapped view of the staging buffer after all: the host rows go up
     e = hipMemcpyAsync(T->dev, h, upload, hipMemcpyHostToDevice, st);
   }
   if (e == hipSuccess && !have_grid) {

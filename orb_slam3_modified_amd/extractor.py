@@ -105,6 +105,12 @@ class ORBextractor:
                                            int(vLappingArea[0]), int(vLappingArea[1]), ptr(kps), ptr(desc), C.byref(n), C.byref(mono)), self._ctx)
         return mono.value, kps[:n.value].copy(), desc[:n.value].copy()
 
+    def publish_descriptors(self, desc: np.ndarray) -> None:
+        """orbx_publish_descriptors: `desc` (C-contiguous [n, 32] uint8) holds the rows of this context's last single-frame extraction;
+        a search target created from this very array takes them from HBM."""
+        assert desc.dtype == np.uint8 and desc.flags["C_CONTIGUOUS"]
+        check(self._L.orbx_publish_descriptors(self._ctx, ptr(desc), int(desc.shape[0])), self._ctx)
+
     def extract_batch(self, images: np.ndarray, vLappingArea: Sequence[int] = (0, 0)
                       ) -> List[Tuple[int, np.ndarray, np.ndarray]]:
         """Batch replay over host frames [B, H, W] (frames are independent: SURVEY.md §8(e))."""

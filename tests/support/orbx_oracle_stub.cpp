@@ -66,6 +66,7 @@ int orbx_scale_tables(const orbx_ctx* c, float* scale, float* inv_scale, float* 
   return ORBX_OK;
 }
 int orbx_set_host_pyramid(orbx_ctx*, int) { return ORBX_OK; }
+int orbx_publish_descriptors(orbx_ctx*, const void*, int) { return ORBX_OK; }
 int orbx_host_pyramid_level(orbx_ctx*, int, const uint8_t**, size_t*, int*, int*) { return ORBX_E_INVALID; }
 int orbx_extract(orbx_ctx* c, const uint8_t* img, int rows, int cols, size_t stride, int lap0, int lap1, orbx_keypoint* kps, uint8_t* desc, int* n_out,
                  int* mono_out) {

@@ -431,3 +431,38 @@ def test_failed_target_assign_leaves_an_invalid_target_not_an_empty_one(frames):
     got = T.search(qx, qy, qr, lo, hi, d1[:nq])
     assert len(T) == 500 and np.array_equal(got["cand"], want["cand"]) and np.array_equal(got["dist"], want["dist"])
     T.close()
+
+
+def test_descriptor_handover_from_the_extractor_to_a_search_target():
+    """orbx_publish_descriptors: a target created from the host buffer an extraction's rows were copied into takes them from HBM
+    (k_stage_in_handover) — same results as the host path; after the context has extracted ANOTHER frame the published entry is dead
+    and the host bytes are used (the HBM rows now belong to the other frame)."""
+    from orb_slam3_modified_amd import synth
+    fr = synth.make_stream(2, 480, 640, 31)
+    ex = ORBextractor(1000, 1.2, 8, 20, 7)
+    m = ORBmatcher(ex)
+    mono, k1, d1 = ex(fr[0], None, (0, 1000))
+    d1 = np.ascontiguousarray(d1)
+    ex.publish_descriptors(d1)
+    grid = dict(min_x=0.0, min_y=0.0, inv_w=64 / 640.0, inv_h=48 / 480.0, cell_start=None, cell_idx=None)
+    nq = 600
+    qx, qy = k1["x"][:nq].copy(), k1["y"][:nq].copy()
+    qr = np.full(nq, 12.0, np.float32)
+    lo = np.full(nq, -1, np.int32); hi = np.full(nq, -1, np.int32)
+    qd = d1[::-1][:nq].copy()
+    want = po.window_search_grid(k1, d1, grid, qx, qy, qr, lo, hi, qd)
+    T = m.Target(k1, d1, grid)                       # rows from HBM
+    got = T.search(qx, qy, qr, lo, hi, qd)
+    for key in ("row_ptr", "cand", "dist", "best_idx", "best_dist"):
+        assert np.array_equal(got[key], want[key]), key
+    assert len(want["cand"]) > nq
+    mono2, k2, d2 = ex(fr[1], None, (0, 1000))       # the context moves on: its HBM rows are frame 1's now
+    T2 = m.Target(k1, d1, grid)                      # same host buffer, published entry stale -> host bytes
+    got2 = T2.search(qx, qy, qr, lo, hi, qd)
+    for key in ("row_ptr", "cand", "dist", "best_idx", "best_dist"):
+        assert np.array_equal(got2[key], want[key]), key
+    ex.publish_descriptors(d1[:10])                  # a count that does not match the extraction: ignored
+    T3 = m.Target(k1[:10], d1[:10], grid)
+    assert len(T3) == 10
+    for t in (T, T2, T3):
+        t.close()

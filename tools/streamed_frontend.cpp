@@ -111,6 +111,7 @@ int main(int argc, char** argv) {
         // ---- rest of Frame::Frame on the host (UndistortKeyPoints without distortion = copy, AssignFeaturesToGrid): the same code in both builds
         t0 = std::chrono::steady_clock::now();
         s.make_frame(Cur, t, false, s.pose(t));
+        Cur.mDescriptors = V.desc;   // Frame::Frame hands mDescriptors itself to operator() (src/Frame.cc:311,418-425): the same buffer, not a copy
         const double f_ms = ms_since(t0);
         d.val(V.n); d.bytes(V.kps.data(), (size_t)V.n * sizeof(cv::KeyPoint));
         for (int j = 0; j < V.n; j++) d.bytes(V.desc.ptr((int)j), 32);
