@@ -280,6 +280,14 @@ int orbx_target_search(orbx_ctx* ctx, const orbx_target* target, const uint8_t* 
                        const int32_t* qmin_level, const int32_t* qmax_level, const uint8_t* q_desc, const float* q_xr, int nq, int32_t* row_ptr,
                        int32_t* cand, int32_t* dist, int cand_cap, int32_t* best_idx, int32_t* best_dist, int32_t* second_idx,
                        int32_t* second_dist);
+/* orbx_target_search without the copy-out: the candidate lists are read where the kernel wrote them — the call's pinned, mapped blob.
+ * Query q's candidates are pool[spans[q].start .. spans[q].start + spans[q].count), in GetFeaturesInArea's order, each with its
+ * Hamming distance.  Both pointers stay valid until the NEXT call on this context.  Returns the total number of candidates. */
+typedef struct orbx_list_span { int32_t start, count; } orbx_list_span;
+typedef struct orbx_candidate { int32_t idx, dist; } orbx_candidate;
+int orbx_target_search_view(orbx_ctx* ctx, const orbx_target* target, const uint8_t* kp_skip, const float* qx, const float* qy, const float* qr,
+                            const int32_t* qmin_level, const int32_t* qmax_level, const uint8_t* q_desc, const float* q_xr, int nq,
+                            const orbx_list_span** spans, const orbx_candidate** pool);
 /* = orbx_window_nearest on the target; reprojection_gate != 0 needs a target created with kp_uright + inv_level_sigma2, and q_ur */
 int orbx_target_nearest(orbx_ctx* ctx, const orbx_target* target, int reprojection_gate, const float* qx, const float* qy, const float* qr,
                         const int32_t* qmin_level, const int32_t* qmax_level, const float* q_ur, const uint8_t* q_desc, int nq, int32_t* best_idx,

@@ -442,7 +442,9 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
   }
   // small batches (the single-frame graph): every launch costs about 5 us of device time whatever it does, so FAST and the blur —
   // both only read the finished pyramid — share one launch, and the assembly runs as the tail of the quadtree launch
-  const bool small_fused = small_batch && ctx->small_fused && !ctx->profiling && ctx->fast_stop == 0;
+  // (latency-bound calls only: at 32 frames of 1024 x 1024 — config 4's replay lanes, still a "small batch" by the fork rule above — the shared
+  // launch with its 256-thread FAST workgroups and worst-case LDS costs 20 % of the throughput)
+  const bool small_fused = small_batch && nframes <= 4 && ctx->small_fused && !ctx->profiling && ctx->fast_stop == 0;
   BlurConsts bc;
   {
     int gk[7];

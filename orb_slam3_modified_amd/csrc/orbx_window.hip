@@ -722,7 +722,9 @@ void target_destroy(orbx_target* T) {
 int window_call_target(orbx_ctx* ctx, const char* who, const orbx_target* T, const uint8_t* kp_skip, bool chi2, const float* qx, const float* qy,
                        const float* qr, const int32_t* qlo, const int32_t* qhi, const float* qaux, const uint8_t* q_desc, int nq, bool lists,
                        int32_t* row_ptr, int32_t* cand, int32_t* dist, int cand_cap, int32_t* best_idx, int32_t* best_dist, int32_t* second_idx,
-                       int32_t* second_dist) {
+                       int32_t* second_dist, const orbx_list_span** v_spans = nullptr, const orbx_candidate** v_pool = nullptr) {
+  if (v_spans) *v_spans = nullptr;
+  if (v_pool) *v_pool = nullptr;
   if (row_ptr) for (int q = 0; q <= nq; q++) row_ptr[q] = 0;
   for (int q = 0; q < nq; q++) {
     if (best_idx) best_idx[q] = -1;
@@ -827,6 +829,16 @@ int window_call_target(orbx_ctx* ctx, const char* who, const orbx_target* T, con
   const WinQueryShort* qs = (const WinQueryShort*)(hout + p_q);
   auto q_start = [&](int q) { return compact ? qs[q].start : qo[q].start; };
   auto q_count = [&](int q) { return compact ? qs[q].count : qo[q].count; };
+  if (v_spans) {   // the caller reads the lists where the kernel left them (the call's pinned blob, valid until the context's next call)
+    if (total > pool_cap) { if (row_ptr) row_ptr[nq] = total; return set_err(ctx, ORBX_E_CAPACITY, std::string(who) + ": candidate buffer too small"); }
+    static_assert(sizeof(orbx_list_span) == sizeof(WinQueryShort) && sizeof(orbx_candidate) == sizeof(int2), "view layout");
+    *v_spans = (const orbx_list_span*)(hout + p_q);
+    *v_pool = (const orbx_candidate*)(hout + p_pool);
+    if (trace)
+      std::fprintf(stderr, "[orbx window] %s (resident target, view) n=%d nq=%d total=%d: pack %.1f us, issue %.1f, wait %.1f\n", who, n, nq, total, us_pack,
+                   us_issue - us_pack, us_sync - us_issue);
+    return total;
+  }
   if (row_ptr) {
     int acc = 0;
     for (int q = 0; q < nq; q++) { acc += q_count(q); row_ptr[q + 1] = acc; }
@@ -965,6 +977,26 @@ int orbx_target_search(orbx_ctx* ctx, const orbx_target* target, const uint8_t* 
   const bool lists = cand != nullptr || dist != nullptr;
   return window_call_target(ctx, "orbx_target_search", target, kp_skip, false, qx, qy, qr, qmin_level, qmax_level, q_xr, q_desc, nq, lists, row_ptr,
                             cand, dist, cand_cap, best_idx, best_dist, second_idx, second_dist);
+}
+
+int orbx_target_search_view(orbx_ctx* ctx, const orbx_target* target, const uint8_t* kp_skip, const float* qx, const float* qy, const float* qr,
+                            const int32_t* qmin_level, const int32_t* qmax_level, const uint8_t* q_desc, const float* q_xr, int nq,
+                            const orbx_list_span** spans, const orbx_candidate** pool) {
+  if (!ctx || !target || target->ctx != ctx || nq < 0 || !spans || !pool ||
+      (nq > 0 && (!qx || !qy || !qr || !qmin_level || !qmax_level || !q_desc)) || (q_xr && !target->has_ur))
+    return ctx ? set_err(ctx, ORBX_E_INVALID, "orbx_target_search_view: bad arguments") : ORBX_E_INVALID;
+  *spans = nullptr; *pool = nullptr;
+  if (nq == 0 || target->n == 0) return target->valid ? 0 : set_err(ctx, ORBX_E_INVALID, "orbx_target_search_view: invalid target");
+  // the pool is sized from what earlier calls of this context needed; a call that needs more reports the size and is repeated once
+  for (int attempt = 0; attempt < 2; attempt++) {
+    std::vector<int32_t>& rp = ctx->view_row_ptr;
+    rp.assign((size_t)nq + 1, 0);
+    const int rc = window_call_target(ctx, "orbx_target_search_view", target, kp_skip, false, qx, qy, qr, qmin_level, qmax_level, q_xr, q_desc, nq, true,
+                                      rp.data(), nullptr, nullptr, ctx->view_pool_cap, nullptr, nullptr, nullptr, nullptr, spans, pool);
+    if (rc >= 0 || rc != ORBX_E_CAPACITY || attempt) return rc;
+    ctx->view_pool_cap = std::max(2 * ctx->view_pool_cap, rp[nq] + rp[nq] / 4 + 64);
+  }
+  return ORBX_E_CAPACITY;
 }
 
 int orbx_target_nearest(orbx_ctx* ctx, const orbx_target* target, int reprojection_gate, const float* qx, const float* qy, const float* qr,

@@ -134,10 +134,20 @@ struct Queries {
   }
 };
 
-struct Lists {   // CSR candidate lists of a query batch, in GetFeaturesInArea's order, with the distances
-  std::vector<int32_t> row_ptr, cand, dist;
-  int begin(int q) const { return row_ptr[q]; }
-  int end(int q) const { return row_ptr[q + 1]; }
+// Candidate lists of a query batch, in GetFeaturesInArea's order, with the distances: positions [begin(q), end(q)) of `cand` / `dist`.
+// Either copies (row_ptr / own vectors) or a VIEW of the device pass's own output in the context's pinned blob (orbx_target_search_view:
+// no copy-out; valid until the thread's next device call — the two per-frame Tracking routines read their lists before any other call).
+struct Lists {
+  std::vector<int32_t> row_ptr, cand_v, dist_v;
+  const orbx_list_span* spans = nullptr;
+  struct Column {
+    const int32_t* own = nullptr; const orbx_candidate* view = nullptr; bool second = false;
+    int32_t operator[](int c) const { return view ? (second ? view[c].dist : view[c].idx) : own[c]; }
+  } cand, dist;
+  int begin(int q) const { return spans ? spans[q].start : row_ptr[q]; }
+  int end(int q) const { return spans ? spans[q].start + spans[q].count : row_ptr[q + 1]; }
+  void own() { spans = nullptr; cand = Column{cand_v.data(), nullptr, false}; dist = Column{dist_v.data(), nullptr, true}; }
+  void view(const orbx_list_span* s, const orbx_candidate* p) { spans = s; cand = Column{nullptr, p, false}; dist = Column{nullptr, p, true}; }
 };
 
 // ---- resident search targets -----------------------------------------------------------------------------------------------------
@@ -320,19 +330,28 @@ orbx_target* fuse_target(const char* routine, KeyFrame* pKF, bool bRight) {
   });
 }
 
-void window_lists(const char* routine, orbx_target* T, const Queries& Q, Lists& L) {
+void window_lists(const char* routine, orbx_target* T, const Queries& Q, Lists& L, bool view_ok = false) {
   const int nq = Q.size();
   L.row_ptr.assign(nq + 1, 0);
+  L.own();
   if (nq == 0 || orbx_target_size(T) == 0) return;
   orbx_ctx* ctx = ORBmatcher::DefaultContext();
-  if (L.cand.size() < 4096) { L.cand.resize(4096); L.dist.resize(4096); }
+  if (view_ok) {
+    const orbx_list_span* spans = nullptr;
+    const orbx_candidate* pool = nullptr;
+    if (orbx_target_search_view(ctx, T, nullptr, Q.x.data(), Q.y.data(), Q.r.data(), Q.lo.data(), Q.hi.data(), Q.desc.data(), nullptr, nq, &spans, &pool) < 0)
+      fail(routine, ctx);
+    L.view(spans, pool);
+    return;
+  }
+  if (L.cand_v.size() < 4096) { L.cand_v.resize(4096); L.dist_v.resize(4096); }
   for (int attempt = 0; attempt < 2; attempt++) {
     const int rc = orbx_target_search(ctx, T, nullptr, Q.x.data(), Q.y.data(), Q.r.data(), Q.lo.data(), Q.hi.data(), Q.desc.data(), nullptr, nq,
-                                      L.row_ptr.data(), L.cand.data(), L.dist.data(), (int)L.cand.size(), nullptr, nullptr, nullptr, nullptr);
-    if (rc >= 0) return;
+                                      L.row_ptr.data(), L.cand_v.data(), L.dist_v.data(), (int)L.cand_v.size(), nullptr, nullptr, nullptr, nullptr);
+    if (rc >= 0) { L.own(); return; }
     if (rc != ORBX_E_CAPACITY || attempt) fail(routine, ctx);
     const size_t need = (size_t)L.row_ptr[nq] + 64;   // row_ptr is complete on ORBX_E_CAPACITY
-    L.cand.resize(need); L.dist.resize(need);
+    L.cand_v.resize(need); L.dist_v.resize(need);
   }
 }
 
@@ -463,7 +482,7 @@ int ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoint
   orbx_target* TL = QL.size() ? frame_target("SearchByProjection", F, false) : nullptr;
   orbx_target* TR = QR.size() ? frame_target("SearchByProjection", F, true) : nullptr;
   tr.mark("target");
-  if (TL) window_lists("SearchByProjection", TL, QL, LL);
+  if (TL) window_lists("SearchByProjection", TL, QL, LL, /*view_ok=*/!TR);   // a rig keeps two lists alive: copies
   if (TR) window_lists("SearchByProjection", TR, QR, LR);
   tr.mark("device");
   // phase 3 (:76-140, :151-207): a keypoint bound to an observed map point — before the call or by an earlier map point of
@@ -1227,7 +1246,7 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
   tr.mark("prepass");
   // phase 2
   Lists LL, LR;
-  window_lists("SearchByProjection", TL, QL, LL);
+  window_lists("SearchByProjection", TL, QL, LL, /*view_ok=*/!rig);
   if (rig) window_lists("SearchByProjection", TR, QR, LR);
   tr.mark("device");
   // phase 3 (:1735-1858)

@@ -212,6 +212,32 @@ int orbx_target_search(orbx_ctx*, const orbx_target* T, const uint8_t* kp_skip, 
   return r < 0 ? ORBX_E_CAPACITY : r;
 }
 
+int orbx_target_search_view(orbx_ctx* ctx, const orbx_target* T, const uint8_t* kp_skip, const float* qx, const float* qy, const float* qr, const int32_t* qmin,
+                            const int32_t* qmax, const uint8_t* q_desc, const float* q_xr, int nq, const orbx_list_span** spans, const orbx_candidate** pool) {
+  static thread_local std::vector<int32_t> rp, cand, dist;
+  static thread_local std::vector<orbx_list_span> sp;
+  static thread_local std::vector<orbx_candidate> pl;
+  rp.assign(nq + 1, 0);
+  cand.resize(1 << 16); dist.resize(1 << 16);
+  int rc = orbx_target_search(ctx, T, kp_skip, qx, qy, qr, qmin, qmax, q_desc, q_xr, nq, rp.data(), cand.data(), dist.data(), (int)cand.size(), nullptr, nullptr,
+                              nullptr, nullptr);
+  if (rc == ORBX_E_CAPACITY) {
+    cand.resize(rp[nq] + 64); dist.resize(rp[nq] + 64);
+    rc = orbx_target_search(ctx, T, kp_skip, qx, qy, qr, qmin, qmax, q_desc, q_xr, nq, rp.data(), cand.data(), dist.data(), (int)cand.size(), nullptr, nullptr,
+                            nullptr, nullptr);
+  }
+  if (rc < 0) return rc;
+  sp.resize(nq); pl.resize(rp[nq] + 1);
+  // the device pool is not in query order (segments are reserved as the waves finish): mimic that with a reversed segment layout, so that
+  // a reader that assumed CSR order would fail
+  int at = 0;
+  for (int q = nq - 1; q >= 0; q--) {
+    sp[q].start = at; sp[q].count = rp[q + 1] - rp[q];
+    for (int c = rp[q]; c < rp[q + 1]; c++) { pl[at].idx = cand[c]; pl[at].dist = dist[c]; at++; }
+  }
+  *spans = sp.data(); *pool = pl.data();
+  return rp[nq];
+}
 int orbx_target_nearest(orbx_ctx*, const orbx_target* T, int reprojection_gate, const float* qx, const float* qy, const float* qr, const int32_t* qmin,
                         const int32_t* qmax, const float* q_ur, const uint8_t* q_desc, int nq, int32_t* best_idx, int32_t* best_dist) {
   mo_window_nearest(T->kps.data(), T->desc.data(), T->n, &T->g, reprojection_gate ? T->ur.data() : nullptr, reprojection_gate ? T->sig.data() : nullptr,
