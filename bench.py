@@ -334,8 +334,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU")
-    ap.add_argument("--batches", type=int, default=4, help="distinct batches the steps rotate through")
+    ap.add_argument("--batch", type=int, default=None, help="frames per step per camera stream (default 256; 64 with --streams)")
+    ap.add_argument("--batches", type=int, default=None, help="distinct batches the steps rotate through (default 4; 2 with --streams)")
     ap.add_argument("--rows", type=int, default=480)
     ap.add_argument("--cols", type=int, default=640)
     ap.add_argument("--nfeatures", type=int, default=1000)
@@ -353,6 +353,10 @@ def main():
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("ORBX_LANES", "2")),
                     help="extractor contexts per GPU, each on its own free-running stream over 1/lanes of the batch")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 64 if args.streams > 0 else 256     # SURVEY 8(e) sizes the S-8cam exchange for B = 64 frames per stream
+    if args.batches is None:
+        args.batches = 2 if args.streams > 0 else 4
 
     import torch
     import torch.distributed as dist
