@@ -888,7 +888,7 @@ static int extract_one_graph(orbx_ctx* ctx, const uint8_t* img, int rows, int co
   if (in_bytes > ctx->h_in_bytes) {
     if (ctx->h_in) (void)hipHostFree(ctx->h_in);
     ctx->h_in = nullptr; ctx->h_in_bytes = 0;
-    if (hipHostMalloc((void**)&ctx->h_in, in_bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->use_graph = false; return 0; }
+    if (hipHostMalloc((void**)&ctx->h_in, in_bytes, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); ctx->use_graph = false; return 0; }
     ctx->h_in_bytes = in_bytes;
     ctx->buf_epoch++;
   }
@@ -909,7 +909,18 @@ static int extract_one_graph(orbx_ctx* ctx, const uint8_t* img, int rows, int co
     hipGraph_t graph = nullptr;
     bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess;
     if (ok) {
-      ok = hipMemcpy2DAsync(ctx->d_stage_img, pitch, ctx->h_in, (size_t)cols, (size_t)cols, (size_t)rows, hipMemcpyHostToDevice, st) == hipSuccess;
+      // the upload: a kernel pulling the rows from the mapped pinned buffer with 16-byte loads (k_upload_rows) where the shape allows,
+      // otherwise a copy node
+      uint8_t* hdev = nullptr;
+      static const int upload_kernel = getenv("ORBX_UPLOAD_KERNEL") ? atoi(getenv("ORBX_UPLOAD_KERNEL")) : 1;   // A/B knob
+      if (upload_kernel && (cols & 15) == 0 && hipHostGetDevicePointer((void**)&hdev, ctx->h_in, 0) == hipSuccess && hdev) {
+        const int row16 = cols / 16, n = rows * row16;
+        hipLaunchKernelGGL(k_upload_rows, dim3(std::min((n + 255) / 256, 512)), dim3(256), 0, st, (const uint4*)hdev, ctx->d_stage_img, rows, row16, (int)pitch);
+        ok = hipGetLastError() == hipSuccess;
+      } else {
+        (void)hipGetLastError();
+        ok = hipMemcpy2DAsync(ctx->d_stage_img, pitch, ctx->h_in, (size_t)cols, (size_t)cols, (size_t)rows, hipMemcpyHostToDevice, st) == hipSuccess;
+      }
       if (ok) ok = launch_pipeline(ctx, ctx->d_stage_img, 0, 1, rows, cols, pitch, fbytes, lap0, lap1, (orbx_keypoint*)(d + L.kps_off),
                                    d + L.desc_off, (int32_t*)(d + L.counts_off), st) == ORBX_OK;
       // keypoints | descriptors | counts are one staging block with the same layout on both sides: ONE copy node (every node of

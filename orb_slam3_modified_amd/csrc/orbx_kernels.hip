@@ -59,6 +59,17 @@ __device__ __forceinline__ int xcd_logical_block(int n_items) {
   return L < n_items ? L : -1;
 }
 
+// The single-frame path's upload as a kernel: rows of `row16` 16-byte units from the caller's image in mapped pinned host memory (tight
+// rows) into the staging image (pitch `dst_pitch`).  A copy NODE costs 11.6 us of DMA for 300 KB plus a 7.7 us hand-over to the first
+// kernel; wide loads from a kernel pull the same bytes over PCIe without the hand-over.
+__global__ __launch_bounds__(256) void k_upload_rows(const uint4* __restrict__ src, uint8_t* __restrict__ dst, int rows, int row16, int dst_pitch) {
+  const int n = rows * row16;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int r = i / row16, c = i - r * row16;
+    *(uint4*)(dst + (size_t)r * dst_pitch + 16 * c) = src[i];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1: cv::resize INTER_LINEAR, CV_8UC1 (src/ORBextractor.cc:1183), one pyramid level from the previous one.
 // The byte-gather formulation is bound by the texture-address unit (one VMEM instruction per source byte), so a
