@@ -423,10 +423,74 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
     launch_fast(0, ncells0, fst);
     ORBX_HIP(ctx, hipEventRecord(ctx->ev_f0_join[sb], fst));
   }
+  // small batches (the single-frame graph): every launch costs about 5 us of device time whatever it does, so FAST and the blur —
+  // both only read the finished pyramid — share one launch, and the assembly runs as the tail of the quadtree launch
+  // (latency-bound calls only: at 32 frames of 1024 x 1024 — config 4's replay lanes, still a "small batch" by the fork rule above — the shared
+  // launch with its 256-thread FAST workgroups and worst-case LDS costs 20 % of the throughput)
+  const bool small_fused = small_batch && nframes <= 4 && ctx->small_fused && !ctx->profiling && ctx->fast_stop == 0;
+  // K1, small batches: groups of consecutive levels in one launch each (k_resize_chain); the plan (which levels, LDS rectangles) and
+  // the coverage check run on the host tables; anything the plan cannot serve takes the launch per level below
+  int chained_upto = 0;   // levels 1 .. chained_upto are produced by chain launches
+  if (small_fused && geo.nlevels > 2) {
+    int l = 1;
+    while (l < geo.nlevels) {
+      const int left = geo.nlevels - l;
+      const int K = left == 3 ? 3 : (left >= 2 ? 2 : 1);
+      if (K == 1) break;
+      // rectangles of every tile of the group's last level, as the kernel derives them
+      const LevelGeom& LD = geo.lv[l + K - 1];
+      const int nbx = (LD.w + kRT_W - 1) / kRT_W, nby = (LD.h + kRT_H - 1) / kRT_H;
+      int mw[4] = {0, 0, 0, 0}, mh[4] = {0, 0, 0, 0};
+      std::vector<std::vector<uint8_t> > colhit(K), rowhit(K);
+      for (int k = 1; k < K; k++) { colhit[k].assign(geo.lv[l + k - 1].w, 0); rowhit[k].assign(geo.lv[l + k - 1].h, 0); }
+      for (int b = 0; b < std::max(nbx, nby); b++) {   // columns and rows are independent: one sweep over tile columns, one over tile rows
+        int X0 = b * kRT_W, X1 = std::min(b * kRT_W + kRT_W, LD.w) - 1, Y0 = b * kRT_H, Y1 = std::min(b * kRT_H + kRT_H, LD.h) - 1;
+        for (int k = K; k >= 1; k--) {
+          const LevelGeom& L = geo.lv[l + k - 1];
+          if (b < nbx) {
+            const XTab ta = geo.xtab[L.xtab_off + X0], tb = geo.xtab[L.xtab_off + std::min(X1, L.w - 1)];
+            X0 = (int)ta.s0 & ~3; X1 = std::max((int)tb.s0, (int)tb.s1) | 3;
+            mw[k - 1] = std::max(mw[k - 1], X1 - X0 + 1);
+            if (k - 1 >= 1) for (int x = X0; x <= std::min(X1, (int)colhit[k - 1].size() - 1); x++) colhit[k - 1][x] = 1;
+          }
+          if (b < nby) {
+            const XTab ua = geo.ytab[L.ytab_off + Y0], ub = geo.ytab[L.ytab_off + Y1];
+            Y0 = ua.s0; Y1 = std::max((int)ub.s0, (int)ub.s1);
+            mh[k - 1] = std::max(mh[k - 1], Y1 - Y0 + 1);
+            if (k - 1 >= 1) for (int y = Y0; y <= Y1; y++) rowhit[k - 1][y] = 1;
+          }
+        }
+      }
+      bool covered = true;
+      for (int k = 1; k < K && covered; k++) {
+        for (uint8_t h : colhit[k]) covered = covered && h;
+        for (uint8_t h : rowhit[k]) covered = covered && h;
+      }
+      size_t lds = 0;
+      int off[3] = {0, 0, 0};
+      for (int k = 0; k < K; k++) { off[k] = (int)lds; lds += (size_t)mw[k] * mh[k]; lds = (lds + 15) & ~(size_t)15; }
+      if (!covered || lds > 64 * 1024) break;
+      auto fill = [&](auto& ca) {
+        if (l == 1) { ca.src = d_imgs; ca.src_frame_stride = (long long)frame_stride; ca.src_pitch = (int)row_stride; }
+        else { ca.src = b_pyr + geo.lv[l - 1].plane_off; ca.src_frame_stride = geo.pyr_bytes; ca.src_pitch = geo.lv[l - 1].pitch; }
+        ca.sw = geo.lv[l - 1].w; ca.dst_frame_stride = (long long)geo.pyr_bytes; ca.nbx = nbx; ca.nby = nby;
+        for (int k = 0; k < K; k++) {
+          const LevelGeom& L = geo.lv[l + k];
+          ca.lv[k].xt = ctx->d_xtab + L.xtab_off; ca.lv[k].yt = ctx->d_ytab + L.ytab_off; ca.lv[k].dst = b_pyr + L.plane_off;
+          ca.lv[k].pitch = L.pitch; ca.lv[k].w = L.w; ca.lv[k].h = L.h;
+          ca.buf_off[k] = off[k]; ca.buf_pitch[k] = mw[k];
+        }
+      };
+      if (K == 2) { ChainArgs<2> ca; fill(ca); hipLaunchKernelGGL(k_resize_chain<2>, dim3(nbx * nby, nframes), dim3(ctx->chain_threads), lds, st, ca); }
+      else { ChainArgs<3> ca; fill(ca); hipLaunchKernelGGL(k_resize_chain<3>, dim3(nbx * nby, nframes), dim3(ctx->chain_threads), lds, st, ca); }
+      chained_upto = l + K - 1;
+      l += K;
+    }
+  }
   // K1: pyramid chain (levels depend on each other: one launch per level over the whole batch)
   {
     ProfScope ps(ctx, 0, st);
-    for (int l = 1; l < geo.nlevels; l++) {
+    for (int l = chained_upto + 1; l < geo.nlevels; l++) {
       const LevelGeom& D = geo.lv[l];
       const LevelGeom& S = geo.lv[l - 1];
       const uint8_t* src; long long sfs; int sp;
@@ -440,11 +504,6 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
                          256 / (D.rs_lds_pitch / 4));
     }
   }
-  // small batches (the single-frame graph): every launch costs about 5 us of device time whatever it does, so FAST and the blur —
-  // both only read the finished pyramid — share one launch, and the assembly runs as the tail of the quadtree launch
-  // (latency-bound calls only: at 32 frames of 1024 x 1024 — config 4's replay lanes, still a "small batch" by the fork rule above — the shared
-  // launch with its 256-thread FAST workgroups and worst-case LDS costs 20 % of the throughput)
-  const bool small_fused = small_batch && nframes <= 4 && ctx->small_fused && !ctx->profiling && ctx->fast_stop == 0;
   BlurConsts bc;
   {
     int gk[7];
@@ -695,6 +754,7 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, 
   }
   ctx->fast_threads = fast_threads_from_env();
   { const char* e = getenv("ORBX_SMALL_FUSED"); ctx->small_fused = e ? atoi(e) != 0 : true; }
+  { const char* e = getenv("ORBX_CHAIN_THREADS"); const int v = e ? atoi(e) : 1024; ctx->chain_threads = (v == 256 || v == 512 || v == 1024) ? v : 1024; }
   { const char* e = getenv("ORBX_QT_POINTS"); const int v = e ? atoi(e) : kQtLdsPoints; ctx->qt_points = (v >= 256 && v <= 4096 && v % 128 == 0) ? v : kQtLdsPoints; }
   { const char* e = getenv("ORBX_FAST_SPLIT"); ctx->fast_split = e ? atoi(e) != 0 : true; }
   { const char* e = getenv("ORBX_WINDOW_DIRECT"); ctx->window_direct = e ? atoi(e) != 0 : true; }

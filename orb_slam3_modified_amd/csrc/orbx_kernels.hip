@@ -169,6 +169,108 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
 }
 
 // ------------------------------------------------------------------------------------------------
+// K1, small batches: K consecutive pyramid levels in ONE launch.  Inside the single-frame graph every launch costs about 5 us whatever
+// it does, and the seven dependent resizes were 38 us of a 150 us frame.  Here a workgroup owns one 64x64 tile of the LAST level of
+// the group and computes, in LDS, the rectangles of the intermediate levels that tile needs (at scale 1.2 a halo of a few pixels: 6 %
+// redundant work per level), writing them to the pyramid on the way.  Neighbouring workgroups write the overlap of their rectangles
+// with identical bytes (every pixel is the same function of the same source pixels); rectangles are dword-aligned so that no store
+// touches a byte its workgroup did not compute; together the rectangles cover every pixel of the intermediate levels (the host
+// checks this on the tables before it takes this path).  Same arithmetic as resize_tile: bytes identical to the separate launches.
+// ------------------------------------------------------------------------------------------------
+struct ChainLevel { const XTab* xt; const XTab* yt; uint8_t* dst; int pitch, w, h; };
+template <int K>
+struct ChainArgs {
+  const uint8_t* src; long long src_frame_stride, dst_frame_stride; int src_pitch, sw;
+  ChainLevel lv[K];          // destination levels, in order
+  int nbx, nby;              // tiles of the last level
+  int buf_off[K], buf_pitch[K];   // LDS rectangles: [0] = source, [k] = destination level k - 1 of the group (k < K)
+};
+
+__device__ __forceinline__ uint32_t chain_px4(const uint8_t* __restrict__ prev, int pp, int ox, int oy, const XTab* __restrict__ xt,
+                                              const XTab ty, int x4, int w) {
+  const uint8_t* R0 = prev + ((int)ty.s0 - oy) * pp;
+  const uint8_t* R1 = prev + ((int)ty.s1 - oy) * pp;
+  const int b0 = ty.a0, b1 = ty.a1;
+  uint32_t packed = 0;
+  XTab txs[4];
+  if (x4 + 3 < w) {   // the level tables are 32-byte aligned and x4 is a multiple of 4: two 16-byte loads
+    const uint4 q0 = *(const uint4*)(xt + x4), q1 = *(const uint4*)(xt + x4 + 2);
+    txs[0] = *(const XTab*)&q0.x; txs[1] = *(const XTab*)&q0.z; txs[2] = *(const XTab*)&q1.x; txs[3] = *(const XTab*)&q1.z;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; i++) txs[i] = xt[min(x4 + i, w - 1)];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const XTab tx = txs[i];
+    const int c0 = (int)tx.s0 - ox, c1 = (int)tx.s1 - ox, a0 = tx.a0, a1 = tx.a1;
+    const int h0 = (int)R0[c0] * a0 + (int)R0[c1] * a1;
+    const int h1 = (int)R1[c0] * a0 + (int)R1[c1] * a1;
+    const int v = ((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xff;
+    packed |= (uint32_t)v << (8 * i);
+  }
+  return packed;
+}
+
+template <int K>
+__global__ __launch_bounds__(1024) void k_resize_chain(const ChainArgs<K> a) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  const int t = threadIdx.x, T = blockDim.x, frame = blockIdx.y;
+  const int by = (int)blockIdx.x / a.nbx, bx = (int)blockIdx.x - by * a.nbx;
+  // rectangles, inclusive: [k] for k = K (the tile of the last level) down to 0 (the source); columns of k < K span whole dwords
+  int X0[K + 1], X1[K + 1], Y0[K + 1], Y1[K + 1];
+  X0[K] = bx * kRT_W; X1[K] = min(bx * kRT_W + kRT_W, a.lv[K - 1].w) - 1;
+  Y0[K] = by * kRT_H; Y1[K] = min(by * kRT_H + kRT_H, a.lv[K - 1].h) - 1;
+#pragma unroll
+  for (int k = K; k >= 1; k--) {
+    const ChainLevel& L = a.lv[k - 1];
+    const XTab ta = L.xt[X0[k]], tb = L.xt[min(X1[k], L.w - 1)], ua = L.yt[Y0[k]], ub = L.yt[Y1[k]];
+    X0[k - 1] = (int)ta.s0 & ~3; X1[k - 1] = max((int)tb.s0, (int)tb.s1) | 3;
+    Y0[k - 1] = ua.s0; Y1[k - 1] = max((int)ub.s0, (int)ub.s1);
+  }
+  // ---- stage the source rectangle
+  {
+    const uint8_t* S = a.src + (long long)frame * a.src_frame_stride + (long long)Y0[0] * a.src_pitch + X0[0];
+    uint8_t* B = smem + a.buf_off[0];
+    const int bp = a.buf_pitch[0], nd = (X1[0] - X0[0] + 1) >> 2, nr = Y1[0] - Y0[0] + 1, swr = (a.sw + 3) & ~3;
+    const bool al = ((a.src_pitch & 3) == 0) && ((((unsigned long long)a.src) & 3) == 0) && ((a.src_frame_stride & 3) == 0);
+    const uint32_t m = nd > 1 ? (uint32_t)(((1ull << 32) + nd - 1) / nd) : 0u;
+    for (int i = t; i < nd * nr; i += T) {
+      const int r = fast_div(i, m), c = i - r * nd;
+      uint32_t v = 0;
+      if (X0[0] + 4 * c < swr) {
+        if (al) v = *(const uint32_t*)(S + (long long)r * a.src_pitch + 4 * c);
+        else {
+          const uint8_t* q = S + (long long)r * a.src_pitch + 4 * c;
+#pragma unroll
+          for (int j = 0; j < 4; j++) v |= (uint32_t)((X0[0] + 4 * c + j < a.sw) ? q[j] : 0) << (8 * j);
+        }
+      }
+      *(uint32_t*)(B + r * bp + 4 * c) = v;
+    }
+  }
+  __syncthreads();
+  // ---- level by level
+#pragma unroll
+  for (int k = 1; k <= K; k++) {
+    const ChainLevel& L = a.lv[k - 1];
+    const uint8_t* prev = smem + a.buf_off[k - 1];
+    const int pp = a.buf_pitch[k - 1];
+    const int nd = (X1[k] - X0[k] + 4) >> 2, nr = Y1[k] - Y0[k] + 1;   // k == K: the tile may end inside a dword (the pad bytes repeat the last pixel)
+    uint8_t* outp = L.dst + (long long)frame * a.dst_frame_stride;
+    const uint32_t m = nd > 1 ? (uint32_t)(((1ull << 32) + nd - 1) / nd) : 0u;
+    for (int i = t; i < nd * nr; i += T) {
+      const int r = fast_div(i, m), c = i - r * nd;
+      const int y = Y0[k] + r, x4 = X0[k] + 4 * c;
+      const uint32_t packed = chain_px4(prev, pp, X0[k - 1], Y0[k - 1], L.xt, L.yt[y], x4, L.w);
+      if (x4 < ((L.w + 3) & ~3)) *(uint32_t*)(outp + (long long)y * L.pitch + x4) = packed;
+      if (k < K) *(uint32_t*)(smem + a.buf_off[k] + r * a.buf_pitch[k] + 4 * c) = packed;
+    }
+    if (k < K) __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K2: FAST score + per-cell NMS + threshold selection + ordered compaction.
 // ------------------------------------------------------------------------------------------------
 // S(p) = max over the 16 nine-pixel arcs of min(v - p_k), and the same for (p_k - v), minus 1:
