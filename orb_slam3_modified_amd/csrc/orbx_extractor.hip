@@ -317,9 +317,13 @@ static void gaussian_kernel7(int k[7]) {
 
 // One pass of the hot path over frames [f0, f0 + nframes) of the batch, on stream `st`.  Every buffer is indexed by
 // frame, so a sub-batch is the same launch sequence on offset base pointers.
+// mirror (optional): device-visible addresses of the caller's pinned result block — the single-frame graph lets the last kernels write
+// keypoints, descriptors and counts there as well, instead of a download node; *mirrored tells whether that happened
+struct ResultMirror { orbx_keypoint* kps = nullptr; uint8_t* desc = nullptr; int32_t* counts = nullptr; };
 static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nframes, int rows, int cols, size_t row_stride,
                            size_t frame_stride, int lap0, int lap1, orbx_keypoint* d_kps, uint8_t* d_desc,
-                           int32_t* d_counts, hipStream_t st) {
+                           int32_t* d_counts, hipStream_t st, const ResultMirror* mirror = nullptr, bool* mirrored = nullptr) {
+  if (mirrored) *mirrored = false;
   const Geometry& geo = ctx->geo;
   d_imgs += (size_t)f0 * frame_stride;
   d_kps += (size_t)f0 * ctx->out_cap;
@@ -608,6 +612,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
         qa.g = ctx->d_geo; qa.cells = ctx->d_cells; qa.cand = b_cand; qa.cell_cnt = b_cell_cnt; qa.pts = b_pts; qa.lvl_kp = b_lvl_kp; qa.lvl_n = b_lvl_n;
         qa.node_cap = node_cap; qa.scan_cap = scan_cap; qa.pts_cap = qt_pts;
         qa.kp_list = b_kp_list; qa.counts = d_counts; qa.lap0 = lap0; qa.lap1 = lap1; qa.fin = ctx->d_qt_fin;
+        qa.mirror_counts = (mirror && nframes == 1) ? mirror->counts : nullptr;
         hipLaunchKernelGGL(k_quadtree_assemble, dim3(geo.nlevels, nframes, 1), dim3(ctx->qt_threads ? ctx->qt_threads : 512), lds, st, qa);
         assembled = true;
       }
@@ -642,6 +647,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
   if (fork_blur) { ORBX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_blur_join[f0 != 0], 0)); forks.joined(bst); }
   {
     ProfScope ps(ctx, 5, st);
+    const bool use_mirror = mirror && assembled && nframes == 1 && mirror->kps && mirror->desc && mirror->counts;   // counts were mirrored by the quadtree's tail
     DescConsts dc;
     for (int i = 0; i < 16; i++) dc.umax[i] = ctx->umax[i];
     const int K = ctx->desc_k;  // keypoints per wave
@@ -650,7 +656,9 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
     if (ctx->desc_lds && (K == 2 || K == 4 || K == 8)) kern = K == 2 ? k_describe<2, true> : K == 4 ? k_describe<4, true> : k_describe<8, true>;
     hipLaunchKernelGGL(kern, dim3(xcd_grid(nitems)), dim3(256), 0, st, ctx->d_geo, d_imgs, (long long)row_stride,
                        (long long)frame_stride, b_pyr, (long long)geo.pyr_bytes, b_blur, (long long)geo.blur_bytes,
-                       b_kp_list, d_counts, d_kps, d_desc, dc, gpf, nitems, div_magic((uint32_t)gpf));
+                       b_kp_list, d_counts, d_kps, d_desc, dc, gpf, nitems, div_magic((uint32_t)gpf),
+                       use_mirror ? mirror->kps : (orbx_keypoint*)nullptr, use_mirror ? mirror->desc : (uint8_t*)nullptr);
+    if (use_mirror && mirrored) *mirrored = true;
   }
   ORBX_HIP(ctx, hipGetLastError());
   return ORBX_OK;
@@ -931,7 +939,7 @@ static int ensure_stage(orbx_ctx* ctx, int nframes, size_t img_bytes) {
     ctx->d_stage_out = nullptr; ctx->h_stage_out = nullptr; ctx->stage_frames = 0;
     const StageLayout L = stage_layout(ctx, nframes);
     ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_stage_out, L.bytes));
-    ORBX_HIP(ctx, hipHostMalloc((void**)&ctx->h_stage_out, L.bytes, hipHostMallocDefault));
+    ORBX_HIP(ctx, hipHostMalloc((void**)&ctx->h_stage_out, L.bytes, hipHostMallocMapped));
     ctx->stage_frames = nframes;
     ctx->buf_epoch++;
   }
@@ -981,12 +989,20 @@ static int extract_one_graph(orbx_ctx* ctx, const uint8_t* img, int rows, int co
         (void)hipGetLastError();
         ok = hipMemcpy2DAsync(ctx->d_stage_img, pitch, ctx->h_in, (size_t)cols, (size_t)cols, (size_t)rows, hipMemcpyHostToDevice, st) == hipSuccess;
       }
+      // results: the last kernels write them into the pinned block themselves (mapped view) where the fused single-frame launches are
+      // in use; otherwise ONE copy node (every node of the graph costs about 5 us of device time, whatever it moves)
+      ResultMirror mir;
+      uint8_t* hout_dev = nullptr;
+      static const bool mirror_on = !(getenv("ORBX_MIRROR") && atoi(getenv("ORBX_MIRROR")) == 0);   // A/B knob
+      if (mirror_on && hipHostGetDevicePointer((void**)&hout_dev, ctx->h_stage_out, 0) == hipSuccess && hout_dev) {
+        mir.kps = (orbx_keypoint*)(hout_dev + L.kps_off); mir.desc = hout_dev + L.desc_off; mir.counts = (int32_t*)(hout_dev + L.counts_off);
+      } else (void)hipGetLastError();
+      bool mirrored = false;
       if (ok) ok = launch_pipeline(ctx, ctx->d_stage_img, 0, 1, rows, cols, pitch, fbytes, lap0, lap1, (orbx_keypoint*)(d + L.kps_off),
-                                   d + L.desc_off, (int32_t*)(d + L.counts_off), st) == ORBX_OK;
-      // keypoints | descriptors | counts are one staging block with the same layout on both sides: ONE copy node (every node of
-      // the graph costs about 5 us of device time, whatever it moves: three copies were 15 us of a 140 us frame)
+                                   d + L.desc_off, (int32_t*)(d + L.counts_off), st, &mir, &mirrored) == ORBX_OK;
       const size_t kb = (size_t)ctx->out_cap * sizeof(orbx_keypoint), db = (size_t)ctx->out_cap * 32, cb = 2 * sizeof(int32_t);
-      if (ctx->stage_frames == 1) {
+      if (mirrored) {
+      } else if (ctx->stage_frames == 1) {
         if (ok) ok = hipMemcpyAsync(ctx->h_stage_out, d, L.counts_off + cb, hipMemcpyDeviceToHost, st) == hipSuccess;
       } else {   // the staging block was laid out for an earlier, larger batch: this frame's three ranges
         if (ok) ok = hipMemcpyAsync(ctx->h_stage_out + L.kps_off, d + L.kps_off, kb, hipMemcpyDeviceToHost, st) == hipSuccess;

@@ -1708,7 +1708,8 @@ template <bool GS>
 __device__ __forceinline__ void assemble_main(const DeviceGeom* __restrict__ g, const uint32_t* __restrict__ lvl_kp,
                                               const int32_t* __restrict__ lvl_n, uint2* __restrict__ kp_list,
                                               int32_t* __restrict__ counts, int lap0, int lap1, unsigned long long* scan,
-                                              unsigned long long* wt, int* loff, int* s_overflow, const int frame) {
+                                              unsigned long long* wt, int* loff, int* s_overflow, const int frame,
+                                              int32_t* __restrict__ mirror_counts = nullptr) {
   const int t = threadIdx.x, T = blockDim.x;
   if (t == 0) {
     int acc = 0, ovf = 0;
@@ -1745,7 +1746,10 @@ __device__ __forceinline__ void assemble_main(const DeviceGeom* __restrict__ g, 
     const int slot = st ? total - 1 - pre : i - pre;
     kp_list[(long long)frame * g->out_cap + i] = make_uint2(p, (uint32_t)l | ((uint32_t)slot << 8));
   }
-  if (t == 0) { counts[frame * 2] = *s_overflow ? -1 : total; counts[frame * 2 + 1] = total - nst; }
+  if (t == 0) {
+    counts[frame * 2] = *s_overflow ? -1 : total; counts[frame * 2 + 1] = total - nst;
+    if (mirror_counts) { mirror_counts[frame * 2] = *s_overflow ? -1 : total; mirror_counts[frame * 2 + 1] = total - nst; }
+  }
 }
 
 // gscan: per-frame scan scratch in HBM for capacities whose scan array does not fit the LDS (nullptr: LDS)
@@ -1770,7 +1774,7 @@ struct QtaArgs {
   const DeviceGeom* g; const CellGeom* cells; const uint32_t* cand; const int32_t* cell_cnt; uint32_t* pts; uint32_t* lvl_kp; int32_t* lvl_n;
   int node_cap, scan_cap, pts_cap;
   // the tail's own arguments: read from the kernel-argument segment AFTER the quadtree (see below)
-  uint2* kp_list; int32_t* counts; int lap0, lap1; int* fin;
+  uint2* kp_list; int32_t* counts; int lap0, lap1; int* fin; int32_t* mirror_counts;
 };
 __global__ __launch_bounds__(512, ORBX_QT_WPE) void k_quadtree_assemble(const QtaArgs a) {
   extern __shared__ __align__(16) uint8_t smem[];
@@ -1798,7 +1802,8 @@ __global__ __launch_bounds__(512, ORBX_QT_WPE) void k_quadtree_assemble(const Qt
   __syncthreads();
   if (!s_last) return;   // block-uniform
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  assemble_main<false>(ap->g, ap->lvl_kp, ap->lvl_n, ap->kp_list, ap->counts, ap->lap0, ap->lap1, (unsigned long long*)smem, wt, loff, &s_overflow, frame);
+  assemble_main<false>(ap->g, ap->lvl_kp, ap->lvl_n, ap->kp_list, ap->counts, ap->lap0, ap->lap1, (unsigned long long*)smem, wt, loff, &s_overflow, frame,
+                       ap->mirror_counts);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2055,7 +2060,8 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
                                                   const uint8_t* __restrict__ blur, long long blur_frame_bytes,
                                                   const uint2* __restrict__ kp_list, const int32_t* __restrict__ counts,
                                                   orbx_keypoint* __restrict__ out_kps, uint8_t* __restrict__ out_desc,
-                                                  DescConsts dc, int groups_per_frame, int nitems, uint32_t m_gpf) {
+                                                  DescConsts dc, int groups_per_frame, int nitems, uint32_t m_gpf,
+                                                  orbx_keypoint* __restrict__ mirror_kps, uint8_t* __restrict__ mirror_desc) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int L = xcd_logical_block(nitems);
   if (L < 0) return;
@@ -2219,6 +2225,9 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
       if (lane == q) mine = bits;
     }
     if (lane < 4) *(unsigned long long*)(out_desc + ((long long)frame * g->out_cap + slot) * 32 + lane * 8) = mine;
+    // the single-frame graph: the same rows straight into the caller-visible pinned block (no download node; the HBM copy stays for the
+    // searches that take the rows from there)
+    if (mirror_desc && lane < 4) *(unsigned long long*)(mirror_desc + ((long long)frame * g->out_cap + slot) * 32 + lane * 8) = mine;
     if (lane == 0) {
       orbx_keypoint kp;
       float fx = (float)kx, fy = (float)ky;
@@ -2226,6 +2235,7 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
       kp.x = fx; kp.y = fy; kp.size = (float)lv.scaled_patch; kp.angle = angle; kp.response = (float)pt_s(p);
       kp.octave = l; kp.class_id = -1;
       out_kps[(long long)frame * g->out_cap + slot] = kp;
+      if (mirror_kps) mirror_kps[(long long)frame * g->out_cap + slot] = kp;
     }
   }
 }
