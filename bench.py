@@ -240,8 +240,9 @@ def e2e_operator(host_frames, nfeatures):
         if r.returncode != 0:
             return {"error": (r.stderr or r.stdout).strip()[:200]}
         out = json.loads(r.stdout.strip().splitlines()[-1])
-        out["what"] = ("ORB_SLAM3::ORBextractor::operator() through include/ORBextractor.h, one frame per call, host buffers: H2D image, "
-                       "kernels, D2H keypoints + descriptors (PCIe-inclusive, latency-bound; never the headline value)")
+        out["what"] = ("ORB_SLAM3::ORBextractor::operator() through include/ORBextractor.h, one frame per call, host buffers: image in, "
+                       "kernels, keypoints + descriptors + the host mirror of mvImagePyramid out (PCIe-inclusive, latency-bound; never the "
+                       "headline value); ms_per_frame_without_host_pyramid = the same with SetKeepHostPyramid(false), the monocular setting")
         return out
     except Exception as e:   # noqa: BLE001 — a missing compiler must not fail the benchmark line
         return {"error": str(e)[:200]}

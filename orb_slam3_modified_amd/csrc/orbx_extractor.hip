@@ -650,7 +650,9 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
     const bool use_mirror = mirror && assembled && nframes == 1 && mirror->kps && mirror->desc && mirror->counts;   // counts were mirrored by the quadtree's tail
     DescConsts dc;
     for (int i = 0; i < 16; i++) dc.umax[i] = ctx->umax[i];
-    const int K = ctx->desc_k;  // keypoints per wave
+    // keypoints per wave: K = 4 amortises the trig pass in a batch; a single frame has 1000 keypoints for 1024 SIMDs and is served fastest by
+    // one keypoint per wave (operator() -6 us) unless the caller chose a value
+    const int K = (small_fused && !ctx->desc_k_user) ? 1 : ctx->desc_k;
     const int gpf = (ctx->out_cap + 4 * K - 1) / (4 * K), nitems = gpf * nframes;
     auto kern = K == 1 ? k_describe<1> : K == 2 ? k_describe<2> : K == 4 ? k_describe<4> : K == 8 ? k_describe<8> : k_describe<16>;
     if (ctx->desc_lds && (K == 2 || K == 4 || K == 8)) kern = K == 2 ? k_describe<2, true> : K == 4 ? k_describe<4, true> : k_describe<8, true>;
@@ -771,6 +773,7 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, 
     const char* e = getenv("ORBX_DESC_K");  // keypoints per wave of k_describe (tuning knob)
     const int v = e ? atoi(e) : 4;
     ctx->desc_k = (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ? v : 4;
+    ctx->desc_k_user = e != nullptr;
   }
   ctx->out_cap = 0;
   for (int l = 0; l < nlevels; l++) ctx->out_cap += std::max(ctx->quota[l] + 3, 4 * kMaxRoots);
@@ -1287,7 +1290,7 @@ int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
   else if (n == "desc_lds") ctx->desc_lds = value != 0;
   else if (n == "fast_threads" && (value == 64 || value == 128 || value == 256)) ctx->fast_threads = value;
   else if (n == "qt_threads" && (value == 0 || value == 64 || value == 128 || value == 256 || value == 512)) ctx->qt_threads = value;   // 0: chosen by batch size
-  else if (n == "desc_k" && (value == 1 || value == 2 || value == 4 || value == 8 || value == 16)) ctx->desc_k = value;
+  else if (n == "desc_k" && (value == 1 || value == 2 || value == 4 || value == 8 || value == 16)) { ctx->desc_k = value; ctx->desc_k_user = true; }
   else if (n == "streams" && value >= 1 && value <= 2) ctx->nstreams = value;
   else return set_err(ctx, ORBX_E_INVALID, "orbx_set_option: unknown option or value out of range: " + n);
   ctx->buf_epoch++;   // a captured single-frame graph holds the launch shape of the old options: capture again

@@ -140,6 +140,7 @@ struct orbx_ctx {
   int qt_threads = 0;      // workgroup size of k_quadtree (0: by batch size)
   bool fast_split = true;  // k_fast_cells launched per group of levels, each with its own LDS footprint
   int desc_k = 8;          // keypoints per wave of k_describe
+  bool desc_k_user = false; // set by ORBX_DESC_K / "desc_k": the single-frame path then keeps it instead of choosing 1
 
   hipStream_t stream = nullptr;
   static constexpr int kMaxAux = 8;

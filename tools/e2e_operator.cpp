@@ -21,20 +21,25 @@ int main(int argc, char** argv) {
     std::vector<cv::KeyPoint> keys;
     cv::Mat desc;
     long total = 0;
-    double ms = 0;
-    for (int pass = 0; pass < 2; pass++) {   // pass 0 = warm-up
-      total = 0;
-      const auto t0 = std::chrono::steady_clock::now();
-      for (int rep = 0; rep < (pass ? reps : 2); rep++)
-        for (int f = 0; f < nfr; f++) {
-          cv::Mat im(rows, cols, CV_8UC1, buf.data() + (size_t)f * rows * cols);
-          ex(im, cv::Mat(), keys, desc, lap);
-          total += (long)keys.size();
-        }
-      ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    double ms = 0, ms_mono = 0;
+    // mode 0: as constructed — the host mirror of mvImagePyramid refreshed on every call (stereo reads it, src/Frame.cc:818,908-925);
+    // mode 1: SetKeepHostPyramid(false), what a monocular configuration would set
+    for (int mode = 0; mode < 2; mode++) {
+      ex.SetKeepHostPyramid(mode == 0);
+      for (int pass = 0; pass < 2; pass++) {   // pass 0 = warm-up
+        total = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int rep = 0; rep < (pass ? reps : 2); rep++)
+          for (int f = 0; f < nfr; f++) {
+            cv::Mat im(rows, cols, CV_8UC1, buf.data() + (size_t)f * rows * cols);
+            ex(im, cv::Mat(), keys, desc, lap);
+            total += (long)keys.size();
+          }
+        (mode ? ms_mono : ms) = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      }
     }
-    std::printf("{\"frames\": %d, \"ms_per_frame\": %.5f, \"features_per_ms\": %.2f, \"features_per_frame\": %.1f}\n", reps * nfr, ms / (reps * nfr),
-                total / ms, (double)total / (reps * nfr));
+    std::printf("{\"frames\": %d, \"ms_per_frame\": %.5f, \"features_per_ms\": %.2f, \"features_per_frame\": %.1f, \"ms_per_frame_without_host_pyramid\": %.5f}\n",
+                reps * nfr, ms / (reps * nfr), total / ms, (double)total / (reps * nfr), ms_mono / (reps * nfr));
   } catch (const std::exception& e) {
     std::fprintf(stderr, "e2e_operator: %s\n", e.what());
     return 3;
