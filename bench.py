@@ -242,7 +242,10 @@ def e2e_operator(host_frames, nfeatures):
         out = json.loads(r.stdout.strip().splitlines()[-1])
         out["what"] = ("ORB_SLAM3::ORBextractor::operator() through include/ORBextractor.h, one frame per call, host buffers: image in, "
                        "kernels, keypoints + descriptors + the host mirror of mvImagePyramid out (PCIe-inclusive, latency-bound; never the "
-                       "headline value); ms_per_frame_without_host_pyramid = the same with SetKeepHostPyramid(false), the monocular setting")
+                       "headline value); ms_per_frame_without_host_pyramid = the same with SetKeepHostPyramid(false), the monocular setting; "
+                       "device_ms_per_frame = HIP events around the replayed graph (upload kernel, three pyramid groups, FAST + blur, quadtree + "
+                       "assembly, descriptors[, pyramid mirror]): the kernels' share of a call, the rest is the host (image into the pinned buffer, "
+                       "graph launch, wake-up)")
         return out
     except Exception as e:   # noqa: BLE001 — a missing compiler must not fail the benchmark line
         return {"error": str(e)[:200]}

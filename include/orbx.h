@@ -166,6 +166,10 @@ int orbx_debug_calib_copy(orbx_ctx* ctx, const void* d_src, void* d_dst, size_t 
 int orbx_profile_enable(orbx_ctx* ctx, int on);
 int orbx_profile_read(orbx_ctx* ctx, double ms[ORBX_NUM_KERNELS], int64_t launches[ORBX_NUM_KERNELS]);
 const char* orbx_kernel_name(int slot);
+/* Device time of the single-frame path: with "graph_timing" set (orbx_set_option) every orbx_extract records an event before and after
+ * its replayed graph; this returns the last call's elapsed device time in microseconds (< 0: no timed call yet).  The host part of a call
+ * (image into the pinned buffer, graph launch, wake-up) is the call's wall time minus this. */
+double orbx_last_graph_device_us(orbx_ctx* ctx);
 
 /* ---- matcher primitives: replace the inner loops of ORB_SLAM3::ORBmatcher --------------------------- */
 

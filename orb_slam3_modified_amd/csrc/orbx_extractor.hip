@@ -837,6 +837,8 @@ void orbx_destroy(orbx_ctx* ctx) {
   if (ctx->ev_handover) { (void)hipEventDestroy(ctx->ev_handover); ctx->ev_handover = nullptr; }
   if (ctx->d_win_ctr) { (void)hipFree(ctx->d_win_ctr); ctx->d_win_ctr = nullptr; }
   if (ctx->d_qt_fin) { (void)hipFree(ctx->d_qt_fin); ctx->d_qt_fin = nullptr; }
+  if (ctx->ev_g0) { (void)hipEventDestroy(ctx->ev_g0); ctx->ev_g0 = nullptr; }
+  if (ctx->ev_g1) { (void)hipEventDestroy(ctx->ev_g1); ctx->ev_g1 = nullptr; }
   if (ctx->h_tgt) { (void)hipHostFree(ctx->h_tgt); ctx->h_tgt = nullptr; }
   if (ctx->ev_tgt) { (void)hipEventDestroy(ctx->ev_tgt); ctx->ev_tgt = nullptr; }
   if (ctx->d_color) { (void)hipFree(ctx->d_color); ctx->d_color = nullptr; }
@@ -1035,9 +1037,15 @@ static int extract_one_graph(orbx_ctx* ctx, const uint8_t* img, int rows, int co
   const double us_in = since();
   ctx->last_imgs = ctx->d_stage_img; ctx->last_row_stride = pitch; ctx->last_frame_stride = fbytes; ctx->last_nframes = 1;
   ctx->h_pyr_valid = false;
+  if (ctx->graph_timing) {
+    if (!ctx->ev_g0) { ORBX_HIP(ctx, hipEventCreate(&ctx->ev_g0)); ORBX_HIP(ctx, hipEventCreate(&ctx->ev_g1)); }
+    ORBX_HIP(ctx, hipEventRecord(ctx->ev_g0, st));
+  }
   ORBX_HIP(ctx, hipGraphLaunch(ctx->graph_exec, st));
+  if (ctx->graph_timing) ORBX_HIP(ctx, hipEventRecord(ctx->ev_g1, st));
   const double us_launch = since();
   ORBX_HIP(ctx, hipStreamSynchronize(st));
+  if (ctx->graph_timing) { float ms = 0.f; if (hipEventElapsedTime(&ms, ctx->ev_g0, ctx->ev_g1) == hipSuccess) ctx->last_graph_us = 1e3 * ms; else (void)hipGetLastError(); }
   if (trace) std::fprintf(stderr, "[orbx extract] %dx%d: image into the pinned buffer %.1f us, graph launch %.1f, wait %.1f\n", cols, rows, us_in,
                           us_launch - us_in, since() - us_launch);
   ctx->h_pyr_valid = keep && ctx->geo.pyr_bytes > 0;
@@ -1281,6 +1289,7 @@ int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
   else if (n == "fork_fast0") ctx->fork_fast0 = value != 0;
   else if (n == "fork_qt") ctx->fork_qt = value != 0;
   else if (n == "graph") ctx->use_graph = value != 0;
+  else if (n == "graph_timing") { ctx->graph_timing = value != 0; return ORBX_OK; }   // no re-capture needed
   else if (n == "fast_pk") ctx->fast_pk = value != 0;
   else if (n == "qt_points" && value >= 256 && value <= 4096 && value % 128 == 0) ctx->qt_points = value;   // LDS-resident candidates per (frame, level) of the big quadtree levels (half of it for the small ones)
   else if (n == "small_fused") ctx->small_fused = value != 0;
@@ -1296,6 +1305,8 @@ int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
   ctx->buf_epoch++;   // a captured single-frame graph holds the launch shape of the old options: capture again
   return ORBX_OK;
 }
+
+double orbx_last_graph_device_us(orbx_ctx* ctx) { return ctx ? ctx->last_graph_us : -1.0; }
 
 int orbx_set_host_pyramid(orbx_ctx* ctx, int on) {
   if (!ctx) return ORBX_E_INVALID;

@@ -193,6 +193,7 @@ struct orbx_ctx {
   int win_guess = 0;            // candidates of the last window call: how much of the pool the first read-back copy takes
   // single-frame operator() path as a replayed hipGraph (H2D, the 13 launches, D2H): one graph launch per frame instead
   // of ~16 API calls; re-captured when the shape / lapping area / buffers change, disabled on any capture failure
+  bool graph_timing = false; hipEvent_t ev_g0 = nullptr, ev_g1 = nullptr; double last_graph_us = -1.0;   // "graph_timing": events around the replayed graph
   bool use_graph = true;
   hipGraphExec_t graph_exec = nullptr;
   int graph_key[6] = {0, 0, 0, 0, 0, 0};

@@ -38,8 +38,25 @@ int main(int argc, char** argv) {
         (mode ? ms_mono : ms) = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       }
     }
-    std::printf("{\"frames\": %d, \"ms_per_frame\": %.5f, \"features_per_ms\": %.2f, \"features_per_frame\": %.1f, \"ms_per_frame_without_host_pyramid\": %.5f}\n",
-                reps * nfr, ms / (reps * nfr), total / ms, (double)total / (reps * nfr), ms_mono / (reps * nfr));
+    // the device share of a call: events around the replayed graph (a separate, short pass: the two event records cost the host a little)
+    double dev_us[2] = {0, 0};
+    orbx_set_option(ex.Context(), "graph_timing", 1);
+    for (int mode = 0; mode < 2; mode++) {
+      ex.SetKeepHostPyramid(mode == 0);
+      double acc = 0;
+      int n = 0;
+      for (int rep = 0; rep < 3; rep++)
+        for (int f = 0; f < nfr; f++) {
+          cv::Mat im(rows, cols, CV_8UC1, buf.data() + (size_t)f * rows * cols);
+          ex(im, cv::Mat(), keys, desc, lap);
+          const double us = orbx_last_graph_device_us(ex.Context());
+          if (rep && us > 0) { acc += us; n++; }
+        }
+      dev_us[mode] = n ? acc / n : -1;
+    }
+    std::printf("{\"frames\": %d, \"ms_per_frame\": %.5f, \"features_per_ms\": %.2f, \"features_per_frame\": %.1f, \"ms_per_frame_without_host_pyramid\": %.5f, "
+                "\"device_ms_per_frame\": %.5f, \"device_ms_per_frame_without_host_pyramid\": %.5f}\n",
+                reps * nfr, ms / (reps * nfr), total / ms, (double)total / (reps * nfr), ms_mono / (reps * nfr), dev_us[0] * 1e-3, dev_us[1] * 1e-3);
   } catch (const std::exception& e) {
     std::fprintf(stderr, "e2e_operator: %s\n", e.what());
     return 3;

@@ -26,3 +26,42 @@ for name, r in (("radius 3 px x scale (SearchByProjection, th = 3)", 3.0), ("rad
         for _ in range(200): res = T.search(qx, qy, qr, lvl - 1, lvl, d1[:nq], want_lists=want_lists)
         dt = (time.perf_counter() - t0) / 200
         print(f"{name}: {nq} queries, lists={want_lists}, {int(res['row_ptr'][-1])} candidates: {dt * 1e6:.1f} us per call (python caller)")
+
+# ---- first search of a NEW frame (target created from host arrays, then searched) against a search on a resident target: what the
+# hand-over work of round 3 is measured by.  Three ways of making the target: host arrays with a caller-held grid (round 2),
+# host arrays with the grid built on the device, and descriptor rows handed over from the extractor's staging block (orbx_publish_descriptors)
+import ctypes as C
+print()
+qr = (np.float32(3.0) * np.float32(1.2) ** lvl).astype(np.float32)
+from oracle import pyoracle as po
+cs, ci = po.assign_grid(k2, np.float32(0), np.float32(0), np.float32(64 / 640.0), np.float32(48 / 480.0))
+held = dict(grid, cell_start=cs, cell_idx=ci)
+img = fr[1]
+R = m.Target(k2, d2, held)     # the recycled target: the adapters' LRU refills a device block (orbx_target_assign), it does not allocate
+def first_search(make):
+    ts = []
+    for rep in range(60):
+        mono, kk, dd = gpu(img, None, (0, 0))          # a fresh extraction: the context's staging block holds these rows
+        dd = np.ascontiguousarray(dd)
+        t0 = time.perf_counter()
+        make(kk, dd)
+        R.search(qx, qy, qr, lvl - 1, lvl, d1[:nq], want_lists=False)
+        ts.append(time.perf_counter() - t0)
+    return 1e6 * float(np.median(ts[10:]))
+def resident():
+    for _ in range(5): T.search(qx, qy, qr, lvl - 1, lvl, d1[:nq], want_lists=False)
+    t0 = time.perf_counter()
+    for _ in range(200): T.search(qx, qy, qr, lvl - 1, lvl, d1[:nq], want_lists=False)
+    return 1e6 * (time.perf_counter() - t0) / 200
+r = resident()
+a = first_search(lambda kk, dd: R.assign(kk, dd, held))
+b = first_search(lambda kk, dd: R.assign(kk, dd, grid))
+def handed(kk, dd):
+    gpu.publish_descriptors(dd)
+    R.assign(kk, dd, grid)
+c = first_search(handed)
+print(f"search on a resident target: {r:.1f} us")
+print(f"first search of a new frame = refill a recycled target (orbx_target_assign) + search (python caller, median of 50):")
+print(f"  host arrays + caller-held grid (round 2's way): {a:.1f} us  (+{a - r:.1f})")
+print(f"  host arrays, grid built on the device:           {b:.1f} us  (+{b - r:.1f})")
+print(f"  descriptor rows handed over in HBM, device grid:  {c:.1f} us  (+{c - r:.1f})")
