@@ -483,3 +483,33 @@ def test_device_std_sort_restatement_equals_the_host_permutation():
             assert np.array_equal(got, want), (rep, n, mode, threads, int(np.flatnonzero(got != want)[0]))
         cases += 1
     assert cases == 260
+
+
+@pytest.mark.parametrize("shape,nlevels,sf", [((480, 640), 8, 1.2), ((480, 752), 8, 1.2), ((350, 600), 8, 1.2), ((400, 500), 3, 1.2), ((480, 640), 2, 1.2),
+                                              ((600, 800), 5, 1.5), ((1024, 1024), 8, 1.2)])
+@pytest.mark.parametrize("opts", [dict(small_fused=1, graph=1), dict(small_fused=1, graph=0), dict(small_fused=0, graph=1), dict(small_fused=0, graph=0),
+                                  dict(small_fused=1, graph=1, desc_k=4)])
+def test_single_frame_launch_shapes_give_the_same_bytes(shape, nlevels, sf, opts):
+    """The latency-bound call (one to four frames) has its own launch plan — the upload as a kernel, groups of pyramid levels per launch
+    (k_resize_chain, with the intermediate levels computed redundantly per tile and written on the way), FAST + blur in one launch, the
+    assembly as the quadtree's tail, results mirrored into the pinned block, one keypoint per wave — inside a replayed graph or as plain
+    launches.  Every combination must return the oracle's bytes, and every pyramid level the same bytes (stereo reads mvImagePyramid):
+    level counts that leave a group of one, two or three, widths that are not multiples of 16 (the copy-node upload), other scales."""
+    rows, cols = shape
+    nf = 2000 if rows * cols > 500000 else 1000
+    img = synth.make_stream(2, rows, cols, 1234)[1]
+    ora = po.OracleExtractor(nf, sf, nlevels, 20, 7)
+    want = ora.extract(img, (0, 1000))
+    gpu = ORBextractor(nf, sf, nlevels, 20, 7)
+    for k, v in opts.items():
+        gpu.set_option(k, v)
+    for rep in range(2):          # the second call replays the captured graph
+        assert_same(gpu(img, None, (0, 1000)), want, f"{opts} rep {rep}")
+        for l in range(nlevels):
+            assert np.array_equal(gpu.pyramid_level(l), ora.level(l)), (opts, rep, l)
+    # two and four frames per call take the same plan with a second grid dimension; five leave it
+    for nb in (2, 4, 5):
+        batch = np.stack([img] + [synth.make_stream(1, rows, cols, 77 + i)[0] for i in range(nb - 1)])
+        res = gpu.extract_batch(batch, (0, 1000))
+        for f in range(nb):
+            assert_same(res[f], ora.extract(batch[f], (0, 1000)), f"{opts} batch {nb} frame {f}")
