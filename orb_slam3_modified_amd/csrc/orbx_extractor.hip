@@ -699,6 +699,11 @@ static bool handover_begin_extraction(orbx_ctx* ctx) {
   ctx->handover_pending = false;
   return pending;
 }
+// the extraction has finished: its rows sit at `d_desc` (the matcher threads read these two fields under the same lock)
+static void handover_end_extraction(orbx_ctx* ctx, const uint8_t* d_desc, int n0) {
+  std::lock_guard<std::mutex> lock(g_pub_mu);
+  ctx->last_d_desc = d_desc; ctx->last_n0 = n0;
+}
 // a search target on `stream` has queued a device-to-device copy out of src's staging block
 hipError_t orbx::handover_copied(orbx_ctx* src, hipStream_t stream) {
   std::lock_guard<std::mutex> lock(g_pub_mu);
@@ -1146,7 +1151,7 @@ static int extract_batch_impl(orbx_ctx* ctx, const uint8_t* imgs, int nframes, i
       std::memcpy(desc, ctx->h_stage_out + L.desc_off, db);
       std::memcpy(counts, ctx->h_stage_out + L.counts_off, cb);
       if (counts[0] < 0) return set_err(ctx, ORBX_E_CAPACITY, "quadtree produced more nodes than the level capacity");
-      ctx->last_d_desc = ctx->d_stage_out + L.desc_off; ctx->last_n0 = counts[0];
+      handover_end_extraction(ctx, ctx->d_stage_out + L.desc_off, counts[0]);
       return ORBX_OK;
     }
   }
@@ -1207,7 +1212,7 @@ static int extract_batch_impl(orbx_ctx* ctx, const uint8_t* imgs, int nframes, i
   // k_assemble reports a quadtree capacity overflow (never expected) as a negative keypoint count: fail loudly
   for (int f = 0; f < nframes; f++)
     if (counts[2 * f] < 0) return set_err(ctx, ORBX_E_CAPACITY, "quadtree produced more nodes than the level capacity");
-  ctx->last_d_desc = ctx->d_stage_out + L.desc_off; ctx->last_n0 = counts[0];
+  handover_end_extraction(ctx, ctx->d_stage_out + L.desc_off, counts[0]);
   return ORBX_OK;
 }
 
