@@ -593,12 +593,18 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
       }
       // small batches are latency-bound on the big levels' workgroups: more waves split more nodes at a time
       const int qthreads = ctx->qt_threads ? ctx->qt_threads : (nframes * geo.nlevels <= 512) ? 512 : 256;
-      hipLaunchKernelGGL(k_quadtree, dim3(l1 - l0, nframes, 1), dim3(qthreads), lds, s, ctx->d_geo, ctx->d_cells, b_cand, b_cell_cnt,
-                         b_pts, b_lvl_kp, b_lvl_n, node_cap, scan_cap, pts_cap, l0, gnodes, (long long)ctx->qt_node_stride);
+      // level-major order (LDS-resident node arrays only: the HBM node slices are indexed frame-major): all workgroups of the largest
+      // level of the launch are dispatched first, the short ones fill the CUs behind them
+      if (ctx->qt_level_major && !gnodes && !small_batch)
+        hipLaunchKernelGGL(k_quadtree, dim3(nframes, l1 - l0, 1), dim3(qthreads), lds, s, ctx->d_geo, ctx->d_cells, b_cand, b_cell_cnt,
+                           b_pts, b_lvl_kp, b_lvl_n, node_cap, scan_cap, pts_cap, l0 | 0x100, gnodes, (long long)ctx->qt_node_stride);
+      else
+        hipLaunchKernelGGL(k_quadtree, dim3(l1 - l0, nframes, 1), dim3(qthreads), lds, s, ctx->d_geo, ctx->d_cells, b_cand, b_cell_cnt,
+                           b_pts, b_lvl_kp, b_lvl_n, node_cap, scan_cap, pts_cap, l0, gnodes, (long long)ctx->qt_node_stride);
       return ORBX_OK;
     };
     const int qt_pts = ctx->qt_points;   // measured: 1024 ... 2048 points make no difference to the launch (128 VGPRs hold it at four workgroups per CU)
-    const int nbig = (geo.nlevels >= 4 && !small_batch) ? kQtBigLevels : geo.nlevels;  // small batch: one launch, all levels
+    const int nbig = (geo.nlevels >= 4 && !small_batch && !ctx->qt_one_launch) ? kQtBigLevels : geo.nlevels;  // small batch: one launch, all levels
     int qrc = ORBX_OK;
     if (small_fused && ctx->d_qt_fin && !ctx->d_asm_scan && nframes <= kSmallBatchFrames) {
       // all levels in one launch with the assembly as its tail (k_quadtree_assemble), when everything is LDS-resident
@@ -769,6 +775,8 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, 
   }
   ctx->fast_threads = fast_threads_from_env();
   { const char* e = getenv("ORBX_SMALL_FUSED"); ctx->small_fused = e ? atoi(e) != 0 : true; }
+  { const char* e = getenv("ORBX_QT_LEVEL_MAJOR"); ctx->qt_level_major = e ? atoi(e) != 0 : true; }
+  { const char* e = getenv("ORBX_QT_ONE_LAUNCH"); ctx->qt_one_launch = e ? atoi(e) != 0 : false; }
   { const char* e = getenv("ORBX_CHAIN_THREADS"); const int v = e ? atoi(e) : 1024; ctx->chain_threads = (v == 256 || v == 512 || v == 1024) ? v : 1024; }
   { const char* e = getenv("ORBX_QT_POINTS"); const int v = e ? atoi(e) : kQtLdsPoints; ctx->qt_points = (v >= 256 && v <= 4096 && v % 128 == 0) ? v : kQtLdsPoints; }
   { const char* e = getenv("ORBX_FAST_SPLIT"); ctx->fast_split = e ? atoi(e) != 0 : true; }
@@ -1298,6 +1306,8 @@ int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
   else if (n == "fast_pk") ctx->fast_pk = value != 0;
   else if (n == "qt_points" && value >= 256 && value <= 4096 && value % 128 == 0) ctx->qt_points = value;   // LDS-resident candidates per (frame, level) of the big quadtree levels (half of it for the small ones)
   else if (n == "small_fused") ctx->small_fused = value != 0;
+  else if (n == "qt_level_major") ctx->qt_level_major = value != 0;
+  else if (n == "qt_one_launch") ctx->qt_one_launch = value != 0;
   else if (n == "window_direct") ctx->window_direct = value != 0;
   else if (n == "fast_split") ctx->fast_split = value != 0;   // FAST launched per group of levels with its own LDS size (batch calls)
   else if (n == "fast_stop") ctx->fast_stop = value;   // timing experiment: FAST returns after staging (1) / after the necessary test (2); results are void

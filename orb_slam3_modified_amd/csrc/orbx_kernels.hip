@@ -1072,7 +1072,8 @@ __device__ __forceinline__ void quadtree_body(const DeviceGeom* __restrict__ g, 
   int& sh_jstar = *sh_jstar_p;
 
   const int T = blockDim.x, t = threadIdx.x, lane = t & 63, w = t >> 6, NW = T >> 6;
-  const int level = level_base + blockIdx.x, frame = blockIdx.y;
+  // level_base bit 8: level-major launch (grid = frames x levels: all workgroups of the largest level start first — longest first)
+  const int level = (level_base & 0xff) + ((level_base & 0x100) ? (int)blockIdx.y : (int)blockIdx.x), frame = (level_base & 0x100) ? (int)blockIdx.x : (int)blockIdx.y;
   const DeviceLevel& lv = g->lv[level];
   const int N = lv.quota;
   // node arrays hold node_cap entries; the list never grows beyond min(N + 3, n) nodes (it stops at N, and every node
@@ -1648,7 +1649,8 @@ __device__ __forceinline__ void quadtree_main(const DeviceGeom* __restrict__ g, 
                                               unsigned long long* wt, int* sh_cnt, int* sh_jstar) {
   unsigned long long* scan = (unsigned long long*)(nb + (size_t)node_cap * (2 * sizeof(QNode) + 2 * 8));
   const int T = blockDim.x, t = threadIdx.x;
-  const int level = level_base + blockIdx.x, frame = blockIdx.y;
+  // level_base bit 8: level-major launch (grid = frames x levels: all workgroups of the largest level start first — longest first)
+  const int level = (level_base & 0xff) + ((level_base & 0x100) ? (int)blockIdx.y : (int)blockIdx.x), frame = (level_base & 0x100) ? (int)blockIdx.x : (int)blockIdx.y;
   const DeviceLevel& lv = g->lv[level];
   uint32_t* gcur = pts + ((long long)frame * 2 + 0) * g->cand_total + lv.cand_off;
   uint32_t* gnxt = pts + ((long long)frame * 2 + 1) * g->cand_total + lv.cand_off;
