@@ -12,6 +12,12 @@
 #                               against the same object model (KeyFrame's database fields, covisibility accessors, a Map stand-in) + the
 #                               scenario driver tests/support/kfdb_world.cpp; the reference's own BowVector.h / FeatureVector.h are
 #                               force-included first so that ONE definition of the two DBoW2 classes is seen
+#   _ref/ref_frame_world        src/Frame.cc + include/Frame.h, unmodified ("the drop-in boundary's only caller"), + src/ORBextractor.cc + the DBoW2 library
+#                               above, against the stand-ins of tests/support/frame_world (IMU / Converter / Settings by include guard, cameras,
+#                               MapPoint, a two-constant ORBmatcher) + the scenario driver tests/support/frame_world.cpp
+#   _ref/dropin_frame_world     THE SAME src/Frame.cc over this repository's include/ORBextractor.h + include/ORBVocabulary.h, linked against
+#                               orb_slam3_modified_amd/liborbx.so: what the GPU test runs (the GPU box has no /root/reference to compile from)
+#   _ref/dropin_frame_world_cpu the same, linked against the oracle-backed C-ABI stub (tests/support/orbx_oracle_stub.cpp): the CPU test
 #   _ref/libref_orbextractor.so src/ORBextractor.cc + include/ORBextractor.h, unmodified, against the container shim; the five
 #                               OpenCV algorithms it calls forward to the oracle's isolated primitives (liborb_oracle.so)
 REFROOT ?= /root/reference
@@ -23,7 +29,8 @@ SRCS := $(REF)/DBoW2/BowVector.cpp $(REF)/DBoW2/FeatureVector.cpp $(REF)/DBoW2/S
 WORLD := ../tests/support/ref_world
 WORLD_HDRS := $(wildcard $(WORLD)/*.h $(WORLD)/*/* $(WORLD)/*/*/*/*) $(wildcard ref_shims/opencv2/*/*.hpp)
 
-all: _ref/libref_dbow2.so _ref/ref_matcher_world _ref/libref_orbextractor.so _ref/ref_streamed_frontend _ref/ref_kfdb_world
+all: _ref/libref_dbow2.so _ref/ref_matcher_world _ref/libref_orbextractor.so _ref/ref_streamed_frontend _ref/ref_kfdb_world _ref/ref_frame_world \
+     _ref/dropin_frame_world_cpu $(if $(wildcard ../orb_slam3_modified_amd/liborbx.so),_ref/dropin_frame_world)
 
 _ref/libref_dbow2.so: $(SRCS) ref_shims/opencv2/core/core.hpp ref_shims/boost/serialization/serialization.hpp
 	mkdir -p _ref
@@ -56,4 +63,36 @@ _ref/ref_kfdb_world: $(REFROOT)/src/KeyFrameDatabase.cc $(REFROOT)/include/KeyFr
 	$(CXX) -O2 -std=c++17 -ffp-contract=off -w -include $(REF)/DBoW2/BowVector.h -include $(REF)/DBoW2/FeatureVector.h -include $(WORLD)/ref_world.h \
 	    -I$(WORLD) -Iref_shims -I$(REFROOT)/include -I$(REFROOT) $(REFROOT)/src/KeyFrameDatabase.cc ../tests/support/kfdb_world.cpp -o $@ \
 	    -L_ref -lref_dbow2 -Wl,-rpath,'$$ORIGIN'
+
+# -include prelude.h: defines the guards of include/ImuTypes.h, Converter.h, Settings.h (which include/Frame.h pulls from its own directory) and
+# supplies the members src/Frame.cc uses; everything else is shadowed through the include path (tests/support/frame_world comes first)
+FW := ../tests/support/frame_world
+FW_HDRS := $(wildcard $(FW)/*.h $(FW)/*/* $(FW)/*/*/* $(FW)/*/*/*/*) $(WORLD)/Eigen/Core $(WORLD)/sophus/se3.hpp $(wildcard ref_shims/opencv2/*/*.hpp)
+FW_FLAGS := -O2 -std=c++17 -ffp-contract=off -w -pthread -include $(FW)/prelude.h -I$(FW) -Iref_shims
+_ref/ref_frame_world: $(REFROOT)/src/Frame.cc $(REFROOT)/include/Frame.h $(REFROOT)/src/ORBextractor.cc ../tests/support/frame_world.cpp $(FW_HDRS) \
+                      _ref/libref_dbow2.so liborb_oracle.so
+	mkdir -p _ref
+	$(CXX) $(FW_FLAGS) -I$(REFROOT) -I$(REFROOT)/include -I$(REFROOT)/include/CameraModels \
+	    $(REFROOT)/src/Frame.cc $(REFROOT)/src/ORBextractor.cc ../tests/support/frame_world.cpp -o $@ \
+	    -L. -lorb_oracle -L_ref -lref_dbow2 -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,'$$ORIGIN'
+
+# the drop-in builds: this repository's include/ first, so "ORBextractor.h" and (through the prelude, -DFRAME_WORLD_DROPIN) "ORBVocabulary.h"
+# are the drop-in headers; src/Frame.cc and include/Frame.h are still the reference's files
+# include/ORBVocabulary.h takes DBoW2::BowVector / FeatureVector from the reference's own two headers when they are on the include path
+# (INTEGRATION.md section 3), so their two small source files are linked exactly as a maintainer's libDBoW2 would supply them
+DROPIN_HDRS := ../include/ORBextractor.h ../include/ORBVocabulary.h ../include/orbx.h
+DROPIN_DBOW2 := $(REF)/DBoW2/BowVector.cpp $(REF)/DBoW2/FeatureVector.cpp
+_ref/dropin_frame_world_cpu: $(REFROOT)/src/Frame.cc $(REFROOT)/include/Frame.h ../tests/support/frame_world.cpp ../tests/support/orbx_oracle_stub.cpp \
+                             $(FW_HDRS) $(DROPIN_HDRS) liborb_oracle.so
+	mkdir -p _ref
+	$(CXX) $(FW_FLAGS) -DFRAME_WORLD_DROPIN -I../include -I$(REFROOT) -I$(REFROOT)/include -I$(REFROOT)/include/CameraModels \
+	    $(REFROOT)/src/Frame.cc $(DROPIN_DBOW2) ../tests/support/frame_world.cpp ../tests/support/orbx_oracle_stub.cpp -o $@ \
+	    -L. -lorb_oracle -Wl,-rpath,'$$ORIGIN/..'
+
+_ref/dropin_frame_world: $(REFROOT)/src/Frame.cc $(REFROOT)/include/Frame.h ../tests/support/frame_world.cpp $(FW_HDRS) $(DROPIN_HDRS) \
+                         ../orb_slam3_modified_amd/liborbx.so liborb_oracle.so
+	mkdir -p _ref
+	$(CXX) $(FW_FLAGS) -DFRAME_WORLD_DROPIN -I../include -I$(REFROOT) -I$(REFROOT)/include -I$(REFROOT)/include/CameraModels \
+	    $(REFROOT)/src/Frame.cc $(DROPIN_DBOW2) ../tests/support/frame_world.cpp -o $@ \
+	    -L../orb_slam3_modified_amd -lorbx -L. -lorb_oracle -Wl,-rpath,'$$ORIGIN/../../orb_slam3_modified_amd' -Wl,-rpath,'$$ORIGIN/..'
 .PHONY: all

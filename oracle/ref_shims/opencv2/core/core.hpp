@@ -97,6 +97,7 @@ class Mat {
   void create(Size s, int type) { create(s.height, s.width, type); }
   void release() { own_.reset(); data = nullptr; rows = cols = 0; step = 0; }
   bool empty() const { return !data || rows * cols == 0; }
+  size_t total() const { return (size_t)rows * cols; }
   int type() const { return type_; }
   Size size() const { return Size(cols, rows); }
   size_t step1() const { return step / esz(); }
@@ -128,6 +129,12 @@ class Mat {
   }
   template <typename T> T& at(int r, int c) { return *reinterpret_cast<T*>(data + (size_t)r * step + (size_t)c * sizeof(T)); }
   template <typename T> const T& at(int r, int c) const { return *reinterpret_cast<const T*>(data + (size_t)r * step + (size_t)c * sizeof(T)); }
+  /* at(i): element i of a single-row or single-column matrix (cv::Mat::at(int i0)), as src/Frame.cc:749 reads mDistCoef */
+  template <typename T> T& at(int i) { return rows == 1 ? at<T>(0, i) : at<T>(i, 0); }
+  template <typename T> const T& at(int i) const { return rows == 1 ? at<T>(0, i) : at<T>(i, 0); }
+  /* reshape(cn): this shim has no channel dimension — an N x 2 float matrix stays N x 2 whether it is read as 1 or 2 channels
+     (src/Frame.cc:765-767: reshape(2), undistortPoints, reshape(1)) */
+  Mat reshape(int) const { return *this; }
   unsigned char* ptr(int r = 0) { return data + (size_t)r * step; }
   const unsigned char* ptr(int r = 0) const { return data + (size_t)r * step; }
   template <typename T> T* ptr(int r = 0) { return reinterpret_cast<T*>(data + (size_t)r * step); }

@@ -366,6 +366,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
   auto fast_kern = pitchB == 64 ? (ft == 64 ? k_fast_cells<64, 64> : ft == 128 ? k_fast_cells<128, 64> : k_fast_cells<256, 64>)
                                 : (ft == 64 ? k_fast_cells<64, 96> : ft == 128 ? k_fast_cells<128, 96> : k_fast_cells<256, 96>);
   if (ctx->fast_pk && ft == 128) fast_kern = pitchB == 64 ? k_fast_cells<128, 64, true> : k_fast_cells<128, 96, true>;
+  if (ctx->fast_pk && ft == 64) fast_kern = pitchB == 64 ? k_fast_cells<64, 64, true> : k_fast_cells<64, 96, true>;
   auto launch_fast_range = [&](int cell_base, int ncells_sub, hipStream_t s) {
     const int nitems = ncells_sub * nframes;
     if (nitems <= 0) return;

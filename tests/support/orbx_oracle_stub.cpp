@@ -27,6 +27,8 @@ void mo_window_nearest(const void* kps, const uint8_t* desc, int n, const void* 
 extern "C" {
 void* orbo_create(int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh);
 void orbo_destroy(void* h);
+int orbo_level_size(void* h, int level, int* w, int* hgt);
+int orbo_level_copy(void* h, int level, int blurred, uint8_t* dst, int dst_stride);
 int orbo_extract(void* h, const uint8_t* img, int rows, int cols, int stride, int lap0, int lap1, void* kps, uint8_t* desc, int cap, int* n_out,
                  int* mono_out);
 void orbo_tables(void* h, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2, int* quota, int* umax16);
@@ -46,7 +48,7 @@ int mo_kfdb_query(void* h, const uint32_t* q_ids, const double* q_vals, int nq, 
 #include <map>
 #include <utility>
 
-struct orbx_ctx { void* ora = nullptr; int nfeatures = 0, nlevels = 0; };
+struct orbx_ctx { void* ora = nullptr; int nfeatures = 0, nlevels = 0; std::vector<std::vector<uint8_t> > pyr; std::vector<int> pw, ph; };
 struct orbx_kfdb { void* h = nullptr; std::map<int64_t, std::pair<std::vector<uint32_t>, std::vector<double> > > rows; };
 struct orbx_voc { void* h = nullptr; std::vector<uint8_t> last_desc; int last_levelsup = 0; };
 
@@ -67,11 +69,23 @@ int orbx_scale_tables(const orbx_ctx* c, float* scale, float* inv_scale, float* 
 }
 int orbx_set_host_pyramid(orbx_ctx*, int) { return ORBX_OK; }
 int orbx_publish_descriptors(orbx_ctx*, const void*, int) { return ORBX_OK; }
-int orbx_host_pyramid_level(orbx_ctx*, int, const uint8_t**, size_t*, int*, int*) { return ORBX_E_INVALID; }
+// the host mirror of mvImagePyramid (levels >= 1) that include/ORBextractor.h hands to Frame::ComputeStereoMatches: the oracle's levels
+int orbx_host_pyramid_level(orbx_ctx* c, int level, const uint8_t** data, size_t* stride, int* w, int* h) {
+  if (level < 1 || level >= c->nlevels || (size_t)level >= c->pyr.size() || c->pyr[level].empty()) return ORBX_E_INVALID;
+  *data = c->pyr[level].data(); *stride = (size_t)c->pw[level]; *w = c->pw[level]; *h = c->ph[level];
+  return ORBX_OK;
+}
 int orbx_extract(orbx_ctx* c, const uint8_t* img, int rows, int cols, size_t stride, int lap0, int lap1, orbx_keypoint* kps, uint8_t* desc, int* n_out,
                  int* mono_out) {
   if (!img || rows <= 0 || cols <= 0) return ORBX_E_EMPTY;
-  return orbo_extract(c->ora, img, rows, cols, (int)stride, lap0, lap1, kps, desc, orbx_keypoint_capacity(c), n_out, mono_out) == 0 ? ORBX_OK : ORBX_E_INVALID;
+  if (orbo_extract(c->ora, img, rows, cols, (int)stride, lap0, lap1, kps, desc, orbx_keypoint_capacity(c), n_out, mono_out) != 0) return ORBX_E_INVALID;
+  c->pyr.assign(c->nlevels, std::vector<uint8_t>()); c->pw.assign(c->nlevels, 0); c->ph.assign(c->nlevels, 0);
+  for (int l = 1; l < c->nlevels; l++) {
+    if (orbo_level_size(c->ora, l, &c->pw[l], &c->ph[l]) != 0) continue;
+    c->pyr[l].resize((size_t)c->pw[l] * c->ph[l]);
+    orbo_level_copy(c->ora, l, 0, c->pyr[l].data(), c->pw[l]);
+  }
+  return ORBX_OK;
 }
 int orbx_voc_load_text(orbx_ctx*, const char* path, orbx_voc** out) {
   void* h = mo_voc_load(path);
