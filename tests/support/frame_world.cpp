@@ -115,6 +115,14 @@ cv::Mat make_dist(float k1, float k2, float p1, float p2, int n = 4, float k3 = 
   return D;
 }
 
+// optional: the generated images as raw files (rows x cols bytes / floats), so that tests can feed the same pixels to the oracle and the device API
+std::string g_dump_dir;
+void dump_image(const char* name, const cv::Mat& m) {
+  if (g_dump_dir.empty()) return;
+  std::ofstream f(g_dump_dir + "/" + name + "_" + std::to_string(m.rows) + "x" + std::to_string(m.cols) + ".raw", std::ios::binary);
+  for (int r = 0; r < m.rows; r++) f.write((const char*)m.ptr(r), (std::streamsize)((size_t)m.cols * m.elemSize()));
+}
+
 // ---- Frame storage with a defined `mb` (see the header of this file)
 struct FrameBox {
   alignas(64) unsigned char raw[sizeof(Frame)];
@@ -265,7 +273,8 @@ void dump_copy(Frame& F) {
 }  // namespace
 
 int main(int argc, char** argv) {
-  if (argc < 3) { std::fprintf(stderr, "usage: %s <vocabulary.txt> <out.txt> [repeat]\n", argv[0]); return 2; }
+  if (argc < 3) { std::fprintf(stderr, "usage: %s <vocabulary.txt> <out.txt> [repeat [image dump directory]]\n", argv[0]); return 2; }
+  if (argc > 4) g_dump_dir = argv[4];
   g_out = std::fopen(argv[2], "w");
   if (!g_out) return 2;
   const int repeat = argc > 3 ? std::atoi(argv[3]) : 1;
@@ -289,6 +298,7 @@ int main(int argc, char** argv) {
       ORBextractor exL(1200, 1.2f, 8, 20, 7), exR(1200, 1.2f, 8, 20, 7);
       for (int t = 0; t < 2; t++) {   // the second frame: persistent extractor state, statics already set, ids go on
         cv::Mat imL = cut(canvas, crows, ccols, rows, cols, 0, 2 * t, 0, 11 + t), imR = cut(canvas, crows, ccols, rows, cols, 0, 5 + 2 * t, 3, 23 + t);
+        if (t == 0) { dump_image("stereo_left", imL); dump_image("stereo_right", imR); }
         Frame::mbInitialComputations = t == 0;
         FrameBox box;
         box.prefill(bf / fx);
@@ -308,6 +318,8 @@ int main(int argc, char** argv) {
       cv::Mat depth(rows, cols, CV_32F);
       for (int y = 0; y < rows; y++)
         for (int x = 0; x < cols; x++) depth.at<float>(y, x) = ((x / 16 + y / 16) % 7 == 0) ? 0.f : 0.5f + (float)((x * 7 + y * 13) % 400) * 0.01f;
+      dump_image("rgbd_gray", im);
+      dump_image("rgbd_depth", depth);
       ORBextractor ex(1000, 1.2f, 8, 20, 7);
       Frame::mbInitialComputations = true;
       FrameBox box;
@@ -329,6 +341,7 @@ int main(int argc, char** argv) {
         const int rows = shapes[t][0], cols = shapes[t][1];
         const std::vector<uint8_t> canvas = make_canvas(rows, cols, 3003 + t);
         cv::Mat im = cut(canvas, rows, cols, rows, cols, 0, 0, 0, 41 + t);
+        if (t == 0) dump_image("mono_distorted", im);
         Frame::mbInitialComputations = true;
         boxes[t].prefill(bf / fx);
         boxes[t].f = new (boxes[t].raw) Frame(im, 2.0 + t, t == 1 ? &exIni : &ex, &voc, &pin, t == 1 ? D0 : D4, bf, thDepth, prev);
