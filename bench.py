@@ -224,6 +224,34 @@ def streamed_frontend(host_frames, nfeatures, voc_descriptors, nframes=48):
         return {"error": str(e)[:300]}
 
 
+def frame_constructor():
+    """Frame::Frame of the reference's UNMODIFIED src/Frame.cc (stereo: two extractions on two threads + ComputeStereoMatches on the host mirror of
+    mvImagePyramid + the grid; monocular: extraction + grid), 752x480, compiled over the drop-in headers + liborbx.so (oracle/_ref/dropin_frame_world)
+    and over the reference's own extractor (oracle/_ref/ref_frame_world) — both prebuilt by oracle/ref_fragments.mk where /root/reference exists;
+    their results are compared by tests/test_frame_world.py, here they are timed."""
+    ref_dir = os.path.join(ROOT, "oracle", "_ref")
+    voc = os.path.join(ROOT, "tests", "golden", "voc_k5_L3.txt")
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="orbx_frame_")
+    try:
+        for key, exe, n in (("gpu", "dropin_frame_world", 200), ("cpu", "ref_frame_world", 12)):
+            path = os.path.join(ref_dir, exe)
+            if not os.path.exists(path):
+                out[key] = {"error": f"oracle/_ref/{exe} not built"}
+                continue
+            r = subprocess.run([path, voc, os.path.join(tmp, "o.txt"), str(-n)], capture_output=True, text=True, timeout=300)
+            if r.returncode != 0:
+                out[key] = {"error": (r.stderr or r.stdout).strip()[-200:]}
+                continue
+            out[key] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        out["what"] = ("the reference's own src/Frame.cc constructors, 752x480: gpu = compiled over include/ORBextractor.h + liborbx.so, cpu = over the "
+                       "reference's src/ORBextractor.cc (OpenCV primitives restated, 2 threads in the stereo constructor as in the reference); "
+                       "ComputeStereoMatches runs on the host in both (Frame.cc untouched)")
+        return out
+    except Exception as e:   # noqa: BLE001
+        return {"error": str(e)[:300]}
+
+
 def e2e_operator(host_frames, nfeatures):
     """ORBextractor::operator() per frame through the C++ adapter, host buffers (tools/e2e_operator.cpp built here)."""
     pkg = os.path.join(ROOT, "orb_slam3_modified_amd")
@@ -521,6 +549,7 @@ def main():
                 raise
             except Exception as e:   # noqa: BLE001
                 result["streamed_frontend"] = {"error": str(e)[:300]}
+            result["frame_constructor"] = frame_constructor()
         if world == 1 and not args.no_secondary:
             result["end_to_end_operator"] = e2e_operator(host_frames, args.nfeatures)
             # ---- BASELINE config 4: TUM-VI shape, 1024x1024, 2000 features (large-image configuration)

@@ -68,7 +68,7 @@ _ref/ref_kfdb_world: $(REFROOT)/src/KeyFrameDatabase.cc $(REFROOT)/include/KeyFr
 # supplies the members src/Frame.cc uses; everything else is shadowed through the include path (tests/support/frame_world comes first)
 FW := ../tests/support/frame_world
 FW_HDRS := $(wildcard $(FW)/*.h $(FW)/*/* $(FW)/*/*/* $(FW)/*/*/*/*) $(WORLD)/Eigen/Core $(WORLD)/sophus/se3.hpp $(wildcard ref_shims/opencv2/*/*.hpp)
-FW_FLAGS := -O2 -std=c++17 -ffp-contract=off -w -pthread -include $(FW)/prelude.h -I$(FW) -Iref_shims
+FW_FLAGS := -O3 -std=c++17 -ffp-contract=off -w -pthread -include $(FW)/prelude.h -I$(FW) -Iref_shims
 _ref/ref_frame_world: $(REFROOT)/src/Frame.cc $(REFROOT)/include/Frame.h $(REFROOT)/src/ORBextractor.cc ../tests/support/frame_world.cpp $(FW_HDRS) \
                       _ref/libref_dbow2.so liborb_oracle.so
 	mkdir -p _ref

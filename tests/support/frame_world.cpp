@@ -13,6 +13,7 @@
 // constructor assigns it (:178 mb = mbf / fx), i.e. it reads whatever the Frame's storage held.  The driver therefore constructs every
 // Frame by placement new into storage pre-filled with the float the constructor is about to assign, which is what a Tracking loop that
 // keeps re-assigning mCurrentFrame converges to.
+#include <chrono>
 #include <cinttypes>
 #include <cstdio>
 #include <cstring>
@@ -273,13 +274,48 @@ void dump_copy(Frame& F) {
 }  // namespace
 
 int main(int argc, char** argv) {
-  if (argc < 3) { std::fprintf(stderr, "usage: %s <vocabulary.txt> <out.txt> [repeat [image dump directory]]\n", argv[0]); return 2; }
+  if (argc < 3) { std::fprintf(stderr, "usage: %s <vocabulary.txt> <out.txt> [repeat | -timed_frames [image dump directory]]\n", argv[0]); return 2; }
   if (argc > 4) g_dump_dir = argv[4];
   g_out = std::fopen(argv[2], "w");
   if (!g_out) return 2;
   const int repeat = argc > 3 ? std::atoi(argv[3]) : 1;
   ORBVocabulary voc;
   if (!voc.loadFromTextFile(argv[1])) { std::fprintf(stderr, "cannot load the vocabulary %s\n", argv[1]); return 2; }
+
+  // timing mode (repeat < 0): the stereo and the monocular constructor, -repeat times each on 8 rotating image pairs, as Tracking builds
+  // mCurrentFrame for every camera frame (src/Tracking.cc:1545-1566, :1599-1617); one JSON line on stdout
+  if (repeat < 0) {
+    const int n = -repeat, rows = 480, cols = 752, ccols = cols + 48;
+    const float fx = 458.654f, bf = 47.90639f;
+    cv::Mat K = make_K(fx, 457.296f, 367.215f, 248.375f), D0 = make_dist(0, 0, 0, 0);
+    Pinhole pin;
+    pin.fx = fx; pin.fy = 457.296f; pin.cx = 367.215f; pin.cy = 248.375f;
+    std::vector<cv::Mat> L, R;
+    for (int i = 0; i < 8; i++) {
+      const std::vector<uint8_t> canvas = make_canvas(rows, ccols, 9000 + i);
+      L.push_back(cut(canvas, rows, ccols, rows, cols, 0, 0, 0, 100 + i));
+      R.push_back(cut(canvas, rows, ccols, rows, cols, 0, 6, 2, 200 + i));
+    }
+    ORBextractor exL(1200, 1.2f, 8, 20, 7), exR(1200, 1.2f, 8, 20, 7), exM(1000, 1.2f, 8, 20, 7);
+    double ms[2] = {0, 0};
+    long feats[2] = {0, 0}, depth = 0;
+    for (int mode = 0; mode < 2; mode++) {
+      for (int i = -3; i < n; i++) {   // three untimed warm-up frames
+        const auto t0 = std::chrono::steady_clock::now();
+        FrameBox box;
+        box.prefill(bf / fx);
+        if (mode == 0) box.f = new (box.raw) Frame(L[(i + 8) % 8], R[(i + 8) % 8], 0.05 * i, &exL, &exR, &voc, K, D0, bf, 35.f * bf / fx, &pin);
+        else box.f = new (box.raw) Frame(L[(i + 8) % 8], 0.05 * i, &exM, &voc, &pin, D0, bf, 35.f * bf / fx);
+        const double dt = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (i >= 0) { ms[mode] += dt; feats[mode] += box.f->N; if (mode == 0) for (float d : box.f->mvDepth) depth += d > 0; }
+      }
+    }
+    std::printf("{\"frames\": %d, \"stereo_frame_ms\": %.4f, \"stereo_features_per_frame\": %.1f, \"stereo_with_depth_per_frame\": %.1f, "
+                "\"mono_frame_ms\": %.4f, \"mono_features_per_frame\": %.1f}\n", n, ms[0] / n, (double)feats[0] / n, (double)depth / n, ms[1] / n,
+                (double)feats[1] / n);
+    std::fclose(g_out);
+    return 0;
+  }
 
   const float fx = 458.654f, fy = 457.296f, cx = 367.215f, cy = 248.375f, bf = 47.90639f;
   const float thDepth = 35.f * bf / fx;
