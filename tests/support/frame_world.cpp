@@ -62,9 +62,14 @@ struct Lcg {
 
 // four octaves of value noise + filled rectangles + a near-flat quarter (so that cells fall back to minThFAST) — the recipe of
 // orb_slam3_modified_amd/synth.py in integers.  `canvas` is wider than the images cut from it (the stereo shift).
+// FRAME_WORLD_VARIANT=v (environment, default 0 = the golden scenes): other scenes, image sizes and feature counts — the fuzz of
+// tools/fuzz_frame_world.py, which runs the reference build and the drop-in build on the same variant and compares their texts
+int g_variant = 0;
+int vpick(int salt, int n) { Lcg r((uint64_t)g_variant * 1000003ull + (uint64_t)salt); return r.below(n); }
+
 std::vector<uint8_t> make_canvas(int rows, int cols, uint64_t seed) {
   std::vector<int> acc((size_t)rows * cols, 128 - 45);
-  Lcg rng(seed);
+  Lcg rng(seed + (uint64_t)g_variant * 7919ull);
   const int cells[4] = {64, 32, 16, 8}, amps[4] = {48, 24, 12, 6};
   for (int o = 0; o < 4; o++) {
     const int c = cells[o], gw = cols / c + 2, gh = rows / c + 2;
@@ -276,6 +281,7 @@ void dump_copy(Frame& F) {
 int main(int argc, char** argv) {
   if (argc < 3) { std::fprintf(stderr, "usage: %s <vocabulary.txt> <out.txt> [repeat | -timed_frames [image dump directory]]\n", argv[0]); return 2; }
   if (argc > 4) g_dump_dir = argv[4];
+  if (const char* v = std::getenv("FRAME_WORLD_VARIANT")) g_variant = std::atoi(v);
   g_out = std::fopen(argv[2], "w");
   if (!g_out) return 2;
   const int repeat = argc > 3 ? std::atoi(argv[3]) : 1;
@@ -329,9 +335,12 @@ int main(int argc, char** argv) {
   for (int rep = 0; rep < repeat; rep++) {
     // ---- 1. rectified stereo, 752 x 480 (EuRoC): two extractors on two threads, ComputeStereoMatches on their pyramids
     {
-      const int rows = 480, cols = 752, crows = rows, ccols = cols + 48;
+      static const int sshapes[4][2] = {{480, 752}, {480, 640}, {376, 1241}, {400, 848}};
+      static const int sfeat[4] = {1200, 1000, 2000, 1500};
+      const int sv = g_variant ? vpick(1, 4) : 0, fv = g_variant ? vpick(2, 4) : 0;
+      const int rows = sshapes[sv][0], cols = sshapes[sv][1], crows = rows, ccols = cols + 48;
       const std::vector<uint8_t> canvas = make_canvas(crows, ccols, 1001);
-      ORBextractor exL(1200, 1.2f, 8, 20, 7), exR(1200, 1.2f, 8, 20, 7);
+      ORBextractor exL(sfeat[fv], 1.2f, 8, 20, 7), exR(sfeat[fv], 1.2f, 8, 20, 7);
       for (int t = 0; t < 2; t++) {   // the second frame: persistent extractor state, statics already set, ids go on
         cv::Mat imL = cut(canvas, crows, ccols, rows, cols, 0, 2 * t, 0, 11 + t), imR = cut(canvas, crows, ccols, rows, cols, 0, 5 + 2 * t, 3, 23 + t);
         if (t == 0) { dump_image("stereo_left", imL); dump_image("stereo_right", imR); }
@@ -370,7 +379,13 @@ int main(int argc, char** argv) {
     //         then 1024 x 512 (columns beyond 1000: both branches of the output assembly), then a frame with a predecessor
     {
       ORBextractor ex(1000, 1.2f, 8, 20, 7), exIni(5000, 1.2f, 8, 20, 7);
-      const int shapes[3][2] = {{480, 752}, {512, 1024}, {480, 752}};
+      int shapes[3][2] = {{480, 752}, {512, 1024}, {480, 752}};
+      if (g_variant) {
+        static const int alt[4][2] = {{480, 640}, {600, 350 * 2}, {376, 1241}, {720, 1280}};
+        const int a = vpick(3, 4);
+        shapes[0][0] = shapes[2][0] = alt[a][0]; shapes[0][1] = shapes[2][1] = alt[a][1];
+        shapes[1][0] = 480 + 32 * vpick(4, 4); shapes[1][1] = 1008 + 8 * vpick(5, 8);
+      }
       Frame* prev = nullptr;
       FrameBox boxes[3];
       for (int t = 0; t < 3; t++) {
