@@ -593,7 +593,8 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
           return set_err(ctx, ORBX_E_CAPACITY, "nfeatures too large for the quadtree kernel's LDS");
       }
       // small batches are latency-bound on the big levels' workgroups: more waves split more nodes at a time
-      const int qthreads = ctx->qt_threads ? ctx->qt_threads : (nframes * geo.nlevels <= 512) ? 512 : 256;
+      int qthreads = ctx->qt_threads ? ctx->qt_threads : (nframes * geo.nlevels <= 512) ? 512 : 256;
+      if (!small_batch && l0 >= ctx->qt_big_levels && l0 > 0 && ctx->qt_threads_small) qthreads = ctx->qt_threads_small;   // the small levels' launch of a batch
       // level-major order (LDS-resident node arrays only: the HBM node slices are indexed frame-major): all workgroups of the largest
       // level of the launch are dispatched first, the short ones fill the CUs behind them
       if (ctx->qt_level_major && !gnodes && !small_batch)
@@ -605,7 +606,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
       return ORBX_OK;
     };
     const int qt_pts = ctx->qt_points;   // measured: 1024 ... 2048 points make no difference to the launch (128 VGPRs hold it at four workgroups per CU)
-    const int nbig = (geo.nlevels >= 4 && !small_batch && !ctx->qt_one_launch) ? kQtBigLevels : geo.nlevels;  // small batch: one launch, all levels
+    const int nbig = (geo.nlevels >= 4 && !small_batch && !ctx->qt_one_launch) ? std::min(ctx->qt_big_levels, geo.nlevels) : geo.nlevels;  // small batch: one launch, all levels
     int qrc = ORBX_OK;
     if (small_fused && ctx->d_qt_fin && !ctx->d_asm_scan && nframes <= kSmallBatchFrames) {
       // all levels in one launch with the assembly as its tail (k_quadtree_assemble), when everything is LDS-resident
@@ -776,6 +777,8 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, 
   }
   ctx->fast_threads = fast_threads_from_env();
   { const char* e = getenv("ORBX_SMALL_FUSED"); ctx->small_fused = e ? atoi(e) != 0 : true; }
+  { const char* e = getenv("ORBX_QT_THREADS_SMALL"); const int v = e ? atoi(e) : 128; ctx->qt_threads_small = (v == 64 || v == 128 || v == 192 || v == 256 || v == 512) ? v : 0; }
+  { const char* e = getenv("ORBX_QT_BIG_LEVELS"); const int v = e ? atoi(e) : 0; ctx->qt_big_levels = (v >= 1 && v <= 8) ? v : kQtBigLevels; }
   { const char* e = getenv("ORBX_QT_LEVEL_MAJOR"); ctx->qt_level_major = e ? atoi(e) != 0 : true; }
   { const char* e = getenv("ORBX_QT_ONE_LAUNCH"); ctx->qt_one_launch = e ? atoi(e) != 0 : false; }
   { const char* e = getenv("ORBX_CHAIN_THREADS"); const int v = e ? atoi(e) : 1024; ctx->chain_threads = (v == 256 || v == 512 || v == 1024) ? v : 1024; }
@@ -1308,13 +1311,15 @@ int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
   else if (n == "qt_points" && value >= 256 && value <= 4096 && value % 128 == 0) ctx->qt_points = value;   // LDS-resident candidates per (frame, level) of the big quadtree levels (half of it for the small ones)
   else if (n == "small_fused") ctx->small_fused = value != 0;
   else if (n == "qt_level_major") ctx->qt_level_major = value != 0;
+  else if (n == "qt_big_levels" && value >= 1 && value <= 8) ctx->qt_big_levels = value;
+  else if (n == "qt_threads_small" && (value == 0 || value == 64 || value == 128 || value == 192 || value == 256 || value == 512)) ctx->qt_threads_small = value;
   else if (n == "qt_one_launch") ctx->qt_one_launch = value != 0;
   else if (n == "window_direct") ctx->window_direct = value != 0;
   else if (n == "fast_split") ctx->fast_split = value != 0;   // FAST launched per group of levels with its own LDS size (batch calls)
   else if (n == "fast_stop") ctx->fast_stop = value;   // timing experiment: FAST returns after staging (1) / after the necessary test (2); results are void
   else if (n == "desc_lds") ctx->desc_lds = value != 0;
   else if (n == "fast_threads" && (value == 64 || value == 128 || value == 256)) ctx->fast_threads = value;
-  else if (n == "qt_threads" && (value == 0 || value == 64 || value == 128 || value == 256 || value == 512)) ctx->qt_threads = value;   // 0: chosen by batch size
+  else if (n == "qt_threads" && value >= 0 && value <= 512 && value % 64 == 0) ctx->qt_threads = value;   // 0: chosen by batch size
   else if (n == "desc_k" && (value == 1 || value == 2 || value == 4 || value == 8 || value == 16)) { ctx->desc_k = value; ctx->desc_k_user = true; }
   else if (n == "streams" && value >= 1 && value <= 2) ctx->nstreams = value;
   else return set_err(ctx, ORBX_E_INVALID, "orbx_set_option: unknown option or value out of range: " + n);
