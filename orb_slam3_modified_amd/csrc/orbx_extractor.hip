@@ -436,7 +436,8 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
   // K1, small batches: groups of consecutive levels in one launch each (k_resize_chain); the plan (which levels, LDS rectangles) and
   // the coverage check run on the host tables; anything the plan cannot serve takes the launch per level below
   int chained_upto = 0;   // levels 1 .. chained_upto are produced by chain launches
-  if (small_fused && geo.nlevels > 2) {
+  if ((small_fused || ctx->chain_batch) && geo.nlevels > 2) {
+    ProfScope ps(ctx, 0, st);
     int l = 1;
     while (l < geo.nlevels) {
       const int left = geo.nlevels - l;
@@ -779,6 +780,7 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, 
   { const char* e = getenv("ORBX_SMALL_FUSED"); ctx->small_fused = e ? atoi(e) != 0 : true; }
   { const char* e = getenv("ORBX_QT_THREADS_SMALL"); const int v = e ? atoi(e) : 128; ctx->qt_threads_small = (v == 64 || v == 128 || v == 192 || v == 256 || v == 512) ? v : 0; }
   { const char* e = getenv("ORBX_QT_BIG_LEVELS"); const int v = e ? atoi(e) : 0; ctx->qt_big_levels = (v >= 1 && v <= 8) ? v : kQtBigLevels; }
+  { const char* e = getenv("ORBX_CHAIN_BATCH"); ctx->chain_batch = e ? atoi(e) != 0 : false; }
   { const char* e = getenv("ORBX_QT_LEVEL_MAJOR"); ctx->qt_level_major = e ? atoi(e) != 0 : true; }
   { const char* e = getenv("ORBX_QT_ONE_LAUNCH"); ctx->qt_one_launch = e ? atoi(e) != 0 : false; }
   { const char* e = getenv("ORBX_CHAIN_THREADS"); const int v = e ? atoi(e) : 1024; ctx->chain_threads = (v == 256 || v == 512 || v == 1024) ? v : 1024; }
@@ -1311,6 +1313,8 @@ int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
   else if (n == "qt_points" && value >= 256 && value <= 4096 && value % 128 == 0) ctx->qt_points = value;   // LDS-resident candidates per (frame, level) of the big quadtree levels (half of it for the small ones)
   else if (n == "small_fused") ctx->small_fused = value != 0;
   else if (n == "qt_level_major") ctx->qt_level_major = value != 0;
+  else if (n == "chain_batch") ctx->chain_batch = value != 0;
+  else if (n == "chain_threads" && value >= 64 && value <= 1024 && value % 64 == 0) ctx->chain_threads = value;
   else if (n == "qt_big_levels" && value >= 1 && value <= 8) ctx->qt_big_levels = value;
   else if (n == "qt_threads_small" && (value == 0 || value == 64 || value == 128 || value == 192 || value == 256 || value == 512)) ctx->qt_threads_small = value;
   else if (n == "qt_one_launch") ctx->qt_one_launch = value != 0;
