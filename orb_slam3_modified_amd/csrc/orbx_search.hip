@@ -262,38 +262,62 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoGeom sg, const orbx_
 
 // The median filter of the accepted matches (src/Frame.cc:969-981): only the value of the (n/2)-th smallest SAD
 // matters (all matches with SAD >= 1.5 * 1.4 * median are removed), so no sort is needed — one workgroup counts ranks.
+// sad values staged in LDS when they fit (the median is found by rank counting: every thread walks all of them); `h_u / h_d / h_done`
+// (optional): the caller-visible mapped copy of the two result arrays and the word the waiting host polls
+constexpr int kStereoLdsSad = 12288;
 __global__ __launch_bounds__(1024) void k_stereo_filter(int N, float* __restrict__ uRight, float* __restrict__ depth,
-                                                        const int32_t* __restrict__ sad, int32_t* __restrict__ kept_out) {
+                                                        const int32_t* __restrict__ sad, int32_t* __restrict__ kept_out,
+                                                        float* __restrict__ h_u, float* __restrict__ h_d,
+                                                        unsigned long long* __restrict__ h_done) {
   __shared__ int s_n, s_median, s_kept;
+  __shared__ int32_t s_sad[kStereoLdsSad];
   const int t = threadIdx.x;
   if (t == 0) { s_n = 0; s_median = -1; s_kept = 0; }
+  const bool lds = N <= kStereoLdsSad;   // block-uniform
+  if (lds) for (int i = t; i < N; i += 1024) s_sad[i] = sad[i];
   __syncthreads();
+  const int32_t* S = lds ? s_sad : sad;
   int mine = 0;
-  for (int i = t; i < N; i += 1024) mine += sad[i] >= 0;
+  for (int i = t; i < N; i += 1024) mine += S[i] >= 0;
   if (mine) atomicAdd(&s_n, mine);
   __syncthreads();
   const int n = s_n;
-  if (n == 0) { if (t == 0) *kept_out = 0; return; }
-  const int k = n / 2;
-  for (int i = t; i < N; i += 1024) {
-    const int v = sad[i];
-    if (v < 0) continue;
-    int lo = 0, eq = 0;
-    for (int j = 0; j < N; j++) { const int u = sad[j]; lo += (u >= 0 && u < v); eq += (u == v); }
-    if (lo <= k && k < lo + eq) s_median = v;   // every thread that hits writes the same value
+  if (n > 0) {   // block-uniform
+    const int k = n / 2;
+    for (int i = t; i < N; i += 1024) {
+      const int v = S[i];
+      if (v < 0) continue;
+      int lo = 0, eq = 0;
+      for (int j = 0; j < N; j++) { const int u = S[j]; lo += (u >= 0 && u < v); eq += (u == v); }
+      if (lo <= k && k < lo + eq) s_median = v;   // every thread that hits writes the same value
+    }
+    __syncthreads();
+    const float thDist = __fmul_rn(1.5f * 1.4f, (float)s_median);
+    int kept = 0;
+    for (int i = t; i < N; i += 1024) {
+      const int v = S[i];
+      if (v < 0) continue;
+      if ((float)v < thDist) kept++;
+      else { uRight[i] = -1.0f; depth[i] = -1.0f; }
+    }
+    if (kept) atomicAdd(&s_kept, kept);
   }
-  __syncthreads();
-  const float thDist = __fmul_rn(1.5f * 1.4f, (float)s_median);
-  int kept = 0;
-  for (int i = t; i < N; i += 1024) {
-    const int v = sad[i];
-    if (v < 0) continue;
-    if ((float)v < thDist) kept++;
-    else { uRight[i] = -1.0f; depth[i] = -1.0f; }
-  }
-  if (kept) atomicAdd(&s_kept, kept);
   __syncthreads();
   if (t == 0) *kept_out = s_kept;
+  if (h_done) {   // block-uniform: every thread mirrors the entries it finalised, then ONE system-scope release and the done word
+    for (int i = t; i < N; i += 1024) { h_u[i] = uRight[i]; h_d[i] = depth[i]; }
+    __builtin_amdgcn_s_waitcnt(0);   // this wave's stores have left
+    __syncthreads();
+    if (t == 0) {
+      __threadfence_system();
+      __hip_atomic_store(h_done, 0x100000000ull | (unsigned long long)(uint32_t)s_kept, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// input blob from mapped pinned memory into HBM (k_stereo_match gathers right keypoints and descriptors at random)
+__global__ __launch_bounds__(256) void k_stereo_stage_in(const uint4* __restrict__ src, uint4* __restrict__ dst, int n16) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = src[i];
 }
 
 // Scratch buffers of one entry-point call: slices of the context's arena (rewound by ArenaScope at the call's start).
@@ -869,25 +893,70 @@ int orbx_stereo_matches(orbx_ctx* left, orbx_ctx* right, const orbx_keypoint* kp
     sg.scale[l] = left->scale[l]; sg.inv_scale[l] = left->inv_scale[l];
   }
   ArenaScope scope(ctx);
-  DBuf<orbx_keypoint> dkl, dkr;
-  DBuf<uint8_t> ddl, ddr;
+  hipStream_t st = ctx->stream;
+  // one packed blob in pinned memory (keypoints and descriptors of both sides), pulled into HBM by a copy kernel; the filter kernel
+  // writes the two result arrays into the mapped output and the host polls a done word — no copy node, no stream synchronisation
+  // ("window_direct" = 0 selects copies + synchronisation instead)
+  BlobLayout in, out;
+  const size_t o_kl = in.add(sizeof(orbx_keypoint) * (size_t)nL), o_kr = in.add(sizeof(orbx_keypoint) * (size_t)nR),
+               o_dl = in.add((size_t)nL * 32), o_dr = in.add((size_t)nR * 32);
+  const size_t p_u = out.add(sizeof(float) * (size_t)nL), p_d = out.add(sizeof(float) * (size_t)nL), p_done = out.add(16);
+  uint8_t* h = nullptr;
+  ORBX_HIP(ctx, host_stage(ctx, in.size + out.size, &h));
+  std::memcpy(h + o_kl, kpsL, sizeof(orbx_keypoint) * (size_t)nL);
+  std::memcpy(h + o_kr, kpsR, sizeof(orbx_keypoint) * (size_t)nR);
+  std::memcpy(h + o_dl, descL, (size_t)nL * 32);
+  std::memcpy(h + o_dr, descR, (size_t)nR * 32);
+  DBuf<uint8_t> din;
   DBuf<float> du, dd;
   DBuf<int32_t> dsad, dkept;
-  ORBX_HIP(ctx, dkl.alloc(nL)); ORBX_HIP(ctx, dkr.alloc(nR)); ORBX_HIP(ctx, ddl.alloc((size_t)nL * 32)); ORBX_HIP(ctx, ddr.alloc((size_t)nR * 32));
+  ORBX_HIP(ctx, din.alloc(in.size));
   ORBX_HIP(ctx, du.alloc(nL)); ORBX_HIP(ctx, dd.alloc(nL)); ORBX_HIP(ctx, dsad.alloc(nL)); ORBX_HIP(ctx, dkept.alloc(1));
-  hipStream_t st = ctx->stream;
-  ORBX_HIP(ctx, hipMemcpyAsync(dkl.p, kpsL, sizeof(orbx_keypoint) * nL, hipMemcpyHostToDevice, st));
-  ORBX_HIP(ctx, hipMemcpyAsync(dkr.p, kpsR, sizeof(orbx_keypoint) * nR, hipMemcpyHostToDevice, st));
-  ORBX_HIP(ctx, hipMemcpyAsync(ddl.p, descL, (size_t)nL * 32, hipMemcpyHostToDevice, st));
-  ORBX_HIP(ctx, hipMemcpyAsync(ddr.p, descR, (size_t)nR * 32, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(k_stereo_match, dim3((nL + 3) / 4), dim3(256), 0, st, sg, dkl.p, ddl.p, nL, dkr.p, ddr.p, nR, mb, mbf, du.p, dd.p, dsad.p);
-  hipLaunchKernelGGL(k_stereo_filter, dim3(1), dim3(1024), 0, st, nL, du.p, dd.p, dsad.p, dkept.p);
-  ORBX_HIP(ctx, hipGetLastError());
+  const orbx_keypoint* dkl = (const orbx_keypoint*)(din.p + o_kl);
+  const orbx_keypoint* dkr = (const orbx_keypoint*)(din.p + o_kr);
+  uint8_t* hdev = nullptr;
+  const bool direct = ctx->window_direct && hipHostGetDevicePointer((void**)&hdev, h, 0) == hipSuccess && hdev != nullptr;
+  if (!direct) (void)hipGetLastError();
   int32_t kept = 0;
-  ORBX_HIP(ctx, hipMemcpyAsync(u_right, du.p, sizeof(float) * nL, hipMemcpyDeviceToHost, st));
-  ORBX_HIP(ctx, hipMemcpyAsync(depth, dd.p, sizeof(float) * nL, hipMemcpyDeviceToHost, st));
-  ORBX_HIP(ctx, hipMemcpyAsync(&kept, dkept.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-  ORBX_HIP(ctx, hipStreamSynchronize(st));
+  if (direct) {
+    uint8_t* hout = h + in.size;
+    volatile unsigned long long* done = (volatile unsigned long long*)(hout + p_done);
+    __atomic_store_n(done, 0ull, __ATOMIC_RELEASE);
+    const int n16 = (int)((in.size + 15) / 16);
+    hipLaunchKernelGGL(k_stereo_stage_in, dim3(std::min((n16 + 255) / 256, 512)), dim3(256), 0, st, (const uint4*)hdev, (uint4*)din.p, n16);
+    hipLaunchKernelGGL(k_stereo_match, dim3((nL + 3) / 4), dim3(256), 0, st, sg, dkl, din.p + o_dl, nL, dkr, din.p + o_dr, nR, mb, mbf, du.p, dd.p, dsad.p);
+    hipLaunchKernelGGL(k_stereo_filter, dim3(1), dim3(1024), 0, st, nL, du.p, dd.p, dsad.p, dkept.p, (float*)(hdev + in.size + p_u),
+                       (float*)(hdev + in.size + p_d), (unsigned long long*)(hdev + in.size + p_done));
+    ORBX_HIP(ctx, hipGetLastError());
+    unsigned long long word = 0;
+    for (unsigned spin = 1;; spin++) {
+      if ((word = __atomic_load_n(done, __ATOMIC_ACQUIRE)) != 0) break;
+      if ((spin & 0x3fff) == 0) {
+        const hipError_t qe = hipStreamQuery(st);
+        if (qe == hipSuccess) {
+          if ((word = __atomic_load_n(done, __ATOMIC_ACQUIRE)) != 0) break;
+          return set_err(ctx, ORBX_E_DEVICE, "orbx_stereo_matches: the pass finished without publishing its results");
+        }
+        if (qe != hipErrorNotReady) { ORBX_HIP(ctx, qe); }
+      }
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+    kept = (int32_t)(uint32_t)word;
+    std::memcpy(u_right, hout + p_u, sizeof(float) * (size_t)nL);
+    std::memcpy(depth, hout + p_d, sizeof(float) * (size_t)nL);
+  } else {
+    ORBX_HIP(ctx, hipMemcpyAsync(din.p, h, in.size, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_stereo_match, dim3((nL + 3) / 4), dim3(256), 0, st, sg, dkl, din.p + o_dl, nL, dkr, din.p + o_dr, nR, mb, mbf, du.p, dd.p, dsad.p);
+    hipLaunchKernelGGL(k_stereo_filter, dim3(1), dim3(1024), 0, st, nL, du.p, dd.p, dsad.p, dkept.p, (float*)nullptr, (float*)nullptr,
+                       (unsigned long long*)nullptr);
+    ORBX_HIP(ctx, hipGetLastError());
+    ORBX_HIP(ctx, hipMemcpyAsync(u_right, du.p, sizeof(float) * nL, hipMemcpyDeviceToHost, st));
+    ORBX_HIP(ctx, hipMemcpyAsync(depth, dd.p, sizeof(float) * nL, hipMemcpyDeviceToHost, st));
+    ORBX_HIP(ctx, hipMemcpyAsync(&kept, dkept.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    ORBX_HIP(ctx, hipStreamSynchronize(st));
+  }
   if (nmatches) *nmatches = kept;
   return ORBX_OK;
 }
