@@ -287,7 +287,12 @@ int orbx_target_search(orbx_ctx* ctx, const orbx_target* target, const uint8_t* 
 /* orbx_target_search without the copy-out: the candidate lists are read where the kernel wrote them — the call's pinned, mapped blob.
  * Query q's candidates are pool[spans[q].start .. spans[q].start + spans[q].count), in GetFeaturesInArea's order, each with its
  * Hamming distance.  Both pointers stay valid until the NEXT call on this context.  Returns the total number of candidates. */
-typedef struct orbx_list_span { int32_t start, count; } orbx_list_span;
+/* One record per query of a list view.  start / count: the query's segment of the candidate pool, in the reference's list order.
+ * best_* / second_*: the two smallest (distance, list position) among that segment — what a loop over the segment with
+ * `if (d < best) { second = best; best = d; } else if (d < second) second = d;` ends with — idx = -1 / dist = 256 when there is none.
+ * A caller whose own gates pass on the best (and second) entry can skip the loop: an entry that is minimal in the whole segment is
+ * minimal in every subset that contains it. */
+typedef struct orbx_list_span { int32_t start, count, best_idx, best_dist, second_idx, second_dist, reserved0, reserved1; } orbx_list_span;
 typedef struct orbx_candidate { int32_t idx, dist; } orbx_candidate;
 int orbx_target_search_view(orbx_ctx* ctx, const orbx_target* target, const uint8_t* kp_skip, const float* qx, const float* qy, const float* qr,
                             const int32_t* qmin_level, const int32_t* qmax_level, const uint8_t* q_desc, const float* q_xr, int nq,

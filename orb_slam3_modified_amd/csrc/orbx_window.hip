@@ -745,7 +745,7 @@ int window_call_target(orbx_ctx* ctx, const char* who, const orbx_target* T, con
   Layout in;
   const size_t o_q = in.add(sizeof(WinQueryIn) * (size_t)nq), o_skip = in.add((size_t)nskip);
   Layout out;
-  const bool compact = !(best_idx || best_dist || second_idx || second_dist);
+  const bool compact = !(best_idx || best_dist || second_idx || second_dist) && !v_spans;   // a view hands the full records to the caller
   const size_t qrec = compact ? sizeof(WinQueryShort) : sizeof(WinQueryOut);
   const size_t p_hdr = out.add(16), p_q = out.add(qrec * (size_t)nq), p_pool = out.add(8 * (size_t)pool_cap);
   uint8_t* h = nullptr;
@@ -831,7 +831,7 @@ int window_call_target(orbx_ctx* ctx, const char* who, const orbx_target* T, con
   auto q_count = [&](int q) { return compact ? qs[q].count : qo[q].count; };
   if (v_spans) {   // the caller reads the lists where the kernel left them (the call's pinned blob, valid until the context's next call)
     if (total > pool_cap) { if (row_ptr) row_ptr[nq] = total; return set_err(ctx, ORBX_E_CAPACITY, std::string(who) + ": candidate buffer too small"); }
-    static_assert(sizeof(orbx_list_span) == sizeof(WinQueryShort) && sizeof(orbx_candidate) == sizeof(int2), "view layout");
+    static_assert(sizeof(orbx_list_span) == sizeof(WinQueryOut) && sizeof(orbx_candidate) == sizeof(int2), "view layout");
     *v_spans = (const orbx_list_span*)(hout + p_q);
     *v_pool = (const orbx_candidate*)(hout + p_pool);
     if (trace)

@@ -144,6 +144,9 @@ struct Lists {
     const int32_t* own = nullptr; const orbx_candidate* view = nullptr; bool second = false;
     int32_t operator[](int c) const { return view ? (second ? view[c].dist : view[c].idx) : own[c]; }
   } cand, dist;
+  // view mode only: the two smallest (distance, list position) of the query's whole segment, from the device pass (orbx_list_span)
+  bool has_best() const { return spans != nullptr; }
+  const orbx_list_span& span(int q) const { return spans[q]; }
   int begin(int q) const { return spans ? spans[q].start : row_ptr[q]; }
   int end(int q) const { return spans ? spans[q].start + spans[q].count : row_ptr[q + 1]; }
   void own() { spans = nullptr; cand = Column{cand_v.data(), nullptr, false}; dist = Column{dist_v.data(), nullptr, true}; }
@@ -494,14 +497,30 @@ int ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoint
       const int q = qLeft[iMP];
       if (LL.begin(q) != LL.end(q)) {
         int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
-        for (int c = LL.begin(q); c < LL.end(q); c++) {
-          const size_t idx = LL.cand[c];
+        auto eligible = [&](size_t idx) {   // the gates of :89-101 on one candidate
           if (F.mvpMapPoints[idx])
-            if (F.mvpMapPoints[idx]->Observations() > 0) continue;
+            if (F.mvpMapPoints[idx]->Observations() > 0) return false;
           if (F.Nleft == -1 && F.mvuRight[idx] > 0) {
             const float er = fabs(pMP->mTrackProjXR - F.mvuRight[idx]);
-            if (er > QL.r[q]) continue;
+            if (er > QL.r[q]) return false;
           }
+          return true;
+        };
+        // the device pass found the two smallest (distance, list position) of the whole list: when both pass the gates here they are the
+        // two smallest of the gated list as well (a list of one: the best alone), and the loop is not needed
+        bool have = false;
+        if (LL.has_best()) {
+          const orbx_list_span& sp = LL.span(q);
+          if (sp.best_idx >= 0 && eligible((size_t)sp.best_idx) && (sp.count == 1 || (sp.second_idx >= 0 && eligible((size_t)sp.second_idx)))) {
+            bestDist = sp.best_dist; bestIdx = sp.best_idx; bestLevel = keysL[sp.best_idx].octave;
+            if (sp.count > 1) { bestDist2 = sp.second_dist; bestLevel2 = keysL[sp.second_idx].octave; }
+            have = true;
+          }
+        }
+        if (!have)
+        for (int c = LL.begin(q); c < LL.end(q); c++) {
+          const size_t idx = LL.cand[c];
+          if (!eligible(idx)) continue;
           const int dist = LL.dist[c];
           if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = keysL[idx].octave; bestIdx = idx; }
           else if (dist < bestDist2) { bestLevel2 = keysL[idx].octave; bestDist2 = dist; }
@@ -1260,14 +1279,24 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
     const int q = qLeft[i];
     if (LL.begin(q) == LL.end(q)) continue;   // (`if(vIndices2.empty()) continue;` skips the right camera too, :1735-1736)
     int bestDist = 256, bestIdx2 = -1;
-    for (int c = LL.begin(q); c < LL.end(q); c++) {
-      const size_t i2 = LL.cand[c];
+    // the gates of :1741-1760 on one candidate
+    auto eligible = [&](size_t i2) {
       if (CurrentFrame.mvpMapPoints[i2])
-        if (CurrentFrame.mvpMapPoints[i2]->Observations() > 0) continue;
+        if (CurrentFrame.mvpMapPoints[i2]->Observations() > 0) return false;
       if (CurrentFrame.Nleft == -1 && CurrentFrame.mvuRight[i2] > 0) {
         const float er = fabs(QL.aux[q] - CurrentFrame.mvuRight[i2]);
-        if (er > QL.r[q]) continue;
+        if (er > QL.r[q]) return false;
       }
+      return true;
+    };
+    // The device pass already found the first minimum of the whole list; if that candidate passes the gates here — which depend on
+    // what earlier points of this loop took — it is also the first minimum of the gated list and the loop is not needed.
+    if (LL.has_best() && LL.span(q).best_idx >= 0 && eligible((size_t)LL.span(q).best_idx)) {
+      bestDist = LL.span(q).best_dist; bestIdx2 = LL.span(q).best_idx;
+    } else
+    for (int c = LL.begin(q); c < LL.end(q); c++) {
+      const size_t i2 = LL.cand[c];
+      if (!eligible(i2)) continue;
       const int dist = LL.dist[c];
       if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
     }

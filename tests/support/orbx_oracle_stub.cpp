@@ -247,7 +247,13 @@ int orbx_target_search_view(orbx_ctx* ctx, const orbx_target* T, const uint8_t* 
   int at = 0;
   for (int q = nq - 1; q >= 0; q--) {
     sp[q].start = at; sp[q].count = rp[q + 1] - rp[q];
-    for (int c = rp[q]; c < rp[q + 1]; c++) { pl[at].idx = cand[c]; pl[at].dist = dist[c]; at++; }
+    sp[q].best_idx = sp[q].second_idx = -1; sp[q].best_dist = sp[q].second_dist = 256; sp[q].reserved0 = sp[q].reserved1 = 0;
+    for (int c = rp[q]; c < rp[q + 1]; c++) {
+      pl[at].idx = cand[c]; pl[at].dist = dist[c]; at++;
+      // the two smallest (distance, list position)
+      if (dist[c] < sp[q].best_dist) { sp[q].second_idx = sp[q].best_idx; sp[q].second_dist = sp[q].best_dist; sp[q].best_idx = cand[c]; sp[q].best_dist = dist[c]; }
+      else if (dist[c] < sp[q].second_dist) { sp[q].second_idx = cand[c]; sp[q].second_dist = dist[c]; }
+    }
   }
   *spans = sp.data(); *pool = pl.data();
   return rp[nq];
