@@ -791,11 +791,25 @@ int orbx_bow_finalize(const orbx_voc* v, const uint32_t* word, const double* wei
   // the reference accumulates into an ordered map feature by feature (addWeight: `vit->second += v` in feature order); sorting
   // (word, feature index) keys gives the same words in ascending order and, inside a word, the same order of additions
   const bool tf = v->weighting == 0 /*TF_IDF*/ || v->weighting == 1 /*TF*/;
-  static thread_local std::vector<uint64_t> keys;
+  static thread_local std::vector<uint64_t> keys, tmp;
   keys.clear();
+  uint32_t maxw = 0;
   for (int i = 0; i < n; i++)
-    if (weight[i] > 0) keys.push_back(((uint64_t)word[i] << 32) | (uint32_t)i);
-  std::sort(keys.begin(), keys.end());
+    if (weight[i] > 0) { keys.push_back(((uint64_t)word[i] << 32) | (uint32_t)i); maxw = std::max(maxw, word[i]); }
+  // ascending (word, feature): the keys start out in feature order, so a STABLE sort by word alone does it — LSD radix, 11 bits a pass
+  // (two passes for a 10^6-word vocabulary) instead of a comparison sort
+  {
+    tmp.resize(keys.size());
+    uint32_t cnt[2048];
+    for (int shift = 0; shift < 32 && (maxw >> shift) != 0; shift += 11) {
+      std::memset(cnt, 0, sizeof(cnt));
+      for (uint64_t k : keys) cnt[(uint32_t)(k >> (32 + shift)) & 2047u]++;
+      uint32_t run = 0;
+      for (int b = 0; b < 2048; b++) { const uint32_t c = cnt[b]; cnt[b] = run; run += c; }
+      for (uint64_t k : keys) tmp[cnt[(uint32_t)(k >> (32 + shift)) & 2047u]++] = k;
+      keys.swap(tmp);
+    }
+  }
   int k = 0;
   for (size_t a = 0; a < keys.size();) {
     const uint32_t w = (uint32_t)(keys[a] >> 32);
