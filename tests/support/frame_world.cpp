@@ -407,6 +407,34 @@ int main(int argc, char** argv) {
         dump_copy(*boxes[t].f);
       }
     }
+    // ---- 3b. degenerate inputs: a constant image (no keypoint at all: the constructor returns early, :324-325) and a nearly flat one
+    //          (a handful of corners from the sensor noise only: far fewer than nfeatures, most grid cells empty)
+    {
+      ORBextractor ex(1000, 1.2f, 8, 20, 7);
+      for (int t = 0; t < 2; t++) {
+        const int rows = 480, cols = 640;
+        cv::Mat im(rows, cols, CV_8UC1);
+        Lcg rng(777);
+        for (int y = 0; y < rows; y++)
+          for (int x = 0; x < cols; x++) {
+            int v = 128;
+            if (t == 1) { v += rng.below(3) - 1; if (((x / 80) + (y / 80)) % 5 == 0 && (x % 80) < 2 && (y % 80) < 2) v = 255; }   // a few bright 2 x 2 dots
+            im.at<unsigned char>(y, x) = (unsigned char)v;
+          }
+        Frame::mbInitialComputations = true;
+        FrameBox box;
+        box.prefill(bf / fx);
+        box.f = new (box.raw) Frame(im, 4.0 + t, &ex, &voc, &pin, D0, bf, thDepth);
+        if (t == 0) {   // nothing after `N = mvKeys.size()` ran: only what the constructor set before the early return is defined
+          std::fprintf(g_out, "mono_constant_640x480 id=%lu N=%d levels=%d keys=%zu desc_rows=%d\n", box.f->mnId, box.f->N, box.f->mnScaleLevels, box.f->mvKeys.size(),
+                       box.f->mDescriptors.rows);
+        } else {
+          dump_frame("mono_nearly_flat_640x480", *box.f, false);
+          dump_bow(*box.f);
+          dump_areas(*box.f, false);
+        }
+      }
+    }
     // ---- 4. two fisheye cameras, 512 x 512 (TUM-VI): lapping areas, kNN-2 between the lapping descriptors, both grids
     {
       const int rows = 512, cols = 512, ccols = cols + 32;

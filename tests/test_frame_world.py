@@ -59,10 +59,13 @@ def _golden():
 def test_golden_covers_every_constructor():
     frames = [l.split()[0] for l in _golden().splitlines() if not l.startswith(" ")]
     assert frames == ["stereo_752x480", "stereo_752x480_next", "rgbd_640x480_distorted", "mono_752x480_distorted", "mono_1024x512_5000",
-                      "mono_752x480_with_prev", "fisheye_pair_512"]
+                      "mono_752x480_with_prev", "mono_constant_640x480", "mono_nearly_flat_640x480", "fisheye_pair_512"]
     txt = _golden()
     depth = [int(l.split("with_depth=")[1].split()[0]) for l in txt.splitlines() if "with_depth=" in l]
-    assert depth[0] > 500 and depth[1] > 500 and depth[2] > 500 and depth[3] == 0 and depth[6] > 50     # stereo, RGB-D and fisheye matches exist
+    assert depth[0] > 500 and depth[1] > 500 and depth[2] > 500 and depth[3] == 0 and depth[-1] > 50     # stereo, RGB-D and fisheye matches exist
+    heads = {l.split()[0]: l for l in txt.splitlines() if not l.startswith(" ")}
+    assert " N=0 " in heads["mono_constant_640x480"] and "keys=0" in heads["mono_constant_640x480"]       # the early return of the constructor
+    assert 0 < int(heads["mono_nearly_flat_640x480"].split("N=")[1].split()[0]) < 200                      # far fewer keypoints than asked for
     both = [l for l in txt.splitlines() if l.startswith("mono_1024x512_5000")][0]
     mono_left = int(both.split("monoLeft=")[1].split()[0])
     assert mono_left == -1        # the monocular constructor resets it after the extraction (:363); the split shows in mvKeys' order instead
