@@ -441,16 +441,24 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
     int l = 1;
     while (l < geo.nlevels) {
       const int left = geo.nlevels - l;
-      const int K = left == 3 ? 3 : (left >= 2 ? 2 : 1);
+      // which levels share a launch.  A single frame: ALL of them (up to seven per launch), on 16 x 16 tiles of the last level — 108 workgroups
+      // at 640 x 480, each recomputing the rectangles of the six levels above its tile (about twice the pixels of the pyramid in total: a few
+      // microseconds of arithmetic), against ≈ 8 us of device time for every launch saved inside the replayed graph.  Measured on the whole
+      // operator(): device 110.8 us with the groups (1,2)(3,4)(5,6,7) of 64 x 64 tiles, 104.8 / 102.2 with (1,2)(3..7) on 32 / 16-px tiles,
+      // 96.7 with one launch ("chain_long" = 0: the groups of two or three; "chain_first": levels in the first launch; "chain_long_tile")
+      int K = left == 3 ? 3 : (left >= 2 ? 2 : 1);
+      if (ctx->chain_long && !ctx->chain_batch && left >= 2) K = l > 1 ? std::min(left, 7) : std::min(left, ctx->chain_first);
       if (K == 1) break;
       // rectangles of every tile of the group's last level, as the kernel derives them
       const LevelGeom& LD = geo.lv[l + K - 1];
-      const int nbx = (LD.w + kRT_W - 1) / kRT_W, nby = (LD.h + kRT_H - 1) / kRT_H;
-      int mw[4] = {0, 0, 0, 0}, mh[4] = {0, 0, 0, 0};
+      const int tile = K >= 4 ? ctx->chain_long_tile : kRT_W;   // long chains: smaller tiles, more workgroups
+      const int cthreads = K >= 4 ? std::min(ctx->chain_threads, 512) : ctx->chain_threads;
+      const int nbx = (LD.w + tile - 1) / tile, nby = (LD.h + tile - 1) / tile;
+      int mw[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mh[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       std::vector<std::vector<uint8_t> > colhit(K), rowhit(K);
       for (int k = 1; k < K; k++) { colhit[k].assign(geo.lv[l + k - 1].w, 0); rowhit[k].assign(geo.lv[l + k - 1].h, 0); }
       for (int b = 0; b < std::max(nbx, nby); b++) {   // columns and rows are independent: one sweep over tile columns, one over tile rows
-        int X0 = b * kRT_W, X1 = std::min(b * kRT_W + kRT_W, LD.w) - 1, Y0 = b * kRT_H, Y1 = std::min(b * kRT_H + kRT_H, LD.h) - 1;
+        int X0 = b * tile, X1 = std::min(b * tile + tile, LD.w) - 1, Y0 = b * tile, Y1 = std::min(b * tile + tile, LD.h) - 1;
         for (int k = K; k >= 1; k--) {
           const LevelGeom& L = geo.lv[l + k - 1];
           if (b < nbx) {
@@ -473,13 +481,16 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
         for (uint8_t h : rowhit[k]) covered = covered && h;
       }
       size_t lds = 0;
-      int off[3] = {0, 0, 0};
+      int off[7] = {0, 0, 0, 0, 0, 0, 0};
       for (int k = 0; k < K; k++) { off[k] = (int)lds; lds += (size_t)mw[k] * mh[k]; lds = (lds + 15) & ~(size_t)15; }
-      if (!covered || lds > 64 * 1024) break;
+      if (!covered || lds > kLdsMax) break;
+      const void* chain_kern = K == 2 ? (const void*)k_resize_chain<2> : K == 3 ? (const void*)k_resize_chain<3> : K == 4 ? (const void*)k_resize_chain<4>
+                               : K == 5 ? (const void*)k_resize_chain<5> : K == 6 ? (const void*)k_resize_chain<6> : (const void*)k_resize_chain<7>;
+      if (lds > 64 * 1024 && ensure_dynamic_lds(chain_kern, (int)lds) != hipSuccess) { (void)hipGetLastError(); break; }
       auto fill = [&](auto& ca) {
         if (l == 1) { ca.src = d_imgs; ca.src_frame_stride = (long long)frame_stride; ca.src_pitch = (int)row_stride; }
         else { ca.src = b_pyr + geo.lv[l - 1].plane_off; ca.src_frame_stride = geo.pyr_bytes; ca.src_pitch = geo.lv[l - 1].pitch; }
-        ca.sw = geo.lv[l - 1].w; ca.dst_frame_stride = (long long)geo.pyr_bytes; ca.nbx = nbx; ca.nby = nby;
+        ca.sw = geo.lv[l - 1].w; ca.dst_frame_stride = (long long)geo.pyr_bytes; ca.nbx = nbx; ca.nby = nby; ca.tile = tile;
         for (int k = 0; k < K; k++) {
           const LevelGeom& L = geo.lv[l + k];
           ca.lv[k].xt = ctx->d_xtab + L.xtab_off; ca.lv[k].yt = ctx->d_ytab + L.ytab_off; ca.lv[k].dst = b_pyr + L.plane_off;
@@ -487,8 +498,12 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
           ca.buf_off[k] = off[k]; ca.buf_pitch[k] = mw[k];
         }
       };
-      if (K == 2) { ChainArgs<2> ca; fill(ca); hipLaunchKernelGGL(k_resize_chain<2>, dim3(nbx * nby, nframes), dim3(ctx->chain_threads), lds, st, ca); }
-      else { ChainArgs<3> ca; fill(ca); hipLaunchKernelGGL(k_resize_chain<3>, dim3(nbx * nby, nframes), dim3(ctx->chain_threads), lds, st, ca); }
+      if (K == 2) { ChainArgs<2> ca; fill(ca); hipLaunchKernelGGL(k_resize_chain<2>, dim3(nbx * nby, nframes), dim3(cthreads), lds, st, ca); }
+      else if (K == 3) { ChainArgs<3> ca; fill(ca); hipLaunchKernelGGL(k_resize_chain<3>, dim3(nbx * nby, nframes), dim3(cthreads), lds, st, ca); }
+      else if (K == 4) { ChainArgs<4> ca; fill(ca); hipLaunchKernelGGL(k_resize_chain<4>, dim3(nbx * nby, nframes), dim3(cthreads), lds, st, ca); }
+      else if (K == 5) { ChainArgs<5> ca; fill(ca); hipLaunchKernelGGL(k_resize_chain<5>, dim3(nbx * nby, nframes), dim3(cthreads), lds, st, ca); }
+      else if (K == 6) { ChainArgs<6> ca; fill(ca); hipLaunchKernelGGL(k_resize_chain<6>, dim3(nbx * nby, nframes), dim3(cthreads), lds, st, ca); }
+      else { ChainArgs<7> ca; fill(ca); hipLaunchKernelGGL(k_resize_chain<7>, dim3(nbx * nby, nframes), dim3(cthreads), lds, st, ca); }
       chained_upto = l + K - 1;
       l += K;
     }
@@ -780,6 +795,9 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, 
   { const char* e = getenv("ORBX_SMALL_FUSED"); ctx->small_fused = e ? atoi(e) != 0 : true; }
   { const char* e = getenv("ORBX_QT_THREADS_SMALL"); const int v = e ? atoi(e) : 128; ctx->qt_threads_small = (v == 64 || v == 128 || v == 192 || v == 256 || v == 512) ? v : 0; }
   { const char* e = getenv("ORBX_QT_BIG_LEVELS"); const int v = e ? atoi(e) : 0; ctx->qt_big_levels = (v >= 1 && v <= 8) ? v : kQtBigLevels; }
+  { const char* e = getenv("ORBX_CHAIN_LONG"); ctx->chain_long = e ? atoi(e) != 0 : true; }
+  { const char* e = getenv("ORBX_CHAIN_LONG_TILE"); const int v = e ? atoi(e) : 16; ctx->chain_long_tile = (v >= 8 && v <= 64 && v % 4 == 0) ? v : 16; }
+  { const char* e = getenv("ORBX_CHAIN_FIRST"); const int v = e ? atoi(e) : 7; ctx->chain_first = (v >= 2 && v <= 7) ? v : 7; }
   { const char* e = getenv("ORBX_CHAIN_BATCH"); ctx->chain_batch = e ? atoi(e) != 0 : false; }
   { const char* e = getenv("ORBX_QT_LEVEL_MAJOR"); ctx->qt_level_major = e ? atoi(e) != 0 : true; }
   { const char* e = getenv("ORBX_QT_ONE_LAUNCH"); ctx->qt_one_launch = e ? atoi(e) != 0 : false; }
@@ -1314,6 +1332,9 @@ int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
   else if (n == "small_fused") ctx->small_fused = value != 0;
   else if (n == "qt_level_major") ctx->qt_level_major = value != 0;
   else if (n == "chain_batch") ctx->chain_batch = value != 0;
+  else if (n == "chain_long") ctx->chain_long = value != 0;
+  else if (n == "chain_long_tile" && value >= 8 && value <= 64 && value % 4 == 0) ctx->chain_long_tile = value;
+  else if (n == "chain_first" && value >= 2 && value <= 7) ctx->chain_first = value;
   else if (n == "chain_threads" && value >= 64 && value <= 1024 && value % 64 == 0) ctx->chain_threads = value;
   else if (n == "qt_big_levels" && value >= 1 && value <= 8) ctx->qt_big_levels = value;
   else if (n == "qt_threads_small" && (value == 0 || value == 64 || value == 128 || value == 192 || value == 256 || value == 512)) ctx->qt_threads_small = value;

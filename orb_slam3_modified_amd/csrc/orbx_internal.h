@@ -153,6 +153,9 @@ struct orbx_ctx {
   bool fork_blur = true, fork_fast0 = false, fork_qt = true, fast_pk = true, desc_lds = true;
   int qt_points = 2048;       // LDS-resident candidate capacity per (frame, level) of k_quadtree's big levels ("qt_points" / ORBX_QT_POINTS)
   int chain_threads = 1024;   // workgroup size of k_resize_chain (ORBX_CHAIN_THREADS)
+  int chain_first = 7;           // levels in the first chain launch of a single frame (2 .. 7)
+  int chain_long_tile = 16;      // tile of the last level of a long chain
+  bool chain_long = true;        // single-frame pyramid: levels 1-2 in one launch, then up to five small levels per launch
   bool chain_batch = false;      // batches too build the pyramid with the chain launches (k_resize_chain) instead of one launch per level
   int qt_big_levels = 2;         // levels of a batch launched with the large quadtree workgroup configuration
   int qt_threads_small = 128;    // threads of the small-level quadtree launch of a batch (0 = as the big levels): 127.9 -> 115.4 us per 256 frames

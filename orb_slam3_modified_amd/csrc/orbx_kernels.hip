@@ -182,7 +182,7 @@ template <int K>
 struct ChainArgs {
   const uint8_t* src; long long src_frame_stride, dst_frame_stride; int src_pitch, sw;
   ChainLevel lv[K];          // destination levels, in order
-  int nbx, nby;              // tiles of the last level
+  int nbx, nby, tile;        // tiles of the last level (tile x tile pixels: kRT_W, or smaller for long chains of small levels)
   int buf_off[K], buf_pitch[K];   // LDS rectangles: [0] = source, [k] = destination level k - 1 of the group (k < K)
 };
 
@@ -219,8 +219,8 @@ __global__ __launch_bounds__(1024) void k_resize_chain(const ChainArgs<K> a) {
   const int by = (int)blockIdx.x / a.nbx, bx = (int)blockIdx.x - by * a.nbx;
   // rectangles, inclusive: [k] for k = K (the tile of the last level) down to 0 (the source); columns of k < K span whole dwords
   int X0[K + 1], X1[K + 1], Y0[K + 1], Y1[K + 1];
-  X0[K] = bx * kRT_W; X1[K] = min(bx * kRT_W + kRT_W, a.lv[K - 1].w) - 1;
-  Y0[K] = by * kRT_H; Y1[K] = min(by * kRT_H + kRT_H, a.lv[K - 1].h) - 1;
+  X0[K] = bx * a.tile; X1[K] = min(bx * a.tile + a.tile, a.lv[K - 1].w) - 1;
+  Y0[K] = by * a.tile; Y1[K] = min(by * a.tile + a.tile, a.lv[K - 1].h) - 1;
 #pragma unroll
   for (int k = K; k >= 1; k--) {
     const ChainLevel& L = a.lv[k - 1];
