@@ -271,7 +271,7 @@ def e2e_operator(host_frames, nfeatures):
         out["what"] = ("ORB_SLAM3::ORBextractor::operator() through include/ORBextractor.h, one frame per call, host buffers: image in, "
                        "kernels, keypoints + descriptors + the host mirror of mvImagePyramid out (PCIe-inclusive, latency-bound; never the "
                        "headline value); ms_per_frame_without_host_pyramid = the same with SetKeepHostPyramid(false), the monocular setting; "
-                       "device_ms_per_frame = HIP events around the replayed graph (upload kernel, three pyramid groups, FAST + blur, quadtree + "
+                       "device_ms_per_frame = HIP events around the replayed graph (upload kernel, the pyramid in one launch, FAST + blur, quadtree + "
                        "assembly, descriptors[, pyramid mirror]): the kernels' share of a call, the rest is the host (image into the pinned buffer, "
                        "graph launch, wake-up)")
         return out

@@ -805,7 +805,7 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, 
   { const char* e = getenv("ORBX_QT_POINTS"); const int v = e ? atoi(e) : kQtLdsPoints; ctx->qt_points = (v >= 256 && v <= 4096 && v % 128 == 0) ? v : kQtLdsPoints; }
   { const char* e = getenv("ORBX_FAST_SPLIT"); ctx->fast_split = e ? atoi(e) != 0 : true; }
   { const char* e = getenv("ORBX_WINDOW_DIRECT"); ctx->window_direct = e ? atoi(e) != 0 : true; }
-  { const char* e = getenv("ORBX_QT_THREADS"); const int v = e ? atoi(e) : 0; ctx->qt_threads = (v == 64 || v == 128 || v == 256 || v == 512) ? v : 0; }
+  { const char* e = getenv("ORBX_QT_THREADS"); const int v = e ? atoi(e) : 0; ctx->qt_threads = (v >= 64 && v <= 512 && v % 64 == 0) ? v : 0; }
   {
     const char* e = getenv("ORBX_DESC_K");  // keypoints per wave of k_describe (tuning knob)
     const int v = e ? atoi(e) : 4;
