@@ -575,6 +575,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
   if (fork_blur) ORBX_HIP(ctx, hipEventRecord(ctx->ev_blur_join[f0 != 0], bst));
   // K3: quadtree
   bool assembled = false;
+  int direct_mode = 0;
   if (fork_fast0) { ORBX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_f0_join[sb], 0)); forks.joined(ctx->aux[orbx_ctx::kMaxAux - 3 - sb]); }
   {
     ProfScope ps(ctx, 2, st);
@@ -624,7 +625,12 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
     const int qt_pts = ctx->qt_points;   // measured: 1024 ... 2048 points make no difference to the launch (128 VGPRs hold it at four workgroups per CU)
     const int nbig = (geo.nlevels >= 4 && !small_batch && !ctx->qt_one_launch) ? std::min(ctx->qt_big_levels, geo.nlevels) : geo.nlevels;  // small batch: one launch, all levels
     int qrc = ORBX_OK;
-    if (small_fused && ctx->d_qt_fin && !ctx->d_asm_scan && nframes <= kSmallBatchFrames) {
+    // a single frame whose lapping area holds every keypoint or none (every configuration but the fisheye rigs and images wider than the
+    // 1000 columns Frame.cc passes): no assembly at all — k_describe finds its keypoints in the quadtree's per-level output (DIRECT)
+    if (small_fused && nframes == 1 && ctx->describe_direct && !ctx->desc_k_user)
+      direct_mode = (lap0 <= 0 && lap1 >= cols) ? 1 : (lap1 < 16 || lap0 >= cols) ? 2 : 0;
+    if (direct_mode) {
+    } else if (small_fused && ctx->d_qt_fin && !ctx->d_asm_scan && nframes <= kSmallBatchFrames) {
       // all levels in one launch with the assembly as its tail (k_quadtree_assemble), when everything is LDS-resident
       int mq = 1, mc = 1, mp = 1;
       for (int l = 0; l < geo.nlevels; l++) { mq = std::max(mq, geo.lv[l].quota); mc = std::max(mc, geo.lv[l].ncells); mp = std::max(mp, geo.lv[l].cand_cap); }
@@ -642,6 +648,9 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
       }
     }
     if (assembled) {
+    } else if (direct_mode) {
+      qrc = launch_qt(0, geo.nlevels, qt_pts, st);
+      if (qrc != ORBX_OK) return qrc;
     } else if (nbig < geo.nlevels && !ctx->profiling && ctx->fork_qt) {
       hipStream_t qst = ctx->aux[orbx_ctx::kMaxAux - 5 - sb];
       ORBX_HIP(ctx, hipEventRecord(ctx->ev_qt_fork[sb], st));
@@ -661,7 +670,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
     }
   }
   // K3b: output slots
-  if (!assembled) {
+  if (!assembled && !direct_mode) {
     ProfScope ps(ctx, 3, st);
     const bool gs = ctx->d_asm_scan != nullptr;
     hipLaunchKernelGGL(k_assemble, dim3(nframes), dim3(256), gs ? 0 : (size_t)ctx->out_cap * 8 + 64, st, ctx->d_geo, b_lvl_kp,
@@ -671,7 +680,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
   if (fork_blur) { ORBX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_blur_join[f0 != 0], 0)); forks.joined(bst); }
   {
     ProfScope ps(ctx, 5, st);
-    const bool use_mirror = mirror && assembled && nframes == 1 && mirror->kps && mirror->desc && mirror->counts;   // counts were mirrored by the quadtree's tail
+    const bool use_mirror = mirror && (assembled || direct_mode) && nframes == 1 && mirror->kps && mirror->desc && mirror->counts;   // counts: mirrored by the quadtree's tail, or by k_describe (DIRECT)
     DescConsts dc;
     for (int i = 0; i < 16; i++) dc.umax[i] = ctx->umax[i];
     // keypoints per wave: K = 4 amortises the trig pass in a batch; a single frame has 1000 keypoints for 1024 SIMDs and is served fastest by
@@ -680,10 +689,18 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
     const int gpf = (ctx->out_cap + 4 * K - 1) / (4 * K), nitems = gpf * nframes;
     auto kern = K == 1 ? k_describe<1> : K == 2 ? k_describe<2> : K == 4 ? k_describe<4> : K == 8 ? k_describe<8> : k_describe<16>;
     if (ctx->desc_lds && (K == 2 || K == 4 || K == 8)) kern = K == 2 ? k_describe<2, true> : K == 4 ? k_describe<4, true> : k_describe<8, true>;
+    if (direct_mode)
+      hipLaunchKernelGGL((k_describe<1, false, true>), dim3(xcd_grid(nitems)), dim3(256), 0, st, ctx->d_geo, d_imgs, (long long)row_stride,
+                         (long long)frame_stride, b_pyr, (long long)geo.pyr_bytes, b_blur, (long long)geo.blur_bytes,
+                         b_kp_list, d_counts, d_kps, d_desc, dc, gpf, nitems, div_magic((uint32_t)gpf),
+                         use_mirror ? mirror->kps : (orbx_keypoint*)nullptr, use_mirror ? mirror->desc : (uint8_t*)nullptr,
+                         (const uint32_t*)b_lvl_kp, (const int32_t*)b_lvl_n, direct_mode, d_counts, use_mirror ? mirror->counts : (int32_t*)nullptr);
+    else
     hipLaunchKernelGGL(kern, dim3(xcd_grid(nitems)), dim3(256), 0, st, ctx->d_geo, d_imgs, (long long)row_stride,
                        (long long)frame_stride, b_pyr, (long long)geo.pyr_bytes, b_blur, (long long)geo.blur_bytes,
                        b_kp_list, d_counts, d_kps, d_desc, dc, gpf, nitems, div_magic((uint32_t)gpf),
-                       use_mirror ? mirror->kps : (orbx_keypoint*)nullptr, use_mirror ? mirror->desc : (uint8_t*)nullptr);
+                       use_mirror ? mirror->kps : (orbx_keypoint*)nullptr, use_mirror ? mirror->desc : (uint8_t*)nullptr,
+                       (const uint32_t*)nullptr, (const int32_t*)nullptr, 0, (int32_t*)nullptr, (int32_t*)nullptr);
     if (use_mirror && mirrored) *mirrored = true;
   }
   ORBX_HIP(ctx, hipGetLastError());
@@ -796,6 +813,7 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, 
   { const char* e = getenv("ORBX_QT_THREADS_SMALL"); const int v = e ? atoi(e) : 128; ctx->qt_threads_small = (v == 64 || v == 128 || v == 192 || v == 256 || v == 512) ? v : 0; }
   { const char* e = getenv("ORBX_QT_BIG_LEVELS"); const int v = e ? atoi(e) : 0; ctx->qt_big_levels = (v >= 1 && v <= 8) ? v : kQtBigLevels; }
   { const char* e = getenv("ORBX_CHAIN_LONG"); ctx->chain_long = e ? atoi(e) != 0 : true; }
+  { const char* e = getenv("ORBX_DESCRIBE_DIRECT"); ctx->describe_direct = e ? atoi(e) != 0 : true; }
   { const char* e = getenv("ORBX_CHAIN_LONG_TILE"); const int v = e ? atoi(e) : 16; ctx->chain_long_tile = (v >= 8 && v <= 64 && v % 4 == 0) ? v : 16; }
   { const char* e = getenv("ORBX_CHAIN_FIRST"); const int v = e ? atoi(e) : 7; ctx->chain_first = (v >= 2 && v <= 7) ? v : 7; }
   { const char* e = getenv("ORBX_CHAIN_BATCH"); ctx->chain_batch = e ? atoi(e) != 0 : false; }
@@ -1333,6 +1351,7 @@ int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
   else if (n == "qt_level_major") ctx->qt_level_major = value != 0;
   else if (n == "chain_batch") ctx->chain_batch = value != 0;
   else if (n == "chain_long") ctx->chain_long = value != 0;
+  else if (n == "describe_direct") ctx->describe_direct = value != 0;
   else if (n == "chain_long_tile" && value >= 8 && value <= 64 && value % 4 == 0) ctx->chain_long_tile = value;
   else if (n == "chain_first" && value >= 2 && value <= 7) ctx->chain_first = value;
   else if (n == "chain_threads" && value >= 64 && value <= 1024 && value % 64 == 0) ctx->chain_threads = value;

@@ -155,6 +155,7 @@ struct orbx_ctx {
   int chain_threads = 1024;   // workgroup size of k_resize_chain (ORBX_CHAIN_THREADS)
   int chain_first = 7;           // levels in the first chain launch of a single frame (2 .. 7)
   int chain_long_tile = 16;      // tile of the last level of a long chain
+  bool describe_direct = true;   // single frame, trivial lapping area: no assembly pass, k_describe reads the quadtree's per-level output
   bool chain_long = true;        // single-frame pyramid: levels 1-2 in one launch, then up to five small levels per launch
   bool chain_batch = false;      // batches too build the pyramid with the chain launches (k_resize_chain) instead of one launch per level
   int qt_big_levels = 2;         // levels of a batch launched with the large quadtree workgroup configuration

@@ -2055,7 +2055,11 @@ __device__ __forceinline__ int wave_sum_lane63(int v) {
 
 // K keypoints per wave: the cos/sin/atan2 evaluation (the largest VALU block, identical in all 64 lanes for one
 // keypoint) is done once for K keypoints held in lanes 0..K-1.
-template <int K, bool LDSP = false>
+// DIRECT (single frame, lapping area trivially all-in or all-out): no assembly pass — the wave finds its keypoints in the quadtree's
+// per-level output itself (eight counts to scan) and the output slot is the closed form of src/ORBextractor.cc:1153-1162 for that case
+// (everything in the lapping area: slot = N-1-i, return value 0; nothing in it: slot = i, return value N); the first workgroup writes
+// the two counts.  direct_mode: 1 = all-in, 2 = all-out.
+template <int K, bool LDSP = false, bool DIRECT = false>
 __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__ g, const uint8_t* __restrict__ imgs,
                                                   long long img_row_stride, long long img_frame_stride,
                                                   const uint8_t* __restrict__ pyr, long long pyr_frame_bytes,
@@ -2063,19 +2067,54 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
                                                   const uint2* __restrict__ kp_list, const int32_t* __restrict__ counts,
                                                   orbx_keypoint* __restrict__ out_kps, uint8_t* __restrict__ out_desc,
                                                   DescConsts dc, int groups_per_frame, int nitems, uint32_t m_gpf,
-                                                  orbx_keypoint* __restrict__ mirror_kps, uint8_t* __restrict__ mirror_desc) {
+                                                  orbx_keypoint* __restrict__ mirror_kps, uint8_t* __restrict__ mirror_desc,
+                                                  const uint32_t* __restrict__ lvl_kp = nullptr, const int32_t* __restrict__ lvl_n = nullptr,
+                                                  int direct_mode = 0, int32_t* __restrict__ counts_out = nullptr,
+                                                  int32_t* __restrict__ mirror_counts = nullptr) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int L = xcd_logical_block(nitems);
   if (L < 0) return;
   const int frame = fast_div(L, m_gpf);
   const int g0 = ((L - frame * groups_per_frame) * 4 + w) * K;  // first keypoint (level-major index) of this wave
-  const int total = counts[frame * 2];
+  int total;
+  int loffr = 0;   // DIRECT: lane l < nlevels holds the first level-major index of level l, lane nlevels the total
+  if constexpr (DIRECT) {
+    int nl = 0;
+    if (lane < g->nlevels) nl = lvl_n[frame * g->nlevels + lane];   // negative = the quadtree overflowed this level's capacity
+    const bool ovf = __ballot(nl < 0) != 0ull;
+    int inc = max(nl, 0);
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }   // nlevels <= 16
+    loffr = inc - max(nl, 0);
+    total = min(__shfl(inc, g->nlevels - 1), g->out_cap);
+    if (lane == g->nlevels) loffr = total;
+    if (L - frame * groups_per_frame == 0 && w == 0 && lane == 0) {
+      const int c0 = ovf ? -1 : total, c1 = direct_mode == 1 ? 0 : total;
+      counts_out[frame * 2] = c0; counts_out[frame * 2 + 1] = c1;
+      if (mirror_counts) { mirror_counts[frame * 2] = c0; mirror_counts[frame * 2 + 1] = c1; }
+    }
+  } else {
+    total = counts[frame * 2];
+  }
   // the block's first wave always has work (or the whole block is past the frame's keypoints): later waves without keypoints
   // still take part in the two workgroup barriers below
   if (((L - frame * groups_per_frame) * 4) * K >= total) return;  // block-uniform
   const int nk = max(0, min(K, total - g0));
   uint2 rec = make_uint2(0u, 0u);
-  if (lane < nk) rec = kp_list[(long long)frame * g->out_cap + g0 + lane];
+  if constexpr (DIRECT) {
+    const int i = g0 + lane;   // level-major index of this lane's keypoint
+    int l = 0;
+#pragma unroll 1
+    for (int q = 1; q < g->nlevels; q++) l += i >= __shfl(loffr, q);   // all lanes take part in the lane reads
+    const int first = __shfl(loffr, l);
+    if (lane < nk) {
+      const uint32_t p = lvl_kp[(long long)frame * g->kp_total + g->lv[l].kp_off + (i - first)];
+      const int slot = direct_mode == 1 ? total - 1 - i : i;
+      rec = make_uint2(p, (uint32_t)l | ((uint32_t)slot << 8));
+    }
+  } else {
+    if (lane < nk) rec = kp_list[(long long)frame * g->out_cap + g0 + lane];
+  }
   // rotated-pattern operands: independent of the keypoints, issued first
   char4 pat[4];
 #pragma unroll
