@@ -3,7 +3,10 @@
 // the vendored DBoW2 (oracle/_ref/libref_dbow2.so; tests/test_ref_fragments.py compares the vocabulary / scoring
 // functions below with it) and src/ORBmatcher.cc itself (oracle/_ref/ref_matcher_world, against the object model of
 // tests/support/ref_world; tests/test_matcher_world.py compares the drop-in matcher — running on the window / nn
-// primitives at the end of this file — with it on all 12 routines).
+// primitives at the end of this file — with it on all 12 routines).  Round 3: src/Frame.cc is compiled too (oracle/_ref/ref_frame_world,
+// tests/support/frame_world*): tests/test_frame_pins.py holds the Frame.cc restatements below — ComputeStereoMatches, AssignFeaturesToGrid /
+// PosInGrid, GetFeaturesInArea, the UndistortKeyPoints wrapper — to what that compiled file leaves in a Frame, bit for bit; and
+// src/KeyFrameDatabase.cc (oracle/_ref/ref_kfdb_world, tests/test_kfdb_world.py).  Still recalled, not pinned: cv::undistortPoints itself.
 //
 // CPU restatement of
 //   * ORBmatcher::DescriptorDistance                     src/ORBmatcher.cc:2058-2074 (== FORB::distance, FORB.cpp:77-96)
