@@ -346,6 +346,30 @@ class SearchTarget:
                 out.update(cand=cand[:rc].copy(), dist=dist[:rc].copy())
             return out
 
+    def search_view(self, qx, qy, qr, min_level, max_level, q_desc, kp_skip=None, q_xr=None):
+        """orbx_target_search_view: the candidate lists read where the kernel left them (the call's pinned output, valid until the
+        context's next call — copied here).  Returns (spans [nq] structured: start, count, best_idx, best_dist, second_idx, second_dist;
+        pool [total] structured: idx, dist)."""
+        qx, qy, qr = (np.ascontiguousarray(v, np.float32) for v in (qx, qy, qr))
+        lo, hi = (np.ascontiguousarray(v, np.int32) for v in (min_level, max_level))
+        qd = np.ascontiguousarray(q_desc, np.uint8).reshape(-1, 32)
+        nq = len(qx)
+        skip = None if kp_skip is None else np.ascontiguousarray(kp_skip, np.uint8)
+        xr = None if q_xr is None else np.ascontiguousarray(q_xr, np.float32)
+        sp, pl = C.c_void_p(), C.c_void_p()
+        total = check(int(self._L.orbx_target_search_view(self._ctx, self._h, ptr(skip), ptr(qx), ptr(qy), ptr(qr), ptr(lo), ptr(hi), ptr(qd), ptr(xr), nq,
+                                                          C.byref(sp), C.byref(pl))), self._ctx)
+        span_t = np.dtype([("start", "<i4"), ("count", "<i4"), ("best_idx", "<i4"), ("best_dist", "<i4"), ("second_idx", "<i4"), ("second_dist", "<i4"),
+                           ("reserved0", "<i4"), ("reserved1", "<i4")])
+        cand_t = np.dtype([("idx", "<i4"), ("dist", "<i4")])
+        if nq == 0 or not sp.value:
+            return np.zeros(0, span_t), np.zeros(0, cand_t)
+        spans = np.frombuffer((C.c_char * (span_t.itemsize * nq)).from_address(sp.value), span_t).copy()
+        end = int((spans["start"] + spans["count"]).max()) if nq else 0
+        pool = np.frombuffer((C.c_char * (cand_t.itemsize * max(end, 1))).from_address(pl.value), cand_t)[:end].copy() if end and pl.value else np.zeros(0, cand_t)
+        assert int(spans["count"].sum()) == total
+        return spans, pool
+
     def nearest(self, qx, qy, qr, min_level, max_level, q_desc, q_ur=None):
         qx, qy, qr = (np.ascontiguousarray(v, np.float32) for v in (qx, qy, qr))
         lo, hi = (np.ascontiguousarray(v, np.int32) for v in (min_level, max_level))

@@ -403,6 +403,43 @@ def test_resident_target_searches_equal_oracle(frames, held, direct):
     m.set_option("window_direct", 1)
 
 
+def test_list_view_spans_carry_the_two_smallest_of_every_list(frames):
+    """orbx_target_search_view: the lists in place (pool segments in any order) equal the copied-out lists, and every span's best / second
+    are the two smallest (distance, list position) of its segment — the contract the adapters' order-dependent replays rely on to skip
+    the walk over a list (include/orbx.h: orbx_list_span)."""
+    gpu, fr = frames
+    m = ORBmatcher(gpu)
+    k2, d2, d1 = fr[1].mvKeysUn, fr[1].mDescriptors, fr[0].mDescriptors
+    rng = np.random.default_rng(33)
+    grid = dict(_kf_grid(k2, (0.0, 0.0, 640.0, 480.0), True), cell_start=None, cell_idx=None)
+    ur = np.where(rng.random(len(k2)) < 0.3, -1.0, k2["x"] - rng.uniform(1, 40, len(k2))).astype(np.float32)
+    tgt = m.Target(k2, d2, grid, kp_uright=ur, inv_level_sigma2=(1.0 / (np.float32(1.2) ** np.arange(8, dtype=np.float32)) ** 2).astype(np.float32))
+    for rep in range(3):
+        nq = int(rng.integers(200, 900))
+        src = rng.integers(0, len(k2), nq)
+        qx = (k2["x"][src] + rng.normal(0, 4, nq)).astype(np.float32); qy = (k2["y"][src] + rng.normal(0, 4, nq)).astype(np.float32)
+        qr = rng.choice([0.0, 2.5, 7.0, 15.0, 36.0, 120.0], nq).astype(np.float32)
+        lo = rng.choice([-1, 0, 1, 3], nq).astype(np.int32); hi = rng.choice([-1, 0, 2, 7], nq).astype(np.int32)
+        skip = (rng.random(len(k2)) < 0.2).astype(np.uint8)
+        xr = (qx - rng.uniform(1, 40, nq)).astype(np.float32) if rep else None
+        qd = d1[rng.integers(0, len(d1), nq)]
+        qd[::7] = d2[src[::7]]     # exact copies: distance 0 and ties among the candidates
+        want = po.window_search_grid(k2, d2, grid, qx, qy, qr, lo, hi, qd, kp_skip=skip, **({} if xr is None else dict(kp_uright=ur, q_xr=xr)))
+        spans, pool = tgt.search_view(qx, qy, qr, lo, hi, qd, kp_skip=skip, q_xr=xr)
+        assert len(spans) == nq and int(spans["count"].sum()) == int(want["row_ptr"][-1])
+        for q in range(nq):
+            a, b = int(want["row_ptr"][q]), int(want["row_ptr"][q + 1])
+            seg = pool[int(spans["start"][q]):int(spans["start"][q]) + int(spans["count"][q])]
+            assert np.array_equal(seg["idx"], want["cand"][a:b]) and np.array_equal(seg["dist"], want["dist"][a:b]), q
+            order = np.lexsort((np.arange(b - a), seg["dist"]))      # by distance, then list position
+            exp = [(int(seg["idx"][order[0]]), int(seg["dist"][order[0]])) if b - a > 0 else (-1, 256),
+                   (int(seg["idx"][order[1]]), int(seg["dist"][order[1]])) if b - a > 1 else (-1, 256)]
+            got = [(int(spans["best_idx"][q]), int(spans["best_dist"][q])), (int(spans["second_idx"][q]), int(spans["second_dist"][q]))]
+            assert got == exp, (rep, q, got, exp)
+        assert np.array_equal(spans["best_idx"], want["best_idx"]) and np.array_equal(spans["second_dist"], want["second_dist"])
+    tgt.close()
+
+
 def test_failed_target_assign_leaves_an_invalid_target_not_an_empty_one(frames):
     """orbx_target_assign that fails (here: a grid whose indices point past the keypoints) must not leave a target that answers
     searches with 0 candidates and ORBX_OK: it is invalid until a later assign succeeds."""
