@@ -513,3 +513,24 @@ def test_single_frame_launch_shapes_give_the_same_bytes(shape, nlevels, sf, opts
         res = gpu.extract_batch(batch, (0, 1000))
         for f in range(nb):
             assert_same(res[f], ora.extract(batch[f], (0, 1000)), f"{opts} batch {nb} frame {f}")
+
+
+@pytest.mark.parametrize("rows,cols,nf,sf,nlevels,lap", [
+    (480, 640, 1000, 1.1, 12, (0, 1000)), (480, 752, 1500, 1.1, 10, (0, 0)), (512, 1024, 2000, 1.08, 16, (0, 1000)), (480, 640, 800, 1.15, 9, (100, 300)),
+    (376, 1241, 2000, 1.1, 11, (0, 2000)), (480, 640, 1000, 1.2, 3, (0, 1000)), (480, 640, 1000, 1.3, 5, (0, 1000)), (480, 640, 500, 1.2, 2, (0, 1000))])
+@pytest.mark.parametrize("opts", [dict(), dict(chain_long=0), dict(describe_direct=0), dict(chain_first=3, chain_long_tile=32)])
+def test_single_frame_level_counts_and_lapping_shortcuts(rows, cols, nf, sf, nlevels, lap, opts):
+    """The single-frame plan of round 3: the whole pyramid as one chain launch of up to seven levels (more levels: a second long launch; the
+    16-level maximum: three), on 16-px tiles, and no assembly pass when the lapping area holds every keypoint or none ((0, 1000) on a
+    narrower image, (0, 0), (0, 2000) on a 1241-wide one) — against the general path ((100, 300); (0, 1000) on a 1024-wide image) and
+    against the options that switch each shortcut off.  Keypoints, descriptors, return value and every pyramid level must be the oracle's."""
+    img = synth.make_stream(1, rows, cols, 11 + nlevels)[0]
+    ora = po.OracleExtractor(nf, sf, nlevels, 20, 7)
+    want = ora.extract(img, lap)
+    gpu = ORBextractor(nf, sf, nlevels, 20, 7)
+    for k, v in opts.items():
+        gpu.set_option(k, v)
+    for rep in range(2):
+        assert_same(gpu(img, None, lap), want, f"{opts} rep {rep}")
+        for l in range(1, nlevels):
+            assert np.array_equal(gpu.mvImagePyramid[l], ora.level(l)), (opts, rep, l)
