@@ -83,6 +83,21 @@ def test_reference_frame_cc_over_the_dropin_headers_cpu(tmp_path):
     assert out == _golden(), _first_difference(_golden(), out)
 
 
+@pytest.mark.parametrize("variant", [3, 8, 21, 34, 55])
+def test_other_scenes_sizes_and_feature_counts_cpu(tmp_path, variant):
+    """FRAME_WORLD_VARIANT: other scenes, image sizes (640x480 ... 1280x720) and feature counts (1000 ... 2000) through the same driver —
+    the reference build against the drop-in build over the oracle-backed stub (tools/fuzz_frame_world.py does the same on the GPU)."""
+    ref, cpu = _build("ref_frame_world"), _build("dropin_frame_world_cpu")
+    env = dict(os.environ, FRAME_WORLD_VARIANT=str(variant))
+    outs = []
+    for exe, name in ((ref, "ref.txt"), (cpu, "cpu.txt")):
+        out = str(tmp_path / name)
+        subprocess.run([exe, VOC, out], check=True, stdout=subprocess.DEVNULL, timeout=600, env=env)
+        outs.append(open(out).read())
+    assert outs[0] == outs[1], _first_difference(outs[0], outs[1])
+    assert outs[0] != _golden()       # it IS another scene
+
+
 @pytest.mark.gpu
 def test_reference_frame_cc_over_the_dropin_headers_gpu(tmp_path):
     exe = os.path.join(REFDIR, "dropin_frame_world")
@@ -90,3 +105,19 @@ def test_reference_frame_cc_over_the_dropin_headers_gpu(tmp_path):
         pytest.skip("oracle/_ref/dropin_frame_world not built (it is compiled from /root/reference/src/Frame.cc against liborbx.so by oracle/ref_fragments.mk)")
     out = _run(exe, str(tmp_path / "gpu.txt"))
     assert out == _golden(), _first_difference(_golden(), out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [5, 13, 89])
+def test_other_scenes_sizes_and_feature_counts_gpu(tmp_path, variant):
+    """The same variants on the GPU: the reference build (CPU code, prebuilt) against the drop-in build over liborbx.so, both run here."""
+    ref, gpu = os.path.join(REFDIR, "ref_frame_world"), os.path.join(REFDIR, "dropin_frame_world")
+    if not (os.path.exists(ref) and os.path.exists(gpu)):
+        pytest.skip("oracle/_ref/ref_frame_world / dropin_frame_world not built (oracle/ref_fragments.mk compiles them from /root/reference)")
+    env = dict(os.environ, FRAME_WORLD_VARIANT=str(variant))
+    outs = []
+    for exe, name in ((ref, "ref.txt"), (gpu, "gpu.txt")):
+        out = str(tmp_path / name)
+        subprocess.run([exe, VOC, out], check=True, stdout=subprocess.DEVNULL, timeout=600, env=env)
+        outs.append(open(out).read())
+    assert outs[0] == outs[1], _first_difference(outs[0], outs[1])
