@@ -610,7 +610,9 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
           return set_err(ctx, ORBX_E_CAPACITY, "nfeatures too large for the quadtree kernel's LDS");
       }
       // small batches are latency-bound on the big levels' workgroups: more waves split more nodes at a time
-      int qthreads = ctx->qt_threads ? ctx->qt_threads : (nframes * geo.nlevels <= 512) ? 512 : 256;
+      // one to four frames are latency-bound on the big levels' workgroups (more waves split more nodes at a time: 512); from there on the
+      // launch is throughput-bound and 256 wins (config 4's 32-frame lanes of 1024 x 1024: 134.1 k -> 144.6 k features/ms)
+      int qthreads = ctx->qt_threads ? ctx->qt_threads : nframes <= 4 ? 512 : 256;
       if (!small_batch && l0 >= ctx->qt_big_levels && l0 > 0 && ctx->qt_threads_small) qthreads = ctx->qt_threads_small;   // the small levels' launch of a batch
       // level-major order (LDS-resident node arrays only: the HBM node slices are indexed frame-major): all workgroups of the largest
       // level of the launch are dispatched first, the short ones fill the CUs behind them
