@@ -115,10 +115,19 @@ int orbx_set_host_pyramid(orbx_ctx* ctx, int on);
 /* Allocate the context's device buffers for batches of up to `nframes` frames of rows x cols now instead of inside the
  * first extraction call (the buffers are persistent and grow-only; a later call with another shape re-sizes them). */
 int orbx_reserve(orbx_ctx* ctx, int rows, int cols, int nframes);
-/* Scheduling / launch-shape knobs of one context (results never depend on them); the ORBX_* environment variables set
- * the defaults at orbx_create.  name: "fork_blur" | "fork_fast0" | "fork_qt" (0|1: run that kernel on a second stream
+/* Options of one context.  Scheduling / launch-shape knobs (results never depend on them; the ORBX_* environment variables set
+ * the defaults at orbx_create): "fork_blur" | "fork_fast0" | "fork_qt" (0|1: run that kernel on a second stream
  * beside its neighbour), "graph" (0|1), "fast_threads" (64|128|256), "fast_pk" (0|1), "desc_k" (1|2|4|8|16),
- * "desc_lds" (0|1), "streams" (1|2). */
+ * "desc_lds" (0|1), "streams" (1|2).
+ * The two options that DO change results — they select which OpenCV release's cv::GaussianBlur(7x7, sigma 2) of CV_8UC1 the blur in
+ * front of the descriptors (src/ORBextractor.cc:1133) equals, bit for bit (INTEGRATION.md section 6 has the release table, and
+ * tools/validate_opencv.cpp tells a maintainer which pair his OpenCV build needs; also ORBX_GAUSS_KERNEL / ORBX_GAUSS_ROUND in the
+ * environment at orbx_create):
+ *   "gauss_kernel"  0 (default) = 8.8 weights {18,34,48,56,48,34,18}, rounding error diffused, sum 256 — OpenCV >= 4.5.1;
+ *                   1 = {18,34,49,55,49,34,18}, every coefficient rounded on its own, sum 257 — OpenCV 3.x .. 4.5.0
+ *   "gauss_round"   0 (default) = (acc + 2^15) >> 16; 1 = exact ties to even, except in the last (width mod 4) columns (the SSE2
+ *                   column pass of OpenCV <= 3.4.1); 2 = floor (the SIMD column pass of 3.4.2 .. 4.5.0 under the 257 kernel).
+ *                   Every variant saturates to 255. */
 int orbx_set_option(orbx_ctx* ctx, const char* name, int value);
 int orbx_host_pyramid_level(orbx_ctx* ctx, int level, const uint8_t** data, size_t* stride, int* w, int* h);
 

@@ -250,8 +250,25 @@ inline int reflect101(int p, int n) {
   return p;
 }
 
+// Which cv::GaussianBlur the blur restates is a process-wide switch of the oracle (orbo_set_gauss_variant; the product's twin is
+// orbx_set_option("gauss_kernel" / "gauss_round")), because the 8-bit Gaussian is the one primitive of this path whose BYTES depend on the
+// OpenCV release (INTEGRATION.md section 6 has the table):
+//   kernel 0  {18,34,48,56,48,34,18}: getGaussianKernelFixedPoint_ED — the 8.8 weights with the rounding error diffused from the outside
+//             in, centre = 256 - 2 * sum(others); sum exactly 256.  OpenCV >= 4.5.1 (recalled).
+//   kernel 1  {18,34,49,55,49,34,18}: every coefficient rounded on its own (sum 257).  OpenCV 3.4.2 .. 4.5.0's ufixedpoint16 kernel
+//             (recalled) and, with the same integers, the 8-bit "smooth symmetrical" integer path of sepFilter2D in OpenCV <= 3.4.1
+//             (createSeparableLinearFilter: float kernel x 256 -> CV_32S, bits = 8).
+//   round 0   (acc + 2^15) >> 16, saturated to 255: the scalar fixed-point column pass (every 4.x; the scalar tail of 3.x).
+//   round 1   round-half-to-even of acc / 2^16, saturated: the SSE2 column pass of OpenCV <= 3.4.1 (SymmColumnVec_32s8u sums the rows in
+//             float — exact here — and converts with cvtps2dq); only exact .5 ties differ from round 0.
+//   tail V    the last (w mod V) columns of a row are the SIMD loop's scalar tail and round half up whatever `round` says (V = 4 for
+//             the SSE2 pass of <= 3.4.1; 8 / 16 / 32 = v_uint16::nlanes of the build's dispatch for 3.4.2 .. 4.5.0); 0 = none.
+//   round 2   floor(acc / 2^16), saturated: what the SIMD column pass of 3.4.2 .. 4.5.0 yields when the kernel sums to 257 (its
+//             signed-arithmetic bias correction assumes a sum of exactly 256) — recalled, the least certain of the three.
+std::atomic<int> g_gauss_kernel{0}, g_gauss_round{0}, g_gauss_tail{0};   // tail V: the last (w mod V) columns round half up
+
 void gaussian_kernel7_fixed(int k[7]) {
-  // bit-exact kernel exp(-x^2/(2 sigma^2)), normalised, x256, error-diffused from the outside in.
+  // bit-exact kernel exp(-x^2/(2 sigma^2)), normalised, x256
   const double sigma = 2.0;
   double v[7], sum = 0;
   for (int i = 0; i < 7; i++) {
@@ -259,6 +276,11 @@ void gaussian_kernel7_fixed(int k[7]) {
     v[i] = std::exp(-0.5 * x * x / (sigma * sigma));
     sum += v[i];
   }
+  if (g_gauss_kernel.load() == 1) {   // each coefficient rounded separately
+    for (int i = 0; i < 7; i++) k[i] = cv_round(v[i] / sum * 256.0);
+    return;
+  }
+  // error-diffused from the outside in
   double err = 0;
   int s = 0;
   for (int i = 0; i < 3; i++) {
@@ -274,20 +296,29 @@ void gaussian_kernel7_fixed(int k[7]) {
 void gaussian_blur7(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride) {
   int k[7];
   gaussian_kernel7_fixed(k);
+  const int rmode = g_gauss_round.load(), tail = g_gauss_tail.load();
+  const int body = tail > 1 ? w - (w % tail) : w;
   std::vector<uint16_t> tmp((size_t)w * h);
   for (int y = 0; y < h; y++) {
     const uint8_t* S = src + (size_t)y * sstride;
     for (int x = 0; x < w; x++) {
       uint32_t acc = 0;
       for (int t = 0; t < 7; t++) acc += (uint32_t)k[t] * S[reflect101(x + t - 3, w)];
-      tmp[(size_t)y * w + x] = (uint16_t)acc;  // <= 255*256, exact in 16 bit
+      tmp[(size_t)y * w + x] = (uint16_t)acc;  // <= 255*257 = 65535, exact in 16 bit
     }
   }
   for (int y = 0; y < h; y++) {
     for (int x = 0; x < w; x++) {
       uint32_t acc = 0;
       for (int t = 0; t < 7; t++) acc += (uint32_t)k[t] * tmp[(size_t)reflect101(y + t - 3, h) * w + x];
-      dst[(size_t)y * dstride + x] = (uint8_t)((acc + 32768u) >> 16);
+      uint32_t r;
+      const int m = x < body ? rmode : 0;   // the scalar tail of a SIMD column pass rounds half up
+      if (m == 2) r = acc >> 16;
+      else {
+        r = (acc + 32768u) >> 16;
+        if (m == 1 && (acc & 0xffffu) == 0x8000u) r &= ~1u;   // tie -> even
+      }
+      dst[(size_t)y * dstride + x] = (uint8_t)std::min(r, 255u);
     }
   }
 }
@@ -295,21 +326,27 @@ void gaussian_blur7(const uint8_t* src, int w, int h, int sstride, uint8_t* dst,
 // ---------------------------------------------------------------------------
 // cv::fastAtan2(y, x) in degrees — SURVEY §8(c)-A.  Called at src/ORBextractor.cc:102.
 // ---------------------------------------------------------------------------
+// g_atan_fma = 1: the same polynomial with the contractions a compiler makes when OpenCV's file is built with -mfma (the AVX2 dispatch
+// copy of mathfuncs_core; GCC / clang contract a * b + c by default): three fused Horner steps, and 90 - poly * c as one fnma.
+std::atomic<int> g_atan_fma{0};
 float fast_atan2(float y, float x) {
   const float p1 = 0.9997878412794807f * (float)(180 / M_PI);
   const float p3 = -0.3258083974640975f * (float)(180 / M_PI);
   const float p5 = 0.1555786518463281f * (float)(180 / M_PI);
   const float p7 = -0.04432655554792128f * (float)(180 / M_PI);
+  const bool fma = g_atan_fma.load(std::memory_order_relaxed) != 0;
   float ax = std::fabs(x), ay = std::fabs(y);
   float a, c, c2;
   if (ax >= ay) {
     c = ay / (ax + (float)DBL_EPSILON);
     c2 = c * c;
-    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    if (fma) a = fmaf(fmaf(fmaf(p7, c2, p5), c2, p3), c2, p1) * c;
+    else a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
   } else {
     c = ax / (ay + (float)DBL_EPSILON);
     c2 = c * c;
-    a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    if (fma) a = fmaf(-fmaf(fmaf(fmaf(p7, c2, p5), c2, p3), c2, p1), c, 90.f);
+    else a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
   }
   if (x < 0) a = 180.f - a;
   if (y < 0) a = 360.f - a;
@@ -777,6 +814,21 @@ void orbo_gaussian_blur7(const uint8_t* src, int w, int h, int sstride, uint8_t*
   gaussian_blur7(src, w, h, sstride, dst, dstride);
 }
 void orbo_gaussian_kernel7(int* k) { gaussian_kernel7_fixed(k); }
+// which OpenCV GaussianBlur the oracle (and everything compiled over oracle/ref_shims) restates; returns 0, or -1 for values out of range
+int orbo_set_gauss_variant(int kernel, int round) {
+  if (kernel < 0 || kernel > 1 || round < 0 || round > 2) return -1;
+  g_gauss_kernel.store(kernel); g_gauss_round.store(round);
+  return 0;
+}
+int orbo_set_gauss_tail(int v) {
+  if (!(v == 0 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64)) return -1;
+  g_gauss_tail.store(v);
+  return 0;
+}
+int orbo_get_gauss_tail() { return g_gauss_tail.load(); }
+int orbo_set_atan_fma(int on) { if (on != 0 && on != 1) return -1; g_atan_fma.store(on); return 0; }
+int orbo_get_atan_fma() { return g_atan_fma.load(); }
+void orbo_get_gauss_variant(int* kernel, int* round) { if (kernel) *kernel = g_gauss_kernel.load(); if (round) *round = g_gauss_round.load(); }
 float orbo_fast_atan2(float y, float x) { return fast_atan2(y, x); }
 void orbo_cos_sin_deg(float angle_deg, float* a, float* b) {
   const float factorPI = (float)(M_PI / 180.f);

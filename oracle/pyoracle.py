@@ -52,6 +52,15 @@ def lib() -> C.CDLL:
         L.orbo_fast.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
         L.orbo_gaussian_blur7.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p, C.c_int]
         L.orbo_gaussian_kernel7.argtypes = [vp]
+        L.orbo_set_gauss_variant.restype = C.c_int
+        L.orbo_set_gauss_variant.argtypes = [C.c_int, C.c_int]
+        L.orbo_get_gauss_variant.argtypes = [ip, ip]
+        L.orbo_set_gauss_tail.restype = C.c_int
+        L.orbo_set_gauss_tail.argtypes = [C.c_int]
+        L.orbo_get_gauss_tail.restype = C.c_int
+        L.orbo_set_atan_fma.restype = C.c_int
+        L.orbo_set_atan_fma.argtypes = [C.c_int]
+        L.orbo_get_atan_fma.restype = C.c_int
         L.orbo_fast_atan2.restype = C.c_float
         L.orbo_fast_atan2.argtypes = [C.c_float, C.c_float]
         L.orbo_cos_sin_deg.argtypes = [C.c_float, fp, fp]
@@ -158,6 +167,56 @@ def gaussian_blur7(img: np.ndarray) -> np.ndarray:
     dst = np.zeros_like(img)
     lib().orbo_gaussian_blur7(_ptr(img), img.shape[1], img.shape[0], img.strides[0], _ptr(dst), dst.strides[0])
     return dst
+
+
+class opencv_variant:
+    """with opencv_variant(gauss_kernel, gauss_round, gauss_tail, atan_fma): ... — which OpenCV build's cv::GaussianBlur / cv::fastAtan2 the
+    oracle restates inside the block (process-wide switches of liborb_oracle.so, so also of everything compiled over oracle/ref_shims);
+    the previous variant is restored on exit.  Same meaning as the product's orbx_set_option names (include/orbx.h, INTEGRATION.md
+    section 6): kernel 0 = {18,34,48,56,...} (OpenCV >= 4.5.1), 1 = {18,34,49,55,...} (3.x .. 4.5.0); round 0 = half up, 1 = ties to even
+    (<= 3.4.1 SSE2 column pass), 2 = floor (3.4.2 .. 4.5.0 SIMD column pass under the 257 kernel); tail V = the last w mod V columns round
+    half up; atan_fma 1 = fastAtan2's polynomial contracted into FMAs."""
+
+    def __init__(self, gauss_kernel: int = 0, gauss_round: int = 0, gauss_tail: int = 0, atan_fma: int = 0):
+        self.want = (int(gauss_kernel), int(gauss_round), int(gauss_tail), int(atan_fma))
+
+    @staticmethod
+    def _set(v):
+        L = lib()
+        if L.orbo_set_gauss_variant(v[0], v[1]) != 0 or L.orbo_set_gauss_tail(v[2]) != 0 or L.orbo_set_atan_fma(v[3]) != 0:
+            raise ValueError(f"no such OpenCV variant: {v}")
+
+    def __enter__(self):
+        k, r = C.c_int(0), C.c_int(0)
+        lib().orbo_get_gauss_variant(C.byref(k), C.byref(r))
+        self.prev = (k.value, r.value, lib().orbo_get_gauss_tail(), lib().orbo_get_atan_fma())
+        try:
+            self._set(self.want)
+        except ValueError:
+            self._set(self.prev)
+            raise
+        return self
+
+    def __exit__(self, *exc):
+        self._set(self.prev)
+        return False
+
+    def options(self) -> dict:
+        """the same variant as orbx_set_option name -> value pairs"""
+        return dict(gauss_kernel=self.want[0], gauss_round=self.want[1], gauss_tail=self.want[2], atan_fma=self.want[3])
+
+
+# (gauss_kernel, gauss_round, gauss_tail, atan_fma); the first is the default.  The named ones are INTEGRATION.md section 6's rows.
+OPENCV_VARIANTS = {
+    "opencv>=4.5.1": (0, 0, 0, 0),
+    "opencv>=4.5.1+fma": (0, 0, 0, 1),
+    "opencv3.4.2-4.5.0 scalar": (1, 0, 0, 0),
+    "opencv3.4.2-4.5.0 simd8": (1, 2, 8, 0),
+    "opencv3.4.2-4.5.0 simd16+fma": (1, 2, 16, 1),
+    "opencv<=3.4.1 sse2": (1, 1, 4, 0),
+    "diffused kernel, ties to even": (0, 1, 0, 0),
+    "diffused kernel, floor, tail 32": (0, 2, 32, 0),
+}
 
 
 def gaussian_kernel7() -> np.ndarray:

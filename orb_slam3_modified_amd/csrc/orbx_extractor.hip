@@ -302,10 +302,13 @@ struct ProfScope {
   }
 };
 
-static void gaussian_kernel7(int k[7]) {
-  // cv::getGaussianKernel(7, 2) in 8.8 fixed point, rounding error diffused from the outside in
+static void gaussian_kernel7(int k[7], int variant) {
+  // cv::getGaussianKernel(7, 2) in 8.8 fixed point.  variant 0: rounding error diffused from the outside in, centre =
+  // 256 - 2 * sum(others) — {18,34,48,56,...}, OpenCV >= 4.5.1; variant 1: every coefficient rounded on its own — {18,34,49,55,...}, sum
+  // 257, the kernel of OpenCV 3.x .. 4.5.0
   double v[7], sum = 0;
   for (int i = 0; i < 7; i++) { const double x = i - 3; v[i] = std::exp(-0.5 * x * x / 4.0); sum += v[i]; }
+  if (variant == 1) { for (int i = 0; i < 7; i++) k[i] = cv_round(v[i] / sum * 256.0); return; }
   double err = 0; int s = 0;
   for (int i = 0; i < 3; i++) {
     const double adj = v[i] / sum * 256.0 + err;
@@ -528,7 +531,12 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
   BlurConsts bc;
   {
     int gk[7];
-    gaussian_kernel7(gk);
+    gaussian_kernel7(gk, ctx->gauss_kernel);
+    // the default variant needs neither saturation nor a tie rule nor a tail: the kernel's fast path (flags == 0)
+    const bool general = ctx->gauss_kernel != 0 || ctx->gauss_round != 0;
+    bc.radd = general ? 0u : 32768u;
+    bc.flags = general ? (1u | ((uint32_t)ctx->gauss_round << 1)) : 0u;
+    bc.tail_mask = (general && ctx->gauss_round != 0 && ctx->gauss_tail > 1) ? (uint32_t)ctx->gauss_tail - 1u : 0u;
     auto b4 = [&](int a, int b, int c, int d) {   // weights of the four bytes of a dword; index -1 = no tap
       auto w = [&](int i) { return i < 0 ? 0u : (uint32_t)gk[i]; };
       return w(a) | (w(b) << 8) | (w(c) << 16) | (w(d) << 24);
@@ -696,13 +704,14 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
                          (long long)frame_stride, b_pyr, (long long)geo.pyr_bytes, b_blur, (long long)geo.blur_bytes,
                          b_kp_list, d_counts, d_kps, d_desc, dc, gpf, nitems, div_magic((uint32_t)gpf),
                          use_mirror ? mirror->kps : (orbx_keypoint*)nullptr, use_mirror ? mirror->desc : (uint8_t*)nullptr,
-                         (const uint32_t*)b_lvl_kp, (const int32_t*)b_lvl_n, direct_mode, d_counts, use_mirror ? mirror->counts : (int32_t*)nullptr);
+                         (const uint32_t*)b_lvl_kp, (const int32_t*)b_lvl_n, direct_mode, d_counts, use_mirror ? mirror->counts : (int32_t*)nullptr,
+                         ctx->atan_fma);
     else
     hipLaunchKernelGGL(kern, dim3(xcd_grid(nitems)), dim3(256), 0, st, ctx->d_geo, d_imgs, (long long)row_stride,
                        (long long)frame_stride, b_pyr, (long long)geo.pyr_bytes, b_blur, (long long)geo.blur_bytes,
                        b_kp_list, d_counts, d_kps, d_desc, dc, gpf, nitems, div_magic((uint32_t)gpf),
                        use_mirror ? mirror->kps : (orbx_keypoint*)nullptr, use_mirror ? mirror->desc : (uint8_t*)nullptr,
-                       (const uint32_t*)nullptr, (const int32_t*)nullptr, 0, (int32_t*)nullptr, (int32_t*)nullptr);
+                       (const uint32_t*)nullptr, (const int32_t*)nullptr, 0, (int32_t*)nullptr, (int32_t*)nullptr, ctx->atan_fma);
     if (use_mirror && mirrored) *mirrored = true;
   }
   ORBX_HIP(ctx, hipGetLastError());
@@ -853,6 +862,10 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, 
     const char* fb = getenv("ORBX_FORK_BLUR");
     ctx->fork_blur = fb ? atoi(fb) != 0 : true;
     const char* ff = getenv("ORBX_FORK_FAST0");
+    { const char* e = getenv("ORBX_GAUSS_KERNEL"); const int v = e ? atoi(e) : 0; ctx->gauss_kernel = v == 1 ? 1 : 0; }
+    { const char* e = getenv("ORBX_GAUSS_ROUND"); const int v = e ? atoi(e) : 0; ctx->gauss_round = (v >= 0 && v <= 2) ? v : 0; }
+    { const char* e = getenv("ORBX_GAUSS_TAIL"); const int v = e ? atoi(e) : 0; ctx->gauss_tail = (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) ? v : 0; }
+    { const char* e = getenv("ORBX_ATAN_FMA"); ctx->atan_fma = e && atoi(e) == 1 ? 1 : 0; }
     const char* fpk = getenv("ORBX_FAST_PK");   // packed 16-bit necessary test in k_fast_cells (128-thread workgroups)
     ctx->fast_pk = fpk ? atoi(fpk) != 0 : true;
     const char* fs = getenv("ORBX_FAST_STOP");
@@ -1348,6 +1361,10 @@ int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
   else if (n == "graph") ctx->use_graph = value != 0;
   else if (n == "graph_timing") { ctx->graph_timing = value != 0; return ORBX_OK; }   // no re-capture needed
   else if (n == "fast_pk") ctx->fast_pk = value != 0;
+  else if (n == "gauss_kernel" && (value == 0 || value == 1)) ctx->gauss_kernel = value;   // which OpenCV's 8-bit Gaussian weights (include/orbx.h)
+  else if (n == "gauss_round" && value >= 0 && value <= 2) ctx->gauss_round = value;       // ... which rounding of the column pass
+  else if (n == "gauss_tail" && (value == 0 || value == 4 || value == 8 || value == 16 || value == 32 || value == 64)) ctx->gauss_tail = value;   // ... and its scalar tail
+  else if (n == "atan_fma" && (value == 0 || value == 1)) ctx->atan_fma = value;          // cv::fastAtan2 compiled with / without FMA contraction
   else if (n == "qt_points" && value >= 256 && value <= 4096 && value % 128 == 0) ctx->qt_points = value;   // LDS-resident candidates per (frame, level) of the big quadtree levels (half of it for the small ones)
   else if (n == "small_fused") ctx->small_fused = value != 0;
   else if (n == "qt_level_major") ctx->qt_level_major = value != 0;
@@ -1476,7 +1493,7 @@ int orbx_debug_trig(orbx_ctx* ctx, const float* y, const float* x, int n, int an
   ORBX_HIP(ctx, hipMalloc((void**)&dang, bytes)); ORBX_HIP(ctx, hipMalloc((void**)&da, bytes)); ORBX_HIP(ctx, hipMalloc((void**)&db, bytes));
   ORBX_HIP(ctx, copy_sync(ctx, dy, y, bytes, hipMemcpyHostToDevice));
   if (x) ORBX_HIP(ctx, copy_sync(ctx, dx, x, bytes, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_debug_trig, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, dy, dx, n, angle_is_input, dang, da, db);
+  hipLaunchKernelGGL(k_debug_trig, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, dy, dx, n, angle_is_input, dang, da, db, ctx->atan_fma);
   ORBX_HIP(ctx, hipGetLastError());
   ORBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ORBX_HIP(ctx, copy_sync(ctx, angle, dang, bytes, hipMemcpyDeviceToHost));
@@ -1519,7 +1536,7 @@ static int run_hash_kernel(orbx_ctx* ctx, int which, uint32_t first_bits, uint32
   ORBX_HIP(ctx, hipMalloc((void**)&d, sizeof(unsigned long long)));
   ORBX_HIP(ctx, hipMemsetAsync(d, 0, sizeof(unsigned long long), ctx->stream));
   if (count && which == 0) hipLaunchKernelGGL(k_debug_trig_hash, dim3(256 * 32), dim3(256), 0, ctx->stream, first_bits, count, d);
-  if (count && which == 1) hipLaunchKernelGGL(k_debug_atan_hash, dim3(256 * 32), dim3(256), 0, ctx->stream, first_bits, count, d);
+  if (count && which == 1) hipLaunchKernelGGL(k_debug_atan_hash, dim3(256 * 32), dim3(256), 0, ctx->stream, first_bits, count, d, ctx->atan_fma);
   ORBX_HIP(ctx, hipGetLastError());
   unsigned long long h = 0;
   ORBX_HIP(ctx, hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));

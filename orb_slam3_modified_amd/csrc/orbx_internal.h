@@ -155,6 +155,12 @@ struct orbx_ctx {
   int chain_threads = 1024;   // workgroup size of k_resize_chain (ORBX_CHAIN_THREADS)
   int chain_first = 7;           // levels in the first chain launch of a single frame (2 .. 7)
   int chain_long_tile = 16;      // tile of the last level of a long chain
+  // which cv::GaussianBlur the blur equals (orbx_set_option "gauss_kernel" / "gauss_round"; include/orbx.h):
+  // kernel 0 = {18,34,48,56,...} (error-diffused, sum 256), 1 = {18,34,49,55,...} (each coefficient rounded, sum 257);
+  // round 0 = (acc + 2^15) >> 16, 1 = half to even (last w mod 4 columns half up), 2 = floor; all saturated to 255
+  // gauss_tail V: the last (w mod V) columns of a row round half up whatever gauss_round says (the scalar tail of a SIMD column pass)
+  // atan_fma: cv::fastAtan2's polynomial with the contractions a compiler makes under -mfma (OpenCV's AVX2 dispatch), 0 = separate mul / add
+  int gauss_kernel = 0, gauss_round = 0, gauss_tail = 0, atan_fma = 0;
   bool describe_direct = true;   // single frame, trivial lapping area: no assembly pass, k_describe reads the quadtree's per-level output
   bool chain_long = true;        // single-frame pyramid: levels 1-2 in one launch, then up to five small levels per launch
   bool chain_batch = false;      // batches too build the pyramid with the chain launches (k_resize_chain) instead of one launch per level

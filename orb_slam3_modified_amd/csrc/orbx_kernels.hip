@@ -1819,7 +1819,13 @@ __global__ __launch_bounds__(512, ORBX_QT_WPE) void k_quadtree_assemble(const Qt
 //   * vertical pass: v_dot2_u32_u16 on those pairs (4 instructions per pixel, exact 32-bit accumulation,
 //     single rounding (acc + 2^15) >> 16), one lane = 2 rows x 4 px, one dword store per row.
 // ------------------------------------------------------------------------------------------------
-struct BlurConsts { uint32_t hw[10]; uint32_t we[4], wo[4]; };   // hw: the 7 horizontal weights at the four byte alignments (hrow4)
+// hw: the 7 horizontal weights at the four byte alignments (hrow4); radd: rounding constant folded into the column pass (2^15 on the
+// default path, 0 when `flags` asks for the general rounding below).
+// flags == 0: the default arithmetic (OpenCV >= 4.5.1: weights sum to 256, (acc + 2^15) >> 16, no saturation needed).  Otherwise the
+// arithmetic of the other OpenCV releases (include/orbx.h "gauss_kernel" / "gauss_round" / "gauss_tail"): bit 0 = set whenever the general
+// path is taken (results saturate to 255: the 257 kernel reaches 256), bits 1-2 = rounding of the body columns (0 half up, 1 exact ties to
+// even, 2 floor); tail_mask = V - 1: the last (w mod V) columns of every row round half up (a SIMD column pass's scalar tail), 0 = no tail
+struct BlurConsts { uint32_t hw[10]; uint32_t we[4], wo[4]; uint32_t radd, flags, tail_mask; };
 
 __device__ __forceinline__ int reflect101(int p, int n) {
   while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
@@ -1968,8 +1974,22 @@ __device__ __forceinline__ void blur_tile(const int L, const DeviceGeom* __restr
       const uint32_t p1 = c == 0 ? P[1].x : c == 1 ? P[1].y : c == 2 ? P[1].z : P[1].w;
       const uint32_t p2 = c == 0 ? P[2].x : c == 1 ? P[2].y : c == 2 ? P[2].z : P[2].w;
       const uint32_t p3 = c == 0 ? P[3].x : c == 1 ? P[3].y : c == 2 ? P[3].z : P[3].w;
-      e[c] = udot2(p3, bc.we[3], udot2(p2, bc.we[2], udot2(p1, bc.we[1], udot2(p0, bc.we[0], 32768u))));
-      o[c] = udot2(p3, bc.wo[3], udot2(p2, bc.wo[2], udot2(p1, bc.wo[1], udot2(p0, bc.wo[0], 32768u))));
+      e[c] = udot2(p3, bc.we[3], udot2(p2, bc.we[2], udot2(p1, bc.we[1], udot2(p0, bc.we[0], bc.radd))));
+      o[c] = udot2(p3, bc.wo[3], udot2(p2, bc.wo[2], udot2(p1, bc.wo[1], udot2(p0, bc.wo[0], bc.radd))));
+    }
+    if (bc.flags) {   // uniform (kernel argument): the other OpenCV releases' arithmetic; radd is 0 here
+      const int body = w - (w & (int)bc.tail_mask);   // columns [body, w) round half up
+      const uint32_t mode = (bc.flags >> 1) & 3u;
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const uint32_t m = x + c < body ? mode : 0u;
+        uint32_t re = (e[c] + (m == 2u ? 0u : 32768u)) >> 16, ro = (o[c] + (m == 2u ? 0u : 32768u)) >> 16;
+        if (m == 1u) {   // an exact tie: low half == 2^15
+          if ((e[c] & 0xffffu) == 0x8000u) re &= ~1u;
+          if ((o[c] & 0xffffu) == 0x8000u) ro &= ~1u;
+        }
+        e[c] = min(re, 255u) << 16; o[c] = min(ro, 255u) << 16;
+      }
     }
     // byte 2 of each 32-bit sum is the rounded pixel ((acc + 2^15) >> 16 <= 255): three byte permutes pack four of them
     const uint32_t pe = __builtin_amdgcn_perm(__builtin_amdgcn_perm(e[3], e[2], 0x0c0c0602u), __builtin_amdgcn_perm(e[1], e[0], 0x0c0c0602u), 0x05040100u);
@@ -2020,8 +2040,11 @@ __global__ __launch_bounds__(256) void k_fast_blur(const DeviceGeom* __restrict_
 // ------------------------------------------------------------------------------------------------
 struct DescConsts { int umax[16]; };
 
-// cv::fastAtan2, degrees; separate IEEE mul/add, correctly rounded division.
-__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+// cv::fastAtan2, degrees; correctly rounded division.  FMA = false: separate IEEE mul / add (the repository's canonical
+// form: OpenCV's baseline build).  FMA = true: the contractions a compiler makes when OpenCV's file is built with -mfma (its AVX2 dispatch
+// copy, GCC / clang default -ffp-contract): the three Horner steps fused, and 90 - poly * c as one fnma ("atan_fma" option, include/orbx.h).
+template <bool FMA>
+__device__ __forceinline__ float fast_atan2_deg_t(float y, float x) {
   const float scale = (float)(180.0 / 3.14159265358979323846);
   const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale;
   const float p5 = 0.1555786518463281f * scale, p7 = -0.04432655554792128f * scale;
@@ -2031,15 +2054,20 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
   if (ax >= ay) {
     c = __fdiv_rn(ay, __fadd_rn(ax, eps));
     c2 = __fmul_rn(c, c);
-    a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    if (FMA) a = __fmul_rn(__fmaf_rn(__fmaf_rn(__fmaf_rn(p7, c2, p5), c2, p3), c2, p1), c);
+    else a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
   } else {
     c = __fdiv_rn(ax, __fadd_rn(ay, eps));
     c2 = __fmul_rn(c, c);
-    a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+    if (FMA) a = __fmaf_rn(-__fmaf_rn(__fmaf_rn(__fmaf_rn(p7, c2, p5), c2, p3), c2, p1), c, 90.f);
+    else a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
   }
   if (x < 0) a = __fsub_rn(180.f, a);
   if (y < 0) a = __fsub_rn(360.f, a);
   return a;
+}
+__device__ __forceinline__ float fast_atan2_deg(float y, float x, int fma = 0) {
+  return fma ? fast_atan2_deg_t<true>(y, x) : fast_atan2_deg_t<false>(y, x);
 }
 
 // Sum over the wave by DPP (no LDS traffic); the total lands in lane 63 (rows 2,3 of the last step).
@@ -2070,7 +2098,7 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
                                                   orbx_keypoint* __restrict__ mirror_kps, uint8_t* __restrict__ mirror_desc,
                                                   const uint32_t* __restrict__ lvl_kp = nullptr, const int32_t* __restrict__ lvl_n = nullptr,
                                                   int direct_mode = 0, int32_t* __restrict__ counts_out = nullptr,
-                                                  int32_t* __restrict__ mirror_counts = nullptr) {
+                                                  int32_t* __restrict__ mirror_counts = nullptr, int atan_fma = 0) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int L = xcd_logical_block(nitems);
   if (L < 0) return;
@@ -2191,7 +2219,7 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
   if (lane < nk) { s_mom[w * K + lane][0] = my_m01; s_mom[w * K + lane][1] = my_m10; }
   __syncthreads();
   if (w == 0 && lane < 4 * K) {   // entries of waves without keypoints hold garbage; nobody reads their results
-    const float ang = fast_atan2_deg((float)s_mom[lane][0], (float)s_mom[lane][1]);
+    const float ang = fast_atan2_deg((float)s_mom[lane][0], (float)s_mom[lane][1], atan_fma);
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     const float rad = __fmul_rn(ang, factorPI);
     s_trig[lane][0] = ang; s_trig[lane][1] = orbx_glibc::cosf_exact(rad); s_trig[lane][2] = orbx_glibc::sinf_exact(rad);
@@ -2284,10 +2312,10 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
 // Debug/test kernel: the two float paths of K4 in isolation (fastAtan2, then glibc-exact cosf/sinf of
 // angle*factorPI) so tests can sweep far more arguments than real frames produce.
 __global__ void k_debug_trig(const float* __restrict__ y, const float* __restrict__ x, int n, int angle_is_input,
-                             float* __restrict__ angle, float* __restrict__ a, float* __restrict__ b) {
+                             float* __restrict__ angle, float* __restrict__ a, float* __restrict__ b, int atan_fma) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float ang = angle_is_input ? y[i] : fast_atan2_deg(y[i], x[i]);
+  const float ang = angle_is_input ? y[i] : fast_atan2_deg(y[i], x[i], atan_fma);
   const float factorPI = (float)(3.14159265358979323846 / 180.f);
   const float r = __fmul_rn(ang, factorPI);
   angle[i] = ang;
@@ -2315,13 +2343,13 @@ __global__ __launch_bounds__(256) void k_debug_trig_hash(uint32_t first, uint32_
 // The same for fastAtan2: digest over `count` pseudo-random integer moment pairs derived from the index by a fixed
 // integer mix (identical on the oracle side).
 __device__ __forceinline__ uint32_t mix32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
-__global__ __launch_bounds__(256) void k_debug_atan_hash(uint32_t seed, uint32_t count, unsigned long long* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_debug_atan_hash(uint32_t seed, uint32_t count, unsigned long long* __restrict__ out, int atan_fma) {
   unsigned long long h = 0;
   for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count;
        i += (unsigned long long)gridDim.x * blockDim.x) {
     const uint32_t a = mix32(seed + 2u * (uint32_t)i), b = mix32(seed + 2u * (uint32_t)i + 1u);
     const int m01 = (int)(a % 6000001u) - 3000000, m10 = (b & 15u) == 0 ? 0 : (int)(b % 6000001u) - 3000000;
-    const uint32_t bits = __float_as_uint(fast_atan2_deg((float)m01, (float)m10));
+    const uint32_t bits = __float_as_uint(fast_atan2_deg((float)m01, (float)m10, atan_fma));
     h += ((unsigned long long)bits * 0x9E3779B97F4A7C15ull) ^ (unsigned long long)(uint32_t)i;
   }
 #pragma unroll
