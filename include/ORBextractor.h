@@ -10,6 +10,9 @@
  *   - mvImagePyramid[0] is a header over the caller's image and mvImagePyramid[l >= 1] are headers over a pinned host
  *     mirror that one asynchronous copy inside the call refreshes; there is no EDGE_THRESHOLD padding around them
  *     (nothing reads the pad), and like the reference's they are valid until the next call.
+ * Which OpenCV: the constructor calibrates the context against the OpenCV this translation unit is built with (the 8-bit GaussianBlur
+ * and fastAtan2 differ between releases / builds, and -march=native changes the reference's own pattern rotation): see
+ * include/orbx_cv_calibrate.h and INTEGRATION.md section 6.
  * Errors: an empty image returns -1 like the reference (src/ORBextractor.cc:1090-1091); a missing GPU or a HIP
  * failure throws std::runtime_error from the constructor / operator() (the reference has no failure path at all;
  * there is deliberately no CPU fallback).
@@ -25,6 +28,7 @@
 
 #include "orbx.h"
 #include "orbx_cv_compat.h"
+#include "orbx_cv_calibrate.h"
 
 namespace ORB_SLAM3 {
 
@@ -42,6 +46,12 @@ class ORBextractor {
     orbx_scale_tables(ctx_, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(), mvInvLevelSigma2.data(),
                       mnFeaturesPerLevel.data());
     orbx_set_host_pyramid(ctx_, 1);
+#ifdef ORBX_CV_CALIBRATION
+    // which OpenCV release / build (and which compiler flags) is the CPU path this object replaces: found out once per process by running
+    // the real cv::GaussianBlur / cv::fastAtan2 on a probe (include/orbx_cv_calibrate.h); the context then computes exactly those bytes
+    if (orbx_cv::apply(ctx_, orbx_cv::opencv_calibration()) != ORBX_OK)
+      throw std::runtime_error(std::string("ORBextractor: ") + orbx_last_error(ctx_));
+#endif
     cap_ = orbx_keypoint_capacity(ctx_);
     kps_.resize(cap_);
     desc_.resize((size_t)cap_ * 32);

@@ -157,6 +157,9 @@ int orbx_debug_trig_hash(orbx_ctx* ctx, uint32_t first_bits, uint32_t count, uin
 /* The same for cv::fastAtan2: digest over `count` pseudo-random integer moment pairs (|m| <= 3e6, the range IC_Angle
  * produces; every 16th pair has m10 = 0) generated from `seed` by a fixed integer mix on both sides. */
 int orbx_debug_atan_hash(orbx_ctx* ctx, uint32_t seed, uint32_t count, uint64_t* hash);
+/* The same for the rotated test pattern of the steered BRIEF (src/ORBextractor.cc:118-120): digest of (ry, rx) of all 512 pattern points
+ * over `count` consecutive float bit patterns of the keypoint angle, first_bits + i; honours the "brief_fma" option. */
+int orbx_debug_brief_hash(orbx_ctx* ctx, uint32_t first_bits, uint32_t count, uint64_t* hash);
 
 /* Test hook for the quadtree's exact std::sort: sorts elems[0..n) (n <= 2048; key = high 32 bits, payload = low 32 bits) with
  * the workgroup-parallel restatement of libstdc++'s introsort the kernel uses (src/ORBextractor.cc:697-701 sorts with

@@ -1,0 +1,241 @@
+/* orbx — which OpenCV is the CPU path I replace?  Self-calibration of the drop-in against the OpenCV it is built with.
+ *
+ * "Bit-exact with the reference CPU path" (BASELINE.json north_star) has three inputs the reference does not fix:
+ *   (1) the OpenCV release: cv::GaussianBlur(Size(7,7), 2, 2, BORDER_REFLECT_101) of CV_8UC1 (src/ORBextractor.cc:1133) changed its
+ *       fixed-point weights and the rounding of its column pass between releases (CMakeLists.txt:33 asks for 4.4, README.md:560 names
+ *       3.2.0 and 4.4.0; orbx's default equals >= 4.5.1);
+ *   (2) the OpenCV BUILD: cv::fastAtan2 (src/ORBextractor.cc:102) is one polynomial, but its AVX2 dispatch copy is compiled with FMA
+ *       contraction and then differs in the last bit for some arguments;
+ *   (3) the reference's own build: CMakeLists.txt:10-13 compiles src/ORBextractor.cc with -O3 -march=native, under which GCC / clang
+ *       contract the pattern rotation of :118-120 into FMAs (one rotated point in ten million rounds differently).
+ * liborbx.so carries every known variant as a context option (include/orbx.h: "gauss_kernel", "gauss_round", "gauss_tail", "atan_fma",
+ * "brief_fma").  This header finds out which one applies, AT RUN TIME, from the very libraries and flags the caller is built with — no
+ * version table involved: it runs the real cv::GaussianBlur on a 127 x 72 probe image that separates all variants (noise, plus row
+ * bands constructed so that the column pass hits exact .5 ties under either kernel, a saturated band, and a width whose SIMD tails
+ * differ for every vector length), the real cv::fastAtan2 on 4096 moment pairs, and an expression of the shape of :118-120 compiled
+ * in THIS translation unit on an operand at which contraction matters.  include/ORBextractor.h does this once per process in its
+ * constructor and applies the result (ORBX_CV_CALIBRATE=0, or any of ORBX_GAUSS_KERNEL / ORBX_GAUSS_ROUND / ORBX_GAUSS_TAIL / ORBX_ATAN_FMA /
+ * ORBX_BRIEF_FMA in the environment, switch that off).  When no variant reproduces the OpenCV at hand (an IPP or OpenCL path, a release
+ * unknown to this file) it says so on stderr, with the number of differing bytes, and leaves the defaults.
+ * tools/validate_opencv.cpp is the long form: every primitive, natural images, first mismatch.
+ *
+ * The host code below restates 60 lines of arithmetic for a 9 KB probe image; it is never on the per-frame path.
+ */
+#ifndef ORBX_CV_CALIBRATE_H
+#define ORBX_CV_CALIBRATE_H
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "orbx.h"
+
+namespace orbx_cv {
+
+struct Calibration {
+  int gauss_kernel = 0, gauss_round = 0, gauss_tail = 0, atan_fma = 0, brief_fma = 0;
+  bool gauss_exact = false, atan_exact = false;   // a variant reproduces every byte / bit of the probe
+  int gauss_mismatch = 0, atan_mismatch = 0;      // differing bytes / angles of the closest variant otherwise
+  int gauss_candidates = 0;                       // variants that reproduce the probe (>= 1 when gauss_exact)
+};
+
+constexpr int kProbeW = 127, kProbeH = 72;   // 127 mod V differs for V = 4, 8, 16, 32, 64: every tail length is visible
+
+/* noise + tie bands (sum k_i a_i = 32768 under {18,34,49,55,..}: acc = 257 * 32768; = 32896 under {18,34,48,56,..}: acc = 256 * 32896)
+ * + a saturated band (the 257 kernel reaches 256 there) + a black band */
+inline void probe_image(std::vector<uint8_t>& img) {
+  img.assign((size_t)kProbeW * kProbeH, 0);
+  uint32_t s = 0x9E3779B9u;
+  for (size_t i = 0; i < img.size(); i++) { s ^= s << 13; s ^= s >> 17; s ^= s << 5; img[i] = (uint8_t)(s >> 11); }
+  static const uint8_t t1[7] = {127, 128, 128, 126, 128, 128, 128}, t0[7] = {132, 128, 128, 129, 128, 128, 128};
+  for (int r = 0; r < 7; r++) { std::memset(&img[(size_t)(6 + r) * kProbeW], t1[r], kProbeW); std::memset(&img[(size_t)(20 + r) * kProbeW], t0[r], kProbeW); }
+  for (int r = 34; r < 44; r++) std::memset(&img[(size_t)r * kProbeW], 255, kProbeW);
+  for (int r = 50; r < 58; r++) std::memset(&img[(size_t)r * kProbeW], 0, kProbeW);
+}
+
+inline void gauss_weights(int kernel, int k[7]) {
+  double v[7], sum = 0;
+  for (int i = 0; i < 7; i++) { const double x = i - 3; v[i] = std::exp(-0.5 * x * x / 4.0); sum += v[i]; }
+  if (kernel == 1) { for (int i = 0; i < 7; i++) k[i] = (int)std::lrint(v[i] / sum * 256.0); return; }
+  double err = 0; int s = 0;
+  for (int i = 0; i < 3; i++) { const double adj = v[i] / sum * 256.0 + err; const int q = (int)std::lrint(adj); err = adj - q; k[i] = k[6 - i] = q; s += q; }
+  k[3] = 256 - 2 * s;
+}
+
+inline int reflect101(int p, int n) { while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p; return p; }
+
+/* exact 32-bit sums of the separable 7 x 7 correlation under reflect-101 (integer arithmetic: no compiler flag can change them) */
+inline void gauss_acc(const uint8_t* src, int w, int h, int kernel, std::vector<uint32_t>& acc) {
+  int k[7];
+  gauss_weights(kernel, k);
+  std::vector<uint32_t> hor((size_t)w * h);
+  for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) {
+    uint32_t a = 0;
+    for (int t = 0; t < 7; t++) a += (uint32_t)k[t] * src[(size_t)y * w + reflect101(x + t - 3, w)];
+    hor[(size_t)y * w + x] = a;
+  }
+  acc.assign((size_t)w * h, 0);
+  for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) {
+    uint32_t a = 0;
+    for (int t = 0; t < 7; t++) a += (uint32_t)k[t] * hor[(size_t)reflect101(y + t - 3, h) * w + x];
+    acc[(size_t)y * w + x] = a;
+  }
+}
+inline uint8_t gauss_round_px(uint32_t acc, int mode) {
+  uint32_t r = mode == 2 ? acc >> 16 : (acc + 32768u) >> 16;
+  if (mode == 1 && (acc & 0xffffu) == 0x8000u) r &= ~1u;
+  return (uint8_t)(r > 255u ? 255u : r);
+}
+
+/* separate IEEE operations whatever the compiler's contraction setting: every intermediate goes through a volatile */
+inline float atan_variant(float y, float x, int fma) {
+  const float sc = (float)(180.0 / 3.14159265358979323846);
+  const float p1 = 0.9997878412794807f * sc, p3 = -0.3258083974640975f * sc, p5 = 0.1555786518463281f * sc, p7 = -0.04432655554792128f * sc;
+  const float ax = std::fabs(x), ay = std::fabs(y), eps = (float)2.2204460492503131e-16;
+  volatile float t, c, c2, a;
+  if (ax >= ay) {
+    t = ax + eps; c = ay / t; c2 = c * c;
+    if (fma) { t = std::fma(p7, (float)c2, p5); t = std::fma((float)t, (float)c2, p3); t = std::fma((float)t, (float)c2, p1); a = t * c; }
+    else { t = p7 * c2; t = t + p5; t = t * c2; t = t + p3; t = t * c2; t = t + p1; a = t * c; }
+  } else {
+    t = ay + eps; c = ax / t; c2 = c * c;
+    if (fma) { t = std::fma(p7, (float)c2, p5); t = std::fma((float)t, (float)c2, p3); t = std::fma((float)t, (float)c2, p1); a = std::fma(-(float)t, (float)c, 90.f); }
+    else { t = p7 * c2; t = t + p5; t = t * c2; t = t + p3; t = t * c2; t = t + p1; t = t * c; a = 90.f - t; }
+  }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
+/* (3): does THIS translation unit (= the flags src/ORBextractor.cc would have been compiled with) contract x*b + y*a ?  One operand set
+ * at which the fused and the unfused form round to different integers (found by tests/support/contract_probe.cpp's sweep). */
+#if defined(__GNUC__)
+__attribute__((noinline))
+#endif
+inline int contraction_probe(const int* p, const float* ab) { return (int)std::lrint(p[0] * ab[1] + p[1] * ab[0]); }
+inline int build_contracts_fma() {
+  // {x, y, bits of a = cos, bits of b = sin}: cvRound(x*b + y*a) is 14 / 6 / 2 unfused and 13 / 7 / 1 fused
+  static const int32_t kOps[3][4] = {{-12, 10, 0x3e2ad13d, (int32_t)0xbf7c69bdu}, {9, 4, (int32_t)0xbed644d7u, 0x3f688114}, {-9, -10, (int32_t)0xbf3f6716u, 0x3f2a00c4}};
+  int votes_fused = 0, votes_unfused = 0;
+  for (int i = 0; i < 3; i++) {
+    volatile int32_t vx = kOps[i][0], vy = kOps[i][1], va = kOps[i][2], vb = kOps[i][3];   // opaque to constant folding
+    const int p[2] = {vx, vy};
+    const uint32_t ua = (uint32_t)va, ub = (uint32_t)vb;
+    float ab[2];
+    std::memcpy(&ab[0], &ua, 4); std::memcpy(&ab[1], &ub, 4);
+    const float fx = (float)p[0], fy = (float)p[1];
+    volatile float m = fy * ab[0];
+    const int fused = (int)std::lrint(std::fma(fx, ab[1], (float)m));
+    volatile float m2 = fx * ab[1];
+    volatile float sum = (float)m2 + (float)m;
+    const int unfused = (int)std::lrint((float)sum);
+    if (fused == unfused) continue;
+    const int got = contraction_probe(p, ab);
+    votes_fused += got == fused; votes_unfused += got == unfused;
+  }
+  return votes_fused > 0 && votes_unfused == 0 ? 1 : 0;
+}
+
+/* Blur: void(const uint8_t* src, int w, int h, uint8_t* dst) — the OpenCV at hand; Atan: float(float y, float x) */
+template <class Blur, class Atan>
+inline Calibration calibrate(Blur blur, Atan at) {
+  Calibration c;
+  std::vector<uint8_t> img, got((size_t)kProbeW * kProbeH);
+  probe_image(img);
+  blur(img.data(), kProbeW, kProbeH, got.data());
+  int best = 1 << 30;
+  static const int tails[6] = {0, 4, 8, 16, 32, 64};
+  for (int k = 0; k < 2; k++) {
+    std::vector<uint32_t> acc;
+    gauss_acc(img.data(), kProbeW, kProbeH, k, acc);
+    for (int r = 0; r < 3; r++) for (int ti = 0; ti < (r == 0 ? 1 : 6); ti++) {
+      const int V = tails[ti], body = V > 1 ? kProbeW - kProbeW % V : kProbeW;
+      int bad = 0;
+      for (int y = 0; y < kProbeH; y++) for (int x = 0; x < kProbeW; x++)
+        bad += gauss_round_px(acc[(size_t)y * kProbeW + x], x < body ? r : 0) != got[(size_t)y * kProbeW + x];
+      if (bad == 0) c.gauss_candidates++;
+      if (bad < best) { best = bad; c.gauss_kernel = k; c.gauss_round = r; c.gauss_tail = V; }
+    }
+  }
+  c.gauss_exact = best == 0; c.gauss_mismatch = best;
+  if (!c.gauss_exact) c.gauss_kernel = c.gauss_round = c.gauss_tail = 0;
+  int bad[2] = {0, 0};
+  uint32_t s = 12345u;
+  for (int i = 0; i < 4096; i++) {
+    s = s * 1664525u + 1013904223u; const int m01 = (int)((s >> 8) % 6000001u) - 3000000;
+    s = s * 1664525u + 1013904223u; const int m10 = (i & 15) == 0 ? 0 : (int)((s >> 8) % 6000001u) - 3000000;
+    const float g = at((float)m01, (float)m10);
+    for (int f = 0; f < 2; f++) { const float e = atan_variant((float)m01, (float)m10, f); bad[f] += std::memcmp(&g, &e, 4) != 0; }
+  }
+  c.atan_fma = bad[1] < bad[0] ? 1 : 0;
+  c.atan_mismatch = bad[c.atan_fma]; c.atan_exact = c.atan_mismatch == 0;
+  if (!c.atan_exact) c.atan_fma = 0;
+  c.brief_fma = build_contracts_fma();
+  return c;
+}
+
+inline bool env_overrides() {
+  static const char* names[] = {"ORBX_GAUSS_KERNEL", "ORBX_GAUSS_ROUND", "ORBX_GAUSS_TAIL", "ORBX_ATAN_FMA", "ORBX_BRIEF_FMA"};
+  for (const char* n : names) if (std::getenv(n)) return true;
+  const char* e = std::getenv("ORBX_CV_CALIBRATE");
+  return e && std::atoi(e) == 0;
+}
+
+/* applies a calibration to a context; returns ORBX_OK or the first failing orbx_set_option code */
+inline int apply(orbx_ctx* ctx, const Calibration& c) {
+  if (env_overrides()) return ORBX_OK;
+  int rc = orbx_set_option(ctx, "gauss_kernel", c.gauss_kernel);
+  if (rc == ORBX_OK) rc = orbx_set_option(ctx, "gauss_round", c.gauss_round);
+  if (rc == ORBX_OK) rc = orbx_set_option(ctx, "gauss_tail", c.gauss_tail);
+  if (rc == ORBX_OK) rc = orbx_set_option(ctx, "atan_fma", c.atan_fma);
+  if (rc == ORBX_OK) rc = orbx_set_option(ctx, "brief_fma", c.brief_fma);
+  return rc;
+}
+
+inline void report(const Calibration& c, const char* opencv_version, std::FILE* f = stderr) {
+  const bool dflt = c.gauss_kernel == 0 && c.gauss_round == 0 && c.gauss_tail == 0 && c.atan_fma == 0 && c.brief_fma == 0;
+  if (c.gauss_exact && c.atan_exact && dflt && !std::getenv("ORBX_CV_VERBOSE")) return;
+  std::fprintf(f, "[orbx] OpenCV %s: cv::GaussianBlur(7x7, sigma 2, 8u) %s gauss_kernel=%d gauss_round=%d gauss_tail=%d", opencv_version,
+               c.gauss_exact ? "== variant" : "matches NO known variant; keeping", c.gauss_kernel, c.gauss_round, c.gauss_tail);
+  if (!c.gauss_exact) std::fprintf(f, " (closest variant differs in %d of %d probe bytes: descriptors will not be bit-identical to this OpenCV's; see tools/validate_opencv.cpp)", c.gauss_mismatch, kProbeW * kProbeH);
+  std::fprintf(f, "; cv::fastAtan2 %s atan_fma=%d", c.atan_exact ? "==" : "matches neither form; keeping", c.atan_fma);
+  if (!c.atan_exact) std::fprintf(f, " (%d of 4096 angles differ)", c.atan_mismatch);
+  std::fprintf(f, "; this build %s the pattern rotation: brief_fma=%d\n", c.brief_fma ? "contracts" : "does not contract", c.brief_fma);
+}
+
+}  // namespace orbx_cv
+
+/* With OpenCV's imgproc in sight: the calibration against it, once per process. */
+#if defined(__has_include)
+#if __has_include(<opencv2/imgproc/imgproc.hpp>) && __has_include(<opencv2/core/core.hpp>) && !defined(ORBX_FORCE_CV_COMPAT) && !defined(ORBX_NO_CV_CALIBRATION)
+#include <opencv2/core/core.hpp>
+#include <opencv2/imgproc/imgproc.hpp>
+#define ORBX_CV_CALIBRATION 1
+namespace orbx_cv {
+inline const Calibration& opencv_calibration() {
+  static const Calibration cal = [] {
+    Calibration c = calibrate(
+        [](const uint8_t* src, int w, int h, uint8_t* dst) {
+          cv::Mat s(h, w, CV_8UC1, (void*)src, (size_t)w), d;
+          cv::Mat work = s.clone();   // as src/ORBextractor.cc:1132-1133: in place on a continuous clone
+          cv::GaussianBlur(work, work, cv::Size(7, 7), 2, 2, cv::BORDER_REFLECT_101);
+          for (int y = 0; y < h; y++) std::memcpy(dst + (size_t)y * w, work.ptr<unsigned char>(y), (size_t)w);
+        },
+        [](float y, float x) { return cv::fastAtan2(y, x); });
+#ifdef CV_VERSION
+    report(c, CV_VERSION);
+#else
+    report(c, "(version macro absent)");
+#endif
+    return c;
+  }();
+  return cal;
+}
+}  // namespace orbx_cv
+#endif
+#endif
+
+#endif /* ORBX_CV_CALIBRATE_H */

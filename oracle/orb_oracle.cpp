@@ -30,6 +30,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <list>
@@ -308,6 +309,14 @@ void gaussian_blur7(const uint8_t* src, int w, int h, int sstride, uint8_t* dst,
     }
   }
   for (int y = 0; y < h; y++) {
+    if (rmode == 0) {   // the default rounding: the plain loop (this is also the timed cpu_baseline path)
+      for (int x = 0; x < w; x++) {
+        uint32_t acc = 0;
+        for (int t = 0; t < 7; t++) acc += (uint32_t)k[t] * tmp[(size_t)reflect101(y + t - 3, h) * w + x];
+        dst[(size_t)y * dstride + x] = (uint8_t)std::min((acc + 32768u) >> 16, 255u);
+      }
+      continue;
+    }
     for (int x = 0; x < w; x++) {
       uint32_t acc = 0;
       for (int t = 0; t < 7; t++) acc += (uint32_t)k[t] * tmp[(size_t)reflect101(y + t - 3, h) * w + x];
@@ -382,6 +391,11 @@ float ic_angle(const Image& im, float ptx, float pty, const std::vector<int>& um
   return fast_atan2((float)m_01, (float)m_10);
 }
 
+// g_brief_fma = 1: the rotation of the test pattern as GCC / clang compile src/ORBextractor.cc:118-120 when the reference is built the way
+// its CMakeLists.txt:10-13 asks (-O3 -march=native on an FMA machine, default -ffp-contract): x*b + y*a -> fma(x, b, y*a),
+// x*a - y*b -> fma(x, a, -(y*b)) (the first product is the fused one).  Pinned by oracle/_ref/libref_orbextractor_fma.so = the reference's
+// file compiled here with -O3 -mfma (tests/test_opencv_variants.py).  0 = separate IEEE operations (the canonical form).
+std::atomic<int> g_brief_fma{0};
 // src/ORBextractor.cc:106-146
 void orb_descriptor(const KeyPt& kp, const Image& blurred, uint8_t* desc) {
   const float factorPI = (float)(M_PI / 180.f);
@@ -390,10 +404,12 @@ void orb_descriptor(const KeyPt& kp, const Image& blurred, uint8_t* desc) {
   const int step = blurred.w;
   const uint8_t* center = blurred.row(cv_round(kp.y)) + cv_round(kp.x);
   const int8_t* pat = kPattern;
+  const bool bfma = g_brief_fma.load(std::memory_order_relaxed) != 0;
   auto tap = [&](int idx) -> int {
     float px = (float)pat[idx * 2], py = (float)pat[idx * 2 + 1];
-    int ry = cv_round(px * b + py * a);
-    int rx = cv_round(px * a - py * b);
+    int ry, rx;
+    if (bfma) { ry = cv_round(fmaf(px, b, py * a)); rx = cv_round(fmaf(px, a, -(py * b))); }
+    else { ry = cv_round(px * b + py * a); rx = cv_round(px * a - py * b); }
     return center[ry * step + rx];
   };
   for (int i = 0; i < 32; ++i, pat += 32) {
@@ -828,6 +844,20 @@ int orbo_set_gauss_tail(int v) {
 int orbo_get_gauss_tail() { return g_gauss_tail.load(); }
 int orbo_set_atan_fma(int on) { if (on != 0 && on != 1) return -1; g_atan_fma.store(on); return 0; }
 int orbo_get_atan_fma() { return g_atan_fma.load(); }
+int orbo_set_brief_fma(int on) { if (on != 0 && on != 1) return -1; g_brief_fma.store(on); return 0; }
+// ORBO_VARIANT="kernel,round,tail,atan_fma,brief_fma" in the environment selects the variant at load time: how a test makes the shim of
+// oracle/ref_shims behave like another OpenCV build inside a separate executable (tests/test_adapters.py)
+static const int g_env_variant = [] {
+  const char* e = getenv("ORBO_VARIANT");
+  int v[5] = {0, 0, 0, 0, 0};
+  if (e && sscanf(e, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]) == 5 && v[0] >= 0 && v[0] <= 1 && v[1] >= 0 && v[1] <= 2 &&
+      (v[2] == 0 || v[2] == 4 || v[2] == 8 || v[2] == 16 || v[2] == 32 || v[2] == 64) && (v[3] | 1) == 1 && (v[4] | 1) == 1) {
+    g_gauss_kernel.store(v[0]); g_gauss_round.store(v[1]); g_gauss_tail.store(v[2]); g_atan_fma.store(v[3]); g_brief_fma.store(v[4]);
+    return 1;
+  }
+  return 0;
+}();
+int orbo_get_brief_fma() { return g_brief_fma.load(); }
 void orbo_get_gauss_variant(int* kernel, int* round) { if (kernel) *kernel = g_gauss_kernel.load(); if (round) *round = g_gauss_round.load(); }
 float orbo_fast_atan2(float y, float x) { return fast_atan2(y, x); }
 void orbo_cos_sin_deg(float angle_deg, float* a, float* b) {
@@ -889,6 +919,81 @@ uint64_t orbo_atan_hash(uint32_t seed, uint32_t count) {
   for (auto& x : th) x.join();
   uint64_t h = 0;
   for (uint64_t v : part) h += v;
+  return h;
+}
+// Digest of the rotated test pattern (src/ORBextractor.cc:118-120) over `count` consecutive float bit patterns of the keypoint angle,
+// first + i (degrees, as kpt.angle holds it): a, b = cosf / sinf(angle * factorPI), then (ry, rx) of all 512 pattern points — the CPU side
+// of orbx_debug_brief_hash.  Honours the brief_fma switch.  *n_diff (optional): how many of the count * 512 points would round
+// differently under the other setting of the switch.
+uint64_t orbo_brief_hash(uint32_t first, uint32_t count, uint64_t* n_diff) {
+  unsigned nt = std::thread::hardware_concurrency();
+  if (nt == 0) nt = 1;
+  std::vector<uint64_t> part(nt, 0), diff(nt, 0);
+  std::vector<std::thread> th;
+  const bool bfma = g_brief_fma.load() != 0;
+  const float factorPI = (float)(M_PI / 180.f);
+  for (unsigned t = 0; t < nt; t++)
+    th.emplace_back([&, t] {
+      uint64_t h = 0, nd = 0;
+      for (uint64_t i = t; i < count; i += nt) {
+        const uint32_t bits = first + (uint32_t)i;
+        float ang;
+        std::memcpy(&ang, &bits, 4);
+        const float r = ang * factorPI;
+        const float a = p_cosf(r), b = p_sinf(r);
+        uint64_t hk = 0;
+        for (int idx = 0; idx < 512; idx++) {
+          const float px = (float)kPattern[idx * 2], py = (float)kPattern[idx * 2 + 1];
+          const int ryf = cv_round(fmaf(px, b, py * a)), rxf = cv_round(fmaf(px, a, -(py * b)));
+          const int ryu = cv_round(px * b + py * a), rxu = cv_round(px * a - py * b);
+          nd += (ryf != ryu) + (rxf != rxu);
+          const int ry = bfma ? ryf : ryu, rx = bfma ? rxf : rxu;
+          hk += (uint64_t)(uint32_t)(ry * 64 + rx + 4096) * (0x9E3779B97F4A7C15ull + 2u * (uint64_t)idx);
+        }
+        h += hk ^ (uint64_t)bits;
+      }
+      part[t] = h; diff[t] = nd;
+    });
+  for (auto& x : th) x.join();
+  uint64_t h = 0, nd = 0;
+  for (unsigned t = 0; t < nt; t++) { h += part[t]; nd += diff[t]; }
+  if (n_diff) *n_diff = nd;
+  return h;
+}
+// one rotated pattern point under the current brief_fma switch (tests/support/contract_probe.cpp is compared with this)
+void orbo_rot_tap(int x, int y, float a, float b, int* ry, int* rx) {
+  const float px = (float)x, py = (float)y;
+  if (g_brief_fma.load() != 0) { *ry = cv_round(fmaf(px, b, py * a)); *rx = cv_round(fmaf(px, a, -(py * b))); }
+  else { *ry = cv_round(px * b + py * a); *rx = cv_round(px * a - py * b); }
+}
+// the operand sequence and digest of tests/support/contract_probe.cpp under the current brief_fma switch; *n_diff = operand sets at which
+// the two settings of the switch disagree
+uint64_t orbo_rot_probe_hash(uint32_t n, uint64_t* n_diff) {
+  unsigned nt = std::thread::hardware_concurrency();
+  if (nt == 0) nt = 1;
+  std::vector<uint64_t> part(nt, 0), diff(nt, 0);
+  std::vector<std::thread> th;
+  const bool bfma = g_brief_fma.load() != 0;
+  for (unsigned t = 0; t < nt; t++)
+    th.emplace_back([&, t] {
+      uint64_t h = 0, nd = 0;
+      for (uint64_t i = t; i < n; i += nt) {
+        const uint32_t r0 = mix32(2 * (uint32_t)i + 1), r1 = mix32(2 * (uint32_t)i + 2);
+        const float px = (float)((int)(r0 % 27u) - 13), py = (float)((int)((r0 >> 8) % 27u) - 13);
+        const float ang = (float)(r1 % 36000001u) * 1e-5f * (float)(M_PI / 180.f);
+        const float a = p_cosf(ang), b = p_sinf(ang);
+        const int ryf = cv_round(fmaf(px, b, py * a)), rxf = cv_round(fmaf(px, a, -(py * b)));
+        const int ryu = cv_round(px * b + py * a), rxu = cv_round(px * a - py * b);
+        nd += (ryf != ryu) || (rxf != rxu);
+        const int ry = bfma ? ryf : ryu, rx = bfma ? rxf : rxu;
+        h += (uint64_t)(uint32_t)(ry * 64 + rx + 4096) * (0x9E3779B97F4A7C15ull + 2ull * (uint64_t)(i & 1023u));
+      }
+      part[t] = h; diff[t] = nd;
+    });
+  for (auto& x : th) x.join();
+  uint64_t h = 0, nd = 0;
+  for (unsigned t = 0; t < nt; t++) { h += part[t]; nd += diff[t]; }
+  if (n_diff) *n_diff = nd;
   return h;
 }
 int orbo_distribute(const void* cand, int n, int minX, int maxX, int minY, int maxY, int N, void* dst, int cap) {

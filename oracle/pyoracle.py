@@ -61,6 +61,9 @@ def lib() -> C.CDLL:
         L.orbo_set_atan_fma.restype = C.c_int
         L.orbo_set_atan_fma.argtypes = [C.c_int]
         L.orbo_get_atan_fma.restype = C.c_int
+        L.orbo_set_brief_fma.restype = C.c_int
+        L.orbo_set_brief_fma.argtypes = [C.c_int]
+        L.orbo_get_brief_fma.restype = C.c_int
         L.orbo_fast_atan2.restype = C.c_float
         L.orbo_fast_atan2.argtypes = [C.c_float, C.c_float]
         L.orbo_cos_sin_deg.argtypes = [C.c_float, fp, fp]
@@ -71,6 +74,11 @@ def lib() -> C.CDLL:
         L.orbo_atan_hash.restype = C.c_uint64
         L.orbo_atan_hash.argtypes = [C.c_uint32, C.c_uint32]
         L.orbo_pattern.restype = C.POINTER(C.c_int8)
+        L.orbo_brief_hash.restype = C.c_uint64
+        L.orbo_brief_hash.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+        L.orbo_rot_tap.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, ip, ip]
+        L.orbo_rot_probe_hash.restype = C.c_uint64
+        L.orbo_rot_probe_hash.argtypes = [C.c_uint32, C.POINTER(C.c_uint64)]
         _lib = L
     return _lib
 
@@ -175,21 +183,23 @@ class opencv_variant:
     the previous variant is restored on exit.  Same meaning as the product's orbx_set_option names (include/orbx.h, INTEGRATION.md
     section 6): kernel 0 = {18,34,48,56,...} (OpenCV >= 4.5.1), 1 = {18,34,49,55,...} (3.x .. 4.5.0); round 0 = half up, 1 = ties to even
     (<= 3.4.1 SSE2 column pass), 2 = floor (3.4.2 .. 4.5.0 SIMD column pass under the 257 kernel); tail V = the last w mod V columns round
-    half up; atan_fma 1 = fastAtan2's polynomial contracted into FMAs."""
+    half up; atan_fma 1 = fastAtan2's polynomial contracted into FMAs (OpenCV's AVX2 dispatch copy); brief_fma 1 = the pattern rotation of
+    src/ORBextractor.cc:118-120 contracted into FMAs (the reference itself built with -march=native)."""
 
-    def __init__(self, gauss_kernel: int = 0, gauss_round: int = 0, gauss_tail: int = 0, atan_fma: int = 0):
-        self.want = (int(gauss_kernel), int(gauss_round), int(gauss_tail), int(atan_fma))
+    def __init__(self, gauss_kernel: int = 0, gauss_round: int = 0, gauss_tail: int = 0, atan_fma: int = 0, brief_fma: int = 0):
+        self.want = (int(gauss_kernel), int(gauss_round), int(gauss_tail), int(atan_fma), int(brief_fma))
 
     @staticmethod
     def _set(v):
         L = lib()
-        if L.orbo_set_gauss_variant(v[0], v[1]) != 0 or L.orbo_set_gauss_tail(v[2]) != 0 or L.orbo_set_atan_fma(v[3]) != 0:
+        if (L.orbo_set_gauss_variant(v[0], v[1]) != 0 or L.orbo_set_gauss_tail(v[2]) != 0 or L.orbo_set_atan_fma(v[3]) != 0
+                or L.orbo_set_brief_fma(v[4]) != 0):
             raise ValueError(f"no such OpenCV variant: {v}")
 
     def __enter__(self):
         k, r = C.c_int(0), C.c_int(0)
         lib().orbo_get_gauss_variant(C.byref(k), C.byref(r))
-        self.prev = (k.value, r.value, lib().orbo_get_gauss_tail(), lib().orbo_get_atan_fma())
+        self.prev = (k.value, r.value, lib().orbo_get_gauss_tail(), lib().orbo_get_atan_fma(), lib().orbo_get_brief_fma())
         try:
             self._set(self.want)
         except ValueError:
@@ -203,19 +213,19 @@ class opencv_variant:
 
     def options(self) -> dict:
         """the same variant as orbx_set_option name -> value pairs"""
-        return dict(gauss_kernel=self.want[0], gauss_round=self.want[1], gauss_tail=self.want[2], atan_fma=self.want[3])
+        return dict(gauss_kernel=self.want[0], gauss_round=self.want[1], gauss_tail=self.want[2], atan_fma=self.want[3], brief_fma=self.want[4])
 
 
-# (gauss_kernel, gauss_round, gauss_tail, atan_fma); the first is the default.  The named ones are INTEGRATION.md section 6's rows.
+# (gauss_kernel, gauss_round, gauss_tail, atan_fma, brief_fma); the first is the default.  The named ones are INTEGRATION.md section 6's rows.
 OPENCV_VARIANTS = {
-    "opencv>=4.5.1": (0, 0, 0, 0),
-    "opencv>=4.5.1+fma": (0, 0, 0, 1),
-    "opencv3.4.2-4.5.0 scalar": (1, 0, 0, 0),
-    "opencv3.4.2-4.5.0 simd8": (1, 2, 8, 0),
-    "opencv3.4.2-4.5.0 simd16+fma": (1, 2, 16, 1),
-    "opencv<=3.4.1 sse2": (1, 1, 4, 0),
-    "diffused kernel, ties to even": (0, 1, 0, 0),
-    "diffused kernel, floor, tail 32": (0, 2, 32, 0),
+    "opencv>=4.5.1": (0, 0, 0, 0, 0),
+    "opencv>=4.5.1, avx2 dispatch, reference -march=native": (0, 0, 0, 1, 1),
+    "opencv3.4.2-4.5.0 scalar": (1, 0, 0, 0, 0),
+    "opencv3.4.2-4.5.0 simd8": (1, 2, 8, 0, 0),
+    "opencv3.4.2-4.5.0 simd16, avx2 dispatch, reference -march=native": (1, 2, 16, 1, 1),
+    "opencv<=3.4.1 sse2": (1, 1, 4, 0, 0),
+    "diffused kernel, ties to even": (0, 1, 0, 0, 1),
+    "diffused kernel, floor, tail 32": (0, 2, 32, 0, 0),
 }
 
 
@@ -238,6 +248,27 @@ def cos_sin_deg(angle_deg: float):
 def trig_hash(first_bits: int, count: int) -> int:
     """64-bit digest of (cosf, sinf)(angle * pi/180) over `count` consecutive float bit patterns (see orbx_debug_trig_hash)."""
     return int(lib().orbo_trig_hash(first_bits, count))
+
+
+def brief_hash(first_bits: int, count: int):
+    """(digest, n_diff): 64-bit digest of the 512 rotated pattern points over `count` consecutive float bit patterns of the angle (see
+    orbx_debug_brief_hash), and how many points round differently under the other brief_fma setting."""
+    nd = C.c_uint64(0)
+    h = lib().orbo_brief_hash(first_bits, count, C.byref(nd))
+    return int(h), int(nd.value)
+
+
+def rot_probe_hash(n: int):
+    """(digest, n_diff) over the operand sequence of tests/support/contract_probe.cpp under the current brief_fma setting."""
+    nd = C.c_uint64(0)
+    h = lib().orbo_rot_probe_hash(n, C.byref(nd))
+    return int(h), int(nd.value)
+
+
+def rot_tap(x: int, y: int, a: float, b: float):
+    ry, rx = C.c_int(0), C.c_int(0)
+    lib().orbo_rot_tap(x, y, a, b, C.byref(ry), C.byref(rx))
+    return ry.value, rx.value
 
 
 def atan_hash(seed: int, count: int) -> int:
@@ -669,18 +700,26 @@ class OracleKeyFrameDatabase:
 
 # ---- the REFERENCE's own ORBextractor (oracle/_ref/libref_orbextractor.so: src/ORBextractor.cc compiled where it lies) ----
 _REF_EXT_PATH = os.path.join(_HERE, "_ref", "libref_orbextractor.so")
-_ref_ext = None
+# the same file compiled the way the reference's CMakeLists.txt:10-13 does on an FMA machine (-O3 -mfma, the compiler's default
+# -ffp-contract): what "the reference CPU path" is for a maintainer who builds with -march=native
+_REF_EXT_FMA_PATH = os.path.join(_HERE, "_ref", "libref_orbextractor_fma.so")
+_ref_ext = {}
 
 
-def ref_extractor_available() -> bool:
+def ref_extractor_available(fma: bool = False) -> bool:
+    if fma:
+        try:
+            has = " fma " in open("/proc/cpuinfo").read()
+        except OSError:
+            has = False
+        return has and os.path.exists(_REF_EXT_FMA_PATH)
     return os.path.exists(_REF_EXT_PATH)
 
 
-def _ref_ext_lib():
-    global _ref_ext
-    if _ref_ext is None:
+def _ref_ext_lib(fma: bool = False):
+    if fma not in _ref_ext:
         lib()   # liborb_oracle.so provides the five forwarded OpenCV primitives
-        R = C.CDLL(_REF_EXT_PATH)
+        R = C.CDLL(_REF_EXT_FMA_PATH if fma else _REF_EXT_PATH)
         vp = C.c_void_p
         R.ref_ext_create.restype = vp
         R.ref_ext_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
@@ -690,27 +729,28 @@ def _ref_ext_lib():
         R.ref_ext_tables.argtypes = [vp, vp, vp, vp, vp]
         R.ref_ext_level.restype = C.c_int
         R.ref_ext_level.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
-        _ref_ext = R
-    return _ref_ext
+        _ref_ext[fma] = R
+    return _ref_ext[fma]
 
 
 class RefExtractor:
     """ORB_SLAM3::ORBextractor — the reference's own class (include/ORBextractor.h:49-83)."""
 
-    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, fma: bool = False):
         self.nfeatures, self.nlevels = nfeatures, nlevels
-        self._h = _ref_ext_lib().ref_ext_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        self._R = _ref_ext_lib(fma)
+        self._h = self._R.ref_ext_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
         self.cap = nfeatures + 35 * nlevels + 64   # a level returns up to max(quota + 3, 4 x root nodes) keypoints (<= 8 roots)
 
     def __del__(self):
         if getattr(self, "_h", None):
-            _ref_ext_lib().ref_ext_destroy(self._h)
+            self._R.ref_ext_destroy(self._h)
             self._h = None
 
     def tables(self):
         n = self.nlevels
         sc, isc, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
-        _ref_ext_lib().ref_ext_tables(self._h, _ptr(sc), _ptr(isc), _ptr(s2), _ptr(is2))
+        self._R.ref_ext_tables(self._h, _ptr(sc), _ptr(isc), _ptr(s2), _ptr(is2))
         return dict(scale=sc, inv_scale=isc, sigma2=s2, inv_sigma2=is2)
 
     def extract(self, img: np.ndarray, lapping=(0, 0)):
@@ -719,7 +759,7 @@ class RefExtractor:
         kps = np.zeros(self.cap, KP_DTYPE)
         desc = np.zeros((self.cap, 32), np.uint8)
         n = C.c_int(0)
-        mono = _ref_ext_lib().ref_ext_extract(self._h, img.ctypes.data, img.shape[0], img.shape[1], img.strides[0], int(lapping[0]),
+        mono = self._R.ref_ext_extract(self._h, img.ctypes.data, img.shape[0], img.shape[1], img.strides[0], int(lapping[0]),
                                               int(lapping[1]), _ptr(kps), _ptr(desc), self.cap, C.byref(n))
         if mono == -100000:
             raise RuntimeError(f"reference extractor returned {n.value} keypoints, more than the capacity {self.cap}")
@@ -727,8 +767,8 @@ class RefExtractor:
 
     def level(self, level: int, with_border: bool = False) -> np.ndarray:
         w, h = C.c_int(0), C.c_int(0)
-        assert _ref_ext_lib().ref_ext_level(self._h, level, 0, None, C.byref(w), C.byref(h)) == 0
+        assert self._R.ref_ext_level(self._h, level, 0, None, C.byref(w), C.byref(h)) == 0
         b = 19 if with_border else 0
         out = np.zeros((h.value + 2 * b, w.value + 2 * b), np.uint8)
-        assert _ref_ext_lib().ref_ext_level(self._h, level, int(with_border), _ptr(out), C.byref(w), C.byref(h)) == 0
+        assert self._R.ref_ext_level(self._h, level, int(with_border), _ptr(out), C.byref(w), C.byref(h)) == 0
         return out

@@ -20,6 +20,9 @@
 #   _ref/dropin_frame_world_cpu the same, linked against the oracle-backed C-ABI stub (tests/support/orbx_oracle_stub.cpp): the CPU test
 #   _ref/libref_orbextractor.so src/ORBextractor.cc + include/ORBextractor.h, unmodified, against the container shim; the five
 #                               OpenCV algorithms it calls forward to the oracle's isolated primitives (liborb_oracle.so)
+#   _ref/libref_orbextractor_fma.so  the same, compiled with -O3 -mfma and the compiler's default FP contraction (a -march=native build)
+#   _ref/validate_opencv        tools/validate_opencv.cpp + src/ORBextractor.cc over the shim + liborbx.so + the oracle (the harness of the
+#                               maintainer's OpenCV check)
 REFROOT ?= /root/reference
 REF ?= $(REFROOT)/Thirdparty/DBoW2
 CXX ?= g++
@@ -29,8 +32,8 @@ SRCS := $(REF)/DBoW2/BowVector.cpp $(REF)/DBoW2/FeatureVector.cpp $(REF)/DBoW2/S
 WORLD := ../tests/support/ref_world
 WORLD_HDRS := $(wildcard $(WORLD)/*.h $(WORLD)/*/* $(WORLD)/*/*/*/*) $(wildcard ref_shims/opencv2/*/*.hpp)
 
-all: _ref/libref_dbow2.so _ref/ref_matcher_world _ref/libref_orbextractor.so _ref/ref_streamed_frontend _ref/ref_kfdb_world _ref/ref_frame_world \
-     _ref/dropin_frame_world_cpu $(if $(wildcard ../orb_slam3_modified_amd/liborbx.so),_ref/dropin_frame_world)
+all: _ref/libref_dbow2.so _ref/ref_matcher_world _ref/libref_orbextractor.so _ref/libref_orbextractor_fma.so _ref/ref_streamed_frontend _ref/ref_kfdb_world _ref/ref_frame_world \
+     _ref/dropin_frame_world_cpu $(if $(wildcard ../orb_slam3_modified_amd/liborbx.so),_ref/dropin_frame_world _ref/validate_opencv)
 
 _ref/libref_dbow2.so: $(SRCS) ref_shims/opencv2/core/core.hpp ref_shims/boost/serialization/serialization.hpp
 	mkdir -p _ref
@@ -47,6 +50,14 @@ _ref/ref_matcher_world: $(REFROOT)/src/ORBmatcher.cc $(REFROOT)/include/ORBmatch
 _ref/libref_orbextractor.so: $(REFROOT)/src/ORBextractor.cc $(REFROOT)/include/ORBextractor.h ref_wrap_extractor.cpp liborb_oracle.so $(wildcard ref_shims/opencv2/*/*.hpp)
 	mkdir -p _ref
 	$(CXX) -O2 -std=c++14 -fPIC -ffp-contract=off -w -Iref_shims -I$(REFROOT)/include -shared -o $@ $(REFROOT)/src/ORBextractor.cc ref_wrap_extractor.cpp \
+	    -L. -lorb_oracle -Wl,-rpath,'$$ORIGIN/..'
+
+# The same file the way the reference's CMakeLists.txt:10-13 builds it on an FMA machine: -O3 and -mfma (what -march=native adds that can change
+# results) under the compiler's DEFAULT -ffp-contract — GCC / clang then contract the pattern rotation of src/ORBextractor.cc:118-120 into
+# FMAs.  Pins the oracle's "brief_fma" variant (tests/test_opencv_variants.py); loaded only on hosts whose /proc/cpuinfo lists fma.
+_ref/libref_orbextractor_fma.so: $(REFROOT)/src/ORBextractor.cc $(REFROOT)/include/ORBextractor.h ref_wrap_extractor.cpp liborb_oracle.so $(wildcard ref_shims/opencv2/*/*.hpp)
+	mkdir -p _ref
+	$(CXX) -O3 -mfma -std=c++14 -fPIC -w -Iref_shims -I$(REFROOT)/include -shared -o $@ $(REFROOT)/src/ORBextractor.cc ref_wrap_extractor.cpp \
 	    -L. -lorb_oracle -Wl,-rpath,'$$ORIGIN/..'
 
 # -O3 like the reference's own CMAKE_CXX_FLAGS_RELEASE (CMakeLists.txt:13-15; -march=native left out: the binary travels to the GPU box)
@@ -96,3 +107,12 @@ _ref/dropin_frame_world: $(REFROOT)/src/Frame.cc $(REFROOT)/include/Frame.h ../t
 	    $(REFROOT)/src/Frame.cc $(DROPIN_DBOW2) ../tests/support/frame_world.cpp -o $@ \
 	    -L../orb_slam3_modified_amd -lorbx -L. -lorb_oracle -Wl,-rpath,'$$ORIGIN/../../orb_slam3_modified_amd' -Wl,-rpath,'$$ORIGIN/..'
 .PHONY: all
+
+# tools/validate_opencv.cpp — the maintainer's OpenCV check (tools/validate_opencv.cmake) — built HERE over the container shim, with the
+# reference's src/ORBextractor.cc compiled in for the operator() leg: proves the harness (the shim's cv:: functions are the oracle's), and on
+# the GPU box compares the reference-compiled operator() with liborbx.so image by image (tests/test_validate_opencv.py)
+_ref/validate_opencv: ../tools/validate_opencv.cpp $(REFROOT)/src/ORBextractor.cc $(REFROOT)/include/ORBextractor.h ../include/orbx.h ../include/orbx_cv_calibrate.h \
+                      ../orb_slam3_modified_amd/liborbx.so liborb_oracle.so $(wildcard ref_shims/opencv2/*/*.hpp)
+	mkdir -p _ref
+	$(CXX) -O2 -std=c++14 -ffp-contract=off -w -DORBX_VALIDATE_REFERENCE -I$(REFROOT)/include -I../include -Iref_shims ../tools/validate_opencv.cpp $(REFROOT)/src/ORBextractor.cc -o $@ \
+	    -L../orb_slam3_modified_amd -lorbx -L. -lorb_oracle -Wl,-rpath,'$$ORIGIN/../../orb_slam3_modified_amd' -Wl,-rpath,'$$ORIGIN/..' -Wl,--allow-shlib-undefined

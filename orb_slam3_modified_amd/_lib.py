@@ -60,6 +60,7 @@ def lib() -> C.CDLL:
         "orbx_debug_trig": (i32, [vp, vp, vp, i32, i32, vp, vp, vp]),
         "orbx_debug_trig_hash": (i32, [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
         "orbx_debug_atan_hash": (i32, [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
+        "orbx_debug_brief_hash": (i32, [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
         "orbx_debug_calib_copy": (i32, [vp, vp, vp, sz, i32, vp]),
         "orbx_debug_gnu_sort": (i32, [vp, vp, i32, i32]),
         "orbx_profile_enable": (i32, [vp, i32]),

@@ -705,13 +705,13 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
                          b_kp_list, d_counts, d_kps, d_desc, dc, gpf, nitems, div_magic((uint32_t)gpf),
                          use_mirror ? mirror->kps : (orbx_keypoint*)nullptr, use_mirror ? mirror->desc : (uint8_t*)nullptr,
                          (const uint32_t*)b_lvl_kp, (const int32_t*)b_lvl_n, direct_mode, d_counts, use_mirror ? mirror->counts : (int32_t*)nullptr,
-                         ctx->atan_fma);
+                         ctx->atan_fma, ctx->brief_fma);
     else
     hipLaunchKernelGGL(kern, dim3(xcd_grid(nitems)), dim3(256), 0, st, ctx->d_geo, d_imgs, (long long)row_stride,
                        (long long)frame_stride, b_pyr, (long long)geo.pyr_bytes, b_blur, (long long)geo.blur_bytes,
                        b_kp_list, d_counts, d_kps, d_desc, dc, gpf, nitems, div_magic((uint32_t)gpf),
                        use_mirror ? mirror->kps : (orbx_keypoint*)nullptr, use_mirror ? mirror->desc : (uint8_t*)nullptr,
-                       (const uint32_t*)nullptr, (const int32_t*)nullptr, 0, (int32_t*)nullptr, (int32_t*)nullptr, ctx->atan_fma);
+                       (const uint32_t*)nullptr, (const int32_t*)nullptr, 0, (int32_t*)nullptr, (int32_t*)nullptr, ctx->atan_fma, ctx->brief_fma);
     if (use_mirror && mirrored) *mirrored = true;
   }
   ORBX_HIP(ctx, hipGetLastError());
@@ -866,6 +866,7 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, 
     { const char* e = getenv("ORBX_GAUSS_ROUND"); const int v = e ? atoi(e) : 0; ctx->gauss_round = (v >= 0 && v <= 2) ? v : 0; }
     { const char* e = getenv("ORBX_GAUSS_TAIL"); const int v = e ? atoi(e) : 0; ctx->gauss_tail = (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) ? v : 0; }
     { const char* e = getenv("ORBX_ATAN_FMA"); ctx->atan_fma = e && atoi(e) == 1 ? 1 : 0; }
+    { const char* e = getenv("ORBX_BRIEF_FMA"); ctx->brief_fma = e && atoi(e) == 1 ? 1 : 0; }
     const char* fpk = getenv("ORBX_FAST_PK");   // packed 16-bit necessary test in k_fast_cells (128-thread workgroups)
     ctx->fast_pk = fpk ? atoi(fpk) != 0 : true;
     const char* fs = getenv("ORBX_FAST_STOP");
@@ -1365,6 +1366,7 @@ int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
   else if (n == "gauss_round" && value >= 0 && value <= 2) ctx->gauss_round = value;       // ... which rounding of the column pass
   else if (n == "gauss_tail" && (value == 0 || value == 4 || value == 8 || value == 16 || value == 32 || value == 64)) ctx->gauss_tail = value;   // ... and its scalar tail
   else if (n == "atan_fma" && (value == 0 || value == 1)) ctx->atan_fma = value;          // cv::fastAtan2 compiled with / without FMA contraction
+  else if (n == "brief_fma" && (value == 0 || value == 1)) ctx->brief_fma = value;        // the reference's own pattern rotation compiled with / without it
   else if (n == "qt_points" && value >= 256 && value <= 4096 && value % 128 == 0) ctx->qt_points = value;   // LDS-resident candidates per (frame, level) of the big quadtree levels (half of it for the small ones)
   else if (n == "small_fused") ctx->small_fused = value != 0;
   else if (n == "qt_level_major") ctx->qt_level_major = value != 0;
@@ -1525,6 +1527,11 @@ int orbx_debug_atan_hash(orbx_ctx* ctx, uint32_t seed, uint32_t count, uint64_t*
   return run_hash_kernel(ctx, 1, seed, count, hash);
 }
 
+int orbx_debug_brief_hash(orbx_ctx* ctx, uint32_t first_bits, uint32_t count, uint64_t* hash) {
+  if (!ctx || !hash) return ORBX_E_INVALID;
+  return run_hash_kernel(ctx, 2, first_bits, count, hash);
+}
+
 int orbx_debug_trig_hash(orbx_ctx* ctx, uint32_t first_bits, uint32_t count, uint64_t* hash) {
   if (!ctx || !hash) return ORBX_E_INVALID;
   return run_hash_kernel(ctx, 0, first_bits, count, hash);
@@ -1537,6 +1544,7 @@ static int run_hash_kernel(orbx_ctx* ctx, int which, uint32_t first_bits, uint32
   ORBX_HIP(ctx, hipMemsetAsync(d, 0, sizeof(unsigned long long), ctx->stream));
   if (count && which == 0) hipLaunchKernelGGL(k_debug_trig_hash, dim3(256 * 32), dim3(256), 0, ctx->stream, first_bits, count, d);
   if (count && which == 1) hipLaunchKernelGGL(k_debug_atan_hash, dim3(256 * 32), dim3(256), 0, ctx->stream, first_bits, count, d, ctx->atan_fma);
+  if (count && which == 2) hipLaunchKernelGGL(k_debug_brief_hash, dim3(256 * 32), dim3(256), 0, ctx->stream, first_bits, count, d, ctx->brief_fma);
   ORBX_HIP(ctx, hipGetLastError());
   unsigned long long h = 0;
   ORBX_HIP(ctx, hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));

@@ -160,7 +160,8 @@ struct orbx_ctx {
   // round 0 = (acc + 2^15) >> 16, 1 = half to even (last w mod 4 columns half up), 2 = floor; all saturated to 255
   // gauss_tail V: the last (w mod V) columns of a row round half up whatever gauss_round says (the scalar tail of a SIMD column pass)
   // atan_fma: cv::fastAtan2's polynomial with the contractions a compiler makes under -mfma (OpenCV's AVX2 dispatch), 0 = separate mul / add
-  int gauss_kernel = 0, gauss_round = 0, gauss_tail = 0, atan_fma = 0;
+  // brief_fma: the pattern rotation of src/ORBextractor.cc:118-120 as a -march=native build of the reference contracts it (fma(x, b, y*a))
+  int gauss_kernel = 0, gauss_round = 0, gauss_tail = 0, atan_fma = 0, brief_fma = 0;
   bool describe_direct = true;   // single frame, trivial lapping area: no assembly pass, k_describe reads the quadtree's per-level output
   bool chain_long = true;        // single-frame pyramid: levels 1-2 in one launch, then up to five small levels per launch
   bool chain_batch = false;      // batches too build the pyramid with the chain launches (k_resize_chain) instead of one launch per level

@@ -2070,6 +2070,40 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x, int fma = 0) {
   return fma ? fast_atan2_deg_t<true>(y, x) : fast_atan2_deg_t<false>(y, x);
 }
 
+// One rotated test point of the steered BRIEF (src/ORBextractor.cc:118-120): cvRound(x*b + y*a), cvRound(x*a - y*b).  fma == 0: separate
+// IEEE operations (canonical); fma != 0 (uniform): the contraction GCC / clang make when the reference is built as its
+// CMakeLists.txt asks (-O3 -march=native): the FIRST product is the fused one — fma(x, b, y*a), fma(x, a, -(y*b)) ("brief_fma" option).
+template <bool FMA>
+__device__ __forceinline__ void rot_tap(float x, float y, float a, float b, int& ry, int& rx) {
+  if (FMA) {
+    ry = __float2int_rn(__fmaf_rn(x, b, __fmul_rn(y, a)));
+    rx = __float2int_rn(__fmaf_rn(x, a, -__fmul_rn(y, b)));
+  } else {
+    ry = __float2int_rn(__fadd_rn(__fmul_rn(x, b), __fmul_rn(y, a)));
+    rx = __float2int_rn(__fsub_rn(__fmul_rn(x, a), __fmul_rn(y, b)));
+  }
+}
+// the eight taps of one lane (four tests) read from `base` with row pitch `pitch` (LDS window or the blurred plane); the loads sit inside
+// the caller's uniform branch on the variant, so the two arithmetic forms are never both evaluated
+template <bool FMA, bool MUL40>
+__device__ __forceinline__ void brief_taps(const uint8_t* __restrict__ base, int ctr, int pitch, const char4 (&pat)[4], float a, float b,
+                                           int (&t0)[4], int (&t1)[4]) {
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const float x0 = (float)pat[q].x, y0 = (float)pat[q].y, x1 = (float)pat[q].z, y1 = (float)pat[q].w;
+    int ry0, rx0, ry1, rx1;
+    rot_tap<FMA>(x0, y0, a, b, ry0, rx0);
+    rot_tap<FMA>(x1, y1, a, b, ry1, rx1);
+    if (MUL40) {
+      t0[q] = base[ctr + __mul24(ry0, 40) + rx0];
+      t1[q] = base[ctr + __mul24(ry1, 40) + rx1];
+    } else {
+      t0[q] = base[(uint32_t)(ctr + __mul24(ry0, pitch) + rx0)];
+      t1[q] = base[(uint32_t)(ctr + __mul24(ry1, pitch) + rx1)];
+    }
+  }
+}
+
 // Sum over the wave by DPP (no LDS traffic); the total lands in lane 63 (rows 2,3 of the last step).
 __device__ __forceinline__ int wave_sum_lane63(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
@@ -2098,7 +2132,7 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
                                                   orbx_keypoint* __restrict__ mirror_kps, uint8_t* __restrict__ mirror_desc,
                                                   const uint32_t* __restrict__ lvl_kp = nullptr, const int32_t* __restrict__ lvl_n = nullptr,
                                                   int direct_mode = 0, int32_t* __restrict__ counts_out = nullptr,
-                                                  int32_t* __restrict__ mirror_counts = nullptr, int atan_fma = 0) {
+                                                  int32_t* __restrict__ mirror_counts = nullptr, int atan_fma = 0, int brief_fma = 0) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int L = xcd_logical_block(nitems);
   if (L < 0) return;
@@ -2265,27 +2299,12 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
       }
       wave_lds_sync();
       const int lctr = 18 * 40 + 18 + sh2;
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const float x0 = (float)pat[q].x, y0 = (float)pat[q].y, x1 = (float)pat[q].z, y1 = (float)pat[q].w;
-        const int ry0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
-        const int rx0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-        const int ry1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
-        const int rx1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        t0[q] = sp[lctr + __mul24(ry0, 40) + rx0];
-        t1[q] = sp[lctr + __mul24(ry1, 40) + rx1];
-      }
+      if (brief_fma) brief_taps<true, true>(sp, lctr, 40, pat, a, b, t0, t1);   // uniform (kernel argument)
+      else brief_taps<false, true>(sp, lctr, 40, pat, a, b, t0, t1);
       wave_lds_sync();   // the next keypoint overwrites the slice
-    } else
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const float x0 = (float)pat[q].x, y0 = (float)pat[q].y, x1 = (float)pat[q].z, y1 = (float)pat[q].w;
-      const int ry0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
-      const int rx0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-      const int ry1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
-      const int rx1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-      t0[q] = bplane[(uint32_t)(ctr + __mul24(ry0, bp) + rx0)];
-      t1[q] = bplane[(uint32_t)(ctr + __mul24(ry1, bp) + rx1)];
+    } else {
+      if (brief_fma) brief_taps<true, false>(bplane, ctr, bp, pat, a, b, t0, t1);
+      else brief_taps<false, false>(bplane, ctr, bp, pat, a, b, t0, t1);
     }
     unsigned long long mine = 0;
 #pragma unroll
@@ -2351,6 +2370,31 @@ __global__ __launch_bounds__(256) void k_debug_atan_hash(uint32_t seed, uint32_t
     const int m01 = (int)(a % 6000001u) - 3000000, m10 = (b & 15u) == 0 ? 0 : (int)(b % 6000001u) - 3000000;
     const uint32_t bits = __float_as_uint(fast_atan2_deg((float)m01, (float)m10, atan_fma));
     h += ((unsigned long long)bits * 0x9E3779B97F4A7C15ull) ^ (unsigned long long)(uint32_t)i;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, h);
+}
+
+// The same for the rotated test pattern of the steered BRIEF: digest of (ry, rx) of all 512 pattern points over the float bit patterns
+// [first, first + count) of the keypoint angle (degrees) — the oracle computes the same digest on the host (orbo_brief_hash).
+__global__ __launch_bounds__(256) void k_debug_brief_hash(uint32_t first, uint32_t count, unsigned long long* __restrict__ out, int brief_fma) {
+  const float factorPI = (float)(3.14159265358979323846 / 180.f);
+  unsigned long long h = 0;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += (unsigned long long)gridDim.x * blockDim.x) {
+    const uint32_t bits = first + (uint32_t)i;
+    const float r = __fmul_rn(__uint_as_float(bits), factorPI);
+    const float a = orbx_glibc::cosf_exact(r), b = orbx_glibc::sinf_exact(r);
+    unsigned long long hk = 0;
+#pragma unroll 4
+    for (int idx = 0; idx < 512; idx++) {
+      const float px = (float)c_pattern[idx * 2], py = (float)c_pattern[idx * 2 + 1];
+      int ry, rx;
+      if (brief_fma) rot_tap<true>(px, py, a, b, ry, rx); else rot_tap<false>(px, py, a, b, ry, rx);
+      hk += (unsigned long long)(uint32_t)(ry * 64 + rx + 4096) * (0x9E3779B97F4A7C15ull + 2ull * (unsigned long long)idx);
+    }
+    h += hk ^ (unsigned long long)bits;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o);

@@ -190,6 +190,12 @@ class ORBextractor:
         check(self._L.orbx_debug_atan_hash(self._ctx, seed, count, C.byref(h)), self._ctx)
         return int(h.value)
 
+    def debug_brief_hash(self, first_bits: int, count: int) -> int:
+        """Digest of the device's rotated BRIEF pattern (all 512 points) over `count` consecutive float bit patterns of the angle (test hook)."""
+        h = C.c_uint64(0)
+        check(self._L.orbx_debug_brief_hash(self._ctx, first_bits, count, C.byref(h)), self._ctx)
+        return int(h.value)
+
     def debug_calib_copy(self, d_src: int, d_dst: int, nbytes: int, width: int, stream: int = 0):
         """Known-traffic device copy (counter calibration, tools/pmc_traffic.py)."""
         check(self._L.orbx_debug_calib_copy(self._ctx, ptr(d_src), ptr(d_dst), nbytes, width, ptr(stream)), self._ctx)
@@ -212,7 +218,9 @@ class ORBextractor:
         check(self._L.orbx_reserve(self._ctx, int(rows), int(cols), int(nframes)), self._ctx)
 
     def set_option(self, name: str, value: int) -> None:
-        """Scheduling knob of this context (orbx_set_option); never changes results."""
+        """Option of this context (orbx_set_option, include/orbx.h).  Scheduling / launch-shape knobs never change results; the five
+        OpenCV-build options do, by design: gauss_kernel / gauss_round / gauss_tail (which release's 8-bit cv::GaussianBlur), atan_fma,
+        brief_fma (FMA contraction in cv::fastAtan2 / in the reference's own pattern rotation) — INTEGRATION.md section 6."""
         check(self._L.orbx_set_option(self._ctx, name.encode(), int(value)), self._ctx)
 
     def profile_enable(self, on: bool = True):

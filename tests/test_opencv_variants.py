@@ -152,11 +152,68 @@ def test_reference_compiled_extractor_follows_the_variant(name, v):
     from orb_slam3_modified_amd import synth
     img = synth.make_stream(1, 240, 320)[0]
     base = po.OracleExtractor(500, 1.2, 6, 20, 7).extract(img, (0, 1000))
+    if v[4] and not po.ref_extractor_available(fma=True):
+        pytest.skip("no FMA on this host (or libref_orbextractor_fma.so not built)")
     with po.opencv_variant(*v):
         ok, od, om = po.OracleExtractor(500, 1.2, 6, 20, 7).extract(img, (0, 1000))
-        rk, rd, rm = po.RefExtractor(500, 1.2, 6, 20, 7).extract(img, (0, 1000))
+        rk, rd, rm = po.RefExtractor(500, 1.2, 6, 20, 7, fma=bool(v[4])).extract(img, (0, 1000))   # brief_fma <-> the -mfma build of the file
     assert om == rm and ok.tobytes() == rk.tobytes() and np.array_equal(od, rd), name
     assert not np.array_equal(od, base[1]) or ok.tobytes() != base[0].tobytes(), name
+
+
+def _have_fma():
+    try:
+        return " fma " in open("/proc/cpuinfo").read()
+    except OSError:
+        return False
+
+
+@pytest.mark.skipif(not _have_fma(), reason="host CPU without FMA")
+def test_brief_fma_is_what_the_compiler_makes_of_the_reference_expression(tmp_path):
+    """tests/support/contract_probe.cpp holds an expression of the shape of src/ORBextractor.cc:118-120; built like the reference
+    (-O3, FMA available, default contraction) its digest over 60 million operand sets must equal the oracle's under brief_fma = 1,
+    built with -ffp-contract=off under brief_fma = 0 — and the sample holds operands at which the two settings disagree."""
+    import os, subprocess
+    src = os.path.join(os.path.dirname(__file__), "support", "contract_probe.cpp")
+    n = 60_000_000
+    dig = {}
+    for tag, flags in (("fma", ["-O3", "-mfma"]), ("plain", ["-O3", "-ffp-contract=off"])):
+        exe = str(tmp_path / f"probe_{tag}")
+        subprocess.check_call(["g++", "-std=c++14"] + flags + [src, "-o", exe])
+        dig[tag] = int(subprocess.check_output([exe, str(n)]).decode().strip(), 16)
+    h0, nd = po.rot_probe_hash(n)
+    with po.opencv_variant(brief_fma=1):
+        h1, nd1 = po.rot_probe_hash(n)
+    assert nd == nd1 and nd > 0, "the sample holds no operand at which contraction matters"
+    assert h0 != h1
+    assert dig["plain"] == h0 and dig["fma"] == h1, (nd, dig, h0, h1)
+
+
+def test_adapter_calibration_recognises_every_variant(tmp_path):
+    """include/orbx_cv_calibrate.h against an "OpenCV" whose variant is known (the shim's cv::GaussianBlur / cv::fastAtan2 forward to the
+    oracle): every named variant and a sweep of all (kernel, round, tail) combinations is detected exactly and uniquely from the cv::
+    functions alone."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "calibrate_check")
+    odir = os.path.join(root, "oracle")
+    po.build()
+    subprocess.check_call(["g++", "-std=c++14", "-O2", "-ffp-contract=off", "-I", os.path.join(root, "include"), "-I", os.path.join(odir, "ref_shims"),
+                           os.path.join(root, "tests", "support", "calibrate_check.cpp"), "-o", exe, "-L", odir, "-lorb_oracle", "-Wl,-rpath," + odir])
+    want = [v[:4] for _, v in VARIANTS]
+    want += [(k, r, t, f) for k in (0, 1) for r in (1, 2) for t in (0, 4, 8, 16, 32, 64) for f in (0, 1)] + [(k, 0, 0, f) for k in (0, 1) for f in (0, 1)]
+    args = [str(x) for v in want for x in v]
+    lines = subprocess.check_output([exe] + args).decode().strip().splitlines()
+    assert len(lines) == len(want)
+    for v, line in zip(want, lines):
+        assert line.startswith("%d %d %d %d -> %d %d %d %d exact 1 1 candidates 1 " % (v + v)), line
+
+
+def test_oracle_brief_hash_sees_the_switch():
+    h0, nd0 = po.brief_hash(0x43a00000, 60_000)     # angles from 320 degrees on
+    with po.opencv_variant(brief_fma=1):
+        h1, nd1 = po.brief_hash(0x43a00000, 60_000)
+    assert nd0 == nd1 > 0 and h0 != h1
 
 
 # ------------------------------------------------------------------------------------------------ GPU
@@ -195,8 +252,7 @@ def test_gpu_extract_equals_oracle_under_every_variant(name, v):
     from orb_slam3_modified_amd import synth
     from tests.test_gpu_extractor import assert_same
     nat = np.load("tests/golden/natural_crops.npz")
-    imgs = [synth.make_stream(1)[0], synth.make_stream(1, 480, 752)[0], nat[sorted(nat.files)[0]]]
-    imgs = [i for i in imgs if i.ndim == 2 and i.dtype == np.uint8]
+    imgs = [synth.make_stream(1)[0], synth.make_stream(1, 480, 752)[0], nat["result_640x480_img"]]
     base = po.OracleExtractor(1000, 1.2, 8, 20, 7)
     with po.opencv_variant(*v) as var:
         gpu = _gpu(**var.options())
@@ -207,7 +263,7 @@ def test_gpu_extract_equals_oracle_under_every_variant(name, v):
         ok, od, om = ora.extract(imgs[0], (0, 1000))
         for f in range(3):
             assert_same((res[0][f], res[1][f], res[2][f]), (ok, od, om), f"{name} batch frame {f}")
-    if v != (0, 0, 0, 0):   # and the variant is visible in the output
+    if v[:4] != (0, 0, 0, 0):   # and the variant is visible in the output (brief_fma alone changes one rotated point in a million)
         bk, bd, _ = base.extract(imgs[0], (0, 1000))
         assert not np.array_equal(bd, od) or bk.tobytes() != ok.tobytes(), name
 
@@ -223,9 +279,25 @@ def test_gpu_fast_atan2_fma_digest():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fma", [0, 1])
+def test_gpu_brief_rotation_digest(fma):
+    """The rotated test pattern (all 512 points) on the device equals the host's for every angle of four ranges of float bit patterns
+    (300 000 angles each = 6 x 10^8 points), under both settings of brief_fma; the ranges hold points at which the settings disagree."""
+    gpu = _gpu(brief_fma=fma)
+    with po.opencv_variant(brief_fma=fma):
+        ndt = 0
+        for first in (0x00000000, 0x3f800000, 0x42000000, 0x43a00000):   # 0, 1, 32, 320 degrees
+            h, nd = po.brief_hash(first, 300_000)
+            assert gpu.debug_brief_hash(first, 300_000) == h, hex(first)
+            ndt += nd
+        assert ndt > 0
+    assert gpu.debug_brief_hash(0x42000000, 1000) != gpu.debug_brief_hash(0x42000001, 1000)
+
+
+@pytest.mark.gpu
 def test_gpu_rejects_unknown_variant_values():
     from orb_slam3_modified_amd import OrbxError
     gpu = _gpu()
-    for k, val in (("gauss_kernel", 2), ("gauss_round", 3), ("gauss_tail", 5), ("atan_fma", 2)):
+    for k, val in (("gauss_kernel", 2), ("gauss_round", 3), ("gauss_tail", 5), ("atan_fma", 2), ("brief_fma", -1)):
         with pytest.raises(OrbxError):
             gpu.set_option(k, val)

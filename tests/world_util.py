@@ -73,7 +73,9 @@ def build_adapter_world(backend: str) -> str:
     if backend == "orbx":
         from orb_slam3_modified_amd import build
         build.build()
-        link = ["-L", PKG, "-lorbx", "-Wl,-rpath," + PKG, "-Wl,--allow-shlib-undefined"]
+        # no OpenCV calibration in the product-path builds: the shim's cv::GaussianBlur would pull the oracle in as "the OpenCV at hand"
+        # (tests/test_adapters.py has the one GPU build that does exactly that, on purpose)
+        link = ["-DORBX_NO_CV_CALIBRATION", "-L", PKG, "-lorbx", "-Wl,-rpath," + PKG, "-Wl,--allow-shlib-undefined"]
         deps = _deps() + [os.path.join(PKG, "liborbx.so")]
     else:
         from oracle import pyoracle
@@ -119,7 +121,7 @@ def build_frontend(backend: str, outdir: str = SUP) -> str:
     if backend == "orbx":
         from orb_slam3_modified_amd import build
         build.build()
-        link = ["-L", PKG, "-lorbx", "-Wl,-rpath," + PKG, "-Wl,--allow-shlib-undefined"]
+        link = ["-DORBX_NO_CV_CALIBRATION", "-L", PKG, "-lorbx", "-Wl,-rpath," + PKG, "-Wl,--allow-shlib-undefined"]
         deps = _deps() + [FRONTEND_SRC, os.path.join(PKG, "liborbx.so")]
     else:
         from oracle import pyoracle
