@@ -96,7 +96,7 @@ class KeyFrameDatabase {
  private:
   struct Sharing;                       // one query's sharing list: keyframes in the reference's list order + common-word counts
   void EnsureDb();
-  bool Share(const DBoW2::BowVector& q, Sharing& out);
+  bool Share(const DBoW2::BowVector& q, Sharing& out, std::unique_lock<std::mutex>& lock);
   void Score(const DBoW2::BowVector& q, const std::vector<KeyFrame*>& sel, std::vector<float>& si);
 
   orbx_ctx* ctx_ = nullptr;             // own context: queries come from Tracking (relocalisation) and LoopClosing under mMutex

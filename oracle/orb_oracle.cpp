@@ -13,11 +13,26 @@
 // container-only OpenCV shim (oracle/ref_shims/opencv2) and tests/test_ref_fragments.py requires this restatement to
 // equal it bit for bit — constructor tables, level chain, cell loop with the iniTh -> minTh retry, quadtree with the host
 // std::sort, IC_Angle, steered BRIEF, operator()'s output order — on every benchmark configuration, degenerate images
-// and 120 random shapes / parameters.  What remains **unpinned** ("recalled from OpenCV 4.x", no OpenCV source or binary
-// exists in the container) are the five algorithms that file calls into OpenCV for: cv::FAST, cv::resize,
-// cv::copyMakeBorder, cv::GaussianBlur, cv::fastAtan2 — isolated here as orbo_fast, orbo_resize_linear,
-// orbo_gaussian_blur7, orbo_fast_atan2 (the shim forwards to exactly these) so they can be re-validated against a real
-// OpenCV build later; tests/test_oracle_independent.py checks them against their published definitions.
+// and 120 random shapes / parameters.  What remains **unpinned** ("recalled", no OpenCV source or binary of any version
+// exists in the container) are the five algorithms that file calls into OpenCV for — isolated here as orbo_fast, orbo_resize_linear,
+// orbo_gaussian_blur7, orbo_fast_atan2 and the reflect-101 border (the shim forwards to exactly these).
+//
+// WHICH OPENCV each restatement is of (INTEGRATION.md section 6 has the full table):
+//   cv::resize INTER_LINEAR 8u   the classic 11-bit fixed-point path, the same in every 3.x / 4.x release (IPP builds of <= 3.4 differ)
+//   cv::FAST 9/16 + score + NMS  3.x / 4.x FAST_t<16> + cornerScore<16>
+//   cv::copyMakeBorder           reflect-101 index map, every release
+//   cv::GaussianBlur 8u 7x7      DEFAULT = OpenCV >= 4.5.1 (error-diffused 8.8 weights {18,34,48,56,...}).  The reference names 4.4.0 and
+//                                3.2.0 (CMakeLists.txt:33, README.md:560), whose weights are {18,34,49,55,...} and whose column pass rounds
+//                                differently: selectable, orbo_set_gauss_variant / orbo_set_gauss_tail below (product: "gauss_kernel",
+//                                "gauss_round", "gauss_tail")
+//   cv::fastAtan2                3.x / 4.x polynomial; DEFAULT = separate mul / add, the FMA-contracted form of OpenCV's AVX2 dispatch
+//                                copy is orbo_set_atan_fma(1) (product: "atan_fma")
+//   and of the reference itself: DEFAULT = src/ORBextractor.cc compiled without FP contraction; its -march=native form (the pattern
+//                                rotation of :118-120 fused) is orbo_set_brief_fma(1) (product: "brief_fma"), pinned by the reference's
+//                                file compiled with -O3 -mfma (oracle/_ref/libref_orbextractor_fma.so)
+// A maintainer checks them against a REAL OpenCV with tools/validate_opencv.cpp; the product's adapter finds the variant of the OpenCV it
+// is built with by itself (include/orbx_cv_calibrate.h).  tests/test_oracle_independent.py and tests/test_opencv_variants.py check the
+// restatements against independent statements of their definitions.
 //
 // Float rules: compile with -ffp-contract=off (no FMA fusion),
 // cosf/sinf are the host glibc's, division is IEEE.

@@ -5,6 +5,7 @@
 
 #include <map>
 #include <mutex>
+#include <condition_variable>
 
 #include <algorithm>
 #include <climits>
@@ -727,46 +728,66 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
 // bytes up again.  Valid only while the publishing context has not extracted again (sequence number) — and that context's next
 // extraction waits for a copy still in flight.  Contract, as in the reference: nobody writes into mDescriptors after ExtractORB.
 namespace {
-struct Published { const void* host; orbx_ctx* ctx; unsigned long long seq; int n; const uint8_t* d_desc; };
 std::mutex g_pub_mu;
-Published g_pub[8];
-int g_pub_next = 0;
+std::condition_variable g_pub_cv;          // handover_inflight dropped to zero
+std::vector<orbx_ctx*> g_pub_list;         // contexts that hold a publication (each context at most one: nobody evicts anybody)
+void drop_publication(orbx_ctx* c) {       // g_pub_mu held
+  c->pub_host = nullptr; c->pub_n = 0; c->pub_digest = 0;
+  g_pub_list.erase(std::remove(g_pub_list.begin(), g_pub_list.end(), c), g_pub_list.end());
+}
 }  // namespace
 
-const uint8_t* orbx::published_descriptors(const void* host_desc, int n, int device, orbx_ctx** src) {
+const uint8_t* orbx::handover_acquire(const void* host_desc, int n, int device, orbx_ctx** src) {
   std::lock_guard<std::mutex> lock(g_pub_mu);
-  for (const Published& p : g_pub)
-    if (p.host == host_desc && p.ctx && p.n == n && p.ctx->device == device && p.ctx->extract_seq == p.seq && p.ctx->last_d_desc == p.d_desc) {
-      if (src) *src = p.ctx;
-      return p.d_desc;
+  for (orbx_ctx* c : g_pub_list)
+    if (c->pub_host == host_desc && c->pub_n == n && c->device == device && c->last_d_desc && c->last_n0 == n) {
+      // the buffer must still hold the bytes that were published: a freed cv::Mat reallocated at the same address with the same row
+      // count would otherwise be filled from stale rows (the digest reads 8 bytes per row)
+      const bool same = rows_digest((const uint8_t*)host_desc, n) == c->pub_digest;
+      const uint8_t* d = same ? c->last_d_desc : nullptr;
+      drop_publication(c);   // consumed by its first taker (a target stays resident; later refills take the host bytes) — or stale
+      if (d) { c->handover_inflight++; if (src) *src = c; }
+      return d;
     }
   return nullptr;
 }
-// a new extraction begins on ctx: its staging block is about to be overwritten.  Returns true when a hand-over copy may still be reading it.
+// a new extraction begins on ctx: its staging block is about to be overwritten.  Waits for targets that have chosen the rows but not yet
+// queued their copy; returns true when a queued copy may still be reading the block (the caller orders its stream behind ev_handover).
 static bool handover_begin_extraction(orbx_ctx* ctx) {
-  std::lock_guard<std::mutex> lock(g_pub_mu);
+  std::unique_lock<std::mutex> lock(g_pub_mu);
+  g_pub_cv.wait(lock, [ctx] { return ctx->handover_inflight == 0; });
   ctx->extract_seq++;
   ctx->last_d_desc = nullptr; ctx->last_n0 = 0;
+  drop_publication(ctx);
   const bool pending = ctx->handover_pending && ctx->ev_handover;
   ctx->handover_pending = false;
   return pending;
 }
-// the extraction has finished: its rows sit at `d_desc` (the matcher threads read these two fields under the same lock)
+// the extraction has finished: its rows sit at `d_desc`
 static void handover_end_extraction(orbx_ctx* ctx, const uint8_t* d_desc, int n0) {
   std::lock_guard<std::mutex> lock(g_pub_mu);
   ctx->last_d_desc = d_desc; ctx->last_n0 = n0;
 }
-// a search target on `stream` has queued a device-to-device copy out of src's staging block
 hipError_t orbx::handover_copied(orbx_ctx* src, hipStream_t stream) {
   std::lock_guard<std::mutex> lock(g_pub_mu);
-  if (!src->ev_handover) { const hipError_t e = hipEventCreateWithFlags(&src->ev_handover, hipEventDisableTiming); if (e != hipSuccess) return e; }
-  const hipError_t e = hipEventRecord(src->ev_handover, stream);
+  hipError_t e = hipSuccess;
+  if (!src->ev_handover) e = hipEventCreateWithFlags(&src->ev_handover, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventRecord(src->ev_handover, stream);
   if (e == hipSuccess) src->handover_pending = true;
+  src->handover_inflight--;
+  g_pub_cv.notify_all();
   return e;
 }
-void orbx::unpublish_context(orbx_ctx* ctx) {
+void orbx::handover_abort(orbx_ctx* src) {
   std::lock_guard<std::mutex> lock(g_pub_mu);
-  for (Published& p : g_pub) if (p.ctx == ctx) p = Published{nullptr, nullptr, 0, 0, nullptr};
+  src->handover_inflight--;
+  g_pub_cv.notify_all();
+}
+void orbx::unpublish_context(orbx_ctx* ctx) {   // orbx_destroy: nobody may still be about to read this context's staging block
+  std::unique_lock<std::mutex> lock(g_pub_mu);
+  g_pub_cv.wait(lock, [ctx] { return ctx->handover_inflight == 0; });
+  drop_publication(ctx);
+  ctx->last_d_desc = nullptr; ctx->last_n0 = 0;
 }
 
 using namespace orbx;
@@ -1182,11 +1203,13 @@ static int ingest_resized(orbx_ctx* ctx, const uint8_t* img, int src_rows, int s
 
 int orbx_publish_descriptors(orbx_ctx* ctx, const void* host_desc, int n) {
   if (!ctx || !host_desc || n < 0) return ORBX_E_INVALID;
-  if (!ctx->last_d_desc || n != ctx->last_n0) return ORBX_OK;   // nothing resident that matches: the host bytes will be used
+  const uint64_t dig = rows_digest((const uint8_t*)host_desc, n);   // the caller's buffer as it is NOW (outside the lock: host memory only)
   std::lock_guard<std::mutex> lock(g_pub_mu);
-  for (Published& p : g_pub) if (p.host == host_desc) p = Published{nullptr, nullptr, 0, 0, nullptr};   // a reused buffer: the old entry dies
-  g_pub[g_pub_next] = Published{host_desc, ctx, ctx->extract_seq, n, ctx->last_d_desc};
-  g_pub_next = (g_pub_next + 1) % 8;
+  for (orbx_ctx* c : std::vector<orbx_ctx*>(g_pub_list)) if (c->pub_host == host_desc) drop_publication(c);   // a reused buffer: the old entry dies
+  drop_publication(ctx);                                          // a context publishes its last extraction once
+  if (!ctx->last_d_desc || n != ctx->last_n0 || n == 0) return ORBX_OK;   // nothing resident that matches: the host bytes will be used
+  ctx->pub_host = host_desc; ctx->pub_n = n; ctx->pub_digest = dig;
+  g_pub_list.push_back(ctx);
   return ORBX_OK;
 }
 

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstring>
 #include <string>
 #include <utility>
 #include <vector>
@@ -225,6 +226,10 @@ struct orbx_ctx {
   unsigned long long extract_seq = 0;
   const uint8_t* last_d_desc = nullptr; int last_n0 = 0;
   hipEvent_t ev_handover = nullptr; bool handover_pending = false;
+  // this context's publication (orbx_publish_descriptors; at most one — the rows of its last extraction): the host buffer that holds a copy
+  // of the rows, their count, a digest of the host bytes taken at publish time, and how many search targets are between having chosen the
+  // rows and having queued their copy (a new extraction / orbx_destroy waits for that count to drop).  All under orbx_extractor.hip's g_pub_mu
+  const void* pub_host = nullptr; int pub_n = 0; uint64_t pub_digest = 0; int handover_inflight = 0;
   hipStream_t last_ext_stream = nullptr;   // caller's stream of the last orbx_extract_batch_device (its work may still use our buffers)
   // profiling
   bool profiling = false;
@@ -265,9 +270,21 @@ hipError_t ensure_dynamic_lds(const void* kernel, int bytes);
 hipError_t host_stage(orbx_ctx* ctx, size_t bytes, uint8_t** p);
 // descriptor rows published by an extractor context for the host buffer `host_desc` (orbx_publish_descriptors): device address when the
 // publishing context still holds that extraction on `device`, else nullptr; *src = the publishing context
-const uint8_t* published_descriptors(const void* host_desc, int n, int device, orbx_ctx** src);
+// A publication is consumed by the first target that takes it, is only taken when the host buffer still holds the published bytes (digest),
+// and the publishing context can neither start another extraction nor be destroyed between handover_acquire and handover_copied / _abort.
+const uint8_t* handover_acquire(const void* host_desc, int n, int device, orbx_ctx** src);
+hipError_t handover_copied(orbx_ctx* src, hipStream_t stream);   // the copy out of src's staging block is queued on `stream`
+void handover_abort(orbx_ctx* src);                              // ... or will not happen after all
 void unpublish_context(orbx_ctx* ctx);
-hipError_t handover_copied(orbx_ctx* src, hipStream_t stream);
+// 64-bit digest of n descriptor rows: the first, the middle and the last row whole, one 8-byte word of every other row (1.5 us for 1000 rows)
+inline uint64_t rows_digest(const uint8_t* rows, int n) {
+  uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)(uint32_t)n;
+  auto mix = [&h](uint64_t v) { h = (h ^ v) * 0xff51afd7ed558ccdull; h ^= h >> 32; };
+  auto word = [rows](size_t off) { uint64_t v; std::memcpy(&v, rows + off, 8); return v; };
+  for (int i = 0; i < n; i++) mix(word((size_t)i * 32 + 8 * (size_t)(i & 3)));
+  if (n > 0) for (int r : {0, n / 2, n - 1}) for (int k = 0; k < 4; k++) mix(word((size_t)r * 32 + 8 * (size_t)k));
+  return h;
+}
 }  // namespace orbx
 // A Frame's / KeyFrame's keypoints, descriptors and grid resident in HBM (orbx_target_create, orbx_window.hip)
 struct orbx_target {

@@ -665,8 +665,10 @@ int target_assign(orbx_ctx* ctx, orbx_target* reuse, const orbx_keypoint* kps, c
   // descriptor rows an extractor context published for this very host buffer are taken from HBM (k_stage_in_handover); both blocks
   // are 256-byte aligned, rows are 32 bytes
   orbx_ctx* pub_ctx = nullptr;
-  const uint8_t* d_rows = (n > 0 && ctx->window_direct) ? published_descriptors(desc, n, ctx->device, &pub_ctx) : nullptr;
-  if (d_rows && ((uintptr_t)d_rows & 15)) d_rows = nullptr;
+  // (taken only while the host buffer still holds the published bytes; from here until handover_copied / handover_abort the publishing
+  // context can neither extract again nor be destroyed)
+  const uint8_t* d_rows = (n > 0 && ctx->window_direct) ? handover_acquire(desc, n, ctx->device, &pub_ctx) : nullptr;
+  if (d_rows && ((uintptr_t)d_rows & 15)) { handover_abort(pub_ctx); d_rows = nullptr; }
   if (n) { std::memcpy(h + T->o_kps, kps, sizeof(orbx_keypoint) * (size_t)n); if (!d_rows) std::memcpy(h + T->o_desc, desc, (size_t)n * 32); }
   if (kp_uright) std::memcpy(h + T->o_ur, kp_uright, 4 * (size_t)n);
   if (inv_sigma2) std::memcpy(h + T->o_sig, inv_sigma2, 4 * (size_t)nlevels);
@@ -682,14 +684,15 @@ int target_assign(orbx_ctx* ctx, orbx_target* reuse, const orbx_keypoint* kps, c
       hipLaunchKernelGGL(k_stage_in_handover, dim3(std::min((n16 + 255) / 256, 256)), dim3(256), 0, st, (const uint4*)hdev, (uint4*)T->dev, n16,
                          (int)(T->o_desc / 16), (int)((T->o_desc + (size_t)n * 32) / 16), (const uint4*)d_rows);
       e = hipGetLastError();
-      if (e == hipSuccess) e = handover_copied(pub_ctx, st);   // the publishing context's next extraction waits for this copy
+      const hipError_t e2 = handover_copied(pub_ctx, st);   // the publishing context's next extraction waits for this copy
+      if (e == hipSuccess) e = e2;
     } else {
       hipLaunchKernelGGL(k_stage_in, dim3(std::min((n16 + 255) / 256, 256)), dim3(256), 0, st, (const uint4*)hdev, (uint4*)T->dev, n16);
       e = hipGetLastError();
     }
   } else {
     (void)hipGetLastError();
-    if (d_rows && n) std::memcpy(h + T->o_desc, desc, (size_t)n * 32);   // no mapped view of the staging buffer after all: the host rows go up
+    if (d_rows) { handover_abort(pub_ctx); if (n) std::memcpy(h + T->o_desc, desc, (size_t)n * 32); }   // no mapped view of the staging buffer after all: the host rows go up
     e = hipMemcpyAsync(T->dev, h, upload, hipMemcpyHostToDevice, st);
   }
   if (e == hipSuccess && !have_grid) {

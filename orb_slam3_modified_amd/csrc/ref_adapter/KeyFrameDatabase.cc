@@ -107,7 +107,9 @@ void Flatten(const DBoW2::BowVector& v, std::vector<uint32_t>& ids, std::vector<
 
 }  // namespace
 
-KeyFrameDatabase::KeyFrameDatabase(const ORBVocabulary& voc) : mpVoc(&voc) {}
+// the device context is created here, so that a missing GPU fails at start-up (System's constructor) and not as an uncaught exception in
+// the LocalMapping thread's first add()
+KeyFrameDatabase::KeyFrameDatabase(const ORBVocabulary& voc) : mpVoc(&voc) { EnsureDb(); }
 
 KeyFrameDatabase::~KeyFrameDatabase() {
   if (db_) orbx_kfdb_destroy(db_);
@@ -160,10 +162,11 @@ void KeyFrameDatabase::SetORBVocabulary(ORBVocabulary* pORBVoc) {   // :850-858
   clear();
 }
 
-// device pass 1 (under the mutex, like the reference's walk): every keyframe sharing a word with q, in list order
-bool KeyFrameDatabase::Share(const DBoW2::BowVector& q, Sharing& out) {
+// device pass 1: every keyframe sharing a word with q, in list order.  Takes mMutex through the CALLER's lock object, which stays locked
+// until the caller has finished its Visit loop — the reference does the whole walk, marks included, under the mutex (:106-136 etc.)
+bool KeyFrameDatabase::Share(const DBoW2::BowVector& q, Sharing& out, std::unique_lock<std::mutex>& lock) {
   out.kf.clear(); out.words.clear();
-  unique_lock<mutex> lock(mMutex);
+  lock = std::unique_lock<std::mutex>(mMutex);
   if (!db_ || kfs_.empty() || q.empty()) return false;
   std::vector<uint32_t> ids;
   std::vector<double> vals;
@@ -229,13 +232,15 @@ void ScoreList_(KeyFrameDatabase* self, void (KeyFrameDatabase::*score)(const DB
 vector<KeyFrame*> KeyFrameDatabase::DetectLoopCandidates(KeyFrame* pKF, float minScore) {
   set<KeyFrame*> spConnectedKeyFrames = pKF->GetConnectedKeyFrames();
   Sharing sh;
-  Share(pKF->mBowVec, sh);
+  std::unique_lock<std::mutex> walk;
+  Share(pKF->mBowVec, sh, walk);
   const long unsigned int id = pKF->mnId;
   std::vector<KeyFrame*> list;
   for (size_t i = 0; i < sh.kf.size(); i++) {
     KeyFrame* pKFi = sh.kf[i];
     if (pKFi->GetMap() == pKF->GetMap()) Visit(pKFi, kLoop, id, sh.words[i], !spConnectedKeyFrames.count(pKFi), list);   // a loop candidate must be in the same map
   }
+  if (walk.owns_lock()) walk.unlock();
   if (list.empty()) return vector<KeyFrame*>();
   const int minCommonWords = MinCommonWords(list, kLoop);
   ScoreList scored, acc;
@@ -252,7 +257,8 @@ vector<KeyFrame*> KeyFrameDatabase::DetectLoopCandidates(KeyFrame* pKF, float mi
 void KeyFrameDatabase::DetectCandidates(KeyFrame* pKF, float minScore, vector<KeyFrame*>& vpLoopCand, vector<KeyFrame*>& vpMergeCand) {
   set<KeyFrame*> spConnectedKeyFrames = pKF->GetConnectedKeyFrames();
   Sharing sh;
-  Share(pKF->mBowVec, sh);
+  std::unique_lock<std::mutex> walk;
+  Share(pKF->mBowVec, sh, walk);
   const long unsigned int id = pKF->mnId;
   std::vector<KeyFrame*> loop, merge;
   for (size_t i = 0; i < sh.kf.size(); i++) {
@@ -261,6 +267,7 @@ void KeyFrameDatabase::DetectCandidates(KeyFrame* pKF, float minScore, vector<Ke
     if (pKFi->GetMap() == pKF->GetMap()) Visit(pKFi, kLoop, id, sh.words[i], listable, loop);
     else if (!pKFi->GetMap()->IsBad()) Visit(pKFi, kMerge, id, sh.words[i], listable, merge);
   }
+  if (walk.owns_lock()) walk.unlock();
   if (loop.empty() && merge.empty()) return;
   struct Group { std::vector<KeyFrame*>* list; const Slot* slot; vector<KeyFrame*>* out; };
   const Group groups[2] = {{&loop, &kLoop, &vpLoopCand}, {&merge, &kMerge, &vpMergeCand}};
@@ -283,11 +290,13 @@ void KeyFrameDatabase::DetectCandidates(KeyFrame* pKF, float minScore, vector<Ke
 void KeyFrameDatabase::DetectBestCandidates(KeyFrame* pKF, vector<KeyFrame*>& vpLoopCand, vector<KeyFrame*>& vpMergeCand, int nMinWords) {
   set<KeyFrame*> spConnectedKF = pKF->GetConnectedKeyFrames();
   Sharing sh;
-  Share(pKF->mBowVec, sh);
+  std::unique_lock<std::mutex> walk;
+  Share(pKF->mBowVec, sh, walk);
   const long unsigned int id = pKF->mnId;
   std::vector<KeyFrame*> list;
   for (size_t i = 0; i < sh.kf.size(); i++)
     if (spConnectedKF.find(sh.kf[i]) == spConnectedKF.end()) Visit(sh.kf[i], kPlace, id, sh.words[i], true, list);   // connected keyframes are skipped untouched (:485-488)
+  if (walk.owns_lock()) walk.unlock();
   if (list.empty()) return;
   int minCommonWords = MinCommonWords(list, kPlace);
   if (minCommonWords < nMinWords) minCommonWords = nMinWords;
@@ -304,10 +313,12 @@ void KeyFrameDatabase::DetectBestCandidates(KeyFrame* pKF, vector<KeyFrame*>& vp
 void KeyFrameDatabase::DetectNBestCandidates(KeyFrame* pKF, vector<KeyFrame*>& vpLoopCand, vector<KeyFrame*>& vpMergeCand, int nNumCandidates) {
   set<KeyFrame*> spConnectedKF = pKF->GetConnectedKeyFrames();
   Sharing sh;
-  Share(pKF->mBowVec, sh);
+  std::unique_lock<std::mutex> walk;
+  Share(pKF->mBowVec, sh, walk);
   const long unsigned int id = pKF->mnId;
   std::vector<KeyFrame*> list;
   for (size_t i = 0; i < sh.kf.size(); i++) Visit(sh.kf[i], kPlace, id, sh.words[i], !spConnectedKF.count(sh.kf[i]), list);
+  if (walk.owns_lock()) walk.unlock();
   if (list.empty()) return;
   const int minCommonWords = MinCommonWords(list, kPlace);
   ScoreList scored, acc;
@@ -333,10 +344,12 @@ void KeyFrameDatabase::DetectNBestCandidates(KeyFrame* pKF, vector<KeyFrame*>& v
 // :733-848
 vector<KeyFrame*> KeyFrameDatabase::DetectRelocalizationCandidates(Frame* F, Map* pMap) {
   Sharing sh;
-  Share(F->mBowVec, sh);
+  std::unique_lock<std::mutex> walk;
+  Share(F->mBowVec, sh, walk);
   const long unsigned int id = F->mnId;
   std::vector<KeyFrame*> list;
   for (size_t i = 0; i < sh.kf.size(); i++) Visit(sh.kf[i], kReloc, id, sh.words[i], true, list);
+  if (walk.owns_lock()) walk.unlock();
   if (list.empty()) return vector<KeyFrame*>();
   const int minCommonWords = MinCommonWords(list, kReloc);
   ScoreList scored, acc;

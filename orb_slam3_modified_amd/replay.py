@@ -67,10 +67,12 @@ class ReplayEngine:
     the step's feature block."""
 
     def __init__(self, extractor, frames_dev, lapping=(0, 1000), gather: bool = True, process_group=None, lanes: int = 1,
-                 gather_what: str = "descriptors"):
+                 gather_what: str = "blocks"):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
+        # gather_what: "blocks" (default: `gathered` holds whole feature blocks, indexable with BlockLayout offsets) or "descriptors"
+        # (north_star's exchange, what bench.py asks for: descriptor rows + counts only — read it through gathered_view())
         assert gather_what in ("descriptors", "blocks")
         self.gather_what = gather_what
         self.ex = extractor
@@ -128,8 +130,9 @@ class ReplayEngine:
         cuda = dev.type == "cuda"
         self.streams = [torch.cuda.Stream(device=dev) if cuda else None for _ in self.lane_ranges]
         self.stream = self.streams[0]
-        # the collective runs on its own stream behind every lane of the step
-        self.gstream = (torch.cuda.Stream(device=dev) if len(self.lane_ranges) > 1 else self.stream) if cuda else None
+        # the collective ALWAYS runs on its own stream behind every lane of the step: on a lane's stream step k + 1's kernels would queue
+        # behind step k's collective and the overlap would be gone
+        self.gstream = torch.cuda.Stream(device=dev) if cuda else None
         self.lane_done = [[torch.cuda.Event() for _ in self.lane_ranges] for _ in range(2)] if cuda else None
 
     def step(self):
@@ -149,15 +152,14 @@ class ReplayEngine:
                 self.exs[j].extract_batch_device(fr.data_ptr(), f1 - f0, self.H, self.W, frames.stride(1), frames.stride(0),
                                                  base + f0 * lo.cap * KP_BYTES, base + lo.desc_off + f0 * lo.cap * 32,
                                                  base + lo.counts_off + f0 * 8, self.lap, self.streams[j].cuda_stream)
-                if self.gather and len(self.lane_ranges) > 1:
+                if self.gather:
                     self.lane_done[i][j].record(self.streams[j])
         self.pending[i] = None
         if self.gather:  # enqueued behind the kernels of this step, overlaps the next step's kernels
             send = blk[self.send_off:]
             with torch.cuda.stream(self.gstream):
-                if len(self.lane_ranges) > 1:
-                    for ev in self.lane_done[i]:
-                        self.gstream.wait_event(ev)
+                for ev in self.lane_done[i]:
+                    self.gstream.wait_event(ev)
                 if self.device_collective:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(self.gstream)
