@@ -212,7 +212,11 @@ def streamed_frontend(host_frames, nfeatures, voc_descriptors, nframes=48):
             nref = min(n, 24)
             ref = wu.run_frontend(wu.REF_FRONTEND_EXE, raw, rows, cols, nref, nfeatures, vocp, passes=1, timeout=300)
             chk = wu.run_frontend(exe, raw, rows, cols, nref, nfeatures, vocp, passes=1, timeout=300) if nref != n else out
+            # the comparison is made on a run of EQUAL length on both sides (the CPU loop is too slow for the timed run's frame count):
+            # both digests of that comparison are printed, next to the frame count they cover
             ref["identical_results"] = bool(ref["results_digest"] == chk["results_digest"])
+            ref["compared"] = {"frames": int(nref), "digest_cpu": ref["results_digest"], "digest_gpu_same_frames": chk["results_digest"]}
+            out["results_digest_frames"] = int(out.get("frames_timed", n))
             ref["cores"] = 1
             out["cpu"] = ref
             if not ref["identical_results"]:
@@ -347,6 +351,36 @@ def kernel_roofline(ex, eng, frames, B, H, W, counts, world, steps, dt, nprof=5)
         "kernels_ms_per_launch": {k: round(v, 4) for k, v in per_kernel.items()}}
 
 
+def self_gather_exchange(ex, frame_sets, args, step_ms_plain, timed_replay, sync_all):
+    """N = 1: what the per-step collective costs this GPU even alone — a ONE-rank RCCL group, the same ReplayEngine with the all-gather
+    switched on, the same timed loop.  No link carries anything (one rank), so gather_ms is RCCL's own launch + copy kernel on this GPU and
+    step_ms_with_gather - step_ms_without_gather is what those kernels take from the extractor's (VALU-bound) kernels: the two numbers
+    DESIGN.md section 5's estimate for G = 8 starts from.  Runs after the timed region of `value`."""
+    import socket as _socket
+    import torch.distributed as dist
+    from orb_slam3_modified_amd.replay import ReplayEngine
+    try:
+        if not dist.is_initialized():
+            s = _socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+        eng = ReplayEngine(ex.clone(), frame_sets, lapping=(0, 1000), gather=True, lanes=args.lanes, gather_what=args.gather)
+        steps = max(10, min(args.steps, 30))
+        eng.reset_gather_timing()
+        dt_g, _ = timed_replay(eng, steps, 3, sync_all)
+        g_ms = eng.gather_ms()
+        eng.gather = False
+        dt_ng, _ = timed_replay(eng, steps, 2, sync_all)
+        out = {"collective": f"rccl all_gather_into_tensor({args.gather}) in a ONE-rank group (self-gather: no link traffic), one per step, async on its own "
+                             "stream, double-buffered", "bytes_per_rank_per_step": int(eng.send_bytes), "bytes_received_per_rank_per_step": 0,
+               "gather_ms": None if g_ms is None else round(g_ms, 4), "step_ms_with_gather": round(dt_g / steps * 1e3, 4),
+               "step_ms_without_gather": round(dt_ng / steps * 1e3, 4), "exposed_ms_per_step": round(max(0.0, (dt_g - dt_ng) / steps * 1e3), 4),
+               "steps": steps, "headline_step_ms": round(step_ms_plain, 4)}
+        del eng
+        return out
+    except Exception as e:   # noqa: BLE001 — a diagnostic leg must not cost the bench line
+        return {"error": str(e)[:300]}
+
+
 def timed_replay(eng, steps, warmup, sync_all):
     for _ in range(warmup):
         eng.step()
@@ -366,7 +400,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=None, help="frames per step per camera stream (default 256; 64 with --streams)")
+    ap.add_argument("--batch", type=int, default=None, help="frames per step per camera stream (default 256, also with --streams: at G = 8 every GPU "
+                                                            "then still steps over 256 frames = two 128-frame lanes; 64-frame steps lose 20 %% to short launches)")
     ap.add_argument("--batches", type=int, default=None, help="distinct batches the steps rotate through (default 4; 2 with --streams)")
     ap.add_argument("--rows", type=int, default=480)
     ap.add_argument("--cols", type=int, default=640)
@@ -386,7 +421,7 @@ def main():
                     help="extractor contexts per GPU, each on its own free-running stream over 1/lanes of the batch")
     args = ap.parse_args()
     if args.batch is None:
-        args.batch = 64 if args.streams > 0 else 256     # SURVEY 8(e) sizes the S-8cam exchange for B = 64 frames per stream
+        args.batch = 256   # per camera stream; SURVEY 8(e)'s B = 64 leaves a GPU two 32-frame lanes at G = 8 (measured: -20 %)
     if args.batches is None:
         args.batches = 2 if args.streams > 0 else 4
 
@@ -408,6 +443,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != world:
+            raise SystemExit(f"bench.py: WORLD_SIZE {world} but the process group has {dist.get_world_size()} ranks")
     dev = torch.device("cuda", local_rank)
 
     from orb_slam3_modified_amd import ORBextractor, synth
@@ -537,7 +574,14 @@ def main():
                        "parallelism": (f"{args.streams} camera streams over {world} GPUs" if args.streams > 0 else f"one camera stream per GPU x{world}")},
             "roofline": roof,
         }
+        if exchange is None and world == 1 and not args.no_gather:
+            exchange = self_gather_exchange(ex, frame_sets, args, step_ms, timed_replay, sync_all)
         if exchange is not None:
+            try:
+                exchange["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:   # noqa: BLE001
+                exchange["rccl_version"] = None
+            exchange["ranks"] = dist.get_world_size() if dist.is_initialized() else 1
             result["exchange"] = exchange
         if world == 1 and not args.no_frontend:
             try:

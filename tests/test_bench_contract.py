@@ -53,6 +53,13 @@ def test_bench_json_line():
     assert 0 < cb["scaling_efficiency"] <= 1.2 and cb["value_1core"] > 0
     if cb["kind"] == "reference":
         assert cb["port"]["kind"] == "port" and cb["port"]["value"] > 0
+    # N = 1 carries the exchange too: a one-rank RCCL self-gather (what the collective costs this GPU even alone)
+    xc = j["exchange"]
+    assert "error" not in xc, xc
+    for k in ("collective", "bytes_per_rank_per_step", "gather_ms", "step_ms_with_gather", "step_ms_without_gather", "exposed_ms_per_step", "rccl_version", "ranks"):
+        assert k in xc, k
+    assert xc["ranks"] == 1 and xc["bytes_per_rank_per_step"] == 256 * 1024 * 32 + 256 * 2 * 4 + (-(256 * 2 * 4) % 256) and xc["gather_ms"] > 0
+    assert 0.3 < xc["step_ms_without_gather"] < 5 and xc["step_ms_with_gather"] > 0.3
     sf = j["streamed_frontend"]
     assert "error" not in sf, sf
     assert 0.05 < sf["ms_per_frame"] < 20 and sf["features_per_frame"] > 900 and sf["matches_last_per_frame"] > 100
