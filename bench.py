@@ -365,7 +365,6 @@ def self_gather_exchange(ex, frame_sets, args, step_ms_plain, timed_replay, sync
             dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
         eng = ReplayEngine(ex.clone(), frame_sets, lapping=(0, 1000), gather=True, lanes=args.lanes, gather_what=args.gather)
         steps = max(10, min(args.steps, 30))
-        eng.reset_gather_timing()
         dt_g, _ = timed_replay(eng, steps, 3, sync_all)
         g_ms = eng.gather_ms()
         eng.gather = False
@@ -381,11 +380,28 @@ def self_gather_exchange(ex, frame_sets, args, step_ms_plain, timed_replay, sync
         return {"error": str(e)[:300]}
 
 
+class stdout_to_stderr:
+    """RCCL prints its version banner to the C stdout when a communicator is created; the driver reads ONE JSON line from stdout."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def timed_replay(eng, steps, warmup, sync_all):
     for _ in range(warmup):
         eng.step()
     eng.drain()
     sync_all()
+    eng.reset_gather_timing()   # the first collective creates the communicator (hundreds of ms): not part of a step's gather time
     t0 = time.perf_counter()
     last = 0
     for _ in range(steps):
@@ -442,7 +458,9 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        with stdout_to_stderr():   # the communicator (and RCCL's banner) now, not inside the first timed collective
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.barrier()
         if dist.get_world_size() != world:
             raise SystemExit(f"bench.py: WORLD_SIZE {world} but the process group has {dist.get_world_size()} ranks")
     dev = torch.device("cuda", local_rank)
@@ -476,7 +494,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    eng.reset_gather_timing()
     dt, last = timed_replay(eng, args.steps, args.warmup, sync_all)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -575,7 +592,8 @@ def main():
             "roofline": roof,
         }
         if exchange is None and world == 1 and not args.no_gather:
-            exchange = self_gather_exchange(ex, frame_sets, args, step_ms, timed_replay, sync_all)
+            with stdout_to_stderr():
+                exchange = self_gather_exchange(ex, frame_sets, args, step_ms, timed_replay, sync_all)
         if exchange is not None:
             try:
                 exchange["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())

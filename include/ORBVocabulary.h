@@ -206,11 +206,26 @@ class ORBVocabulary {
     const auto t0 = std::chrono::steady_clock::now();
     auto us = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); };
     Scratch& s = scratch();
-    s.desc.resize((size_t)n * 32);
-    for (int i = 0; i < n; i++) std::memcpy(&s.desc[(size_t)i * 32], features[i].ptr<unsigned char>(), 32);
     s.word.resize(n); s.node.resize(n); s.ids.resize(n); s.weight.resize(n); s.vals.resize(n);
-    const double t_pack = us();
-    {  // Tracking, LocalMapping and LoopClosing all call transform on the one vocabulary: one caller at a time on its context
+    // Frame::ComputeBoW right after Frame::ExtractORB: `features` are the rows of Frame::mDescriptors, the very buffer the extractor adapter
+    // filled and published.  Once this vocabulary is attached to that extractor's context (the first call below does it) the extraction's
+    // own graph has already run the descent and the records wait in its pinned result block: no device round trip here.
+    bool served = false;
+    {
+      const unsigned char* base = features[0].ptr<unsigned char>();
+      bool contiguous = true;
+      for (int i = 1; i < n && contiguous; i++) contiguous = features[i].ptr<unsigned char>() == base + (size_t)i * 32;
+      if (contiguous) {
+        const int rc = orbx_bow_transform_published(voc_, base, n, levelsup, s.word.data(), s.weight.data(), s.node.data());
+        if (rc < 0) throw std::runtime_error(std::string("ORBVocabulary::transform: ") + orbx_last_error(ctx_));
+        served = rc == ORBX_OK;
+      }
+    }
+    double t_pack = us();
+    if (!served) {  // Tracking, LocalMapping and LoopClosing all call transform on the one vocabulary: one caller at a time on its context
+      s.desc.resize((size_t)n * 32);
+      for (int i = 0; i < n; i++) std::memcpy(&s.desc[(size_t)i * 32], features[i].ptr<unsigned char>(), 32);
+      t_pack = us();
       std::lock_guard<std::mutex> lock(mu_);
       if (orbx_bow_transform(voc_, s.desc.data(), n, levelsup, s.word.data(), s.weight.data(), s.node.data()) != ORBX_OK)
         throw std::runtime_error(std::string("ORBVocabulary::transform: ") + orbx_last_error(ctx_));

@@ -420,6 +420,13 @@ int orbx_bow_transform(orbx_voc* voc, const uint8_t* desc, int n, int levelsup, 
                        uint32_t* node);
 int orbx_bow_transform_device(orbx_voc* voc, const uint8_t* d_desc, int n, int levelsup, uint32_t* d_word,
                               double* d_weight, uint32_t* d_node, void* stream);
+/* The same for descriptor rows that an extractor context has published (orbx_publish_descriptors: `host_desc` is the caller's buffer that
+ * holds the rows of that context's last single-frame extraction, contiguous, n rows) — Frame::ComputeBoW after Frame::ExtractORB
+ * (src/Frame.cc:738-745 after :311).  Returns ORBX_OK when the extraction's own graph already ran the descent with this vocabulary and
+ * levelsup (the records are copied from the context's pinned result block: no device round trip), 1 when it did not — the caller then
+ * uses orbx_bow_transform; the first such call attaches the vocabulary to the publishing context, so that from its next extraction on
+ * the single-frame graph ends with the descent.  The buffer must still hold the published bytes (digest), as for the target hand-over. */
+int orbx_bow_transform_published(orbx_voc* voc, const void* host_desc, int n, int levelsup, uint32_t* word, double* weight, uint32_t* node);
 /* BowVector accumulate (addWeight) + normalize(L1): out ids ascending, values double; returns nnz in *n_out.
  * ids/vals hold n entries. */
 int orbx_bow_finalize(const orbx_voc* voc, const uint32_t* word, const double* weight, int n, uint32_t* ids,

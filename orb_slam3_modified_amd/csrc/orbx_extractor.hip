@@ -731,6 +731,8 @@ namespace {
 std::mutex g_pub_mu;
 std::condition_variable g_pub_cv;          // handover_inflight dropped to zero
 std::vector<orbx_ctx*> g_pub_list;         // contexts that hold a publication (each context at most one: nobody evicts anybody)
+std::vector<orbx_ctx*> g_bow_attached;     // contexts with a vocabulary attached (orbx_bow_transform_published)
+std::vector<orbx_ctx*> g_publishers;       // every context that has ever published (until it is destroyed): who extracted the rows in this buffer?
 void drop_publication(orbx_ctx* c) {       // g_pub_mu held
   c->pub_host = nullptr; c->pub_n = 0; c->pub_digest = 0;
   g_pub_list.erase(std::remove(g_pub_list.begin(), g_pub_list.end(), c), g_pub_list.end());
@@ -759,14 +761,20 @@ static bool handover_begin_extraction(orbx_ctx* ctx) {
   ctx->extract_seq++;
   ctx->last_d_desc = nullptr; ctx->last_n0 = 0;
   drop_publication(ctx);
+  ctx->rows_host = nullptr; ctx->rows_n = 0;
+  if (ctx->bow_active != ctx->bow_voc || ctx->bow_active_levelsup != ctx->bow_levelsup) {   // attached / detached since the last call: the graph changes
+    ctx->bow_active = ctx->bow_voc; ctx->bow_active_levelsup = ctx->bow_levelsup;
+    ctx->buf_epoch++;
+  }
   const bool pending = ctx->handover_pending && ctx->ev_handover;
   ctx->handover_pending = false;
   return pending;
 }
 // the extraction has finished: its rows sit at `d_desc`
-static void handover_end_extraction(orbx_ctx* ctx, const uint8_t* d_desc, int n0) {
+static void handover_end_extraction(orbx_ctx* ctx, const uint8_t* d_desc, int n0, bool bow_records = false) {
   std::lock_guard<std::mutex> lock(g_pub_mu);
   ctx->last_d_desc = d_desc; ctx->last_n0 = n0;
+  if (bow_records) ctx->bow_seq = ctx->extract_seq;   // the pinned block holds this extraction's {word, node, weight} records
 }
 hipError_t orbx::handover_copied(orbx_ctx* src, hipStream_t stream) {
   std::lock_guard<std::mutex> lock(g_pub_mu);
@@ -788,6 +796,14 @@ void orbx::unpublish_context(orbx_ctx* ctx) {   // orbx_destroy: nobody may stil
   g_pub_cv.wait(lock, [ctx] { return ctx->handover_inflight == 0; });
   drop_publication(ctx);
   ctx->last_d_desc = nullptr; ctx->last_n0 = 0;
+  ctx->bow_voc = nullptr; ctx->rows_host = nullptr;
+  g_bow_attached.erase(std::remove(g_bow_attached.begin(), g_bow_attached.end(), ctx), g_bow_attached.end());
+  g_publishers.erase(std::remove(g_publishers.begin(), g_publishers.end(), ctx), g_publishers.end());
+}
+void orbx::voc_detach_all(const orbx_voc* v) {
+  std::lock_guard<std::mutex> lock(g_pub_mu);
+  for (orbx_ctx* c : g_bow_attached) if (c->bow_voc == v) { c->bow_voc = nullptr; c->bow_seq = ~0ull; }
+  g_bow_attached.erase(std::remove_if(g_bow_attached.begin(), g_bow_attached.end(), [](orbx_ctx* c) { return c->bow_voc == nullptr; }), g_bow_attached.end());
 }
 
 using namespace orbx;
@@ -1012,13 +1028,14 @@ int orbx_extract_batch_device(orbx_ctx* ctx, const uint8_t* d_imgs, int nframes,
 
 // Staging of the host-buffer entry points: one device block [keypoints | descriptors | counts] per call and a pinned
 // host mirror of it, so the results come back in ONE device-to-host copy.
-struct StageLayout { size_t kps_off, desc_off, counts_off, bytes; };
+struct StageLayout { size_t kps_off, desc_off, counts_off, bow_off, bytes; };
 static StageLayout stage_layout(const orbx_ctx* ctx, int nframes) {
   StageLayout L;
   L.kps_off = 0;
   L.desc_off = ((size_t)nframes * ctx->out_cap * sizeof(orbx_keypoint) + 255) / 256 * 256;
   L.counts_off = L.desc_off + ((size_t)nframes * ctx->out_cap * 32 + 255) / 256 * 256;
-  L.bytes = L.counts_off + ((size_t)nframes * 2 * sizeof(int32_t) + 255) / 256 * 256;
+  L.bow_off = L.counts_off + ((size_t)nframes * 2 * sizeof(int32_t) + 255) / 256 * 256;   // {word, node, weight} records of frame 0 (single-frame graph)
+  L.bytes = L.bow_off + ((size_t)ctx->out_cap * 16 + 255) / 256 * 256;
   return L;
 }
 
@@ -1105,6 +1122,12 @@ static int extract_one_graph(orbx_ctx* ctx, const uint8_t* img, int rows, int co
         if (ok) ok = hipMemcpyAsync(ctx->h_stage_out + L.kps_off, d + L.kps_off, kb, hipMemcpyDeviceToHost, st) == hipSuccess;
         if (ok) ok = hipMemcpyAsync(ctx->h_stage_out + L.desc_off, d + L.desc_off, db, hipMemcpyDeviceToHost, st) == hipSuccess;
         if (ok) ok = hipMemcpyAsync(ctx->h_stage_out + L.counts_off, d + L.counts_off, cb, hipMemcpyDeviceToHost, st) == hipSuccess;
+      }
+      // a vocabulary is attached: the descent of the frame's descriptors as the graph's tail, records into the pinned block
+      ctx->bow_in_graph = false;
+      if (ok && ctx->bow_active && hout_dev && voc_device(ctx->bow_active) == ctx->device) {
+        ok = launch_bow_records(ctx->bow_active, d + L.desc_off, (const int32_t*)(d + L.counts_off), ctx->out_cap, ctx->bow_active_levelsup, hout_dev + L.bow_off, st) == hipSuccess;
+        ctx->bow_in_graph = ok;
       }
       if (ok && keep && ctx->geo.pyr_bytes > 0)
         ok = hipMemcpyAsync(ctx->h_pyr, ctx->d_pyr, (size_t)ctx->geo.pyr_bytes, hipMemcpyDeviceToHost, st) == hipSuccess;
@@ -1206,11 +1229,37 @@ int orbx_publish_descriptors(orbx_ctx* ctx, const void* host_desc, int n) {
   const uint64_t dig = rows_digest((const uint8_t*)host_desc, n);   // the caller's buffer as it is NOW (outside the lock: host memory only)
   std::lock_guard<std::mutex> lock(g_pub_mu);
   for (orbx_ctx* c : std::vector<orbx_ctx*>(g_pub_list)) if (c->pub_host == host_desc) drop_publication(c);   // a reused buffer: the old entry dies
+  for (orbx_ctx* c : g_publishers) if (c->rows_host == host_desc) { c->rows_host = nullptr; c->rows_n = 0; }
   drop_publication(ctx);                                          // a context publishes its last extraction once
   if (!ctx->last_d_desc || n != ctx->last_n0 || n == 0) return ORBX_OK;   // nothing resident that matches: the host bytes will be used
   ctx->pub_host = host_desc; ctx->pub_n = n; ctx->pub_digest = dig;
   g_pub_list.push_back(ctx);
+  // "whose rows are these" outlives the hand-over (which is consumed by the first target): Frame::ComputeBoW may come after the first search
+  ctx->rows_host = host_desc; ctx->rows_n = n; ctx->rows_digest_v = dig;
+  if (std::find(g_publishers.begin(), g_publishers.end(), ctx) == g_publishers.end()) g_publishers.push_back(ctx);
   return ORBX_OK;
+}
+
+int orbx_bow_transform_published(orbx_voc* voc, const void* host_desc, int n, int levelsup, uint32_t* word, double* weight, uint32_t* node) {
+  if (!voc || !host_desc || n <= 0 || !word || !weight || !node) return ORBX_E_INVALID;
+  const uint64_t dig = rows_digest((const uint8_t*)host_desc, n);
+  std::lock_guard<std::mutex> lock(g_pub_mu);
+  for (orbx_ctx* c : g_publishers)
+    if (c->rows_host == host_desc && c->rows_n == n && c->rows_digest_v == dig) {
+      if (c->bow_active == voc && c->bow_active_levelsup == levelsup && c->bow_seq == c->extract_seq && c->h_stage_out) {
+        struct Rec { uint32_t word, node; double weight; };
+        const Rec* rec = (const Rec*)(c->h_stage_out + c->bow_off);   // the extracting thread cannot overwrite the block while g_pub_mu is held
+        for (int i = 0; i < n; i++) { word[i] = rec[i].word; node[i] = rec[i].node; weight[i] = rec[i].weight; }
+        return ORBX_OK;
+      }
+      // this extractor's frames are being transformed with `voc`: from its next extraction on the graph does the descent itself
+      if (voc_device(voc) == c->device && (c->bow_voc != voc || c->bow_levelsup != levelsup)) {
+        c->bow_voc = voc; c->bow_levelsup = levelsup;
+        if (std::find(g_bow_attached.begin(), g_bow_attached.end(), c) == g_bow_attached.end()) g_bow_attached.push_back(c);
+      }
+      return 1;
+    }
+  return 1;
 }
 
 // channels == 1: grey frames.  channels == 3 / 4: interleaved colour frames, converted on the device behind the upload
@@ -1240,7 +1289,8 @@ static int extract_batch_impl(orbx_ctx* ctx, const uint8_t* imgs, int nframes, i
       std::memcpy(desc, ctx->h_stage_out + L.desc_off, db);
       std::memcpy(counts, ctx->h_stage_out + L.counts_off, cb);
       if (counts[0] < 0) return set_err(ctx, ORBX_E_CAPACITY, "quadtree produced more nodes than the level capacity");
-      handover_end_extraction(ctx, ctx->d_stage_out + L.desc_off, counts[0]);
+      ctx->bow_off = L.bow_off;
+      handover_end_extraction(ctx, ctx->d_stage_out + L.desc_off, counts[0], ctx->bow_in_graph);
       return ORBX_OK;
     }
   }

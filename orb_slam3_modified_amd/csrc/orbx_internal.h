@@ -230,6 +230,17 @@ struct orbx_ctx {
   // of the rows, their count, a digest of the host bytes taken at publish time, and how many search targets are between having chosen the
   // rows and having queued their copy (a new extraction / orbx_destroy waits for that count to drop).  All under orbx_extractor.hip's g_pub_mu
   const void* pub_host = nullptr; int pub_n = 0; uint64_t pub_digest = 0; int handover_inflight = 0;
+  // vocabulary attached to this extractor context (orbx_bow_transform_published attaches the first vocabulary that asks for the words of
+  // one of its extractions): the single-frame graph then ends with the tree descent of the frame's descriptors and leaves the
+  // {word, node, weight} records in the pinned result block — Frame::ComputeBoW costs no device round trip of its own.  bow_voc /
+  // bow_levelsup are written under g_pub_mu by any thread; the extracting thread takes its snapshot (bow_active*) at the start of a call
+  orbx_voc* bow_voc = nullptr; int bow_levelsup = 0;
+  orbx_voc* bow_active = nullptr; int bow_active_levelsup = 0;
+  unsigned long long bow_seq = ~0ull;   // extract_seq of the extraction whose records the pinned block holds
+  size_t bow_off = 0;                   // offset of the records in h_stage_out
+  bool bow_in_graph = false;            // the captured single-frame graph ends with the descent
+  // the host buffer that holds (a copy of) the rows of the last extraction, until the next extraction begins (not consumed by the hand-over)
+  const void* rows_host = nullptr; int rows_n = 0; uint64_t rows_digest_v = 0;
   hipStream_t last_ext_stream = nullptr;   // caller's stream of the last orbx_extract_batch_device (its work may still use our buffers)
   // profiling
   bool profiling = false;
@@ -276,6 +287,12 @@ const uint8_t* handover_acquire(const void* host_desc, int n, int device, orbx_c
 hipError_t handover_copied(orbx_ctx* src, hipStream_t stream);   // the copy out of src's staging block is queued on `stream`
 void handover_abort(orbx_ctx* src);                              // ... or will not happen after all
 void unpublish_context(orbx_ctx* ctx);
+// orbx_matcher.hip: the tree descent of the single-frame graph — descriptors and the frame's keypoint count read on the device, records
+// {word, node, weight} (16 bytes each) written to rec_out; nullptr stream error codes as hipError_t.  voc_device: the GPU the tree lives on
+hipError_t launch_bow_records(const orbx_voc* v, const uint8_t* d_desc, const int32_t* d_counts, int cap, int levelsup, void* rec_out, hipStream_t st);
+int voc_device(const orbx_voc* v);
+// orbx_extractor.hip: a vocabulary is going away — no context may keep it attached
+void voc_detach_all(const orbx_voc* v);
 // 64-bit digest of n descriptor rows: the first, the middle and the last row whole, one 8-byte word of every other row (1.5 us for 1000 rows)
 inline uint64_t rows_digest(const uint8_t* rows, int n) {
   uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)(uint32_t)n;

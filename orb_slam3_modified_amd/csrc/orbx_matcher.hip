@@ -299,6 +299,18 @@ __global__ __launch_bounds__(256) void k_bow_descend_direct(const DevNode* __res
   }
 }
 
+// The single-frame extraction graph's tail (orbx_voc attached to the extractor context): the same descent over the descriptors the graph has
+// just produced; the frame's keypoint count is only known on the device.  Records go straight into the caller-visible pinned block.
+__global__ __launch_bounds__(256) void k_bow_descend_graph(const DevNode* __restrict__ nodes, const uint8_t* __restrict__ slot_desc,
+                                                           const int32_t* __restrict__ slot_node, const uint8_t* __restrict__ desc,
+                                                           const int32_t* __restrict__ counts, int L, int levelsup, BowRecord* __restrict__ rec) {
+  const int lane = threadIdx.x & 63;
+  const int fi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (fi >= counts[0]) return;
+  const BowLeaf lf = bow_descend_wave(nodes, slot_desc, slot_node, load_desc(desc + (size_t)fi * 32), L, levelsup, lane);
+  if (lane == 0) rec[fi] = BowRecord{(uint32_t)lf.word_id, lf.nid, lf.weight};
+}
+
 // L1Scoring::score (ScoringObject.cpp:23-68): thread per database vector, sequential merge in ascending id
 // order so the double accumulation order equals std::map iteration.
 __global__ __launch_bounds__(256) void k_bow_score_l1(const uint32_t* __restrict__ qid, const double* __restrict__ qv, int nq,
@@ -339,6 +351,15 @@ struct orbx_voc {
   uint8_t* d_slot_desc = nullptr;
   int32_t* d_slot_node = nullptr;
 };
+
+hipError_t orbx::launch_bow_records(const orbx_voc* v, const uint8_t* d_desc, const int32_t* d_counts, int cap, int levelsup, void* rec_out,
+                                    hipStream_t st) {
+  if (!v || v->parent.size() <= 1 || !v->d_nodes || cap <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_bow_descend_graph, dim3((cap + 3) / 4), dim3(256), 0, st, v->d_nodes, v->d_slot_desc, v->d_slot_node, d_desc, d_counts, v->L, levelsup,
+                     (BowRecord*)rec_out);
+  return hipGetLastError();
+}
+int orbx::voc_device(const orbx_voc* v) { return v && v->ctx ? v->ctx->device : -1; }
 
 using namespace orbx;
 
@@ -689,6 +710,7 @@ int orbx_voc_load_binary(orbx_ctx* ctx, const char* path, orbx_voc** out) {
 
 void orbx_voc_destroy(orbx_voc* v) {
   if (!v) return;
+  orbx::voc_detach_all(v);   // extractor contexts that descend this tree inside their single-frame graph
   if (v->d_nodes) (void)hipFree(v->d_nodes);
   if (v->d_slot_desc) (void)hipFree(v->d_slot_desc);
   if (v->d_slot_node) (void)hipFree(v->d_slot_node);

@@ -64,6 +64,17 @@ class ORBVocabulary:
         check(self._L.orbx_bow_transform(self._voc, ptr(d), n, levelsup, ptr(word), ptr(weight), ptr(node)), self._ctx)
         return word[:n], weight[:n], node[:n]
 
+    def descend_published(self, desc: np.ndarray, levelsup: int = 4):
+        """orbx_bow_transform_published: `desc` is the very array an ORBextractor's publish_descriptors() named (the rows of its last
+        single-frame extraction).  Returns (word, weight, node) when that extraction's own graph already ran the descent with this
+        vocabulary, else None — and attaches the vocabulary to that extractor for its next extractions."""
+        assert desc.dtype == np.uint8 and desc.flags["C_CONTIGUOUS"]
+        n = int(desc.shape[0])
+        word, node = np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.uint32)
+        weight = np.zeros(max(n, 1), np.float64)
+        rc = check(self._L.orbx_bow_transform_published(self._voc, ptr(desc), n, levelsup, ptr(word), ptr(weight), ptr(node)), self._ctx)
+        return (word[:n], weight[:n], node[:n]) if rc == 0 else None
+
     def transform(self, desc: np.ndarray, levelsup: int = 4
                   ) -> Tuple[Tuple[np.ndarray, np.ndarray], Dict[int, List[int]]]:
         """transform(features, BowVector&, FeatureVector&, levelsup), TemplatedVocabulary.h:1127-1194.

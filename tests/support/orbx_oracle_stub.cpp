@@ -71,6 +71,7 @@ int orbx_set_host_pyramid(orbx_ctx*, int) { return ORBX_OK; }
 // the adapter's OpenCV calibration (include/orbx_cv_calibrate.h) sets the variant it detected in the shim's cv:: functions — which ARE the
 // oracle's primitives under the oracle's current switches, i.e. what this stub computes with anyway
 int orbx_set_option(orbx_ctx*, const char*, int) { return ORBX_OK; }
+int orbx_bow_transform_published(orbx_voc*, const void*, int, int, uint32_t*, double*, uint32_t*) { return 1; }   // nothing is ever precomputed here
 int orbx_publish_descriptors(orbx_ctx*, const void*, int) { return ORBX_OK; }
 // the host mirror of mvImagePyramid (levels >= 1) that include/ORBextractor.h hands to Frame::ComputeStereoMatches: the oracle's levels
 int orbx_host_pyramid_level(orbx_ctx* c, int level, const uint8_t** data, size_t* stride, int* w, int* h) {

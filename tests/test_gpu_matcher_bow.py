@@ -91,6 +91,68 @@ def test_bow_transform_and_scores(feats, tmp_path, k, L):
         assert host == ref and dev.tolist() == ref
 
 
+def test_bow_descent_inside_the_extraction_graph(tmp_path):
+    """Frame::ComputeBoW after Frame::ExtractORB without a device round trip of its own: the first published transform attaches the
+    vocabulary to the extractor that produced the rows; from its next extraction on the single-frame graph ends with the tree descent and
+    the records are served from the extractor's pinned block.  Same words / weights / nodes as the ordinary call and as the oracle; a
+    buffer whose bytes changed, another levelsup, a batch extraction, another extractor or a destroyed vocabulary are not served."""
+    frames = synth.make_stream(5)
+    ex = ORBextractor(1000, 1.2, 8, 20, 7)
+    d0 = ex(frames[0], None, (0, 1000))[2]
+    p = str(tmp_path / "voc.txt")
+    make_vocabulary(p, d0, 10, 4, seed=5)
+    gv = ORBVocabulary(ex)
+    assert gv.loadFromTextFile(p)
+    ov = po.OracleVocabulary(p)
+
+    def extract(i, e=ex):
+        d = np.ascontiguousarray(e(frames[i], None, (0, 1000))[2])
+        e.publish_descriptors(d)
+        return d
+
+    d = extract(0)
+    assert gv.descend_published(d, 4) is None            # not attached yet: this call attaches
+    served = 0
+    for i in (1, 2, 3, 1):
+        d = extract(i)
+        got = gv.descend_published(d, 4)
+        assert got is not None, i
+        w, wt, nd = got
+        ow, owt, ond = gv.descend(d, 4)
+        assert np.array_equal(w, ow) and wt.tobytes() == owt.tobytes() and np.array_equal(nd, ond)
+        (oi, ovals), ofv = ov.transform(d, 4)
+        (gi, gvals), gfv = gv.transform(d, 4)
+        assert np.array_equal(gi, oi) and gvals.tobytes() == ovals.tobytes() and gfv == ofv
+        served += 1
+        assert gv.descend_published(d, 4) is not None     # asking twice is fine (the records stay until the next extraction)
+    assert served == 4
+    # the caller's buffer no longer holds the published bytes
+    d = extract(2)
+    d[5, 3] ^= 0xff
+    assert gv.descend_published(d, 4) is None
+    # another levelsup: not what the graph computed (and the context is re-attached with the new value)
+    d = extract(3)
+    assert gv.descend_published(d, 2) is None
+    d = extract(3)
+    got = gv.descend_published(d, 2)
+    assert got is not None and np.array_equal(got[2], gv.descend(d, 2)[2])
+    # a batch extraction publishes nothing of the kind
+    ex.extract_batch(frames[:2], (0, 1000))
+    assert gv.descend_published(d, 2) is None
+    # rows of another extractor are found through THAT extractor
+    ex2 = ORBextractor(1000, 1.2, 8, 20, 7)
+    d2 = extract(4, ex2)
+    assert gv.descend_published(d2, 2) is None
+    d2 = extract(4, ex2)
+    assert gv.descend_published(d2, 2) is not None
+    # a vocabulary that goes away detaches itself; extraction keeps working
+    del gv
+    import gc; gc.collect()
+    k = ex(frames[0], None, (0, 1000))
+    okps, odesc, omono = po.OracleExtractor(1000, 1.2, 8, 20, 7).extract(frames[0], (0, 1000))
+    assert k[0] == omono and k[1].tobytes() == okps.tobytes() and np.array_equal(k[2], odesc)
+
+
 def test_vocabulary_loader_rejects_garbage(feats, tmp_path):
     gpu, _ = feats
     p = tmp_path / "bad.txt"
