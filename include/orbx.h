@@ -203,6 +203,20 @@ int orbx_nn_csr(orbx_ctx* ctx, const uint8_t* q_desc, int nq, const uint8_t* t_d
                 const int32_t* cand, int last_wins, int32_t* best_idx, int32_t* best_dist, int32_t* second_idx,
                 int32_t* second_dist, int32_t* dist_out);
 
+struct orbx_candidate;   /* {int32_t idx, dist}, defined with the window searches below */
+/* Guided matching inside vocabulary nodes — SearchByBoW (src/ORBmatcher.cc:223-425, :765-899) and SearchForTriangulation (:901-1146) compare
+ * every feature of a node on one side with every feature of the same node on the other.  Queries are GROUPED: all queries of group g
+ * (q_group[q] = g) share the candidate list group_cand[group_ptr[g] .. group_ptr[g+1]) (rows of t_desc), so the host never builds the
+ * per-query repetition of those lists; and only candidates at Hamming distance <= max_dist are reported — the host replays of those
+ * routines never look at the others (TH_LOW for the triangulation search; for the ratio test the bound beyond which it passes anyway).
+ *   q_off[q], q_cnt[q] : query q's near candidates are entries[q_off[q] .. q_off[q] + q_cnt[q]), in the order of its group's list
+ *   entries[i]         : {idx = row of t_desc, dist}
+ *   *n_entries         : entries produced; when that exceeds pool_cap the call returns ORBX_E_CAPACITY and nothing else is valid (the
+ *                        caller repeats with a larger pool or uses orbx_nn_csr) */
+int orbx_nn_groups(orbx_ctx* ctx, const uint8_t* q_desc, const int32_t* q_group, int nq, const uint8_t* t_desc, int nt,
+                   const int32_t* group_ptr, const int32_t* group_cand, int ngroups, int max_dist, int32_t* q_off, int32_t* q_cnt,
+                   struct orbx_candidate* entries, int pool_cap, int* n_entries);
+
 /* cv::BFMatcher(NORM_HAMMING).knnMatch(k=2) as used at src/Frame.cc:43,1144: for each query the two nearest
  * train descriptors (ties -> lower train index first).  idx/dist: [nq][2]; missing entries = -1 / 256. */
 int orbx_knn2_allpairs(orbx_ctx* ctx, const uint8_t* q_desc, int nq, const uint8_t* t_desc, int nt, int32_t* idx,

@@ -101,6 +101,7 @@ def lib() -> C.CDLL:
         "orbx_voc_info": (i32, [vp, ip, ip, ip, ip]),
         "orbx_bow_transform": (i32, [vp, vp, i32, i32, vp, vp, vp]),
         "orbx_bow_transform_published": (i32, [vp, vp, i32, i32, vp, vp, vp]),
+        "orbx_nn_groups": (i32, [vp, vp, vp, i32, vp, i32, vp, vp, i32, i32, vp, vp, vp, i32, C.POINTER(C.c_int)]),
         "orbx_bow_transform_device": (i32, [vp, vp, i32, i32, vp, vp, vp, vp]),
         "orbx_bow_finalize": (i32, [vp, vp, vp, i32, vp, vp, ip]),
         "orbx_bow_score_l1": (C.c_double, [vp, vp, i32, vp, vp, i32]),

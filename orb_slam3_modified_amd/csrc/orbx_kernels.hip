@@ -358,6 +358,29 @@ __device__ __forceinline__ uint32_t fast_pretest_pk_lo(uint32_t c, uint32_t p0, 
   return as_u32(__builtin_elementwise_sub_sat(lo, maxmin)) | as_u32(__builtin_elementwise_sub_sat(minmax, hi));
 }
 
+// The same tests in two halves — the compass pairs (0,8) (4,12) first, the diagonal pairs (2,10) (6,14) second — for the wave-uniform
+// early-out of stage B ("fast_early"): {max of the pair minima, min of the pair maxima} of two opposite pairs.
+struct PkHalf { u16x2_t maxmin, minmax; };
+__device__ __forceinline__ PkHalf pk_half(uint32_t pa, uint32_t pa8, uint32_t pb, uint32_t pb8) {
+  const u16x2_t a = as_u16x2(pa), a8 = as_u16x2(pa8), b = as_u16x2(pb), b8 = as_u16x2(pb8);
+  PkHalf h;
+  h.maxmin = __builtin_elementwise_max(__builtin_elementwise_min(a, a8), __builtin_elementwise_min(b, b8));
+  h.minmax = __builtin_elementwise_min(__builtin_elementwise_max(a, a8), __builtin_elementwise_max(b, b8));
+  return h;
+}
+// lanes non-zero where the pixel passes: `hi_form` = pixels in the high byte of each 16-bit lane (odd pixels), else in the low byte
+__device__ __forceinline__ uint32_t pk_verdict(uint32_t c, const PkHalf h, uint32_t t, bool hi_form) {
+  const u16x2_t T = as_u16x2(t);
+  if (hi_form) {
+    const u16x2_t lo = __builtin_elementwise_sub_sat(as_u16x2(c & 0xff00ff00u), T);
+    const u16x2_t hi = __builtin_elementwise_add_sat(as_u16x2(c | 0x00ff00ffu), T);
+    return as_u32(__builtin_elementwise_sub_sat(lo, h.maxmin)) | as_u32(__builtin_elementwise_sub_sat(h.minmax, hi));
+  }
+  const u16x2_t lo = __builtin_elementwise_sub_sat(as_u16x2(c), T);
+  const u16x2_t hi = as_u16x2(c) + T;
+  return as_u32(__builtin_elementwise_sub_sat(lo, h.maxmin)) | as_u32(__builtin_elementwise_sub_sat(h.minmax, hi));
+}
+
 // one cell (logical item L of a launch over cells [cell_base, cell_base + ncells_sub) of every frame); T threads
 template <int T, int PITCH, bool PK>
 __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
@@ -411,6 +434,8 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
   for (int i = t; i < nwords; i += T) bitmap[i] = 0;
   if (t == 0) s_cnt = 0;
   __syncthreads();
+  const int early = (stop_after >> 8) & 1;   // "fast_early": the wave-uniform early-out of stage B (same results)
+  stop_after &= 0xff;
   if (stop_after == 1) {   // timing experiment only ("fast_stop" option): the cell reports no keypoint
     if (t == 0) cell_cnt[(long long)frame * g->ncells_total + cell] = 0;
     return;
@@ -429,6 +454,18 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
       const uint32_t dC = rowp[0], dL = rowp[-1], dR = rowp[1], dU = rowp[-3 * P4], dD = rowp[3 * P4];
       const uint32_t Q4 = __builtin_amdgcn_alignbyte(dR, dC, 3);   // x+3 of pixel j in byte j
       const uint32_t Q12 = __builtin_amdgcn_alignbyte(dC, dL, 1);  // x-3 of pixel j in byte j
+      constexpr uint32_t LO = 0x00ff00ffu;
+      const uint32_t t_hi = (uint32_t)min_th * 0x01000100u, t_lo = (uint32_t)min_th * 0x00010001u;
+      PkHalf hcO, hcE;
+      if (PK && early) {
+        // Wave-uniform early-out: a corner needs BOTH halves of the test, so a trip in which no pixel of the wave passes the compass
+        // pairs alone (flat areas: sky, walls, the stream's flat quarter) skips the six diagonal LDS reads, the diagonal pairs, the
+        // ballots and the append.  No per-lane divergence; the compass halves are reused below.
+        hcO = pk_half(dD, dU, Q4, Q12);
+        hcE = pk_half(dD & LO, dU & LO, Q4 & LO, Q12 & LO);
+        const uint32_t some = pk_verdict(dC, hcO, t_hi, true) | pk_verdict(dC & LO, hcE, t_lo, false);
+        if (__ballot(act && some != 0u) == 0ull) continue;
+      }
       // the two diagonal pairs (2,10) and (6,14): rows +-2, columns +-2
       const uint32_t eC = rowp[2 * P4], eL = rowp[2 * P4 - 1], eR = rowp[2 * P4 + 1];
       const uint32_t fC = rowp[-2 * P4], fL = rowp[-2 * P4 - 1], fR = rowp[-2 * P4 + 1];
@@ -439,10 +476,18 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
       if constexpr (PK) {
         // pixels 1 and 3 sit in the high bytes of the raw dwords' 16-bit lanes (the low bytes are don't-cares there); pixels 0
         // and 2 are the low bytes, isolated by a mask
-        const uint32_t t_hi = (uint32_t)min_th * 0x01000100u, t_lo = (uint32_t)min_th * 0x00010001u;
-        constexpr uint32_t LO = 0x00ff00ffu;
-        uint32_t rO = fast_pretest_pk(dC, dD, dU, Q4, Q12, Q2, Q10, Q6, Q14, t_hi);
-        uint32_t rE = fast_pretest_pk_lo(dC & LO, dD & LO, dU & LO, Q4 & LO, Q12 & LO, Q2 & LO, Q10 & LO, Q6 & LO, Q14 & LO, t_lo);
+        uint32_t rO, rE;
+        if (early) {
+          const PkHalf hdO = pk_half(Q2, Q10, Q6, Q14), hdE = pk_half(Q2 & LO, Q10 & LO, Q6 & LO, Q14 & LO);
+          PkHalf hO, hE;
+          hO.maxmin = __builtin_elementwise_max(hcO.maxmin, hdO.maxmin); hO.minmax = __builtin_elementwise_min(hcO.minmax, hdO.minmax);
+          hE.maxmin = __builtin_elementwise_max(hcE.maxmin, hdE.maxmin); hE.minmax = __builtin_elementwise_min(hcE.minmax, hdE.minmax);
+          rO = pk_verdict(dC, hO, t_hi, true);
+          rE = pk_verdict(dC & LO, hE, t_lo, false);
+        } else {
+          rO = fast_pretest_pk(dC, dD, dU, Q4, Q12, Q2, Q10, Q6, Q14, t_hi);
+          rE = fast_pretest_pk_lo(dC & LO, dD & LO, dU & LO, Q4 & LO, Q12 & LO, Q2 & LO, Q10 & LO, Q6 & LO, Q14 & LO, t_lo);
+        }
         // validity (x inside the detection domain, lane active) on the same lanes: (unsigned)(c0 + j) < dw, c0 >= -3
         const uint32_t c0a = act ? (uint32_t)c0 : 0x4000u;
         const u16x2_t C0 = as_u16x2(__builtin_amdgcn_perm(c0a, c0a, 0x01000100u));

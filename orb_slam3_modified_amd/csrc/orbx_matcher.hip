@@ -126,6 +126,64 @@ __global__ __launch_bounds__(256) void k_nn_csr(const uint8_t* __restrict__ q, i
   }
 }
 
+// Guided matching inside vocabulary nodes (SearchByBoW, SearchForTriangulation): every query of a group (= a node both sides share) is
+// compared with the group's whole candidate list, but the host replays only ever use candidates within a distance bound (TH_LOW, or the
+// bound beyond which the ratio test passes anyway): a wave per query counts its candidates within `max_dist`, reserves that many entries
+// of a pool with one atomic, and writes (train index, distance) in list order.  The O(pairs) arrays of the CSR form (candidate lists
+// repeated per query, every distance shipped back) never exist: the host builds O(queries + features) and reads O(near candidates).
+// pool_ctr: [0] = entries reserved so far (reset by the last workgroup), [1] = workgroup counter of the publication protocol.
+__global__ __launch_bounds__(256) void k_nn_groups(const uint8_t* __restrict__ q, const int32_t* __restrict__ q_group, int nq,
+                                                   const uint8_t* __restrict__ tr, const int32_t* __restrict__ group_ptr,
+                                                   const int32_t* __restrict__ group_cand, int max_dist, int pool_cap,
+                                                   int32_t* __restrict__ q_off, int32_t* __restrict__ q_cnt, int2* __restrict__ pool,
+                                                   unsigned* __restrict__ pool_ctr, unsigned long long* __restrict__ done_host) {
+  const int lane = threadIdx.x & 63;
+  const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  __shared__ int wg_done;
+  if (threadIdx.x == 0) wg_done = 0;
+  __syncthreads();
+  if (qi >= nq) return;
+  const Desc dq = load_desc(q + (size_t)qi * 32);
+  const int g = q_group[qi];
+  const int b = group_ptr[g], e = group_ptr[g + 1];
+  int cnt = 0;
+  for (int c0 = b; c0 < e; c0 += 64) {
+    const int c = c0 + lane;
+    const bool near = c < e && hamming(dq, load_desc(tr + (size_t)group_cand[c] * 32)) <= max_dist;
+    cnt += __popcll(__ballot(near));
+  }
+  int base = 0;
+  if (lane == 0 && cnt > 0) base = (int)atomicAdd(&pool_ctr[0], (unsigned)cnt);
+  base = __builtin_amdgcn_readfirstlane(base);
+  const bool fits = cnt > 0 && base + cnt <= pool_cap;
+  if (lane == 0) { q_off[qi] = base; q_cnt[qi] = cnt; }   // the host sees the total and refuses an overflowing pass as a whole
+  if (fits) {
+    int run = base;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int c0 = b; c0 < e; c0 += 64) {
+      const int c = c0 + lane;
+      int ti = 0, d = 256;
+      if (c < e) { ti = group_cand[c]; d = hamming(dq, load_desc(tr + (size_t)ti * 32)); }
+      const unsigned long long m = __ballot(d <= max_dist);
+      if (d <= max_dist) pool[run + __popcll(m & lt)] = make_int2(ti, d);
+      run += __popcll(m);
+    }
+  }
+  const int nactive = min(4, nq - (int)blockIdx.x * 4);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0 && atomicAdd(&wg_done, 1) == nactive - 1) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __threadfence_system();
+    if (atomicInc(&pool_ctr[1], gridDim.x - 1) == gridDim.x - 1) {
+      __threadfence();
+      const unsigned total = atomicExch(&pool_ctr[0], 0u);   // every workgroup has reserved: the final count, and the counter is zero for the next call
+      __atomic_store_n(done_host, ((unsigned long long)total << 1) | 1ull, __ATOMIC_RELEASE);
+      __threadfence_system();
+    }
+  }
+}
+
 // All-pairs 2-NN, small problems (the SLAM sizes, ~1000 x 1000, are launch-bound): wave per query, the train set is
 // streamed through LDS in tiles shared by the block's 4 queries; one launch.
 __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ tr, int nt,
@@ -543,6 +601,89 @@ int orbx_nn_csr(orbx_ctx* ctx, const uint8_t* q_desc, int nq, const uint8_t* t_d
   if (trace)
     std::fprintf(stderr, "[orbx window] orbx_nn_csr nq=%d nt=%d pairs=%d in=%zu B out=%zu B: pack %.1f us, issue %.1f, wait %.1f, scatter %.1f\n", nq, nt, nnz,
                  in.size, out.size, us_pack, us_issue - us_pack, us_sync - us_issue, since() - us_sync);
+  return ORBX_OK;
+}
+
+int orbx_nn_groups(orbx_ctx* ctx, const uint8_t* q_desc, const int32_t* q_group, int nq, const uint8_t* t_desc, int nt, const int32_t* group_ptr,
+                   const int32_t* group_cand, int ngroups, int max_dist, int32_t* q_off, int32_t* q_cnt, orbx_candidate* entries, int pool_cap,
+                   int* n_entries) {
+  if (n_entries) *n_entries = 0;
+  if (!ctx || nq < 0 || nt < 0 || ngroups < 0 || pool_cap < 0 || !n_entries || (nq > 0 && (!q_desc || !q_group || !group_ptr || !q_off || !q_cnt)) ||
+      (pool_cap > 0 && !entries))
+    return ORBX_E_INVALID;
+  if (nq == 0) return ORBX_OK;
+  if (ngroups == 0 || group_ptr[0] != 0) return set_err(ctx, ORBX_E_INVALID, "orbx_nn_groups: bad group lists");
+  for (int g = 0; g < ngroups; g++)
+    if (group_ptr[g + 1] < group_ptr[g]) return set_err(ctx, ORBX_E_INVALID, "orbx_nn_groups: group_ptr not ascending");
+  const int ncand = group_ptr[ngroups];
+  if (ncand > 0 && (!group_cand || !t_desc)) return set_err(ctx, ORBX_E_INVALID, "orbx_nn_groups: bad candidate lists");
+  for (int i = 0; i < ncand; i++)
+    if (group_cand[i] < 0 || group_cand[i] >= nt) return set_err(ctx, ORBX_E_INVALID, "orbx_nn_groups: candidate index out of range");
+  for (int i = 0; i < nq; i++)
+    if (q_group[i] < 0 || q_group[i] >= ngroups) return set_err(ctx, ORBX_E_INVALID, "orbx_nn_groups: query group out of range");
+  ORBX_HIP(ctx, hipSetDevice(ctx->device));
+  BlobLayout in, out;
+  const size_t o_q = in.add((size_t)nq * 32), o_g = in.add(4 * (size_t)nq), o_t = in.add((size_t)nt * 32), o_gp = in.add(4 * (size_t)(ngroups + 1)),
+               o_gc = in.add(4 * (size_t)std::max(ncand, 1));
+  const size_t p_off = out.add(4 * (size_t)nq), p_cnt = out.add(4 * (size_t)nq), p_pool = out.add(8 * (size_t)std::max(pool_cap, 1)), p_done = out.add(16);
+  uint8_t* h = nullptr;
+  ORBX_HIP(ctx, host_stage(ctx, in.size + out.size, &h));
+  uint8_t* hout = h + in.size;
+  std::memcpy(h + o_q, q_desc, (size_t)nq * 32);
+  std::memcpy(h + o_g, q_group, 4 * (size_t)nq);
+  if (nt) std::memcpy(h + o_t, t_desc, (size_t)nt * 32);
+  std::memcpy(h + o_gp, group_ptr, 4 * (size_t)(ngroups + 1));
+  if (ncand) std::memcpy(h + o_gc, group_cand, 4 * (size_t)ncand);
+  ctx->arena.rewind();
+  hipError_t aerr = hipSuccess;
+  uint8_t* din = (uint8_t*)ctx->arena.alloc(in.size, &aerr);
+  ORBX_HIP(ctx, aerr);
+  uint8_t* dout = (uint8_t*)ctx->arena.alloc(out.size, &aerr);
+  ORBX_HIP(ctx, aerr);
+  hipStream_t st = ctx->stream;
+  if (!ctx->d_win_ctr) { ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_win_ctr, 64)); ctx->win_ctr_dirty = true; }
+  if (ctx->win_ctr_dirty) { ORBX_HIP(ctx, hipMemsetAsync(ctx->d_win_ctr, 0, 64, st)); ctx->win_ctr_dirty = false; }
+  uint8_t* hdev = nullptr;
+  const bool direct = ctx->window_direct && hipHostGetDevicePointer((void**)&hdev, h, 0) == hipSuccess && hdev != nullptr;
+  if (!direct) (void)hipGetLastError();
+  volatile unsigned long long* done = (volatile unsigned long long*)(hout + p_done);
+  __atomic_store_n(done, 0ull, __ATOMIC_RELEASE);
+  ctx->win_ctr_dirty = true;
+  const int n16 = (int)((in.size + 15) / 16);
+  uint8_t* res = direct ? hdev + in.size : dout;   // where the kernel writes: the mapped blob itself, or HBM + one copy back
+  if (direct) hipLaunchKernelGGL(k_nn_stage_in, dim3(std::min((n16 + 255) / 256, 512)), dim3(256), 0, st, (const uint4*)hdev, (uint4*)din, n16);
+  else ORBX_HIP(ctx, hipMemcpyAsync(din, h, in.size, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_nn_groups, dim3((nq + 3) / 4), dim3(256), 0, st, din + o_q, (const int32_t*)(din + o_g), nq, din + o_t, (const int32_t*)(din + o_gp),
+                     (const int32_t*)(din + o_gc), max_dist, pool_cap, (int32_t*)(res + p_off), (int32_t*)(res + p_cnt), (int2*)(res + p_pool),
+                     (unsigned*)ctx->d_win_ctr + 10, (unsigned long long*)(res + p_done));
+  ORBX_HIP(ctx, hipGetLastError());
+  if (direct) {
+    for (unsigned spin = 1;; spin++) {
+      if (__atomic_load_n(done, __ATOMIC_ACQUIRE)) break;
+      if ((spin & 0x3fff) == 0) {
+        const hipError_t qe = hipStreamQuery(st);
+        if (qe == hipSuccess) {
+          if (__atomic_load_n(done, __ATOMIC_ACQUIRE)) break;
+          return set_err(ctx, ORBX_E_DEVICE, "orbx_nn_groups: the pass finished without publishing its results");
+        }
+        if (qe != hipErrorNotReady) { ORBX_HIP(ctx, qe); }
+      }
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+  } else {
+    ORBX_HIP(ctx, hipMemcpyAsync(hout, dout, out.size, hipMemcpyDeviceToHost, st));
+    ORBX_HIP(ctx, hipStreamSynchronize(st));
+  }
+  ctx->win_ctr_dirty = false;
+  const unsigned long long dw = *done;
+  const int total = (int)(dw >> 1);
+  *n_entries = total;
+  if (total > pool_cap) return set_err(ctx, ORBX_E_CAPACITY, "orbx_nn_groups: more near candidates than the pool holds");
+  std::memcpy(q_off, hout + p_off, 4 * (size_t)nq);
+  std::memcpy(q_cnt, hout + p_cnt, 4 * (size_t)nq);
+  if (total) std::memcpy(entries, hout + p_pool, 8 * (size_t)total);
   return ORBX_OK;
 }
 

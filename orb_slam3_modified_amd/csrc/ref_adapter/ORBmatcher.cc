@@ -6,7 +6,7 @@
 //      query arrays (centre, radius, level range, descriptor);
 //   2. ONE device pass per camera (include/orbx.h): the grid window of every query (Frame / KeyFrame::GetFeaturesInArea), the
 //      Hamming distance of every candidate and — for the routines whose queries are independent (Fuse x2, SearchBySim3,
-//      SURVEY.md §3.3) — the arg-min itself; vocabulary-node routines send their CSR candidate lists to orbx_nn_csr;
+//      SURVEY.md §3.3) — the arg-min itself; vocabulary-node routines send their node groups to orbx_nn_groups (near candidates only);
 //   3. a host replay in the reference's query order of whatever depends on earlier queries (occupancy of keypoints, stolen
 //      matches, map mutation) and the rotation-consistency filter, written with the reference's own comparison operators
 //      (each routine has its own accept test: `<= TH_HIGH`, `<= TH_LOW`, `< TH_LOW`, `<= TH_LOW*ratioHamming`, ...).
@@ -381,6 +381,49 @@ void common_nodes(const DBoW2::FeatureVector& a, const DBoW2::FeatureVector& b, 
   }
 }
 
+// The node-by-node searches (SearchByBoW x 2, SearchForTriangulation) compare every feature of a vocabulary node on one side with every
+// feature of the same node on the other; their replays only ever USE candidates within a distance bound.  orbx_nn_groups takes the groups
+// as they are (no per-query repetition of the candidate lists) and returns, per query, the candidates within the bound in list order.
+struct NodeGroups {
+  std::vector<int32_t> q_group, group_ptr, group_cand;   // group_ptr starts with 0
+  std::vector<unsigned char> qd;
+  NodeGroups() { group_ptr.push_back(0); }
+  int open_group() const { return (int)group_ptr.size() - 1; }           // the group whose candidates are being appended
+  void close_group() { group_ptr.push_back((int32_t)group_cand.size()); }
+  void add_query(const unsigned char* d) { q_group.push_back(open_group()); qd.insert(qd.end(), d, d + 32); }
+  int nq() const { return (int)q_group.size(); }
+};
+struct NearLists {
+  std::vector<int32_t> off, cnt;
+  std::vector<orbx_candidate> ent;
+  int begin(int q) const { return off[q]; }
+  int end(int q) const { return off[q] + cnt[q]; }
+};
+// the distance beyond which `(float)best < ratio * (float)second` holds for every best <= th: a second-best candidate further away than
+// this cannot fail the ratio test, so the replay may treat it as absent (second = 256, as when the list has no second entry)
+int ratio_bound(float ratio, int th) {
+  int t = th;
+  while (t < 255 && !(static_cast<float>(th) < ratio * static_cast<float>(t + 1))) t++;
+  return t;
+}
+void near_lists(const char* routine, const NodeGroups& G, const cv::Mat& trainDescriptors, int max_dist, NearLists& out) {
+  const int nq = G.nq();
+  out.off.assign(nq + 1, 0); out.cnt.assign(nq + 1, 0); out.ent.clear();
+  if (nq == 0) return;
+  DescView D(trainDescriptors);
+  orbx_ctx* ctx = ORBmatcher::DefaultContext();
+  int cap = 8 * nq + 4096;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    out.ent.resize(cap);
+    int n = 0;
+    const int rc = orbx_nn_groups(ctx, G.qd.data(), G.q_group.data(), nq, D.p, trainDescriptors.rows, G.group_ptr.data(), G.group_cand.data(),
+                                  G.open_group(), max_dist, out.off.data(), out.cnt.data(), out.ent.data(), cap, &n);
+    if (rc == ORBX_OK) { out.ent.resize(n); return; }
+    if (rc != ORBX_E_CAPACITY || attempt == 1) fail(routine, ctx);
+    cap = n + 64;   // the pass reported how many entries it needs
+  }
+}
+
 // rotation-consistency histogram (e.g. :345-352): bin = round(rot / 30) over rot in [0, 360)
 struct RotHist {
   std::vector<int>* bins;   // [30], per-thread storage reused from call to call (the reference reserves 30 x 500 ints per call)
@@ -566,33 +609,31 @@ int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPoi
   const vector<MapPoint*> vpMapPointsKF = pKF->GetMapPointMatches();
   vpMapPointMatches = vector<MapPoint*>(F.N, static_cast<MapPoint*>(NULL));
   int nmatches = 0;
-  // phase 1: keyframe features with a good map point, node by node; candidates = the frame's features of the node
+  // phase 1: keyframe features with a good map point, node by node; candidates = the frame's features of the node (one list per node)
   std::vector<unsigned int> qKF;
-  std::vector<int32_t> rowPtr(1, 0), cand;
-  std::vector<unsigned char> qd;
+  NodeGroups G;
   common_nodes(pKF->mFeatVec, F.mFeatVec, [&](const vector<unsigned int>& vIndicesKF, const vector<unsigned int>& vIndicesF) {
+    bool any = false;
     for (size_t iKF = 0; iKF < vIndicesKF.size(); iKF++) {
       const unsigned int realIdxKF = vIndicesKF[iKF];
       MapPoint* pMP = vpMapPointsKF[realIdxKF];
       if (!pMP) continue;
       if (pMP->isBad()) continue;
       qKF.push_back(realIdxKF);
-      const unsigned char* d = pKF->mDescriptors.ptr<unsigned char>((int)realIdxKF);
-      qd.insert(qd.end(), d, d + 32);
-      for (size_t iF = 0; iF < vIndicesF.size(); iF++) cand.push_back((int32_t)vIndicesF[iF]);
-      rowPtr.push_back((int32_t)cand.size());
+      G.add_query(pKF->mDescriptors.ptr<unsigned char>((int)realIdxKF));
+      any = true;
+    }
+    if (any) {
+      for (size_t iF = 0; iF < vIndicesF.size(); iF++) G.group_cand.push_back((int32_t)vIndicesF[iF]);
+      G.close_group();
     }
   });
   const int nq = (int)qKF.size();
   if (nq == 0) return 0;
-  // phase 2
-  std::vector<int32_t> dist(cand.size() + 1);
-  if (!cand.empty()) {
-    DescView D(F.mDescriptors);
-    orbx_ctx* ctx = DefaultContext();
-    if (orbx_nn_csr(ctx, qd.data(), nq, D.p, F.mDescriptors.rows, rowPtr.data(), cand.data(), 0, nullptr, nullptr, nullptr, nullptr, dist.data()) != ORBX_OK)
-      fail("SearchByBoW", ctx);
-  }
+  // phase 2: per query the frame features of its node within the distance the replay can tell apart — a match needs best <= TH_LOW, and a
+  // second-best beyond ratio_bound passes the ratio test whatever its value
+  NearLists NL;
+  near_lists("SearchByBoW", G, F.mDescriptors, ratio_bound(mfNNratio, TH_LOW), NL);
   // phase 3 (:264-391): a frame feature taken by an earlier keyframe feature is no candidate
   RotHist rot;
   auto kfKey = [&](unsigned int i) -> const cv::KeyPoint& {
@@ -603,10 +644,10 @@ int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPoi
     MapPoint* pMP = vpMapPointsKF[realIdxKF];
     int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
     int bestDist1R = 256, bestIdxFR = -1, bestDist2R = 256;
-    for (int c = rowPtr[q]; c < rowPtr[q + 1]; c++) {
-      const unsigned int realIdxF = cand[c];
+    for (int c = NL.begin(q); c < NL.end(q); c++) {
+      const unsigned int realIdxF = NL.ent[c].idx;
       if (vpMapPointMatches[realIdxF]) continue;
-      const int d = dist[c];
+      const int d = NL.ent[c].dist;
       if (F.Nleft == -1) {
         if (d < bestDist1) { bestDist2 = bestDist1; bestDist1 = d; bestIdxF = realIdxF; }
         else if (d < bestDist2) { bestDist2 = d; }
@@ -804,9 +845,9 @@ int ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& v
   int nmatches = 0;
   // phase 1 (:797-833): features with a good map point on both sides (right-camera features of a rig are skipped)
   std::vector<size_t> q1;
-  std::vector<int32_t> rowPtr(1, 0), cand;
-  std::vector<unsigned char> qd;
+  NodeGroups G;
   common_nodes(pKF1->mFeatVec, pKF2->mFeatVec, [&](const vector<unsigned int>& v1, const vector<unsigned int>& v2) {
+    bool any = false;
     for (size_t i1 = 0, iend1 = v1.size(); i1 < iend1; i1++) {
       const size_t idx1 = v1[i1];
       if (pKF1->NLeft != -1 && idx1 >= pKF1->mvKeysUn.size()) continue;
@@ -814,38 +855,34 @@ int ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& v
       if (!pMP1) continue;
       if (pMP1->isBad()) continue;
       q1.push_back(idx1);
-      const unsigned char* d = pKF1->mDescriptors.ptr<unsigned char>((int)idx1);
-      qd.insert(qd.end(), d, d + 32);
-      for (size_t i2 = 0, iend2 = v2.size(); i2 < iend2; i2++) {
-        const size_t idx2 = v2[i2];
-        if (pKF2->NLeft != -1 && idx2 >= pKF2->mvKeysUn.size()) continue;
-        MapPoint* pMP2 = vpMapPoints2[idx2];
-        if (!pMP2) continue;
-        if (pMP2->isBad()) continue;
-        cand.push_back((int32_t)idx2);
-      }
-      rowPtr.push_back((int32_t)cand.size());
+      G.add_query(pKF1->mDescriptors.ptr<unsigned char>((int)idx1));
+      any = true;
     }
+    if (!any) return;
+    for (size_t i2 = 0, iend2 = v2.size(); i2 < iend2; i2++) {   // the candidate filter does not depend on the query
+      const size_t idx2 = v2[i2];
+      if (pKF2->NLeft != -1 && idx2 >= pKF2->mvKeysUn.size()) continue;
+      MapPoint* pMP2 = vpMapPoints2[idx2];
+      if (!pMP2) continue;
+      if (pMP2->isBad()) continue;
+      G.group_cand.push_back((int32_t)idx2);
+    }
+    G.close_group();
   });
   const int nq = (int)q1.size();
   if (nq == 0) return 0;
   // phase 2
-  std::vector<int32_t> dist(cand.size() + 1);
-  if (!cand.empty()) {
-    DescView D2(pKF2->mDescriptors);
-    orbx_ctx* ctx = DefaultContext();
-    if (orbx_nn_csr(ctx, qd.data(), nq, D2.p, pKF2->mDescriptors.rows, rowPtr.data(), cand.data(), 0, nullptr, nullptr, nullptr, nullptr, dist.data()) != ORBX_OK)
-      fail("SearchByBoW", ctx);
-  }
+  NearLists NL;
+  near_lists("SearchByBoW", G, pKF2->mDescriptors, ratio_bound(mfNNratio, TH_LOW), NL);
   // phase 3 (:821-867): strict `< TH_LOW` here
   RotHist rot;
   for (int q = 0; q < nq; q++) {
     const size_t idx1 = q1[q];
     int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
-    for (int c = rowPtr[q]; c < rowPtr[q + 1]; c++) {
-      const size_t idx2 = cand[c];
+    for (int c = NL.begin(q); c < NL.end(q); c++) {
+      const size_t idx2 = NL.ent[c].idx;
       if (vbMatched2[idx2]) continue;
-      const int d = dist[c];
+      const int d = NL.ent[c].dist;
       if (d < bestDist1) { bestDist2 = bestDist1; bestDist1 = d; bestIdx2 = idx2; }
       else if (d < bestDist2) { bestDist2 = d; }
     }
@@ -908,9 +945,9 @@ int ORBmatcher::SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, vector<pa
     return (pKF2->NLeft == -1) ? pKF2->mvKeysUn[i] : (i < (size_t)pKF2->NLeft) ? pKF2->mvKeys[i] : pKF2->mvKeysRight[i - pKF2->NLeft];
   };
   std::vector<size_t> q1;
-  std::vector<int32_t> rowPtr(1, 0), cand;
-  std::vector<unsigned char> qd;
+  NodeGroups G;
   common_nodes(pKF1->mFeatVec, pKF2->mFeatVec, [&](const vector<unsigned int>& v1, const vector<unsigned int>& v2) {
+    bool any = false;
     for (size_t i1 = 0, iend1 = v1.size(); i1 < iend1; i1++) {
       const size_t idx1 = v1[i1];
       if (pKF1->GetMapPoint(idx1)) continue;
@@ -918,28 +955,24 @@ int ORBmatcher::SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, vector<pa
       if (bOnlyStereo)
         if (!bStereo1) continue;
       q1.push_back(idx1);
-      const unsigned char* d = pKF1->mDescriptors.ptr<unsigned char>((int)idx1);
-      qd.insert(qd.end(), d, d + 32);
-      for (size_t i2 = 0, iend2 = v2.size(); i2 < iend2; i2++) {
-        const size_t idx2 = v2[i2];
-        if (pKF2->GetMapPoint(idx2)) continue;   // (vbMatched2 is never set in this routine)
-        const bool bStereo2 = (!pKF2->mpCamera2 && pKF2->mvuRight[idx2] >= 0);
-        if (bOnlyStereo)
-          if (!bStereo2) continue;
-        cand.push_back((int32_t)idx2);
-      }
-      rowPtr.push_back((int32_t)cand.size());
+      G.add_query(pKF1->mDescriptors.ptr<unsigned char>((int)idx1));
+      any = true;
     }
+    if (!any) return;
+    for (size_t i2 = 0, iend2 = v2.size(); i2 < iend2; i2++) {   // the candidate filter does not depend on the query
+      const size_t idx2 = v2[i2];
+      if (pKF2->GetMapPoint(idx2)) continue;   // (vbMatched2 is never set in this routine)
+      const bool bStereo2 = (!pKF2->mpCamera2 && pKF2->mvuRight[idx2] >= 0);
+      if (bOnlyStereo)
+        if (!bStereo2) continue;
+      G.group_cand.push_back((int32_t)idx2);
+    }
+    G.close_group();
   });
   const int nq = (int)q1.size();
-  // phase 2
-  std::vector<int32_t> dist(cand.size() + 1);
-  if (nq && !cand.empty()) {
-    DescView D2(pKF2->mDescriptors);
-    orbx_ctx* ctx = DefaultContext();
-    if (orbx_nn_csr(ctx, qd.data(), nq, D2.p, pKF2->mDescriptors.rows, rowPtr.data(), cand.data(), 1, nullptr, nullptr, nullptr, nullptr, dist.data()) != ORBX_OK)
-      fail("SearchForTriangulation", ctx);
-  }
+  // phase 2: the replay skips every candidate beyond TH_LOW (:1013)
+  NearLists NL;
+  near_lists("SearchForTriangulation", G, pKF2->mDescriptors, TH_LOW, NL);
   // phase 3 (:1010-1100): among the candidates that pass the distance tests, the LAST one that also passes the epipole and
   // epipolar tests wins (`dist>bestDist -> continue`, then `<=` replaces)
   int nmatches = 0;
@@ -952,9 +985,9 @@ int ORBmatcher::SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, vector<pa
     const bool bRight1 = (pKF1->NLeft == -1 || idx1 < (size_t)pKF1->NLeft) ? false : true;
     int bestDist = TH_LOW;
     int bestIdx2 = -1;
-    for (int c = rowPtr[q]; c < rowPtr[q + 1]; c++) {
-      const size_t idx2 = cand[c];
-      const int d = dist[c];
+    for (int c = NL.begin(q); c < NL.end(q); c++) {
+      const size_t idx2 = NL.ent[c].idx;
+      const int d = NL.ent[c].dist;
       if (d > TH_LOW || d > bestDist) continue;
       const bool bStereo2 = (!pKF2->mpCamera2 && pKF2->mvuRight[idx2] >= 0);
       const cv::KeyPoint& kp2 = key2(idx2);

@@ -47,6 +47,22 @@ class ORBmatcher:
         out = (bi[:nq], bd[:nq], si[:nq], sd[:nq])
         return out + (do[:len(cd)],) if want_dist else out
 
+    def nn_groups(self, q_desc, q_group, t_desc, group_ptr, group_cand, max_dist: int, pool_cap: int):
+        """orbx_nn_groups: every query against its group's whole candidate list, only candidates within max_dist reported.
+        Returns (q_off, q_cnt, entries[(idx, dist)]); raises OrbxError(ORBX_E_CAPACITY) when pool_cap entries do not suffice."""
+        q = np.ascontiguousarray(q_desc, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t_desc, np.uint8).reshape(-1, 32)
+        qg = np.ascontiguousarray(q_group, np.int32)
+        gp = np.ascontiguousarray(group_ptr, np.int32)
+        gc = np.ascontiguousarray(group_cand, np.int32)
+        nq = len(q)
+        off, cnt = np.zeros(max(nq, 1), np.int32), np.zeros(max(nq, 1), np.int32)
+        ent = np.zeros((max(pool_cap, 1), 2), np.int32)
+        n = C.c_int(0)
+        check(self._L.orbx_nn_groups(self._ctx, ptr(q), ptr(qg), nq, ptr(t), len(t), ptr(gp), ptr(gc), len(gp) - 1, int(max_dist), ptr(off), ptr(cnt),
+                                     ptr(ent), int(pool_cap), C.byref(n)), self._ctx)
+        return off[:nq], cnt[:nq], ent[:n.value]
+
     def knn2(self, q_desc, t_desc):
         """cv::BFMatcher(NORM_HAMMING).knnMatch(k=2) (src/Frame.cc:43,1144) -> (idx[nq,2], dist[nq,2])."""
         q = np.ascontiguousarray(q_desc, np.uint8).reshape(-1, 32)

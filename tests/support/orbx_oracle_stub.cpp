@@ -72,6 +72,22 @@ int orbx_set_host_pyramid(orbx_ctx*, int) { return ORBX_OK; }
 // oracle's primitives under the oracle's current switches, i.e. what this stub computes with anyway
 int orbx_set_option(orbx_ctx*, const char*, int) { return ORBX_OK; }
 int orbx_bow_transform_published(orbx_voc*, const void*, int, int, uint32_t*, double*, uint32_t*) { return 1; }   // nothing is ever precomputed here
+// orbx_nn_groups by plain loops over the oracle's Hamming distance: per query the candidates of its group within max_dist, in list order
+int orbx_nn_groups(orbx_ctx*, const uint8_t* q_desc, const int32_t* q_group, int nq, const uint8_t* t_desc, int, const int32_t* group_ptr,
+                   const int32_t* group_cand, int, int max_dist, int32_t* q_off, int32_t* q_cnt, orbx_candidate* entries, int pool_cap, int* n_entries) {
+  int n = 0;
+  for (int q = 0; q < nq; q++) {
+    q_off[q] = n; q_cnt[q] = 0;
+    for (int c = group_ptr[q_group[q]]; c < group_ptr[q_group[q] + 1]; c++) {
+      const int d = mo_hamming(q_desc + (size_t)q * 32, t_desc + (size_t)group_cand[c] * 32);
+      if (d > max_dist) continue;
+      if (n < pool_cap) { entries[n].idx = group_cand[c]; entries[n].dist = d; }
+      n++; q_cnt[q]++;
+    }
+  }
+  *n_entries = n;
+  return n > pool_cap ? ORBX_E_CAPACITY : ORBX_OK;
+}
 int orbx_publish_descriptors(orbx_ctx*, const void*, int) { return ORBX_OK; }
 // the host mirror of mvImagePyramid (levels >= 1) that include/ORBextractor.h hands to Frame::ComputeStereoMatches: the oracle's levels
 int orbx_host_pyramid_level(orbx_ctx* c, int level, const uint8_t** data, size_t* stride, int* w, int* h) {

@@ -53,6 +53,43 @@ def test_nn_csr_first_and_last_wins(feats):
     assert (g[0][::7] == -1).all() and (g[1][::7] == 256).all()
 
 
+def test_nn_groups_near_candidates_in_list_order(feats):
+    """orbx_nn_groups (the node-by-node searches): per query the candidates of its group within max_dist, in list order, against a plain
+    numpy statement; empty groups, groups longer than a wave, a pool that is too small (ORBX_E_CAPACITY with the needed size)."""
+    from orb_slam3_modified_amd import OrbxError
+    gpu, out = feats
+    q, t = out[0][2], out[1][2]
+    rng = np.random.default_rng(4)
+    m = ORBmatcher(gpu)
+    sizes = [0, 1, 63, 64, 65, 200, 300, 5]
+    group_ptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    group_cand = rng.integers(0, len(t), group_ptr[-1]).astype(np.int32)
+    q_group = rng.integers(0, len(sizes), len(q)).astype(np.int32)
+    pop = np.array([bin(i).count("1") for i in range(256)], np.int32)
+    for max_dist in (30, 50, 72, 110, 256):
+        want_off, want_cnt, want = [], [], []
+        for i in range(len(q)):
+            c = group_cand[group_ptr[q_group[i]]:group_ptr[q_group[i] + 1]]
+            d = pop[np.bitwise_xor(q[i][None, :], t[c])].sum(1) if len(c) else np.zeros(0, np.int32)
+            keep = d <= max_dist
+            want_off.append(len(want)); want_cnt.append(int(keep.sum()))
+            want += list(zip(c[keep].tolist(), d[keep].tolist()))
+        try:
+            off, cnt, ent = m.nn_groups(q, q_group, t, group_ptr, group_cand, max_dist, len(want) + 3)
+        except OrbxError:
+            raise
+        assert cnt.tolist() == want_cnt
+        for i in range(len(q)):   # the pool is filled in whatever order the waves reserve it: compare per query
+            assert [tuple(e) for e in ent[off[i]:off[i] + cnt[i]].tolist()] == want[want_off[i]:want_off[i] + want_cnt[i]], (max_dist, i)
+        if len(want) > 10:
+            with pytest.raises(OrbxError) as ei:
+                m.nn_groups(q, q_group, t, group_ptr, group_cand, max_dist, len(want) - 5)
+            assert ei.value.code == -4 or "pool" in str(ei.value)
+            # and the next call works again (the pass's counters reset themselves)
+            off2, cnt2, _ = m.nn_groups(q, q_group, t, group_ptr, group_cand, max_dist, len(want))
+            assert cnt2.tolist() == want_cnt
+
+
 def test_knn2_allpairs(feats):
     gpu, out = feats
     m = ORBmatcher(gpu)
@@ -128,7 +165,7 @@ def test_bow_descent_inside_the_extraction_graph(tmp_path):
     assert served == 4
     # the caller's buffer no longer holds the published bytes
     d = extract(2)
-    d[5, 3] ^= 0xff
+    d[5, 8 + 3] ^= 0xff     # (the digest reads 8 bytes of every row: bytes 8..15 of row 5)
     assert gv.descend_published(d, 4) is None
     # another levelsup: not what the graph computed (and the context is re-attached with the new value)
     d = extract(3)
