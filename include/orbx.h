@@ -312,7 +312,8 @@ int orbx_target_search(orbx_ctx* ctx, const orbx_target* target, const uint8_t* 
                        int32_t* second_dist);
 /* orbx_target_search without the copy-out: the candidate lists are read where the kernel wrote them — the call's pinned, mapped blob.
  * Query q's candidates are pool[spans[q].start .. spans[q].start + spans[q].count), in GetFeaturesInArea's order, each with its
- * Hamming distance.  Both pointers stay valid until the NEXT call on this context.  Returns the total number of candidates. */
+ * Hamming distance.  Both pointers stay valid until the SECOND next view call on this context and across its other calls (two blobs are
+ * used alternately: a two-camera rig views the left and the right frame back to back).  Returns the total number of candidates. */
 /* One record per query of a list view.  start / count: the query's segment of the candidate pool, in the reference's list order.
  * best_* / second_*: the two smallest (distance, list position) among that segment — what a loop over the segment with
  * `if (d < best) { second = best; best = d; } else if (d < second) second = d;` ends with — idx = -1 / dist = 256 when there is none.

@@ -942,6 +942,7 @@ void orbx_destroy(orbx_ctx* ctx) {
   if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
   if (ctx->h_in) { (void)hipHostFree(ctx->h_in); ctx->h_in = nullptr; }
   if (ctx->h_call) { (void)hipHostFree(ctx->h_call); ctx->h_call = nullptr; }
+  for (int i = 0; i < 2; i++) if (ctx->h_view[i]) { (void)hipHostFree(ctx->h_view[i]); ctx->h_view[i] = nullptr; }
   unpublish_context(ctx);
   if (ctx->ev_handover) { (void)hipEventDestroy(ctx->ev_handover); ctx->ev_handover = nullptr; }
   if (ctx->d_win_ctr) { (void)hipFree(ctx->d_win_ctr); ctx->d_win_ctr = nullptr; }

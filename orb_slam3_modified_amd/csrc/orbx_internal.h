@@ -205,6 +205,7 @@ struct orbx_ctx {
   uint8_t* h_tgt = nullptr; size_t h_tgt_bytes = 0; hipEvent_t ev_tgt = nullptr;   // pinned staging of orbx_target uploads + "staging free again"
   std::vector<int32_t> view_row_ptr; int view_pool_cap = 16384;   // orbx_target_search_view: scratch and the candidate-pool capacity learnt from earlier calls
   int32_t* d_win_ctr = nullptr; bool win_ctr_dirty = true;   // the two self-resetting counters of resident-target window passes
+  uint8_t* h_view[2] = {nullptr, nullptr}; size_t h_view_bytes[2] = {0, 0}; int view_par = 0;   // the blobs of view calls, used alternately
   uint8_t* h_call = nullptr; size_t h_call_bytes = 0;   // pinned [inputs | outputs] blob of the window / nn entry points (orbx_window.hip)
   int win_guess = 0;            // candidates of the last window call: how much of the pool the first read-back copy takes
   // single-frame operator() path as a replayed hipGraph (H2D, the 13 launches, D2H): one graph launch per frame instead

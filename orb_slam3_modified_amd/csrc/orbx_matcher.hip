@@ -162,10 +162,11 @@ __global__ __launch_bounds__(256) void k_nn_groups(const uint8_t* __restrict__ q
     const unsigned long long lt = (1ull << lane) - 1ull;
     for (int c0 = b; c0 < e; c0 += 64) {
       const int c = c0 + lane;
-      int ti = 0, d = 256;
+      int ti = 0, d = 0;
       if (c < e) { ti = group_cand[c]; d = hamming(dq, load_desc(tr + (size_t)ti * 32)); }
-      const unsigned long long m = __ballot(d <= max_dist);
-      if (d <= max_dist) pool[run + __popcll(m & lt)] = make_int2(ti, d);
+      const bool near = c < e && d <= max_dist;
+      const unsigned long long m = __ballot(near);
+      if (near) pool[run + __popcll(m & lt)] = make_int2(ti, d);
       run += __popcll(m);
     }
   }

@@ -393,6 +393,26 @@ hipError_t host_stage(orbx_ctx* ctx, size_t bytes, uint8_t** p) {
   return hipSuccess;
 }
 
+// The blob of a VIEW call (orbx_target_search_view: the caller reads the lists in place): two of them, used alternately, so that a view stays
+// valid while the NEXT view call of the context runs — a two-camera rig searches the left and the right frame back to back and replays
+// both lists together.
+static hipError_t host_stage_view(orbx_ctx* ctx, size_t bytes, uint8_t** p) {
+  const int i = ctx->view_par ^= 1;
+  if (bytes > ctx->h_view_bytes[i]) {
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return e;
+    if (ctx->h_view[i]) (void)hipHostFree(ctx->h_view[i]);
+    ctx->h_view[i] = nullptr; ctx->h_view_bytes[i] = 0;
+    const size_t want = std::max<size_t>(bytes + bytes / 2, 1 << 20);
+    e = hipHostMalloc((void**)&ctx->h_view[i], want, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipHostMalloc((void**)&ctx->h_view[i], want, hipHostMallocDefault); }
+    if (e != hipSuccess) return e;
+    ctx->h_view_bytes[i] = want;
+  }
+  *p = ctx->h_view[i];
+  return hipSuccess;
+}
+
 typedef BlobLayout Layout;
 
 static void pack_queries(uint8_t* dst, const float* qx, const float* qy, const float* qr, const float* qaux, const int32_t* qlo, const int32_t* qhi,
@@ -752,7 +772,8 @@ int window_call_target(orbx_ctx* ctx, const char* who, const orbx_target* T, con
   const size_t qrec = compact ? sizeof(WinQueryShort) : sizeof(WinQueryOut);
   const size_t p_hdr = out.add(16), p_q = out.add(qrec * (size_t)nq), p_pool = out.add(8 * (size_t)pool_cap);
   uint8_t* h = nullptr;
-  ORBX_HIP(ctx, host_stage(ctx, in.size + out.size, &h));
+  if (v_spans) { ORBX_HIP(ctx, host_stage_view(ctx, in.size + out.size, &h)); }
+  else { ORBX_HIP(ctx, host_stage(ctx, in.size + out.size, &h)); }
   uint8_t* hin = h;
   uint8_t* hout = h + in.size;
   pack_queries(hin + o_q, qx, qy, qr, qaux, qlo, qhi, q_desc, nq);

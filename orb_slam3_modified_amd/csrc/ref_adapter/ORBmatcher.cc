@@ -528,8 +528,8 @@ int ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoint
   orbx_target* TL = QL.size() ? frame_target("SearchByProjection", F, false) : nullptr;
   orbx_target* TR = QR.size() ? frame_target("SearchByProjection", F, true) : nullptr;
   tr.mark("target");
-  if (TL) window_lists("SearchByProjection", TL, QL, LL, /*view_ok=*/!TR);   // a rig keeps two lists alive: copies
-  if (TR) window_lists("SearchByProjection", TR, QR, LR);
+  if (TL) window_lists("SearchByProjection", TL, QL, LL, /*view_ok=*/true);   // a rig keeps two lists alive: the two view blobs alternate
+  if (TR) window_lists("SearchByProjection", TR, QR, LR, /*view_ok=*/true);
   tr.mark("device");
   // phase 3 (:76-140, :151-207): a keypoint bound to an observed map point — before the call or by an earlier map point of
   // this call — is no candidate
@@ -582,10 +582,24 @@ int ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoint
       const int q = qRight[iMP];
       if (LR.begin(q) == LR.end(q)) continue;
       int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+      auto eligibleR = [&](size_t idx) {
+        if (F.mvpMapPoints[idx + F.Nleft])
+          if (F.mvpMapPoints[idx + F.Nleft]->Observations() > 0) return false;
+        return true;
+      };
+      bool haveR = false;
+      if (LR.has_best()) {   // as on the left: the two smallest of the whole list, when both pass the gate
+        const orbx_list_span& sp = LR.span(q);
+        if (sp.best_idx >= 0 && eligibleR((size_t)sp.best_idx) && (sp.count == 1 || (sp.second_idx >= 0 && eligibleR((size_t)sp.second_idx)))) {
+          bestDist = sp.best_dist; bestIdx = sp.best_idx; bestLevel = F.mvKeysRight[sp.best_idx].octave;
+          if (sp.count > 1) { bestDist2 = sp.second_dist; bestLevel2 = F.mvKeysRight[sp.second_idx].octave; }
+          haveR = true;
+        }
+      }
+      if (!haveR)
       for (int c = LR.begin(q); c < LR.end(q); c++) {
         const size_t idx = LR.cand[c];
-        if (F.mvpMapPoints[idx + F.Nleft])
-          if (F.mvpMapPoints[idx + F.Nleft]->Observations() > 0) continue;
+        if (!eligibleR(idx)) continue;
         const int dist = LR.dist[c];
         if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = F.mvKeysRight[idx].octave; bestIdx = idx; }
         else if (dist < bestDist2) { bestLevel2 = F.mvKeysRight[idx].octave; bestDist2 = dist; }
@@ -1298,8 +1312,8 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
   tr.mark("prepass");
   // phase 2
   Lists LL, LR;
-  window_lists("SearchByProjection", TL, QL, LL, /*view_ok=*/!rig);
-  if (rig) window_lists("SearchByProjection", TR, QR, LR);
+  window_lists("SearchByProjection", TL, QL, LL, /*view_ok=*/true);   // two view blobs alternate: the left lists stay readable
+  if (rig) window_lists("SearchByProjection", TR, QR, LR, /*view_ok=*/true);
   tr.mark("device");
   // phase 3 (:1735-1858)
   RotHist rot;
@@ -1345,10 +1359,18 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
     if (rig) {
       const int qr = qRight[i];
       int bestDistR = 256, bestIdxR = -1;
+      auto eligibleR = [&](size_t i2) {
+        if (CurrentFrame.mvpMapPoints[i2 + CurrentFrame.Nleft])
+          if (CurrentFrame.mvpMapPoints[i2 + CurrentFrame.Nleft]->Observations() > 0) return false;
+        return true;
+      };
+      // as on the left: the first minimum of the whole list, when it passes the gate, is the first minimum of the gated list
+      if (LR.has_best() && LR.span(qr).best_idx >= 0 && eligibleR((size_t)LR.span(qr).best_idx)) {
+        bestDistR = LR.span(qr).best_dist; bestIdxR = LR.span(qr).best_idx;
+      } else
       for (int c = LR.begin(qr); c < LR.end(qr); c++) {
         const size_t i2 = LR.cand[c];
-        if (CurrentFrame.mvpMapPoints[i2 + CurrentFrame.Nleft])
-          if (CurrentFrame.mvpMapPoints[i2 + CurrentFrame.Nleft]->Observations() > 0) continue;
+        if (!eligibleR(i2)) continue;
         const int dist = LR.dist[c];
         if (dist < bestDistR) { bestDistR = dist; bestIdxR = i2; }
       }

@@ -249,8 +249,13 @@ int orbx_target_search(orbx_ctx*, const orbx_target* T, const uint8_t* kp_skip, 
 int orbx_target_search_view(orbx_ctx* ctx, const orbx_target* T, const uint8_t* kp_skip, const float* qx, const float* qy, const float* qr, const int32_t* qmin,
                             const int32_t* qmax, const uint8_t* q_desc, const float* q_xr, int nq, const orbx_list_span** spans, const orbx_candidate** pool) {
   static thread_local std::vector<int32_t> rp, cand, dist;
-  static thread_local std::vector<orbx_list_span> sp;
-  static thread_local std::vector<orbx_candidate> pl;
+  // like the library: two result sets used alternately — a view stays valid while the next view call runs (a rig's left and right lists)
+  static thread_local std::vector<orbx_list_span> sp2[2];
+  static thread_local std::vector<orbx_candidate> pl2[2];
+  static thread_local int par = 0;
+  par ^= 1;
+  std::vector<orbx_list_span>& sp = sp2[par];
+  std::vector<orbx_candidate>& pl = pl2[par];
   rp.assign(nq + 1, 0);
   cand.resize(1 << 16); dist.resize(1 << 16);
   int rc = orbx_target_search(ctx, T, kp_skip, qx, qy, qr, qmin, qmax, q_desc, q_xr, nq, rp.data(), cand.data(), dist.data(), (int)cand.size(), nullptr, nullptr,
