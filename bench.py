@@ -577,28 +577,44 @@ def main():
 
     if rank == 0:
         dom, nkp, fused, roof = kernel_roofline(ex, eng, frame_sets[0], B, H, W, counts, world, args.steps, dt)
+        # HBM traffic and issue-side counters of the dominant kernel come from committed rocprofv3 --pmc passes (tools/pmc_traffic.py,
+        # tools/pmc_sq.py): they are only reported when the files are stamped with the hash of the kernel sources this run was built from
+        from orb_slam3_modified_amd.build import kernels_hash
+        khash = kernels_hash()
+        roof["kernels_hash"] = khash
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
+                st = j.get("stamp", {})
                 if j.get("batch") == B and j.get("rows") == H and j.get("cols") == W:
                     ent = j.get("kernels", {}).get(dom.split("(")[0])
-                    # HBM bytes per launch of the dominant kernel: FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc
-                    # passes, corrected with the known-traffic calibration copy (tools/pmc_traffic.py)
-                    roof["traffic"] = int(ent["hbm_bytes_per_launch"]) if ent else None
-                    if ent:
-                        roof["traffic_source"] = ("profiles/pmc_traffic.json: builder-run rocprofv3 --pmc passes of tools/pmc_traffic.py on this "
-                                                  "workload, committed; NOT measured in this run")
+                    if ent and st.get("kernels_hash") == khash:
+                        # FETCH_SIZE + WRITE_SIZE from separate passes, corrected with the known-traffic calibration copy
+                        roof["traffic"] = int(ent["hbm_bytes_per_launch"])
+                        roof["traffic_source"] = (f"profiles/pmc_traffic.json: builder-run rocprofv3 --pmc passes of tools/pmc_traffic.py on this workload, commit "
+                                                  f"{st.get('commit')} of {st.get('date')}, kernel sources {khash} = this build; NOT measured in this run")
+                    elif ent:
+                        roof["traffic_source"] = (f"profiles/pmc_traffic.json is STALE: measured on kernel sources {st.get('kernels_hash')} (commit {st.get('commit')}), "
+                                                  f"this build is {khash}: traffic not reported")
             except Exception:
                 pass
-        # issue-side evidence for the same kernel (SQ counters from a separate rocprofv3 --pmc run, tools/pmc_sq.py)
         sqp = os.path.join(ROOT, "profiles", "pmc_sq.json")
         if os.path.exists(sqp):
             try:
-                issue = json.load(open(sqp)).get("derived", {}).get(dom.split("(")[0])
-                roof["issue_limits_pmc"] = {k: round(float(v), 4) for k, v in issue.items()} if issue else None
-                if issue:
-                    roof["issue_limits_pmc"]["source"] = "profiles/pmc_sq.json: builder-run rocprofv3 --pmc pass (tools/pmc_sq.py), committed; NOT measured in this run"
+                j = json.load(open(sqp))
+                st = j.get("stamp", {})
+                issue = j.get("derived", {}).get(dom.split("(")[0])
+                if issue and st.get("kernels_hash") == khash:
+                    roof["issue_limits_pmc"] = {k: round(float(v), 4) for k, v in issue.items()}
+                    # valu_busy prices every VALU instruction at 4 cycles; the kernel's own mix holds 2-cycle instructions (profiles/isa_weighted_r3.md:
+                    # weighted price 0.85 of that): the fraction of the ISA-weighted issue ceiling
+                    if dom.startswith("k_fast_cells") and "valu_busy" in issue:
+                        roof["issue_limits_pmc"]["valu_busy_isa_weighted"] = round(float(issue["valu_busy"]) * 0.85, 4)
+                    roof["issue_limits_pmc"]["source"] = (f"profiles/pmc_sq.json: builder-run rocprofv3 --pmc pass (tools/pmc_sq.py), commit {st.get('commit')} of "
+                                                          f"{st.get('date')}, kernel sources {khash} = this build; NOT measured in this run")
+                elif issue:
+                    roof["issue_limits_pmc"] = {"source": f"profiles/pmc_sq.json is STALE (kernel sources {st.get('kernels_hash')}, this build {khash}): not reported"}
             except Exception:
                 pass
         step_ms = dt / args.steps * 1e3

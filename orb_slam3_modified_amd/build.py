@@ -15,6 +15,29 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
          "-Wno-unused-function"]
 
 
+def kernels_hash() -> str:
+    """sha256 over the kernel sources (csrc/*.hip, *.h, *.inc, sorted by name), first 16 hex digits: what the committed counter files
+    (profiles/pmc_*.json) are stamped with, so that bench.py can tell whether they were measured on THIS code."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".h", ".inc")):
+            h.update(f.encode() + b"\0" + open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def stamp() -> dict:
+    """{kernels_hash, commit, date} for evidence files: the commit comes from ORBX_COMMIT (the GPU box has no .git) or `git rev-parse`."""
+    import datetime
+    commit = os.environ.get("ORBX_COMMIT")
+    if not commit:
+        try:
+            commit = subprocess.check_output(["git", "-C", HERE, "rev-parse", "--short=12", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+        except Exception:   # noqa: BLE001
+            commit = "unknown"
+    return {"kernels_hash": kernels_hash(), "commit": commit, "date": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ")}
+
+
 def _stale() -> bool:
     if not os.path.exists(OUT):
         return True

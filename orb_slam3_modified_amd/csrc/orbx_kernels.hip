@@ -655,6 +655,10 @@ __device__ long long g_qt_prof[kMaxLevels * 8];
 #endif
 
 constexpr unsigned long long kM21 = (1ull << 21) - 1ull;
+#ifndef ORBX_QT_SYNC_SORT
+#define ORBX_QT_SYNC_SORT 1
+#endif
+constexpr bool kQtSyncSort = ORBX_QT_SYNC_SORT != 0;   // A/B: -DORBX_QT_SYNC_SORT=0 restores the one-segment-at-a-time wave sort
 
 __device__ __forceinline__ unsigned long long block_excl_scan(unsigned long long* a, int n, unsigned long long* wt) {
   const int T = blockDim.x, t = threadIdx.x, lane = t & 63, w = t >> 6, NW = T >> 6;
@@ -904,6 +908,91 @@ __device__ __forceinline__ void wave_introsort_small(unsigned long long* v, int 
   }
 }
 
+// position of the k-th set bit of m, counted from bit 0 (k = 0: the lowest); the bit must exist
+__device__ __forceinline__ int select_bit64(unsigned long long m, int k) {
+  uint32_t w = (uint32_t)m;
+  int base = 0;
+  const int c = __popc(w);
+  if (k >= c) { k -= c; w = (uint32_t)(m >> 32); base = 32; }
+#pragma unroll
+  for (int sft = 16; sft >= 1; sft >>= 1) {
+    const uint32_t lowm = w & ((1u << sft) - 1u);
+    const int cl = __popc(lowm);
+    if (k >= cl) { k -= cl; w >>= sft; base += sft; } else w = lowm;
+  }
+  return base;
+}
+
+// One wave, a block of at most 64 consecutive positions [first, last): the whole introsort loop of that block with the elements in
+// registers (lane e <-> position first + e) and EVERY pending segment of the block advancing in the same step — the steps of a block are
+// its recursion depth (3-4), not its number of segments (7-15), and a step touches no LDS: the median candidates, the pivot and the swap
+// partners travel by lane permutes, and a lane finds its partner arithmetically (the closed form of partition_closed_form pairs the j-th
+// key >= pivot from the left with the j-th key <= pivot from the right: "the j-th set bit" of a ballot restricted to the lane's segment).
+// Same permutation as wave_introsort_small (gnu_sort.h is the sequential statement).  seg: as in block_gnu_sort.
+__device__ __forceinline__ void wave_introsort_sync(unsigned long long* v, int first, int last, int depth, uint32_t* seg) {
+  const int lane = threadIdx.x & 63;
+  const int base = __builtin_amdgcn_readfirstlane(first), n = __builtin_amdgcn_readfirstlane(last) - base;
+  const bool in = lane < n;
+  unsigned long long mine = in ? v[base + lane] : 0ull;
+  int sf = 0, sl = n, sd = __builtin_amdgcn_readfirstlane(depth);   // this lane's segment [sf, sl) in lane indices, its remaining depth
+  bool act = in && n > 16;
+  const unsigned long long ltm = (1ull << lane) - 1ull, gtm = ~(ltm | (1ull << lane));
+  while (true) {
+    if (__ballot(act) == 0ull) break;
+    unsigned long long heap = __ballot(act && sd == 0);
+    if (heap) {   // depth limit (practically never): the sequential heapsort on those segments, through LDS
+      if (in) v[base + lane] = mine;
+      wave_lds_sync();
+      while (heap) {
+        const int p = __ffsll((long long)heap) - 1;
+        const int hf = __builtin_amdgcn_readlane(sf, p), hl = __builtin_amdgcn_readlane(sl, p);
+        if (lane == 0) orbx_sort::heap_sort(v, base + hf, base + hl);
+        const unsigned long long hm = (hl >= 64 ? ~0ull : ((1ull << hl) - 1ull)) & ~((1ull << hf) - 1ull);
+        heap &= ~hm;
+        if (lane >= hf && lane < hl) { sf = lane; sl = lane + 1; act = false; }   // in final order: every element its own segment
+      }
+      wave_lds_sync();
+      if (in) mine = v[base + lane];
+      continue;
+    }
+    if (act) sd--;
+    uint32_t key = (uint32_t)(mine >> 32);
+    // std::__move_median_to_first(first, first + 1, mid, last - 1), then the pivot sits at `first`
+    const int pa = sf + 1, pb = sf + ((sl - sf) >> 1), pc = sl - 1;
+    const uint32_t ka = __shfl(key, pa), kb = __shfl(key, pb), kc = __shfl(key, pc);
+    int pm;
+    if (ka < kb) pm = kb < kc ? pb : (ka < kc ? pc : pa);
+    else pm = ka < kc ? pa : (kb < kc ? pc : pb);
+    const unsigned long long piv = __shfl(mine, pm), vf = __shfl(mine, sf);
+    const uint32_t kp = (uint32_t)(piv >> 32);
+    if (act) { if (lane == sf) mine = piv; else if (lane == pm) mine = vf; }
+    key = (uint32_t)(mine >> 32);
+    // std::__unguarded_partition(first + 1, last, first), closed form, inside the lane's own segment
+    const bool inr = act && lane > sf;
+    const bool isL = inr && key >= kp, isR = inr && key <= kp;
+    const unsigned long long segm = (sl >= 64 ? ~0ull : ((1ull << sl) - 1ull)) & ~((2ull << sf) - 1ull);   // bits (sf, sl)
+    const unsigned long long mL = __ballot(isL) & segm, mR = __ballot(isR) & segm;
+    const int rankL = __popcll(mL & ltm), rankR = __popcll(mR & gtm);
+    const bool partL = isL && rankR >= rankL + 1, partR = isR && rankL >= rankR + 1;
+    const unsigned long long pL = __ballot(partL), pR = __ballot(partR) & segm;
+    // partner: the key <= pivot with exactly rankL such keys after it / the key >= pivot with exactly rankR such keys before it
+    const int partner = partL ? select_bit64(mR, __popcll(mR) - 1 - rankL) : partR ? select_bit64(mL, rankR) : lane;
+    const unsigned long long other = __shfl(mine, partner);
+    if (partL || partR) mine = other;
+    // the cut: the first key >= pivot that did not swap, or the lowest position that received one, whichever comes first
+    const unsigned long long rest = mL & ~pL;
+    const int aJ = rest ? __ffsll((long long)rest) - 1 : 0x7fffffff;
+    const int rprev = pR ? __ffsll((long long)pR) - 1 : sl;
+    const int cut = aJ < rprev ? aJ : rprev;
+    if (act) {
+      if (lane < cut) sl = cut; else sf = cut;
+      act = sl - sf > 16;
+    }
+  }
+  if (in) { v[base + lane] = mine; seg[base + lane] = (uint32_t)(base + sf) | (uint32_t)(base + sl) << 16; }
+  wave_lds_sync();
+}
+
 // std::sort(v, v + n) with the reference's (count, UL.x) comparator, exact libstdc++ permutation (ties included),
 // by the whole workgroup: level-synchronous introsort loop (one wave per pending segment and round), then a stable
 // rank inside every final segment (== __final_insertion_sort).  tmp: n elements; seg: n words; q0/q1: n/16+2 entries each;
@@ -923,6 +1012,10 @@ __device__ __forceinline__ void block_gnu_sort(unsigned long long* v, int n, uns
       for (int sidx = w; sidx < ncur; sidx += NW) {
         const unsigned long long pk = q0[sidx];
         const int f = (int)(pk & 0xffffull), l = (int)((pk >> 16) & 0xffffull), d = (int)(pk >> 32);
+        if (l - f <= 64 && kQtSyncSort) {  // a block of <= 64 positions: all its segments step together, in registers, without LDS
+          wave_introsort_sync(v, f, l, d, seg);
+          continue;
+        }
         if (l - f <= 65) {  // fits a wave's registers: this wave finishes the segment and everything below it
           wave_introsort_small(v, f, l, d, seg, ia, ir, 0);
           continue;

@@ -2,8 +2,11 @@
 # End-of-round evidence refresh on the GPU box: everything lands in gpurun_out/ (merged back), then copied into profiles/.
 # usage (from the repo root on the box): bash tools/final_refresh.sh r1h
 TAG=${1:-r1x}
+export ORBX_COMMIT=${2:-unknown}      # the GPU box has no .git: the caller passes `git rev-parse --short=12 HEAD`; every evidence file is stamped with it
 mkdir -p gpurun_out
 export TMPDIR=/tmp
+STAMP=$(python -c "from orb_slam3_modified_amd.build import stamp; s = stamp(); print('commit', s['commit'], 'kernel sources', s['kernels_hash'], s['date'])")
+echo "$STAMP"
 timeout 900 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu_$TAG.log 2>&1; grep -E "passed|failed" gpurun_out/pytest_gpu_$TAG.log | tail -1
 # HBM traffic (separate FETCH_SIZE / WRITE_SIZE passes) and issue-side counters, full-batch launches
 timeout 600 python tools/pmc_traffic.py > /dev/null 2>&1 && cp gpurun_out/pmc_traffic.json profiles/pmc_traffic.json
@@ -17,9 +20,10 @@ rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$TAG -o $TAG -- python bench
 DB=$(ls gpurun_out/prof_$TAG/*/${TAG}_results.db gpurun_out/prof_$TAG/${TAG}_results.db 2>/dev/null | head -1)
 { python tools/rocpd_summary.py "$DB" --title "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline ($TAG): all launches";
   echo; python tools/rocpd_summary.py "$DB" --by-grid --title "the same run, one row per launch shape (timed region: 2 lanes x 128 frames, overlapping; roofline passes: 256 frames, back to back)"; } > gpurun_out/${TAG}_kernel_stats.md
+sed -i "1i $STAMP\n" gpurun_out/${TAG}_kernel_stats.md
 head -12 gpurun_out/${TAG}_kernel_stats.md
 rm -rf gpurun_out/prof_$TAG/*/*.db gpurun_out/prof_$TAG/*.db   # keep the merge-back small
 timeout 300 python tools/bench_aux.py > /dev/null 2>&1; ls -la gpurun_out/bench_aux.json
-timeout 300 python tools/matcher_times.py > gpurun_out/matcher_times_$TAG.md 2>&1; tail -2 gpurun_out/matcher_times_$TAG.md
-hipcc --offload-arch=gfx950 -O3 tools/valu_ceiling.hip -o /tmp/valu_ceiling && /tmp/valu_ceiling > gpurun_out/valu_ceiling_$TAG.txt
+{ echo "$STAMP"; echo; timeout 300 python tools/matcher_times.py 2>&1 | grep -v "^\["; } > gpurun_out/matcher_times_$TAG.md; tail -2 gpurun_out/matcher_times_$TAG.md
+{ echo "$STAMP"; for i in 1 2; do python tools/frontend_ab.py; ORBX_BOW_IN_GRAPH=0 python tools/frontend_ab.py; done; } > gpurun_out/frontend_ab_$TAG.txt 2>&1; cat gpurun_out/frontend_ab_$TAG.txt
 timeout 400 python tools/fuzz_extractor.py 400 150 2>&1 | tail -3 | tee gpurun_out/fuzz_$TAG.log

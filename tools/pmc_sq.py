@@ -48,7 +48,8 @@ for k, cs in rows.items():
         if "SQ_WAVE_CYCLES" in avg:
             d["waves_per_simd"] = avg["SQ_WAVE_CYCLES"] * 4.0 / (1024.0 * cyc)   # average residency
         derived[k.split("<")[0]] = d
-json.dump({"derived": derived, "raw_per_dispatch_avg": {k: {c: v[0] / v[1] for c, v in cs.items()} for k, cs in rows.items()}},
+from orb_slam3_modified_amd.build import stamp
+json.dump({"stamp": stamp(), "derived": derived, "raw_per_dispatch_avg": {k: {c: v[0] / v[1] for c, v in cs.items()} for k, cs in rows.items()}},
           open(os.path.join(ROOT, "gpurun_out", "pmc_sq.json"), "w"), indent=1)
 lines += ["", "derived: " + json.dumps(derived)]
 open(os.path.join(ROOT, "gpurun_out", "pmc_sq.md"), "w").write("per-dispatch averages\n\n" + "\n".join(lines) + "\n")

@@ -108,7 +108,8 @@ def main():
                "fetch_bytes_per_launch": fpl * f4, "write_bytes_per_launch": wpl * w4,
                "hbm_bytes_per_launch": fpl * f4 + wpl * w4}
         kernels[short] = ent
-    res = {"batch": B, "rows": H, "cols": W, "steps": STEPS,
+    from orb_slam3_modified_amd.build import stamp
+    res = {"stamp": stamp(), "batch": B, "rows": H, "cols": W, "steps": STEPS,
            "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE in separate passes; KiB -> bytes; corrected by the "
                      "4-byte-per-lane factor of the known-traffic calibration copy (512 MiB) run in the same pass",
            "calibration_factor_fetch": {str(k): v for k, v in sorted(cf.items())},
