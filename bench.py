@@ -421,6 +421,11 @@ class stdout_to_stderr:
 
     def __exit__(self, *exc):
         sys.stdout.flush()
+        try:   # RCCL printed through libc's buffered stdout (a pipe is fully buffered): push it out while fd 1 still points at stderr
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:   # noqa: BLE001
+            pass
         os.dup2(self.saved, 1)
         os.close(self.saved)
         return False
@@ -681,7 +686,9 @@ def main():
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
-        dist.destroy_process_group()
+    if dist.is_initialized():
+        with stdout_to_stderr():
+            dist.destroy_process_group()
     return 0
 
 

@@ -3,6 +3,7 @@
    python tools/pmc_sq.py "SQ_WAVES SQ_WAVE_CYCLES ..." "second pass counters" ...   -> gpurun_out/pmc_sq.md"""
 import csv, glob, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 out = os.path.join(ROOT, "gpurun_out", "pmc_sq")
 rows = {}
 order = []
