@@ -627,10 +627,10 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
       // level of the launch are dispatched first, the short ones fill the CUs behind them
       if (ctx->qt_level_major && !gnodes && !small_batch)
         hipLaunchKernelGGL(k_quadtree, dim3(nframes, l1 - l0, 1), dim3(qthreads), lds, s, ctx->d_geo, ctx->d_cells, b_cand, b_cell_cnt,
-                           b_pts, b_lvl_kp, b_lvl_n, node_cap, scan_cap, pts_cap, l0 | 0x100, gnodes, (long long)ctx->qt_node_stride);
+                           b_pts, b_lvl_kp, b_lvl_n, node_cap, scan_cap, pts_cap, l0 | 0x100 | (ctx->qt_fused ? 0 : 0x200), gnodes, (long long)ctx->qt_node_stride);
       else
         hipLaunchKernelGGL(k_quadtree, dim3(l1 - l0, nframes, 1), dim3(qthreads), lds, s, ctx->d_geo, ctx->d_cells, b_cand, b_cell_cnt,
-                           b_pts, b_lvl_kp, b_lvl_n, node_cap, scan_cap, pts_cap, l0, gnodes, (long long)ctx->qt_node_stride);
+                           b_pts, b_lvl_kp, b_lvl_n, node_cap, scan_cap, pts_cap, l0 | (ctx->qt_fused ? 0 : 0x200), gnodes, (long long)ctx->qt_node_stride);
       return ORBX_OK;
     };
     const int qt_pts = ctx->qt_points;   // measured: 1024 ... 2048 points make no difference to the launch (128 VGPRs hold it at four workgroups per CU)
@@ -866,6 +866,7 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, 
   { const char* e = getenv("ORBX_CHAIN_FIRST"); const int v = e ? atoi(e) : 7; ctx->chain_first = (v >= 2 && v <= 7) ? v : 7; }
   { const char* e = getenv("ORBX_CHAIN_BATCH"); ctx->chain_batch = e ? atoi(e) != 0 : false; }
   { const char* e = getenv("ORBX_QT_LEVEL_MAJOR"); ctx->qt_level_major = e ? atoi(e) != 0 : true; }
+  { const char* e = getenv("ORBX_QT_FUSED"); ctx->qt_fused = e ? atoi(e) != 0 : true; }
   { const char* e = getenv("ORBX_QT_ONE_LAUNCH"); ctx->qt_one_launch = e ? atoi(e) != 0 : false; }
   { const char* e = getenv("ORBX_CHAIN_THREADS"); const int v = e ? atoi(e) : 1024; ctx->chain_threads = (v == 256 || v == 512 || v == 1024) ? v : 1024; }
   { const char* e = getenv("ORBX_QT_POINTS"); const int v = e ? atoi(e) : kQtLdsPoints; ctx->qt_points = (v >= 256 && v <= 4096 && v % 128 == 0) ? v : kQtLdsPoints; }
@@ -1447,6 +1448,7 @@ int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
   else if (n == "qt_points" && value >= 256 && value <= 4096 && value % 128 == 0) ctx->qt_points = value;   // LDS-resident candidates per (frame, level) of the big quadtree levels (half of it for the small ones)
   else if (n == "small_fused") ctx->small_fused = value != 0;
   else if (n == "qt_level_major") ctx->qt_level_major = value != 0;
+  else if (n == "qt_fused") ctx->qt_fused = value != 0;   // the first (up to three) quadtree passes in one sweep over the points
   else if (n == "chain_batch") ctx->chain_batch = value != 0;
   else if (n == "chain_long") ctx->chain_long = value != 0;
   else if (n == "describe_direct") ctx->describe_direct = value != 0;

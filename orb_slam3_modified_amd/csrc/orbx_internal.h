@@ -163,6 +163,7 @@ struct orbx_ctx {
   // atan_fma: cv::fastAtan2's polynomial with the contractions a compiler makes under -mfma (OpenCV's AVX2 dispatch), 0 = separate mul / add
   // brief_fma: the pattern rotation of src/ORBextractor.cc:118-120 as a -march=native build of the reference contracts it (fma(x, b, y*a))
   int gauss_kernel = 0, gauss_round = 0, gauss_tail = 0, atan_fma = 0, brief_fma = 0;
+  bool qt_fused = true;          // quadtree: the first passes fused into one sweep (level_base bit 9 switches it off)
   bool describe_direct = true;   // single frame, trivial lapping area: no assembly pass, k_describe reads the quadtree's per-level output
   bool chain_long = true;        // single-frame pyramid: levels 1-2 in one launch, then up to five small levels per launch
   bool chain_batch = false;      // batches too build the pyramid with the chain launches (k_resize_chain) instead of one launch per level

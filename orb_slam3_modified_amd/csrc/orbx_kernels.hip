@@ -658,7 +658,11 @@ constexpr unsigned long long kM21 = (1ull << 21) - 1ull;
 #ifndef ORBX_QT_SYNC_SORT
 #define ORBX_QT_SYNC_SORT 1
 #endif
-constexpr bool kQtSyncSort = ORBX_QT_SYNC_SORT != 0;   // A/B: -DORBX_QT_SYNC_SORT=0 restores the one-segment-at-a-time wave sort
+constexpr bool kQtSyncSort = ORBX_QT_SYNC_SORT != 0;
+#ifndef ORBX_QT_FUSED_PASSES
+#define ORBX_QT_FUSED_PASSES 1
+#endif
+constexpr bool kQtFusedPasses = ORBX_QT_FUSED_PASSES != 0;   // A/B: -DORBX_QT_FUSED_PASSES=0 restores one barrier-separated pass per tree level   // A/B: -DORBX_QT_SYNC_SORT=0 restores the one-segment-at-a-time wave sort
 
 __device__ __forceinline__ unsigned long long block_excl_scan(unsigned long long* a, int n, unsigned long long* wt) {
   const int T = blockDim.x, t = threadIdx.x, lane = t & 63, w = t >> 6, NW = T >> 6;
@@ -1191,10 +1195,16 @@ __device__ __forceinline__ void quadtree_body(const DeviceGeom* __restrict__ g, 
                                               uint32_t* lcur, uint32_t* lnxt, uint32_t* __restrict__ lvl_kp,
                                               int32_t* __restrict__ lvl_n, int node_cap, int scan_cap, uint8_t* smem, int n,
                                               unsigned long long* wt, int* sh_cnt, int* sh_jstar_p, int level_base, int pts_cap) {
-  uint32_t* cur = LP ? lcur : gcur;
-  uint32_t* nxt = LP ? lnxt : gnxt;
+  // LP with lcur == nullptr: the OVERFLOW form of the LDS algorithm — a level with more candidates than the LDS point buffers hold (up to
+  // twice as many, at most 4096) keeps its points in the HBM ping-pong buffers (L2-resident) and uses the whole LDS point area for the
+  // node-index arrays and chunk tables of that many points: the same thread-per-point passes, slower point accesses — instead of the
+  // wave-per-node fallback below (natural images put 1 600 - 2 300 corners on level 0 where the synthetic stream puts 800)
+  const bool overflow = LP && lcur == nullptr;
+  uint32_t* cur = (LP && !overflow) ? lcur : gcur;
+  uint32_t* nxt = (LP && !overflow) ? lnxt : gnxt;
+  if (overflow) pts_cap *= 2;
   // LP only: node index of every point (list position of the node that holds it) and the chunk tables of the full passes
-  uint16_t* nid = (uint16_t*)(lnxt + pts_cap);
+  uint16_t* nid = overflow ? (uint16_t*)lnxt : (uint16_t*)(lnxt + pts_cap);   // overflow: lnxt = start of the LDS point area
   uint16_t* nidn = nid + pts_cap;
   unsigned long long* cpre = (unsigned long long*)(nidn + pts_cap);
   unsigned long long* cbal = cpre + (pts_cap >> 6) + 1;
@@ -1236,6 +1246,11 @@ __device__ __forceinline__ void quadtree_body(const DeviceGeom* __restrict__ g, 
     }
   }
   if constexpr (LP) for (int e = t; e < n; e += T) nid[e] = 0;
+  // the fused first passes (below) count, per 64-point chunk, the points of every depth-3 class: the table starts from zero
+  const int fz_nch = (n + 63) >> 6;
+  const bool fused_ok = LP && kQtFusedPasses && !(level_base & 0x200) && lv.nroots == 1 && n <= 2048 && fz_nch * 128 <= node_cap * (int)sizeof(QNode) &&
+                        fz_nch * 64 <= node_cap * (int)sizeof(int4) && node_cap >= 64;   // block-uniform
+  if (fused_ok) for (int e = t; e < fz_nch * 16; e += T) ((uint32_t*)kids)[e] = 0u;
   __syncthreads();
   int nL = 0, nE = 0;
   // ---- root nodes (src/ORBextractor.cc:559-601)
@@ -1293,6 +1308,169 @@ __device__ __forceinline__ void quadtree_body(const DeviceGeom* __restrict__ g, 
 
   QT_ACC(0);
   bool finish = false, sorted_phase = false;
+  if constexpr (LP) {
+    if (fused_ok) {
+      // ======== the first (up to three) full passes in ONE pass over the points.  The quadrant a point falls into at depth 1, 2, 3 is a
+      // function of its coordinates and the root alone (DivideNode's bounds are midpoints, src/ORBextractor.cc:480-536), so one sweep
+      // classifies every point to depth 3 and counts the classes per 64-point chunk; ONE wave then replays the reference's list
+      // evolution pass by pass on those counts (which nodes split, where their children enter the list, the stop tests of :683-690)
+      // with a lane per depth-3 class, and one more sweep moves the points (stable, by the class of the depth actually reached).
+      // Three barriers instead of twelve.  State on exit = the state the generic passes below would have left.
+      uint8_t* cc = (uint8_t*)kids;                 // [nch][64] points of (chunk, class)          (zeroed in the gather phase)
+      uint16_t* cpf = (uint16_t*)LB;                // [nch][64] exclusive prefix over the chunks, per class (later: per depth-D class)
+      uint16_t* tpos = (uint16_t*)flag;             // [64] list position of the node that holds class l
+      uint16_t* tstart = tpos + 64;                 // [64] first position of class l's depth-D group in the sorted point array
+      const int RX0 = lv.root_x0[0], RX1 = lv.root_x1[0];
+      const unsigned long long ltm = (1ull << lane) - 1ull;
+      // ---- A: classify, count
+      for (int c = w; c < fz_nch; c += NW) {
+        const int i = (c << 6) + lane;
+        int code = 0;
+        const bool valid = i < n;
+        if (valid) {
+          const uint32_t p = cur[i];
+          const int px = pt_x(p), py = pt_y(p);
+          int x0 = RX0, x1 = RX1, y0 = 0, y1 = H;
+#pragma unroll
+          for (int d = 0; d < 3; d++) {
+            const int sx = x0 + ((x1 - x0 + 1) >> 1), sy = y0 + ((y1 - y0 + 1) >> 1);
+            const int cx = px < sx ? 0 : 1, cy = py < sy ? 0 : 1;
+            if (cx) x0 = sx; else x1 = sx;
+            if (cy) y0 = sy; else y1 = sy;
+            code = (code << 2) | cx | (cy << 1);
+          }
+          nid[i] = (uint16_t)code;
+        }
+        unsigned long long m = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 6; b++) {
+          const unsigned long long bb = __ballot((code >> b) & 1);
+          m &= ((code >> b) & 1) ? bb : ~bb;
+        }
+        if (valid && (m & ltm) == 0ull) cc[(c << 6) + code] = (uint8_t)__popcll(m);   // the first lane of every class present in the chunk
+      }
+      __syncthreads();
+      // ---- B: one wave replays the passes on the counts
+      int* fz = (int*)wt;   // [0] nL  [1] nE  [2] D | finish << 8 | sorted << 9   (wt is free here: no block scan is in flight)
+      if (w == 0) {
+        // exclusive prefix over the chunks, per depth-3 class (lane = class); h3 = points of the class
+        int h3 = 0;
+        for (int c = 0; c < fz_nch; c++) { const int v = cc[(c << 6) + lane]; cpf[(c << 6) + lane] = (uint16_t)h3; h3 += v; }
+        // class counts at depth 2 (quads of lanes) and depth 1 (groups of 16), in every lane of the group
+        int h2 = h3; h2 += __shfl_xor(h2, 1); h2 += __shfl_xor(h2, 2);
+        int h1 = h2; h1 += __shfl_xor(h1, 4); h1 += __shfl_xor(h1, 8);
+        int inc = h3;   // lexicographic start of every depth-3 class in the sorted point array
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+        const int start3 = inc - h3;
+        // per lane: the list node its class currently belongs to
+        bool alive = true;
+        int ndepth = 0, ncount = n, npos = 0, eidx = -1;
+        int curL = 1, curE = 0, D = 0;
+        bool fin = false, srt = false;
+#pragma unroll 1
+        for (int p = 1; p <= 3 && !fin && !srt; p++) {
+          const int sp = 2 * (3 - p);                       // lanes of one depth-p class share lane >> sp
+          const int hp = p == 1 ? h1 : p == 2 ? h2 : h3;     // points of my depth-p class
+          const bool split = alive && ncount > 1, nomore = alive && ncount == 1;
+          // my parent's four children
+          const int pbase = (lane >> (sp + 2)) << 2, cme = (lane >> sp) & 3;
+          int k = 0, q = 0, ci = 0, qi = 0;
+#pragma unroll
+          for (int c4 = 0; c4 < 4; c4++) {
+            const int sc = __shfl(hp, (pbase | c4) << sp);
+            k += sc > 0; q += sc > 1;
+            ci += (c4 < cme) && sc > 0; qi += (c4 < cme) && sc > 1;
+          }
+          // one value per list node, at the lane of its position: children (k), expandable children (q), no-more flag — then their
+          // exclusive prefixes in list order.  The representative lane of a node is the first lane of its class group.
+          const int gmask = (1 << (2 * (3 - ndepth))) - 1;
+          const bool rep = alive && (lane & gmask) == 0;
+          uint16_t* inv = tstart;   // scratch until the tables are written: position -> representative lane
+          if (rep) inv[npos] = (uint16_t)lane;
+          wave_lds_sync();
+          const int src = lane < curL ? (int)inv[lane] : 0;
+          wave_lds_sync();
+          const int packed = split ? (k | (q << 8)) : nomore ? (1 << 16) : 0;
+          int vpos = __shfl(packed, src);                    // the node at list position `lane`
+          if (lane >= curL) vpos = 0;
+          int vinc = vpos;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(vinc, o); if (lane >= o) vinc += u; }
+          const int vex = vinc - vpos, vtot = __shfl(vinc, 63);
+          const int mine = __shfl(vex, npos);                // prefixes at my node's position
+          const int totalKids = vtot & 0xff, totalQ = (vtot >> 8) & 0xff, totalM = vtot >> 16;
+          const int kpre = mine & 0xff, qpre = (mine >> 8) & 0xff, spre = mine >> 16;
+          // my class after this pass
+          if (split) {
+            if (hp == 0) alive = false;
+            else {
+              ndepth = p; ncount = hp;
+              npos = totalKids - (kpre + k) + (k - 1 - ci);
+              eidx = hp > 1 ? qpre + qi : -1;
+            }
+          } else if (nomore) { npos = totalKids + spre; eidx = -1; }
+          const int newL = totalKids + totalM;
+          D = p;
+          fin = newL >= N || newL == curL;
+          srt = !fin && newL + 3 * totalQ > N;
+          curL = newL; curE = totalQ;
+        }
+        // ---- the state the generic passes would have left: list, expandable list, tables for the point sweep
+        const int sD = 2 * (3 - D);
+        const int gmask = (1 << (2 * (3 - ndepth))) - 1;
+        const bool rep = alive && (lane & gmask) == 0;
+        if (rep) {
+          int x0 = RX0, x1 = RX1, y0 = 0, y1 = H;
+          for (int d = 1; d <= ndepth; d++) {
+            const int c4 = (lane >> (2 * (3 - d))) & 3;
+            const int sx = x0 + ((x1 - x0 + 1) >> 1), sy = y0 + ((y1 - y0 + 1) >> 1);
+            if (c4 & 1) x0 = sx; else x1 = sx;
+            if (c4 & 2) y0 = sy; else y1 = sy;
+          }
+          QNode nd;
+          nd.x0 = (int16_t)x0; nd.y0 = (int16_t)y0; nd.x1 = (int16_t)x1; nd.y1 = (int16_t)y1; nd.start = start3; nd.count = ncount;
+          LA[npos] = nd;
+          if (ndepth == D && eidx >= 0) EA[eidx] = expand_elem(nd, npos);
+        }
+        wave_lds_sync();   // inv (in tstart) has been read by everyone
+        tpos[lane] = (uint16_t)npos;
+        tstart[lane] = (uint16_t)__shfl(start3, (lane >> sD) << sD);
+        if (D < 3)   // the points are sorted by their depth-D class: prefix over the chunks per depth-D class
+          for (int c = 0; c < fz_nch; c++) {
+            int v = cpf[(c << 6) + lane];
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2);
+            if (D < 2) { v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); }
+            cpf[(c << 6) + lane] = (uint16_t)v;
+          }
+        if (lane == 0) { fz[0] = curL; fz[1] = curE; fz[2] = D | (fin ? 0x100 : 0) | (srt ? 0x200 : 0); }
+      }
+      __syncthreads();
+      nL = fz[0]; nE = fz[1];
+      const int D = fz[2] & 0xff;
+      finish = (fz[2] & 0x100) != 0; sorted_phase = (fz[2] & 0x200) != 0;
+      // ---- C: the points move (stable inside a depth-D class) and learn their node's list position
+      for (int c = w; c < fz_nch; c += NW) {
+        const int i = (c << 6) + lane;
+        const bool valid = i < n;
+        const int code = valid ? (int)nid[i] : 0;
+        unsigned long long m = __ballot(valid);
+        for (int b = 5; b >= 6 - 2 * D; b--) {
+          const unsigned long long bb = __ballot((code >> b) & 1);
+          m &= ((code >> b) & 1) ? bb : ~bb;
+        }
+        if (valid) {
+          const int dst = (int)tstart[code] + (int)cpf[(c << 6) + code] + __popcll(m & ltm);
+          nxt[dst] = cur[i];
+          nidn[dst] = tpos[code];
+        }
+      }
+      __syncthreads();
+      { uint16_t* tn = nid; nid = nidn; nidn = tn; }
+      { uint32_t* tp = cur; cur = nxt; nxt = tp; }
+      QT_ACC(1);
+    }
+  }
   while (!finish) {
     if (!sorted_phase) {
       // ======== full pass: split every node holding more than one point (src/ORBextractor.cc:612-681)
@@ -1803,6 +1981,8 @@ __device__ __forceinline__ void quadtree_main(const DeviceGeom* __restrict__ g, 
   }
   if (!GN && n <= pts_cap)
     quadtree_body<true>(g, cells, fcand, gcur, gnxt, lpts, lpts + pts_cap, lvl_kp, lvl_n, node_cap, scan_cap, nb, n, wt, sh_cnt, sh_jstar, level_base, pts_cap);
+  else if (!GN && pts_cap >= 64 && n <= 2 * pts_cap && n <= 4096 && !(level_base & 0x400))   // block-uniform
+    quadtree_body<true>(g, cells, fcand, gcur, gnxt, (uint32_t*)nullptr, lpts, lvl_kp, lvl_n, node_cap, scan_cap, nb, n, wt, sh_cnt, sh_jstar, level_base, pts_cap);
   else
     quadtree_body<false>(g, cells, fcand, gcur, gnxt, lpts, lpts + pts_cap, lvl_kp, lvl_n, node_cap, scan_cap, nb, n, wt, sh_cnt, sh_jstar, level_base, pts_cap);
 }

@@ -107,6 +107,32 @@ def test_other_parameters(nlevels, sf, ini, mn):
     assert np.array_equal(gpu.GetInverseScaleSigmaSquares(), t["inv_sigma2"])
 
 
+@pytest.mark.parametrize("qt_points,fused", [(512, 1), (512, 0), (384, 1), (256, 1), (1024, 1), (2048, 0)])
+def test_quadtree_point_capacities_and_fused_passes(qt_points, fused):
+    """The three homes of a level's candidates — LDS point buffers, the overflow form (points in HBM, node indices for twice the capacity in
+    LDS, same thread-per-point passes) and the wave-per-node fallback beyond that — and the fused first passes on / off give the same
+    keypoints: a small LDS capacity pushes the synthetic frames' levels (770 ... 250 candidates) through all of them; single frame,
+    batch, and a natural crop with 2 275 corners on level 0."""
+    frames = synth.make_stream(3)
+    nat = np.load("tests/golden/natural_crops.npz")["pineapple_640x480_img"]
+    gpu = ORBextractor(1000, 1.2, 8, 20, 7)
+    gpu.set_option("qt_points", qt_points)
+    gpu.set_option("qt_fused", fused)
+    ora = po.OracleExtractor(1000, 1.2, 8, 20, 7)
+    want = [ora.extract(f, (0, 1000)) for f in frames]
+    for f, wnt in zip(frames, want):
+        assert_same(gpu(f, None, (0, 1000)), wnt, f"single qt_points {qt_points}")
+    assert_same(gpu(nat, None, (0, 1000)), ora.extract(nat, (0, 1000)), f"natural qt_points {qt_points}")
+    batch = np.stack(list(frames) * 3 + [frames[0]])      # 10 frames: the batch launch shapes (big / small level groups)
+    res = gpu.extract_batch(batch, (0, 1000))
+    for i, r in enumerate(res):
+        assert_same(r, want[i % 3] if i < 9 else want[0], f"batch frame {i} qt_points {qt_points}")
+    res = gpu.extract_batch(np.stack([nat, frames[1], nat, frames[2], nat, nat]), (0, 1000))
+    wn = ora.extract(nat, (0, 1000))
+    for i, r in enumerate(res):
+        assert_same(r, wn if i in (0, 2, 4, 5) else want[1 if i == 1 else 2], f"mixed batch frame {i} qt_points {qt_points}")
+
+
 def test_strided_input_and_roi():
     big = synth.make_stream(1, 600, 800)[0]
     roi = big[60:540, 80:720]            # non-contiguous rows, like a cv::Mat ROI with step > cols

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of the extractor against the oracle (same generator as
-tests/test_gpu_extractor.py::test_random_shapes_and_parameters, more seeds): python tools/fuzz_extractor.py [first] [count]"""
+tests/test_gpu_extractor.py::test_random_shapes_and_parameters, more seeds): python tools/fuzz_extractor.py [first] [count] [--variants]
+--variants: every configuration also draws a random OpenCV / build variant (gauss_kernel, gauss_round, gauss_tail, atan_fma, brief_fma —
+INTEGRATION.md section 6), set on the oracle and on the GPU context alike."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,8 +10,10 @@ sys.path.insert(0, ROOT)
 from oracle import pyoracle as po
 from orb_slam3_modified_amd import ORBextractor, OrbxError, synth
 
-first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-count = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+variants = "--variants" in sys.argv
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+first = int(argv[0]) if len(argv) > 0 else 100
+count = int(argv[1]) if len(argv) > 1 else 60
 bad = rejected = 0
 for seed in range(first, first + count):
     rng = np.random.default_rng(1000 + seed)
@@ -38,14 +42,23 @@ for seed in range(first, first + count):
         img = rng.integers(0, 256, (rows, cols)).astype(np.uint8)
     else:
         img = (synth.make_stream(1, rows, cols, 7 + seed)[0].astype(np.float32) * 0.25 + 90).astype(np.uint8)
-    tag = f"seed {seed}: {cols}x{rows} sf{sf:.2f} L{nlev} nf{nf} th{ini}/{mn} lap{lap} {kind}"
+    var = (0, 0, 0, 0, 0)
+    if variants:
+        rnd = int(rng.integers(0, 3))
+        var = (int(rng.integers(0, 2)), rnd, int(rng.choice([0, 4, 8, 16, 32, 64])) if rnd else 0, int(rng.integers(0, 2)), int(rng.integers(0, 2)))
+    tag = f"seed {seed}: {cols}x{rows} sf{sf:.2f} L{nlev} nf{nf} th{ini}/{mn} lap{lap} {kind}" + (f" variant{var}" if variants else "")
     try:
-        mono, kps, desc = ORBextractor(nf, sf, nlev, ini, mn)(img, None, lap)
+        gpu = ORBextractor(nf, sf, nlev, ini, mn)
+        with po.opencv_variant(*var) as v:
+            for k, val in v.options().items():
+                gpu.set_option(k, val)
+        mono, kps, desc = gpu(img, None, lap)
     except OrbxError as e:
         rejected += 1
         print("REJECTED", tag, e)
         continue
-    okps, odesc, omono = po.OracleExtractor(nf, sf, nlev, ini, mn).extract(img, lap)
+    with po.opencv_variant(*var):
+        okps, odesc, omono = po.OracleExtractor(nf, sf, nlev, ini, mn).extract(img, lap)
     ok = mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc)
     if not ok:
         bad += 1
