@@ -133,6 +133,21 @@ def test_quadtree_point_capacities_and_fused_passes(qt_points, fused):
         assert_same(r, wn if i in (0, 2, 4, 5) else want[1 if i == 1 else 2], f"mixed batch frame {i} qt_points {qt_points}")
 
 
+@pytest.mark.parametrize("qt_points", [256, 512, 1024])
+def test_quadtree_point_capacities_with_two_and_three_roots(qt_points):
+    """The same three homes of a level's candidates on images whose levels start from two (752 x 480) and three (1241 x 376) root nodes —
+    the fused passes do not apply there, the overflow form and the fallback do."""
+    for rows, cols, nf in ((480, 752, 1200), (376, 1241, 2000)):
+        frames = synth.make_stream(2, rows, cols, 77 + cols)
+        gpu = ORBextractor(nf, 1.2, 8, 20, 7)
+        gpu.set_option("qt_points", qt_points)
+        ora = po.OracleExtractor(nf, 1.2, 8, 20, 7)
+        want = [ora.extract(f, (0, 1000)) for f in frames]
+        assert_same(gpu(frames[0], None, (0, 1000)), want[0], f"{cols}x{rows} single qt_points {qt_points}")
+        for i, r in enumerate(gpu.extract_batch(np.stack([frames[0], frames[1], frames[1], frames[0], frames[1]]), (0, 1000))):
+            assert_same(r, want[(0, 1, 1, 0, 1)[i]], f"{cols}x{rows} batch frame {i} qt_points {qt_points}")
+
+
 def test_strided_input_and_roi():
     big = synth.make_stream(1, 600, 800)[0]
     roi = big[60:540, 80:720]            # non-contiguous rows, like a cv::Mat ROI with step > cols
