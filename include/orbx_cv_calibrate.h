@@ -29,6 +29,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <utility>
 #include <vector>
 
 #include "orbx.h"
@@ -40,6 +42,7 @@ struct Calibration {
   bool gauss_exact = false, atan_exact = false;   // a variant reproduces every byte / bit of the probe
   int gauss_mismatch = 0, atan_mismatch = 0;      // differing bytes / angles of the closest variant otherwise
   int gauss_candidates = 0;                       // variants that reproduce the probe (>= 1 when gauss_exact)
+  bool sort_libstdcxx = true;                     // this toolchain's std::sort leaves equal keys in libstdc++'s order (the one liborbx restates)
 };
 
 constexpr int kProbeW = 127, kProbeH = 72;   // 127 mod V differs for V = 4, 8, 16, 32, 64: every tail length is visible
@@ -139,6 +142,32 @@ inline int build_contracts_fma() {
   return votes_fused > 0 && votes_unfused == 0 ? 1 : 0;
 }
 
+/* (4): the tie order of std::sort.  DistributeOctTree sorts its (point count, UL.x) pairs with std::sort (src/ORBextractor.cc:700); equal
+ * keys are the rule there (stacked nodes share UL.x, small counts repeat), and the order in which they come out is the STANDARD LIBRARY's:
+ * it decides the order of the keypoints and, where a tie sits at the node at which the quota is reached, the keypoints themselves.
+ * liborbx restates libstdc++'s introsort (csrc/gnu_sort.h).  The probe sorts three keyed id sequences (40 / 100 / 300 elements, 5 - 9
+ * distinct keys) with the std::sort of the caller's toolchain — the one src/ORBextractor.cc would be built with — and compares a digest of
+ * the permutations with libstdc++'s.  There is no option behind it: another library (libc++, MSVC) means another tie order. */
+template <class Sorter>
+inline uint64_t sort_probe_digest(Sorter sorter) {
+  uint64_t h = 1469598103934665603ull;
+  static const int sizes[3] = {40, 100, 300}, nkeys[3] = {5, 7, 9};
+  uint32_t s = 0x2545F491u;
+  for (int p = 0; p < 3; p++) {
+    std::vector<std::pair<int, int> > v((size_t)sizes[p]);
+    for (int i = 0; i < sizes[p]; i++) { s = s * 1664525u + 1013904223u; v[(size_t)i] = std::make_pair((int)((s >> 10) % (uint32_t)nkeys[p]), i); }
+    sorter(v);
+    for (const std::pair<int, int>& e : v) { h ^= (uint64_t)(uint32_t)e.second; h *= 1099511628211ull; }
+  }
+  return h;
+}
+constexpr uint64_t kLibstdcxxSortDigest = 0x462bd45918e0b9e3ull;
+inline bool std_sort_is_libstdcxx() {
+  return sort_probe_digest([](std::vector<std::pair<int, int> >& v) {
+           std::sort(v.begin(), v.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first < b.first; });
+         }) == kLibstdcxxSortDigest;
+}
+
 /* Blur: void(const uint8_t* src, int w, int h, uint8_t* dst) — the OpenCV at hand; Atan: float(float y, float x) */
 template <class Blur, class Atan>
 inline Calibration calibrate(Blur blur, Atan at) {
@@ -174,6 +203,7 @@ inline Calibration calibrate(Blur blur, Atan at) {
   c.atan_mismatch = bad[c.atan_fma]; c.atan_exact = c.atan_mismatch == 0;
   if (!c.atan_exact) c.atan_fma = 0;
   c.brief_fma = build_contracts_fma();
+  c.sort_libstdcxx = std_sort_is_libstdcxx();
   return c;
 }
 
@@ -197,13 +227,17 @@ inline int apply(orbx_ctx* ctx, const Calibration& c) {
 
 inline void report(const Calibration& c, const char* opencv_version, std::FILE* f = stderr) {
   const bool dflt = c.gauss_kernel == 0 && c.gauss_round == 0 && c.gauss_tail == 0 && c.atan_fma == 0 && c.brief_fma == 0;
+  if (!c.sort_libstdcxx)
+    std::fprintf(f, "[orbx] std::sort of this toolchain does not leave equal keys in libstdc++'s order: DistributeOctTree (src/ORBextractor.cc:700) "
+                    "built with it orders tied nodes differently from liborbx — keypoint order (and some keypoints) will differ from a CPU build here\n");
   if (c.gauss_exact && c.atan_exact && dflt && !std::getenv("ORBX_CV_VERBOSE")) return;
   std::fprintf(f, "[orbx] OpenCV %s: cv::GaussianBlur(7x7, sigma 2, 8u) %s gauss_kernel=%d gauss_round=%d gauss_tail=%d", opencv_version,
                c.gauss_exact ? "== variant" : "matches NO known variant; keeping", c.gauss_kernel, c.gauss_round, c.gauss_tail);
   if (!c.gauss_exact) std::fprintf(f, " (closest variant differs in %d of %d probe bytes: descriptors will not be bit-identical to this OpenCV's; see tools/validate_opencv.cpp)", c.gauss_mismatch, kProbeW * kProbeH);
   std::fprintf(f, "; cv::fastAtan2 %s atan_fma=%d", c.atan_exact ? "==" : "matches neither form; keeping", c.atan_fma);
   if (!c.atan_exact) std::fprintf(f, " (%d of 4096 angles differ)", c.atan_mismatch);
-  std::fprintf(f, "; this build %s the pattern rotation: brief_fma=%d\n", c.brief_fma ? "contracts" : "does not contract", c.brief_fma);
+  std::fprintf(f, "; this build %s the pattern rotation: brief_fma=%d; std::sort tie order %s\n", c.brief_fma ? "contracts" : "does not contract", c.brief_fma,
+               c.sort_libstdcxx ? "= libstdc++" : "NOT libstdc++");
 }
 
 }  // namespace orbx_cv

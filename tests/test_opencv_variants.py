@@ -209,6 +209,23 @@ def test_adapter_calibration_recognises_every_variant(tmp_path):
         assert line.startswith("%d %d %d %d -> %d %d %d %d exact 1 1 candidates 1 " % (v + v)), line
 
 
+def test_std_sort_probe_knows_libstdcxx_tie_order(tmp_path):
+    """The fourth build-dependent input of the CPU path: the order in which std::sort leaves EQUAL keys (DistributeOctTree's (count, UL.x)
+    pairs tie all the time).  include/orbx_cv_calibrate.h's probe — three keyed sequences sorted with the toolchain's std::sort — must give
+    the digest the header holds for libstdc++, the repository's restatement of libstdc++'s introsort (csrc/gnu_sort.h, what the device code is
+    checked against) must give the same, and another tie order (std::stable_sort) must be told apart — at -O0 and -O2, C++14 and C++17."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for i, flags in enumerate((["-O2", "-std=c++17"], ["-O0", "-std=c++14"])):
+        exe = str(tmp_path / f"sort_probe{i}")
+        subprocess.check_call(["g++"] + flags + ["-I", os.path.join(root, "include"), "-I", os.path.join(root, "orb_slam3_modified_amd", "csrc"),
+                               os.path.join(root, "tests", "support", "sort_probe.cpp"), "-o", exe])
+        f = dict(zip(*[iter(subprocess.check_output([exe]).decode().split())] * 2))
+        assert f["std_sort"] == f["constant"] == f["gnu_sort_h"], f
+        assert f["stable_sort"] != f["constant"], f
+        assert f["is_libstdcxx"] == "1", f
+
+
 def test_oracle_brief_hash_sees_the_switch():
     h0, nd0 = po.brief_hash(0x43a00000, 60_000)     # angles from 320 degrees on
     with po.opencv_variant(brief_fma=1):
