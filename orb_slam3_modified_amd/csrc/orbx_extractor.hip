@@ -375,10 +375,21 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
     const int nitems = ncells_sub * nframes;
     if (nitems <= 0) return;
     const FastLds f = fast_lds_of(cell_base, cell_base + ncells_sub);
+    // experiment ("fast_dma" = cells per workgroup, 0 = off): the next cell's tile by LDS-DMA while the current one is scored
+    if (ctx->fast_dma > 0 && ctx->fast_pk && ft == 128 && pitchB == 64 && ctx->fast_stop == 0 && (row_stride & 3) == 0 && (frame_stride & 3) == 0 &&
+        ((uintptr_t)d_imgs & 3) == 0) {
+      auto dk = k_fast_cells_dma<128, 64>;
+      const int cpw = ctx->fast_dma;
+      hipLaunchKernelGGL(dk, dim3(xcd_grid((nitems + cpw - 1) / cpw)), dim3(ft), f.bytes + 16 + (size_t)pitchB * f.tile_rows, s, ctx->d_geo, ctx->d_cells,
+                         d_imgs, (long long)row_stride, (long long)frame_stride, b_pyr, (long long)geo.pyr_bytes, b_cand, b_cell_cnt, ctx->ini_th,
+                         ctx->min_th, f.tile_rows, nitems, cell_base, ncells_sub, div_magic((uint32_t)ncells_sub), ctx->fast_early ? 0x100 : 0,
+                         f.list_cap, f.nwords, cpw);
+      return;
+    }
     hipLaunchKernelGGL(fast_kern, dim3(xcd_grid(nitems)), dim3(ft), f.bytes, s, ctx->d_geo, ctx->d_cells, d_imgs,
                        (long long)row_stride, (long long)frame_stride, b_pyr, (long long)geo.pyr_bytes, b_cand, b_cell_cnt,
                        ctx->ini_th, ctx->min_th, f.tile_rows, nitems, cell_base, ncells_sub, div_magic((uint32_t)ncells_sub),
-                       ctx->fast_stop | (ctx->fast_early ? 0x100 : 0), f.list_cap, f.nwords);
+                       ctx->fast_stop | (ctx->fast_early ? 0x100 : 0) | (ctx->fast_stage_dma ? 0x200 : 0), f.list_cap, f.nwords);
   };
   // The cells of the small levels are taller (fewer rows of cells share the same height): one launch over all levels would give
   // every workgroup the LDS of the tallest cell and cost the many cells of the large levels their residency.  A range of cells
@@ -557,7 +568,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
     auto fk = pitchB == 64 ? (ctx->fast_pk ? k_fast_blur<64, true> : k_fast_blur<64, false>) : (ctx->fast_pk ? k_fast_blur<96, true> : k_fast_blur<96, false>);
     hipLaunchKernelGGL(fk, dim3(nfast + nblur), dim3(256), f.bytes, st, ctx->d_geo, ctx->d_cells, d_imgs, (long long)row_stride, (long long)frame_stride,
                        b_pyr, (long long)geo.pyr_bytes, b_cand, b_cell_cnt, ctx->ini_th, ctx->min_th, f.tile_rows, nfast, ncells_all,
-                       div_magic((uint32_t)ncells_all), ctx->fast_early ? 0x100 : 0, f.list_cap, f.nwords, b_blur, (long long)geo.blur_bytes, bc);
+                       div_magic((uint32_t)ncells_all), (ctx->fast_early ? 0x100 : 0) | (ctx->fast_stage_dma ? 0x200 : 0), f.list_cap, f.nwords, b_blur, (long long)geo.blur_bytes, bc);
   } else {
     ProfScope ps(ctx, 1, st);
     if (fork_fast0) launch_fast(ncells0, ncells_all - ncells0, st);
@@ -908,6 +919,8 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, 
     const char* fpk = getenv("ORBX_FAST_PK");   // packed 16-bit necessary test in k_fast_cells (128-thread workgroups)
     ctx->fast_pk = fpk ? atoi(fpk) != 0 : true;
     { const char* e = getenv("ORBX_FAST_EARLY"); ctx->fast_early = e ? atoi(e) != 0 : false; }
+    { const char* e = getenv("ORBX_FAST_STAGE_DMA"); ctx->fast_stage_dma = e ? atoi(e) != 0 : true; }
+    { const char* e = getenv("ORBX_FAST_DMA"); if (e && atoi(e) >= 0 && atoi(e) <= 64) ctx->fast_dma = atoi(e); }
     const char* fs = getenv("ORBX_FAST_STOP");
     ctx->fast_stop = fs ? atoi(fs) : 0;
     const char* dl = getenv("ORBX_DESC_LDS");   // blurred 37x37 window staged in LDS for the descriptor taps
@@ -1439,6 +1452,8 @@ int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
   else if (n == "graph") ctx->use_graph = value != 0;
   else if (n == "graph_timing") { ctx->graph_timing = value != 0; return ORBX_OK; }   // no re-capture needed
   else if (n == "fast_pk") ctx->fast_pk = value != 0;
+  else if (n == "fast_stage_dma") ctx->fast_stage_dma = value != 0;   // FAST tile staged by LDS-DMA loads instead of load + ds_write
+  else if (n == "fast_dma" && value >= 0 && value <= 64) ctx->fast_dma = value;   // cells per FAST workgroup with LDS-DMA tile prefetch (0 = off; experiment)
   else if (n == "fast_early") ctx->fast_early = value != 0;   // wave-uniform early-out of the FAST pre-test after the compass pairs
   else if (n == "gauss_kernel" && (value == 0 || value == 1)) ctx->gauss_kernel = value;   // which OpenCV's 8-bit Gaussian weights (include/orbx.h)
   else if (n == "gauss_round" && value >= 0 && value <= 2) ctx->gauss_round = value;       // ... which rounding of the column pass

@@ -382,41 +382,87 @@ __device__ __forceinline__ uint32_t pk_verdict(uint32_t c, const PkHalf h, uint3
 }
 
 // one cell (logical item L of a launch over cells [cell_base, cell_base + ncells_sub) of every frame); T threads
-template <int T, int PITCH, bool PK>
+// A cell's geometry through dword loads of a uniform address: scalar loads (the 16-bit fields of a plain struct copy come by vector loads,
+// whose s_waitcnt vmcnt(0) would also wait for an LDS-DMA in flight).
+__device__ __forceinline__ CellGeom load_cell_scalar(const CellGeom* __restrict__ cells, int cell) {
+  static_assert(sizeof(CellGeom) == 40, "CellGeom layout");
+  const uint32_t* p = (const uint32_t*)(cells + cell);
+  uint32_t w[10];
+#pragma unroll
+  for (int i = 0; i < 10; i++) w[i] = p[i];
+  CellGeom cg;
+  __builtin_memcpy(&cg, w, sizeof(cg));
+  return cg;
+}
+
+// LDS atomics the compiler does not see (DMA mode only): before an LDS atomic it can prove nothing about, hipcc waits for vmcnt(0) — i.e. for the
+// LDS-DMA of the next tile — although the DMA's destination is the OTHER tile buffer.
+__device__ __forceinline__ int lds_add_rtn_opaque(int* p, int v) {
+  int r;
+  asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"((uint32_t)(size_t)(__attribute__((address_space(3))) int*)p), "v"(v) : "memory");
+  return r;
+}
+__device__ __forceinline__ void lds_or_opaque(uint32_t* p, uint32_t v) {
+  asm volatile("ds_or_b32 %0, %1" : : "v"((uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t*)p), "v"(v) : "memory");
+}
+
+// DMA = the looped kernel below: the tile has been put into `tile_dma` by LDS-DMA loads that the caller issued and waited for, `smem` starts at
+// the score plane, and every workgroup barrier is the raw form (s_waitcnt lgkmcnt(0); s_barrier) — __syncthreads() also waits for vmcnt(0)
+// and would drain the NEXT cell's tile, in flight while this one is scored.
+__device__ __forceinline__ void raw_block_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <bool RAW>
+__device__ __forceinline__ void cell_sync() { if constexpr (RAW) raw_block_sync(); else __syncthreads(); }
+
+template <int T, int PITCH, bool PK, bool DMA = false>
 __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
                                           const uint8_t* __restrict__ imgs, long long img_row_stride,
                                           long long img_frame_stride, const uint8_t* __restrict__ pyr,
                                           long long pyr_frame_bytes, uint32_t* __restrict__ cand,
                                           int32_t* __restrict__ cell_cnt, int ini_th, int min_th, int tile_rows,
                                           int cell_base, int ncells_sub, uint32_t m_ncells_sub, int stop_after,
-                                          int list_cap, int nwords) {
+                                          int list_cap, int nwords, uint8_t* tile_dma = nullptr) {
   // LDS: [16 B pad][tile_rows][PITCH] raw pixels (+ alignment shift xo) | [tile_rows][PITCH] scores with a 1-px
   // zero frame | list | bitmap | word prefix.  PITCH is a compile-time constant so every circle / neighbour access is an
   // immediate offset.  Everything is sized by the launch for the cells it covers (tile_rows, list_cap, nwords = 64 or 256): the
   // LDS footprint of a workgroup decides how many of them a CU holds, and this kernel lives on residency.
-  uint8_t* tile = smem + 16;
-  uint8_t* sc = tile + tile_rows * PITCH;
+  uint8_t* tile = DMA ? tile_dma : smem + 16;
+  uint8_t* sc = DMA ? smem : tile + tile_rows * PITCH;
   uint16_t* list = (uint16_t*)(sc + tile_rows * PITCH);  // candidate pixels (bit 15: NMS survivor)
   uint32_t* bitmap = (uint32_t*)(list + list_cap);        // list_cap is a multiple of 8
   int* wpre = (int*)(bitmap + nwords);
   constexpr int NW = T / 64, WPT = 256 / T, P4 = PITCH / 4;
   __shared__ int wave_tot[NW];
   __shared__ int s_cnt;
+  __shared__ int s_any;
 
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   // this launch covers cells [cell_base, cell_base + ncells_sub) of every frame (level 0 runs as its own launch,
   // concurrently with the pyramid chain)
   const int frame = fast_div(L, m_ncells_sub), cell = cell_base + (L - frame * ncells_sub);
-  const CellGeom cg = cells[cell];
+  const CellGeom cg = DMA ? load_cell_scalar(cells, cell) : cells[cell];
   const uint8_t* img;
   int pitch;  // < 2^23 (checked on the host): row offsets are 24-bit multiplies
   if (cg.level == 0) { img = imgs + (long long)frame * img_frame_stride; pitch = (int)img_row_stride; }
   else { img = pyr + (long long)frame * pyr_frame_bytes + cg.plane_off; pitch = cg.pitch; }
   const int cw = cg.cw, ch = cg.ch, dw = cw - 6, dh = ch - 6;
   // ---- A: stage the sub-image with aligned dword loads when the source allows it
-  const bool al = ((pitch & 3) == 0) && ((((unsigned long long)img) & 3) == 0);
+  const bool al = DMA || (((pitch & 3) == 0) && ((((unsigned long long)img) & 3) == 0));   // DMA: the host only takes this path for aligned images
   const int xo = al ? (cg.x0 & 3) : 0;
-  if (al) {
+  if constexpr (DMA) {
+  } else if (PITCH == 64 && al && (stop_after & 0x200)) {   // a 64-byte tile pitch: one wave-instruction = four whole rows
+    // "fast_stage_dma": the same dwords straight into the tile by LDS-DMA (global_load_lds: no staging VGPRs, no ds_write pass); lane <->
+    // (row r0 + t / 16, dword t % 16), so the LDS image of one wave-instruction is 64 consecutive dwords = four tile rows.  The zeroing
+    // below runs while the loads are in flight; the barrier that ends stage A waits for them (vmcnt).
+    const uint8_t* src = img + (long long)cg.y0 * pitch + (cg.x0 - xo);
+    const int ndw = (xo + cw + 3) >> 2;
+    for (int r0 = 0; r0 < ch; r0 += T / 16) {
+      const int r = r0 + (t >> 4), c = t & 15;
+      uint8_t* dst = tile + (size_t)(r0 * 16 + (t & ~63)) * 4;   // wave-uniform; the hardware adds lane * 4
+      if (r < ch && c < ndw)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (uint32_t)(__mul24(r, pitch) + 4 * c)),
+                                         (__attribute__((address_space(3))) void*)dst, 4, 0, 0);
+    }
+  } else if (al) {
     const uint8_t* src = img + (long long)cg.y0 * pitch + (cg.x0 - xo);
     const int ndw = (xo + cw + 3) >> 2;
     for (int r = t >> 4; r < ch; r += T / 16)
@@ -432,8 +478,9 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
   }
   for (int i = t; i < ((dh + 2) * P4 + 3) >> 2; i += T) ((uint4*)sc)[i] = make_uint4(0u, 0u, 0u, 0u);  // sc is 16-byte aligned
   for (int i = t; i < nwords; i += T) bitmap[i] = 0;
-  if (t == 0) s_cnt = 0;
-  __syncthreads();
+  if (t == 0) { s_cnt = 0; s_any = 0; }
+  if (!DMA && PITCH == 64 && (stop_after & 0x200)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile's LDS-DMA loads (block-uniform)
+  cell_sync<DMA>();
   const int early = (stop_after >> 8) & 1;   // "fast_early": the wave-uniform early-out of stage B (same results)
   stop_after &= 0xff;
   if (stop_after == 1) {   // timing experiment only ("fast_stop" option): the cell reports no keypoint
@@ -514,7 +561,7 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
       const int tot = n0 + n1_ + n2 + n3;
       if (tot) {  // wave-uniform
         int base = 0;
-        if (lane == 0) base = atomicAdd(&s_cnt, tot);
+        if (lane == 0) base = DMA ? lds_add_rtn_opaque(&s_cnt, tot) : atomicAdd(&s_cnt, tot);
         base = __builtin_amdgcn_readfirstlane(base);
         // slot of pixel j of this lane: base + (passes of pixels < j in the wave) + (passes of pixel j in lower lanes);
         // v_mbcnt accumulates onto a scalar start value, so each slot costs two VALU instructions
@@ -530,7 +577,7 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
       }
     }
   }
-  __syncthreads();
+  cell_sync<DMA>();
   if (stop_after == 2) {
     if (t == 0) cell_cnt[(long long)frame * g->ncells_total + cell] = 0;
     return;
@@ -550,7 +597,7 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
     const int s = fast_score16(v, p);
     if (s >= min_th && s > 0) sc[(y + 1) * PITCH + (x + 1)] = (uint8_t)s;
   }
-  __syncthreads();
+  cell_sync<DMA>();
   // ---- D: 3x3 strict NMS inside the cell (neighbours outside the detection domain are 0)
   int any_ini = 0;
   for (int e = t; e < n1; e += T) {
@@ -567,7 +614,9 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
       }
     }
   }
-  const int use_ini = __syncthreads_or(any_ini);
+  int use_ini;
+  if constexpr (DMA) { if (any_ini) s_any = 1; raw_block_sync(); use_ini = s_any; }
+  else use_ini = __syncthreads_or(any_ini);
   const int TH = use_ini ? ini_th : min_th;
   // ---- E: bitmap of the selected survivors (bit index = row-major pixel index)
   for (int e = t; e < n1; e += T) {
@@ -575,10 +624,13 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
     if (le & 0x8000) {
       const int x = le & 127, y = (le >> 7) & 127;
       const int i = y * dw + x;
-      if (sc[(y + 1) * PITCH + (x + 1)] >= TH) atomicOr(&bitmap[i >> 5], 1u << (i & 31));
+      if (sc[(y + 1) * PITCH + (x + 1)] >= TH) {
+        if constexpr (DMA) lds_or_opaque(&bitmap[i >> 5], 1u << (i & 31));
+        else atomicOr(&bitmap[i >> 5], 1u << (i & 31));
+      }
     }
   }
-  __syncthreads();
+  cell_sync<DMA>();
   // ---- F: exclusive popcount prefix over the bitmap words
   const int npx = dw * dh;
   if (npx <= 2048) {  // block-uniform; the usual case: <= 64 words, one wave scans them, the others go straight on
@@ -598,7 +650,7 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
     if (lane == 63) wave_tot[wv] = inc;
-    __syncthreads();
+    cell_sync<DMA>();
     int off = 0, tot = 0;
 #pragma unroll
     for (int k = 0; k < NW; k++) { const int wt = wave_tot[k]; off += k < wv ? wt : 0; tot += wt; }
@@ -607,7 +659,7 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
     for (int k = 0; k < WPT; k++) { wpre[t * WPT + k] = run; run += cw_[k]; }
     if (t == 0) cell_cnt[(long long)frame * g->ncells_total + cell] = tot;
   }
-  __syncthreads();
+  cell_sync<DMA>();
   // ---- G: row-major rank of every selected survivor -> its slot
   uint32_t* slot = cand + (long long)frame * g->cand_total + cg.slot_off;
   for (int e = t; e < n1; e += T) {
@@ -637,6 +689,63 @@ __global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__
   if (L < 0) return;  // block-uniform
   fast_cell<T, PITCH, PK>(smem, L, g, cells, imgs, img_row_stride, img_frame_stride, pyr, pyr_frame_bytes, cand, cell_cnt, ini_th, min_th, tile_rows,
                           cell_base, ncells_sub, m_ncells_sub, stop_after, list_cap, nwords);
+}
+
+// The cells as a loop of `cpw` consecutive logical items per workgroup with the NEXT cell's tile arriving by LDS-DMA (global_load_lds: no
+// VGPRs, no ds_write pass) into a second tile buffer while the current cell is scored ("fast_dma" option: an experiment, see HISTORY.md).
+// LDS: [16 B pad][tile 0][16 B pad][tile 1][score plane | list | bitmap | word prefix].  Aligned sources and the 64-byte tile pitch only
+// (the host checks): one wave-instruction of the DMA writes 64 consecutive dwords = four whole tile rows.
+template <int T, int PITCH>
+__device__ __forceinline__ void fast_dma_issue(uint8_t* tile, const int L, const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
+                                               const uint8_t* __restrict__ imgs, long long img_row_stride, long long img_frame_stride,
+                                               const uint8_t* __restrict__ pyr, long long pyr_frame_bytes, int cell_base, int ncells_sub,
+                                               uint32_t m_ncells_sub) {
+  const int t = threadIdx.x;
+  const int frame = fast_div(L, m_ncells_sub), cell = cell_base + (L - frame * ncells_sub);
+  const CellGeom cg = load_cell_scalar(cells, cell);
+  const uint8_t* img;
+  int pitch;
+  if (cg.level == 0) { img = imgs + (long long)frame * img_frame_stride; pitch = (int)img_row_stride; }
+  else { img = pyr + (long long)frame * pyr_frame_bytes + cg.plane_off; pitch = cg.pitch; }
+  const int xo = cg.x0 & 3, ndw = (xo + cg.cw + 3) >> 2, ch = cg.ch;
+  const uint8_t* src = img + (long long)cg.y0 * pitch + (cg.x0 - xo);
+  // lane <-> (row r0 + t / 16, dword t % 16): the LDS image of one wave-instruction is 64 consecutive dwords = four tile rows
+  for (int r0 = 0; r0 < ch; r0 += T / 16) {
+    const int r = r0 + (t >> 4), c = t & 15;
+    uint8_t* dst = tile + (size_t)(r0 * 16 + (t & ~63)) * 4;   // wave-uniform; the hardware adds lane * 4
+    if (r < ch && c < ndw)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (uint32_t)(__mul24(r, pitch) + 4 * c)),
+                                       (__attribute__((address_space(3))) void*)dst, 4, 0, 0);
+  }
+}
+
+template <int T, int PITCH>
+__global__ __launch_bounds__(T, 6) void k_fast_cells_dma(const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
+                                                         const uint8_t* __restrict__ imgs, long long img_row_stride,
+                                                         long long img_frame_stride, const uint8_t* __restrict__ pyr,
+                                                         long long pyr_frame_bytes, uint32_t* __restrict__ cand,
+                                                         int32_t* __restrict__ cell_cnt, int ini_th, int min_th, int tile_rows,
+                                                         int nitems, int cell_base, int ncells_sub, uint32_t m_ncells_sub, int early,
+                                                         int list_cap, int nwords, int cpw) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  const int G = xcd_logical_block((nitems + cpw - 1) / cpw);
+  if (G < 0) return;  // block-uniform
+  const int L0 = G * cpw, n = min(cpw, nitems - L0);
+  uint8_t* tile0 = smem + 16;
+  uint8_t* tile1 = tile0 + tile_rows * PITCH + 16;
+  uint8_t* rest = tile1 + tile_rows * PITCH;
+  fast_dma_issue<T, PITCH>(tile0, L0, g, cells, imgs, img_row_stride, img_frame_stride, pyr, pyr_frame_bytes, cell_base, ncells_sub, m_ncells_sub);
+#pragma unroll 1
+  for (int i = 0; i < n; i++) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of tile i has landed ...
+    raw_block_sync();                                  // ... and so has everybody else's
+    if (i + 1 < n)   // the other buffer was last read in iteration i - 1, which ended with a barrier
+      fast_dma_issue<T, PITCH>((i & 1) ? tile0 : tile1, L0 + i + 1, g, cells, imgs, img_row_stride, img_frame_stride, pyr, pyr_frame_bytes, cell_base,
+                               ncells_sub, m_ncells_sub);
+    fast_cell<T, PITCH, true, true>(rest, L0 + i, g, cells, imgs, img_row_stride, img_frame_stride, pyr, pyr_frame_bytes, cand, cell_cnt, ini_th, min_th,
+                                    tile_rows, cell_base, ncells_sub, m_ncells_sub, early, list_cap, nwords, (i & 1) ? tile1 : tile0);
+    raw_block_sync();
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
