@@ -526,6 +526,36 @@ def test_device_std_sort_restatement_equals_the_host_permutation():
     assert cases == 260
 
 
+@pytest.mark.parametrize("opts", [dict(fast_stage_dma=1), dict(fast_stage_dma=0), dict(fast_dma=1), dict(fast_dma=3), dict(fast_dma=8, fast_stage_dma=0)])
+def test_fast_tile_staging_variants(opts):
+    """How a FAST cell's tile reaches LDS: LDS-DMA loads (global_load_lds, the default on aligned sources and the 64-byte tile pitch), plain
+    loads + ds_write (the fall-back: odd strides, wide cells), or the looped kernel with the NEXT cell's tile in flight while the current one is
+    scored ("fast_dma" = cells per workgroup: raw barriers, LDS atomics the compiler does not see) — same keypoints and descriptors on batches
+    and single frames, on an image whose row stride is odd, and on a geometry whose cells need the 96-byte tile pitch."""
+    ora = po.OracleExtractor(1000, 1.2, 8, 20, 7)
+    frames = synth.make_stream(7)
+    gpu = ORBextractor(1000, 1.2, 8, 20, 7)
+    for k, v in opts.items():
+        gpu.set_option(k, v)
+    want = [ora.extract(f, (0, 1000)) for f in frames]
+    for i, r in enumerate(gpu.extract_batch(frames, (0, 1000))):
+        assert_same(r, want[i], f"{opts} batch frame {i}")
+    assert_same(gpu(frames[3], None, (0, 1000)), want[3], f"{opts} single")
+    # odd row stride: a view into a wider buffer (the aligned-dword staging does not apply)
+    wide = np.zeros((480, 643), np.uint8)
+    wide[:, 1:641] = frames[2]
+    assert_same(gpu(wide[:, 1:641], None, (0, 1000)), want[2], f"{opts} odd stride")
+    # a 95-px-wide top level: one column of cells, 75 px wide -> the 96-byte tile pitch for the whole launch
+    ora2 = po.OracleExtractor(200, 1.2, 2, 20, 7)
+    gpu2 = ORBextractor(200, 1.2, 2, 20, 7)
+    for k, v in opts.items():
+        gpu2.set_option(k, v)
+    big = synth.make_stream(3, 100, 114, 5)
+    w2 = [ora2.extract(f, (0, 1000)) for f in big]
+    for i, r in enumerate(gpu2.extract_batch(np.stack([big[0], big[1], big[2], big[1], big[0]]), (0, 1000))):
+        assert_same(r, w2[(0, 1, 2, 1, 0)[i]], f"{opts} wide cells frame {i}")
+
+
 @pytest.mark.parametrize("shape,nlevels,sf", [((480, 640), 8, 1.2), ((480, 752), 8, 1.2), ((350, 600), 8, 1.2), ((400, 500), 3, 1.2), ((480, 640), 2, 1.2),
                                               ((600, 800), 5, 1.5), ((1024, 1024), 8, 1.2)])
 @pytest.mark.parametrize("opts", [dict(small_fused=1, graph=1), dict(small_fused=1, graph=0), dict(small_fused=0, graph=1), dict(small_fused=0, graph=0),

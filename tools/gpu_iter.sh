@@ -1,4 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 300 python tools/fuzz_extractor.py 9000 80 2>&1 | tail -4
-timeout 300 python tools/fuzz_extractor.py 9500 200 2>&1 | tail -2
-ORBX_FAST_DMA=3 timeout 300 python tools/fuzz_extractor.py 9000 80 2>&1 | tail -2
+timeout 600 python -m pytest tests/test_gpu_extractor.py -x -q -m gpu -k "staging_variants" 2>&1 | tail -5
