@@ -105,11 +105,30 @@ __device__ __forceinline__ void resize_tile(uint8_t* smem, const int L, const ui
     // thread = (dword column c, row phase of nph = 256 / lp4): the column-only work once, then down the column nph rows at a time
     const int lp4 = lds_pitch >> 2, swr = (sw + 3) & ~3;
     const int rph = fast_div(t, m_lp4), c = t - rph * lp4;
+#ifndef ORBX_RESIZE_NO_DMA
+    // LDS-DMA loads: the LDS dword index of (row rph + k nph, column c) is t + k nph lp4 — lane-linear, as global_load_lds writes
+    // (wave-uniform base + lane * 4); no staging registers, no ds_write pass
+    {
+      const bool mine = rph < nph && X0 + 4 * c < swr;
+      const uint8_t* sp = S + 4 * c;
+      const int stride = __mul24(nph, lp4);
+      for (int r0 = 0; r0 < nrows; r0 += nph) {   // block-uniform trip count
+        const int r = r0 + rph;
+        uint32_t* dp = (uint32_t*)smem + __mul24(r0, lp4) + (t & ~63);
+        (void)stride;
+        if (mine && r < nrows)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sp + (uint32_t)__mul24(r, src_pitch)),
+                                           (__attribute__((address_space(3))) void*)dp, 4, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#else
     if (rph < nph && X0 + 4 * c < swr) {
       const uint8_t* sp = S + 4 * c;
       uint32_t* dp = (uint32_t*)smem + c;
       for (int r = rph; r < nrows; r += nph) dp[__mul24(r, lp4)] = *(const uint32_t*)(sp + (uint32_t)__mul24(r, src_pitch));
     }
+#endif
   } else {
 #pragma unroll 1  // cold path: keep it out of the register budget
     for (int r = t >> 6; r < nrows; r += 4) {
