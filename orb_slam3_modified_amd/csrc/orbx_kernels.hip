@@ -2735,6 +2735,18 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
         uint32_t off = wbase + (uint32_t)(__mul24(rph, bp) + 4 * dcol);
         const uint32_t step = 6u * (uint32_t)bp;
         uint32_t* lp = (uint32_t*)sp + lane;   // row rph, column dcol
+#ifndef ORBX_DESC_NO_DMA
+        // LDS-DMA loads: the slice's dword index is lane + 60 k — lane-linear, as global_load_lds writes it
+        (void)lp;
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+          if (lane < 60 && rph + 6 * k < 37)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bplane + off),
+                                             (__attribute__((address_space(3))) void*)((uint32_t*)sp + 60 * k), 4, 0, 0);
+          off += step;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
         if (lane < 60) {
 #pragma unroll
           for (int k = 0; k < 7; k++) {
@@ -2742,6 +2754,7 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
             off += step;
           }
         }
+#endif
       }
       wave_lds_sync();
       const int lctr = 18 * 40 + 18 + sh2;
