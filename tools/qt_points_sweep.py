@@ -15,8 +15,10 @@ for pts in (2048, 1536, 1280, 1024, 768):
     pr = ex.profile_read(); ex.profile_enable(False)
     ms, n = pr["k_quadtree"]
     print(f"qt_points {pts}: k_quadtree {1000*ms/max(n,1):.1f} us per 256 frames, same={dig==ref}", flush=True)
-for pts in (2048, 1280, 1024):
-    r = subprocess.run([sys.executable, "bench.py", "--steps", "40", "--warmup", "5", "--no-secondary", "--no-cpu-baseline", "--no-frontend", "--no-verify"],
+for pts in (2048, 1536, 1024, 768):
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "30", "--warmup", "5", "--no-cpu-baseline", "--no-frontend", "--no-verify"],
                        capture_output=True, text=True, env=dict(os.environ, ORBX_QT_POINTS=str(pts)))
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    print(f"bench ORBX_QT_POINTS={pts}: ms_per_step {j['ms_per_step']} value {j['value']}", flush=True)
+    nat = j["secondary_natural"]
+    print(f"bench ORBX_QT_POINTS={pts}: ms_per_step {j['ms_per_step']} value {j['value']} k_quadtree {j['roofline']['kernels_ms_per_launch']['k_quadtree']}"
+          f" | natural {nat['value']} k_quadtree {nat['kernels_ms_per_launch']['k_quadtree']} | config 4 {j['secondary']['value']}", flush=True)
