@@ -500,7 +500,11 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
   if (t == 0) { s_cnt = 0; s_any = 0; }
   if (!DMA && PITCH == 64 && (stop_after & 0x200)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile's LDS-DMA loads (block-uniform)
   cell_sync<DMA>();
-  const int early = (stop_after >> 8) & 1;   // "fast_early": the wave-uniform early-out of stage B (same results)
+#ifdef ORBX_FAST_EARLY_OPTION
+  const int early = (stop_after >> 8) & 1;   // "fast_early": the wave-uniform early-out of stage B (same results; measured at +-1 %, HISTORY.md)
+#else
+  constexpr int early = 0;                   // the option is compiled out: its uniform branches cost the loop more than the skip ever saved
+#endif
   stop_after &= 0xff;
   if (stop_after == 1) {   // timing experiment only ("fast_stop" option): the cell reports no keypoint
     if (t == 0) cell_cnt[(long long)frame * g->ncells_total + cell] = 0;
