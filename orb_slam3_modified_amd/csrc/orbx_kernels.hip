@@ -2340,6 +2340,28 @@ __device__ __forceinline__ void blur_tile(const int L, const DeviceGeom* __restr
     // reflected columns are patched below
     // thread = (column c of 18 dwords, row phase of 14): everything that depends on the column only is computed once,
     // the thread then walks down its column 14 rows at a time (252 of the 256 threads take part)
+#ifndef ORBX_BLUR_NO_DMA
+    if (y0 >= 3 && y0 - 3 + kBT_RR <= h) {   // block-uniform: an interior tile, every source row exists
+      // LDS-DMA loads: thread = (row phase of 10, dword column of the 24-dword LDS row): the LDS dword index of (row rph + 10 k, column c) is
+      // t + 240 k — lane-linear.  The six dwords per row that hold no pixel and the dwords left / right of the level are not loaded (never
+      // read with a non-zero weight, or patched below).
+      if (t < 10 * (kBT_RP / 4)) {
+        const int rph = (int)(((uint32_t)t * 2731u) >> 16), c = t - rph * (kBT_RP / 4);  // t / 24
+        const int sx = x0 - 4 + 4 * c;
+        const bool inx = c < kBT_RB / 4 && sx >= 0 && sx < w;
+        const uint8_t* colp = img + (int)(__mul24(y0 - 3 + rph, pitch) + sx);
+        const int step = __mul24(10, pitch);
+#pragma unroll
+        for (int k = 0; k < (kBT_RR + 9) / 10; k++) {
+          uint32_t* dst = (uint32_t*)raw + 240 * k + (t & ~63);   // wave-uniform; the hardware adds lane * 4
+          if (inx && rph + 10 * k < kBT_RR)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(colp + k * step),
+                                             (__attribute__((address_space(3))) void*)dst, 4, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else
+#endif
     if (t < 14 * (kBT_RB / 4)) {
       const int rph = (int)(((uint32_t)t * 3641u) >> 16), c = t - rph * (kBT_RB / 4);  // t / 18
       const int sx = x0 - 4 + 4 * c;
