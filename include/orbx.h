@@ -118,16 +118,22 @@ int orbx_reserve(orbx_ctx* ctx, int rows, int cols, int nframes);
 /* Options of one context.  Scheduling / launch-shape knobs (results never depend on them; the ORBX_* environment variables set
  * the defaults at orbx_create): "fork_blur" | "fork_fast0" | "fork_qt" (0|1: run that kernel on a second stream
  * beside its neighbour), "graph" (0|1), "fast_threads" (64|128|256), "fast_pk" (0|1), "desc_k" (1|2|4|8|16),
- * "desc_lds" (0|1), "streams" (1|2).
- * The two options that DO change results — they select which OpenCV release's cv::GaussianBlur(7x7, sigma 2) of CV_8UC1 the blur in
- * front of the descriptors (src/ORBextractor.cc:1133) equals, bit for bit (INTEGRATION.md section 6 has the release table, and
- * tools/validate_opencv.cpp tells a maintainer which pair his OpenCV build needs; also ORBX_GAUSS_KERNEL / ORBX_GAUSS_ROUND in the
- * environment at orbx_create):
- *   "gauss_kernel"  0 (default) = 8.8 weights {18,34,48,56,48,34,18}, rounding error diffused, sum 256 — OpenCV >= 4.5.1;
+ * "desc_lds" (0|1), "streams" (1|2), "fast_stage_dma" (0|1: the FAST tile by LDS-DMA loads), "qt_fused" (0|1), ... — the full table with
+ * defaults is INTEGRATION.md section 7.
+ * The FIVE options that DO change results select which build of "the reference CPU path" the output equals, bit for bit (INTEGRATION.md
+ * section 6 has the release table; include/orbx_cv_calibrate.h finds the values for the OpenCV at hand, tools/validate_opencv.cpp checks
+ * them; also ORBX_GAUSS_KERNEL / ORBX_GAUSS_ROUND / ORBX_GAUSS_TAIL / ORBX_ATAN_FMA / ORBX_BRIEF_FMA in the environment at orbx_create):
+ *   "gauss_kernel"  cv::GaussianBlur(7x7, sigma 2) of CV_8UC1 (src/ORBextractor.cc:1133), the 8.8 fixed-point weights:
+ *                   0 (default) = {18,34,48,56,48,34,18}, rounding error diffused, sum 256 — OpenCV >= 4.5.1;
  *                   1 = {18,34,49,55,49,34,18}, every coefficient rounded on its own, sum 257 — OpenCV 3.x .. 4.5.0
- *   "gauss_round"   0 (default) = (acc + 2^15) >> 16; 1 = exact ties to even, except in the last (width mod 4) columns (the SSE2
- *                   column pass of OpenCV <= 3.4.1); 2 = floor (the SIMD column pass of 3.4.2 .. 4.5.0 under the 257 kernel).
- *                   Every variant saturates to 255. */
+ *   "gauss_round"   its column pass: 0 (default) = (acc + 2^15) >> 16; 1 = exact ties to even; 2 = floor.  Every variant saturates to 255.
+ *   "gauss_tail"    V in {0, 4, 8, 16, 32, 64}: the last (width mod V) columns of every row round as "gauss_round" 0 — the scalar tail of a
+ *                   SIMD column loop of vector length V (0 = no tail)
+ *   "atan_fma"      cv::fastAtan2 (src/ORBextractor.cc:102): 0 (default) = separate multiply / add; 1 = the Horner steps and 90 - p*c fused
+ *                   (OpenCV's AVX2 dispatch copy)
+ *   "brief_fma"     the reference's own pattern rotation (src/ORBextractor.cc:118-120): 0 (default) = separate operations;
+ *                   1 = fma(x, b, y*a), fma(x, a, -(y*b)) — what -march=native makes of it on an FMA machine
+ * Unknown names and out-of-range values return ORBX_E_INVALID. */
 int orbx_set_option(orbx_ctx* ctx, const char* name, int value);
 int orbx_host_pyramid_level(orbx_ctx* ctx, int level, const uint8_t** data, size_t* stride, int* w, int* h);
 

@@ -1,11 +1,13 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_gpu_extractor.py tests/test_opencv_variants.py -x -q -m gpu -k "stage_parity or random_shapes or blur or other_param" 2>&1 | tail -2
-timeout 300 python tools/fuzz_extractor.py 13000 100 2>&1 | tail -1
-b() { timeout 200 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-frontend --no-secondary 2>/dev/null | python -c "
+for l in 2 3 4 2 3; do
+timeout 200 python bench.py --lanes $l --steps 30 --warmup 5 --no-cpu-baseline --no-frontend --no-secondary 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-k=d['roofline']['kernels_ms_per_launch']
-print('$1', d['value'], d['ms_per_step'], k['k_blur7'])"; }
-b blurdma; b blurdma; b blurdma
-python -m orb_slam3_modified_amd.build --force > /dev/null 2>&1
-b plain; b plain; b plain
+print('lanes $l', d['value'], d['ms_per_step'])"
+done
+for e in "ORBX_FORK_BLUR=0" "ORBX_FORK_FAST0=0" "ORBX_FORK_QT=0" "ORBX_CHAIN_BATCH=1" "ORBX_QT_ONE_LAUNCH=1"; do
+env $e timeout 200 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-frontend --no-secondary 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$e', d['value'], d['ms_per_step'])"
+done
