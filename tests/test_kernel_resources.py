@@ -27,11 +27,18 @@ def test_no_kernel_uses_scratch_memory():
         procs.append((src, out, subprocess.Popen(["hipcc"] + flags + ["-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, src)],
                                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     kernels, bad = 0, []
+    dma = {}   # kernel symbol -> number of LDS-DMA loads in its body
     for src, out, p in procs:
         log, _ = p.communicate()
         assert p.returncode == 0, log[-2000:]
         name = None
+        body = None
         for line in open(out):
+            m = re.match(r"(_Z\w+):\s", line)
+            if m:
+                body = m.group(1)
+            if body and "global_load_lds_dword" in line:
+                dma[body] = dma.get(body, 0) + 1
             m = re.match(r"\s*\.amdhsa_kernel\s+(\S+)", line)
             if m:
                 name = m.group(1)
@@ -42,3 +49,7 @@ def test_no_kernel_uses_scratch_memory():
     shutil.rmtree(tmp, ignore_errors=True)
     assert kernels >= 30
     assert not bad, bad
+    # the kernels that stage a tile / rectangle / window fill it by LDS-DMA: the builtin must have survived the compiler
+    for frag in ("k_fast_cellsILi128ELi64ELb1", "k_fast_blurILi64ELb1", "k_resize", "k_blur7", "k_describeILi4ELb1ELb0"):
+        hit = [k for k in dma if frag in k]
+        assert hit, (frag, sorted(dma))
