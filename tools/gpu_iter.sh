@@ -1,10 +1,5 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_gpu_extractor.py tests/test_natural_images.py -x -q -m gpu -k "not exhaustive and not billion and not capacities" 2>&1 | tail -2
-timeout 300 python tools/fuzz_extractor.py 14000 100 2>&1 | tail -1
-for rep in 1 2 3; do for c in 0 1; do
-ORBX_DESC_MASK_TABLE=$c timeout 200 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-frontend --no-secondary 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-k=d['roofline']['kernels_ms_per_launch']
-print('mask_table $c', d['value'], d['ms_per_step'], k['k_describe'])"
-done; done
+( time timeout 420 python tools/fuzz_extractor.py 20000 900 ) > gpurun_out/fuzz_r4e_900.log 2>&1; grep "configurations" gpurun_out/fuzz_r4e_900.log; grep -c MISMATCH gpurun_out/fuzz_r4e_900.log
+( time timeout 300 python tools/fuzz_extractor.py 30000 500 --variants ) > gpurun_out/fuzz_r4e_variants_500.log 2>&1; grep "configurations" gpurun_out/fuzz_r4e_variants_500.log; grep -c MISMATCH gpurun_out/fuzz_r4e_variants_500.log
+( time timeout 200 python tools/fuzz_worlds.py 700 10 ) > gpurun_out/fuzz_worlds_r4e.log 2>&1; tail -4 gpurun_out/fuzz_worlds_r4e.log | head -1
+( time timeout 200 python tools/fuzz_frame_world.py 60 20 ) > gpurun_out/fuzz_frame_world_r4e.log 2>&1; tail -4 gpurun_out/fuzz_frame_world_r4e.log | head -1

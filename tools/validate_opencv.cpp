@@ -143,8 +143,10 @@ int main(int argc, char** argv) {
               cal.atan_exact ? "exact" : "NEITHER FORM MATCHES", cal.brief_fma, cal.brief_fma ? "contracts" : "does not contract");
   std::printf("  -> orbx_set_option(ctx, \"gauss_kernel\", %d); (\"gauss_round\", %d); (\"gauss_tail\", %d); (\"atan_fma\", %d); (\"brief_fma\", %d)   [include/ORBextractor.h does this itself]\n",
               cal.gauss_kernel, cal.gauss_round, cal.gauss_tail, cal.atan_fma, cal.brief_fma);
+  std::printf("std::sort of this toolchain (tie order of DistributeOctTree's node vector, src/ORBextractor.cc:700): %s\n",
+              cal.sort_libstdcxx ? "libstdc++'s — the order liborbx restates" : "NOT libstdc++'s: keypoint order WILL differ from liborbx (no option exists for this)");
   orbo_set_gauss_variant(cal.gauss_kernel, cal.gauss_round); orbo_set_gauss_tail(cal.gauss_tail); orbo_set_atan_fma(cal.atan_fma); orbo_set_brief_fma(cal.brief_fma);
-  int failures = (cal.gauss_exact ? 0 : 1) + (cal.atan_exact ? 0 : 1);
+  int failures = (cal.gauss_exact ? 0 : 1) + (cal.atan_exact ? 0 : 1) + (cal.sort_libstdcxx ? 0 : 1);
 
   std::vector<Img> set;
   if (set_path) { if (!load_set(set_path, set)) { std::fprintf(stderr, "cannot read %s\n", set_path); return 2; } }
