@@ -919,6 +919,7 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, 
     const char* fpk = getenv("ORBX_FAST_PK");   // packed 16-bit necessary test in k_fast_cells (128-thread workgroups)
     ctx->fast_pk = fpk ? atoi(fpk) != 0 : true;
     { const char* e = getenv("ORBX_FAST_EARLY"); ctx->fast_early = e ? atoi(e) != 0 : false; }
+    { const char* e = getenv("ORBX_REALIGN"); ctx->realign = e ? atoi(e) != 0 : true; }
     { const char* e = getenv("ORBX_FAST_STAGE_DMA"); ctx->fast_stage_dma = e ? atoi(e) != 0 : true; }
     { const char* e = getenv("ORBX_FAST_DMA"); if (e && atoi(e) >= 0 && atoi(e) <= 64) ctx->fast_dma = atoi(e); }
     const char* fs = getenv("ORBX_FAST_STOP");
@@ -951,7 +952,7 @@ void orbx_destroy(orbx_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   free_buffers(ctx);
   auto fr = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
-  fr(ctx->d_stage_img); fr(ctx->d_stage_out); fr(ctx->d_knn_ws);
+  fr(ctx->d_stage_img); fr(ctx->d_stage_out); fr(ctx->d_knn_ws); fr(ctx->d_realign);
   ctx->arena.release();
   if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
   if (ctx->h_in) { (void)hipHostFree(ctx->h_in); ctx->h_in = nullptr; }
@@ -1017,6 +1018,21 @@ int orbx_extract_batch_device(orbx_ctx* ctx, const uint8_t* d_imgs, int nframes,
   if (rc != ORBX_OK) return rc;
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
   ctx->last_ext_stream = stream ? (hipStream_t)stream : nullptr;
+  // frames whose rows are not dword-aligned take one pass into an aligned copy ("realign" option; k_realign_rows says why); level 0 of this
+  // extraction — what the stereo pass, the debug readers and the pyramid accessors see — is then that copy
+  if (ctx->realign && nframes > 1 && ((row_stride & 3) != 0 || (frame_stride & 3) != 0 || ((uintptr_t)d_imgs & 3) != 0)) {
+    const size_t ap = (size_t)round_up(cols, 64), need = (size_t)nframes * rows * ap;
+    if (need > ctx->realign_bytes) {
+      ORBX_HIP(ctx, sync_ctx(ctx));
+      if (ctx->d_realign) (void)hipFree(ctx->d_realign);
+      ctx->d_realign = nullptr; ctx->realign_bytes = 0;
+      ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_realign, need));
+      ctx->realign_bytes = need;
+    }
+    hipLaunchKernelGGL(k_realign_rows, dim3((unsigned)((ap / 4 + 255) / 256), (unsigned)rows, (unsigned)nframes), dim3(256), 0, st, d_imgs,
+                       (long long)row_stride, (long long)frame_stride, ctx->d_realign, (int)ap, rows, cols);
+    d_imgs = ctx->d_realign; row_stride = ap; frame_stride = (size_t)rows * ap;
+  }
   ctx->last_imgs = d_imgs; ctx->last_row_stride = row_stride; ctx->last_frame_stride = frame_stride;
   ctx->last_nframes = nframes;
   // Sub-batches on concurrent streams: frames are independent, and the pipeline alternates VALU-bound kernels
@@ -1452,6 +1468,7 @@ int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
   else if (n == "graph") ctx->use_graph = value != 0;
   else if (n == "graph_timing") { ctx->graph_timing = value != 0; return ORBX_OK; }   // no re-capture needed
   else if (n == "fast_pk") ctx->fast_pk = value != 0;
+  else if (n == "realign") ctx->realign = value != 0;   // batch frames with rows that are not dword-aligned: one pass into an aligned copy first
   else if (n == "fast_stage_dma") ctx->fast_stage_dma = value != 0;   // FAST tile staged by LDS-DMA loads instead of load + ds_write
   else if (n == "fast_dma" && value >= 0 && value <= 64) ctx->fast_dma = value;   // cells per FAST workgroup with LDS-DMA tile prefetch (0 = off; experiment)
   else if (n == "fast_early") ctx->fast_early = value != 0;   // wave-uniform early-out of the FAST pre-test after the compass pairs

@@ -152,6 +152,9 @@ struct orbx_ctx {
   hipEvent_t ev_f0_fork[2] = {nullptr, nullptr}, ev_f0_join[2] = {nullptr, nullptr};
   hipEvent_t ev_qt_fork[2] = {nullptr, nullptr}, ev_qt_join[2] = {nullptr, nullptr};
   bool fork_blur = true, fork_fast0 = false, fork_qt = true, fast_pk = true, desc_lds = true, fast_early = false;
+  bool realign = true;          // batch calls: frames whose rows are not dword-aligned are copied into an aligned buffer first
+  uint8_t* d_realign = nullptr;
+  size_t realign_bytes = 0;
   bool fast_stage_dma = true;   // FAST: the cell's tile by LDS-DMA loads (aligned sources; stop_after bit 9)
   int fast_dma = 0;   // experiment: cells per FAST workgroup with the next tile prefetched by LDS-DMA (0 = one cell per workgroup, no DMA)
   int qt_points = 2048;       // LDS-resident candidate capacity per (frame, level) of k_quadtree's big levels ("qt_points" / ORBX_QT_POINTS)

@@ -187,6 +187,23 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
                      m_tiles, m_nbx, m_lp4, nph);
 }
 
+// Batch frames whose rows are not dword-aligned (odd strides: KITTI's 1241- and 1226-px rows, ROI views) into an aligned copy: every kernel
+// that reads level 0 — the first resize, FAST, blur, the descriptors' orientation patch — has a slow byte-wise path for such sources
+// (measured on 1241 x 376: resize +46 %, blur +40 %, FAST +14 %, the step +17 %), and one pass over the pixels costs less than that.
+// grid = (dwords of a row / 256, rows, frames); the padding bytes of the copy are zero.
+__global__ __launch_bounds__(256) void k_realign_rows(const uint8_t* __restrict__ src, long long src_row_stride, long long src_frame_stride,
+                                                      uint8_t* __restrict__ dst, int dst_pitch, int rows, int cols) {
+  const int c4 = (int)(blockIdx.x * 256 + threadIdx.x), r = (int)blockIdx.y, f = (int)blockIdx.z;
+  if (4 * c4 >= dst_pitch) return;
+  const uint8_t* s = src + (long long)f * src_frame_stride + (long long)r * src_row_stride + 4 * c4;
+  uint32_t v = 0;
+  if (4 * c4 + 3 < cols) __builtin_memcpy(&v, s, 4);   // no alignment promised: the compiler picks what the target guarantees
+  else
+#pragma unroll
+    for (int j = 0; j < 4; j++) v |= (uint32_t)((4 * c4 + j < cols) ? s[j] : 0) << (8 * j);
+  *(uint32_t*)(dst + ((long long)f * rows + r) * dst_pitch + 4 * c4) = v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1, small batches: K consecutive pyramid levels in ONE launch.  Inside the single-frame graph every launch costs about 5 us whatever
 // it does, and the seven dependent resizes were 38 us of a 150 us frame.  Here a workgroup owns one 64x64 tile of the LAST level of

@@ -526,6 +526,26 @@ def test_device_std_sort_restatement_equals_the_host_permutation():
     assert cases == 260
 
 
+@pytest.mark.parametrize("realign", [1, 0])
+@pytest.mark.parametrize("rows,cols", [(376, 1241), (370, 1226), (240, 643)])
+def test_batches_of_frames_with_odd_row_strides(rows, cols, realign):
+    """KITTI's 1241- and 1226-px rows (Examples/*/KITTI00-02.yaml, KITTI04-12.yaml) are not dword-aligned: a batch of such frames is copied
+    into an aligned buffer first ("realign", k_realign_rows) — or, with the option off, takes the kernels' byte-wise staging paths.  Same
+    keypoints, descriptors and pyramid either way, also for a batch that is a strided view (odd frame stride) of a larger block."""
+    nf = 1500
+    frames = synth.make_stream(4, rows, cols, 31 + cols)
+    ora = po.OracleExtractor(nf, 1.2, 8, 20, 7)
+    want = [ora.extract(f, (0, cols)) for f in frames]
+    gpu = ORBextractor(nf, 1.2, 8, 20, 7)
+    gpu.set_option("realign", realign)
+    for rep in range(2):
+        for i, r in enumerate(gpu.extract_batch(frames, (0, cols))):
+            assert_same(r, want[i], f"{cols}x{rows} realign {realign} rep {rep} frame {i}")
+    ora.extract(frames[2], (0, cols))
+    for l in (0, 1, 3):
+        assert np.array_equal(gpu.pyramid_level(l, frame=2), ora.level(l)), (cols, rows, realign, l)
+
+
 @pytest.mark.parametrize("opts", [dict(fast_stage_dma=1), dict(fast_stage_dma=0), dict(fast_dma=1), dict(fast_dma=3), dict(fast_dma=8, fast_stage_dma=0)])
 def test_fast_tile_staging_variants(opts):
     """How a FAST cell's tile reaches LDS: LDS-DMA loads (global_load_lds, the default on aligned sources and the 64-byte tile pitch), plain
