@@ -1,16 +1,20 @@
 #!/usr/bin/env python3
 """Randomised worlds through the three scenario drivers: the REFERENCE's own src/ORBmatcher.cc / src/KeyFrameDatabase.cc /
 per-frame loop (oracle/_ref/*, prebuilt) against the drop-ins on the GPU, outputs compared as text / digests.
-    python tools/fuzz_worlds.py [first_seed] [count]"""
+    python tools/fuzz_worlds.py [first_seed] [count] [--backend oracle]
+--backend oracle: the drop-ins linked against the oracle-backed C-ABI stub instead of liborbx.so — no GPU needed; what it pins at scale is the
+adapters' own logic (pre-pass, replay order, side effects, the keyframe database's bookkeeping) against the reference's files."""
 import os, sys, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tests import world_util as wu
 
-first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-count = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-mexe, kexe, fexe = wu.build_adapter_world("orbx"), wu.build_kfdb_world("orbx"), wu.build_frontend("orbx")
+backend = "oracle" if "--backend" in sys.argv and sys.argv[sys.argv.index("--backend") + 1] == "oracle" else "orbx"
+_argv = [a for i, a in enumerate(sys.argv) if not a.startswith("--") and (i == 0 or sys.argv[i - 1] != "--backend")]
+first = int(_argv[1]) if len(_argv) > 1 else 100
+count = int(_argv[2]) if len(_argv) > 2 else 20
+mexe, kexe, fexe = wu.build_adapter_world(backend), wu.build_kfdb_world(backend), wu.build_frontend(backend)
 bad = 0
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
