@@ -79,7 +79,8 @@ class ORBextractor {
       _descriptors.create(n, 32, CV_8U);
       cv::Mat d = _descriptors.getMat();
       for (int i = 0; i < n; i++) std::memcpy(d.ptr<unsigned char>(i), desc_.data() + (size_t)i * 32, 32);
-      // this buffer (Frame::mDescriptors) now holds the rows the context still has in HBM: the first search of the frame takes them from there
+      // this buffer (Frame::mDescriptors) holds the rows of the context's last extraction: ORBVocabulary::transform on it (Frame::ComputeBoW) finds
+      // the records the extraction graph already computed
       if (d.isContinuous()) orbx_publish_descriptors(ctx_, d.ptr<unsigned char>(0), n);
     }
     _keypoints.resize(n);

@@ -98,12 +98,12 @@ int orbx_extract_batch(orbx_ctx* ctx, const uint8_t* imgs, int nframes, int rows
  * (the reference's stereo matcher reads it, src/Frame.cc:818,908-925).  dst may be NULL to query w/h. */
 int orbx_pyramid_level(orbx_ctx* ctx, int frame, int level, uint8_t* dst, size_t dst_stride, int* w, int* h);
 
-/* Hand-over extractor -> search target without a host round trip.  After orbx_extract / orbx_extract_color /
- * orbx_extract_resized the context still holds the frame's descriptor rows in HBM.  An adapter that has copied those rows into the
- * caller's own buffer (Frame::mDescriptors) names that buffer here; when orbx_target_create / orbx_target_assign are later given the
- * very same `desc` pointer and count (on the same device, before this context extracts again), the target takes the rows from HBM
- * inside its staging kernel instead of reading the host copy over PCIe.  Contract (the reference's own): nobody writes into the
- * buffer between the extraction and the first search.  n = the extraction's keypoint count; a mismatch simply disables the hand-over. */
+/* "Whose rows are these": after orbx_extract / orbx_extract_color / orbx_extract_resized an adapter that has copied the frame's descriptor
+ * rows into the caller's own buffer (Frame::mDescriptors, src/Frame.cc:311) names that buffer here, so that a later
+ * orbx_bow_transform_published on the very same buffer finds the records the extraction graph already computed (below).  Contract (the
+ * reference's own): nobody writes into the buffer after the extraction.  n = the extraction's keypoint count; a mismatch makes the call a
+ * no-op.  (Rounds 3-4 also handed these rows to the first search target made from the buffer, device to device; that path measured
+ * slower than the host rows — 58.0 vs 51.2 us for the first search of a frame — and was removed: targets always take the host bytes.) */
 int orbx_publish_descriptors(orbx_ctx* ctx, const void* host_desc, int n);
 
 /* Host mirror of mvImagePyramid for the single-frame path: with orbx_set_host_pyramid(ctx, 1) every orbx_extract also
@@ -446,7 +446,7 @@ int orbx_bow_transform_device(orbx_voc* voc, const uint8_t* d_desc, int n, int l
  * (src/Frame.cc:738-745 after :311).  Returns ORBX_OK when the extraction's own graph already ran the descent with this vocabulary and
  * levelsup (the records are copied from the context's pinned result block: no device round trip), 1 when it did not — the caller then
  * uses orbx_bow_transform; the first such call attaches the vocabulary to the publishing context, so that from its next extraction on
- * the single-frame graph ends with the descent.  The buffer must still hold the published bytes (digest), as for the target hand-over. */
+ * the single-frame graph ends with the descent.  The buffer must still hold the published bytes (a digest of them is compared). */
 int orbx_bow_transform_published(orbx_voc* voc, const void* host_desc, int n, int levelsup, uint32_t* word, double* weight, uint32_t* node);
 /* BowVector accumulate (addWeight) + normalize(L1): out ids ascending, values double; returns nnz in *n_out.
  * ids/vals hold n entries. */

@@ -43,7 +43,12 @@ struct Calibration {
   int gauss_mismatch = 0, atan_mismatch = 0;      // differing bytes / angles of the closest variant otherwise
   int gauss_candidates = 0;                       // variants that reproduce the probe (>= 1 when gauss_exact)
   bool sort_libstdcxx = true;                     // this toolchain's std::sort leaves equal keys in libstdc++'s order (the one liborbx restates)
+  int brief_form = 0;                             // build_contraction_form(): 0 unfused, 1 the form brief_fma = 1 reproduces, -1 a form liborbx does not have
+  int frame_w = 0, frame_h = 0, frame_mismatch = -1;   // second probe at a real frame size: bytes at which the chosen variant differs (-1: not run)
 };
+
+constexpr int kFrameProbeW = 752, kFrameProbeH = 480;   // EuRoC's native size: wide enough for any size-dependent path of cv::GaussianBlur (IPP,
+                                                        // OpenCL, parallel_for_ stripes) to show itself; 752 mod V covers the tails of V = 32, 64
 
 constexpr int kProbeW = 127, kProbeH = 72;   // 127 mod V differs for V = 4, 8, 16, 32, 64: every tail length is visible
 
@@ -113,34 +118,48 @@ inline float atan_variant(float y, float x, int fma) {
   return a;
 }
 
-/* (3): does THIS translation unit (= the flags src/ORBextractor.cc would have been compiled with) contract x*b + y*a ?  One operand set
- * at which the fused and the unfused form round to different integers (found by tests/support/contract_probe.cpp's sweep). */
+/* (3): does THIS translation unit (= the flags src/ORBextractor.cc would have been compiled with) contract the pattern rotation of
+ * src/ORBextractor.cc:118-120, and HOW?  Two expressions, x*b + y*a and x*a - y*b, each with two ways to fuse: the FIRST product into the
+ * FMA (form A: fma(x, b, y*a), fma(x, a, -(y*b)) — what GCC and clang emit, and what liborbx's brief_fma = 1 reproduces) or the SECOND
+ * (form B: fma(y, a, x*b), fma(-y, b, x*a)).  Operand sets at which exactly one form rounds to another integer than the unfused
+ * expression (found by a sweep over 4e8 sets of the pattern's coordinate range; both forms never differ on one set) tell them apart.
+ * The probes are `static`: every translation unit that includes this header gets ITS OWN copy, compiled with ITS flags (an `inline`
+ * function would be merged by the linker into one copy of unknown flags). */
 #if defined(__GNUC__)
-__attribute__((noinline))
+#define ORBX_CV_NOINLINE __attribute__((noinline, unused))
+#else
+#define ORBX_CV_NOINLINE
 #endif
-inline int contraction_probe(const int* p, const float* ab) { return (int)std::lrint(p[0] * ab[1] + p[1] * ab[0]); }
-inline int build_contracts_fma() {
-  // {x, y, bits of a = cos, bits of b = sin}: cvRound(x*b + y*a) is 14 / 6 / 2 unfused and 13 / 7 / 1 fused
-  static const int32_t kOps[3][4] = {{-12, 10, 0x3e2ad13d, (int32_t)0xbf7c69bdu}, {9, 4, (int32_t)0xbed644d7u, 0x3f688114}, {-9, -10, (int32_t)0xbf3f6716u, 0x3f2a00c4}};
-  int votes_fused = 0, votes_unfused = 0;
-  for (int i = 0; i < 3; i++) {
-    volatile int32_t vx = kOps[i][0], vy = kOps[i][1], va = kOps[i][2], vb = kOps[i][3];   // opaque to constant folding
+static ORBX_CV_NOINLINE int contraction_probe_sum(const int* p, const float* ab) { return (int)std::lrint(p[0] * ab[1] + p[1] * ab[0]); }
+static ORBX_CV_NOINLINE int contraction_probe_diff(const int* p, const float* ab) { return (int)std::lrint(p[0] * ab[0] - p[1] * ab[1]); }
+/* 0 = not contracted, 1 = form A on both expressions (brief_fma = 1 reproduces it), -1 = anything else (form B, a mix, neither): no
+ * option of liborbx reproduces that build */
+inline int build_contraction_form() {
+  struct Op { int expr; int32_t x, y; uint32_t a, b; int unfused, formA, formB; };
+  static const Op kOps[] = {
+      {0, -12, 10, 0x3e2ad13du, 0xbf7c69bdu, 14, 13, 14}, {0, 9, 4, 0xbed644d7u, 0x3f688114u, 6, 7, 6}, {0, 12, 3, 0x3f50bff3u, 0xbf142ffdu, -5, -4, -5},
+      {0, -8, 10, 0x3f6f411cu, 0x3eb622c6u, 7, 7, 6}, {0, 13, 13, 0xbe5d1242u, 0xbf79f683u, -16, -16, -15}, {0, 13, -10, 0xbf585621u, 0xbf08dfcbu, 2, 2, 1},
+      {1, 10, -4, 0x3f528e6cu, 0x3f119bf3u, 11, 10, 11}, {1, -11, 12, 0xbf7e31f2u, 0x3df2c39cu, 9, 10, 9}, {1, -10, 12, 0x3f7e2dc2u, 0xbdf3dbb1u, -8, -9, -8},
+      {1, 13, 10, 0xbdf7e3f9u, 0x3f7e1e27u, -11, -11, -12}, {1, -4, -10, 0xbf119beeu, 0x3f528e6fu, 10, 10, 11}, {1, 12, 7, 0x3f755488u, 0x3e924667u, 10, 10, 9}};
+  int is_u = 0, is_a = 0, is_b = 0, other = 0;
+  for (const Op& o : kOps) {
+    volatile int32_t vx = o.x, vy = o.y; volatile uint32_t va = o.a, vb = o.b;   // opaque to constant folding
     const int p[2] = {vx, vy};
-    const uint32_t ua = (uint32_t)va, ub = (uint32_t)vb;
+    const uint32_t ua = va, ub = vb;
     float ab[2];
     std::memcpy(&ab[0], &ua, 4); std::memcpy(&ab[1], &ub, 4);
-    const float fx = (float)p[0], fy = (float)p[1];
-    volatile float m = fy * ab[0];
-    const int fused = (int)std::lrint(std::fma(fx, ab[1], (float)m));
-    volatile float m2 = fx * ab[1];
-    volatile float sum = (float)m2 + (float)m;
-    const int unfused = (int)std::lrint((float)sum);
-    if (fused == unfused) continue;
-    const int got = contraction_probe(p, ab);
-    votes_fused += got == fused; votes_unfused += got == unfused;
+    const int got = o.expr == 0 ? contraction_probe_sum(p, ab) : contraction_probe_diff(p, ab);
+    // every set separates exactly one form from the other two
+    if (o.formA != o.unfused) { if (got == o.formA) is_a++; else if (got == o.unfused) { is_u++; is_b++; } else other++; }
+    else { if (got == o.formB) is_b++; else if (got == o.unfused) { is_u++; is_a++; } else other++; }
   }
-  return votes_fused > 0 && votes_unfused == 0 ? 1 : 0;
+  const int n = (int)(sizeof(kOps) / sizeof(kOps[0]));
+  if (other) return -1;
+  if (is_u == n) return 0;            // unfused everywhere (then is_a + is_b == n as well: check it first)
+  if (is_a == n) return 1;
+  return -1;                          // form B, or the two expressions contracted differently
 }
+inline int build_contracts_fma() { return build_contraction_form() == 1 ? 1 : 0; }
 
 /* (4): the tie order of std::sort.  DistributeOctTree sorts its (point count, UL.x) pairs with std::sort (src/ORBextractor.cc:700); equal
  * keys are the rule there (stacked nodes share UL.x, small counts repeat), and the order in which they come out is the STANDARD LIBRARY's:
@@ -202,7 +221,25 @@ inline Calibration calibrate(Blur blur, Atan at) {
   c.atan_fma = bad[1] < bad[0] ? 1 : 0;
   c.atan_mismatch = bad[c.atan_fma]; c.atan_exact = c.atan_mismatch == 0;
   if (!c.atan_exact) c.atan_fma = 0;
-  c.brief_fma = build_contracts_fma();
+  // second probe: the variant found on the small image must also reproduce a FRAME-sized one (OpenCV paths that switch on the image size —
+  // IPP, OpenCL, the stripes of parallel_for_ — do not show on 127 x 72)
+  if (c.gauss_exact) {
+    const int W = kFrameProbeW, H = kFrameProbeH;
+    std::vector<uint8_t> big((size_t)W * H), out((size_t)W * H);
+    uint32_t s2 = 0x85EBCA6Bu;
+    for (size_t i = 0; i < big.size(); i++) { s2 ^= s2 << 13; s2 ^= s2 >> 17; s2 ^= s2 << 5; big[i] = (uint8_t)(s2 >> 9); }
+    for (int y = 200; y < 207; y++) std::memset(&big[(size_t)y * W], (y - 200) == 0 ? 127 : (y - 200) == 3 ? 126 : 128, (size_t)W);   // a tie band
+    for (int y = 300; y < 312; y++) std::memset(&big[(size_t)y * W], 255, (size_t)W);                                                   // saturation
+    blur(big.data(), W, H, out.data());
+    std::vector<uint32_t> acc;
+    gauss_acc(big.data(), W, H, c.gauss_kernel, acc);
+    const int V = c.gauss_tail, body = V > 1 ? W - W % V : W;
+    int bad = 0;
+    for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) bad += gauss_round_px(acc[(size_t)y * W + x], x < body ? c.gauss_round : 0) != out[(size_t)y * W + x];
+    c.frame_w = W; c.frame_h = H; c.frame_mismatch = bad;
+  }
+  c.brief_form = build_contraction_form();
+  c.brief_fma = c.brief_form == 1 ? 1 : 0;
   c.sort_libstdcxx = std_sort_is_libstdcxx();
   return c;
 }
@@ -230,7 +267,17 @@ inline void report(const Calibration& c, const char* opencv_version, std::FILE* 
   if (!c.sort_libstdcxx)
     std::fprintf(f, "[orbx] std::sort of this toolchain does not leave equal keys in libstdc++'s order: DistributeOctTree (src/ORBextractor.cc:700) "
                     "built with it orders tied nodes differently from liborbx — keypoint order (and some keypoints) will differ from a CPU build here\n");
-  if (c.gauss_exact && c.atan_exact && dflt && !std::getenv("ORBX_CV_VERBOSE")) return;
+  if (c.brief_form < 0)
+    std::fprintf(f, "[orbx] this build contracts the pattern rotation (src/ORBextractor.cc:118-120) in a form liborbx has no option for (not fma(x,b,y*a) / "
+                    "fma(x,a,-(y*b))): about one rotated pattern point in ten million will differ from a CPU build with these flags; brief_fma stays 0\n");
+  if (c.frame_mismatch > 0)
+    std::fprintf(f, "[orbx] cv::GaussianBlur equals variant gauss_kernel=%d gauss_round=%d gauss_tail=%d on the %d x %d probe but differs in %d bytes of a %d x %d "
+                    "frame: this OpenCV switches paths with the image size (IPP / OpenCL / threading); descriptors will not be bit-identical — see "
+                    "tools/validate_opencv.cpp\n", c.gauss_kernel, c.gauss_round, c.gauss_tail, kProbeW, kProbeH, c.frame_mismatch, c.frame_w, c.frame_h);
+  if (c.gauss_exact && c.gauss_candidates > 1)
+    std::fprintf(f, "[orbx] %d Gaussian variants reproduce this OpenCV on the probe image (the probe no longer separates them): taking gauss_kernel=%d "
+                    "gauss_round=%d gauss_tail=%d, the first\n", c.gauss_candidates, c.gauss_kernel, c.gauss_round, c.gauss_tail);
+  if (c.gauss_exact && c.atan_exact && dflt && c.brief_form >= 0 && c.frame_mismatch <= 0 && !std::getenv("ORBX_CV_VERBOSE")) return;
   std::fprintf(f, "[orbx] OpenCV %s: cv::GaussianBlur(7x7, sigma 2, 8u) %s gauss_kernel=%d gauss_round=%d gauss_tail=%d", opencv_version,
                c.gauss_exact ? "== variant" : "matches NO known variant; keeping", c.gauss_kernel, c.gauss_round, c.gauss_tail);
   if (!c.gauss_exact) std::fprintf(f, " (closest variant differs in %d of %d probe bytes: descriptors will not be bit-identical to this OpenCV's; see tools/validate_opencv.cpp)", c.gauss_mismatch, kProbeW * kProbeH);

@@ -732,89 +732,68 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
 
 }  // namespace orbx
 
-// ---- hand-over of an extraction's descriptor rows to the searches that follow (no D2H -> H2D ping-pong) -------------
+// ---- whose rows are these?  (Frame::ComputeBoW without a device round trip of its own) ---------------------------------------------------
 // The extractor adapter copies the rows it got from orbx_extract into the caller's cv::Mat (Frame::mDescriptors) and tells the library
-// which host buffer now holds the rows of the context's last extraction.  When a search target is later filled from that very
-// buffer, orbx_target_create / _assign copy the rows device to device from the extractor's staging block instead of sending the host
-// bytes up again.  Valid only while the publishing context has not extracted again (sequence number) — and that context's next
-// extraction waits for a copy still in flight.  Contract, as in the reference: nobody writes into mDescriptors after ExtractORB.
+// which host buffer now holds the rows of the context's last extraction (orbx_publish_descriptors).  ORBVocabulary::transform is handed
+// row headers into that very buffer by the unmodified Frame.cc — the host address (+ row count + a digest of the bytes) is the only key
+// the reference's call chain offers — and finds the {word, node, weight} records the extraction graph left in the pinned result block
+// (orbx_bow_transform_published).  Contract, as in the reference: nobody writes into mDescriptors after ExtractORB.
+// (Rounds 3-4 also handed the rows over to the first search TARGET made from that buffer, device to device; measured at 58.0 us for the
+// first search of a new frame against 51.2 us with the host rows and a caller-held grid — profiles/target_latency_r4.txt — it was removed
+// in round 5 together with its publication list, in-flight counts and per-target digests.)
 namespace {
 std::mutex g_pub_mu;
-std::condition_variable g_pub_cv;          // handover_inflight dropped to zero
-std::vector<orbx_ctx*> g_pub_list;         // contexts that hold a publication (each context at most one: nobody evicts anybody)
+std::condition_variable g_pub_cv;          // a context left its extraction (in_extract dropped)
 std::vector<orbx_ctx*> g_bow_attached;     // contexts with a vocabulary attached (orbx_bow_transform_published)
 std::vector<orbx_ctx*> g_publishers;       // every context that has ever published (until it is destroyed): who extracted the rows in this buffer?
-void drop_publication(orbx_ctx* c) {       // g_pub_mu held
-  c->pub_host = nullptr; c->pub_n = 0; c->pub_digest = 0;
-  g_pub_list.erase(std::remove(g_pub_list.begin(), g_pub_list.end(), c), g_pub_list.end());
-}
 }  // namespace
 
-const uint8_t* orbx::handover_acquire(const void* host_desc, int n, int device, orbx_ctx** src) {
+// a new extraction begins on ctx: its pinned result block is about to be overwritten, what was published about it is void
+static void begin_extraction(orbx_ctx* ctx) {
   std::lock_guard<std::mutex> lock(g_pub_mu);
-  for (orbx_ctx* c : g_pub_list)
-    if (c->pub_host == host_desc && c->pub_n == n && c->device == device && c->last_d_desc && c->last_n0 == n) {
-      // the buffer must still hold the bytes that were published: a freed cv::Mat reallocated at the same address with the same row
-      // count would otherwise be filled from stale rows (the digest reads 8 bytes per row)
-      const bool same = rows_digest((const uint8_t*)host_desc, n) == c->pub_digest;
-      const uint8_t* d = same ? c->last_d_desc : nullptr;
-      drop_publication(c);   // consumed by its first taker (a target stays resident; later refills take the host bytes) — or stale
-      if (d) { c->handover_inflight++; if (src) *src = c; }
-      return d;
-    }
-  return nullptr;
-}
-// a new extraction begins on ctx: its staging block is about to be overwritten.  Waits for targets that have chosen the rows but not yet
-// queued their copy; returns true when a queued copy may still be reading the block (the caller orders its stream behind ev_handover).
-static bool handover_begin_extraction(orbx_ctx* ctx) {
-  std::unique_lock<std::mutex> lock(g_pub_mu);
-  g_pub_cv.wait(lock, [ctx] { return ctx->handover_inflight == 0; });
   ctx->extract_seq++;
-  ctx->last_d_desc = nullptr; ctx->last_n0 = 0;
-  drop_publication(ctx);
+  ctx->in_extract = true;
+  ctx->last_n0 = -1;
   ctx->rows_host = nullptr; ctx->rows_n = 0;
-  if (ctx->bow_active != ctx->bow_voc || ctx->bow_active_levelsup != ctx->bow_levelsup) {   // attached / detached since the last call: the graph changes
-    ctx->bow_active = ctx->bow_voc; ctx->bow_active_levelsup = ctx->bow_levelsup;
+  // attached / detached since the last call (or the attached vocabulary was destroyed and another one now lives at its address: bow_gen):
+  // the graph changes
+  if (ctx->bow_active != ctx->bow_voc || ctx->bow_active_levelsup != ctx->bow_levelsup || ctx->bow_active_gen != ctx->bow_gen) {
+    ctx->bow_active = ctx->bow_voc; ctx->bow_active_levelsup = ctx->bow_levelsup; ctx->bow_active_gen = ctx->bow_gen;
     ctx->buf_epoch++;
   }
-  const bool pending = ctx->handover_pending && ctx->ev_handover;
-  ctx->handover_pending = false;
-  return pending;
 }
-// the extraction has finished: its rows sit at `d_desc`
-static void handover_end_extraction(orbx_ctx* ctx, const uint8_t* d_desc, int n0, bool bow_records = false) {
+// the extraction has finished (n0 >= 0: its rows are in the pinned block; < 0: it failed) — on every path out of extract_batch_impl
+static void end_extraction(orbx_ctx* ctx, int n0, bool bow_records) {
   std::lock_guard<std::mutex> lock(g_pub_mu);
-  ctx->last_d_desc = d_desc; ctx->last_n0 = n0;
-  if (bow_records) ctx->bow_seq = ctx->extract_seq;   // the pinned block holds this extraction's {word, node, weight} records
-}
-hipError_t orbx::handover_copied(orbx_ctx* src, hipStream_t stream) {
-  std::lock_guard<std::mutex> lock(g_pub_mu);
-  hipError_t e = hipSuccess;
-  if (!src->ev_handover) e = hipEventCreateWithFlags(&src->ev_handover, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipEventRecord(src->ev_handover, stream);
-  if (e == hipSuccess) src->handover_pending = true;
-  src->handover_inflight--;
-  g_pub_cv.notify_all();
-  return e;
-}
-void orbx::handover_abort(orbx_ctx* src) {
-  std::lock_guard<std::mutex> lock(g_pub_mu);
-  src->handover_inflight--;
+  ctx->last_n0 = n0;
+  if (n0 >= 0 && bow_records) ctx->bow_seq = ctx->extract_seq;   // the pinned block holds this extraction's {word, node, weight} records
+  ctx->in_extract = false;
   g_pub_cv.notify_all();
 }
-void orbx::unpublish_context(orbx_ctx* ctx) {   // orbx_destroy: nobody may still be about to read this context's staging block
-  std::unique_lock<std::mutex> lock(g_pub_mu);
-  g_pub_cv.wait(lock, [ctx] { return ctx->handover_inflight == 0; });
-  drop_publication(ctx);
-  ctx->last_d_desc = nullptr; ctx->last_n0 = 0;
+namespace {
+struct ExtractionScope {   // begin_extraction ... end_extraction around one host-buffer extraction, whatever path leaves it
+  orbx_ctx* ctx; int n0 = -1; bool bow = false;
+  explicit ExtractionScope(orbx_ctx* c) : ctx(c) { begin_extraction(c); }
+  ~ExtractionScope() { end_extraction(ctx, n0, bow); }
+};
+}  // namespace
+void orbx::unpublish_context(orbx_ctx* ctx) {   // orbx_destroy
+  std::lock_guard<std::mutex> lock(g_pub_mu);
+  ctx->last_n0 = -1;
   ctx->bow_voc = nullptr; ctx->rows_host = nullptr;
   g_bow_attached.erase(std::remove(g_bow_attached.begin(), g_bow_attached.end(), ctx), g_bow_attached.end());
   g_publishers.erase(std::remove(g_publishers.begin(), g_publishers.end(), ctx), g_publishers.end());
 }
+// orbx_voc_destroy: no context may go on descending this tree.  Detaches it everywhere, invalidates the snapshots (bow_gen: a vocabulary
+// created later at the same address is a different one) and waits for extractions in flight that already took their snapshot — a
+// single-frame extraction is synchronous, so once in_extract has dropped its graph is done with the tree.
 void orbx::voc_detach_all(const orbx_voc* v) {
-  std::lock_guard<std::mutex> lock(g_pub_mu);
-  for (orbx_ctx* c : g_bow_attached) if (c->bow_voc == v) { c->bow_voc = nullptr; c->bow_seq = ~0ull; }
+  std::unique_lock<std::mutex> lock(g_pub_mu);
+  std::vector<orbx_ctx*> users;
+  for (orbx_ctx* c : g_bow_attached)
+    if (c->bow_voc == v || c->bow_active == v) { c->bow_voc = nullptr; c->bow_seq = ~0ull; c->bow_gen++; users.push_back(c); }
   g_bow_attached.erase(std::remove_if(g_bow_attached.begin(), g_bow_attached.end(), [](orbx_ctx* c) { return c->bow_voc == nullptr; }), g_bow_attached.end());
+  g_pub_cv.wait(lock, [&] { for (orbx_ctx* c : users) if (c->in_extract && c->bow_active == v) return false; return true; });
 }
 
 using namespace orbx;
@@ -918,7 +897,11 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, 
     { const char* e = getenv("ORBX_BRIEF_FMA"); ctx->brief_fma = e && atoi(e) == 1 ? 1 : 0; }
     const char* fpk = getenv("ORBX_FAST_PK");   // packed 16-bit necessary test in k_fast_cells (128-thread workgroups)
     ctx->fast_pk = fpk ? atoi(fpk) != 0 : true;
+#ifdef ORBX_FAST_EARLY_OPTION
     { const char* e = getenv("ORBX_FAST_EARLY"); ctx->fast_early = e ? atoi(e) != 0 : false; }
+#else
+    ctx->fast_early = false;   // compiled out (HISTORY.md): neither the environment variable nor orbx_set_option can switch on a knob the kernel ignores
+#endif
     { const char* e = getenv("ORBX_REALIGN"); ctx->realign = e ? atoi(e) != 0 : true; }
     { const char* e = getenv("ORBX_FAST_STAGE_DMA"); ctx->fast_stage_dma = e ? atoi(e) != 0 : true; }
     { const char* e = getenv("ORBX_FAST_DMA"); if (e && atoi(e) >= 0 && atoi(e) <= 64) ctx->fast_dma = atoi(e); }
@@ -959,7 +942,6 @@ void orbx_destroy(orbx_ctx* ctx) {
   if (ctx->h_call) { (void)hipHostFree(ctx->h_call); ctx->h_call = nullptr; }
   for (int i = 0; i < 2; i++) if (ctx->h_view[i]) { (void)hipHostFree(ctx->h_view[i]); ctx->h_view[i] = nullptr; }
   unpublish_context(ctx);
-  if (ctx->ev_handover) { (void)hipEventDestroy(ctx->ev_handover); ctx->ev_handover = nullptr; }
   if (ctx->d_win_ctr) { (void)hipFree(ctx->d_win_ctr); ctx->d_win_ctr = nullptr; }
   if (ctx->d_qt_fin) { (void)hipFree(ctx->d_qt_fin); ctx->d_qt_fin = nullptr; }
   if (ctx->ev_g0) { (void)hipEventDestroy(ctx->ev_g0); ctx->ev_g0 = nullptr; }
@@ -1260,13 +1242,9 @@ int orbx_publish_descriptors(orbx_ctx* ctx, const void* host_desc, int n) {
   if (!ctx || !host_desc || n < 0) return ORBX_E_INVALID;
   const uint64_t dig = rows_digest((const uint8_t*)host_desc, n);   // the caller's buffer as it is NOW (outside the lock: host memory only)
   std::lock_guard<std::mutex> lock(g_pub_mu);
-  for (orbx_ctx* c : std::vector<orbx_ctx*>(g_pub_list)) if (c->pub_host == host_desc) drop_publication(c);   // a reused buffer: the old entry dies
-  for (orbx_ctx* c : g_publishers) if (c->rows_host == host_desc) { c->rows_host = nullptr; c->rows_n = 0; }
-  drop_publication(ctx);                                          // a context publishes its last extraction once
-  if (!ctx->last_d_desc || n != ctx->last_n0 || n == 0) return ORBX_OK;   // nothing resident that matches: the host bytes will be used
-  ctx->pub_host = host_desc; ctx->pub_n = n; ctx->pub_digest = dig;
-  g_pub_list.push_back(ctx);
-  // "whose rows are these" outlives the hand-over (which is consumed by the first target): Frame::ComputeBoW may come after the first search
+  for (orbx_ctx* c : g_publishers) if (c->rows_host == host_desc) { c->rows_host = nullptr; c->rows_n = 0; }   // a reused buffer: the old entry dies
+  ctx->rows_host = nullptr; ctx->rows_n = 0;                      // a context names the buffer of its last extraction once
+  if (n != ctx->last_n0 || n == 0) return ORBX_OK;                // not what this context last extracted: nothing to look up later
   ctx->rows_host = host_desc; ctx->rows_n = n; ctx->rows_digest_v = dig;
   if (std::find(g_publishers.begin(), g_publishers.end(), ctx) == g_publishers.end()) g_publishers.push_back(ctx);
   return ORBX_OK;
@@ -1305,7 +1283,7 @@ static int extract_batch_impl(orbx_ctx* ctx, const uint8_t* imgs, int nframes, i
   const bool resized = src_rows > 0;   // rows x cols = the size AFTER cv::resize; the caller's image is src_rows x src_cols
   if (!kps || !desc || !counts || row_stride < (size_t)(resized ? src_cols : cols) * channels) return set_err(ctx, ORBX_E_INVALID, "bad arguments");
   ORBX_HIP(ctx, hipSetDevice(ctx->device));
-  if (handover_begin_extraction(ctx)) ORBX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_handover, 0));   // a search target is still copying the last rows
+  ExtractionScope scope(ctx);   // what was published about the last extraction is void from here; ends on every path out
   const size_t pitch = (size_t)round_up(cols, 64), fbytes = pitch * rows;
   int rc = ensure_stage(ctx, nframes, fbytes * nframes);
   if (rc != ORBX_OK) return rc;
@@ -1323,7 +1301,7 @@ static int extract_batch_impl(orbx_ctx* ctx, const uint8_t* imgs, int nframes, i
       std::memcpy(counts, ctx->h_stage_out + L.counts_off, cb);
       if (counts[0] < 0) return set_err(ctx, ORBX_E_CAPACITY, "quadtree produced more nodes than the level capacity");
       ctx->bow_off = L.bow_off;
-      handover_end_extraction(ctx, ctx->d_stage_out + L.desc_off, counts[0], ctx->bow_in_graph);
+      scope.n0 = counts[0]; scope.bow = ctx->bow_in_graph;
       return ORBX_OK;
     }
   }
@@ -1384,7 +1362,7 @@ static int extract_batch_impl(orbx_ctx* ctx, const uint8_t* imgs, int nframes, i
   // k_assemble reports a quadtree capacity overflow (never expected) as a negative keypoint count: fail loudly
   for (int f = 0; f < nframes; f++)
     if (counts[2 * f] < 0) return set_err(ctx, ORBX_E_CAPACITY, "quadtree produced more nodes than the level capacity");
-  handover_end_extraction(ctx, ctx->d_stage_out + L.desc_off, counts[0]);
+  scope.n0 = counts[0];
   return ORBX_OK;
 }
 
@@ -1471,7 +1449,11 @@ int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
   else if (n == "realign") ctx->realign = value != 0;   // batch frames with rows that are not dword-aligned: one pass into an aligned copy first
   else if (n == "fast_stage_dma") ctx->fast_stage_dma = value != 0;   // FAST tile staged by LDS-DMA loads instead of load + ds_write
   else if (n == "fast_dma" && value >= 0 && value <= 64) ctx->fast_dma = value;   // cells per FAST workgroup with LDS-DMA tile prefetch (0 = off; experiment)
+#ifdef ORBX_FAST_EARLY_OPTION
   else if (n == "fast_early") ctx->fast_early = value != 0;   // wave-uniform early-out of the FAST pre-test after the compass pairs
+#else
+  else if (n == "fast_early") return set_err(ctx, ORBX_E_INVALID, "orbx_set_option: fast_early is compiled out of this build (measured at +-1 %, HISTORY.md; -DORBX_FAST_EARLY_OPTION brings it back)");
+#endif
   else if (n == "gauss_kernel" && (value == 0 || value == 1)) ctx->gauss_kernel = value;   // which OpenCV's 8-bit Gaussian weights (include/orbx.h)
   else if (n == "gauss_round" && value >= 0 && value <= 2) ctx->gauss_round = value;       // ... which rounding of the column pass
   else if (n == "gauss_tail" && (value == 0 || value == 4 || value == 8 || value == 16 || value == 32 || value == 64)) ctx->gauss_tail = value;   // ... and its scalar tail
@@ -1498,6 +1480,7 @@ int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
   else if (n == "qt_threads" && value >= 0 && value <= 512 && value % 64 == 0) ctx->qt_threads = value;   // 0: chosen by batch size
   else if (n == "desc_k" && (value == 1 || value == 2 || value == 4 || value == 8 || value == 16)) { ctx->desc_k = value; ctx->desc_k_user = true; }
   else if (n == "streams" && value >= 1 && value <= 2) ctx->nstreams = value;
+  else if (n == "view_pool_cap" && value >= 16) { ctx->view_pool_cap = value; return ORBX_OK; }   // test hook: the learnt candidate-pool capacity of orbx_target_search_view
   else return set_err(ctx, ORBX_E_INVALID, "orbx_set_option: unknown option or value out of range: " + n);
   ctx->buf_epoch++;   // a captured single-frame graph holds the launch shape of the old options: capture again
   return ORBX_OK;

@@ -228,25 +228,21 @@ struct orbx_ctx {
   uint8_t* h_pyr = nullptr; size_t h_pyr_bytes = 0; bool h_pyr_valid = false;
   // last extraction (for orbx_pyramid_level / debug dumps)
   const uint8_t* last_imgs = nullptr; size_t last_row_stride = 0, last_frame_stride = 0; int last_nframes = 0;
-  // hand-over of the last host-buffer extraction's descriptor rows (orbx_publish_descriptors): which extraction the staging block holds,
-  // and the event of the last device-to-device copy that read it (the next extraction of this context waits for it)
+  // the last host-buffer extraction: its sequence number, its keypoint count (frame 0; -1 while one is running or after a failed one), and
+  // whether one is running right now (orbx_voc_destroy waits for it).  All under orbx_extractor.hip's g_pub_mu
   unsigned long long extract_seq = 0;
-  const uint8_t* last_d_desc = nullptr; int last_n0 = 0;
-  hipEvent_t ev_handover = nullptr; bool handover_pending = false;
-  // this context's publication (orbx_publish_descriptors; at most one — the rows of its last extraction): the host buffer that holds a copy
-  // of the rows, their count, a digest of the host bytes taken at publish time, and how many search targets are between having chosen the
-  // rows and having queued their copy (a new extraction / orbx_destroy waits for that count to drop).  All under orbx_extractor.hip's g_pub_mu
-  const void* pub_host = nullptr; int pub_n = 0; uint64_t pub_digest = 0; int handover_inflight = 0;
+  int last_n0 = -1; bool in_extract = false;
   // vocabulary attached to this extractor context (orbx_bow_transform_published attaches the first vocabulary that asks for the words of
   // one of its extractions): the single-frame graph then ends with the tree descent of the frame's descriptors and leaves the
   // {word, node, weight} records in the pinned result block — Frame::ComputeBoW costs no device round trip of its own.  bow_voc /
   // bow_levelsup are written under g_pub_mu by any thread; the extracting thread takes its snapshot (bow_active*) at the start of a call
   orbx_voc* bow_voc = nullptr; int bow_levelsup = 0;
   orbx_voc* bow_active = nullptr; int bow_active_levelsup = 0;
+  unsigned long long bow_gen = 0, bow_active_gen = 0;   // bumped when the attached vocabulary is destroyed: a later one at the same address is another tree
   unsigned long long bow_seq = ~0ull;   // extract_seq of the extraction whose records the pinned block holds
   size_t bow_off = 0;                   // offset of the records in h_stage_out
   bool bow_in_graph = false;            // the captured single-frame graph ends with the descent
-  // the host buffer that holds (a copy of) the rows of the last extraction, until the next extraction begins (not consumed by the hand-over)
+  // the host buffer that holds (a copy of) the rows of the last extraction (orbx_publish_descriptors), until the next extraction begins
   const void* rows_host = nullptr; int rows_n = 0; uint64_t rows_digest_v = 0;
   hipStream_t last_ext_stream = nullptr;   // caller's stream of the last orbx_extract_batch_device (its work may still use our buffers)
   // profiling
@@ -286,13 +282,7 @@ inline hipError_t sync_ctx(orbx_ctx* ctx) {
 hipError_t ensure_dynamic_lds(const void* kernel, int bytes);
 // orbx_window.hip: pinned staging (grow-only) and the fused window pass behind orbx_window_search* / orbx_window_nearest
 hipError_t host_stage(orbx_ctx* ctx, size_t bytes, uint8_t** p);
-// descriptor rows published by an extractor context for the host buffer `host_desc` (orbx_publish_descriptors): device address when the
-// publishing context still holds that extraction on `device`, else nullptr; *src = the publishing context
-// A publication is consumed by the first target that takes it, is only taken when the host buffer still holds the published bytes (digest),
-// and the publishing context can neither start another extraction nor be destroyed between handover_acquire and handover_copied / _abort.
-const uint8_t* handover_acquire(const void* host_desc, int n, int device, orbx_ctx** src);
-hipError_t handover_copied(orbx_ctx* src, hipStream_t stream);   // the copy out of src's staging block is queued on `stream`
-void handover_abort(orbx_ctx* src);                              // ... or will not happen after all
+// orbx_extractor.hip: orbx_destroy — the context leaves the publisher / attachment lists
 void unpublish_context(orbx_ctx* ctx);
 // orbx_matcher.hip: the tree descent of the single-frame graph — descriptors and the frame's keypoint count read on the device, records
 // {word, node, weight} (16 bytes each) written to rec_out; nullptr stream error codes as hipError_t.  voc_device: the GPU the tree lives on

@@ -395,9 +395,10 @@ hipError_t host_stage(orbx_ctx* ctx, size_t bytes, uint8_t** p) {
 
 // The blob of a VIEW call (orbx_target_search_view: the caller reads the lists in place): two of them, used alternately, so that a view stays
 // valid while the NEXT view call of the context runs — a two-camera rig searches the left and the right frame back to back and replays
-// both lists together.
+// both lists together.  The blob is chosen ONCE per orbx_target_search_view call (ctx->view_par, flipped there): the capacity retry of that
+// call re-uses — and, when it must, re-allocates — the SAME blob, never the one that still backs the previous view.
 static hipError_t host_stage_view(orbx_ctx* ctx, size_t bytes, uint8_t** p) {
-  const int i = ctx->view_par ^= 1;
+  const int i = ctx->view_par;
   if (bytes > ctx->h_view_bytes[i]) {
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return e;
@@ -430,13 +431,6 @@ static void pack_queries(uint8_t* dst, const float* qx, const float* qy, const f
 __global__ __launch_bounds__(256) void k_stage_in(const uint4* __restrict__ src, uint4* __restrict__ dst, int n16) {
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = src[i];
 }
-// the same with the 16-byte units [lo, hi) — a target's descriptor rows — taken from `dev_src` (rows an extractor context left in HBM,
-// orbx_publish_descriptors) instead of the mapped host blob: the hand-over costs no extra launch and the rows never cross PCIe again
-__global__ __launch_bounds__(256) void k_stage_in_handover(const uint4* __restrict__ src, uint4* __restrict__ dst, int n16, int lo, int hi,
-                                                           const uint4* __restrict__ dev_src) {
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = (i >= lo && i < hi) ? dev_src[i - lo] : src[i];
-}
-
 // The whole call: pack -> one H2D -> [grid assignment] -> k_window -> one D2H (+ one more for a long tail) -> scatter.
 int window_call(orbx_ctx* ctx, const char* who, const orbx_keypoint* kps, const uint8_t* desc, int n, const orbx_grid* grid,
                 const uint8_t* kp_skip, const float* kp_uright, const float* inv_sigma2, int nlevels, const float* qx, const float* qy,
@@ -682,14 +676,7 @@ int target_assign(orbx_ctx* ctx, orbx_target* reuse, const orbx_keypoint* kps, c
     if (e == hipSuccess) T->cap = want;
   }
   if (e != hipSuccess) { T->n = 0; if (!reuse) { if (T->dev) (void)hipFree(T->dev); delete T; } ORBX_HIP(ctx, e); }
-  // descriptor rows an extractor context published for this very host buffer are taken from HBM (k_stage_in_handover); both blocks
-  // are 256-byte aligned, rows are 32 bytes
-  orbx_ctx* pub_ctx = nullptr;
-  // (taken only while the host buffer still holds the published bytes; from here until handover_copied / handover_abort the publishing
-  // context can neither extract again nor be destroyed)
-  const uint8_t* d_rows = (n > 0 && ctx->window_direct) ? handover_acquire(desc, n, ctx->device, &pub_ctx) : nullptr;
-  if (d_rows && ((uintptr_t)d_rows & 15)) { handover_abort(pub_ctx); d_rows = nullptr; }
-  if (n) { std::memcpy(h + T->o_kps, kps, sizeof(orbx_keypoint) * (size_t)n); if (!d_rows) std::memcpy(h + T->o_desc, desc, (size_t)n * 32); }
+  if (n) { std::memcpy(h + T->o_kps, kps, sizeof(orbx_keypoint) * (size_t)n); std::memcpy(h + T->o_desc, desc, (size_t)n * 32); }
   if (kp_uright) std::memcpy(h + T->o_ur, kp_uright, 4 * (size_t)n);
   if (inv_sigma2) std::memcpy(h + T->o_sig, inv_sigma2, 4 * (size_t)nlevels);
   if (have_grid) {
@@ -700,19 +687,10 @@ int target_assign(orbx_ctx* ctx, orbx_target* reuse, const orbx_keypoint* kps, c
   uint8_t* hdev = nullptr;
   if (ctx->window_direct && hipHostGetDevicePointer((void**)&hdev, h, 0) == hipSuccess && hdev) {
     const int n16 = (int)((upload + 15) / 16);   // the block is a multiple of 256 bytes
-    if (d_rows) {
-      hipLaunchKernelGGL(k_stage_in_handover, dim3(std::min((n16 + 255) / 256, 256)), dim3(256), 0, st, (const uint4*)hdev, (uint4*)T->dev, n16,
-                         (int)(T->o_desc / 16), (int)((T->o_desc + (size_t)n * 32) / 16), (const uint4*)d_rows);
-      e = hipGetLastError();
-      const hipError_t e2 = handover_copied(pub_ctx, st);   // the publishing context's next extraction waits for this copy
-      if (e == hipSuccess) e = e2;
-    } else {
-      hipLaunchKernelGGL(k_stage_in, dim3(std::min((n16 + 255) / 256, 256)), dim3(256), 0, st, (const uint4*)hdev, (uint4*)T->dev, n16);
-      e = hipGetLastError();
-    }
+    hipLaunchKernelGGL(k_stage_in, dim3(std::min((n16 + 255) / 256, 256)), dim3(256), 0, st, (const uint4*)hdev, (uint4*)T->dev, n16);
+    e = hipGetLastError();
   } else {
     (void)hipGetLastError();
-    if (d_rows) { handover_abort(pub_ctx); if (n) std::memcpy(h + T->o_desc, desc, (size_t)n * 32); }   // no mapped view of the staging buffer after all: the host rows go up
     e = hipMemcpyAsync(T->dev, h, upload, hipMemcpyHostToDevice, st);
   }
   if (e == hipSuccess && !have_grid) {
@@ -1012,6 +990,7 @@ int orbx_target_search_view(orbx_ctx* ctx, const orbx_target* target, const uint
   *spans = nullptr; *pool = nullptr;
   if (nq == 0 || target->n == 0) return target->valid ? 0 : set_err(ctx, ORBX_E_INVALID, "orbx_target_search_view: invalid target");
   // the pool is sized from what earlier calls of this context needed; a call that needs more reports the size and is repeated once
+  ctx->view_par ^= 1;   // this call's blob: the other one keeps the previous view alive (orbx.h: valid until the second next view call)
   for (int attempt = 0; attempt < 2; attempt++) {
     std::vector<int32_t>& rp = ctx->view_row_ptr;
     rp.assign((size_t)nq + 1, 0);

@@ -106,8 +106,8 @@ class ORBextractor:
         return mono.value, kps[:n.value].copy(), desc[:n.value].copy()
 
     def publish_descriptors(self, desc: np.ndarray) -> None:
-        """orbx_publish_descriptors: `desc` (C-contiguous [n, 32] uint8) holds the rows of this context's last single-frame extraction;
-        a search target created from this very array takes them from HBM."""
+        """orbx_publish_descriptors: `desc` (C-contiguous [n, 32] uint8) holds the rows of this context's last single-frame extraction:
+        ORBVocabulary.descend_published(desc) then finds the records the extraction graph computed (no device round trip)."""
         assert desc.dtype == np.uint8 and desc.flags["C_CONTIGUOUS"]
         check(self._L.orbx_publish_descriptors(self._ctx, ptr(desc), int(desc.shape[0])), self._ctx)
 

@@ -362,9 +362,9 @@ class SearchTarget:
                 out.update(cand=cand[:rc].copy(), dist=dist[:rc].copy())
             return out
 
-    def search_view(self, qx, qy, qr, min_level, max_level, q_desc, kp_skip=None, q_xr=None):
+    def search_view(self, qx, qy, qr, min_level, max_level, q_desc, kp_skip=None, q_xr=None, copy=True):
         """orbx_target_search_view: the candidate lists read where the kernel left them (the call's pinned output, valid until the
-        context's next call — copied here).  Returns (spans [nq] structured: start, count, best_idx, best_dist, second_idx, second_dist;
+        context's SECOND next view call — copied here unless copy=False, which hands out arrays over the blob itself).  Returns (spans [nq] structured: start, count, best_idx, best_dist, second_idx, second_dist;
         pool [total] structured: idx, dist)."""
         qx, qy, qr = (np.ascontiguousarray(v, np.float32) for v in (qx, qy, qr))
         lo, hi = (np.ascontiguousarray(v, np.int32) for v in (min_level, max_level))
@@ -380,9 +380,11 @@ class SearchTarget:
         cand_t = np.dtype([("idx", "<i4"), ("dist", "<i4")])
         if nq == 0 or not sp.value:
             return np.zeros(0, span_t), np.zeros(0, cand_t)
-        spans = np.frombuffer((C.c_char * (span_t.itemsize * nq)).from_address(sp.value), span_t).copy()
+        spans = np.frombuffer((C.c_char * (span_t.itemsize * nq)).from_address(sp.value), span_t)
         end = int((spans["start"] + spans["count"]).max()) if nq else 0
-        pool = np.frombuffer((C.c_char * (cand_t.itemsize * max(end, 1))).from_address(pl.value), cand_t)[:end].copy() if end and pl.value else np.zeros(0, cand_t)
+        pool = np.frombuffer((C.c_char * (cand_t.itemsize * max(end, 1))).from_address(pl.value), cand_t)[:end] if end and pl.value else np.zeros(0, cand_t)
+        if copy:
+            spans, pool = spans.copy(), pool.copy()
         assert int(spans["count"].sum()) == total
         return spans, pool
 

@@ -30,8 +30,8 @@ int main(int argc, char** argv) {
           for (int y = 0; y < h; y++) std::memcpy(dst + (size_t)y * w, work.ptr<unsigned char>(y), (size_t)w);
         },
         [](float y, float x) { return cv::fastAtan2(y, x); });
-    std::printf("%d %d %d %d -> %d %d %d %d exact %d %d candidates %d contracts %d\n", k, r, t, f, c.gauss_kernel, c.gauss_round, c.gauss_tail, c.atan_fma,
-                (int)c.gauss_exact, (int)c.atan_exact, c.gauss_candidates, c.brief_fma);
+    std::printf("%d %d %d %d -> %d %d %d %d exact %d %d candidates %d contracts %d form %d frame %dx%d mismatch %d\n", k, r, t, f, c.gauss_kernel, c.gauss_round,
+                c.gauss_tail, c.atan_fma, (int)c.gauss_exact, (int)c.atan_exact, c.gauss_candidates, c.brief_fma, c.brief_form, c.frame_w, c.frame_h, c.frame_mismatch);
   }
   return 0;
 #endif

@@ -440,6 +440,49 @@ def test_list_view_spans_carry_the_two_smallest_of_every_list(frames):
     tgt.close()
 
 
+def test_a_view_survives_the_capacity_retry_of_the_next_view_call(frames):
+    """include/orbx.h: a view stays valid until the context's SECOND next view call (a rig replays the left and the right lists together).
+    The right-hand call of a rig may overflow the learnt candidate-pool capacity and repeat itself with a larger pool: the repeat must reuse
+    (and may re-allocate) ITS OWN blob, not the one that still backs the left view (round-4 advisor finding: the parity used to flip per
+    attempt, so the retry landed on — and could free — the previous view's blob)."""
+    gpu, fr = frames
+    m = ORBmatcher(gpu)
+    k2, d2, d1 = fr[1].mvKeysUn, fr[1].mDescriptors, fr[0].mDescriptors
+    grid = dict(_kf_grid(k2, (0.0, 0.0, 640.0, 480.0), True), cell_start=None, cell_idx=None)
+    tgt = m.Target(k2, d2, grid)
+    rng = np.random.default_rng(5)
+    for rep in range(3):
+        m.set_option("view_pool_cap", 4096)
+        # "left": a small call that fits the pool
+        nq = 120
+        src = rng.integers(0, len(k2), nq)
+        qx, qy = k2["x"][src].copy(), k2["y"][src].copy()
+        qr = np.full(nq, 7.0, np.float32)
+        lo = np.full(nq, -1, np.int32); hi = np.full(nq, -1, np.int32)
+        qd = d1[rng.integers(0, len(d1), nq)]
+        spans_l, pool_l = tgt.search_view(qx, qy, qr, lo, hi, qd, copy=False)      # arrays over the blob itself
+        keep_s, keep_p = spans_l.copy(), pool_l.copy()
+        assert 0 < int(spans_l["count"].sum()) <= 4096
+        # "right": far more candidates than the pool holds -> ORBX_E_CAPACITY inside, one repeat with a larger pool (a larger blob)
+        nq2 = 900 + 200 * rep
+        src2 = rng.integers(0, len(k2), nq2)
+        qx2, qy2 = k2["x"][src2].copy(), k2["y"][src2].copy()
+        qr2 = np.full(nq2, 200.0, np.float32)   # ~ half the target per query: the repeat needs a blob of several MB (re-allocation)
+        lo2 = np.full(nq2, -1, np.int32); hi2 = np.full(nq2, -1, np.int32)
+        qd2 = d1[rng.integers(0, len(d1), nq2)]
+        want = po.window_search_grid(k2, d2, grid, qx2, qy2, qr2, lo2, hi2, qd2)
+        assert int(want["row_ptr"][-1]) > 4 * 4096
+        spans_r, pool_r = tgt.search_view(qx2, qy2, qr2, lo2, hi2, qd2, copy=False)
+        assert int(spans_r["count"].sum()) == int(want["row_ptr"][-1])
+        # the left view is untouched and still readable
+        assert np.array_equal(spans_l, keep_s) and np.array_equal(pool_l, keep_p), rep
+        for q in range(0, nq2, 37):
+            a, b = int(want["row_ptr"][q]), int(want["row_ptr"][q + 1])
+            seg = pool_r[int(spans_r["start"][q]):int(spans_r["start"][q]) + int(spans_r["count"][q])]
+            assert np.array_equal(seg["idx"], want["cand"][a:b]) and np.array_equal(seg["dist"], want["dist"][a:b]), (rep, q)
+    tgt.close()
+
+
 def test_failed_target_assign_leaves_an_invalid_target_not_an_empty_one(frames):
     """orbx_target_assign that fails (here: a grid whose indices point past the keypoints) must not leave a target that answers
     searches with 0 candidates and ORBX_OK: it is invalid until a later assign succeeds."""
@@ -470,10 +513,11 @@ def test_failed_target_assign_leaves_an_invalid_target_not_an_empty_one(frames):
     T.close()
 
 
-def test_descriptor_handover_from_the_extractor_to_a_search_target():
-    """orbx_publish_descriptors: a target created from the host buffer an extraction's rows were copied into takes them from HBM
-    (k_stage_in_handover) — same results as the host path; after the context has extracted ANOTHER frame the published entry is dead
-    and the host bytes are used (the HBM rows now belong to the other frame)."""
+def test_search_targets_always_take_the_host_rows_also_after_publish_descriptors():
+    """orbx_publish_descriptors names the buffer for the BoW lookup only (include/orbx.h).  The device-to-device hand-over of those rows to
+    the first search target (rounds 3-4) was removed in round 5 — it measured slower than the host rows — so a target made from a published
+    buffer must hold what the HOST buffer holds at that moment: the same results as before, and a caller who edits the buffer after the
+    extraction gets the edited rows (the hand-over would have served the extraction's)."""
     from orb_slam3_modified_amd import synth
     fr = synth.make_stream(2, 480, 640, 31)
     ex = ORBextractor(1000, 1.2, 8, 20, 7)
@@ -488,13 +532,23 @@ def test_descriptor_handover_from_the_extractor_to_a_search_target():
     lo = np.full(nq, -1, np.int32); hi = np.full(nq, -1, np.int32)
     qd = d1[::-1][:nq].copy()
     want = po.window_search_grid(k1, d1, grid, qx, qy, qr, lo, hi, qd)
-    T = m.Target(k1, d1, grid)                       # rows from HBM
+    T = m.Target(k1, d1, grid)
     got = T.search(qx, qy, qr, lo, hi, qd)
     for key in ("row_ptr", "cand", "dist", "best_idx", "best_dist"):
         assert np.array_equal(got[key], want[key]), key
     assert len(want["cand"]) > nq
+    ex.publish_descriptors(d1)
+    d1e = d1.copy(); d1[:, 5] ^= 0xff                # the caller edits the published buffer in place
+    wante = po.window_search_grid(k1, d1, grid, qx, qy, qr, lo, hi, qd)
+    Te = m.Target(k1, d1, grid)
+    gote = Te.search(qx, qy, qr, lo, hi, qd)
+    assert not np.array_equal(wante["dist"], want["dist"])
+    for key in ("row_ptr", "cand", "dist", "best_idx", "best_dist"):
+        assert np.array_equal(gote[key], wante[key]), key
+    Te.close()
+    d1[:] = d1e
     mono2, k2, d2 = ex(fr[1], None, (0, 1000))       # the context moves on: its HBM rows are frame 1's now
-    T2 = m.Target(k1, d1, grid)                      # same host buffer, published entry stale -> host bytes
+    T2 = m.Target(k1, d1, grid)
     got2 = T2.search(qx, qy, qr, lo, hi, qd)
     for key in ("row_ptr", "cand", "dist", "best_idx", "best_dist"):
         assert np.array_equal(got2[key], want[key]), key

@@ -207,6 +207,15 @@ def test_adapter_calibration_recognises_every_variant(tmp_path):
     assert len(lines) == len(want)
     for v, line in zip(want, lines):
         assert line.startswith("%d %d %d %d -> %d %d %d %d exact 1 1 candidates 1 " % (v + v)), line
+        # built with -ffp-contract=off: no contraction; and the variant found on the 127 x 72 probe also reproduces a frame-sized blur
+        assert line.endswith("contracts 0 form 0 frame 752x480 mismatch 0"), line
+    # the same header in a translation unit built the way CMakeLists.txt:10-13 builds (-O3 with FMA instructions, default contraction):
+    # the probes are static, so THIS unit's flags decide — form A on both expressions (what brief_fma = 1 reproduces)
+    exe2 = str(tmp_path / "calibrate_check_fma")
+    subprocess.check_call(["g++", "-std=c++14", "-O3", "-mfma", "-ffp-contract=fast", "-I", os.path.join(root, "include"), "-I", os.path.join(odir, "ref_shims"),
+                           os.path.join(root, "tests", "support", "calibrate_check.cpp"), "-o", exe2, "-L", odir, "-lorb_oracle", "-Wl,-rpath," + odir])
+    line = subprocess.check_output([exe2, "0", "0", "0", "0"]).decode().strip()
+    assert line.endswith("contracts 1 form 1 frame 752x480 mismatch 0"), line
 
 
 def test_std_sort_probe_knows_libstdcxx_tie_order(tmp_path):

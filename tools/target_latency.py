@@ -28,8 +28,9 @@ for name, r in (("radius 3 px x scale (SearchByProjection, th = 3)", 3.0), ("rad
         print(f"{name}: {nq} queries, lists={want_lists}, {int(res['row_ptr'][-1])} candidates: {dt * 1e6:.1f} us per call (python caller)")
 
 # ---- first search of a NEW frame (target created from host arrays, then searched) against a search on a resident target: what the
-# hand-over work of round 3 is measured by.  Three ways of making the target: host arrays with a caller-held grid (round 2),
-# host arrays with the grid built on the device, and descriptor rows handed over from the extractor's staging block (orbx_publish_descriptors)
+# front-end tail is measured by.  Two ways of making the target: host arrays with a caller-held grid (round 2) and host arrays
+# with the grid built on the device (what the adapters do).  (Rounds 3-4 had a third: descriptor rows handed over from the extractor's staging
+# block — 58.0 us against 51.2, profiles/target_latency_r4.txt — removed in round 5.)
 import ctypes as C
 print()
 qr = (np.float32(3.0) * np.float32(1.2) ** lvl).astype(np.float32)
@@ -56,12 +57,7 @@ def resident():
 r = resident()
 a = first_search(lambda kk, dd: R.assign(kk, dd, held))
 b = first_search(lambda kk, dd: R.assign(kk, dd, grid))
-def handed(kk, dd):
-    gpu.publish_descriptors(dd)
-    R.assign(kk, dd, grid)
-c = first_search(handed)
 print(f"search on a resident target: {r:.1f} us")
 print(f"first search of a new frame = refill a recycled target (orbx_target_assign) + search (python caller, median of 50):")
 print(f"  host arrays + caller-held grid (round 2's way): {a:.1f} us  (+{a - r:.1f})")
 print(f"  host arrays, grid built on the device:           {b:.1f} us  (+{b - r:.1f})")
-print(f"  descriptor rows handed over in HBM, device grid:  {c:.1f} us  (+{c - r:.1f})")
