@@ -137,6 +137,24 @@ int orbx_reserve(orbx_ctx* ctx, int rows, int cols, int nframes);
 int orbx_set_option(orbx_ctx* ctx, const char* name, int value);
 int orbx_host_pyramid_level(orbx_ctx* ctx, int level, const uint8_t** data, size_t* stride, int* w, int* h);
 
+/* The five result-changing options by NAME: which build of "the reference CPU path" (src/ORBextractor.cc over some OpenCV, compiled with
+ * some flags: CMakeLists.txt:10-13,33, README.md:560) the output equals, bit for bit.  Profiles (INTEGRATION.md section 6 maps each to its
+ * option values and says what is recalled and what is pinned):
+ *   "opencv>=4.5.1" (= "default": what orbx_create gives)      "opencv-4.4" (= "opencv-4.4-avx2": OpenCV 3.4.2 .. 4.5.0, AVX2 dispatch)
+ *   "opencv-4.4-sse" | "opencv-4.4-avx512" | "opencv-4.4-scalar"  (the same releases, other vector lengths / no SIMD)
+ *   "opencv-3.2" (= "opencv<=3.4.1")
+ * fma_build: bit 0 = src/ORBextractor.cc itself was built with -march=native on an FMA machine ("brief_fma"); bit 1 = OpenCV runs its AVX2
+ * (FMA-contracted) dispatch copy of cv::fastAtan2 ("atan_fma"; refused for profiles whose OpenCV has none).  3 = a native build on an AVX2 host.
+ * orbx_cpu_profile_values is the table alone (no context, no device): values = {gauss_kernel, gauss_round, gauss_tail, atan_fma, brief_fma}.
+ * orbx_get_cpu_profile reports the ACTIVE set ("name +flags (option=value ...)"; "custom" when the Gaussian triple matches no profile).
+ * include/ORBextractor.h does not need these: it calibrates itself against the OpenCV it is built with (include/orbx_cv_calibrate.h). */
+int orbx_cpu_profile_count(void);
+const char* orbx_cpu_profile_name(int i);
+const char* orbx_cpu_profile_description(const char* name);
+int orbx_cpu_profile_values(const char* name, int fma_build, int values[5]);
+int orbx_set_cpu_profile(orbx_ctx* ctx, const char* name, int fma_build);
+int orbx_get_cpu_profile(const orbx_ctx* ctx, char* buf, size_t buf_bytes, int values[5]);
+
 /* The 7x7 Gaussian-blurred copy of mvImagePyramid[level] the descriptors were sampled from
  * (cv::GaussianBlur, src/ORBextractor.cc:1132-1133), for stage-level parity tests.  dst: h rows of w bytes. */
 int orbx_debug_blur_level(orbx_ctx* ctx, int frame, int level, uint8_t* dst, size_t dst_stride);
@@ -489,6 +507,57 @@ int orbx_kfdb_query(orbx_kfdb* db, const uint32_t* q_ids, const double* q_vals, 
  * keyframes, doubles bit-identical to the reference's. */
 int orbx_kfdb_sharing(orbx_kfdb* db, const uint32_t* q_ids, int nq, int64_t* kf_ids, int32_t* common_words, int cap, int* n_sharing);
 int orbx_kfdb_score(orbx_kfdb* db, const uint32_t* q_ids, const double* q_vals, int nq, const int64_t* kf_ids, int n, double* scores);
+
+/* ---- batch replay: frames sharded one camera stream per GPU + ONE exchange per step (BASELINE.json config 5) -----------------
+ * The reference has no such mode (its System owns one live camera, src/System.cc:197-264); north_star adds it: every GPU (one process each)
+ * replays its own stream(s) through the extractor — no collective on the extraction path — and after every step all ranks all-gather their
+ * fixed-size feature blocks over RCCL / xGMI, asynchronously on a stream of its own and double-buffered, so that step k's collective runs
+ * under step k + 1's kernels.  A C / C++ host drives it with these entry points alone (INTEGRATION.md section 9 has the 20-line loop);
+ * liborbx binds RCCL at run time (dlopen: the instance already in the process if there is one, else librccl.so.1; ORBX_RCCL_LIB overrides).
+ *
+ * Feature block of one rank and step (device memory, one contiguous buffer; every part 256-byte aligned):
+ *     [frames][capacity] orbx_keypoint | [frames][capacity][32] descriptor bytes | [frames][2] int32 {n, monoIndex}
+ * gather_what: ORBX_GATHER_DESCRIPTORS moves the tail of the block (descriptor rows + counts: north_star's "all-gather of descriptors"),
+ * ORBX_GATHER_BLOCKS the whole block (SURVEY §8(e)'s), ORBX_GATHER_NONE nothing (the sharded extraction alone).
+ *
+ * lanes: 1 .. 16 extractor contexts of ONE device with identical parameters, owned by the caller; each works on its contiguous share of the
+ * step's frames on a stream of its own (two lanes: +7.6 % on 256 x 640x480 — they drift out of phase and fill each other's idle issue slots).
+ * Transport, by argument: unique_id != NULL -> ncclCommInitRank(world, unique_id, rank), the 128 bytes coming from orbx_replay_unique_id() on
+ * one rank and reaching the others by whatever the host has (a file, MPI, a TCP store); host_exchange != NULL -> the caller's own host
+ * all-gather, the block staged through pinned memory (tests, hosts without RCCL between their ranks); both NULL -> world must be 1 and a
+ * one-rank RCCL group is made (the self-gather: the collective's own cost on this GPU).  Not thread-safe; one engine per thread. */
+typedef struct orbx_replay orbx_replay;
+#define ORBX_REPLAY_UNIQUE_ID_BYTES 128   /* sizeof(ncclUniqueId) */
+#define ORBX_GATHER_NONE 0
+#define ORBX_GATHER_DESCRIPTORS 1
+#define ORBX_GATHER_BLOCKS 2
+/* recv[r * bytes_per_rank ..) := rank r's `send`, for every r, on every rank; returns 0 on success.  Called from orbx_replay_step. */
+typedef int (*orbx_host_exchange_fn)(void* user, const void* send, void* recv, size_t bytes_per_rank);
+int orbx_replay_unique_id(uint8_t id[ORBX_REPLAY_UNIQUE_ID_BYTES]);   /* ncclGetUniqueId */
+const char* orbx_replay_rccl_info(void);                               /* "rccl 2.x.y (library)" or why none could be loaded */
+int orbx_replay_create(orbx_replay** out, orbx_ctx* const* lanes, int nlanes, int frames, int rows, int cols, int gather_what, int rank, int world,
+                       const uint8_t* unique_id, orbx_host_exchange_fn host_exchange, void* user);
+void orbx_replay_destroy(orbx_replay* r);                              /* waits for everything in flight; the lanes stay the caller's */
+const char* orbx_replay_last_error(const orbx_replay* r);
+const char* orbx_replay_transport(const orbx_replay* r);
+/* sizes and offsets of the block, and of what the exchange moves (any pointer may be NULL) */
+int orbx_replay_layout(const orbx_replay* r, int* frames, int* capacity, size_t* block_bytes, size_t* desc_off, size_t* counts_off, size_t* send_off,
+                       size_t* send_bytes, int* nlanes);
+int orbx_replay_lane_range(const orbx_replay* r, int lane, int* f0, int* f1);   /* frames [f0, f1) of a step's batch */
+/* One step: the hot path over `frames` resident frames (frame f, row y at d_frames + f*frame_stride + y*row_stride) into block (step & 1), then —
+ * when the exchange is on — the all-gather of that block into gathered buffer (step & 1), queued behind the step's kernels.  Returns at once
+ * (everything is asynchronous; with a host_exchange the call waits for this step's kernels) with the buffer index 0 / 1, or a negative code. */
+int orbx_replay_step(orbx_replay* r, const uint8_t* d_frames, size_t row_stride, size_t frame_stride, int lap0, int lap1);
+int orbx_replay_drain(orbx_replay* r);                                 /* wait for every lane and for the gather stream */
+int orbx_replay_set_gather(orbx_replay* r, int on);                    /* switch the exchange off / on between steps (measurements) */
+int orbx_replay_block(orbx_replay* r, int i, uint8_t** d_block);       /* this rank's block i (device pointer; layout above) */
+int orbx_replay_gathered(orbx_replay* r, int i, int rank, const uint8_t** d_part);   /* rank's send_bytes inside gathered buffer i (device pointer) */
+/* host copies (drain first): what = 0: block i, 1: gathered buffer i (world * send_bytes); orbx_replay_write_block is the reverse, for block i */
+int orbx_replay_read(orbx_replay* r, int what, int i, void* host_dst, size_t offset, size_t nbytes);
+int orbx_replay_write_block(orbx_replay* r, int i, const void* host_src, size_t offset, size_t nbytes);
+/* average device time of one step's collective (HIP events on the gather stream) since the last reset; *avg_ms = -1 when none was timed */
+int orbx_replay_gather_ms(orbx_replay* r, double* avg_ms, long long* n, int reset);
+long long orbx_replay_steps(const orbx_replay* r);
 
 #ifdef __cplusplus
 }

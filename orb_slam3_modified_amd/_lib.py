@@ -118,12 +118,36 @@ def lib() -> C.CDLL:
         "orbx_publish_descriptors": (i32, [vp, vp, i32]),
         "orbx_kfdb_sharing": (i32, [vp, vp, i32, vp, vp, i32, ip]),
         "orbx_kfdb_score": (i32, [vp, vp, vp, i32, vp, i32, vp]),
+        "orbx_cpu_profile_count": (i32, []),
+        "orbx_cpu_profile_name": (C.c_char_p, [i32]),
+        "orbx_cpu_profile_description": (C.c_char_p, [C.c_char_p]),
+        "orbx_cpu_profile_values": (i32, [C.c_char_p, i32, vp]),
+        "orbx_set_cpu_profile": (i32, [vp, C.c_char_p, i32]),
+        "orbx_get_cpu_profile": (i32, [vp, vp, sz, vp]),
+        "orbx_replay_unique_id": (i32, [vp]),
+        "orbx_replay_rccl_info": (C.c_char_p, []),
+        "orbx_replay_create": (i32, [C.POINTER(vp), vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
+        "orbx_replay_destroy": (None, [vp]),
+        "orbx_replay_last_error": (C.c_char_p, [vp]),
+        "orbx_replay_transport": (C.c_char_p, [vp]),
+        "orbx_replay_layout": (i32, [vp, ip, ip, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), ip]),
+        "orbx_replay_lane_range": (i32, [vp, i32, ip, ip]),
+        "orbx_replay_step": (i32, [vp, vp, sz, sz, i32, i32]),
+        "orbx_replay_drain": (i32, [vp]),
+        "orbx_replay_set_gather": (i32, [vp, i32]),
+        "orbx_replay_block": (i32, [vp, i32, C.POINTER(vp)]),
+        "orbx_replay_gathered": (i32, [vp, i32, i32, C.POINTER(vp)]),
+        "orbx_replay_read": (i32, [vp, i32, i32, vp, sz, sz]),
+        "orbx_replay_write_block": (i32, [vp, i32, vp, sz, sz]),
+        "orbx_replay_gather_ms": (i32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), i32]),
+        "orbx_replay_steps": (C.c_longlong, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here == header/library mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
     L._orbx_symbols = tuple(sig)
+    L.HOST_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)   # orbx_host_exchange_fn
     _lib = L
     return L
 

@@ -8,11 +8,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "liborbx.so")
-SOURCES = ["orbx_extractor.hip", "orbx_matcher.hip", "orbx_search.hip", "orbx_window.hip", "orbx_kfdb.hip"]
+SOURCES = ["orbx_extractor.hip", "orbx_matcher.hip", "orbx_search.hip", "orbx_window.hip", "orbx_kfdb.hip", "orbx_replay.hip"]
 # -ffp-contract=off: the float paths (fastAtan2 polynomial, BRIEF rotation) must not be fused into FMAs,
 # the CPU reference evaluates them as separate IEEE operations (DESIGN.md "bit-exactness").
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",
-         "-Wno-unused-function"]
+         "-Wno-unused-function", "-ldl"]
 
 
 def kernels_hash() -> str:
@@ -47,10 +47,36 @@ def _stale() -> bool:
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
+    """One object per source (compiled in parallel, rebuilt only when the source or a header is newer), then one link."""
     if not (force or _stale()):
         return OUT
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "hipcc")
-    cmd = [hipcc] + FLAGS + os.environ.get("ORBX_EXTRA_FLAGS", "").split() + ["-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
+    extra = os.environ.get("ORBX_EXTRA_FLAGS", "").split()
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    cflags = [f for f in FLAGS if f not in ("-shared", "-ldl")] + extra
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if not f.endswith(".hip") or f == "orbx_kernels.hip"] + [os.path.join(HERE, "..", "include", "orbx.h")]
+    hnew = max(os.path.getmtime(h) for h in headers if os.path.isfile(h))
+    tag = os.path.join(objdir, ".flags")
+    flags_now = " ".join([hipcc] + cflags)
+    same_flags = os.path.exists(tag) and open(tag).read() == flags_now
+
+    def compile_one(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        sp = os.path.join(CSRC, src)
+        if not force and same_flags and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(sp), hnew):
+            return obj
+        cmd = [hipcc] + cflags + ["-c", sp, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd, cwd=CSRC)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    open(tag, "w").write(flags_now)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd, cwd=CSRC)

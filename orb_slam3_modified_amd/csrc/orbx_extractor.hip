@@ -345,7 +345,10 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
   // runs concurrently with the (latency-bound) pyramid chain; joined before the quadtree.  Off by default for a lone
   // context (no gain: both kernels fill the CUs); the replay lanes switch it on (orbx_set_option), where it pays.
   const int need = geo.max_cell_w + 3;  // +3: alignment shift of the dword-staged rows
-  const int pitchB = need <= 64 ? 64 : 96;
+  // "fast_pitch" (0 = by cell width): 80 / 96 bytes for every shape are the LDS bank-conflict experiments of round 5 (HISTORY.md); only the
+  // packed 128-thread kernel is instantiated for 80
+  int pitchB = need <= 64 ? 64 : 96;
+  if (ctx->fast_pitch == 96 || (ctx->fast_pitch == 80 && need <= 80 && ctx->fast_pk && ctx->fast_threads == 128 && nframes > 4)) pitchB = std::max(pitchB, ctx->fast_pitch);   // (80: the batch kernel only; the fused single-frame launch has 64 / 96)
   if (need > 96 || geo.max_cell_h > 127 + 6 || round_up((geo.max_cell_w - 6) * (geo.max_cell_h - 6), 8) > 8192)
     return set_err(ctx, ORBX_E_CAPACITY, "FAST cell larger than the kernel's LDS tile");
   if (!div_ok((uint64_t)geo.cells.size() * nframes + 8, geo.cells.size()) ||
@@ -369,7 +372,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
   };
   auto fast_kern = pitchB == 64 ? (ft == 64 ? k_fast_cells<64, 64> : ft == 128 ? k_fast_cells<128, 64> : k_fast_cells<256, 64>)
                                 : (ft == 64 ? k_fast_cells<64, 96> : ft == 128 ? k_fast_cells<128, 96> : k_fast_cells<256, 96>);
-  if (ctx->fast_pk && ft == 128) fast_kern = pitchB == 64 ? k_fast_cells<128, 64, true> : k_fast_cells<128, 96, true>;
+  if (ctx->fast_pk && ft == 128) fast_kern = pitchB == 64 ? k_fast_cells<128, 64, true> : pitchB == 80 ? k_fast_cells<128, 80, true> : k_fast_cells<128, 96, true>;
   if (ctx->fast_pk && ft == 64) fast_kern = pitchB == 64 ? k_fast_cells<64, 64, true> : k_fast_cells<64, 96, true>;
   auto launch_fast_range = [&](int cell_base, int ncells_sub, hipStream_t s) {
     const int nitems = ncells_sub * nframes;
@@ -904,6 +907,7 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, 
 #endif
     { const char* e = getenv("ORBX_REALIGN"); ctx->realign = e ? atoi(e) != 0 : true; }
     { const char* e = getenv("ORBX_FAST_STAGE_DMA"); ctx->fast_stage_dma = e ? atoi(e) != 0 : true; }
+    { const char* e = getenv("ORBX_FAST_PITCH"); const int v = e ? atoi(e) : 0; ctx->fast_pitch = (v == 80 || v == 96) ? v : 0; }
     { const char* e = getenv("ORBX_FAST_DMA"); if (e && atoi(e) >= 0 && atoi(e) <= 64) ctx->fast_dma = atoi(e); }
     const char* fs = getenv("ORBX_FAST_STOP");
     ctx->fast_stop = fs ? atoi(fs) : 0;
@@ -1447,6 +1451,7 @@ int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
   else if (n == "graph_timing") { ctx->graph_timing = value != 0; return ORBX_OK; }   // no re-capture needed
   else if (n == "fast_pk") ctx->fast_pk = value != 0;
   else if (n == "realign") ctx->realign = value != 0;   // batch frames with rows that are not dword-aligned: one pass into an aligned copy first
+  else if (n == "fast_pitch" && (value == 0 || value == 80 || value == 96)) ctx->fast_pitch = value;   // LDS pitch of the FAST tile: 0 = 64 / 96 by cell width
   else if (n == "fast_stage_dma") ctx->fast_stage_dma = value != 0;   // FAST tile staged by LDS-DMA loads instead of load + ds_write
   else if (n == "fast_dma" && value >= 0 && value <= 64) ctx->fast_dma = value;   // cells per FAST workgroup with LDS-DMA tile prefetch (0 = off; experiment)
 #ifdef ORBX_FAST_EARLY_OPTION
@@ -1483,6 +1488,62 @@ int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
   else if (n == "view_pool_cap" && value >= 16) { ctx->view_pool_cap = value; return ORBX_OK; }   // test hook: the learnt candidate-pool capacity of orbx_target_search_view
   else return set_err(ctx, ORBX_E_INVALID, "orbx_set_option: unknown option or value out of range: " + n);
   ctx->buf_epoch++;   // a captured single-frame graph holds the launch shape of the old options: capture again
+  return ORBX_OK;
+}
+
+// ---- named sets of the five result-changing options: WHICH build of "the reference CPU path" the output equals ----
+namespace {
+struct CpuProfile { const char* name; const char* alias; int gauss_kernel, gauss_round, gauss_tail; bool has_avx2_atan; const char* what; };
+// the release ranges are recalled (no OpenCV of any version in the build container): tools/validate_opencv.cpp is how a maintainer checks them
+const CpuProfile kProfiles[] = {
+    {"opencv>=4.5.1", "default", 0, 0, 0, true, "cv::GaussianBlur 8u with the error-diffused kernel {18,34,48,56,...}, (acc + 2^15) >> 16: OpenCV >= 4.5.1 and every scalar path"},
+    {"opencv-4.4", "opencv-4.4-avx2", 1, 2, 16, true, "OpenCV 3.4.2 .. 4.5.0 (CMakeLists.txt:33 asks for 4.4): kernel {18,34,49,55,...}, SIMD column pass that floors, v_uint16 of 16 lanes (AVX2 dispatch)"},
+    {"opencv-4.4-sse", nullptr, 1, 2, 8, false, "the same releases on the SSE baseline: 8 lanes"},
+    {"opencv-4.4-avx512", nullptr, 1, 2, 32, true, "the same releases with the AVX-512 dispatch: 32 lanes"},
+    {"opencv-4.4-scalar", nullptr, 1, 0, 0, false, "the same releases without SIMD (CV_DISABLE_OPTIMIZATION / non-x86): kernel {18,34,49,55,...}, half-up rounding"},
+    {"opencv-3.2", "opencv<=3.4.1", 1, 1, 4, false, "OpenCV <= 3.4.1 (README.md:560 names 3.2.0): integer sepFilter2D, SSE2 column pass (float sum + cvtps2dq: ties to even), 4-column tail"},
+};
+const CpuProfile* find_profile(const char* name) {
+  if (!name) return nullptr;
+  for (const CpuProfile& p : kProfiles) if (!strcmp(name, p.name) || (p.alias && !strcmp(name, p.alias))) return &p;
+  return nullptr;
+}
+}  // namespace
+
+int orbx_cpu_profile_count(void) { return (int)(sizeof(kProfiles) / sizeof(kProfiles[0])); }
+const char* orbx_cpu_profile_name(int i) { return i >= 0 && i < orbx_cpu_profile_count() ? kProfiles[i].name : nullptr; }
+const char* orbx_cpu_profile_description(const char* name) { const CpuProfile* p = find_profile(name); return p ? p->what : nullptr; }
+
+int orbx_cpu_profile_values(const char* name, int fma_build, int values[5]) {
+  const CpuProfile* p = find_profile(name);
+  if (!p || !values || fma_build < 0 || fma_build > 3) return ORBX_E_INVALID;
+  values[0] = p->gauss_kernel; values[1] = p->gauss_round; values[2] = p->gauss_tail;
+  values[3] = (fma_build & 2) ? 1 : 0;   // atan_fma: OpenCV's AVX2 dispatch copy of cv::fastAtan2 runs (an FMA machine AND a release / build that has one)
+  values[4] = (fma_build & 1) ? 1 : 0;   // brief_fma: src/ORBextractor.cc itself built with -march=native on an FMA machine
+  if ((fma_build & 2) && !p->has_avx2_atan) return ORBX_E_INVALID;   // this profile's OpenCV has no FMA copy of fastAtan2
+  return ORBX_OK;
+}
+
+int orbx_set_cpu_profile(orbx_ctx* ctx, const char* name, int fma_build) {
+  if (!ctx) return ORBX_E_INVALID;
+  int v[5];
+  if (orbx_cpu_profile_values(name, fma_build, v) != ORBX_OK)
+    return set_err(ctx, ORBX_E_INVALID, std::string("orbx_set_cpu_profile: unknown profile or fma_build out of range for it: ") + (name ? name : "(null)"));
+  static const char* opt[5] = {"gauss_kernel", "gauss_round", "gauss_tail", "atan_fma", "brief_fma"};
+  for (int i = 0; i < 5; i++) { const int rc = orbx_set_option(ctx, opt[i], v[i]); if (rc != ORBX_OK) return rc; }
+  return ORBX_OK;
+}
+
+int orbx_get_cpu_profile(const orbx_ctx* ctx, char* buf, size_t buf_bytes, int values[5]) {
+  if (!ctx) return ORBX_E_INVALID;
+  const int v[5] = {ctx->gauss_kernel, ctx->gauss_round, ctx->gauss_tail, ctx->atan_fma, ctx->brief_fma};
+  if (values) for (int i = 0; i < 5; i++) values[i] = v[i];
+  if (buf && buf_bytes) {
+    const char* nm = "custom";
+    for (const CpuProfile& p : kProfiles) if (p.gauss_kernel == v[0] && p.gauss_round == v[1] && p.gauss_tail == v[2]) { nm = p.name; break; }
+    snprintf(buf, buf_bytes, "%s%s%s (gauss_kernel=%d gauss_round=%d gauss_tail=%d atan_fma=%d brief_fma=%d)", nm, v[3] ? " +avx2-atan" : "", v[4] ? " +native-build" : "",
+             v[0], v[1], v[2], v[3], v[4]);
+  }
   return ORBX_OK;
 }
 

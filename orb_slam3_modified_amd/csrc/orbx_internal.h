@@ -156,6 +156,7 @@ struct orbx_ctx {
   uint8_t* d_realign = nullptr;
   size_t realign_bytes = 0;
   bool fast_stage_dma = true;   // FAST: the cell's tile by LDS-DMA loads (aligned sources; stop_after bit 9)
+  int fast_pitch = 0;   // LDS pitch of the FAST tile in bytes: 0 = 64 / 96 by cell width; 80 / 96 = for every shape (experiments)
   int fast_dma = 0;   // experiment: cells per FAST workgroup with the next tile prefetched by LDS-DMA (0 = one cell per workgroup, no DMA)
   int qt_points = 2048;       // LDS-resident candidate capacity per (frame, level) of k_quadtree's big levels ("qt_points" / ORBX_QT_POINTS)
   int chain_threads = 1024;   // workgroup size of k_resize_chain (ORBX_CHAIN_THREADS)

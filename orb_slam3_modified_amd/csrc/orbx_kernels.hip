@@ -498,6 +498,19 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (uint32_t)(__mul24(r, pitch) + 4 * c)),
                                          (__attribute__((address_space(3))) void*)dst, 4, 0, 0);
     }
+  } else if (PITCH != 64 && al && (stop_after & 0x200)) {
+    // any other pitch ("fast_pitch" 80 / 96: the bank-conflict experiments of round 5, HISTORY.md): the tile as a FLAT dword stream — dword
+    // d = T * trip + t lands at LDS dword d (lane-linear, as global_load_lds requires) and is fetched from row d / P4, column d % P4 of the
+    // source (per-lane SOURCE addresses are free; the division is by a compile-time constant); pad columns (c >= ndw) are not loaded
+    const uint8_t* src = img + (long long)cg.y0 * pitch + (cg.x0 - xo);
+    const int ndw = (xo + cw + 3) >> 2, total = ch * P4;
+    for (int d0 = 0; d0 < total; d0 += T) {
+      const uint32_t d = (uint32_t)(d0 + t), r = d / (uint32_t)P4, c = d - r * (uint32_t)P4;
+      uint8_t* dst = tile + (size_t)(d0 + (t & ~63)) * 4;   // wave-uniform; the hardware adds lane * 4
+      if ((int)d < total && (int)c < ndw)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (uint32_t)(__mul24((int)r, pitch) + 4 * (int)c)),
+                                         (__attribute__((address_space(3))) void*)dst, 4, 0, 0);
+    }
   } else if (al) {
     const uint8_t* src = img + (long long)cg.y0 * pitch + (cg.x0 - xo);
     const int ndw = (xo + cw + 3) >> 2;
@@ -515,7 +528,7 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
   for (int i = t; i < ((dh + 2) * P4 + 3) >> 2; i += T) ((uint4*)sc)[i] = make_uint4(0u, 0u, 0u, 0u);  // sc is 16-byte aligned
   for (int i = t; i < nwords; i += T) bitmap[i] = 0;
   if (t == 0) { s_cnt = 0; s_any = 0; }
-  if (!DMA && PITCH == 64 && (stop_after & 0x200)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile's LDS-DMA loads (block-uniform)
+  if (!DMA && (stop_after & 0x200)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile's LDS-DMA loads (block-uniform)
   cell_sync<DMA>();
 #ifdef ORBX_FAST_EARLY_OPTION
   const int early = (stop_after >> 8) & 1;   // "fast_early": the wave-uniform early-out of stage B (same results; measured at +-1 %, HISTORY.md)

@@ -39,7 +39,10 @@ class ORBextractor:
     def clone(self) -> "ORBextractor":
         """A second context with the same parameters (own stream, own buffers): contexts are independent, so two of them
         can work on two halves of a batch concurrently (replay lanes, stereo)."""
-        return ORBextractor(self.nfeatures, self._ctor_scale, self.nlevels, self.iniThFAST, self.minThFAST, self.device_id)
+        c = ORBextractor(self.nfeatures, self._ctor_scale, self.nlevels, self.iniThFAST, self.minThFAST, self.device_id)
+        for k, v in self.cpu_profile()[1].items():   # the five result-changing options travel with the clone (launch-shape knobs do not)
+            c.set_option(k, v)
+        return c
 
     def close(self):
         if getattr(self, "_ctx", None) and self._ctx.value:
@@ -222,6 +225,31 @@ class ORBextractor:
         OpenCV-build options do, by design: gauss_kernel / gauss_round / gauss_tail (which release's 8-bit cv::GaussianBlur), atan_fma,
         brief_fma (FMA contraction in cv::fastAtan2 / in the reference's own pattern rotation) — INTEGRATION.md section 6."""
         check(self._L.orbx_set_option(self._ctx, name.encode(), int(value)), self._ctx)
+
+    def set_cpu_profile(self, name: str, fma_build: int = 0) -> None:
+        """orbx_set_cpu_profile: the five result-changing options by name — "opencv>=4.5.1" (default), "opencv-4.4" (= -avx2; also -sse,
+        -avx512, -scalar), "opencv-3.2"; fma_build bit 0 = the reference built -march=native on an FMA machine, bit 1 = OpenCV's AVX2 fastAtan2."""
+        check(self._L.orbx_set_cpu_profile(self._ctx, name.encode(), int(fma_build)), self._ctx)
+
+    def cpu_profile(self):
+        """(description string, {option: value}) of the ACTIVE set (orbx_get_cpu_profile)."""
+        import ctypes as C
+        buf = C.create_string_buffer(256)
+        v = np.zeros(5, np.int32)
+        check(self._L.orbx_get_cpu_profile(self._ctx, buf, 256, ptr(v)), self._ctx)
+        return buf.value.decode(), dict(zip(("gauss_kernel", "gauss_round", "gauss_tail", "atan_fma", "brief_fma"), (int(x) for x in v)))
+
+    @staticmethod
+    def cpu_profiles():
+        """{name: (description, option values with fma_build = 0)} of every named profile (host-only table: no device needed)."""
+        L = _lib.lib()
+        out = {}
+        for i in range(L.orbx_cpu_profile_count()):
+            nm = L.orbx_cpu_profile_name(i)
+            v = np.zeros(5, np.int32)
+            check(L.orbx_cpu_profile_values(nm, 0, ptr(v)))
+            out[nm.decode()] = (L.orbx_cpu_profile_description(nm).decode(), tuple(int(x) for x in v))
+        return out
 
     def profile_enable(self, on: bool = True):
         check(self._L.orbx_profile_enable(self._ctx, int(on)), self._ctx)

@@ -1,10 +1,12 @@
-"""Batch-replay driver: camera streams sharded one per GPU, optional RCCL all-gather of the per-frame
-feature blocks (BASELINE.json config 5).
+"""Batch replay: camera streams sharded one per GPU, one all-gather of the per-step feature blocks (BASELINE.json
+config 5).  The engine itself is C++ behind the C ABI (include/orbx.h: orbx_replay_*, csrc/orbx_replay.hip): lanes on their own streams,
+double-buffered blocks, ncclAllGather called directly on a gather stream.  This module is the ctypes mirror of it plus the host-side
+pieces a Python job adds: which rank am I and how do the 128 bytes of the ncclUniqueId reach the other ranks (torch.distributed when the
+job was launched by it — process launch and control plane only — or explicit arguments), and, for a process group without RCCL between its
+ranks (gloo: the CPU suite, two ranks sharing one GPU), a host all-gather handed to the engine as a callback.
 
-One process per GPU (`torch.distributed`, backend "nccl" = RCCL on ROCm; "gloo" for the CPU unit tests of the
-sharding / packing logic).  Frames are independent units, so extraction itself needs no collective; the only
-exchange is the all-gather that gives every rank all cameras' descriptors, and it is issued asynchronously so it
-overlaps the next batch's kernels (double-buffered feature blocks).
+Frames are independent units, so extraction itself needs no collective; the only exchange is the all-gather that gives every rank all
+cameras' descriptors, queued behind the step's kernels so that it overlaps the next step's.
 
 Feature block layout per rank and step (one contiguous uint8 buffer, fixed size so the gather is regular):
     [B][cap] orbx_keypoint (28 B) | [B][cap][32] descriptor bytes | [B][2] int32 (n, monoIndex)
@@ -58,168 +60,212 @@ def unpack_block(block: np.ndarray, layout: BlockLayout):
 
 
 class ReplayEngine:
-    """Per-rank replay loop over device-resident frames with an overlapped all-gather of feature blocks.
+    """Per-rank replay loop over device-resident frames with an overlapped all-gather of feature blocks (ctypes mirror of orbx_replay).
 
     lanes > 1 splits the batch over that many extractor contexts, each on its own free-running stream.  The hot path
     alternates issue-bound kernels (FAST, blur, descriptors) with latency-bound ones (pyramid chain, quadtree); lanes that
     are never joined per step drift out of phase and fill each other's idle issue slots (measured: 2 lanes +7.6 % on
     256 x 640x480, 4 lanes less).  Results are identical: frames are independent and each lane writes its own rows of
-    the step's feature block."""
+    the step's feature block.
+
+    frames_dev: one batch or a list of batches the steps rotate through (step k takes batch k mod len); a batch is anything with
+    .data_ptr() / .shape == (B, H, W) / .stride() in elements of one byte (a torch uint8 tensor on this rank's GPU) or a tuple
+    (device_address, B, H, W, row_stride, frame_stride).
+    gather: True -> one exchange per step.  Who the other ranks are: rank / world / unique_id arguments (any launcher), else the
+    torch.distributed group this process is in — backend "nccl": rank 0 makes the ncclUniqueId (orbx_replay_unique_id) and broadcasts it, the
+    collective is RCCL called by liborbx; any other backend (gloo): the engine stages the block through pinned memory and calls back into
+    dist.all_gather — else a one-rank RCCL group (the self-gather)."""
 
     def __init__(self, extractor, frames_dev, lapping=(0, 1000), gather: bool = True, process_group=None, lanes: int = 1,
-                 gather_what: str = "blocks"):
-        import torch
-        import torch.distributed as dist
-        self.torch, self.dist = torch, dist
-        # gather_what: "blocks" (default: `gathered` holds whole feature blocks, indexable with BlockLayout offsets) or "descriptors"
-        # (north_star's exchange, what bench.py asks for: descriptor rows + counts only — read it through gathered_view())
+                 gather_what: str = "blocks", rank: Optional[int] = None, world: Optional[int] = None, unique_id: Optional[bytes] = None):
+        import ctypes as C
+        import sys
+        from . import _lib
+        self._C, self._lib = C, _lib
+        self._L = L = _lib.lib()
         assert gather_what in ("descriptors", "blocks")
         self.gather_what = gather_what
         self.ex = extractor
-        # frames_dev: torch uint8 [B, H, W] on this rank's GPU, or a list of such batches (same shape) that the steps rotate
-        # through — step k processes batch k mod len
-        self.frame_sets = list(frames_dev) if isinstance(frames_dev, (list, tuple)) else [frames_dev]
-        frames_dev = self.frame_sets[0]
-        assert all(f.shape == frames_dev.shape and f.stride() == frames_dev.stride() for f in self.frame_sets)
-        self.frames = frames_dev
-        self.B, self.H, self.W = frames_dev.shape
-        self.lap = lapping
-        self.layout = BlockLayout(self.B, extractor.capacity)
-        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.gather = gather and dist.is_initialized()   # a 1-rank group still exercises the collective path (tests)
+        sets = list(frames_dev) if isinstance(frames_dev, list) or (isinstance(frames_dev, tuple) and not isinstance(frames_dev[0], int)) else [frames_dev]
+        self._keep = sets                     # the caller's buffers stay alive as long as the engine steps over them
+        self.frame_sets = [self._describe(f) for f in sets]
+        assert all(f[1:] == self.frame_sets[0][1:] for f in self.frame_sets), "every batch of the rotation must have the same shape and strides"
+        _, self.B, self.H, self.W, self._row_stride, self._frame_stride = self.frame_sets[0]
+        self.lap = (int(lapping[0]), int(lapping[1]))
+        # ---- who are the other ranks
+        dist = None
+        if rank is None and world is None and "torch" in sys.modules:
+            import torch.distributed as _dist
+            if _dist.is_available() and _dist.is_initialized():
+                dist = _dist
         self.pg = process_group
-        dev = frames_dev.device
-        self.blocks = [torch.zeros(self.layout.nbytes, dtype=torch.uint8, device=dev) for _ in range(2)]
-        # what every rank receives from every other rank per step: the descriptor rows + the per-frame counts (north_star: "RCCL
-        # all-gather of descriptors"; [B][cap][32] + [B][2] int32 — the tail of the block, contiguous), or the whole block with the
-        # 28-byte keypoints as well (SURVEY.md §8(e)'s block).  Fixed size, so the collective is regular.
-        self.send_off = self.layout.desc_off if gather_what == "descriptors" else 0
-        self.send_bytes = self.layout.nbytes - self.send_off
-        self.gathered = [torch.zeros(self.send_bytes * self.world, dtype=torch.uint8, device=dev) if self.gather else None
-                         for _ in range(2)]
-        self.pending = [None, None]
-        # transport: RCCL ("nccl") moves device buffers asynchronously on the gather stream; any other backend (gloo: the CPU suite and the
-        # two-ranks-on-one-GPU test, where RCCL refuses a shared device) stages through pinned host buffers, synchronously
-        self.device_collective = self.gather and dist.get_backend(process_group) == "nccl"
-        if self.gather and not self.device_collective:
-            pin = dev.type == "cuda"
-            self.h_send = torch.zeros(self.send_bytes, dtype=torch.uint8, pin_memory=pin)
-            self.h_recv = torch.zeros(self.send_bytes * self.world, dtype=torch.uint8, pin_memory=pin)
-        self.gather_events = []   # (start, end) timing events of the collectives since reset_gather_timing()
-        self.step_idx = 0
-        # Explicit (non-default) streams carry the kernels AND order the collective behind them: the default stream's
-        # handle is NULL, which the C ABI reads as "use the context's own stream" — invisible to torch/RCCL.
+        if dist is not None:
+            rank, world = dist.get_rank(process_group), dist.get_world_size(process_group)
+        self.rank, self.world = int(rank or 0), int(world or 1)
+        host_cb = None
+        if gather and dist is not None and dist.get_backend(process_group) == "nccl":
+            if unique_id is None:   # RCCL between the ranks, called by liborbx: the id travels over the job's own control plane
+                box = [None]
+                if self.rank == 0:
+                    buf = (C.c_uint8 * 128)()
+                    _lib.check(L.orbx_replay_unique_id(buf))
+                    box[0] = bytes(buf)
+                dist.broadcast_object_list(box, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0, group=process_group)
+                unique_id = box[0]
+        elif gather and dist is not None:
+            import numpy as _np
+            import torch
+
+            def _exchange(_user, send, recv, nbytes):   # orbx_host_exchange_fn over the job's (non-RCCL) process group
+                try:
+                    s = torch.from_numpy(_np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(send)))
+                    r = torch.from_numpy(_np.ctypeslib.as_array((C.c_uint8 * (nbytes * self.world)).from_address(recv)))
+                    try:
+                        dist.all_gather_into_tensor(r, s, group=process_group)
+                    except (RuntimeError, AttributeError, NotImplementedError):   # a backend without the flat form
+                        dist.all_gather(list(r.view(self.world, nbytes).unbind(0)), s, group=process_group)
+                    return 0
+                except Exception as e:   # noqa: BLE001 — must not unwind through the C frame
+                    sys.stderr.write(f"[orbx replay] host all-gather failed: {e}\n")
+                    return 1
+            host_cb = L.HOST_EXCHANGE_FN(_exchange)
+        self._host_cb = host_cb               # keeps the trampoline alive
+        if gather and self.world > 1 and unique_id is None and host_cb is None:
+            raise ValueError("ReplayEngine: world > 1 with gather needs a unique_id (orbx_replay_unique_id on one rank) or a torch.distributed group")
+        # ---- lanes: contexts of the caller's extractor's parameters (the first lane IS the caller's context)
         lanes = max(1, min(int(lanes), self.B // 32 if self.B >= 64 else 1))
         per = (self.B + lanes - 1) // lanes
-        self.lane_ranges = [(j * per, min(self.B, (j + 1) * per)) for j in range(lanes) if j * per < self.B]
-        self.exs = [extractor] + [extractor.clone() for _ in self.lane_ranges[1:]]
-        if len(self.lane_ranges) > 1:
-            # with a second lane filling the idle issue slots, the in-lane forks that pay are different from the single-lane
-            # ones.  Measured on all eight combinations, 2 lanes x 128 frames, three repetitions (round 2, after FAST reached
-            # full residency): blur forked behind FAST + level-0 FAST beside the pyramid chain + the quadtree as one launch
-            # = 0.985 ms per step against 0.999 for round 1's choice (blur in line, quadtree levels split) and 1.03 with no
-            # fork at all; ORBX_* environment variables still win
-            import os
-            for ex in self.exs:
-                for name, env, val in (("fork_blur", "ORBX_FORK_BLUR", 1), ("fork_fast0", "ORBX_FORK_FAST0", 1), ("fork_qt", "ORBX_FORK_QT", 0)):
-                    if env not in os.environ:
-                        ex.set_option(name, val)
-        if dev.type == "cuda":   # buffers of every lane now, not inside the first (possibly timed) step
-            for ex, (f0, f1) in zip(self.exs, self.lane_ranges):
-                ex.reserve(self.H, self.W, f1 - f0)
-        cuda = dev.type == "cuda"
-        self.streams = [torch.cuda.Stream(device=dev) if cuda else None for _ in self.lane_ranges]
-        self.stream = self.streams[0]
-        # the collective ALWAYS runs on its own stream behind every lane of the step: on a lane's stream step k + 1's kernels would queue
-        # behind step k's collective and the overlap would be gone
-        self.gstream = torch.cuda.Stream(device=dev) if cuda else None
-        self.lane_done = [[torch.cuda.Event() for _ in self.lane_ranges] for _ in range(2)] if cuda else None
+        nl = len([j for j in range(lanes) if j * per < self.B])
+        self.exs = [extractor] + [extractor.clone() for _ in range(nl - 1)]
+        arr = (C.c_void_p * nl)(*[e._ctx for e in self.exs])
+        h = C.c_void_p()
+        what = 0 if not gather else (1 if gather_what == "descriptors" else 2)
+        uid = (C.c_uint8 * 128).from_buffer_copy(unique_id) if unique_id is not None else None
+        rc = L.orbx_replay_create(C.byref(h), arr, nl, self.B, self.H, self.W, what, self.rank, self.world, uid,
+                                  C.cast(host_cb, C.c_void_p) if host_cb is not None else None, None)
+        _lib.check(rc, self.exs[0]._ctx)
+        self._h = h
+        fr, cap, nb, do, co, so, sb, nlan = C.c_int(), C.c_int(), C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_int()
+        self._check(L.orbx_replay_layout(h, C.byref(fr), C.byref(cap), C.byref(nb), C.byref(do), C.byref(co), C.byref(so), C.byref(sb), C.byref(nlan)))
+        self.layout = BlockLayout(self.B, cap.value)
+        assert (self.layout.nbytes, self.layout.desc_off, self.layout.counts_off) == (nb.value, do.value, co.value), "BlockLayout != orbx_replay_layout"
+        self.send_off, self.send_bytes = so.value, sb.value
+        self.lane_ranges = []
+        for j in range(nlan.value):
+            f0, f1 = C.c_int(), C.c_int()
+            self._check(L.orbx_replay_lane_range(h, j, C.byref(f0), C.byref(f1)))
+            self.lane_ranges.append((f0.value, f1.value))
+        self._gather_cfg = bool(gather)
+        self._gather = bool(gather)
+        self.device_collective = bool(gather) and host_cb is None      # RCCL, asynchronous on the gather stream
+        self.transport = L.orbx_replay_transport(h).decode()
+        self.step_idx = 0
 
-    def step(self):
-        """One pass of the hot path over this rank's batch (+ async all-gather of the resulting block)."""
-        torch = self.torch
-        i = self.step_idx & 1
-        blk = self.blocks[i]
-        base = blk.data_ptr()
-        lo = self.layout
-        pend = self.pending[i]
-        frames = self.frame_sets[self.step_idx % len(self.frame_sets)]
-        for j, (f0, f1) in enumerate(self.lane_ranges):
-            with torch.cuda.stream(self.streams[j]):
-                if pend is not None:  # the gather that last read this buffer must be done before a lane overwrites it
-                    pend.wait()       # (makes this lane's stream wait for the collective)
-                fr = frames[f0:f1]
-                self.exs[j].extract_batch_device(fr.data_ptr(), f1 - f0, self.H, self.W, frames.stride(1), frames.stride(0),
-                                                 base + f0 * lo.cap * KP_BYTES, base + lo.desc_off + f0 * lo.cap * 32,
-                                                 base + lo.counts_off + f0 * 8, self.lap, self.streams[j].cuda_stream)
-                if self.gather:
-                    self.lane_done[i][j].record(self.streams[j])
-        self.pending[i] = None
-        if self.gather:  # enqueued behind the kernels of this step, overlaps the next step's kernels
-            send = blk[self.send_off:]
-            with torch.cuda.stream(self.gstream):
-                for ev in self.lane_done[i]:
-                    self.gstream.wait_event(ev)
-                if self.device_collective:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record(self.gstream)
-                    self.pending[i] = self.dist.all_gather_into_tensor(self.gathered[i], send, group=self.pg, async_op=True)
-                    self.pending[i].wait()   # orders the gather stream behind the collective (no host wait)
-                    e1.record(self.gstream)
-                    if len(self.gather_events) < 4096:
-                        self.gather_events.append((e0, e1))
-                else:
-                    self.h_send.copy_(send, non_blocking=True)
-                    self.gstream.synchronize()
-                    self._host_all_gather()
-                    self.gathered[i].copy_(self.h_recv, non_blocking=True)
+    @staticmethod
+    def _describe(f):
+        if isinstance(f, tuple):
+            ptr, B, H, W, rs, fs = f
+            return (int(ptr), int(B), int(H), int(W), int(rs), int(fs))
+        B, H, W = (int(v) for v in f.shape)
+        st = f.stride() if callable(getattr(f, "stride", None)) else f.strides
+        assert int(st[2]) == 1, "pixels of a row must be contiguous"
+        return (int(f.data_ptr()), B, H, W, int(st[1]), int(st[0]))
+
+    def _check(self, rc):
+        if rc < 0:
+            raise self._lib.OrbxError(rc, self._L.orbx_replay_last_error(self._h).decode())
+        return rc
+
+    # ---- the exchange can be switched off / on between steps (bench.py measures the same loop both ways)
+    @property
+    def gather(self) -> bool:
+        return self._gather
+
+    @gather.setter
+    def gather(self, on: bool):
+        if on and not self._gather_cfg:
+            raise ValueError("this engine was created without an exchange")
+        self._check(self._L.orbx_replay_set_gather(self._h, 1 if on else 0))
+        self._gather = bool(on)
+
+    def step(self) -> int:
+        """One pass of the hot path over this rank's batch (+ the asynchronous all-gather of the resulting block).  Returns the buffer index."""
+        ptr = self.frame_sets[self.step_idx % len(self.frame_sets)][0]
+        i = self._check(self._L.orbx_replay_step(self._h, ptr, self._row_stride, self._frame_stride, self.lap[0], self.lap[1]))
         self.step_idx += 1
         return i
 
-    def _host_all_gather(self):
-        dist = self.dist
-        try:
-            dist.all_gather_into_tensor(self.h_recv, self.h_send, group=self.pg)
-        except (RuntimeError, AttributeError, NotImplementedError):   # a backend without the flat form
-            parts = list(self.h_recv.view(self.world, self.send_bytes).unbind(0))
-            dist.all_gather(parts, self.h_send, group=self.pg)
+    def drain(self):
+        self._check(self._L.orbx_replay_drain(self._h))
 
     def reset_gather_timing(self):
-        self.gather_events = []
+        self._check(self._L.orbx_replay_gather_ms(self._h, None, None, 1))
 
     def gather_ms(self):
         """Average device time of one step's collective (HIP events on the gather stream) since reset_gather_timing(); None without one."""
-        if not self.gather_events:
-            return None
-        self.drain()
-        return sum(a.elapsed_time(b) for a, b in self.gather_events) / len(self.gather_events)
+        C = self._C
+        ms, n = C.c_double(), C.c_longlong()
+        self._check(self._L.orbx_replay_gather_ms(self._h, C.byref(ms), C.byref(n), 0))
+        return ms.value if n.value > 0 else None
+
+    # ---- buffers: device addresses for callers with their own device code, host copies (numpy) for everybody else
+    def block_ptr(self, i: int) -> int:
+        p = self._C.c_void_p()
+        self._check(self._L.orbx_replay_block(self._h, i, self._C.byref(p)))
+        return int(p.value)
+
+    def gathered_ptr(self, i: int, rank: int) -> int:
+        p = self._C.c_void_p()
+        self._check(self._L.orbx_replay_gathered(self._h, i, rank, self._C.byref(p)))
+        return int(p.value)
+
+    def block_host(self, i: int) -> np.ndarray:
+        """This rank's feature block i as host bytes (waits for everything in flight); unpack_block() reads it."""
+        out = np.empty(self.layout.nbytes, np.uint8)
+        self._check(self._L.orbx_replay_read(self._h, 0, i, self._lib.ptr(out), 0, out.nbytes))
+        return out
+
+    def write_block(self, i: int, data: np.ndarray):
+        data = np.ascontiguousarray(data, np.uint8).reshape(-1)
+        assert data.nbytes == self.layout.nbytes
+        self._check(self._L.orbx_replay_write_block(self._h, i, self._lib.ptr(data), 0, data.nbytes))
+
+    def gathered_host(self, i: int) -> np.ndarray:
+        """Gathered buffer i, [world][send_bytes] host bytes."""
+        out = np.empty(self.send_bytes * self.world, np.uint8)
+        self._check(self._L.orbx_replay_read(self._h, 1, i, self._lib.ptr(out), 0, out.nbytes))
+        return out.reshape(self.world, self.send_bytes)
 
     def gathered_view(self, i: int, rank: int):
-        """Rank `rank`'s contribution inside gathered buffer i, as (descriptor rows [B][cap][32], counts [B][2]) device views
-        (gather_what == "blocks": the whole block as uint8)."""
+        """Rank `rank`'s contribution inside gathered buffer i, on the host: (descriptor rows [B][cap][32], counts [B][2]) for
+        gather_what == "descriptors", the whole block as uint8 for "blocks"."""
         lo = self.layout
-        part = self.gathered[i][rank * self.send_bytes:(rank + 1) * self.send_bytes]
+        part = np.empty(self.send_bytes, np.uint8)
+        self._check(self._L.orbx_replay_read(self._h, 1, i, self._lib.ptr(part), rank * self.send_bytes, part.nbytes))
         if self.gather_what == "blocks":
             return part
-        desc = part[:lo.desc_bytes].view(self.B, lo.cap, 32)
+        desc = part[:lo.desc_bytes].reshape(self.B, lo.cap, 32)
         c0 = lo.counts_off - lo.desc_off
-        counts = part[c0:c0 + lo.counts_bytes].view(self.torch.int32).reshape(self.B, 2)
+        counts = part[c0:c0 + lo.counts_bytes].view(np.int32).reshape(self.B, 2)
         return desc, counts
 
-    def drain(self):
-        if self.gstream is not None:
-            with self.torch.cuda.stream(self.gstream):
-                for i in (0, 1):
-                    if self.pending[i] is not None:
-                        self.pending[i].wait()
-                        self.pending[i] = None
-        for st in self.streams + [self.gstream]:
-            if st is not None:
-                st.synchronize()
-
-    def counts(self, i: int):
+    def counts(self, i: int) -> np.ndarray:
+        """[B][2] int32 {n keypoints, monoIndex} of block i (host copy)."""
         lo = self.layout
-        return self.blocks[i][lo.counts_off:lo.counts_off + lo.counts_bytes].view(self.torch.int32).reshape(self.B, 2)
+        out = np.empty(lo.counts_bytes, np.uint8)
+        self._check(self._L.orbx_replay_read(self._h, 0, i, self._lib.ptr(out), lo.counts_off, out.nbytes))
+        return out.view(np.int32).reshape(self.B, 2)
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h is not None and h.value:
+            self._L.orbx_replay_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # noqa: BLE001
+            pass
 
 
 def gather_blocks_cpu(block: np.ndarray, layout: BlockLayout, process_group=None) -> Optional[List[np.ndarray]]:

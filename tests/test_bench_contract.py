@@ -43,7 +43,15 @@ def test_bench_json_line():
     assert j["scaling"] == "weak" and j["vs_baseline"] is None and j["dtype"] == "u8" and j["data"] == "synthetic"
     assert "workload" in j["config"] and "model" not in j["config"]
     assert j["value"] > 50000 and abs(j["value"] * j["ms_per_step"] - 256 * j["config"]["features_per_frame"]) < 0.01 * 256 * 1005
+    # the headline is the MEDIAN of an odd number of repeats of the steps-long timed loop, with its extremes beside it
+    tm = j["timing"]
+    assert tm["repeats"] >= 7 and tm["repeats"] % 2 == 1 and len(tm["ms_per_step_all"]) == tm["repeats"]
+    assert tm["ms_per_step_min"] <= j["ms_per_step"] <= tm["ms_per_step_max"] and sorted(tm["ms_per_step_all"])[tm["repeats"] // 2] == j["ms_per_step"]
+    assert abs(tm["timed_region_s"] - sum(tm["ms_per_step_all"]) * j["steps"] / 1e3) < 1e-3 and 0 <= tm["spread_frac"] < 1
+    cp = j["config"]["cpu_path_profile"]
+    assert cp["active"].startswith("opencv>=4.5.1 (") and cp["options"] == dict(gauss_kernel=0, gauss_round=0, gauss_tail=0, atan_fma=0, brief_fma=0)
     rf = j["roofline"]
+    assert "HIP events" in rf["avg_launch_ms_source"] and ("rocprof" not in rf or rf["rocprof"]["file"].startswith("profiles/"))
     assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and 0 < rf["frac"] < 1
     assert rf["traffic"] is None or rf["traffic"] > 0
@@ -56,8 +64,11 @@ def test_bench_json_line():
     # N = 1 carries the exchange too: a one-rank RCCL self-gather (what the collective costs this GPU even alone)
     xc = j["exchange"]
     assert "error" not in xc, xc
-    for k in ("collective", "bytes_per_rank_per_step", "gather_ms", "step_ms_with_gather", "step_ms_without_gather", "exposed_ms_per_step", "rccl_version", "ranks"):
+    for k in ("collective", "transport", "bytes_per_rank_per_step", "gather_ms", "step_ms_with_gather", "step_ms_without_gather", "exposed_ms_per_step",
+              "step_ms_with_gather_min_max", "step_ms_without_gather_min_max", "spread_frac", "repeats", "ranks"):
         assert k in xc, k
+    assert "ncclAllGather" in xc["transport"] and "rccl" in xc["transport"] and xc["repeats"] >= 3
+    assert xc["step_ms_with_gather_min_max"][0] <= xc["step_ms_with_gather"] <= xc["step_ms_with_gather_min_max"][1]
     assert xc["ranks"] == 1 and xc["bytes_per_rank_per_step"] == 256 * 1024 * 32 + 256 * 2 * 4 + (-(256 * 2 * 4) % 256) and xc["gather_ms"] > 0
     assert 0.3 < xc["step_ms_without_gather"] < 5 and xc["step_ms_with_gather"] > 0.3
     sf = j["streamed_frontend"]
@@ -65,3 +76,24 @@ def test_bench_json_line():
     assert 0.05 < sf["ms_per_frame"] < 20 and sf["features_per_frame"] > 900 and sf["matches_last_per_frame"] > 100
     if "cpu" in sf:   # the same loop on the reference-compiled CPU code: same results, and slower
         assert sf["cpu"]["identical_results"] is True and sf["cpu"]["ms_per_frame"] > sf["ms_per_frame"]
+
+
+def test_bench_helpers_median_cells_and_rocprof_row(tmp_path, monkeypatch):
+    """Host-side pieces of the line: the median, the FAST cell count that identifies the whole-batch launches in a committed rocprofv3
+    summary, and the parser of that summary (only a file stamped with THIS build's kernel-source hash is cited)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.median_of([3.0, 1.0, 2.0]) == 2.0 and bench.median_of([4.0, 1.0, 2.0, 3.0]) == 2.5
+    assert bench.fast_cells_per_frame(480, 640) == 577 and bench.fast_cells_per_frame(1024, 1024) == 2312      # SURVEY.md section 8's geometry table
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    (prof / "rX_kernel_stats.md").write_text(
+        "commit abc kernel sources 0123456789abcdef 2026-09-27T00:00Z\n\n| kernel | calls | total ms | avg us | min us | max us | % |\n|---|---:|---:|---:|---:|---:|---:|\n"
+        "| void orbx::k_fast_cells<128, 64, true> [grid 41728x1x1 wg] | 278 | 37.068 | 133.34 | 95.80 | 234.24 | 11.0 |\n"
+        "| void orbx::k_fast_cells<128, 64, true> [grid 135680x1x1 wg] | 8 | 3.081 | 385.12 | 345.80 | 450.08 | 0.9 |\n"
+        "| void orbx::k_fast_cells<128, 64, true> [grid 12032x1x1 wg] | 8 | 0.530 | 66.22 | 62.88 | 71.48 | 0.2 |\n")
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    r = bench.rocprof_row("k_fast_cells", 256, 480, 640, "0123456789abcdef")
+    assert r == {"file": "profiles/rX_kernel_stats.md", "rocprof_avg_ms": 0.4513, "calls": [8, 8], "grids": [135680, 12032], "min_ms": 0.4087, "max_ms": 0.5216}
+    assert bench.rocprof_row("k_fast_cells", 256, 480, 640, "ffffffffffffffff") is None      # another build's profile is not cited
+    assert bench.rocprof_row("k_fast_cells", 128, 480, 640, "0123456789abcdef") is None      # no launch of that shape in the file

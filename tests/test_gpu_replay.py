@@ -1,5 +1,6 @@
-"""Batch-replay engine on the GPU: the RCCL all-gather path (1-rank NCCL group: same code, same stream ordering as
-N > 1) returns exactly the per-rank feature block, and the blocks decode to the oracle's keypoints/descriptors."""
+"""Batch-replay engine on the GPU (the C ABI's orbx_replay_* through its ctypes mirror, and once from a plain C++ host): the RCCL
+all-gather path (one-rank group: same code, same stream ordering as N > 1) returns exactly the per-rank feature block, and the blocks
+decode to the oracle's keypoints / descriptors."""
 import os
 import socket
 
@@ -34,14 +35,15 @@ def test_replay_engine_gather_matches_block_and_oracle(lanes, what):
         eng.drain()
         torch.cuda.synchronize()
         assert eng.gather_ms() is not None and eng.gather_ms() > 0
-        blk = eng.blocks[last].cpu().numpy()
-        gat = eng.gathered[last].cpu().numpy()
+        assert "ncclAllGather" in eng.transport and "rccl" in eng.transport, eng.transport
+        blk = eng.block_host(last)
+        gat = eng.gathered_host(last).reshape(-1)
         assert len(gat) == eng.send_bytes and np.array_equal(blk[eng.send_off:], gat)
         if what == "descriptors":   # descriptor rows + counts travel; the keypoints stay on their rank
             desc, counts = eng.gathered_view(last, 0)
             lo = eng.layout
-            assert np.array_equal(desc.cpu().numpy().reshape(-1), blk[lo.desc_off:lo.desc_off + lo.desc_bytes])
-            assert np.array_equal(counts.cpu().numpy(), eng.counts(last).cpu().numpy())
+            assert np.array_equal(desc.reshape(-1), blk[lo.desc_off:lo.desc_off + lo.desc_bytes])
+            assert np.array_equal(counts, eng.counts(last))
             gat = blk
         res = unpack_block(gat[:eng.layout.nbytes], eng.layout)
         ora = po.OracleExtractor(1000, 1.2, 8, 20, 7)
@@ -51,6 +53,80 @@ def test_replay_engine_gather_matches_block_and_oracle(lanes, what):
             assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc)
     finally:
         dist.destroy_process_group()
+
+
+def test_replay_engine_without_a_process_group_self_gather_and_toggle():
+    """No torch.distributed anywhere: gather=True alone makes the one-rank RCCL group inside liborbx (ncclGetUniqueId + ncclCommInitRank(1)).
+    The exchange can be switched off and on between steps; an engine created without one refuses to switch it on."""
+    import torch
+    from orb_slam3_modified_amd import ORBextractor, OrbxError, synth
+    from orb_slam3_modified_amd.replay import ReplayEngine
+    dev = torch.device("cuda", 0)
+    host = synth.make_stream(4)
+    frames = torch.from_numpy(host[np.arange(64) % 4]).to(dev)
+    ex = ORBextractor(1000, 1.2, 8, 20, 7, device_id=0)
+    eng = ReplayEngine(ex, frames, lapping=(0, 1000), gather=True, lanes=2, gather_what="descriptors")
+    assert eng.world == 1 and eng.rank == 0 and eng.device_collective and len(eng.lane_ranges) == 2
+    for _ in range(3):
+        i = eng.step()
+    blk = eng.block_host(i)
+    assert np.array_equal(eng.gathered_host(i)[0], blk[eng.send_off:])
+    assert eng.gather_ms() > 0
+    eng.reset_gather_timing()
+    eng.gather = False
+    keep = eng.gathered_host(i ^ 1).copy()
+    j = eng.step()                       # no collective: the gathered buffer of this parity keeps what it had
+    assert j == (i ^ 1) and eng.gather_ms() is None and np.array_equal(eng.gathered_host(j), keep)
+    eng.gather = True
+    k = eng.step()
+    assert np.array_equal(eng.gathered_host(k)[0], eng.block_host(k)[eng.send_off:]) and eng.gather_ms() > 0
+    eng.close()
+    plain = ReplayEngine(ex, frames, lapping=(0, 1000), gather=False, lanes=1)
+    assert plain.transport == "none"
+    with pytest.raises(ValueError):
+        plain.gather = True
+    with pytest.raises(OrbxError):
+        plain.gathered_host(0)
+    plain.close()
+
+
+def test_replay_from_a_plain_cpp_host(tmp_path):
+    """include/orbx.h alone, no Python, no torch: tests/support/replay_host.cpp (the loop INTEGRATION.md section 9 shows) creates two lanes and a
+    one-rank engine, steps over device-resident frames with the RCCL self-gather, and prints a digest of block and gathered buffer per step;
+    the digests must equal the ones the ctypes mirror produces for the same frames."""
+    import subprocess
+    import torch
+    from orb_slam3_modified_amd import ORBextractor, synth
+    from orb_slam3_modified_amd.replay import ReplayEngine
+
+    def digest(b):   # replay_host.cpp's: sum of 8-byte words w_k * (2k + 1) modulo 2^64
+        b = np.ascontiguousarray(b, np.uint8).reshape(-1)
+        b = np.concatenate([b, np.zeros((-len(b)) % 8, np.uint8)]).view("<u8")
+        with np.errstate(over="ignore"):
+            return int((b * (2 * np.arange(len(b), dtype=np.uint64) + np.uint64(1))).sum(dtype=np.uint64))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "replay_host")
+    pkg = os.path.join(root, "orb_slam3_modified_amd")
+    subprocess.check_call(["hipcc", "-O2", "-std=c++17", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "support", "replay_host.cpp"), "-o", exe,
+                           "-L", pkg, "-lorbx", "-Wl,-rpath," + pkg])
+    host = synth.make_stream(4)
+    nfr, steps = 64, 4
+    frames_host = np.ascontiguousarray(host[np.arange(nfr) % 4])
+    raw = str(tmp_path / "frames.u8")
+    frames_host.tofile(raw)
+    out = subprocess.check_output([exe, raw, str(nfr), "480", "640", str(steps)], timeout=600).decode().strip().splitlines()
+    assert out[0].startswith("transport ncclAllGather"), out[0]
+    dev = torch.device("cuda", 0)
+    eng = ReplayEngine(ORBextractor(1000, 1.2, 8, 20, 7, device_id=0), torch.from_numpy(frames_host).to(dev), lapping=(0, 1000), gather=True, lanes=2,
+                       gather_what="blocks")
+    want = []
+    for s in range(steps):
+        i = eng.step()
+        b = eng.block_host(i)
+        want.append(f"step {s} buffer {i} block {digest(b):016x} gathered {digest(eng.gathered_host(i)):016x} keypoints {int(eng.counts(i)[:, 0].sum())}")
+    assert out[1:1 + steps] == want, (out, want)
+    assert out[1 + steps].startswith("gather_ms ") and float(out[1 + steps].split()[1]) > 0
+    assert out[-1] == "ok"
 
 
 def _check_every_frame(block, layout, host, ora, lap):
@@ -90,7 +166,7 @@ def test_the_configuration_bench_times_is_bit_exact_on_every_frame():
     torch.cuda.synchronize()
     for back in (0, 1):     # the last step and the one before it (the other block buffer)
         k = (eng.step_idx - 1 - back) % 3
-        blk = eng.blocks[last ^ back].cpu().numpy()
+        blk = eng.block_host(last ^ back)
         cache_host = sets_host[k]
         from orb_slam3_modified_amd.replay import unpack_block
         res = unpack_block(blk, eng.layout)
@@ -160,7 +236,7 @@ def _world2_worker(rank, world, port, what, q):
         sets = [torch.from_numpy(h).to(dev) for h in host[rank]]
         ex = ORBextractor(1000, 1.2, 8, 20, 7, device_id=0)
         eng = ReplayEngine(ex, sets, lapping=(0, 1000), gather=True, lanes=2, gather_what=what)
-        assert eng.gather and not eng.device_collective and eng.world == world and len(eng.lane_ranges) == 2
+        assert eng.gather and not eng.device_collective and eng.world == world and len(eng.lane_ranges) == 2 and "host all-gather" in eng.transport
         ora = po.OracleExtractor(1000, 1.2, 8, 20, 7)
         lo = eng.layout
         ok, notes = True, []
@@ -171,8 +247,8 @@ def _world2_worker(rank, world, port, what, q):
             eng.drain()
             torch.cuda.synchronize()
             k = step % nsets
-            mine = eng.blocks[i].cpu().numpy()
-            gat = eng.gathered[i].cpu().numpy().reshape(world, eng.send_bytes)
+            mine = eng.block_host(i)
+            gat = eng.gathered_host(i)
             ok &= bool(np.array_equal(gat[rank], mine[eng.send_off:]))          # my own contribution, every frame, bit for bit
             # both ranks must hold the same gathered buffer
             digests = [None] * world
@@ -186,8 +262,8 @@ def _world2_worker(rank, world, port, what, q):
                         good = mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc)
                     else:
                         desc_all, counts = eng.gathered_view(i, r)
-                        n, mono = (int(v) for v in counts[f].cpu().numpy())
-                        good = n == len(okps) and mono == omono and np.array_equal(desc_all[f, :n].cpu().numpy(), odesc)
+                        n, mono = (int(v) for v in counts[f])
+                        good = n == len(okps) and mono == omono and np.array_equal(desc_all[f, :n], odesc)
                     if not good:
                         notes.append((step, r, f))
                     ok &= good

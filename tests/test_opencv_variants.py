@@ -327,3 +327,65 @@ def test_gpu_rejects_unknown_variant_values():
     for k, val in (("gauss_kernel", 2), ("gauss_round", 3), ("gauss_tail", 5), ("atan_fma", 2), ("brief_fma", -1)):
         with pytest.raises(OrbxError):
             gpu.set_option(k, val)
+
+
+# ------------------------------------------------------------------------------------------------ named CPU-path profiles
+PROFILE_CASES = [("opencv>=4.5.1", 0), ("default", 3), ("opencv-4.4", 0), ("opencv-4.4", 3), ("opencv-4.4-avx2", 1), ("opencv-4.4-sse", 1), ("opencv-4.4-avx512", 2),
+                 ("opencv-4.4-scalar", 0), ("opencv-3.2", 0), ("opencv<=3.4.1", 1)]
+
+
+def test_cpu_profile_table_is_what_the_integration_guide_says():
+    """orbx_cpu_profile_values (host-only: no device): every named profile maps to the option values INTEGRATION.md section 6 lists, the
+    aliases resolve, fma_build sets brief_fma (bit 0) / atan_fma (bit 1), and OpenCV builds without an FMA copy of cv::fastAtan2 refuse bit 1."""
+    import os
+    from orb_slam3_modified_amd import ORBextractor, _lib
+    L = _lib.lib()
+    prof = ORBextractor.cpu_profiles()
+    assert {k: v[1] for k, v in prof.items()} == {"opencv>=4.5.1": (0, 0, 0, 0, 0), "opencv-4.4": (1, 2, 16, 0, 0), "opencv-4.4-sse": (1, 2, 8, 0, 0),
+                                                  "opencv-4.4-avx512": (1, 2, 32, 0, 0), "opencv-4.4-scalar": (1, 0, 0, 0, 0), "opencv-3.2": (1, 1, 4, 0, 0)}
+    v = np.zeros(5, np.int32)
+    for alias, name in (("default", "opencv>=4.5.1"), ("opencv-4.4-avx2", "opencv-4.4"), ("opencv<=3.4.1", "opencv-3.2")):
+        assert L.orbx_cpu_profile_values(alias.encode(), 0, _lib.ptr(v)) == 0 and tuple(v) == prof[name][1]
+    assert L.orbx_cpu_profile_values(b"opencv-4.4", 3, _lib.ptr(v)) == 0 and tuple(v) == (1, 2, 16, 1, 1)
+    assert L.orbx_cpu_profile_values(b"opencv-4.4", 1, _lib.ptr(v)) == 0 and tuple(v) == (1, 2, 16, 0, 1)
+    assert L.orbx_cpu_profile_values(b"opencv>=4.5.1", 2, _lib.ptr(v)) == 0 and tuple(v) == (0, 0, 0, 1, 0)
+    for bad in ((b"opencv-3.2", 2), (b"opencv-4.4-sse", 3), (b"opencv-4.4", 4), (b"opencv-4.4", -1), (b"opencv-5", 0)):
+        assert L.orbx_cpu_profile_values(bad[0], bad[1], _lib.ptr(v)) == -1
+    # every profile is one of the oracle's variants or differs from one only in the two FMA flags; the guide names each of them
+    guide = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    for name, (what, vals) in prof.items():
+        assert f"`{name}`" in guide, name
+        with po.opencv_variant(*vals):      # the oracle has a twin of every profile
+            assert tuple(int(x) for x in po.gaussian_kernel7()) == ((18, 34, 49, 55, 49, 34, 18) if vals[0] else (18, 34, 48, 56, 48, 34, 18))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,fma", PROFILE_CASES)
+def test_gpu_extract_equals_oracle_under_every_named_profile(name, fma):
+    """orbx_set_cpu_profile(name, fma_build) on the C ABI == the oracle under the five values the table gives: single frame, batch, a natural
+    crop; orbx_get_cpu_profile reports the set back."""
+    from orb_slam3_modified_amd import ORBextractor, _lib, synth
+    from tests.test_gpu_extractor import assert_same
+    v = np.zeros(5, np.int32)
+    assert _lib.lib().orbx_cpu_profile_values(name.encode(), fma, _lib.ptr(v)) == 0
+    vals = tuple(int(x) for x in v)
+    gpu = ORBextractor(1000, 1.2, 8, 20, 7)
+    assert gpu.cpu_profile()[1] == dict(gauss_kernel=0, gauss_round=0, gauss_tail=0, atan_fma=0, brief_fma=0) and gpu.cpu_profile()[0].startswith("opencv>=4.5.1 (")
+    gpu.set_cpu_profile(name, fma)
+    text, got = gpu.cpu_profile()
+    assert tuple(got.values()) == vals and ("+native-build" in text) == bool(fma & 1) and ("+avx2-atan" in text) == bool(fma & 2), text
+    nat = np.load("tests/golden/natural_crops.npz")
+    imgs = [synth.make_stream(1)[0], nat["result_640x480_img"]]
+    with po.opencv_variant(*vals):
+        ora = po.OracleExtractor(1000, 1.2, 8, 20, 7)
+        for i, img in enumerate(imgs):
+            assert_same(gpu(img, None, (0, 1000)), ora.extract(img, (0, 1000)), f"{name}/{fma} image {i}")
+        res = gpu.extract_batch(np.stack([imgs[0], imgs[1]]), (0, 1000))
+        for f in range(2):
+            assert_same(res[f], ora.extract(imgs[f], (0, 1000)), f"{name}/{fma} batch frame {f}")
+    from orb_slam3_modified_amd import OrbxError
+    with pytest.raises(OrbxError):
+        gpu.set_cpu_profile("opencv-3.2", 2)
+    with pytest.raises(OrbxError):
+        gpu.set_cpu_profile("no-such-opencv", 0)
+    assert tuple(gpu.cpu_profile()[1].values()) == vals      # a refused call changes nothing

@@ -4,7 +4,8 @@
 import csv, glob, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-out = os.path.join(ROOT, "gpurun_out", "pmc_sq")
+TAG = os.environ.get("PMC_SQ_TAG", "")     # suffix of the output files (A/B runs under different ORBX_* settings)
+out = os.path.join(ROOT, "gpurun_out", "pmc_sq" + TAG)
 rows = {}
 order = []
 for i, cs in enumerate(sys.argv[1:]):
@@ -42,6 +43,8 @@ for k, cs in rows.items():
              "valu_busy": avg["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cyc)}   # quad-cycles, 1024 SIMDs
         if "SQ_ACTIVE_INST_LDS" in avg:
             d["lds_busy"] = avg["SQ_ACTIVE_INST_LDS"] * 4.0 / (256.0 * cyc)
+            if "SQ_LDS_BANK_CONFLICT" in avg and avg["SQ_ACTIVE_INST_LDS"] > 0:   # share of the LDS-active cycles that is conflict replay
+                d["lds_conflict_frac"] = avg["SQ_LDS_BANK_CONFLICT"] / (4.0 * avg["SQ_ACTIVE_INST_LDS"])
         if "TA_BUSY_avr" in avg:
             d["ta_busy"] = avg["TA_BUSY_avr"] / cyc
         if "SQ_INSTS_VALU" in avg:
@@ -51,7 +54,7 @@ for k, cs in rows.items():
         derived[k.split("<")[0]] = d
 from orb_slam3_modified_amd.build import stamp
 json.dump({"stamp": stamp(), "derived": derived, "raw_per_dispatch_avg": {k: {c: v[0] / v[1] for c, v in cs.items()} for k, cs in rows.items()}},
-          open(os.path.join(ROOT, "gpurun_out", "pmc_sq.json"), "w"), indent=1)
+          open(os.path.join(ROOT, "gpurun_out", f"pmc_sq{TAG}.json"), "w"), indent=1)
 lines += ["", "derived: " + json.dumps(derived)]
-open(os.path.join(ROOT, "gpurun_out", "pmc_sq.md"), "w").write("per-dispatch averages\n\n" + "\n".join(lines) + "\n")
+open(os.path.join(ROOT, "gpurun_out", f"pmc_sq{TAG}.md"), "w").write("per-dispatch averages\n\n" + "\n".join(lines) + "\n")
 print("\n".join(lines))
