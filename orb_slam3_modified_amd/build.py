@@ -7,7 +7,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OUT = os.path.join(HERE, "liborbx.so")
+OUT = os.environ.get("ORBX_BUILD_OUT") or os.path.join(HERE, "liborbx.so")   # ORBX_BUILD_OUT (+ ORBX_EXTRA_FLAGS): experiment builds beside the product
 SOURCES = ["orbx_extractor.hip", "orbx_matcher.hip", "orbx_search.hip", "orbx_window.hip", "orbx_kfdb.hip", "orbx_replay.hip"]
 # -ffp-contract=off: the float paths (fastAtan2 polynomial, BRIEF rotation) must not be fused into FMAs,
 # the CPU reference evaluates them as separate IEEE operations (DESIGN.md "bit-exactness").
@@ -53,7 +53,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "hipcc")
     extra = os.environ.get("ORBX_EXTRA_FLAGS", "").split()
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build") if OUT.endswith("/liborbx.so") else OUT + ".obj"
     os.makedirs(objdir, exist_ok=True)
     cflags = [f for f in FLAGS if f not in ("-shared", "-ldl")] + extra
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if not f.endswith(".hip") or f == "orbx_kernels.hip"] + [os.path.join(HERE, "..", "include", "orbx.h")]

@@ -2782,6 +2782,38 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
       // Variant: the 37 x 37 window of the blurred level staged in this wave's LDS slice (37 rows x 10 aligned dwords,
       // coalesced loads), the 512 taps read from LDS instead of 8 scattered byte gathers per lane.  The window starts at
       // the dword below kx - 18: at most 2 bytes before / after the row, inside the plane's pitch or the neighbouring row.
+#ifdef ORBX_DESC_DBUF
+      // Experiment of round 5 (measured in HISTORY.md): TWO slices per wave — keypoint k + 1's window is put in flight
+      // (LDS-DMA) before keypoint k's taps are read, so that its HBM / L2 latency runs under k's 512 taps instead of in front of its own.
+      __shared__ __align__(16) uint8_t s_patch[4][2][37 * 40];
+      auto issue_window = [&](int kk, uint8_t* dstslice) {   // wave-uniform arguments
+        const uint32_t pp = __builtin_amdgcn_readlane(rec.x, kk);
+        const int ll = (int)(__builtin_amdgcn_readlane(rec.y, kk) & 0xffu);
+        const DeviceLevel& lw = g->lv[ll];
+        const uint8_t* bpl = blur + (long long)frame * blur_frame_bytes + lw.bplane_off;
+        const int kxx = pt_x(pp), kyy = pt_y(pp), bpp = lw.pitch;
+        const uint32_t wb = (uint32_t)(__mul24(kyy - 18, bpp) + (kxx - 18 - ((kxx - 18) & 3)));
+        const int rph = (int)(((uint32_t)lane * 6554u) >> 16), dcol = lane - rph * 10;  // lane / 10
+        uint32_t off = wb + (uint32_t)(__mul24(rph, bpp) + 4 * dcol);
+        const uint32_t step = 6u * (uint32_t)bpp;
+#pragma unroll
+        for (int q = 0; q < 7; q++) {
+          if (lane < 60 && rph + 6 * q < 37)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bpl + off),
+                                             (__attribute__((address_space(3))) void*)((uint32_t*)dstslice + 60 * q), 4, 0, 0);
+          off += step;
+        }
+      };
+      if (k == 0) issue_window(0, s_patch[w][0]);
+      uint8_t* sp = s_patch[w][k & 1];
+      const int sh2 = (kx - 18) & 3;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // window k (issued one keypoint ago) and the stores of keypoint k - 1
+      wave_lds_sync();                                      // ... also: everybody is done reading slice (k + 1) & 1 (keypoint k - 1's)
+      if (k + 1 < nk) issue_window(k + 1, s_patch[w][(k + 1) & 1]);
+      const int lctr = 18 * 40 + 18 + sh2;
+      if (brief_fma) brief_taps<true, true>(sp, lctr, 40, pat, a, b, t0, t1);   // uniform (kernel argument)
+      else brief_taps<false, true>(sp, lctr, 40, pat, a, b, t0, t1);
+#else
       __shared__ __align__(16) uint8_t s_patch[4][37 * 40];
       uint8_t* sp = s_patch[w];
       const int sh2 = (kx - 18) & 3;
@@ -2817,6 +2849,7 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
       if (brief_fma) brief_taps<true, true>(sp, lctr, 40, pat, a, b, t0, t1);   // uniform (kernel argument)
       else brief_taps<false, true>(sp, lctr, 40, pat, a, b, t0, t1);
       wave_lds_sync();   // the next keypoint overwrites the slice
+#endif
     } else {
       if (brief_fma) brief_taps<true, false>(bplane, ctr, bp, pat, a, b, t0, t1);
       else brief_taps<false, false>(bplane, ctr, bp, pat, a, b, t0, t1);
