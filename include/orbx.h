@@ -512,7 +512,7 @@ int orbx_kfdb_score(orbx_kfdb* db, const uint32_t* q_ids, const double* q_vals, 
  * The reference has no such mode (its System owns one live camera, src/System.cc:197-264); north_star adds it: every GPU (one process each)
  * replays its own stream(s) through the extractor — no collective on the extraction path — and after every step all ranks all-gather their
  * fixed-size feature blocks over RCCL / xGMI, asynchronously on a stream of its own and double-buffered, so that step k's collective runs
- * under step k + 1's kernels.  A C / C++ host drives it with these entry points alone (INTEGRATION.md section 9 has the 20-line loop);
+ * under step k + 1's kernels.  A C / C++ host drives it with these entry points alone (INTEGRATION.md section 8 has the 20-line loop);
  * liborbx binds RCCL at run time (dlopen: the instance already in the process if there is one, else librccl.so.1; ORBX_RCCL_LIB overrides).
  *
  * Feature block of one rank and step (device memory, one contiguous buffer; every part 256-byte aligned):

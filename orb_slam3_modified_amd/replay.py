@@ -108,9 +108,11 @@ class ReplayEngine:
                 box = [None]
                 if self.rank == 0:
                     buf = (C.c_uint8 * 128)()
-                    _lib.check(L.orbx_replay_unique_id(buf))
-                    box[0] = bytes(buf)
+                    rc = L.orbx_replay_unique_id(buf)   # a failure must reach the other ranks too: they are waiting in the broadcast
+                    box[0] = bytes(buf) if rc == 0 else f"orbx_replay_unique_id failed ({rc}): {L.orbx_replay_rccl_info().decode()}"
                 dist.broadcast_object_list(box, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0, group=process_group)
+                if not isinstance(box[0], bytes):
+                    raise _lib.OrbxError(-3, str(box[0]))
                 unique_id = box[0]
         elif gather and dist is not None:
             import numpy as _np

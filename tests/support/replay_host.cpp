@@ -1,4 +1,4 @@
-// TEST INFRASTRUCTURE — and the example INTEGRATION.md section 9 points to: batch replay driven from a plain C++ host through include/orbx.h
+// TEST INFRASTRUCTURE — and the example INTEGRATION.md section 8 points to: batch replay driven from a plain C++ host through include/orbx.h
 // alone (no Python, no torch).  One rank: two lanes, the RCCL self-gather of whole blocks.  Prints, per step, position-weighted 64-bit sums
 // of the feature block and of the gathered buffer and the step's keypoint count; tests/test_gpu_replay.py compares them with what the ctypes
 // mirror of the same entry points produces on the same frames.
@@ -32,7 +32,7 @@ int main(int argc, char** argv) {
   uint8_t* d_frames = nullptr;
   if (hipMalloc((void**)&d_frames, host.size()) != hipSuccess || hipMemcpy(d_frames, host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess) return 3;
 
-  // ---- the loop of INTEGRATION.md section 9
+  // ---- the loop of INTEGRATION.md section 8
   orbx_ctx* lanes[2] = {nullptr, nullptr};
   orbx_replay* eng = nullptr;
   for (orbx_ctx*& c : lanes) if (orbx_create(&c, 1000, 1.2f, 8, 20, 7, 0) != ORBX_OK) { std::fprintf(stderr, "orbx_create failed\n"); return 3; }
