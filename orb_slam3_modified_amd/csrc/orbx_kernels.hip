@@ -2470,28 +2470,44 @@ __device__ __forceinline__ void blur_tile(const int L, const DeviceGeom* __restr
 #pragma unroll
     for (int q = 0; q < 4; q++) P[q] = *(const uint4*)(hp + (op + q) * kBT_W + 4 * j);
     uint32_t e[4], o[4];
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-      const uint32_t p0 = c == 0 ? P[0].x : c == 1 ? P[0].y : c == 2 ? P[0].z : P[0].w;
-      const uint32_t p1 = c == 0 ? P[1].x : c == 1 ? P[1].y : c == 2 ? P[1].z : P[1].w;
-      const uint32_t p2 = c == 0 ? P[2].x : c == 1 ? P[2].y : c == 2 ? P[2].z : P[2].w;
-      const uint32_t p3 = c == 0 ? P[3].x : c == 1 ? P[3].y : c == 2 ? P[3].z : P[3].w;
-      e[c] = udot2(p3, bc.we[3], udot2(p2, bc.we[2], udot2(p1, bc.we[1], udot2(p0, bc.we[0], bc.radd))));
-      o[c] = udot2(p3, bc.wo[3], udot2(p2, bc.wo[2], udot2(p1, bc.wo[1], udot2(p0, bc.wo[0], bc.radd))));
-    }
-    if (bc.flags) {   // uniform (kernel argument): the other OpenCV releases' arithmetic; radd is 0 here
-      const int body = w - (w & (int)bc.tail_mask);   // columns [body, w) round half up
-      const uint32_t mode = (bc.flags >> 1) & 3u;
+    // the four dot2 chains of a column, started from `init` (the rounding constant: folded into the accumulation)
+    auto column_sums = [&](const uint32_t (&init)[4]) {
 #pragma unroll
       for (int c = 0; c < 4; c++) {
-        const uint32_t m = x + c < body ? mode : 0u;
-        uint32_t re = (e[c] + (m == 2u ? 0u : 32768u)) >> 16, ro = (o[c] + (m == 2u ? 0u : 32768u)) >> 16;
-        if (m == 1u) {   // an exact tie: low half == 2^15
-          if ((e[c] & 0xffffu) == 0x8000u) re &= ~1u;
-          if ((o[c] & 0xffffu) == 0x8000u) ro &= ~1u;
-        }
-        e[c] = min(re, 255u) << 16; o[c] = min(ro, 255u) << 16;
+        const uint32_t p0 = c == 0 ? P[0].x : c == 1 ? P[0].y : c == 2 ? P[0].z : P[0].w;
+        const uint32_t p1 = c == 0 ? P[1].x : c == 1 ? P[1].y : c == 2 ? P[1].z : P[1].w;
+        const uint32_t p2 = c == 0 ? P[2].x : c == 1 ? P[2].y : c == 2 ? P[2].z : P[2].w;
+        const uint32_t p3 = c == 0 ? P[3].x : c == 1 ? P[3].y : c == 2 ? P[3].z : P[3].w;
+        e[c] = udot2(p3, bc.we[3], udot2(p2, bc.we[2], udot2(p1, bc.we[1], udot2(p0, bc.we[0], init[c]))));
+        o[c] = udot2(p3, bc.wo[3], udot2(p2, bc.wo[2], udot2(p1, bc.wo[1], udot2(p0, bc.wo[0], init[c]))));
       }
+    };
+    if (!bc.flags) {   // uniform (kernel argument): the default arithmetic, radd = 2^15 in a scalar register
+      const uint32_t in4[4] = {bc.radd, bc.radd, bc.radd, bc.radd};
+      column_sums(in4);
+    } else {
+      // The other OpenCV releases' arithmetic (round 5: k_blur7 0.219 -> 0.181 ms per 256 frames under "opencv-4.4", 0.170 by default; it had been a
+      // per-pixel chain of selects — profiles/blur_variants_r5.txt).  The rounding
+      // constant still rides in the accumulation — 2^15 (half up, and the base of ties-to-even), 0 (floor) — chosen per COLUMN only where a floor body
+      // meets a half-up tail; an exact tie is "low half == 0 after the 2^15" and rounding it to even clears bit 16; saturation (the 257 kernel
+      // reaches 256) is one min on the 32-bit sum; the pixel is byte 2, packed like the default path's.
+      const int body = w - (w & (int)bc.tail_mask);   // columns [body, w) round half up (a SIMD column pass's scalar tail)
+      const uint32_t mode = (bc.flags >> 1) & 3u;     // uniform: 0 half up, 1 exact ties to even, 2 floor
+      uint32_t in4[4];
+#pragma unroll
+      for (int c = 0; c < 4; c++) in4[c] = (mode == 2u && x + c < body) ? 0u : 32768u;
+      column_sums(in4);
+      if (mode == 1u) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          if (x + c < body) {
+            if ((e[c] & 0xffffu) == 0u) e[c] &= ~0x10000u;
+            if ((o[c] & 0xffffu) == 0u) o[c] &= ~0x10000u;
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; c++) { e[c] = min(e[c], 0x00ffffffu); o[c] = min(o[c], 0x00ffffffu); }
     }
     // byte 2 of each 32-bit sum is the rounded pixel ((acc + 2^15) >> 16 <= 255): three byte permutes pack four of them
     const uint32_t pe = __builtin_amdgcn_perm(__builtin_amdgcn_perm(e[3], e[2], 0x0c0c0602u), __builtin_amdgcn_perm(e[1], e[0], 0x0c0c0602u), 0x05040100u);

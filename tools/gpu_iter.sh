@@ -1,11 +1,9 @@
 # Scratch script for one gpurun call during development (overwritten freely): `gpurun -- 'bash tools/gpu_iter.sh'`.
-# The reproducible end-of-round sequence is tools/final_refresh.sh.
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-B="python bench.py --no-cpu-baseline --no-frontend --no-secondary --no-gather --steps 20 --warmup 5"
-{ for rep in 1 2 3; do
-    echo "default      : $($B 2>/dev/null | tail -1 | python -c 'import json,sys; j=json.loads(sys.stdin.read()); print(j["ms_per_step"], j["timing"]["ms_per_step_min"], j["timing"]["ms_per_step_max"], j["roofline"]["kernels_ms_per_launch"])')"
-    echo "chain_batch  : $(ORBX_CHAIN_BATCH=1 ORBX_CHAIN_THREADS=256 $B 2>/dev/null | tail -1 | python -c 'import json,sys; j=json.loads(sys.stdin.read()); print(j["ms_per_step"], j["timing"]["ms_per_step_min"], j["timing"]["ms_per_step_max"], j["roofline"]["kernels_ms_per_launch"])')"
-  done; } 2>&1 | tee gpurun_out/chain_batch_ab.txt
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee gpurun_out/iter_tests_full.log
+STAMP=$(python -c "from orb_slam3_modified_amd.build import stamp; s = stamp(); print('commit', s['commit'], 'kernel sources', s['kernels_hash'], s['date'])")
+timeout 900 python -m pytest tests/test_opencv_variants.py tests/test_validate_opencv.py tests/test_adapters.py -x -q -m gpu 2>&1 | tail -4
+{ echo "$STAMP"; echo "k_blur7 per 256 frames of 640x480 under the named CPU-path profiles (tools/kernel_times.py: us, median of 7 x 5 passes), after the general path's rewrite"
+  for V in "0 0 0" "1 2 16" "1 2 8" "1 0 0" "1 1 4"; do set -- $V
+    echo "gauss_kernel=$1 gauss_round=$2 gauss_tail=$3: $(ORBX_GAUSS_KERNEL=$1 ORBX_GAUSS_ROUND=$2 ORBX_GAUSS_TAIL=$3 python tools/kernel_times.py 256)"; done; } 2>&1 | tee gpurun_out/blur_variants_after.txt
