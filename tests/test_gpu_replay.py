@@ -292,3 +292,54 @@ def test_replay_engine_world2_every_rank_holds_both_ranks_results(what):
         assert p.exitcode == 0
     assert sorted(r for r, _, _ in res) == [0, 1]
     assert all(ok for _, ok, _ in res), res
+
+
+def _two_ranks_one_device_worker(rank, idfile, q):
+    import time
+    import torch
+    from orb_slam3_modified_amd import ORBextractor, OrbxError, _lib, synth
+    from orb_slam3_modified_amd.replay import ReplayEngine
+    import ctypes as C
+    L = _lib.lib()
+    torch.cuda.set_device(0)
+    if rank == 0:
+        buf = (C.c_uint8 * 128)()
+        assert L.orbx_replay_unique_id(buf) == 0
+        with open(idfile + ".tmp", "wb") as f:
+            f.write(bytes(buf))
+        os.replace(idfile + ".tmp", idfile)
+    else:
+        for _ in range(600):
+            if os.path.exists(idfile):
+                break
+            time.sleep(0.1)
+    uid = open(idfile, "rb").read()
+    frames = torch.from_numpy(synth.make_stream(2)[np.arange(32) % 2]).to("cuda:0")
+    try:
+        eng = ReplayEngine(ORBextractor(1000, 1.2, 8, 20, 7, device_id=0), frames, gather=True, lanes=1, gather_what="descriptors", rank=rank, world=2, unique_id=uid)
+        i = eng.step(); eng.drain()
+        q.put((rank, "created", eng.transport, int(eng.counts(i)[:, 0].sum())))
+    except OrbxError as e:
+        q.put((rank, "refused", str(e), 0))
+
+
+def test_two_ranks_bootstrap_through_the_c_abi_is_refused_loudly_on_one_device(tmp_path):
+    """The multi-rank bootstrap of the C ABI as far as a one-GPU box can take it: rank 0 makes the ncclUniqueId (orbx_replay_unique_id), the 128
+    bytes reach rank 1 through a FILE (no torch.distributed anywhere: the host's own control plane), both ranks call orbx_replay_create(world = 2) —
+    i.e. ncclCommInitRank finds its peer over RCCL's own bootstrap — and RCCL refuses the shared device ("Duplicate GPU detected",
+    profiles/rccl_two_ranks_one_gpu_r4.txt).  What must hold: both ranks meet (no hang), both get ORBX_E_DEVICE with RCCL's message in
+    orbx_last_error, nothing crashes.  On a box with two GPUs the same exchange would create the communicator."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    idfile = str(tmp_path / "nccl_id.bin")
+    procs = [ctx.Process(target=_two_ranks_one_device_worker, args=(r, idfile, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [r[0] for r in res] == [0, 1]
+    for rank, what, msg, _ in res:
+        assert what == "refused" and "ncclCommInitRank" in msg, res
