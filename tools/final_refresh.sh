@@ -14,9 +14,11 @@ timeout 900 python tools/pmc_sq.py "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_AC
    "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT TA_BUSY_avr" > /dev/null 2>&1
 [ -f gpurun_out/pmc_sq.json ] && cp gpurun_out/pmc_sq.json profiles/pmc_sq.json
 # kernel trace of the bench command FIRST (without the CPU leg): the bench line below cites this summary (roofline.rocprof) when it carries this build's hash
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$TAG -o $TAG -- python bench.py --no-cpu-baseline > gpurun_out/prof_$TAG.log 2>&1
+# (--no-secondary: the natural-crop leg launches the same grids as the headline's roofline passes — 256 frames of 640x480 — on slower input and would
+# sit in the same by-grid rows)
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$TAG -o $TAG -- python bench.py --no-cpu-baseline --no-secondary > gpurun_out/prof_$TAG.log 2>&1
 DB=$(ls gpurun_out/prof_$TAG/*/${TAG}_results.db gpurun_out/prof_$TAG/${TAG}_results.db 2>/dev/null | head -1)
-{ python tools/rocpd_summary.py "$DB" --title "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline ($TAG): all launches";
+{ python tools/rocpd_summary.py "$DB" --title "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-secondary ($TAG): all launches";
   echo; python tools/rocpd_summary.py "$DB" --by-grid --title "the same run, one row per launch shape (timed region: 2 lanes x 128 frames, overlapping; roofline passes: 256 frames back to back, 8 timed + one warm-up of 248 frames)"; } > gpurun_out/${TAG}_kernel_stats.md
 sed -i "1i $STAMP\n" gpurun_out/${TAG}_kernel_stats.md
 cp gpurun_out/${TAG}_kernel_stats.md profiles/${TAG}_kernel_stats.md
