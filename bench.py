@@ -563,6 +563,11 @@ def main():
     ap.add_argument("--profile", default="opencv>=4.5.1", help="which CPU path the output must equal (orbx_set_cpu_profile; INTEGRATION.md section 6): "
                                                               "opencv>=4.5.1 | opencv-4.4 | opencv-4.4-sse | opencv-4.4-avx512 | opencv-4.4-scalar | opencv-3.2")
     ap.add_argument("--fma-build", type=int, default=0, help="bit 0: the reference built with -march=native on an FMA machine; bit 1: OpenCV's AVX2 fastAtan2")
+    ap.add_argument("--control-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend of the job's CONTROL plane (barrier, MAX of times, the ncclUniqueId's broadcast).  nccl (default): the "
+                         "exchange is RCCL called by liborbx.  gloo: the exchange takes the engine's host transport — with --share-gpu this is how the N > 1 code "
+                         "path of this script is exercised on a one-GPU box (tests/test_bench_contract.py); never a configuration to quote")
+    ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses cuda:0 (RCCL refuses a shared device: needs --control-backend gloo)")
     args = ap.parse_args()
     args.repeats = max(1, args.repeats) | 1      # odd: the median is a measured repeat
     if args.batch is None:
@@ -582,17 +587,23 @@ def main():
             os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
                                       "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.share_gpu and args.control_backend == "nccl" and world > 1:
+        raise SystemExit("bench.py: --share-gpu needs --control-backend gloo (RCCL refuses two ranks on one device)")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         with stdout_to_stderr():   # the communicator (and RCCL's banner) now, not inside the first timed collective
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            if args.control_backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
             dist.barrier()
         if dist.get_world_size() != world:
             raise SystemExit(f"bench.py: WORLD_SIZE {world} but the process group has {dist.get_world_size()} ranks")
     dev = torch.device("cuda", local_rank)
+    cdev = dev if args.control_backend == "nccl" else torch.device("cpu")   # where the control plane's little tensors live
 
     from orb_slam3_modified_amd import ORBextractor, synth
     from orb_slam3_modified_amd.replay import ReplayEngine
@@ -629,7 +640,7 @@ def main():
         exchange_error = f"{type(e).__name__}: {e}"[:300]
         eng = None
     if world > 1:
-        flag = torch.tensor([1 if eng is None else 0], dtype=torch.int32, device=dev)
+        flag = torch.tensor([1 if eng is None else 0], dtype=torch.int32, device=cdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         if int(flag.item()) and want_gather:     # one rank without a communicator: nobody may enter the collective
             if eng is not None:
@@ -644,7 +655,7 @@ def main():
         torch.cuda.synchronize()
 
     def reduce_max(vals):
-        t = torch.tensor(list(vals), dtype=torch.float64, device=dev)
+        t = torch.tensor(list(vals), dtype=torch.float64, device=cdev)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return [float(v) for v in t.tolist()]
@@ -685,7 +696,7 @@ def main():
         per_set[k] = int(eng.counts(i)[:, 0].sum())
     eng.write_block(last, last_block)
     feats_of = lambda r: sum(per_set[(starts[r] + s_) % nsets] for s_ in range(args.steps))   # noqa: E731
-    total_feats = torch.tensor([feats_of(rmed)], dtype=torch.int64, device=dev)
+    total_feats = torch.tensor([feats_of(rmed)], dtype=torch.int64, device=cdev)
     if world > 1:
         dist.all_reduce(total_feats, op=dist.ReduceOp.SUM)
     total_feats = int(total_feats.item())
@@ -694,7 +705,7 @@ def main():
 
     lane_edges = sorted({0, B - 1} | {f for (f0, f1) in eng.lane_ranges for f in (f0, f1 - 1)} | {B // 3})
     verified = 0 if args.no_verify else verify_block(eng, last, host_frames[last_set * B:(last_set + 1) * B], lane_edges, args.nfeatures, (0, 1000), args.variant)
-    vt = torch.tensor([verified], dtype=torch.int64, device=dev)
+    vt = torch.tensor([verified], dtype=torch.int64, device=cdev)
     if world > 1:
         dist.all_reduce(vt, op=dist.ReduceOp.SUM)
 

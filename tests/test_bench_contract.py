@@ -97,3 +97,35 @@ def test_bench_helpers_median_cells_and_rocprof_row(tmp_path, monkeypatch):
     assert r == {"file": "profiles/rX_kernel_stats.md", "rocprof_avg_ms": 0.4513, "calls": [8, 8], "grids": [135680, 12032], "min_ms": 0.4087, "max_ms": 0.5216}
     assert bench.rocprof_row("k_fast_cells", 256, 480, 640, "ffffffffffffffff") is None      # another build's profile is not cited
     assert bench.rocprof_row("k_fast_cells", 128, 480, 640, "0123456789abcdef") is None      # no launch of that shape in the file
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_code_path_on_one_gpu():
+    """The N > 1 path of bench.py — launched exactly as the driver launches it (torch.distributed.run, one rank per process, RANK / WORLD_SIZE from
+    the environment) — on the one GPU a box of this pool has: both ranks on cuda:0 (--share-gpu), the control plane on gloo, so that the engine's
+    exchange takes its host transport (RCCL refuses a shared device).  Everything else is the code the 8-GPU run executes: per-rank camera streams,
+    MAX over ranks of every repeat, SUM of the features, every rank's verification, the exchange legs with their all-reduces, rank 0's one JSON line."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--repeats", "3", "--batch", "64", "--batches", "2",
+                        "--control-backend", "gloo", "--share-gpu"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # rank 0 alone prints
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 4 and j["scaling"] == "weak" and j["config"]["frames_per_step_per_gpu"] == 64
+    assert j["timing"]["repeats"] == 3 and len(j["timing"]["ms_per_step_all"]) == 3
+    # the whole job's features: two ranks x 64 frames x ~1000 features per step
+    assert abs(j["value"] * j["ms_per_step"] - 2 * 64 * j["config"]["features_per_frame"]) < 0.02 * 2 * 64 * 1005
+    assert j["verified_frames"] >= 2 * 3              # both ranks verified their own frames against the oracle
+    xc = j["exchange"]
+    assert "error" not in xc, xc
+    assert "host all-gather" in xc["transport"] and xc["ranks"] == 2
+    assert xc["bytes_received_per_rank_per_step"] == xc["bytes_per_rank_per_step"] == 64 * 1024 * 32 + 64 * 2 * 4 + (-(64 * 2 * 4) % 256)
+    assert xc["step_ms_with_gather"] > 0 and xc["step_ms_without_gather"] > 0 and xc["repeats"] >= 3
+    for k in ("end_to_end_operator", "secondary", "streamed_frontend", "cpu_baseline"):
+        assert k not in j, k                           # the N = 1 extras are not part of an N > 1 line
