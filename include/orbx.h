@@ -348,6 +348,16 @@ typedef struct orbx_candidate { int32_t idx, dist; } orbx_candidate;
 int orbx_target_search_view(orbx_ctx* ctx, const orbx_target* target, const uint8_t* kp_skip, const float* qx, const float* qy, const float* qr,
                             const int32_t* qmin_level, const int32_t* qmax_level, const uint8_t* q_desc, const float* q_xr, int nq,
                             const orbx_list_span** spans, const orbx_candidate** pool);
+/* The same call split into ISSUE and WAIT, for a caller with two batches of queries and host work of its own on either side (the drop-in
+ * ORBmatcher's per-frame routines: the reference's per-point pre-pass of the second half runs while the device works on the first, the replay
+ * of the first half while it works on the second).  _begin packs the queries into the next of the context's two view blobs and queues the window
+ * kernel — nothing waits — and returns the slot (0 / 1) to hand to _end; at most one call per blob can be pending, so at most two in flight.
+ * _end waits for that call and hands out the view exactly as orbx_target_search_view does (same lifetime rule: valid until the second next view
+ * call); a pool that was too small, or a build without the mapped-blob path, makes _end run the ordinary synchronous call.  The query arrays
+ * (and kp_skip) must stay valid and unchanged until _end; other calls on the context are allowed in between. */
+int orbx_target_search_view_begin(orbx_ctx* ctx, const orbx_target* target, const uint8_t* kp_skip, const float* qx, const float* qy, const float* qr,
+                                  const int32_t* qmin_level, const int32_t* qmax_level, const uint8_t* q_desc, const float* q_xr, int nq);
+int orbx_target_search_view_end(orbx_ctx* ctx, int slot, const orbx_list_span** spans, const orbx_candidate** pool);
 /* = orbx_window_nearest on the target; reprojection_gate != 0 needs a target created with kp_uright + inv_level_sigma2, and q_ur */
 int orbx_target_nearest(orbx_ctx* ctx, const orbx_target* target, int reprojection_gate, const float* qx, const float* qy, const float* qr,
                         const int32_t* qmin_level, const int32_t* qmax_level, const float* q_ur, const uint8_t* q_desc, int nq, int32_t* best_idx,

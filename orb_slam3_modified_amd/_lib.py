@@ -114,6 +114,8 @@ def lib() -> C.CDLL:
         "orbx_kfdb_size": (i32, [vp]),
         "orbx_kfdb_query": (i32, [vp, vp, vp, i32, vp, i32, i32, vp, vp, vp, i32, ip, ip, ip]),
         "orbx_target_search_view": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]),
+        "orbx_target_search_view_begin": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32]),
+        "orbx_target_search_view_end": (i32, [vp, i32, vp, vp]),
         "orbx_last_graph_device_us": (C.c_double, [vp]),
         "orbx_publish_descriptors": (i32, [vp, vp, i32]),
         "orbx_kfdb_sharing": (i32, [vp, vp, i32, vp, vp, i32, ip]),

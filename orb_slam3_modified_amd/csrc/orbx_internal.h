@@ -213,6 +213,14 @@ struct orbx_ctx {
   std::vector<int32_t> view_row_ptr; int view_pool_cap = 16384;   // orbx_target_search_view: scratch and the candidate-pool capacity learnt from earlier calls
   int32_t* d_win_ctr = nullptr; bool win_ctr_dirty = true;   // the two self-resetting counters of resident-target window passes
   uint8_t* h_view[2] = {nullptr, nullptr}; size_t h_view_bytes[2] = {0, 0}; int view_par = 0;   // the blobs of view calls, used alternately
+  // orbx_target_search_view_begin / _end: a view call split into issue and wait (a caller with two halves of work overlaps its own host
+  // passes with the device: ref_adapter/ORBmatcher.cc).  One pending call per blob.
+  struct ViewCall {
+    bool pending = false, sync_fallback = false;
+    const orbx_target* target = nullptr; const uint8_t* kp_skip = nullptr;
+    const float *qx = nullptr, *qy = nullptr, *qr = nullptr, *q_xr = nullptr; const int32_t *qlo = nullptr, *qhi = nullptr; const uint8_t* q_desc = nullptr;
+    int nq = 0, pool_cap = 0; size_t in_size = 0, p_hdr = 0, p_q = 0, p_pool = 0;
+  } view_call[2];
   uint8_t* h_call = nullptr; size_t h_call_bytes = 0;   // pinned [inputs | outputs] blob of the window / nn entry points (orbx_window.hip)
   int win_guess = 0;            // candidates of the last window call: how much of the pool the first read-back copy takes
   // single-frame operator() path as a replayed hipGraph (H2D, the 13 launches, D2H): one graph launch per frame instead

@@ -1002,6 +1002,103 @@ int orbx_target_search_view(orbx_ctx* ctx, const orbx_target* target, const uint
   return ORBX_E_CAPACITY;
 }
 
+// ---- a view call as issue + wait ------------------------------------------------------------------------------------------------------------
+// begin: this call's blob is chosen (the other one keeps the previous view / the other pending call), the queries are packed into it and the
+// window kernel is queued; nothing waits.  end: polls the blob's done word and hands out the view — or, when the learnt pool capacity was too
+// small (or the mapped-blob path is not available), runs the ordinary synchronous call on the same blob.  The query arrays must stay valid and
+// unchanged until _end.  Between a _begin and its _end the context may take other calls (another _begin, searches on other targets): the stream
+// orders the kernels, the results of every call live in its own blob.
+int orbx_target_search_view_begin(orbx_ctx* ctx, const orbx_target* target, const uint8_t* kp_skip, const float* qx, const float* qy, const float* qr,
+                                  const int32_t* qmin_level, const int32_t* qmax_level, const uint8_t* q_desc, const float* q_xr, int nq) {
+  if (!ctx || !target || target->ctx != ctx || nq < 0 ||
+      (nq > 0 && (!qx || !qy || !qr || !qmin_level || !qmax_level || !q_desc)) || (q_xr && !target->has_ur))
+    return ctx ? set_err(ctx, ORBX_E_INVALID, "orbx_target_search_view_begin: bad arguments") : ORBX_E_INVALID;
+  if (!target->valid) return set_err(ctx, ORBX_E_INVALID, "orbx_target_search_view_begin: the target's last orbx_target_assign failed; assign it again");
+  const int slot = ctx->view_par ^ 1;
+  orbx_ctx::ViewCall& vc = ctx->view_call[slot];
+  if (vc.pending) return set_err(ctx, ORBX_E_INVALID, "orbx_target_search_view_begin: both view blobs hold a pending call (finish one with _end first)");
+  ctx->view_par = slot;
+  vc = orbx_ctx::ViewCall();
+  vc.pending = true; vc.target = target; vc.kp_skip = kp_skip; vc.qx = qx; vc.qy = qy; vc.qr = qr; vc.q_xr = q_xr; vc.qlo = qmin_level; vc.qhi = qmax_level;
+  vc.q_desc = q_desc; vc.nq = nq;
+  const int n = target->n;
+  if (nq == 0 || n == 0) { vc.sync_fallback = true; return slot; }   // nothing to launch: _end answers from the ordinary path
+  ORBX_HIP(ctx, hipSetDevice(ctx->device));
+  const int pool_cap = std::max(ctx->view_pool_cap, 0);
+  const int nskip = kp_skip ? (n + 3) & ~3 : 0;
+  Layout in;
+  const size_t o_q = in.add(sizeof(WinQueryIn) * (size_t)nq), o_skip = in.add((size_t)nskip);
+  Layout out;
+  const size_t p_hdr = out.add(16), p_q = out.add(sizeof(WinQueryOut) * (size_t)nq), p_pool = out.add(8 * (size_t)pool_cap);
+  uint8_t* h = nullptr;
+  ORBX_HIP(ctx, host_stage_view(ctx, in.size + out.size, &h));
+  uint8_t* hdev = nullptr;
+  const bool direct = ctx->window_direct && nskip <= 48 * 1024 && hipHostGetDevicePointer((void**)&hdev, h, 0) == hipSuccess && hdev != nullptr;
+  if (!direct) { (void)hipGetLastError(); vc.sync_fallback = true; return slot; }   // the copy + synchronise path has nothing to overlap
+  pack_queries(h + o_q, qx, qy, qr, q_xr, qmin_level, qmax_level, q_desc, nq);
+  if (kp_skip) { std::memcpy(h + o_skip, kp_skip, (size_t)n); std::memset(h + o_skip + n, 0, (size_t)(nskip - n)); }
+  std::memset(h + in.size + p_hdr, 0, 16);
+  hipStream_t st = ctx->stream;
+  if (!ctx->d_win_ctr) { ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_win_ctr, 64)); ctx->win_ctr_dirty = true; }
+  const bool other_pending = ctx->view_call[slot ^ 1].pending && !ctx->view_call[slot ^ 1].sync_fallback;
+  if (ctx->win_ctr_dirty && !other_pending) ORBX_HIP(ctx, hipMemsetAsync(ctx->d_win_ctr, 0, 64, st));   // (dirty because of the other pending call: its kernel resets the counters itself)
+  ctx->win_ctr_dirty = true;
+  WinArgs a;
+  std::memset(&a, 0, sizeof(a));
+  const orbx_target* T = target;
+  a.kps = (const orbx_keypoint*)(T->dev + T->o_kps); a.desc = T->dev + T->o_desc;
+  a.cell_start = (const int32_t*)(T->dev + T->o_cs); a.cell_idx = (const int32_t*)(T->dev + T->o_ci);
+  a.minX = T->min_x; a.minY = T->min_y; a.invW = T->inv_w; a.invH = T->inv_h;
+  a.qin = (const WinQueryIn*)(hdev + o_q); a.has_aux = q_xr ? 1 : 0; a.nq = nq;
+  if (kp_skip) { a.skip_map = hdev + o_skip; a.n_skip = nskip; }
+  a.kp_uright = T->has_ur ? (const float*)(T->dev + T->o_ur) : nullptr;
+  uint8_t* const res = hdev + in.size;
+  a.out = (WinQueryOut*)(res + p_q); a.pool = (int2*)(res + p_pool); a.pool_cap = pool_cap; a.total = ctx->d_win_ctr;
+  a.out_hdr = (int32_t*)(res + p_hdr); a.compact = 0; a.host_out = 1; a.self_reset = 1;
+  hipLaunchKernelGGL((k_window<true, false>), dim3((nq + kWinWPG - 1) / kWinWPG), dim3(64 * kWinWPG), a.skip_map ? (size_t)nskip : 0, st, a);
+  ORBX_HIP(ctx, hipGetLastError());
+  vc.pool_cap = pool_cap; vc.in_size = in.size; vc.p_hdr = p_hdr; vc.p_q = p_q; vc.p_pool = p_pool;
+  return slot;
+}
+
+int orbx_target_search_view_end(orbx_ctx* ctx, int slot, const orbx_list_span** spans, const orbx_candidate** pool) {
+  if (!ctx || slot < 0 || slot > 1 || !spans || !pool) return ctx ? set_err(ctx, ORBX_E_INVALID, "orbx_target_search_view_end: bad arguments") : ORBX_E_INVALID;
+  *spans = nullptr; *pool = nullptr;
+  orbx_ctx::ViewCall vc = ctx->view_call[slot];
+  if (!vc.pending) return set_err(ctx, ORBX_E_INVALID, "orbx_target_search_view_end: no pending call in this slot");
+  ctx->view_call[slot].pending = false;
+  auto run_sync = [&]() {   // the ordinary call, on THIS call's blob (the other blob may back a live view or another pending call)
+    ctx->view_par = slot ^ 1;   // orbx_target_search_view flips to `slot`
+    return orbx_target_search_view(ctx, vc.target, vc.kp_skip, vc.qx, vc.qy, vc.qr, vc.qlo, vc.qhi, vc.q_desc, vc.q_xr, vc.nq, spans, pool);
+  };
+  if (vc.sync_fallback) return run_sync();
+  uint8_t* const hout = ctx->h_view[slot] + vc.in_size;
+  const volatile unsigned long long* hdr = (const volatile unsigned long long*)(hout + vc.p_hdr);
+  for (unsigned spin = 1;; spin++) {
+    if (__atomic_load_n(hdr, __ATOMIC_ACQUIRE) >> 32) break;
+    if ((spin & 0x3fff) == 0) {
+      const hipError_t qe = hipStreamQuery(ctx->stream);
+      if (qe == hipSuccess) {
+        if (__atomic_load_n(hdr, __ATOMIC_ACQUIRE) >> 32) break;
+        return set_err(ctx, ORBX_E_DEVICE, "orbx_target_search_view_end: window pass finished without publishing its results");
+      }
+      if (qe != hipErrorNotReady) { ORBX_HIP(ctx, qe); }
+    }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+  if (!ctx->view_call[slot ^ 1].pending) ctx->win_ctr_dirty = false;
+  const int total = *(const int32_t*)(hout + vc.p_hdr);
+  if (total > vc.pool_cap) {   // the learnt capacity was too small: once more, synchronously, with room
+    ctx->view_pool_cap = std::max(2 * ctx->view_pool_cap, total + total / 4 + 64);
+    return run_sync();
+  }
+  *spans = (const orbx_list_span*)(hout + vc.p_q);
+  *pool = (const orbx_candidate*)(hout + vc.p_pool);
+  return total;
+}
+
 int orbx_target_nearest(orbx_ctx* ctx, const orbx_target* target, int reprojection_gate, const float* qx, const float* qy, const float* qr,
                         const int32_t* qmin_level, const int32_t* qmax_level, const float* q_ur, const uint8_t* q_desc, int nq, int32_t* best_idx,
                         int32_t* best_dist) {

@@ -358,6 +358,35 @@ void window_lists(const char* routine, orbx_target* T, const Queries& Q, Lists& 
   }
 }
 
+// The two per-frame routines of Tracking split their points into two halves and overlap their own host passes with the device
+// (orbx_target_search_view_begin / _end): the pre-pass of the second half runs while the device works on the first, the replay of the first
+// half while it works on the second.  The replay stays in the reference's order (first half first), the device pass does not depend on
+// what the replay binds, so the results are the same calls' results.  ORBX_SEARCH_PIPELINE=0 switches it off (A/B, tests).
+bool search_pipeline_enabled() {
+  static const bool on = [] { const char* e = std::getenv("ORBX_SEARCH_PIPELINE"); return !(e && std::atoi(e) == 0); }();
+  return on;
+}
+// queries [q0, q0 + nq) of Q against T, issued only; -1 = nothing was issued (no queries or an empty target).  Q's vectors must not reallocate
+// before window_lists_end (the callers reserve them for the whole call up front).
+int window_lists_begin(const char* routine, orbx_target* T, const Queries& Q, int q0, int nq) {
+  if (nq == 0 || !T || orbx_target_size(T) == 0) return -1;
+  orbx_ctx* ctx = ORBmatcher::DefaultContext();
+  const int slot = orbx_target_search_view_begin(ctx, T, nullptr, Q.x.data() + q0, Q.y.data() + q0, Q.r.data() + q0, Q.lo.data() + q0, Q.hi.data() + q0,
+                                                 Q.desc.data() + (size_t)q0 * 32, nullptr, nq);
+  if (slot < 0) fail(routine, ctx);
+  return slot;
+}
+void window_lists_end(const char* routine, int slot, int nq, Lists& L) {
+  L.row_ptr.assign(nq + 1, 0);
+  L.own();
+  if (slot < 0) return;
+  orbx_ctx* ctx = ORBmatcher::DefaultContext();
+  const orbx_list_span* spans = nullptr;
+  const orbx_candidate* pool = nullptr;
+  if (orbx_target_search_view_end(ctx, slot, &spans, &pool) < 0) fail(routine, ctx);
+  if (spans) L.view(spans, pool);
+}
+
 void window_best(const char* routine, orbx_target* T, bool reprojection_gate, const Queries& Q, std::vector<int32_t>& bestIdx,
                  std::vector<int32_t>& bestDist) {
   const int nq = Q.size();
@@ -499,7 +528,8 @@ int ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoint
   Queries QL, QR;
   QL.reserve(nMP);
   std::vector<int> qLeft(nMP, -1), qRight(nMP, -1);
-  for (int iMP = 0; iMP < nMP; iMP++) {
+  auto prepass = [&](int iMP0, int iMP1) {
+  for (int iMP = iMP0; iMP < iMP1; iMP++) {
     MapPoint* pMP = vpMapPoints[iMP];
     if (!pMP->mbTrackInView && !pMP->mbTrackInViewR) continue;
     if (bFarPoints && pMP->mTrackDepth > thFarPoints) continue;
@@ -520,25 +550,18 @@ int ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoint
       }
     }
   }
-  if (QL.size() == 0 && QR.size() == 0) return 0;
-  tr.mark("prepass");
-  // phase 2
+  };
   const std::vector<cv::KeyPoint>& keysL = rig ? F.mvKeys : F.mvKeysUn;
-  Lists LL, LR;
-  orbx_target* TL = QL.size() ? frame_target("SearchByProjection", F, false) : nullptr;
-  orbx_target* TR = QR.size() ? frame_target("SearchByProjection", F, true) : nullptr;
-  tr.mark("target");
-  if (TL) window_lists("SearchByProjection", TL, QL, LL, /*view_ok=*/true);   // a rig keeps two lists alive: the two view blobs alternate
-  if (TR) window_lists("SearchByProjection", TR, QR, LR, /*view_ok=*/true);
-  tr.mark("device");
+  Lists LR;
   // phase 3 (:76-140, :151-207): a keypoint bound to an observed map point — before the call or by an earlier map point of
-  // this call — is no candidate
-  for (int iMP = 0; iMP < nMP; iMP++) {
+  // this call — is no candidate.  LL holds the lists of the left queries [qbase, ...): position ql = q - qbase
+  auto replay = [&](int iMP0, int iMP1, const Lists& LL, int qbase) {
+  for (int iMP = iMP0; iMP < iMP1; iMP++) {
     if (qLeft[iMP] < 0 && qRight[iMP] < 0) continue;
     MapPoint* pMP = vpMapPoints[iMP];
     if (qLeft[iMP] >= 0) {
-      const int q = qLeft[iMP];
-      if (LL.begin(q) != LL.end(q)) {
+      const int q = qLeft[iMP], ql = q - qbase;
+      if (LL.begin(ql) != LL.end(ql)) {
         int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
         auto eligible = [&](size_t idx) {   // the gates of :89-101 on one candidate
           if (F.mvpMapPoints[idx])
@@ -553,7 +576,7 @@ int ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoint
         // two smallest of the gated list as well (a list of one: the best alone), and the loop is not needed
         bool have = false;
         if (LL.has_best()) {
-          const orbx_list_span& sp = LL.span(q);
+          const orbx_list_span& sp = LL.span(ql);
           if (sp.best_idx >= 0 && eligible((size_t)sp.best_idx) && (sp.count == 1 || (sp.second_idx >= 0 && eligible((size_t)sp.second_idx)))) {
             bestDist = sp.best_dist; bestIdx = sp.best_idx; bestLevel = keysL[sp.best_idx].octave;
             if (sp.count > 1) { bestDist2 = sp.second_dist; bestLevel2 = keysL[sp.second_idx].octave; }
@@ -561,7 +584,7 @@ int ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoint
           }
         }
         if (!have)
-        for (int c = LL.begin(q); c < LL.end(q); c++) {
+        for (int c = LL.begin(ql); c < LL.end(ql); c++) {
           const size_t idx = LL.cand[c];
           if (!eligible(idx)) continue;
           const int dist = LL.dist[c];
@@ -612,6 +635,42 @@ int ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoint
       }
     }
   }
+  };
+  if (!rig && search_pipeline_enabled() && nMP >= 128) {
+    // two halves, the host passes of one under the device pass of the other (the frame is resident already: SearchLocalPoints follows
+    // TrackWithMotionModel / TrackReferenceKeyFrame on the same frame)
+    orbx_target* TL = frame_target("SearchByProjection", F, false);
+    tr.mark("target");
+    const int mid = nMP / 2;
+    prepass(0, mid);
+    const int nA = QL.size();
+    const int sA = window_lists_begin("SearchByProjection", TL, QL, 0, nA);
+    prepass(mid, nMP);
+    const int nB = QL.size() - nA;
+    if (nA + nB == 0) return 0;
+    const int sB = window_lists_begin("SearchByProjection", TL, QL, nA, nB);
+    tr.mark("prepass");
+    Lists LA, LB;
+    window_lists_end("SearchByProjection", sA, nA, LA);
+    replay(0, mid, LA, 0);
+    window_lists_end("SearchByProjection", sB, nB, LB);
+    tr.mark("half");
+    replay(mid, nMP, LB, nA);
+    tr.mark("replay");
+    return nmatches;
+  }
+  prepass(0, nMP);
+  if (QL.size() == 0 && QR.size() == 0) return 0;
+  tr.mark("prepass");
+  // phase 2
+  Lists LL;
+  orbx_target* TL = QL.size() ? frame_target("SearchByProjection", F, false) : nullptr;
+  orbx_target* TR = QR.size() ? frame_target("SearchByProjection", F, true) : nullptr;
+  tr.mark("target");
+  if (TL) window_lists("SearchByProjection", TL, QL, LL, /*view_ok=*/true);   // a rig keeps two lists alive: the two view blobs alternate
+  if (TR) window_lists("SearchByProjection", TR, QR, LR, /*view_ok=*/true);
+  tr.mark("device");
+  replay(0, nMP, LL, 0);
   tr.mark("replay");
   return nmatches;
 }
@@ -1285,7 +1344,8 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
   Queries QL, QR;
   QL.reserve(LastFrame.N);
   std::vector<int> qLeft(LastFrame.N, -1), qRight(LastFrame.N, -1);
-  for (int i = 0; i < LastFrame.N; i++) {
+  auto prepass = [&](int i0, int i1) {
+  for (int i = i0; i < i1; i++) {
     MapPoint* pMP = LastFrame.mvpMapPoints[i];
     if (!pMP) continue;
     if (LastFrame.mvbOutlier[i]) continue;
@@ -1308,23 +1368,19 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
       qRight[i] = QR.add(uvr(0), uvr(1), radius, lo, hi, pMP->GetDescriptor());
     }
   }
-  if (QL.size() == 0) return 0;
-  tr.mark("prepass");
-  // phase 2
-  Lists LL, LR;
-  window_lists("SearchByProjection", TL, QL, LL, /*view_ok=*/true);   // two view blobs alternate: the left lists stay readable
-  if (rig) window_lists("SearchByProjection", TR, QR, LR, /*view_ok=*/true);
-  tr.mark("device");
-  // phase 3 (:1735-1858)
+  };
+  Lists LR;
+  // phase 3 (:1735-1858).  LL holds the lists of the left queries [qbase, ...): position ql = q - qbase
   RotHist rot;
   auto lastKey = [&](int i) -> const cv::KeyPoint& {
     return (LastFrame.Nleft == -1) ? LastFrame.mvKeysUn[i] : (i < LastFrame.Nleft) ? LastFrame.mvKeys[i] : LastFrame.mvKeysRight[i - LastFrame.Nleft];
   };
-  for (int i = 0; i < LastFrame.N; i++) {
+  auto replay = [&](int i0, int i1, const Lists& LL, int qbase) {
+  for (int i = i0; i < i1; i++) {
     if (qLeft[i] < 0) continue;
     MapPoint* pMP = LastFrame.mvpMapPoints[i];
-    const int q = qLeft[i];
-    if (LL.begin(q) == LL.end(q)) continue;   // (`if(vIndices2.empty()) continue;` skips the right camera too, :1735-1736)
+    const int q = qLeft[i], ql = q - qbase;
+    if (LL.begin(ql) == LL.end(ql)) continue;   // (`if(vIndices2.empty()) continue;` skips the right camera too, :1735-1736)
     int bestDist = 256, bestIdx2 = -1;
     // the gates of :1741-1760 on one candidate
     auto eligible = [&](size_t i2) {
@@ -1338,10 +1394,10 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
     };
     // The device pass already found the first minimum of the whole list; if that candidate passes the gates here — which depend on
     // what earlier points of this loop took — it is also the first minimum of the gated list and the loop is not needed.
-    if (LL.has_best() && LL.span(q).best_idx >= 0 && eligible((size_t)LL.span(q).best_idx)) {
-      bestDist = LL.span(q).best_dist; bestIdx2 = LL.span(q).best_idx;
+    if (LL.has_best() && LL.span(ql).best_idx >= 0 && eligible((size_t)LL.span(ql).best_idx)) {
+      bestDist = LL.span(ql).best_dist; bestIdx2 = LL.span(ql).best_idx;
     } else
-    for (int c = LL.begin(q); c < LL.end(q); c++) {
+    for (int c = LL.begin(ql); c < LL.end(ql); c++) {
       const size_t i2 = LL.cand[c];
       if (!eligible(i2)) continue;
       const int dist = LL.dist[c];
@@ -1380,6 +1436,36 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
         if (mbCheckOrientation) rot.add(lastKey(i).angle, CurrentFrame.mvKeysRight[bestIdxR].angle, bestIdxR + CurrentFrame.Nleft);
       }
     }
+  }
+  };
+  const int N = LastFrame.N;
+  if (!rig && search_pipeline_enabled() && N >= 128) {
+    // two halves, the host passes of one under the device pass of the other (ORBmatcher.cc's window_lists_begin / _end)
+    const int mid = N / 2;
+    prepass(0, mid);
+    const int nA = QL.size();
+    const int sA = window_lists_begin("SearchByProjection", TL, QL, 0, nA);
+    prepass(mid, N);
+    const int nB = QL.size() - nA;
+    if (nA + nB == 0) return 0;
+    const int sB = window_lists_begin("SearchByProjection", TL, QL, nA, nB);
+    tr.mark("prepass");
+    Lists LA, LB;
+    window_lists_end("SearchByProjection", sA, nA, LA);
+    replay(0, mid, LA, 0);
+    window_lists_end("SearchByProjection", sB, nB, LB);
+    tr.mark("half");
+    replay(mid, N, LB, nA);
+  } else {
+    prepass(0, N);
+    if (QL.size() == 0) return 0;
+    tr.mark("prepass");
+    // phase 2
+    Lists LL;
+    window_lists("SearchByProjection", TL, QL, LL, /*view_ok=*/true);   // two view blobs alternate: the left lists stay readable
+    if (rig) window_lists("SearchByProjection", TR, QR, LR, /*view_ok=*/true);
+    tr.mark("device");
+    replay(0, N, LL, 0);
   }
   if (mbCheckOrientation) {
     int ind1 = -1, ind2 = -1, ind3 = -1;

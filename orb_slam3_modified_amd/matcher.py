@@ -388,6 +388,34 @@ class SearchTarget:
         assert int(spans["count"].sum()) == total
         return spans, pool
 
+    def search_view_begin(self, qx, qy, qr, min_level, max_level, q_desc, kp_skip=None, q_xr=None):
+        """orbx_target_search_view_begin: the call issued, nothing waited for.  Returns a ticket for search_view_end (it keeps the query arrays
+        alive: the C ABI wants them valid and unchanged until _end)."""
+        qx, qy, qr = (np.ascontiguousarray(v, np.float32) for v in (qx, qy, qr))
+        lo, hi = (np.ascontiguousarray(v, np.int32) for v in (min_level, max_level))
+        qd = np.ascontiguousarray(q_desc, np.uint8).reshape(-1, 32)
+        skip = None if kp_skip is None else np.ascontiguousarray(kp_skip, np.uint8)
+        xr = None if q_xr is None else np.ascontiguousarray(q_xr, np.float32)
+        slot = check(int(self._L.orbx_target_search_view_begin(self._ctx, self._h, ptr(skip), ptr(qx), ptr(qy), ptr(qr), ptr(lo), ptr(hi), ptr(qd), ptr(xr), len(qx))),
+                     self._ctx)
+        return (slot, len(qx), (qx, qy, qr, lo, hi, qd, skip, xr))
+
+    def search_view_end(self, ticket, copy=True):
+        """orbx_target_search_view_end -> (spans, pool) as search_view returns them."""
+        slot, nq, _keep = ticket
+        sp, pl = C.c_void_p(), C.c_void_p()
+        total = check(int(self._L.orbx_target_search_view_end(self._ctx, slot, C.byref(sp), C.byref(pl))), self._ctx)
+        span_t = np.dtype([("start", "<i4"), ("count", "<i4"), ("best_idx", "<i4"), ("best_dist", "<i4"), ("second_idx", "<i4"), ("second_dist", "<i4"),
+                           ("reserved0", "<i4"), ("reserved1", "<i4")])
+        cand_t = np.dtype([("idx", "<i4"), ("dist", "<i4")])
+        if nq == 0 or not sp.value:
+            return np.zeros(0, span_t), np.zeros(0, cand_t)
+        spans = np.frombuffer((C.c_char * (span_t.itemsize * nq)).from_address(sp.value), span_t)
+        end = int((spans["start"] + spans["count"]).max())
+        pool = np.frombuffer((C.c_char * (cand_t.itemsize * max(end, 1))).from_address(pl.value), cand_t)[:end] if end and pl.value else np.zeros(0, cand_t)
+        assert int(spans["count"].sum()) == total
+        return (spans.copy(), pool.copy()) if copy else (spans, pool)
+
     def nearest(self, qx, qy, qr, min_level, max_level, q_desc, q_ur=None):
         qx, qy, qr = (np.ascontiguousarray(v, np.float32) for v in (qx, qy, qr))
         lo, hi = (np.ascontiguousarray(v, np.int32) for v in (min_level, max_level))

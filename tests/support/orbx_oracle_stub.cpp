@@ -283,6 +283,25 @@ int orbx_target_search_view(orbx_ctx* ctx, const orbx_target* T, const uint8_t* 
   *spans = sp.data(); *pool = pl.data();
   return rp[nq];
 }
+// issue + wait: the stub has nothing to overlap — _begin remembers the arguments, _end runs the call (same results, same lifetimes)
+namespace {
+struct StubViewCall { bool pending = false; const orbx_target* T; const uint8_t* skip; const float *qx, *qy, *qr, *qxr; const int32_t *qmin, *qmax; const uint8_t* qd; int nq; };
+thread_local StubViewCall g_view_calls[2];
+thread_local int g_view_next = 0;
+}  // namespace
+int orbx_target_search_view_begin(orbx_ctx*, const orbx_target* T, const uint8_t* kp_skip, const float* qx, const float* qy, const float* qr, const int32_t* qmin,
+                                  const int32_t* qmax, const uint8_t* q_desc, const float* q_xr, int nq) {
+  const int slot = g_view_next; g_view_next ^= 1;
+  if (g_view_calls[slot].pending) return ORBX_E_INVALID;
+  g_view_calls[slot] = StubViewCall{true, T, kp_skip, qx, qy, qr, q_xr, qmin, qmax, q_desc, nq};
+  return slot;
+}
+int orbx_target_search_view_end(orbx_ctx* ctx, int slot, const orbx_list_span** spans, const orbx_candidate** pool) {
+  if (slot < 0 || slot > 1 || !g_view_calls[slot].pending) return ORBX_E_INVALID;
+  const StubViewCall c = g_view_calls[slot];
+  g_view_calls[slot].pending = false;
+  return orbx_target_search_view(ctx, c.T, c.skip, c.qx, c.qy, c.qr, c.qmin, c.qmax, c.qd, c.qxr, c.nq, spans, pool);
+}
 int orbx_target_nearest(orbx_ctx*, const orbx_target* T, int reprojection_gate, const float* qx, const float* qy, const float* qr, const int32_t* qmin,
                         const int32_t* qmax, const float* q_ur, const uint8_t* q_desc, int nq, int32_t* best_idx, int32_t* best_dist) {
   mo_window_nearest(T->kps.data(), T->desc.data(), T->n, &T->g, reprojection_gate ? T->ur.data() : nullptr, reprojection_gate ? T->sig.data() : nullptr,

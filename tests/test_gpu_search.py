@@ -483,6 +483,64 @@ def test_a_view_survives_the_capacity_retry_of_the_next_view_call(frames):
     tgt.close()
 
 
+def test_view_calls_issued_and_waited_for_separately(frames):
+    """orbx_target_search_view_begin / _end (the split the drop-in's per-frame routines use to overlap their host passes with the device): two
+    calls in flight on the two view blobs, another call on the context in between, ends in either order; a pool that turns out too small makes
+    _end fall back to the synchronous call with the same results; a third _begin while two are pending and an _end without a _begin are errors."""
+    gpu, fr = frames
+    m = ORBmatcher(gpu)
+    k2, d2, d1 = fr[1].mvKeysUn, fr[1].mDescriptors, fr[0].mDescriptors
+    grid = dict(_kf_grid(k2, (0.0, 0.0, 640.0, 480.0), True), cell_start=None, cell_idx=None)
+    tgt = m.Target(k2, d2, grid)
+    rng = np.random.default_rng(17)
+
+    def queries(nq, radius):
+        src = rng.integers(0, len(k2), nq)
+        return (k2["x"][src].copy(), k2["y"][src].copy(), np.full(nq, radius, np.float32), np.full(nq, -1, np.int32), np.full(nq, -1, np.int32),
+                d1[rng.integers(0, len(d1), nq)].copy())
+
+    def check_view(view, q):
+        spans, pool = view
+        want = po.window_search_grid(k2, d2, grid, *q)
+        assert int(spans["count"].sum()) == int(want["row_ptr"][-1])
+        for i in range(len(q[0])):
+            a, b = int(want["row_ptr"][i]), int(want["row_ptr"][i + 1])
+            seg = pool[int(spans["start"][i]):int(spans["start"][i]) + int(spans["count"][i])]
+            assert np.array_equal(seg["idx"], want["cand"][a:b]) and np.array_equal(seg["dist"], want["dist"][a:b]), i
+        assert np.array_equal(spans["best_idx"], want["best_idx"])
+
+    for order in ("ab", "ba"):
+        qa, qb, qc = queries(400, 9.0), queries(700, 14.0), queries(50, 5.0)
+        ta = tgt.search_view_begin(*qa)
+        tb = tgt.search_view_begin(*qb)
+        assert {ta[0], tb[0]} == {0, 1}
+        with pytest.raises(OrbxError):
+            tgt.search_view_begin(*qc)                    # both blobs hold a pending call
+        other = tgt.search(*qc)                            # an ordinary call in between
+        wc = po.window_search_grid(k2, d2, grid, *qc)
+        assert np.array_equal(other["cand"], wc["cand"])
+        if order == "ab":
+            va = tgt.search_view_end(ta, copy=False); vb = tgt.search_view_end(tb, copy=False)
+        else:
+            vb = tgt.search_view_end(tb, copy=False); va = tgt.search_view_end(ta, copy=False)
+        check_view(va, qa); check_view(vb, qb)            # both views readable at the same time
+        with pytest.raises(OrbxError):
+            tgt.search_view_end(ta)                        # nothing pending in that slot any more
+    # overflow of the learnt capacity inside a pending call: _end repeats it synchronously
+    m.set_option("view_pool_cap", 256)
+    qa, qb = queries(300, 10.0), queries(600, 60.0)
+    ta = tgt.search_view_begin(*qa); tb = tgt.search_view_begin(*qb)
+    va = tgt.search_view_end(ta, copy=False)
+    keep = (va[0].copy(), va[1].copy())
+    vb = tgt.search_view_end(tb, copy=False)
+    check_view(vb, qb); check_view(va, qa)
+    assert np.array_equal(va[0], keep[0]) and np.array_equal(va[1], keep[1])     # B's repeat did not touch A's blob
+    # empty query set and empty target
+    te = tgt.search_view_begin(*queries(0, 1.0))
+    assert len(tgt.search_view_end(te)[0]) == 0
+    tgt.close()
+
+
 def test_failed_target_assign_leaves_an_invalid_target_not_an_empty_one(frames):
     """orbx_target_assign that fails (here: a grid whose indices point past the keypoints) must not leave a target that answers
     searches with 0 candidates and ORBX_OK: it is invalid until a later assign succeeds."""
