@@ -467,6 +467,15 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
   uint32_t* bitmap = (uint32_t*)(list + list_cap);        // list_cap is a multiple of 8
   int* wpre = (int*)(bitmap + nwords);
   constexpr int NW = T / 64, WPT = 256 / T, P4 = PITCH / 4;
+#ifdef ORBX_FAST_ENDS
+  // Experiment of round 5 (HISTORY.md): the two waves of a workgroup keep their OWN candidate counts in scalar registers — wave 0's entries grow up
+  // from list[0], wave 1's down from list[list_cap - 1] — instead of reserving list positions with an LDS atomic per trip (the compiler's
+  // wave-aggregated form of it: nine vector instructions and a dependent LDS round trip on the critical path of every trip that finds a pixel).
+  // The later stages address entry e of n0 + n1 as e < n0 ? list[e] : list[list_cap - 1 - (e - n0)]; list order never mattered (bitmap rank).
+  constexpr bool ENDS = (T == 128) && !DMA;
+#else
+  constexpr bool ENDS = false;
+#endif
   __shared__ int wave_tot[NW];
   __shared__ int s_cnt;
   __shared__ int s_any;
@@ -545,6 +554,9 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
     const int kmin = (3 + xo) >> 2, kmax = (cw - 4 + xo) >> 2, ng = kmax - kmin + 1;
     const int nit = dh * ng;
     const uint32_t magic = (65536u + (uint32_t)ng - 1u) / (uint32_t)ng;  // i / ng == (i * magic) >> 16 for i < 65536 / ng
+    int wcount = 0;                                                       // ENDS: this wave's entries so far (wave-uniform: a scalar register)
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);
+    uint16_t* const lend = list + (list_cap - 1);
     for (int i0 = 0; i0 < nit; i0 += T) {
       const int act = (i0 + t) < nit;
       const int i = act ? i0 + t : nit - 1;
@@ -614,8 +626,11 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
       const int tot = n0 + n1_ + n2 + n3;
       if (tot) {  // wave-uniform
         int base = 0;
-        if (lane == 0) base = DMA ? lds_add_rtn_opaque(&s_cnt, tot) : atomicAdd(&s_cnt, tot);
-        base = __builtin_amdgcn_readfirstlane(base);
+        if constexpr (ENDS) { base = wcount; wcount += tot; }
+        else {
+          if (lane == 0) base = DMA ? lds_add_rtn_opaque(&s_cnt, tot) : atomicAdd(&s_cnt, tot);
+          base = __builtin_amdgcn_readfirstlane(base);
+        }
         // slot of pixel j of this lane: base + (passes of pixels < j in the wave) + (passes of pixel j in lower lanes);
         // v_mbcnt accumulates onto a scalar start value, so each slot costs two VALU instructions
         const int ent = c0 + (ry << 7);  // c0 may be negative for the first group; pixel j is only listed when c0 + j >= 0
@@ -623,22 +638,34 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
         const int o1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, base + n0));
         const int o2 = __builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, base + n0 + n1_));
         const int o3 = __builtin_amdgcn_mbcnt_hi((uint32_t)(b3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b3, base + n0 + n1_ + n2));
-        if (ps[0]) list[o0] = (uint16_t)ent;
-        if (ps[1]) list[o1] = (uint16_t)(ent + 1);
-        if (ps[2]) list[o2] = (uint16_t)(ent + 2);
-        if (ps[3]) list[o3] = (uint16_t)(ent + 3);
+        if (ENDS && wvu != 0) {   // wave-uniform: the second wave fills the list from its far end
+          if (ps[0]) lend[-o0] = (uint16_t)ent;
+          if (ps[1]) lend[-o1] = (uint16_t)(ent + 1);
+          if (ps[2]) lend[-o2] = (uint16_t)(ent + 2);
+          if (ps[3]) lend[-o3] = (uint16_t)(ent + 3);
+        } else {
+          if (ps[0]) list[o0] = (uint16_t)ent;
+          if (ps[1]) list[o1] = (uint16_t)(ent + 1);
+          if (ps[2]) list[o2] = (uint16_t)(ent + 2);
+          if (ps[3]) list[o3] = (uint16_t)(ent + 3);
+        }
       }
     }
+    if (ENDS && lane == 0) wave_tot[wvu] = wcount;
   }
   cell_sync<DMA>();
   if (stop_after == 2) {
     if (t == 0) cell_cnt[(long long)frame * g->ncells_total + cell] = 0;
     return;
   }
-  const int n1 = s_cnt;
+  int n0 = 0, n1;
+  if constexpr (ENDS) { n0 = wave_tot[0]; n1 = n0 + wave_tot[NW - 1]; } else n1 = s_cnt;
+  // entry e of the n1 listed pixels (ENDS: the second wave's entries sit at the far end of the list, last first)
+  const int lflip = list_cap - 1 + n0;
+  auto entry = [&](int e) -> uint16_t& { return list[ENDS ? (e < n0 ? e : lflip - e) : e]; };
   // ---- C: exact score of the listed pixels
   for (int e = t; e < n1; e += T) {
-    const int ent = list[e];
+    const int ent = entry(e);
     const int x = ent & 127, y = ent >> 7;
     const uint8_t* c0 = tile + y * PITCH + (x + xo);  // top-left of the 7x7 window; centre = c0[3 * PITCH + 3]
     const int v = c0[3 * PITCH + 3];
@@ -654,7 +681,7 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
   // ---- D: 3x3 strict NMS inside the cell (neighbours outside the detection domain are 0)
   int any_ini = 0;
   for (int e = t; e < n1; e += T) {
-    const int ent = list[e];
+    const int ent = entry(e);
     const int x = ent & 127, y = ent >> 7;
     const uint8_t* q = sc + y * PITCH + x;  // top-left of the 3x3 window
     const int s = q[PITCH + 1];
@@ -662,7 +689,7 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
       const int m = max(max(max((int)q[0], (int)q[1]), max((int)q[2], (int)q[PITCH])),
                         max(max((int)q[PITCH + 2], (int)q[2 * PITCH]), max((int)q[2 * PITCH + 1], (int)q[2 * PITCH + 2])));
       if (s > m) {
-        list[e] = (uint16_t)(ent | 0x8000);
+        entry(e) = (uint16_t)(ent | 0x8000);
         any_ini |= s >= ini_th;
       }
     }
@@ -673,7 +700,7 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
   const int TH = use_ini ? ini_th : min_th;
   // ---- E: bitmap of the selected survivors (bit index = row-major pixel index)
   for (int e = t; e < n1; e += T) {
-    const int le = list[e];
+    const int le = entry(e);
     if (le & 0x8000) {
       const int x = le & 127, y = (le >> 7) & 127;
       const int i = y * dw + x;
@@ -716,7 +743,7 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
   // ---- G: row-major rank of every selected survivor -> its slot
   uint32_t* slot = cand + (long long)frame * g->cand_total + cg.slot_off;
   for (int e = t; e < n1; e += T) {
-    const int le = list[e];
+    const int le = entry(e);
     if (le & 0x8000) {
       const int x = le & 127, y = (le >> 7) & 127;
       const int s = sc[(y + 1) * PITCH + (x + 1)];

@@ -1,9 +1,11 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_search.py tests/test_matcher_world.py tests/test_streamed_frontend.py tests/test_frame_world.py -x -q -m gpu 2>&1 | tail -12
 STAMP=$(python -c "from orb_slam3_modified_amd.build import stamp; s = stamp(); print('commit', s['commit'], 'kernel sources', s['kernels_hash'], s['date'])")
-{ echo "$STAMP"; echo "the per-frame Tracking sequence (tools/frontend_ab.py), alternating: pipelined searches (default) / ORBX_SEARCH_PIPELINE=0"
-  for i in 1 2 3; do echo "pipelined: $(python tools/frontend_ab.py 2>/dev/null)"; echo "serial:    $(ORBX_SEARCH_PIPELINE=0 python tools/frontend_ab.py 2>/dev/null)"; done; } 2>&1 | tee gpurun_out/search_pipeline_ab.txt
-CMD=$(python tools/frontend_ab.py --print-cmd)
-ORBX_TRACE_MATCHER=1 $CMD 2>&1 >/dev/null | tail -6
+ORBX_LIB=$PWD/gpurun_exp/liborbx_ends.so timeout 900 python -m pytest tests/test_gpu_extractor.py tests/test_natural_images.py -x -q -m gpu 2>&1 | tail -3
+ORBX_LIB=$PWD/gpurun_exp/liborbx_ends.so timeout 300 python tools/fuzz_extractor.py 3000 80 2>&1 | tail -1
+{ echo "$STAMP"; echo "k_fast_cells: candidate list filled from both ends by the two waves (-DORBX_FAST_ENDS, no LDS atomic per trip) against the product; tools/kernel_times.py, us per 256 frames"
+  for rep in 1 2 3; do echo "product: $(python tools/kernel_times.py 256)"; echo "ends:    $(ORBX_LIB=$PWD/gpurun_exp/liborbx_ends.so python tools/kernel_times.py 256)"; done
+  B="python bench.py --no-cpu-baseline --no-frontend --no-secondary --no-gather --steps 20 --warmup 5"
+  brief='import json,sys; j=json.loads(sys.stdin.read()); print(j["ms_per_step"], j["timing"]["ms_per_step_min"], j["timing"]["ms_per_step_max"], j["value"])'
+  for rep in 1 2; do echo "product bench: $($B 2>/dev/null | tail -1 | python -c "$brief")"; echo "ends bench:    $(ORBX_LIB=$PWD/gpurun_exp/liborbx_ends.so $B 2>/dev/null | tail -1 | python -c "$brief")"; done; } 2>&1 | tee gpurun_out/fast_ends_ab.txt
