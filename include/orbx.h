@@ -535,7 +535,8 @@ int orbx_kfdb_score(orbx_kfdb* db, const uint32_t* q_ids, const double* q_vals, 
  * Transport, by argument: unique_id != NULL -> ncclCommInitRank(world, unique_id, rank), the 128 bytes coming from orbx_replay_unique_id() on
  * one rank and reaching the others by whatever the host has (a file, MPI, a TCP store); host_exchange != NULL -> the caller's own host
  * all-gather, the block staged through pinned memory (tests, hosts without RCCL between their ranks); both NULL -> world must be 1 and a
- * one-rank RCCL group is made (the self-gather: the collective's own cost on this GPU).  Not thread-safe; one engine per thread. */
+ * one-rank RCCL group is made (the self-gather: the collective's own cost on this GPU).  Not thread-safe; one engine per thread.
+ * When orbx_replay_create fails, the reason is in orbx_last_error(lanes[0]) (there is no engine yet to ask); afterwards in orbx_replay_last_error. */
 typedef struct orbx_replay orbx_replay;
 #define ORBX_REPLAY_UNIQUE_ID_BYTES 128   /* sizeof(ncclUniqueId) */
 #define ORBX_GATHER_NONE 0

@@ -1,6 +1,7 @@
 """Multi-process (world_size 2, gloo, CPU) tests of the N > 1 path: camera-stream sharding, the fixed-size feature
-block layout, and the all-gather exchange of batch-replay mode.  On the GPU node the same code
-runs over RCCL ("nccl" backend) inside bench.py; the extraction itself needs no collective."""
+block layout, and the all-gather exchange of batch-replay mode on host buffers.  On the GPU node the
+exchange is ncclAllGather called by liborbx (orbx_replay_*; tests/test_gpu_replay.py) and the layout checked here is the one
+orbx_replay_layout reports (ReplayEngine asserts they agree); the extraction itself needs no collective."""
 import os
 import socket
 
