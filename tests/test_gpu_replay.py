@@ -343,3 +343,45 @@ def test_two_ranks_bootstrap_through_the_c_abi_is_refused_loudly_on_one_device(t
     assert [r[0] for r in res] == [0, 1]
     for rank, what, msg, _ in res:
         assert what == "refused" and "ncclCommInitRank" in msg, res
+
+
+def test_replay_c_abi_argument_checks_and_uneven_lanes():
+    """orbx_replay_create refuses what it cannot run (no lanes, fewer frames than lanes, the same context twice, contexts of different
+    parameters, more than one rank without a way to reach the others, both transports at once) with ORBX_E_INVALID and no engine; three lanes
+    over 100 frames (34 + 34 + 32) give the oracle's bytes on every frame."""
+    import ctypes as C
+    import torch
+    from oracle import pyoracle as po
+    from orb_slam3_modified_amd import ORBextractor, _lib, synth
+    from orb_slam3_modified_amd.replay import ReplayEngine, unpack_block
+    L = _lib.lib()
+    a, b = ORBextractor(1000, 1.2, 8, 20, 7, device_id=0), ORBextractor(1000, 1.2, 8, 20, 7, device_id=0)
+    other = ORBextractor(500, 1.2, 6, 20, 7, device_id=0)
+    h = C.c_void_p()
+
+    def create(ctxs, frames, what=0, rank=0, world=1, uid=None, cb=None):
+        arr = (C.c_void_p * max(len(ctxs), 1))(*[c._ctx for c in ctxs])
+        return L.orbx_replay_create(C.byref(h), arr, len(ctxs), frames, 480, 640, what, rank, world, uid, cb, None)
+
+    uid = (C.c_uint8 * 128)()
+    cb = L.HOST_EXCHANGE_FN(lambda u, s, r, n: 0)
+    for args in (([], 64), ([a, b], 1), ([a, a], 64), ([a, other], 64), ([a], 64, 3), ([a], 64, 1, 2, 2), ([a], 64, 1, 0, 2),
+                 ([a], 64, 1, 0, 2, uid, C.cast(cb, C.c_void_p)), ([a], 0), ([a], 70000)):
+        assert create(*args) == -1 and not h.value, args
+    host = synth.make_stream(5)
+    nfr = 100
+    frames = torch.from_numpy(host[np.arange(nfr) % 5]).to("cuda:0")
+    eng = ReplayEngine(a, frames, lapping=(0, 1000), gather=True, lanes=3, gather_what="blocks")
+    assert eng.lane_ranges == [(0, 34), (34, 68), (68, 100)]
+    for _ in range(3):
+        i = eng.step()
+    blk = eng.block_host(i)
+    assert np.array_equal(eng.gathered_host(i)[0], blk)
+    res = unpack_block(blk, eng.layout)
+    ora = po.OracleExtractor(1000, 1.2, 8, 20, 7)
+    want = [ora.extract(host[k], (0, 1000)) for k in range(5)]
+    for f in range(nfr):
+        okps, odesc, omono = want[f % 5]
+        mono, kps, desc = res[f]
+        assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc), f
+    eng.close()
