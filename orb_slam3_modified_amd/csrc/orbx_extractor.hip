@@ -879,7 +879,8 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, 
     return ORBX_E_DEVICE;
   }
   if (hipMalloc((void**)&ctx->d_qt_fin, kSmallBatchFrames * sizeof(int32_t)) != hipSuccess ||
-      hipMemset(ctx->d_qt_fin, 0, kSmallBatchFrames * sizeof(int32_t)) != hipSuccess) {
+      hipMemsetAsync(ctx->d_qt_fin, 0, kSmallBatchFrames * sizeof(int32_t), ctx->stream) != hipSuccess ||   // never the legacy stream (orbx_internal.h):
+      hipStreamSynchronize(ctx->stream) != hipSuccess) {                                                        // contexts are created lazily, per thread, at any time
     (void)hipGetLastError();
     if (ctx->d_qt_fin) (void)hipFree(ctx->d_qt_fin);
     ctx->d_qt_fin = nullptr;   // the separate launches serve instead

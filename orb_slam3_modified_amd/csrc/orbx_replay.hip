@@ -205,20 +205,26 @@ int orbx_replay_create(orbx_replay** out, orbx_ctx* const* lanes, int nlanes, in
     const int rc = orbx_reserve(r->lanes[j], rows, cols, r->ranges[j].second - r->ranges[j].first);
     if (rc != ORBX_OK) return bail(rc, std::string("orbx_replay_create: orbx_reserve: ") + orbx_last_error(r->lanes[j]));
   }
+  // Explicit non-blocking streams carry the lanes; the collective ALWAYS runs on its own stream behind every lane of the step: on a lane's
+  // stream step k + 1's kernels would queue behind step k's collective and the overlap would be gone.
   hipError_t e = hipSuccess;
+  r->streams.assign(r->lanes.size(), nullptr);
+  for (size_t j = 0; j < r->lanes.size() && e == hipSuccess; j++) e = hipStreamCreateWithFlags(&r->streams[j], hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->gstream, hipStreamNonBlocking);
+  // (no entry point of this library touches the legacy stream — orbx_internal.h: a null-stream operation of one thread poisons another
+  // thread's graph capture — so the buffers are cleared on the engine's own stream)
   for (int i = 0; i < 2 && e == hipSuccess; i++) {
     e = hipMalloc((void**)&r->blocks[i], r->nbytes);
-    if (e == hipSuccess) e = hipMemset(r->blocks[i], 0, r->nbytes);
-    if (e == hipSuccess && r->gather_on) { e = hipMalloc((void**)&r->gathered[i], r->send_bytes * (size_t)world); if (e == hipSuccess) e = hipMemset(r->gathered[i], 0, r->send_bytes * (size_t)world); }
+    if (e == hipSuccess) e = hipMemsetAsync(r->blocks[i], 0, r->nbytes, r->gstream);
+    if (e == hipSuccess && r->gather_on) {
+      e = hipMalloc((void**)&r->gathered[i], r->send_bytes * (size_t)world);
+      if (e == hipSuccess) e = hipMemsetAsync(r->gathered[i], 0, r->send_bytes * (size_t)world, r->gstream);
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&r->gather_done[i], hipEventDisableTiming);
     r->lane_done[i].assign(r->lanes.size(), nullptr);
     for (size_t j = 0; j < r->lanes.size() && e == hipSuccess; j++) e = hipEventCreateWithFlags(&r->lane_done[i][j], hipEventDisableTiming);
   }
-  // Explicit non-blocking streams carry the lanes; the collective ALWAYS runs on its own stream behind every lane of the step: on a lane's
-  // stream step k + 1's kernels would queue behind step k's collective and the overlap would be gone.
-  r->streams.assign(r->lanes.size(), nullptr);
-  for (size_t j = 0; j < r->lanes.size() && e == hipSuccess; j++) e = hipStreamCreateWithFlags(&r->streams[j], hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->gstream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamSynchronize(r->gstream);
   for (int k = 0; k < kTimingPairs && e == hipSuccess && r->gather_on; k++) { e = hipEventCreate(&r->t0[k]); if (e == hipSuccess) e = hipEventCreate(&r->t1[k]); }
   if (e != hipSuccess) return bail(ORBX_E_DEVICE, std::string("orbx_replay_create: ") + hipGetErrorString(e));
   if (r->gather_on) {
@@ -347,7 +353,8 @@ int orbx_replay_read(orbx_replay* r, int what, int i, void* host_dst, size_t off
   if (!src || offset > total || nbytes > total - offset) return rfail(r, ORBX_E_INVALID, "orbx_replay_read: range outside the buffer");
   const int rc = orbx_replay_drain(r);
   if (rc != ORBX_OK) return rc;
-  RHIP(r, hipMemcpy(host_dst, src + offset, nbytes, hipMemcpyDeviceToHost));
+  RHIP(r, hipMemcpyAsync(host_dst, src + offset, nbytes, hipMemcpyDeviceToHost, r->gstream));   // never the legacy stream (orbx_internal.h)
+  RHIP(r, hipStreamSynchronize(r->gstream));
   return ORBX_OK;
 }
 
@@ -355,7 +362,8 @@ int orbx_replay_write_block(orbx_replay* r, int i, const void* host_src, size_t 
   if (!r || !host_src || i < 0 || i > 1 || offset > r->nbytes || nbytes > r->nbytes - offset) return ORBX_E_INVALID;
   const int rc = orbx_replay_drain(r);
   if (rc != ORBX_OK) return rc;
-  RHIP(r, hipMemcpy(r->blocks[i] + offset, host_src, nbytes, hipMemcpyHostToDevice));
+  RHIP(r, hipMemcpyAsync(r->blocks[i] + offset, host_src, nbytes, hipMemcpyHostToDevice, r->gstream));
+  RHIP(r, hipStreamSynchronize(r->gstream));
   return ORBX_OK;
 }
 

@@ -27,6 +27,11 @@ class ORBVocabulary:
 
     def loadFromTextFile(self, filename: str) -> bool:
         """TemplatedVocabulary.h:1338-1424; returns False on a malformed file like the reference."""
+        # as include/ORBVocabulary.h (and the reference: loadFromTextFile clears the tree first): the old vocabulary goes away BEFORE the new one
+        # is built — the new one may well come back at the same address
+        if self._voc and self._voc.value:
+            self._L.orbx_voc_destroy(self._voc)
+            self._voc = C.c_void_p(0)
         v = C.c_void_p(0)
         rc = self._L.orbx_voc_load_text(self._ctx, filename.encode(), C.byref(v))
         if rc != 0:

@@ -249,3 +249,60 @@ def test_vocabulary_writers_and_binary_cache(feats, tmp_path):
         open(pbad, "wb").write(bad)
         assert not ORBVocabulary(gpu).loadBinary(pbad)
     assert not ORBVocabulary(gpu).loadBinary(str(tmp_path / "missing.bin"))
+
+
+def test_vocabulary_reload_while_an_extractor_descends_it(tmp_path):
+    """Round-4 advisor finding: a vocabulary destroyed and loaded again can come back at the same heap address (ORBVocabulary::loadFrom* is
+    destroy + load); a context that had it attached must not keep launching the descent over the freed tree, and orbx_voc_destroy must not free
+    the tree under an extraction that already took its snapshot.  One thread extracts frame after frame and asks for the published records,
+    another reloads the vocabulary the whole time (ctypes calls release the GIL: the threads really run concurrently).  Every served record
+    must equal the ordinary descent's of the vocabulary as it is afterwards (the file never changes), nothing may hang or crash."""
+    import threading
+    import time
+    frames = synth.make_stream(4)
+    ex = ORBextractor(1000, 1.2, 8, 20, 7)
+    d0 = ex(frames[0], None, (0, 1000))[2]
+    p = str(tmp_path / "voc.txt")
+    make_vocabulary(p, d0, 10, 3, seed=7)
+    gv = ORBVocabulary(ORBextractor(1000, 1.2, 8, 20, 7))       # its OWN context, like include/ORBVocabulary.h: a context is not thread-safe
+    assert gv.loadFromTextFile(p)
+    ref = ORBVocabulary(ORBextractor(1000, 1.2, 8, 20, 7))      # never reloaded: the expected records
+    assert ref.loadFromTextFile(p)
+    stop = threading.Event()
+    errors, served, reloads = [], [0], [0]
+    lock = threading.Lock()                                      # the Python mirror's handle swap (not the library) needs it
+
+    def reloader():
+        try:
+            while not stop.is_set():
+                with lock:
+                    assert gv.loadFromTextFile(p)                # orbx_voc_destroy (detach everywhere, wait for extractions in flight) + load
+                reloads[0] += 1
+                time.sleep(0.002)                                # (the extractor thread needs the Python lock now and then)
+        except Exception as e:   # noqa: BLE001
+            errors.append(("reload", repr(e)))
+
+    def extractor():
+        try:
+            for it in range(40):
+                d = np.ascontiguousarray(ex(frames[it % 4], None, (0, 1000))[2])
+                ex.publish_descriptors(d)
+                with lock:
+                    got = gv.descend_published(d, 4)
+                if got is not None:
+                    w, wt, nd = got
+                    ow, owt, ond = ref.descend(d, 4)
+                    if not (np.array_equal(w, ow) and wt.tobytes() == owt.tobytes() and np.array_equal(nd, ond)):
+                        errors.append(("records", it))
+                    served[0] += 1
+        except Exception as e:   # noqa: BLE001
+            errors.append(("extract", repr(e)))
+        finally:
+            stop.set()
+
+    ta, tb = threading.Thread(target=reloader), threading.Thread(target=extractor)
+    ta.start(); tb.start()
+    tb.join(300); stop.set(); ta.join(60)
+    assert not tb.is_alive() and not ta.is_alive(), "a thread hangs"
+    assert not errors, errors[:5]
+    assert reloads[0] > 3      # the vocabulary really went away and came back while frames were being extracted

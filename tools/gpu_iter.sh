@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_replay.py -x -q -m gpu 2>&1 | tail -8
+timeout 900 python -m pytest tests/test_gpu_replay.py -x -q -m gpu --durations=6 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -14
