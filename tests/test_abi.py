@@ -60,3 +60,22 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".inc")):
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "pyoracle" not in txt and "liborb_oracle" not in txt and "oracle/" not in txt.replace("oracle/orb_pattern", ""), f
+
+
+def test_no_entry_point_touches_the_legacy_stream():
+    """orbx_internal.h's rule: a null-stream copy / memset or a device-wide synchronisation issued by one thread while ANOTHER context captures
+    its single-frame graph poisons that capture (two extractors run on two threads in stereo, matcher contexts are created lazily per thread).
+    Every synchronous copy therefore goes through a stream of its own.  Static check over the library's sources (the quadtree phase profiler's
+    symbol copies only exist in -DORBX_QT_PROFILE builds)."""
+    csrc = os.path.join(ROOT, "orb_slam3_modified_amd", "csrc")
+    bad = re.compile(r"\b(hipMemcpy|hipMemset|hipMemcpy2D|hipMemset2D|hipDeviceSynchronize|hipMemcpyToSymbol|hipMemcpyFromSymbol)\s*\(")
+    hits = []
+    for dp, _, fs in os.walk(csrc):
+        for f in fs:
+            if not f.endswith((".hip", ".h", ".cc")):
+                continue
+            for n, line in enumerate(open(os.path.join(dp, f), errors="replace"), 1):
+                code = line.split("//")[0]
+                if bad.search(code) and "g_qt_prof" not in code:
+                    hits.append(f"{f}:{n}: {line.strip()[:100]}")
+    assert not hits, hits
