@@ -34,6 +34,28 @@ def test_the_reference_call_sites_compile_over_the_drop_in_headers(tmp_path):
     assert r2.returncode != 0 and "SearchByBoW" in r2.stderr
 
 
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src")), reason="the reference checkout is not on this machine (GPU box)")
+def test_tracking_constructs_frames_from_the_drop_in_extractors(tmp_path):
+    """The ten `mCurrentFrame = Frame(...)` statements of src/Tracking.cc (GrabImageStereo / RGBD / Monocular, with and without IMU and a second
+    camera) hand Tracking's ORBextractor* / ORBVocabulary* members to the constructors of the reference's UNMODIFIED include/Frame.h: lifted
+    verbatim and compiled the way oracle/ref_fragments.mk compiles dropin_frame_world — the reference's Frame.h over include/ORBextractor.h and
+    include/ORBVocabulary.h."""
+    tu = str(tmp_path / "callsites_frame_tu.cpp")
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "gen_callsites.py"), "--frames", REF, tu]).decode()
+    assert out.startswith("10 Frame constructions"), out
+    fw = os.path.join(ROOT, "tests", "support", "frame_world")
+    cmd = ["g++", "-fsyntax-only", "-std=c++17", "-ffp-contract=off", "-w", "-pthread", "-include", os.path.join(fw, "prelude.h"), "-I", fw,
+           "-I", os.path.join(ROOT, "oracle", "ref_shims"), "-DFRAME_WORLD_DROPIN", "-I", os.path.join(ROOT, "include"), "-I", REF, "-I", os.path.join(REF, "include"),
+           "-I", os.path.join(REF, "include", "CameraModels"), tu]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    # teeth: an extractor of another type is refused by the same command
+    bad = str(tmp_path / "bad.cpp")
+    open(bad, "w").write(open(tu).read() + "\nvoid negative(cv::Mat& im, ORBVocabulary* v, GeometricCamera* c, cv::Mat& d) { int* e = nullptr; Frame f(im, 0.0, e, v, c, d, 1.f, 1.f); }\n")
+    r2 = subprocess.run(cmd[:-1] + [bad], capture_output=True, text=True)
+    assert r2.returncode != 0
+
+
 def test_generator_notices_a_moved_reference(tmp_path):
     """Line numbers are pinned together with a token of the statement: against a file whose lines moved the generator stops instead of lifting
     the wrong statement."""

@@ -83,7 +83,45 @@ struct World { Frame &f0, &f1; KeyFrame *kf, *kf2; Map* map; KeyFrameDatabase* d
 '''
 
 
+# ---- second unit: the Frame constructions of src/Tracking.cc (GrabImageStereo / GrabImageRGBD / GrabImageMonocular), compiled like
+# oracle/ref_fragments.mk compiles dropin_frame_world: the reference's UNMODIFIED include/Frame.h over include/ORBextractor.h + ORBVocabulary.h and
+# the stand-ins of tests/support/frame_world — the extractor and vocabulary pointers Tracking owns are handed to Frame's constructors as written there
+FRAME_LINES = [(1496, "mpORBextractorLeft,mpORBextractorRight,mpORBVocabulary,mK,mDistCoef,mbf,mThDepth,mpCamera);"),
+               (1498, "mpCamera,mpCamera2,mTlr);"), (1500, "mpCamera,&mLastFrame,*mpImuCalib);"), (1502, "mpCamera2,mTlr,&mLastFrame,*mpImuCalib);"),
+               (1546, "imDepth,timestamp,mpORBextractorLeft,mpORBVocabulary"), (1548, "imDepth,timestamp,mpORBextractorLeft,mpORBVocabulary"),
+               (1590, "mpIniORBextractor,mpORBVocabulary,mpCamera,mDistCoef,mbf,mThDepth);"), (1592, "mpORBextractorLeft,mpORBVocabulary,mpCamera,mDistCoef,mbf,mThDepth);"),
+               (1598, "mpIniORBextractor,mpORBVocabulary,mpCamera,mDistCoef,mbf,mThDepth,&mLastFrame,*mpImuCalib);"),
+               (1601, "mpORBextractorLeft,mpORBVocabulary,mpCamera,mDistCoef,mbf,mThDepth,&mLastFrame,*mpImuCalib);")]
+FRAME_PRELUDE = r'''// GENERATED by tools/gen_callsites.py --frames from the reference's src/Tracking.cc where it lies: do not commit.  TEST INFRASTRUCTURE.
+// compile with the flags of oracle/ref_fragments.mk's dropin_frame_world (-include tests/support/frame_world/prelude.h -DFRAME_WORLD_DROPIN ...)
+#include "Frame.h"              // the reference's own include/Frame.h; "ORBextractor.h" / "ORBVocabulary.h" resolve to the drop-in headers
+using namespace std;
+using namespace ORB_SLAM3;
+// include/Tracking.h:176-182, 303-310, 326-340: the members the statements mention
+void callsites_Tracking_GrabImage(cv::Mat& mImGray, cv::Mat& imGrayRight, cv::Mat& imDepth, double timestamp, ORBextractor* mpORBextractorLeft,
+                                  ORBextractor* mpORBextractorRight, ORBextractor* mpIniORBextractor, ORBVocabulary* mpORBVocabulary, cv::Mat& mK,
+                                  cv::Mat& mDistCoef, float mbf, float mThDepth, GeometricCamera* mpCamera, GeometricCamera* mpCamera2, Sophus::SE3f& mTlr,
+                                  Frame& mLastFrame, Frame& mCurrentFrame, IMU::Calib* mpImuCalib) {
+'''
+
+
+def frames_unit(ref, out):
+    path = os.path.join(ref, "src/Tracking.cc")
+    src = open(path, encoding="utf-8", errors="replace").read().splitlines()
+    body = []
+    for ln, token in FRAME_LINES:
+        text = src[ln - 1]
+        if token not in text or "mCurrentFrame = Frame(" not in text:
+            raise SystemExit(f"src/Tracking.cc:{ln} does not hold the expected Frame construction any more (found: {text.strip()[:100]})")
+        body.append(f'#line {ln} "{path}"\n{text}')
+    open(out, "w").write(FRAME_PRELUDE + "\n".join(body) + "\n}\n")
+    print(f"{len(body)} Frame constructions of src/Tracking.cc -> {out}")
+
+
 def main():
+    if "--frames" in sys.argv:
+        a = [x for x in sys.argv[1:] if x != "--frames"]
+        return frames_unit(a[0], a[1])
     ref, out = sys.argv[1], sys.argv[2]
     parts = [PRELUDE]
     cache = {}
