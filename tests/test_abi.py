@@ -79,3 +79,14 @@ def test_no_entry_point_touches_the_legacy_stream():
                 if bad.search(code) and "g_qt_prof" not in code:
                     hits.append(f"{f}:{n}: {line.strip()[:100]}")
     assert not hits, hits
+
+
+def test_rccl_is_bound_at_run_time_not_at_link_time():
+    """liborbx.so carries no link-time dependency on RCCL (a process without it can use everything else; a process that already has one shares that
+    instance): the replay engine finds the library and its six entry points by dlopen / dlsym, and says which library and version it bound."""
+    import subprocess
+    from orb_slam3_modified_amd import _lib
+    needed = subprocess.check_output(["readelf", "-d", _lib.LIB_PATH]).decode()
+    assert "rccl" not in needed.lower() and "nccl" not in needed.lower()
+    info = _lib.lib().orbx_replay_rccl_info().decode()
+    assert info.startswith("rccl 2.") and "librccl" in info, info      # /opt/rocm/lib/librccl.so.1 in this image (no GPU needed to bind it)
