@@ -150,9 +150,25 @@ def frontend_inputs(tmpdir: str, nframes: int = 12, rows: int = 480, cols: int =
     return raw, vocp
 
 
-def run_frontend(exe: str, raw: str, rows: int, cols: int, nframes: int, nfeatures: int, vocp: str, passes: int = 1, timeout: int = 600) -> dict:
+MH01_STAMPS_GZ = os.path.join(ROOT, "tests", "golden", "mh01_stamps.txt.gz")
+
+
+def mh01_stamps(tmpdir: str) -> str:
+    """The 3 682 image time stamps of EuRoC MH_01 (fixture made by tools/make_mh01_stamps.py), unpacked for --timestamps."""
+    import gzip
+    out = os.path.join(tmpdir, "MH01.txt")
+    with gzip.open(MH01_STAMPS_GZ, "rb") as f, open(out, "wb") as g:
+        g.write(f.read())
+    return out
+
+
+def run_frontend(exe: str, raw: str, rows: int, cols: int, nframes: int, nfeatures: int, vocp: str, passes: int = 1, timeout: int = 600,
+                 frames: int = 0, stamps: str = "", pace: int = 0) -> dict:
+    """frames > 0: the long form (`--frames`: that many frames per pass, forth and back through the `nframes` images, ring of 8)."""
     import json
-    r = subprocess.run([exe, raw, str(rows), str(cols), str(nframes), str(nfeatures), vocp, str(passes)], capture_output=True, text=True, timeout=timeout)
+    extra = (["--frames", str(frames)] if frames else []) + (["--timestamps", stamps] if stamps else []) + (["--pace", str(pace)] if pace else [])
+    r = subprocess.run([exe, raw, str(rows), str(cols), str(nframes), str(nfeatures), vocp, str(passes)] + extra, capture_output=True, text=True,
+                       timeout=timeout)
     if r.returncode != 0:
         raise RuntimeError(f"{exe} failed ({r.returncode}): {r.stdout}{r.stderr}")
     return json.loads(r.stdout.strip().splitlines()[-1])

@@ -11,8 +11,16 @@
 //                     restatements) + the reference's DBoW2 through oracle/_ref/libref_dbow2.so
 // Both print one JSON line: ms per frame of every stage and a digest of everything the sequence produced (keypoints, descriptors,
 // BoW vectors, both searches' match vectors), which must be equal between the two builds.
-//   streamed_frontend <frames.raw> <rows> <cols> <nframes> <nfeatures> <voc.txt> <passes>
+//   streamed_frontend <frames.raw> <rows> <cols> <nframes> <nfeatures> <voc.txt> <passes> [--frames T] [--timestamps <stamps.txt>] [--pace 0|1]
+// Long form (BASELINE config 3 at length: Examples/Monocular/mono_euroc.cc:84-160 feeds 3 682 images of MH_01 at the rate of their
+// time stamps): `--frames T` streams T frames per pass by walking the <nframes> images forth and back (0 … n-1, n-2 … 1, 0 …: the
+// camera of the synthetic stream pans one way, then the other, so consecutive frames always overlap), keeping only the last 8 frames and
+// their points alive, as Tracking does (mCurrentFrame / mLastFrame + the local map); `--timestamps` + `--pace 1` sleep after every frame
+// until the next stamp is due, exactly the wait of mono_euroc.cc:150-160 (T = stamp[ni+1] - stamp[ni]; if ttrack < T usleep(T - ttrack));
+// every call's time is kept per frame and reported as p50 / p90 / p99 / max.
 #include "ORBextractor.h"
+
+#include <thread>
 
 #include "../tests/support/world_scene.h"
 
@@ -38,11 +46,46 @@ double ms_since(std::chrono::steady_clock::time_point t0) { return std::chrono::
 
 struct Stage { double extract = 0, bow = 0, frame_host = 0, search_last = 0, frustum_host = 0, search_local = 0; long frames = 0, feats = 0, m_last = 0, m_local = 0, retries = 0; };
 
+// every timed frame's time of one call, for the percentiles of the long form
+struct Series {
+  std::vector<float> v;
+  void add(double x) { v.push_back((float)x); }
+  std::string json() {
+    if (v.empty()) return "null";
+    std::vector<float> s(v);
+    std::sort(s.begin(), s.end());
+    auto q = [&](double p) { return s[std::min(s.size() - 1, (size_t)(p * (double)s.size()))]; };
+    double sum = 0;
+    for (float x : s) sum += x;
+    char b[200];
+    std::snprintf(b, sizeof b, "{\"mean\": %.4f, \"p50\": %.4f, \"p90\": %.4f, \"p99\": %.4f, \"max\": %.4f}", sum / (double)s.size(), q(0.50), q(0.90), q(0.99), s.back());
+    return b;
+  }
+};
+
 }  // namespace
 
 int main(int argc, char** argv) {
-  if (argc < 8) { std::fprintf(stderr, "usage: streamed_frontend <frames.raw> <rows> <cols> <nframes> <nfeatures> <voc.txt> <passes>\n"); return 2; }
+  if (argc < 8) {
+    std::fprintf(stderr, "usage: streamed_frontend <frames.raw> <rows> <cols> <nframes> <nfeatures> <voc.txt> <passes> [--frames T] [--timestamps <stamps.txt>] [--pace 0|1]\n");
+    return 2;
+  }
   const int rows = std::atoi(argv[2]), cols = std::atoi(argv[3]), nfr = std::atoi(argv[4]), nfeatures = std::atoi(argv[5]), passes = std::atoi(argv[7]);
+  int long_frames = 0, pace = 0;
+  std::vector<double> stamps;   // seconds
+  for (int a = 8; a + 1 < argc; a += 2) {
+    const std::string k = argv[a];
+    if (k == "--frames") long_frames = std::atoi(argv[a + 1]);
+    else if (k == "--pace") pace = std::atoi(argv[a + 1]);
+    else if (k == "--timestamps") {   // Examples/Monocular/mono_euroc.cc:193-199 (LoadImages): one integer of nanoseconds per line, t = ns / 1e9
+      std::ifstream f(argv[a + 1]);
+      std::string line;
+      while (std::getline(f, line))
+        if (!line.empty()) stamps.push_back(std::strtod(line.c_str(), nullptr) / 1e9);
+      if (stamps.empty()) { std::fprintf(stderr, "cannot read time stamps from %s\n", argv[a + 1]); return 2; }
+    } else { std::fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
+  }
+  if (pace && stamps.empty()) { std::fprintf(stderr, "--pace 1 needs --timestamps\n"); return 2; }
   std::vector<unsigned char> buf((size_t)rows * cols * nfr);
   { std::ifstream f(argv[1], std::ios::binary); f.read((char*)buf.data(), (std::streamsize)buf.size()); if (!f) { std::fprintf(stderr, "cannot read %s\n", argv[1]); return 2; } }
   try {
@@ -66,19 +109,35 @@ int main(int argc, char** argv) {
     w.scale = ex.GetScaleFactors(); w.sigma2 = ex.GetScaleSigmaSquares(); w.inv_sigma2 = ex.GetInverseScaleSigmaSquares();
     w.scaleFactor = ex.GetScaleFactor(); w.logScaleFactor = std::log(w.scaleFactor);
     std::vector<int> lap = {0, 1000};
+    // short form: every pass walks the nfr images once and keeps all of them; long form: T frames per timed pass over a ring of 8
+    // (Tracking keeps mCurrentFrame, mLastFrame and the local map's points: here the points of frames t-2 and t-5)
+    const bool longform = long_frames > 0;
+    const int ring = longform ? 8 : nfr;
+    const int warm_frames = longform ? std::min(long_frames, 32) : nfr;
+    const int period = nfr > 1 ? 2 * (nfr - 1) : 1;
+    const int first_timed = longform ? 8 : 5;   // steady state: a last frame and both local-map sources exist
     Fnv digest;
     Stage st;
+    Series q_extract, q_bow, q_last, q_local, q_total, q_wall;
+    double wall_s = 0, slept_s = 0;
     for (int pass = 0; pass <= passes; pass++) {   // pass 0 = warm-up (graph capture, first-touch allocations), not timed
       const bool timed_pass = pass > 0;
-      w.views.assign(nfr, View());
+      const int T = longform ? (timed_pass ? long_frames : warm_frames) : nfr;
+      w.views.assign(ring, View());
       Scene s(w, false);
-      std::vector<Frame> frames(nfr);
-      std::vector<std::vector<MapPoint> > pts(nfr);
+      std::vector<Frame> frames(ring);
+      std::vector<std::vector<MapPoint> > pts(ring);
       Fnv d;
-      for (int t = 0; t < nfr; t++) {
-        View& V = w.views[t];
-        Frame& Cur = frames[t];
-        cv::Mat im(rows, cols, CV_8UC1, buf.data() + (size_t)t * rows * cols);
+      const auto pass_t0 = std::chrono::steady_clock::now();
+      for (int t = 0; t < T; t++) {
+        const auto frame_t0 = std::chrono::steady_clock::now();
+        const int slot = t % ring;
+        int v = t % period;           // image of frame t: forth and back through the set
+        if (v >= nfr) v = period - v;
+        View& V = w.views[slot];
+        Frame& Cur = frames[slot];
+        if (longform) { V = View(); Cur = Frame(); }
+        cv::Mat im(rows, cols, CV_8UC1, buf.data() + (size_t)v * rows * cols);
         // ---- Frame::Frame: ExtractORB
         auto t0 = std::chrono::steady_clock::now();
         ex(im, cv::Mat(), V.kps, V.desc, lap);
@@ -110,7 +169,7 @@ int main(int argc, char** argv) {
         const double b_ms = ms_since(t0);
         // ---- rest of Frame::Frame on the host (UndistortKeyPoints without distortion = copy, AssignFeaturesToGrid): the same code in both builds
         t0 = std::chrono::steady_clock::now();
-        s.make_frame(Cur, t, false, s.pose(t));
+        s.make_frame(Cur, slot, false, s.pose(v));
         Cur.mDescriptors = V.desc;   // Frame::Frame hands mDescriptors itself to operator() (src/Frame.cc:311,418-425): the same buffer, not a copy
         const double f_ms = ms_since(t0);
         d.val(V.n); d.bytes(V.kps.data(), (size_t)V.n * sizeof(cv::KeyPoint));
@@ -118,13 +177,14 @@ int main(int argc, char** argv) {
         for (auto& kv : bow) { d.val(kv.first); d.val(kv.second); }
         for (auto& kv : V.fv) { d.val(kv.first); d.bytes(kv.second.data(), kv.second.size() * sizeof(unsigned)); }
         // the map this frame sees: points triangulated from this frame's own keypoints (used when it is the last frame / an older keyframe)
-        s.make_points(pts[t], t, s.pose(t), 1000000 * (t + 1), t);
+        s.make_points(pts[slot], slot, s.pose(v), 1000000 * (t % 2000 + 1), t);
         double sl_ms = 0, fr_ms = 0, sp_ms = 0;
         int nLast = 0, nLocal = 0;
         if (t >= 1) {
-          Frame& Last = frames[t - 1];
+          Frame& Last = frames[(t - 1) % ring];
+          std::vector<MapPoint>& lastPts = pts[(t - 1) % ring];
           for (int i = 0; i < Last.N; i++) {   // what tracking the last frame left: most keypoints carry a point, a few are outliers
-            Last.mvpMapPoints[i] = (H(i, 40 + t) % 6 != 0) ? &pts[t - 1][i] : static_cast<MapPoint*>(NULL);
+            Last.mvpMapPoints[i] = (H(i, 40 + t) % 6 != 0) ? &lastPts[i] : static_cast<MapPoint*>(NULL);
             Last.mvbOutlier[i] = H(i, 41 + t) % 10 == 0;
           }
           // ---- TrackWithMotionModel (src/Tracking.cc:2859-2897)
@@ -144,7 +204,7 @@ int main(int argc, char** argv) {
           std::vector<MapPoint*> vpLocal;
           for (int back : {2, 5})
             if (t - back >= 0)
-              for (MapPoint& m : pts[t - back]) vpLocal.push_back(&m);
+              for (MapPoint& m : pts[(t - back) % ring]) vpLocal.push_back(&m);
           if (!vpLocal.empty()) {
             std::vector<MapPoint> local;   // set_track_fields works on a contiguous vector: a copy of the points, gate fields included
             local.reserve(vpLocal.size());
@@ -167,21 +227,42 @@ int main(int argc, char** argv) {
             }
           }
         }
-        if (timed_pass && t >= 5) {   // steady state: a last frame and both local-map sources exist
+        if (timed_pass && t >= first_timed) {
           st.extract += e_ms; st.bow += b_ms; st.frame_host += f_ms; st.search_last += sl_ms; st.frustum_host += fr_ms; st.search_local += sp_ms;
           st.frames++; st.feats += V.n; st.m_last += nLast; st.m_local += nLocal;
+          if (longform) {
+            q_extract.add(e_ms); q_bow.add(b_ms); q_last.add(sl_ms); q_local.add(sp_ms); q_total.add(e_ms + b_ms + sl_ms + sp_ms);
+            q_wall.add(ms_since(frame_t0));
+          }
+        }
+        if (pace && timed_pass && t + 1 < T) {   // mono_euroc.cc:150-160: wait for the next image
+          const size_t ni = (size_t)t % (stamps.size() - 1);
+          const double Tnext = stamps[ni + 1] - stamps[ni];
+          const double ttrack = ms_since(frame_t0) * 1e-3;
+          if (ttrack < Tnext) {
+            std::this_thread::sleep_for(std::chrono::duration<double>(Tnext - ttrack));
+            slept_s += Tnext - ttrack;
+          }
         }
       }
-      if (pass == 0) digest = d;
-      else if (d.h != digest.h) { std::fprintf(stderr, "pass %d produced different results than pass 0\n", pass); return 4; }
+      if (timed_pass) wall_s += ms_since(pass_t0) * 1e-3;
+      if (pass == 0 && !longform) digest = d;
+      else if (pass == 1 && longform) digest = d;
+      else if (pass > 0 && d.h != digest.h) { std::fprintf(stderr, "pass %d produced different results than pass %d\n", pass, longform ? 1 : 0); return 4; }
     }
     const double n = (double)std::max(st.frames, 1L);
     const double device_path = (st.extract + st.bow + st.search_last + st.search_local) / n;
     std::printf("{\"build\": \"%s\", \"frames_timed\": %ld, \"ms_per_frame\": %.4f, \"extract_ms\": %.4f, \"bow_ms\": %.4f, \"search_last_ms\": %.4f, "
                 "\"search_local_ms\": %.4f, \"host_frame_ms\": %.4f, \"host_frustum_ms\": %.4f, \"features_per_frame\": %.1f, "
-                "\"matches_last_per_frame\": %.1f, \"matches_local_per_frame\": %.1f, \"wide_retries\": %ld, \"results_digest\": \"%016llx\"}\n",
+                "\"matches_last_per_frame\": %.1f, \"matches_local_per_frame\": %.1f, \"wide_retries\": %ld, \"results_digest\": \"%016llx\"",
                 build, st.frames, device_path, st.extract / n, st.bow / n, st.search_last / n, st.search_local / n, st.frame_host / n, st.frustum_host / n,
                 st.feats / n, st.m_last / n, st.m_local / n, st.retries, (unsigned long long)digest.h);
+    if (longform)
+      std::printf(", \"stream\": {\"frames_per_pass\": %d, \"images\": %d, \"order\": \"forth and back\", \"ring\": %d, \"paced\": %s, \"stamps\": %zu, \"wall_s\": %.2f, \"slept_s\": %.2f}, "
+                  "\"percentiles\": {\"extract_ms\": %s, \"bow_ms\": %s, \"search_last_ms\": %s, \"search_local_ms\": %s, \"four_calls_ms\": %s, \"frame_wall_ms\": %s}",
+                  long_frames, nfr, ring, pace ? "true" : "false", stamps.size(), wall_s, slept_s, q_extract.json().c_str(), q_bow.json().c_str(),
+                  q_last.json().c_str(), q_local.json().c_str(), q_total.json().c_str(), q_wall.json().c_str());
+    std::printf("}\n");
 #ifndef ORBX_H
     ref_voc_free(voc);
 #endif
