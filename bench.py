@@ -238,7 +238,7 @@ def frame_constructor():
     out = {}
     tmp = tempfile.mkdtemp(prefix="orbx_frame_")
     try:
-        for key, exe, n in (("gpu", "dropin_frame_world", 200), ("cpu", "ref_frame_world", 12)):
+        for key, exe, n in (("gpu", "dropin_frame_world", 200), ("gpu_stereo_patch", "dropin_frame_world_stereo", 200), ("cpu", "ref_frame_world", 12)):
             path = os.path.join(ref_dir, exe)
             if not os.path.exists(path):
                 out[key] = {"error": f"oracle/_ref/{exe} not built"}
@@ -250,7 +250,10 @@ def frame_constructor():
             out[key] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         out["what"] = ("the reference's own src/Frame.cc constructors, 752x480: gpu = compiled over include/ORBextractor.h + liborbx.so, cpu = over the "
                        "reference's src/ORBextractor.cc (OpenCV primitives restated, 2 threads in the stereo constructor as in the reference); "
-                       "ComputeStereoMatches runs on the host in both (Frame.cc untouched)")
+                       "ComputeStereoMatches runs on the host in both (Frame.cc untouched); gpu_stereo_patch = src/Frame.cc with "
+                       "integration/Frame_stereo.patch (4 lines) and -DORBX_DEVICE_STEREO: the association on the device pyramids, no host pyramid")
+        if "stereo_frame_ms" in out.get("gpu_stereo_patch", {}) and "gpu" in out:
+            out["gpu"]["stereo_patched_ms"] = out["gpu_stereo_patch"]["stereo_frame_ms"]
         return out
     except Exception as e:   # noqa: BLE001
         return {"error": str(e)[:300]}

@@ -6,7 +6,9 @@
  * Differences a caller cannot observe through this interface:
  *   - the pyramid lives in persistent device buffers (the reference reallocates it per call);
  *     mvImagePyramid[l] is a host copy made after each call (needed only by the stereo matcher,
- *     src/Frame.cc:818,908-925) — switch it off for mono with SetKeepHostPyramid(false);
+ *     src/Frame.cc:818,908-925) — switch it off for mono with SetKeepHostPyramid(false); a build with -DORBX_DEVICE_STEREO (and
+ *     integration/Frame_stereo.patch applied to src/Frame.cc: four lines) never makes it: ComputeStereoMatches then runs on the two
+ *     extractors' device pyramids (DeviceStereoMatches below);
  *   - mvImagePyramid[0] is a header over the caller's image and mvImagePyramid[l >= 1] are headers over a pinned host
  *     mirror that one asynchronous copy inside the call refreshes; there is no EDGE_THRESHOLD padding around them
  *     (nothing reads the pad), and like the reference's they are valid until the next call.
@@ -45,7 +47,10 @@ class ORBextractor {
     mvInvLevelSigma2.resize(nlevels); mnFeaturesPerLevel.resize(nlevels);
     orbx_scale_tables(ctx_, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(), mvInvLevelSigma2.data(),
                       mnFeaturesPerLevel.data());
-    orbx_set_host_pyramid(ctx_, 1);
+#ifdef ORBX_DEVICE_STEREO
+    keep_host_pyramid_ = false;   // the only reader of mvImagePyramid (Frame::ComputeStereoMatches) is patched to DeviceStereoMatches
+#endif
+    orbx_set_host_pyramid(ctx_, keep_host_pyramid_ ? 1 : 0);
 #ifdef ORBX_CV_CALIBRATION
     // which OpenCV release / build (and which compiler flags) is the CPU path this object replaces: found out once per process by running
     // the real cv::GaussianBlur / cv::fastAtan2 on a probe (include/orbx_cv_calibrate.h); the context then computes exactly those bytes
@@ -113,6 +118,24 @@ class ORBextractor {
   // orbx extensions (not in the reference)
   void SetKeepHostPyramid(bool on) { keep_host_pyramid_ = on; orbx_set_host_pyramid(ctx_, on ? 1 : 0); }
   orbx_ctx* Context() { return ctx_; }
+  // Frame::ComputeStereoMatches (src/Frame.cc:811-981) as one call on the device pyramids the two extractors hold from their last
+  // operator(): what integration/Frame_stereo.patch puts at the top of that routine (arguments = the Frame's own members, so the routine's
+  // read of `mb` before the constructor assigns it, src/Frame.cc:840 vs :178, is kept as it is).  mvuRight / mvDepth bit-identical.
+  static void DeviceStereoMatches(ORBextractor* left, ORBextractor* right, const std::vector<cv::KeyPoint>& mvKeys, const cv::Mat& mDescriptors,
+                                  const std::vector<cv::KeyPoint>& mvKeysRight, const cv::Mat& mDescriptorsRight, float mb, float mbf,
+                                  std::vector<float>& mvuRight, std::vector<float>& mvDepth) {
+    const int N = (int)mvKeys.size(), Nr = (int)mvKeysRight.size();
+    mvuRight.assign(N, -1.0f);
+    mvDepth.assign(N, -1.0f);
+    if (N == 0) return;
+    if ((N && !mDescriptors.isContinuous()) || (Nr && !mDescriptorsRight.isContinuous()))
+      throw std::runtime_error("ORBextractor::DeviceStereoMatches: descriptor matrices must be continuous (operator() makes them so)");
+    int kept = 0;
+    const int rc = orbx_stereo_matches(left->ctx_, right->ctx_, (const orbx_keypoint*)mvKeys.data(), mDescriptors.data, N,
+                                       (const orbx_keypoint*)mvKeysRight.data(), Nr ? mDescriptorsRight.data : nullptr, Nr, mb, mbf, mvuRight.data(),
+                                       mvDepth.data(), &kept);
+    if (rc != ORBX_OK) throw std::runtime_error(std::string("ORBextractor::DeviceStereoMatches: ") + orbx_last_error(left->ctx_));
+  }
 
  protected:
   int nfeatures;

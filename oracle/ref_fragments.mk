@@ -18,12 +18,16 @@
 #   _ref/dropin_frame_world     THE SAME src/Frame.cc over this repository's include/ORBextractor.h + include/ORBVocabulary.h, linked against
 #                               orb_slam3_modified_amd/liborbx.so: what the GPU test runs (the GPU box has no /root/reference to compile from)
 #   _ref/dropin_frame_world_cpu the same, linked against the oracle-backed C-ABI stub (tests/support/orbx_oracle_stub.cpp): the CPU test
+#   _ref/dropin_frame_world_stereo[_cpu]  the two drop-in builds again with integration/Frame_stereo.patch applied to a TEMPORARY copy of src/Frame.cc
+#                               (made by `patch -o` under $$TMPDIR, compiled, deleted: never stored) and -DORBX_DEVICE_STEREO: ComputeStereoMatches on the
+#                               device pyramids, no host mirror of mvImagePyramid — the opt-in of INTEGRATION.md section 4, held to the same golden
 #   _ref/libref_orbextractor.so src/ORBextractor.cc + include/ORBextractor.h, unmodified, against the container shim; the five
 #                               OpenCV algorithms it calls forward to the oracle's isolated primitives (liborb_oracle.so)
 #   _ref/libref_orbextractor_fma.so  the same, compiled with -O3 -mfma and the compiler's default FP contraction (a -march=native build)
 #   _ref/validate_opencv        tools/validate_opencv.cpp + src/ORBextractor.cc over the shim + liborbx.so + the oracle (the harness of the
 #                               maintainer's OpenCV check)
 REFROOT ?= /root/reference
+comma := ,
 REF ?= $(REFROOT)/Thirdparty/DBoW2
 CXX ?= g++
 CXXFLAGS ?= -O2 -std=c++14 -fPIC -ffp-contract=off -w
@@ -33,7 +37,8 @@ WORLD := ../tests/support/ref_world
 WORLD_HDRS := $(wildcard $(WORLD)/*.h $(WORLD)/*/* $(WORLD)/*/*/*/*) $(wildcard ref_shims/opencv2/*/*.hpp)
 
 all: _ref/libref_dbow2.so _ref/ref_matcher_world _ref/libref_orbextractor.so _ref/libref_orbextractor_fma.so _ref/ref_streamed_frontend _ref/ref_kfdb_world _ref/ref_frame_world \
-     _ref/dropin_frame_world_cpu $(if $(wildcard ../orb_slam3_modified_amd/liborbx.so),_ref/dropin_frame_world _ref/validate_opencv)
+     _ref/dropin_frame_world_cpu _ref/dropin_frame_world_stereo_cpu \
+     $(if $(wildcard ../orb_slam3_modified_amd/liborbx.so),_ref/dropin_frame_world _ref/dropin_frame_world_stereo _ref/validate_opencv)
 
 _ref/libref_dbow2.so: $(SRCS) ref_shims/opencv2/core/core.hpp ref_shims/boost/serialization/serialization.hpp
 	mkdir -p _ref
@@ -106,6 +111,23 @@ _ref/dropin_frame_world: $(REFROOT)/src/Frame.cc $(REFROOT)/include/Frame.h ../t
 	$(CXX) $(FW_FLAGS) -DFRAME_WORLD_DROPIN -I../include -I$(REFROOT) -I$(REFROOT)/include -I$(REFROOT)/include/CameraModels \
 	    $(REFROOT)/src/Frame.cc $(DROPIN_DBOW2) ../tests/support/frame_world.cpp -o $@ \
 	    -L../orb_slam3_modified_amd -lorbx -L. -lorb_oracle -Wl,-rpath,'$$ORIGIN/../../orb_slam3_modified_amd' -Wl,-rpath,'$$ORIGIN/..'
+
+# The opt-in: src/Frame.cc with integration/Frame_stereo.patch.  The patched text exists only as a temporary file next to nothing of ours; the
+# reference's quoted includes ("Frame.h", "G2oTypes.h", ...) resolve through the include path as before.
+STEREO_PATCH := ../integration/Frame_stereo.patch
+define patched_frame_build
+	mkdir -p _ref
+	t=$$(mktemp -d) && patch -s -o $$t/Frame.cc $(REFROOT)/src/Frame.cc $(STEREO_PATCH) && \
+	  { $(CXX) $(FW_FLAGS) -DFRAME_WORLD_DROPIN -DORBX_DEVICE_STEREO -I../include -I$(REFROOT) -I$(REFROOT)/include -I$(REFROOT)/include/CameraModels -I$(REFROOT)/src \
+	    $$t/Frame.cc $(DROPIN_DBOW2) ../tests/support/frame_world.cpp $(1) -o $@ $(2); rc=$$?; rm -rf $$t; exit $$rc; }
+endef
+_ref/dropin_frame_world_stereo_cpu: $(REFROOT)/src/Frame.cc $(REFROOT)/include/Frame.h $(STEREO_PATCH) ../tests/support/frame_world.cpp ../tests/support/orbx_oracle_stub.cpp \
+                                    $(FW_HDRS) $(DROPIN_HDRS) liborb_oracle.so
+	$(call patched_frame_build,../tests/support/orbx_oracle_stub.cpp,-L. -lorb_oracle -Wl$(comma)-rpath$(comma)'$$ORIGIN/..')
+
+_ref/dropin_frame_world_stereo: $(REFROOT)/src/Frame.cc $(REFROOT)/include/Frame.h $(STEREO_PATCH) ../tests/support/frame_world.cpp $(FW_HDRS) $(DROPIN_HDRS) \
+                                ../orb_slam3_modified_amd/liborbx.so liborb_oracle.so
+	$(call patched_frame_build,,-L../orb_slam3_modified_amd -lorbx -L. -lorb_oracle -Wl$(comma)-rpath$(comma)'$$ORIGIN/../../orb_slam3_modified_amd' -Wl$(comma)-rpath$(comma)'$$ORIGIN/..')
 .PHONY: all
 
 # tools/validate_opencv.cpp — the maintainer's OpenCV check (tools/validate_opencv.cmake) — built HERE over the container shim, with the

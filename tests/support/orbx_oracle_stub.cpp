@@ -49,6 +49,9 @@ int mo_kfdb_query(void* h, const uint32_t* q_ids, const double* q_vals, int nq, 
 #include <utility>
 
 struct orbx_ctx { void* ora = nullptr; int nfeatures = 0, nlevels = 0; std::vector<std::vector<uint8_t> > pyr; std::vector<int> pw, ph; };
+extern "C" int mo_stereo_matches(const void* kpsL, const uint8_t* descL, int N, const void* kpsR, const uint8_t* descR, int Nr, const uint8_t* const* pyrL,
+                                 const uint8_t* const* pyrR, const int32_t* w, const int32_t* h, const int32_t* pitch, const float* scale,
+                                 const float* inv_scale, float mb, float mbf, float* mvuRight, float* mvDepth);
 struct orbx_kfdb { void* h = nullptr; std::map<int64_t, std::pair<std::vector<uint32_t>, std::vector<double> > > rows; };
 struct orbx_voc { void* h = nullptr; std::vector<uint8_t> last_desc; int last_levelsup = 0; };
 
@@ -100,11 +103,30 @@ int orbx_extract(orbx_ctx* c, const uint8_t* img, int rows, int cols, size_t str
   if (!img || rows <= 0 || cols <= 0) return ORBX_E_EMPTY;
   if (orbo_extract(c->ora, img, rows, cols, (int)stride, lap0, lap1, kps, desc, orbx_keypoint_capacity(c), n_out, mono_out) != 0) return ORBX_E_INVALID;
   c->pyr.assign(c->nlevels, std::vector<uint8_t>()); c->pw.assign(c->nlevels, 0); c->ph.assign(c->nlevels, 0);
-  for (int l = 1; l < c->nlevels; l++) {
+  for (int l = 0; l < c->nlevels; l++) {   // level 0 is kept for orbx_stereo_matches only (orbx_host_pyramid_level serves levels >= 1)
     if (orbo_level_size(c->ora, l, &c->pw[l], &c->ph[l]) != 0) continue;
     c->pyr[l].resize((size_t)c->pw[l] * c->ph[l]);
     orbo_level_copy(c->ora, l, 0, c->pyr[l].data(), c->pw[l]);
   }
+  return ORBX_OK;
+}
+// Frame::ComputeStereoMatches on the pyramids of the two contexts' last extractions (the patched src/Frame.cc, integration/Frame_stereo.patch)
+int orbx_stereo_matches(orbx_ctx* L, orbx_ctx* R, const orbx_keypoint* kpsL, const uint8_t* descL, int nL, const orbx_keypoint* kpsR, const uint8_t* descR,
+                        int nR, float mb, float mbf, float* u_right, float* depth, int* nmatches) {
+  const int nl = L->nlevels;
+  if (R->nlevels != nl || (int)L->pyr.size() != nl || (int)R->pyr.size() != nl) return ORBX_E_INVALID;
+  std::vector<const uint8_t*> pl(nl), pr(nl);
+  std::vector<int32_t> w(nl), h(nl);
+  std::vector<float> scale(nl), inv_scale(nl), s2(nl), is2(nl);
+  std::vector<int32_t> quota(nl);
+  orbo_tables(L->ora, scale.data(), inv_scale.data(), s2.data(), is2.data(), quota.data(), nullptr);
+  for (int l = 0; l < nl; l++) {
+    if (L->pw[l] != R->pw[l] || L->ph[l] != R->ph[l] || L->pyr[l].empty() || R->pyr[l].empty()) return ORBX_E_INVALID;
+    pl[l] = L->pyr[l].data(); pr[l] = R->pyr[l].data(); w[l] = L->pw[l]; h[l] = L->ph[l];
+  }
+  const int kept = mo_stereo_matches(kpsL, descL, nL, kpsR, descR, nR, pl.data(), pr.data(), w.data(), h.data(), w.data(), scale.data(), inv_scale.data(), mb,
+                                     mbf, u_right, depth);
+  if (nmatches) *nmatches = kept;
   return ORBX_OK;
 }
 int orbx_voc_load_text(orbx_ctx*, const char* path, orbx_voc** out) {

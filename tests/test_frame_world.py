@@ -10,7 +10,11 @@ prints everything the Frame holds as bit patterns.
   CPU      oracle/_ref/dropin_frame_world_cpu: the same Frame.cc over the drop-in headers and the oracle-backed stub of the C-ABI
   GPU      oracle/_ref/dropin_frame_world:     the same Frame.cc over the drop-in headers and liborbx.so — the shipped path
 
-The two drop-in executables contain compiled reference code, so they are built by oracle/ref_fragments.mk (from `__graft_entry__.build()`)
+  opt-in   oracle/_ref/dropin_frame_world_stereo[_cpu]: src/Frame.cc with integration/Frame_stereo.patch (four lines at the top of
+           ComputeStereoMatches, applied to a temporary copy at build time) and -DORBX_DEVICE_STEREO: the association runs on the two extractors'
+           device pyramids and no pyramid is mirrored to the host — held to the SAME golden, every constructor
+
+The drop-in executables contain compiled reference code, so they are built by oracle/ref_fragments.mk (from `__graft_entry__.build()`)
 in the container that has /root/reference and travel to the GPU box as built files; nothing here reads /root/reference at run time."""
 import gzip
 import os
@@ -83,6 +87,41 @@ def test_reference_frame_cc_over_the_dropin_headers_cpu(tmp_path):
     assert out == _golden(), _first_difference(_golden(), out)
 
 
+def test_patched_frame_cc_device_stereo_cpu(tmp_path):
+    """integration/Frame_stereo.patch: the patched file's host logic (argument order, the `mb` it passes, the vectors it sizes) over the stub,
+    whose orbx_stereo_matches is the oracle's restatement of src/Frame.cc:811-981 on the oracle's pyramids."""
+    out = _run(_build("dropin_frame_world_stereo_cpu"), str(tmp_path / "cpu.txt"))
+    assert out == _golden(), _first_difference(_golden(), out)
+
+
+def test_stereo_patch_is_four_lines_and_applies_to_the_reference(tmp_path):
+    patch = os.path.join(ROOT, "integration", "Frame_stereo.patch")
+    body = open(patch).read().split("--- a/src/Frame.cc")[1].splitlines()
+    added = [l for l in body if l.startswith("+") and not l.startswith("+++")]
+    removed = [l for l in body if l.startswith("-") and not l.startswith("---")]
+    assert len(added) == 4 and not removed and added[0].startswith("+#ifdef ORBX_DEVICE_STEREO") and added[-1] == "+#endif"
+    if not HAVE_REF:
+        pytest.skip("needs /root/reference")
+    out = tmp_path / "Frame.cc"
+    subprocess.check_call(["patch", "-s", "-o", str(out), "/root/reference/src/Frame.cc", patch])
+    ref, got = open("/root/reference/src/Frame.cc").read().splitlines(), out.read_text().splitlines()
+    assert len(got) == len(ref) + 4
+    i = next(k for k, l in enumerate(got) if "ORBX_DEVICE_STEREO" in l)
+    assert "void Frame::ComputeStereoMatches()" in got[i - 2] and got[:i] == ref[:i] and got[i + 4:] == ref[i:]
+
+
+@pytest.mark.parametrize("variant", [8, 34])
+def test_patched_frame_cc_other_scenes_cpu(tmp_path, variant):
+    ref, cpu = _build("ref_frame_world"), _build("dropin_frame_world_stereo_cpu")
+    env = dict(os.environ, FRAME_WORLD_VARIANT=str(variant))
+    outs = []
+    for exe, name in ((ref, "ref.txt"), (cpu, "cpu.txt")):
+        out = str(tmp_path / name)
+        subprocess.run([exe, VOC, out], check=True, stdout=subprocess.DEVNULL, timeout=600, env=env)
+        outs.append(open(out).read())
+    assert outs[0] == outs[1], _first_difference(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("variant", [3, 8, 21, 34, 55])
 def test_other_scenes_sizes_and_feature_counts_cpu(tmp_path, variant):
     """FRAME_WORLD_VARIANT: other scenes, image sizes (640x480 ... 1280x720) and feature counts (1000 ... 2000) through the same driver —
@@ -114,6 +153,32 @@ def test_other_scenes_sizes_and_feature_counts_gpu(tmp_path, variant):
     ref, gpu = os.path.join(REFDIR, "ref_frame_world"), os.path.join(REFDIR, "dropin_frame_world")
     if not (os.path.exists(ref) and os.path.exists(gpu)):
         pytest.skip("oracle/_ref/ref_frame_world / dropin_frame_world not built (oracle/ref_fragments.mk compiles them from /root/reference)")
+    env = dict(os.environ, FRAME_WORLD_VARIANT=str(variant))
+    outs = []
+    for exe, name in ((ref, "ref.txt"), (gpu, "gpu.txt")):
+        out = str(tmp_path / name)
+        subprocess.run([exe, VOC, out], check=True, stdout=subprocess.DEVNULL, timeout=600, env=env)
+        outs.append(open(out).read())
+    assert outs[0] == outs[1], _first_difference(outs[0], outs[1])
+
+
+@pytest.mark.gpu
+def test_patched_frame_cc_device_stereo_gpu(tmp_path):
+    """The opt-in as shipped: the reference's src/Frame.cc + integration/Frame_stereo.patch over liborbx.so, both extractors without a host
+    pyramid (-DORBX_DEVICE_STEREO) — every constructor's Frame (stereo, RGB-D, monocular, fisheye pair) byte-identical to the reference's."""
+    exe = os.path.join(REFDIR, "dropin_frame_world_stereo")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/dropin_frame_world_stereo not built (oracle/ref_fragments.mk compiles it from /root/reference/src/Frame.cc + the patch)")
+    out = _run(exe, str(tmp_path / "gpu.txt"))
+    assert out == _golden(), _first_difference(_golden(), out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [5, 13, 89, 144])
+def test_patched_frame_cc_other_scenes_gpu(tmp_path, variant):
+    ref, gpu = os.path.join(REFDIR, "ref_frame_world"), os.path.join(REFDIR, "dropin_frame_world_stereo")
+    if not (os.path.exists(ref) and os.path.exists(gpu)):
+        pytest.skip("oracle/_ref/ref_frame_world / dropin_frame_world_stereo not built")
     env = dict(os.environ, FRAME_WORLD_VARIANT=str(variant))
     outs = []
     for exe, name in ((ref, "ref.txt"), (gpu, "gpu.txt")):
