@@ -537,6 +537,54 @@ def timed_replay(eng, steps, warmup, sync_all):
     return time.perf_counter() - t0, last
 
 
+def fixed_streams_leg(args, ex, dev, rank, world, cdev, sync_all, reduce_max, want_gather, nstreams=8):
+    """SURVEY 8(e)'s curve in the SAME run as the weak line: a FIXED set of `nstreams` camera streams (S-8cam), stream c on GPU c mod G,
+    --batch frames per stream and step — total work per step the same for every G (strong scaling), so the driver's N = 1, 2, 4, 8 runs give the
+    survey's frames/s curve from this record while `value` stays the contract's weak line.  Same engine, lanes, exchange; one batch set (at
+    2048 frames per step the level-0 input is 630 MB: nothing of it survives in the Infinity Cache between steps anyway)."""
+    import torch
+    import torch.distributed as dist
+    from orb_slam3_modified_amd import synth
+    from orb_slam3_modified_amd.replay import ReplayEngine, shard_streams
+    if nstreams % world:
+        return {"skipped": f"{nstreams} streams do not divide over {world} ranks evenly"}
+    cams = shard_streams(nstreams, world, rank)
+    Bs = args.batch * len(cams)
+    host = np.concatenate([synth.make_stream(args.batch, args.rows, args.cols, synth.DEFAULT_SEED + 1000 * c) for c in cams])
+    frames = torch.from_numpy(host).to(dev)
+    exs = ex.clone()
+    err = None
+    try:
+        with stdout_to_stderr():
+            eng = ReplayEngine(exs, frames, lapping=(0, 1000), gather=want_gather, lanes=args.lanes, gather_what=args.gather)
+    except Exception as e:   # noqa: BLE001 — every rank fails together here (replay.py agrees over the control plane before anybody connects)
+        err = f"{type(e).__name__}: {e}"[:300]
+        eng = ReplayEngine(exs, frames, lapping=(0, 1000), gather=False, lanes=args.lanes, gather_what=args.gather, rank=rank, world=world)
+    steps = max(3, min(args.steps, (args.steps * 256 + Bs - 1) // Bs))   # about the weak line's number of frames per repeat
+    repeats = 3
+    dts, last = [], 0
+    for r in range(repeats):
+        d, last = timed_replay(eng, steps, 2 if r == 0 else 0, sync_all)
+        dts.append(d)
+    dts = reduce_max(dts)
+    dt = sorted(dts)[repeats // 2]
+    feats = torch.tensor([int(eng.counts(last)[:, 0].sum())], dtype=torch.int64, device=cdev)
+    if world > 1:
+        dist.all_reduce(feats, op=dist.ReduceOp.SUM)
+    gms = eng.gather_ms() if eng.gather else None
+    out = {"what": f"SURVEY 8(e): the same {nstreams} camera streams for every G, stream c -> GPU c mod G, {args.batch} frames per stream and step",
+           "scaling": "strong", "streams": nstreams, "n_gpus": world, "frames_per_step_total": Bs * world, "frames_per_step_per_gpu": Bs,
+           "steps": steps, "repeats": repeats, "ms_per_step": round(dt / steps * 1e3, 4),
+           "ms_per_step_min_max": [round(min(dts) / steps * 1e3, 4), round(max(dts) / steps * 1e3, 4)],
+           "frames_per_s": round(Bs * world * steps / dt, 1), "value": round(int(feats.item()) * steps / (dt * 1e3), 1), "unit": "features/ms",
+           "exchange": ({"transport": eng.transport, "bytes_per_rank_per_step": int(eng.send_bytes), "gather_ms": (round(gms, 4) if gms else None)}
+                        if eng.gather else ({"error": err} if err else "none"))}
+    eng.close()
+    del eng, frames
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -554,6 +602,8 @@ def main():
     ap.add_argument("--streams", type=int, default=0,
                     help="SURVEY 8(e)'s curve: a FIXED set of S camera streams (S-8cam: --streams 8) sharded stream c -> GPU c mod G, "
                          "--batch frames per stream and step (strong scaling).  0 (default): one stream per GPU (weak scaling)")
+    ap.add_argument("--no-fixed-streams", action="store_true", help="skip the `strong` record (the fixed-8-stream curve of SURVEY 8(e)) that the default weak "
+                                                                     "line carries beside it")
     ap.add_argument("--no-frontend", action="store_true", help="skip the streamed front-end leg (operator() + BoW + two guided searches per frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config-4 (1024x1024, 2000 features) leg and the operator() leg")
@@ -712,6 +762,10 @@ def main():
     if world > 1:
         dist.all_reduce(vt, op=dist.ReduceOp.SUM)
 
+    strong = None
+    if args.streams == 0 and not args.no_fixed_streams:   # every rank takes part
+        strong = fixed_streams_leg(args, ex, dev, rank, world, cdev, sync_all, reduce_max, want_gather and exchange_error is None)
+
     if rank == 0:
         dom, nkp, fused, roof = kernel_roofline(ex, eng, frame_sets[0], B, H, W, counts, world, args.steps, dt)
         # HBM traffic and issue-side counters of the dominant kernel come from committed rocprofv3 --pmc passes (tools/pmc_traffic.py,
@@ -785,7 +839,7 @@ def main():
                        "lanes_per_gpu": len(eng.lane_ranges), "requested_gpus": requested,
                        "streams": (args.streams if args.streams > 0 else world), "frames_per_stream_per_step": args.batch,
                        "scaling_mode": (f"strong: the same {args.streams} camera streams for every G, stream c -> GPU c mod G (SURVEY 8(e))" if args.streams > 0
-                                        else "weak: one camera stream per GPU, per-GPU work fixed (--streams 8 selects SURVEY 8(e)'s fixed-8-stream curve)"),
+                                        else "weak: one camera stream per GPU, per-GPU work fixed; SURVEY 8(e)'s fixed-8-stream curve is the `strong` record of this line"),
                        "parallelism": (f"{args.streams} camera streams over {world} GPUs" if args.streams > 0 else f"one camera stream per GPU x{world}")},
             "roofline": roof,
         }
@@ -795,6 +849,8 @@ def main():
         if exchange is not None:
             exchange["ranks"] = world
             result["exchange"] = exchange
+        if strong is not None:
+            result["strong"] = strong
         if world == 1 and not args.no_frontend:
             try:
                 fex = ORBextractor(args.nfeatures, 1.2, 8, 20, 7, device_id=local_rank)

@@ -28,6 +28,7 @@ extern "C" {
 #define ORBX_E_DEVICE (-3)    /* no usable GPU / HIP runtime error (see orbx_last_error) */
 #define ORBX_E_CAPACITY (-4)  /* an internal or caller buffer is too small */
 #define ORBX_E_FORMAT (-5)    /* vocabulary file malformed */
+#define ORBX_E_TIMEOUT (-6)   /* a bounded wait ran out (orbx_replay_wait_gathered_host) */
 
 typedef struct orbx_ctx orbx_ctx;
 typedef struct orbx_voc orbx_voc;
@@ -135,6 +136,7 @@ int orbx_reserve(orbx_ctx* ctx, int rows, int cols, int nframes);
  *                   1 = fma(x, b, y*a), fma(x, a, -(y*b)) — what -march=native makes of it on an FMA machine
  * Unknown names and out-of-range values return ORBX_E_INVALID. */
 int orbx_set_option(orbx_ctx* ctx, const char* name, int value);
+int orbx_get_option(const orbx_ctx* ctx, const char* name);   /* the current value (all options are >= 0); ORBX_E_INVALID for an unknown name */
 int orbx_host_pyramid_level(orbx_ctx* ctx, int level, const uint8_t** data, size_t* stride, int* w, int* h);
 
 /* The five result-changing options by NAME: which build of "the reference CPU path" (src/ORBextractor.cc over some OpenCV, compiled with
@@ -548,6 +550,16 @@ int orbx_replay_unique_id(uint8_t id[ORBX_REPLAY_UNIQUE_ID_BYTES]);   /* ncclGet
 const char* orbx_replay_rccl_info(void);                               /* "rccl 2.x.y (library)" or why none could be loaded */
 int orbx_replay_create(orbx_replay** out, orbx_ctx* const* lanes, int nlanes, int frames, int rows, int cols, int gather_what, int rank, int world,
                        const uint8_t* unique_id, orbx_host_exchange_fn host_exchange, void* user);
+/* orbx_replay_create in two halves, FOR HOSTS WITH MORE THAN ONE RANK: prepare = everything a rank can fail at on its own (argument and
+ * lane checks, buffers, streams, resolving the RCCL library; use_rccl != 0: the transport will be RCCL) and touches no other rank;
+ * connect = ncclCommInitRank, in which a rank waits for ALL its peers.  A rank that failed locally never arrives, so the host must agree over
+ * its own control plane (an all-reduce of "prepare succeeded") that every rank is ready BEFORE any rank calls connect — bench.py and
+ * replay.py do.  orbx_replay_create = prepare + connect for one-rank hosts and hosts that accept that risk.  The lanes must agree in everything
+ * that decides a result byte (nfeatures, levels, scale factor, thresholds, the five CPU-path options): a mismatch is ORBX_E_INVALID with the
+ * reason in orbx_last_error(lanes[0]).  The engine sets the lanes' stream-fork options for its launch shape and puts them back in destroy. */
+int orbx_replay_prepare(orbx_replay** out, orbx_ctx* const* lanes, int nlanes, int frames, int rows, int cols, int gather_what, int rank, int world,
+                        int use_rccl, orbx_host_exchange_fn host_exchange, void* user);
+int orbx_replay_connect(orbx_replay* r, const uint8_t* unique_id);     /* unique_id NULL: world must be 1 (the self-gather) */
 void orbx_replay_destroy(orbx_replay* r);                              /* waits for everything in flight; the lanes stay the caller's */
 const char* orbx_replay_last_error(const orbx_replay* r);
 const char* orbx_replay_transport(const orbx_replay* r);
@@ -563,6 +575,23 @@ int orbx_replay_drain(orbx_replay* r);                                 /* wait f
 int orbx_replay_set_gather(orbx_replay* r, int on);                    /* switch the exchange off / on between steps (measurements) */
 int orbx_replay_block(orbx_replay* r, int i, uint8_t** d_block);       /* this rank's block i (device pointer; layout above) */
 int orbx_replay_gathered(orbx_replay* r, int i, int rank, const uint8_t** d_part);   /* rank's send_bytes inside gathered buffer i (device pointer) */
+/* Ordering a consumer of gathered buffer i against ONE step's exchange without draining the engine (the pointer above carries no ordering:
+ * the collective runs on the engine's private gather stream).  wait: `consumer` (a hipStream_t, passed as void* so that this header needs no
+ * HIP) waits ON THE DEVICE for the last collective queued into buffer i; everything launched on it afterwards sees the gathered data.
+ * release: records "the consumer has finished with buffer i" at the current tail of `consumer`; the next collective INTO buffer i (two steps
+ * later) waits for it.  A consumer that does neither must call orbx_replay_drain.  wait_host: the same wait on the host, bounded:
+ * ORBX_E_TIMEOUT after timeout_ms (< 0: unbounded) — the sign of a peer that left; see orbx_replay_abort. */
+int orbx_replay_wait_gathered(orbx_replay* r, int i, void* consumer_stream);
+int orbx_replay_release_gathered(orbx_replay* r, int i, void* consumer_stream);
+int orbx_replay_wait_gathered_host(orbx_replay* r, int i, int timeout_ms);
+/* Failure containment.  A lane error inside orbx_replay_step does NOT keep the rank out of that step's exchange (the other ranks would wait in
+ * theirs for ever): the rank takes part, in this and in every later step, with a POISONED block — every {n, monoIndex} of the block is
+ * {-1, -1}, which no extraction produces — and orbx_replay_step returns the first error from then on (orbx_replay_failed: 0 or that code).
+ * The host tells its peers by its own means and leaves with orbx_replay_destroy (all ranks together) or orbx_replay_abort (ncclCommAbort: no
+ * hand-shake with ranks that may be gone; the engine keeps working with the exchange off). */
+int orbx_replay_failed(const orbx_replay* r);
+int orbx_replay_abort(orbx_replay* r);
+int orbx_replay_debug_fail_at(orbx_replay* r, long long step);   /* testing: the lanes of that step fail (-1: never) */
 /* host copies (drain first): what = 0: block i, 1: gathered buffer i (world * send_bytes); orbx_replay_write_block is the reverse, for block i */
 int orbx_replay_read(orbx_replay* r, int what, int i, void* host_dst, size_t offset, size_t nbytes);
 int orbx_replay_write_block(orbx_replay* r, int i, const void* host_src, size_t offset, size_t nbytes);

@@ -93,6 +93,7 @@ def lib() -> C.CDLL:
         "orbx_voc_load_text": (i32, [vp, C.c_char_p, C.POINTER(vp)]),
         "orbx_voc_create": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, C.POINTER(vp)]),
         "orbx_set_option": (i32, [vp, C.c_char_p, i32]),
+        "orbx_get_option": (i32, [vp, C.c_char_p]),
         "orbx_reserve": (i32, [vp, i32, i32, i32]),
         "orbx_voc_save_text": (i32, [vp, C.c_char_p]),
         "orbx_voc_save_binary": (i32, [vp, C.c_char_p]),
@@ -129,6 +130,14 @@ def lib() -> C.CDLL:
         "orbx_replay_unique_id": (i32, [vp]),
         "orbx_replay_rccl_info": (C.c_char_p, []),
         "orbx_replay_create": (i32, [C.POINTER(vp), vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
+        "orbx_replay_prepare": (i32, [C.POINTER(vp), vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
+        "orbx_replay_connect": (i32, [vp, vp]),
+        "orbx_replay_wait_gathered": (i32, [vp, i32, vp]),
+        "orbx_replay_release_gathered": (i32, [vp, i32, vp]),
+        "orbx_replay_wait_gathered_host": (i32, [vp, i32, i32]),
+        "orbx_replay_failed": (i32, [vp]),
+        "orbx_replay_abort": (i32, [vp]),
+        "orbx_replay_debug_fail_at": (i32, [vp, C.c_longlong]),
         "orbx_replay_destroy": (None, [vp]),
         "orbx_replay_last_error": (C.c_char_p, [vp]),
         "orbx_replay_transport": (C.c_char_p, [vp]),

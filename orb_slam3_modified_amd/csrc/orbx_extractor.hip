@@ -1492,6 +1492,23 @@ int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
   return ORBX_OK;
 }
 
+// the current value of an option (all are >= 0), ORBX_E_INVALID for an unknown name
+int orbx_get_option(const orbx_ctx* ctx, const char* name) {
+  if (!ctx || !name) return ORBX_E_INVALID;
+  const std::string n(name);
+  const struct { const char* name; int value; } tab[] = {
+      {"fork_blur", ctx->fork_blur}, {"fork_fast0", ctx->fork_fast0}, {"fork_qt", ctx->fork_qt}, {"graph", ctx->use_graph}, {"graph_timing", ctx->graph_timing},
+      {"fast_pk", ctx->fast_pk}, {"realign", ctx->realign}, {"fast_stage_dma", ctx->fast_stage_dma},
+      {"gauss_kernel", ctx->gauss_kernel}, {"gauss_round", ctx->gauss_round}, {"gauss_tail", ctx->gauss_tail}, {"atan_fma", ctx->atan_fma}, {"brief_fma", ctx->brief_fma},
+      {"qt_points", ctx->qt_points}, {"small_fused", ctx->small_fused}, {"qt_level_major", ctx->qt_level_major}, {"qt_fused", ctx->qt_fused},
+      {"chain_batch", ctx->chain_batch}, {"chain_long", ctx->chain_long}, {"describe_direct", ctx->describe_direct}, {"chain_long_tile", ctx->chain_long_tile},
+      {"chain_first", ctx->chain_first}, {"chain_threads", ctx->chain_threads}, {"qt_big_levels", ctx->qt_big_levels}, {"qt_threads_small", ctx->qt_threads_small},
+      {"qt_one_launch", ctx->qt_one_launch}, {"window_direct", ctx->window_direct}, {"fast_split", ctx->fast_split}, {"desc_lds", ctx->desc_lds},
+      {"fast_threads", ctx->fast_threads}, {"qt_threads", ctx->qt_threads}, {"desc_k", ctx->desc_k}, {"streams", ctx->nstreams}, {"view_pool_cap", ctx->view_pool_cap}};
+  for (const auto& t : tab) if (n == t.name) return t.value;
+  return ORBX_E_INVALID;
+}
+
 // ---- named sets of the five result-changing options: WHICH build of "the reference CPU path" the output equals ----
 namespace {
 struct CpuProfile { const char* name; const char* alias; int gauss_kernel, gauss_round, gauss_tail; bool has_avx2_atan; const char* what; };

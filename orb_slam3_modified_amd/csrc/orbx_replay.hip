@@ -13,9 +13,11 @@
 // gather "descriptors" moves the tail (descriptor rows + counts: north_star's exchange), "blocks" the whole block (SURVEY §8(e)'s).
 #include <dlfcn.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -33,6 +35,7 @@ struct Rccl {
   int (*GetUniqueId)(RcclUniqueId*) = nullptr;
   int (*CommInitRank)(RcclComm*, int, RcclUniqueId, int) = nullptr;
   int (*CommDestroy)(RcclComm) = nullptr;
+  int (*CommAbort)(RcclComm) = nullptr;
   int (*AllGather)(const void*, void*, size_t, int, RcclComm, hipStream_t) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
   int (*GetVersion)(int*) = nullptr;
@@ -62,6 +65,7 @@ const Rccl* rccl() {
     r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(h, "ncclGetUniqueId");
     r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+    r.CommAbort = (decltype(r.CommAbort))dlsym(h, "ncclCommAbort");
     r.AllGather = (decltype(r.AllGather))dlsym(h, "ncclAllGather");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
     r.GetVersion = (decltype(r.GetVersion))dlsym(h, "ncclGetVersion");
@@ -99,6 +103,18 @@ struct orbx_replay {
   std::vector<hipEvent_t> lane_done[2];
   hipEvent_t gather_done[2] = {nullptr, nullptr};
   bool pending[2] = {false, false};   // a collective that read blocks[i] has been queued and no lane has waited for it yet
+  bool gathered_valid[2] = {false, false};     // gather_done[i] has been recorded at least once: gathered buffer i holds (or will hold) a step
+  // a consumer of gathered buffer i on a stream of its own (orbx_replay_wait_gathered / _release_gathered): the next collective INTO buffer i
+  // waits for the event the consumer's release recorded
+  hipEvent_t consumer_done[2] = {nullptr, nullptr};
+  bool consumer_pending[2] = {false, false};
+  // what create changed in the caller's lane contexts (restored on destroy): fork_blur, fork_fast0, fork_qt
+  std::vector<int> saved_forks;
+  bool connected = false;                      // transport up (ncclCommInitRank done, or host transport / none)
+  // failure containment: once a lane failed, this rank keeps taking part in every step's exchange with a POISONED block (all counts -1), so that
+  // the other ranks' collectives complete; every later step returns the first error again
+  int failed_code = 0; std::string failed_msg;
+  long long inject_fail_step = -1;             // testing: the lanes of that step "fail" (orbx_replay_debug_fail_at)
   // transport
   RcclComm comm = nullptr;
   orbx_host_exchange_fn host_fn = nullptr; void* host_user = nullptr;
@@ -135,7 +151,13 @@ void release(orbx_replay* r) {
   for (hipStream_t s : r->streams) if (s) (void)hipStreamSynchronize(s);
   if (r->gstream) (void)hipStreamSynchronize(r->gstream);
   if (r->comm) { const Rccl* R = rccl(); if (R) (void)R->CommDestroy(r->comm); r->comm = nullptr; }
+  for (size_t j = 0; j * 3 + 2 < r->saved_forks.size() && j < r->lanes.size(); j++) {   // the lanes are the caller's: give them back as they came
+    (void)orbx_set_option(r->lanes[j], "fork_blur", r->saved_forks[j * 3]);
+    (void)orbx_set_option(r->lanes[j], "fork_fast0", r->saved_forks[j * 3 + 1]);
+    (void)orbx_set_option(r->lanes[j], "fork_qt", r->saved_forks[j * 3 + 2]);
+  }
   for (int i = 0; i < 2; i++) {
+    if (r->consumer_done[i]) (void)hipEventDestroy(r->consumer_done[i]);
     if (r->blocks[i]) (void)hipFree(r->blocks[i]);
     if (r->gathered[i]) (void)hipFree(r->gathered[i]);
     for (hipEvent_t e : r->lane_done[i]) if (e) (void)hipEventDestroy(e);
@@ -168,17 +190,35 @@ const char* orbx_replay_rccl_info(void) {
   return R ? R->where.c_str() : g_rccl_err.c_str();
 }
 
-int orbx_replay_create(orbx_replay** out, orbx_ctx* const* lanes, int nlanes, int frames, int rows, int cols, int gather_what, int rank, int world,
-                       const uint8_t* unique_id, orbx_host_exchange_fn host_exchange, void* user) {
+// Everything a rank can fail at ON ITS OWN (arguments, lane parameters, buffers, streams, the RCCL library itself) happens here and touches no
+// other rank: a multi-rank host all-reduces "did prepare succeed" over its control plane BEFORE any rank enters ncclCommInitRank
+// (orbx_replay_connect), in which a rank whose peers never arrive would wait forever.
+int orbx_replay_prepare(orbx_replay** out, orbx_ctx* const* lanes, int nlanes, int frames, int rows, int cols, int gather_what, int rank, int world,
+                        int use_rccl, orbx_host_exchange_fn host_exchange, void* user) {
   if (!out) return ORBX_E_INVALID;
   *out = nullptr;
   if (!lanes || nlanes < 1 || nlanes > 16 || frames < nlanes || frames > 65535 || rows <= 0 || cols <= 0 || world < 1 || rank < 0 || rank >= world ||
-      gather_what < ORBX_GATHER_NONE || gather_what > ORBX_GATHER_BLOCKS || (unique_id && host_exchange))
+      gather_what < ORBX_GATHER_NONE || gather_what > ORBX_GATHER_BLOCKS || (use_rccl && host_exchange))
     return ORBX_E_INVALID;
-  for (int j = 0; j < nlanes; j++)
-    if (!lanes[j] || lanes[j]->device != lanes[0]->device || lanes[j]->out_cap != lanes[0]->out_cap || lanes[j]->nlevels != lanes[0]->nlevels) return ORBX_E_INVALID;
+  for (int j = 0; j < nlanes; j++) if (!lanes[j]) return ORBX_E_INVALID;
   for (int j = 0; j < nlanes; j++) for (int k = 0; k < j; k++) if (lanes[j] == lanes[k]) return ORBX_E_INVALID;
-  if (gather_what != ORBX_GATHER_NONE && world > 1 && !unique_id && !host_exchange) return ORBX_E_INVALID;   // more than one rank needs a way to reach the others
+  // "identical parameters": everything that decides a result byte — frame ranges of ONE block must not follow different builds of the reference
+  for (int j = 1; j < nlanes; j++) {
+    const orbx_ctx *a = lanes[0], *b = lanes[j];
+    const char* what = nullptr;
+    if (b->device != a->device) what = "device";
+    else if (b->nfeatures != a->nfeatures || b->out_cap != a->out_cap) what = "nfeatures";
+    else if (b->nlevels != a->nlevels || b->scale_factor != a->scale_factor) what = "pyramid (levels, scale factor)";
+    else if (b->ini_th != a->ini_th || b->min_th != a->min_th) what = "FAST thresholds";
+    else if (b->gauss_kernel != a->gauss_kernel || b->gauss_round != a->gauss_round || b->gauss_tail != a->gauss_tail || b->atan_fma != a->atan_fma ||
+             b->brief_fma != a->brief_fma) what = "CPU-path profile (gauss_kernel / gauss_round / gauss_tail / atan_fma / brief_fma)";
+    if (what) {
+      orbx::set_err(lanes[0], ORBX_E_INVALID, std::string("orbx_replay_prepare: lane ") + std::to_string(j) + " differs from lane 0 in its " + what +
+                                                  ": the lanes of one engine must compute the same reference build");
+      return ORBX_E_INVALID;
+    }
+  }
+  if (gather_what != ORBX_GATHER_NONE && world > 1 && !use_rccl && !host_exchange) return ORBX_E_INVALID;   // more than one rank needs a way to reach the others
   orbx_replay* r = new orbx_replay;
   r->lanes.assign(lanes, lanes + nlanes);
   r->device = lanes[0]->device; r->B = frames; r->rows = rows; r->cols = cols; r->cap = lanes[0]->out_cap;
@@ -191,10 +231,11 @@ int orbx_replay_create(orbx_replay** out, orbx_ctx* const* lanes, int nlanes, in
   for (int j = 0; j < nlanes; j++) if (j * per < frames) r->ranges.push_back({j * per, std::min(frames, (j + 1) * per)});
   r->lanes.resize(r->ranges.size());
   auto bail = [&](int code, const std::string& msg) { if (r->lanes[0]) orbx::set_err(r->lanes[0], code, msg); release(r); return code; };
-  if (hipSetDevice(r->device) != hipSuccess) return bail(ORBX_E_DEVICE, "orbx_replay_create: hipSetDevice failed");
+  if (hipSetDevice(r->device) != hipSuccess) return bail(ORBX_E_DEVICE, "orbx_replay_prepare: hipSetDevice failed");
   // With a second lane filling the idle issue slots the in-lane forks that pay differ from a lone context's.  Measured on all eight
   // combinations (2 lanes x 128 frames, round 2): blur forked behind FAST + level-0 FAST beside the pyramid chain + the quadtree as one
-  // launch.  The ORBX_* environment variables still win.
+  // launch.  The ORBX_* environment variables still win.  The contexts are the caller's: destroy puts the three options back.
+  for (orbx_ctx* c : r->lanes) { r->saved_forks.push_back(c->fork_blur); r->saved_forks.push_back(c->fork_fast0); r->saved_forks.push_back(c->fork_qt); }
   if (r->lanes.size() > 1)
     for (orbx_ctx* c : r->lanes) {
       if (!getenv("ORBX_FORK_BLUR")) (void)orbx_set_option(c, "fork_blur", 1);
@@ -203,7 +244,7 @@ int orbx_replay_create(orbx_replay** out, orbx_ctx* const* lanes, int nlanes, in
     }
   for (size_t j = 0; j < r->lanes.size(); j++) {   // every lane's buffers now, not inside the first (possibly timed) step
     const int rc = orbx_reserve(r->lanes[j], rows, cols, r->ranges[j].second - r->ranges[j].first);
-    if (rc != ORBX_OK) return bail(rc, std::string("orbx_replay_create: orbx_reserve: ") + orbx_last_error(r->lanes[j]));
+    if (rc != ORBX_OK) return bail(rc, std::string("orbx_replay_prepare: orbx_reserve: ") + orbx_last_error(r->lanes[j]));
   }
   // Explicit non-blocking streams carry the lanes; the collective ALWAYS runs on its own stream behind every lane of the step: on a lane's
   // stream step k + 1's kernels would queue behind step k's collective and the overlap would be gone.
@@ -221,31 +262,62 @@ int orbx_replay_create(orbx_replay** out, orbx_ctx* const* lanes, int nlanes, in
       if (e == hipSuccess) e = hipMemsetAsync(r->gathered[i], 0, r->send_bytes * (size_t)world, r->gstream);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&r->gather_done[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&r->consumer_done[i], hipEventDisableTiming);
     r->lane_done[i].assign(r->lanes.size(), nullptr);
     for (size_t j = 0; j < r->lanes.size() && e == hipSuccess; j++) e = hipEventCreateWithFlags(&r->lane_done[i][j], hipEventDisableTiming);
   }
   if (e == hipSuccess) e = hipStreamSynchronize(r->gstream);
   for (int k = 0; k < kTimingPairs && e == hipSuccess && r->gather_on; k++) { e = hipEventCreate(&r->t0[k]); if (e == hipSuccess) e = hipEventCreate(&r->t1[k]); }
-  if (e != hipSuccess) return bail(ORBX_E_DEVICE, std::string("orbx_replay_create: ") + hipGetErrorString(e));
+  if (e != hipSuccess) return bail(ORBX_E_DEVICE, std::string("orbx_replay_prepare: ") + hipGetErrorString(e));
   if (r->gather_on) {
     if (host_exchange) {
       r->host_fn = host_exchange; r->host_user = user;
       e = hipHostMalloc((void**)&r->h_send, r->send_bytes, hipHostMallocDefault);
       if (e == hipSuccess) e = hipHostMalloc((void**)&r->h_recv, r->send_bytes * (size_t)world, hipHostMallocDefault);
-      if (e != hipSuccess) return bail(ORBX_E_DEVICE, std::string("orbx_replay_create: pinned staging: ") + hipGetErrorString(e));
+      if (e != hipSuccess) return bail(ORBX_E_DEVICE, std::string("orbx_replay_prepare: pinned staging: ") + hipGetErrorString(e));
       r->transport = "host all-gather supplied by the caller (block staged through pinned memory, synchronous)";
-    } else {
-      const Rccl* R = rccl();
-      if (!R) return bail(ORBX_E_DEVICE, "orbx_replay_create: " + g_rccl_err);
-      RcclUniqueId u;
-      if (unique_id) std::memcpy(u.internal, unique_id, sizeof u.internal);
-      else if (R->GetUniqueId(&u) != 0) return bail(ORBX_E_DEVICE, "orbx_replay_create: ncclGetUniqueId failed");   // a one-rank group: the self-gather
-      const int rc = R->CommInitRank(&r->comm, world, u, rank);
-      if (rc != 0) { r->comm = nullptr; return bail(ORBX_E_DEVICE, std::string("orbx_replay_create: ncclCommInitRank: ") + (R->GetErrorString ? R->GetErrorString(rc) : "error")); }
-      r->transport = "ncclAllGather, " + R->where;
+      r->connected = true;
+    } else if (!rccl()) return bail(ORBX_E_DEVICE, "orbx_replay_prepare: " + g_rccl_err);   // the library is resolved HERE, not inside connect
+  } else r->connected = true;
+  *out = r;
+  return ORBX_OK;
+}
+
+// The one step that meets the other ranks: ncclCommInitRank.  unique_id NULL: world must be 1 (a one-rank group: the self-gather).
+// On failure the engine stays usable for the sharded extraction after orbx_replay_set_gather(r, 0).
+int orbx_replay_connect(orbx_replay* r, const uint8_t* unique_id) {
+  if (!r) return ORBX_E_INVALID;
+  if (r->connected) return ORBX_OK;
+  if (!unique_id && r->world > 1) return rfail(r, ORBX_E_INVALID, "orbx_replay_connect: more than one rank needs the ncclUniqueId of orbx_replay_unique_id()");
+  const Rccl* R = rccl();
+  if (!R) return rfail(r, ORBX_E_DEVICE, "orbx_replay_connect: " + g_rccl_err);
+  RHIP(r, hipSetDevice(r->device));
+  RcclUniqueId u;
+  if (unique_id) std::memcpy(u.internal, unique_id, sizeof u.internal);
+  else if (R->GetUniqueId(&u) != 0) return rfail(r, ORBX_E_DEVICE, "orbx_replay_connect: ncclGetUniqueId failed");
+  const int rc = R->CommInitRank(&r->comm, r->world, u, r->rank);
+  if (rc != 0) { r->comm = nullptr; return rfail(r, ORBX_E_DEVICE, std::string("orbx_replay_connect: ncclCommInitRank: ") + (R->GetErrorString ? R->GetErrorString(rc) : "error")); }
+  r->transport = "ncclAllGather, " + R->where;
+  r->connected = true;
+  return ORBX_OK;
+}
+
+int orbx_replay_create(orbx_replay** out, orbx_ctx* const* lanes, int nlanes, int frames, int rows, int cols, int gather_what, int rank, int world,
+                       const uint8_t* unique_id, orbx_host_exchange_fn host_exchange, void* user) {
+  if (unique_id && host_exchange) return ORBX_E_INVALID;
+  if (gather_what != ORBX_GATHER_NONE && world > 1 && !unique_id && !host_exchange) return ORBX_E_INVALID;
+  const int use_rccl = gather_what != ORBX_GATHER_NONE && !host_exchange;
+  int rc = orbx_replay_prepare(out, lanes, nlanes, frames, rows, cols, gather_what, rank, world, use_rccl, host_exchange, user);
+  if (rc != ORBX_OK) return rc;
+  if (!(*out)->connected) {
+    rc = orbx_replay_connect(*out, unique_id);
+    if (rc != ORBX_OK) {
+      orbx::set_err((*out)->lanes[0], rc, "orbx_replay_create: " + (*out)->err);
+      release(*out);
+      *out = nullptr;
+      return rc;
     }
   }
-  *out = r;
   return ORBX_OK;
 }
 
@@ -284,44 +356,145 @@ int orbx_replay_set_gather(orbx_replay* r, int on) {
 
 int orbx_replay_step(orbx_replay* r, const uint8_t* d_frames, size_t row_stride, size_t frame_stride, int lap0, int lap1) {
   if (!r || !d_frames) return r ? rfail(r, ORBX_E_INVALID, "orbx_replay_step: bad arguments") : ORBX_E_INVALID;
+  if (r->gather_on && !r->connected) return rfail(r, ORBX_E_INVALID, "orbx_replay_step: the exchange is on but orbx_replay_connect has not succeeded");
   RHIP(r, hipSetDevice(r->device));
   const int i = (int)(r->step_idx & 1);
   uint8_t* const base = r->blocks[i];
-  for (size_t j = 0; j < r->lanes.size(); j++) {
+  // A lane that fails must not keep this rank out of the step's collective: the other ranks are (or will be) inside theirs and would wait for
+  // ever.  The rank goes on taking part — this step and every later one — with a POISONED block: every count of the block is {-1, -1}, which
+  // no extraction produces, so a reader of the gathered buffer sees which rank dropped out at which step; the caller of THIS rank gets the
+  // lane's error from this call and from every later one (orbx_replay_failed), and decides when to leave (orbx_replay_destroy after the
+  // others have been told over the host's own control plane, or orbx_replay_abort).
+  const bool inject = r->inject_fail_step >= 0 && (long long)r->step_idx == r->inject_fail_step;
+  for (size_t j = 0; j < r->lanes.size() && !r->failed_code; j++) {
     const int f0 = r->ranges[j].first, f1 = r->ranges[j].second;
     // the collective that last read this block must be done before a lane overwrites it (a device-side wait: no host stall)
     if (r->pending[i]) RHIP(r, hipStreamWaitEvent(r->streams[j], r->gather_done[i], 0));
-    const int rc = orbx_extract_batch_device(r->lanes[j], d_frames + (size_t)f0 * frame_stride, f1 - f0, r->rows, r->cols, row_stride, frame_stride, lap0, lap1,
-                                             (orbx_keypoint*)(base + (size_t)f0 * r->cap * sizeof(orbx_keypoint)), base + r->desc_off + (size_t)f0 * r->cap * 32,
-                                             (int32_t*)(base + r->counts_off + (size_t)f0 * 8), r->streams[j]);
-    if (rc != ORBX_OK) return rfail(r, rc, std::string("orbx_replay_step: lane ") + std::to_string(j) + ": " + orbx_last_error(r->lanes[j]));
-    if (r->gather_on) RHIP(r, hipEventRecord(r->lane_done[i][j], r->streams[j]));
+    const int rc = inject ? ORBX_E_DEVICE
+                          : orbx_extract_batch_device(r->lanes[j], d_frames + (size_t)f0 * frame_stride, f1 - f0, r->rows, r->cols, row_stride, frame_stride, lap0, lap1,
+                                                      (orbx_keypoint*)(base + (size_t)f0 * r->cap * sizeof(orbx_keypoint)), base + r->desc_off + (size_t)f0 * r->cap * 32,
+                                                      (int32_t*)(base + r->counts_off + (size_t)f0 * 8), r->streams[j]);
+    if (rc != ORBX_OK) {
+      r->failed_code = rc;
+      r->failed_msg = std::string("orbx_replay_step: step ") + std::to_string(r->step_idx) + ", lane " + std::to_string(j) + ": " +
+                      (inject ? "failure injected by orbx_replay_debug_fail_at" : orbx_last_error(r->lanes[j]));
+    }
   }
+  if (r->failed_code) {
+    r->err = r->failed_msg;
+    if (!r->gather_on) { r->step_idx++; return r->failed_code; }
+    // the poison, behind whatever the lanes of this step already queued and behind the collective that last read the block
+    if (r->pending[i]) (void)hipStreamWaitEvent(r->streams[0], r->gather_done[i], 0);
+    for (size_t j = 1; j < r->lanes.size(); j++)
+      if (hipEventRecord(r->lane_done[i][j], r->streams[j]) == hipSuccess) (void)hipStreamWaitEvent(r->streams[0], r->lane_done[i][j], 0);
+    (void)hipMemsetAsync(base + r->counts_off, 0xff, r->counts_bytes, r->streams[0]);
+  }
+  if (r->gather_on)
+    for (size_t j = 0; j < r->lanes.size(); j++)
+      if (hipEventRecord(r->lane_done[i][j], r->streams[j]) != hipSuccess && !r->failed_code) return rfail(r, ORBX_E_DEVICE, "orbx_replay_step: hipEventRecord failed");
   r->pending[i] = false;
+  int xrc = ORBX_OK;   // the exchange's own failure (reported when the lanes were fine)
   if (r->gather_on) {   // queued behind this step's kernels, overlaps the next step's
-    for (hipEvent_t ev : r->lane_done[i]) RHIP(r, hipStreamWaitEvent(r->gstream, ev, 0));
+    for (hipEvent_t ev : r->lane_done[i]) (void)hipStreamWaitEvent(r->gstream, ev, 0);
+    // a consumer that announced it is still reading gathered buffer i (orbx_replay_release_gathered) is waited for on the device
+    if (r->consumer_pending[i]) { (void)hipStreamWaitEvent(r->gstream, r->consumer_done[i], 0); r->consumer_pending[i] = false; }
     const uint8_t* send = base + r->send_off;
     if (r->comm) {
       const int k = (int)(r->step_idx % kTimingPairs);
       harvest(r, k);
-      RHIP(r, hipEventRecord(r->t0[k], r->gstream));
+      (void)hipEventRecord(r->t0[k], r->gstream);
       const Rccl* R = rccl();
       const int rc = R->AllGather(send, r->gathered[i], r->send_bytes, /* ncclUint8 */ 1, r->comm, r->gstream);
-      if (rc != 0) return rfail(r, ORBX_E_DEVICE, std::string("ncclAllGather: ") + (R->GetErrorString ? R->GetErrorString(rc) : "error"));
-      RHIP(r, hipEventRecord(r->t1[k], r->gstream));
-      r->t_live[k] = true;
+      if (rc != 0) xrc = rfail(r, ORBX_E_DEVICE, std::string("ncclAllGather: ") + (R->GetErrorString ? R->GetErrorString(rc) : "error"));
+      (void)hipEventRecord(r->t1[k], r->gstream);
+      r->t_live[k] = xrc == ORBX_OK;
     } else {
-      RHIP(r, hipMemcpyAsync(r->h_send, send, r->send_bytes, hipMemcpyDeviceToHost, r->gstream));
-      RHIP(r, hipStreamSynchronize(r->gstream));
+      hipError_t e = hipMemcpyAsync(r->h_send, send, r->send_bytes, hipMemcpyDeviceToHost, r->gstream);
+      if (e == hipSuccess) e = hipStreamSynchronize(r->gstream);
+      if (e != hipSuccess) {   // even then the other ranks are waiting in their host all-gather: send them the poison from the host side
+        (void)hipGetLastError();
+        std::memset(r->h_send, 0, r->send_bytes);
+        std::memset(r->h_send + (r->counts_off - r->send_off), 0xff, r->counts_bytes);
+        if (!r->failed_code) { r->failed_code = ORBX_E_DEVICE; r->failed_msg = std::string("orbx_replay_step: staging the block: ") + hipGetErrorString(e); r->err = r->failed_msg; }
+      }
       const int rc = r->host_fn(r->host_user, r->h_send, r->h_recv, r->send_bytes);
-      if (rc != 0) return rfail(r, ORBX_E_DEVICE, "orbx_replay_step: the caller's host all-gather failed with " + std::to_string(rc));
-      RHIP(r, hipMemcpyAsync(r->gathered[i], r->h_recv, r->send_bytes * (size_t)r->world, hipMemcpyHostToDevice, r->gstream));
+      if (rc != 0) xrc = rfail(r, ORBX_E_DEVICE, "orbx_replay_step: the caller's host all-gather failed with " + std::to_string(rc));
+      else if (hipMemcpyAsync(r->gathered[i], r->h_recv, r->send_bytes * (size_t)r->world, hipMemcpyHostToDevice, r->gstream) != hipSuccess)
+        xrc = rfail(r, ORBX_E_DEVICE, "orbx_replay_step: gathered buffer upload failed");
     }
-    RHIP(r, hipEventRecord(r->gather_done[i], r->gstream));
-    r->pending[i] = true;
+    if (hipEventRecord(r->gather_done[i], r->gstream) == hipSuccess) { r->pending[i] = true; r->gathered_valid[i] = true; }
   }
   r->step_idx++;
+  if (r->failed_code) { r->err = r->failed_msg; return r->failed_code; }
+  if (xrc != ORBX_OK) return xrc;
   return i;
+}
+
+// ---- failure containment (see orbx_replay_step)
+int orbx_replay_failed(const orbx_replay* r) { return r ? r->failed_code : ORBX_E_INVALID; }
+
+int orbx_replay_debug_fail_at(orbx_replay* r, long long step) {
+  if (!r) return ORBX_E_INVALID;
+  r->inject_fail_step = step;
+  return ORBX_OK;
+}
+
+// Leaving a group whose other ranks may be gone: ncclCommAbort frees the communicator WITHOUT the collective hand-shake of ncclCommDestroy and
+// releases collectives of this rank that are stuck on the gather stream.  The engine keeps working with the exchange off.
+int orbx_replay_abort(orbx_replay* r) {
+  if (!r) return ORBX_E_INVALID;
+  (void)hipSetDevice(r->device);
+  if (r->comm) {
+    const Rccl* R = rccl();
+    if (R && R->CommAbort) (void)R->CommAbort(r->comm);
+    else if (R) (void)R->CommDestroy(r->comm);
+    r->comm = nullptr;
+  }
+  r->gather_on = false;
+  r->transport += " [aborted]";
+  return ORBX_OK;
+}
+
+// ---- ordering a consumer against ONE step's exchange, without draining the engine
+// orbx_replay_step returns at once and the collective into gathered buffer i runs on the engine's own gather stream: a kernel the caller
+// launches on ITS stream knows nothing of it.  wait: `consumer` waits (on the device) for the last collective queued into buffer i.
+// release: the consumer is done with buffer i as far as `consumer` has been fed so far — the next collective INTO buffer i (two steps later)
+// waits for that point instead of overwriting what is being read.
+int orbx_replay_wait_gathered(orbx_replay* r, int i, void* consumer_stream) {
+  hipStream_t consumer = (hipStream_t)consumer_stream;
+  if (!r || i < 0 || i > 1) return ORBX_E_INVALID;
+  if (!r->gathered[i] || !r->gathered_valid[i]) return rfail(r, ORBX_E_INVALID, "orbx_replay_wait_gathered: no exchange has been queued into this buffer");
+  RHIP(r, hipSetDevice(r->device));
+  RHIP(r, hipStreamWaitEvent(consumer, r->gather_done[i], 0));
+  return ORBX_OK;
+}
+
+int orbx_replay_release_gathered(orbx_replay* r, int i, void* consumer_stream) {
+  hipStream_t consumer = (hipStream_t)consumer_stream;
+  if (!r || i < 0 || i > 1) return ORBX_E_INVALID;
+  if (!r->gathered[i]) return rfail(r, ORBX_E_INVALID, "orbx_replay_release_gathered: the engine was created without an exchange");
+  RHIP(r, hipSetDevice(r->device));
+  RHIP(r, hipEventRecord(r->consumer_done[i], consumer));
+  r->consumer_pending[i] = true;
+  return ORBX_OK;
+}
+
+// host variant of wait: returns ORBX_OK when the last collective into buffer i has completed, ORBX_E_TIMEOUT after timeout_ms (< 0: no limit)
+// — a rank whose peer died never completes its collective: the caller then tells its control plane and calls orbx_replay_abort
+int orbx_replay_wait_gathered_host(orbx_replay* r, int i, int timeout_ms) {
+  if (!r || i < 0 || i > 1) return ORBX_E_INVALID;
+  if (!r->gathered[i] || !r->gathered_valid[i]) return rfail(r, ORBX_E_INVALID, "orbx_replay_wait_gathered_host: no exchange has been queued into this buffer");
+  RHIP(r, hipSetDevice(r->device));
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t e = hipEventQuery(r->gather_done[i]);
+    if (e == hipSuccess) return ORBX_OK;
+    if (e != hipErrorNotReady) return rfail(r, ORBX_E_DEVICE, std::string("orbx_replay_wait_gathered_host: ") + hipGetErrorString(e));
+    if (timeout_ms >= 0 && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > (double)timeout_ms)
+      return rfail(r, ORBX_E_TIMEOUT, "orbx_replay_wait_gathered_host: the exchange into buffer " + std::to_string(i) + " did not complete within " +
+                                          std::to_string(timeout_ms) + " ms (a peer that left?)");
+    std::this_thread::yield();
+  }
 }
 
 int orbx_replay_drain(orbx_replay* r) {

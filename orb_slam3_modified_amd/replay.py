@@ -103,18 +103,8 @@ class ReplayEngine:
             rank, world = dist.get_rank(process_group), dist.get_world_size(process_group)
         self.rank, self.world = int(rank or 0), int(world or 1)
         host_cb = None
-        if gather and dist is not None and dist.get_backend(process_group) == "nccl":
-            if unique_id is None:   # RCCL between the ranks, called by liborbx: the id travels over the job's own control plane
-                box = [None]
-                if self.rank == 0:
-                    buf = (C.c_uint8 * 128)()
-                    rc = L.orbx_replay_unique_id(buf)   # a failure must reach the other ranks too: they are waiting in the broadcast
-                    box[0] = bytes(buf) if rc == 0 else f"orbx_replay_unique_id failed ({rc}): {L.orbx_replay_rccl_info().decode()}"
-                dist.broadcast_object_list(box, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0, group=process_group)
-                if not isinstance(box[0], bytes):
-                    raise _lib.OrbxError(-3, str(box[0]))
-                unique_id = box[0]
-        elif gather and dist is not None:
+        use_rccl = bool(gather) and (dist is None or dist.get_backend(process_group) == "nccl")
+        if gather and dist is not None and not use_rccl:
             import numpy as _np
             import torch
 
@@ -132,7 +122,7 @@ class ReplayEngine:
                     return 1
             host_cb = L.HOST_EXCHANGE_FN(_exchange)
         self._host_cb = host_cb               # keeps the trampoline alive
-        if gather and self.world > 1 and unique_id is None and host_cb is None:
+        if gather and self.world > 1 and unique_id is None and host_cb is None and dist is None:
             raise ValueError("ReplayEngine: world > 1 with gather needs a unique_id (orbx_replay_unique_id on one rank) or a torch.distributed group")
         # ---- lanes: contexts of the caller's extractor's parameters (the first lane IS the caller's context)
         lanes = max(1, min(int(lanes), self.B // 32 if self.B >= 64 else 1))
@@ -142,10 +132,40 @@ class ReplayEngine:
         arr = (C.c_void_p * nl)(*[e._ctx for e in self.exs])
         h = C.c_void_p()
         what = 0 if not gather else (1 if gather_what == "descriptors" else 2)
-        uid = (C.c_uint8 * 128).from_buffer_copy(unique_id) if unique_id is not None else None
-        rc = L.orbx_replay_create(C.byref(h), arr, nl, self.B, self.H, self.W, what, self.rank, self.world, uid,
-                                  C.cast(host_cb, C.c_void_p) if host_cb is not None else None, None)
-        _lib.check(rc, self.exs[0]._ctx)
+        # ---- two halves (include/orbx.h): prepare = everything this rank can fail at on its own; then every rank learns over the job's control
+        # plane whether ALL ranks are ready, and only then does anybody enter ncclCommInitRank (a rank whose peer never arrives waits for ever)
+        rc = L.orbx_replay_prepare(C.byref(h), arr, nl, self.B, self.H, self.W, what, self.rank, self.world, 1 if (use_rccl and host_cb is None) else 0,
+                                   C.cast(host_cb, C.c_void_p) if host_cb is not None else None, None)
+        local_error = None if rc == 0 else f"orbx_replay_prepare failed ({rc}): {L.orbx_last_error(self.exs[0]._ctx).decode()}"
+        if gather and dist is not None and self.world > 1:
+            box = [None]
+            if use_rccl and self.rank == 0 and local_error is None and unique_id is None:
+                buf = (C.c_uint8 * 128)()
+                rc = L.orbx_replay_unique_id(buf)
+                if rc == 0:
+                    box[0] = bytes(buf)
+                else:
+                    local_error = f"orbx_replay_unique_id failed ({rc}): {L.orbx_replay_rccl_info().decode()}"
+            states = [None] * self.world
+            dist.all_gather_object(states, local_error, group=process_group)     # every rank's verdict on its own half
+            bad = [(r_, e_) for r_, e_ in enumerate(states) if e_ is not None]
+            if bad:
+                if h.value:
+                    L.orbx_replay_destroy(h)
+                raise _lib.OrbxError(-3, "ReplayEngine: no rank enters the exchange because " +
+                                     "; ".join(f"rank {r_}: {e_}" for r_, e_ in bad))
+            if use_rccl and unique_id is None:   # RCCL between the ranks, called by liborbx: the id travels over the job's own control plane
+                dist.broadcast_object_list(box, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0, group=process_group)
+                unique_id = box[0]
+        elif local_error is not None:
+            raise _lib.OrbxError(rc, local_error)
+        if gather and host_cb is None:
+            uid = (C.c_uint8 * 128).from_buffer_copy(unique_id) if unique_id is not None else None
+            rc = L.orbx_replay_connect(h, uid)
+            if rc != 0:
+                msg = L.orbx_replay_last_error(h).decode()
+                L.orbx_replay_destroy(h)
+                raise _lib.OrbxError(rc, msg)
         self._h = h
         fr, cap, nb, do, co, so, sb, nlan = C.c_int(), C.c_int(), C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_int()
         self._check(L.orbx_replay_layout(h, C.byref(fr), C.byref(cap), C.byref(nb), C.byref(do), C.byref(co), C.byref(so), C.byref(sb), C.byref(nlan)))
@@ -199,6 +219,34 @@ class ReplayEngine:
 
     def drain(self):
         self._check(self._L.orbx_replay_drain(self._h))
+
+    # ---- ordering a consumer on its own stream against ONE step's exchange (no drain): `stream` = a hipStream_t as an integer
+    # (torch.cuda.Stream().cuda_stream), 0 / None = the legacy stream is NOT accepted by the library's rule — pass a real stream
+    def wait_gathered(self, i: int, stream: int):
+        self._check(self._L.orbx_replay_wait_gathered(self._h, i, self._C.c_void_p(int(stream))))
+
+    def release_gathered(self, i: int, stream: int):
+        self._check(self._L.orbx_replay_release_gathered(self._h, i, self._C.c_void_p(int(stream))))
+
+    def wait_gathered_host(self, i: int, timeout_ms: int = -1) -> bool:
+        """True when the last exchange into gathered buffer i has completed, False after timeout_ms (a peer that left?)."""
+        rc = self._L.orbx_replay_wait_gathered_host(self._h, i, int(timeout_ms))
+        if rc == -6:
+            return False
+        self._check(rc)
+        return True
+
+    # ---- failure containment: a rank whose lanes failed keeps taking part in every exchange with a poisoned block (all counts -1)
+    @property
+    def failed(self) -> int:
+        return int(self._L.orbx_replay_failed(self._h))
+
+    def abort(self):
+        self._check(self._L.orbx_replay_abort(self._h))
+        self._gather = False
+
+    def debug_fail_at(self, step: int):
+        self._check(self._L.orbx_replay_debug_fail_at(self._h, int(step)))
 
     def reset_gather_timing(self):
         self._check(self._L.orbx_replay_gather_ms(self._h, None, None, 1))

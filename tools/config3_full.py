@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--images", type=int, default=256)
     ap.add_argument("--no-ref", action="store_true")
     ap.add_argument("--no-paced", action="store_true")
+    ap.add_argument("--spin", action="store_true", help="a third drop-in run paced by busy-waiting instead of sleeping (is the paced tail the CPU's or the GPU's idle state?)")
     ap.add_argument("--env", action="append", default=[], help="KEY=VALUE for the drop-in runs (e.g. ORBX_KEEP_WARM=1)")
     a = ap.parse_args()
     from orb_slam3_modified_amd import build
@@ -37,6 +38,8 @@ def main():
     rows["dropin_back_to_back"] = wu.run_frontend(exe, raw, 480, 640, a.images, 1000, voc, 1, timeout=1200, frames=a.frames)
     if not a.no_paced:
         rows["dropin_paced_20hz"] = wu.run_frontend(exe, raw, 480, 640, a.images, 1000, voc, 1, timeout=1200, frames=a.frames, stamps=stamps, pace=1)
+    if a.spin:
+        rows["dropin_paced_20hz_busy_wait"] = wu.run_frontend(exe, raw, 480, 640, a.images, 1000, voc, 1, timeout=1200, frames=a.frames, stamps=stamps, pace=2)
     if not a.no_ref and os.path.exists(wu.REF_FRONTEND_EXE):
         rows["reference_back_to_back"] = wu.run_frontend(wu.REF_FRONTEND_EXE, raw, 480, 640, a.images, 1000, voc, 1, timeout=2400, frames=a.frames)
     digests = {k: v["results_digest"] for k, v in rows.items()}

@@ -11,7 +11,7 @@
 //                     restatements) + the reference's DBoW2 through oracle/_ref/libref_dbow2.so
 // Both print one JSON line: ms per frame of every stage and a digest of everything the sequence produced (keypoints, descriptors,
 // BoW vectors, both searches' match vectors), which must be equal between the two builds.
-//   streamed_frontend <frames.raw> <rows> <cols> <nframes> <nfeatures> <voc.txt> <passes> [--frames T] [--timestamps <stamps.txt>] [--pace 0|1]
+//   streamed_frontend <frames.raw> <rows> <cols> <nframes> <nfeatures> <voc.txt> <passes> [--frames T] [--timestamps <stamps.txt>] [--pace 0|1|2]
 // Long form (BASELINE config 3 at length: Examples/Monocular/mono_euroc.cc:84-160 feeds 3 682 images of MH_01 at the rate of their
 // time stamps): `--frames T` streams T frames per pass by walking the <nframes> images forth and back (0 … n-1, n-2 … 1, 0 …: the
 // camera of the synthetic stream pans one way, then the other, so consecutive frames always overlap), keeping only the last 8 frames and
@@ -67,7 +67,7 @@ struct Series {
 
 int main(int argc, char** argv) {
   if (argc < 8) {
-    std::fprintf(stderr, "usage: streamed_frontend <frames.raw> <rows> <cols> <nframes> <nfeatures> <voc.txt> <passes> [--frames T] [--timestamps <stamps.txt>] [--pace 0|1]\n");
+    std::fprintf(stderr, "usage: streamed_frontend <frames.raw> <rows> <cols> <nframes> <nfeatures> <voc.txt> <passes> [--frames T] [--timestamps <stamps.txt>] [--pace 0|1|2]\n");
     return 2;
   }
   const int rows = std::atoi(argv[2]), cols = std::atoi(argv[3]), nfr = std::atoi(argv[4]), nfeatures = std::atoi(argv[5]), passes = std::atoi(argv[7]);
@@ -240,7 +240,9 @@ int main(int argc, char** argv) {
           const double Tnext = stamps[ni + 1] - stamps[ni];
           const double ttrack = ms_since(frame_t0) * 1e-3;
           if (ttrack < Tnext) {
-            std::this_thread::sleep_for(std::chrono::duration<double>(Tnext - ttrack));
+            if (pace == 2) {   // attribution only: the same 20 Hz with the host core kept busy (GPU idle between frames as before, no CPU sleep state)
+              while (ms_since(frame_t0) * 1e-3 < Tnext) {}
+            } else std::this_thread::sleep_for(std::chrono::duration<double>(Tnext - ttrack));
             slept_s += Tnext - ttrack;
           }
         }
@@ -258,9 +260,9 @@ int main(int argc, char** argv) {
                 build, st.frames, device_path, st.extract / n, st.bow / n, st.search_last / n, st.search_local / n, st.frame_host / n, st.frustum_host / n,
                 st.feats / n, st.m_last / n, st.m_local / n, st.retries, (unsigned long long)digest.h);
     if (longform)
-      std::printf(", \"stream\": {\"frames_per_pass\": %d, \"images\": %d, \"order\": \"forth and back\", \"ring\": %d, \"paced\": %s, \"stamps\": %zu, \"wall_s\": %.2f, \"slept_s\": %.2f}, "
+      std::printf(", \"stream\": {\"frames_per_pass\": %d, \"images\": %d, \"order\": \"forth and back\", \"ring\": %d, \"paced\": %s, \"wait\": \"%s\", \"stamps\": %zu, \"wall_s\": %.2f, \"slept_s\": %.2f}, "
                   "\"percentiles\": {\"extract_ms\": %s, \"bow_ms\": %s, \"search_last_ms\": %s, \"search_local_ms\": %s, \"four_calls_ms\": %s, \"frame_wall_ms\": %s}",
-                  long_frames, nfr, ring, pace ? "true" : "false", stamps.size(), wall_s, slept_s, q_extract.json().c_str(), q_bow.json().c_str(),
+                  long_frames, nfr, ring, pace ? "true" : "false", pace == 2 ? "busy-wait" : pace ? "sleep" : "none", stamps.size(), wall_s, slept_s, q_extract.json().c_str(), q_bow.json().c_str(),
                   q_last.json().c_str(), q_local.json().c_str(), q_total.json().c_str(), q_wall.json().c_str());
     std::printf("}\n");
 #ifndef ORBX_H
