@@ -360,6 +360,10 @@ int orbx_target_search_view(orbx_ctx* ctx, const orbx_target* target, const uint
 int orbx_target_search_view_begin(orbx_ctx* ctx, const orbx_target* target, const uint8_t* kp_skip, const float* qx, const float* qy, const float* qr,
                                   const int32_t* qmin_level, const int32_t* qmax_level, const uint8_t* q_desc, const float* q_xr, int nq);
 int orbx_target_search_view_end(orbx_ctx* ctx, int slot, const orbx_list_span** spans, const orbx_candidate** pool);
+/* Gives back the slot of a _begin whose _end will not be called (an error between the two halves, a dropped ticket); waits for the kernel that
+ * may still be writing the blob.  A slot without a pending call: ORBX_OK.  The synchronous orbx_target_search_view never takes a blob with a
+ * pending call: with one pending it uses the other, with both pending it returns ORBX_E_INVALID. */
+int orbx_target_search_view_cancel(orbx_ctx* ctx, int slot);
 /* = orbx_window_nearest on the target; reprojection_gate != 0 needs a target created with kp_uright + inv_level_sigma2, and q_ur */
 int orbx_target_nearest(orbx_ctx* ctx, const orbx_target* target, int reprojection_gate, const float* qx, const float* qy, const float* qr,
                         const int32_t* qmin_level, const int32_t* qmax_level, const float* q_ur, const uint8_t* q_desc, int nq, int32_t* best_idx,

@@ -117,6 +117,7 @@ def lib() -> C.CDLL:
         "orbx_target_search_view": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]),
         "orbx_target_search_view_begin": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32]),
         "orbx_target_search_view_end": (i32, [vp, i32, vp, vp]),
+        "orbx_target_search_view_cancel": (i32, [vp, i32]),
         "orbx_last_graph_device_us": (C.c_double, [vp]),
         "orbx_publish_descriptors": (i32, [vp, vp, i32]),
         "orbx_kfdb_sharing": (i32, [vp, vp, i32, vp, vp, i32, ip]),

@@ -990,7 +990,13 @@ int orbx_target_search_view(orbx_ctx* ctx, const orbx_target* target, const uint
   *spans = nullptr; *pool = nullptr;
   if (nq == 0 || target->n == 0) return target->valid ? 0 : set_err(ctx, ORBX_E_INVALID, "orbx_target_search_view: invalid target");
   // the pool is sized from what earlier calls of this context needed; a call that needs more reports the size and is repeated once
-  ctx->view_par ^= 1;   // this call's blob: the other one keeps the previous view alive (orbx.h: valid until the second next view call)
+  // this call's blob: normally the other one than the last view's (which stays alive: orbx.h, valid until the second next view call) — but never
+  // one that backs a call issued by _begin and not yet collected by _end (its kernel may still be writing it, and _end reads its header)
+  int sel = ctx->view_par ^ 1;
+  if (ctx->view_call[sel].pending) sel ^= 1;
+  if (ctx->view_call[sel].pending)
+    return set_err(ctx, ORBX_E_INVALID, "orbx_target_search_view: both view blobs hold a pending call (finish one with _end, or _cancel it, first)");
+  ctx->view_par = sel;
   for (int attempt = 0; attempt < 2; attempt++) {
     std::vector<int32_t>& rp = ctx->view_row_ptr;
     rp.assign((size_t)nq + 1, 0);
@@ -1097,6 +1103,22 @@ int orbx_target_search_view_end(orbx_ctx* ctx, int slot, const orbx_list_span** 
   *spans = (const orbx_list_span*)(hout + vc.p_q);
   *pool = (const orbx_candidate*)(hout + vc.p_pool);
   return total;
+}
+
+// A call issued by _begin whose _end will never come (an error between the two, a dropped ticket): the slot is given back.  The kernel that
+// may still be writing the blob is waited for first.
+int orbx_target_search_view_cancel(orbx_ctx* ctx, int slot) {
+  if (!ctx || slot < 0 || slot > 1) return ctx ? set_err(ctx, ORBX_E_INVALID, "orbx_target_search_view_cancel: bad arguments") : ORBX_E_INVALID;
+  orbx_ctx::ViewCall& vc = ctx->view_call[slot];
+  if (!vc.pending) return ORBX_OK;
+  const bool launched = !vc.sync_fallback;
+  vc = orbx_ctx::ViewCall();
+  if (launched) {
+    ORBX_HIP(ctx, hipSetDevice(ctx->device));
+    ORBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx->view_call[slot ^ 1].pending) ctx->win_ctr_dirty = true;   // whatever the kernel left in the counters: the next call clears them
+  }
+  return ORBX_OK;
 }
 
 int orbx_target_nearest(orbx_ctx* ctx, const orbx_target* target, int reprojection_gate, const float* qx, const float* qy, const float* qr,

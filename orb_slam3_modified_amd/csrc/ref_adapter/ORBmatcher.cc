@@ -376,16 +376,28 @@ int window_lists_begin(const char* routine, orbx_target* T, const Queries& Q, in
   if (slot < 0) fail(routine, ctx);
   return slot;
 }
-void window_lists_end(const char* routine, int slot, int nq, Lists& L) {
+void window_lists_end(const char* routine, int& slot, int nq, Lists& L) {
   L.row_ptr.assign(nq + 1, 0);
   L.own();
   if (slot < 0) return;
   orbx_ctx* ctx = ORBmatcher::DefaultContext();
   const orbx_list_span* spans = nullptr;
   const orbx_candidate* pool = nullptr;
-  if (orbx_target_search_view_end(ctx, slot, &spans, &pool) < 0) fail(routine, ctx);
+  const int s = slot;
+  slot = -1;   // whatever happens now, the call has been collected: _end cleared the slot's pending flag before anything could fail
+  if (orbx_target_search_view_end(ctx, s, &spans, &pool) < 0) fail(routine, ctx);
   if (spans) L.view(spans, pool);
 }
+// The two issued halves of a pipelined search: whatever leaves the routine between a _begin and its _end (fail() throws) must not leave a
+// slot of the thread's context pending for ever — every later pipelined search of this thread would find "both view blobs hold a pending
+// call".  Slots still >= 0 at scope exit are cancelled.
+struct PendingHalves {
+  int a = -1, b = -1;
+  ~PendingHalves() {
+    for (int s : {a, b})
+      if (s >= 0) (void)orbx_target_search_view_cancel(ORBmatcher::DefaultContext(), s);
+  }
+};
 
 void window_best(const char* routine, orbx_target* T, bool reprojection_gate, const Queries& Q, std::vector<int32_t>& bestIdx,
                  std::vector<int32_t>& bestDist) {
@@ -644,16 +656,17 @@ int ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoint
     const int mid = nMP / 2;
     prepass(0, mid);
     const int nA = QL.size();
-    const int sA = window_lists_begin("SearchByProjection", TL, QL, 0, nA);
+    PendingHalves ph;
+    ph.a = window_lists_begin("SearchByProjection", TL, QL, 0, nA);
     prepass(mid, nMP);
     const int nB = QL.size() - nA;
     if (nA + nB == 0) return 0;
-    const int sB = window_lists_begin("SearchByProjection", TL, QL, nA, nB);
+    ph.b = window_lists_begin("SearchByProjection", TL, QL, nA, nB);
     tr.mark("prepass");
     Lists LA, LB;
-    window_lists_end("SearchByProjection", sA, nA, LA);
+    window_lists_end("SearchByProjection", ph.a, nA, LA);
     replay(0, mid, LA, 0);
-    window_lists_end("SearchByProjection", sB, nB, LB);
+    window_lists_end("SearchByProjection", ph.b, nB, LB);
     tr.mark("half");
     replay(mid, nMP, LB, nA);
     tr.mark("replay");
@@ -1444,16 +1457,17 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
     const int mid = N / 2;
     prepass(0, mid);
     const int nA = QL.size();
-    const int sA = window_lists_begin("SearchByProjection", TL, QL, 0, nA);
+    PendingHalves ph;
+    ph.a = window_lists_begin("SearchByProjection", TL, QL, 0, nA);
     prepass(mid, N);
     const int nB = QL.size() - nA;
     if (nA + nB == 0) return 0;
-    const int sB = window_lists_begin("SearchByProjection", TL, QL, nA, nB);
+    ph.b = window_lists_begin("SearchByProjection", TL, QL, nA, nB);
     tr.mark("prepass");
     Lists LA, LB;
-    window_lists_end("SearchByProjection", sA, nA, LA);
+    window_lists_end("SearchByProjection", ph.a, nA, LA);
     replay(0, mid, LA, 0);
-    window_lists_end("SearchByProjection", sB, nB, LB);
+    window_lists_end("SearchByProjection", ph.b, nB, LB);
     tr.mark("half");
     replay(mid, N, LB, nA);
   } else {

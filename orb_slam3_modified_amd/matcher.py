@@ -400,6 +400,10 @@ class SearchTarget:
                      self._ctx)
         return (slot, len(qx), (qx, qy, qr, lo, hi, qd, skip, xr))
 
+    def search_view_cancel(self, ticket):
+        """orbx_target_search_view_cancel: gives back the slot of a ticket that search_view_end will never see."""
+        check(int(self._L.orbx_target_search_view_cancel(self._ctx, int(ticket[0]))), self._ctx)
+
     def search_view_end(self, ticket, copy=True):
         """orbx_target_search_view_end -> (spans, pool) as search_view returns them."""
         slot, nq, _keep = ticket

@@ -324,6 +324,11 @@ int orbx_target_search_view_end(orbx_ctx* ctx, int slot, const orbx_list_span** 
   g_view_calls[slot].pending = false;
   return orbx_target_search_view(ctx, c.T, c.skip, c.qx, c.qy, c.qr, c.qmin, c.qmax, c.qd, c.qxr, c.nq, spans, pool);
 }
+int orbx_target_search_view_cancel(orbx_ctx*, int slot) {
+  if (slot < 0 || slot > 1) return ORBX_E_INVALID;
+  g_view_calls[slot].pending = false;
+  return ORBX_OK;
+}
 int orbx_target_nearest(orbx_ctx*, const orbx_target* T, int reprojection_gate, const float* qx, const float* qy, const float* qr, const int32_t* qmin,
                         const int32_t* qmax, const float* q_ur, const uint8_t* q_desc, int nq, int32_t* best_idx, int32_t* best_dist) {
   mo_window_nearest(T->kps.data(), T->desc.data(), T->n, &T->g, reprojection_gate ? T->ur.data() : nullptr, reprojection_gate ? T->sig.data() : nullptr,

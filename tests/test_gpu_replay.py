@@ -427,8 +427,19 @@ def test_a_consumer_stream_is_ordered_against_one_steps_exchange_without_a_drain
     for k in range(nsets):
         i = ref.step()
         want.append(ref.block_host(i)[eng.send_off:].copy())
+    lo = eng.layout
+    c0 = lo.counts_off - lo.desc_off
+
+    def valid(part):   # counts + the descriptor rows they cover (rows beyond a frame's count keep whatever an earlier step left in that buffer)
+        counts = part[c0:c0 + lo.counts_bytes].view(np.int32).reshape(B, 2)
+        desc = part[:lo.desc_bytes].reshape(B, lo.cap, 32)
+        return counts, [desc[f, :counts[f, 0]] for f in range(B)]
     for k in range(steps):
-        assert np.array_equal(copies[k].cpu().numpy(), want[k % nsets]), f"the consumer's copy of step {k} is not that step's exchange"
+        gc, gd = valid(copies[k].cpu().numpy())
+        wc, wd = valid(want[k % nsets])
+        assert np.array_equal(gc, wc) and gc[:, 0].min() > 500, f"the consumer's copy of step {k} does not hold that step's counts"
+        assert all(np.array_equal(a, b) for a, b in zip(gd, wd)), f"the consumer's copy of step {k} does not hold that step's descriptor rows"
+    assert len({want[k][c0:c0 + lo.counts_bytes].tobytes() for k in range(nsets)}) == nsets      # the batches do differ: a stale buffer would show
     assert eng.wait_gathered_host(0, 1000) and eng.wait_gathered_host(1, 1000)
     eng.close(); ref.close()
 

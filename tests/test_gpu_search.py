@@ -538,6 +538,27 @@ def test_view_calls_issued_and_waited_for_separately(frames):
     # empty query set and empty target
     te = tgt.search_view_begin(*queries(0, 1.0))
     assert len(tgt.search_view_end(te)[0]) == 0
+    # the SYNCHRONOUS view call between a _begin and its _end must not take the pending call's blob; with both slots pending it
+    # refuses; a ticket nobody will end is cancelled and the slot is free again
+    qa, qb, qc = queries(500, 12.0), queries(300, 8.0), queries(200, 10.0)
+    ta = tgt.search_view_begin(*qa)
+    vc1 = tgt.search_view(*qc, copy=False)                 # one pending: takes the other blob
+    vc2 = tgt.search_view(*qa, copy=False)                 # ... and again (the same non-pending blob: vc1 is dead now, by the lifetime rule)
+    check_view(vc2, qa)
+    va = tgt.search_view_end(ta, copy=False)
+    check_view(va, qa)
+    del vc1
+    ta = tgt.search_view_begin(*qa); tb = tgt.search_view_begin(*qb)
+    with pytest.raises(OrbxError):
+        tgt.search_view(*qc)                               # both pending: refused, nothing overwritten
+    tgt.search_view_cancel(tb)                             # the ticket of a caller that unwound between the halves
+    tgt.search_view_cancel(tb)                             # idempotent
+    with pytest.raises(OrbxError):
+        tgt.search_view_end(tb)
+    check_view(tgt.search_view(*qc, copy=False), qc)       # the cancelled slot serves again
+    check_view(tgt.search_view_end(ta, copy=False), qa)    # and the other half is still intact
+    t1 = tgt.search_view_begin(*qb); t2 = tgt.search_view_begin(*qc)
+    check_view(tgt.search_view_end(t2, copy=False), qc); check_view(tgt.search_view_end(t1, copy=False), qb)
     tgt.close()
 
 

@@ -3,6 +3,6 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 900 python tools/config3_full.py > gpurun_out/config3_full.txt 2> gpurun_out/config3_full.err; echo "config3 exit $?"
-head -c 6000 gpurun_out/config3_full.txt | grep -v '^{'
-timeout 300 python -m pytest tests/test_streamed_frontend.py -m gpu -x -q 2>&1 | tail -3
+timeout 1500 python -m pytest tests/test_gpu_replay.py tests/test_frame_world.py tests/test_bench_contract.py -m gpu -x -q 2>&1 | tail -15
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>gpurun_out/bench.err | tail -1 > gpurun_out/bench_iter.json; python -c "
+import json; j=json.load(open('gpurun_out/bench_iter.json')); print(j['value'], j['ms_per_step'], j['strong'], j['frame_constructor'])"
