@@ -537,6 +537,101 @@ def timed_replay(eng, steps, warmup, sync_all):
     return time.perf_counter() - t0, last
 
 
+def matcher_roofline(host_frames, nfeatures, voc_descriptors):
+    """the matcher and bag-of-words kernels next to THEIR ceilings, HIP-event timed in this run, on the stream each kernel runs on.
+      k_knn2      all-pairs Hamming + two best (cv::BFMatcher.knnMatch(k=2), src/Frame.cc:1144): pairs/s against the integer VALU bound — 256 bits of
+                  XOR + popcount are 16 lane-operations per pair (8 v_xor_b32 + 8 v_bcnt_u32_b32 with accumulate) at the 4-cycle wave-instruction
+                  rate of profiles/valu_ceiling_r2.txt: 1024 SIMDs x 2.4 GHz / 4 x 64 lanes / 16 = 2.46e12 pairs/s
+      k_window    the per-frame guided search (SearchByProjection's device pass over a resident target): algorithmic bytes
+                  32 (Q + T) + 4 nnz + 12 Q against HBM — a single ~10 us launch, latency-bound by construction
+      k_bow_descend  the vocabulary tree descent: N L k 32 gathered bytes per call against the L2 rate (34.5 TB/s: the tree is L2-resident)"""
+    import torch
+    from orb_slam3_modified_amd import ORBextractor, ORBmatcher, ORBVocabulary, _lib
+    from orb_slam3_modified_amd._lib import ptr
+    from tests.vocab_util import make_vocabulary
+    out = {}
+    try:
+        L = _lib.lib()
+        dev = torch.device("cuda", torch.cuda.current_device())
+        ex = ORBextractor(nfeatures, 1.2, 8, 20, 7, device_id=dev.index)
+        fr = [ex(f, None, (0, 1000)) for f in host_frames[:2]]
+        (k0, d0h), (k1, d1h) = (fr[0][1], fr[0][2]), (fr[1][1], fr[1][2])
+        side = torch.cuda.Stream()
+        st = side.cuda_stream
+
+        def ev_time(fn, reps):   # torch events on the stream the kernel is launched on
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(side)
+            for _ in range(reps):
+                fn()
+            b.record(side)
+            torch.cuda.synchronize()
+            return a.elapsed_time(b) / reps * 1e-3
+        valu_pairs_peak = 1024 * 2.4e9 / 4 * 64 / 16
+        knn = {}
+        for name, q, t in (("1000x1000", torch.from_numpy(d0h).to(dev), torch.from_numpy(d1h).to(dev)),
+                           ("8192x8192", *(torch.randint(0, 256, (8192, 32), dtype=torch.uint8, device=dev) for _ in range(2)))):
+            nq, nt = int(q.shape[0]), int(t.shape[0])
+            idx = torch.zeros(nq * 2, dtype=torch.int32, device=dev); dist = torch.zeros(nq * 2, dtype=torch.int32, device=dev)
+            sec = ev_time(lambda: L.orbx_knn2_allpairs_device(ex._ctx, ptr(q.data_ptr()), nq, ptr(t.data_ptr()), nt, ptr(idx.data_ptr()), ptr(dist.data_ptr()), ptr(st)),
+                          40 if nq < 4000 else 8)
+            ach = nq * nt / sec
+            knn[name] = {"queries": nq, "train": nt, "us_per_call": round(sec * 1e6, 2), "achieved": round(ach / 1e9, 2), "peak": round(valu_pairs_peak / 1e9, 1),
+                         "unit": "Gpairs/s", "frac": round(ach / valu_pairs_peak, 4)}
+        out["k_knn2"] = dict(knn, bound="valu-int32", peak_derivation="16 lane-ops per 256-bit pair (8 xor + 8 popcount-accumulate) at one wave-instruction per 4 cycles: "
+                             "1024 SIMDs x 2.4 GHz / 4 x 64 / 16 (profiles/valu_ceiling_r2.txt measures 0.59-0.60 T wave-instr/s for v_bcnt_u32_b32)")
+        # ---- k_window: frame 0's keypoints as map points projected into frame 1 (th = 15 as TrackWithMotionModel, src/Tracking.cc:2889)
+        m = ORBmatcher(ex, 0.9, True)
+        grid = dict(min_x=0.0, min_y=0.0, inv_w=64.0 / float(host_frames.shape[2]), inv_h=48.0 / float(host_frames.shape[1]), cell_start=None, cell_idx=None)
+        T = m.Target(k1, d1h, grid)
+        lvl = k0["octave"].astype(np.int32)
+        qx, qy = (k0["x"] + np.float32(1.5)).astype(np.float32), (k0["y"] + np.float32(0.5)).astype(np.float32)
+        qr = (np.float32(15.0) * np.float32(1.2) ** lvl).astype(np.float32)
+        ex.set_option("window_timing", 1)
+        us, nnz = [], 0
+        for i in range(60):
+            r = T.search(qx, qy, qr, lvl - 1, lvl + 1, d0h, want_lists=True)
+            nnz = int(r["row_ptr"][-1])
+            if i >= 10:
+                us.append(float(L.orbx_last_window_device_us(ex._ctx)))
+        ex.set_option("window_timing", 0)
+        T.close()
+        sec = float(np.median(us)) * 1e-6
+        Q, Tn = len(k0), len(k1)
+        wbytes = 32 * (Q + Tn) + 4 * nnz + 12 * Q
+        out["k_window"] = {"queries": Q, "target_keypoints": Tn, "candidates": nnz, "us_per_call": round(sec * 1e6, 2), "algorithmic_bytes": wbytes,
+                           "achieved": round(wbytes / sec / 1e9, 2), "peak": 8000.0, "unit": "GB/s", "bound": "hbm", "frac": round(wbytes / sec / 8e12, 6),
+                           "note": "one launch of ~10 us over 100 KB: launch- and latency-bound; the call's wall time (pack + launch + poll) is in streamed_frontend"}
+        # ---- BoW descent
+        tmp = tempfile.mkdtemp(prefix="orbx_mr_")
+        try:
+            vp = os.path.join(tmp, "voc.txt")
+            info = make_vocabulary(vp, np.concatenate(list(voc_descriptors) + [d0h, d1h]), 10, 4, seed=9)
+            voc = ORBVocabulary(ex)
+            assert voc.loadFromTextFile(vp)
+            dq = torch.from_numpy(d0h).to(dev)
+            n = int(dq.shape[0])
+            dw = torch.zeros(n, dtype=torch.int32, device=dev); dwt = torch.zeros(n, dtype=torch.float64, device=dev); dn = torch.zeros(n, dtype=torch.int32, device=dev)
+            sec = ev_time(lambda: L.orbx_bow_transform_device(voc._voc, ptr(dq.data_ptr()), n, 4, ptr(dw.data_ptr()), ptr(dwt.data_ptr()), ptr(dn.data_ptr()), ptr(st)), 40)
+            k_, L_ = 10, 4
+            gb = n * L_ * k_ * 32
+            out["k_bow_descend"] = {"features": n, "vocabulary": {"k": k_, "L": L_},
+                                    "us_per_call": round(sec * 1e6, 2), "gathered_bytes": gb, "achieved": round(gb / sec / 1e9, 2), "peak": 34500.0, "unit": "GB/s",
+                                    "bound": "l2", "frac": round(gb / sec / 34.5e12, 6),
+                                    "note": "L dependent gather rounds of k child descriptors per feature on a 1000-feature call: latency-bound, not bandwidth-bound"}
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+        return out
+    except SystemExit:
+        raise
+    except Exception as e:   # noqa: BLE001
+        out["error"] = f"{type(e).__name__}: {e}"[:300]
+        return out
+
+
 def fixed_streams_leg(args, ex, dev, rank, world, cdev, sync_all, reduce_max, want_gather, nstreams=8):
     """SURVEY 8(e)'s curve in the SAME run as the weak line: a FIXED set of `nstreams` camera streams (S-8cam), stream c on GPU c mod G,
     --batch frames per stream and step — total work per step the same for every G (strong scaling), so the driver's N = 1, 2, 4, 8 runs give the
@@ -863,6 +958,7 @@ def main():
             except Exception as e:   # noqa: BLE001
                 result["streamed_frontend"] = {"error": str(e)[:300]}
             result["frame_constructor"] = frame_constructor()
+            result["matcher_roofline"] = matcher_roofline(host_frames, args.nfeatures, [])
         if world == 1 and not args.no_secondary:
             result["end_to_end_operator"] = e2e_operator(host_frames, args.nfeatures)
             # ---- BASELINE config 4: TUM-VI shape, 1024x1024, 2000 features (large-image configuration)

@@ -208,6 +208,9 @@ const char* orbx_kernel_name(int slot);
  * its replayed graph; this returns the last call's elapsed device time in microseconds (< 0: no timed call yet).  The host part of a call
  * (image into the pinned buffer, graph launch, wake-up) is the call's wall time minus this. */
 double orbx_last_graph_device_us(orbx_ctx* ctx);
+/* The same for a window pass over a resident target (orbx_target_search / _search_view / _nearest): with "window_timing" set, HIP events are
+ * recorded around the k_window launch on the stream it runs on; this returns the last pass's device time in microseconds (< 0: none yet). */
+double orbx_last_window_device_us(orbx_ctx* ctx);
 
 /* ---- matcher primitives: replace the inner loops of ORB_SLAM3::ORBmatcher --------------------------- */
 

@@ -119,6 +119,7 @@ def lib() -> C.CDLL:
         "orbx_target_search_view_end": (i32, [vp, i32, vp, vp]),
         "orbx_target_search_view_cancel": (i32, [vp, i32]),
         "orbx_last_graph_device_us": (C.c_double, [vp]),
+        "orbx_last_window_device_us": (C.c_double, [vp]),
         "orbx_publish_descriptors": (i32, [vp, vp, i32]),
         "orbx_kfdb_sharing": (i32, [vp, vp, i32, vp, vp, i32, ip]),
         "orbx_kfdb_score": (i32, [vp, vp, vp, i32, vp, i32, vp]),

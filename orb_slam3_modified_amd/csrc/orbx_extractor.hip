@@ -951,6 +951,8 @@ void orbx_destroy(orbx_ctx* ctx) {
   if (ctx->d_qt_fin) { (void)hipFree(ctx->d_qt_fin); ctx->d_qt_fin = nullptr; }
   if (ctx->ev_g0) { (void)hipEventDestroy(ctx->ev_g0); ctx->ev_g0 = nullptr; }
   if (ctx->ev_g1) { (void)hipEventDestroy(ctx->ev_g1); ctx->ev_g1 = nullptr; }
+  if (ctx->ev_w0) { (void)hipEventDestroy(ctx->ev_w0); ctx->ev_w0 = nullptr; }
+  if (ctx->ev_w1) { (void)hipEventDestroy(ctx->ev_w1); ctx->ev_w1 = nullptr; }
   if (ctx->h_tgt) { (void)hipHostFree(ctx->h_tgt); ctx->h_tgt = nullptr; }
   if (ctx->ev_tgt) { (void)hipEventDestroy(ctx->ev_tgt); ctx->ev_tgt = nullptr; }
   if (ctx->d_color) { (void)hipFree(ctx->d_color); ctx->d_color = nullptr; }
@@ -1450,6 +1452,7 @@ int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
   else if (n == "fork_qt") ctx->fork_qt = value != 0;
   else if (n == "graph") ctx->use_graph = value != 0;
   else if (n == "graph_timing") { ctx->graph_timing = value != 0; return ORBX_OK; }   // no re-capture needed
+  else if (n == "window_timing") { ctx->window_timing = value != 0; return ORBX_OK; }   // HIP events around every resident-target window pass (orbx_last_window_device_us)
   else if (n == "fast_pk") ctx->fast_pk = value != 0;
   else if (n == "realign") ctx->realign = value != 0;   // batch frames with rows that are not dword-aligned: one pass into an aligned copy first
   else if (n == "fast_pitch" && (value == 0 || value == 80 || value == 96)) ctx->fast_pitch = value;   // LDS pitch of the FAST tile: 0 = 64 / 96 by cell width
@@ -1497,7 +1500,7 @@ int orbx_get_option(const orbx_ctx* ctx, const char* name) {
   if (!ctx || !name) return ORBX_E_INVALID;
   const std::string n(name);
   const struct { const char* name; int value; } tab[] = {
-      {"fork_blur", ctx->fork_blur}, {"fork_fast0", ctx->fork_fast0}, {"fork_qt", ctx->fork_qt}, {"graph", ctx->use_graph}, {"graph_timing", ctx->graph_timing},
+      {"fork_blur", ctx->fork_blur}, {"fork_fast0", ctx->fork_fast0}, {"fork_qt", ctx->fork_qt}, {"graph", ctx->use_graph}, {"graph_timing", ctx->graph_timing}, {"window_timing", ctx->window_timing},
       {"fast_pk", ctx->fast_pk}, {"realign", ctx->realign}, {"fast_stage_dma", ctx->fast_stage_dma},
       {"gauss_kernel", ctx->gauss_kernel}, {"gauss_round", ctx->gauss_round}, {"gauss_tail", ctx->gauss_tail}, {"atan_fma", ctx->atan_fma}, {"brief_fma", ctx->brief_fma},
       {"qt_points", ctx->qt_points}, {"small_fused", ctx->small_fused}, {"qt_level_major", ctx->qt_level_major}, {"qt_fused", ctx->qt_fused},
@@ -1566,6 +1569,7 @@ int orbx_get_cpu_profile(const orbx_ctx* ctx, char* buf, size_t buf_bytes, int v
 }
 
 double orbx_last_graph_device_us(orbx_ctx* ctx) { return ctx ? ctx->last_graph_us : -1.0; }
+double orbx_last_window_device_us(orbx_ctx* ctx) { return ctx ? ctx->last_window_us : -1.0; }
 
 int orbx_set_host_pyramid(orbx_ctx* ctx, int on) {
   if (!ctx) return ORBX_E_INVALID;

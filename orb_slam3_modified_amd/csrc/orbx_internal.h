@@ -226,6 +226,7 @@ struct orbx_ctx {
   // single-frame operator() path as a replayed hipGraph (H2D, the 13 launches, D2H): one graph launch per frame instead
   // of ~16 API calls; re-captured when the shape / lapping area / buffers change, disabled on any capture failure
   bool graph_timing = false; hipEvent_t ev_g0 = nullptr, ev_g1 = nullptr; double last_graph_us = -1.0;   // "graph_timing": events around the replayed graph
+  bool window_timing = false; hipEvent_t ev_w0 = nullptr, ev_w1 = nullptr; double last_window_us = -1.0; // "window_timing": events around a resident-target window pass
   bool use_graph = true;
   hipGraphExec_t graph_exec = nullptr;
   int graph_key[6] = {0, 0, 0, 0, 0, 0};

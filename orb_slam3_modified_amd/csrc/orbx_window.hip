@@ -797,10 +797,16 @@ int window_call_target(orbx_ctx* ctx, const char* who, const orbx_target* T, con
   a.out_hdr = (int32_t*)(res + p_hdr); a.compact = compact ? 1 : 0; a.host_out = direct ? 1 : 0; a.self_reset = 1;
   const dim3 gridDim((nq + kWinWPG - 1) / kWinWPG), block(64 * kWinWPG);
   const size_t lds = a.skip_map ? (size_t)nskip : 0;
+  const bool timing = ctx->window_timing;   // measurement only (bench.py's matcher_roofline): HIP events around the pass, on the pass's own stream
+  if (timing) {
+    if (!ctx->ev_w0) { ORBX_HIP(ctx, hipEventCreate(&ctx->ev_w0)); ORBX_HIP(ctx, hipEventCreate(&ctx->ev_w1)); }
+    ORBX_HIP(ctx, hipEventRecord(ctx->ev_w0, st));
+  }
   if (chi2) hipLaunchKernelGGL((k_window<false, true>), gridDim, block, lds, st, a);
   else if (lists) hipLaunchKernelGGL((k_window<true, false>), gridDim, block, lds, st, a);
   else hipLaunchKernelGGL((k_window<false, false>), gridDim, block, lds, st, a);
   ORBX_HIP(ctx, hipGetLastError());
+  if (timing) ORBX_HIP(ctx, hipEventRecord(ctx->ev_w1, st));
   double us_issue;
   if (direct) {
     us_issue = since(tr0);
@@ -826,6 +832,11 @@ int window_call_target(orbx_ctx* ctx, const char* who, const orbx_target* T, con
   }
   ctx->win_ctr_dirty = false;
   const double us_sync = since(tr0);
+  if (timing) {
+    float ms = 0.f;
+    if (hipEventSynchronize(ctx->ev_w1) == hipSuccess && hipEventElapsedTime(&ms, ctx->ev_w0, ctx->ev_w1) == hipSuccess) ctx->last_window_us = 1e3 * ms;
+    else (void)hipGetLastError();
+  }
   const int total = *(const int32_t*)(hout + p_hdr);
   const WinQueryOut* qo = (const WinQueryOut*)(hout + p_q);
   const WinQueryShort* qs = (const WinQueryShort*)(hout + p_q);

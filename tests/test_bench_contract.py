@@ -76,6 +76,15 @@ def test_bench_json_line():
     assert st["scaling"] == "strong" and st["streams"] == 8 and st["n_gpus"] == 1 and st["frames_per_step_total"] == 8 * 256 == st["frames_per_step_per_gpu"]
     assert st["value"] > 50000 and st["frames_per_s"] > 50000 and st["ms_per_step_min_max"][0] <= st["ms_per_step"] <= st["ms_per_step_max" if False else "ms_per_step_min_max"][1]
     assert abs(st["value"] / st["frames_per_s"] * 1e3 - j["config"]["features_per_frame"]) < 30      # features per frame of the eight cameras ~ the headline's
+    # the matcher / bag-of-words kernels against their own ceilings, HIP-event timed in the run
+    mr = j["matcher_roofline"]
+    assert "error" not in mr, mr
+    for rec in (mr["k_knn2"]["1000x1000"], mr["k_knn2"]["8192x8192"], mr["k_window"], mr["k_bow_descend"]):
+        assert rec["achieved"] > 0 and rec["peak"] > 0 and abs(rec["frac"] - rec["achieved"] / rec["peak"]) < 2e-3 * max(rec["frac"], 1e-3) + 1e-6, rec
+    assert mr["k_knn2"]["bound"] == "valu-int32" and 0.2 < mr["k_knn2"]["8192x8192"]["frac"] < 1.0 and mr["k_knn2"]["8192x8192"]["unit"] == "Gpairs/s"
+    assert mr["k_window"]["candidates"] > 1000 and mr["k_window"]["algorithmic_bytes"] == 32 * (mr["k_window"]["queries"] + mr["k_window"]["target_keypoints"]) + \
+        4 * mr["k_window"]["candidates"] + 12 * mr["k_window"]["queries"] and 2 < mr["k_window"]["us_per_call"] < 200
+    assert mr["k_bow_descend"]["bound"] == "l2" and mr["k_bow_descend"]["gathered_bytes"] == mr["k_bow_descend"]["features"] * 4 * 10 * 32
     fc = j["frame_constructor"]
     assert fc["gpu"]["stereo_patched_ms"] < 0.6 * fc["gpu"]["stereo_frame_ms"]                       # integration/Frame_stereo.patch: the association on the device
     sf = j["streamed_frontend"]
