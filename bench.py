@@ -24,6 +24,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import shutil
 import socket
 import subprocess
 import sys

@@ -150,52 +150,13 @@ int orbx_host_pyramid_level(orbx_ctx* ctx, int level, const uint8_t** data, size
  * orbx_cpu_profile_values is the table alone (no context, no device): values = {gauss_kernel, gauss_round, gauss_tail, atan_fma, brief_fma}.
  * orbx_get_cpu_profile reports the ACTIVE set ("name +flags (option=value ...)"; "custom" when the Gaussian triple matches no profile).
  * include/ORBextractor.h does not need these: it calibrates itself against the OpenCV it is built with (include/orbx_cv_calibrate.h). */
-int orbx_cpu_profile_count(void);
-const char* orbx_cpu_profile_name(int i);
+const char* orbx_cpu_profile_name(int i);   /* i = 0, 1, ...: NULL ends the table */
 const char* orbx_cpu_profile_description(const char* name);
 int orbx_cpu_profile_values(const char* name, int fma_build, int values[5]);
 int orbx_set_cpu_profile(orbx_ctx* ctx, const char* name, int fma_build);
 int orbx_get_cpu_profile(const orbx_ctx* ctx, char* buf, size_t buf_bytes, int values[5]);
 
-/* The 7x7 Gaussian-blurred copy of mvImagePyramid[level] the descriptors were sampled from
- * (cv::GaussianBlur, src/ORBextractor.cc:1132-1133), for stage-level parity tests.  dst: h rows of w bytes. */
-int orbx_debug_blur_level(orbx_ctx* ctx, int frame, int level, uint8_t* dst, size_t dst_stride);
-
-/* Stage dumps of the last extraction, for parity tests.
- *  stage 0: FAST candidates handed to the quadtree, in the reference's order (vToDistributeKeys,
- *           src/ORBextractor.cc:863-868): packed x | y<<12 | score<<24, border-relative coordinates.
- *  stage 1: keypoints kept by the quadtree, list order (src/ORBextractor.cc:758-776): same packing,
- *           level coordinates.
- * Returns the number of entries (or a negative error); dst may be NULL. */
-int orbx_debug_level_points(orbx_ctx* ctx, int frame, int level, int stage, uint32_t* dst, int cap);
-
-/* Test hook for the two float paths of the descriptor kernel: angle[i] = cv::fastAtan2(y[i], x[i]) (or y[i] itself
- * when angle_is_input), a[i] / b[i] = cosf / sinf(angle * pi/180) as the reference computes them
- * (src/ORBextractor.cc:102,111-112).  Host pointers. */
-int orbx_debug_trig(orbx_ctx* ctx, const float* y, const float* x, int n, int angle_is_input, float* angle, float* a,
-                    float* b);
-
-/* Exhaustive test hook for the device cos/sin path: *hash = order-independent 64-bit digest of
- * (cosf, sinf)(angle * pi/180) over the `count` float bit patterns starting at `first_bits`; the oracle computes the same
- * digest with the host glibc, so one call covers every angle in [0, 360] (1.13e9 floats). */
-int orbx_debug_trig_hash(orbx_ctx* ctx, uint32_t first_bits, uint32_t count, uint64_t* hash);
-
-/* The same for cv::fastAtan2: digest over `count` pseudo-random integer moment pairs (|m| <= 3e6, the range IC_Angle
- * produces; every 16th pair has m10 = 0) generated from `seed` by a fixed integer mix on both sides. */
-int orbx_debug_atan_hash(orbx_ctx* ctx, uint32_t seed, uint32_t count, uint64_t* hash);
-/* The same for the rotated test pattern of the steered BRIEF (src/ORBextractor.cc:118-120): digest of (ry, rx) of all 512 pattern points
- * over `count` consecutive float bit patterns of the keypoint angle, first_bits + i; honours the "brief_fma" option. */
-int orbx_debug_brief_hash(orbx_ctx* ctx, uint32_t first_bits, uint32_t count, uint64_t* hash);
-
-/* Test hook for the quadtree's exact std::sort: sorts elems[0..n) (n <= 2048; key = high 32 bits, payload = low 32 bits) with
- * the workgroup-parallel restatement of libstdc++'s introsort the kernel uses (src/ORBextractor.cc:697-701 sorts with
- * std::sort and a comparator that leaves ties to the library's internals), one workgroup of `threads` (64..512) threads. */
-int orbx_debug_gnu_sort(orbx_ctx* ctx, uint64_t* elems, int n, int threads);
-
-/* Counter-calibration hook: copies nbytes (multiple of 16) from d_src to d_dst on the device with `width` (1, 4 or
- * 16) bytes per lane per access — a kernel with exactly known HBM traffic, used by tools/pmc_traffic.py to calibrate
- * rocprofv3's FETCH_SIZE / WRITE_SIZE for the access widths the extractor kernels use.  Asynchronous on `stream`. */
-int orbx_debug_calib_copy(orbx_ctx* ctx, const void* d_src, void* d_dst, size_t nbytes, int width, void* stream);
+/* (Stage dumps and numeric test hooks — orbx_debug_* — are not part of this ABI: include/orbx_debug.h, liborbx_debug.so.) */
 
 /* Per-kernel device time of the extractor, measured with HIP events on the launch stream.
  * orbx_profile_enable(ctx,1) makes every following extraction record events around each kernel;
@@ -598,13 +559,11 @@ int orbx_replay_wait_gathered_host(orbx_replay* r, int i, int timeout_ms);
  * hand-shake with ranks that may be gone; the engine keeps working with the exchange off). */
 int orbx_replay_failed(const orbx_replay* r);
 int orbx_replay_abort(orbx_replay* r);
-int orbx_replay_debug_fail_at(orbx_replay* r, long long step);   /* testing: the lanes of that step fail (-1: never) */
 /* host copies (drain first): what = 0: block i, 1: gathered buffer i (world * send_bytes); orbx_replay_write_block is the reverse, for block i */
 int orbx_replay_read(orbx_replay* r, int what, int i, void* host_dst, size_t offset, size_t nbytes);
 int orbx_replay_write_block(orbx_replay* r, int i, const void* host_src, size_t offset, size_t nbytes);
 /* average device time of one step's collective (HIP events on the gather stream) since the last reset; *avg_ms = -1 when none was timed */
 int orbx_replay_gather_ms(orbx_replay* r, double* avg_ms, long long* n, int reset);
-long long orbx_replay_steps(const orbx_replay* r);
 
 #ifdef __cplusplus
 }

@@ -12,6 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ORBX_LIB", os.path.join(_HERE, "liborbx.so"))   # ORBX_LIB: experiment builds (tools/)
+DEBUG_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "liborbx_debug.so")   # the diagnostic ABI (include/orbx_debug.h): tests and tools only
 
 ORBX_OK, ORBX_E_INVALID, ORBX_E_EMPTY, ORBX_E_DEVICE, ORBX_E_CAPACITY, ORBX_E_FORMAT = 0, -1, -2, -3, -4, -5
 NUM_KERNELS = 6
@@ -55,14 +56,6 @@ def lib() -> C.CDLL:
         "orbx_pyramid_level": (i32, [vp, i32, i32, vp, sz, ip, ip]),
         "orbx_set_host_pyramid": (i32, [vp, i32]),
         "orbx_host_pyramid_level": (i32, [vp, i32, C.POINTER(vp), C.POINTER(sz), ip, ip]),
-        "orbx_debug_blur_level": (i32, [vp, i32, i32, vp, sz]),
-        "orbx_debug_level_points": (i32, [vp, i32, i32, i32, vp, i32]),
-        "orbx_debug_trig": (i32, [vp, vp, vp, i32, i32, vp, vp, vp]),
-        "orbx_debug_trig_hash": (i32, [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
-        "orbx_debug_atan_hash": (i32, [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
-        "orbx_debug_brief_hash": (i32, [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
-        "orbx_debug_calib_copy": (i32, [vp, vp, vp, sz, i32, vp]),
-        "orbx_debug_gnu_sort": (i32, [vp, vp, i32, i32]),
         "orbx_profile_enable": (i32, [vp, i32]),
         "orbx_profile_read": (i32, [vp, vp, vp]),
         "orbx_kernel_name": (C.c_char_p, [i32]),
@@ -123,7 +116,6 @@ def lib() -> C.CDLL:
         "orbx_publish_descriptors": (i32, [vp, vp, i32]),
         "orbx_kfdb_sharing": (i32, [vp, vp, i32, vp, vp, i32, ip]),
         "orbx_kfdb_score": (i32, [vp, vp, vp, i32, vp, i32, vp]),
-        "orbx_cpu_profile_count": (i32, []),
         "orbx_cpu_profile_name": (C.c_char_p, [i32]),
         "orbx_cpu_profile_description": (C.c_char_p, [C.c_char_p]),
         "orbx_cpu_profile_values": (i32, [C.c_char_p, i32, vp]),
@@ -139,7 +131,6 @@ def lib() -> C.CDLL:
         "orbx_replay_wait_gathered_host": (i32, [vp, i32, i32]),
         "orbx_replay_failed": (i32, [vp]),
         "orbx_replay_abort": (i32, [vp]),
-        "orbx_replay_debug_fail_at": (i32, [vp, C.c_longlong]),
         "orbx_replay_destroy": (None, [vp]),
         "orbx_replay_last_error": (C.c_char_p, [vp]),
         "orbx_replay_transport": (C.c_char_p, [vp]),
@@ -153,13 +144,35 @@ def lib() -> C.CDLL:
         "orbx_replay_read": (i32, [vp, i32, i32, vp, sz, sz]),
         "orbx_replay_write_block": (i32, [vp, i32, vp, sz, sz]),
         "orbx_replay_gather_ms": (i32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), i32]),
-        "orbx_replay_steps": (C.c_longlong, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here == header/library mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
     L._orbx_symbols = tuple(sig)
+    # the diagnostic ABI lives in a library of its own (the product has no debug entry point): its functions are bound onto the same object so
+    # that the mirrors' debug helpers read `L.orbx_debug_*`; without the library they raise when called
+    dsig = {
+        "orbx_debug_blur_level": (i32, [vp, i32, i32, vp, sz]),
+        "orbx_debug_level_points": (i32, [vp, i32, i32, i32, vp, i32]),
+        "orbx_debug_trig": (i32, [vp, vp, vp, i32, i32, vp, vp, vp]),
+        "orbx_debug_trig_hash": (i32, [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
+        "orbx_debug_atan_hash": (i32, [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
+        "orbx_debug_brief_hash": (i32, [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
+        "orbx_debug_calib_copy": (i32, [vp, vp, vp, sz, i32, vp]),
+        "orbx_debug_gnu_sort": (i32, [vp, vp, i32, i32]),
+    }
+    L._orbx_debug_symbols = tuple(dsig)
+    D = C.CDLL(DEBUG_LIB_PATH) if os.path.exists(DEBUG_LIB_PATH) else None
+    for name, (res, args) in dsig.items():
+        if D is not None:
+            fn = getattr(D, name)
+            fn.restype = res
+            fn.argtypes = args
+        else:
+            def fn(*_a, _n=name):
+                raise ImportError(f"{_n}: {DEBUG_LIB_PATH} not built (the diagnostic ABI is not part of liborbx.so)")
+        setattr(L, name, fn)
     L.HOST_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)   # orbx_host_exchange_fn
     _lib = L
     return L

@@ -1,4 +1,6 @@
-"""In-tree build of liborbx.so (HIP, gfx950 only).  `python -m orb_slam3_modified_amd.build [--force]`."""
+"""In-tree build of liborbx.so — the product — and of liborbx_debug.so — the diagnostic ABI (include/orbx_debug.h: stage dumps and numeric test
+hooks for the parity tests and the profiling tools; the product library has none of them).  HIP, gfx950 only.
+`python -m orb_slam3_modified_amd.build [--force]`."""
 from __future__ import annotations
 
 import os
@@ -9,6 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.environ.get("ORBX_BUILD_OUT") or os.path.join(HERE, "liborbx.so")   # ORBX_BUILD_OUT (+ ORBX_EXTRA_FLAGS): experiment builds beside the product
 SOURCES = ["orbx_extractor.hip", "orbx_matcher.hip", "orbx_search.hip", "orbx_window.hip", "orbx_kfdb.hip", "orbx_replay.hip"]
+DEBUG_OUT = os.path.join(os.path.dirname(OUT), "liborbx_debug.so")
+DEBUG_SOURCE = "orbx_debug.hip"     # = the extractor's translation unit with ORBX_DEBUG_ABI; -fvisibility=hidden: exports orbx_debug_* alone
 # -ffp-contract=off: the float paths (fastAtan2 polynomial, BRIEF rotation) must not be fused into FMAs,
 # the CPU reference evaluates them as separate IEEE operations (DESIGN.md "bit-exactness").
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",
@@ -39,10 +43,10 @@ def stamp() -> dict:
 
 
 def _stale() -> bool:
-    if not os.path.exists(OUT):
+    if not os.path.exists(OUT) or not os.path.exists(DEBUG_OUT):
         return True
-    t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "orbx.h")]
+    t = min(os.path.getmtime(OUT), os.path.getmtime(DEBUG_OUT))
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "orbx.h"), os.path.join(HERE, "..", "include", "orbx_debug.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -56,7 +60,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     objdir = os.path.join(HERE, "build") if OUT.endswith("/liborbx.so") else OUT + ".obj"
     os.makedirs(objdir, exist_ok=True)
     cflags = [f for f in FLAGS if f not in ("-shared", "-ldl")] + extra
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if not f.endswith(".hip") or f == "orbx_kernels.hip"] + [os.path.join(HERE, "..", "include", "orbx.h")]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if not f.endswith(".hip") or f == "orbx_kernels.hip"] + \
+              [os.path.join(HERE, "..", "include", "orbx.h"), os.path.join(HERE, "..", "include", "orbx_debug.h")]
     hnew = max(os.path.getmtime(h) for h in headers if os.path.isfile(h))
     tag = os.path.join(objdir, ".flags")
     flags_now = " ".join([hipcc] + cflags)
@@ -65,21 +70,27 @@ def build(force: bool = False, verbose: bool = True) -> str:
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         sp = os.path.join(CSRC, src)
-        if not force and same_flags and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(sp), hnew):
+        newest = max(os.path.getmtime(sp), hnew)
+        if src == DEBUG_SOURCE:   # it IS the extractor's translation unit
+            newest = max(newest, os.path.getmtime(os.path.join(CSRC, "orbx_extractor.hip")))
+        if not force and same_flags and os.path.exists(obj) and os.path.getmtime(obj) > newest:
             return obj
-        cmd = [hipcc] + cflags + ["-c", sp, "-o", obj]
+        cmd = [hipcc] + cflags + (["-fvisibility=hidden"] if src == DEBUG_SOURCE else []) + ["-c", sp, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd, cwd=CSRC)
         return obj
 
-    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
-        objs = list(ex.map(compile_one, SOURCES))
+    with ThreadPoolExecutor(max_workers=len(SOURCES) + 1) as ex:
+        objs = list(ex.map(compile_one, SOURCES + [DEBUG_SOURCE]))
     open(tag, "w").write(flags_now)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd, cwd=CSRC)
+    # the debug library is the extractor's translation unit alone: what that unit takes from the others (the vocabulary's device view, ...) it takes
+    # from liborbx.so at load time ($ORIGIN)
+    for out, oo, more in ((OUT, objs[:-1], []), (DEBUG_OUT, objs[-1:], ["-L", os.path.dirname(OUT), "-l:" + os.path.basename(OUT), "-Wl,-rpath,$ORIGIN"])):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + oo + more + ["-ldl"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd, cwd=CSRC)
     return OUT
 
 

@@ -345,10 +345,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
   // runs concurrently with the (latency-bound) pyramid chain; joined before the quadtree.  Off by default for a lone
   // context (no gain: both kernels fill the CUs); the replay lanes switch it on (orbx_set_option), where it pays.
   const int need = geo.max_cell_w + 3;  // +3: alignment shift of the dword-staged rows
-  // "fast_pitch" (0 = by cell width): 80 / 96 bytes for every shape are the LDS bank-conflict experiments of round 5 (HISTORY.md); only the
-  // packed 128-thread kernel is instantiated for 80
-  int pitchB = need <= 64 ? 64 : 96;
-  if (ctx->fast_pitch == 96 || (ctx->fast_pitch == 80 && need <= 80 && ctx->fast_pk && ctx->fast_threads == 128 && nframes > 4)) pitchB = std::max(pitchB, ctx->fast_pitch);   // (80: the batch kernel only; the fused single-frame launch has 64 / 96)
+  const int pitchB = need <= 64 ? 64 : 96;   // LDS pitch of the FAST tile (another pitch against the bank conflicts was measured slower: HISTORY.md, round 5)
   if (need > 96 || geo.max_cell_h > 127 + 6 || round_up((geo.max_cell_w - 6) * (geo.max_cell_h - 6), 8) > 8192)
     return set_err(ctx, ORBX_E_CAPACITY, "FAST cell larger than the kernel's LDS tile");
   if (!div_ok((uint64_t)geo.cells.size() * nframes + 8, geo.cells.size()) ||
@@ -372,27 +369,16 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
   };
   auto fast_kern = pitchB == 64 ? (ft == 64 ? k_fast_cells<64, 64> : ft == 128 ? k_fast_cells<128, 64> : k_fast_cells<256, 64>)
                                 : (ft == 64 ? k_fast_cells<64, 96> : ft == 128 ? k_fast_cells<128, 96> : k_fast_cells<256, 96>);
-  if (ctx->fast_pk && ft == 128) fast_kern = pitchB == 64 ? k_fast_cells<128, 64, true> : pitchB == 80 ? k_fast_cells<128, 80, true> : k_fast_cells<128, 96, true>;
+  if (ctx->fast_pk && ft == 128) fast_kern = pitchB == 64 ? k_fast_cells<128, 64, true> : k_fast_cells<128, 96, true>;
   if (ctx->fast_pk && ft == 64) fast_kern = pitchB == 64 ? k_fast_cells<64, 64, true> : k_fast_cells<64, 96, true>;
   auto launch_fast_range = [&](int cell_base, int ncells_sub, hipStream_t s) {
     const int nitems = ncells_sub * nframes;
     if (nitems <= 0) return;
     const FastLds f = fast_lds_of(cell_base, cell_base + ncells_sub);
-    // experiment ("fast_dma" = cells per workgroup, 0 = off): the next cell's tile by LDS-DMA while the current one is scored
-    if (ctx->fast_dma > 0 && ctx->fast_pk && ft == 128 && pitchB == 64 && ctx->fast_stop == 0 && (row_stride & 3) == 0 && (frame_stride & 3) == 0 &&
-        ((uintptr_t)d_imgs & 3) == 0) {
-      auto dk = k_fast_cells_dma<128, 64>;
-      const int cpw = ctx->fast_dma;
-      hipLaunchKernelGGL(dk, dim3(xcd_grid((nitems + cpw - 1) / cpw)), dim3(ft), f.bytes + 16 + (size_t)pitchB * f.tile_rows, s, ctx->d_geo, ctx->d_cells,
-                         d_imgs, (long long)row_stride, (long long)frame_stride, b_pyr, (long long)geo.pyr_bytes, b_cand, b_cell_cnt, ctx->ini_th,
-                         ctx->min_th, f.tile_rows, nitems, cell_base, ncells_sub, div_magic((uint32_t)ncells_sub), ctx->fast_early ? 0x100 : 0,
-                         f.list_cap, f.nwords, cpw);
-      return;
-    }
     hipLaunchKernelGGL(fast_kern, dim3(xcd_grid(nitems)), dim3(ft), f.bytes, s, ctx->d_geo, ctx->d_cells, d_imgs,
                        (long long)row_stride, (long long)frame_stride, b_pyr, (long long)geo.pyr_bytes, b_cand, b_cell_cnt,
                        ctx->ini_th, ctx->min_th, f.tile_rows, nitems, cell_base, ncells_sub, div_magic((uint32_t)ncells_sub),
-                       ctx->fast_stop | (ctx->fast_early ? 0x100 : 0) | (ctx->fast_stage_dma ? 0x200 : 0), f.list_cap, f.nwords);
+                       ctx->fast_stage_dma ? 1 : 0, f.list_cap, f.nwords);
   };
   // The cells of the small levels are taller (fewer rows of cells share the same height): one launch over all levels would give
   // every workgroup the LDS of the tallest cell and cost the many cells of the large levels their residency.  A range of cells
@@ -450,7 +436,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
   // both only read the finished pyramid — share one launch, and the assembly runs as the tail of the quadtree launch
   // (latency-bound calls only: at 32 frames of 1024 x 1024 — config 4's replay lanes, still a "small batch" by the fork rule above — the shared
   // launch with its 256-thread FAST workgroups and worst-case LDS costs 20 % of the throughput)
-  const bool small_fused = small_batch && nframes <= 4 && ctx->small_fused && !ctx->profiling && ctx->fast_stop == 0;
+  const bool small_fused = small_batch && nframes <= 4 && ctx->small_fused && !ctx->profiling;
   // K1, small batches: groups of consecutive levels in one launch each (k_resize_chain); the plan (which levels, LDS rectangles) and
   // the coverage check run on the host tables; anything the plan cannot serve takes the launch per level below
   int chained_upto = 0;   // levels 1 .. chained_upto are produced by chain launches
@@ -571,7 +557,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
     auto fk = pitchB == 64 ? (ctx->fast_pk ? k_fast_blur<64, true> : k_fast_blur<64, false>) : (ctx->fast_pk ? k_fast_blur<96, true> : k_fast_blur<96, false>);
     hipLaunchKernelGGL(fk, dim3(nfast + nblur), dim3(256), f.bytes, st, ctx->d_geo, ctx->d_cells, d_imgs, (long long)row_stride, (long long)frame_stride,
                        b_pyr, (long long)geo.pyr_bytes, b_cand, b_cell_cnt, ctx->ini_th, ctx->min_th, f.tile_rows, nfast, ncells_all,
-                       div_magic((uint32_t)ncells_all), (ctx->fast_early ? 0x100 : 0) | (ctx->fast_stage_dma ? 0x200 : 0), f.list_cap, f.nwords, b_blur, (long long)geo.blur_bytes, bc);
+                       div_magic((uint32_t)ncells_all), ctx->fast_stage_dma ? 1 : 0, f.list_cap, f.nwords, b_blur, (long long)geo.blur_bytes, bc);
   } else {
     ProfScope ps(ctx, 1, st);
     if (fork_fast0) launch_fast(ncells0, ncells_all - ncells0, st);
@@ -901,17 +887,8 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, 
     { const char* e = getenv("ORBX_BRIEF_FMA"); ctx->brief_fma = e && atoi(e) == 1 ? 1 : 0; }
     const char* fpk = getenv("ORBX_FAST_PK");   // packed 16-bit necessary test in k_fast_cells (128-thread workgroups)
     ctx->fast_pk = fpk ? atoi(fpk) != 0 : true;
-#ifdef ORBX_FAST_EARLY_OPTION
-    { const char* e = getenv("ORBX_FAST_EARLY"); ctx->fast_early = e ? atoi(e) != 0 : false; }
-#else
-    ctx->fast_early = false;   // compiled out (HISTORY.md): neither the environment variable nor orbx_set_option can switch on a knob the kernel ignores
-#endif
     { const char* e = getenv("ORBX_REALIGN"); ctx->realign = e ? atoi(e) != 0 : true; }
     { const char* e = getenv("ORBX_FAST_STAGE_DMA"); ctx->fast_stage_dma = e ? atoi(e) != 0 : true; }
-    { const char* e = getenv("ORBX_FAST_PITCH"); const int v = e ? atoi(e) : 0; ctx->fast_pitch = (v == 80 || v == 96) ? v : 0; }
-    { const char* e = getenv("ORBX_FAST_DMA"); if (e && atoi(e) >= 0 && atoi(e) <= 64) ctx->fast_dma = atoi(e); }
-    const char* fs = getenv("ORBX_FAST_STOP");
-    ctx->fast_stop = fs ? atoi(fs) : 0;
     const char* dl = getenv("ORBX_DESC_LDS");   // blurred 37x37 window staged in LDS for the descriptor taps
     ctx->desc_lds = dl ? atoi(dl) != 0 : true;
     const char* fq = getenv("ORBX_FORK_QT");
@@ -1455,14 +1432,7 @@ int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
   else if (n == "window_timing") { ctx->window_timing = value != 0; return ORBX_OK; }   // HIP events around every resident-target window pass (orbx_last_window_device_us)
   else if (n == "fast_pk") ctx->fast_pk = value != 0;
   else if (n == "realign") ctx->realign = value != 0;   // batch frames with rows that are not dword-aligned: one pass into an aligned copy first
-  else if (n == "fast_pitch" && (value == 0 || value == 80 || value == 96)) ctx->fast_pitch = value;   // LDS pitch of the FAST tile: 0 = 64 / 96 by cell width
   else if (n == "fast_stage_dma") ctx->fast_stage_dma = value != 0;   // FAST tile staged by LDS-DMA loads instead of load + ds_write
-  else if (n == "fast_dma" && value >= 0 && value <= 64) ctx->fast_dma = value;   // cells per FAST workgroup with LDS-DMA tile prefetch (0 = off; experiment)
-#ifdef ORBX_FAST_EARLY_OPTION
-  else if (n == "fast_early") ctx->fast_early = value != 0;   // wave-uniform early-out of the FAST pre-test after the compass pairs
-#else
-  else if (n == "fast_early") return set_err(ctx, ORBX_E_INVALID, "orbx_set_option: fast_early is compiled out of this build (measured at +-1 %, HISTORY.md; -DORBX_FAST_EARLY_OPTION brings it back)");
-#endif
   else if (n == "gauss_kernel" && (value == 0 || value == 1)) ctx->gauss_kernel = value;   // which OpenCV's 8-bit Gaussian weights (include/orbx.h)
   else if (n == "gauss_round" && value >= 0 && value <= 2) ctx->gauss_round = value;       // ... which rounding of the column pass
   else if (n == "gauss_tail" && (value == 0 || value == 4 || value == 8 || value == 16 || value == 32 || value == 64)) ctx->gauss_tail = value;   // ... and its scalar tail
@@ -1483,7 +1453,6 @@ int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
   else if (n == "qt_one_launch") ctx->qt_one_launch = value != 0;
   else if (n == "window_direct") ctx->window_direct = value != 0;
   else if (n == "fast_split") ctx->fast_split = value != 0;   // FAST launched per group of levels with its own LDS size (batch calls)
-  else if (n == "fast_stop") ctx->fast_stop = value;   // timing experiment: FAST returns after staging (1) / after the necessary test (2); results are void
   else if (n == "desc_lds") ctx->desc_lds = value != 0;
   else if (n == "fast_threads" && (value == 64 || value == 128 || value == 256)) ctx->fast_threads = value;
   else if (n == "qt_threads" && value >= 0 && value <= 512 && value % 64 == 0) ctx->qt_threads = value;   // 0: chosen by batch size
@@ -1531,8 +1500,7 @@ const CpuProfile* find_profile(const char* name) {
 }
 }  // namespace
 
-int orbx_cpu_profile_count(void) { return (int)(sizeof(kProfiles) / sizeof(kProfiles[0])); }
-const char* orbx_cpu_profile_name(int i) { return i >= 0 && i < orbx_cpu_profile_count() ? kProfiles[i].name : nullptr; }
+const char* orbx_cpu_profile_name(int i) { return i >= 0 && i < (int)(sizeof(kProfiles) / sizeof(kProfiles[0])) ? kProfiles[i].name : nullptr; }
 const char* orbx_cpu_profile_description(const char* name) { const CpuProfile* p = find_profile(name); return p ? p->what : nullptr; }
 
 int orbx_cpu_profile_values(const char* name, int fma_build, int values[5]) {
@@ -1591,6 +1559,33 @@ int orbx_host_pyramid_level(orbx_ctx* ctx, int level, const uint8_t** data, size
   return ORBX_OK;
 }
 
+int orbx_profile_enable(orbx_ctx* ctx, int on) {
+  if (!ctx) return ORBX_E_INVALID;
+  ctx->profiling = on != 0;
+  return ORBX_OK;
+}
+
+int orbx_profile_read(orbx_ctx* ctx, double ms[ORBX_NUM_KERNELS], int64_t launches[ORBX_NUM_KERNELS]) {
+  if (!ctx) return ORBX_E_INVALID;
+  ORBX_HIP(ctx, hipSetDevice(ctx->device));
+  ORBX_HIP(ctx, sync_ctx(ctx));
+  for (size_t i = 0; i + 3 <= ctx->ev_pool.size(); i += 3) {
+    hipEvent_t e0 = ctx->ev_pool[i], e1 = ctx->ev_pool[i + 1];
+    const int slot = (int)(intptr_t)ctx->ev_pool[i + 2] - 1;
+    float t = 0;
+    if (hipEventElapsedTime(&t, e0, e1) == hipSuccess && slot >= 0 && slot < ORBX_NUM_KERNELS) ctx->prof_ms[slot] += t;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  }
+  ctx->ev_pool.clear();
+  for (int i = 0; i < ORBX_NUM_KERNELS; i++) {
+    if (ms) ms[i] = ctx->prof_ms[i];
+    if (launches) launches[i] = ctx->prof_n[i];
+    ctx->prof_ms[i] = 0; ctx->prof_n[i] = 0;
+  }
+  return ORBX_OK;
+}
+
+#ifdef ORBX_DEBUG_ABI   // the diagnostic ABI (include/orbx_debug.h): compiled into liborbx_debug.so only (csrc/orbx_debug.hip), never into liborbx.so
 int orbx_debug_blur_level(orbx_ctx* ctx, int frame, int level, uint8_t* dst, size_t dst_stride) {
   if (!ctx || !ctx->d_geo || !dst || level < 0 || level >= ctx->nlevels || frame < 0 || frame >= ctx->last_nframes)
     return ctx ? set_err(ctx, ORBX_E_INVALID, "no such pyramid level") : ORBX_E_INVALID;
@@ -1633,32 +1628,6 @@ int orbx_debug_level_points(orbx_ctx* ctx, int frame, int level, int stage, uint
     ORBX_HIP(ctx, copy_sync(ctx, dst, ctx->d_lvl_kp + (size_t)frame * geo.kp_total + L.kp_off, sizeof(uint32_t) * std::min(n, cap),
                             hipMemcpyDeviceToHost));
   return n;
-}
-
-int orbx_profile_enable(orbx_ctx* ctx, int on) {
-  if (!ctx) return ORBX_E_INVALID;
-  ctx->profiling = on != 0;
-  return ORBX_OK;
-}
-
-int orbx_profile_read(orbx_ctx* ctx, double ms[ORBX_NUM_KERNELS], int64_t launches[ORBX_NUM_KERNELS]) {
-  if (!ctx) return ORBX_E_INVALID;
-  ORBX_HIP(ctx, hipSetDevice(ctx->device));
-  ORBX_HIP(ctx, sync_ctx(ctx));
-  for (size_t i = 0; i + 3 <= ctx->ev_pool.size(); i += 3) {
-    hipEvent_t e0 = ctx->ev_pool[i], e1 = ctx->ev_pool[i + 1];
-    const int slot = (int)(intptr_t)ctx->ev_pool[i + 2] - 1;
-    float t = 0;
-    if (hipEventElapsedTime(&t, e0, e1) == hipSuccess && slot >= 0 && slot < ORBX_NUM_KERNELS) ctx->prof_ms[slot] += t;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  }
-  ctx->ev_pool.clear();
-  for (int i = 0; i < ORBX_NUM_KERNELS; i++) {
-    if (ms) ms[i] = ctx->prof_ms[i];
-    if (launches) launches[i] = ctx->prof_n[i];
-    ctx->prof_ms[i] = 0; ctx->prof_n[i] = 0;
-  }
-  return ORBX_OK;
 }
 
 int orbx_debug_trig(orbx_ctx* ctx, const float* y, const float* x, int n, int angle_is_input, float* angle, float* a,
@@ -1753,6 +1722,8 @@ int orbx_debug_qt_profile(orbx_ctx* ctx, long long* out, int reset) {
   return 0;
 }
 #endif
+
+#endif  // ORBX_DEBUG_ABI
 
 const char* orbx_kernel_name(int slot) {
   static const char* names[ORBX_NUM_KERNELS] = {"k_resize(pyramid chain)", "k_fast_cells", "k_quadtree", "k_assemble",

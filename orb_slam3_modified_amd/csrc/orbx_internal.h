@@ -151,13 +151,11 @@ struct orbx_ctx {
   int nstreams = 1;
   hipEvent_t ev_f0_fork[2] = {nullptr, nullptr}, ev_f0_join[2] = {nullptr, nullptr};
   hipEvent_t ev_qt_fork[2] = {nullptr, nullptr}, ev_qt_join[2] = {nullptr, nullptr};
-  bool fork_blur = true, fork_fast0 = false, fork_qt = true, fast_pk = true, desc_lds = true, fast_early = false;
+  bool fork_blur = true, fork_fast0 = false, fork_qt = true, fast_pk = true, desc_lds = true;
   bool realign = true;          // batch calls: frames whose rows are not dword-aligned are copied into an aligned buffer first
   uint8_t* d_realign = nullptr;
   size_t realign_bytes = 0;
-  bool fast_stage_dma = true;   // FAST: the cell's tile by LDS-DMA loads (aligned sources; stop_after bit 9)
-  int fast_pitch = 0;   // LDS pitch of the FAST tile in bytes: 0 = 64 / 96 by cell width; 80 / 96 = for every shape (experiments)
-  int fast_dma = 0;   // experiment: cells per FAST workgroup with the next tile prefetched by LDS-DMA (0 = one cell per workgroup, no DMA)
+  bool fast_stage_dma = true;   // FAST: the cell's tile by LDS-DMA loads (aligned sources)
   int qt_points = 2048;       // LDS-resident candidate capacity per (frame, level) of k_quadtree's big levels ("qt_points" / ORBX_QT_POINTS)
   int chain_threads = 1024;   // workgroup size of k_resize_chain (ORBX_CHAIN_THREADS)
   int chain_first = 7;           // levels in the first chain launch of a single frame (2 .. 7)
@@ -179,7 +177,6 @@ struct orbx_ctx {
   bool small_fused = true;    // small batches (single-frame graph): FAST + blur in one launch, assemble as the quadtree's tail (ORBX_SMALL_FUSED=0 / "small_fused")
   int32_t* d_qt_fin = nullptr;   // per-frame finished-level counters of k_quadtree_assemble (zero between launches)
 
-  int fast_stop = 0;          // timing experiment only (orbx_set_option "fast_stop"): results are void when set
   std::string err;
 
   // geometry + device buffers for the current (rows, cols, batch capacity)

@@ -105,7 +105,6 @@ __device__ __forceinline__ void resize_tile(uint8_t* smem, const int L, const ui
     // thread = (dword column c, row phase of nph = 256 / lp4): the column-only work once, then down the column nph rows at a time
     const int lp4 = lds_pitch >> 2, swr = (sw + 3) & ~3;
     const int rph = fast_div(t, m_lp4), c = t - rph * lp4;
-#ifndef ORBX_RESIZE_NO_DMA
     // LDS-DMA loads: the LDS dword index of (row rph + k nph, column c) is t + k nph lp4 — lane-linear, as global_load_lds writes
     // (wave-uniform base + lane * 4); no staging registers, no ds_write pass
     {
@@ -122,13 +121,6 @@ __device__ __forceinline__ void resize_tile(uint8_t* smem, const int L, const ui
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-#else
-    if (rph < nph && X0 + 4 * c < swr) {
-      const uint8_t* sp = S + 4 * c;
-      uint32_t* dp = (uint32_t*)smem + c;
-      for (int r = rph; r < nrows; r += nph) dp[__mul24(r, lp4)] = *(const uint32_t*)(sp + (uint32_t)__mul24(r, src_pitch));
-    }
-#endif
   } else {
 #pragma unroll 1  // cold path: keep it out of the register budget
     for (int r = t >> 6; r < nrows; r += 4) {
@@ -394,107 +386,42 @@ __device__ __forceinline__ uint32_t fast_pretest_pk_lo(uint32_t c, uint32_t p0, 
   return as_u32(__builtin_elementwise_sub_sat(lo, maxmin)) | as_u32(__builtin_elementwise_sub_sat(minmax, hi));
 }
 
-// The same tests in two halves — the compass pairs (0,8) (4,12) first, the diagonal pairs (2,10) (6,14) second — for the wave-uniform
-// early-out of stage B ("fast_early"): {max of the pair minima, min of the pair maxima} of two opposite pairs.
-struct PkHalf { u16x2_t maxmin, minmax; };
-__device__ __forceinline__ PkHalf pk_half(uint32_t pa, uint32_t pa8, uint32_t pb, uint32_t pb8) {
-  const u16x2_t a = as_u16x2(pa), a8 = as_u16x2(pa8), b = as_u16x2(pb), b8 = as_u16x2(pb8);
-  PkHalf h;
-  h.maxmin = __builtin_elementwise_max(__builtin_elementwise_min(a, a8), __builtin_elementwise_min(b, b8));
-  h.minmax = __builtin_elementwise_min(__builtin_elementwise_max(a, a8), __builtin_elementwise_max(b, b8));
-  return h;
-}
-// lanes non-zero where the pixel passes: `hi_form` = pixels in the high byte of each 16-bit lane (odd pixels), else in the low byte
-__device__ __forceinline__ uint32_t pk_verdict(uint32_t c, const PkHalf h, uint32_t t, bool hi_form) {
-  const u16x2_t T = as_u16x2(t);
-  if (hi_form) {
-    const u16x2_t lo = __builtin_elementwise_sub_sat(as_u16x2(c & 0xff00ff00u), T);
-    const u16x2_t hi = __builtin_elementwise_add_sat(as_u16x2(c | 0x00ff00ffu), T);
-    return as_u32(__builtin_elementwise_sub_sat(lo, h.maxmin)) | as_u32(__builtin_elementwise_sub_sat(h.minmax, hi));
-  }
-  const u16x2_t lo = __builtin_elementwise_sub_sat(as_u16x2(c), T);
-  const u16x2_t hi = as_u16x2(c) + T;
-  return as_u32(__builtin_elementwise_sub_sat(lo, h.maxmin)) | as_u32(__builtin_elementwise_sub_sat(h.minmax, hi));
-}
-
 // one cell (logical item L of a launch over cells [cell_base, cell_base + ncells_sub) of every frame); T threads
-// A cell's geometry through dword loads of a uniform address: scalar loads (the 16-bit fields of a plain struct copy come by vector loads,
-// whose s_waitcnt vmcnt(0) would also wait for an LDS-DMA in flight).
-__device__ __forceinline__ CellGeom load_cell_scalar(const CellGeom* __restrict__ cells, int cell) {
-  static_assert(sizeof(CellGeom) == 40, "CellGeom layout");
-  const uint32_t* p = (const uint32_t*)(cells + cell);
-  uint32_t w[10];
-#pragma unroll
-  for (int i = 0; i < 10; i++) w[i] = p[i];
-  CellGeom cg;
-  __builtin_memcpy(&cg, w, sizeof(cg));
-  return cg;
-}
-
-// LDS atomics the compiler does not see (DMA mode only): before an LDS atomic it can prove nothing about, hipcc waits for vmcnt(0) — i.e. for the
-// LDS-DMA of the next tile — although the DMA's destination is the OTHER tile buffer.
-__device__ __forceinline__ int lds_add_rtn_opaque(int* p, int v) {
-  int r;
-  asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"((uint32_t)(size_t)(__attribute__((address_space(3))) int*)p), "v"(v) : "memory");
-  return r;
-}
-__device__ __forceinline__ void lds_or_opaque(uint32_t* p, uint32_t v) {
-  asm volatile("ds_or_b32 %0, %1" : : "v"((uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t*)p), "v"(v) : "memory");
-}
-
-// DMA = the looped kernel below: the tile has been put into `tile_dma` by LDS-DMA loads that the caller issued and waited for, `smem` starts at
-// the score plane, and every workgroup barrier is the raw form (s_waitcnt lgkmcnt(0); s_barrier) — __syncthreads() also waits for vmcnt(0)
-// and would drain the NEXT cell's tile, in flight while this one is scored.
-__device__ __forceinline__ void raw_block_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-template <bool RAW>
-__device__ __forceinline__ void cell_sync() { if constexpr (RAW) raw_block_sync(); else __syncthreads(); }
-
-template <int T, int PITCH, bool PK, bool DMA = false>
+template <int T, int PITCH, bool PK>
 __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
                                           const uint8_t* __restrict__ imgs, long long img_row_stride,
                                           long long img_frame_stride, const uint8_t* __restrict__ pyr,
                                           long long pyr_frame_bytes, uint32_t* __restrict__ cand,
                                           int32_t* __restrict__ cell_cnt, int ini_th, int min_th, int tile_rows,
-                                          int cell_base, int ncells_sub, uint32_t m_ncells_sub, int stop_after,
-                                          int list_cap, int nwords, uint8_t* tile_dma = nullptr) {
+                                          int cell_base, int ncells_sub, uint32_t m_ncells_sub, int stage_dma,
+                                          int list_cap, int nwords) {
   // LDS: [16 B pad][tile_rows][PITCH] raw pixels (+ alignment shift xo) | [tile_rows][PITCH] scores with a 1-px
   // zero frame | list | bitmap | word prefix.  PITCH is a compile-time constant so every circle / neighbour access is an
   // immediate offset.  Everything is sized by the launch for the cells it covers (tile_rows, list_cap, nwords = 64 or 256): the
   // LDS footprint of a workgroup decides how many of them a CU holds, and this kernel lives on residency.
-  uint8_t* tile = DMA ? tile_dma : smem + 16;
-  uint8_t* sc = DMA ? smem : tile + tile_rows * PITCH;
+  uint8_t* tile = smem + 16;
+  uint8_t* sc = tile + tile_rows * PITCH;
   uint16_t* list = (uint16_t*)(sc + tile_rows * PITCH);  // candidate pixels (bit 15: NMS survivor)
   uint32_t* bitmap = (uint32_t*)(list + list_cap);        // list_cap is a multiple of 8
   int* wpre = (int*)(bitmap + nwords);
   constexpr int NW = T / 64, WPT = 256 / T, P4 = PITCH / 4;
-#ifdef ORBX_FAST_ENDS
-  // Experiment of round 5 (HISTORY.md): the two waves of a workgroup keep their OWN candidate counts in scalar registers — wave 0's entries grow up
-  // from list[0], wave 1's down from list[list_cap - 1] — instead of reserving list positions with an LDS atomic per trip (the compiler's
-  // wave-aggregated form of it: nine vector instructions and a dependent LDS round trip on the critical path of every trip that finds a pixel).
-  // The later stages address entry e of n0 + n1 as e < n0 ? list[e] : list[list_cap - 1 - (e - n0)]; list order never mattered (bitmap rank).
-  constexpr bool ENDS = (T == 128) && !DMA;
-#else
-  constexpr bool ENDS = false;
-#endif
   __shared__ int wave_tot[NW];
   __shared__ int s_cnt;
-  __shared__ int s_any;
 
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   // this launch covers cells [cell_base, cell_base + ncells_sub) of every frame (level 0 runs as its own launch,
   // concurrently with the pyramid chain)
   const int frame = fast_div(L, m_ncells_sub), cell = cell_base + (L - frame * ncells_sub);
-  const CellGeom cg = DMA ? load_cell_scalar(cells, cell) : cells[cell];
+  const CellGeom cg = cells[cell];
   const uint8_t* img;
   int pitch;  // < 2^23 (checked on the host): row offsets are 24-bit multiplies
   if (cg.level == 0) { img = imgs + (long long)frame * img_frame_stride; pitch = (int)img_row_stride; }
   else { img = pyr + (long long)frame * pyr_frame_bytes + cg.plane_off; pitch = cg.pitch; }
   const int cw = cg.cw, ch = cg.ch, dw = cw - 6, dh = ch - 6;
   // ---- A: stage the sub-image with aligned dword loads when the source allows it
-  const bool al = DMA || (((pitch & 3) == 0) && ((((unsigned long long)img) & 3) == 0));   // DMA: the host only takes this path for aligned images
+  const bool al = ((pitch & 3) == 0) && ((((unsigned long long)img) & 3) == 0);
   const int xo = al ? (cg.x0 & 3) : 0;
-  if constexpr (DMA) {
-  } else if (PITCH == 64 && al && (stop_after & 0x200)) {   // a 64-byte tile pitch: one wave-instruction = four whole rows
+  if (PITCH == 64 && al && stage_dma) {   // a 64-byte tile pitch: one wave-instruction = four whole rows
     // "fast_stage_dma": the same dwords straight into the tile by LDS-DMA (global_load_lds: no staging VGPRs, no ds_write pass); lane <->
     // (row r0 + t / 16, dword t % 16), so the LDS image of one wave-instruction is 64 consecutive dwords = four tile rows.  The zeroing
     // below runs while the loads are in flight; the barrier that ends stage A waits for them (vmcnt).
@@ -507,8 +434,8 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (uint32_t)(__mul24(r, pitch) + 4 * c)),
                                          (__attribute__((address_space(3))) void*)dst, 4, 0, 0);
     }
-  } else if (PITCH != 64 && al && (stop_after & 0x200)) {
-    // any other pitch ("fast_pitch" 80 / 96: the bank-conflict experiments of round 5, HISTORY.md): the tile as a FLAT dword stream — dword
+  } else if (PITCH != 64 && al && stage_dma) {
+    // the 96-byte pitch of wide cells: the tile as a FLAT dword stream — dword
     // d = T * trip + t lands at LDS dword d (lane-linear, as global_load_lds requires) and is fetched from row d / P4, column d % P4 of the
     // source (per-lane SOURCE addresses are free; the division is by a compile-time constant); pad columns (c >= ndw) are not loaded
     const uint8_t* src = img + (long long)cg.y0 * pitch + (cg.x0 - xo);
@@ -536,27 +463,14 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
   }
   for (int i = t; i < ((dh + 2) * P4 + 3) >> 2; i += T) ((uint4*)sc)[i] = make_uint4(0u, 0u, 0u, 0u);  // sc is 16-byte aligned
   for (int i = t; i < nwords; i += T) bitmap[i] = 0;
-  if (t == 0) { s_cnt = 0; s_any = 0; }
-  if (!DMA && (stop_after & 0x200)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile's LDS-DMA loads (block-uniform)
-  cell_sync<DMA>();
-#ifdef ORBX_FAST_EARLY_OPTION
-  const int early = (stop_after >> 8) & 1;   // "fast_early": the wave-uniform early-out of stage B (same results; measured at +-1 %, HISTORY.md)
-#else
-  constexpr int early = 0;                   // the option is compiled out: its uniform branches cost the loop more than the skip ever saved
-#endif
-  stop_after &= 0xff;
-  if (stop_after == 1) {   // timing experiment only ("fast_stop" option): the cell reports no keypoint
-    if (t == 0) cell_cnt[(long long)frame * g->ncells_total + cell] = 0;
-    return;
-  }
+  if (t == 0) s_cnt = 0;
+  if (stage_dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile's LDS-DMA loads (block-uniform)
+  __syncthreads();
   // ---- B: necessary test, 4 pixels (one aligned LDS dword of centres) per lane and step; branch-free
   {
     const int kmin = (3 + xo) >> 2, kmax = (cw - 4 + xo) >> 2, ng = kmax - kmin + 1;
     const int nit = dh * ng;
     const uint32_t magic = (65536u + (uint32_t)ng - 1u) / (uint32_t)ng;  // i / ng == (i * magic) >> 16 for i < 65536 / ng
-    int wcount = 0;                                                       // ENDS: this wave's entries so far (wave-uniform: a scalar register)
-    const int wvu = __builtin_amdgcn_readfirstlane(wv);
-    uint16_t* const lend = list + (list_cap - 1);
     for (int i0 = 0; i0 < nit; i0 += T) {
       const int act = (i0 + t) < nit;
       const int i = act ? i0 + t : nit - 1;
@@ -568,16 +482,6 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
       const uint32_t Q12 = __builtin_amdgcn_alignbyte(dC, dL, 1);  // x-3 of pixel j in byte j
       constexpr uint32_t LO = 0x00ff00ffu;
       const uint32_t t_hi = (uint32_t)min_th * 0x01000100u, t_lo = (uint32_t)min_th * 0x00010001u;
-      PkHalf hcO, hcE;
-      if (PK && early) {
-        // Wave-uniform early-out: a corner needs BOTH halves of the test, so a trip in which no pixel of the wave passes the compass
-        // pairs alone (flat areas: sky, walls, the stream's flat quarter) skips the six diagonal LDS reads, the diagonal pairs, the
-        // ballots and the append.  No per-lane divergence; the compass halves are reused below.
-        hcO = pk_half(dD, dU, Q4, Q12);
-        hcE = pk_half(dD & LO, dU & LO, Q4 & LO, Q12 & LO);
-        const uint32_t some = pk_verdict(dC, hcO, t_hi, true) | pk_verdict(dC & LO, hcE, t_lo, false);
-        if (__ballot(act && some != 0u) == 0ull) continue;
-      }
       // the two diagonal pairs (2,10) and (6,14): rows +-2, columns +-2
       const uint32_t eC = rowp[2 * P4], eL = rowp[2 * P4 - 1], eR = rowp[2 * P4 + 1];
       const uint32_t fC = rowp[-2 * P4], fL = rowp[-2 * P4 - 1], fR = rowp[-2 * P4 + 1];
@@ -588,18 +492,8 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
       if constexpr (PK) {
         // pixels 1 and 3 sit in the high bytes of the raw dwords' 16-bit lanes (the low bytes are don't-cares there); pixels 0
         // and 2 are the low bytes, isolated by a mask
-        uint32_t rO, rE;
-        if (early) {
-          const PkHalf hdO = pk_half(Q2, Q10, Q6, Q14), hdE = pk_half(Q2 & LO, Q10 & LO, Q6 & LO, Q14 & LO);
-          PkHalf hO, hE;
-          hO.maxmin = __builtin_elementwise_max(hcO.maxmin, hdO.maxmin); hO.minmax = __builtin_elementwise_min(hcO.minmax, hdO.minmax);
-          hE.maxmin = __builtin_elementwise_max(hcE.maxmin, hdE.maxmin); hE.minmax = __builtin_elementwise_min(hcE.minmax, hdE.minmax);
-          rO = pk_verdict(dC, hO, t_hi, true);
-          rE = pk_verdict(dC & LO, hE, t_lo, false);
-        } else {
-          rO = fast_pretest_pk(dC, dD, dU, Q4, Q12, Q2, Q10, Q6, Q14, t_hi);
-          rE = fast_pretest_pk_lo(dC & LO, dD & LO, dU & LO, Q4 & LO, Q12 & LO, Q2 & LO, Q10 & LO, Q6 & LO, Q14 & LO, t_lo);
-        }
+        uint32_t rO = fast_pretest_pk(dC, dD, dU, Q4, Q12, Q2, Q10, Q6, Q14, t_hi);
+        uint32_t rE = fast_pretest_pk_lo(dC & LO, dD & LO, dU & LO, Q4 & LO, Q12 & LO, Q2 & LO, Q10 & LO, Q6 & LO, Q14 & LO, t_lo);
         // validity (x inside the detection domain, lane active) on the same lanes: (unsigned)(c0 + j) < dw, c0 >= -3
         const uint32_t c0a = act ? (uint32_t)c0 : 0x4000u;
         const u16x2_t C0 = as_u16x2(__builtin_amdgcn_perm(c0a, c0a, 0x01000100u));
@@ -626,11 +520,8 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
       const int tot = n0 + n1_ + n2 + n3;
       if (tot) {  // wave-uniform
         int base = 0;
-        if constexpr (ENDS) { base = wcount; wcount += tot; }
-        else {
-          if (lane == 0) base = DMA ? lds_add_rtn_opaque(&s_cnt, tot) : atomicAdd(&s_cnt, tot);
-          base = __builtin_amdgcn_readfirstlane(base);
-        }
+        if (lane == 0) base = atomicAdd(&s_cnt, tot);
+        base = __builtin_amdgcn_readfirstlane(base);
         // slot of pixel j of this lane: base + (passes of pixels < j in the wave) + (passes of pixel j in lower lanes);
         // v_mbcnt accumulates onto a scalar start value, so each slot costs two VALU instructions
         const int ent = c0 + (ry << 7);  // c0 may be negative for the first group; pixel j is only listed when c0 + j >= 0
@@ -638,34 +529,18 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
         const int o1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, base + n0));
         const int o2 = __builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, base + n0 + n1_));
         const int o3 = __builtin_amdgcn_mbcnt_hi((uint32_t)(b3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b3, base + n0 + n1_ + n2));
-        if (ENDS && wvu != 0) {   // wave-uniform: the second wave fills the list from its far end
-          if (ps[0]) lend[-o0] = (uint16_t)ent;
-          if (ps[1]) lend[-o1] = (uint16_t)(ent + 1);
-          if (ps[2]) lend[-o2] = (uint16_t)(ent + 2);
-          if (ps[3]) lend[-o3] = (uint16_t)(ent + 3);
-        } else {
-          if (ps[0]) list[o0] = (uint16_t)ent;
-          if (ps[1]) list[o1] = (uint16_t)(ent + 1);
-          if (ps[2]) list[o2] = (uint16_t)(ent + 2);
-          if (ps[3]) list[o3] = (uint16_t)(ent + 3);
-        }
+        if (ps[0]) list[o0] = (uint16_t)ent;
+        if (ps[1]) list[o1] = (uint16_t)(ent + 1);
+        if (ps[2]) list[o2] = (uint16_t)(ent + 2);
+        if (ps[3]) list[o3] = (uint16_t)(ent + 3);
       }
     }
-    if (ENDS && lane == 0) wave_tot[wvu] = wcount;
   }
-  cell_sync<DMA>();
-  if (stop_after == 2) {
-    if (t == 0) cell_cnt[(long long)frame * g->ncells_total + cell] = 0;
-    return;
-  }
-  int n0 = 0, n1;
-  if constexpr (ENDS) { n0 = wave_tot[0]; n1 = n0 + wave_tot[NW - 1]; } else n1 = s_cnt;
-  // entry e of the n1 listed pixels (ENDS: the second wave's entries sit at the far end of the list, last first)
-  const int lflip = list_cap - 1 + n0;
-  auto entry = [&](int e) -> uint16_t& { return list[ENDS ? (e < n0 ? e : lflip - e) : e]; };
+  __syncthreads();
+  const int n1 = s_cnt;
   // ---- C: exact score of the listed pixels
   for (int e = t; e < n1; e += T) {
-    const int ent = entry(e);
+    const int ent = list[e];
     const int x = ent & 127, y = ent >> 7;
     const uint8_t* c0 = tile + y * PITCH + (x + xo);  // top-left of the 7x7 window; centre = c0[3 * PITCH + 3]
     const int v = c0[3 * PITCH + 3];
@@ -677,11 +552,11 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
     const int s = fast_score16(v, p);
     if (s >= min_th && s > 0) sc[(y + 1) * PITCH + (x + 1)] = (uint8_t)s;
   }
-  cell_sync<DMA>();
+  __syncthreads();
   // ---- D: 3x3 strict NMS inside the cell (neighbours outside the detection domain are 0)
   int any_ini = 0;
   for (int e = t; e < n1; e += T) {
-    const int ent = entry(e);
+    const int ent = list[e];
     const int x = ent & 127, y = ent >> 7;
     const uint8_t* q = sc + y * PITCH + x;  // top-left of the 3x3 window
     const int s = q[PITCH + 1];
@@ -689,28 +564,25 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
       const int m = max(max(max((int)q[0], (int)q[1]), max((int)q[2], (int)q[PITCH])),
                         max(max((int)q[PITCH + 2], (int)q[2 * PITCH]), max((int)q[2 * PITCH + 1], (int)q[2 * PITCH + 2])));
       if (s > m) {
-        entry(e) = (uint16_t)(ent | 0x8000);
+        list[e] = (uint16_t)(ent | 0x8000);
         any_ini |= s >= ini_th;
       }
     }
   }
-  int use_ini;
-  if constexpr (DMA) { if (any_ini) s_any = 1; raw_block_sync(); use_ini = s_any; }
-  else use_ini = __syncthreads_or(any_ini);
+  const int use_ini = __syncthreads_or(any_ini);
   const int TH = use_ini ? ini_th : min_th;
   // ---- E: bitmap of the selected survivors (bit index = row-major pixel index)
   for (int e = t; e < n1; e += T) {
-    const int le = entry(e);
+    const int le = list[e];
     if (le & 0x8000) {
       const int x = le & 127, y = (le >> 7) & 127;
       const int i = y * dw + x;
       if (sc[(y + 1) * PITCH + (x + 1)] >= TH) {
-        if constexpr (DMA) lds_or_opaque(&bitmap[i >> 5], 1u << (i & 31));
-        else atomicOr(&bitmap[i >> 5], 1u << (i & 31));
+        atomicOr(&bitmap[i >> 5], 1u << (i & 31));
       }
     }
   }
-  cell_sync<DMA>();
+  __syncthreads();
   // ---- F: exclusive popcount prefix over the bitmap words
   const int npx = dw * dh;
   if (npx <= 2048) {  // block-uniform; the usual case: <= 64 words, one wave scans them, the others go straight on
@@ -730,7 +602,7 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
     if (lane == 63) wave_tot[wv] = inc;
-    cell_sync<DMA>();
+    __syncthreads();
     int off = 0, tot = 0;
 #pragma unroll
     for (int k = 0; k < NW; k++) { const int wt = wave_tot[k]; off += k < wv ? wt : 0; tot += wt; }
@@ -739,11 +611,11 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
     for (int k = 0; k < WPT; k++) { wpre[t * WPT + k] = run; run += cw_[k]; }
     if (t == 0) cell_cnt[(long long)frame * g->ncells_total + cell] = tot;
   }
-  cell_sync<DMA>();
+  __syncthreads();
   // ---- G: row-major rank of every selected survivor -> its slot
   uint32_t* slot = cand + (long long)frame * g->cand_total + cg.slot_off;
   for (int e = t; e < n1; e += T) {
-    const int le = entry(e);
+    const int le = list[e];
     if (le & 0x8000) {
       const int x = le & 127, y = (le >> 7) & 127;
       const int s = sc[(y + 1) * PITCH + (x + 1)];
@@ -762,70 +634,13 @@ __global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__
                                                   long long img_frame_stride, const uint8_t* __restrict__ pyr,
                                                   long long pyr_frame_bytes, uint32_t* __restrict__ cand,
                                                   int32_t* __restrict__ cell_cnt, int ini_th, int min_th, int tile_rows,
-                                                  int nitems, int cell_base, int ncells_sub, uint32_t m_ncells_sub, int stop_after,
+                                                  int nitems, int cell_base, int ncells_sub, uint32_t m_ncells_sub, int stage_dma,
                                                   int list_cap, int nwords) {
   extern __shared__ __align__(16) uint8_t smem[];
   const int L = xcd_logical_block(nitems);
   if (L < 0) return;  // block-uniform
   fast_cell<T, PITCH, PK>(smem, L, g, cells, imgs, img_row_stride, img_frame_stride, pyr, pyr_frame_bytes, cand, cell_cnt, ini_th, min_th, tile_rows,
-                          cell_base, ncells_sub, m_ncells_sub, stop_after, list_cap, nwords);
-}
-
-// The cells as a loop of `cpw` consecutive logical items per workgroup with the NEXT cell's tile arriving by LDS-DMA (global_load_lds: no
-// VGPRs, no ds_write pass) into a second tile buffer while the current cell is scored ("fast_dma" option: an experiment, see HISTORY.md).
-// LDS: [16 B pad][tile 0][16 B pad][tile 1][score plane | list | bitmap | word prefix].  Aligned sources and the 64-byte tile pitch only
-// (the host checks): one wave-instruction of the DMA writes 64 consecutive dwords = four whole tile rows.
-template <int T, int PITCH>
-__device__ __forceinline__ void fast_dma_issue(uint8_t* tile, const int L, const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
-                                               const uint8_t* __restrict__ imgs, long long img_row_stride, long long img_frame_stride,
-                                               const uint8_t* __restrict__ pyr, long long pyr_frame_bytes, int cell_base, int ncells_sub,
-                                               uint32_t m_ncells_sub) {
-  const int t = threadIdx.x;
-  const int frame = fast_div(L, m_ncells_sub), cell = cell_base + (L - frame * ncells_sub);
-  const CellGeom cg = load_cell_scalar(cells, cell);
-  const uint8_t* img;
-  int pitch;
-  if (cg.level == 0) { img = imgs + (long long)frame * img_frame_stride; pitch = (int)img_row_stride; }
-  else { img = pyr + (long long)frame * pyr_frame_bytes + cg.plane_off; pitch = cg.pitch; }
-  const int xo = cg.x0 & 3, ndw = (xo + cg.cw + 3) >> 2, ch = cg.ch;
-  const uint8_t* src = img + (long long)cg.y0 * pitch + (cg.x0 - xo);
-  // lane <-> (row r0 + t / 16, dword t % 16): the LDS image of one wave-instruction is 64 consecutive dwords = four tile rows
-  for (int r0 = 0; r0 < ch; r0 += T / 16) {
-    const int r = r0 + (t >> 4), c = t & 15;
-    uint8_t* dst = tile + (size_t)(r0 * 16 + (t & ~63)) * 4;   // wave-uniform; the hardware adds lane * 4
-    if (r < ch && c < ndw)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (uint32_t)(__mul24(r, pitch) + 4 * c)),
-                                       (__attribute__((address_space(3))) void*)dst, 4, 0, 0);
-  }
-}
-
-template <int T, int PITCH>
-__global__ __launch_bounds__(T, 6) void k_fast_cells_dma(const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
-                                                         const uint8_t* __restrict__ imgs, long long img_row_stride,
-                                                         long long img_frame_stride, const uint8_t* __restrict__ pyr,
-                                                         long long pyr_frame_bytes, uint32_t* __restrict__ cand,
-                                                         int32_t* __restrict__ cell_cnt, int ini_th, int min_th, int tile_rows,
-                                                         int nitems, int cell_base, int ncells_sub, uint32_t m_ncells_sub, int early,
-                                                         int list_cap, int nwords, int cpw) {
-  extern __shared__ __align__(16) uint8_t smem[];
-  const int G = xcd_logical_block((nitems + cpw - 1) / cpw);
-  if (G < 0) return;  // block-uniform
-  const int L0 = G * cpw, n = min(cpw, nitems - L0);
-  uint8_t* tile0 = smem + 16;
-  uint8_t* tile1 = tile0 + tile_rows * PITCH + 16;
-  uint8_t* rest = tile1 + tile_rows * PITCH;
-  fast_dma_issue<T, PITCH>(tile0, L0, g, cells, imgs, img_row_stride, img_frame_stride, pyr, pyr_frame_bytes, cell_base, ncells_sub, m_ncells_sub);
-#pragma unroll 1
-  for (int i = 0; i < n; i++) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of tile i has landed ...
-    raw_block_sync();                                  // ... and so has everybody else's
-    if (i + 1 < n)   // the other buffer was last read in iteration i - 1, which ended with a barrier
-      fast_dma_issue<T, PITCH>((i & 1) ? tile0 : tile1, L0 + i + 1, g, cells, imgs, img_row_stride, img_frame_stride, pyr, pyr_frame_bytes, cell_base,
-                               ncells_sub, m_ncells_sub);
-    fast_cell<T, PITCH, true, true>(rest, L0 + i, g, cells, imgs, img_row_stride, img_frame_stride, pyr, pyr_frame_bytes, cand, cell_cnt, ini_th, min_th,
-                                    tile_rows, cell_base, ncells_sub, m_ncells_sub, early, list_cap, nwords, (i & 1) ? tile1 : tile0);
-    raw_block_sync();
-  }
+                          cell_base, ncells_sub, m_ncells_sub, stage_dma, list_cap, nwords);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -844,14 +659,6 @@ __device__ long long g_qt_prof[kMaxLevels * 8];
 #endif
 
 constexpr unsigned long long kM21 = (1ull << 21) - 1ull;
-#ifndef ORBX_QT_SYNC_SORT
-#define ORBX_QT_SYNC_SORT 1
-#endif
-constexpr bool kQtSyncSort = ORBX_QT_SYNC_SORT != 0;
-#ifndef ORBX_QT_FUSED_PASSES
-#define ORBX_QT_FUSED_PASSES 1
-#endif
-constexpr bool kQtFusedPasses = ORBX_QT_FUSED_PASSES != 0;   // A/B: -DORBX_QT_FUSED_PASSES=0 restores one barrier-separated pass per tree level   // A/B: -DORBX_QT_SYNC_SORT=0 restores the one-segment-at-a-time wave sort
 
 __device__ __forceinline__ unsigned long long block_excl_scan(unsigned long long* a, int n, unsigned long long* wt) {
   const int T = blockDim.x, t = threadIdx.x, lane = t & 63, w = t >> 6, NW = T >> 6;
@@ -1208,7 +1015,7 @@ __device__ __forceinline__ void block_gnu_sort(unsigned long long* v, int n, uns
       for (int sidx = w; sidx < ncur; sidx += NW) {
         const unsigned long long pk = q0[sidx];
         const int f = (int)(pk & 0xffffull), l = (int)((pk >> 16) & 0xffffull), d = (int)(pk >> 32);
-        if (l - f <= 64 && kQtSyncSort) {  // a block of <= 64 positions: all its segments step together, in registers, without LDS
+        if (l - f <= 64) {  // a block of <= 64 positions: all its segments step together, in registers, without LDS
           wave_introsort_sync(v, f, l, d, seg);
           continue;
         }
@@ -1440,7 +1247,7 @@ __device__ __forceinline__ void quadtree_body(const DeviceGeom* __restrict__ g, 
   if constexpr (LP) for (int e = t; e < n; e += T) nid[e] = 0;
   // the fused first passes (below) count, per 64-point chunk, the points of every depth-3 class: the table starts from zero
   const int fz_nch = (n + 63) >> 6;
-  const bool fused_ok = LP && kQtFusedPasses && !(level_base & 0x200) && lv.nroots == 1 && n <= 2048 && fz_nch * 128 <= node_cap * (int)sizeof(QNode) &&
+  const bool fused_ok = LP && !(level_base & 0x200) && lv.nroots == 1 && n <= 2048 && fz_nch * 128 <= node_cap * (int)sizeof(QNode) &&
                         fz_nch * 64 <= node_cap * (int)sizeof(int4) && node_cap >= 64;   // block-uniform
   if (fused_ok) for (int e = t; e < fz_nch * 16; e += T) ((uint32_t*)kids)[e] = 0u;
   __syncthreads();
@@ -2179,10 +1986,8 @@ __device__ __forceinline__ void quadtree_main(const DeviceGeom* __restrict__ g, 
     quadtree_body<false>(g, cells, fcand, gcur, gnxt, lpts, lpts + pts_cap, lvl_kp, lvl_n, node_cap, scan_cap, nb, n, wt, sh_cnt, sh_jstar, level_base, pts_cap);
 }
 
-#ifndef ORBX_QT_WPE
-#define ORBX_QT_WPE 1   // no register cap: capping at 128 VGPRs (4 waves per SIMD) is 5 % faster in a batch but spills 36 bytes to scratch, and a kernel with a private segment pays a scratch set-up on every queue that first runs it
-#endif
-__global__ __launch_bounds__(512, ORBX_QT_WPE) void k_quadtree(const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
+// (no register cap: capping at 128 VGPRs — 4 waves per SIMD — was measured at +-1 % in a batch and spills to scratch; HISTORY.md, round 5)
+__global__ __launch_bounds__(512, 1) void k_quadtree(const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
                                                   const uint32_t* __restrict__ cand, const int32_t* __restrict__ cell_cnt,
                                                   uint32_t* __restrict__ pts, uint32_t* __restrict__ lvl_kp,
                                                   int32_t* __restrict__ lvl_n, int node_cap, int scan_cap, int pts_cap, int level_base,
@@ -2201,6 +2006,7 @@ __global__ __launch_bounds__(512, ORBX_QT_WPE) void k_quadtree(const DeviceGeom*
   }
 }
 
+#ifdef ORBX_DEBUG_ABI
 // Test hook: block_gnu_sort on caller data (n <= 2048), one workgroup.
 __global__ __launch_bounds__(512) void k_debug_gnu_sort(unsigned long long* __restrict__ data, int n) {
   __shared__ unsigned long long sv[2048], stmp[2048], sq[2 * (2048 / 16 + 2)];
@@ -2212,6 +2018,8 @@ __global__ __launch_bounds__(512) void k_debug_gnu_sort(unsigned long long* __re
   block_gnu_sort(sv, n, stmp, sseg, sq, sq + (2048 / 16 + 2), sidx, &scnt);
   for (int i = threadIdx.x; i < n; i += blockDim.x) data[i] = sv[i];
 }
+
+#endif  // ORBX_DEBUG_ABI
 
 // ------------------------------------------------------------------------------------------------
 // K3b: output slots (src/ORBextractor.cc:1122,1143-1164)
@@ -2288,7 +2096,7 @@ struct QtaArgs {
   // the tail's own arguments: read from the kernel-argument segment AFTER the quadtree (see below)
   uint2* kp_list; int32_t* counts; int lap0, lap1; int* fin; int32_t* mirror_counts;
 };
-__global__ __launch_bounds__(512, ORBX_QT_WPE) void k_quadtree_assemble(const QtaArgs a) {
+__global__ __launch_bounds__(512, 1) void k_quadtree_assemble(const QtaArgs a) {
   extern __shared__ __align__(16) uint8_t smem[];
   __shared__ unsigned long long wt[16];
   __shared__ int sh_cnt[kMaxRoots];
@@ -2400,7 +2208,6 @@ __device__ __forceinline__ void blur_tile(const int L, const DeviceGeom* __restr
     // reflected columns are patched below
     // thread = (column c of 18 dwords, row phase of 14): everything that depends on the column only is computed once,
     // the thread then walks down its column 14 rows at a time (252 of the 256 threads take part)
-#ifndef ORBX_BLUR_NO_DMA
     if (y0 >= 3 && y0 - 3 + kBT_RR <= h) {   // block-uniform: an interior tile, every source row exists
       // LDS-DMA loads: thread = (row phase of 10, dword column of the 24-dword LDS row): the LDS dword index of (row rph + 10 k, column c) is
       // t + 240 k — lane-linear.  The six dwords per row that hold no pixel and the dwords left / right of the level are not loaded (never
@@ -2420,9 +2227,7 @@ __device__ __forceinline__ void blur_tile(const int L, const DeviceGeom* __restr
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else
-#endif
-    if (t < 14 * (kBT_RB / 4)) {
+    } else if (t < 14 * (kBT_RB / 4)) {
       const int rph = (int)(((uint32_t)t * 3641u) >> 16), c = t - rph * (kBT_RB / 4);  // t / 18
       const int sx = x0 - 4 + 4 * c;
       const bool inx = sx >= 0 && sx < w;
@@ -2565,13 +2370,13 @@ __global__ __launch_bounds__(256) void k_fast_blur(const DeviceGeom* __restrict_
                                                    const uint8_t* __restrict__ imgs, long long img_row_stride, long long img_frame_stride,
                                                    const uint8_t* __restrict__ pyr, long long pyr_frame_bytes, uint32_t* __restrict__ cand,
                                                    int32_t* __restrict__ cell_cnt, int ini_th, int min_th, int tile_rows, int nfast, int ncells,
-                                                   uint32_t m_ncells, int stop_after, int list_cap, int nwords, uint8_t* __restrict__ blur,
+                                                   uint32_t m_ncells, int stage_dma, int list_cap, int nwords, uint8_t* __restrict__ blur,
                                                    long long blur_frame_bytes, BlurConsts bc) {
   extern __shared__ __align__(16) uint8_t smem[];
   const int b = (int)blockIdx.x;
   if (b < nfast)   // block-uniform
     fast_cell<256, PITCH, PK>(smem, b, g, cells, imgs, img_row_stride, img_frame_stride, pyr, pyr_frame_bytes, cand, cell_cnt, ini_th, min_th, tile_rows, 0,
-                              ncells, m_ncells, stop_after, list_cap, nwords);
+                              ncells, m_ncells, stage_dma, list_cap, nwords);
   else
     blur_tile(b - nfast, g, imgs, img_row_stride, img_frame_stride, pyr, pyr_frame_bytes, blur, blur_frame_bytes, bc);
 }
@@ -2828,38 +2633,6 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
       // Variant: the 37 x 37 window of the blurred level staged in this wave's LDS slice (37 rows x 10 aligned dwords,
       // coalesced loads), the 512 taps read from LDS instead of 8 scattered byte gathers per lane.  The window starts at
       // the dword below kx - 18: at most 2 bytes before / after the row, inside the plane's pitch or the neighbouring row.
-#ifdef ORBX_DESC_DBUF
-      // Experiment of round 5 (measured in HISTORY.md): TWO slices per wave — keypoint k + 1's window is put in flight
-      // (LDS-DMA) before keypoint k's taps are read, so that its HBM / L2 latency runs under k's 512 taps instead of in front of its own.
-      __shared__ __align__(16) uint8_t s_patch[4][2][37 * 40];
-      auto issue_window = [&](int kk, uint8_t* dstslice) {   // wave-uniform arguments
-        const uint32_t pp = __builtin_amdgcn_readlane(rec.x, kk);
-        const int ll = (int)(__builtin_amdgcn_readlane(rec.y, kk) & 0xffu);
-        const DeviceLevel& lw = g->lv[ll];
-        const uint8_t* bpl = blur + (long long)frame * blur_frame_bytes + lw.bplane_off;
-        const int kxx = pt_x(pp), kyy = pt_y(pp), bpp = lw.pitch;
-        const uint32_t wb = (uint32_t)(__mul24(kyy - 18, bpp) + (kxx - 18 - ((kxx - 18) & 3)));
-        const int rph = (int)(((uint32_t)lane * 6554u) >> 16), dcol = lane - rph * 10;  // lane / 10
-        uint32_t off = wb + (uint32_t)(__mul24(rph, bpp) + 4 * dcol);
-        const uint32_t step = 6u * (uint32_t)bpp;
-#pragma unroll
-        for (int q = 0; q < 7; q++) {
-          if (lane < 60 && rph + 6 * q < 37)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bpl + off),
-                                             (__attribute__((address_space(3))) void*)((uint32_t*)dstslice + 60 * q), 4, 0, 0);
-          off += step;
-        }
-      };
-      if (k == 0) issue_window(0, s_patch[w][0]);
-      uint8_t* sp = s_patch[w][k & 1];
-      const int sh2 = (kx - 18) & 3;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // window k (issued one keypoint ago) and the stores of keypoint k - 1
-      wave_lds_sync();                                      // ... also: everybody is done reading slice (k + 1) & 1 (keypoint k - 1's)
-      if (k + 1 < nk) issue_window(k + 1, s_patch[w][(k + 1) & 1]);
-      const int lctr = 18 * 40 + 18 + sh2;
-      if (brief_fma) brief_taps<true, true>(sp, lctr, 40, pat, a, b, t0, t1);   // uniform (kernel argument)
-      else brief_taps<false, true>(sp, lctr, 40, pat, a, b, t0, t1);
-#else
       __shared__ __align__(16) uint8_t s_patch[4][37 * 40];
       uint8_t* sp = s_patch[w];
       const int sh2 = (kx - 18) & 3;
@@ -2868,10 +2641,7 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
         const int rph = (int)(((uint32_t)lane * 6554u) >> 16), dcol = lane - rph * 10;  // lane / 10
         uint32_t off = wbase + (uint32_t)(__mul24(rph, bp) + 4 * dcol);
         const uint32_t step = 6u * (uint32_t)bp;
-        uint32_t* lp = (uint32_t*)sp + lane;   // row rph, column dcol
-#ifndef ORBX_DESC_NO_DMA
         // LDS-DMA loads: the slice's dword index is lane + 60 k — lane-linear, as global_load_lds writes it
-        (void)lp;
 #pragma unroll
         for (int k = 0; k < 7; k++) {
           if (lane < 60 && rph + 6 * k < 37)
@@ -2880,22 +2650,12 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
           off += step;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
-        if (lane < 60) {
-#pragma unroll
-          for (int k = 0; k < 7; k++) {
-            if (rph + 6 * k < 37) lp[60 * k] = *(const uint32_t*)(bplane + off);
-            off += step;
-          }
-        }
-#endif
       }
       wave_lds_sync();
       const int lctr = 18 * 40 + 18 + sh2;
       if (brief_fma) brief_taps<true, true>(sp, lctr, 40, pat, a, b, t0, t1);   // uniform (kernel argument)
       else brief_taps<false, true>(sp, lctr, 40, pat, a, b, t0, t1);
       wave_lds_sync();   // the next keypoint overwrites the slice
-#endif
     } else {
       if (brief_fma) brief_taps<true, false>(bplane, ctr, bp, pat, a, b, t0, t1);
       else brief_taps<false, false>(bplane, ctr, bp, pat, a, b, t0, t1);
@@ -2922,6 +2682,7 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
   }
 }
 
+#ifdef ORBX_DEBUG_ABI
 // Debug/test kernel: the two float paths of K4 in isolation (fastAtan2, then glibc-exact cosf/sinf of
 // angle*factorPI) so tests can sweep far more arguments than real frames produce.
 __global__ void k_debug_trig(const float* __restrict__ y, const float* __restrict__ x, int n, int angle_is_input,
@@ -2995,6 +2756,8 @@ __global__ __launch_bounds__(256) void k_debug_brief_hash(uint32_t first, uint32
   if ((threadIdx.x & 63) == 0) atomicAdd(out, h);
 }
 
+#endif  // ORBX_DEBUG_ABI
+
 // cv::resize's INTER_AREA shortcut for an exact 2 x 2 downscale (the rounded mean of each block): image ingestion only
 // (src/System.cc:441-446); the pyramid's scale factor never hits it.
 __global__ __launch_bounds__(256) void k_box2(const uint8_t* __restrict__ src, int src_pitch, uint8_t* __restrict__ dst, int dst_pitch, int dw,
@@ -3026,6 +2789,7 @@ __global__ __launch_bounds__(256) void k_color_to_gray(const uint8_t* __restrict
   *(uint32_t*)(dst + (long long)blockIdx.z * dst_frame_stride + (long long)y * dst_pitch + x4) = packed;  // pitch is a multiple of 64
 }
 
+#ifdef ORBX_DEBUG_ABI
 // Calibration kernel for the rocprofv3 FETCH_SIZE / WRITE_SIZE counters (MI355X_MICROARCH.md "HBM": the counters
 // are only calibrated for wide streaming reads): copies n bytes with W bytes per lane per access (W = 1, 4, 16),
 // i.e. a kernel whose HBM traffic is known exactly, in the access widths the extractor kernels use.
@@ -3034,5 +2798,6 @@ __global__ __launch_bounds__(256) void k_calib_copy(const T* __restrict__ src, T
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
     dst[i] = src[i];
 }
+#endif  // ORBX_DEBUG_ABI
 
 }  // namespace orbx

@@ -114,7 +114,6 @@ struct orbx_replay {
   // failure containment: once a lane failed, this rank keeps taking part in every step's exchange with a POISONED block (all counts -1), so that
   // the other ranks' collectives complete; every later step returns the first error again
   int failed_code = 0; std::string failed_msg;
-  long long inject_fail_step = -1;             // testing: the lanes of that step "fail" (orbx_replay_debug_fail_at)
   // transport
   RcclComm comm = nullptr;
   orbx_host_exchange_fn host_fn = nullptr; void* host_user = nullptr;
@@ -365,19 +364,17 @@ int orbx_replay_step(orbx_replay* r, const uint8_t* d_frames, size_t row_stride,
   // no extraction produces, so a reader of the gathered buffer sees which rank dropped out at which step; the caller of THIS rank gets the
   // lane's error from this call and from every later one (orbx_replay_failed), and decides when to leave (orbx_replay_destroy after the
   // others have been told over the host's own control plane, or orbx_replay_abort).
-  const bool inject = r->inject_fail_step >= 0 && (long long)r->step_idx == r->inject_fail_step;
   for (size_t j = 0; j < r->lanes.size() && !r->failed_code; j++) {
     const int f0 = r->ranges[j].first, f1 = r->ranges[j].second;
     // the collective that last read this block must be done before a lane overwrites it (a device-side wait: no host stall)
     if (r->pending[i]) RHIP(r, hipStreamWaitEvent(r->streams[j], r->gather_done[i], 0));
-    const int rc = inject ? ORBX_E_DEVICE
-                          : orbx_extract_batch_device(r->lanes[j], d_frames + (size_t)f0 * frame_stride, f1 - f0, r->rows, r->cols, row_stride, frame_stride, lap0, lap1,
-                                                      (orbx_keypoint*)(base + (size_t)f0 * r->cap * sizeof(orbx_keypoint)), base + r->desc_off + (size_t)f0 * r->cap * 32,
-                                                      (int32_t*)(base + r->counts_off + (size_t)f0 * 8), r->streams[j]);
+    const int rc = orbx_extract_batch_device(r->lanes[j], d_frames + (size_t)f0 * frame_stride, f1 - f0, r->rows, r->cols, row_stride, frame_stride, lap0, lap1,
+                                             (orbx_keypoint*)(base + (size_t)f0 * r->cap * sizeof(orbx_keypoint)), base + r->desc_off + (size_t)f0 * r->cap * 32,
+                                             (int32_t*)(base + r->counts_off + (size_t)f0 * 8), r->streams[j]);
     if (rc != ORBX_OK) {
       r->failed_code = rc;
       r->failed_msg = std::string("orbx_replay_step: step ") + std::to_string(r->step_idx) + ", lane " + std::to_string(j) + ": " +
-                      (inject ? "failure injected by orbx_replay_debug_fail_at" : orbx_last_error(r->lanes[j]));
+                      orbx_last_error(r->lanes[j]);
     }
   }
   if (r->failed_code) {
@@ -432,12 +429,6 @@ int orbx_replay_step(orbx_replay* r, const uint8_t* d_frames, size_t row_stride,
 
 // ---- failure containment (see orbx_replay_step)
 int orbx_replay_failed(const orbx_replay* r) { return r ? r->failed_code : ORBX_E_INVALID; }
-
-int orbx_replay_debug_fail_at(orbx_replay* r, long long step) {
-  if (!r) return ORBX_E_INVALID;
-  r->inject_fail_step = step;
-  return ORBX_OK;
-}
 
 // Leaving a group whose other ranks may be gone: ncclCommAbort frees the communicator WITHOUT the collective hand-shake of ncclCommDestroy and
 // releases collectives of this rank that are stuck on the gather stream.  The engine keeps working with the exchange off.
@@ -551,6 +542,5 @@ int orbx_replay_gather_ms(orbx_replay* r, double* avg_ms, long long* n, int rese
   return ORBX_OK;
 }
 
-long long orbx_replay_steps(const orbx_replay* r) { return r ? (long long)r->step_idx : -1; }
 
 }  // extern "C"

@@ -244,8 +244,10 @@ class ORBextractor:
         """{name: (description, option values with fma_build = 0)} of every named profile (host-only table: no device needed)."""
         L = _lib.lib()
         out = {}
-        for i in range(L.orbx_cpu_profile_count()):
+        for i in range(64):
             nm = L.orbx_cpu_profile_name(i)
+            if not nm:      # NULL ends the table
+                break
             v = np.zeros(5, np.int32)
             check(L.orbx_cpu_profile_values(nm, 0, ptr(v)))
             out[nm.decode()] = (L.orbx_cpu_profile_description(nm).decode(), tuple(int(x) for x in v))

@@ -245,9 +245,6 @@ class ReplayEngine:
         self._check(self._L.orbx_replay_abort(self._h))
         self._gather = False
 
-    def debug_fail_at(self, step: int):
-        self._check(self._L.orbx_replay_debug_fail_at(self._h, int(step)))
-
     def reset_gather_timing(self):
         self._check(self._L.orbx_replay_gather_ms(self._h, None, None, 1))
 

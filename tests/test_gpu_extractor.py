@@ -546,14 +546,12 @@ def test_batches_of_frames_with_odd_row_strides(rows, cols, realign):
         assert np.array_equal(gpu.pyramid_level(l, frame=2), ora.level(l)), (cols, rows, realign, l)
 
 
-@pytest.mark.parametrize("opts", [dict(fast_stage_dma=1), dict(fast_stage_dma=0), dict(fast_dma=1), dict(fast_dma=3), dict(fast_dma=8, fast_stage_dma=0),
-                                  dict(fast_pitch=80), dict(fast_pitch=96), dict(fast_pitch=80, fast_stage_dma=0), dict(fast_pitch=96, fast_stage_dma=0)])
+@pytest.mark.parametrize("opts", [dict(fast_stage_dma=1), dict(fast_stage_dma=0), dict(fast_stage_dma=1, fast_pk=0), dict(fast_stage_dma=0, fast_threads=64)])
 def test_fast_tile_staging_variants(opts):
-    """How a FAST cell's tile reaches LDS: LDS-DMA loads (global_load_lds, the default on aligned sources and the 64-byte tile pitch), plain
-    loads + ds_write (the fall-back: odd strides, wide cells), or the looped kernel with the NEXT cell's tile in flight while the current one is
-    scored ("fast_dma" = cells per workgroup: raw barriers, LDS atomics the compiler does not see) — same keypoints and descriptors on batches
-    and single frames, on an image whose row stride is odd, and on a geometry whose cells need the 96-byte tile pitch.  "fast_pitch" 80 / 96:
-    the tile on another LDS pitch for every shape, staged as a flat dword stream (the bank-conflict experiments of round 5)."""
+    """How a FAST cell's tile reaches LDS: LDS-DMA loads (global_load_lds, the default on aligned sources: four whole rows per wave-instruction
+    on the 64-byte tile pitch, a flat dword stream on the 96-byte pitch of wide cells) or plain loads + ds_write (odd strides) — same keypoints
+    and descriptors on batches and single frames, on an image whose row stride is odd, and on a geometry whose cells need the 96-byte pitch.
+    (The looped kernel with the next tile in flight, other pitches and the early-out were measured and removed: HISTORY.md.)"""
     ora = po.OracleExtractor(1000, 1.2, 8, 20, 7)
     frames = synth.make_stream(7)
     gpu = ORBextractor(1000, 1.2, 8, 20, 7)

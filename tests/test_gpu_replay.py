@@ -470,7 +470,7 @@ def test_lanes_must_compute_the_same_reference_build_and_get_their_fork_options_
 
 
 def _failing_rank_worker(rank, world, port, q):
-    """world ranks on cuda:0 over the host transport; rank 1's lanes fail at step 2.  Nobody may hang: the failing rank keeps taking part with a
+    """world ranks on cuda:0 over the host transport; rank 1's lane fails at step 2 (and, the failure being sticky, at every later step).  Nobody may hang: the failing rank keeps taking part with a
     poisoned block, the healthy ranks see counts of -1 in its part from that step on."""
     import torch
     import torch.distributed as dist
@@ -485,10 +485,10 @@ def _failing_rank_worker(rank, world, port, q):
         frames = torch.from_numpy(synth.make_stream(B, 240, 320, synth.DEFAULT_SEED + rank)).to(dev)
         ex = ORBextractor(500, 1.2, 6, 20, 7, device_id=0)
         eng = ReplayEngine(ex, frames, lapping=(0, 1000), gather=True, lanes=1, gather_what="descriptors")
-        if rank == bad_rank:
-            eng.debug_fail_at(bad_step)
         errors, seen = [], []
         for step in range(steps):
+            if rank == bad_rank and step == bad_step:
+                eng._row_stride = 1       # a row stride smaller than the image: this rank's lane refuses the step (a real lane error, no test hook)
             try:
                 i = eng.step()
             except OrbxError as e:
@@ -522,7 +522,7 @@ def test_a_failing_rank_poisons_its_block_and_nobody_hangs():
     assert [s[1] for s in s0] == [s0[0][1], s0[1][1], -1, -1, -1] and s0[0][1] > 50 and all(s[0] > 50 for s in s0), s0
     # the failing rank got the error at step 2 and at every later step, and still holds the healthy rank's real results
     e1, s1, f1 = res[1]
-    assert [st for st, _ in e1] == [2, 3, 4] and "injected" in e1[0][1] and f1 == -3, e1
+    assert [st for st, _ in e1] == [2, 3, 4] and "step 2, lane 0" in e1[0][1] and "bad batch arguments" in e1[0][1] and f1 == -1, e1
     assert all(s[0] > 50 for s in s1) and [s[1] for s in s1][2:] == [-1, -1, -1], s1
 
 
