@@ -931,6 +931,8 @@ def main():
                                             "meaning": "which build of the reference CPU path the timed contexts (and the oracle that verified them) compute, bit for "
                                                        "bit: INTEGRATION.md section 6; the default is what orbx_create gives (OpenCV >= 4.5.1 blur, unfused fastAtan2 and "
                                                        "pattern rotation); the reference names OpenCV 4.4.0 / 3.2.0 and builds -march=native: --profile opencv-4.4 --fma-build 3"},
+                       "cv_primitives": "recalled",   # cv::resize / FAST / GaussianBlur / fastAtan2 as the oracle restates them: no OpenCV exists where this was built and
+                                                       # verified; tools/opencv_pin/run.sh is the maintainer's one-command pin against a real one
                        "exchange": (f"ncclAllGather({args.gather}) by liborbx, async/overlapped" if eng.gather else "none"),
                        "lanes_per_gpu": len(eng.lane_ranges), "requested_gpus": requested,
                        "streams": (args.streams if args.streams > 0 else world), "frames_per_stream_per_step": args.batch,

@@ -54,7 +54,14 @@ class ORBextractor {
 #ifdef ORBX_CV_CALIBRATION
     // which OpenCV release / build (and which compiler flags) is the CPU path this object replaces: found out once per process by running
     // the real cv::GaussianBlur / cv::fastAtan2 on a probe (include/orbx_cv_calibrate.h); the context then computes exactly those bytes
-    if (orbx_cv::apply(ctx_, orbx_cv::opencv_calibration()) != ORBX_OK)
+    const orbx_cv::Calibration& cal = orbx_cv::opencv_calibration();
+    if (!orbx_cv::pinned(cal) && !orbx_cv::allow_unpinned()) {
+      orbx_destroy(ctx_);
+      ctx_ = nullptr;
+      throw std::runtime_error("ORBextractor: the OpenCV / toolchain this program is built with is not one liborbx can reproduce bit for bit: " +
+                               orbx_cv::why_unpinned(cal) + "run tools/opencv_pin/run.sh (INTEGRATION.md section 6); ORBX_ALLOW_UNPINNED=1 accepts the difference");
+    }
+    if (orbx_cv::apply(ctx_, cal) != ORBX_OK)
       throw std::runtime_error(std::string("ORBextractor: ") + orbx_last_error(ctx_));
 #endif
     cap_ = orbx_keypoint_capacity(ctx_);

@@ -29,6 +29,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <algorithm>
 #include <utility>
 #include <vector>
@@ -252,6 +253,21 @@ inline bool env_overrides() {
 }
 
 /* applies a calibration to a context; returns ORBX_OK or the first failing orbx_set_option code */
+// "No variant reproduces this OpenCV" must not pass as a drop-in: the bits the reference's CPU build would produce over THIS OpenCV are then
+// not the bits liborbx computes, and nothing downstream would ever say so.  pinned() is what include/ORBextractor.h's constructor demands;
+// ORBX_ALLOW_UNPINNED=1 in the environment turns the refusal back into the stderr report (a maintainer who accepts a documented difference).
+inline bool pinned(const Calibration& c) { return c.gauss_exact && c.atan_exact && c.frame_mismatch <= 0 && c.brief_form >= 0 && c.sort_libstdcxx; }
+inline bool allow_unpinned() { const char* e = std::getenv("ORBX_ALLOW_UNPINNED"); return e && std::atoi(e) != 0; }
+inline std::string why_unpinned(const Calibration& c) {
+  std::string w;
+  if (!c.gauss_exact) w += "cv::GaussianBlur(7x7, sigma 2, 8u) matches no known variant (closest differs in " + std::to_string(c.gauss_mismatch) + " probe bytes); ";
+  if (c.frame_mismatch > 0) w += "cv::GaussianBlur changes its arithmetic with the image size (" + std::to_string(c.frame_mismatch) + " bytes of a frame differ); ";
+  if (!c.atan_exact) w += "cv::fastAtan2 matches neither form (" + std::to_string(c.atan_mismatch) + " of 4096 angles differ); ";
+  if (c.brief_form < 0) w += "this build contracts the pattern rotation in a form liborbx has no option for; ";
+  if (!c.sort_libstdcxx) w += "std::sort of this toolchain does not leave equal keys in libstdc++'s order; ";
+  return w;
+}
+
 inline int apply(orbx_ctx* ctx, const Calibration& c) {
   if (env_overrides()) return ORBX_OK;
   int rc = orbx_set_option(ctx, "gauss_kernel", c.gauss_kernel);

@@ -53,6 +53,9 @@ static inline void GaussianBlur(const Mat& src, Mat& dst, Size ksize, double sx,
   (void)ksize; (void)sx; (void)sy; (void)borderType;
   Mat out(src.rows, src.cols, src.type());
   orbo_gaussian_blur7(src.data, src.cols, src.rows, (int)src.step, out.data, (int)out.step);
+#ifdef ORBO_SHIM_UNKNOWN_BLUR   // tests only: "an OpenCV whose Gaussian no known variant reproduces" (every 97th byte one off)
+  for (int i = 0; i < src.rows * src.cols; i += 97) { unsigned char& b = out.data[(i / src.cols) * (int)out.step + i % src.cols]; b = (unsigned char)(b < 255 ? b + 1 : 254); }
+#endif
   out.copyTo(dst);
 }
 

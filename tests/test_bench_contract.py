@@ -48,6 +48,7 @@ def test_bench_json_line():
     assert tm["repeats"] >= 7 and tm["repeats"] % 2 == 1 and len(tm["ms_per_step_all"]) == tm["repeats"]
     assert tm["ms_per_step_min"] <= j["ms_per_step"] <= tm["ms_per_step_max"] and sorted(tm["ms_per_step_all"])[tm["repeats"] // 2] == j["ms_per_step"]
     assert abs(tm["timed_region_s"] - sum(tm["ms_per_step_all"]) * j["steps"] / 1e3) < 1e-3 and 0 <= tm["spread_frac"] < 1
+    assert j["config"]["cv_primitives"] == "recalled"      # said in the line itself: the OpenCV primitives are pinned to the oracle, not to an OpenCV
     cp = j["config"]["cpu_path_profile"]
     assert cp["active"].startswith("opencv>=4.5.1 (") and cp["options"] == dict(gauss_kernel=0, gauss_round=0, gauss_tail=0, atan_fma=0, brief_fma=0)
     rf = j["roofline"]

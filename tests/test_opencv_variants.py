@@ -218,6 +218,29 @@ def test_adapter_calibration_recognises_every_variant(tmp_path):
     assert line.endswith("contracts 1 form 1 frame 752x480 mismatch 0"), line
 
 
+def test_adapter_refuses_an_opencv_it_cannot_reproduce(tmp_path):
+    """"no variant reproduces this OpenCV" is a hard error of the ORBextractor constructor (it was a line on stderr), unless
+    ORBX_ALLOW_UNPINNED=1; a known variant still constructs."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    odir = os.path.join(root, "oracle")
+    po.build()
+    src = [os.path.join(root, "tests", "support", "unpinned_check.cpp"), os.path.join(root, "tests", "support", "orbx_oracle_stub.cpp")]
+    base = ["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-w", "-I", os.path.join(root, "include"), "-I", os.path.join(odir, "ref_shims")]
+    link = ["-L", odir, "-lorb_oracle", "-Wl,-rpath," + odir]
+    bad, good = str(tmp_path / "unpinned_bad"), str(tmp_path / "unpinned_good")
+    subprocess.check_call(base + ["-DORBO_SHIM_UNKNOWN_BLUR"] + src + ["-o", bad] + link)
+    subprocess.check_call(base + src + ["-o", good] + link)
+    env = {k: v for k, v in os.environ.items() if k != "ORBX_ALLOW_UNPINNED"}
+    r = subprocess.run([bad], capture_output=True, text=True, env=env)
+    assert r.returncode == 7 and "refused: ORBextractor: the OpenCV / toolchain" in r.stdout and "matches no known variant" in r.stdout and \
+        "tools/opencv_pin/run.sh" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([bad], capture_output=True, text=True, env=dict(env, ORBX_ALLOW_UNPINNED="1"))
+    assert r.returncode == 0 and "constructed pinned=0" in r.stdout and "matches NO known variant" in r.stderr, r.stdout + r.stderr
+    r = subprocess.run([good], capture_output=True, text=True, env=dict(env, ORBO_VARIANT="1,2,16,1,0"))
+    assert r.returncode == 0 and "constructed pinned=1" in r.stdout, r.stdout + r.stderr
+
+
 def test_std_sort_probe_knows_libstdcxx_tie_order(tmp_path):
     """The fourth build-dependent input of the CPU path: the order in which std::sort leaves EQUAL keys (DistributeOctTree's (count, UL.x)
     pairs tie all the time).  include/orbx_cv_calibrate.h's probe — three keyed sequences sorted with the toolchain's std::sort — must give

@@ -37,6 +37,59 @@ def test_natural_crop_set_is_read(tmp_path):
     assert r.returncode == 2
 
 
+def test_the_tool_names_the_profile_of_the_opencv_at_hand(tmp_path):
+    """tools/opencv_pin: the digest table (expected_digests.txt) is current, and under every named profile — the shim's cv:: functions then ARE
+    that profile's arithmetic — the program names it from the cv:: outputs alone, with the orbx_set_cpu_profile call to make."""
+    import ctypes as C
+    import numpy as np
+    from orb_slam3_modified_amd import _lib
+    pin = os.path.join(ROOT, "tools", "opencv_pin")
+    assert subprocess.run([sys.executable, os.path.join(pin, "make_expected.py"), "--check"]).returncode == 0, "tools/opencv_pin/expected_digests.txt is stale"
+    table = os.path.join(pin, "expected_digests.txt")
+    st = _set(tmp_path)
+    L = _lib.lib()
+    i = 0
+    while L.orbx_cpu_profile_name(i):
+        nm = L.orbx_cpu_profile_name(i).decode()
+        v = np.zeros(5, np.int32)
+        for fma in (0, 2):
+            if L.orbx_cpu_profile_values(nm.encode(), fma, _lib.ptr(v)) != 0:
+                continue                                    # this profile's OpenCV has no FMA copy of fastAtan2
+            env = dict(os.environ, ORBO_VARIANT=",".join(str(int(x)) for x in v))
+            r = subprocess.run([EXE, "--set", st, "--expect", table], capture_output=True, text=True, env=env)
+            assert r.returncode == 0 and "RESULT: ALL MATCH" in r.stdout, r.stdout[-1500:]
+            assert f'-> orbx_set_cpu_profile(ctx, "{nm}", {fma})' in r.stdout and "IN NO PROFILE" not in r.stdout, r.stdout[-1500:]
+        i += 1
+    assert i == 6
+    # another image set: the table does not apply, and the tool says so instead of naming a profile
+    other = str(tmp_path / "other.bin")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_validate_set.py"), other, "--synthetic", "2"])
+    r = subprocess.run([EXE, "--set", other, "--expect", table], capture_output=True, text=True)
+    assert r.returncode == 1 and "ANOTHER image set" in r.stdout
+    # the stand-alone project and the one-command script are in place (cmake needs a real OpenCV: not run here)
+    for f in ("CMakeLists.txt", "run.sh", "no_orbx.cpp", "README.md"):
+        assert os.path.exists(os.path.join(pin, f)), f
+    assert os.access(os.path.join(pin, "run.sh"), os.X_OK) and "find_package(OpenCV REQUIRED)" in open(os.path.join(pin, "CMakeLists.txt")).read()
+
+
+def test_the_one_command_recipe_end_to_end_over_the_shim(tmp_path):
+    """tools/opencv_pin/run.sh as a maintainer runs it — cmake finds "OpenCV" (here: a two-line OpenCVConfig.cmake that points at the container's
+    shim headers, whose cv:: functions forward to the oracle the project builds), builds the oracle and the tool, the reference's own
+    src/ORBextractor.cc compiled in, writes the set, runs every leg and names the profile."""
+    import shutil
+    if not shutil.which("cmake") or not os.path.isdir("/root/reference"):
+        pytest.skip("needs cmake and /root/reference")
+    cfg = tmp_path / "fake_opencv"
+    cfg.mkdir()
+    (cfg / "OpenCVConfig.cmake").write_text(f'set(OpenCV_VERSION "0.0-shim")\nset(OpenCV_INCLUDE_DIRS "{ROOT}/oracle/ref_shims")\nset(OpenCV_LIBS "")\n')
+    env = dict(os.environ, CMAKE_PREFIX_PATH=str(cfg), OpenCV_DIR=str(cfg), OPENCV_PIN_CMAKE_ARGS="-DWITH_EXTRAS=OFF")   # the shim has no calib3d
+    env.pop("ORBO_VARIANT", None)
+    r = subprocess.run([os.path.join(ROOT, "tools", "opencv_pin", "run.sh"), "/root/reference"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "RESULT: ALL MATCH" in r.stdout and "12 images" in r.stdout and '-> orbx_set_cpu_profile(ctx, "opencv>=4.5.1", ' in r.stdout, r.stdout[-2000:]
+    assert r.stdout.count("MATCH") >= 7 and "0.0-shim" not in r.stderr
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("variant", ["", "1,0,0,0,0", "1,2,8,1,0"])
 def test_operator_leg_reference_compiled_vs_liborbx(tmp_path, variant):

@@ -20,7 +20,12 @@
 // functions ARE the oracle's), which proves the harness, not OpenCV: oracle/ref_fragments.mk -> oracle/_ref/validate_opencv,
 // tests/test_validate_opencv.py.
 //
-//   validate_opencv [--set validate_set.bin] [--orbx] [--nfeatures 1000] [--verbose]
+//   4. with --expect tools/opencv_pin/expected_digests.txt: prints a 64-bit digest of everything the OpenCV at hand computed per primitive on
+//      the set and says which NAMED profile (orbx_set_cpu_profile) carries that digest — the table was made by
+//      running this program over the oracle under every profile (tools/opencv_pin/make_expected.py), so it needs no oracle at run time to
+//      answer "which CPU path is mine"; --print-digests writes the table lines of the current run.
+//
+//   validate_opencv [--set validate_set.bin] [--orbx] [--nfeatures 1000] [--verbose] [--expect table.txt] [--print-digests]
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -101,6 +106,10 @@ void builtin_set(std::vector<Img>& out) {   // value noise + rectangles + flat a
 }
 
 struct Tally { long compared = 0, differing = 0; int fails = 0; };
+struct Fnv64 {
+  uint64_t h = 1469598103934665603ull;
+  void add(const void* p, size_t n) { const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } }
+};
 void verdict(const char* what, const Tally& t, const std::string& first) {
   if (t.differing == 0) std::printf("  %-58s MATCH   (%ld elements)\n", what, t.compared);
   else std::printf("  %-58s MISMATCH %ld of %ld elements; first: %s\n", what, t.differing, t.compared, first.c_str());
@@ -120,15 +129,18 @@ void level_sizes(int rows, int cols, int nlevels, float sf, std::vector<int>& w,
 
 int main(int argc, char** argv) {
   const char* set_path = nullptr;
-  bool with_orbx = false, verbose = false;
+  const char* expect_path = nullptr;
+  bool with_orbx = false, verbose = false, print_digests = false;
   int nfeatures = 1000;
   for (int i = 1; i < argc; i++) {
     const std::string a = argv[i];
     if (a == "--set" && i + 1 < argc) set_path = argv[++i];
     else if (a == "--orbx") with_orbx = true;
     else if (a == "--verbose") verbose = true;
+    else if (a == "--expect" && i + 1 < argc) expect_path = argv[++i];
+    else if (a == "--print-digests") print_digests = true;
     else if (a == "--nfeatures" && i + 1 < argc) nfeatures = std::atoi(argv[++i]);
-    else { std::fprintf(stderr, "usage: validate_opencv [--set validate_set.bin] [--orbx] [--nfeatures N] [--verbose]\n"); return 2; }
+    else { std::fprintf(stderr, "usage: validate_opencv [--set validate_set.bin] [--orbx] [--nfeatures N] [--verbose] [--expect table.txt] [--print-digests]\n"); return 2; }
   }
 #ifdef CV_VERSION
   std::printf("OpenCV %s\n", CV_VERSION);
@@ -154,6 +166,8 @@ int main(int argc, char** argv) {
   std::printf("%zu images (%s)\n", set.size(), set_path ? set_path : "built-in synthetic set; use tools/make_validate_set.py for the natural crops");
 
   // ---- 2. the primitives
+  Fnv64 d_set, d_resize, d_fast20, d_fast7, d_blur, d_atan;   // what the OpenCV at hand computed, primitive by primitive
+  for (const Img& im : set) { d_set.add(&im.rows, 4); d_set.add(&im.cols, 4); d_set.add(im.px.data(), im.px.size()); }
   Tally t_resize, t_border, t_fast20, t_fast7, t_blur, t_atan;
   std::string f_resize, f_border, f_fast20, f_fast7, f_blur, f_atan;
   const int nlevels = 8;
@@ -170,6 +184,7 @@ int main(int argc, char** argv) {
       if (l == 0) { cur_cv = prev_cv; cur_or = prev_or; }
       else {
         cv::resize(prev_cv, cur_cv, cv::Size(lw[l], lh[l]), 0, 0, cv::INTER_LINEAR);
+        for (int y = 0; y < lh[l]; y++) d_resize.add(cur_cv.ptr<unsigned char>(y), (size_t)lw[l]);
         cur_or.resize((size_t)lw[l] * lh[l]);
         orbo_resize_linear(prev_or.data(), lw[l - 1], lh[l - 1], lw[l - 1], cur_or.data(), lw[l], lh[l], lw[l]);
         for (int y = 0; y < lh[l]; y++) for (int x = 0; x < lw[l]; x++) {
@@ -196,6 +211,7 @@ int main(int argc, char** argv) {
         std::string& F = th == 20 ? f_fast20 : f_fast7;
         std::vector<cv::KeyPoint> kc;
         cv::FAST(cur_cv, kc, th, true);
+        for (const cv::KeyPoint& k : kc) { const float r3[3] = {k.pt.x, k.pt.y, k.response}; (th == 20 ? d_fast20 : d_fast7).add(r3, sizeof r3); }
         std::vector<cv::KeyPoint> ko((size_t)lw[l] * lh[l] + 1);
         // the oracle side runs on the OpenCV side's level so that FAST is judged on identical pixels
         std::vector<uint8_t> same((size_t)lw[l] * lh[l]);
@@ -212,6 +228,7 @@ int main(int argc, char** argv) {
       {
         cv::Mat work = cur_cv.clone();
         cv::GaussianBlur(work, work, cv::Size(7, 7), 2, 2, cv::BORDER_REFLECT_101);
+        for (int y = 0; y < lh[l]; y++) d_blur.add(work.ptr<unsigned char>(y), (size_t)lw[l]);
         std::vector<uint8_t> same((size_t)lw[l] * lh[l]), bo((size_t)lw[l] * lh[l]);
         for (int y = 0; y < lh[l]; y++) std::memcpy(&same[(size_t)y * lw[l]], cur_cv.ptr<unsigned char>(y), lw[l]);
         orbo_gaussian_blur7(same.data(), lw[l], lh[l], lw[l], bo.data(), lw[l]);
@@ -231,6 +248,7 @@ int main(int argc, char** argv) {
       s = s * 1664525u + 1013904223u; const int m10 = (i & 31) == 0 ? 0 : (int)((s >> 8) % 6000001u) - 3000000;
       const float a = cv::fastAtan2((float)m01, (float)m10), b = orbo_fast_atan2((float)m01, (float)m10);
       t_atan.compared++;
+      d_atan.add(&a, 4);
       if (std::memcmp(&a, &b, 4) != 0 && !t_atan.differing++) f_atan = "fastAtan2(" + std::to_string(m01) + ", " + std::to_string(m10) + "): cv " + std::to_string(a) + " oracle " + std::to_string(b);
     }
   }
@@ -284,6 +302,51 @@ int main(int argc, char** argv) {
     failures += (t_un.differing != 0) + (t_gray.differing != 0);
   }
 #endif
+
+  // ---- 2b. which NAMED profile is this OpenCV?  (digests of what it computed against the table made over the oracle under every profile)
+  {
+    struct Row { const char* key; const char* what; uint64_t h; } rows[] = {
+        {"resize", "cv::resize INTER_LINEAR (every level)", d_resize.h}, {"fast20", "cv::FAST threshold 20", d_fast20.h}, {"fast7", "cv::FAST threshold 7", d_fast7.h},
+        {"blur", "cv::GaussianBlur 7x7 sigma 2", d_blur.h}, {"atan", "cv::fastAtan2", d_atan.h}};
+    if (print_digests) {
+      std::printf("DIGEST set %016llx\n", (unsigned long long)d_set.h);
+      for (const Row& r : rows) std::printf("DIGEST %s %016llx\n", r.key, (unsigned long long)r.h);
+    }
+    if (expect_path) {
+      FILE* f = std::fopen(expect_path, "r");
+      if (!f) { std::fprintf(stderr, "cannot read %s\n", expect_path); return 2; }
+      struct Exp { std::string profile, key; uint64_t h; };
+      std::vector<Exp> table;
+      char line[512];
+      while (std::fgets(line, sizeof line, f)) {
+        char prof[128], key[64];
+        unsigned long long h = 0;
+        if (line[0] == '#' || std::sscanf(line, "%127s %63s %llx", prof, key, &h) != 3) continue;
+        table.push_back({prof, key, (uint64_t)h});
+      }
+      std::fclose(f);
+      bool set_ok = false;
+      for (const Exp& e : table) if (e.key == "set" && e.h == d_set.h) set_ok = true;
+      std::printf("which named profile is this OpenCV (table %s, %zu rows):\n", expect_path, table.size());
+      if (!set_ok) { std::printf("  the table was made for ANOTHER image set (set digest %016llx is not in it): regenerate the set with tools/make_validate_set.py <out> --synthetic 1\n", (unsigned long long)d_set.h); failures++; }
+      else {
+        std::string blur_prof, atan_prof;
+        for (const Row& r : rows) {
+          std::string who;
+          for (const Exp& e : table) if (e.key == r.key && e.h == r.h) who += (who.empty() ? "" : ", ") + e.profile;
+          std::printf("  %-40s %016llx  %s\n", r.what, (unsigned long long)r.h, who.empty() ? "IN NO PROFILE OF THE TABLE" : ("= " + who).c_str());
+          if (who.empty()) failures++;
+          if (std::string(r.key) == "blur") blur_prof = who;
+          if (std::string(r.key) == "atan") atan_prof = who;
+        }
+        if (!blur_prof.empty() && !atan_prof.empty()) {
+          const std::string first = blur_prof.substr(0, blur_prof.find(','));
+          const int fma_build = (atan_prof.find("atan_fma=1") != std::string::npos ? 2 : 0) | (cal.brief_fma ? 1 : 0);
+          std::printf("  -> orbx_set_cpu_profile(ctx, \"%s\", %d)   (bench.py --profile %s --fma-build %d)\n", first.c_str(), fma_build, first.c_str(), fma_build);
+        }
+      }
+    }
+  }
 
   // ---- 3. whole operator() on the GPU
   if (with_orbx) {
