@@ -352,6 +352,9 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
       !div_ok((uint64_t)geo.btiles_total * nframes + 8, geo.btiles_total))
     return set_err(ctx, ORBX_E_CAPACITY, "batch too large for 32-bit tile indexing");
   const int ft = ctx->fast_threads;
+  // the reference runs cv::FAST at iniThFAST and, where that leaves a cell empty, again at minThFAST (src/ORBextractor.cc:826-850): with
+  // minThFAST > iniThFAST the second run can only find a subset of nothing, i.e. the cell's result is iniThFAST's whatever minThFAST says
+  const int th_min = std::min(ctx->min_th, ctx->ini_th);
   // LDS of a FAST workgroup over cells [c0, c1): tile + score plane of the tallest cell, list for the largest detection domain,
   // bitmap + word prefix (64 words up to 2048 pixels, 256 beyond)
   struct FastLds { int tile_rows, list_cap, nwords; size_t bytes; };
@@ -377,7 +380,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
     const FastLds f = fast_lds_of(cell_base, cell_base + ncells_sub);
     hipLaunchKernelGGL(fast_kern, dim3(xcd_grid(nitems)), dim3(ft), f.bytes, s, ctx->d_geo, ctx->d_cells, d_imgs,
                        (long long)row_stride, (long long)frame_stride, b_pyr, (long long)geo.pyr_bytes, b_cand, b_cell_cnt,
-                       ctx->ini_th, ctx->min_th, f.tile_rows, nitems, cell_base, ncells_sub, div_magic((uint32_t)ncells_sub),
+                       ctx->ini_th, th_min, f.tile_rows, nitems, cell_base, ncells_sub, div_magic((uint32_t)ncells_sub),
                        ctx->fast_stage_dma ? 1 : 0, f.list_cap, f.nwords);
   };
   // The cells of the small levels are taller (fewer rows of cells share the same height): one launch over all levels would give
@@ -556,7 +559,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
     const int nfast = ncells_all * nframes, nblur = geo.btiles_total * nframes;
     auto fk = pitchB == 64 ? (ctx->fast_pk ? k_fast_blur<64, true> : k_fast_blur<64, false>) : (ctx->fast_pk ? k_fast_blur<96, true> : k_fast_blur<96, false>);
     hipLaunchKernelGGL(fk, dim3(nfast + nblur), dim3(256), f.bytes, st, ctx->d_geo, ctx->d_cells, d_imgs, (long long)row_stride, (long long)frame_stride,
-                       b_pyr, (long long)geo.pyr_bytes, b_cand, b_cell_cnt, ctx->ini_th, ctx->min_th, f.tile_rows, nfast, ncells_all,
+                       b_pyr, (long long)geo.pyr_bytes, b_cand, b_cell_cnt, ctx->ini_th, th_min, f.tile_rows, nfast, ncells_all,
                        div_magic((uint32_t)ncells_all), ctx->fast_stage_dma ? 1 : 0, f.list_cap, f.nwords, b_blur, (long long)geo.blur_bytes, bc);
   } else {
     ProfScope ps(ctx, 1, st);

@@ -387,7 +387,13 @@ __device__ __forceinline__ uint32_t fast_pretest_pk_lo(uint32_t c, uint32_t p0, 
 }
 
 // one cell (logical item L of a launch over cells [cell_base, cell_base + ncells_sub) of every frame); T threads
-template <int T, int PITCH, bool PK>
+// TWOPASS (the batch kernel, round 6): the cell loop of the reference LITERALLY — cv::FAST at iniThFAST, and only when that leaves the cell
+// without a keypoint cv::FAST again at minThFAST (src/ORBextractor.cc:826-850) — stages B, C, D run at iniTh first.  Four cells in five hold an
+// iniTh corner (tools/fast_pass_rates.py: 78 % on the synthetic stream, 80 % on natural crops), and the candidate list of iniTh is a third
+// (natural) to two thirds (synthetic) of minTh's, so the 130-instruction exact score, the NMS and the compaction run over 1.3 - 1.5 trips per
+// cell instead of 2.1 - 3.0; the fifth cell pays stage B twice.  Without TWOPASS (the fused single-frame launch, where the slowest cell sets the
+// kernel's time): one pass at minTh, the threshold chosen afterwards — the same keypoints by the closed form of SURVEY.md section 8(c)-F.
+template <int T, int PITCH, bool PK, bool TWOPASS = false>
 __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
                                           const uint8_t* __restrict__ imgs, long long img_row_stride,
                                           long long img_frame_stride, const uint8_t* __restrict__ pyr,
@@ -466,6 +472,10 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
   if (t == 0) s_cnt = 0;
   if (stage_dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile's LDS-DMA loads (block-uniform)
   __syncthreads();
+  int TH = TWOPASS ? ini_th : min_th;   // threshold of the current pass
+  int n1 = 0;
+#pragma unroll 1
+  for (int pass = 0;; pass++) {
   // ---- B: necessary test, 4 pixels (one aligned LDS dword of centres) per lane and step; branch-free
   {
     const int kmin = (3 + xo) >> 2, kmax = (cw - 4 + xo) >> 2, ng = kmax - kmin + 1;
@@ -481,7 +491,7 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
       const uint32_t Q4 = __builtin_amdgcn_alignbyte(dR, dC, 3);   // x+3 of pixel j in byte j
       const uint32_t Q12 = __builtin_amdgcn_alignbyte(dC, dL, 1);  // x-3 of pixel j in byte j
       constexpr uint32_t LO = 0x00ff00ffu;
-      const uint32_t t_hi = (uint32_t)min_th * 0x01000100u, t_lo = (uint32_t)min_th * 0x00010001u;
+      const uint32_t t_hi = (uint32_t)TH * 0x01000100u, t_lo = (uint32_t)TH * 0x00010001u;
       // the two diagonal pairs (2,10) and (6,14): rows +-2, columns +-2
       const uint32_t eC = rowp[2 * P4], eL = rowp[2 * P4 - 1], eR = rowp[2 * P4 + 1];
       const uint32_t fC = rowp[-2 * P4], fL = rowp[-2 * P4 - 1], fR = rowp[-2 * P4 + 1];
@@ -510,8 +520,8 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
         const int v = (dC >> (8 * j)) & 0xff, p0 = (dD >> (8 * j)) & 0xff, p8 = (dU >> (8 * j)) & 0xff;
         const int p4 = (Q4 >> (8 * j)) & 0xff, p12 = (Q12 >> (8 * j)) & 0xff;
         const int p2 = (Q2 >> (8 * j)) & 0xff, p10 = (Q10 >> (8 * j)) & 0xff, p6 = (Q6 >> (8 * j)) & 0xff, p14 = (Q14 >> (8 * j)) & 0xff;
-        const bool dark = max(max(min(p0, p8), min(p4, p12)), max(min(p2, p10), min(p6, p14))) < v - min_th;
-        const bool bright = min(min(max(p0, p8), max(p4, p12)), min(max(p2, p10), max(p6, p14))) > v + min_th;
+        const bool dark = max(max(min(p0, p8), min(p4, p12)), max(min(p2, p10), min(p6, p14))) < v - TH;
+        const bool bright = min(min(max(p0, p8), max(p4, p12)), min(max(p2, p10), max(p6, p14))) > v + TH;
         const bool valid = (unsigned)(c0 + j) < (unsigned)dw;
         ps[j] = (dark | bright) & valid & (act != 0);
       }
@@ -537,7 +547,7 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
     }
   }
   __syncthreads();
-  const int n1 = s_cnt;
+  n1 = s_cnt;
   // ---- C: exact score of the listed pixels
   for (int e = t; e < n1; e += T) {
     const int ent = list[e];
@@ -550,7 +560,7 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
     p[8] = c0[3];              p[9] = c0[2];              p[10] = c0[1 * PITCH + 1]; p[11] = c0[2 * PITCH];
     p[12] = c0[3 * PITCH];     p[13] = c0[4 * PITCH];     p[14] = c0[5 * PITCH + 1]; p[15] = c0[6 * PITCH + 2];
     const int s = fast_score16(v, p);
-    if (s >= min_th && s > 0) sc[(y + 1) * PITCH + (x + 1)] = (uint8_t)s;
+    if (s >= TH && s > 0) sc[(y + 1) * PITCH + (x + 1)] = (uint8_t)s;
   }
   __syncthreads();
   // ---- D: 3x3 strict NMS inside the cell (neighbours outside the detection domain are 0)
@@ -565,12 +575,20 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
                         max(max((int)q[PITCH + 2], (int)q[2 * PITCH]), max((int)q[2 * PITCH + 1], (int)q[2 * PITCH + 2])));
       if (s > m) {
         list[e] = (uint16_t)(ent | 0x8000);
-        any_ini |= s >= ini_th;
+        any_ini |= TWOPASS ? 1 : (int)(s >= ini_th);
       }
     }
   }
-  const int use_ini = __syncthreads_or(any_ini);
-  const int TH = use_ini ? ini_th : min_th;
+  const int use_ini = __syncthreads_or(any_ini);   // (also the barrier after which s_cnt may be reset and the list rewritten)
+  if constexpr (!TWOPASS) { TH = use_ini ? ini_th : min_th; break; }
+  else {
+    // every stored score is >= TH, so any NMS survivor is a keypoint of this pass
+    if (use_ini || pass == 1) break;   // block-uniform
+    TH = min_th;
+    if (t == 0) s_cnt = 0;
+    __syncthreads();
+  }
+  }
   // ---- E: bitmap of the selected survivors (bit index = row-major pixel index)
   for (int e = t; e < n1; e += T) {
     const int le = list[e];
@@ -628,7 +646,7 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
   }
 }
 
-template <int T, int PITCH, bool PK = false>
+template <int T, int PITCH, bool PK = false, bool TWOPASS = true>
 __global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
                                                   const uint8_t* __restrict__ imgs, long long img_row_stride,
                                                   long long img_frame_stride, const uint8_t* __restrict__ pyr,
@@ -639,8 +657,8 @@ __global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__
   extern __shared__ __align__(16) uint8_t smem[];
   const int L = xcd_logical_block(nitems);
   if (L < 0) return;  // block-uniform
-  fast_cell<T, PITCH, PK>(smem, L, g, cells, imgs, img_row_stride, img_frame_stride, pyr, pyr_frame_bytes, cand, cell_cnt, ini_th, min_th, tile_rows,
-                          cell_base, ncells_sub, m_ncells_sub, stage_dma, list_cap, nwords);
+  fast_cell<T, PITCH, PK, TWOPASS>(smem, L, g, cells, imgs, img_row_stride, img_frame_stride, pyr, pyr_frame_bytes, cand, cell_cnt, ini_th, min_th, tile_rows,
+                                   cell_base, ncells_sub, m_ncells_sub, stage_dma, list_cap, nwords);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -5,6 +5,8 @@ byte for byte, the return value (monoIndex) and the output ORDER included (SURVE
 integer FAST score (the reference never computes a Harris score), so the north-star's 1e-4
 tolerance collapses to exact equality; the only float fields (angle, scaled x/y) are required bit-exact too.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -105,6 +107,29 @@ def test_other_parameters(nlevels, sf, ini, mn):
     t = po.OracleExtractor(800, sf, nlevels, ini, mn).tables()
     assert np.array_equal(gpu.GetScaleFactors(), t["scale"]) and np.array_equal(gpu.features_per_level(), t["quota"])
     assert np.array_equal(gpu.GetInverseScaleSigmaSquares(), t["inv_sigma2"])
+
+
+@pytest.mark.parametrize("ini,mn", [(20, 7), (12, 12), (7, 20), (35, 3), (20, 0), (0, 0)])
+@pytest.mark.parametrize("kind", ["synth", "natural", "sparse"])
+def test_the_two_threshold_cell_loop_on_batches_and_single_frames(ini, mn, kind):
+    """src/ORBextractor.cc:826-850: cv::FAST at iniThFAST, and at minThFAST only where that left the cell empty.  The batch kernel runs the two
+    passes literally (round 6: stages B-D at iniTh first), the fused single-frame launch one pass at minTh with the threshold chosen afterwards:
+    both against the oracle — also with equal thresholds, with minTh ABOVE iniTh (the second run then finds nothing new: the result is iniTh's),
+    with threshold 0, on natural texture (most cells hold an iniTh corner) and on an image where most cells need the second pass."""
+    if kind == "synth":
+        imgs = synth.make_stream(5, 480, 640, 77)
+    elif kind == "natural":
+        nat = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "natural_crops.npz"))
+        base = [np.ascontiguousarray(nat[k]) for k in ("result_640x480_img", "pineapple_640x480_img")]
+        imgs = np.stack([np.roll(base[i % 2], (11 * i, 17 * i), (0, 1)) for i in range(5)])
+    else:   # low contrast: almost every corner lies between the two thresholds
+        imgs = (synth.make_stream(5, 480, 640, 78).astype(np.float32) * 0.12 + 100).astype(np.uint8)
+    ora = po.OracleExtractor(1000, 1.2, 8, ini, mn)
+    gpu = ORBextractor(1000, 1.2, 8, ini, mn)
+    want = [ora.extract(f, (0, 1000)) for f in imgs]
+    for i, r in enumerate(gpu.extract_batch(imgs, (0, 1000))):
+        assert_same(r, want[i], f"{kind} th {ini}/{mn} batch frame {i}")
+    assert_same(gpu(imgs[2], None, (0, 1000)), want[2], f"{kind} th {ini}/{mn} single frame")
 
 
 @pytest.mark.parametrize("qt_points,fused", [(512, 1), (512, 0), (384, 1), (256, 1), (1024, 1), (2048, 0)])
