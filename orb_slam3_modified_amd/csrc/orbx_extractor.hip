@@ -381,7 +381,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
     hipLaunchKernelGGL(fast_kern, dim3(xcd_grid(nitems)), dim3(ft), f.bytes, s, ctx->d_geo, ctx->d_cells, d_imgs,
                        (long long)row_stride, (long long)frame_stride, b_pyr, (long long)geo.pyr_bytes, b_cand, b_cell_cnt,
                        ctx->ini_th, th_min, f.tile_rows, nitems, cell_base, ncells_sub, div_magic((uint32_t)ncells_sub),
-                       ctx->fast_stage_dma ? 1 : 0, f.list_cap, f.nwords);
+                       (ctx->fast_stage_dma ? 1 : 0) | (ctx->fast_passes == 2 ? 2 : 0), f.list_cap, f.nwords);
   };
   // The cells of the small levels are taller (fewer rows of cells share the same height): one launch over all levels would give
   // every workgroup the LDS of the tallest cell and cost the many cells of the large levels their residency.  A range of cells
@@ -892,6 +892,7 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, 
     ctx->fast_pk = fpk ? atoi(fpk) != 0 : true;
     { const char* e = getenv("ORBX_REALIGN"); ctx->realign = e ? atoi(e) != 0 : true; }
     { const char* e = getenv("ORBX_FAST_STAGE_DMA"); ctx->fast_stage_dma = e ? atoi(e) != 0 : true; }
+    { const char* e = getenv("ORBX_FAST_PASSES"); ctx->fast_passes = e && atoi(e) == 1 ? 1 : 2; }
     const char* dl = getenv("ORBX_DESC_LDS");   // blurred 37x37 window staged in LDS for the descriptor taps
     ctx->desc_lds = dl ? atoi(dl) != 0 : true;
     const char* fq = getenv("ORBX_FORK_QT");
@@ -1436,6 +1437,7 @@ int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
   else if (n == "fast_pk") ctx->fast_pk = value != 0;
   else if (n == "realign") ctx->realign = value != 0;   // batch frames with rows that are not dword-aligned: one pass into an aligned copy first
   else if (n == "fast_stage_dma") ctx->fast_stage_dma = value != 0;   // FAST tile staged by LDS-DMA loads instead of load + ds_write
+  else if (n == "fast_passes" && (value == 1 || value == 2)) ctx->fast_passes = value;   // batch FAST: 2 = iniTh first, minTh where the cell stayed empty; 1 = one pass at minTh
   else if (n == "gauss_kernel" && (value == 0 || value == 1)) ctx->gauss_kernel = value;   // which OpenCV's 8-bit Gaussian weights (include/orbx.h)
   else if (n == "gauss_round" && value >= 0 && value <= 2) ctx->gauss_round = value;       // ... which rounding of the column pass
   else if (n == "gauss_tail" && (value == 0 || value == 4 || value == 8 || value == 16 || value == 32 || value == 64)) ctx->gauss_tail = value;   // ... and its scalar tail
@@ -1473,7 +1475,7 @@ int orbx_get_option(const orbx_ctx* ctx, const char* name) {
   const std::string n(name);
   const struct { const char* name; int value; } tab[] = {
       {"fork_blur", ctx->fork_blur}, {"fork_fast0", ctx->fork_fast0}, {"fork_qt", ctx->fork_qt}, {"graph", ctx->use_graph}, {"graph_timing", ctx->graph_timing}, {"window_timing", ctx->window_timing},
-      {"fast_pk", ctx->fast_pk}, {"realign", ctx->realign}, {"fast_stage_dma", ctx->fast_stage_dma},
+      {"fast_pk", ctx->fast_pk}, {"fast_passes", ctx->fast_passes}, {"realign", ctx->realign}, {"fast_stage_dma", ctx->fast_stage_dma},
       {"gauss_kernel", ctx->gauss_kernel}, {"gauss_round", ctx->gauss_round}, {"gauss_tail", ctx->gauss_tail}, {"atan_fma", ctx->atan_fma}, {"brief_fma", ctx->brief_fma},
       {"qt_points", ctx->qt_points}, {"small_fused", ctx->small_fused}, {"qt_level_major", ctx->qt_level_major}, {"qt_fused", ctx->qt_fused},
       {"chain_batch", ctx->chain_batch}, {"chain_long", ctx->chain_long}, {"describe_direct", ctx->describe_direct}, {"chain_long_tile", ctx->chain_long_tile},

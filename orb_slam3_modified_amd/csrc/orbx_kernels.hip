@@ -387,24 +387,29 @@ __device__ __forceinline__ uint32_t fast_pretest_pk_lo(uint32_t c, uint32_t p0, 
 }
 
 // one cell (logical item L of a launch over cells [cell_base, cell_base + ncells_sub) of every frame); T threads
-// TWOPASS (the batch kernel, round 6): the cell loop of the reference LITERALLY — cv::FAST at iniThFAST, and only when that leaves the cell
-// without a keypoint cv::FAST again at minThFAST (src/ORBextractor.cc:826-850) — stages B, C, D run at iniTh first.  Four cells in five hold an
-// iniTh corner (tools/fast_pass_rates.py: 78 % on the synthetic stream, 80 % on natural crops), and the candidate list of iniTh is a third
-// (natural) to two thirds (synthetic) of minTh's, so the 130-instruction exact score, the NMS and the compaction run over 1.3 - 1.5 trips per
-// cell instead of 2.1 - 3.0; the fifth cell pays stage B twice.  Without TWOPASS (the fused single-frame launch, where the slowest cell sets the
-// kernel's time): one pass at minTh, the threshold chosen afterwards — the same keypoints by the closed form of SURVEY.md section 8(c)-F.
-template <int T, int PITCH, bool PK, bool TWOPASS = false>
+// Two passes (flags bit 1; the batch kernel's default since round 6): the cell loop of the reference LITERALLY — cv::FAST at iniThFAST, and only
+// where that leaves the cell without a keypoint cv::FAST again at minThFAST (src/ORBextractor.cc:826-850) — stages B, C, D run at iniTh first.
+// Four cells in five hold an iniTh corner (tools/fast_pass_rates.py: 78 % on the synthetic stream, 80 % on natural crops) and iniTh's candidate
+// list is a third (natural) to two thirds (synthetic) of minTh's, so the 130-instruction exact score, the NMS and the compaction run over fewer
+// trips; the fifth cell pays stage B twice.  Measured (profiles/fast_passes_r6.txt): natural crops k_fast_cells 0.520 -> 0.385 ms per 256 frames,
+// the step 232 k -> 259 k features/ms; 1024 x 1024: +2 %; the synthetic stream: the kernel alone 0.412 -> 0.383 ms but +2 % VALU instructions
+// (a quarter of its cells are flat and pay stage B twice for nothing), i.e. -1 % on the two-lane step, inside the run-to-run spread.
+// One pass (flags bit 1 clear: the fused single-frame launch, where the slowest cell sets the kernel's time; "fast_passes" = 1): stage B at minTh,
+// the threshold chosen afterwards — the same keypoints by the closed form of SURVEY.md section 8(c)-F.
+template <int T, int PITCH, bool PK>
 __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
                                           const uint8_t* __restrict__ imgs, long long img_row_stride,
                                           long long img_frame_stride, const uint8_t* __restrict__ pyr,
                                           long long pyr_frame_bytes, uint32_t* __restrict__ cand,
                                           int32_t* __restrict__ cell_cnt, int ini_th, int min_th, int tile_rows,
-                                          int cell_base, int ncells_sub, uint32_t m_ncells_sub, int stage_dma,
+                                          int cell_base, int ncells_sub, uint32_t m_ncells_sub, int flags,
                                           int list_cap, int nwords) {
   // LDS: [16 B pad][tile_rows][PITCH] raw pixels (+ alignment shift xo) | [tile_rows][PITCH] scores with a 1-px
   // zero frame | list | bitmap | word prefix.  PITCH is a compile-time constant so every circle / neighbour access is an
   // immediate offset.  Everything is sized by the launch for the cells it covers (tile_rows, list_cap, nwords = 64 or 256): the
   // LDS footprint of a workgroup decides how many of them a CU holds, and this kernel lives on residency.
+  const int stage_dma = flags & 1;          // the tile by LDS-DMA loads
+  const bool twopass = (flags & 2) != 0;    // block-uniform (kernel argument)
   uint8_t* tile = smem + 16;
   uint8_t* sc = tile + tile_rows * PITCH;
   uint16_t* list = (uint16_t*)(sc + tile_rows * PITCH);  // candidate pixels (bit 15: NMS survivor)
@@ -472,7 +477,7 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
   if (t == 0) s_cnt = 0;
   if (stage_dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile's LDS-DMA loads (block-uniform)
   __syncthreads();
-  int TH = TWOPASS ? ini_th : min_th;   // threshold of the current pass
+  int TH = twopass ? ini_th : min_th;   // threshold of the current pass
   int n1 = 0;
 #pragma unroll 1
   for (int pass = 0;; pass++) {
@@ -575,19 +580,17 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
                         max(max((int)q[PITCH + 2], (int)q[2 * PITCH]), max((int)q[2 * PITCH + 1], (int)q[2 * PITCH + 2])));
       if (s > m) {
         list[e] = (uint16_t)(ent | 0x8000);
-        any_ini |= TWOPASS ? 1 : (int)(s >= ini_th);
+        any_ini |= twopass ? 1 : (int)(s >= ini_th);
       }
     }
   }
   const int use_ini = __syncthreads_or(any_ini);   // (also the barrier after which s_cnt may be reset and the list rewritten)
-  if constexpr (!TWOPASS) { TH = use_ini ? ini_th : min_th; break; }
-  else {
-    // every stored score is >= TH, so any NMS survivor is a keypoint of this pass
-    if (use_ini || pass == 1) break;   // block-uniform
-    TH = min_th;
-    if (t == 0) s_cnt = 0;
-    __syncthreads();
-  }
+  if (!twopass) { TH = use_ini ? ini_th : min_th; break; }
+  // two passes: every stored score is >= TH, so any NMS survivor is a keypoint of this pass
+  if (use_ini || pass == 1 || ini_th == min_th) break;   // block-uniform
+  TH = min_th;
+  if (t == 0) s_cnt = 0;
+  __syncthreads();
   }
   // ---- E: bitmap of the selected survivors (bit index = row-major pixel index)
   for (int e = t; e < n1; e += T) {
@@ -646,19 +649,19 @@ __device__ __forceinline__ void fast_cell(uint8_t* smem, const int L, const Devi
   }
 }
 
-template <int T, int PITCH, bool PK = false, bool TWOPASS = true>
+template <int T, int PITCH, bool PK = false>
 __global__ __launch_bounds__(T) void k_fast_cells(const DeviceGeom* __restrict__ g, const CellGeom* __restrict__ cells,
                                                   const uint8_t* __restrict__ imgs, long long img_row_stride,
                                                   long long img_frame_stride, const uint8_t* __restrict__ pyr,
                                                   long long pyr_frame_bytes, uint32_t* __restrict__ cand,
                                                   int32_t* __restrict__ cell_cnt, int ini_th, int min_th, int tile_rows,
-                                                  int nitems, int cell_base, int ncells_sub, uint32_t m_ncells_sub, int stage_dma,
+                                                  int nitems, int cell_base, int ncells_sub, uint32_t m_ncells_sub, int flags,
                                                   int list_cap, int nwords) {
   extern __shared__ __align__(16) uint8_t smem[];
   const int L = xcd_logical_block(nitems);
   if (L < 0) return;  // block-uniform
-  fast_cell<T, PITCH, PK, TWOPASS>(smem, L, g, cells, imgs, img_row_stride, img_frame_stride, pyr, pyr_frame_bytes, cand, cell_cnt, ini_th, min_th, tile_rows,
-                                   cell_base, ncells_sub, m_ncells_sub, stage_dma, list_cap, nwords);
+  fast_cell<T, PITCH, PK>(smem, L, g, cells, imgs, img_row_stride, img_frame_stride, pyr, pyr_frame_bytes, cand, cell_cnt, ini_th, min_th, tile_rows,
+                          cell_base, ncells_sub, m_ncells_sub, flags, list_cap, nwords);
 }
 
 // ------------------------------------------------------------------------------------------------

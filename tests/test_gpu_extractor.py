@@ -127,8 +127,10 @@ def test_the_two_threshold_cell_loop_on_batches_and_single_frames(ini, mn, kind)
     ora = po.OracleExtractor(1000, 1.2, 8, ini, mn)
     gpu = ORBextractor(1000, 1.2, 8, ini, mn)
     want = [ora.extract(f, (0, 1000)) for f in imgs]
-    for i, r in enumerate(gpu.extract_batch(imgs, (0, 1000))):
-        assert_same(r, want[i], f"{kind} th {ini}/{mn} batch frame {i}")
+    for passes in (2, 1):          # "fast_passes": 2 = the batch default, 1 = one pass at minTh (what the single-frame launch always does)
+        gpu.set_option("fast_passes", passes)
+        for i, r in enumerate(gpu.extract_batch(imgs, (0, 1000))):
+            assert_same(r, want[i], f"{kind} th {ini}/{mn} batch frame {i} passes {passes}")
     assert_same(gpu(imgs[2], None, (0, 1000)), want[2], f"{kind} th {ini}/{mn} single frame")
 
 
