@@ -539,7 +539,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
     // the default variant needs neither saturation nor a tie rule nor a tail: the kernel's fast path (flags == 0)
     const bool general = ctx->gauss_kernel != 0 || ctx->gauss_round != 0;
     bc.radd = general ? 0u : 32768u;
-    bc.flags = (general ? (1u | ((uint32_t)ctx->gauss_round << 1)) : 0u) | (ctx->blur_mfma ? 0x100u : 0u);   // bit 8: the horizontal pass as MFMA blocks
+    bc.flags = general ? (1u | ((uint32_t)ctx->gauss_round << 1)) : 0u;
     bc.tail_mask = (general && ctx->gauss_round != 0 && ctx->gauss_tail > 1) ? (uint32_t)ctx->gauss_tail - 1u : 0u;
     auto b4 = [&](int a, int b, int c, int d) {   // weights of the four bytes of a dword; index -1 = no tap
       auto w = [&](int i) { return i < 0 ? 0u : (uint32_t)gk[i]; };
@@ -893,7 +893,6 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, 
     { const char* e = getenv("ORBX_REALIGN"); ctx->realign = e ? atoi(e) != 0 : true; }
     { const char* e = getenv("ORBX_FAST_STAGE_DMA"); ctx->fast_stage_dma = e ? atoi(e) != 0 : true; }
     { const char* e = getenv("ORBX_FAST_PASSES"); ctx->fast_passes = e && atoi(e) == 1 ? 1 : 2; }
-    { const char* e = getenv("ORBX_BLUR_MFMA"); ctx->blur_mfma = e ? atoi(e) != 0 : false; }
     const char* dl = getenv("ORBX_DESC_LDS");   // blurred 37x37 window staged in LDS for the descriptor taps
     ctx->desc_lds = dl ? atoi(dl) != 0 : true;
     const char* fq = getenv("ORBX_FORK_QT");
@@ -1438,7 +1437,6 @@ int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
   else if (n == "fast_pk") ctx->fast_pk = value != 0;
   else if (n == "realign") ctx->realign = value != 0;   // batch frames with rows that are not dword-aligned: one pass into an aligned copy first
   else if (n == "fast_stage_dma") ctx->fast_stage_dma = value != 0;   // FAST tile staged by LDS-DMA loads instead of load + ds_write
-  else if (n == "blur_mfma") ctx->blur_mfma = value != 0;   // k_blur7's horizontal pass as v_mfma_i32_16x16x32_i8 blocks (same bytes)
   else if (n == "fast_passes" && (value == 1 || value == 2)) ctx->fast_passes = value;   // batch FAST: 2 = iniTh first, minTh where the cell stayed empty; 1 = one pass at minTh
   else if (n == "gauss_kernel" && (value == 0 || value == 1)) ctx->gauss_kernel = value;   // which OpenCV's 8-bit Gaussian weights (include/orbx.h)
   else if (n == "gauss_round" && value >= 0 && value <= 2) ctx->gauss_round = value;       // ... which rounding of the column pass
@@ -1477,7 +1475,7 @@ int orbx_get_option(const orbx_ctx* ctx, const char* name) {
   const std::string n(name);
   const struct { const char* name; int value; } tab[] = {
       {"fork_blur", ctx->fork_blur}, {"fork_fast0", ctx->fork_fast0}, {"fork_qt", ctx->fork_qt}, {"graph", ctx->use_graph}, {"graph_timing", ctx->graph_timing}, {"window_timing", ctx->window_timing},
-      {"fast_pk", ctx->fast_pk}, {"fast_passes", ctx->fast_passes}, {"blur_mfma", ctx->blur_mfma}, {"realign", ctx->realign}, {"fast_stage_dma", ctx->fast_stage_dma},
+      {"fast_pk", ctx->fast_pk}, {"fast_passes", ctx->fast_passes}, {"realign", ctx->realign}, {"fast_stage_dma", ctx->fast_stage_dma},
       {"gauss_kernel", ctx->gauss_kernel}, {"gauss_round", ctx->gauss_round}, {"gauss_tail", ctx->gauss_tail}, {"atan_fma", ctx->atan_fma}, {"brief_fma", ctx->brief_fma},
       {"qt_points", ctx->qt_points}, {"small_fused", ctx->small_fused}, {"qt_level_major", ctx->qt_level_major}, {"qt_fused", ctx->qt_fused},
       {"chain_batch", ctx->chain_batch}, {"chain_long", ctx->chain_long}, {"describe_direct", ctx->describe_direct}, {"chain_long_tile", ctx->chain_long_tile},

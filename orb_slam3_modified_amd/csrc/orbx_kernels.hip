@@ -2305,38 +2305,6 @@ __device__ __forceinline__ void blur_tile(const int L, const DeviceGeom* __restr
     }
   }
   __syncthreads();
-  if (bc.flags & 0x100u) {   // uniform (kernel argument): "blur_mfma"
-    // ---- horizontal pass on the MATRIX pipe (round 6: the step is VALU-issue bound and the MFMA units idle).  A 16-row x 16-column block of
-    // horizontal sums is one v_mfma_i32_16x16x32_i8: A = 16 rows x 32 consecutive raw bytes (pixels as p - 128: one XOR makes them int8),
-    // B = the banded Toeplitz matrix of the seven weights (k = raw byte, n = output column: w[k - 1 - n], weights <= 56), accumulator
-    // initialised with 128 * sum(w), so that D = sum w p EXACTLY (int32; the sums fit 16 bits).  A 64 x 64 tile = 4 x 4 such blocks: wave w takes
-    // the four blocks of rows 16w .. 16w + 15.  Per block and lane: one ds_read_b64, two XORs, the MFMA, two packs, two stores — against ten
-    // v_dot4 and their packing per 256 sums.  The K range of a block ends at raw byte X + 31 <= 79 < the 96-byte LDS pitch: bytes beyond the
-    // 72 staged ones meet zero weights.
-    typedef int v4i32_t __attribute__((ext_vector_type(4)));
-    const int lane = t & 63, wv = t >> 6, n = lane & 15, kg = lane >> 4;
-    const uint32_t wk[7] = {bc.we[0] & 0xffffu, bc.we[0] >> 16, bc.we[1] & 0xffffu, bc.we[1] >> 16, bc.we[2] & 0xffffu, bc.we[2] >> 16, bc.we[3] & 0xffffu};
-    unsigned long long bw = 0ull;   // B[k = 8 kg + q][n], q = 0 .. 7
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-      const int tap = 8 * kg + q - 1 - n;
-      uint32_t wq = 0u;
-#pragma unroll
-      for (int u = 0; u < 7; u++) wq = tap == u ? wk[u] : wq;
-      bw |= (unsigned long long)wq << (8 * q);
-    }
-    const int c128 = 128 * (int)(wk[0] + wk[1] + wk[2] + wk[3] + wk[4] + wk[5] + wk[6]);
-    const v4i32_t cinit = {c128, c128, c128, c128};
-    const uint8_t* arow = raw + (16 * wv + n) * kBT_RP + 8 * kg;
-    uint32_t* hrow = hp + (8 * wv + 2 * kg) * kBT_W + n;   // rows 16 wv + 4 kg + {0, 1} = pair 8 wv + 2 kg; + {2, 3} = the next pair
-#pragma unroll
-    for (int X = 0; X < kBT_W; X += 16) {
-      const unsigned long long a = *(const unsigned long long*)(arow + X) ^ 0x8080808080808080ull;
-      const v4i32_t d = __builtin_amdgcn_mfma_i32_16x16x32_i8((long)a, (long)bw, cinit, 0, 0, 0);
-      hrow[X] = (uint32_t)d[0] | ((uint32_t)d[1] << 16);
-      hrow[kBT_W + X] = (uint32_t)d[2] | ((uint32_t)d[3] << 16);
-    }
-  } else
   // horizontal: item = (row pair rp, group j): rows 2rp, 2rp+1, output columns 4j..4j+3
   for (int i = t; i < (kBT_RR / 2) * (kBT_W / 4); i += 256) {
     const int rp = i >> 4, j = i & 15;
@@ -2370,7 +2338,7 @@ __device__ __forceinline__ void blur_tile(const int L, const DeviceGeom* __restr
         o[c] = udot2(p3, bc.wo[3], udot2(p2, bc.wo[2], udot2(p1, bc.wo[1], udot2(p0, bc.wo[0], init[c]))));
       }
     };
-    if (!(bc.flags & 0xffu)) {   // uniform (kernel argument): the default arithmetic, radd = 2^15 in a scalar register
+    if (!bc.flags) {   // uniform (kernel argument): the default arithmetic, radd = 2^15 in a scalar register
       const uint32_t in4[4] = {bc.radd, bc.radd, bc.radd, bc.radd};
       column_sums(in4);
     } else {
