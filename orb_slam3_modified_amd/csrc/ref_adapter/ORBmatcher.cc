@@ -58,6 +58,9 @@ struct PhaseTrace {
   }
 };
 
+// the rigid part of a similarity: rotation, and the translation brought to unit scale (what every Sim3 routine of the reference starts from)
+inline Sophus::SE3f rigid_part(const Sophus::Sim3f& S) { return Sophus::SE3f(S.rotationMatrix(), S.translation() / S.scale()); }
+
 [[noreturn]] void fail(const char* routine, orbx_ctx* ctx) {
   throw std::runtime_error(std::string("ORBmatcher::") + routine + ": " + (ctx ? orbx_last_error(ctx) : "no orbx context"));
 }
@@ -782,12 +785,9 @@ int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPoi
 static int SearchByProjectionSim3(const char* routine, KeyFrame* pKF, Sophus::Sim3f& Scw, const vector<MapPoint*>& vpPoints,
                                   const vector<KeyFrame*>* vpPointsKFs, vector<MapPoint*>& vpMatched, vector<KeyFrame*>* vpMatchedKF, int th,
                                   float ratioHamming) {
-  const float& fx = pKF->fx;
-  const float& fy = pKF->fy;
-  const float& cx = pKF->cx;
-  const float& cy = pKF->cy;
-  Sophus::SE3f Tcw = Sophus::SE3f(Scw.rotationMatrix(), Scw.translation() / Scw.scale());
-  Eigen::Vector3f Ow = Tcw.inverse().translation();
+  const float fx = pKF->fx, fy = pKF->fy, cx = pKF->cx, cy = pKF->cy;   // the keyframe's pinhole intrinsics
+  const Sophus::SE3f Tcw = rigid_part(Scw);
+  const Eigen::Vector3f Ow = Tcw.inverse().translation();
   set<MapPoint*> spAlreadyFound(vpMatched.begin(), vpMatched.end());
   spAlreadyFound.erase(static_cast<MapPoint*>(NULL));
   // phase 1 (:445-491 / :553-610)
@@ -995,34 +995,36 @@ int ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& v
 // ---------------------------------------------------------------------------------------------------------------------
 // SearchForTriangulation  :907-1146
 // ---------------------------------------------------------------------------------------------------------------------
+namespace {
+// The cameras of two keyframes relative to each other: (R, t)[a][b] takes camera b of the second keyframe into camera a of the first — a / b = 0
+// for the left (or only) camera, 1 for the right camera of a two-camera rig — and the epipole: the first keyframe's camera centre seen by the
+// second keyframe's left camera.  One table instead of the reference's five named transforms and the per-pair selection among them.
+struct PairGeometry {
+  Eigen::Matrix3f R[2][2];
+  Eigen::Vector3f t[2][2];
+  GeometricCamera* cam1[2];
+  GeometricCamera* cam2[2];
+  Eigen::Vector2f epipole;
+  bool rig;
+  PairGeometry(KeyFrame* k1, KeyFrame* k2) : rig(k1->mpCamera2 && k2->mpCamera2) {
+    cam1[0] = k1->mpCamera; cam1[1] = k1->mpCamera2; cam2[0] = k2->mpCamera; cam2[1] = k2->mpCamera2;
+    epipole = k2->mpCamera->project(k2->GetPose() * k1->GetCameraCenter());
+    const int nc = rig ? 2 : 1;
+    for (int a = 0; a < nc; a++)
+      for (int b = 0; b < nc; b++) {
+        const Sophus::SE3f T = (a ? k1->GetRightPose() : k1->GetPose()) * (b ? k2->GetRightPoseInverse() : k2->GetPoseInverse());
+        R[a][b] = T.rotationMatrix();
+        t[a][b] = T.translation();
+      }
+  }
+};
+}  // namespace
+
 int ORBmatcher::SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, vector<pair<size_t, size_t> >& vMatchedPairs, const bool bOnlyStereo,
                                        const bool bCoarse) {
-  // epipole of the first camera in the second image and the relative poses (:913-943)
-  Sophus::SE3f T1w = pKF1->GetPose();
-  Sophus::SE3f T2w = pKF2->GetPose();
-  Sophus::SE3f Tw2 = pKF2->GetPoseInverse();
-  Eigen::Vector3f Cw = pKF1->GetCameraCenter();
-  Eigen::Vector3f C2 = T2w * Cw;
-  Eigen::Vector2f ep = pKF2->mpCamera->project(C2);
-  Sophus::SE3f T12;
-  Sophus::SE3f Tll, Tlr, Trl, Trr;
-  Eigen::Matrix3f R12;
-  Eigen::Vector3f t12;
-  GeometricCamera *pCamera1 = pKF1->mpCamera, *pCamera2 = pKF2->mpCamera;
-  if (!pKF1->mpCamera2 && !pKF2->mpCamera2) {
-    T12 = T1w * Tw2;
-    R12 = T12.rotationMatrix();
-    t12 = T12.translation();
-  } else {
-    Sophus::SE3f Tr1w = pKF1->GetRightPose();
-    Sophus::SE3f Twr2 = pKF2->GetRightPoseInverse();
-    Tll = T1w * Tw2;
-    Tlr = T1w * Twr2;
-    Trl = Tr1w * Tw2;
-    Trr = Tr1w * Twr2;
-  }
-  Eigen::Matrix3f Rll = Tll.rotationMatrix(), Rlr = Tlr.rotationMatrix(), Rrl = Trl.rotationMatrix(), Rrr = Trr.rotationMatrix();
-  Eigen::Vector3f tll = Tll.translation(), tlr = Tlr.translation(), trl = Trl.translation(), trr = Trr.translation();
+  // relative geometry of the two keyframes' cameras (:913-943) as a table [camera of KF1][camera of KF2] (0 = left / only, 1 = right of a rig)
+  const PairGeometry geo(pKF1, pKF2);
+  const Eigen::Vector2f& ep = geo.epipole;
   // phase 1 (:963-996): features of KF1 without a map point against the ones of KF2 in the same node that have none either
   auto key1 = [&](size_t i) -> const cv::KeyPoint& {
     return (pKF1->NLeft == -1) ? pKF1->mvKeysUn[i] : (i < (size_t)pKF1->NLeft) ? pKF1->mvKeys[i] : pKF1->mvKeysRight[i - pKF1->NLeft];
@@ -1083,13 +1085,9 @@ int ORBmatcher::SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, vector<pa
         const float distey = ep(1) - kp2.pt.y;
         if (distex * distex + distey * distey < 100 * pKF2->mvScaleFactors[kp2.octave]) continue;
       }
-      if (pKF1->mpCamera2 && pKF2->mpCamera2) {
-        if (bRight1 && bRight2) { R12 = Rrr; t12 = trr; T12 = Trr; pCamera1 = pKF1->mpCamera2; pCamera2 = pKF2->mpCamera2; }
-        else if (bRight1 && !bRight2) { R12 = Rrl; t12 = trl; T12 = Trl; pCamera1 = pKF1->mpCamera2; pCamera2 = pKF2->mpCamera; }
-        else if (!bRight1 && bRight2) { R12 = Rlr; t12 = tlr; T12 = Tlr; pCamera1 = pKF1->mpCamera; pCamera2 = pKF2->mpCamera2; }
-        else { R12 = Rll; t12 = tll; T12 = Tll; pCamera1 = pKF1->mpCamera; pCamera2 = pKF2->mpCamera; }
-      }
-      if (bCoarse || pCamera1->epipolarConstrain(pCamera2, kp1, kp2, R12, t12, pKF1->mvLevelSigma2[kp1.octave], pKF2->mvLevelSigma2[kp2.octave])) {
+      const int c1 = geo.rig && bRight1, c2 = geo.rig && bRight2;   // which camera of each keyframe holds the two keypoints (:1066-1095)
+      if (bCoarse || geo.cam1[c1]->epipolarConstrain(geo.cam2[c2], kp1, kp2, geo.R[c1][c2], geo.t[c1][c2], pKF1->mvLevelSigma2[kp1.octave],
+                                                     pKF2->mvLevelSigma2[kp2.octave])) {
         bestIdx2 = idx2;
         bestDist = d;
       }
@@ -1210,8 +1208,8 @@ int ORBmatcher::Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, const 
 // Fuse(KeyFrame*, Sim3, points, th, vpReplacePoint)  :1340-1455
 // ---------------------------------------------------------------------------------------------------------------------
 int ORBmatcher::Fuse(KeyFrame* pKF, Sophus::Sim3f& Scw, const vector<MapPoint*>& vpPoints, float th, vector<MapPoint*>& vpReplacePoint) {
-  Sophus::SE3f Tcw = Sophus::SE3f(Scw.rotationMatrix(), Scw.translation() / Scw.scale());
-  Eigen::Vector3f Ow = Tcw.inverse().translation();
+  const Sophus::SE3f Tcw = rigid_part(Scw);
+  const Eigen::Vector3f Ow = Tcw.inverse().translation();
   const set<MapPoint*> spAlreadyFound = pKF->GetMapPoints();
   const int nPoints = vpPoints.size();
   // phase 1 (:1358-1405)
@@ -1264,10 +1262,7 @@ int ORBmatcher::Fuse(KeyFrame* pKF, Sophus::Sim3f& Scw, const vector<MapPoint*>&
 // SearchBySim3  :1457-1674
 // ---------------------------------------------------------------------------------------------------------------------
 int ORBmatcher::SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const Sophus::Sim3f& S12, const float th) {
-  const float& fx = pKF1->fx;
-  const float& fy = pKF1->fy;
-  const float& cx = pKF1->cx;
-  const float& cy = pKF1->cy;
+  const float fx = pKF1->fx, fy = pKF1->fy, cx = pKF1->cx, cy = pKF1->cy;
   Sophus::SE3f T1w = pKF1->GetPose();
   Sophus::SE3f T2w = pKF2->GetPose();
   Sophus::Sim3f S21 = S12.inverse();
