@@ -222,6 +222,18 @@ def streamed_frontend(host_frames, nfeatures, voc_descriptors, nframes=48):
             out["cpu"] = ref
             if not ref["identical_results"]:
                 raise SystemExit("bench.py: the streamed front-end on the GPU and the reference-compiled CPU loop DISAGREE — no number reported")
+        # the same sequence AS A STREAM (tools/streamed_frontend.cpp --frames: forth and back through the images, a ring of 8 frames): 512 frames back to
+        # back, and 160 frames paced by the 20 Hz time stamps of EuRoC MH_01 (Examples/Monocular/mono_euroc.cc:150-160: the GPU idles 49.6 of every
+        # 50 ms) — every call's p50 / p90 / p99 / max.  The full 3 682-frame runs with the digest against the reference: profiles/config3_full_r6.txt
+        try:
+            stamps = wu.mh01_stamps(tmp)
+            free = wu.run_frontend(exe, raw, rows, cols, n, nfeatures, vocp, passes=1, timeout=300, frames=512)
+            paced = wu.run_frontend(exe, raw, rows, cols, n, nfeatures, vocp, passes=1, timeout=300, frames=160, stamps=stamps, pace=1)
+            out["stream"] = {"back_to_back": {"frames": free["frames_timed"], "percentiles": free["percentiles"]},
+                             "paced_20hz": {"frames": paced["frames_timed"], "percentiles": paced["percentiles"], "wall_s": paced["stream"]["wall_s"]},
+                             "paced_over_back_to_back_p50": round(paced["percentiles"]["four_calls_ms"]["p50"] / free["percentiles"]["four_calls_ms"]["p50"], 3)}
+        except Exception as e:   # noqa: BLE001
+            out["stream"] = {"error": str(e)[:200]}
         return out
     except SystemExit:
         raise

@@ -91,6 +91,14 @@ def test_bench_json_line():
     sf = j["streamed_frontend"]
     assert "error" not in sf, sf
     assert 0.05 < sf["ms_per_frame"] < 20 and sf["features_per_frame"] > 900 and sf["matches_last_per_frame"] > 100
+    # ... and as a stream: back to back and paced at MH_01's 20 Hz, with percentiles of every call
+    st = sf["stream"]
+    assert "error" not in st, st
+    assert st["back_to_back"]["frames"] == 504 and st["paced_20hz"]["frames"] == 152 and 7.0 < st["paced_20hz"]["wall_s"] < 9.5
+    for leg in ("back_to_back", "paced_20hz"):
+        q = st[leg]["percentiles"]["four_calls_ms"]
+        assert 0.05 < q["p50"] <= q["p90"] <= q["p99"] <= q["max"] < 50
+    assert 0.8 < st["paced_over_back_to_back_p50"] < 3.0
     if "cpu" in sf:   # the same loop on the reference-compiled CPU code: same results, and slower
         assert sf["cpu"]["identical_results"] is True and sf["cpu"]["ms_per_frame"] > sf["ms_per_frame"]
 
