@@ -1,7 +1,7 @@
 #!/bin/bash
 # End-of-round evidence refresh on the GPU box: everything lands in gpurun_out/ (merged back), then copied into profiles/.
-# usage (from the repo root on the box): bash tools/final_refresh.sh r5a <commit>
-TAG=${1:-r5x}
+# usage (from the repo root on the box): bash tools/final_refresh.sh r6a <commit>
+TAG=${1:-r6x}
 export ORBX_COMMIT=${2:-unknown}      # the GPU box has no .git: the caller passes `git rev-parse --short=12 HEAD`; every evidence file is stamped with it
 mkdir -p gpurun_out
 export TMPDIR=/tmp
@@ -39,3 +39,6 @@ timeout 400 python tools/fuzz_extractor.py 400 150 2>&1 | tail -3 | tee gpurun_o
 timeout 500 python tools/fuzz_extractor.py 900 200 --variants 2>&1 | tail -3 | tee gpurun_out/fuzz_${TAG}_variants.log
 timeout 600 python tools/fuzz_worlds.py 700 8 2>&1 | tail -4 | tee gpurun_out/fuzz_worlds_$TAG.log
 timeout 600 python tools/fuzz_frame_world.py 201 10 2>&1 | tail -4 | tee gpurun_out/fuzz_frame_world_$TAG.log
+# BASELINE config 3 at length: 3 682 frames back to back, paced at MH_01's 20 Hz (sleeping, and busy-waiting: whose idle state is the paced tail?), and the
+# reference-compiled loop; digests over ALL frames
+timeout 1500 python tools/config3_full.py --spin > gpurun_out/config3_full_$TAG.txt 2> gpurun_out/config3_full_$TAG.err; echo "config3 exit $?"; grep -E "^digest|^paced" gpurun_out/config3_full_$TAG.txt
