@@ -579,3 +579,26 @@ def test_eight_ranks_on_one_device_every_rank_holds_all_eight_blocks():
     assert len(set(own)) == world                                                  # eight different cameras
     for r in res:
         assert r[4] == own and all(n > 20000 for n in r[5]), r[5]                  # every part = its owner's block; ~1000 features x 32 frames each
+
+
+def test_abort_leaves_the_group_and_the_engine_goes_on_without_the_exchange():
+    """orbx_replay_abort (ncclCommAbort: no hand-shake with ranks that may be gone): a one-rank RCCL engine steps with its self-gather, aborts,
+    and keeps extracting — same blocks as before — with the exchange off; the bounded host wait reports a finished exchange at once."""
+    import torch
+    from orb_slam3_modified_amd import ORBextractor, synth
+    from orb_slam3_modified_amd.replay import ReplayEngine
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    frames = torch.from_numpy(synth.make_stream(32, 240, 320)).to(dev)
+    eng = ReplayEngine(ORBextractor(500, 1.2, 6, 20, 7, device_id=0), frames, lapping=(0, 1000), gather=True, lanes=1, gather_what="descriptors")
+    assert eng.failed == 0
+    i = eng.step()
+    assert eng.wait_gathered_host(i, 5000)
+    before = eng.block_host(i).copy()
+    assert np.array_equal(eng.gathered_host(i).reshape(-1), before[eng.send_off:])
+    eng.abort()
+    assert not eng.gather and "[aborted]" in eng._L.orbx_replay_transport(eng._h).decode()
+    for _ in range(3):
+        j = eng.step()
+    assert np.array_equal(eng.block_host(j), before) and eng.failed == 0        # the same frames: the same block, no exchange needed
+    eng.close()
