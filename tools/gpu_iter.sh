@@ -2,9 +2,10 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-export ORBX_COMMIT=$(cat .commit_stamp 2>/dev/null)
-STAMP=$(python -c "from orb_slam3_modified_amd.build import stamp; s = stamp(); print('commit', s['commit'], 'kernel sources', s['kernels_hash'], s['date'])")
-{ echo "$STAMP"; timeout 1500 python tools/fuzz_extractor.py 5000 900 2>&1 | tail -4; } | tee gpurun_out/fuzz_r6b_900.log
-{ echo "$STAMP"; timeout 1200 python tools/fuzz_extractor.py 7000 500 --variants 2>&1 | tail -4; } | tee gpurun_out/fuzz_r6b_variants_500.log
-{ echo "$STAMP"; timeout 900 python tools/fuzz_worlds.py 900 20 2>&1 | tail -3; } | tee gpurun_out/fuzz_worlds_r6b_20.log
-{ echo "$STAMP"; timeout 900 python tools/fuzz_frame_world.py 301 30 2>&1 | tail -2; } | tee gpurun_out/fuzz_frame_world_r6b_30.log
+python -c "
+import ctypes
+h=ctypes.CDLL('libamdhip64.so'); lo=ctypes.c_int(); hi=ctypes.c_int(); print('priority range rc', h.hipDeviceGetStreamPriorityRange(ctypes.byref(lo), ctypes.byref(hi)), lo.value, hi.value)"
+run() { echo "$1: $(env $1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-frontend --no-fixed-streams --no-secondary 2>/dev/null | tail -1 | python -c "
+import sys,json; j=json.loads(sys.stdin.read()); print('step', j['ms_per_step'], 'min/max', j['timing']['ms_per_step_min'], j['timing']['ms_per_step_max'], 'value', j['value'])")"; }
+{ for rep in 1 2; do
+for E in "ORBX_AUX_PRIO=0,0,0" "ORBX_AUX_PRIO=1,0,0" "ORBX_AUX_PRIO=0,0,-1" "ORBX_AUX_PRIO=1,0,-1" "ORBX_AUX_PRIO=1,-1,-1" "ORBX_AUX_PRIO=-1,0,0" "ORBX_LANE_PRIO=-1" "ORBX_LANE_PRIO=1"; do run "$E"; done; done; } 2>&1 | tee gpurun_out/prio_ab.txt
