@@ -94,7 +94,7 @@ def test_bench_json_line():
     # ... and as a stream: back to back and paced at MH_01's 20 Hz, with percentiles of every call
     st = sf["stream"]
     assert "error" not in st, st
-    assert st["back_to_back"]["frames"] == 504 and st["paced_20hz"]["frames"] == 152 and 7.0 < st["paced_20hz"]["wall_s"] < 9.5
+    assert st["back_to_back"]["frames"] == 504 and st["paced_20hz"]["frames"] == 152 and 7.0 < st["paced_20hz"]["wall_s"] < 12.0
     for leg in ("back_to_back", "paced_20hz"):
         q = st[leg]["percentiles"]["four_calls_ms"]
         assert 0.05 < q["p50"] <= q["p90"] <= q["p99"] <= q["max"] < 50
