@@ -864,7 +864,7 @@ def main():
     total_frames = B * world * args.steps
     value = total_feats / (dt * 1e3)
 
-    lane_edges = sorted({0, B - 1} | {f for (f0, f1) in eng.lane_ranges for f in (f0, f1 - 1)} | {B // 3})
+    lane_edges = sorted({0, B - 1, B // 2 - 1, B // 2} | {f for (f0, f1) in eng.lane_ranges for f in (f0, f1 - 1)} | {B // 3})
     verified = 0 if args.no_verify else verify_block(eng, last, host_frames[last_set * B:(last_set + 1) * B], lane_edges, args.nfeatures, (0, 1000), args.variant)
     vt = torch.tensor([verified], dtype=torch.int64, device=cdev)
     if world > 1:
@@ -947,6 +947,8 @@ def main():
                                                        # verified; tools/opencv_pin/run.sh is the maintainer's one-command pin against a real one
                        "exchange": (f"ncclAllGather({args.gather}) by liborbx, async/overlapped" if eng.gather else "none"),
                        "lanes_per_gpu": len(eng.lane_ranges), "requested_gpus": requested,
+                       "lane_schedule": ("alternate: the lanes take whole steps in turn (step k on lane k mod L over all frames; two steps in flight)" if eng.alternate
+                                         else "split: every lane works on its share of every step"),
                        "streams": (args.streams if args.streams > 0 else world), "frames_per_stream_per_step": args.batch,
                        "scaling_mode": (f"strong: the same {args.streams} camera streams for every G, stream c -> GPU c mod G (SURVEY 8(e))" if args.streams > 0
                                         else "weak: one camera stream per GPU, per-GPU work fixed; SURVEY 8(e)'s fixed-8-stream curve is the `strong` record of this line"),

@@ -500,8 +500,12 @@ int orbx_kfdb_score(orbx_kfdb* db, const uint32_t* q_ids, const double* q_vals, 
  * gather_what: ORBX_GATHER_DESCRIPTORS moves the tail of the block (descriptor rows + counts: north_star's "all-gather of descriptors"),
  * ORBX_GATHER_BLOCKS the whole block (SURVEY §8(e)'s), ORBX_GATHER_NONE nothing (the sharded extraction alone).
  *
- * lanes: 1 .. 16 extractor contexts of ONE device with identical parameters, owned by the caller; each works on its contiguous share of the
- * step's frames on a stream of its own (two lanes: +7.6 % on 256 x 640x480 — they drift out of phase and fill each other's idle issue slots).
+ * lanes: 1 .. 16 extractor contexts of ONE device with identical parameters, owned by the caller, each on a stream of its own (two lanes: +7.6 %
+ * on 256 x 640x480 — they drift out of phase and fill each other's idle issue slots).  Schedule: by default the lanes take WHOLE steps in turn
+ * (step k runs on lane k mod L over all `frames` frames while the other lanes are still busy with the steps before it: +3.5 % over the split
+ * form, every launch covers the whole batch; a step's results are complete one step later and every lane holds buffers for `frames` frames);
+ * orbx_set_option(lanes[0], "replay_alternate", 0) before creation (or ORBX_REPLAY_ALTERNATE=0) = every lane works on its contiguous share of
+ * every step.  orbx_replay_lane_range tells which frames a lane covers ([0, frames) for every lane under the default schedule).
  * Transport, by argument: unique_id != NULL -> ncclCommInitRank(world, unique_id, rank), the 128 bytes coming from orbx_replay_unique_id() on
  * one rank and reaching the others by whatever the host has (a file, MPI, a TCP store); host_exchange != NULL -> the caller's own host
  * all-gather, the block staged through pinned memory (tests, hosts without RCCL between their ranks); both NULL -> world must be 1 and a

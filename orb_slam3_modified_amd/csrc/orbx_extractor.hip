@@ -1437,6 +1437,7 @@ int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
   else if (n == "fast_pk") ctx->fast_pk = value != 0;
   else if (n == "realign") ctx->realign = value != 0;   // batch frames with rows that are not dword-aligned: one pass into an aligned copy first
   else if (n == "fast_stage_dma") ctx->fast_stage_dma = value != 0;   // FAST tile staged by LDS-DMA loads instead of load + ds_write
+  else if (n == "replay_alternate" && (value == 0 || value == 1)) { ctx->replay_alternate = value; return ORBX_OK; }   // read by orbx_replay_prepare from lane 0
   else if (n == "fast_passes" && (value == 1 || value == 2)) ctx->fast_passes = value;   // batch FAST: 2 = iniTh first, minTh where the cell stayed empty; 1 = one pass at minTh
   else if (n == "gauss_kernel" && (value == 0 || value == 1)) ctx->gauss_kernel = value;   // which OpenCV's 8-bit Gaussian weights (include/orbx.h)
   else if (n == "gauss_round" && value >= 0 && value <= 2) ctx->gauss_round = value;       // ... which rounding of the column pass

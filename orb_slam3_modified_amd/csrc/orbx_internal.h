@@ -155,6 +155,7 @@ struct orbx_ctx {
   bool realign = true;          // batch calls: frames whose rows are not dword-aligned are copied into an aligned buffer first
   uint8_t* d_realign = nullptr;
   size_t realign_bytes = 0;
+  int replay_alternate = -1;    // lane schedule of a replay engine whose lane 0 this context is: -1 default (alternate for >= 2 lanes), 0 split, 1 alternate
   int fast_passes = 2;          // batch FAST: 2 = the reference's two-threshold cell loop literally (iniTh, then minTh where the cell stayed empty); 1 = one pass at minTh
   bool fast_stage_dma = true;   // FAST: the cell's tile by LDS-DMA loads (aligned sources)
   int qt_points = 2048;       // LDS-resident candidate capacity per (frame, level) of k_quadtree's big levels ("qt_points" / ORBX_QT_POINTS)

@@ -125,6 +125,12 @@ struct orbx_replay {
   double t_sum_ms = 0; long long t_n = 0;
   unsigned long long step_idx = 0;
   std::string err;
+  // lane schedule (round 6).  alternate: the lanes take WHOLE steps in turn — step k runs on lane k mod L over all `frames` frames while the other
+  // lanes are still busy with the steps before it — instead of every lane working on its share of every step.  Same results, the same overlap of
+  // two free-running streams, but every launch covers the whole batch: +3.5 % at 256 frames per step (0.912 -> 0.878 ms, profiles/replay_alternate_ab_r6.txt);
+  // a step's results are complete one step later.  Default for two and more lanes; lane 0's option "replay_alternate" = 0 (or ORBX_REPLAY_ALTERNATE=0)
+  // keeps the split form.
+  bool alternate = false;
 };
 
 namespace {
@@ -227,7 +233,13 @@ int orbx_replay_prepare(orbx_replay** out, orbx_ctx* const* lanes, int nlanes, i
   r->send_off = gather_what == ORBX_GATHER_DESCRIPTORS ? r->desc_off : 0;
   r->send_bytes = r->nbytes - r->send_off;
   const int per = (frames + nlanes - 1) / nlanes;
-  for (int j = 0; j < nlanes; j++) if (j * per < frames) r->ranges.push_back({j * per, std::min(frames, (j + 1) * per)});
+  {
+    int want = lanes[0]->replay_alternate;   // -1 = by default, 0 / 1 = the caller's choice
+    if (const char* ae = getenv("ORBX_REPLAY_ALTERNATE")) want = atoi(ae) != 0;
+    r->alternate = nlanes >= 2 && want != 0;
+  }
+  if (r->alternate) r->ranges.assign(nlanes, {0, frames});
+  else for (int j = 0; j < nlanes; j++) if (j * per < frames) r->ranges.push_back({j * per, std::min(frames, (j + 1) * per)});
   r->lanes.resize(r->ranges.size());
   auto bail = [&](int code, const std::string& msg) { if (r->lanes[0]) orbx::set_err(r->lanes[0], code, msg); release(r); return code; };
   if (hipSetDevice(r->device) != hipSuccess) return bail(ORBX_E_DEVICE, "orbx_replay_prepare: hipSetDevice failed");
@@ -364,10 +376,14 @@ int orbx_replay_step(orbx_replay* r, const uint8_t* d_frames, size_t row_stride,
   // no extraction produces, so a reader of the gathered buffer sees which rank dropped out at which step; the caller of THIS rank gets the
   // lane's error from this call and from every later one (orbx_replay_failed), and decides when to leave (orbx_replay_destroy after the
   // others have been told over the host's own control plane, or orbx_replay_abort).
+  const size_t active = r->alternate ? (size_t)(r->step_idx % r->lanes.size()) : 0;
   for (size_t j = 0; j < r->lanes.size() && !r->failed_code; j++) {
+    if (r->alternate && j != active) continue;
     const int f0 = r->ranges[j].first, f1 = r->ranges[j].second;
     // the collective that last read this block must be done before a lane overwrites it (a device-side wait: no host stall)
     if (r->pending[i]) RHIP(r, hipStreamWaitEvent(r->streams[j], r->gather_done[i], 0));
+    if (r->alternate)   // ... and so must the lane that wrote this block two steps ago, when that was another lane
+      for (size_t jj = 0; jj < r->lanes.size(); jj++) if (jj != j) (void)hipStreamWaitEvent(r->streams[j], r->lane_done[i][jj], 0);
     const int rc = orbx_extract_batch_device(r->lanes[j], d_frames + (size_t)f0 * frame_stride, f1 - f0, r->rows, r->cols, row_stride, frame_stride, lap0, lap1,
                                              (orbx_keypoint*)(base + (size_t)f0 * r->cap * sizeof(orbx_keypoint)), base + r->desc_off + (size_t)f0 * r->cap * 32,
                                              (int32_t*)(base + r->counts_off + (size_t)f0 * 8), r->streams[j]);
@@ -380,15 +396,20 @@ int orbx_replay_step(orbx_replay* r, const uint8_t* d_frames, size_t row_stride,
   if (r->failed_code) {
     r->err = r->failed_msg;
     if (!r->gather_on) { r->step_idx++; return r->failed_code; }
-    // the poison, behind whatever the lanes of this step already queued and behind the collective that last read the block
-    if (r->pending[i]) (void)hipStreamWaitEvent(r->streams[0], r->gather_done[i], 0);
-    for (size_t j = 1; j < r->lanes.size(); j++)
-      if (hipEventRecord(r->lane_done[i][j], r->streams[j]) == hipSuccess) (void)hipStreamWaitEvent(r->streams[0], r->lane_done[i][j], 0);
-    (void)hipMemsetAsync(base + r->counts_off, 0xff, r->counts_bytes, r->streams[0]);
+    // the poison, behind whatever the lanes of this step already queued and behind the collective that last read the block (alternate schedule:
+    // on the step's own lane, whose stream already waits for the block's previous writers)
+    hipStream_t ps = r->streams[r->alternate ? active : 0];
+    if (r->pending[i]) (void)hipStreamWaitEvent(ps, r->gather_done[i], 0);
+    if (!r->alternate)
+      for (size_t j = 1; j < r->lanes.size(); j++)
+        if (hipEventRecord(r->lane_done[i][j], r->streams[j]) == hipSuccess) (void)hipStreamWaitEvent(ps, r->lane_done[i][j], 0);
+    (void)hipMemsetAsync(base + r->counts_off, 0xff, r->counts_bytes, ps);
   }
-  if (r->gather_on)
-    for (size_t j = 0; j < r->lanes.size(); j++)
+  if (r->gather_on || r->alternate)
+    for (size_t j = 0; j < r->lanes.size(); j++) {
+      if (r->alternate && j != active) continue;
       if (hipEventRecord(r->lane_done[i][j], r->streams[j]) != hipSuccess && !r->failed_code) return rfail(r, ORBX_E_DEVICE, "orbx_replay_step: hipEventRecord failed");
+    }
   r->pending[i] = false;
   int xrc = ORBX_OK;   // the exchange's own failure (reported when the lanes were fine)
   if (r->gather_on) {   // queued behind this step's kernels, overlaps the next step's

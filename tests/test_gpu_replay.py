@@ -159,8 +159,8 @@ def test_the_configuration_bench_times_is_bit_exact_on_every_frame():
     sets_host = [host[(np.arange(nfr) + 7 * k) % 24] for k in range(3)]
     sets = [torch.from_numpy(h).to(dev) for h in sets_host]
     ex = ORBextractor(1000, 1.2, 8, 20, 7, device_id=0)
-    eng = ReplayEngine(ex, sets, lapping=(0, 1000), gather=False, lanes=2)
-    assert len(eng.lane_ranges) == 2 and eng.lane_ranges[0][1] - eng.lane_ranges[0][0] == 130
+    eng = ReplayEngine(ex, sets, lapping=(0, 1000), gather=False, lanes=2, alternate=False)     # the SPLIT schedule: every lane its share of every step
+    assert len(eng.lane_ranges) == 2 and eng.lane_ranges[0][1] - eng.lane_ranges[0][0] == 130 and not eng.alternate
     ora = po.OracleExtractor(1000, 1.2, 8, 20, 7)
     last = 0
     for _ in range(7):
@@ -372,7 +372,7 @@ def test_replay_c_abi_argument_checks_and_uneven_lanes():
     host = synth.make_stream(5)
     nfr = 100
     frames = torch.from_numpy(host[np.arange(nfr) % 5]).to("cuda:0")
-    eng = ReplayEngine(a, frames, lapping=(0, 1000), gather=True, lanes=3, gather_what="blocks")
+    eng = ReplayEngine(a, frames, lapping=(0, 1000), gather=True, lanes=3, gather_what="blocks", alternate=False)
     assert eng.lane_ranges == [(0, 34), (34, 68), (68, 100)]
     for _ in range(3):
         i = eng.step()
@@ -601,4 +601,37 @@ def test_abort_leaves_the_group_and_the_engine_goes_on_without_the_exchange():
     for _ in range(3):
         j = eng.step()
     assert np.array_equal(eng.block_host(j), before) and eng.failed == 0        # the same frames: the same block, no exchange needed
+    eng.close()
+
+
+@pytest.mark.parametrize("lanes", [2, 3])
+def test_the_alternate_lane_schedule_is_bit_exact_on_every_frame_with_steps_in_flight(lanes):
+    """The default schedule since round 6: the lanes take WHOLE steps in turn (step k on lane k mod L, all frames), so two steps are in flight on
+    free-running streams and every launch covers the whole batch.  Rotating batches, the exchange on, nothing drained until the end — EVERY frame
+    of the last two steps (both blocks) against the oracle, each gathered buffer equal to its block; with three lanes the block of step k is written
+    by another lane than the one that wrote it two steps before (the cross-lane wait)."""
+    import torch
+    from oracle import pyoracle as po
+    from orb_slam3_modified_amd import ORBextractor, synth
+    from orb_slam3_modified_amd.replay import ReplayEngine, unpack_block
+    dev = torch.device("cuda", 0)
+    host = synth.make_stream(24)
+    nfr, nsets, steps = 96, 3, 9
+    src = [[(f + 5 * k) % 24 for f in range(nfr)] for k in range(nsets)]            # which image frame f of batch k is
+    sets = [torch.from_numpy(np.ascontiguousarray(host[src[k]])).to(dev) for k in range(nsets)]
+    eng = ReplayEngine(ORBextractor(1000, 1.2, 8, 20, 7, device_id=0), sets, lapping=(0, 1000), gather=True, lanes=lanes, gather_what="blocks")
+    assert eng.alternate and eng.lane_ranges == [(0, nfr)] * lanes
+    ora = po.OracleExtractor(1000, 1.2, 8, 20, 7)
+    want = [ora.extract(host[m], (0, 1000)) for m in range(24)]
+    kept = [eng.step() for _ in range(steps)]
+    assert kept == [s_ & 1 for s_ in range(steps)]
+    for s_ in (steps - 2, steps - 1):
+        i, k = kept[s_], s_ % nsets
+        blk = eng.block_host(i)
+        assert np.array_equal(eng.gathered_host(i)[0], blk)
+        res = unpack_block(blk, eng.layout)
+        for f in range(nfr):
+            okps, odesc, omono = want[src[k][f]]
+            mono, kps, desc = res[f]
+            assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc), (lanes, s_, f)
     eng.close()
