@@ -13,10 +13,11 @@ import sys
 
 def kernel_stats(db, by_grid=False):
     c = sqlite3.connect(db)
-    if by_grid:   # one row per launch shape: a run that launches a kernel over different batch sizes keeps them apart
-        rows = c.execute("select name || ' [grid ' || (grid_x / workgroup_x) || 'x' || grid_y || 'x' || grid_z || ' wg]', count(*), "
+    if by_grid:   # one row per launch shape AND queue: a run that launches a kernel over different batch sizes keeps them apart, and so does one
+        # that launches the same shape from different streams (the replay lanes' overlapped launches against bench.py's isolated roofline passes)
+        rows = c.execute("select name || ' [grid ' || (grid_x / workgroup_x) || 'x' || grid_y || 'x' || grid_z || ' wg] [queue ' || queue_id || ']', count(*), "
                          "sum(end-start), avg(end-start), min(end-start), max(end-start) "
-                         "from kernels group by name, grid_x, grid_y, grid_z order by name, sum(end-start) desc").fetchall()
+                         "from kernels group by name, grid_x, grid_y, grid_z, queue_id order by name, sum(end-start) desc").fetchall()
     else:
         rows = c.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
                          "from kernels group by name order by sum(end-start) desc").fetchall()
@@ -42,7 +43,7 @@ def kernel_stats(db, by_grid=False):
 
 
 def short(name, n=70):
-    tail = name[name.rfind(" [grid"):] if " [grid" in name else ""
+    tail = name[name.find(" [grid"):] if " [grid" in name else ""
     name = name.split("(")[0]
     if tail and not name.endswith(tail):
         name += tail
