@@ -365,8 +365,8 @@ def rocprof_row(kernel, B, rows, cols, khash, ncalls=8):
     average duration of `kernel`'s whole-batch launches in the ISOLATED roofline passes, when the file is stamped with the kernel sources of THIS
     build.  The roofline's own time is the HIP-event one measured in this run; this is the cross-check the contract asks for, with the file it
     comes from.  k_fast_cells runs as two launches (residency groups) whose workgroup counts sum to (cells per frame) x B.  The summary has one row
-    per (launch shape, queue): since the replay lanes take whole steps in turn their overlapped launches have the same shapes as the isolated
-    passes, but they come from other queues — the rows taken are those of ONE queue whose call counts equal the number of isolated passes."""
+    per (launch shape, stream): since the replay lanes take whole steps in turn their overlapped launches have the same shapes as the isolated
+    passes, but they come from other streams — the rows taken are those of ONE stream whose call counts equal the number of isolated passes."""
     import glob
     import itertools
     import re
@@ -381,7 +381,7 @@ def rocprof_row(kernel, B, rows, cols, khash, ncalls=8):
             continue
         found = []   # (grid workgroups, calls, avg us, min us, max us, queue)
         for line in txt.splitlines():
-            mm = re.match(r"\|[^|]*\b" + re.escape(name) + r"\b[^|]*\[grid (\d+)x1x1 wg\](?: \[queue (\d+)\])?\s*\|\s*(\d+)\s*\|\s*[\d.]+\s*\|\s*([\d.]+)\s*\|\s*([\d.]+)\s*\|\s*([\d.]+)", line)
+            mm = re.match(r"\|[^|]*\b" + re.escape(name) + r"\b[^|]*\[grid (\d+)x1x1 wg\](?: \[(?:queue|stream) (\d+)\])?\s*\|\s*(\d+)\s*\|\s*[\d.]+\s*\|\s*([\d.]+)\s*\|\s*([\d.]+)\s*\|\s*([\d.]+)", line)
             if mm:
                 found.append((int(mm.group(1)), int(mm.group(3)), float(mm.group(4)), float(mm.group(5)), float(mm.group(6)), mm.group(2)))
         if not name.startswith("k_fast_cells"):
@@ -402,7 +402,7 @@ def rocprof_row(kernel, B, rows, cols, khash, ncalls=8):
             out = {"file": os.path.relpath(path, ROOT), "rocprof_avg_ms": round(sum(r[2] for r in combo) / 1e3, 4), "calls": [r[1] for r in combo],
                    "grids": [r[0] for r in combo], "min_ms": round(sum(r[3] for r in combo) / 1e3, 4), "max_ms": round(sum(r[4] for r in combo) / 1e3, 4)}
             if q is not None:
-                out["queue"] = int(q)
+                out["stream"] = int(q)
             return out
     return None
 
@@ -463,7 +463,7 @@ def kernel_roofline(ex, eng, frames, B, H, W, counts, world, steps, dt, nprof=8)
         "avg_launch_ms_source": f"HIP events around the kernel on its own stream, {nprof} whole-batch passes in this run (orbx_profile_read)",
         "launch_conditions": "whole per-GPU batch in one launch, kernels back to back on one context and its own queue (passes after the timed region; the one "
                              "untimed warm-up pass runs B - 8 frames, i.e. other grid sizes; the replay lanes' launches of the timed region have the same "
-                             "shapes but overlap each other and come from other queues: a kernel trace of this command tells them apart by queue)",
+                             "shapes but overlap each other and come from other streams: a kernel trace of this command tells them apart by stream)",
         "pipeline_fused_ideal_bytes_per_frame": int(fused),
         "pipeline_frac": round(fused * (B * world * steps / dt) / 1e9 / (HBM_PEAK_GBS * world), 5),
         "kernels_ms_per_launch": {k: round(v, 4) for k, v in per_kernel.items()}}

@@ -125,13 +125,13 @@ def test_bench_helpers_median_cells_and_rocprof_row(tmp_path, monkeypatch):
     # summary has one row per (shape, queue) and the isolated passes are the rows of ONE queue with exactly `ncalls` launches
     (prof / "rY_kernel_stats.md").write_text(
         "commit abc kernel sources 0123456789abcdee 2026-09-27T00:00Z\n\n| kernel | calls | total ms | avg us | min us | max us | % |\n|---|---:|---:|---:|---:|---:|---:|\n"
-        "| void orbx::k_fast_cells<128, 64, true> [grid 83456x1x1 wg] [queue 3] | 406 | 125.0 | 309.32 | 195.80 | 431.21 | 6.0 |\n"
-        "| void orbx::k_fast_cells<128, 64, true> [grid 52224x1x1 wg] [queue 5] | 406 | 72.0 | 178.75 | 117.52 | 274.85 | 3.0 |\n"
-        "| void orbx::k_fast_cells<128, 64, true> [grid 12032x1x1 wg] [queue 3] | 406 | 30.0 | 73.90 | 47.20 | 234.68 | 1.0 |\n"
-        "| void orbx::k_fast_cells<128, 64, true> [grid 135680x1x1 wg] [queue 1] | 8 | 2.707 | 338.42 | 328.41 | 347.64 | 0.1 |\n"
-        "| void orbx::k_fast_cells<128, 64, true> [grid 12032x1x1 wg] [queue 1] | 8 | 0.5 | 62.10 | 60.00 | 64.00 | 0.0 |\n")
+        "| void orbx::k_fast_cells<128, 64, true> [grid 83456x1x1 wg] [stream 3] | 406 | 125.0 | 309.32 | 195.80 | 431.21 | 6.0 |\n"
+        "| void orbx::k_fast_cells<128, 64, true> [grid 52224x1x1 wg] [stream 5] | 406 | 72.0 | 178.75 | 117.52 | 274.85 | 3.0 |\n"
+        "| void orbx::k_fast_cells<128, 64, true> [grid 12032x1x1 wg] [stream 3] | 406 | 30.0 | 73.90 | 47.20 | 234.68 | 1.0 |\n"
+        "| void orbx::k_fast_cells<128, 64, true> [grid 135680x1x1 wg] [stream 1] | 8 | 2.707 | 338.42 | 328.41 | 347.64 | 0.1 |\n"
+        "| void orbx::k_fast_cells<128, 64, true> [grid 12032x1x1 wg] [stream 1] | 8 | 0.5 | 62.10 | 60.00 | 64.00 | 0.0 |\n")
     r = bench.rocprof_row("k_fast_cells", 256, 480, 640, "0123456789abcdee")
-    assert r["queue"] == 1 and r["calls"] == [8, 8] and r["rocprof_avg_ms"] == 0.4005 and sorted(r["grids"]) == [12032, 135680]
+    assert r["stream"] == 1 and r["calls"] == [8, 8] and r["rocprof_avg_ms"] == 0.4005 and sorted(r["grids"]) == [12032, 135680]
     assert bench.rocprof_row("k_fast_cells", 128, 480, 640, "0123456789abcdef") is None      # no launch of that shape in the file
 
 

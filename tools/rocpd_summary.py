@@ -15,9 +15,9 @@ def kernel_stats(db, by_grid=False):
     c = sqlite3.connect(db)
     if by_grid:   # one row per launch shape AND queue: a run that launches a kernel over different batch sizes keeps them apart, and so does one
         # that launches the same shape from different streams (the replay lanes' overlapped launches against bench.py's isolated roofline passes)
-        rows = c.execute("select name || ' [grid ' || (grid_x / workgroup_x) || 'x' || grid_y || 'x' || grid_z || ' wg] [queue ' || queue_id || ']', count(*), "
+        rows = c.execute("select name || ' [grid ' || (grid_x / workgroup_x) || 'x' || grid_y || 'x' || grid_z || ' wg] [stream ' || stream_id || ']', count(*), "
                          "sum(end-start), avg(end-start), min(end-start), max(end-start) "
-                         "from kernels group by name, grid_x, grid_y, grid_z, queue_id order by name, sum(end-start) desc").fetchall()
+                         "from kernels group by name, grid_x, grid_y, grid_z, stream_id order by name, sum(end-start) desc").fetchall()
     else:
         rows = c.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
                          "from kernels group by name order by sum(end-start) desc").fetchall()
