@@ -2447,34 +2447,42 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x, int fma = 0) {
 // One rotated test point of the steered BRIEF (src/ORBextractor.cc:118-120): cvRound(x*b + y*a), cvRound(x*a - y*b).  fma == 0: separate
 // IEEE operations (canonical); fma != 0 (uniform): the contraction GCC / clang make when the reference is built as its
 // CMakeLists.txt asks (-O3 -march=native): the FIRST product is the fused one — fma(x, b, y*a), fma(x, a, -(y*b)) ("brief_fma" option).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t __attribute__((aligned(1))) u32_una;   // a dword at any byte address (global loads take it in one instruction)
+struct __attribute__((packed, aligned(1))) U4una { uint32_t x, y, z, w; };   // sixteen bytes at any byte address, one global_load_dwordx4
+constexpr int kDescSlicePitch = 48;   // bytes per row of k_describe's LDS slices (three 16-byte LDS-DMA transfers)
+constexpr uint32_t kRndBits = 0x4B400000u;   // 1.5 * 2^23 as a float: x + it leaves cvRound(x) in the low mantissa bits (|x| < 2^22), ties to even
+// Both coordinates of one rotated test point at once (v_pk_mul_f32 / v_pk_add_f32: two IEEE operations per instruction, each rounded on its
+// own): {x b + y a, x a - y b} with AB = {b, a}, ANB = {a, -b} (the negation is exact: x a + (y (-b)) is x a - y b bit for bit).  The results
+// stay floats + the rounding constant: the caller's address arithmetic takes the integer out of the mantissa.
 template <bool FMA>
-__device__ __forceinline__ void rot_tap(float x, float y, float a, float b, int& ry, int& rx) {
-  if (FMA) {
-    ry = __float2int_rn(__fmaf_rn(x, b, __fmul_rn(y, a)));
-    rx = __float2int_rn(__fmaf_rn(x, a, -__fmul_rn(y, b)));
-  } else {
-    ry = __float2int_rn(__fadd_rn(__fmul_rn(x, b), __fmul_rn(y, a)));
-    rx = __float2int_rn(__fsub_rn(__fmul_rn(x, a), __fmul_rn(y, b)));
-  }
+__device__ __forceinline__ void rot_tap(float x, float y, f32x2 AB, f32x2 ANB, int& ryb, int& rxb) {
+  const f32x2 X = {x, x}, Y = {y, y};
+  const f32x2 yy = Y * ANB;
+  f32x2 r;
+  if (FMA) r = __builtin_elementwise_fma(X, AB, yy);
+  else r = X * AB + yy;
+  r = r + (f32x2){12582912.f, 12582912.f};
+  ryb = __float_as_int(r.x); rxb = __float_as_int(r.y);
 }
 // the eight taps of one lane (four tests) read from `base` with row pitch `pitch` (LDS window or the blurred plane); the loads sit inside
-// the caller's uniform branch on the variant, so the two arithmetic forms are never both evaluated
-template <bool FMA, bool MUL40>
+// the caller's uniform branch on the variant, so the two arithmetic forms are never both evaluated.  ryb = kRndBits + ry: v_mul_i24 sees
+// its low 24 bits, 0x400000 + ry, so ryb * pitch + rxb = ry * pitch + rx + (pitch << 22) + kRndBits (mod 2^32): one uniform correction.
+template <bool FMA, bool SLICE>
 __device__ __forceinline__ void brief_taps(const uint8_t* __restrict__ base, int ctr, int pitch, const char4 (&pat)[4], float a, float b,
                                            int (&t0)[4], int (&t1)[4]) {
+  const f32x2 AB = {b, a}, ANB = {a, -b};
+  const uint32_t cu = (uint32_t)ctr - (((uint32_t)(SLICE ? kDescSlicePitch : pitch) << 22) + kRndBits);   // uniform; the sums below are exact mod 2^32
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     const float x0 = (float)pat[q].x, y0 = (float)pat[q].y, x1 = (float)pat[q].z, y1 = (float)pat[q].w;
     int ry0, rx0, ry1, rx1;
-    rot_tap<FMA>(x0, y0, a, b, ry0, rx0);
-    rot_tap<FMA>(x1, y1, a, b, ry1, rx1);
-    if (MUL40) {
-      t0[q] = base[ctr + __mul24(ry0, 40) + rx0];
-      t1[q] = base[ctr + __mul24(ry1, 40) + rx1];
-    } else {
-      t0[q] = base[(uint32_t)(ctr + __mul24(ry0, pitch) + rx0)];
-      t1[q] = base[(uint32_t)(ctr + __mul24(ry1, pitch) + rx1)];
-    }
+    rot_tap<FMA>(x0, y0, AB, ANB, ry0, rx0);
+    rot_tap<FMA>(x1, y1, AB, ANB, ry1, rx1);
+    int o0 = __mul24(ry0, SLICE ? kDescSlicePitch : pitch) + rx0, o1 = __mul24(ry1, SLICE ? kDescSlicePitch : pitch) + rx1;   // one v_mad_i32_i24 each
+    asm("" : "+v"(o0), "+v"(o1));   // kept apart from the uniform part: the compiler would re-associate the sum into three additions
+    t0[q] = base[(uint32_t)o0 + cu];
+    t1[q] = base[(uint32_t)o1 + cu];
   }
 }
 
@@ -2507,7 +2515,7 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
                                                   const uint32_t* __restrict__ lvl_kp = nullptr, const int32_t* __restrict__ lvl_n = nullptr,
                                                   int direct_mode = 0, int32_t* __restrict__ counts_out = nullptr,
                                                   int32_t* __restrict__ mirror_counts = nullptr, int atan_fma = 0, int brief_fma = 0) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: the wave's LDS slice is an SGPR base
   const int L = xcd_logical_block(nitems);
   if (L < 0) return;
   const int frame = fast_div(L, m_gpf);
@@ -2559,66 +2567,88 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
   unsigned long long umpk = 0;
 #pragma unroll
   for (int i = 0; i < 16; i++) umpk |= (unsigned long long)(dc.umax[i] & 15) << (4 * i);
-  const bool al_img = ((img_row_stride & 3) == 0) && ((img_frame_stride & 3) == 0) && ((((unsigned long long)imgs) & 3) == 0);
-  // ---- intensity centroid of every keypoint (src/ORBextractor.cc:76-103): exact int32 moments, any summation order
-  int my_m01 = 0, my_m10 = 0;
-#pragma unroll 1
-  for (int k = 0; k < nk; k++) {
-    const uint32_t p = __builtin_amdgcn_readlane(rec.x, k);
-    const int l = (int)(__builtin_amdgcn_readlane(rec.y, k) & 0xffu);
-    const DeviceLevel& lv = g->lv[l];
-    const int kx = pt_x(p), ky = pt_y(p);
-    const uint8_t* img;
-    int pitch;  // < 2^23 (checked on the host)
-    bool al;
-    if (l == 0) { img = imgs + (long long)frame * img_frame_stride; pitch = (int)img_row_stride; al = al_img; }
-    else { img = pyr + (long long)frame * pyr_frame_bytes + lv.plane_off; pitch = lv.pitch; al = true; }  // pyramid planes are 64-byte aligned
-    int m10 = 0, m01 = 0;
-    if (al) {
-      // 31 rows x 10 aligned dwords cover the patch columns [kx-15, kx+15]; per dword the valid bytes form a range
-      const int xs = kx - kHalfPatch, sh = xs & 3;
-      const uint32_t src0 = (uint32_t)(__mul24(ky - kHalfPatch, pitch) + (xs - sh));  // offset of the patch window in the plane
+  // ---- intensity centroid of every keypoint (src/ORBextractor.cc:76-103): exact int32 moments, any summation order.  The patch is read as
+  // 32 rows x 2 x 16 bytes from column kx - 16 — ONE unaligned 16-byte load per lane (the kernel is bound by its vector-memory instructions), so the window's phase never enters and a lane's byte weights are constants
+  // of the wave.  pixel ^ 0x80 is I - 128 as a signed byte; the weights u (v) on the bytes inside the circle are signed bytes, 0 outside; the
+  // patch is symmetric (sum u = sum v = 0 over it), so sum u (I - 128) IS m10: two v_dot4_i32_i8 per dword and nothing else.
+  int wu[4], wv[4];
+  {
+    const int r = lane >> 1, v = r - kHalfPatch;   // one 16-byte load per lane: row r of 32, columns kx - 16 + 16 (lane & 1) .. + 15
+    const int um = r <= 2 * kHalfPatch ? (int)((umpk >> (4 * (v < 0 ? -v : v))) & 15ull) : -1;
 #pragma unroll
-      for (int i = 0; i < 5; i++) {
-        const int it = lane + 64 * i;
-        const int r = (int)(((uint32_t)it * 6554u) >> 16), dcol = it - r * 10;  // it / 10
-        const int v = r - kHalfPatch;
-        const int um = (int)((umpk >> (4 * (v < 0 ? -v : v))) & 15ull);
-        const int u0 = 4 * dcol - sh - kHalfPatch;
-        const int lo = max(-um - u0, 0), hi = min(um - u0, 3);
-        uint32_t F = 0;   // 0xff on the valid bytes of this dword
-        if (it < 31 * 10 && lo <= hi) F = (0xffffffffu << (8 * lo)) & (0xffffffffu >> (8 * (3 - hi)));
-        uint32_t dw = 0;
-        if (F) dw = *(const uint32_t*)(img + (src0 + (uint32_t)(__mul24(r, pitch) + 4 * dcol)));   // the kernel is TA-bound: no load for masked-out dwords
-        // S <= 4 * 255: the (no-op) mask lets the compiler prove 24-bit operands and pick the full-rate v_mad_i32_i24
-        // instead of the quarter-rate v_mul_lo_u32.  (Not the inline-asm mul_i24 here: the hazard recogniser does not see
-        // that an asm statement reads a VGPR a v_dot4 has just written, and the multiply then reads the stale value.)
-        const int S = (int)(__builtin_amdgcn_udot4(dw, F & 0x01010101u, 0u, false) & 0x7ffu);
-        const int Tt = (int)__builtin_amdgcn_udot4(dw, F & 0x03020100u, 0u, false);  // weights b on the valid bytes
-        int u0o = u0;
-        asm("" : "+v"(u0o));   // opaque to the optimiser, or it drops the sign extension below as redundant — and instruction
-                               // selection, which only sees this basic block, then cannot prove the 24-bit range any more
-        const int u0s = __builtin_amdgcn_sbfe(u0o, 0, 12), vs = (v << 20) >> 20;   // |u0| <= 31, |v| <= 15
-        m10 += u0s * S + Tt;
-        m01 += vs * S;
+    for (int i = 0; i < 4; i++) {
+      const int u0 = 16 * (lane & 1) - 16 + 4 * i;
+      uint32_t a = 0, b = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int u = u0 + j;
+        if ((u < 0 ? -u : u) <= um) { a |= (uint32_t)(u & 0xff) << (8 * j); b |= (uint32_t)(v & 0xff) << (8 * j); }
       }
-    } else {
-      const int c = lane & 31, r2 = lane >> 5;
-      const int u = c - kHalfPatch;
-      const int au = u < 0 ? -u : u;
-      const uint8_t* src = img + (uint32_t)(__mul24(ky - kHalfPatch + r2, pitch) + (kx - kHalfPatch) + c);
+      wu[i] = (int)a; wv[i] = (int)b;
+    }
+  }
+  // Every load of the wave's K keypoints is issued before anything waits: (LDSP) the 37 x 37 windows of the blurred level into the wave's K LDS slices by LDS-DMA — they depend on the position only —
+  // then the orientation patches into registers: loads return in order, so the one wait for the patches covers the windows too.  The kernel is bound by load latency, not by instructions: one keypoint at a time (load, wait,
+  // compute) left a wave with one patch in flight.  Slots k >= nk repeat the wave's last keypoint (straight-line code, exact wait counts).
+  __shared__ __align__(16) uint8_t s_patch[LDSP ? 4 * K : 1][37 * kDescSlicePitch + 16];   // 111 transfers of 16 bytes; slices stay 16-byte aligned
+  int my_m01 = 0, my_m10 = 0;
+  __builtin_amdgcn_sched_barrier(0);   // the loads below go out together, behind the constants above and before the first use
+  if (nk > 0) {   // wave-uniform
+    if constexpr (LDSP) {
+      // The window starts at the dword below kx - 18; a slice row is 48 bytes = three 16-byte LDS-DMA transfers (gfx950's
+      // global_load_lds_dwordx4), 37 rows = 111 transfers = TWO instructions of the wave (seven with dword transfers): transfer s = lane + 64 j
+      // is row s / 3, bytes 16 (s % 3) .. + 15, and lands at byte 16 s of the slice — lane-linear, as the instruction writes.  Up to 30 bytes
+      // past the window's last column are read along: inside the plane's pitch or the next row (the window's last row is not the plane's).
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
-        const int v = 2 * i - kHalfPatch + r2;
-        const int um = v <= kHalfPatch ? (int)((umpk >> (4 * (v < 0 ? -v : v))) & 15ull) : -1;
-        const int I = (au <= um) ? (int)src[(uint32_t)__mul24(2 * i, pitch)] : 0;
-        m10 += u * I;
-        m01 += v * I;
+      for (int k = 0; k < K; k++) {
+        const int kk = min(k, nk - 1);
+        const uint32_t p = __builtin_amdgcn_readlane(rec.x, kk);
+        const int l = (int)(__builtin_amdgcn_readlane(rec.y, kk) & 0xffu);
+        const DeviceLevel& lv = g->lv[l];
+        const int kx = pt_x(p), ky = pt_y(p), bp = lv.pitch;
+        const uint8_t* bplane = blur + (long long)frame * blur_frame_bytes + lv.bplane_off;  // uniform
+        uint8_t* sp = s_patch[w * K + k];
+        const uint32_t wbase = (uint32_t)(__mul24(ky - 18, bp) + (kx - 18 - ((kx - 18) & 3)));
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const int sidx = lane + 64 * j, row = (int)(((uint32_t)sidx * 21846u) >> 16), c16 = sidx - 3 * row;   // sidx / 3
+          if (sidx < 37 * 3)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bplane + (wbase + (uint32_t)(__mul24(row, bp) + 16 * c16))),
+                                             (__attribute__((address_space(3))) void*)(sp + 1024 * j), 16, 0, 0);
+        }
       }
     }
-    m10 = __builtin_amdgcn_readlane(wave_sum_lane63(m10), 63);
-    m01 = __builtin_amdgcn_readlane(wave_sum_lane63(m01), 63);
-    if (lane == k) { my_m10 = m10; my_m01 = m01; }
+    U4una dwm[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const int kk = min(k, nk - 1);
+      const uint32_t p = __builtin_amdgcn_readlane(rec.x, kk);
+      const int l = (int)(__builtin_amdgcn_readlane(rec.y, kk) & 0xffu);
+      const DeviceLevel& lv = g->lv[l];
+      const int kx = pt_x(p), ky = pt_y(p);
+      const uint8_t* img;
+      int pitch;  // < 2^23 (checked on the host)
+      if (l == 0) { img = imgs + (long long)frame * img_frame_stride; pitch = (int)img_row_stride; }
+      else { img = pyr + (long long)frame * pyr_frame_bytes + lv.plane_off; pitch = lv.pitch; }
+      // rows ky-15 .. ky+16, columns kx-16 .. kx+15: inside the plane (keypoints keep 19 px from every border); row ky+16 and column kx-16
+      // carry zero weights, and so does every byte outside the circle
+      const uint8_t* win = img + (uint32_t)(__mul24(ky - kHalfPatch, pitch) + (kx - 16));
+      dwm[k] = *(const U4una*)(win + (__umul24((uint32_t)(lane >> 1), (uint32_t)pitch) + 16u * (uint32_t)(lane & 1)));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      int m10 = 0, m01 = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int px = (int)((i == 0 ? dwm[k].x : i == 1 ? dwm[k].y : i == 2 ? dwm[k].z : dwm[k].w) ^ 0x80808080u);
+        m10 = __builtin_amdgcn_sdot4(px, wu[i], m10, false);
+        m01 = __builtin_amdgcn_sdot4(px, wv[i], m01, false);
+      }
+      m10 = __builtin_amdgcn_readlane(wave_sum_lane63(m10), 63);
+      m01 = __builtin_amdgcn_readlane(wave_sum_lane63(m01), 63);
+      if (lane == k) { my_m10 = m10; my_m01 = m01; }
+    }
   }
   // ---- angle, cos, sin: ONE pass of the (long, glibc-exact) trig code per workgroup — wave 0 computes them for the 4 K
   // keypoints of all four waves, one per lane, instead of every wave running the pass for its own K lanes
@@ -2633,9 +2663,25 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
     s_trig[lane][0] = ang; s_trig[lane][1] = orbx_glibc::cosf_exact(rad); s_trig[lane][2] = orbx_glibc::sinf_exact(rad);
   }
   __syncthreads();
-  float my_angle = 0.f, my_a = 0.f, my_b = 0.f;
-  if (lane < nk) { my_angle = s_trig[w * K + lane][0]; my_a = s_trig[w * K + lane][1]; my_b = s_trig[w * K + lane][2]; }
+  float my_a = 0.f, my_b = 0.f;
+  if (lane < nk) {
+    my_a = s_trig[w * K + lane][1]; my_b = s_trig[w * K + lane][2];
+    // the keypoint record (src/ORBextractor.cc:1128-1140), one keypoint per lane
+    const int l = (int)(rec.y & 0xffu), slot = (int)(rec.y >> 8);
+    const DeviceLevel& lv = g->lv[l];
+    orbx_keypoint kp;
+    float fx = (float)pt_x(rec.x), fy = (float)pt_y(rec.x);
+    if (l != 0) { fx = __fmul_rn(fx, lv.scale); fy = __fmul_rn(fy, lv.scale); }
+    kp.x = fx; kp.y = fy; kp.size = (float)lv.scaled_patch; kp.angle = s_trig[w * K + lane][0]; kp.response = (float)pt_s(rec.x);
+    kp.octave = l; kp.class_id = -1;
+    out_kps[(long long)frame * g->out_cap + slot] = kp;
+    if (mirror_kps) mirror_kps[(long long)frame * g->out_cap + slot] = kp;
+  }
   // ---- steered BRIEF (src/ORBextractor.cc:107-146) on the blurred level
+  if constexpr (LDSP) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the windows have landed (long ago)
+    wave_lds_sync();
+  }
 #pragma unroll 1
   for (int k = 0; k < nk; k++) {
     const uint32_t p = __builtin_amdgcn_readlane(rec.x, k);
@@ -2643,7 +2689,6 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
     const int l = (int)(ry & 0xffu), slot = (int)(ry >> 8);
     const float a = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_a), k));
     const float b = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_b), k));
-    const float angle = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_angle), k));
     const DeviceLevel& lv = g->lv[l];
     const int kx = pt_x(p), ky = pt_y(p);
     const uint8_t* bplane = blur + (long long)frame * blur_frame_bytes + lv.bplane_off;  // uniform
@@ -2651,55 +2696,30 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
     const int ctr = __mul24(ky, bp) + kx;  // taps stay >= 1 px inside the plane: offsets are non-negative
     int t0[4], t1[4];
     if constexpr (LDSP) {
-      // Variant: the 37 x 37 window of the blurred level staged in this wave's LDS slice (37 rows x 10 aligned dwords,
-      // coalesced loads), the 512 taps read from LDS instead of 8 scattered byte gathers per lane.  The window starts at
-      // the dword below kx - 18: at most 2 bytes before / after the row, inside the plane's pitch or the neighbouring row.
-      __shared__ __align__(16) uint8_t s_patch[4][37 * 40];
-      uint8_t* sp = s_patch[w];
-      const int sh2 = (kx - 18) & 3;
-      const uint32_t wbase = (uint32_t)(__mul24(ky - 18, bp) + (kx - 18 - sh2));
-      {  // lane = (dword column of 10, row phase of 6): walks down its column six rows at a time (60 lanes take part)
-        const int rph = (int)(((uint32_t)lane * 6554u) >> 16), dcol = lane - rph * 10;  // lane / 10
-        uint32_t off = wbase + (uint32_t)(__mul24(rph, bp) + 4 * dcol);
-        const uint32_t step = 6u * (uint32_t)bp;
-        // LDS-DMA loads: the slice's dword index is lane + 60 k — lane-linear, as global_load_lds writes it
-#pragma unroll
-        for (int k = 0; k < 7; k++) {
-          if (lane < 60 && rph + 6 * k < 37)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bplane + off),
-                                             (__attribute__((address_space(3))) void*)((uint32_t*)sp + 60 * k), 4, 0, 0);
-          off += step;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      wave_lds_sync();
-      const int lctr = 18 * 40 + 18 + sh2;
-      if (brief_fma) brief_taps<true, true>(sp, lctr, 40, pat, a, b, t0, t1);   // uniform (kernel argument)
-      else brief_taps<false, true>(sp, lctr, 40, pat, a, b, t0, t1);
-      wave_lds_sync();   // the next keypoint overwrites the slice
+      // the 512 taps from the wave's LDS slice of this keypoint (staged above) instead of 8 scattered byte gathers per lane
+      const uint8_t* sp = s_patch[w * K + k];
+      const int lctr = 18 * kDescSlicePitch + 18 + ((kx - 18) & 3);
+      if (brief_fma) brief_taps<true, true>(sp, lctr, kDescSlicePitch, pat, a, b, t0, t1);   // uniform (kernel argument)
+      else brief_taps<false, true>(sp, lctr, kDescSlicePitch, pat, a, b, t0, t1);
     } else {
       if (brief_fma) brief_taps<true, false>(bplane, ctr, bp, pat, a, b, t0, t1);
       else brief_taps<false, false>(bplane, ctr, bp, pat, a, b, t0, t1);
     }
-    unsigned long long mine = 0;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const unsigned long long bits = __ballot(t0[q] < t1[q]);
-      if (lane == q) mine = bits;
-    }
-    if (lane < 4) *(unsigned long long*)(out_desc + ((long long)frame * g->out_cap + slot) * 32 + lane * 8) = mine;
+    // test 64 q + lane is bit `lane` of the row's q-th 64-bit word: the four ballots land in lanes 0..7 as the row's eight dwords
+    // (v_writelane has no builtin in this compiler.  One statement for the eight of them, behind five wait states: the compiler's hazard
+    // recogniser does not look into it, and a v_writelane issued right behind the v_cmp that wrote its SGPR operand reads the old value —
+    // measured, the ISA manual lists the wait only for the lane-select operand.)
+    const unsigned long long b0 = __ballot(t0[0] < t1[0]), b1 = __ballot(t0[1] < t1[1]), b2 = __ballot(t0[2] < t1[2]), b3 = __ballot(t0[3] < t1[3]);
+    uint32_t word = 0;
+    asm("s_nop 4\n\tv_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 1\n\tv_writelane_b32 %0, %3, 2\n\tv_writelane_b32 %0, %4, 3\n\t"
+        "v_writelane_b32 %0, %5, 4\n\tv_writelane_b32 %0, %6, 5\n\tv_writelane_b32 %0, %7, 6\n\tv_writelane_b32 %0, %8, 7"
+        : "+v"(word)
+        : "s"((uint32_t)b0), "s"((uint32_t)(b0 >> 32)), "s"((uint32_t)b1), "s"((uint32_t)(b1 >> 32)), "s"((uint32_t)b2), "s"((uint32_t)(b2 >> 32)),
+          "s"((uint32_t)b3), "s"((uint32_t)(b3 >> 32)));
+    if (lane < 8) *(uint32_t*)(out_desc + ((long long)frame * g->out_cap + slot) * 32 + lane * 4) = word;
     // the single-frame graph: the same rows straight into the caller-visible pinned block (no download node; the HBM copy stays for the
     // searches that take the rows from there)
-    if (mirror_desc && lane < 4) *(unsigned long long*)(mirror_desc + ((long long)frame * g->out_cap + slot) * 32 + lane * 8) = mine;
-    if (lane == 0) {
-      orbx_keypoint kp;
-      float fx = (float)kx, fy = (float)ky;
-      if (l != 0) { fx = __fmul_rn(fx, lv.scale); fy = __fmul_rn(fy, lv.scale); }
-      kp.x = fx; kp.y = fy; kp.size = (float)lv.scaled_patch; kp.angle = angle; kp.response = (float)pt_s(p);
-      kp.octave = l; kp.class_id = -1;
-      out_kps[(long long)frame * g->out_cap + slot] = kp;
-      if (mirror_kps) mirror_kps[(long long)frame * g->out_cap + slot] = kp;
-    }
+    if (mirror_desc && lane < 8) *(uint32_t*)(mirror_desc + ((long long)frame * g->out_cap + slot) * 32 + lane * 4) = word;
   }
 }
 
@@ -2767,7 +2787,9 @@ __global__ __launch_bounds__(256) void k_debug_brief_hash(uint32_t first, uint32
     for (int idx = 0; idx < 512; idx++) {
       const float px = (float)c_pattern[idx * 2], py = (float)c_pattern[idx * 2 + 1];
       int ry, rx;
-      if (brief_fma) rot_tap<true>(px, py, a, b, ry, rx); else rot_tap<false>(px, py, a, b, ry, rx);
+      const f32x2 AB = {b, a}, ANB = {a, -b};
+      if (brief_fma) rot_tap<true>(px, py, AB, ANB, ry, rx); else rot_tap<false>(px, py, AB, ANB, ry, rx);
+      ry -= (int)kRndBits; rx -= (int)kRndBits;   // the product path leaves the constant in its address arithmetic
       hk += (unsigned long long)(uint32_t)(ry * 64 + rx + 4096) * (0x9E3779B97F4A7C15ull + 2ull * (unsigned long long)idx);
     }
     h += hk ^ (unsigned long long)bits;
