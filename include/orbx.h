@@ -119,7 +119,7 @@ int orbx_reserve(orbx_ctx* ctx, int rows, int cols, int nframes);
 /* Options of one context.  Scheduling / launch-shape knobs (results never depend on them; the ORBX_* environment variables set
  * the defaults at orbx_create): "fork_blur" | "fork_fast0" | "fork_qt" (0|1: run that kernel on a second stream
  * beside its neighbour), "graph" (0|1), "fast_threads" (64|128|256), "fast_pk" (0|1), "desc_k" (1|2|4|8|16),
- * "desc_lds" (0|1), "streams" (1|2), "fast_stage_dma" (0|1: the FAST tile by LDS-DMA loads), "qt_fused" (0|1), ... — the full table with
+ * "desc_lds" (0|1), "desc_fused_blur" (-1|0|1: the Gaussian inside the descriptor kernel — -1 = where it pays), "streams" (1|2), "fast_stage_dma" (0|1: the FAST tile by LDS-DMA loads), "qt_fused" (0|1), ... — the full table with
  * defaults is INTEGRATION.md section 7.
  * The FIVE options that DO change results select which build of "the reference CPU path" the output equals, bit for bit (INTEGRATION.md
  * section 6 has the release table; include/orbx_cv_calibrate.h finds the values for the OpenCV at hand, tools/validate_opencv.cpp checks

@@ -569,7 +569,16 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
   // K4a: 7x7 fixed-point Gaussian of every level (the reference blurs each level that holds keypoints).  It only needs
   // the pyramid, and it is VALU-bound while the quadtree that follows FAST is latency-bound with few workgroups, so it
   // is forked onto a second stream behind FAST and joined before the descriptors (ORBX_FORK_BLUR=0 disables).
-  const bool fork_blur = ctx->fork_blur && !ctx->profiling && !small_batch;
+  // Batches under the default blur arithmetic take the Gaussian inside the descriptor kernel (k_describe_blur): no k_blur7 launch, no blurred
+  // planes.  The other arithmetic variants (bc.flags), the single-frame graph and desc_lds = 0 keep the separate kernel.
+  // It blurs a 43 x 40 window per keypoint where k_blur7 blurs every pixel once: measured equal at 1000 pixels of pyramid per keypoint slot
+  // (640 x 480, 1000 features: 0.33 ms per 256 frames either way), +13 % on the step at 1700 (1024 x 1024, 2000 features).
+  long long pyr_px = 0;
+  for (int l = 0; l < geo.nlevels; l++) pyr_px += (long long)geo.lv[l].w * geo.lv[l].h;
+  constexpr long long kFusedBlurPxPerKp = 1300;
+  const bool fused_pays = ctx->desc_fused_blur > 0 || (ctx->desc_fused_blur < 0 && pyr_px >= kFusedBlurPxPerKp * ctx->out_cap);
+  const bool fused_blur = fused_pays && !small_fused && bc.flags == 0 && ctx->desc_lds;
+  const bool fork_blur = ctx->fork_blur && !ctx->profiling && !small_batch && !fused_blur;
   hipStream_t bst = st;
   if (fork_blur) {
     bst = ctx->aux[orbx_ctx::kMaxAux - 1 - (f0 != 0)];
@@ -577,7 +586,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
     ORBX_HIP(ctx, hipStreamWaitEvent(bst, ctx->ev_blur_fork[f0 != 0], 0));
     forks.forked(bst, ctx->ev_blur_join[f0 != 0]);
   }
-  if (!small_fused) {
+  if (!small_fused && !fused_blur) {
     ProfScope ps(ctx, 4, bst);
     const int nitems = geo.btiles_total * nframes;
     hipLaunchKernelGGL(k_blur7, dim3(xcd_grid(nitems)), dim3(256), 0, bst, ctx->d_geo, d_imgs, (long long)row_stride,
@@ -703,7 +712,13 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
     const int gpf = (ctx->out_cap + 4 * K - 1) / (4 * K), nitems = gpf * nframes;
     auto kern = K == 1 ? k_describe<1> : K == 2 ? k_describe<2> : K == 4 ? k_describe<4> : K == 8 ? k_describe<8> : k_describe<16>;
     if (ctx->desc_lds && (K == 2 || K == 4 || K == 8)) kern = K == 2 ? k_describe<2, true> : K == 4 ? k_describe<4, true> : k_describe<8, true>;
-    if (direct_mode)
+    if (fused_blur) {
+      constexpr int KF = 2;   // keypoints per wave: two raw slices + one row-pair buffer per wave keep five workgroups on a CU (measured: K = 1 and K = 4 are 9 % slower)
+      const int gpf_f = (ctx->out_cap + 4 * KF - 1) / (4 * KF), nitems_f = gpf_f * nframes;
+      hipLaunchKernelGGL(k_describe_blur<KF>, dim3(xcd_grid(nitems_f)), dim3(256), 0, st, ctx->d_geo, d_imgs, (long long)row_stride,
+                         (long long)frame_stride, b_pyr, (long long)geo.pyr_bytes, b_kp_list, d_counts, d_kps, d_desc, dc, bc, gpf_f, nitems_f,
+                         div_magic((uint32_t)gpf_f), ctx->atan_fma, ctx->brief_fma);
+    } else if (direct_mode)
       hipLaunchKernelGGL((k_describe<1, false, true>), dim3(xcd_grid(nitems)), dim3(256), 0, st, ctx->d_geo, d_imgs, (long long)row_stride,
                          (long long)frame_stride, b_pyr, (long long)geo.pyr_bytes, b_blur, (long long)geo.blur_bytes,
                          b_kp_list, d_counts, d_kps, d_desc, dc, gpf, nitems, div_magic((uint32_t)gpf),
@@ -895,6 +910,7 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scale_factor, int nlevels, 
     { const char* e = getenv("ORBX_FAST_PASSES"); ctx->fast_passes = e && atoi(e) == 1 ? 1 : 2; }
     const char* dl = getenv("ORBX_DESC_LDS");   // blurred 37x37 window staged in LDS for the descriptor taps
     ctx->desc_lds = dl ? atoi(dl) != 0 : true;
+    { const char* e = getenv("ORBX_DESC_FUSED_BLUR"); ctx->desc_fused_blur = e ? std::max(-1, std::min(1, atoi(e))) : -1; }
     const char* fq = getenv("ORBX_FORK_QT");
     ctx->fork_qt = fq ? atoi(fq) != 0 : true;
     ctx->fork_fast0 = ff ? atoi(ff) != 0 : false;  // measured: no gain (both kernels already fill the CUs), kept as a knob
@@ -1460,6 +1476,7 @@ int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
   else if (n == "window_direct") ctx->window_direct = value != 0;
   else if (n == "fast_split") ctx->fast_split = value != 0;   // FAST launched per group of levels with its own LDS size (batch calls)
   else if (n == "desc_lds") ctx->desc_lds = value != 0;
+  else if (n == "desc_fused_blur" && value >= -1 && value <= 1) ctx->desc_fused_blur = value;
   else if (n == "fast_threads" && (value == 64 || value == 128 || value == 256)) ctx->fast_threads = value;
   else if (n == "qt_threads" && value >= 0 && value <= 512 && value % 64 == 0) ctx->qt_threads = value;   // 0: chosen by batch size
   else if (n == "desc_k" && (value == 1 || value == 2 || value == 4 || value == 8 || value == 16)) { ctx->desc_k = value; ctx->desc_k_user = true; }
@@ -1481,7 +1498,7 @@ int orbx_get_option(const orbx_ctx* ctx, const char* name) {
       {"qt_points", ctx->qt_points}, {"small_fused", ctx->small_fused}, {"qt_level_major", ctx->qt_level_major}, {"qt_fused", ctx->qt_fused},
       {"chain_batch", ctx->chain_batch}, {"chain_long", ctx->chain_long}, {"describe_direct", ctx->describe_direct}, {"chain_long_tile", ctx->chain_long_tile},
       {"chain_first", ctx->chain_first}, {"chain_threads", ctx->chain_threads}, {"qt_big_levels", ctx->qt_big_levels}, {"qt_threads_small", ctx->qt_threads_small},
-      {"qt_one_launch", ctx->qt_one_launch}, {"window_direct", ctx->window_direct}, {"fast_split", ctx->fast_split}, {"desc_lds", ctx->desc_lds},
+      {"qt_one_launch", ctx->qt_one_launch}, {"window_direct", ctx->window_direct}, {"fast_split", ctx->fast_split}, {"desc_lds", ctx->desc_lds}, {"desc_fused_blur", ctx->desc_fused_blur},
       {"fast_threads", ctx->fast_threads}, {"qt_threads", ctx->qt_threads}, {"desc_k", ctx->desc_k}, {"streams", ctx->nstreams}, {"view_pool_cap", ctx->view_pool_cap}};
   for (const auto& t : tab) if (n == t.name) return t.value;
   return ORBX_E_INVALID;

@@ -2468,18 +2468,18 @@ __device__ __forceinline__ void rot_tap(float x, float y, f32x2 AB, f32x2 ANB, i
 // the eight taps of one lane (four tests) read from `base` with row pitch `pitch` (LDS window or the blurred plane); the loads sit inside
 // the caller's uniform branch on the variant, so the two arithmetic forms are never both evaluated.  ryb = kRndBits + ry: v_mul_i24 sees
 // its low 24 bits, 0x400000 + ry, so ryb * pitch + rxb = ry * pitch + rx + (pitch << 22) + kRndBits (mod 2^32): one uniform correction.
-template <bool FMA, bool SLICE>
+template <bool FMA, int SP>   // SP > 0: an LDS slice of that row pitch; 0: the blurred plane, pitch at run time
 __device__ __forceinline__ void brief_taps(const uint8_t* __restrict__ base, int ctr, int pitch, const char4 (&pat)[4], float a, float b,
                                            int (&t0)[4], int (&t1)[4]) {
   const f32x2 AB = {b, a}, ANB = {a, -b};
-  const uint32_t cu = (uint32_t)ctr - (((uint32_t)(SLICE ? kDescSlicePitch : pitch) << 22) + kRndBits);   // uniform; the sums below are exact mod 2^32
+  const uint32_t cu = (uint32_t)ctr - (((uint32_t)(SP ? SP : pitch) << 22) + kRndBits);   // uniform; the sums below are exact mod 2^32
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     const float x0 = (float)pat[q].x, y0 = (float)pat[q].y, x1 = (float)pat[q].z, y1 = (float)pat[q].w;
     int ry0, rx0, ry1, rx1;
     rot_tap<FMA>(x0, y0, AB, ANB, ry0, rx0);
     rot_tap<FMA>(x1, y1, AB, ANB, ry1, rx1);
-    int o0 = __mul24(ry0, SLICE ? kDescSlicePitch : pitch) + rx0, o1 = __mul24(ry1, SLICE ? kDescSlicePitch : pitch) + rx1;   // one v_mad_i32_i24 each
+    int o0 = __mul24(ry0, SP ? SP : pitch) + rx0, o1 = __mul24(ry1, SP ? SP : pitch) + rx1;   // one v_mad_i32_i24 each
     asm("" : "+v"(o0), "+v"(o1));   // kept apart from the uniform part: the compiler would re-associate the sum into three additions
     t0[q] = base[(uint32_t)o0 + cu];
     t1[q] = base[(uint32_t)o1 + cu];
@@ -2699,11 +2699,11 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
       // the 512 taps from the wave's LDS slice of this keypoint (staged above) instead of 8 scattered byte gathers per lane
       const uint8_t* sp = s_patch[w * K + k];
       const int lctr = 18 * kDescSlicePitch + 18 + ((kx - 18) & 3);
-      if (brief_fma) brief_taps<true, true>(sp, lctr, kDescSlicePitch, pat, a, b, t0, t1);   // uniform (kernel argument)
-      else brief_taps<false, true>(sp, lctr, kDescSlicePitch, pat, a, b, t0, t1);
+      if (brief_fma) brief_taps<true, kDescSlicePitch>(sp, lctr, kDescSlicePitch, pat, a, b, t0, t1);   // uniform (kernel argument)
+      else brief_taps<false, kDescSlicePitch>(sp, lctr, kDescSlicePitch, pat, a, b, t0, t1);
     } else {
-      if (brief_fma) brief_taps<true, false>(bplane, ctr, bp, pat, a, b, t0, t1);
-      else brief_taps<false, false>(bplane, ctr, bp, pat, a, b, t0, t1);
+      if (brief_fma) brief_taps<true, 0>(bplane, ctr, bp, pat, a, b, t0, t1);
+      else brief_taps<false, 0>(bplane, ctr, bp, pat, a, b, t0, t1);
     }
     // test 64 q + lane is bit `lane` of the row's q-th 64-bit word: the four ballots land in lanes 0..7 as the row's eight dwords
     // (v_writelane has no builtin in this compiler.  One statement for the eight of them, behind five wait states: the compiler's hazard
@@ -2720,6 +2720,217 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
     // the single-frame graph: the same rows straight into the caller-visible pinned block (no download node; the HBM copy stays for the
     // searches that take the rows from there)
     if (mirror_desc && lane < 8) *(uint32_t*)(mirror_desc + ((long long)frame * g->out_cap + slot) * 32 + lane * 4) = word;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4, batches under the default blur arithmetic: the 7x7 Gaussian INSIDE the descriptor kernel.  The blurred levels have one reader — the 512
+// taps around each keypoint — and k_describe is bound by its loads, k_blur7 by its instructions: a wave that stages the RAW 43 x 48 window of a
+// keypoint (rows ky-21 .. ky+21, columns kx-24 .. kx+23) holds the orientation patch in it already, blurs the 37 x 37 window it needs with the
+// arithmetic of blur_tile (hrow4 / v_dot2 column sums, the same constants: the bytes are those k_blur7 writes), and never touches a blurred
+// plane: no k_blur7 launch, no 2 x 1 MB per frame of blurred levels through HBM, 2.0 KB of loads per keypoint instead of 2.8.
+// Layout of a slice: raw[r][c] = level(reflect(ky - 21 + r), kx - 24 + c), pitch 48.  Row pairs of horizontal sums: hp[rp][o], o = output
+// column, centre raw column o + 4 (x = kx - 20 + o).  Blurred bytes: B[b][o] over the raw slice, pitch 40: y = ky - 18 + b, x = kx - 20 + o.
+// Windows that would need reflected COLUMNS or would read past the row (kx < 24 or kx + 24 > w: a band of a few pixels) are staged byte by
+// byte with reflect-101 in both directions; everything after the staging is the same.
+// ------------------------------------------------------------------------------------------------
+constexpr int kFB_ROWS = 43, kFB_PITCH = 48, kFB_X0 = 24, kFB_Y0 = 21, kFB_HP_ROWS = 22, kFB_HP_COLS = 40, kFB_BPITCH = 40;
+
+template <int K>
+__global__ __launch_bounds__(256) void k_describe_blur(const DeviceGeom* __restrict__ g, const uint8_t* __restrict__ imgs,
+                                                       long long img_row_stride, long long img_frame_stride,
+                                                       const uint8_t* __restrict__ pyr, long long pyr_frame_bytes,
+                                                       const uint2* __restrict__ kp_list, const int32_t* __restrict__ counts,
+                                                       orbx_keypoint* __restrict__ out_kps, uint8_t* __restrict__ out_desc,
+                                                       DescConsts dc, BlurConsts bc, int groups_per_frame, int nitems, uint32_t m_gpf,
+                                                       int atan_fma, int brief_fma) {
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int L = xcd_logical_block(nitems);
+  if (L < 0) return;
+  const int frame = fast_div(L, m_gpf);
+  const int g0 = ((L - frame * groups_per_frame) * 4 + w) * K;  // first keypoint (level-major index) of this wave
+  const int total = counts[frame * 2];
+  if (((L - frame * groups_per_frame) * 4) * K >= total) return;  // block-uniform
+  const int nk = max(0, min(K, total - g0));
+  uint2 rec = make_uint2(0u, 0u);
+  if (lane < nk) rec = kp_list[(long long)frame * g->out_cap + g0 + lane];
+  char4 pat[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) pat[q] = ((const char4*)c_pattern)[q * 64 + lane];
+  unsigned long long umpk = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++) umpk |= (unsigned long long)(dc.umax[i] & 15) << (4 * i);
+  // moment weights (as in k_describe): lane = (patch row r of 32, half); the patch's sixteen bytes sit at raw row 6 + r, column 8 + 16 half
+  int wu[4], wv[4];
+  {
+    const int r = lane >> 1, v = r - kHalfPatch;
+    const int um = r <= 2 * kHalfPatch ? (int)((umpk >> (4 * (v < 0 ? -v : v))) & 15ull) : -1;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int u0 = 16 * (lane & 1) - 16 + 4 * i;
+      uint32_t a = 0, b = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int u = u0 + j;
+        if ((u < 0 ? -u : u) <= um) { a |= (uint32_t)(u & 0xff) << (8 * j); b |= (uint32_t)(v & 0xff) << (8 * j); }
+      }
+      wu[i] = (int)a; wv[i] = (int)b;
+    }
+  }
+  __shared__ __align__(16) uint8_t s_raw[4 * K][kFB_ROWS * kFB_PITCH + 16];
+  __shared__ __align__(16) uint32_t s_hp[4][kFB_HP_ROWS * kFB_HP_COLS];
+  int my_m01 = 0, my_m10 = 0;
+  __builtin_amdgcn_sched_barrier(0);
+  if (nk > 0) {   // wave-uniform
+    // ---- stage the K raw windows: 129 sixteen-byte LDS-DMA transfers each (transfer s = lane + 64 j: row s / 3, bytes 16 (s % 3) ..)
+    bool fast[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const int kk = min(k, nk - 1);
+      const uint32_t p = __builtin_amdgcn_readlane(rec.x, kk);
+      const int l = (int)(__builtin_amdgcn_readlane(rec.y, kk) & 0xffu);
+      const DeviceLevel& lv = g->lv[l];
+      const int kx = pt_x(p), ky = pt_y(p), lw = lv.w, lh = lv.h;
+      const uint8_t* img;
+      int pitch;  // < 2^23 (checked on the host)
+      if (l == 0) { img = imgs + (long long)frame * img_frame_stride; pitch = (int)img_row_stride; }
+      else { img = pyr + (long long)frame * pyr_frame_bytes + lv.plane_off; pitch = lv.pitch; }
+      fast[k] = kx >= kFB_X0 && kx + (kFB_PITCH - kFB_X0) <= lw;   // uniform: no reflected column, no byte past the row's pixels
+      if (fast[k]) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          const int sidx = min(lane + 64 * j, kFB_ROWS * 3 - 1), row = (int)(((uint32_t)sidx * 21846u) >> 16), c16 = sidx - 3 * row;   // sidx / 3
+          int y = ky - kFB_Y0 + row;
+          y = y < 0 ? -y : (y >= lh ? 2 * lh - 2 - y : y);   // reflect-101 (one reflection: keypoints keep 19 rows from the border)
+          if (lane + 64 * j < kFB_ROWS * 3)   // LDS-DMA takes a source at any byte address: the slice needs no phase
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img + (uint32_t)(__mul24(y, pitch) + (kx - kFB_X0) + 16 * c16)),
+                                             (__attribute__((address_space(3))) void*)(s_raw[w * K + k] + 1024 * j), 16, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      uint8_t* sp = s_raw[w * K + k];
+      if (!fast[k]) {
+        const int kk = min(k, nk - 1);
+        const uint32_t p = __builtin_amdgcn_readlane(rec.x, kk);
+        const int l = (int)(__builtin_amdgcn_readlane(rec.y, kk) & 0xffu);
+        const DeviceLevel& lv = g->lv[l];
+        const int kx = pt_x(p), ky = pt_y(p), lw = lv.w, lh = lv.h;
+        const uint8_t* img;
+        int pitch;
+        if (l == 0) { img = imgs + (long long)frame * img_frame_stride; pitch = (int)img_row_stride; }
+        else { img = pyr + (long long)frame * pyr_frame_bytes + lv.plane_off; pitch = lv.pitch; }
+#pragma unroll 1
+        for (int i = lane; i < kFB_ROWS * kFB_PITCH; i += 64) {
+          const int row = (int)(((uint32_t)i * 1366u) >> 16), c = i - kFB_PITCH * row;   // i / 48 for i < 2064
+          int y = ky - kFB_Y0 + row, x = kx - kFB_X0 + c;
+          y = y < 0 ? -y : (y >= lh ? 2 * lh - 2 - y : y);
+          x = x < 0 ? -x : (x >= lw ? 2 * lw - 2 - x : x);
+          sp[i] = img[(uint32_t)(__mul24(y, pitch) + x)];
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wave_lds_sync();
+    // ---- moments from the raw slices (src/ORBextractor.cc:76-103)
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const uint8_t* sp = s_raw[w * K + k];
+      const uint2 a = *(const uint2*)(sp + (6 + (lane >> 1)) * kFB_PITCH + 8 + 16 * (lane & 1));
+      const uint2 b = *(const uint2*)(sp + (6 + (lane >> 1)) * kFB_PITCH + 16 + 16 * (lane & 1));
+      const uint32_t dwv[4] = {a.x, a.y, b.x, b.y};
+      int m10 = 0, m01 = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int px = (int)(dwv[i] ^ 0x80808080u);
+        m10 = __builtin_amdgcn_sdot4(px, wu[i], m10, false);
+        m01 = __builtin_amdgcn_sdot4(px, wv[i], m01, false);
+      }
+      m10 = __builtin_amdgcn_readlane(wave_sum_lane63(m10), 63);
+      m01 = __builtin_amdgcn_readlane(wave_sum_lane63(m01), 63);
+      if (lane == k) { my_m10 = m10; my_m01 = m01; }
+    }
+  }
+  __shared__ int s_mom[4 * K][2];
+  __shared__ float s_trig[4 * K][3];
+  if (lane < nk) { s_mom[w * K + lane][0] = my_m01; s_mom[w * K + lane][1] = my_m10; }
+  __syncthreads();
+  if (w == 0 && lane < 4 * K) {
+    const float ang = fast_atan2_deg((float)s_mom[lane][0], (float)s_mom[lane][1], atan_fma);
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    const float rad = __fmul_rn(ang, factorPI);
+    s_trig[lane][0] = ang; s_trig[lane][1] = orbx_glibc::cosf_exact(rad); s_trig[lane][2] = orbx_glibc::sinf_exact(rad);
+  }
+  __syncthreads();
+  float my_a = 0.f, my_b = 0.f;
+  if (lane < nk) {
+    my_a = s_trig[w * K + lane][1]; my_b = s_trig[w * K + lane][2];
+    const int l = (int)(rec.y & 0xffu), slot = (int)(rec.y >> 8);
+    const DeviceLevel& lv = g->lv[l];
+    orbx_keypoint kp;
+    float fx = (float)pt_x(rec.x), fy = (float)pt_y(rec.x);
+    if (l != 0) { fx = __fmul_rn(fx, lv.scale); fy = __fmul_rn(fy, lv.scale); }
+    kp.x = fx; kp.y = fy; kp.size = (float)lv.scaled_patch; kp.angle = s_trig[w * K + lane][0]; kp.response = (float)pt_s(rec.x);
+    kp.octave = l; kp.class_id = -1;
+    out_kps[(long long)frame * g->out_cap + slot] = kp;
+  }
+  uint32_t* hp = s_hp[w];
+#pragma unroll 1
+  for (int k = 0; k < nk; k++) {
+    const int slot = (int)(__builtin_amdgcn_readlane(rec.y, k) >> 8);
+    const float a = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_a), k));
+    const float b = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_b), k));
+    uint8_t* sp = s_raw[w * K + k];
+    // ---- horizontal sums, a row pair and four columns per item (blur_tile's form)
+#pragma unroll 1
+    for (int i = lane; i < kFB_HP_ROWS * 10; i += 64) {
+      const int rp = (int)(((uint32_t)i * 6554u) >> 16), j = i - 10 * rp;   // i / 10
+      const int r1 = min(2 * rp + 1, kFB_ROWS - 1);   // the pair past the last row repeats it (its weight is 0 wherever it is read)
+      uint32_t ha[4], hb[4];
+      hrow4((const uint32_t*)(sp + (2 * rp) * kFB_PITCH) + j, bc, ha);
+      hrow4((const uint32_t*)(sp + r1 * kFB_PITCH) + j, bc, hb);
+      uint4 o;
+      o.x = ha[0] | (hb[0] << 16); o.y = ha[1] | (hb[1] << 16); o.z = ha[2] | (hb[2] << 16); o.w = ha[3] | (hb[3] << 16);
+      *(uint4*)(hp + rp * kFB_HP_COLS + 4 * j) = o;
+    }
+    wave_lds_sync();
+    // ---- column sums -> blurred bytes over the raw slice (two rows x four columns per item)
+#pragma unroll 1
+    for (int i = lane; i < 19 * 10; i += 64) {
+      const int op = (int)(((uint32_t)i * 6554u) >> 16), j = i - 10 * op;
+      uint4 P[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) P[q] = *(const uint4*)(hp + (op + q) * kFB_HP_COLS + 4 * j);
+      uint32_t e[4], o[4];
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const uint32_t p0 = c == 0 ? P[0].x : c == 1 ? P[0].y : c == 2 ? P[0].z : P[0].w;
+        const uint32_t p1 = c == 0 ? P[1].x : c == 1 ? P[1].y : c == 2 ? P[1].z : P[1].w;
+        const uint32_t p2 = c == 0 ? P[2].x : c == 1 ? P[2].y : c == 2 ? P[2].z : P[2].w;
+        const uint32_t p3 = c == 0 ? P[3].x : c == 1 ? P[3].y : c == 2 ? P[3].z : P[3].w;
+        e[c] = udot2(p3, bc.we[3], udot2(p2, bc.we[2], udot2(p1, bc.we[1], udot2(p0, bc.we[0], bc.radd))));
+        o[c] = udot2(p3, bc.wo[3], udot2(p2, bc.wo[2], udot2(p1, bc.wo[1], udot2(p0, bc.wo[0], bc.radd))));
+      }
+      const uint32_t pe = __builtin_amdgcn_perm(__builtin_amdgcn_perm(e[3], e[2], 0x0c0c0602u), __builtin_amdgcn_perm(e[1], e[0], 0x0c0c0602u), 0x05040100u);
+      const uint32_t po = __builtin_amdgcn_perm(__builtin_amdgcn_perm(o[3], o[2], 0x0c0c0602u), __builtin_amdgcn_perm(o[1], o[0], 0x0c0c0602u), 0x05040100u);
+      *(uint32_t*)(sp + (2 * op) * kFB_BPITCH + 4 * j) = pe;
+      *(uint32_t*)(sp + (2 * op + 1) * kFB_BPITCH + 4 * j) = po;
+    }
+    wave_lds_sync();
+    // ---- steered BRIEF on the blurred bytes: (ky + ry, kx + rx) is B[ry + 18][rx + 20]
+    int t0[4], t1[4];
+    const int lctr = 18 * kFB_BPITCH + 20;
+    if (brief_fma) brief_taps<true, kFB_BPITCH>(sp, lctr, kFB_BPITCH, pat, a, b, t0, t1);   // uniform (kernel argument)
+    else brief_taps<false, kFB_BPITCH>(sp, lctr, kFB_BPITCH, pat, a, b, t0, t1);
+    const unsigned long long b0 = __ballot(t0[0] < t1[0]), b1 = __ballot(t0[1] < t1[1]), b2 = __ballot(t0[2] < t1[2]), b3 = __ballot(t0[3] < t1[3]);
+    uint32_t word = 0;
+    asm("s_nop 4\n\tv_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 1\n\tv_writelane_b32 %0, %3, 2\n\tv_writelane_b32 %0, %4, 3\n\t"
+        "v_writelane_b32 %0, %5, 4\n\tv_writelane_b32 %0, %6, 5\n\tv_writelane_b32 %0, %7, 6\n\tv_writelane_b32 %0, %8, 7"
+        : "+v"(word)
+        : "s"((uint32_t)b0), "s"((uint32_t)(b0 >> 32)), "s"((uint32_t)b1), "s"((uint32_t)(b1 >> 32)), "s"((uint32_t)b2), "s"((uint32_t)(b2 >> 32)),
+          "s"((uint32_t)b3), "s"((uint32_t)(b3 >> 32)));
+    if (lane < 8) *(uint32_t*)(out_desc + ((long long)frame * g->out_cap + slot) * 32 + lane * 4) = word;
   }
 }
 

@@ -209,6 +209,56 @@ def test_batch_equals_single_and_is_order_independent():
         assert again[t][1].tobytes() == res[t][1].tobytes() and np.array_equal(again[t][2], res[t][2])
 
 
+@pytest.mark.parametrize("rows,cols,nf,lap", [(480, 640, 1000, (0, 1000)), (1024, 1024, 2000, (0, 1000)), (376, 1241, 2000, (0, 0)),
+                                              (300, 400, 700, (0, 1000)), (480, 752, 1200, (200, 400))])
+def test_gaussian_inside_the_descriptor_kernel(rows, cols, nf, lap):
+    """k_describe_blur ("desc_fused_blur"): batches under the default blur arithmetic blur the 43 x 48 raw window of every keypoint inside the
+    descriptor kernel instead of launching k_blur7 — the same bytes (blur_tile's arithmetic), so the same descriptors: forced on for every
+    shape (small levels put many keypoints into the column bands that are staged byte by byte with reflect-101), against the oracle."""
+    frames = synth.make_stream(3, rows, cols, 5)
+    ora = po.OracleExtractor(nf, 1.2, 8, 20, 7)
+    want = [ora.extract(f, lap) for f in frames]
+    for mode in (1, 0):
+        gpu = ORBextractor(nf, 1.2, 8, 20, 7)
+        gpu.set_option("desc_fused_blur", mode)
+        res = gpu.extract_batch(frames, lap)
+        for t in range(3):
+            assert_same(res[t], want[t], f"fused={mode} {cols}x{rows} f{t}")
+
+
+def test_the_fused_gaussian_is_chosen_where_it_pays_and_never_for_another_arithmetic():
+    """Default (-1): by pyramid pixels per keypoint slot — 1024 x 1024 with 2000 features takes the fused kernel (no k_blur7 launch), 640 x 480 with
+    1000 features the separate one; a CPU-path profile with another blur arithmetic always keeps k_blur7 (and its parity)."""
+    def blur_launches(gpu, frames):
+        gpu.extract_batch(frames, (0, 1000))
+        gpu.profile_enable(True)
+        gpu.extract_batch(frames, (0, 1000))
+        pr = gpu.profile_read()
+        gpu.profile_enable(False)
+        return [n for k, (ms, n) in pr.items() if k.startswith("k_blur7")][0]
+    big = synth.make_stream(2, 1024, 1024, 3)
+    small = synth.make_stream(2, 480, 640, 3)
+    assert blur_launches(ORBextractor(2000, 1.2, 8, 20, 7), big) == 0
+    assert blur_launches(ORBextractor(1000, 1.2, 8, 20, 7), small) > 0
+    gpu = ORBextractor(2000, 1.2, 8, 20, 7)
+    gpu.set_cpu_profile("opencv-4.4")
+    gpu.set_option("desc_fused_blur", 1)
+    assert blur_launches(gpu, big) > 0
+    res = gpu.extract_batch(big, (0, 1000))
+    with po.opencv_variant(*ORBextractor.cpu_profiles()["opencv-4.4"][1]):
+        assert_same(res[0], po.OracleExtractor(2000, 1.2, 8, 20, 7).extract(big[0], (0, 1000)), "opencv-4.4, separate blur")
+    # the FMA builds of the reference take the fused kernel too (v_pk_fma_f32 taps, the contracted atan)
+    gpu = ORBextractor(2000, 1.2, 8, 20, 7)
+    gpu.set_cpu_profile("opencv>=4.5.1", 3)
+    assert blur_launches(gpu, big) == 0
+    res = gpu.extract_batch(big, (0, 1000))
+    v = np.zeros(5, np.int32)
+    from orb_slam3_modified_amd import _lib
+    assert _lib.lib().orbx_cpu_profile_values(b"opencv>=4.5.1", 3, _lib.ptr(v)) == 0
+    with po.opencv_variant(*(int(x) for x in v)):
+        assert_same(res[1], po.OracleExtractor(2000, 1.2, 8, 20, 7).extract(big[1], (0, 1000)), "default blur, FMA build, fused")
+
+
 def test_shape_change_and_two_instances():
     a, b = ORBextractor(1000, 1.2, 8, 20, 7), ORBextractor(1000, 1.2, 8, 20, 7)   # stereo: two instances live together
     ora = po.OracleExtractor(1000, 1.2, 8, 20, 7)
