@@ -60,6 +60,18 @@ for seed in range(first, first + count):
     with po.opencv_variant(*var):
         okps, odesc, omono = po.OracleExtractor(nf, sf, nlev, ini, mn).extract(img, lap)
     ok = mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc)
+    # the batch kernels on the same image (two frames: the two-pass FAST, k_describe's batch form, and — forced on for even seeds, by shape for
+    # odd ones — the Gaussian inside the descriptor kernel)
+    if ok and rows * cols <= 2_000_000:
+        try:
+            if seed % 2 == 0:
+                gpu.set_option("desc_fused_blur", 1)
+            res = gpu.extract_batch(np.stack([img, img]), lap)
+            ok = all(r[0] == omono and r[1].tobytes() == okps.tobytes() and np.array_equal(r[2], odesc) for r in res)
+            if not ok:
+                tag += " [batch]"
+        except OrbxError as e:
+            print("REJECTED (batch)", tag, e)
     if not ok:
         bad += 1
         print("MISMATCH", tag, len(kps), len(okps))
