@@ -571,11 +571,12 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
   // is forked onto a second stream behind FAST and joined before the descriptors (ORBX_FORK_BLUR=0 disables).
   // Batches under the default blur arithmetic take the Gaussian inside the descriptor kernel (k_describe_blur): no k_blur7 launch, no blurred
   // planes.  The other arithmetic variants (bc.flags), the single-frame graph and desc_lds = 0 keep the separate kernel.
-  // It blurs a 43 x 40 window per keypoint where k_blur7 blurs every pixel once: measured equal at 1000 pixels of pyramid per keypoint slot
-  // (640 x 480, 1000 features: 0.33 ms per 256 frames either way), +13 % on the step at 1700 (1024 x 1024, 2000 features).
+  // It blurs a window per keypoint (only the positions the rotated pattern can read: fb_items.inc) where k_blur7 blurs every pixel once, so its
+  // cost goes with the keypoints, not with the pixels.  Measured per 256 frames: 640 x 480 with 1000 features (975 pyramid pixels per keypoint
+  // slot) 0.304 ms against 0.171 + 0.168, the step +2 %, natural crops +6 %; 1024 x 1024 with 2000 features (1690) the step +18 %.
   long long pyr_px = 0;
   for (int l = 0; l < geo.nlevels; l++) pyr_px += (long long)geo.lv[l].w * geo.lv[l].h;
-  constexpr long long kFusedBlurPxPerKp = 1300;
+  constexpr long long kFusedBlurPxPerKp = 800;
   const bool fused_pays = ctx->desc_fused_blur > 0 || (ctx->desc_fused_blur < 0 && pyr_px >= kFusedBlurPxPerKp * ctx->out_cap);
   const bool fused_blur = fused_pays && !small_fused && bc.flags == 0 && ctx->desc_lds;
   const bool fork_blur = ctx->fork_blur && !ctx->profiling && !small_batch && !fused_blur;

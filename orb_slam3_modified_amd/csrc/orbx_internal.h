@@ -153,7 +153,7 @@ struct orbx_ctx {
   hipEvent_t ev_qt_fork[2] = {nullptr, nullptr}, ev_qt_join[2] = {nullptr, nullptr};
   bool fork_blur = true, fork_fast0 = false, fork_qt = true, fast_pk = true, desc_lds = true;
   int desc_fused_blur = -1;   // batches under the default blur arithmetic: the Gaussian inside the descriptor kernel (k_describe_blur), no k_blur7 launch.
-                              // -1: where it pays (>= kFusedBlurPxPerKp pyramid pixels per keypoint slot), 0: never, 1: wherever the arithmetic allows
+                              // -1: where it pays (>= kFusedBlurPxPerKp = 800 pyramid pixels per keypoint slot), 0: never, 1: wherever the arithmetic allows
   bool realign = true;          // batch calls: frames whose rows are not dword-aligned are copied into an aligned buffer first
   uint8_t* d_realign = nullptr;
   size_t realign_bytes = 0;

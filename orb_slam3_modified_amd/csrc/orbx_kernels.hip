@@ -2481,8 +2481,16 @@ __device__ __forceinline__ void brief_taps(const uint8_t* __restrict__ base, int
     rot_tap<FMA>(x1, y1, AB, ANB, ry1, rx1);
     int o0 = __mul24(ry0, SP ? SP : pitch) + rx0, o1 = __mul24(ry1, SP ? SP : pitch) + rx1;   // one v_mad_i32_i24 each
     asm("" : "+v"(o0), "+v"(o1));   // kept apart from the uniform part: the compiler would re-associate the sum into three additions
-    t0[q] = base[(uint32_t)o0 + cu];
-    t1[q] = base[(uint32_t)o1 + cu];
+    if (SP) {   // an LDS slice: 32-bit addresses, the uniform part is one scalar sum (opaque: the compiler would otherwise express the
+      // slice's own base as this sum minus the constant in every other access of the caller)
+      int cus = (int)cu;
+      asm("" : "+s"(cus));
+      const uint8_t* __restrict__ bu = base + cus;
+      t0[q] = bu[o0]; t1[q] = bu[o1];
+    } else {
+      t0[q] = base[(uint32_t)o0 + cu];
+      t1[q] = base[(uint32_t)o1 + cu];
+    }
   }
 }
 
@@ -2735,6 +2743,7 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
 // byte with reflect-101 in both directions; everything after the staging is the same.
 // ------------------------------------------------------------------------------------------------
 constexpr int kFB_ROWS = 43, kFB_PITCH = 48, kFB_X0 = 24, kFB_Y0 = 21, kFB_HP_ROWS = 22, kFB_HP_COLS = 40, kFB_BPITCH = 40;
+#include "fb_items.inc"
 
 template <int K>
 __global__ __launch_bounds__(256) void k_describe_blur(const DeviceGeom* __restrict__ g, const uint8_t* __restrict__ imgs,
@@ -2779,6 +2788,19 @@ __global__ __launch_bounds__(256) void k_describe_blur(const DeviceGeom* __restr
   }
   __shared__ __align__(16) uint8_t s_raw[4 * K][kFB_ROWS * kFB_PITCH + 16];
   __shared__ __align__(16) uint32_t s_hp[4][kFB_HP_ROWS * kFB_HP_COLS];
+  // the items of the two blur passes this lane works on (fb_items.inc: only what the rotated pattern can read — three wave-trips each), as byte
+  // offsets into the slice / the row-pair buffer: constants of the wave, so a trip's addressing is one addition
+  int h_r0[3], h_r1[3], h_hp[3], v_hp[3], v_b[3];
+#pragma unroll
+  for (int t = 0; t < 3; t++) {
+    const int eh = c_fb_h[min(lane + 64 * t, kFB_NH - 1)], rp = eh & 0xff, jh = eh >> 8;
+    h_r0[t] = (2 * rp) * kFB_PITCH + 4 * jh;
+    h_r1[t] = min(2 * rp + 1, kFB_ROWS - 1) * kFB_PITCH + 4 * jh;   // the pair past the last row repeats it (its weight is 0 wherever it is read)
+    h_hp[t] = (rp * kFB_HP_COLS + 4 * jh) * 4;
+    const int ev = c_fb_v[min(lane + 64 * t, kFB_NV - 1)], op = ev & 0xff, jv = ev >> 8;
+    v_hp[t] = (op * kFB_HP_COLS + 4 * jv) * 4;
+    v_b[t] = (2 * op) * kFB_BPITCH + 4 * jv;
+  }
   int my_m01 = 0, my_m10 = 0;
   __builtin_amdgcn_sched_barrier(0);
   if (nk > 0) {   // wave-uniform
@@ -2883,25 +2905,23 @@ __global__ __launch_bounds__(256) void k_describe_blur(const DeviceGeom* __restr
     const float b = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_b), k));
     uint8_t* sp = s_raw[w * K + k];
     // ---- horizontal sums, a row pair and four columns per item (blur_tile's form)
-#pragma unroll 1
-    for (int i = lane; i < kFB_HP_ROWS * 10; i += 64) {
-      const int rp = (int)(((uint32_t)i * 6554u) >> 16), j = i - 10 * rp;   // i / 10
-      const int r1 = min(2 * rp + 1, kFB_ROWS - 1);   // the pair past the last row repeats it (its weight is 0 wherever it is read)
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
       uint32_t ha[4], hb[4];
-      hrow4((const uint32_t*)(sp + (2 * rp) * kFB_PITCH) + j, bc, ha);
-      hrow4((const uint32_t*)(sp + r1 * kFB_PITCH) + j, bc, hb);
-      uint4 o;
-      o.x = ha[0] | (hb[0] << 16); o.y = ha[1] | (hb[1] << 16); o.z = ha[2] | (hb[2] << 16); o.w = ha[3] | (hb[3] << 16);
-      *(uint4*)(hp + rp * kFB_HP_COLS + 4 * j) = o;
+      hrow4((const uint32_t*)(sp + h_r0[t]), bc, ha);
+      hrow4((const uint32_t*)(sp + h_r1[t]), bc, hb);
+      uint4 o;   // the low halves of the two sums side by side: one v_perm each
+      o.x = __builtin_amdgcn_perm(hb[0], ha[0], 0x05040100u); o.y = __builtin_amdgcn_perm(hb[1], ha[1], 0x05040100u);
+      o.z = __builtin_amdgcn_perm(hb[2], ha[2], 0x05040100u); o.w = __builtin_amdgcn_perm(hb[3], ha[3], 0x05040100u);
+      if (t < 2 || lane + 128 < kFB_NH) *(uint4*)((uint8_t*)hp + h_hp[t]) = o;
     }
     wave_lds_sync();
     // ---- column sums -> blurred bytes over the raw slice (two rows x four columns per item)
-#pragma unroll 1
-    for (int i = lane; i < 19 * 10; i += 64) {
-      const int op = (int)(((uint32_t)i * 6554u) >> 16), j = i - 10 * op;
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
       uint4 P[4];
 #pragma unroll
-      for (int q = 0; q < 4; q++) P[q] = *(const uint4*)(hp + (op + q) * kFB_HP_COLS + 4 * j);
+      for (int q = 0; q < 4; q++) P[q] = *(const uint4*)((const uint8_t*)hp + v_hp[t] + q * (kFB_HP_COLS * 4));
       uint32_t e[4], o[4];
 #pragma unroll
       for (int c = 0; c < 4; c++) {
@@ -2914,8 +2934,10 @@ __global__ __launch_bounds__(256) void k_describe_blur(const DeviceGeom* __restr
       }
       const uint32_t pe = __builtin_amdgcn_perm(__builtin_amdgcn_perm(e[3], e[2], 0x0c0c0602u), __builtin_amdgcn_perm(e[1], e[0], 0x0c0c0602u), 0x05040100u);
       const uint32_t po = __builtin_amdgcn_perm(__builtin_amdgcn_perm(o[3], o[2], 0x0c0c0602u), __builtin_amdgcn_perm(o[1], o[0], 0x0c0c0602u), 0x05040100u);
-      *(uint32_t*)(sp + (2 * op) * kFB_BPITCH + 4 * j) = pe;
-      *(uint32_t*)(sp + (2 * op + 1) * kFB_BPITCH + 4 * j) = po;
+      if (t < 2 || lane + 128 < kFB_NV) {
+        *(uint32_t*)(sp + v_b[t]) = pe;
+        *(uint32_t*)(sp + v_b[t] + kFB_BPITCH) = po;
+      }
     }
     wave_lds_sync();
     // ---- steered BRIEF on the blurred bytes: (ky + ry, kx + rx) is B[ry + 18][rx + 20]

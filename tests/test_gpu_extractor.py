@@ -227,8 +227,9 @@ def test_gaussian_inside_the_descriptor_kernel(rows, cols, nf, lap):
 
 
 def test_the_fused_gaussian_is_chosen_where_it_pays_and_never_for_another_arithmetic():
-    """Default (-1): by pyramid pixels per keypoint slot — 1024 x 1024 with 2000 features takes the fused kernel (no k_blur7 launch), 640 x 480 with
-    1000 features the separate one; a CPU-path profile with another blur arithmetic always keeps k_blur7 (and its parity)."""
+    """Default (-1): by pyramid pixels per keypoint slot (its cost goes with the keypoints, k_blur7's with the pixels) — 1024 x 1024 with 2000 features
+    and 640 x 480 with 1000 take the fused kernel (no k_blur7 launch), 640 x 480 with 2500 features the separate one; a CPU-path profile with
+    another blur arithmetic always keeps k_blur7 (and its parity)."""
     def blur_launches(gpu, frames):
         gpu.extract_batch(frames, (0, 1000))
         gpu.profile_enable(True)
@@ -239,7 +240,8 @@ def test_the_fused_gaussian_is_chosen_where_it_pays_and_never_for_another_arithm
     big = synth.make_stream(2, 1024, 1024, 3)
     small = synth.make_stream(2, 480, 640, 3)
     assert blur_launches(ORBextractor(2000, 1.2, 8, 20, 7), big) == 0
-    assert blur_launches(ORBextractor(1000, 1.2, 8, 20, 7), small) > 0
+    assert blur_launches(ORBextractor(1000, 1.2, 8, 20, 7), small) == 0
+    assert blur_launches(ORBextractor(2500, 1.2, 8, 20, 7), small) > 0
     gpu = ORBextractor(2000, 1.2, 8, 20, 7)
     gpu.set_cpu_profile("opencv-4.4")
     gpu.set_option("desc_fused_blur", 1)
