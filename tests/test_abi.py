@@ -108,3 +108,33 @@ def test_rccl_is_bound_at_run_time_not_at_link_time():
     assert "rccl" not in needed.lower() and "nccl" not in needed.lower()
     info = _lib.lib().orbx_replay_rccl_info().decode()
     assert info.startswith("rccl 2.") and "librccl" in info, info      # /opt/rocm/lib/librccl.so.1 in this image (no GPU needed to bind it)
+
+
+def test_generated_kernel_tables_are_current():
+    """csrc/fb_items.inc (the blur items k_describe_blur works on: only what the rotated BRIEF pattern can read) is what tools/gen_fb_items.py derives
+    from csrc/orb_pattern.inc — and every tap position any angle can produce lies inside the listed items (checked here by brute force over
+    angles, not by the generator's own radius argument)."""
+    import subprocess
+    import sys
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    want = subprocess.check_output([sys.executable, os.path.join(root, "tools", "gen_fb_items.py")]).decode()
+    have = open(os.path.join(root, "orb_slam3_modified_amd", "csrc", "fb_items.inc")).read()
+    assert want == have, "run: python tools/gen_fb_items.py > orb_slam3_modified_amd/csrc/fb_items.inc"
+    tabs = {m.group(1): [int(x, 16) for x in re.findall(r"0x[0-9a-f]{4}", m.group(2))] for m in re.finditer(r"(c_fb_[hv])\[192\] = \{([^}]*)\}", have)}
+    V = {(e & 0xff, e >> 8) for e in tabs["c_fb_v"] if e != 0xffff}
+    H = {(e & 0xff, e >> 8) for e in tabs["c_fb_h"] if e != 0xffff}
+    assert all((op + q, j) in H for op, j in V for q in range(4))        # every column-sum item finds its four row pairs
+    pat = []
+    for ln in open(os.path.join(root, "orb_slam3_modified_amd", "csrc", "orb_pattern.inc")):
+        if not ln.strip().startswith(("/*", "*")):
+            pat += [int(x) for x in re.findall(r"-?\d+", ln.split("//")[0])]
+    pts = np.array(pat[-1024:], np.float32).reshape(-1, 2)
+    ang = np.deg2rad(np.arange(0, 360, 0.05, dtype=np.float64)).astype(np.float32)
+    a, b = np.cos(ang)[:, None], np.sin(ang)[:, None]
+    for lo, hi in ((np.float32(1) - np.float32(1e-6), np.float32(1) + np.float32(1e-6)), (np.float32(1), np.float32(1))):
+        ry = np.rint(pts[None, :, 0] * b * lo + pts[None, :, 1] * a * hi).astype(int)     # src/ORBextractor.cc:118-120, with a little slack either way
+        rx = np.rint(pts[None, :, 0] * a * hi - pts[None, :, 1] * b * lo).astype(int)
+        assert np.abs(ry).max() <= 18 and np.abs(rx).max() <= 18
+        items = {((y + 18) // 2, (x + 20) // 4) for y, x in set(zip(ry.ravel().tolist(), rx.ravel().tolist()))}
+        assert items <= V, sorted(items - V)[:5]
