@@ -2739,8 +2739,9 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
 // plane: no k_blur7 launch, no 2 x 1 MB per frame of blurred levels through HBM, 2.0 KB of loads per keypoint instead of 2.8.
 // Layout of a slice: raw[r][c] = level(reflect(ky - 21 + r), kx - 24 + c), pitch 48.  Row pairs of horizontal sums: hp[rp][o], o = output
 // column, centre raw column o + 4 (x = kx - 20 + o).  Blurred bytes: B[b][o] over the raw slice, pitch 40: y = ky - 18 + b, x = kx - 20 + o.
-// Windows that would need reflected COLUMNS or would read past the row (kx < 24 or kx + 24 > w: a band of a few pixels) are staged byte by
-// byte with reflect-101 in both directions; everything after the staging is the same.
+// Windows at the left / right border: the transfers run a few bytes into the neighbouring row (never read with a weight) and the one or two
+// reflect-101 columns are patched in the slice; only where that neighbouring row would be outside the plane (two corners) is the window
+// staged byte by byte with reflect-101 in both directions.  Everything after the staging is the same.
 // ------------------------------------------------------------------------------------------------
 constexpr int kFB_ROWS = 43, kFB_PITCH = 48, kFB_X0 = 24, kFB_Y0 = 21, kFB_HP_ROWS = 22, kFB_HP_COLS = 40, kFB_BPITCH = 40;
 #include "fb_items.inc"
@@ -2817,7 +2818,10 @@ __global__ __launch_bounds__(256) void k_describe_blur(const DeviceGeom* __restr
       int pitch;  // < 2^23 (checked on the host)
       if (l == 0) { img = imgs + (long long)frame * img_frame_stride; pitch = (int)img_row_stride; }
       else { img = pyr + (long long)frame * pyr_frame_bytes + lv.plane_off; pitch = lv.pitch; }
-      fast[k] = kx >= kFB_X0 && kx + (kFB_PITCH - kFB_X0) <= lw;   // uniform: no reflected column, no byte past the row's pixels
+      // uniform.  The transfers may start up to 5 bytes before the row (kx >= 19) and end up to 4 bytes past its pixels: the neighbouring row of
+      // the same plane — unless that row is the plane's first (last) one: only those two corners are staged byte by byte.  Columns that need
+      // reflect-101 (kx < 21, kx > lw - 22) are patched in the slice below; the other out-of-row bytes are never read with a weight.
+      fast[k] = !((kx < kFB_X0 && ky <= kFB_Y0) || (kx + (kFB_PITCH - kFB_X0) > lw && ky + kFB_Y0 >= lh - 1));
       if (fast[k]) {
 #pragma unroll
         for (int j = 0; j < 3; j++) {
@@ -2855,6 +2859,26 @@ __global__ __launch_bounds__(256) void k_describe_blur(const DeviceGeom* __restr
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wave_lds_sync();
+    // reflect-101 columns of the windows that reach over the left / right border (two pixels at most: kx >= 19, kx <= lw - 20); lane = row.
+    // The blur reads them after the workgroup barriers below; the moments' patch (columns 8 .. 39) does not contain them.
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const int kk = min(k, nk - 1);
+      const uint32_t p = __builtin_amdgcn_readlane(rec.x, kk);
+      const int l = (int)(__builtin_amdgcn_readlane(rec.y, kk) & 0xffu);
+      const int kx = pt_x(p), lw = g->lv[l].w;
+      uint8_t* sp = s_raw[w * K + k];
+      if (fast[k] && (kx < kFB_Y0 || kx + kFB_Y0 >= lw) && lane < kFB_ROWS) {   // (the first condition is uniform)
+        uint8_t* row = sp + lane * kFB_PITCH;
+        if (kx < kFB_Y0) {   // x = kx - 24 + c < 0 for c < 24 - kx; needed from c = 3: the mirror of x is -x, column 2 (24 - kx) - c
+          const int c0 = kFB_X0 - kx;
+          for (int c = 3; c < c0; c++) row[c] = row[2 * c0 - c];
+        } else {             // x >= lw for c > lw - 1 - kx + 24; needed up to c = 45: the mirror of x is 2 lw - 2 - x
+          const int c1 = lw - 1 - kx + kFB_X0;   // the column of x = lw - 1
+          for (int c = c1 + 1; c <= 45; c++) row[c] = row[2 * c1 - c];
+        }
+      }
+    }
     // ---- moments from the raw slices (src/ORBextractor.cc:76-103)
 #pragma unroll
     for (int k = 0; k < K; k++) {
