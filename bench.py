@@ -60,7 +60,8 @@ def algorithmic_bytes(rows, cols, n_keypoints_per_frame, n_candidates_per_frame)
         "k_quadtree": 4 * n_candidates_per_frame * 2,                 # gather candidates + final read (points stay in L2)
         "k_assemble": 8 * n_keypoints_per_frame,
         "k_blur7": 2 * P,                                              # read every level once, write its blurred copy
-        "k_describe": (961 + 1369 + 60) * n_keypoints_per_frame,       # 31x31 patch + taps within 37x37 + 60 B out
+        "k_describe": (961 + 1369 + 60) * n_keypoints_per_frame,       # 31x31 patch + taps within 37x37 + 60 B out (with the Gaussian inside — k_describe_blur,
+                                                                       # no k_blur7 — it is the 43x43 raw window + 60 B, and the 2 P of the blur row go away)
     }
     return fused, staged
 

@@ -203,7 +203,7 @@ static void free_buffers(orbx_ctx* ctx) {
   auto fr = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
   fr(ctx->d_geo); fr(ctx->d_cells); fr(ctx->d_xtab); fr(ctx->d_ytab);
   fr(ctx->d_pyr); fr(ctx->d_blur); fr(ctx->d_cand); fr(ctx->d_cell_cnt); fr(ctx->d_pts); fr(ctx->d_lvl_kp); fr(ctx->d_lvl_n); fr(ctx->d_kp_list); fr(ctx->d_qt_nodes); fr(ctx->d_asm_scan);
-  ctx->batch_cap = 0;
+  ctx->batch_cap = 0; ctx->blur_cap = 0;
 }
 
 // LDS bytes of one quadtree workgroup over levels with at most `mq` quota and `mc` cells (see k_quadtree's carve-up)
@@ -263,7 +263,6 @@ static int ensure_buffers(orbx_ctx* ctx, int rows, int cols, int nframes) {
   }
   const size_t B = (size_t)nframes;
   ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_pyr, std::max<size_t>(B * (size_t)geo.pyr_bytes, 64)));
-  ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_blur, B * (size_t)geo.blur_bytes));
   ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_cand, B * geo.cand_total * sizeof(uint32_t)));
   ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_cell_cnt, B * geo.cells.size() * sizeof(int32_t)));
   ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_pts, B * 2 * geo.cand_total * sizeof(uint32_t)));
@@ -284,6 +283,35 @@ static int ensure_buffers(orbx_ctx* ctx, int rows, int cols, int nframes) {
   if (ctx->qt_node_slots) ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_qt_nodes, B * ctx->qt_node_slots * ctx->qt_node_stride));
   if ((size_t)ctx->out_cap * 8 + 64 > kLdsMax) ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_asm_scan, B * (size_t)ctx->out_cap * 8));
   ctx->batch_cap = nframes;
+  return ORBX_OK;
+}
+
+// Does an extraction of `nframes` frames take the Gaussian inside the descriptor kernel (k_describe_blur) instead of launching k_blur7?  It blurs a
+// window per keypoint (only the positions the rotated pattern can read: fb_items.inc) where k_blur7 blurs every pixel once, so its cost goes with
+// the keypoints, not with the pixels.  Measured per 256 frames: 640 x 480 with 1000 features (975 pyramid pixels per keypoint slot) 0.264 ms
+// against 0.171 + 0.168, the step +6 %; 1024 x 1024 with 2000 features (1690) the step +18 %.  The other blur arithmetics (the kernel's
+// general path), the single-frame graph and desc_lds = 0 keep the separate kernel.
+static bool small_fused_launch(const orbx_ctx* ctx, int nframes) {
+  return nframes * ctx->geo.nlevels <= 512 && nframes <= 4 && ctx->small_fused && !ctx->profiling;
+}
+static bool use_fused_blur(const orbx_ctx* ctx, int nframes) {
+  const Geometry& geo = ctx->geo;
+  long long pyr_px = 0;
+  for (int l = 0; l < geo.nlevels; l++) pyr_px += (long long)geo.lv[l].w * geo.lv[l].h;
+  constexpr long long kFusedBlurPxPerKp = 800;
+  const bool pays = ctx->desc_fused_blur > 0 || (ctx->desc_fused_blur < 0 && pyr_px >= kFusedBlurPxPerKp * ctx->out_cap);
+  const bool general_blur = ctx->gauss_kernel != 0 || ctx->gauss_round != 0;
+  return pays && !small_fused_launch(ctx, nframes) && !general_blur && ctx->desc_lds;
+}
+// The blurred planes ([batch][blur_bytes]) exist only for extractions that launch k_blur7; allocated (for the whole batch capacity) by the entry
+// points before they queue anything — never inside launch_pipeline, which may run under stream capture.
+static int ensure_blur(orbx_ctx* ctx, int nframes) {
+  if (use_fused_blur(ctx, nframes) || ctx->blur_cap >= ctx->batch_cap) return ORBX_OK;
+  ORBX_HIP(ctx, sync_ctx(ctx));
+  if (ctx->d_blur) { (void)hipFree(ctx->d_blur); ctx->d_blur = nullptr; }
+  ctx->blur_cap = 0;
+  ORBX_HIP(ctx, hipMalloc((void**)&ctx->d_blur, (size_t)ctx->batch_cap * (size_t)ctx->geo.blur_bytes));
+  ctx->blur_cap = ctx->batch_cap;
   return ORBX_OK;
 }
 
@@ -334,7 +362,7 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
   d_desc += (size_t)f0 * ctx->out_cap * 32;
   d_counts += (size_t)f0 * 2;
   uint8_t* const b_pyr = ctx->d_pyr + (size_t)f0 * geo.pyr_bytes;
-  uint8_t* const b_blur = ctx->d_blur + (size_t)f0 * geo.blur_bytes;
+  uint8_t* const b_blur = ctx->d_blur ? ctx->d_blur + (size_t)f0 * geo.blur_bytes : nullptr;   // only when k_blur7 runs (ensure_blur)
   uint32_t* const b_cand = ctx->d_cand + (size_t)f0 * geo.cand_total;
   int32_t* const b_cell_cnt = ctx->d_cell_cnt + (size_t)f0 * geo.cells.size();
   uint32_t* const b_pts = ctx->d_pts + (size_t)f0 * 2 * geo.cand_total;
@@ -570,15 +598,10 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
   // the pyramid, and it is VALU-bound while the quadtree that follows FAST is latency-bound with few workgroups, so it
   // is forked onto a second stream behind FAST and joined before the descriptors (ORBX_FORK_BLUR=0 disables).
   // Batches under the default blur arithmetic take the Gaussian inside the descriptor kernel (k_describe_blur): no k_blur7 launch, no blurred
-  // planes.  The other arithmetic variants (bc.flags), the single-frame graph and desc_lds = 0 keep the separate kernel.
-  // It blurs a window per keypoint (only the positions the rotated pattern can read: fb_items.inc) where k_blur7 blurs every pixel once, so its
-  // cost goes with the keypoints, not with the pixels.  Measured per 256 frames: 640 x 480 with 1000 features (975 pyramid pixels per keypoint
-  // slot) 0.304 ms against 0.171 + 0.168, the step +2 %, natural crops +6 %; 1024 x 1024 with 2000 features (1690) the step +18 %.
-  long long pyr_px = 0;
-  for (int l = 0; l < geo.nlevels; l++) pyr_px += (long long)geo.lv[l].w * geo.lv[l].h;
-  constexpr long long kFusedBlurPxPerKp = 800;
-  const bool fused_pays = ctx->desc_fused_blur > 0 || (ctx->desc_fused_blur < 0 && pyr_px >= kFusedBlurPxPerKp * ctx->out_cap);
-  const bool fused_blur = fused_pays && !small_fused && bc.flags == 0 && ctx->desc_lds;
+  // planes (use_fused_blur has the rule).
+  const bool fused_blur = use_fused_blur(ctx, nframes);
+  ctx->last_fused_blur = fused_blur;
+  if (!fused_blur && (!ctx->d_blur || ctx->blur_cap < f0 + nframes)) return set_err(ctx, ORBX_E_DEVICE, "internal: blurred planes not allocated");
   const bool fork_blur = ctx->fork_blur && !ctx->profiling && !small_batch && !fused_blur;
   hipStream_t bst = st;
   if (fork_blur) {
@@ -1002,6 +1025,7 @@ int orbx_extract_batch_device(orbx_ctx* ctx, const uint8_t* d_imgs, int nframes,
     return set_err(ctx, ORBX_E_INVALID, "row stride / frame size beyond the kernels' 32-bit in-frame offsets");
   ORBX_HIP(ctx, hipSetDevice(ctx->device));
   int rc = ensure_buffers(ctx, rows, cols, nframes);
+  if (rc == ORBX_OK) rc = ensure_blur(ctx, nframes);
   if (rc != ORBX_OK) return rc;
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
   ctx->last_ext_stream = stream ? (hipStream_t)stream : nullptr;
@@ -1095,6 +1119,7 @@ static int extract_one_graph(orbx_ctx* ctx, const uint8_t* img, int rows, int co
   }
   const bool keep = ctx->keep_host_pyr;
   int rc = ensure_buffers(ctx, rows, cols, 1);
+  if (rc == ORBX_OK) rc = ensure_blur(ctx, 1);
   if (rc != ORBX_OK) return rc;
   if (keep && ctx->geo.pyr_bytes > 0 && (size_t)ctx->geo.pyr_bytes > ctx->h_pyr_bytes) {
     if (ctx->h_pyr) (void)hipHostFree(ctx->h_pyr);
@@ -1439,7 +1464,8 @@ int orbx_pyramid_level(orbx_ctx* ctx, int frame, int level, uint8_t* dst, size_t
 int orbx_reserve(orbx_ctx* ctx, int rows, int cols, int nframes) {
   if (!ctx || rows <= 0 || cols <= 0 || nframes <= 0 || nframes > 65535) return ctx ? set_err(ctx, ORBX_E_INVALID, "orbx_reserve: bad arguments") : ORBX_E_INVALID;
   ORBX_HIP(ctx, hipSetDevice(ctx->device));
-  return ensure_buffers(ctx, rows, cols, nframes);
+  const int rc = ensure_buffers(ctx, rows, cols, nframes);
+  return rc == ORBX_OK ? ensure_blur(ctx, nframes) : rc;
 }
 
 int orbx_set_option(orbx_ctx* ctx, const char* name, int value) {
@@ -1614,6 +1640,8 @@ int orbx_debug_blur_level(orbx_ctx* ctx, int frame, int level, uint8_t* dst, siz
   if (!ctx || !ctx->d_geo || !dst || level < 0 || level >= ctx->nlevels || frame < 0 || frame >= ctx->last_nframes)
     return ctx ? set_err(ctx, ORBX_E_INVALID, "no such pyramid level") : ORBX_E_INVALID;
   const LevelGeom& L = ctx->geo.lv[level];
+  if (ctx->last_fused_blur || !ctx->d_blur || frame >= ctx->blur_cap)
+    return set_err(ctx, ORBX_E_INVALID, "no blurred planes: the last extraction blurred inside the descriptor kernel (desc_fused_blur)");
   ORBX_HIP(ctx, hipSetDevice(ctx->device));
   ORBX_HIP(ctx, sync_ctx(ctx));
   ORBX_HIP(ctx, copy2d_sync(ctx, dst, dst_stride, ctx->d_blur + (size_t)frame * ctx->geo.blur_bytes + L.bplane_off, L.pitch, L.w, L.h,

@@ -190,6 +190,8 @@ struct orbx_ctx {
   orbx::XTab* d_xtab = nullptr;
   orbx::XTab* d_ytab = nullptr;
   int batch_cap = 0;
+  int blur_cap = 0;        // frames d_blur holds: the blurred planes exist only for extractions that launch k_blur7 (ensure_blur)
+  bool last_fused_blur = false;   // the last extraction blurred inside the descriptor kernel: there are no blurred planes to read back
   uint8_t* d_pyr = nullptr;        // [batch][pyr_bytes]
   uint8_t* d_blur = nullptr;       // [batch][blur_bytes] 7x7 Gaussian of every level
   uint32_t* d_cand = nullptr;      // [batch][cand_total]
