@@ -301,7 +301,9 @@ static bool use_fused_blur(const orbx_ctx* ctx, int nframes) {
   constexpr long long kFusedBlurPxPerKp = 800;
   const bool pays = ctx->desc_fused_blur > 0 || (ctx->desc_fused_blur < 0 && pyr_px >= kFusedBlurPxPerKp * ctx->out_cap);
   const bool general_blur = ctx->gauss_kernel != 0 || ctx->gauss_round != 0;
-  return pays && !small_fused_launch(ctx, nframes) && !general_blur && ctx->desc_lds;
+  bool same_umax = true;   // the kernel's moment weights are a generated table (fb_items.inc) for exactly these circle half-widths
+  for (int i = 0; i < 16; i++) same_umax = same_umax && ctx->umax[i] == kFB_UMAX[i];
+  return pays && !small_fused_launch(ctx, nframes) && !general_blur && ctx->desc_lds && same_umax;
 }
 // The blurred planes ([batch][blur_bytes]) exist only for extractions that launch k_blur7; allocated (for the whole batch capacity) by the entry
 // points before they queue anything — never inside launch_pipeline, which may run under stream capture.
@@ -737,10 +739,11 @@ static int launch_pipeline(orbx_ctx* ctx, const uint8_t* d_imgs, int f0, int nfr
     auto kern = K == 1 ? k_describe<1> : K == 2 ? k_describe<2> : K == 4 ? k_describe<4> : K == 8 ? k_describe<8> : k_describe<16>;
     if (ctx->desc_lds && (K == 2 || K == 4 || K == 8)) kern = K == 2 ? k_describe<2, true> : K == 4 ? k_describe<4, true> : k_describe<8, true>;
     if (fused_blur) {
-      constexpr int KF = 2;   // keypoints per wave: two raw slices + one row-pair buffer per wave keep five workgroups on a CU (measured: K = 1 and K = 4 are 9 % slower)
-      const int gpf_f = (ctx->out_cap + 4 * KF - 1) / (4 * KF), nitems_f = gpf_f * nframes;
-      hipLaunchKernelGGL(k_describe_blur<KF>, dim3(xcd_grid(nitems_f)), dim3(256), 0, st, ctx->d_geo, d_imgs, (long long)row_stride,
-                         (long long)frame_stride, b_pyr, (long long)geo.pyr_bytes, b_kp_list, d_counts, d_kps, d_desc, dc, bc, gpf_f, nitems_f,
+      constexpr int KF = 2;   // keypoints per wave and round: two raw slices + one row-pair buffer per wave keep five workgroups on a CU (measured: K = 1 and K = 4 are 9 % slower)
+      constexpr int RF = 1;   // rounds per workgroup (k_describe_blur says why 1)
+      const int gpf_f = (ctx->out_cap + 4 * KF * RF - 1) / (4 * KF * RF), nitems_f = gpf_f * nframes;
+      hipLaunchKernelGGL((k_describe_blur<KF, RF>), dim3(xcd_grid(nitems_f)), dim3(256), 0, st, ctx->d_geo, d_imgs, (long long)row_stride,
+                         (long long)frame_stride, b_pyr, (long long)geo.pyr_bytes, b_kp_list, d_counts, d_kps, d_desc, bc, gpf_f, nitems_f,
                          div_magic((uint32_t)gpf_f), ctx->atan_fma, ctx->brief_fma);
     } else if (direct_mode)
       hipLaunchKernelGGL((k_describe<1, false, true>), dim3(xcd_grid(nitems)), dim3(256), 0, st, ctx->d_geo, d_imgs, (long long)row_stride,

@@ -2746,62 +2746,60 @@ __global__ __launch_bounds__(256) void k_describe(const DeviceGeom* __restrict__
 constexpr int kFB_ROWS = 43, kFB_PITCH = 48, kFB_X0 = 24, kFB_Y0 = 21, kFB_HP_ROWS = 22, kFB_HP_COLS = 40, kFB_BPITCH = 40;
 #include "fb_items.inc"
 
-template <int K>
+template <int K, int R>
 __global__ __launch_bounds__(256) void k_describe_blur(const DeviceGeom* __restrict__ g, const uint8_t* __restrict__ imgs,
                                                        long long img_row_stride, long long img_frame_stride,
                                                        const uint8_t* __restrict__ pyr, long long pyr_frame_bytes,
                                                        const uint2* __restrict__ kp_list, const int32_t* __restrict__ counts,
                                                        orbx_keypoint* __restrict__ out_kps, uint8_t* __restrict__ out_desc,
-                                                       DescConsts dc, BlurConsts bc, int groups_per_frame, int nitems, uint32_t m_gpf,
+                                                       BlurConsts bc, int groups_per_frame, int nitems, uint32_t m_gpf,
                                                        int atan_fma, int brief_fma) {
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int L = xcd_logical_block(nitems);
   if (L < 0) return;
   const int frame = fast_div(L, m_gpf);
-  const int g0 = ((L - frame * groups_per_frame) * 4 + w) * K;  // first keypoint (level-major index) of this wave
   const int total = counts[frame * 2];
-  if (((L - frame * groups_per_frame) * 4) * K >= total) return;  // block-uniform
-  const int nk = max(0, min(K, total - g0));
-  uint2 rec = make_uint2(0u, 0u);
-  if (lane < nk) rec = kp_list[(long long)frame * g->out_cap + g0 + lane];
+  // a workgroup serves R consecutive groups of 4 K keypoints (R = 1 in the product: with a loop around the rounds the compiler keeps 138 registers
+  // where the straight-line kernel keeps 81, and the residency lost costs more than the wave's 100 instructions of set-up: measured)
+  const int first = (L - frame * groups_per_frame) * R * 4 * K;   // first keypoint (level-major index) of this workgroup
+  if (first >= total) return;  // block-uniform
   char4 pat[4];
 #pragma unroll
   for (int q = 0; q < 4; q++) pat[q] = ((const char4*)c_pattern)[q * 64 + lane];
-  unsigned long long umpk = 0;
-#pragma unroll
-  for (int i = 0; i < 16; i++) umpk |= (unsigned long long)(dc.umax[i] & 15) << (4 * i);
-  // moment weights (as in k_describe): lane = (patch row r of 32, half); the patch's sixteen bytes sit at raw row 6 + r, column 8 + 16 half
+  // moment weights (fb_items.inc, as in k_describe): lane = (patch row r of 32, half); the patch's sixteen bytes sit at raw row 6 + r, column 8 + 16 half
   int wu[4], wv[4];
   {
-    const int r = lane >> 1, v = r - kHalfPatch;
-    const int um = r <= 2 * kHalfPatch ? (int)((umpk >> (4 * (v < 0 ? -v : v))) & 15ull) : -1;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int u0 = 16 * (lane & 1) - 16 + 4 * i;
-      uint32_t a = 0, b = 0;
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int u = u0 + j;
-        if ((u < 0 ? -u : u) <= um) { a |= (uint32_t)(u & 0xff) << (8 * j); b |= (uint32_t)(v & 0xff) << (8 * j); }
-      }
-      wu[i] = (int)a; wv[i] = (int)b;
-    }
+    const uint4 a = ((const uint4*)c_fb_w)[2 * lane], b = ((const uint4*)c_fb_w)[2 * lane + 1];
+    wu[0] = (int)a.x; wu[1] = (int)a.y; wu[2] = (int)a.z; wu[3] = (int)a.w;
+    wv[0] = (int)b.x; wv[1] = (int)b.y; wv[2] = (int)b.z; wv[3] = (int)b.w;
   }
   __shared__ __align__(16) uint8_t s_raw[4 * K][kFB_ROWS * kFB_PITCH + 16];
   __shared__ __align__(16) uint32_t s_hp[4][kFB_HP_ROWS * kFB_HP_COLS];
   // the items of the two blur passes this lane works on (fb_items.inc: only what the rotated pattern can read — three wave-trips each), as byte
-  // offsets into the slice / the row-pair buffer: constants of the wave, so a trip's addressing is one addition
+  // offsets into the slice / the row-pair buffer (a generated table): constants of the wave, so a trip's addressing is one addition
   int h_r0[3], h_r1[3], h_hp[3], v_hp[3], v_b[3];
+  {
+    uint32_t o[16];
 #pragma unroll
-  for (int t = 0; t < 3; t++) {
-    const int eh = c_fb_h[min(lane + 64 * t, kFB_NH - 1)], rp = eh & 0xff, jh = eh >> 8;
-    h_r0[t] = (2 * rp) * kFB_PITCH + 4 * jh;
-    h_r1[t] = min(2 * rp + 1, kFB_ROWS - 1) * kFB_PITCH + 4 * jh;   // the pair past the last row repeats it (its weight is 0 wherever it is read)
-    h_hp[t] = (rp * kFB_HP_COLS + 4 * jh) * 4;
-    const int ev = c_fb_v[min(lane + 64 * t, kFB_NV - 1)], op = ev & 0xff, jv = ev >> 8;
-    v_hp[t] = (op * kFB_HP_COLS + 4 * jv) * 4;
-    v_b[t] = (2 * op) * kFB_BPITCH + 4 * jv;
+    for (int i = 0; i < 4; i++) {
+      const uint4 q = ((const uint4*)c_fb_off)[4 * lane + i];
+      o[4 * i] = q.x; o[4 * i + 1] = q.y; o[4 * i + 2] = q.z; o[4 * i + 3] = q.w;
+    }
+#pragma unroll
+    for (int t = 0; t < 3; t++) { h_r0[t] = (int)o[5 * t]; h_r1[t] = (int)o[5 * t + 1]; h_hp[t] = (int)o[5 * t + 2]; v_hp[t] = (int)o[5 * t + 3]; v_b[t] = (int)o[5 * t + 4]; }
   }
+  __shared__ int s_mom[4 * K][2];
+  __shared__ float s_trig[4 * K][3];
+  uint32_t* hp = s_hp[w];
+#pragma unroll 1
+  for (int rnd = 0; rnd < R; rnd++) {
+  const int gfirst = first + rnd * 4 * K;                       // this round's first keypoint of the workgroup
+  if (gfirst >= total) break;  // block-uniform
+  const int g0 = gfirst + w * K;                                 // first keypoint of this wave
+  const int nk = max(0, min(K, total - g0));
+  uint2 rec = make_uint2(0u, 0u);
+  if (lane < nk) rec = kp_list[(long long)frame * g->out_cap + g0 + lane];
+  if (rnd) __syncthreads();   // the previous round's readers of s_trig / the slices are done
   int my_m01 = 0, my_m10 = 0;
   __builtin_amdgcn_sched_barrier(0);
   if (nk > 0) {   // wave-uniform
@@ -2898,8 +2896,6 @@ __global__ __launch_bounds__(256) void k_describe_blur(const DeviceGeom* __restr
       if (lane == k) { my_m10 = m10; my_m01 = m01; }
     }
   }
-  __shared__ int s_mom[4 * K][2];
-  __shared__ float s_trig[4 * K][3];
   if (lane < nk) { s_mom[w * K + lane][0] = my_m01; s_mom[w * K + lane][1] = my_m10; }
   __syncthreads();
   if (w == 0 && lane < 4 * K) {
@@ -2921,7 +2917,6 @@ __global__ __launch_bounds__(256) void k_describe_blur(const DeviceGeom* __restr
     kp.octave = l; kp.class_id = -1;
     out_kps[(long long)frame * g->out_cap + slot] = kp;
   }
-  uint32_t* hp = s_hp[w];
 #pragma unroll 1
   for (int k = 0; k < nk; k++) {
     const int slot = (int)(__builtin_amdgcn_readlane(rec.y, k) >> 8);
@@ -2967,8 +2962,18 @@ __global__ __launch_bounds__(256) void k_describe_blur(const DeviceGeom* __restr
     // ---- steered BRIEF on the blurred bytes: (ky + ry, kx + rx) is B[ry + 18][rx + 20]
     int t0[4], t1[4];
     const int lctr = 18 * kFB_BPITCH + 20;
-    if (brief_fma) brief_taps<true, kFB_BPITCH>(sp, lctr, kFB_BPITCH, pat, a, b, t0, t1);   // uniform (kernel argument)
-    else brief_taps<false, kFB_BPITCH>(sp, lctr, kFB_BPITCH, pat, a, b, t0, t1);
+    // the pattern stays four packed registers across the kernel's loops: its 16 floats are converted per keypoint (the compiler would keep
+    // them — as 32 registers of pairs — and the kernel lives on its residency)
+    char4 patk[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      uint32_t pq;
+      __builtin_memcpy(&pq, &pat[q], 4);
+      asm volatile("" : "+v"(pq));
+      __builtin_memcpy(&patk[q], &pq, 4);
+    }
+    if (brief_fma) brief_taps<true, kFB_BPITCH>(sp, lctr, kFB_BPITCH, patk, a, b, t0, t1);   // uniform (kernel argument)
+    else brief_taps<false, kFB_BPITCH>(sp, lctr, kFB_BPITCH, patk, a, b, t0, t1);
     const unsigned long long b0 = __ballot(t0[0] < t1[0]), b1 = __ballot(t0[1] < t1[1]), b2 = __ballot(t0[2] < t1[2]), b3 = __ballot(t0[3] < t1[3]);
     uint32_t word = 0;
     asm("s_nop 4\n\tv_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 1\n\tv_writelane_b32 %0, %3, 2\n\tv_writelane_b32 %0, %4, 3\n\t"
@@ -2978,6 +2983,7 @@ __global__ __launch_bounds__(256) void k_describe_blur(const DeviceGeom* __restr
           "s"((uint32_t)b3), "s"((uint32_t)(b3 >> 32)));
     if (lane < 8) *(uint32_t*)(out_desc + ((long long)frame * g->out_cap + slot) * 32 + lane * 4) = word;
   }
+  }   // rounds
 }
 
 #ifdef ORBX_DEBUG_ABI

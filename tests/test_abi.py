@@ -125,6 +125,24 @@ def test_generated_kernel_tables_are_current():
     V = {(e & 0xff, e >> 8) for e in tabs["c_fb_v"] if e != 0xffff}
     H = {(e & 0xff, e >> 8) for e in tabs["c_fb_h"] if e != 0xffff}
     assert all((op + q, j) in H for op, j in V for q in range(4))        # every column-sum item finds its four row pairs
+    # the per-lane offsets the kernel actually reads are those lists, in order (three wave-trips)
+    off = [int(x) for x in re.findall(r"\d+", re.search(r"c_fb_off\[64 \* 16\] = \{([^}]*)\}", have).group(1))]
+    Hl = [(e & 0xff, e >> 8) for e in tabs["c_fb_h"] if e != 0xffff]
+    Vl = [(e & 0xff, e >> 8) for e in tabs["c_fb_v"] if e != 0xffff]
+    for lane in range(64):
+        for t in range(3):
+            rp, j = Hl[min(lane + 64 * t, len(Hl) - 1)]
+            op, jv = Vl[min(lane + 64 * t, len(Vl) - 1)]
+            assert off[16 * lane + 5 * t: 16 * lane + 5 * t + 5] == [96 * rp + 4 * j, 48 * min(2 * rp + 1, 42) + 4 * j, 160 * rp + 16 * j, 160 * op + 16 * jv, 80 * op + 4 * jv]
+    # and the orientation weights are the circle of src/ORBextractor.cc:452-466 for HALF_PATCH_SIZE 15: sum u = sum v = 0, 749 pixels
+    w = [int(x, 16) for x in re.findall(r"0x[0-9a-f]{8}", re.search(r"c_fb_w\[64 \* 8\] = \{([^}]*)\}", have).group(1))]
+    sb = lambda x: x - 256 if x > 127 else x
+    us = [sb((w[8 * l + i] >> (8 * jj)) & 255) for l in range(64) for i in range(4) for jj in range(4)]
+    vs = [sb((w[8 * l + 4 + i] >> (8 * jj)) & 255) for l in range(64) for i in range(4) for jj in range(4)]
+    assert sum(us) == 0 and sum(vs) == 0
+    inside = sum(1 for l in range(64) for i in range(4) for jj in range(4)
+                 if abs(16 * (l & 1) - 16 + 4 * i + jj) <= [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3, -1][min(abs((l >> 1) - 15), 16)])
+    assert inside == 749
     pat = []
     for ln in open(os.path.join(root, "orb_slam3_modified_amd", "csrc", "orb_pattern.inc")):
         if not ln.strip().startswith(("/*", "*")):
