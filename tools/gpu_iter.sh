@@ -1,9 +1,16 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-export ORBX_COMMIT=14f17ed20d20
-STAMP=$(python -c "from orb_slam3_modified_amd.build import stamp; s = stamp(); print('commit', s['commit'], 'kernel sources', s['kernels_hash'], s['date'])")
-{ echo "$STAMP"; timeout 1500 python tools/fuzz_extractor.py 5000 900 2>&1 | tail -4; } > gpurun_out/fuzz_r6f_900.log
-{ echo "$STAMP"; timeout 1200 python tools/fuzz_extractor.py 7000 500 --variants 2>&1 | tail -4; } > gpurun_out/fuzz_r6f_variants_500.log
-{ echo "$STAMP"; timeout 900 python tools/fuzz_worlds.py 900 20 2>&1 | tail -3; } > gpurun_out/fuzz_worlds_r6f_20.log
-{ echo "$STAMP"; timeout 900 python tools/fuzz_frame_world.py 301 30 2>&1 | tail -2; } > gpurun_out/fuzz_frame_world_r6f_30.log
-tail -1 gpurun_out/fuzz_r6f_900.log gpurun_out/fuzz_r6f_variants_500.log gpurun_out/fuzz_worlds_r6f_20.log gpurun_out/fuzz_frame_world_r6f_30.log | cut -c1-200
+mkdir -p gpurun_out
+rocprofv3 --kernel-trace -d gpurun_out/t1 -o t -- python tools/kernel_times.py 64 > /dev/null 2>&1
+DB=$(ls gpurun_out/t1/*/t_results.db gpurun_out/t1/t_results.db 2>/dev/null | head -1)
+python - <<PY
+import sqlite3
+c=sqlite3.connect("$DB")
+print([r[1] for r in c.execute("pragma table_info(kernels)")])
+print(c.execute("select * from kernels limit 1").fetchall())
+PY
+rm -rf gpurun_out/t1
+for rep in 1 2; do for L in 2 3 4; do
+  echo "alternate NOWAIT lanes $L (rep $rep): $(ORBX_REPLAY_NOWAIT=1 python bench.py --steps 20 --warmup 5 --lanes $L --no-verify --no-cpu-baseline --no-frontend --no-fixed-streams --no-secondary --no-gather 2>/dev/null | tail -1 | python -c "
+import sys,json; j=json.loads(sys.stdin.read()); print('step', j['ms_per_step'], 'min/max', j['timing']['ms_per_step_min'], j['timing']['ms_per_step_max'], 'value', j['value'])")"
+done; done
