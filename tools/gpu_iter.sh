@@ -1,16 +1,17 @@
-cd $GRAFT_REPO_ROOT
+#!/bin/bash
+# The short build -> measure loop on the GPU box (one gpurun call, ~2 minutes):
+#   gpurun --timeout 900 -- 'bash tools/gpu_iter.sh'
+# kernel times of a 256-frame batch (HIP events per kernel), the extractor parity tests, and two short headline runs with the natural-crop
+# and config-4 legs.  Everything an experiment needs before it is worth a full tools/final_refresh.sh.
+cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-rocprofv3 --kernel-trace -d gpurun_out/t1 -o t -- python tools/kernel_times.py 64 > /dev/null 2>&1
-DB=$(ls gpurun_out/t1/*/t_results.db gpurun_out/t1/t_results.db 2>/dev/null | head -1)
-python - <<PY
-import sqlite3
-c=sqlite3.connect("$DB")
-print([r[1] for r in c.execute("pragma table_info(kernels)")])
-print(c.execute("select * from kernels limit 1").fetchall())
-PY
-rm -rf gpurun_out/t1
-for rep in 1 2; do for L in 2 3 4; do
-  echo "alternate NOWAIT lanes $L (rep $rep): $(ORBX_REPLAY_NOWAIT=1 python bench.py --steps 20 --warmup 5 --lanes $L --no-verify --no-cpu-baseline --no-frontend --no-fixed-streams --no-secondary --no-gather 2>/dev/null | tail -1 | python -c "
-import sys,json; j=json.loads(sys.stdin.read()); print('step', j['ms_per_step'], 'min/max', j['timing']['ms_per_step_min'], j['timing']['ms_per_step_max'], 'value', j['value'])")"
-done; done
+python tools/kernel_times.py 256 2>/dev/null | tail -1
+python -m pytest tests/test_gpu_extractor.py -m gpu -x -q 2>&1 | tail -2
+for rep in 1 2; do
+  python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-frontend --no-fixed-streams --no-gather 2>/dev/null | tail -1 | python -c "
+import sys, json
+j = json.loads(sys.stdin.read())
+print('bench (rep $rep): step', j['ms_per_step'], 'value', j['value'], 'nat', j.get('secondary_natural', {}).get('value'), 'cfg4', j.get('secondary', {}).get('value'),
+      j['roofline'].get('kernels_ms_per_launch'))"
+done
