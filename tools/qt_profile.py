@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Phase timing of k_quadtree (needs a build with ORBX_EXTRA_FLAGS=-DORBX_QT_PROFILE)."""
+"""Phase timing of k_quadtree (needs a build with ORBX_EXTRA_FLAGS=-DORBX_QT_PROFILE).
+Rounds 4 - 5 tool (profiles/qt_profile_r4*.txt).  Since the diagnostic ABI moved into liborbx_debug.so (round 6) its read-out hook sits in a library whose
+copy of the counters no kernel writes: to use it again, build the hook (orbx_debug_qt_profile, csrc/orbx_extractor.hip) into the profiling library itself."""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
